@@ -1,0 +1,228 @@
+// TEST INFRASTRUCTURE ONLY (see vxo_linalg.hpp header).  PARITY UNPINNED.
+//
+// extern "C" surface of the CPU oracle so tests/ and bench.py's cpu_baseline leg
+// can drive it through ctypes.  Packed formats are the same as include/vxba.h:
+//   cluster  : 10 f64  [Pxx Pxy Pxz Pyy Pyz Pzz vx vy vz N]
+//   pose     : 12 f64  [R col-major (9) | p (3)]
+//   eig_vec  :  9 f64  col-major (column k = eigenvector k)
+//   Hess     : (6W)x(6W) f64 col-major
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+
+#include "vxo_ba.hpp"
+
+using namespace vxo;
+
+namespace {
+
+PointCluster unpack_cluster(const double* c) {
+  PointCluster pc;
+  pc.P(0,0) = c[0]; pc.P(0,1) = pc.P(1,0) = c[1]; pc.P(0,2) = pc.P(2,0) = c[2];
+  pc.P(1,1) = c[3]; pc.P(1,2) = pc.P(2,1) = c[4]; pc.P(2,2) = c[5];
+  pc.v = v3(c[6], c[7], c[8]);
+  pc.N = (int)c[9];
+  return pc;
+}
+void pack_cluster(const PointCluster& pc, double* c) {
+  c[0] = pc.P(0,0); c[1] = pc.P(0,1); c[2] = pc.P(0,2); c[3] = pc.P(1,1); c[4] = pc.P(1,2); c[5] = pc.P(2,2);
+  c[6] = pc.v[0]; c[7] = pc.v[1]; c[8] = pc.v[2]; c[9] = (double)pc.N;
+}
+M3 unpack_m3_colmajor(const double* m) { M3 r; for (int c = 0; c < 3; c++) for (int rr = 0; rr < 3; rr++) r(rr, c) = m[3 * c + rr]; return r; }
+void pack_m3_colmajor(const M3& a, double* m) { for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) m[3 * c + r] = a(r, c); }
+std::vector<Pose> unpack_poses(const double* Rp, int W) {
+  std::vector<Pose> xs(W);
+  for (int i = 0; i < W; i++) {
+    xs[i].R = unpack_m3_colmajor(Rp + 12 * i);
+    xs[i].p = v3(Rp[12 * i + 9], Rp[12 * i + 10], Rp[12 * i + 11]);
+  }
+  return xs;
+}
+void pack_poses(const std::vector<Pose>& xs, double* Rp) {
+  for (size_t i = 0; i < xs.size(); i++) {
+    pack_m3_colmajor(xs[i].R, Rp + 12 * i);
+    for (int k = 0; k < 3; k++) Rp[12 * i + 9 + k] = xs[i].p[k];
+  }
+}
+
+struct Handle {
+  LidarFactor factor;
+  explicit Handle(int w) : factor(w) {}
+};
+
+}  // namespace
+
+extern "C" {
+
+void* vxo_create(int win_size) { return new Handle(win_size); }
+void vxo_destroy(void* h) { delete (Handle*)h; }
+void vxo_clear(void* h) { ((Handle*)h)->factor.clear(); }
+int vxo_size(void* h) { return (int)((Handle*)h)->factor.plvec_voxels.size(); }
+
+// batched LidarFactor::push_voxel (voxel_map.hpp:122-130)
+void vxo_push_voxels(void* h, int n, const double* clusters, const double* fix, const double* coe, const double* eig_val,
+                     const double* eig_vec, const double* merged) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  const int W = f.win_size;
+  for (int a = 0; a < n; a++) {
+    std::vector<PointCluster> vec(W);
+    for (int i = 0; i < W; i++) vec[i] = unpack_cluster(clusters + ((size_t)a * W + i) * 10);
+    f.push_voxel(vec, unpack_cluster(fix + (size_t)a * 10), coe[a], v3(eig_val[3 * a], eig_val[3 * a + 1], eig_val[3 * a + 2]),
+                 unpack_m3_colmajor(eig_vec + 9 * (size_t)a), unpack_cluster(merged + (size_t)a * 10));
+  }
+}
+
+void vxo_acc_evaluate2(void* h, const double* Rp, int head, int end, double* Hess, double* JacT, double* residual) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  const int n = 6 * f.win_size;
+  MatX H(n, n);
+  std::vector<double> J(n, 0.0);
+  f.acc_evaluate2(unpack_poses(Rp, f.win_size), head, end, H, J, *residual);
+  std::memcpy(Hess, H.a.data(), sizeof(double) * n * n);
+  std::memcpy(JacT, J.data(), sizeof(double) * n);
+}
+
+void vxo_evaluate_only_residual(void* h, const double* Rp, int head, int end, double* residual) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  f.evaluate_only_residual(unpack_poses(Rp, f.win_size), head, end, *residual);
+}
+
+void vxo_read_cache(void* h, int head, int end, double* eig_val, double* eig_vec, double* merged) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  for (int a = head; a < end; a++) {
+    size_t k = a - head;
+    for (int j = 0; j < 3; j++) eig_val[3 * k + j] = f.eig_values[a][j];
+    pack_m3_colmajor(f.eig_vectors[a], eig_vec + 9 * k);
+    pack_cluster(f.pcr_adds[a], merged + 10 * k);
+  }
+}
+
+// Lidar_BA_Optimizer::divide_thread / only_residual with an explicit thread count
+double vxo_divide_thread(void* h, const double* Rp, int thd_num, double* Hess, double* JacT) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  Lidar_BA_Optimizer opt;
+  opt.win_size = f.win_size; opt.jac_leng = 6 * f.win_size; opt.thd_num = thd_num;
+  MatX H(opt.jac_leng, opt.jac_leng);
+  std::vector<double> J(opt.jac_leng, 0.0);
+  std::vector<Pose> xs = unpack_poses(Rp, f.win_size);
+  double r = opt.divide_thread(xs, f, H, J);
+  if (Hess) std::memcpy(Hess, H.a.data(), sizeof(double) * H.a.size());
+  if (JacT) std::memcpy(JacT, J.data(), sizeof(double) * J.size());
+  return r;
+}
+double vxo_only_residual(void* h, const double* Rp, int thd_num) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  Lidar_BA_Optimizer opt;
+  opt.win_size = f.win_size; opt.jac_leng = 6 * f.win_size; opt.thd_num = thd_num;
+  std::vector<Pose> xs = unpack_poses(Rp, f.win_size);
+  return opt.only_residual(xs, f);
+}
+
+// Lidar_BA_Optimizer::damping_iter (voxel_map.hpp:367-442).
+// Rp is in/out.  resis_out[2].  trace_out: up to max_iter rows of 8 doubles
+// [residual1 residual2 u v q q1 accepted recomputed_hess]; *n_trace = rows written.
+int vxo_damping_iter(void* h, double* Rp, int thd_num, int max_iter, double* hess_out, double* resis_out, double* trace_out,
+                     int* n_trace) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  Lidar_BA_Optimizer opt;
+  opt.thd_num = thd_num;
+  std::vector<Pose> xs = unpack_poses(Rp, f.win_size);
+  MatX hess;
+  std::vector<double> resis;
+  bool conv = opt.damping_iter(xs, f, &hess, resis, max_iter);
+  pack_poses(xs, Rp);
+  if (hess_out) std::memcpy(hess_out, hess.a.data(), sizeof(double) * hess.a.size());
+  if (resis_out) { resis_out[0] = resis[0]; resis_out[1] = resis[1]; }
+  if (n_trace) *n_trace = (int)opt.trace.size();
+  if (trace_out)
+    for (size_t i = 0; i < opt.trace.size(); i++) {
+      const LMTraceEntry& t = opt.trace[i];
+      double* o = trace_out + 8 * i;
+      o[0] = t.residual1; o[1] = t.residual2; o[2] = t.u; o[3] = t.v; o[4] = t.q; o[5] = t.q1; o[6] = t.accepted; o[7] = t.recomputed_hess;
+    }
+  return conv ? 1 : 0;
+}
+
+// Timed accepted-step BA iteration for the cpu_baseline leg: Hessian sweep
+// (divide_thread) + gauge fix + damped solve + state update + residual sweep
+// (only_residual), `iters` times; poses are NOT advanced so every iteration does
+// identical work.  Returns seconds per iteration (median of iters).
+double vxo_time_ba_iteration(void* h, const double* Rp, int thd_num, int warmup, int iters, double* hess_s, double* resid_s) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  Lidar_BA_Optimizer opt;
+  opt.win_size = f.win_size; opt.jac_leng = 6 * f.win_size; opt.thd_num = thd_num;
+  const int n = opt.jac_leng;
+  std::vector<Pose> xs = unpack_poses(Rp, f.win_size), xt = xs;
+  MatX H(n, n), A(n, n);
+  std::vector<double> J(n), rhs(n);
+  std::vector<double> tot, th, tr;
+  for (int it = 0; it < warmup + iters; it++) {
+    auto t0 = std::chrono::steady_clock::now();
+    opt.divide_thread(xs, f, H, J);
+    auto t1 = std::chrono::steady_clock::now();
+    for (int r = 0; r < 6; r++) for (int c = 0; c < n; c++) { H(r, c) = 0.0; H(c, r) = 0.0; }
+    for (int r = 0; r < 6; r++) { H(r, r) = 1.0; J[r] = 0.0; }
+    for (int c = 0; c < n; c++) for (int r = 0; r < n; r++) A(r, c) = H(r, c) + (r == c ? 0.01 * H(r, r) : 0.0);
+    for (int r = 0; r < n; r++) rhs[r] = -J[r];
+    std::vector<double> dxi = ldlt_solve(A, rhs);
+    for (int j = 0; j < f.win_size; j++) {
+      xt[j].R = xs[j].R * Exp(v3(dxi[6 * j], dxi[6 * j + 1], dxi[6 * j + 2]));
+      xt[j].p = xs[j].p + v3(dxi[6 * j + 3], dxi[6 * j + 4], dxi[6 * j + 5]);
+    }
+    auto t2 = std::chrono::steady_clock::now();
+    opt.only_residual(xt, f);
+    auto t3 = std::chrono::steady_clock::now();
+    if (it >= warmup) {
+      tot.push_back(std::chrono::duration<double>(t3 - t0).count());
+      th.push_back(std::chrono::duration<double>(t1 - t0).count());
+      tr.push_back(std::chrono::duration<double>(t3 - t2).count());
+    }
+  }
+  auto median = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+  if (hess_s) *hess_s = median(th);
+  if (resid_s) *resid_s = median(tr);
+  return median(tot);
+}
+
+// ---- building blocks exposed for unit tests ---------------------------------
+void vxo_eig_sym3(const double* C_colmajor, double* val, double* vec_colmajor) {
+  V3 l; M3 U;
+  eig_sym3(unpack_m3_colmajor(C_colmajor), l, U);
+  for (int i = 0; i < 3; i++) val[i] = l[i];
+  pack_m3_colmajor(U, vec_colmajor);
+}
+void vxo_exp(const double* ang, double* R_colmajor) { pack_m3_colmajor(Exp(v3(ang[0], ang[1], ang[2])), R_colmajor); }
+void vxo_log(const double* R_colmajor, double* ang) { V3 a = Log(unpack_m3_colmajor(R_colmajor)); for (int i = 0; i < 3; i++) ang[i] = a[i]; }
+void vxo_ldlt_solve(int n, const double* A_colmajor, const double* b, double* x) {
+  MatX A(n, n);
+  std::memcpy(A.a.data(), A_colmajor, sizeof(double) * n * n);
+  std::vector<double> r = ldlt_solve(A, std::vector<double>(b, b + n));
+  std::memcpy(x, r.data(), sizeof(double) * n);
+}
+// PointCluster::transform (tools.hpp:357-363)
+void vxo_cluster_transform(const double* cluster, const double* Rp, double* out) {
+  PointCluster o;
+  cluster_transform(o, unpack_cluster(cluster), unpack_poses(Rp, 1)[0]);
+  pack_cluster(o, out);
+}
+// K1: PointCluster::push over bucketed points (tools.hpp:326-331, call sites
+// voxel_map.hpp:988, loop_refine.hpp:383-385).  cell_ptr has n_cells+1 entries.
+void vxo_build_clusters(int64_t n_cells, const int64_t* cell_ptr, const double* xyz, double* out) {
+  for (int64_t c = 0; c < n_cells; c++) {
+    PointCluster pc;
+    for (int64_t k = cell_ptr[c]; k < cell_ptr[c + 1]; k++) pc.push(v3(xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2]));
+    pack_cluster(pc, out + 10 * c);
+  }
+}
+// K4: plane fit eig(pcr.cov()) (voxel_map.hpp:1161-1163)
+void vxo_plane_fit(int64_t n, const double* clusters, double* eig_val, double* eig_vec) {
+  for (int64_t a = 0; a < n; a++) {
+    PointCluster pc = unpack_cluster(clusters + 10 * a);
+    V3 l; M3 U;
+    eig_sym3(pc.cov(), l, U);
+    for (int i = 0; i < 3; i++) eig_val[3 * a + i] = l[i];
+    pack_m3_colmajor(U, eig_vec + 9 * a);
+  }
+}
+
+}  // extern "C"

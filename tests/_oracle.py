@@ -1,0 +1,164 @@
+"""ctypes driver for the CPU oracle (oracle/liboracle.so).  Test infrastructure only:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(path):
+        build_oracle()
+    L = C.CDLL(path)
+    L.vxo_create.restype = C.c_void_p
+    L.vxo_create.argtypes = [C.c_int]
+    L.vxo_destroy.argtypes = [C.c_void_p]
+    L.vxo_clear.argtypes = [C.c_void_p]
+    L.vxo_size.argtypes = [C.c_void_p]
+    L.vxo_push_voxels.argtypes = [C.c_void_p, C.c_int, f64p, f64p, f64p, f64p, f64p, f64p]
+    L.vxo_acc_evaluate2.argtypes = [C.c_void_p, f64p, C.c_int, C.c_int, f64p, f64p, C.POINTER(C.c_double)]
+    L.vxo_evaluate_only_residual.argtypes = [C.c_void_p, f64p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.vxo_read_cache.argtypes = [C.c_void_p, C.c_int, C.c_int, f64p, f64p, f64p]
+    L.vxo_divide_thread.restype = C.c_double
+    L.vxo_divide_thread.argtypes = [C.c_void_p, f64p, C.c_int, f64p, f64p]
+    L.vxo_only_residual.restype = C.c_double
+    L.vxo_only_residual.argtypes = [C.c_void_p, f64p, C.c_int]
+    L.vxo_damping_iter.argtypes = [C.c_void_p, f64p, C.c_int, C.c_int, f64p, f64p, f64p, C.POINTER(C.c_int)]
+    L.vxo_time_ba_iteration.restype = C.c_double
+    L.vxo_time_ba_iteration.argtypes = [C.c_void_p, f64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.vxo_eig_sym3.argtypes = [f64p, f64p, f64p]
+    L.vxo_exp.argtypes = [f64p, f64p]
+    L.vxo_log.argtypes = [f64p, f64p]
+    L.vxo_ldlt_solve.argtypes = [C.c_int, f64p, f64p, f64p]
+    L.vxo_cluster_transform.argtypes = [f64p, f64p, f64p]
+    L.vxo_build_clusters.argtypes = [C.c_int64, i64p, f64p, f64p]
+    L.vxo_plane_fit.argtypes = [C.c_int64, f64p, f64p, f64p]
+    _LIB = L
+    return L
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Oracle:
+    """Mirror of the reference LidarFactor + Lidar_BA_Optimizer interface on the CPU oracle."""
+
+    def __init__(self, win_size):
+        self.win_size = int(win_size)
+        self._h = lib().vxo_create(self.win_size)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vxo_destroy(self._h)
+            self._h = None
+
+    def clear(self):
+        lib().vxo_clear(self._h)
+
+    def size(self):
+        return lib().vxo_size(self._h)
+
+    def push_voxels(self, clusters, fix, coe, eig_val=None, eig_vec=None, merged=None):
+        clusters = _c(clusters)
+        n = clusters.shape[0]
+        assert clusters.shape == (n, self.win_size, 10)
+        eig_val = np.zeros((n, 3)) if eig_val is None else _c(eig_val)
+        eig_vec = np.tile(np.eye(3).reshape(1, 9), (n, 1)) if eig_vec is None else _c(eig_vec)
+        merged = np.zeros((n, 10)) if merged is None else _c(merged)
+        lib().vxo_push_voxels(self._h, n, clusters, _c(fix), _c(coe), eig_val, eig_vec, merged)
+
+    def acc_evaluate2(self, Rp, head=0, end=None):
+        end = self.size() if end is None else end
+        n = 6 * self.win_size
+        H = np.zeros((n, n)); J = np.zeros(n); r = C.c_double(0)
+        lib().vxo_acc_evaluate2(self._h, _c(Rp), head, end, H, J, C.byref(r))
+        return H.T.copy(), J, r.value  # H returned col-major -> transpose view gives H[r,c]
+
+    def evaluate_only_residual(self, Rp, head=0, end=None):
+        end = self.size() if end is None else end
+        r = C.c_double(0)
+        lib().vxo_evaluate_only_residual(self._h, _c(Rp), head, end, C.byref(r))
+        return r.value
+
+    def read_cache(self, head=0, end=None):
+        end = self.size() if end is None else end
+        n = end - head
+        ev = np.zeros((n, 3)); U = np.zeros((n, 9)); m = np.zeros((n, 10))
+        lib().vxo_read_cache(self._h, head, end, ev, U, m)
+        return ev, U, m
+
+    def divide_thread(self, Rp, thd_num=2):
+        n = 6 * self.win_size
+        H = np.zeros((n, n)); J = np.zeros(n)
+        r = lib().vxo_divide_thread(self._h, _c(Rp), thd_num, H, J)
+        return H.T.copy(), J, r
+
+    def only_residual(self, Rp, thd_num=2):
+        return lib().vxo_only_residual(self._h, _c(Rp), thd_num)
+
+    def damping_iter(self, Rp, max_iter=3, thd_num=2):
+        Rp = _c(Rp).copy()
+        n = 6 * self.win_size
+        hess = np.zeros((n, n)); resis = np.zeros(2); trace = np.zeros((max_iter, 8)); nt = C.c_int(0)
+        conv = lib().vxo_damping_iter(self._h, Rp, thd_num, max_iter, hess, resis, trace, C.byref(nt))
+        return dict(poses=Rp, hess=hess.T.copy(), resis=resis, trace=trace[: nt.value].copy(), is_converge=bool(conv))
+
+    def time_ba_iteration(self, Rp, thd_num, warmup=1, iters=5):
+        th = C.c_double(0); tr = C.c_double(0)
+        t = lib().vxo_time_ba_iteration(self._h, _c(Rp), thd_num, warmup, iters, C.byref(th), C.byref(tr))
+        return t, th.value, tr.value
+
+
+def eig_sym3(Cm):
+    val = np.zeros(3); vec = np.zeros(9)
+    lib().vxo_eig_sym3(_c(np.asarray(Cm).T.reshape(9)), val, vec)
+    return val, vec.reshape(3, 3).T.copy()
+
+
+def exp_so3(a):
+    R = np.zeros(9)
+    lib().vxo_exp(_c(a), R)
+    return R.reshape(3, 3).T.copy()
+
+
+def ldlt_solve(A, b):
+    n = len(b); x = np.zeros(n)
+    lib().vxo_ldlt_solve(n, _c(np.asarray(A).T), _c(b), x)
+    return x
+
+
+def cluster_transform(cluster, Rp):
+    out = np.zeros(10)
+    lib().vxo_cluster_transform(_c(cluster), _c(Rp), out)
+    return out
+
+
+def build_clusters(xyz, cell_ptr):
+    cell_ptr = np.ascontiguousarray(cell_ptr, dtype=np.int64)
+    out = np.zeros((cell_ptr.shape[0] - 1, 10))
+    lib().vxo_build_clusters(cell_ptr.shape[0] - 1, cell_ptr, _c(xyz), out)
+    return out
+
+
+def plane_fit(clusters):
+    clusters = _c(clusters)
+    n = clusters.shape[0]
+    ev = np.zeros((n, 3)); U = np.zeros((n, 9))
+    lib().vxo_plane_fit(n, clusters, ev, U)
+    return ev, U
