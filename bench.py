@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""BA-iterations/s of the local-mapping LiDAR bundle adjustment on N MI355X (BASELINE.json metric).
+
+A *step* is one LM iteration of ``Lidar_BA_Optimizer::damping_iter`` on the accepted-step path
+(reference voxel_map.hpp:386-439): Hessian/gradient sweep over all voxels (K3) + on-device reduction
+[+ RCCL all-reduce] + D2H + gauge fix + damped LDL^T solve + trial-state update + residual sweep (K2:
+merge, covariance, eigensolve, cache write) + reduction [+ all-reduce] + D2H + accept/reject.  Every
+third step a new window starts: initial guess, fresh damping, cache re-seeded from a device snapshot
+(inside the timed region).  Inputs are resident in HBM before the timed region starts.
+
+Workload: BASELINE.json configs[1] ("cfg2"): 10-frame window, 100k points/scan, 50k voxels, fp64.
+N > 1: voxel-sharded weak scaling (configs[3] is exactly 8 x cfg2): every rank owns a cfg2-sized shard
+of one shared window, the packed [Hess | JacT | residual] buffer is all-reduced over RCCL each sweep;
+value = N * K / time (shard-iterations per second), the global iteration rate is in config.
+
+Launch: ``python bench.py`` (N=1) or
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N``.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--steps-per-solve", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run with N ranks")
+        args.gpus = world
+
+    # torch first: it brings its own HIP runtime with the same SONAME; loading it before libvxba.so keeps ONE
+    # runtime in the process so torch's stream / tensors and the library's kernels share a context.
+    import torch
+    import torch.distributed as dist
+    import numpy as np
+
+    from voxel_slam_amd import synth, vxba
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- synthetic window: every rank builds its own voxel shard of one shared window ------------
+    base_seed = synth.MASTER_SEED + list(synth.CONFIGS).index(args.config) + 1
+    sc = synth.make_config(args.config, seed=base_seed + 1000 * rank, pose_seed=base_seed)
+    W, V = sc.win_size, sc.n_voxels
+
+    f = vxba.LidarFactor(W, device=local_rank)
+    stream = torch.cuda.current_stream()
+    f.set_stream(stream.cuda_stream)
+    f.push_points(V, sc.points_body, sc.cell_ptr)          # K1 on the GPU; data now resident in HBM
+    if world > 1:
+        xbuf = torch.zeros(f.packed_len() + 1, dtype=torch.float64, device="cuda")
+        packed_t, scalar_t = xbuf[: f.packed_len()], xbuf[f.packed_len():]
+        f.use_external_buffers(packed_t.data_ptr(), scalar_t.data_ptr())
+
+        def hook(ptr, count, _stream):
+            dist.all_reduce(packed_t if count > 1 else scalar_t)
+
+        f.set_allreduce(hook)
+    f.evaluate_only_residual(sc.poses_init)                # seeds the (lambda, U, merged) cache (recut's eig)
+    f.snapshot_cache()
+    abytes = f.algorithmic_bytes()
+    nnz = f.nnz()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sps = args.steps_per_solve
+    if args.warmup > 0:
+        f.lm_steps(sc.poses_init, args.warmup, sps)
+    f.kernel_times(reset=True)
+    f.set_profiling(True)                                  # hipEvents around K3/K2 on the launch stream
+    sync()
+    t0 = time.perf_counter()
+    poses, resis = f.lm_steps(sc.poses_init, args.steps, sps)
+    sync()
+    t1 = time.perf_counter()
+    f.set_profiling(False)
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kt = f.kernel_times(reset=True)
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        k3_ms = kt["k3_hessian"]["ms_sum"] / max(1, kt["k3_hessian"]["calls"])
+        k2_ms = kt["k2_residual"]["ms_sum"] / max(1, kt["k2_residual"]["calls"])
+        k3f_ms = kt["k3_finalize"]["ms_sum"] / max(1, kt["k3_finalize"]["calls"])
+        achieved = abytes["k3"] / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0
+        out = {
+            "metric": "BA iterations/sec (10-frame window, 100k pts/scan)",
+            "value": world * args.steps / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}: W={W}, {sc.points_body.shape[0] // W} pts/scan, {V} voxels per GPU, nnz={nnz}",
+                "steps_per_solve": sps,
+                "global_voxels": V * world,
+                "global_iterations_per_s": args.steps / elapsed,
+                "parallelism": f"voxel-shard x{world}" + (" + RCCL all-reduce of [Hess|JacT|res]" if world > 1 else ""),
+                "final_residual": float(resis[1]),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k3_hessian_kernel<10>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": abytes["k3"],
+                "avg_launch_ms": k3_ms,
+                "launches": kt["k3_hessian"]["calls"],
+                "k2_residual": {"avg_launch_ms": k2_ms, "algorithmic_bytes_per_launch": abytes["k2"],
+                                "achieved": (abytes["k2"] / (k2_ms * 1e-3) / 1e9) if k2_ms > 0 else 0.0,
+                                "frac": (abytes["k2"] / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k2_ms > 0 else 0.0},
+                "k3_finalize_avg_ms": k3f_ms,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, f, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    f.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sc, f, budget_s):
+    """The CPU oracle (reference-equivalent restatement, 5 std::threads like LI_BA_Optimizer, voxel_map.hpp:467)
+    timed on this host on a bounded sample of the same workload.  A reported baseline, not the target."""
+    from tests import _oracle as O
+    nthreads = 5
+    fo = O.Oracle(sc.win_size)
+    clusters = f.read_clusters()
+    fo.push_voxels(clusters, sc.fix, sc.coe)
+    fo.evaluate_only_residual(sc.poses_init)
+    t1, _, _ = fo.time_ba_iteration(sc.poses_init, nthreads, warmup=0, iters=1)
+    iters = int(max(2, min(20, budget_s / max(t1, 1e-3))))
+    t, th, tr = fo.time_ba_iteration(sc.poses_init, nthreads, warmup=1, iters=iters)
+    ncpu = os.cpu_count()
+    return {
+        "value": 1.0 / t, "unit": "iterations/s", "cores": nthreads, "kind": "port",
+        "sample": f"full {sc.n_voxels}-voxel window, median of {iters} accepted-step iterations "
+                  f"(Hessian sweep {th * 1e3:.1f} ms + residual sweep {tr * 1e3:.1f} ms), host has {ncpu} logical CPUs",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+/* vxba.h -- C ABI of the MI355X-native LiDAR bundle-adjustment factor (libvxba.so).
+ *
+ * Drop-in boundary for the local-mapping BA hot path of hku-mars/Voxel-SLAM: everything
+ * `class LidarFactor` (VoxelSLAM/src/voxel_map.hpp:109-290) does, plus the optimizer shell that
+ * owns the loop (`Lidar_BA_Optimizer`, voxel_map.hpp:293-444), behind plain pointers and sizes.
+ * The reference has no FFI; these are the entry points a binding of that class would need
+ * (INTEGRATION.md shows the adapter a maintainer would add to voxel_map.hpp).
+ *
+ * All kernels behind this header are hand-written HIP for gfx950 (CDNA4).  There is NO CPU
+ * fallback: every entry point that needs the GPU returns VXBA_ERR_HIP / VXBA_ERR_NODEV if the
+ * device or the HIP runtime is unavailable.
+ *
+ * Packed formats (all f64, caller-owned, host memory unless the name says `_device`):
+ *   cluster : 10 f64  [Pxx Pxy Pxz Pyy Pyz Pzz vx vy vz N]        <- PointCluster, tools.hpp:304-365
+ *                     (P symmetric; N stored as an exact integer-valued double; N == 0 means
+ *                      "frame did not observe this voxel", voxel_map.hpp:178,217,221,258)
+ *   pose    : 12 f64  [R column-major (9) | p (3)]                 <- IMUST::R, IMUST::p, tools.hpp:139-140
+ *   eig_val :  3 f64  ascending                                     <- LidarFactor::eig_values
+ *   eig_vec :  9 f64  column-major, column k = eigenvector k        <- LidarFactor::eig_vectors
+ *   Hess    : (6W)x(6W) f64 column-major (Eigen::MatrixXd layout), JacT : 6W f64
+ *             per-frame tangent order [dphi(3); dp(3)], R <- R Exp(dphi), p <- p + dp (tools.hpp:154-162)
+ */
+#ifndef VXBA_H
+#define VXBA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vxba_factor vxba_factor; /* opaque; one per `LidarFactor` instance */
+
+enum {
+  VXBA_OK = 0,
+  VXBA_ERR_ARG = 1,    /* bad argument (null pointer, range, win_size) */
+  VXBA_ERR_HIP = 2,    /* a HIP runtime call failed; see vxba_last_error */
+  VXBA_ERR_NODEV = 3,  /* no usable gfx950 device */
+  VXBA_ERR_STATE = 4,  /* call not legal in the current state (e.g. empty factor) */
+  VXBA_ERR_UNSUPPORTED = 5
+};
+
+/* Largest window the current kernels accept (6W <= 64 columns of the MFMA accumulator tile set). */
+#define VXBA_MAX_WIN 10
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+/* LidarFactor(int _w)                                   voxel_map.hpp:120 */
+int vxba_create(int win_size, int device, vxba_factor** out);
+int vxba_destroy(vxba_factor* f);
+/* LidarFactor::clear()                                  voxel_map.hpp:281-286 */
+int vxba_clear(vxba_factor* f);
+/* `voxhess.win_size = ...` (voxelslam.cpp:623,1609); only legal on an empty factor */
+int vxba_set_win_size(vxba_factor* f, int win_size);
+int vxba_win_size(const vxba_factor* f);
+/* plvec_voxels.size()                                   voxel_map.hpp:314,344 */
+int vxba_size(const vxba_factor* f);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the factor's own. */
+int vxba_set_stream(vxba_factor* f, void* hip_stream);
+int vxba_reserve(vxba_factor* f, int n_voxels);
+const char* vxba_last_error(const vxba_factor* f);
+
+/* ---- factor construction --------------------------------------------------------------------- */
+/* Batched LidarFactor::push_voxel (voxel_map.hpp:122-130): appends n voxels.
+ *   clusters n*W*10 (voxel-major, frames chronological, voxel_map.hpp:1317-1319), fix n*10 (world frame),
+ *   coe n (>= 0), eig_val n*3, eig_vec n*9, merged n*10 -- the (lambda, U, pcr_add) cache seeded by the
+ *   caller (recut's eigen-decomposition, voxel_map.hpp:1161-1163).  eig_val/eig_vec/merged may be NULL:
+ *   the cache is then undefined until vxba_evaluate_only_residual has run. */
+int vxba_push_voxels(vxba_factor* f, int n, const double* clusters, const double* fix, const double* coe,
+                     const double* eig_val, const double* eig_vec, const double* merged);
+
+/* K1 -- per-(voxel, frame) cluster accumulation from raw points, PointCluster::push (tools.hpp:326-331;
+ * call sites voxel_map.hpp:988, loop_refine.hpp:383-385).  Appends n_voxels voxels whose body-frame
+ * clusters are built on the GPU from points bucketed contiguously per cell:
+ *   cell index = frame * n_voxels + voxel;  cell_ptr has W*n_voxels + 1 entries;  xyz_body n_points*3.
+ *   fix / coe as in vxba_push_voxels (fix may be NULL = no fix clusters, coe NULL = all ones). */
+int vxba_push_points(vxba_factor* f, int n_voxels, int64_t n_points, const double* xyz_body, const int64_t* cell_ptr,
+                     const double* fix, const double* coe);
+
+/* Read back the body-frame clusters of voxels [head,end) as n*W*10 (parity checks of K1). */
+int vxba_read_clusters(vxba_factor* f, int head, int end, double* clusters);
+
+/* ---- the two sweeps -------------------------------------------------------------------------- */
+/* LidarFactor::acc_evaluate2 (voxel_map.hpp:132-241): Hessian / gradient / residual of voxels [head,end)
+ * under poses Rp (W*12) using the CACHED (lambda, U, merged) of the last evaluate_only_residual / push.
+ * Outputs are overwritten (the reference zeroes them, :134) and the lower block triangle is mirrored (:237-239). */
+int vxba_acc_evaluate2(vxba_factor* f, const double* Rp, int head, int end, double* Hess, double* JacT, double* residual);
+
+/* LidarFactor::evaluate_only_residual (voxel_map.hpp:243-279): world merge of the clusters under Rp,
+ * 3x3 covariance, symmetric eigen-decomposition; WRITES the (lambda, U, merged) cache of [head,end);
+ * residual = sum coe * lambda_0. */
+int vxba_evaluate_only_residual(vxba_factor* f, const double* Rp, int head, int end, double* residual);
+
+/* Same sweeps leaving the result in DEVICE memory (for an RCCL all-reduce across voxel shards):
+ *   d_out of acc_evaluate2: packed [Hess (6W)^2 col-major | JacT 6W | residual 1] = (6W)^2 + 6W + 1 f64
+ *   d_out of evaluate_only_residual: 1 f64.  Asynchronous on the factor's stream. */
+int vxba_acc_evaluate2_device(vxba_factor* f, const double* Rp, int head, int end, double* d_out);
+int vxba_evaluate_only_residual_device(vxba_factor* f, const double* Rp, int head, int end, double* d_out);
+size_t vxba_packed_len(const vxba_factor* f); /* (6W)^2 + 6W + 1 */
+
+/* Public members pcr_adds / eig_values / eig_vectors read by OctoTree::margi (voxel_map.hpp:1211-1222)
+ * and motion_init (voxelslam.cpp:651-655).  Any output may be NULL. */
+int vxba_read_cache(vxba_factor* f, int head, int end, double* eig_val, double* eig_vec, double* merged);
+/* Keep / restore a device-side copy of the cache (a new window re-seeds the cache; used by bench.py). */
+int vxba_snapshot_cache(vxba_factor* f);
+int vxba_restore_cache(vxba_factor* f);
+
+/* ---- K4: batched plane fit ---------------------------------------------------------------------- */
+/* eig(pcr.cov()) for n clusters (OctoTree::recut voxel_map.hpp:1161-1163, margi :1242-1244,
+ * OctreeGBA::recut loop_refine.hpp:363-366).  Stand-alone; runs on `device`. */
+int vxba_plane_fit(int device, int64_t n, const double* clusters, double* eig_val, double* eig_vec);
+
+/* ---- the LM shell that owns the loop ------------------------------------------------------------ */
+/* Collective hook for voxel-sharded multi-GPU BA: called on the packed device buffer after each sweep's
+ * on-device reduction, before the host reads it.  Must sum `count` f64 across ranks in place, stream-ordered
+ * on `hip_stream`.  NULL = single GPU. */
+typedef int (*vxba_allreduce_fn)(void* ctx, double* d_buf, size_t count, void* hip_stream);
+int vxba_set_allreduce(vxba_factor* f, vxba_allreduce_fn fn, void* ctx);
+/* Let the caller own the exchange buffers the sweeps reduce into (e.g. a torch tensor, so torch.distributed /
+ * RCCL can all-reduce it): d_packed holds vxba_packed_len() f64, d_scalar 1 f64.  NULL restores the internal ones. */
+int vxba_use_external_buffers(vxba_factor* f, double* d_packed, double* d_scalar);
+
+/* One LM trace row: [residual1 residual2 u v q q1 accepted recomputed_hess] */
+#define VXBA_TRACE_COLS 8
+
+/* Lidar_BA_Optimizer::damping_iter (voxel_map.hpp:367-442).  Rp (W*12) in/out.  hess_out (6W)^2 col-major =
+ * `*hess`, exported BEFORE the gauge fix (:391).  resis_out[2] = residual before / after (:394-395,440).
+ * trace_out max_iter*VXBA_TRACE_COLS (may be NULL).  *is_converge as the reference's return value. */
+int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out, double* resis_out, double* trace_out,
+                      int* n_trace, int* is_converge);
+
+/* Benchmark driver: exactly n_steps LM iterations of the accepted-step path (Hessian sweep + reduction
+ * [+ all-reduce] + damped solve + state update + residual sweep [+ all-reduce] + accept/reject), without the
+ * early break; every `steps_per_solve` steps a new solve starts from Rp_init with u = 0.01, v = 2 and the
+ * snapshot cache restored (a new window).  Rp_out (W*12) receives the poses of the last completed solve. */
+int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_per_solve, double* Rp_out,
+                  double* last_resis);
+
+/* ---- measurement --------------------------------------------------------------------------------- */
+/* When on, every sweep brackets its dominant kernel with hipEvents on the launch stream. */
+int vxba_set_profiling(vxba_factor* f, int on);
+/* Sum of kernel durations [ms] and launch counts since the last reset: index 0 = Hessian sweep (K3),
+ * 1 = residual sweep (K2), 2 = K3 cross-block reduction, 3 = cluster build (K1). */
+int vxba_get_kernel_times(vxba_factor* f, double ms_sum[4], int64_t calls[4], int reset);
+/* Algorithmic bytes of one full sweep over the current factor: 0 = K3, 1 = K2. */
+int vxba_algorithmic_bytes(const vxba_factor* f, double bytes[2]);
+int vxba_nnz(vxba_factor* f, int64_t* nnz);
+
+/* Debug: D(16x16, row-major) = A(16x4) B(4x16) through one v_mfma_f64_16x16x4_f64 with the lane maps the Hessian
+ * kernel relies on (unit-tested on the GPU so a wrong operand layout is caught in isolation). */
+int vxba_debug_mfma_probe(int device, const double* A16x4, const double* B4x16, double* D16x16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VXBA_H */

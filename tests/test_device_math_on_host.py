@@ -1,0 +1,87 @@
+"""The per-lane arithmetic of the HIP kernels (voxel-slam_amd/csrc/vxba_math.hpp), compiled for the host and
+checked against the oracle term by term: Jacobi eigensolver, K2 merge + cache, K3 rank-3 rows / gradient /
+block-diagonal correction.  (The kernels themselves are exercised by the -m gpu tests.)"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+from voxel_slam_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+@pytest.fixture(scope="module")
+def hm():
+    src = os.path.join(HERE, "hostmath", "vxm_hostcheck.cpp")
+    so = os.path.join(HERE, "hostmath", "libvxm_hostcheck.so")
+    hdr = os.path.join(HERE, "..", "voxel-slam_amd", "csrc", "vxba_math.hpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
+    L = C.CDLL(so)
+    L.vxmh_eig_sym3.argtypes = [f64p, f64p, f64p]
+    L.vxmh_k2.argtypes = [C.c_int, C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, f64p, C.POINTER(C.c_double)]
+    L.vxmh_k3.argtypes = [C.c_int, C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p, C.POINTER(C.c_double)]
+    return L
+
+
+def test_jacobi_eigensolver(hm):
+    rng = np.random.default_rng(5)
+    mats = []
+    for s in (1e-8, 1.0, 1e5):
+        for _ in range(100):
+            A = rng.normal(size=(3, 3)) * s
+            mats.append(0.5 * (A + A.T))
+    for _ in range(200):   # planar covariances incl. nearly equal in-plane eigenvalues
+        Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        lam = np.array([4e-4 * rng.uniform(0.2, 3), 0.07, 0.07 * (1 + rng.choice([0, 1e-12, 1e-6, 0.3]))])
+        mats.append(Q @ np.diag(lam) @ Q.T)
+    mats += [np.zeros((3, 3)), np.eye(3), np.diag([3.0, 1.0, 2.0])]
+    for M in mats:
+        M = 0.5 * (M + M.T)
+        c6 = np.array([M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2]])
+        lam = np.zeros(3); U = np.zeros(9)
+        hm.vxmh_eig_sym3(c6, lam, U)
+        U = U.reshape(3, 3)
+        ref = np.linalg.eigvalsh(M)
+        nrm = max(np.abs(M).max(), 1e-300)
+        assert np.all(np.diff(lam) >= 0)
+        assert np.allclose(lam, ref, rtol=0, atol=1e-14 * nrm)
+        assert np.allclose(U.T @ U, np.eye(3), atol=1e-14)
+        assert np.allclose(M @ U, U * lam, atol=2e-14 * nrm)
+
+
+@pytest.mark.parametrize("p_obs,fix_frac", [(1.0, 0.0), (0.6, 0.4)])
+def test_k2_and_k3_lane_math_match_oracle(hm, p_obs, fix_frac):
+    sc = synth.make_scene(win_size=5, pts_per_scan=3000, n_voxels=150, p_obs=p_obs, fix_frac=fix_frac, seed=21,
+                          rot_sigma_deg=0.2, trans_sigma=0.03)
+    V, W = sc.n_voxels, sc.win_size
+    coe = np.linspace(0.5, 2.0, V)
+    f = O.Oracle(W)
+    f.push_voxels(sc.clusters, sc.fix, coe)
+    r_ref = f.evaluate_only_residual(sc.poses_init)
+    ev_ref, U_ref, m_ref = f.read_cache()
+
+    ev = np.zeros((V, 3)); U = np.zeros((V, 9)); m = np.zeros((V, 10)); r = C.c_double(0)
+    hm.vxmh_k2(V, W, sc.clusters, sc.fix, coe, sc.poses_init, ev, U, m, C.byref(r))
+    assert np.allclose(m, m_ref, rtol=1e-13, atol=1e-9)
+    assert np.array_equal(m[:, 9], m_ref[:, 9])
+    assert np.allclose(ev, ev_ref, rtol=1e-9, atol=1e-12)
+    assert np.isclose(r.value, r_ref, rtol=1e-10)
+    # eigenvectors agree up to sign
+    d = np.abs(np.einsum("nck,nck->nc", U.reshape(V, 3, 3), U_ref.reshape(V, 3, 3)))
+    assert np.all(d[:, 0] > 1 - 1e-9)
+
+    # K3 lane math against the oracle's acc_evaluate2 (same cache on both sides)
+    H_ref, J_ref, res_ref = f.acc_evaluate2(sc.poses_init)
+    n = 6 * W
+    H = np.zeros((n, n)); J = np.zeros(n); rr = C.c_double(0)
+    hm.vxmh_k3(V, W, sc.clusters, coe, ev_ref, U_ref, m_ref, sc.poses_init, H, J, C.byref(rr))
+    H = H.T
+    assert np.allclose(H, H_ref, rtol=1e-9, atol=1e-10 * np.abs(H_ref).max())
+    assert np.allclose(J, J_ref, rtol=1e-9, atol=1e-11 * np.abs(J_ref).max())
+    assert np.isclose(rr.value, res_ref, rtol=1e-13)

@@ -1,0 +1,695 @@
+// C-ABI implementation (include/vxba.h): device memory, streams, launch sequencing and the host part of
+// the LM shell.  No CPU fallback anywhere: without a gfx950 device every entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vxba.h"
+#include "vxba_host.hpp"
+#include "vxba_kernels.h"
+
+using vxk::FactorView;
+using vxk::PoseArg;
+
+namespace {
+
+constexpr int N_META_PLANES = 10 + 1 + 3 + 9 + 10 + 2;  // fix, coe, eigval, eigvec, merged, aux
+constexpr int N_CACHE_PLANES = 3 + 9 + 10 + 2;          // eigval, eigvec, merged, aux (contiguous at the tail)
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+}  // namespace
+
+struct vxba_factor {
+  int W = 0, device = 0;
+  int V = 0;        // voxels in the factor
+  int VS = 0;       // plane stride (capacity, multiple of 64)
+  int cus = 0;
+  hipStream_t stream = nullptr, own_stream = nullptr;
+  double* planes = nullptr;      // [(10W + N_META_PLANES)][VS]
+  double* snapshot = nullptr;    // [N_CACHE_PLANES][snapshot_vs]
+  int snapshot_vs = 0, snapshot_v = 0;
+  double* staging = nullptr;     // device scratch for uploads / read-backs
+  size_t staging_len = 0;
+  double* d_partial3 = nullptr;  // K3 workgroup partials
+  size_t partial3_len = 0;
+  double* d_partial2 = nullptr;  // K2 wave partials
+  size_t partial2_len = 0;
+  double* d_packed = nullptr;    // [Hess | JacT | residual] (points at own_packed or a caller buffer)
+  double* d_scalar = nullptr;
+  double* own_packed = nullptr;
+  double* own_scalar = nullptr;
+  unsigned long long* d_count = nullptr;
+  double* h_packed = nullptr;    // pinned
+  double* h_scalar = nullptr;    // pinned
+  vxba_allreduce_fn allreduce = nullptr;
+  void* allreduce_ctx = nullptr;
+  bool profiling = false;
+  std::vector<EventPair> pending;
+  std::vector<hipEvent_t> free_events;
+  double ms_sum[4] = {0, 0, 0, 0};
+  int64_t calls[4] = {0, 0, 0, 0};
+  std::string err;
+  vxh::LMWorkspace ws;
+};
+
+namespace {
+
+#define VX_HIP(f, call)                                                                              \
+  do {                                                                                               \
+    hipError_t e__ = (call);                                                                         \
+    if (e__ != hipSuccess) {                                                                         \
+      (f)->err = std::string(#call) + ": " + hipGetErrorString(e__);                                 \
+      return VXBA_ERR_HIP;                                                                           \
+    }                                                                                                \
+  } while (0)
+
+int fail(vxba_factor* f, int code, const char* msg) {
+  if (f) f->err = msg;
+  return code;
+}
+
+int n_planes(const vxba_factor* f) { return 10 * f->W + N_META_PLANES; }
+
+FactorView view(const vxba_factor* f) {
+  FactorView fv;
+  const size_t VS = (size_t)f->VS;
+  double* p = f->planes;
+  fv.cl = p;                     p += (size_t)10 * f->W * VS;
+  fv.fix = p;                    p += 10 * VS;
+  fv.coe = p;                    p += VS;
+  fv.eigval = p;                 p += 3 * VS;
+  fv.eigvec = p;                 p += 9 * VS;
+  fv.merged = p;                 p += 10 * VS;
+  fv.aux = p;
+  fv.VS = f->VS;
+  fv.W = f->W;
+  return fv;
+}
+
+int ensure_staging(vxba_factor* f, size_t len) {
+  if (len <= f->staging_len) return VXBA_OK;
+  if (f->staging) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->staging)); f->staging = nullptr; f->staging_len = 0; }
+  len = std::max(len, (size_t)1 << 16);
+  VX_HIP(f, hipMalloc((void**)&f->staging, len * sizeof(double)));
+  f->staging_len = len;
+  return VXBA_OK;
+}
+
+int ensure_capacity(vxba_factor* f, int n_total) {
+  if (n_total <= f->VS) return VXBA_OK;
+  int want = std::max(n_total, 2 * f->VS);
+  want = (want + 63) / 64 * 64;
+  double* np = nullptr;
+  const size_t bytes = (size_t)n_planes(f) * want * sizeof(double);
+  VX_HIP(f, hipMalloc((void**)&np, bytes));
+  VX_HIP(f, hipMemsetAsync(np, 0, bytes, f->stream));
+  if (f->planes && f->V > 0) vxk::launch_copy_planes(f->planes, f->VS, np, want, n_planes(f), f->V, f->stream);
+  if (f->planes) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->planes)); }
+  f->planes = np;
+  f->VS = want;
+  const size_t p2 = (size_t)want / 64 + 1;
+  if (p2 > f->partial2_len) {
+    if (f->d_partial2) VX_HIP(f, hipFree(f->d_partial2));
+    VX_HIP(f, hipMalloc((void**)&f->d_partial2, p2 * sizeof(double)));
+    f->partial2_len = p2;
+  }
+  return VXBA_OK;
+}
+
+int ensure_partials3(vxba_factor* f) {
+  const size_t need = (size_t)vxk::k3_grid_blocks(f->cus) * vxk::k3_partial_len(f->W);
+  if (need <= f->partial3_len) return VXBA_OK;
+  if (f->d_partial3) VX_HIP(f, hipFree(f->d_partial3));
+  VX_HIP(f, hipMalloc((void**)&f->d_partial3, need * sizeof(double)));
+  f->partial3_len = need;
+  return VXBA_OK;
+}
+
+int check_range(vxba_factor* f, int head, int end) {
+  if (head < 0 || end < head || end > f->V) return fail(f, VXBA_ERR_ARG, "voxel range [head,end) outside the factor");
+  return VXBA_OK;
+}
+
+void fill_poses(const vxba_factor* f, const double* Rp, PoseArg& pa) {
+  std::memset(&pa, 0, sizeof pa);
+  std::memcpy(pa.Rp, Rp, sizeof(double) * 12 * f->W);
+}
+
+// ---- profiling helpers ----
+hipEvent_t get_event(vxba_factor* f) {
+  if (!f->free_events.empty()) { hipEvent_t e = f->free_events.back(); f->free_events.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+struct ScopedKernelTimer {
+  vxba_factor* f; int kind; hipEvent_t a = nullptr, b = nullptr;
+  ScopedKernelTimer(vxba_factor* f_, int kind_) : f(f_), kind(kind_) {
+    if (f->profiling) { a = get_event(f); b = get_event(f); if (a) hipEventRecord(a, f->stream); }
+  }
+  ~ScopedKernelTimer() {
+    if (f->profiling && a && b) { hipEventRecord(b, f->stream); f->pending.push_back({a, b, kind}); }
+  }
+};
+int drain_events(vxba_factor* f) {
+  if (f->pending.empty()) return VXBA_OK;
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  for (auto& ep : f->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { f->ms_sum[ep.kind] += ms; f->calls[ep.kind]++; }
+    f->free_events.push_back(ep.a);
+    f->free_events.push_back(ep.b);
+  }
+  f->pending.clear();
+  return VXBA_OK;
+}
+
+// ---- sweeps (asynchronous on f->stream; results in device memory) ----
+int sweep_hess_device(vxba_factor* f, const double* Rp, int head, int end, double* d_out) {
+  const size_t plen = vxba_packed_len(f);
+  if (end == head) { VX_HIP(f, hipMemsetAsync(d_out, 0, plen * sizeof(double), f->stream)); return VXBA_OK; }
+  int rc = ensure_partials3(f);
+  if (rc) return rc;
+  PoseArg pa;
+  fill_poses(f, Rp, pa);
+  const FactorView fv = view(f);
+  // one wave per batch of NV voxels; never launch more workgroups than there are batches / 4
+  const int nt = vxk::k3_num_tiles(f->W);
+  const int nvcap = nt <= 2 ? 12 : 8;
+  const int nv = std::min(64 / f->W, nvcap);
+  const int nbatches = (end - head + nv - 1) / nv;
+  const int nblocks = std::max(1, std::min(vxk::k3_grid_blocks(f->cus), (nbatches + 3) / 4));
+  {
+    ScopedKernelTimer t(f, 0);
+    vxk::launch_k3_hessian(fv, pa, head, end, f->d_partial3, nblocks, f->stream);
+  }
+  {
+    ScopedKernelTimer t(f, 2);
+    vxk::launch_k3_finalize(f->d_partial3, nblocks, f->W, d_out, f->stream);
+  }
+  VX_HIP(f, hipGetLastError());
+  if (f->allreduce) {
+    if (f->allreduce(f->allreduce_ctx, d_out, plen, (void*)f->stream) != 0) return fail(f, VXBA_ERR_STATE, "all-reduce hook failed");
+  }
+  return VXBA_OK;
+}
+
+int sweep_residual_device(vxba_factor* f, const double* Rp, int head, int end, double* d_out) {
+  if (end == head) { VX_HIP(f, hipMemsetAsync(d_out, 0, sizeof(double), f->stream)); return VXBA_OK; }
+  PoseArg pa;
+  fill_poses(f, Rp, pa);
+  const FactorView fv = view(f);
+  int nparts;
+  {
+    ScopedKernelTimer t(f, 1);
+    nparts = vxk::launch_k2_residual(fv, pa, head, end, f->d_partial2, f->stream);
+  }
+  vxk::launch_sum_partials(f->d_partial2, nparts, d_out, f->stream);
+  VX_HIP(f, hipGetLastError());
+  if (f->allreduce) {
+    if (f->allreduce(f->allreduce_ctx, d_out, 1, (void*)f->stream) != 0) return fail(f, VXBA_ERR_STATE, "all-reduce hook failed");
+  }
+  return VXBA_OK;
+}
+
+int sweep_hess_host(vxba_factor* f, const double* Rp, int head, int end) {
+  int rc = sweep_hess_device(f, Rp, head, end, f->d_packed);
+  if (rc) return rc;
+  VX_HIP(f, hipMemcpyAsync(f->h_packed, f->d_packed, vxba_packed_len(f) * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  return VXBA_OK;
+}
+int sweep_residual_host(vxba_factor* f, const double* Rp, int head, int end, double* residual) {
+  int rc = sweep_residual_device(f, Rp, head, end, f->d_scalar);
+  if (rc) return rc;
+  VX_HIP(f, hipMemcpyAsync(f->h_scalar, f->d_scalar, sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  *residual = f->h_scalar[0];
+  return VXBA_OK;
+}
+
+// Append per-voxel metadata rows (fix, coe and optionally the cache) for n voxels at offset v0.
+int append_meta(vxba_factor* f, int v0, int n, const double* fix, const double* coe, const double* eig_val, const double* eig_vec,
+                const double* merged) {
+  const FactorView fv = view(f);
+  const size_t per = 10 + 1 + 3 + 9 + 10;
+  int rc = ensure_staging(f, (size_t)n * per);
+  if (rc) return rc;
+  double* s = f->staging;
+  std::vector<double> tmp;
+  if (!fix) tmp.assign((size_t)n * 10, 0.0);
+  VX_HIP(f, hipMemcpyAsync(s, fix ? fix : tmp.data(), sizeof(double) * n * 10, hipMemcpyHostToDevice, f->stream));
+  vxk::launch_scatter_rows(s, fv.fix, f->VS, v0, n, 10, f->stream);
+  s += (size_t)n * 10;
+  std::vector<double> ones;
+  if (!coe) ones.assign(n, 1.0);
+  VX_HIP(f, hipMemcpyAsync(s, coe ? coe : ones.data(), sizeof(double) * n, hipMemcpyHostToDevice, f->stream));
+  vxk::launch_scatter_rows(s, fv.coe, f->VS, v0, n, 1, f->stream);
+  s += n;
+  if (eig_val && eig_vec && merged) {
+    VX_HIP(f, hipMemcpyAsync(s, eig_val, sizeof(double) * n * 3, hipMemcpyHostToDevice, f->stream));
+    vxk::launch_scatter_rows(s, fv.eigval, f->VS, v0, n, 3, f->stream);
+    s += (size_t)n * 3;
+    VX_HIP(f, hipMemcpyAsync(s, eig_vec, sizeof(double) * n * 9, hipMemcpyHostToDevice, f->stream));
+    vxk::launch_scatter_rows(s, fv.eigvec, f->VS, v0, n, 9, f->stream);
+    s += (size_t)n * 9;
+    VX_HIP(f, hipMemcpyAsync(s, merged, sizeof(double) * n * 10, hipMemcpyHostToDevice, f->stream));
+    vxk::launch_scatter_rows(s, fv.merged, f->VS, v0, n, 10, f->stream);
+    vxk::launch_seed_aux(fv, v0, v0 + n, f->stream);
+  }
+  // host temporaries (tmp/ones) and the caller's arrays must outlive the async copies
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  VX_HIP(f, hipGetLastError());
+  return VXBA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vxba_create(int win_size, int device, vxba_factor** out) {
+  if (!out) return VXBA_ERR_ARG;
+  *out = nullptr;
+  if (win_size < 1 || win_size > VXBA_MAX_WIN) return VXBA_ERR_UNSUPPORTED;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VXBA_ERR_NODEV;
+  if (device < 0 || device >= ndev) return VXBA_ERR_NODEV;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return VXBA_ERR_NODEV;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return VXBA_ERR_NODEV;  // kernels are built for gfx950 only
+  if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_HIP;
+  vxba_factor* f = new vxba_factor();
+  f->W = win_size;
+  f->device = device;
+  f->cus = prop.multiProcessorCount;
+  auto bail = [&](hipError_t) { vxba_destroy(f); return VXBA_ERR_HIP; };
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e);
+  f->stream = f->own_stream;
+  const size_t plen = (size_t)36 * VXBA_MAX_WIN * VXBA_MAX_WIN + 6 * VXBA_MAX_WIN + 1;
+  if ((e = hipMalloc((void**)&f->own_packed, plen * sizeof(double))) != hipSuccess) return bail(e);
+  if ((e = hipMalloc((void**)&f->own_scalar, sizeof(double))) != hipSuccess) return bail(e);
+  f->d_packed = f->own_packed;
+  f->d_scalar = f->own_scalar;
+  if ((e = hipMalloc((void**)&f->d_count, sizeof(unsigned long long))) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc((void**)&f->h_packed, plen * sizeof(double), hipHostMallocDefault)) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc((void**)&f->h_scalar, 2 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return bail(e);
+  *out = f;
+  return VXBA_OK;
+}
+
+int vxba_destroy(vxba_factor* f) {
+  if (!f) return VXBA_OK;
+  hipSetDevice(f->device);
+  if (f->stream) hipStreamSynchronize(f->stream);
+  for (auto& ep : f->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
+  for (auto e : f->free_events) hipEventDestroy(e);
+  hipFree(f->planes); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2);
+  hipFree(f->own_packed); hipFree(f->own_scalar); hipFree(f->d_count);
+  if (f->h_packed) hipHostFree(f->h_packed);
+  if (f->h_scalar) hipHostFree(f->h_scalar);
+  if (f->own_stream) hipStreamDestroy(f->own_stream);
+  delete f;
+  return VXBA_OK;
+}
+
+int vxba_clear(vxba_factor* f) {
+  if (!f) return VXBA_ERR_ARG;
+  f->V = 0;
+  f->snapshot_v = 0;
+  return VXBA_OK;
+}
+
+int vxba_set_win_size(vxba_factor* f, int win_size) {
+  if (!f) return VXBA_ERR_ARG;
+  if (win_size < 1 || win_size > VXBA_MAX_WIN) return fail(f, VXBA_ERR_UNSUPPORTED, "win_size outside [1, VXBA_MAX_WIN]");
+  if (win_size == f->W) return VXBA_OK;
+  if (f->V != 0) return fail(f, VXBA_ERR_STATE, "win_size can only change on an empty factor");
+  hipSetDevice(f->device);
+  if (f->planes) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->planes)); f->planes = nullptr; }
+  f->VS = 0;
+  f->W = win_size;
+  return VXBA_OK;
+}
+
+int vxba_win_size(const vxba_factor* f) { return f ? f->W : 0; }
+int vxba_size(const vxba_factor* f) { return f ? f->V : 0; }
+size_t vxba_packed_len(const vxba_factor* f) { return f ? (size_t)36 * f->W * f->W + 6 * f->W + 1 : 0; }
+const char* vxba_last_error(const vxba_factor* f) { return f ? f->err.c_str() : "null factor"; }
+
+int vxba_set_stream(vxba_factor* f, void* hip_stream) {
+  if (!f) return VXBA_ERR_ARG;
+  hipSetDevice(f->device);
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  f->stream = hip_stream ? (hipStream_t)hip_stream : f->own_stream;
+  return VXBA_OK;
+}
+
+int vxba_reserve(vxba_factor* f, int n_voxels) {
+  if (!f || n_voxels < 0) return VXBA_ERR_ARG;
+  hipSetDevice(f->device);
+  return ensure_capacity(f, n_voxels);
+}
+
+int vxba_set_allreduce(vxba_factor* f, vxba_allreduce_fn fn, void* ctx) {
+  if (!f) return VXBA_ERR_ARG;
+  f->allreduce = fn;
+  f->allreduce_ctx = ctx;
+  return VXBA_OK;
+}
+
+int vxba_use_external_buffers(vxba_factor* f, double* d_packed, double* d_scalar) {
+  if (!f) return VXBA_ERR_ARG;
+  hipSetDevice(f->device);
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  f->d_packed = d_packed ? d_packed : f->own_packed;
+  f->d_scalar = d_scalar ? d_scalar : f->own_scalar;
+  return VXBA_OK;
+}
+
+int vxba_push_voxels(vxba_factor* f, int n, const double* clusters, const double* fix, const double* coe, const double* eig_val,
+                     const double* eig_vec, const double* merged) {
+  if (!f || n < 0 || (n > 0 && (!clusters || !fix || !coe))) return fail(f, VXBA_ERR_ARG, "push_voxels: null input");
+  if (n == 0) return VXBA_OK;
+  for (int a = 0; a < n; a++)
+    if (!(coe[a] >= 0.0)) return fail(f, VXBA_ERR_ARG, "push_voxels: coe must be >= 0");
+  hipSetDevice(f->device);
+  int rc = ensure_capacity(f, f->V + n);
+  if (rc) return rc;
+  const size_t ncl = (size_t)n * f->W * 10;
+  rc = ensure_staging(f, ncl);
+  if (rc) return rc;
+  VX_HIP(f, hipMemcpyAsync(f->staging, clusters, ncl * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  vxk::launch_scatter_clusters(f->staging, view(f), f->V, n, f->stream);
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  rc = append_meta(f, f->V, n, fix, coe, eig_val, eig_vec, merged);
+  if (rc) return rc;
+  f->V += n;
+  return VXBA_OK;
+}
+
+int vxba_push_points(vxba_factor* f, int n_voxels, int64_t n_points, const double* xyz_body, const int64_t* cell_ptr, const double* fix,
+                     const double* coe) {
+  if (!f || n_voxels < 0 || n_points < 0 || !cell_ptr || (n_points > 0 && !xyz_body)) return fail(f, VXBA_ERR_ARG, "push_points: null input");
+  if (n_voxels == 0) return VXBA_OK;
+  const int64_t ncells = (int64_t)n_voxels * f->W;
+  if (cell_ptr[0] != 0 || cell_ptr[ncells] != n_points) return fail(f, VXBA_ERR_ARG, "push_points: cell_ptr must span [0, n_points]");
+  if (coe)
+    for (int a = 0; a < n_voxels; a++)
+      if (!(coe[a] >= 0.0)) return fail(f, VXBA_ERR_ARG, "push_points: coe must be >= 0");
+  hipSetDevice(f->device);
+  int rc = ensure_capacity(f, f->V + n_voxels);
+  if (rc) return rc;
+  double* d_xyz = nullptr;
+  int64_t* d_ptr = nullptr;
+  VX_HIP(f, hipMalloc((void**)&d_xyz, std::max<size_t>(1, (size_t)n_points * 3) * sizeof(double)));
+  hipError_t e = hipMalloc((void**)&d_ptr, (size_t)(ncells + 1) * sizeof(int64_t));
+  if (e != hipSuccess) { hipFree(d_xyz); f->err = std::string("hipMalloc cell_ptr: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
+  auto cleanup = [&]() { hipFree(d_xyz); hipFree(d_ptr); };
+  if (n_points) e = hipMemcpyAsync(d_xyz, xyz_body, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_ptr, cell_ptr, (size_t)(ncells + 1) * sizeof(int64_t), hipMemcpyHostToDevice, f->stream);
+  if (e != hipSuccess) { cleanup(); f->err = std::string("push_points H2D: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
+  {
+    ScopedKernelTimer t(f, 3);
+    vxk::launch_k1_build(d_xyz, d_ptr, n_voxels, f->W, view(f), f->V, f->stream);
+  }
+  e = hipStreamSynchronize(f->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  cleanup();
+  if (e != hipSuccess) { f->err = std::string("K1: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
+  rc = append_meta(f, f->V, n_voxels, fix, coe, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  f->V += n_voxels;
+  return VXBA_OK;
+}
+
+int vxba_read_clusters(vxba_factor* f, int head, int end, double* clusters) {
+  if (!f || !clusters) return VXBA_ERR_ARG;
+  int rc = check_range(f, head, end);
+  if (rc) return rc;
+  const int n = end - head;
+  if (n == 0) return VXBA_OK;
+  hipSetDevice(f->device);
+  const size_t len = (size_t)n * f->W * 10;
+  rc = ensure_staging(f, len);
+  if (rc) return rc;
+  vxk::launch_gather_clusters(view(f), head, n, f->staging, f->stream);
+  VX_HIP(f, hipMemcpyAsync(clusters, f->staging, len * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  return VXBA_OK;
+}
+
+int vxba_acc_evaluate2(vxba_factor* f, const double* Rp, int head, int end, double* Hess, double* JacT, double* residual) {
+  if (!f || !Rp || !Hess || !JacT || !residual) return fail(f, VXBA_ERR_ARG, "acc_evaluate2: null argument");
+  int rc = check_range(f, head, end);
+  if (rc) return rc;
+  hipSetDevice(f->device);
+  rc = sweep_hess_host(f, Rp, head, end);
+  if (rc) return rc;
+  const int n = 6 * f->W;
+  std::memcpy(Hess, f->h_packed, sizeof(double) * n * n);
+  std::memcpy(JacT, f->h_packed + (size_t)n * n, sizeof(double) * n);
+  *residual = f->h_packed[(size_t)n * n + n];
+  return VXBA_OK;
+}
+
+int vxba_evaluate_only_residual(vxba_factor* f, const double* Rp, int head, int end, double* residual) {
+  if (!f || !Rp || !residual) return fail(f, VXBA_ERR_ARG, "evaluate_only_residual: null argument");
+  int rc = check_range(f, head, end);
+  if (rc) return rc;
+  hipSetDevice(f->device);
+  return sweep_residual_host(f, Rp, head, end, residual);
+}
+
+int vxba_acc_evaluate2_device(vxba_factor* f, const double* Rp, int head, int end, double* d_out) {
+  if (!f || !Rp || !d_out) return fail(f, VXBA_ERR_ARG, "acc_evaluate2_device: null argument");
+  int rc = check_range(f, head, end);
+  if (rc) return rc;
+  hipSetDevice(f->device);
+  return sweep_hess_device(f, Rp, head, end, d_out);
+}
+
+int vxba_evaluate_only_residual_device(vxba_factor* f, const double* Rp, int head, int end, double* d_out) {
+  if (!f || !Rp || !d_out) return fail(f, VXBA_ERR_ARG, "evaluate_only_residual_device: null argument");
+  int rc = check_range(f, head, end);
+  if (rc) return rc;
+  hipSetDevice(f->device);
+  return sweep_residual_device(f, Rp, head, end, d_out);
+}
+
+int vxba_read_cache(vxba_factor* f, int head, int end, double* eig_val, double* eig_vec, double* merged) {
+  if (!f) return VXBA_ERR_ARG;
+  int rc = check_range(f, head, end);
+  if (rc) return rc;
+  const int n = end - head;
+  if (n == 0) return VXBA_OK;
+  hipSetDevice(f->device);
+  rc = ensure_staging(f, (size_t)n * 22);
+  if (rc) return rc;
+  const FactorView fv = view(f);
+  double* s = f->staging;
+  if (eig_val) {
+    vxk::launch_gather_rows(fv.eigval, f->VS, head, n, 3, s, f->stream);
+    VX_HIP(f, hipMemcpyAsync(eig_val, s, sizeof(double) * n * 3, hipMemcpyDeviceToHost, f->stream));
+  }
+  s += (size_t)n * 3;
+  if (eig_vec) {
+    vxk::launch_gather_rows(fv.eigvec, f->VS, head, n, 9, s, f->stream);
+    VX_HIP(f, hipMemcpyAsync(eig_vec, s, sizeof(double) * n * 9, hipMemcpyDeviceToHost, f->stream));
+  }
+  s += (size_t)n * 9;
+  if (merged) {
+    vxk::launch_gather_rows(fv.merged, f->VS, head, n, 10, s, f->stream);
+    VX_HIP(f, hipMemcpyAsync(merged, s, sizeof(double) * n * 10, hipMemcpyDeviceToHost, f->stream));
+  }
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  return VXBA_OK;
+}
+
+int vxba_snapshot_cache(vxba_factor* f) {
+  if (!f) return VXBA_ERR_ARG;
+  if (f->V == 0) return fail(f, VXBA_ERR_STATE, "snapshot_cache on an empty factor");
+  hipSetDevice(f->device);
+  if (f->snapshot_vs != f->VS) {
+    if (f->snapshot) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->snapshot)); f->snapshot = nullptr; }
+    VX_HIP(f, hipMalloc((void**)&f->snapshot, (size_t)N_CACHE_PLANES * f->VS * sizeof(double)));
+    f->snapshot_vs = f->VS;
+  }
+  VX_HIP(f, hipMemcpyAsync(f->snapshot, view(f).eigval, (size_t)N_CACHE_PLANES * f->VS * sizeof(double), hipMemcpyDeviceToDevice, f->stream));
+  f->snapshot_v = f->V;
+  return VXBA_OK;
+}
+
+int vxba_restore_cache(vxba_factor* f) {
+  if (!f) return VXBA_ERR_ARG;
+  if (!f->snapshot || f->snapshot_v != f->V || f->snapshot_vs != f->VS) return fail(f, VXBA_ERR_STATE, "no matching cache snapshot");
+  hipSetDevice(f->device);
+  VX_HIP(f, hipMemcpyAsync(view(f).eigval, f->snapshot, (size_t)N_CACHE_PLANES * f->VS * sizeof(double), hipMemcpyDeviceToDevice, f->stream));
+  return VXBA_OK;
+}
+
+int vxba_plane_fit(int device, int64_t n, const double* clusters, double* eig_val, double* eig_vec) {
+  if (n < 0 || (n > 0 && (!clusters || !eig_val || !eig_vec))) return VXBA_ERR_ARG;
+  if (n == 0) return VXBA_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VXBA_ERR_NODEV;
+  if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_HIP;
+  double *d_c = nullptr, *d_l = nullptr, *d_u = nullptr;
+  hipError_t e = hipMalloc((void**)&d_c, (size_t)n * 10 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_l, (size_t)n * 3 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_u, (size_t)n * 9 * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(d_c, clusters, (size_t)n * 10 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    vxk::launch_k4_plane_fit(d_c, n, d_l, d_u, nullptr);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(eig_val, d_l, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(eig_vec, d_u, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(d_c); hipFree(d_l); hipFree(d_u);
+  return e == hipSuccess ? VXBA_OK : VXBA_ERR_HIP;
+}
+
+// Lidar_BA_Optimizer::damping_iter (voxel_map.hpp:367-442): same control flow, the two sweeps run on the GPU.
+int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out, double* resis_out, double* trace_out, int* n_trace,
+                      int* is_converge) {
+  if (!f || !Rp || max_iter < 0) return fail(f, VXBA_ERR_ARG, "damping_iter: bad argument");
+  if (f->V == 0) return fail(f, VXBA_ERR_STATE, "damping_iter on an empty factor");
+  hipSetDevice(f->device);
+  const int W = f->W, n = 6 * W;
+  double u = 0.01, v = 2;
+  std::vector<double> Hess((size_t)n * n), JacT(n), x(Rp, Rp + 12 * W), x_temp(x);
+  double residual1 = 0, residual2 = 0;
+  bool is_calc_hess = true, converge = true;
+  int nt = 0;
+  for (int i = 0; i < max_iter; i++) {
+    const bool recomputed = is_calc_hess;
+    if (is_calc_hess) {
+      int rc = sweep_hess_host(f, x.data(), 0, f->V);
+      if (rc) return rc;
+      std::memcpy(Hess.data(), f->h_packed, sizeof(double) * n * n);
+      std::memcpy(JacT.data(), f->h_packed + (size_t)n * n, sizeof(double) * n);
+      residual1 = f->h_packed[(size_t)n * n + n];
+      if (hess_out) std::memcpy(hess_out, Hess.data(), sizeof(double) * n * n);  // *hess = Hess, before the gauge fix
+    }
+    if (i == 0 && resis_out) resis_out[0] = residual1;
+    const double q1 = vxh::lm_damped_step(W, Hess.data(), JacT.data(), u, x.data(), x_temp.data(), f->ws);
+    int rc = sweep_residual_host(f, x_temp.data(), 0, f->V, &residual2);
+    if (rc) return rc;
+    const double q = residual1 - residual2;
+    const double u_used = u, v_used = v;
+    const bool accepted = vxh::lm_update_damping(residual1, residual2, q1, u, v);
+    if (accepted) { x = x_temp; is_calc_hess = true; }
+    else { is_calc_hess = false; converge = false; }
+    if (trace_out) {
+      double* o = trace_out + (size_t)VXBA_TRACE_COLS * nt;
+      o[0] = residual1; o[1] = residual2; o[2] = u_used; o[3] = v_used; o[4] = q; o[5] = q1; o[6] = accepted; o[7] = recomputed;
+    }
+    nt++;
+    if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
+  }
+  if (resis_out) resis_out[1] = residual2;
+  if (n_trace) *n_trace = nt;
+  if (is_converge) *is_converge = converge ? 1 : 0;
+  std::memcpy(Rp, x.data(), sizeof(double) * 12 * W);
+  return VXBA_OK;
+}
+
+int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_per_solve, double* Rp_out, double* last_resis) {
+  if (!f || !Rp_init || n_steps < 0 || steps_per_solve < 1) return fail(f, VXBA_ERR_ARG, "lm_steps: bad argument");
+  if (f->V == 0) return fail(f, VXBA_ERR_STATE, "lm_steps on an empty factor");
+  hipSetDevice(f->device);
+  const int W = f->W, n = 6 * W;
+  std::vector<double> Hess((size_t)n * n), JacT(n), x(Rp_init, Rp_init + 12 * W), x_temp(x);
+  double u = 0.01, v = 2, residual1 = 0, residual2 = 0;
+  for (int s = 0; s < n_steps; s++) {
+    if (s % steps_per_solve == 0) {  // a new window: initial guess, fresh damping, re-seeded cache
+      x.assign(Rp_init, Rp_init + 12 * W);
+      u = 0.01; v = 2;
+      int rc = vxba_restore_cache(f);
+      if (rc) return rc;
+    }
+    int rc = sweep_hess_host(f, x.data(), 0, f->V);   // accepted-step path: the Hessian is always recomputed
+    if (rc) return rc;
+    std::memcpy(Hess.data(), f->h_packed, sizeof(double) * n * n);
+    std::memcpy(JacT.data(), f->h_packed + (size_t)n * n, sizeof(double) * n);
+    residual1 = f->h_packed[(size_t)n * n + n];
+    const double q1 = vxh::lm_damped_step(W, Hess.data(), JacT.data(), u, x.data(), x_temp.data(), f->ws);
+    rc = sweep_residual_host(f, x_temp.data(), 0, f->V, &residual2);
+    if (rc) return rc;
+    if (vxh::lm_update_damping(residual1, residual2, q1, u, v)) x = x_temp;
+    else {
+      // rejected: the cache now describes the trial state (Appendix B.2); the next forced Hessian sweep must see
+      // the cache of the state it linearises at, so refresh it (one extra residual sweep, only on rejections)
+      double tmp;
+      rc = sweep_residual_host(f, x.data(), 0, f->V, &tmp);
+      if (rc) return rc;
+    }
+  }
+  if (Rp_out) std::memcpy(Rp_out, x.data(), sizeof(double) * 12 * W);
+  if (last_resis) { last_resis[0] = residual1; last_resis[1] = residual2; }
+  return VXBA_OK;
+}
+
+int vxba_debug_mfma_probe(int device, const double* A16x4, const double* B4x16, double* D16x16) {
+  if (!A16x4 || !B4x16 || !D16x16) return VXBA_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_NODEV;
+  double* d = nullptr;
+  if (hipMalloc((void**)&d, (64 + 64 + 256) * sizeof(double)) != hipSuccess) return VXBA_ERR_HIP;
+  hipError_t e = hipMemcpy(d, A16x4, 64 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + 64, B4x16, 64 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) { vxk::launch_mfma_probe(d, d + 64, d + 128, nullptr); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpy(D16x16, d + 128, 256 * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(d);
+  return e == hipSuccess ? VXBA_OK : VXBA_ERR_HIP;
+}
+
+int vxba_set_profiling(vxba_factor* f, int on) {
+  if (!f) return VXBA_ERR_ARG;
+  f->profiling = on != 0;
+  return VXBA_OK;
+}
+
+int vxba_get_kernel_times(vxba_factor* f, double ms_sum[4], int64_t calls[4], int reset) {
+  if (!f) return VXBA_ERR_ARG;
+  hipSetDevice(f->device);
+  int rc = drain_events(f);
+  if (rc) return rc;
+  for (int k = 0; k < 4; k++) {
+    if (ms_sum) ms_sum[k] = f->ms_sum[k];
+    if (calls) calls[k] = f->calls[k];
+    if (reset) { f->ms_sum[k] = 0; f->calls[k] = 0; }
+  }
+  return VXBA_OK;
+}
+
+int vxba_nnz(vxba_factor* f, int64_t* nnz) {
+  if (!f || !nnz) return VXBA_ERR_ARG;
+  *nnz = 0;
+  if (f->V == 0) return VXBA_OK;
+  hipSetDevice(f->device);
+  VX_HIP(f, hipMemsetAsync(f->d_count, 0, sizeof(unsigned long long), f->stream));
+  vxk::launch_count_nnz(view(f), f->V, f->d_count, f->stream);
+  unsigned long long h = 0;
+  VX_HIP(f, hipMemcpyAsync(&h, f->d_count, sizeof h, hipMemcpyDeviceToHost, f->stream));
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  *nnz = (int64_t)h;
+  return VXBA_OK;
+}
+
+int vxba_algorithmic_bytes(const vxba_factor* f, double bytes[2]) {
+  if (!f || !bytes) return VXBA_ERR_ARG;
+  int64_t nnz = 0;
+  int rc = vxba_nnz(const_cast<vxba_factor*>(f), &nnz);
+  if (rc) return rc;
+  // K3 = 80 nnz + 136 V read;  K2 = 80 nnz + 88 V read + 176 V written
+  bytes[0] = 80.0 * (double)nnz + 136.0 * f->V;
+  bytes[1] = 80.0 * (double)nnz + 264.0 * f->V;
+  return VXBA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+// Host-side (CPU, O(W^3)) part of the LM shell: what stays on the host between the two GPU sweeps of
+// Lidar_BA_Optimizer::damping_iter (voxel_map.hpp:367-442): gauge fix, damped solve, trial-state update,
+// gain ratio and damping schedule.  Dense math on (6W)^2 systems, W <= 10 -> 60x60.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <utility>
+#include <vector>
+
+namespace vxh {
+
+// Column-major dense solve of the symmetric system A x = b by LDL^T with symmetric diagonal pivoting
+// (the reference uses Eigen's LDLT, voxel_map.hpp:403).  A (n x n, lower triangle read) is overwritten.
+inline void ldlt_solve_inplace(int n, double* A, const double* b, double* x, int* perm, double* work) {
+  auto at = [&](int r, int c) -> double& { return A[(size_t)c * n + r]; };
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    double best = std::fabs(at(k, k));
+    for (int i = k + 1; i < n; ++i) {
+      const double v = std::fabs(at(i, i));
+      if (v > best) { best = v; piv = i; }
+    }
+    perm[k] = piv;
+    if (piv != k) {
+      for (int j = 0; j < k; ++j) std::swap(at(k, j), at(piv, j));
+      for (int i = piv + 1; i < n; ++i) std::swap(at(i, k), at(i, piv));
+      std::swap(at(k, k), at(piv, piv));
+      for (int i = k + 1; i < piv; ++i) std::swap(at(i, k), at(piv, i));
+    }
+    for (int j = 0; j < k; ++j) work[j] = at(j, j) * at(k, j);
+    double d = at(k, k);
+    for (int j = 0; j < k; ++j) d -= at(k, j) * work[j];
+    at(k, k) = d;
+    for (int i = k + 1; i < n; ++i) {
+      double s = at(i, k);
+      for (int j = 0; j < k; ++j) s -= at(i, j) * work[j];
+      at(i, k) = (std::fabs(d) > 0.0) ? s / d : s;
+    }
+  }
+  for (int i = 0; i < n; ++i) x[i] = b[i];
+  for (int k = 0; k < n; ++k) std::swap(x[k], x[perm[k]]);
+  for (int i = 0; i < n; ++i) {
+    double s = x[i];
+    for (int j = 0; j < i; ++j) s -= at(i, j) * x[j];
+    x[i] = s;
+  }
+  const double tol = 1.0 / std::numeric_limits<double>::max();
+  for (int i = 0; i < n; ++i) x[i] = (std::fabs(at(i, i)) > tol) ? x[i] / at(i, i) : 0.0;
+  for (int i = n - 1; i >= 0; --i) {
+    double s = x[i];
+    for (int j = i + 1; j < n; ++j) s -= at(j, i) * x[j];
+    x[i] = s;
+  }
+  for (int k = n - 1; k >= 0; --k) std::swap(x[k], x[perm[k]]);
+}
+
+// R <- R * Exp(dphi), column-major 3x3 in/out; Rodrigues with the reference's 1e-11 cut-off (tools.hpp:51-66).
+inline void right_multiply_exp(const double* Rin, const double* dphi, double* Rout) {
+  const double th = std::sqrt(dphi[0] * dphi[0] + dphi[1] * dphi[1] + dphi[2] * dphi[2]);
+  double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // row-major Exp(dphi)
+  if (th >= 1e-11) {
+    const double k0 = dphi[0] / th, k1 = dphi[1] / th, k2 = dphi[2] / th;
+    const double K[9] = {0, -k2, k1, k2, 0, -k0, -k1, k0, 0};
+    double KK[9];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) KK[3 * r + c] = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
+    const double s = std::sin(th), c1 = 1.0 - std::cos(th);
+    for (int q = 0; q < 9; q++) E[q] += s * K[q] + c1 * KK[q];
+  }
+  double out[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      // (R E)(r,c) with R column-major: R(r,k) = Rin[3k + r]
+      out[3 * c + r] = Rin[r] * E[c] + Rin[3 + r] * E[3 + c] + Rin[6 + r] * E[6 + c];
+    }
+  std::memcpy(Rout, out, sizeof out);
+}
+
+// One damped step of voxel_map.hpp:397-410 on the LiDAR-only (6W) system.
+//   Hess (n x n col-major) and JacT (n) are modified in place (gauge fix), exactly like the reference's locals.
+//   Rp -> Rp_trial = Rp (+) dxi;  returns q1 = 0.5 dxi . (u D dxi - JacT).
+struct LMWorkspace {
+  std::vector<double> A, rhs, dxi, work;
+  std::vector<int> perm;
+  void resize(int n) { A.resize((size_t)n * n); rhs.resize(n); dxi.resize(n); work.resize(n); perm.resize(n); }
+};
+
+inline double lm_damped_step(int W, double* Hess, double* JacT, double u, const double* Rp, double* Rp_trial, LMWorkspace& ws) {
+  const int n = 6 * W;
+  ws.resize(n);
+  // gauge: frame 0 fixed (voxel_map.hpp:397-400)
+  for (int c = 0; c < n; c++)
+    for (int r = 0; r < 6; r++) { Hess[(size_t)c * n + r] = 0.0; Hess[(size_t)r * n + c] = 0.0; }
+  for (int r = 0; r < 6; r++) { Hess[(size_t)r * n + r] = 1.0; JacT[r] = 0.0; }
+  // (Hess + u D) dxi = -JacT,  D = diag(Hess)  (voxel_map.hpp:402-403)
+  std::memcpy(ws.A.data(), Hess, sizeof(double) * n * n);
+  for (int r = 0; r < n; r++) ws.A[(size_t)r * n + r] = Hess[(size_t)r * n + r] + u * Hess[(size_t)r * n + r];
+  for (int r = 0; r < n; r++) ws.rhs[r] = -JacT[r];
+  ldlt_solve_inplace(n, ws.A.data(), ws.rhs.data(), ws.dxi.data(), ws.perm.data(), ws.work.data());
+  // trial state (voxel_map.hpp:405-409)
+  for (int j = 0; j < W; j++) {
+    right_multiply_exp(Rp + 12 * j, ws.dxi.data() + 6 * j, Rp_trial + 12 * j);
+    for (int k = 0; k < 3; k++) Rp_trial[12 * j + 9 + k] = Rp[12 * j + 9 + k] + ws.dxi[6 * j + 3 + k];
+  }
+  double q1 = 0.0;
+  for (int r = 0; r < n; r++) q1 += ws.dxi[r] * (u * Hess[(size_t)r * n + r] * ws.dxi[r] - JacT[r]);
+  return 0.5 * q1;
+}
+
+// Damping schedule of voxel_map.hpp:418-435.  Returns true if the step is accepted.
+inline bool lm_update_damping(double residual1, double residual2, double q1, double& u, double& v) {
+  double q = residual1 - residual2;
+  if (q > 0) {
+    const double one_three = 1.0 / 3;
+    q = q / q1;
+    v = 2;
+    q = 1 - std::pow(2 * q - 1, 3);
+    u *= (q < one_three ? one_three : q);
+    return true;
+  }
+  u = u * v;
+  v = 2 * v;
+  return false;
+}
+
+}  // namespace vxh

@@ -1,0 +1,263 @@
+// Per-voxel / per-(voxel,frame) arithmetic of the BA hot path, shared by the HIP kernels.
+// Everything here is branch-light straight-line fp64 written for one GPU lane; the functions are
+// also compilable by a host C++ compiler (VX_HD expands to nothing) so tests can check the device
+// arithmetic term by term on the CPU -- the shipped path is the HIP kernels only.
+//
+// Mathematics: SURVEY.md Appendix A (restating VoxelSLAM/src/voxel_map.hpp:132-279 and
+// tools.hpp:326-363).  Conventions: R row-major r[3*row+col]; symmetric 3x3 as
+// [xx xy xz yy yz zz]; cluster = (P sym6, v3, n).
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define VX_HD __host__ __device__ __forceinline__
+#else
+#define VX_HD inline
+#endif
+
+namespace vxm {
+
+// ---------------------------------------------------------------------------------------------
+// K2: world transform of one body-frame cluster under pose (R, p), accumulated into S.
+//   v' = R v + n p ;  P' = R P R^T + (R v) p^T + p (R v)^T + n p p^T        (tools.hpp:357-363)
+// ---------------------------------------------------------------------------------------------
+VX_HD void transform_accumulate(const double P[6], const double v[3], double n, const double R[9], const double p[3],
+                                double SP[6], double Sv[3], double& SN) {
+  // RP = R * P (3x3, P symmetric)
+  const double Pm[9] = {P[0], P[1], P[2], P[1], P[3], P[4], P[2], P[4], P[5]};
+  double RP[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) RP[3 * i + j] = R[3 * i] * Pm[j] + R[3 * i + 1] * Pm[3 + j] + R[3 * i + 2] * Pm[6 + j];
+  double Rv[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) Rv[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
+  const double np[3] = {n * p[0], n * p[1], n * p[2]};
+  // symmetric entries (i <= j) of  RP R^T + Rv p^T + p Rv^T + n p p^T
+  const int I[6] = {0, 0, 0, 1, 1, 2}, J[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const int i = I[k], j = J[k];
+    double rprt = RP[3 * i] * R[3 * j] + RP[3 * i + 1] * R[3 * j + 1] + RP[3 * i + 2] * R[3 * j + 2];
+    SP[k] += ((rprt + Rv[i] * p[j]) + p[i] * Rv[j]) + np[i] * p[j];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) Sv[i] += Rv[i] + np[i];
+  SN += n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations (fp64, relative accuracy), ascending
+// eigenvalues, unit eigenvectors in the columns of U (row-major U[3*row+col]).  Replaces Eigen's
+// SelfAdjointEigenSolver<Matrix3d> at voxel_map.hpp:267,1161,1242; eigenvalues agree to round-off, the
+// eigenvector SIGN is implementation-defined in both (every use on the path is quadratic in u).
+// ---------------------------------------------------------------------------------------------
+VX_HD void jacobi_rotate(double& app, double& aqq, double& apq, double& arp, double& arq, double* U, int p, int q, bool late) {
+  const double g = 100.0 * fabs(apq);
+  if (late && (fabs(app) + g == fabs(app)) && (fabs(aqq) + g == fabs(aqq))) {
+    apq = 0.0;
+    return;
+  }
+  if (apq == 0.0) return;
+  const double h = aqq - app;
+  double t;
+  if (fabs(h) + g == fabs(h)) {
+    t = apq / h;
+  } else {
+    const double theta = 0.5 * h / apq;
+    t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+    if (theta < 0.0) t = -t;
+  }
+  const double c = 1.0 / sqrt(1.0 + t * t);
+  const double s = t * c;
+  const double tau = s / (1.0 + c);
+  const double hh = t * apq;
+  app -= hh;
+  aqq += hh;
+  apq = 0.0;
+  const double g1 = arp, h1 = arq;
+  arp = g1 - s * (h1 + g1 * tau);
+  arq = h1 + s * (g1 - h1 * tau);
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const double up = U[3 * r + p], uq = U[3 * r + q];
+    U[3 * r + p] = up - s * (uq + up * tau);
+    U[3 * r + q] = uq + s * (up - uq * tau);
+  }
+}
+
+VX_HD void eig_sym3(const double Cin[6], double lam[3], double U[9]) {
+  double a00 = Cin[0], a01 = Cin[1], a02 = Cin[2], a11 = Cin[3], a12 = Cin[4], a22 = Cin[5];
+  U[0] = 1; U[1] = 0; U[2] = 0; U[3] = 0; U[4] = 1; U[5] = 0; U[6] = 0; U[7] = 0; U[8] = 1;
+  for (int sweep = 0; sweep < 12; sweep++) {
+    const double sm = fabs(a01) + fabs(a02) + fabs(a12);
+    if (sm == 0.0) break;
+    const bool late = sweep >= 3;
+    jacobi_rotate(a00, a11, a01, a02, a12, U, 0, 1, late);  // (p,q)=(0,1), other index r=2: a_rp=a02, a_rq=a12
+    jacobi_rotate(a00, a22, a02, a01, a12, U, 0, 2, late);  // (0,2), r=1: a_rp=a01, a_rq=a12
+    jacobi_rotate(a11, a22, a12, a01, a02, U, 1, 2, late);  // (1,2), r=0: a_rp=a01, a_rq=a02
+  }
+  // ascending sort (3-element network) with column swaps
+  double l0 = a00, l1 = a11, l2 = a22;
+#define VXM_SWAPCOL(x, y, cx, cy)                                   \
+  if (y < x) {                                                      \
+    double tl = x; x = y; y = tl;                                   \
+    for (int r = 0; r < 3; r++) { double tu = U[3 * r + cx]; U[3 * r + cx] = U[3 * r + cy]; U[3 * r + cy] = tu; } \
+  }
+  VXM_SWAPCOL(l0, l1, 0, 1)
+  VXM_SWAPCOL(l1, l2, 1, 2)
+  VXM_SWAPCOL(l0, l1, 0, 1)
+#undef VXM_SWAPCOL
+  lam[0] = l0; lam[1] = l1; lam[2] = l2;
+}
+
+// Covariance of a merged cluster exactly as the reference forms it (voxel_map.hpp:264-267,
+// tools.hpp:333-337):  C = P / N - vbar vbar^T,  vbar = v / N.
+VX_HD void cluster_cov(const double P[6], const double v[3], double N, double C[6]) {
+  const double vb[3] = {v[0] / N, v[1] / N, v[2] / N};
+  C[0] = P[0] / N - vb[0] * vb[0];
+  C[1] = P[1] / N - vb[0] * vb[1];
+  C[2] = P[2] / N - vb[0] * vb[2];
+  C[3] = P[3] / N - vb[1] * vb[1];
+  C[4] = P[4] / N - vb[1] * vb[2];
+  C[5] = P[5] / N - vb[2] * vb[2];
+}
+
+// s_k = sqrt(2 / (lambda_k - lambda_0)), k = 1,2: the scale that turns A^T M A (M = sum 2/(l0-lk) u_k u_k^T,
+// voxel_map.hpp:172-174) into -G^T G.
+VX_HD void gap_scales(const double lam[3], double& s1, double& s2) {
+  s1 = sqrt(2.0 / (lam[1] - lam[0]));
+  s2 = sqrt(2.0 / (lam[2] - lam[0]));
+}
+
+VX_HD void cross3(const double a[3], const double b[3], double o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+VX_HD double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// ---------------------------------------------------------------------------------------------
+// K3 per-(voxel a, frame i) block.  With the cached u = u_0, u_1, u_2, s_1, s_2, vbar, 1/N, coe:
+//   rows[0][0..5] = sqrt(coe) s_1 u_1^T A_i          (G row 0, columns 6i..6i+5)
+//   rows[1][0..5] = sqrt(coe) s_2 u_2^T A_i          (G row 1)
+//   rows[2][0..5] = sqrt(coe) (sqrt2 / N) [w_i ; n_i u]   (z row)
+//   acc[0..5]    += coe * g_i,  g_i = A_i^T u         (JacT block,  voxel_map.hpp:202-203)
+//   acc[6..11]   += coe * Drr (sym6), acc[12..20] += coe * Drt (3x3 row-major), acc[21..26] += coe * Dtt (sym6)
+// so that  H = -(sum_a rows^T rows) + blockdiag_i(D_i)   reproduces voxel_map.hpp:176-232.
+// A_i = (1/N)[ (R P + t v^T) hat(r) - R c1 | c2 u^T + (c2.u) I ],  r = R^T u, t = p - vbar,
+// c1 = hat(P r) + hat(v)(u.t), c2 = R v + n t, w = v x r.
+// Row vectors are evaluated without forming A_i:  y^T A_L N = m x r - q x Pr - (u.t) q x v  with
+// q = R^T y, m = P q + (y.t) v;   y^T A_R N = (y.c2) u^T + (c2.u) y^T.
+// ---------------------------------------------------------------------------------------------
+struct VoxelCache {
+  double u0[3], u1[3], u2[3];
+  double s1, s2;     // gap scales
+  double vbar[3];
+  double invN;
+  double coe;
+};
+
+VX_HD void k3_entry(const double P[6], const double v[3], double n, const double R[9], const double p[3],
+                    const VoxelCache& vc, double rows[3][6], double acc[27]) {
+  const double* u = vc.u0;
+  const double invN = vc.invN;
+  const double sc = sqrt(vc.coe);
+  // r = R^T u, t = p - vbar
+  double r[3], t[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) r[j] = R[j] * u[0] + R[3 + j] * u[1] + R[6 + j] * u[2];
+#pragma unroll
+  for (int j = 0; j < 3; j++) t[j] = p[j] - vc.vbar[j];
+  const double ut = dot3(u, t);
+  double Pr[3] = {P[0] * r[0] + P[1] * r[1] + P[2] * r[2], P[1] * r[0] + P[3] * r[1] + P[4] * r[2],
+                  P[2] * r[0] + P[4] * r[1] + P[5] * r[2]};
+  double w[3];
+  cross3(v, r, w);
+  double c2[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) c2[i] = (R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2]) + n * t[i];
+  const double c2u = dot3(c2, u);
+
+  // gradient block g = A^T u = (2/N) [ Pr x r + ut w ; c2u u ]
+  double prxr[3];
+  cross3(Pr, r, prxr);
+  const double two_invN = 2.0 * invN;
+  const double cg = vc.coe * two_invN;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    acc[j] += cg * (prxr[j] + ut * w[j]);
+    acc[3 + j] += cg * c2u * u[j];
+  }
+
+  // G rows for y = u1, u2
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const double* y = (k == 0) ? vc.u1 : vc.u2;
+    const double sk = ((k == 0) ? vc.s1 : vc.s2) * invN * sc;
+    double q[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) q[j] = R[j] * y[0] + R[3 + j] * y[1] + R[6 + j] * y[2];
+    const double yt = dot3(y, t);
+    double m[3] = {P[0] * q[0] + P[1] * q[1] + P[2] * q[2] + yt * v[0], P[1] * q[0] + P[3] * q[1] + P[4] * q[2] + yt * v[1],
+                   P[2] * q[0] + P[4] * q[1] + P[5] * q[2] + yt * v[2]};
+    double mxr[3], qxPr[3], qxv[3];
+    cross3(m, r, mxr);
+    cross3(q, Pr, qxPr);
+    cross3(q, v, qxv);
+    const double yc2 = dot3(y, c2);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      rows[k][j] = sk * ((mxr[j] - qxPr[j]) - ut * qxv[j]);
+      rows[k][3 + j] = sk * (yc2 * u[j] + c2u * y[j]);
+    }
+  }
+  // z row
+  const double sz = 1.4142135623730951 * invN * sc;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    rows[2][j] = sz * w[j];
+    rows[2][3 + j] = sz * n * u[j];
+  }
+
+  // block-diagonal correction D_i (symmetric):
+  //  Drr = (2/N) [ sym(hat(Pr) hat(r)) + ut sym(hat(v) hat(r)) - hat(r) P hat(r) ],
+  //        sym(hat(a) hat(b)) = (b a^T + a b^T)/2 - (a.b) I
+  //  Drt = (2/N) w u^T ;  Dtt = (2 n / N) u u^T
+  const double Prr = dot3(Pr, r), vr = dot3(v, r);
+  // X = P hat(r): columns X0 = r2 P(:,1) - r1 P(:,2), X1 = -r2 P(:,0) + r0 P(:,2), X2 = r1 P(:,0) - r0 P(:,1)
+  const double Pc0[3] = {P[0], P[1], P[2]}, Pc1[3] = {P[1], P[3], P[4]}, Pc2[3] = {P[2], P[4], P[5]};
+  double X0[3], X1[3], X2[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    X0[i] = r[2] * Pc1[i] - r[1] * Pc2[i];
+    X1[i] = r[0] * Pc2[i] - r[2] * Pc0[i];
+    X2[i] = r[1] * Pc0[i] - r[0] * Pc1[i];
+  }
+  double S0[3], S1[3], S2[3];  // columns of hat(r) X
+  cross3(r, X0, S0);
+  cross3(r, X1, S1);
+  cross3(r, X2, S2);
+  const double cD = vc.coe * two_invN;
+  // sym6 order xx xy xz yy yz zz
+  acc[6] += cD * ((r[0] * Pr[0] - Prr) + ut * (r[0] * v[0] - vr) - S0[0]);
+  acc[7] += cD * (0.5 * (r[0] * Pr[1] + Pr[0] * r[1]) + ut * 0.5 * (r[0] * v[1] + v[0] * r[1]) - 0.5 * (S1[0] + S0[1]));
+  acc[8] += cD * (0.5 * (r[0] * Pr[2] + Pr[0] * r[2]) + ut * 0.5 * (r[0] * v[2] + v[0] * r[2]) - 0.5 * (S2[0] + S0[2]));
+  acc[9] += cD * ((r[1] * Pr[1] - Prr) + ut * (r[1] * v[1] - vr) - S1[1]);
+  acc[10] += cD * (0.5 * (r[1] * Pr[2] + Pr[1] * r[2]) + ut * 0.5 * (r[1] * v[2] + v[1] * r[2]) - 0.5 * (S2[1] + S1[2]));
+  acc[11] += cD * ((r[2] * Pr[2] - Prr) + ut * (r[2] * v[2] - vr) - S2[2]);
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) acc[12 + 3 * i + j] += cD * w[i] * u[j];
+  const double cT = cD * n;
+  acc[21] += cT * u[0] * u[0];
+  acc[22] += cT * u[0] * u[1];
+  acc[23] += cT * u[0] * u[2];
+  acc[24] += cT * u[1] * u[1];
+  acc[25] += cT * u[1] * u[2];
+  acc[26] += cT * u[2] * u[2];
+}
+
+}  // namespace vxm

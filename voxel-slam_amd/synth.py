@@ -62,7 +62,7 @@ def clusters_from_points(xyz: np.ndarray, cell_ptr: np.ndarray) -> np.ndarray:
     feats = np.stack([x * x, x * y, x * z, y * y, y * z, z * z, x, y, z, np.ones_like(x)], axis=1)
     cs = np.zeros((xyz.shape[0] + 1, 10))
     np.cumsum(feats, axis=0, out=cs[1:])
-    # cumulative sums lose a few ulps; fine for an input generator (the oracle/K1 parity tests use their own sums)
+    # cumulative sums lose a few ulps; fine for an input generator (the K1 parity tests use their own sums)
     return cs[cell_ptr[1:]] - cs[cell_ptr[:-1]] if n_cells else np.zeros((0, 10))
 
 
@@ -85,10 +85,12 @@ class Scene:
 
 
 def make_scene(win_size=5, pts_per_scan=20_000, n_voxels=5_000, p_obs=1.0, fix_frac=0.0, noise=0.02,
-               rot_sigma_deg=0.05, trans_sigma=0.02, seed=MASTER_SEED, exact_clusters=True) -> Scene:
+               rot_sigma_deg=0.05, trans_sigma=0.02, seed=MASTER_SEED, exact_clusters=True, pose_seed=None) -> Scene:
     """Build one window.  ``exact_clusters`` sums clusters per cell with np.add.reduceat
-    (sequential per-cell order) instead of the cumulative-sum difference."""
+    (sequential per-cell order) instead of the cumulative-sum difference.  ``pose_seed`` draws the initial-guess
+    perturbation from its own stream so voxel shards generated with different ``seed`` share one window."""
     rng = np.random.Generator(np.random.PCG64(seed))
+    prng = np.random.Generator(np.random.PCG64([seed if pose_seed is None else pose_seed, 7919]))
     W, V = win_size, n_voxels
 
     # occupied cells in a slab around the trajectory (surfaces: ground/walls within a few metres of height)
@@ -120,13 +122,23 @@ def make_scene(win_size=5, pts_per_scan=20_000, n_voxels=5_000, p_obs=1.0, fix_f
     ps = np.stack([np.array([0.5 * i, 0.1 * np.sin(i), 0.0]) for i in range(W)])
     Rs_init, ps_init = Rs.copy(), ps.copy()
     for i in range(1, W):
-        Rs_init[i] = Rs[i] @ rodrigues(rng.normal(0, np.deg2rad(rot_sigma_deg), size=3))
-        ps_init[i] = ps[i] + rng.normal(0, trans_sigma, size=3)
+        Rs_init[i] = Rs[i] @ rodrigues(prng.normal(0, np.deg2rad(rot_sigma_deg), size=3))
+        ps_init[i] = ps[i] + prng.normal(0, trans_sigma, size=3)
 
-    # per-frame observation pattern and point counts: every observed cell gets >= 1 point
+    # per-frame observation pattern and point counts: every observed cell gets >= 1 point, and every voxel is
+    # seen from >= min(2, W) frames (the reference drops voxels with too few points / observers:
+    # voxel_map.hpp:1155, loop_refine.hpp:371-376)
+    if p_obs < 1.0:
+        seen_mask = rng.uniform(size=(W, V)) < p_obs
+        need = min(2, W)
+        for a in np.nonzero(seen_mask.sum(axis=0) < need)[0]:
+            missing = np.nonzero(~seen_mask[:, a])[0]
+            seen_mask[rng.choice(missing, size=need - int(seen_mask[:, a].sum()), replace=False), a] = True
+    else:
+        seen_mask = np.ones((W, V), dtype=bool)
     counts = np.zeros((W, V), dtype=np.int64)
     for i in range(W):
-        seen = np.nonzero(rng.uniform(size=V) < p_obs)[0] if p_obs < 1.0 else np.arange(V)
+        seen = np.nonzero(seen_mask[i])[0]
         if seen.size == 0:
             continue
         extra = max(0, pts_per_scan - seen.size)

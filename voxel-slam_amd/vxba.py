@@ -1,0 +1,310 @@
+"""ctypes binding of ``libvxba.so`` (include/vxba.h) with the reference's own names.
+
+``LidarFactor`` mirrors ``class LidarFactor`` (VoxelSLAM/src/voxel_map.hpp:109-290) and
+``Lidar_BA_Optimizer`` mirrors voxel_map.hpp:293-444, so parity tests read like calls into
+the reference.  Everything numeric happens in the HIP kernels behind the C ABI; this module
+holds no arithmetic and has NO CPU fallback -- a missing library or GPU raises ``VxbaError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvxba.so")
+MAX_WIN = 10
+TRACE_COLS = 8
+
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+# every symbol include/vxba.h declares (the CPU test suite checks the library exports all of them)
+EXPORTS = [
+    "vxba_create", "vxba_destroy", "vxba_clear", "vxba_set_win_size", "vxba_win_size", "vxba_size", "vxba_set_stream",
+    "vxba_reserve", "vxba_last_error", "vxba_push_voxels", "vxba_push_points", "vxba_read_clusters", "vxba_acc_evaluate2",
+    "vxba_evaluate_only_residual", "vxba_acc_evaluate2_device", "vxba_evaluate_only_residual_device", "vxba_packed_len",
+    "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_set_allreduce",
+    "vxba_use_external_buffers", "vxba_damping_iter", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe",
+]
+
+_ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
+
+
+class VxbaError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """Load libvxba.so; fails loudly if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise VxbaError(f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')")
+    L = C.CDLL(path)
+    vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+    L.vxba_create.argtypes = [ci, ci, C.POINTER(vp)]
+    L.vxba_destroy.argtypes = [vp]
+    L.vxba_clear.argtypes = [vp]
+    L.vxba_set_win_size.argtypes = [vp, ci]
+    L.vxba_win_size.argtypes = [vp]
+    L.vxba_size.argtypes = [vp]
+    L.vxba_set_stream.argtypes = [vp, vp]
+    L.vxba_reserve.argtypes = [vp, ci]
+    L.vxba_last_error.argtypes = [vp]
+    L.vxba_last_error.restype = C.c_char_p
+    L.vxba_push_voxels.argtypes = [vp, ci, _f64p, _f64p, _f64p, vp, vp, vp]
+    L.vxba_push_points.argtypes = [vp, ci, C.c_int64, _f64p, _i64p, vp, vp]
+    L.vxba_read_clusters.argtypes = [vp, ci, ci, _f64p]
+    L.vxba_acc_evaluate2.argtypes = [vp, _f64p, ci, ci, _f64p, _f64p, C.POINTER(cd)]
+    L.vxba_evaluate_only_residual.argtypes = [vp, _f64p, ci, ci, C.POINTER(cd)]
+    L.vxba_acc_evaluate2_device.argtypes = [vp, _f64p, ci, ci, vp]
+    L.vxba_evaluate_only_residual_device.argtypes = [vp, _f64p, ci, ci, vp]
+    L.vxba_packed_len.argtypes = [vp]
+    L.vxba_packed_len.restype = C.c_size_t
+    L.vxba_read_cache.argtypes = [vp, ci, ci, _f64p, _f64p, _f64p]
+    L.vxba_snapshot_cache.argtypes = [vp]
+    L.vxba_restore_cache.argtypes = [vp]
+    L.vxba_plane_fit.argtypes = [ci, C.c_int64, _f64p, _f64p, _f64p]
+    L.vxba_set_allreduce.argtypes = [vp, _ALLREDUCE_FN, vp]
+    L.vxba_use_external_buffers.argtypes = [vp, vp, vp]
+    L.vxba_damping_iter.argtypes = [vp, _f64p, ci, _f64p, _f64p, _f64p, C.POINTER(ci), C.POINTER(ci)]
+    L.vxba_lm_steps.argtypes = [vp, _f64p, ci, ci, _f64p, _f64p]
+    L.vxba_set_profiling.argtypes = [vp, ci]
+    L.vxba_get_kernel_times.argtypes = [vp, _f64p, _i64p, ci]
+    L.vxba_algorithmic_bytes.argtypes = [vp, _f64p]
+    L.vxba_nnz.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.vxba_debug_mfma_probe.argtypes = [ci, _f64p, _f64p, _f64p]
+    _lib = L
+    return L
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _opt(a):
+    """Optional f64 array -> pointer (or NULL); returns (pointer, keepalive)."""
+    if a is None:
+        return None, None
+    arr = _c(a)
+    return arr.ctypes.data_as(C.c_void_p), arr
+
+
+class LidarFactor:
+    """The LiDAR BA factor on one MI355X (reference: voxel_map.hpp:109-290)."""
+
+    def __init__(self, win_size: int, device: int = 0):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        rc = self._L.vxba_create(int(win_size), int(device), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise VxbaError(f"vxba_create(win_size={win_size}, device={device}) failed: {_ERRNAMES.get(rc, rc)} "
+                            "(needs a gfx950 GPU; there is no CPU fallback)")
+        self._cb = None
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self._L.vxba_last_error(self._h)
+            raise VxbaError(f"{_ERRNAMES.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.vxba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def win_size(self) -> int:
+        return self._L.vxba_win_size(self._h)
+
+    @win_size.setter
+    def win_size(self, w: int):
+        self._chk(self._L.vxba_set_win_size(self._h, int(w)))
+
+    def size(self) -> int:
+        """``plvec_voxels.size()``"""
+        return self._L.vxba_size(self._h)
+
+    def __len__(self):
+        return self.size()
+
+    def set_stream(self, hip_stream: int | None):
+        self._chk(self._L.vxba_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def reserve(self, n):
+        self._chk(self._L.vxba_reserve(self._h, int(n)))
+
+    # -- construction ---------------------------------------------------------------------------
+    def push_voxel(self, vec_orig, fix, coe, eig_value, eig_vector, pcr_add):
+        """Single-voxel form of voxel_map.hpp:122-130 (all arguments in packed format)."""
+        self.push_voxels(np.asarray(vec_orig)[None], np.asarray(fix)[None], [coe], np.asarray(eig_value)[None],
+                         np.asarray(eig_vector).reshape(1, 9), np.asarray(pcr_add)[None])
+
+    def push_voxels(self, clusters, fix, coe, eig_val=None, eig_vec=None, merged=None):
+        clusters = _c(clusters)
+        n = clusters.shape[0]
+        if clusters.shape != (n, self.win_size, 10):
+            raise VxbaError(f"clusters must be (n, {self.win_size}, 10)")
+        pv, kv = _opt(eig_val)
+        pu, ku = _opt(eig_vec)
+        pm, km = _opt(merged)
+        self._chk(self._L.vxba_push_voxels(self._h, n, clusters, _c(fix), _c(coe), pv, pu, pm))
+
+    def push_points(self, n_voxels, xyz_body, cell_ptr, fix=None, coe=None):
+        """K1: build the clusters of ``n_voxels`` voxels on the GPU from bucketed body-frame points."""
+        xyz = _c(xyz_body).reshape(-1, 3)
+        ptr = np.ascontiguousarray(cell_ptr, dtype=np.int64)
+        pf, kf = _opt(fix)
+        pc, kc = _opt(coe)
+        self._chk(self._L.vxba_push_points(self._h, int(n_voxels), xyz.shape[0], xyz, ptr, pf, pc))
+
+    def read_clusters(self, head=0, end=None):
+        end = self.size() if end is None else end
+        out = np.zeros((end - head, self.win_size, 10))
+        self._chk(self._L.vxba_read_clusters(self._h, head, end, out))
+        return out
+
+    def clear(self):
+        self._chk(self._L.vxba_clear(self._h))
+
+    # -- sweeps ---------------------------------------------------------------------------------
+    def acc_evaluate2(self, xs, head=0, end=None):
+        """Returns (Hess[r, c], JacT, residual) for voxels [head, end) under packed poses ``xs`` (W, 12)."""
+        end = self.size() if end is None else end
+        n = 6 * self.win_size
+        H = np.zeros((n, n)); J = np.zeros(n); r = C.c_double(0)
+        self._chk(self._L.vxba_acc_evaluate2(self._h, _c(xs), head, end, H, J, C.byref(r)))
+        return H.T.copy(), J, r.value   # column-major on the wire
+
+    def evaluate_only_residual(self, xs, head=0, end=None):
+        end = self.size() if end is None else end
+        r = C.c_double(0)
+        self._chk(self._L.vxba_evaluate_only_residual(self._h, _c(xs), head, end, C.byref(r)))
+        return r.value
+
+    def packed_len(self) -> int:
+        return self._L.vxba_packed_len(self._h)
+
+    def acc_evaluate2_device(self, xs, d_out_ptr: int, head=0, end=None):
+        end = self.size() if end is None else end
+        self._chk(self._L.vxba_acc_evaluate2_device(self._h, _c(xs), head, end, C.c_void_p(d_out_ptr)))
+
+    def evaluate_only_residual_device(self, xs, d_out_ptr: int, head=0, end=None):
+        end = self.size() if end is None else end
+        self._chk(self._L.vxba_evaluate_only_residual_device(self._h, _c(xs), head, end, C.c_void_p(d_out_ptr)))
+
+    def read_cache(self, head=0, end=None):
+        """(eig_values (n,3), eig_vectors (n,9 col-major), pcr_adds (n,10)) of voxels [head, end)."""
+        end = self.size() if end is None else end
+        n = end - head
+        ev = np.zeros((n, 3)); U = np.zeros((n, 9)); m = np.zeros((n, 10))
+        self._chk(self._L.vxba_read_cache(self._h, head, end, ev, U, m))
+        return ev, U, m
+
+    def snapshot_cache(self):
+        self._chk(self._L.vxba_snapshot_cache(self._h))
+
+    def restore_cache(self):
+        self._chk(self._L.vxba_restore_cache(self._h))
+
+    # -- multi-GPU hook -------------------------------------------------------------------------
+    def set_allreduce(self, fn):
+        """``fn(device_ptr: int, count: int, hip_stream: int) -> None`` sums f64 across voxel shards in place."""
+        if fn is None:
+            self._cb = None
+            self._chk(self._L.vxba_set_allreduce(self._h, C.cast(None, _ALLREDUCE_FN), None))
+            return
+
+        def tramp(ctx, ptr, count, stream):
+            try:
+                fn(int(ptr or 0), int(count), int(stream or 0))
+                return 0
+            except Exception:  # noqa: BLE001 - must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = _ALLREDUCE_FN(tramp)
+        self._chk(self._L.vxba_set_allreduce(self._h, self._cb, None))
+
+    def use_external_buffers(self, d_packed_ptr: int | None, d_scalar_ptr: int | None):
+        self._chk(self._L.vxba_use_external_buffers(self._h, C.c_void_p(d_packed_ptr or 0), C.c_void_p(d_scalar_ptr or 0)))
+
+    # -- measurement ----------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        self._chk(self._L.vxba_set_profiling(self._h, int(bool(on))))
+
+    def kernel_times(self, reset=False):
+        ms = np.zeros(4); calls = np.zeros(4, dtype=np.int64)
+        self._chk(self._L.vxba_get_kernel_times(self._h, ms, calls, int(reset)))
+        names = ("k3_hessian", "k2_residual", "k3_finalize", "k1_build")
+        return {k: dict(ms_sum=float(ms[i]), calls=int(calls[i])) for i, k in enumerate(names)}
+
+    def algorithmic_bytes(self):
+        b = np.zeros(2)
+        self._chk(self._L.vxba_algorithmic_bytes(self._h, b))
+        return dict(k3=float(b[0]), k2=float(b[1]))
+
+    def nnz(self) -> int:
+        v = C.c_int64(0)
+        self._chk(self._L.vxba_nnz(self._h, C.byref(v)))
+        return v.value
+
+    def lm_steps(self, xs_init, n_steps, steps_per_solve=3):
+        out = np.zeros((self.win_size, 12)); resis = np.zeros(2)
+        self._chk(self._L.vxba_lm_steps(self._h, _c(xs_init), int(n_steps), int(steps_per_solve), out, resis))
+        return out, resis
+
+
+class Lidar_BA_Optimizer:
+    """The LM shell that owns the loop (reference: voxel_map.hpp:293-444)."""
+
+    def damping_iter(self, x_stats, voxhess: LidarFactor, max_iter: int = 3):
+        """Returns dict(poses, hess, resis, trace, is_converge); ``x_stats`` (W,12) is not modified."""
+        W = voxhess.win_size
+        n = 6 * W
+        Rp = _c(x_stats).copy()
+        hess = np.zeros((n, n)); resis = np.zeros(2); trace = np.zeros((max(max_iter, 1), TRACE_COLS))
+        nt = C.c_int(0); conv = C.c_int(0)
+        voxhess._chk(voxhess._L.vxba_damping_iter(voxhess.handle, Rp, int(max_iter), hess, resis, trace, C.byref(nt), C.byref(conv)))
+        return dict(poses=Rp, hess=hess.T.copy(), resis=resis, trace=trace[: nt.value].copy(), is_converge=bool(conv.value))
+
+
+def plane_fit(clusters, device: int = 0):
+    """K4: batched eig(cluster.cov()) -> (eig_val (n,3), eig_vec (n,9 col-major))."""
+    L = load_library()
+    cl = _c(clusters).reshape(-1, 10)
+    n = cl.shape[0]
+    ev = np.zeros((n, 3)); U = np.zeros((n, 9))
+    rc = L.vxba_plane_fit(int(device), n, cl, ev, U)
+    if rc != 0:
+        raise VxbaError(f"vxba_plane_fit failed: {_ERRNAMES.get(rc, rc)}")
+    return ev, U
+
+
+def debug_mfma_probe(A, B, device: int = 0):
+    """D = A (16x4) @ B (4x16) through one f64 MFMA with the lane maps K3 assumes."""
+    L = load_library()
+    D = np.zeros((16, 16))
+    rc = L.vxba_debug_mfma_probe(int(device), _c(A).reshape(16, 4), _c(B).reshape(4, 16), D)
+    if rc != 0:
+        raise VxbaError(f"vxba_debug_mfma_probe failed: {_ERRNAMES.get(rc, rc)}")
+    return D
