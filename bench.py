@@ -97,7 +97,7 @@ def main():
     f.set_profiling(True)                                  # hipEvents around K3/K2 on the launch stream
     sync()
     t0 = time.perf_counter()
-    poses, resis = f.lm_steps(sc.poses_init, args.steps, sps)
+    poses, resis, lmstats = f.lm_steps(sc.poses_init, args.steps, sps)
     sync()
     t1 = time.perf_counter()
     f.set_profiling(False)
@@ -134,6 +134,7 @@ def main():
                 "global_iterations_per_s": args.steps / elapsed,
                 "parallelism": f"voxel-shard x{world}" + (" + RCCL all-reduce of [Hess|JacT|res]" if world > 1 else ""),
                 "final_residual": float(resis[1]),
+                "lm_steps_accepted": lmstats["accepted"], "lm_steps_rejected": lmstats["rejected"],
             },
             "roofline": {
                 "bound": "hbm",

@@ -129,12 +129,13 @@ int vxba_use_external_buffers(vxba_factor* f, double* d_packed, double* d_scalar
 int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out, double* resis_out, double* trace_out,
                       int* n_trace, int* is_converge);
 
-/* Benchmark driver: exactly n_steps LM iterations of the accepted-step path (Hessian sweep + reduction
- * [+ all-reduce] + damped solve + state update + residual sweep [+ all-reduce] + accept/reject), without the
- * early break; every `steps_per_solve` steps a new solve starts from Rp_init with u = 0.01, v = 2 and the
- * snapshot cache restored (a new window).  Rp_out (W*12) receives the poses of the last completed solve. */
+/* Benchmark driver: exactly n_steps LM iterations of damping_iter WITHOUT the early break; every `steps_per_solve`
+ * steps a new solve starts from Rp_init with u = 0.01, v = 2 and the snapshot cache restored (a new window).
+ * A rejected step behaves like the reference (no Hessian recompute on the next iteration); stats_out[3] (may be NULL)
+ * receives {iterations run, accepted steps, rejected steps}.
+ * Rp_out (W*12) receives the final poses. */
 int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_per_solve, double* Rp_out,
-                  double* last_resis);
+                  double* last_resis, int64_t* stats_out);
 
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* When on, every sweep brackets its dominant kernel with hipEvents on the launch stream. */
@@ -149,6 +150,10 @@ int vxba_nnz(vxba_factor* f, int64_t* nnz);
 /* Debug: D(16x16, row-major) = A(16x4) B(4x16) through one v_mfma_f64_16x16x4_f64 with the lane maps the Hessian
  * kernel relies on (unit-tested on the GPU so a wrong operand layout is caught in isolation). */
 int vxba_debug_mfma_probe(int device, const double* A16x4, const double* B4x16, double* D16x16);
+
+/* Debug: per-wave s_memtime stamps written by the instrumented kernel instantiations (env VXBA_DBG=1 /
+ * VXBA_K3_SGB=5); 8 slots per wave. */
+int vxba_debug_stamps(int clear, unsigned long long* out, size_t n);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 // Test harness: compiles the DEVICE arithmetic header (voxel-slam_amd/csrc/vxba_math.hpp) with the
 // host compiler and assembles Hess/JacT/residual and the K2 cache with plain loops, so the per-lane
 // math of the HIP kernels can be checked against the oracle without a GPU.  Not part of the product.
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -60,6 +61,7 @@ void vxmh_k3(int V, int W, const double* clusters, const double* coe, const doub
     vc.invN = 1.0 / merged[10 * a + 9];
     for (int k = 0; k < 3; k++) vc.vbar[k] = merged[10 * a + 6 + k] * vc.invN;
     vc.coe = coe[a];
+    vc.sc = std::sqrt(coe[a]);
     std::vector<double> B((size_t)3 * n, 0.0);
     for (int i = 0; i < W; i++) {
       const double* c = clusters + ((size_t)a * W + i) * 10;

@@ -225,7 +225,8 @@ def test_lm_steps_bench_driver_converges_like_damping_iter(vx):
     sc = synth.make_scene(win_size=10, pts_per_scan=20000, n_voxels=2000, seed=81)
     fo, fg = seeded_pair(vx, sc)
     fg.snapshot_cache()
-    poses, resis = fg.lm_steps(sc.poses_init, 6, 3)       # two solves of three iterations from the same start
+    poses, resis, st = fg.lm_steps(sc.poses_init, 6, 3)   # two solves of three iterations from the same start
+    assert st["iters"] == 6 and st["accepted"] + st["rejected"] == 6
     ref = fo.damping_iter(sc.poses_init, max_iter=3, thd_num=2)
     if np.all(ref["trace"][:, 6] == 1) and ref["trace"].shape[0] == 3:
         et, er = synth.pose_errors(poses, ref["poses"])

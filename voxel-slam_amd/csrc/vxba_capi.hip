@@ -17,8 +17,8 @@ using vxk::PoseArg;
 
 namespace {
 
-constexpr int N_META_PLANES = 10 + 1 + 3 + 9 + 10 + 2;  // fix, coe, eigval, eigvec, merged, aux
-constexpr int N_CACHE_PLANES = 3 + 9 + 10 + 2;          // eigval, eigvec, merged, aux (contiguous at the tail)
+constexpr int N_META_PLANES = 10 + 1 + 3 + 9 + 10 + 4;  // fix, coe, eigval, eigvec, merged, aux
+constexpr int N_CACHE_PLANES = 3 + 9 + 10 + 4;          // eigval, eigvec, merged, aux (contiguous at the tail)
 
 struct EventPair { hipEvent_t a, b; int kind; };
 
@@ -31,6 +31,7 @@ struct vxba_factor {
   int cus = 0;
   hipStream_t stream = nullptr, own_stream = nullptr;
   double* planes = nullptr;      // [(10W + N_META_PLANES)][VS]
+  double* clb = nullptr;         // batch-major copy of the clusters for the Hessian sweep
   double* snapshot = nullptr;    // [N_CACHE_PLANES][snapshot_vs]
   int snapshot_vs = 0, snapshot_v = 0;
   double* staging = nullptr;     // device scratch for uploads / read-backs
@@ -46,6 +47,8 @@ struct vxba_factor {
   unsigned long long* d_count = nullptr;
   double* h_packed = nullptr;    // pinned
   double* h_scalar = nullptr;    // pinned
+  vxk::LMState* d_lm = nullptr;  // device-resident LM shell state
+  vxk::LMState* h_lm = nullptr;  // pinned read-back copy
   vxba_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
   bool profiling = false;
@@ -79,6 +82,7 @@ FactorView view(const vxba_factor* f) {
   FactorView fv;
   const size_t VS = (size_t)f->VS;
   double* p = f->planes;
+  fv.clb = f->clb;
   fv.cl = p;                     p += (size_t)10 * f->W * VS;
   fv.fix = p;                    p += 10 * VS;
   fv.coe = p;                    p += VS;
@@ -109,8 +113,15 @@ int ensure_capacity(vxba_factor* f, int n_total) {
   VX_HIP(f, hipMalloc((void**)&np, bytes));
   VX_HIP(f, hipMemsetAsync(np, 0, bytes, f->stream));
   if (f->planes && f->V > 0) vxk::launch_copy_planes(f->planes, f->VS, np, want, n_planes(f), f->V, f->stream);
-  if (f->planes) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->planes)); }
+  double* nclb = nullptr;
+  const size_t clb_bytes = vxk::k3_clb_len(f->W, want) * sizeof(double);
+  VX_HIP(f, hipMalloc((void**)&nclb, clb_bytes));
+  VX_HIP(f, hipMemsetAsync(nclb, 0, clb_bytes, f->stream));
+  if (f->clb && f->V > 0)   // batches are absolute, so the old copy is a prefix of the new one
+    VX_HIP(f, hipMemcpyAsync(nclb, f->clb, vxk::k3_clb_len(f->W, f->V) * sizeof(double), hipMemcpyDeviceToDevice, f->stream));
+  if (f->planes) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->planes)); VX_HIP(f, hipFree(f->clb)); }
   f->planes = np;
+  f->clb = nclb;
   f->VS = want;
   const size_t p2 = (size_t)want / 64 + 1;
   if (p2 > f->partial2_len) {
@@ -170,27 +181,27 @@ int drain_events(vxba_factor* f) {
 }
 
 // ---- sweeps (asynchronous on f->stream; results in device memory) ----
-int sweep_hess_device(vxba_factor* f, const double* Rp, int head, int end, double* d_out) {
+// Poses come either by value (Rp, host pointer -> kernel argument) or from device memory (d_Rp, e.g. the LM state);
+// `gate` lets the GPU skip the work when the device-resident LM loop does not need it.
+int sweep_hess_device(vxba_factor* f, const double* Rp, const double* d_Rp, vxk::LMState* gate, int head, int end, double* d_out) {
   const size_t plen = vxba_packed_len(f);
   if (end == head) { VX_HIP(f, hipMemsetAsync(d_out, 0, plen * sizeof(double), f->stream)); return VXBA_OK; }
   int rc = ensure_partials3(f);
   if (rc) return rc;
   PoseArg pa;
-  fill_poses(f, Rp, pa);
+  if (Rp) fill_poses(f, Rp, pa); else std::memset(&pa, 0, sizeof pa);
   const FactorView fv = view(f);
   // one wave per batch of NV voxels; never launch more workgroups than there are batches / 4
-  const int nt = vxk::k3_num_tiles(f->W);
-  const int nvcap = nt <= 2 ? 12 : 8;
-  const int nv = std::min(64 / f->W, nvcap);
-  const int nbatches = (end - head + nv - 1) / nv;
+  const int nv = vxk::k3_nv(f->W);
+  const int nbatches = (end - 1) / nv - head / nv + 1;
   const int nblocks = std::max(1, std::min(vxk::k3_grid_blocks(f->cus), (nbatches + 3) / 4));
   {
     ScopedKernelTimer t(f, 0);
-    vxk::launch_k3_hessian(fv, pa, head, end, f->d_partial3, nblocks, f->stream);
+    vxk::launch_k3_hessian(fv, pa, d_Rp, gate, head, end, f->d_partial3, nblocks, f->stream);
   }
   {
     ScopedKernelTimer t(f, 2);
-    vxk::launch_k3_finalize(f->d_partial3, nblocks, f->W, d_out, f->stream);
+    vxk::launch_k3_finalize(f->d_partial3, nblocks, f->W, gate, d_out, f->stream);
   }
   VX_HIP(f, hipGetLastError());
   if (f->allreduce) {
@@ -199,33 +210,37 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, int head, int end, doubl
   return VXBA_OK;
 }
 
-int sweep_residual_device(vxba_factor* f, const double* Rp, int head, int end, double* d_out) {
-  if (end == head) { VX_HIP(f, hipMemsetAsync(d_out, 0, sizeof(double), f->stream)); return VXBA_OK; }
+int sweep_residual_device(vxba_factor* f, const double* Rp, const double* d_Rp, const vxk::LMState* gate, int gate_mode, int head, int end,
+                          double* d_out, int* nparts_out = nullptr) {
+  if (end == head) { if (d_out) VX_HIP(f, hipMemsetAsync(d_out, 0, sizeof(double), f->stream)); return VXBA_OK; }
   PoseArg pa;
-  fill_poses(f, Rp, pa);
+  if (Rp) fill_poses(f, Rp, pa); else std::memset(&pa, 0, sizeof pa);
   const FactorView fv = view(f);
   int nparts;
   {
     ScopedKernelTimer t(f, 1);
-    nparts = vxk::launch_k2_residual(fv, pa, head, end, f->d_partial2, f->stream);
+    nparts = vxk::launch_k2_residual(fv, pa, d_Rp, gate, gate_mode, head, end, f->d_partial2, f->stream);
   }
-  vxk::launch_sum_partials(f->d_partial2, nparts, d_out, f->stream);
-  VX_HIP(f, hipGetLastError());
-  if (f->allreduce) {
-    if (f->allreduce(f->allreduce_ctx, d_out, 1, (void*)f->stream) != 0) return fail(f, VXBA_ERR_STATE, "all-reduce hook failed");
+  if (nparts_out) *nparts_out = nparts;
+  if (d_out) {
+    vxk::launch_sum_partials(f->d_partial2, nparts, d_out, f->stream);
+    VX_HIP(f, hipGetLastError());
+    if (f->allreduce) {
+      if (f->allreduce(f->allreduce_ctx, d_out, 1, (void*)f->stream) != 0) return fail(f, VXBA_ERR_STATE, "all-reduce hook failed");
+    }
   }
   return VXBA_OK;
 }
 
 int sweep_hess_host(vxba_factor* f, const double* Rp, int head, int end) {
-  int rc = sweep_hess_device(f, Rp, head, end, f->d_packed);
+  int rc = sweep_hess_device(f, Rp, nullptr, nullptr, head, end, f->d_packed);
   if (rc) return rc;
   VX_HIP(f, hipMemcpyAsync(f->h_packed, f->d_packed, vxba_packed_len(f) * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   VX_HIP(f, hipStreamSynchronize(f->stream));
   return VXBA_OK;
 }
 int sweep_residual_host(vxba_factor* f, const double* Rp, int head, int end, double* residual) {
-  int rc = sweep_residual_device(f, Rp, head, end, f->d_scalar);
+  int rc = sweep_residual_device(f, Rp, nullptr, nullptr, 0, head, end, f->d_scalar);
   if (rc) return rc;
   VX_HIP(f, hipMemcpyAsync(f->h_scalar, f->d_scalar, sizeof(double), hipMemcpyDeviceToHost, f->stream));
   VX_HIP(f, hipStreamSynchronize(f->stream));
@@ -299,6 +314,8 @@ int vxba_create(int win_size, int device, vxba_factor** out) {
   if ((e = hipMalloc((void**)&f->d_count, sizeof(unsigned long long))) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc((void**)&f->h_packed, plen * sizeof(double), hipHostMallocDefault)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc((void**)&f->h_scalar, 2 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return bail(e);
+  if ((e = hipMalloc((void**)&f->d_lm, sizeof(vxk::LMState))) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc((void**)&f->h_lm, sizeof(vxk::LMState), hipHostMallocDefault)) != hipSuccess) return bail(e);
   *out = f;
   return VXBA_OK;
 }
@@ -309,10 +326,12 @@ int vxba_destroy(vxba_factor* f) {
   if (f->stream) hipStreamSynchronize(f->stream);
   for (auto& ep : f->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   for (auto e : f->free_events) hipEventDestroy(e);
-  hipFree(f->planes); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2);
+  hipFree(f->planes); hipFree(f->clb); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2);
   hipFree(f->own_packed); hipFree(f->own_scalar); hipFree(f->d_count);
   if (f->h_packed) hipHostFree(f->h_packed);
   if (f->h_scalar) hipHostFree(f->h_scalar);
+  hipFree(f->d_lm);
+  if (f->h_lm) hipHostFree(f->h_lm);
   if (f->own_stream) hipStreamDestroy(f->own_stream);
   delete f;
   return VXBA_OK;
@@ -331,7 +350,7 @@ int vxba_set_win_size(vxba_factor* f, int win_size) {
   if (win_size == f->W) return VXBA_OK;
   if (f->V != 0) return fail(f, VXBA_ERR_STATE, "win_size can only change on an empty factor");
   hipSetDevice(f->device);
-  if (f->planes) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->planes)); f->planes = nullptr; }
+  if (f->planes) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->planes)); VX_HIP(f, hipFree(f->clb)); f->planes = nullptr; f->clb = nullptr; }
   f->VS = 0;
   f->W = win_size;
   return VXBA_OK;
@@ -386,6 +405,7 @@ int vxba_push_voxels(vxba_factor* f, int n, const double* clusters, const double
   if (rc) return rc;
   VX_HIP(f, hipMemcpyAsync(f->staging, clusters, ncl * sizeof(double), hipMemcpyHostToDevice, f->stream));
   vxk::launch_scatter_clusters(f->staging, view(f), f->V, n, f->stream);
+  vxk::launch_build_clb(view(f), f->V, n, f->stream);
   VX_HIP(f, hipStreamSynchronize(f->stream));
   rc = append_meta(f, f->V, n, fix, coe, eig_val, eig_vec, merged);
   if (rc) return rc;
@@ -418,6 +438,7 @@ int vxba_push_points(vxba_factor* f, int n_voxels, int64_t n_points, const doubl
     ScopedKernelTimer t(f, 3);
     vxk::launch_k1_build(d_xyz, d_ptr, n_voxels, f->W, view(f), f->V, f->stream);
   }
+  vxk::launch_build_clb(view(f), f->V, n_voxels, f->stream);
   e = hipStreamSynchronize(f->stream);
   if (e == hipSuccess) e = hipGetLastError();
   cleanup();
@@ -471,7 +492,7 @@ int vxba_acc_evaluate2_device(vxba_factor* f, const double* Rp, int head, int en
   int rc = check_range(f, head, end);
   if (rc) return rc;
   hipSetDevice(f->device);
-  return sweep_hess_device(f, Rp, head, end, d_out);
+  return sweep_hess_device(f, Rp, nullptr, nullptr, head, end, d_out);
 }
 
 int vxba_evaluate_only_residual_device(vxba_factor* f, const double* Rp, int head, int end, double* d_out) {
@@ -479,7 +500,7 @@ int vxba_evaluate_only_residual_device(vxba_factor* f, const double* Rp, int hea
   int rc = check_range(f, head, end);
   if (rc) return rc;
   hipSetDevice(f->device);
-  return sweep_residual_device(f, Rp, head, end, d_out);
+  return sweep_residual_device(f, Rp, nullptr, nullptr, 0, head, end, d_out);
 }
 
 int vxba_read_cache(vxba_factor* f, int head, int end, double* eig_val, double* eig_vec, double* merged) {
@@ -554,84 +575,73 @@ int vxba_plane_fit(int device, int64_t n, const double* clusters, double* eig_va
   return e == hipSuccess ? VXBA_OK : VXBA_ERR_HIP;
 }
 
-// Lidar_BA_Optimizer::damping_iter (voxel_map.hpp:367-442): same control flow, the two sweeps run on the GPU.
+// Lidar_BA_Optimizer::damping_iter (voxel_map.hpp:367-442).  The whole loop is enqueued on the stream without a host
+// round trip: the LM state (poses, damping, accept/reject flags) lives in device memory (vxk::LMState), the solve and
+// the accept/reject step are single-workgroup kernels, and the sweeps gate themselves on the state's flags exactly
+// where the reference branches (is_calc_hess, the early break).  One D2H copy + one sync at the end.
 int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out, double* resis_out, double* trace_out, int* n_trace,
                       int* is_converge) {
-  if (!f || !Rp || max_iter < 0) return fail(f, VXBA_ERR_ARG, "damping_iter: bad argument");
+  if (!f || !Rp || max_iter < 0 || max_iter > vxk::LM_MAX_ITER) return fail(f, VXBA_ERR_ARG, "damping_iter: bad argument (max_iter <= 64)");
   if (f->V == 0) return fail(f, VXBA_ERR_STATE, "damping_iter on an empty factor");
   hipSetDevice(f->device);
   const int W = f->W, n = 6 * W;
-  double u = 0.01, v = 2;
-  std::vector<double> Hess((size_t)n * n), JacT(n), x(Rp, Rp + 12 * W), x_temp(x);
-  double residual1 = 0, residual2 = 0;
-  bool is_calc_hess = true, converge = true;
-  int nt = 0;
+  PoseArg x0;
+  fill_poses(f, Rp, x0);
+  vxk::launch_lm_init(f->d_lm, x0, W, 0, f->stream);
   for (int i = 0; i < max_iter; i++) {
-    const bool recomputed = is_calc_hess;
-    if (is_calc_hess) {
-      int rc = sweep_hess_host(f, x.data(), 0, f->V);
-      if (rc) return rc;
-      std::memcpy(Hess.data(), f->h_packed, sizeof(double) * n * n);
-      std::memcpy(JacT.data(), f->h_packed + (size_t)n * n, sizeof(double) * n);
-      residual1 = f->h_packed[(size_t)n * n + n];
-      if (hess_out) std::memcpy(hess_out, Hess.data(), sizeof(double) * n * n);  // *hess = Hess, before the gauge fix
-    }
-    if (i == 0 && resis_out) resis_out[0] = residual1;
-    const double q1 = vxh::lm_damped_step(W, Hess.data(), JacT.data(), u, x.data(), x_temp.data(), f->ws);
-    int rc = sweep_residual_host(f, x_temp.data(), 0, f->V, &residual2);
+    int rc = sweep_hess_device(f, nullptr, f->d_lm->x, f->d_lm, 0, f->V, f->d_packed);
     if (rc) return rc;
-    const double q = residual1 - residual2;
-    const double u_used = u, v_used = v;
-    const bool accepted = vxh::lm_update_damping(residual1, residual2, q1, u, v);
-    if (accepted) { x = x_temp; is_calc_hess = true; }
-    else { is_calc_hess = false; converge = false; }
-    if (trace_out) {
-      double* o = trace_out + (size_t)VXBA_TRACE_COLS * nt;
-      o[0] = residual1; o[1] = residual2; o[2] = u_used; o[3] = v_used; o[4] = q; o[5] = q1; o[6] = accepted; o[7] = recomputed;
-    }
-    nt++;
-    if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
+    vxk::launch_lm_solve(f->d_lm, f->d_packed, W, f->stream);
+    // residual sweep at the trial state; without a collective its wave partials are summed inside the update kernel
+    int nparts = 0;
+    rc = sweep_residual_device(f, nullptr, f->d_lm->xt, f->d_lm, 0, 0, f->V, f->allreduce ? f->d_scalar : nullptr, &nparts);
+    if (rc) return rc;
+    vxk::launch_lm_update(f->d_lm, f->allreduce ? f->d_scalar : nullptr, f->d_partial2, nparts, f->d_scalar, W, f->stream);
   }
-  if (resis_out) resis_out[1] = residual2;
+  VX_HIP(f, hipGetLastError());
+  VX_HIP(f, hipMemcpyAsync(f->h_lm, f->d_lm, sizeof(vxk::LMState), hipMemcpyDeviceToHost, f->stream));
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  const vxk::LMState& st = *f->h_lm;
+  std::memcpy(Rp, st.x, sizeof(double) * 12 * W);
+  if (hess_out) std::memcpy(hess_out, st.hess_out, sizeof(double) * n * n);
+  if (resis_out) { resis_out[0] = st.resis[0]; resis_out[1] = st.resis[1]; }
+  const int nt = std::min(st.iter, vxk::LM_MAX_ITER);
+  if (trace_out) std::memcpy(trace_out, st.trace, sizeof(double) * VXBA_TRACE_COLS * nt);
   if (n_trace) *n_trace = nt;
-  if (is_converge) *is_converge = converge ? 1 : 0;
-  std::memcpy(Rp, x.data(), sizeof(double) * 12 * W);
+  if (is_converge) *is_converge = st.converge;
   return VXBA_OK;
 }
 
-int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_per_solve, double* Rp_out, double* last_resis) {
+int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_per_solve, double* Rp_out, double* last_resis,
+                  int64_t* stats_out) {
   if (!f || !Rp_init || n_steps < 0 || steps_per_solve < 1) return fail(f, VXBA_ERR_ARG, "lm_steps: bad argument");
   if (f->V == 0) return fail(f, VXBA_ERR_STATE, "lm_steps on an empty factor");
   hipSetDevice(f->device);
-  const int W = f->W, n = 6 * W;
-  std::vector<double> Hess((size_t)n * n), JacT(n), x(Rp_init, Rp_init + 12 * W), x_temp(x);
-  double u = 0.01, v = 2, residual1 = 0, residual2 = 0;
+  const int W = f->W;
+  PoseArg x0;
+  fill_poses(f, Rp_init, x0);
+  vxk::launch_lm_init(f->d_lm, x0, W, 1, f->stream);
   for (int s = 0; s < n_steps; s++) {
     if (s % steps_per_solve == 0) {  // a new window: initial guess, fresh damping, re-seeded cache
-      x.assign(Rp_init, Rp_init + 12 * W);
-      u = 0.01; v = 2;
+      if (s > 0) vxk::launch_lm_restart(f->d_lm, x0, W, f->stream);
       int rc = vxba_restore_cache(f);
       if (rc) return rc;
     }
-    int rc = sweep_hess_host(f, x.data(), 0, f->V);   // accepted-step path: the Hessian is always recomputed
+    int rc = sweep_hess_device(f, nullptr, f->d_lm->x, f->d_lm, 0, f->V, f->d_packed);   // skipped on the GPU after a rejected step, like the reference
     if (rc) return rc;
-    std::memcpy(Hess.data(), f->h_packed, sizeof(double) * n * n);
-    std::memcpy(JacT.data(), f->h_packed + (size_t)n * n, sizeof(double) * n);
-    residual1 = f->h_packed[(size_t)n * n + n];
-    const double q1 = vxh::lm_damped_step(W, Hess.data(), JacT.data(), u, x.data(), x_temp.data(), f->ws);
-    rc = sweep_residual_host(f, x_temp.data(), 0, f->V, &residual2);
+    vxk::launch_lm_solve(f->d_lm, f->d_packed, W, f->stream);
+    // residual sweep at the trial state; without a collective its wave partials are summed inside the update kernel
+    int nparts = 0;
+    rc = sweep_residual_device(f, nullptr, f->d_lm->xt, f->d_lm, 0, 0, f->V, f->allreduce ? f->d_scalar : nullptr, &nparts);
     if (rc) return rc;
-    if (vxh::lm_update_damping(residual1, residual2, q1, u, v)) x = x_temp;
-    else {
-      // rejected: the cache now describes the trial state (Appendix B.2); the next forced Hessian sweep must see
-      // the cache of the state it linearises at, so refresh it (one extra residual sweep, only on rejections)
-      double tmp;
-      rc = sweep_residual_host(f, x.data(), 0, f->V, &tmp);
-      if (rc) return rc;
-    }
+    vxk::launch_lm_update(f->d_lm, f->allreduce ? f->d_scalar : nullptr, f->d_partial2, nparts, f->d_scalar, W, f->stream);
   }
-  if (Rp_out) std::memcpy(Rp_out, x.data(), sizeof(double) * 12 * W);
-  if (last_resis) { last_resis[0] = residual1; last_resis[1] = residual2; }
+  VX_HIP(f, hipGetLastError());
+  VX_HIP(f, hipMemcpyAsync(f->h_lm, f->d_lm, sizeof(vxk::LMState), hipMemcpyDeviceToHost, f->stream));
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  if (Rp_out) std::memcpy(Rp_out, f->h_lm->x, sizeof(double) * 12 * W);
+  if (last_resis) { last_resis[0] = f->h_lm->residual1; last_resis[1] = f->h_lm->residual2; }
+  if (stats_out) { stats_out[0] = f->h_lm->iter; stats_out[1] = f->h_lm->n_accept; stats_out[2] = f->h_lm->n_reject; }
   return VXBA_OK;
 }
 
@@ -646,6 +656,12 @@ int vxba_debug_mfma_probe(int device, const double* A16x4, const double* B4x16, 
   if (e == hipSuccess) e = hipMemcpy(D16x16, d + 128, 256 * sizeof(double), hipMemcpyDeviceToHost);
   hipFree(d);
   return e == hipSuccess ? VXBA_OK : VXBA_ERR_HIP;
+}
+
+int vxba_debug_stamps(int clear, unsigned long long* out, size_t n) {
+  if (clear) vxk::debug_clear_stamps();
+  if (out && n) { (void)hipDeviceSynchronize(); vxk::debug_read_stamps(out, n); }
+  return VXBA_OK;
 }
 
 int vxba_set_profiling(vxba_factor* f, int on) {

@@ -19,8 +19,12 @@ struct PoseArg {
 //   fix    [10][VS]     world-frame fix clusters
 //   coe    [VS]
 //   eigval [3][VS], eigvec [9][VS] (plane 3*col+row), merged [10][VS]   -- the (lambda, U, pcr_add) cache
-//   aux    [2][VS]      s_k = sqrt(2/(lambda_k - lambda_0)), k = 1,2 (derived from eigval, device-private)
+//   aux    [4][VS]      s_1, s_2 (s_k = sqrt(2/(lambda_k - lambda_0))), 1/N_merged, sqrt(coe): derived, device-private
+//   clb    [ceil(VS/NV)][5][64][2]  the SAME clusters again in K3's batch-major order: batch b = voxels
+//                      [b NV, (b+1) NV), lane = voxel_local * W + frame, component pairs interleaved, so one wave
+//                      reads its 60 entries with five fully contiguous 1 KB dwordx4 loads
 struct FactorView {
+  double* clb;
   double* cl;
   double* fix;
   double* coe;
@@ -32,14 +36,43 @@ struct FactorView {
   int W;
 };
 
+// Device-resident state of the LM shell (Lidar_BA_Optimizer::damping_iter, voxel_map.hpp:367-442): the sweeps read
+// their poses and their run/skip gates from here, so a whole damping_iter is enqueued without a host round trip.
+constexpr int LM_MAX_ITER = 64;
+struct LMState {
+  double x[12 * MAXW];        // accepted poses            (x_stats)
+  double xt[12 * MAXW];       // trial poses               (x_stats_temp)
+  double u, v;                // damping
+  double residual1, residual2, q1;
+  double resis[2];            // residual before / after   (voxel_map.hpp:394-395,440)
+  int calc_hess;              // is_calc_hess: gates the Hessian sweep
+  int done;                   // loop left (early break): gates everything
+  int iter;                   // iterations executed
+  int converge;               // is_converge
+  int rejected;               // last step rejected
+  int bench_mode;             // 1: never take the early break, so exactly n_steps iterations run (vxba_lm_steps)
+  int n_accept, n_reject;     // running totals over all iterations of this init
+  double trace[LM_MAX_ITER * 8];
+  double Jwork[6 * MAXW];                 // gauge-fixed gradient kept across rejected steps
+  double dxi[6 * MAXW];
+  double Hwork[36 * MAXW * MAXW];         // gauge-fixed Hessian kept across rejected steps
+  double hess_out[36 * MAXW * MAXW];      // *hess, exported before the gauge fix (voxel_map.hpp:391)
+};
+
 inline int k3_num_tiles(int W) { return (6 * W + 15) / 16; }
+// voxels per wave-batch of the Hessian sweep (must match K3Cfg<W>::NV)
+inline int k3_nv(int W) { const int cap = k3_num_tiles(W) <= 2 ? 12 : 8; return (64 / W) < cap ? (64 / W) : cap; }
+inline size_t k3_clb_len(int W, int VS) { return (size_t)((VS + k3_nv(W) - 1) / k3_nv(W)) * 640; }
 inline int k3_num_tile_pairs(int W) { int nt = k3_num_tiles(W); return nt * (nt + 1) / 2; }
 // doubles per workgroup partial: MFMA accumulator tiles (register layout) + per-frame linear accumulators
 inline size_t k3_partial_len(int W) { return (size_t)k3_num_tile_pairs(W) * 256 + (size_t)W * DACC; }
 
 // K2: residual sweep over voxels [head,end): merge + covariance + eigen-decomposition, writes the cache,
 // block partials of sum coe*lambda_0 into d_partial[0..nblocks).  Returns the number of partials.
-int launch_k2_residual(const FactorView& fv, const PoseArg& poses, int head, int end, double* d_partial, hipStream_t s);
+// d_Rp (device pointer, W*12 f64) overrides the by-value poses when non-null; gate (device int pointer) skips the
+// launch's work on the GPU when gate[gate_idx] evaluates to "do not run": K2 runs iff !done, K3 iff calc_hess && !done.
+int launch_k2_residual(const FactorView& fv, const PoseArg& poses, const double* d_Rp, const LMState* gate, int gate_mode, int head,
+                       int end, double* d_partial, hipStream_t s);
 // Deterministic sum of n partials into d_out[0].
 void launch_sum_partials(const double* d_partial, int n, double* d_out, hipStream_t s);
 // Derive aux (gap scales) from eigval for voxels [head,end) (after a caller-seeded cache).
@@ -47,9 +80,17 @@ void launch_seed_aux(const FactorView& fv, int head, int end, hipStream_t s);
 
 // K3: Hessian/gradient sweep over voxels [head,end) into per-workgroup partials; returns #workgroups.
 int k3_grid_blocks(int device_cus);
-int launch_k3_hessian(const FactorView& fv, const PoseArg& poses, int head, int end, double* d_partial, int nblocks, hipStream_t s);
+int launch_k3_hessian(const FactorView& fv, const PoseArg& poses, const double* d_Rp, const LMState* gate, int head, int end,
+                      double* d_partial, int nblocks, hipStream_t s);
 // Cross-workgroup reduction + assembly of the packed [Hess (6W)^2 col-major | JacT 6W | residual] buffer.
-void launch_k3_finalize(const double* d_partial, int nblocks, int W, double* d_packed, hipStream_t s);
+void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* gate, double* d_packed, hipStream_t s);
+
+// LM shell on the device: init (poses, damping, flags), damped solve + trial state, accept/reject.
+void launch_lm_init(LMState* st, const PoseArg& x0, int W, int bench_mode, hipStream_t s);
+void launch_lm_restart(LMState* st, const PoseArg& x0, int W, hipStream_t s);
+void launch_lm_solve(LMState* st, const double* d_packed, int W, hipStream_t s);
+// d_scalar != null: use that (all-reduced) residual; else sum the nparts wave partials of the residual sweep here.
+void launch_lm_update(LMState* st, const double* d_scalar, const double* d_partial, int nparts, double* d_scalar_out, int W, hipStream_t s);
 
 // K1: clusters of n_voxels*W cells from bucketed points (cell = frame*n_voxels + voxel), written to the
 // frame-major planes at voxel offset v0.
@@ -58,6 +99,9 @@ void launch_k1_build(const double* d_xyz, const int64_t* d_cell_ptr, int n_voxel
 // K4: plane fit of n packed clusters (AoS n*10) -> eig_val n*3, eig_vec n*9 (col-major).
 void launch_k4_plane_fit(const double* d_clusters, int64_t n, double* d_eigval, double* d_eigvec, hipStream_t s);
 
+// Rebuild the batch-major copy (clb) of voxels [v0, v0+n) from the frame-major planes.
+void launch_build_clb(const FactorView& fv, int v0, int n, hipStream_t s);
+
 // Layout plumbing between the C-ABI's packed AoS rows and the device planes.
 void launch_scatter_clusters(const double* d_src /*[n][W][10]*/, const FactorView& fv, int v0, int n, hipStream_t s);
 void launch_gather_clusters(const FactorView& fv, int head, int n, double* d_dst /*[n][W][10]*/, hipStream_t s);
@@ -65,6 +109,8 @@ void launch_scatter_rows(const double* d_src /*[n][K]*/, double* planes, int VS,
 void launch_gather_rows(const double* planes, int VS, int head, int n, int K, double* d_dst /*[n][K]*/, hipStream_t s);
 void launch_fill(double* p, size_t n, double val, hipStream_t s);
 void launch_copy_planes(const double* src, int src_vs, double* dst, int dst_vs, int nplanes, int n, hipStream_t s);
+void debug_read_stamps(unsigned long long* host, size_t n);
+void debug_clear_stamps();
 void launch_mfma_probe(const double* dA, const double* dB, double* dD, hipStream_t s);
 void launch_count_nnz(const FactorView& fv, int V, unsigned long long* d_out, hipStream_t s);
 

@@ -13,52 +13,76 @@
 // tree, so results are run-to-run bitwise reproducible for a given launch geometry.
 #include "vxba_kernels.h"
 
+#include <cstdlib>
+
 #include "vxba_math.hpp"
 
 namespace vxk {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// Development instrumentation: per-wave s_memtime stamps of the debug kernel instantiations (VXBA_DBG=1).
+constexpr int DBG_SLOTS = 32;
+constexpr int DBG_WAVES = 4096;
+__device__ unsigned long long g_dbg[DBG_WAVES * DBG_SLOTS];
+__device__ __forceinline__ void dbg_stamp(bool on, int wave_id, int slot) {
+  if (on && wave_id < DBG_WAVES && (threadIdx.x & 63) == 0) g_dbg[wave_id * DBG_SLOTS + slot] = __builtin_readcyclecounter();
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2 -- residual sweep.  One lane per voxel, frames unrolled: every load is a 512 B contiguous row of a
 // frame-major plane, poses are wave-uniform (scalar loads from the kernarg segment), no cross-lane traffic
 // until the final residual reduction.
 // ------------------------------------------------------------------------------------------------
-template <int W>
-__global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, int head, int end, double* __restrict__ partial) {
+template <int W, bool DBG = false>
+__global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, const double* __restrict__ d_Rp,
+                                                         const LMState* __restrict__ gate, int gate_mode, int head, int end,
+                                                         double* __restrict__ partial) {
+  // gate_mode 0: skip once the LM loop is done; 1: run only after a rejected step (bench-mode cache refresh)
+  if (gate && (gate_mode == 0 ? gate->done != 0 : gate->rejected == 0)) return;
+  const double* __restrict__ Rp = d_Rp ? d_Rp : poses.Rp;
   const int lane = threadIdx.x;
   const int a = head + blockIdx.x * 64 + lane;
   const size_t VS = (size_t)fv.VS;
   double res = 0.0;
+  dbg_stamp(DBG, blockIdx.x, 0);
   if (a < end) {
+    // issue every load of this voxel up front (10 + 10 W independent 512 B rows per wave): with < 1 wave per
+    // SIMD at 50k voxels the sweep is latency-bound unless all of them are in flight together
+    double fx[10], c[W][10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) fx[k] = fv.fix[k * VS + a];
+#pragma unroll
+    for (int i = 0; i < W; i++)
+#pragma unroll
+      for (int k = 0; k < 10; k++) c[i][k] = fv.cl[((size_t)i * 10 + k) * VS + a];
     double SP[6], Sv[3], SN;
+    if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, blockIdx.x, 1); }
 #pragma unroll
-    for (int k = 0; k < 6; k++) SP[k] = fv.fix[k * VS + a];
+    for (int k = 0; k < 6; k++) SP[k] = fx[k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) Sv[k] = fv.fix[(6 + k) * VS + a];
-    SN = fv.fix[9 * VS + a];
+    for (int k = 0; k < 3; k++) Sv[k] = fx[6 + k];
+    SN = fx[9];
 #pragma unroll
     for (int i = 0; i < W; i++) {
-      const double* clp = fv.cl + (size_t)i * 10 * VS + a;
-      double c[10];
-#pragma unroll
-      for (int k = 0; k < 10; k++) c[k] = clp[k * VS];
       // N == 0 <=> frame i did not observe this voxel (voxel_map.hpp:258): contributes nothing
-      const bool obs = c[9] != 0.0;
+      const bool obs = c[i][9] != 0.0;
 #pragma unroll
-      for (int k = 0; k < 10; k++) c[k] = obs ? c[k] : 0.0;
+      for (int k = 0; k < 10; k++) c[i][k] = obs ? c[i][k] : 0.0;
       double R[9], p[3];
 #pragma unroll
       for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = poses.Rp[12 * i + 3 * cc + r];
+        for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = Rp[12 * i + 3 * cc + r];
 #pragma unroll
-      for (int k = 0; k < 3; k++) p[k] = poses.Rp[12 * i + 9 + k];
-      vxm::transform_accumulate(c, c + 6, c[9], R, p, SP, Sv, SN);
+      for (int k = 0; k < 3; k++) p[k] = Rp[12 * i + 9 + k];
+      vxm::transform_accumulate(c[i], c[i] + 6, c[i][9], R, p, SP, Sv, SN);
     }
     double C[6], lam[3], U[9];
     vxm::cluster_cov(SP, Sv, SN, C);
+    if (DBG) { asm volatile("" :: "v"(C[0]), "v"(C[3]), "v"(C[5])); dbg_stamp(true, blockIdx.x, 2); }
     vxm::eig_sym3(C, lam, U);
+    if (DBG) { asm volatile("" :: "v"(lam[0]), "v"(U[0]), "v"(U[8])); dbg_stamp(true, blockIdx.x, 3); }
 #pragma unroll
     for (int k = 0; k < 3; k++) fv.eigval[k * VS + a] = lam[k];
 #pragma unroll
@@ -72,14 +96,18 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
     fv.merged[9 * VS + a] = SN;
     double s1, s2;
     vxm::gap_scales(lam, s1, s2);
+    const double coe = fv.coe[a];
     fv.aux[a] = s1;
     fv.aux[VS + a] = s2;
-    res = fv.coe[a] * lam[0];
+    fv.aux[2 * VS + a] = 1.0 / SN;
+    fv.aux[3 * VS + a] = sqrt(coe);
+    res = coe * lam[0];
   }
   // fixed-tree wave reduction
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) res += __shfl_down(res, off);
   if (lane == 0) partial[blockIdx.x] = res;
+  if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, blockIdx.x, 4); }
 }
 
 __global__ __launch_bounds__(1024) void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
@@ -104,6 +132,8 @@ __global__ void seed_aux_kernel(FactorView fv, int head, int end) {
   vxm::gap_scales(lam, s1, s2);
   fv.aux[a] = s1;
   fv.aux[VS + a] = s2;
+  fv.aux[2 * VS + a] = 1.0 / fv.merged[9 * VS + a];
+  fv.aux[3 * VS + a] = sqrt(fv.coe[a]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -130,17 +160,119 @@ struct K3Cfg {
   static constexpr int ROWS = 4 * KSTEPS;
   static constexpr int NCOL = 16 * NT;
   static constexpr int RS = NCOL + ((NT & 1) ? 32 : 16);  // row stride == 16 (mod 32) doubles: conflict-free ds_read_b64
-  static constexpr int WAVE_LDS = ROWS * RS;          // doubles
+  static constexpr int WAVE_LDS = (ROWS + 1) * RS;    // doubles; the extra row absorbs the stores of idle lanes
 };
 
+// Register image of one (voxel, frame) entry plus the voxel's cached plane parameters.
+struct K3Entry {
+  double c[10];      // body-frame cluster
+  double u[9];       // eigenvectors, plane 3*col+row
+  double s1, s2;     // gap scales
+  double invN, sc;   // 1 / merged count, sqrt(coe)
+  double mv[3];      // merged first moment
+  double coe, lam0;
+  bool ok;           // lane holds a real (voxel, frame) entry of [head,end)
+};
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
 template <int W>
-__global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, PoseArg poses, int head, int end,
+__device__ __forceinline__ void k3_load_entry(const FactorView& fv, int head, int end, int b1, int b, bool active, int vl, int lane, K3Entry& e) {
+  using C = K3Cfg<W>;
+  const size_t VS = (size_t)fv.VS;
+  const int bc = b <= b1 ? b : b1;  // branch-free: batches past the end re-read the last one and are masked to zero
+  const int a = bc * C::NV + vl;
+  e.ok = active && b <= b1 && a >= head && a < end;
+  // clusters: five contiguous 1 KB rows per wave (batch-major copy)
+  const v2d* cp = reinterpret_cast<const v2d*>(fv.clb) + (size_t)bc * 5 * 64 + lane;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const v2d t = cp[j * 64];
+    e.c[2 * j] = t[0];
+    e.c[2 * j + 1] = t[1];
+  }
+  // plane parameters of my voxel: each row of six voxels sits in one cache line
+  const int ac = e.ok ? a : head;
+#pragma unroll
+  for (int k = 0; k < 9; k++) e.u[k] = fv.eigvec[(size_t)k * VS + ac];
+  e.s1 = fv.aux[ac];
+  e.s2 = fv.aux[VS + ac];
+#pragma unroll
+  for (int k = 0; k < 3; k++) e.mv[k] = fv.merged[(size_t)(6 + k) * VS + ac];
+  e.invN = fv.aux[2 * VS + ac];
+  e.sc = fv.aux[3 * VS + ac];
+  e.coe = fv.coe[ac];
+  e.lam0 = fv.eigval[ac];
+}
+
+// Phase A of one entry: rows of B_a (3 x 6) and the per-frame linear accumulators, branch-free.
+__device__ __forceinline__ void k3_phase_a(K3Entry& e, int fi, const double R[9], const double p[3], double rows[3][6], double dacc[DACC]) {
+  const bool obs = e.ok && e.c[9] != 0.0;   // N == 0: frame did not observe the voxel (voxel_map.hpp:178)
+#pragma unroll
+  for (int k = 0; k < 10; k++) e.c[k] = obs ? e.c[k] : 0.0;
+  vxm::VoxelCache vc;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { vc.u0[k] = e.u[k]; vc.u1[k] = e.u[3 + k]; vc.u2[k] = e.u[6 + k]; }
+  vc.s1 = e.s1;
+  vc.s2 = e.s2;
+  vc.invN = e.invN;
+#pragma unroll
+  for (int k = 0; k < 3; k++) vc.vbar[k] = e.mv[k] * vc.invN;
+  vc.coe = obs ? e.coe : 0.0;
+  vc.sc = obs ? e.sc : 0.0;
+  dacc[27] += (e.ok && fi == 0) ? e.coe * e.lam0 : 0.0;  // residual += coe * lambda_0, once per voxel (voxel_map.hpp:234)
+  vxm::k3_entry(e.c, e.c + 6, e.c[9], R, p, vc, rows, dacc);
+}
+
+template <int W>
+__device__ __forceinline__ void k3_store_rows(double* ldsb, bool active, int vl, int fi, const double rows[3][6]) {
+  using C = K3Cfg<W>;
+  // branch-free: idle lanes (>= NV*W) store into the dump row behind the tile
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    double* dst = ldsb + (active ? (3 * vl + r) * C::RS + 6 * fi : C::ROWS * C::RS);
+#pragma unroll
+    for (int k = 0; k < 6; k++) dst[k] = rows[r][k];
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void k3_mfma_tile(const double* ldsb, int lrow, int lcol, v4d* acc) {
+  using C = K3Cfg<W>;
+#pragma unroll
+  for (int kk = 0; kk < C::KSTEPS; kk++) {
+    double x[C::NT];
+#pragma unroll
+    for (int c = 0; c < C::NT; c++) x[c] = ldsb[(4 * kk + lrow) * C::RS + 16 * c + lcol];
+    int t = 0;
+#pragma unroll
+    for (int I = 0; I < C::NT; I++)
+#pragma unroll
+      for (int J = I; J < C::NT; J++) {
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[I], x[J], acc[t], 0, 0, 0);
+        t++;
+      }
+  }
+}
+
+// Software-pipelined main loop (one wave per SIMD, up to 512 VGPRs): one loop body holds
+//   (1) the global loads of batch b+1 (consumed one iteration later: measured wait at the top of the loop is
+//       ~340 cycles of a ~6200-cycle iteration, i.e. HBM latency is hidden),
+//   (2) the f64 MFMAs of batch b-1, fed from LDS buffer (b-1)&1, and
+//   (3) the phase-A VALU work of batch b, written to LDS buffer b&1.
+// Measured on MI355X: f64 MFMA and f64 VALU do NOT overlap (pinning one MFMA between every ~9 VALU ops with
+// sched_barrier made the kernel slower), so the loop is bound by the sum of both fp64 instruction streams.
+template <int W, bool DBG = false>
+__global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, PoseArg poses, const double* __restrict__ d_Rp,
+                                                                 const LMState* __restrict__ gate, int head, int end,
                                                                  double* __restrict__ partial) {
   using C = K3Cfg<W>;
-  __shared__ double lds[4 * C::WAVE_LDS];
+  if (gate && (gate->done || !gate->calc_hess)) return;
+  const double* __restrict__ Rp = d_Rp ? d_Rp : poses.Rp;
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // [4 waves][2 buffers][WAVE_LDS]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  double* ldsw = lds + wave * C::WAVE_LDS;
-  for (int k = lane; k < C::WAVE_LDS; k += 64) ldsw[k] = 0.0;  // pad rows / pad columns stay zero forever
+  double* ldsw = lds + (size_t)wave * 2 * C::WAVE_LDS;
+  for (int k = lane; k < 2 * C::WAVE_LDS; k += 64) ldsw[k] = 0.0;  // pad rows / pad columns stay zero forever
 
   const bool active = lane < C::NACT;
   const int vl = active ? lane / W : 0;
@@ -149,9 +281,9 @@ __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, 
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = poses.Rp[12 * fi + 3 * cc + r];
+    for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = Rp[12 * fi + 3 * cc + r];
 #pragma unroll
-  for (int k = 0; k < 3; k++) p[k] = poses.Rp[12 * fi + 9 + k];
+  for (int k = 0; k < 3; k++) p[k] = Rp[12 * fi + 9 + k];
 
   v4d acc[C::NTP];
 #pragma unroll
@@ -160,151 +292,168 @@ __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, 
 #pragma unroll
   for (int k = 0; k < DACC; k++) dacc[k] = 0.0;
 
-  const size_t VS = (size_t)fv.VS;
-  const int nb = (end - head + C::NV - 1) / C::NV;
+  // batches are absolute (batch b = voxels [b NV, (b+1) NV)) so the batch-major copy does not depend on `head`
+  const int b0 = head / C::NV, b1 = (end - 1) / C::NV;
   const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
   const int lrow = lane >> 4, lcol = lane & 15;
+  dbg_stamp(DBG, gw, 0);
 
-  for (int b = gw; b < nb; b += nw) {
-    const int a = head + b * C::NV + vl;
-    const bool valid = active && a < end;
+  if (b0 + gw <= b1) {
+    K3Entry cur, nxt;
     double rows[3][6];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int k = 0; k < 6; k++) rows[r][k] = 0.0;
-    if (valid) {
-      const double* clp = fv.cl + (size_t)fi * 10 * VS + a;
-      double c[10];
-#pragma unroll
-      for (int k = 0; k < 10; k++) c[k] = clp[k * VS];
-      const double coe = fv.coe[a];
-      if (fi == 0) dacc[27] += coe * fv.eigval[a];  // residual += coe * lambda_0 (voxel_map.hpp:234), once per voxel
-      if (c[9] != 0.0) {                             // voxel_map.hpp:178
-        vxm::VoxelCache vc;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          vc.u0[k] = fv.eigvec[(size_t)k * VS + a];
-          vc.u1[k] = fv.eigvec[(size_t)(3 + k) * VS + a];
-          vc.u2[k] = fv.eigvec[(size_t)(6 + k) * VS + a];
-        }
-        vc.s1 = fv.aux[a];
-        vc.s2 = fv.aux[VS + a];
-        vc.invN = 1.0 / fv.merged[9 * VS + a];
-#pragma unroll
-        for (int k = 0; k < 3; k++) vc.vbar[k] = fv.merged[(size_t)(6 + k) * VS + a] * vc.invN;
-        vc.coe = coe;
-        vxm::k3_entry(c, c + 6, c[9], R, p, vc, rows, dacc);
-      }
-    }
-    if (active) {
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int k = 0; k < 6; k++) ldsw[(3 * vl + r) * C::RS + 6 * fi + k] = rows[r][k];
-    }
+    k3_load_entry<W>(fv, head, end, b1, b0 + gw, active, vl, lane, cur);
+    k3_load_entry<W>(fv, head, end, b1, b0 + gw + nw, active, vl, lane, nxt);
+    if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 1); }
+    k3_phase_a(cur, fi, R, p, rows, dacc);
+    k3_store_rows<W>(ldsw, active, vl, fi, rows);
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int kk = 0; kk < C::KSTEPS; kk++) {
-      double x[C::NT];
-#pragma unroll
-      for (int c = 0; c < C::NT; c++) x[c] = ldsw[(4 * kk + lrow) * C::RS + 16 * c + lcol];
-      int t = 0;
-#pragma unroll
-      for (int I = 0; I < C::NT; I++)
-#pragma unroll
-        for (int J = I; J < C::NT; J++) {
-          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[I], x[J], acc[t], 0, 0, 0);
-          t++;
-        }
+    if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 2); }
+    int buf = 1;
+    int it_dbg = 0;
+    for (int b = b0 + gw + nw; b <= b1; b += nw) {
+      if (DBG && it_dbg < 10) { dbg_stamp(true, gw, 8 + 2 * it_dbg); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 9 + 2 * it_dbg); it_dbg++; }
+      cur = nxt;
+      k3_load_entry<W>(fv, head, end, b1, b + nw, active, vl, lane, nxt);
+      k3_mfma_tile<W>(ldsw + (buf ^ 1) * C::WAVE_LDS, lrow, lcol, acc);   // batch b - nw
+      k3_phase_a(cur, fi, R, p, rows, dacc);                               // batch b
+      k3_store_rows<W>(ldsw + buf * C::WAVE_LDS, active, vl, fi, rows);
+      __builtin_amdgcn_wave_barrier();
+      buf ^= 1;
     }
-    __builtin_amdgcn_wave_barrier();
+    k3_mfma_tile<W>(ldsw + (buf ^ 1) * C::WAVE_LDS, lrow, lcol, acc);
+    if (DBG) { asm volatile("" :: "v"(acc[0][0])); dbg_stamp(true, gw, 3); }
   }
 
-  // linear accumulators: sum over the NV lanes sharing my frame (fixed order), result valid in lanes < W
-  double dsum[DACC];
-#pragma unroll
-  for (int k = 0; k < DACC; k++) dsum[k] = dacc[k];
-#pragma unroll 1
-  for (int j = 1; j < C::NV; j++) {
-    const int src = (lane + j * W) & 63;
-#pragma unroll
-    for (int k = 0; k < DACC; k++) dsum[k] += __shfl(dacc[k], src);
-  }
-
-  // deterministic in-block reduction over the 4 waves, then one partial per workgroup
-  constexpr size_t PLEN = (size_t)C::NTP * 256 + (size_t)W * DACC;
+  // Deterministic in-block reduction through LDS (fixed order), one partial per workgroup.
+  constexpr int PLEN = C::NTP * 256 + W * DACC;
+  constexpr int DS = DACC + 1;  // padded stride: conflict-free column reads
   double* pout = partial + (size_t)blockIdx.x * PLEN;
+  if (DBG) { asm volatile("" :: "v"(dacc[0])); dbg_stamp(true, gw, 4); }
+  __syncthreads();  // every wave is done with its main-loop tiles
+  dbg_stamp(DBG, gw, 5);
+  // (1) per-frame linear accumulators: every lane parks its 28 values, then W*28 threads sum the 4*NV lanes of a frame
+#pragma unroll
+  for (int k = 0; k < DACC; k++) lds[(wave * 64 + lane) * DS + k] = dacc[k];
   __syncthreads();
+  for (int e = tid; e < W * DACC; e += K3_BLOCK) {
+    const int i = e / DACC, k = e % DACC;
+    double sum = 0.0;
+    for (int w = 0; w < 4; w++)
 #pragma unroll
-  for (int t = 0; t < C::NTP; t++) {
+      for (int v = 0; v < C::NV; v++) sum += lds[(w * 64 + v * W + i) * DS + k];
+    pout[C::NTP * 256 + e] = sum;
+  }
+  __syncthreads();
+  // (2) MFMA accumulator tiles, TPR tiles per round
+  constexpr int TPR = C::NTP < 5 ? C::NTP : 5;
 #pragma unroll
-    for (int j = 0; j < 4; j++) lds[wave * 256 + j * 64 + lane] = acc[t][j];
+  for (int t0 = 0; t0 < C::NTP; t0 += TPR) {
+#pragma unroll
+    for (int tt = 0; tt < TPR; tt++)
+      if (t0 + tt < C::NTP) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) lds[(wave * TPR + tt) * 256 + j * 64 + lane] = acc[t0 + tt][j];
+      }
     __syncthreads();
-    pout[t * 256 + tid] = ((lds[tid] + lds[256 + tid]) + lds[512 + tid]) + lds[768 + tid];
+#pragma unroll
+    for (int tt = 0; tt < TPR; tt++)
+      if (t0 + tt < C::NTP)
+        pout[(t0 + tt) * 256 + tid] = ((lds[tt * 256 + tid] + lds[(TPR + tt) * 256 + tid]) + lds[(2 * TPR + tt) * 256 + tid]) + lds[(3 * TPR + tt) * 256 + tid];
     __syncthreads();
   }
-  if (lane < W) {
-#pragma unroll
-    for (int k = 0; k < DACC; k++) lds[wave * (W * DACC) + lane * DACC + k] = dsum[k];
-  }
-  __syncthreads();
-  for (int e = tid; e < W * DACC; e += K3_BLOCK)
-    pout[C::NTP * 256 + e] = ((lds[e] + lds[W * DACC + e]) + lds[2 * W * DACC + e]) + lds[3 * W * DACC + e];
+  if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 6); }
 }
 
-// Cross-workgroup reduction + assembly.  64 outputs per workgroup x 16 partial-slices; every output sums its
-// workgroup partials in a fixed order.  Output o < n^2 is Hess(r = o % n, c = o / n) (column-major), then JacT, residual.
+// Cross-workgroup reduction + assembly.  One lane per PARTIAL element (consecutive lanes -> consecutive
+// addresses inside every workgroup partial: coalesced), 64 elements x 16 partial-slices per workgroup, fixed
+// summation order.  An MFMA tile element (I,J,row,col) becomes Hess(r,c) = -S(r,c) [+ D term when r and c belong
+// to the same frame] and is mirrored to Hess(c,r) (voxel_map.hpp:237-239); the linear elements become JacT and
+// the residual.  Output buffer: Hess (6W)^2 column-major | JacT 6W | residual.
 __device__ __forceinline__ int sym6_index(int a, int b) { return a == 0 ? b : (a == 1 ? 2 + b : 5); }  // a <= b
 
 template <int W>
-__global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ packed) {
+__global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restrict__ partial, int nblocks, LMState* __restrict__ gate,
+                                                           double* __restrict__ packed) {
   using C = K3Cfg<W>;
+  if (gate && (gate->done || !gate->calc_hess)) return;
   constexpr int n = 6 * W;
-  constexpr int NOUT = n * n + n + 1;
-  constexpr size_t PLEN = (size_t)C::NTP * 256 + (size_t)W * DACC;
+  constexpr int NTILE = C::NTP * 256;
+  constexpr int PLEN = NTILE + W * DACC;
   __shared__ double red0[16][64];
   __shared__ double red1[16][64];
   const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int o = blockIdx.x * 64 + el;
-  int off0 = -1, off1 = -1;  // source offsets inside a partial: MFMA tile element (enters with -), linear element (+)
-  if (o < n * n) {
-    int r = o % n, c = o / n;
-    if (r > c) { int tmp = r; r = c; c = tmp; }  // symmetric; voxel_map.hpp:237-239 mirrors the upper block triangle
-    const int I = r >> 4, J = c >> 4;
-    const int t = I * C::NT - (I * (I - 1)) / 2 + (J - I);
-    const int ri = r & 15, ci = c & 15;
-    off0 = t * 256 + (ri >> 2) * 64 + (ri & 3) * 16 + ci;  // f64 MFMA C/D map: row = lane/16 + 4*reg, col = lane%16
-    if (r / 6 == c / 6) {
-      const int i = r / 6, a = r % 6, b = c % 6;  // a <= b
+  const int e = blockIdx.x * 64 + el;
+  int off1 = -1;        // second stream: block-diagonal D element that lands on the same Hessian entry
+  int r = -1, c = -1;   // Hessian entry of a tile element
+  int lin = -1;         // output index of a linear element (JacT / residual)
+  if (e < NTILE) {
+    const int t = e >> 8, j = (e >> 6) & 3, l = e & 63;
+    int I = 0, rem = t;                      // invert t = I*NT - I(I-1)/2 + (J-I)
+    while (rem >= C::NT - I) { rem -= C::NT - I; I++; }
+    const int J = I + rem;
+    r = 16 * I + (l >> 4) + 4 * j;           // f64 MFMA C/D map: row = lane/16 + 4*reg, col = lane%16
+    c = 16 * J + (l & 15);
+    if (r >= n || c >= n || r > c) { r = -1; c = -1; }   // padding columns; lower half of a diagonal tile is a duplicate
+    else if (r / 6 == c / 6) {
+      const int i = r / 6, a = r % 6, b = c % 6;         // a <= b
       int d;
       if (b < 3) d = 6 + sym6_index(a, b);
       else if (a < 3) d = 12 + 3 * a + (b - 3);
       else d = 21 + sym6_index(a - 3, b - 3);
-      off1 = C::NTP * 256 + i * DACC + d;
+      off1 = NTILE + i * DACC + d;
     }
-  } else if (o < n * n + n) {
-    const int k = o - n * n;
-    off1 = C::NTP * 256 + (k / 6) * DACC + (k % 6);
-  } else if (o == n * n + n) {
-    off1 = C::NTP * 256 + 27;
+  } else if (e < PLEN) {
+    const int q = e - NTILE, i = q / DACC, d = q % DACC;
+    if (d < 6) lin = n * n + 6 * i + d;
+    else if (d == 27 && i == 0) lin = n * n + n;
   }
+  const bool need0 = (r >= 0) || (lin >= 0);
   double s0 = 0.0, s1 = 0.0;
-  if (o < NOUT) {
-    for (int b = slice; b < nblocks; b += 16) {
+  if (need0) {
+    // issue the loads of 8 partials at a time (independent), add in fixed order
+    int b = slice;
+    for (; b + 16 * 7 < nblocks; b += 16 * 8) {
+      double v0[8], v1[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const double* pb = partial + (size_t)(b + 16 * q) * PLEN;
+        v0[q] = pb[e];
+        v1[q] = off1 >= 0 ? pb[off1] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) { s0 += v0[q]; s1 += v1[q]; }
+    }
+    for (; b < nblocks; b += 16) {
       const double* pb = partial + (size_t)b * PLEN;
-      if (off0 >= 0) s0 += pb[off0];
+      s0 += pb[e];
       if (off1 >= 0) s1 += pb[off1];
     }
   }
   red0[slice][el] = s0;
   red1[slice][el] = s1;
   __syncthreads();
-  if (slice == 0 && o < NOUT) {
+  if (slice == 0 && need0) {
     double t0 = 0.0, t1 = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; k++) { t0 += red0[k][el]; t1 += red1[k][el]; }
-    packed[o] = t1 - t0;
+    if (lin >= 0) {
+      packed[lin] = t0;
+      if (gate) {   // LM state: gauge-fixed gradient (voxel_map.hpp:400), residual1 (:388)
+        if (lin < n * n + n) gate->Jwork[lin - n * n] = (lin - n * n < 6) ? 0.0 : t0;
+        else { gate->residual1 = t0; if (gate->iter == 0) gate->resis[0] = t0; }
+      }
+    } else {
+      const double h = t1 - t0;
+      packed[(size_t)c * n + r] = h;
+      packed[(size_t)r * n + c] = h;
+      if (gate) {   // LM state: *hess = Hess before the gauge fix (:391) and the gauge-fixed working copy (:397-400)
+        gate->hess_out[(size_t)c * n + r] = h;
+        gate->hess_out[(size_t)r * n + c] = h;
+        const double hw = (r < 6 || c < 6) ? ((r == c) ? 1.0 : 0.0) : h;
+        gate->Hwork[(size_t)c * n + r] = hw;
+        gate->Hwork[(size_t)r * n + c] = hw;
+      }
+    }
   }
 }
 
@@ -372,6 +521,26 @@ __global__ void k4_plane_fit_kernel(const double* __restrict__ clusters, long lo
 // ------------------------------------------------------------------------------------------------
 // layout plumbing
 // ------------------------------------------------------------------------------------------------
+// frame-major planes -> K3's batch-major copy for the batches touching voxels [v0, v0+n)
+__global__ void build_clb_kernel(FactorView fv, int nv, int V_hi, int b_lo, int nbatches) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (batch, pair j, lane)
+  if (t >= (long long)nbatches * 320) return;
+  const int lane = (int)(t % 64), j = (int)((t / 64) % 5), b = b_lo + (int)(t / 320);
+  const int W = fv.W;
+  double x0 = 0.0, x1 = 0.0;
+  if (lane < nv * W) {
+    const int a = b * nv + lane / W, i = lane % W;
+    if (a < V_hi) {
+      const double* s = fv.cl + ((size_t)i * 10 + 2 * j) * fv.VS + a;
+      x0 = s[0];
+      x1 = s[fv.VS];
+    }
+  }
+  double* d = fv.clb + (((size_t)b * 5 + j) * 64 + lane) * 2;
+  d[0] = x0;
+  d[1] = x1;
+}
+
 __global__ void scatter_clusters_kernel(const double* __restrict__ src, FactorView fv, int v0, int n) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int W = fv.W;
@@ -423,6 +592,202 @@ __global__ void count_nnz_kernel(FactorView fv, int V, unsigned long long* out) 
   if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(out, cnt);
 }
 
+// ------------------------------------------------------------------------------------------------
+// LM shell on the device (what Lidar_BA_Optimizer::damping_iter does between the two sweeps, voxel_map.hpp:391-439).
+// One workgroup; the (6W)^2 system lives in LDS.  LDL^T with symmetric diagonal pivoting like the reference's
+// Eigen::LDLT (largest remaining |diagonal| first), then the damped step, the trial poses and q1.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lm_right_multiply_exp(const double* Rin, const double* dphi, double* Rout) {
+  // R <- R Exp(dphi), column-major 3x3; Rodrigues with the reference's 1e-11 cut-off (tools.hpp:51-66)
+  const double th = sqrt(dphi[0] * dphi[0] + dphi[1] * dphi[1] + dphi[2] * dphi[2]);
+  double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (th >= 1e-11) {
+    const double k0 = dphi[0] / th, k1 = dphi[1] / th, k2 = dphi[2] / th;
+    const double K[9] = {0, -k2, k1, k2, 0, -k0, -k1, k0, 0};
+    double KK[9];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) KK[3 * r + c] = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
+    const double sn = sin(th), c1 = 1.0 - cos(th);
+    for (int q = 0; q < 9; q++) E[q] += sn * K[q] + c1 * KK[q];
+  }
+  double out[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) out[3 * c + r] = Rin[r] * E[c] + Rin[3 + r] * E[3 + c] + Rin[6 + r] * E[6 + c];
+  for (int q = 0; q < 9; q++) Rout[q] = out[q];
+}
+
+__global__ __launch_bounds__(256) void lm_init_kernel(LMState* st, PoseArg x0, int W, int bench_mode) {
+  const int t = threadIdx.x;
+  if (t < 12 * W) { st->x[t] = x0.Rp[t]; st->xt[t] = x0.Rp[t]; }
+  if (t == 0) {
+    st->u = 0.01; st->v = 2.0;
+    st->residual1 = 0; st->residual2 = 0; st->q1 = 0; st->resis[0] = 0; st->resis[1] = 0;
+    st->calc_hess = 1; st->done = 0; st->iter = 0; st->converge = 1; st->rejected = 0; st->bench_mode = bench_mode;
+    st->n_accept = 0; st->n_reject = 0;
+  }
+}
+// bench mode: a new window starts -- initial guess and fresh damping, iteration counter keeps running
+__global__ __launch_bounds__(256) void lm_restart_kernel(LMState* st, PoseArg x0, int W) {
+  const int t = threadIdx.x;
+  if (t < 12 * W) { st->x[t] = x0.Rp[t]; st->xt[t] = x0.Rp[t]; }
+  if (t == 0) { st->u = 0.01; st->v = 2.0; st->calc_hess = 1; st->rejected = 0; }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+// 1/d to fp64 round-off: hardware estimate + two Newton steps (the IEEE division sequence is ~3x longer and sits on
+// the critical path of every elimination step)
+__device__ __forceinline__ double fast_rcp_f64(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
+template <int K, int N>
+struct LmElim {
+  static __device__ __forceinline__ void forward(double (&A)[N > 6 ? N : 7], double& b, double& my_invd, double* colbuf, double* xs, int lane, bool row_ok) {
+    if constexpr (K < N) {
+      colbuf[lane] = A[K];          // lane j publishes A(j,K); symmetric, so this is also row K
+      const double d = readlane_f64(A[K], K);   // pivot and its right-hand side straight from lane K's registers
+      const double bk = readlane_f64(b, K);
+      __builtin_amdgcn_wave_barrier();
+      const double invd = fast_rcp_f64(d);
+      my_invd = (lane == K) ? invd : my_invd;
+      const double l = (lane > K && row_ok) ? A[K] * invd : 0.0;
+#pragma unroll
+      for (int j = K + 1; j < N; j++) A[j] -= l * colbuf[j];
+      b -= l * bk;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      LmElim<K + 1, N>::forward(A, b, my_invd, colbuf, xs, lane, row_ok);
+    }
+  }
+  static __device__ __forceinline__ void backward(double (&A)[N > 6 ? N : 7], double& b, const double my_invd, double& x, double* xs, int lane) {
+    if constexpr (K >= 6) {
+      const double xk = readlane_f64(b * my_invd, K);   // x_K = y_K / pivot_K, broadcast from lane K
+      x = (lane == K) ? xk : x;
+      b -= (lane < K) ? A[K] * xk : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      LmElim<K - 1, N>::backward(A, b, my_invd, x, xs, lane);
+    }
+  }
+};
+
+// Damped solve (H + u D) dxi = -JacT on ONE wave: lane i owns row i of the system in registers, the pivot column is
+// broadcast through LDS, every step is a branch-free rank-1 update -- no barriers, ~n^2/2 FMAs per lane.
+// Elimination runs in natural order without pivoting: after the gauge fix the damped system is (1+u)-diagonally
+// boosted and positive definite wherever LM accepts steps (the reference's Eigen::LDLT pivots on the largest
+// diagonal, voxel_map.hpp:403; both give the same step to round-off on such systems).  Rows/columns 0..5 are the
+// gauge (identity rows, zero right-hand side) and are skipped.
+template <int W>
+__global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, const double* __restrict__ packed) {
+  if (st->done) return;
+  constexpr int n = 6 * W;
+  const int lane = threadIdx.x;
+  __shared__ double colbuf[64];
+  __shared__ double xs[64];
+  const double u = st->u;
+  const bool row_ok = lane < n;
+  const int i = row_ok ? lane : 0;
+
+  // row i of the gauge-fixed system: k3_finalize_kernel left *hess, the gauge-fixed Hessian / gradient and residual1
+  // in the LM state when the Hessian sweep ran; after a rejected step the kept copy is simply reused (with a new u)
+  double A[n > 6 ? n : 7];
+#pragma unroll
+  for (int j = 0; j < n; j++) A[j] = st->Hwork[(size_t)j * n + i];
+  const double rhs = st->Jwork[i];
+  // my diagonal and gradient entry, kept for q1
+  double hii = 0.0;
+#pragma unroll
+  for (int j = 0; j < n; j++) hii = (j == i) ? A[j] : hii;
+  const double gi = rhs;
+  // A = Hess + u D, b = -JacT   (voxel_map.hpp:402-403)
+#pragma unroll
+  for (int j = 0; j < n; j++) A[j] = (j == i) ? A[j] + u * A[j] : A[j];
+  double b = -rhs;
+
+  // forward elimination (rows k = 6 .. n-1) and back substitution, fully unrolled at compile time so that the
+  // row stays in registers (static indices only)
+  double my_invd = 1.0;   // 1 / pivot of my row, captured when the row is eliminated
+  LmElim<6, n>::forward(A, b, my_invd, colbuf, xs, lane, row_ok);
+  double x = 0.0;
+  LmElim<n - 1, n>::backward(A, b, my_invd, x, xs, lane);
+  // dxi, trial state (voxel_map.hpp:405-409), q1 = 0.5 dxi . (u D dxi - JacT) (:410)
+  if (row_ok) st->dxi[i] = x;
+  xs[lane] = row_ok ? x : 0.0;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < W) {
+    double dl[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) dl[k] = xs[6 * lane + k];
+    lm_right_multiply_exp(st->x + 12 * lane, dl, st->xt + 12 * lane);
+    for (int k = 0; k < 3; k++) st->xt[12 * lane + 9 + k] = st->x[12 * lane + 9 + k] + dl[3 + k];
+  }
+  double part = row_ok ? x * (u * hii * x - gi) : 0.0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
+  if (lane == 0) st->q1 = 0.5 * part;
+}
+
+// accept / reject + damping schedule (voxel_map.hpp:411-439).  One workgroup: first the deterministic sum of the
+// residual sweep's wave partials (unless an all-reduced scalar is supplied), then the decision in one lane.
+__global__ __launch_bounds__(256) void lm_update_kernel(LMState* st, const double* __restrict__ d_scalar, const double* __restrict__ partial,
+                                                        int nparts, double* __restrict__ scalar_out, int W) {
+  if (st->done) return;
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  double r2;
+  if (d_scalar) r2 = d_scalar[0];
+  else {
+    double sum = 0.0;
+    for (int k = tid; k < nparts; k += 256) sum += partial[k];
+    red[tid] = sum;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (tid < off) red[tid] += red[tid + off];
+      __syncthreads();
+    }
+    r2 = red[0];
+    if (tid == 0 && scalar_out) scalar_out[0] = r2;
+  }
+  const double r1 = st->residual1, q1 = st->q1, u = st->u, v = st->v;
+  const int it = st->iter, calc = st->calc_hess, bench = st->bench_mode;
+  const double q = r1 - r2;
+  const bool accept = q > 0;
+  __syncthreads();
+  if (accept && tid < 12 * W) st->x[tid] = st->xt[tid];
+  if (tid != 0) return;
+  double* tr = st->trace + 8 * (it < LM_MAX_ITER ? it : LM_MAX_ITER - 1);
+  tr[0] = r1; tr[1] = r2; tr[2] = u; tr[3] = v; tr[4] = q; tr[5] = q1; tr[6] = accept ? 1.0 : 0.0; tr[7] = calc;
+  st->residual2 = r2;
+  if (accept) {
+    const double one_three = 1.0 / 3;
+    const double rho = q / q1;
+    const double g = 1 - pow(2 * rho - 1, 3);
+    st->v = 2;
+    st->u = u * (g < one_three ? one_three : g);
+    st->calc_hess = 1;
+    st->rejected = 0;
+    st->n_accept += 1;
+  } else {
+    st->u = u * v;
+    st->v = 2 * v;
+    st->calc_hess = 0;
+    st->converge = 0;
+    st->rejected = 1;
+    st->n_reject += 1;
+  }
+  st->iter = it + 1;
+  st->resis[1] = r2;
+  if (!bench && fabs((r1 - r2) / r1) < 1e-6) st->done = 1;
+}
+
 // Layout probe for v_mfma_f64_16x16x4_f64 (used by a GPU unit test): D(16x16) = A(16x4) B(4x16) with the operand /
 // result lane maps K3 relies on -- A[i=l%16][k=l/16], B[k=l/16][j=l%16], D[row = l/16 + 4*reg][col = l%16].
 __global__ __launch_bounds__(64) void mfma_probe_kernel(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ D) {
@@ -438,6 +803,14 @@ __global__ __launch_bounds__(64) void mfma_probe_kernel(const double* __restrict
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+void debug_read_stamps(unsigned long long* host, size_t n) {
+  if (n > (size_t)DBG_WAVES * DBG_SLOTS) n = (size_t)DBG_WAVES * DBG_SLOTS;
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg), n * sizeof(unsigned long long));
+}
+void debug_clear_stamps() {
+  static unsigned long long z[DBG_WAVES * DBG_SLOTS];
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof z);
+}
 void launch_mfma_probe(const double* dA, const double* dB, double* dD, hipStream_t s) {
   mfma_probe_kernel<<<dim3(1), dim3(64), 0, s>>>(dA, dB, dD);
 }
@@ -457,10 +830,14 @@ void launch_mfma_probe(const double* dA, const double* dB, double* dD, hipStream
     default: break;                                            \
   }
 
-int launch_k2_residual(const FactorView& fv, const PoseArg& poses, int head, int end, double* d_partial, hipStream_t s) {
+int launch_k2_residual(const FactorView& fv, const PoseArg& poses, const double* d_Rp, const LMState* gate, int gate_mode, int head,
+                       int end, double* d_partial, hipStream_t s) {
   const int nblocks = (end - head + 63) / 64;
   if (nblocks <= 0) return 0;
-  VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, head, end, d_partial));
+  static int dbg = -1;
+  if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
+  if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, d_Rp, gate, gate_mode, head, end, d_partial)); }
+  else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, d_Rp, gate, gate_mode, head, end, d_partial)); }
   return nblocks;
 }
 
@@ -475,14 +852,29 @@ void launch_seed_aux(const FactorView& fv, int head, int end, hipStream_t s) {
 
 int k3_grid_blocks(int device_cus) { return device_cus; }  // one 4-wave workgroup per CU = one wave per SIMD (the kernel needs > 256 VGPRs)
 
-int launch_k3_hessian(const FactorView& fv, const PoseArg& poses, int head, int end, double* d_partial, int nblocks, hipStream_t s) {
-  VXK_DISPATCH_W(fv.W, k3_hessian_kernel<WW><<<dim3(nblocks), dim3(K3_BLOCK), 0, s>>>(fv, poses, head, end, d_partial));
+int launch_k3_hessian(const FactorView& fv, const PoseArg& poses, const double* d_Rp, const LMState* gate, int head, int end,
+                      double* d_partial, int nblocks, hipStream_t s) {
+  VXK_DISPATCH_W(fv.W, {
+    constexpr size_t lds_main = (size_t)4 * 2 * K3Cfg<WW>::WAVE_LDS, lds_epi = (size_t)4 * 64 * (DACC + 1), lds_epi2 = (size_t)4 * 5 * 256;
+    constexpr size_t lds_bytes = (lds_main > lds_epi ? (lds_main > lds_epi2 ? lds_main : lds_epi2) : (lds_epi > lds_epi2 ? lds_epi : lds_epi2)) * sizeof(double);
+    static bool attr_set = false;   // > 64 KB of dynamic LDS must be opted into once per kernel
+    static int dbg = -1;            // development knob: VXBA_DBG=1 runs the s_memtime-instrumented instantiation
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)k3_hessian_kernel<WW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      (void)hipFuncSetAttribute((const void*)k3_hessian_kernel<WW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      const char* ev = getenv("VXBA_DBG");
+      dbg = (ev && ev[0] == '1') ? 1 : 0;
+      attr_set = true;
+    }
+    if (dbg) k3_hessian_kernel<WW, true><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, d_Rp, gate, head, end, d_partial);
+    else k3_hessian_kernel<WW, false><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, d_Rp, gate, head, end, d_partial);
+  });
   return nblocks;
 }
 
-void launch_k3_finalize(const double* d_partial, int nblocks, int W, double* d_packed, hipStream_t s) {
-  const int n = 6 * W, nout = n * n + n + 1;
-  VXK_DISPATCH_W(W, k3_finalize_kernel<WW><<<dim3((nout + 63) / 64), dim3(1024), 0, s>>>(d_partial, nblocks, d_packed));
+void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* gate, double* d_packed, hipStream_t s) {
+  const int plen = (int)k3_partial_len(W);
+  VXK_DISPATCH_W(W, k3_finalize_kernel<WW><<<dim3((plen + 63) / 64), dim3(1024), 0, s>>>(d_partial, nblocks, gate, d_packed));
 }
 
 void launch_k1_build(const double* d_xyz, const int64_t* d_cell_ptr, int n_voxels, int W, const FactorView& fv, int v0, hipStream_t s) {
@@ -498,6 +890,13 @@ void launch_k4_plane_fit(const double* d_clusters, int64_t n, double* d_eigval, 
 
 static inline unsigned nblk(long long n, int b) { return (unsigned)((n + b - 1) / b); }
 
+void launch_build_clb(const FactorView& fv, int v0, int n, hipStream_t s) {
+  if (n <= 0) return;
+  const int nv = k3_nv(fv.W);
+  const int b_lo = v0 / nv, b_hi = (v0 + n - 1) / nv;
+  const int nbatches = b_hi - b_lo + 1;
+  hipLaunchKernelGGL(build_clb_kernel, dim3(nblk((long long)nbatches * 320, 256)), dim3(256), 0, s, fv, nv, v0 + n, b_lo, nbatches);
+}
 void launch_scatter_clusters(const double* d_src, const FactorView& fv, int v0, int n, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(scatter_clusters_kernel, dim3(nblk((long long)n * fv.W, 256)), dim3(256), 0, s, d_src, fv, v0, n);
@@ -525,6 +924,19 @@ void launch_copy_planes(const double* src, int src_vs, double* dst, int dst_vs, 
 void launch_count_nnz(const FactorView& fv, int V, unsigned long long* d_out, hipStream_t s) {
   if (V <= 0) return;
   hipLaunchKernelGGL(count_nnz_kernel, dim3(nblk((long long)V * fv.W, 256)), dim3(256), 0, s, fv, V, d_out);
+}
+
+void launch_lm_init(LMState* st, const PoseArg& x0, int W, int bench_mode, hipStream_t s) {
+  lm_init_kernel<<<dim3(1), dim3(256), 0, s>>>(st, x0, W, bench_mode);
+}
+void launch_lm_restart(LMState* st, const PoseArg& x0, int W, hipStream_t s) {
+  lm_restart_kernel<<<dim3(1), dim3(256), 0, s>>>(st, x0, W);
+}
+void launch_lm_solve(LMState* st, const double* d_packed, int W, hipStream_t s) {
+  VXK_DISPATCH_W(W, lm_solve_kernel<WW><<<dim3(1), dim3(64), 0, s>>>(st, d_packed));
+}
+void launch_lm_update(LMState* st, const double* d_scalar, const double* d_partial, int nparts, double* d_scalar_out, int W, hipStream_t s) {
+  lm_update_kernel<<<dim3(1), dim3(256), 0, s>>>(st, d_scalar, d_partial, nparts, d_scalar_out, W);
 }
 
 }  // namespace vxk

@@ -157,13 +157,14 @@ struct VoxelCache {
   double vbar[3];
   double invN;
   double coe;
+  double sc;         // sqrt(coe)
 };
 
 VX_HD void k3_entry(const double P[6], const double v[3], double n, const double R[9], const double p[3],
                     const VoxelCache& vc, double rows[3][6], double acc[27]) {
   const double* u = vc.u0;
   const double invN = vc.invN;
-  const double sc = sqrt(vc.coe);
+  const double sc = vc.sc;
   // r = R^T u, t = p - vbar
   double r[3], t[3];
 #pragma unroll
@@ -179,23 +180,21 @@ VX_HD void k3_entry(const double P[6], const double v[3], double n, const double
 #pragma unroll
   for (int i = 0; i < 3; i++) c2[i] = (R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2]) + n * t[i];
   const double c2u = dot3(c2, u);
-
   // gradient block g = A^T u = (2/N) [ Pr x r + ut w ; c2u u ]
   double prxr[3];
   cross3(Pr, r, prxr);
   const double two_invN = 2.0 * invN;
   const double cg = vc.coe * two_invN;
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
-    acc[j] += cg * (prxr[j] + ut * w[j]);
-    acc[3 + j] += cg * c2u * u[j];
-  }
-
-  // G rows for y = u1, u2
+  for (int j = 0; j < 3; j++) acc[j] += cg * (prxr[j] + ut * w[j]);
+  const double cgu = cg * c2u;
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const double* y = (k == 0) ? vc.u1 : vc.u2;
-    const double sk = ((k == 0) ? vc.s1 : vc.s2) * invN * sc;
+  for (int j = 0; j < 3; j++) acc[3 + j] += cgu * u[j];
+
+  // G rows for y = u1 (k = 0) and y = u2 (k = 1)
+  {
+    const double* y = vc.u1;
+    const double sk = vc.s1 * invN * sc;
     double q[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) q[j] = R[j] * y[0] + R[3 + j] * y[1] + R[6 + j] * y[2];
@@ -208,17 +207,36 @@ VX_HD void k3_entry(const double P[6], const double v[3], double n, const double
     cross3(q, v, qxv);
     const double yc2 = dot3(y, c2);
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-      rows[k][j] = sk * ((mxr[j] - qxPr[j]) - ut * qxv[j]);
-      rows[k][3 + j] = sk * (yc2 * u[j] + c2u * y[j]);
-    }
+    for (int j = 0; j < 3; j++) rows[0][j] = sk * ((mxr[j] - qxPr[j]) - ut * qxv[j]);
+#pragma unroll
+    for (int j = 0; j < 3; j++) rows[0][3 + j] = sk * (yc2 * u[j] + c2u * y[j]);
+  }
+  {
+    const double* y = vc.u2;
+    const double sk = vc.s2 * invN * sc;
+    double q[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) q[j] = R[j] * y[0] + R[3 + j] * y[1] + R[6 + j] * y[2];
+    const double yt = dot3(y, t);
+    double m[3] = {P[0] * q[0] + P[1] * q[1] + P[2] * q[2] + yt * v[0], P[1] * q[0] + P[3] * q[1] + P[4] * q[2] + yt * v[1],
+                   P[2] * q[0] + P[4] * q[1] + P[5] * q[2] + yt * v[2]};
+    double mxr[3], qxPr[3], qxv[3];
+    cross3(m, r, mxr);
+    cross3(q, Pr, qxPr);
+    cross3(q, v, qxv);
+    const double yc2 = dot3(y, c2);
+#pragma unroll
+    for (int j = 0; j < 3; j++) rows[1][j] = sk * ((mxr[j] - qxPr[j]) - ut * qxv[j]);
+#pragma unroll
+    for (int j = 0; j < 3; j++) rows[1][3 + j] = sk * (yc2 * u[j] + c2u * y[j]);
   }
   // z row
   const double sz = 1.4142135623730951 * invN * sc;
+  const double szn = sz * n;
 #pragma unroll
   for (int j = 0; j < 3; j++) {
     rows[2][j] = sz * w[j];
-    rows[2][3 + j] = sz * n * u[j];
+    rows[2][3 + j] = szn * u[j];
   }
 
   // block-diagonal correction D_i (symmetric):
@@ -230,11 +248,11 @@ VX_HD void k3_entry(const double P[6], const double v[3], double n, const double
   const double Pc0[3] = {P[0], P[1], P[2]}, Pc1[3] = {P[1], P[3], P[4]}, Pc2[3] = {P[2], P[4], P[5]};
   double X0[3], X1[3], X2[3];
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
-    X0[i] = r[2] * Pc1[i] - r[1] * Pc2[i];
-    X1[i] = r[0] * Pc2[i] - r[2] * Pc0[i];
-    X2[i] = r[1] * Pc0[i] - r[0] * Pc1[i];
-  }
+  for (int i = 0; i < 3; i++) X0[i] = r[2] * Pc1[i] - r[1] * Pc2[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) X1[i] = r[0] * Pc2[i] - r[2] * Pc0[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) X2[i] = r[1] * Pc0[i] - r[0] * Pc1[i];
   double S0[3], S1[3], S2[3];  // columns of hat(r) X
   cross3(r, X0, S0);
   cross3(r, X1, S1);
@@ -247,17 +265,21 @@ VX_HD void k3_entry(const double P[6], const double v[3], double n, const double
   acc[9] += cD * ((r[1] * Pr[1] - Prr) + ut * (r[1] * v[1] - vr) - S1[1]);
   acc[10] += cD * (0.5 * (r[1] * Pr[2] + Pr[1] * r[2]) + ut * 0.5 * (r[1] * v[2] + v[1] * r[2]) - 0.5 * (S2[1] + S1[2]));
   acc[11] += cD * ((r[2] * Pr[2] - Prr) + ut * (r[2] * v[2] - vr) - S2[2]);
+  const double cw[3] = {cD * w[0], cD * w[1], cD * w[2]};
 #pragma unroll
-  for (int i = 0; i < 3; i++)
+  for (int j = 0; j < 3; j++) acc[12 + j] += cw[0] * u[j];
 #pragma unroll
-    for (int j = 0; j < 3; j++) acc[12 + 3 * i + j] += cD * w[i] * u[j];
+  for (int j = 0; j < 3; j++) acc[15 + j] += cw[1] * u[j];
+#pragma unroll
+  for (int j = 0; j < 3; j++) acc[18 + j] += cw[2] * u[j];
   const double cT = cD * n;
-  acc[21] += cT * u[0] * u[0];
-  acc[22] += cT * u[0] * u[1];
-  acc[23] += cT * u[0] * u[2];
-  acc[24] += cT * u[1] * u[1];
-  acc[25] += cT * u[1] * u[2];
-  acc[26] += cT * u[2] * u[2];
+  const double cu[3] = {cT * u[0], cT * u[1], cT * u[2]};
+  acc[21] += cu[0] * u[0];
+  acc[22] += cu[0] * u[1];
+  acc[23] += cu[0] * u[2];
+  acc[24] += cu[1] * u[1];
+  acc[25] += cu[1] * u[2];
+  acc[26] += cu[2] * u[2];
 }
 
 }  // namespace vxm

@@ -27,7 +27,7 @@ EXPORTS = [
     "vxba_reserve", "vxba_last_error", "vxba_push_voxels", "vxba_push_points", "vxba_read_clusters", "vxba_acc_evaluate2",
     "vxba_evaluate_only_residual", "vxba_acc_evaluate2_device", "vxba_evaluate_only_residual_device", "vxba_packed_len",
     "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_set_allreduce",
-    "vxba_use_external_buffers", "vxba_damping_iter", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe",
+    "vxba_use_external_buffers", "vxba_damping_iter", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -75,12 +75,13 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_set_allreduce.argtypes = [vp, _ALLREDUCE_FN, vp]
     L.vxba_use_external_buffers.argtypes = [vp, vp, vp]
     L.vxba_damping_iter.argtypes = [vp, _f64p, ci, _f64p, _f64p, _f64p, C.POINTER(ci), C.POINTER(ci)]
-    L.vxba_lm_steps.argtypes = [vp, _f64p, ci, ci, _f64p, _f64p]
+    L.vxba_lm_steps.argtypes = [vp, _f64p, ci, ci, _f64p, _f64p, _i64p]
     L.vxba_set_profiling.argtypes = [vp, ci]
     L.vxba_get_kernel_times.argtypes = [vp, _f64p, _i64p, ci]
     L.vxba_algorithmic_bytes.argtypes = [vp, _f64p]
     L.vxba_nnz.argtypes = [vp, C.POINTER(C.c_int64)]
     L.vxba_debug_mfma_probe.argtypes = [ci, _f64p, _f64p, _f64p]
+    L.vxba_debug_stamps.argtypes = [ci, vp, C.c_size_t]
     _lib = L
     return L
 
@@ -269,9 +270,10 @@ class LidarFactor:
         return v.value
 
     def lm_steps(self, xs_init, n_steps, steps_per_solve=3):
-        out = np.zeros((self.win_size, 12)); resis = np.zeros(2)
-        self._chk(self._L.vxba_lm_steps(self._h, _c(xs_init), int(n_steps), int(steps_per_solve), out, resis))
-        return out, resis
+        """Bench driver: returns (poses, [residual1, residual2] of the last step, dict(iters, accepted, rejected))."""
+        out = np.zeros((self.win_size, 12)); resis = np.zeros(2); st = np.zeros(3, dtype=np.int64)
+        self._chk(self._L.vxba_lm_steps(self._h, _c(xs_init), int(n_steps), int(steps_per_solve), out, resis, st))
+        return out, resis, dict(iters=int(st[0]), accepted=int(st[1]), rejected=int(st[2]))
 
 
 class Lidar_BA_Optimizer:
@@ -308,3 +310,11 @@ def debug_mfma_probe(A, B, device: int = 0):
     if rc != 0:
         raise VxbaError(f"vxba_debug_mfma_probe failed: {_ERRNAMES.get(rc, rc)}")
     return D
+
+
+def debug_stamps(n_waves: int, clear: bool = False):
+    """Per-wave s_memtime stamps of the instrumented kernels: array (n_waves, 32) of uint64."""
+    L = load_library()
+    out = np.zeros((n_waves, 32), dtype=np.uint64)
+    L.vxba_debug_stamps(int(clear), out.ctypes.data_as(C.c_void_p), out.size)
+    return out
