@@ -72,14 +72,8 @@ def main():
     f.set_stream(stream.cuda_stream)
     f.push_points(V, sc.points_body, sc.cell_ptr)          # K1 on the GPU; data now resident in HBM
     if world > 1:
-        xbuf = torch.zeros(f.packed_len() + 1, dtype=torch.float64, device="cuda")
-        packed_t, scalar_t = xbuf[: f.packed_len()], xbuf[f.packed_len():]
-        f.use_external_buffers(packed_t.data_ptr(), scalar_t.data_ptr())
-
-        def hook(ptr, count, _stream):
-            dist.all_reduce(packed_t if count > 1 else scalar_t)
-
-        f.set_allreduce(hook)
+        from voxel_slam_amd import dist as vdist
+        _keep = vdist.attach_allreduce(f)                  # exchange buffers become torch tensors reduced over RCCL
     f.evaluate_only_residual(sc.poses_init)                # seeds the (lambda, U, merged) cache (recut's eig)
     f.snapshot_cache()
     abytes = f.algorithmic_bytes()

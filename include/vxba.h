@@ -129,6 +129,15 @@ int vxba_use_external_buffers(vxba_factor* f, double* d_packed, double* d_scalar
 int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out, double* resis_out, double* trace_out,
                       int* n_trace, int* is_converge);
 
+/* The same LM shell over caller-supplied sweeps (host-only code, needs no GPU): hess_fn must fill `packed`
+ * (vxba_packed_len doubles: Hess col-major | JacT | residual) for poses Rp, resid_fn the residual -- e.g. a local voxel
+ * shard's sweep followed by an all-reduce.  Used to drive voxel-sharded BA from torch.distributed and to test the
+ * N > 1 logic with gloo on CPUs.  Semantics identical to vxba_damping_iter (voxel_map.hpp:367-442). */
+typedef int (*vxba_hess_fn)(void* ctx, const double* Rp, double* packed);
+typedef int (*vxba_resid_fn)(void* ctx, const double* Rp, double* residual);
+int vxba_damping_iter_generic(int win_size, double* Rp, int max_iter, vxba_hess_fn hess_fn, vxba_resid_fn resid_fn, void* ctx,
+                              double* hess_out, double* resis_out, double* trace_out, int* n_trace, int* is_converge);
+
 /* Benchmark driver: exactly n_steps LM iterations of damping_iter WITHOUT the early break; every `steps_per_solve`
  * steps a new solve starts from Rp_init with u = 0.01, v = 2 and the snapshot cache restored (a new window).
  * A rejected step behaves like the reference (no Hessian recompute on the next iteration); stats_out[3] (may be NULL)

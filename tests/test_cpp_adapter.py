@@ -1,0 +1,55 @@
+"""The header-only C++ adapter (include/vxba_lidar_factor.hpp): compiles and links against libvxba.so with stand-in
+Eigen-like types (CPU), and on the GPU reproduces the oracle's BA result when driven the way voxel_map.hpp drives
+``LidarFactor``."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "adapter_demo.cpp")
+EXE = os.path.join(ROOT, "tests", "cpp", "adapter_demo")
+LIBDIR = os.path.join(ROOT, "voxel-slam_amd", "csrc")
+
+
+def build():
+    deps = [SRC, os.path.join(ROOT, "include", "vxba_lidar_factor.hpp"), os.path.join(ROOT, "include", "vxba.h")]
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++14", "-I", os.path.join(ROOT, "include"), SRC, "-o", EXE, "-L", LIBDIR, "-lvxba",
+                               "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"])
+    return EXE
+
+
+def test_adapter_compiles_and_links_as_cxx14():
+    """The reference builds with -std=c++14 (VoxelSLAM/CMakeLists.txt:4-15); the adapter must too."""
+    assert os.path.exists(build())
+
+
+@pytest.mark.gpu
+def test_adapter_end_to_end_matches_oracle(tmp_path):
+    from tests import _oracle as O
+    from voxel_slam_amd import synth
+    exe = build()
+    sc = synth.make_scene(win_size=6, pts_per_scan=4000, n_voxels=333, p_obs=0.9, fix_frac=0.2, seed=77, rot_sigma_deg=0.2, trans_sigma=0.03)
+    max_iter = 4
+    scene = tmp_path / "scene.bin"; out = tmp_path / "out.bin"
+    with open(scene, "wb") as fh:
+        np.array([sc.win_size, sc.n_voxels, max_iter], dtype=np.float64).tofile(fh)
+        sc.clusters.tofile(fh); sc.fix.tofile(fh); sc.coe.tofile(fh); sc.poses_init.tofile(fh)
+    subprocess.check_call([exe, str(scene), str(out)])
+    res = np.fromfile(out, dtype=np.float64)
+    W = sc.win_size
+    poses = res[: 12 * W].reshape(W, 12)
+    r0, resis0, resis1, conv, lam0_first, n_first, h66 = res[12 * W:]
+    f = O.Oracle(W); f.push_voxels(sc.clusters, sc.fix, sc.coe)
+    r0_ref = f.evaluate_only_residual(sc.poses_init)
+    ref = f.damping_iter(sc.poses_init, max_iter=max_iter, thd_num=2)
+    ev, _, m = f.read_cache()
+    et, er = synth.pose_errors(poses, ref["poses"])
+    assert et < 1e-7 and er < 1e-7
+    assert abs(r0 - r0_ref) < 1e-10 * r0_ref
+    assert np.allclose([resis0, resis1], ref["resis"], rtol=1e-9)
+    assert bool(conv) == ref["is_converge"]
+    assert abs(lam0_first - ev[0, 0]) < 1e-9 and n_first == m[0, 9]
+    assert abs(h66 - ref["hess"][6, 6]) < 1e-8 * abs(ref["hess"][6, 6])

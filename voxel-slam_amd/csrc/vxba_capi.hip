@@ -57,7 +57,6 @@ struct vxba_factor {
   double ms_sum[4] = {0, 0, 0, 0};
   int64_t calls[4] = {0, 0, 0, 0};
   std::string err;
-  vxh::LMWorkspace ws;
 };
 
 namespace {
@@ -609,6 +608,48 @@ int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out
   if (trace_out) std::memcpy(trace_out, st.trace, sizeof(double) * VXBA_TRACE_COLS * nt);
   if (n_trace) *n_trace = nt;
   if (is_converge) *is_converge = st.converge;
+  return VXBA_OK;
+}
+
+// Host-only LM shell over caller-supplied sweeps (same control flow as voxel_map.hpp:367-442).
+int vxba_damping_iter_generic(int W, double* Rp, int max_iter, vxba_hess_fn hess_fn, vxba_resid_fn resid_fn, void* ctx, double* hess_out,
+                              double* resis_out, double* trace_out, int* n_trace, int* is_converge) {
+  if (W < 1 || !Rp || max_iter < 0 || !hess_fn || !resid_fn) return VXBA_ERR_ARG;
+  const int n = 6 * W;
+  double u = 0.01, v = 2;
+  std::vector<double> packed((size_t)n * n + n + 1), Hess((size_t)n * n), JacT(n), x(Rp, Rp + 12 * W), x_temp(x);
+  vxh::LMWorkspace ws;
+  double residual1 = 0, residual2 = 0;
+  bool is_calc_hess = true, converge = true;
+  int nt = 0;
+  for (int i = 0; i < max_iter; i++) {
+    const bool recomputed = is_calc_hess;
+    if (is_calc_hess) {
+      if (hess_fn(ctx, x.data(), packed.data()) != 0) return VXBA_ERR_STATE;
+      std::memcpy(Hess.data(), packed.data(), sizeof(double) * n * n);
+      std::memcpy(JacT.data(), packed.data() + (size_t)n * n, sizeof(double) * n);
+      residual1 = packed[(size_t)n * n + n];
+      if (hess_out) std::memcpy(hess_out, Hess.data(), sizeof(double) * n * n);  // *hess = Hess, before the gauge fix
+    }
+    if (i == 0 && resis_out) resis_out[0] = residual1;
+    const double q1 = vxh::lm_damped_step(W, Hess.data(), JacT.data(), u, x.data(), x_temp.data(), ws);
+    if (resid_fn(ctx, x_temp.data(), &residual2) != 0) return VXBA_ERR_STATE;
+    const double q = residual1 - residual2;
+    const double u_used = u, v_used = v;
+    const bool accepted = vxh::lm_update_damping(residual1, residual2, q1, u, v);
+    if (accepted) { x = x_temp; is_calc_hess = true; }
+    else { is_calc_hess = false; converge = false; }
+    if (trace_out) {
+      double* o = trace_out + (size_t)VXBA_TRACE_COLS * nt;
+      o[0] = residual1; o[1] = residual2; o[2] = u_used; o[3] = v_used; o[4] = q; o[5] = q1; o[6] = accepted; o[7] = recomputed;
+    }
+    nt++;
+    if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
+  }
+  if (resis_out) resis_out[1] = residual2;
+  if (n_trace) *n_trace = nt;
+  if (is_converge) *is_converge = converge ? 1 : 0;
+  std::memcpy(Rp, x.data(), sizeof(double) * 12 * W);
   return VXBA_OK;
 }
 

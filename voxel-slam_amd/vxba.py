@@ -20,6 +20,8 @@ TRACE_COLS = 8
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 _ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+_HESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
+_RESID_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 # every symbol include/vxba.h declares (the CPU test suite checks the library exports all of them)
 EXPORTS = [
@@ -27,7 +29,7 @@ EXPORTS = [
     "vxba_reserve", "vxba_last_error", "vxba_push_voxels", "vxba_push_points", "vxba_read_clusters", "vxba_acc_evaluate2",
     "vxba_evaluate_only_residual", "vxba_acc_evaluate2_device", "vxba_evaluate_only_residual_device", "vxba_packed_len",
     "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_set_allreduce",
-    "vxba_use_external_buffers", "vxba_damping_iter", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps",
+    "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -75,6 +77,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_set_allreduce.argtypes = [vp, _ALLREDUCE_FN, vp]
     L.vxba_use_external_buffers.argtypes = [vp, vp, vp]
     L.vxba_damping_iter.argtypes = [vp, _f64p, ci, _f64p, _f64p, _f64p, C.POINTER(ci), C.POINTER(ci)]
+    L.vxba_damping_iter_generic.argtypes = [ci, _f64p, ci, _HESS_FN, _RESID_FN, vp, _f64p, _f64p, _f64p, C.POINTER(ci), C.POINTER(ci)]
     L.vxba_lm_steps.argtypes = [vp, _f64p, ci, ci, _f64p, _f64p, _i64p]
     L.vxba_set_profiling.argtypes = [vp, ci]
     L.vxba_get_kernel_times.argtypes = [vp, _f64p, _i64p, ci]
@@ -288,6 +291,46 @@ class Lidar_BA_Optimizer:
         nt = C.c_int(0); conv = C.c_int(0)
         voxhess._chk(voxhess._L.vxba_damping_iter(voxhess.handle, Rp, int(max_iter), hess, resis, trace, C.byref(nt), C.byref(conv)))
         return dict(poses=Rp, hess=hess.T.copy(), resis=resis, trace=trace[: nt.value].copy(), is_converge=bool(conv.value))
+
+
+def damping_iter_generic(win_size: int, x_stats, hess_fn, resid_fn, max_iter: int = 3):
+    """``Lidar_BA_Optimizer::damping_iter`` over caller-supplied sweeps (host-only; no GPU needed).
+
+    ``hess_fn(xs (W,12)) -> (Hess[r,c] (n,n), JacT (n,), residual)`` and ``resid_fn(xs) -> residual`` -- typically a local
+    voxel shard's sweep followed by an all-reduce (see :mod:`voxel_slam_amd.dist`)."""
+    L = load_library()
+    W = int(win_size); n = 6 * W
+    Rp = _c(x_stats).copy()
+
+    def _h(ctx, rp, packed):
+        try:
+            xs = np.ctypeslib.as_array(rp, shape=(W, 12)).copy()
+            H, J, r = hess_fn(xs)
+            out = np.ctypeslib.as_array(packed, shape=(n * n + n + 1,))
+            out[: n * n] = np.asarray(H, dtype=np.float64).T.reshape(-1)   # column-major on the wire
+            out[n * n: n * n + n] = J
+            out[n * n + n] = r
+            return 0
+        except Exception:  # noqa: BLE001 - must not unwind through C
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _r(ctx, rp, res):
+        try:
+            res[0] = float(resid_fn(np.ctypeslib.as_array(rp, shape=(W, 12)).copy()))
+            return 0
+        except Exception:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    hess = np.zeros((n, n)); resis = np.zeros(2); trace = np.zeros((max(max_iter, 1), TRACE_COLS))
+    nt = C.c_int(0); conv = C.c_int(0)
+    rc = L.vxba_damping_iter_generic(W, Rp, int(max_iter), _HESS_FN(_h), _RESID_FN(_r), None, hess, resis, trace, C.byref(nt), C.byref(conv))
+    if rc != 0:
+        raise VxbaError(f"vxba_damping_iter_generic failed: {_ERRNAMES.get(rc, rc)}")
+    return dict(poses=Rp, hess=hess.T.copy(), resis=resis, trace=trace[: nt.value].copy(), is_converge=bool(conv.value))
 
 
 def plane_fit(clusters, device: int = 0):
