@@ -15,6 +15,12 @@ f.evaluate_only_residual(sc.poses_init)
 for _ in range(3):
     f.acc_evaluate2(sc.poses_init); f.evaluate_only_residual(sc.poses_init)
 vxba.debug_stamps(1, clear=True)
+if which == "solve":
+    from voxel_slam_amd.vxba import Lidar_BA_Optimizer
+    Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=1)
+    st = vxba.debug_stamps(4001).astype(np.int64)[4000, :6]
+    print("solve kernel stamps (cycles since start):", st - st[0])
+    sys.exit(0)
 if which == "k2":
     f.evaluate_only_residual(sc.poses_init); n = (sc.n_voxels + 63) // 64; ns = 5
 else:
@@ -35,3 +41,6 @@ for k in range(ns):
     print(k, "%.2f %.2f %.2f" % (rel[:, k].min(), np.median(rel[:, k]), rel[:, k].max()))
 d = np.diff(st, axis=1) / 100.0
 print("per-phase durations (us): median", np.median(d, axis=0), "max", d.max(axis=0))
+
+if which == "solve":
+    pass

@@ -602,17 +602,22 @@ __device__ __forceinline__ void lm_right_multiply_exp(const double* Rin, const d
   const double th = sqrt(dphi[0] * dphi[0] + dphi[1] * dphi[1] + dphi[2] * dphi[2]);
   double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   if (th >= 1e-11) {
-    const double k0 = dphi[0] / th, k1 = dphi[1] / th, k2 = dphi[2] / th;
-    const double K[9] = {0, -k2, k1, k2, 0, -k0, -k1, k0, 0};
-    double KK[9];
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) KK[3 * r + c] = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
-    const double sn = sin(th), c1 = 1.0 - cos(th);
-    for (int q = 0; q < 9; q++) E[q] += sn * K[q] + c1 * KK[q];
+    const double ith = 1.0 / th;
+    const double k0 = dphi[0] * ith, k1 = dphi[1] * ith, k2 = dphi[2] * ith;
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    const double c1 = 1.0 - cs;
+    // E = I + sin K + (1 - cos) K^2,  K = hat(k):  K^2 = k k^T - I (|k| = 1)
+    E[0] = 1.0 + c1 * (k0 * k0 - 1.0); E[1] = -sn * k2 + c1 * k0 * k1;      E[2] = sn * k1 + c1 * k0 * k2;
+    E[3] = sn * k2 + c1 * k0 * k1;      E[4] = 1.0 + c1 * (k1 * k1 - 1.0); E[5] = -sn * k0 + c1 * k1 * k2;
+    E[6] = -sn * k1 + c1 * k0 * k2;     E[7] = sn * k0 + c1 * k1 * k2;      E[8] = 1.0 + c1 * (k2 * k2 - 1.0);
   }
   double out[9];
+#pragma unroll
   for (int r = 0; r < 3; r++)
+#pragma unroll
     for (int c = 0; c < 3; c++) out[3 * c + r] = Rin[r] * E[c] + Rin[3 + r] * E[3 + c] + Rin[6 + r] * E[6 + c];
+#pragma unroll
   for (int q = 0; q < 9; q++) Rout[q] = out[q];
 }
 
@@ -656,11 +661,17 @@ struct LmElim {
       const double d = readlane_f64(A[K], K);   // pivot and its right-hand side straight from lane K's registers
       const double bk = readlane_f64(b, K);
       __builtin_amdgcn_wave_barrier();
+      // all broadcast reads of the pivot column are issued back to back (the scheduler otherwise pairs every
+      // ds_read with its FMA and exposes the LDS latency 26 times per step), the reciprocal runs in their shadow
+      double col[N - K > 1 ? N - K - 1 : 1];
+#pragma unroll
+      for (int j = K + 1; j < N; j++) col[j - K - 1] = colbuf[j];
       const double invd = fast_rcp_f64(d);
       my_invd = (lane == K) ? invd : my_invd;
       const double l = (lane > K && row_ok) ? A[K] * invd : 0.0;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = K + 1; j < N; j++) A[j] -= l * colbuf[j];
+      for (int j = K + 1; j < N; j++) A[j] -= l * col[j - K - 1];
       b -= l * bk;
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -685,9 +696,11 @@ struct LmElim {
 // boosted and positive definite wherever LM accepts steps (the reference's Eigen::LDLT pivots on the largest
 // diagonal, voxel_map.hpp:403; both give the same step to round-off on such systems).  Rows/columns 0..5 are the
 // gauge (identity rows, zero right-hand side) and are skipped.
-template <int W>
+template <int W, bool DBG = false>
 __global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, const double* __restrict__ packed) {
+  dbg_stamp(DBG, 4000, 0);
   if (st->done) return;
+  dbg_stamp(DBG, 4000, 1);
   constexpr int n = 6 * W;
   const int lane = threadIdx.x;
   __shared__ double colbuf[64];
@@ -715,9 +728,12 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, const double*
   // forward elimination (rows k = 6 .. n-1) and back substitution, fully unrolled at compile time so that the
   // row stays in registers (static indices only)
   double my_invd = 1.0;   // 1 / pivot of my row, captured when the row is eliminated
+  if (DBG) { asm volatile("" :: "v"(A[0]), "v"(A[n - 1]), "v"(b)); dbg_stamp(true, 4000, 2); }
   LmElim<6, n>::forward(A, b, my_invd, colbuf, xs, lane, row_ok);
+  if (DBG) { asm volatile("" :: "v"(A[n - 1]), "v"(b)); dbg_stamp(true, 4000, 3); }
   double x = 0.0;
   LmElim<n - 1, n>::backward(A, b, my_invd, x, xs, lane);
+  if (DBG) { asm volatile("" :: "v"(x)); dbg_stamp(true, 4000, 4); }
   // dxi, trial state (voxel_map.hpp:405-409), q1 = 0.5 dxi . (u D dxi - JacT) (:410)
   if (row_ok) st->dxi[i] = x;
   xs[lane] = row_ok ? x : 0.0;
@@ -733,6 +749,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, const double*
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
   if (lane == 0) st->q1 = 0.5 * part;
+  if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, 4000, 5); }
 }
 
 // accept / reject + damping schedule (voxel_map.hpp:411-439).  One workgroup: first the deterministic sum of the
@@ -933,7 +950,10 @@ void launch_lm_restart(LMState* st, const PoseArg& x0, int W, hipStream_t s) {
   lm_restart_kernel<<<dim3(1), dim3(256), 0, s>>>(st, x0, W);
 }
 void launch_lm_solve(LMState* st, const double* d_packed, int W, hipStream_t s) {
-  VXK_DISPATCH_W(W, lm_solve_kernel<WW><<<dim3(1), dim3(64), 0, s>>>(st, d_packed));
+  static int dbg = -1;
+  if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
+  if (dbg) { VXK_DISPATCH_W(W, lm_solve_kernel<WW, true><<<dim3(1), dim3(64), 0, s>>>(st, d_packed)); }
+  else { VXK_DISPATCH_W(W, lm_solve_kernel<WW><<<dim3(1), dim3(64), 0, s>>>(st, d_packed)); }
 }
 void launch_lm_update(LMState* st, const double* d_scalar, const double* d_partial, int nparts, double* d_scalar_out, int W, hipStream_t s) {
   lm_update_kernel<<<dim3(1), dim3(256), 0, s>>>(st, d_scalar, d_partial, nparts, d_scalar_out, W);
