@@ -11,6 +11,7 @@
 extern "C" {
 
 void vxmh_eig_sym3(const double* C6, double* lam, double* U_rowmajor) { vxm::eig_sym3(C6, lam, U_rowmajor); }
+void vxmh_eig_sym3_warm(const double* C6, const double* Up_rowmajor, double* lam, double* U_rowmajor) { vxm::eig_sym3_warm(C6, Up_rowmajor, lam, U_rowmajor); }
 
 static void pose_rowmajor(const double* Rp, double R[9], double p[3]) {
   for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[3 * r + c] = Rp[3 * c + r];

@@ -24,6 +24,7 @@ def hm():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
     L = C.CDLL(so)
     L.vxmh_eig_sym3.argtypes = [f64p, f64p, f64p]
+    L.vxmh_eig_sym3_warm.argtypes = [f64p, f64p, f64p, f64p]
     L.vxmh_k2.argtypes = [C.c_int, C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, f64p, C.POINTER(C.c_double)]
     L.vxmh_k3.argtypes = [C.c_int, C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p, C.POINTER(C.c_double)]
     return L
@@ -53,6 +54,30 @@ def test_jacobi_eigensolver(hm):
         assert np.allclose(lam, ref, rtol=0, atol=1e-14 * nrm)
         assert np.allclose(U.T @ U, np.eye(3), atol=1e-14)
         assert np.allclose(M @ U, U * lam, atol=2e-14 * nrm)
+
+
+def test_warm_started_eigensolver(hm):
+    """Warm start from a nearby basis (what K2 does between LM iterations), from an exact basis, from garbage."""
+    rng = np.random.default_rng(6)
+    for trial in range(300):
+        Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        lam_true = np.sort(np.array([4e-4 * rng.uniform(0.2, 3), 0.07 * rng.uniform(0.5, 1.5), 0.07 * rng.uniform(0.5, 1.5)]))
+        M = Q @ np.diag(lam_true) @ Q.T; M = 0.5 * (M + M.T)
+        c6 = np.array([M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2]])
+        if trial % 3 == 0:      # nearby basis: previous eigenvectors rotated by a small angle
+            from scipy.spatial.transform import Rotation
+            Up = Q @ Rotation.from_rotvec(rng.normal(size=3) * 1e-3).as_matrix()
+        elif trial % 3 == 1:    # exact previous basis, columns permuted / sign-flipped
+            Up = Q[:, rng.permutation(3)] * rng.choice([-1.0, 1.0], size=3)
+        else:                   # never-written cache (zeros) or non-orthogonal junk -> cold start
+            Up = np.zeros((3, 3)) if trial % 2 else rng.normal(size=(3, 3))
+        lam = np.zeros(3); U = np.zeros(9)
+        hm.vxmh_eig_sym3_warm(c6, np.ascontiguousarray(Up).reshape(9), lam, U)
+        U = U.reshape(3, 3)
+        nrm = np.abs(M).max()
+        assert np.allclose(lam, np.linalg.eigvalsh(M), rtol=0, atol=2e-15 * nrm)
+        assert np.allclose(U.T @ U, np.eye(3), atol=1e-13)
+        assert np.allclose(M @ U, U * lam, atol=4e-15 * nrm + 1e-13 * nrm * (trial % 3 == 0))
 
 
 @pytest.mark.parametrize("p_obs,fix_frac", [(1.0, 0.0), (0.6, 0.4)])

@@ -122,7 +122,7 @@ int ensure_capacity(vxba_factor* f, int n_total) {
   f->planes = np;
   f->clb = nclb;
   f->VS = want;
-  const size_t p2 = (size_t)want / 64 + 1;
+  const size_t p2 = (size_t)want / 64 + 1;   // one partial per wave of 64 voxels
   if (p2 > f->partial2_len) {
     if (f->d_partial2) VX_HIP(f, hipFree(f->d_partial2));
     VX_HIP(f, hipMalloc((void**)&f->d_partial2, p2 * sizeof(double)));

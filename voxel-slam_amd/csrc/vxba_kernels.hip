@@ -31,8 +31,12 @@ __device__ __forceinline__ void dbg_stamp(bool on, int wave_id, int slot) {
 
 // ------------------------------------------------------------------------------------------------
 // K2 -- residual sweep.  One lane per voxel, frames unrolled: every load is a 512 B contiguous row of a
-// frame-major plane, poses are wave-uniform (scalar loads from the kernarg segment), no cross-lane traffic
-// until the final residual reduction.
+// frame-major plane, poses are wave-uniform (scalar loads), no cross-lane traffic until the final residual
+// reduction; the eigensolver is warm-started from the cached eigenvectors.
+// Tried and rejected (measured on MI355X, cfg2): splitting a voxel's frames over 4 lanes (quad shuffles) or over
+// the 4 waves of a 256-thread workgroup (LDS merge, redundant eigensolve) to get ~3 waves per SIMD -- both ran
+// 27-29 us against 17.5 us for this version: the extra pose loads / redundant fp64 work / barrier skew cost more
+// than the hidden dependency stalls buy, because all workgroups start together and sit in the same phase.
 // ------------------------------------------------------------------------------------------------
 template <int W, bool DBG = false>
 __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, const double* __restrict__ d_Rp,
@@ -49,9 +53,14 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
   if (a < end) {
     // issue every load of this voxel up front (10 + 10 W independent 512 B rows per wave): with < 1 wave per
     // SIMD at 50k voxels the sweep is latency-bound unless all of them are in flight together
-    double fx[10], c[W][10];
+    double fx[10], c[W][10], Up[9];
 #pragma unroll
     for (int k = 0; k < 10; k++) fx[k] = fv.fix[k * VS + a];
+    // previous eigenvectors (plane 3*col+row -> row-major): warm start of the eigensolver
+#pragma unroll
+    for (int col = 0; col < 3; col++)
+#pragma unroll
+      for (int row = 0; row < 3; row++) Up[3 * row + col] = fv.eigvec[(size_t)(3 * col + row) * VS + a];
 #pragma unroll
     for (int i = 0; i < W; i++)
 #pragma unroll
@@ -81,7 +90,7 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
     double C[6], lam[3], U[9];
     vxm::cluster_cov(SP, Sv, SN, C);
     if (DBG) { asm volatile("" :: "v"(C[0]), "v"(C[3]), "v"(C[5])); dbg_stamp(true, blockIdx.x, 2); }
-    vxm::eig_sym3(C, lam, U);
+    vxm::eig_sym3_warm(C, Up, lam, U);
     if (DBG) { asm volatile("" :: "v"(lam[0]), "v"(U[0]), "v"(U[8])); dbg_stamp(true, blockIdx.x, 3); }
 #pragma unroll
     for (int k = 0; k < 3; k++) fv.eigval[k * VS + a] = lam[k];

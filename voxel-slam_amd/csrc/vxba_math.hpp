@@ -35,7 +35,7 @@ VX_HD void transform_accumulate(const double P[6], const double v[3], double n, 
   for (int i = 0; i < 3; i++) Rv[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
   const double np[3] = {n * p[0], n * p[1], n * p[2]};
   // symmetric entries (i <= j) of  RP R^T + Rv p^T + p Rv^T + n p p^T
-  const int I[6] = {0, 0, 0, 1, 1, 2}, J[6] = {0, 1, 2, 1, 2, 2};
+  constexpr int I[6] = {0, 0, 0, 1, 1, 2}, J[6] = {0, 1, 2, 1, 2, 2};
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     const int i = I[k], j = J[k];
@@ -53,6 +53,30 @@ VX_HD void transform_accumulate(const double P[6], const double v[3], double n, 
 // SelfAdjointEigenSolver<Matrix3d> at voxel_map.hpp:267,1161,1242; eigenvalues agree to round-off, the
 // eigenvector SIGN is implementation-defined in both (every use on the path is quadratic in u).
 // ---------------------------------------------------------------------------------------------
+// 1/x and 1/sqrt(x) to fp64 round-off without the IEEE division / sqrt expansions (3x shorter dependent chains on
+// the GPU: hardware estimate + Newton steps); plain divisions on the host.
+VX_HD double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+VX_HD double fast_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rsq(x);
+  // two Newton steps: r <- r (1.5 - 0.5 x r^2)
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  return r;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+
 VX_HD void jacobi_rotate(double& app, double& aqq, double& apq, double& arp, double& arq, double* U, int p, int q, bool late) {
   const double g = 100.0 * fabs(apq);
   if (late && (fabs(app) + g == fabs(app)) && (fabs(aqq) + g == fabs(aqq))) {
@@ -63,15 +87,16 @@ VX_HD void jacobi_rotate(double& app, double& aqq, double& apq, double& arp, dou
   const double h = aqq - app;
   double t;
   if (fabs(h) + g == fabs(h)) {
-    t = apq / h;
+    t = apq * fast_rcp(h);
   } else {
-    const double theta = 0.5 * h / apq;
-    t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+    const double theta = 0.5 * h * fast_rcp(apq);
+    const double th2 = 1.0 + theta * theta;
+    t = fast_rcp(fabs(theta) + th2 * fast_rsqrt(th2));
     if (theta < 0.0) t = -t;
   }
-  const double c = 1.0 / sqrt(1.0 + t * t);
+  const double c = fast_rsqrt(1.0 + t * t);
   const double s = t * c;
-  const double tau = s / (1.0 + c);
+  const double tau = s * fast_rcp(1.0 + c);
   const double hh = t * apq;
   app -= hh;
   aqq += hh;
@@ -87,17 +112,20 @@ VX_HD void jacobi_rotate(double& app, double& aqq, double& apq, double& arp, dou
   }
 }
 
-VX_HD void eig_sym3(const double Cin[6], double lam[3], double U[9]) {
-  double a00 = Cin[0], a01 = Cin[1], a02 = Cin[2], a11 = Cin[3], a12 = Cin[4], a22 = Cin[5];
-  U[0] = 1; U[1] = 0; U[2] = 0; U[3] = 0; U[4] = 1; U[5] = 0; U[6] = 0; U[7] = 0; U[8] = 1;
+// Jacobi iteration on (a00..a22) accumulating the rotations into U (row-major, on entry the starting basis);
+// `late_from` = first sweep that may flush negligible off-diagonals.
+VX_HD void jacobi_sweeps(double& a00, double& a01, double& a02, double& a11, double& a12, double& a22, double* U, int late_from) {
   for (int sweep = 0; sweep < 12; sweep++) {
     const double sm = fabs(a01) + fabs(a02) + fabs(a12);
     if (sm == 0.0) break;
-    const bool late = sweep >= 3;
+    const bool late = sweep >= late_from;
     jacobi_rotate(a00, a11, a01, a02, a12, U, 0, 1, late);  // (p,q)=(0,1), other index r=2: a_rp=a02, a_rq=a12
     jacobi_rotate(a00, a22, a02, a01, a12, U, 0, 2, late);  // (0,2), r=1: a_rp=a01, a_rq=a12
     jacobi_rotate(a11, a22, a12, a01, a02, U, 1, 2, late);  // (1,2), r=0: a_rp=a01, a_rq=a02
   }
+}
+
+VX_HD void sort_eigen(double a00, double a11, double a22, double* U, double lam[3]) {
   // ascending sort (3-element network) with column swaps
   double l0 = a00, l1 = a11, l2 = a22;
 #define VXM_SWAPCOL(x, y, cx, cy)                                   \
@@ -110,6 +138,50 @@ VX_HD void eig_sym3(const double Cin[6], double lam[3], double U[9]) {
   VXM_SWAPCOL(l0, l1, 0, 1)
 #undef VXM_SWAPCOL
   lam[0] = l0; lam[1] = l1; lam[2] = l2;
+}
+
+VX_HD void eig_sym3(const double Cin[6], double lam[3], double U[9]) {
+  double a00 = Cin[0], a01 = Cin[1], a02 = Cin[2], a11 = Cin[3], a12 = Cin[4], a22 = Cin[5];
+  U[0] = 1; U[1] = 0; U[2] = 0; U[3] = 0; U[4] = 1; U[5] = 0; U[6] = 0; U[7] = 0; U[8] = 1;
+  jacobi_sweeps(a00, a01, a02, a11, a12, a22, U, 3);
+  sort_eigen(a00, a11, a22, U, lam);
+}
+
+// Warm start: between LM iterations the plane of a voxel barely moves, so C is almost diagonal in the basis of the
+// PREVIOUS eigenvectors Up (row-major): rotate C' = Up^T C Up (exact similarity), iterate on C' from the identity
+// (1-2 sweeps instead of 5-6), and return U = Up V.  Falls back to the cold start if Up is not an orthonormal basis
+// (e.g. a cache that was never written).  Same eigen-decomposition to round-off.
+VX_HD void eig_sym3_warm(const double Cin[6], const double Up[9], double lam[3], double U[9]) {
+  const double n0 = Up[0] * Up[0] + Up[3] * Up[3] + Up[6] * Up[6], n1 = Up[1] * Up[1] + Up[4] * Up[4] + Up[7] * Up[7];
+  const double n2 = Up[2] * Up[2] + Up[5] * Up[5] + Up[8] * Up[8];
+  const double d01 = Up[0] * Up[1] + Up[3] * Up[4] + Up[6] * Up[7], d02 = Up[0] * Up[2] + Up[3] * Up[5] + Up[6] * Up[8];
+  const double d12 = Up[1] * Up[2] + Up[4] * Up[5] + Up[7] * Up[8];
+  const bool ortho = fabs(n0 - 1.0) < 1e-6 && fabs(n1 - 1.0) < 1e-6 && fabs(n2 - 1.0) < 1e-6 && fabs(d01) < 1e-6 && fabs(d02) < 1e-6 &&
+                     fabs(d12) < 1e-6;
+  if (!ortho) { eig_sym3(Cin, lam, U); return; }
+  const double Cm[9] = {Cin[0], Cin[1], Cin[2], Cin[1], Cin[3], Cin[4], Cin[2], Cin[4], Cin[5]};
+  double M[9];  // M = C Up
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) M[3 * i + j] = Cm[3 * i] * Up[j] + Cm[3 * i + 1] * Up[3 + j] + Cm[3 * i + 2] * Up[6 + j];
+  // C' = Up^T M, symmetric entries
+  double a00 = Up[0] * M[0] + Up[3] * M[3] + Up[6] * M[6];
+  double a01 = Up[0] * M[1] + Up[3] * M[4] + Up[6] * M[7];
+  double a02 = Up[0] * M[2] + Up[3] * M[5] + Up[6] * M[8];
+  double a11 = Up[1] * M[1] + Up[4] * M[4] + Up[7] * M[7];
+  double a12 = Up[1] * M[2] + Up[4] * M[5] + Up[7] * M[8];
+  double a22 = Up[2] * M[2] + Up[5] * M[5] + Up[8] * M[8];
+  double V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  jacobi_sweeps(a00, a01, a02, a11, a12, a22, V, 1);
+  double UV[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) UV[3 * i + j] = Up[3 * i] * V[j] + Up[3 * i + 1] * V[3 + j] + Up[3 * i + 2] * V[6 + j];
+  sort_eigen(a00, a11, a22, UV, lam);
+#pragma unroll
+  for (int k = 0; k < 9; k++) U[k] = UV[k];
 }
 
 // Covariance of a merged cluster exactly as the reference forms it (voxel_map.hpp:264-267,
