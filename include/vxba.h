@@ -147,8 +147,9 @@ int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_
                   double* last_resis, int64_t* stats_out);
 
 /* ---- measurement --------------------------------------------------------------------------------- */
-/* When on, every sweep brackets its dominant kernel with hipEvents on the launch stream. */
-int vxba_set_profiling(vxba_factor* f, int on);
+/* Bit mask of kernels to bracket with hipEvents on the launch stream: 1 = Hessian sweep (K3), 2 = residual sweep (K2),
+ * 4 = K3 cross-block reduction, 8 = cluster build (K1); 0 = off. */
+int vxba_set_profiling(vxba_factor* f, int mask);
 /* Sum of kernel durations [ms] and launch counts since the last reset: index 0 = Hessian sweep (K3),
  * 1 = residual sweep (K2), 2 = K3 cross-block reduction, 3 = cluster build (K1). */
 int vxba_get_kernel_times(vxba_factor* f, double ms_sum[4], int64_t calls[4], int reset);

@@ -51,7 +51,7 @@ struct vxba_factor {
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
   vxba_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
-  bool profiling = false;
+  int profiling = 0;             // bit mask of kernel kinds to bracket with events: 1 K3, 2 K2, 4 K3 finalize, 8 K1
   std::vector<EventPair> pending;
   std::vector<hipEvent_t> free_events;
   double ms_sum[4] = {0, 0, 0, 0};
@@ -158,12 +158,13 @@ hipEvent_t get_event(vxba_factor* f) {
   return e;
 }
 struct ScopedKernelTimer {
-  vxba_factor* f; int kind; hipEvent_t a = nullptr, b = nullptr;
+  vxba_factor* f; int kind; int on = 0; hipEvent_t a = nullptr, b = nullptr;
   ScopedKernelTimer(vxba_factor* f_, int kind_) : f(f_), kind(kind_) {
-    if (f->profiling) { a = get_event(f); b = get_event(f); if (a) hipEventRecord(a, f->stream); }
+    on = (f->profiling >> kind_) & 1;
+    if (on) { a = get_event(f); b = get_event(f); if (a) hipEventRecord(a, f->stream); }
   }
   ~ScopedKernelTimer() {
-    if (f->profiling && a && b) { hipEventRecord(b, f->stream); f->pending.push_back({a, b, kind}); }
+    if (on && a && b) { hipEventRecord(b, f->stream); f->pending.push_back({a, b, kind}); }
   }
 };
 int drain_events(vxba_factor* f) {
@@ -182,7 +183,8 @@ int drain_events(vxba_factor* f) {
 // ---- sweeps (asynchronous on f->stream; results in device memory) ----
 // Poses come either by value (Rp, host pointer -> kernel argument) or from device memory (d_Rp, e.g. the LM state);
 // `gate` lets the GPU skip the work when the device-resident LM loop does not need it.
-int sweep_hess_device(vxba_factor* f, const double* Rp, const double* d_Rp, vxk::LMState* gate, int head, int end, double* d_out) {
+int sweep_hess_device(vxba_factor* f, const double* Rp, const double* d_Rp, vxk::LMState* gate, int head, int end, double* d_out,
+                      const double* cache_src = nullptr) {
   const size_t plen = vxba_packed_len(f);
   if (end == head) { VX_HIP(f, hipMemsetAsync(d_out, 0, plen * sizeof(double), f->stream)); return VXBA_OK; }
   int rc = ensure_partials3(f);
@@ -196,7 +198,7 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, const double* d_Rp, vxk:
   const int nblocks = std::max(1, std::min(vxk::k3_grid_blocks(f->cus), (nbatches + 3) / 4));
   {
     ScopedKernelTimer t(f, 0);
-    vxk::launch_k3_hessian(fv, pa, d_Rp, gate, head, end, f->d_partial3, nblocks, f->stream);
+    vxk::launch_k3_hessian(fv, pa, d_Rp, gate, cache_src, head, end, f->d_partial3, nblocks, f->stream);
   }
   {
     ScopedKernelTimer t(f, 2);
@@ -595,7 +597,7 @@ int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out
     int nparts = 0;
     rc = sweep_residual_device(f, nullptr, f->d_lm->xt, f->d_lm, 0, 0, f->V, f->allreduce ? f->d_scalar : nullptr, &nparts);
     if (rc) return rc;
-    vxk::launch_lm_update(f->d_lm, f->allreduce ? f->d_scalar : nullptr, f->d_partial2, nparts, f->d_scalar, W, f->stream);
+    vxk::launch_lm_update(f->d_lm, f->allreduce ? f->d_scalar : nullptr, f->d_partial2, nparts, f->d_scalar, W, nullptr, f->stream);
   }
   VX_HIP(f, hipGetLastError());
   VX_HIP(f, hipMemcpyAsync(f->h_lm, f->d_lm, sizeof(vxk::LMState), hipMemcpyDeviceToHost, f->stream));
@@ -661,21 +663,21 @@ int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_
   const int W = f->W;
   PoseArg x0;
   fill_poses(f, Rp_init, x0);
+  if (!f->snapshot || f->snapshot_v != f->V || f->snapshot_vs != f->VS) return fail(f, VXBA_ERR_STATE, "lm_steps needs vxba_snapshot_cache first");
   vxk::launch_lm_init(f->d_lm, x0, W, 1, f->stream);
   for (int s = 0; s < n_steps; s++) {
-    if (s % steps_per_solve == 0) {  // a new window: initial guess, fresh damping, re-seeded cache
-      if (s > 0) vxk::launch_lm_restart(f->d_lm, x0, W, f->stream);
-      int rc = vxba_restore_cache(f);
-      if (rc) return rc;
-    }
-    int rc = sweep_hess_device(f, nullptr, f->d_lm->x, f->d_lm, 0, f->V, f->d_packed);   // skipped on the GPU after a rejected step, like the reference
+    // a new window every steps_per_solve steps: its first Hessian sweep reads the SNAPSHOT cache directly (the re-seeded
+    // cache of a new window -- no copy), the residual sweeps keep writing the live cache; the previous step's update
+    // kernel already reset poses and damping
+    const bool first = (s % steps_per_solve) == 0;
+    const bool last = ((s + 1) % steps_per_solve) == 0 && s + 1 < n_steps;
+    int rc = sweep_hess_device(f, nullptr, f->d_lm->x, f->d_lm, 0, f->V, f->d_packed, first ? f->snapshot : nullptr);
     if (rc) return rc;
     vxk::launch_lm_solve(f->d_lm, f->d_packed, W, f->stream);
-    // residual sweep at the trial state; without a collective its wave partials are summed inside the update kernel
     int nparts = 0;
     rc = sweep_residual_device(f, nullptr, f->d_lm->xt, f->d_lm, 0, 0, f->V, f->allreduce ? f->d_scalar : nullptr, &nparts);
     if (rc) return rc;
-    vxk::launch_lm_update(f->d_lm, f->allreduce ? f->d_scalar : nullptr, f->d_partial2, nparts, f->d_scalar, W, f->stream);
+    vxk::launch_lm_update(f->d_lm, f->allreduce ? f->d_scalar : nullptr, f->d_partial2, nparts, f->d_scalar, W, last ? &x0 : nullptr, f->stream);
   }
   VX_HIP(f, hipGetLastError());
   VX_HIP(f, hipMemcpyAsync(f->h_lm, f->d_lm, sizeof(vxk::LMState), hipMemcpyDeviceToHost, f->stream));
@@ -707,7 +709,7 @@ int vxba_debug_stamps(int clear, unsigned long long* out, size_t n) {
 
 int vxba_set_profiling(vxba_factor* f, int on) {
   if (!f) return VXBA_ERR_ARG;
-  f->profiling = on != 0;
+  f->profiling = on;
   return VXBA_OK;
 }
 

@@ -80,17 +80,20 @@ void launch_seed_aux(const FactorView& fv, int head, int end, hipStream_t s);
 
 // K3: Hessian/gradient sweep over voxels [head,end) into per-workgroup partials; returns #workgroups.
 int k3_grid_blocks(int device_cus);
-int launch_k3_hessian(const FactorView& fv, const PoseArg& poses, const double* d_Rp, const LMState* gate, int head, int end,
-                      double* d_partial, int nblocks, hipStream_t s);
+// cache_src (nullable): read the (lambda, U, merged, aux) cache planes from this base instead of fv's live cache --
+// used to start a new window from the snapshot without copying it back first.
+int launch_k3_hessian(const FactorView& fv, const PoseArg& poses, const double* d_Rp, const LMState* gate, const double* cache_src,
+                      int head, int end, double* d_partial, int nblocks, hipStream_t s);
 // Cross-workgroup reduction + assembly of the packed [Hess (6W)^2 col-major | JacT 6W | residual] buffer.
 void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* gate, double* d_packed, hipStream_t s);
 
 // LM shell on the device: init (poses, damping, flags), damped solve + trial state, accept/reject.
 void launch_lm_init(LMState* st, const PoseArg& x0, int W, int bench_mode, hipStream_t s);
-void launch_lm_restart(LMState* st, const PoseArg& x0, int W, hipStream_t s);
 void launch_lm_solve(LMState* st, const double* d_packed, int W, hipStream_t s);
 // d_scalar != null: use that (all-reduced) residual; else sum the nparts wave partials of the residual sweep here.
-void launch_lm_update(LMState* st, const double* d_scalar, const double* d_partial, int nparts, double* d_scalar_out, int W, hipStream_t s);
+// restart_x0 != null: after the decision, start a new window (poses <- x0, fresh damping) -- the bench driver's solve boundary.
+void launch_lm_update(LMState* st, const double* d_scalar, const double* d_partial, int nparts, double* d_scalar_out, int W,
+                      const PoseArg* restart_x0, hipStream_t s);
 
 // K1: clusters of n_voxels*W cells from bucketed points (cell = frame*n_voxels + voxel), written to the
 // frame-major planes at voxel offset v0.

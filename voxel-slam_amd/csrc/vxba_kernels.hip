@@ -14,6 +14,7 @@
 #include "vxba_kernels.h"
 
 #include <cstdlib>
+#include <cstring>
 
 #include "vxba_math.hpp"
 
@@ -640,13 +641,6 @@ __global__ __launch_bounds__(256) void lm_init_kernel(LMState* st, PoseArg x0, i
     st->n_accept = 0; st->n_reject = 0;
   }
 }
-// bench mode: a new window starts -- initial guess and fresh damping, iteration counter keeps running
-__global__ __launch_bounds__(256) void lm_restart_kernel(LMState* st, PoseArg x0, int W) {
-  const int t = threadIdx.x;
-  if (t < 12 * W) { st->x[t] = x0.Rp[t]; st->xt[t] = x0.Rp[t]; }
-  if (t == 0) { st->u = 0.01; st->v = 2.0; st->calc_hess = 1; st->rejected = 0; }
-}
-
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, l);
@@ -764,7 +758,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, const double*
 // accept / reject + damping schedule (voxel_map.hpp:411-439).  One workgroup: first the deterministic sum of the
 // residual sweep's wave partials (unless an all-reduced scalar is supplied), then the decision in one lane.
 __global__ __launch_bounds__(256) void lm_update_kernel(LMState* st, const double* __restrict__ d_scalar, const double* __restrict__ partial,
-                                                        int nparts, double* __restrict__ scalar_out, int W) {
+                                                        int nparts, double* __restrict__ scalar_out, int W, int restart, PoseArg x0) {
   if (st->done) return;
   __shared__ double red[256];
   const int tid = threadIdx.x;
@@ -787,7 +781,9 @@ __global__ __launch_bounds__(256) void lm_update_kernel(LMState* st, const doubl
   const double q = r1 - r2;
   const bool accept = q > 0;
   __syncthreads();
-  if (accept && tid < 12 * W) st->x[tid] = st->xt[tid];
+  if (restart) {   // bench driver: the next step starts a new window from the initial guess
+    if (tid < 12 * W) { st->x[tid] = x0.Rp[tid]; st->xt[tid] = x0.Rp[tid]; }
+  } else if (accept && tid < 12 * W) st->x[tid] = st->xt[tid];
   if (tid != 0) return;
   double* tr = st->trace + 8 * (it < LM_MAX_ITER ? it : LM_MAX_ITER - 1);
   tr[0] = r1; tr[1] = r2; tr[2] = u; tr[3] = v; tr[4] = q; tr[5] = q1; tr[6] = accept ? 1.0 : 0.0; tr[7] = calc;
@@ -812,6 +808,7 @@ __global__ __launch_bounds__(256) void lm_update_kernel(LMState* st, const doubl
   st->iter = it + 1;
   st->resis[1] = r2;
   if (!bench && fabs((r1 - r2) / r1) < 1e-6) st->done = 1;
+  if (restart) { st->u = 0.01; st->v = 2.0; st->calc_hess = 1; st->rejected = 0; }
 }
 
 // Layout probe for v_mfma_f64_16x16x4_f64 (used by a GPU unit test): D(16x16) = A(16x4) B(4x16) with the operand /
@@ -878,8 +875,16 @@ void launch_seed_aux(const FactorView& fv, int head, int end, hipStream_t s) {
 
 int k3_grid_blocks(int device_cus) { return device_cus; }  // one 4-wave workgroup per CU = one wave per SIMD (the kernel needs > 256 VGPRs)
 
-int launch_k3_hessian(const FactorView& fv, const PoseArg& poses, const double* d_Rp, const LMState* gate, int head, int end,
-                      double* d_partial, int nblocks, hipStream_t s) {
+int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, const double* d_Rp, const LMState* gate, const double* cache_src,
+                      int head, int end, double* d_partial, int nblocks, hipStream_t s) {
+  FactorView fv = fv_in;
+  if (cache_src) {   // eigval(3) eigvec(9) merged(10) aux(4): 26 consecutive planes
+    const size_t VS = (size_t)fv.VS;
+    fv.eigval = const_cast<double*>(cache_src);
+    fv.eigvec = fv.eigval + 3 * VS;
+    fv.merged = fv.eigvec + 9 * VS;
+    fv.aux = fv.merged + 10 * VS;
+  }
   VXK_DISPATCH_W(fv.W, {
     constexpr size_t lds_main = (size_t)4 * 2 * K3Cfg<WW>::WAVE_LDS, lds_epi = (size_t)4 * 64 * (DACC + 1), lds_epi2 = (size_t)4 * 5 * 256;
     constexpr size_t lds_bytes = (lds_main > lds_epi ? (lds_main > lds_epi2 ? lds_main : lds_epi2) : (lds_epi > lds_epi2 ? lds_epi : lds_epi2)) * sizeof(double);
@@ -955,17 +960,17 @@ void launch_count_nnz(const FactorView& fv, int V, unsigned long long* d_out, hi
 void launch_lm_init(LMState* st, const PoseArg& x0, int W, int bench_mode, hipStream_t s) {
   lm_init_kernel<<<dim3(1), dim3(256), 0, s>>>(st, x0, W, bench_mode);
 }
-void launch_lm_restart(LMState* st, const PoseArg& x0, int W, hipStream_t s) {
-  lm_restart_kernel<<<dim3(1), dim3(256), 0, s>>>(st, x0, W);
-}
 void launch_lm_solve(LMState* st, const double* d_packed, int W, hipStream_t s) {
   static int dbg = -1;
   if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
   if (dbg) { VXK_DISPATCH_W(W, lm_solve_kernel<WW, true><<<dim3(1), dim3(64), 0, s>>>(st, d_packed)); }
   else { VXK_DISPATCH_W(W, lm_solve_kernel<WW><<<dim3(1), dim3(64), 0, s>>>(st, d_packed)); }
 }
-void launch_lm_update(LMState* st, const double* d_scalar, const double* d_partial, int nparts, double* d_scalar_out, int W, hipStream_t s) {
-  lm_update_kernel<<<dim3(1), dim3(256), 0, s>>>(st, d_scalar, d_partial, nparts, d_scalar_out, W);
+void launch_lm_update(LMState* st, const double* d_scalar, const double* d_partial, int nparts, double* d_scalar_out, int W,
+                      const PoseArg* restart_x0, hipStream_t s) {
+  PoseArg x0;
+  if (restart_x0) x0 = *restart_x0; else memset(&x0, 0, sizeof x0);
+  lm_update_kernel<<<dim3(1), dim3(256), 0, s>>>(st, d_scalar, d_partial, nparts, d_scalar_out, W, restart_x0 ? 1 : 0, x0);
 }
 
 }  // namespace vxk

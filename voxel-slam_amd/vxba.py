@@ -253,8 +253,9 @@ class LidarFactor:
         self._chk(self._L.vxba_use_external_buffers(self._h, C.c_void_p(d_packed_ptr or 0), C.c_void_p(d_scalar_ptr or 0)))
 
     # -- measurement ----------------------------------------------------------------------------
-    def set_profiling(self, on: bool):
-        self._chk(self._L.vxba_set_profiling(self._h, int(bool(on))))
+    def set_profiling(self, mask: int):
+        """Bit mask of kernels to time with events: 1 K3, 2 K2, 4 K3 finalize, 8 K1 (0 = off)."""
+        self._chk(self._L.vxba_set_profiling(self._h, int(mask)))
 
     def kernel_times(self, reset=False):
         ms = np.zeros(4); calls = np.zeros(4, dtype=np.int64)
