@@ -309,28 +309,44 @@ __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, 
   dbg_stamp(DBG, gw, 0);
 
   if (b0 + gw <= b1) {
-    K3Entry cur, nxt;
+    // two entry register sets in ping-pong (loop unrolled by two: no register copies, LDS buffer index is static)
+    K3Entry e0, e1;
     double rows[3][6];
-    k3_load_entry<W>(fv, head, end, b1, b0 + gw, active, vl, lane, cur);
-    k3_load_entry<W>(fv, head, end, b1, b0 + gw + nw, active, vl, lane, nxt);
+    double* lds0 = ldsw;
+    double* lds1 = ldsw + C::WAVE_LDS;
+    k3_load_entry<W>(fv, head, end, b1, b0 + gw, active, vl, lane, e0);
+    k3_load_entry<W>(fv, head, end, b1, b0 + gw + nw, active, vl, lane, e1);
     if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 1); }
-    k3_phase_a(cur, fi, R, p, rows, dacc);
-    k3_store_rows<W>(ldsw, active, vl, fi, rows);
+    k3_phase_a(e0, fi, R, p, rows, dacc);
+    k3_store_rows<W>(lds0, active, vl, fi, rows);
     __builtin_amdgcn_wave_barrier();
     if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 2); }
-    int buf = 1;
+    int pending = 0;   // LDS buffer holding the rows whose MFMAs are still to run
     int it_dbg = 0;
-    for (int b = b0 + gw + nw; b <= b1; b += nw) {
+    int b = b0 + gw + nw;
+    while (b <= b1) {
       if (DBG && it_dbg < 10) { dbg_stamp(true, gw, 8 + 2 * it_dbg); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 9 + 2 * it_dbg); it_dbg++; }
-      cur = nxt;
-      k3_load_entry<W>(fv, head, end, b1, b + nw, active, vl, lane, nxt);
-      k3_mfma_tile<W>(ldsw + (buf ^ 1) * C::WAVE_LDS, lrow, lcol, acc);   // batch b - nw
-      k3_phase_a(cur, fi, R, p, rows, dacc);                               // batch b
-      k3_store_rows<W>(ldsw + buf * C::WAVE_LDS, active, vl, fi, rows);
+      // batch b sits in e1: prefetch b + nw into e0, MFMAs of the previous batch (lds0), phase A of b -> lds1
+      k3_load_entry<W>(fv, head, end, b1, b + nw, active, vl, lane, e0);
+      k3_mfma_tile<W>(lds0, lrow, lcol, acc);
+      k3_phase_a(e1, fi, R, p, rows, dacc);
+      k3_store_rows<W>(lds1, active, vl, fi, rows);
       __builtin_amdgcn_wave_barrier();
-      buf ^= 1;
+      b += nw;
+      pending = 1;
+      if (b > b1) break;
+      if (DBG && it_dbg < 10) { dbg_stamp(true, gw, 8 + 2 * it_dbg); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 9 + 2 * it_dbg); it_dbg++; }
+      // batch b sits in e0: prefetch into e1, MFMAs of lds1, phase A -> lds0
+      k3_load_entry<W>(fv, head, end, b1, b + nw, active, vl, lane, e1);
+      k3_mfma_tile<W>(lds1, lrow, lcol, acc);
+      k3_phase_a(e0, fi, R, p, rows, dacc);
+      k3_store_rows<W>(lds0, active, vl, fi, rows);
+      __builtin_amdgcn_wave_barrier();
+      b += nw;
+      pending = 0;
     }
-    k3_mfma_tile<W>(ldsw + (buf ^ 1) * C::WAVE_LDS, lrow, lcol, acc);
+    if (pending) k3_mfma_tile<W>(lds1, lrow, lcol, acc);
+    else k3_mfma_tile<W>(lds0, lrow, lcol, acc);
     if (DBG) { asm volatile("" :: "v"(acc[0][0])); dbg_stamp(true, gw, 3); }
   }
 
