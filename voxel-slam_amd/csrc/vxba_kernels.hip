@@ -270,8 +270,14 @@ __device__ __forceinline__ void k3_mfma_tile(const double* ldsb, int lrow, int l
 //       ~340 cycles of a ~6200-cycle iteration, i.e. HBM latency is hidden),
 //   (2) the f64 MFMAs of batch b-1, fed from LDS buffer (b-1)&1, and
 //   (3) the phase-A VALU work of batch b, written to LDS buffer b&1.
-// Measured on MI355X: f64 MFMA and f64 VALU do NOT overlap (pinning one MFMA between every ~9 VALU ops with
-// sched_barrier made the kernel slower), so the loop is bound by the sum of both fp64 instruction streams.
+// Measured on MI355X (scripts/ubench/fp64_peaks.hip): one wave issues v_mfma_f64_16x16x4_f64 every ~139 cycles (~97
+// with two waves per SIMD, i.e. ~45 TFLOP/s chip-wide), f64 VALU FMA issues every 4.45 cycles (~56-61 TFLOP/s), and the
+// two do NOT overlap: pinning one MFMA between every ~9 VALU ops with sched_barrier made this kernel slower, so the
+// loop is bound by the sum of both fp64 instruction streams.
+// Also tried and rejected: doing the contraction on the VALU instead (one lane per 6x6 frame-pair block, exact upper
+// triangle, 36 FMAs per row).  It needs 12 LDS doubles per 36 FMAs -- 216 doubles per lane and batch against the
+// MFMA form's 20 -- and ran LDS-bandwidth-bound at 45.8 us vs 32-33 us: the matrix core's operand reuse wins even
+// though its raw f64 rate is lower than the VALU's.
 template <int W, bool DBG = false>
 __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, PoseArg poses, const double* __restrict__ d_Rp,
                                                                  const LMState* __restrict__ gate, int head, int end,
