@@ -26,6 +26,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP64_MFMA_MEASURED_TFLOPS = 45.0   # v_mfma_f64_16x16x4_f64, two waves per SIMD, scripts/ubench/fp64_peaks.hip on MI355X
+FP64_SPEC_TFLOPS = 78.6            # vendor figure (not in the local guide)
+
+
+def pmc_traffic_bytes(kernel_key):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/*/pmc_hbm_counters.json):
+    FETCH_SIZE x 2 (the guide's gfx950 correction for wide coalesced reads) + WRITE_SIZE, both reported in KB."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_counters.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    try:
+        f = [v["mean"] for k, v in d["FETCH_SIZE_KB_mean_per_launch"].items() if kernel_key in k][0]
+        w = [v["mean"] for k, v in d["WRITE_SIZE_KB_mean_per_launch"].items() if kernel_key in k][0]
+    except (KeyError, IndexError):
+        return None, None
+    return (2.0 * f + w) * 1024.0, os.path.relpath(files[-1], ROOT)
 
 
 def main():
@@ -113,6 +131,10 @@ def main():
         k2_ms = kt2["k2_residual"]["ms_sum"] / max(1, kt2["k2_residual"]["calls"])
         k3f_ms = kt2["k3_finalize"]["ms_sum"] / max(1, kt2["k3_finalize"]["calls"])
         achieved = abytes["k3"] / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic_bytes("k3_hessian_kernel")
+        # fp64 work of one K3 launch: MFMA SYRK (batches x 50 x 16x16x4x2) + phase A (~300 f64 ops per entry)
+        nbatch = (V + 5) // 6 if W == 10 else 0
+        k3_flops = nbatch * 50 * 2048.0 + nnz * 300.0 * 1.8 if W == 10 else None
         out = {
             "metric": "BA iterations/sec (10-frame window, 100k pts/scan)",
             "value": world * args.steps / elapsed,
@@ -142,8 +164,13 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": abytes["k3"],
+                "fp64": None if not k3_flops else {
+                    "note": "K3 is bound by the f64 matrix pipe, not HBM (DESIGN.md section 4)",
+                    "flops_per_launch": k3_flops, "achieved_tflops": k3_flops / (k3_ms * 1e-3) / 1e12,
+                    "mfma_f64_measured_peak_tflops": FP64_MFMA_MEASURED_TFLOPS, "vendor_spec_tflops": FP64_SPEC_TFLOPS},
                 "avg_launch_ms": k3_ms,
                 "launches": kt["k3_hessian"]["calls"],
                 "k2_residual": {"avg_launch_ms": k2_ms, "algorithmic_bytes_per_launch": abytes["k2"],
