@@ -109,6 +109,16 @@ int vxba_restore_cache(vxba_factor* f);
 /* eig(pcr.cov()) for n clusters (OctoTree::recut voxel_map.hpp:1161-1163, margi :1242-1244,
  * OctreeGBA::recut loop_refine.hpp:363-366).  Stand-alone; runs on `device`. */
 int vxba_plane_fit(int device, int64_t n, const double* clusters, double* eig_val, double* eig_vec);
+/* The same with the reference's plane criteria evaluated on the GPU; flags[a] is a bit set:
+ *   1 = enough points       N > min_point                                   (voxel_map.hpp:1155, loop_refine.hpp:360)
+ *   2 = plane_judge         lambda0 < min_eigen_value && lambda0/lambda2 < eigen_ratio_thre   (voxel_map.hpp:1015-1019)
+ *   4 = factor-worthy       lambda0/lambda1 <= factor_ratio_max (0.12 upstream)   (voxel_map.hpp:1314, loop_refine.hpp:378) */
+int vxba_plane_fit_judge(int device, int64_t n, const double* clusters, int min_point, double min_eigen_value, double eigen_ratio_thre,
+                         double factor_ratio_max, double* eig_val, double* eig_vec, uint8_t* flags);
+/* Stand-alone K1: PointCluster::push over n_cells buckets of points (cell_ptr has n_cells + 1 entries) -> n_cells packed
+ * clusters.  Same kernel arithmetic as vxba_push_points (bit-exact with the CPU); use it for world-frame fix clusters
+ * (OctoTree::push_fix, voxel_map.hpp:996-1013) or to rebuild clusters from stored points (loop_refine.hpp:382-385). */
+int vxba_build_clusters(int device, int64_t n_cells, int64_t n_points, const double* xyz, const int64_t* cell_ptr, double* clusters);
 
 /* ---- the LM shell that owns the loop ------------------------------------------------------------ */
 /* Collective hook for voxel-sharded multi-GPU BA: called on the packed device buffer after each sweep's

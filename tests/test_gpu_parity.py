@@ -184,6 +184,30 @@ def test_k4_plane_fit_matches_oracle(vx):
     assert np.all(d[:, 0] > 1 - 1e-8)
 
 
+def test_k4_plane_criteria_flags_and_standalone_k1(vx):
+    """plane_judge / min_point / factor filter on the GPU (voxel_map.hpp:1015-1019,1155,1314) and K1 for fix clusters."""
+    rng = np.random.default_rng(8)
+    sc = synth.make_scene(win_size=3, pts_per_scan=3000, n_voxels=400, seed=62)
+    # world-frame fix clusters from raw points (OctoTree::push_fix): K1 stand-alone, bit-exact with the CPU
+    counts = rng.integers(0, 40, size=400); counts[::7] = 0
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    pts = rng.normal(size=(int(ptr[-1]), 3)) * np.array([0.4, 0.4, 0.02]) + rng.normal(size=3) * 20
+    cl = vx.build_clusters(pts, ptr)
+    assert np.array_equal(cl, O.build_clusters(pts, ptr))
+    keep = cl[:, 9] > 0
+    ev, U, fl = vx.plane_fit_judge(cl[keep], min_point=5, min_eigen_value=0.0025, eigen_ratio_thre=0.05, factor_ratio_max=0.12)
+    ev_ref, _ = O.plane_fit(cl[keep])
+    N = cl[keep][:, 9]
+    ok = np.isfinite(ev_ref).all(axis=1)
+    ref = (N > 5).astype(np.uint8) | (((ev_ref[:, 0] < 0.0025) & (ev_ref[:, 0] / ev_ref[:, 2] < 0.05)).astype(np.uint8) << 1) \
+        | ((~(ev_ref[:, 0] / ev_ref[:, 1] > 0.12)).astype(np.uint8) << 2)
+    # compare where the criteria are not within round-off of a threshold
+    margin = (np.abs(ev_ref[:, 0] - 0.0025) > 1e-9) & (np.abs(ev_ref[:, 0] / ev_ref[:, 2] - 0.05) > 1e-9) & (np.abs(ev_ref[:, 0] / ev_ref[:, 1] - 0.12) > 1e-9)
+    sel = ok & margin & (N > 3)
+    assert sel.sum() > 200 and np.array_equal(fl[sel], ref[sel])
+    assert set(np.unique(fl[sel])) - {0, 1, 4, 5, 7, 3, 2, 6} == set()
+
+
 # ---------------------------------------------------------------------------------------------------- LM
 def check_lm_parity(vx, sc, max_iter):
     fo, fg = seeded_pair(vx, sc)

@@ -555,24 +555,56 @@ int vxba_restore_cache(vxba_factor* f) {
   return VXBA_OK;
 }
 
-int vxba_plane_fit(int device, int64_t n, const double* clusters, double* eig_val, double* eig_vec) {
+int vxba_plane_fit_judge(int device, int64_t n, const double* clusters, int min_point, double min_eigen_value, double eigen_ratio_thre,
+                         double factor_ratio_max, double* eig_val, double* eig_vec, uint8_t* flags) {
   if (n < 0 || (n > 0 && (!clusters || !eig_val || !eig_vec))) return VXBA_ERR_ARG;
   if (n == 0) return VXBA_OK;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VXBA_ERR_NODEV;
   if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_HIP;
   double *d_c = nullptr, *d_l = nullptr, *d_u = nullptr;
+  unsigned char* d_f = nullptr;
   hipError_t e = hipMalloc((void**)&d_c, (size_t)n * 10 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&d_l, (size_t)n * 3 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&d_u, (size_t)n * 9 * sizeof(double));
+  if (e == hipSuccess && flags) e = hipMalloc((void**)&d_f, (size_t)n);
   if (e == hipSuccess) e = hipMemcpy(d_c, clusters, (size_t)n * 10 * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    vxk::launch_k4_plane_fit(d_c, n, d_l, d_u, nullptr);
+    vxk::PlaneCriteria pc{min_point, min_eigen_value, eigen_ratio_thre, factor_ratio_max};
+    vxk::launch_k4_plane_fit(d_c, n, d_l, d_u, flags ? &pc : nullptr, d_f, nullptr);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(eig_val, d_l, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(eig_vec, d_u, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost);
-  hipFree(d_c); hipFree(d_l); hipFree(d_u);
+  if (e == hipSuccess && flags) e = hipMemcpy(flags, d_f, (size_t)n, hipMemcpyDeviceToHost);
+  hipFree(d_c); hipFree(d_l); hipFree(d_u); hipFree(d_f);
+  return e == hipSuccess ? VXBA_OK : VXBA_ERR_HIP;
+}
+
+int vxba_plane_fit(int device, int64_t n, const double* clusters, double* eig_val, double* eig_vec) {
+  return vxba_plane_fit_judge(device, n, clusters, 0, 0.0, 0.0, 0.0, eig_val, eig_vec, nullptr);
+}
+
+int vxba_build_clusters(int device, int64_t n_cells, int64_t n_points, const double* xyz, const int64_t* cell_ptr, double* clusters) {
+  if (n_cells < 0 || n_points < 0 || !cell_ptr || !clusters || (n_points > 0 && !xyz)) return VXBA_ERR_ARG;
+  if (n_cells == 0) return VXBA_OK;
+  if (cell_ptr[0] != 0 || cell_ptr[n_cells] != n_points) return VXBA_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VXBA_ERR_NODEV;
+  if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_HIP;
+  double *d_xyz = nullptr, *d_cl = nullptr;
+  int64_t* d_ptr = nullptr;
+  hipError_t e = hipMalloc((void**)&d_xyz, std::max<size_t>(1, (size_t)n_points * 3) * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_ptr, (size_t)(n_cells + 1) * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_cl, (size_t)n_cells * 10 * sizeof(double));
+  if (e == hipSuccess && n_points) e = hipMemcpy(d_xyz, xyz, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_ptr, cell_ptr, (size_t)(n_cells + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    vxk::launch_k1_build_aos(d_xyz, d_ptr, n_cells, d_cl, nullptr);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(clusters, d_cl, (size_t)n_cells * 10 * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(d_xyz); hipFree(d_ptr); hipFree(d_cl);
   return e == hipSuccess ? VXBA_OK : VXBA_ERR_HIP;
 }
 

@@ -99,8 +99,12 @@ void launch_lm_update(LMState* st, const double* d_scalar, const double* d_parti
 // frame-major planes at voxel offset v0.
 void launch_k1_build(const double* d_xyz, const int64_t* d_cell_ptr, int n_voxels, int W, const FactorView& fv, int v0, hipStream_t s);
 
-// K4: plane fit of n packed clusters (AoS n*10) -> eig_val n*3, eig_vec n*9 (col-major).
-void launch_k4_plane_fit(const double* d_clusters, int64_t n, double* d_eigval, double* d_eigvec, hipStream_t s);
+// K4: plane fit of n packed clusters (AoS n*10) -> eig_val n*3, eig_vec n*9 (col-major); optional plane criteria flags.
+struct PlaneCriteria { int min_point; double min_eigen_value, eigen_ratio_thre, factor_ratio_max; };
+void launch_k4_plane_fit(const double* d_clusters, int64_t n, double* d_eigval, double* d_eigvec, const PlaneCriteria* crit, unsigned char* d_flags,
+                         hipStream_t s);
+// K1 stand-alone: n_cells buckets -> packed clusters (AoS n_cells*10).
+void launch_k1_build_aos(const double* d_xyz, const int64_t* d_cell_ptr, int64_t n_cells, double* d_clusters, hipStream_t s);
 
 // Rebuild the batch-major copy (clb) of voxels [v0, v0+n) from the frame-major planes.
 void launch_build_clb(const FactorView& fv, int v0, int n, hipStream_t s);

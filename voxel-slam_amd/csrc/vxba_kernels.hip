@@ -496,12 +496,13 @@ __global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restr
 // ------------------------------------------------------------------------------------------------
 constexpr int K1_CHUNK = 1024;  // points per LDS stage (24 KB)
 
+template <bool AOS>
 __global__ __launch_bounds__(256) void k1_build_kernel(const double* __restrict__ xyz, const long long* __restrict__ cell_ptr,
-                                                       int n_voxels, int W, FactorView fv, int v0) {
+                                                       int n_voxels, int W, FactorView fv, int v0, double* __restrict__ aos, long long ncells_aos) {
 #pragma clang fp contract(off)
   __shared__ double pts[3 * K1_CHUNK];
   const int tid = threadIdx.x;
-  const long long ncells = (long long)n_voxels * W;
+  const long long ncells = AOS ? ncells_aos : (long long)n_voxels * W;
   const long long c0 = (long long)blockIdx.x * 256;
   const long long c = c0 + tid;
   const long long cend = (c0 + 256 < ncells) ? c0 + 256 : ncells;
@@ -525,7 +526,12 @@ __global__ __launch_bounds__(256) void k1_build_kernel(const double* __restrict_
     }
     __syncthreads();
   }
-  if (c < ncells) {
+  if (AOS) {
+    if (c < ncells) {
+      double* o = aos + 10 * c;
+      o[0] = P0; o[1] = P1; o[2] = P2; o[3] = P3; o[4] = P4; o[5] = P5; o[6] = vx; o[7] = vy; o[8] = vz; o[9] = N;
+    }
+  } else if (c < ncells) {
     const int i = (int)(c / n_voxels);
     const int a = v0 + (int)(c % n_voxels);
     const size_t VS = (size_t)fv.VS;
@@ -538,13 +544,22 @@ __global__ __launch_bounds__(256) void k1_build_kernel(const double* __restrict_
 // ------------------------------------------------------------------------------------------------
 // K4 -- batched plane fit: eig(P/N - c c^T)   (voxel_map.hpp:1161-1163)
 // ------------------------------------------------------------------------------------------------
-__global__ void k4_plane_fit_kernel(const double* __restrict__ clusters, long long n, double* __restrict__ eigval, double* __restrict__ eigvec) {
+__global__ void k4_plane_fit_kernel(const double* __restrict__ clusters, long long n, double* __restrict__ eigval, double* __restrict__ eigvec,
+                                    PlaneCriteria crit, unsigned char* __restrict__ flags) {
   const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n) return;
   const double* c = clusters + 10 * a;
   double Cm[6], lam[3], U[9];
   vxm::cluster_cov(c, c + 6, c[9], Cm);
   vxm::eig_sym3(Cm, lam, U);
+  if (flags) {
+    // voxel_map.hpp:1155 (N > min_point), :1015-1019 (plane_judge), :1314 (factor filter lambda0/lambda1 <= 0.12)
+    unsigned char fl = 0;
+    if ((int)c[9] > crit.min_point) fl |= 1;
+    if (lam[0] < crit.min_eigen_value && (lam[0] / lam[2]) < crit.eigen_ratio_thre) fl |= 2;
+    if (!(lam[0] / lam[1] > crit.factor_ratio_max)) fl |= 4;
+    flags[a] = fl;
+  }
   for (int k = 0; k < 3; k++) eigval[3 * a + k] = lam[k];
   for (int col = 0; col < 3; col++)
     for (int row = 0; row < 3; row++) eigvec[9 * a + 3 * col + row] = U[3 * row + col];
@@ -740,6 +755,13 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, const double*
 #pragma unroll
   for (int j = 0; j < n; j++) A[j] = st->Hwork[(size_t)j * n + i];
   const double rhs = st->Jwork[i];
+  // current pose of frame `lane` (lanes < W), fetched now so its latency hides behind the elimination
+  double xcur[12];
+  {
+    const int fl = lane < W ? lane : 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) xcur[k] = st->x[12 * fl + k];
+  }
   // my diagonal and gradient entry, kept for q1
   double hii = 0.0;
 #pragma unroll
@@ -767,8 +789,12 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, const double*
     double dl[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) dl[k] = xs[6 * lane + k];
-    lm_right_multiply_exp(st->x + 12 * lane, dl, st->xt + 12 * lane);
-    for (int k = 0; k < 3; k++) st->xt[12 * lane + 9 + k] = st->x[12 * lane + 9 + k] + dl[3 + k];
+    double xn[9];
+    lm_right_multiply_exp(xcur, dl, xn);
+#pragma unroll
+    for (int k = 0; k < 9; k++) st->xt[12 * lane + k] = xn[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) st->xt[12 * lane + 9 + k] = xcur[9 + k] + dl[3 + k];
   }
   double part = row_ok ? x * (u * hii * x - gi) : 0.0;
 #pragma unroll
@@ -933,12 +959,19 @@ void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* ga
 void launch_k1_build(const double* d_xyz, const int64_t* d_cell_ptr, int n_voxels, int W, const FactorView& fv, int v0, hipStream_t s) {
   const long long ncells = (long long)n_voxels * W;
   if (ncells <= 0) return;
-  hipLaunchKernelGGL(k1_build_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, s, d_xyz, (const long long*)d_cell_ptr, n_voxels, W, fv, v0);
+  k1_build_kernel<false><<<dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, s>>>(d_xyz, (const long long*)d_cell_ptr, n_voxels, W, fv, v0, nullptr, 0);
 }
 
-void launch_k4_plane_fit(const double* d_clusters, int64_t n, double* d_eigval, double* d_eigvec, hipStream_t s) {
+void launch_k4_plane_fit(const double* d_clusters, int64_t n, double* d_eigval, double* d_eigvec, const PlaneCriteria* crit, unsigned char* d_flags,
+                         hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k4_plane_fit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_clusters, (long long)n, d_eigval, d_eigvec);
+  PlaneCriteria pc = crit ? *crit : PlaneCriteria{0, 0.0, 0.0, 0.0};
+  k4_plane_fit_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(d_clusters, (long long)n, d_eigval, d_eigvec, pc, crit ? d_flags : nullptr);
+}
+void launch_k1_build_aos(const double* d_xyz, const int64_t* d_cell_ptr, int64_t n_cells, double* d_clusters, hipStream_t s) {
+  if (n_cells <= 0) return;
+  FactorView fv{};
+  k1_build_kernel<true><<<dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s>>>(d_xyz, (const long long*)d_cell_ptr, 0, 0, fv, 0, d_clusters, (long long)n_cells);
 }
 
 static inline unsigned nblk(long long n, int b) { return (unsigned)((n + b - 1) / b); }

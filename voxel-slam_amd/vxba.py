@@ -28,7 +28,7 @@ EXPORTS = [
     "vxba_create", "vxba_destroy", "vxba_clear", "vxba_set_win_size", "vxba_win_size", "vxba_size", "vxba_set_stream",
     "vxba_reserve", "vxba_last_error", "vxba_push_voxels", "vxba_push_points", "vxba_read_clusters", "vxba_acc_evaluate2",
     "vxba_evaluate_only_residual", "vxba_acc_evaluate2_device", "vxba_evaluate_only_residual_device", "vxba_packed_len",
-    "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_set_allreduce",
+    "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_plane_fit_judge", "vxba_build_clusters", "vxba_set_allreduce",
     "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps",
 ]
 
@@ -74,6 +74,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_snapshot_cache.argtypes = [vp]
     L.vxba_restore_cache.argtypes = [vp]
     L.vxba_plane_fit.argtypes = [ci, C.c_int64, _f64p, _f64p, _f64p]
+    L.vxba_plane_fit_judge.argtypes = [ci, C.c_int64, _f64p, ci, cd, cd, cd, _f64p, _f64p, np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")]
+    L.vxba_build_clusters.argtypes = [ci, C.c_int64, C.c_int64, _f64p, _i64p, _f64p]
     L.vxba_set_allreduce.argtypes = [vp, _ALLREDUCE_FN, vp]
     L.vxba_use_external_buffers.argtypes = [vp, vp, vp]
     L.vxba_damping_iter.argtypes = [vp, _f64p, ci, _f64p, _f64p, _f64p, C.POINTER(ci), C.POINTER(ci)]
@@ -344,6 +346,31 @@ def plane_fit(clusters, device: int = 0):
     if rc != 0:
         raise VxbaError(f"vxba_plane_fit failed: {_ERRNAMES.get(rc, rc)}")
     return ev, U
+
+
+def plane_fit_judge(clusters, min_point=5, min_eigen_value=0.0025, eigen_ratio_thre=1.0, factor_ratio_max=0.12, device: int = 0):
+    """K4 + the reference's plane criteria: (eig_val, eig_vec, flags) with flags bits 1 = N > min_point,
+    2 = plane_judge (voxel_map.hpp:1015-1019), 4 = lambda0/lambda1 <= factor_ratio_max (voxel_map.hpp:1314)."""
+    L = load_library()
+    cl = _c(clusters).reshape(-1, 10)
+    n = cl.shape[0]
+    ev = np.zeros((n, 3)); U = np.zeros((n, 9)); fl = np.zeros(n, dtype=np.uint8)
+    rc = L.vxba_plane_fit_judge(int(device), n, cl, int(min_point), float(min_eigen_value), float(eigen_ratio_thre), float(factor_ratio_max), ev, U, fl)
+    if rc != 0:
+        raise VxbaError(f"vxba_plane_fit_judge failed: {_ERRNAMES.get(rc, rc)}")
+    return ev, U, fl
+
+
+def build_clusters(xyz, cell_ptr, device: int = 0):
+    """Stand-alone K1: packed clusters (n_cells, 10) of bucketed points."""
+    L = load_library()
+    xyz = _c(xyz).reshape(-1, 3)
+    ptr = np.ascontiguousarray(cell_ptr, dtype=np.int64)
+    out = np.zeros((ptr.shape[0] - 1, 10))
+    rc = L.vxba_build_clusters(int(device), ptr.shape[0] - 1, xyz.shape[0], xyz, ptr, out)
+    if rc != 0:
+        raise VxbaError(f"vxba_build_clusters failed: {_ERRNAMES.get(rc, rc)}")
+    return out
 
 
 def debug_mfma_probe(A, B, device: int = 0):
