@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--steps-per-solve", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-reduce path even with one rank (plumbing test)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -76,9 +77,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # ---- synthetic window: every rank builds its own voxel shard of one shared window ------------
     base_seed = synth.MASTER_SEED + list(synth.CONFIGS).index(args.config) + 1
@@ -89,7 +93,7 @@ def main():
     stream = torch.cuda.current_stream()
     f.set_stream(stream.cuda_stream)
     f.push_points(V, sc.points_body, sc.cell_ptr)          # K1 on the GPU; data now resident in HBM
-    if world > 1:
+    if use_dist:
         from voxel_slam_amd import dist as vdist
         _keep = vdist.attach_allreduce(f)                  # exchange buffers become torch tensors reduced over RCCL
     f.evaluate_only_residual(sc.poses_init)                # seeds the (lambda, U, merged) cache (recut's eig)
@@ -98,7 +102,7 @@ def main():
     nnz = f.nnz()
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -114,7 +118,7 @@ def main():
     t1 = time.perf_counter()
     f.set_profiling(0)
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -153,7 +157,7 @@ def main():
                 "steps_per_solve": sps,
                 "global_voxels": V * world,
                 "global_iterations_per_s": args.steps / elapsed,
-                "parallelism": f"voxel-shard x{world}" + (" + RCCL all-reduce of [Hess|JacT|res]" if world > 1 else ""),
+                "parallelism": f"voxel-shard x{world}" + (" + RCCL all-reduce of [Hess|JacT|res]" if use_dist else ""),
                 "final_residual": float(resis[1]),
                 "lm_steps_accepted": lmstats["accepted"], "lm_steps_rejected": lmstats["rejected"],
             },
@@ -184,7 +188,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     f.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

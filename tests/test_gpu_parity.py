@@ -353,3 +353,24 @@ def test_allreduce_hook_is_called_on_the_packed_device_buffer(vx):
     assert seen == [(True, f.packed_len()), (True, 1)]
     assert np.array_equal(H0, H1)
     f.set_allreduce(None)
+
+
+def test_bench_rccl_plumbing_single_rank():
+    """bench.py's N > 1 path (torch.distributed "nccl" = RCCL, exchange buffers as torch tensors, all-reduce issued from the
+    C ABI's hook on torch's stream) forced on with one rank: same LM result as the plain path."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    def run(extra):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "cfg1", "--steps", "30", "--warmup", "3",
+                              "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    a = run([])
+    b = run(["--force-dist"])
+    assert a["config"]["lm_steps_accepted"] == b["config"]["lm_steps_accepted"] == 30
+    assert abs(a["config"]["final_residual"] - b["config"]["final_residual"]) <= 1e-12 * abs(a["config"]["final_residual"])
+    assert "RCCL" in b["config"]["parallelism"] and b["value"] > 0
