@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--steps-per-solve", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--hook-allreduce", action="store_true", help="use the torch.distributed hook instead of direct RCCL calls")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-reduce path even with one rank (plumbing test)")
     args = ap.parse_args()
 
@@ -95,7 +96,10 @@ def main():
     f.push_points(V, sc.points_body, sc.cell_ptr)          # K1 on the GPU; data now resident in HBM
     if use_dist:
         from voxel_slam_amd import dist as vdist
-        _keep = vdist.attach_allreduce(f)                  # exchange buffers become torch tensors reduced over RCCL
+        if args.hook_allreduce:
+            _keep = vdist.attach_allreduce(f)              # exchange buffers become torch tensors, collective via a host hook
+        else:
+            vdist.attach_rccl(f)                           # ncclAllReduce issued directly from the C++ loop
     f.evaluate_only_residual(sc.poses_init)                # seeds the (lambda, U, merged) cache (recut's eig)
     f.snapshot_cache()
     abytes = f.algorithmic_bytes()

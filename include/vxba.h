@@ -126,6 +126,16 @@ int vxba_build_clusters(int device, int64_t n_cells, int64_t n_points, const dou
  * on `hip_stream`.  NULL = single GPU. */
 typedef int (*vxba_allreduce_fn)(void* ctx, double* d_buf, size_t count, void* hip_stream);
 int vxba_set_allreduce(vxba_factor* f, vxba_allreduce_fn fn, void* ctx);
+/* Direct RCCL collective (no per-sweep host callback): creates an RCCL communicator for this factor's shard group and
+ * all-reduces the exchange buffers with ncclAllReduce on the factor's stream after every sweep.
+ *   librccl_path : the librccl.so to dlopen -- pass the one the process already uses (e.g. torch/lib/librccl.so) so that
+ *                  there is ONE RCCL instance in the process;
+ *   unique_id    : 128 bytes from vxba_rccl_unique_id() on rank 0, distributed out of band (e.g. torch.distributed.broadcast).
+ * Collective: every rank of the group must call it.  Takes precedence over vxba_set_allreduce. */
+int vxba_rccl_unique_id(const char* librccl_path, void* unique_id_out_128);
+int vxba_rccl_attach(vxba_factor* f, const char* librccl_path, int nranks, int rank, const void* unique_id_128);
+int vxba_rccl_detach(vxba_factor* f);
+
 /* Let the caller own the exchange buffers the sweeps reduce into (e.g. a torch tensor, so torch.distributed /
  * RCCL can all-reduce it): d_packed holds vxba_packed_len() f64, d_scalar 1 f64.  NULL restores the internal ones. */
 int vxba_use_external_buffers(vxba_factor* f, double* d_packed, double* d_scalar);

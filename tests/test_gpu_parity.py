@@ -370,7 +370,8 @@ def test_bench_rccl_plumbing_single_rank():
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     a = run([])
-    b = run(["--force-dist"])
-    assert a["config"]["lm_steps_accepted"] == b["config"]["lm_steps_accepted"] == 30
-    assert abs(a["config"]["final_residual"] - b["config"]["final_residual"]) <= 1e-12 * abs(a["config"]["final_residual"])
-    assert "RCCL" in b["config"]["parallelism"] and b["value"] > 0
+    for extra in (["--force-dist"], ["--force-dist", "--hook-allreduce"]):     # direct ncclAllReduce / torch.distributed hook
+        b = run(extra)
+        assert a["config"]["lm_steps_accepted"] == b["config"]["lm_steps_accepted"] == 30
+        assert abs(a["config"]["final_residual"] - b["config"]["final_residual"]) <= 1e-12 * abs(a["config"]["final_residual"])
+        assert "RCCL" in b["config"]["parallelism"] and b["value"] > 0

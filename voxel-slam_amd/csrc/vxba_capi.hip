@@ -1,6 +1,8 @@
 // C-ABI implementation (include/vxba.h): device memory, streams, launch sequencing and the host part of
 // the LM shell.  No CPU fallback anywhere: without a gfx950 device every entry point fails loudly.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -51,6 +53,11 @@ struct vxba_factor {
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
   vxba_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
+  // direct RCCL path: entry points resolved from the librccl.so the process already uses
+  void* rccl_lib = nullptr;
+  ncclComm_t rccl_comm = nullptr;
+  ncclResult_t (*p_ncclAllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*p_ncclCommDestroy)(ncclComm_t) = nullptr;
   int profiling = 0;             // bit mask of kernel kinds to bracket with events: 1 K3, 2 K2, 4 K3 finalize, 8 K1
   std::vector<EventPair> pending;
   std::vector<hipEvent_t> free_events;
@@ -180,6 +187,18 @@ int drain_events(vxba_factor* f) {
   return VXBA_OK;
 }
 
+// Sum `count` f64 across the voxel shards, stream-ordered: direct RCCL if attached, else the caller's hook.
+bool has_collective(const vxba_factor* f) { return f->rccl_comm != nullptr || f->allreduce != nullptr; }
+int shard_allreduce(vxba_factor* f, double* d_buf, size_t count) {
+  if (f->rccl_comm) {
+    if (f->p_ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, f->rccl_comm, f->stream) != ncclSuccess)
+      return fail(f, VXBA_ERR_STATE, "ncclAllReduce failed");
+    return VXBA_OK;
+  }
+  if (f->allreduce && f->allreduce(f->allreduce_ctx, d_buf, count, (void*)f->stream) != 0) return fail(f, VXBA_ERR_STATE, "all-reduce hook failed");
+  return VXBA_OK;
+}
+
 // ---- sweeps (asynchronous on f->stream; results in device memory) ----
 // Poses come either by value (Rp, host pointer -> kernel argument) or from device memory (d_Rp, e.g. the LM state);
 // `gate` lets the GPU skip the work when the device-resident LM loop does not need it.
@@ -205,10 +224,7 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, const double* d_Rp, vxk:
     vxk::launch_k3_finalize(f->d_partial3, nblocks, f->W, gate, d_out, f->stream);
   }
   VX_HIP(f, hipGetLastError());
-  if (f->allreduce) {
-    if (f->allreduce(f->allreduce_ctx, d_out, plen, (void*)f->stream) != 0) return fail(f, VXBA_ERR_STATE, "all-reduce hook failed");
-  }
-  return VXBA_OK;
+  return shard_allreduce(f, d_out, plen);
 }
 
 int sweep_residual_device(vxba_factor* f, const double* Rp, const double* d_Rp, const vxk::LMState* gate, int gate_mode, int head, int end,
@@ -226,9 +242,7 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, const double* d_Rp, 
   if (d_out) {
     vxk::launch_sum_partials(f->d_partial2, nparts, d_out, f->stream);
     VX_HIP(f, hipGetLastError());
-    if (f->allreduce) {
-      if (f->allreduce(f->allreduce_ctx, d_out, 1, (void*)f->stream) != 0) return fail(f, VXBA_ERR_STATE, "all-reduce hook failed");
-    }
+    return shard_allreduce(f, d_out, 1);
   }
   return VXBA_OK;
 }
@@ -325,6 +339,7 @@ int vxba_destroy(vxba_factor* f) {
   if (!f) return VXBA_OK;
   hipSetDevice(f->device);
   if (f->stream) hipStreamSynchronize(f->stream);
+  vxba_rccl_detach(f);
   for (auto& ep : f->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   for (auto e : f->free_events) hipEventDestroy(e);
   hipFree(f->planes); hipFree(f->clb); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2);
@@ -380,6 +395,50 @@ int vxba_set_allreduce(vxba_factor* f, vxba_allreduce_fn fn, void* ctx) {
   if (!f) return VXBA_ERR_ARG;
   f->allreduce = fn;
   f->allreduce_ctx = ctx;
+  return VXBA_OK;
+}
+
+namespace {
+void* open_rccl(const char* path) { return dlopen(path && path[0] ? path : "librccl.so", RTLD_NOW | RTLD_LOCAL); }
+}  // namespace
+
+int vxba_rccl_unique_id(const char* librccl_path, void* out) {
+  if (!out) return VXBA_ERR_ARG;
+  void* lib = open_rccl(librccl_path);
+  if (!lib) return VXBA_ERR_STATE;
+  auto fn = (ncclResult_t(*)(ncclUniqueId*))dlsym(lib, "ncclGetUniqueId");
+  if (!fn) return VXBA_ERR_STATE;
+  ncclUniqueId id;
+  if (fn(&id) != ncclSuccess) return VXBA_ERR_STATE;
+  std::memcpy(out, &id, sizeof id);
+  return VXBA_OK;
+}
+
+int vxba_rccl_attach(vxba_factor* f, const char* librccl_path, int nranks, int rank, const void* unique_id) {
+  if (!f || !unique_id || nranks < 1 || rank < 0 || rank >= nranks) return fail(f, VXBA_ERR_ARG, "rccl_attach: bad argument");
+  if (f->rccl_comm) return fail(f, VXBA_ERR_STATE, "rccl_attach: already attached");
+  hipSetDevice(f->device);
+  void* lib = open_rccl(librccl_path);
+  if (!lib) return fail(f, VXBA_ERR_STATE, "rccl_attach: cannot dlopen librccl");
+  auto init = (ncclResult_t(*)(ncclComm_t*, int, ncclUniqueId, int))dlsym(lib, "ncclCommInitRank");
+  f->p_ncclAllReduce = (decltype(f->p_ncclAllReduce))dlsym(lib, "ncclAllReduce");
+  f->p_ncclCommDestroy = (decltype(f->p_ncclCommDestroy))dlsym(lib, "ncclCommDestroy");
+  if (!init || !f->p_ncclAllReduce || !f->p_ncclCommDestroy) return fail(f, VXBA_ERR_STATE, "rccl_attach: missing RCCL symbols");
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, sizeof id);
+  if (init(&f->rccl_comm, nranks, id, rank) != ncclSuccess) { f->rccl_comm = nullptr; return fail(f, VXBA_ERR_STATE, "ncclCommInitRank failed"); }
+  f->rccl_lib = lib;
+  return VXBA_OK;
+}
+
+int vxba_rccl_detach(vxba_factor* f) {
+  if (!f) return VXBA_ERR_ARG;
+  if (f->rccl_comm) {
+    hipSetDevice(f->device);
+    hipStreamSynchronize(f->stream);
+    f->p_ncclCommDestroy(f->rccl_comm);
+    f->rccl_comm = nullptr;
+  }
   return VXBA_OK;
 }
 
@@ -627,9 +686,9 @@ int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out
     vxk::launch_lm_solve(f->d_lm, f->d_packed, W, f->stream);
     // residual sweep at the trial state; without a collective its wave partials are summed inside the update kernel
     int nparts = 0;
-    rc = sweep_residual_device(f, nullptr, f->d_lm->xt, f->d_lm, 0, 0, f->V, f->allreduce ? f->d_scalar : nullptr, &nparts);
+    rc = sweep_residual_device(f, nullptr, f->d_lm->xt, f->d_lm, 0, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts);
     if (rc) return rc;
-    vxk::launch_lm_update(f->d_lm, f->allreduce ? f->d_scalar : nullptr, f->d_partial2, nparts, f->d_scalar, W, nullptr, f->stream);
+    vxk::launch_lm_update(f->d_lm, has_collective(f) ? f->d_scalar : nullptr, f->d_partial2, nparts, f->d_scalar, W, nullptr, f->stream);
   }
   VX_HIP(f, hipGetLastError());
   VX_HIP(f, hipMemcpyAsync(f->h_lm, f->d_lm, sizeof(vxk::LMState), hipMemcpyDeviceToHost, f->stream));
@@ -707,9 +766,9 @@ int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_
     if (rc) return rc;
     vxk::launch_lm_solve(f->d_lm, f->d_packed, W, f->stream);
     int nparts = 0;
-    rc = sweep_residual_device(f, nullptr, f->d_lm->xt, f->d_lm, 0, 0, f->V, f->allreduce ? f->d_scalar : nullptr, &nparts);
+    rc = sweep_residual_device(f, nullptr, f->d_lm->xt, f->d_lm, 0, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts);
     if (rc) return rc;
-    vxk::launch_lm_update(f->d_lm, f->allreduce ? f->d_scalar : nullptr, f->d_partial2, nparts, f->d_scalar, W, last ? &x0 : nullptr, f->stream);
+    vxk::launch_lm_update(f->d_lm, has_collective(f) ? f->d_scalar : nullptr, f->d_partial2, nparts, f->d_scalar, W, last ? &x0 : nullptr, f->stream);
   }
   VX_HIP(f, hipGetLastError());
   VX_HIP(f, hipMemcpyAsync(f->h_lm, f->d_lm, sizeof(vxk::LMState), hipMemcpyDeviceToHost, f->stream));

@@ -41,6 +41,25 @@ def attach_allreduce(factor, group=None):
     return xbuf, packed_t, scalar_t
 
 
+def attach_rccl(factor, group=None):
+    """GPU path, no per-sweep host callback: give the factor its own RCCL communicator (created from the SAME librccl.so
+    torch already loaded, so the process has one RCCL instance) and let the C++ loop call ncclAllReduce directly.
+    The ncclUniqueId travels over the existing torch.distributed group.  Collective."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from . import vxba
+
+    lib = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    obj = [vxba.rccl_unique_id(lib) if rank == 0 else None]
+    dist.broadcast_object_list(obj, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    factor.set_stream(torch.cuda.current_stream().cuda_stream)
+    factor.rccl_attach(lib, world, rank, obj[0])
+
+
 def damping_iter_sharded(win_size: int, x_stats, local_hess, local_resid, max_iter: int = 3, group=None):
     """``Lidar_BA_Optimizer::damping_iter`` over a voxel shard per rank, host-driven.
 

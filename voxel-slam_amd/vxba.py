@@ -29,7 +29,7 @@ EXPORTS = [
     "vxba_reserve", "vxba_last_error", "vxba_push_voxels", "vxba_push_points", "vxba_read_clusters", "vxba_acc_evaluate2",
     "vxba_evaluate_only_residual", "vxba_acc_evaluate2_device", "vxba_evaluate_only_residual_device", "vxba_packed_len",
     "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_plane_fit_judge", "vxba_build_clusters", "vxba_set_allreduce",
-    "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps",
+    "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_detach", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -78,6 +78,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_build_clusters.argtypes = [ci, C.c_int64, C.c_int64, _f64p, _i64p, _f64p]
     L.vxba_set_allreduce.argtypes = [vp, _ALLREDUCE_FN, vp]
     L.vxba_use_external_buffers.argtypes = [vp, vp, vp]
+    L.vxba_rccl_unique_id.argtypes = [C.c_char_p, vp]
+    L.vxba_rccl_attach.argtypes = [vp, C.c_char_p, ci, ci, vp]
+    L.vxba_rccl_detach.argtypes = [vp]
     L.vxba_damping_iter.argtypes = [vp, _f64p, ci, _f64p, _f64p, _f64p, C.POINTER(ci), C.POINTER(ci)]
     L.vxba_damping_iter_generic.argtypes = [ci, _f64p, ci, _HESS_FN, _RESID_FN, vp, _f64p, _f64p, _f64p, C.POINTER(ci), C.POINTER(ci)]
     L.vxba_lm_steps.argtypes = [vp, _f64p, ci, ci, _f64p, _f64p, _i64p]
@@ -251,6 +254,14 @@ class LidarFactor:
         self._cb = _ALLREDUCE_FN(tramp)
         self._chk(self._L.vxba_set_allreduce(self._h, self._cb, None))
 
+    def rccl_attach(self, librccl_path: str, nranks: int, rank: int, unique_id: bytes):
+        """Direct RCCL all-reduce of the exchange buffers inside the device-resident LM loop (collective call)."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self._L.vxba_rccl_attach(self._h, librccl_path.encode(), int(nranks), int(rank), C.cast(buf, C.c_void_p)))
+
+    def rccl_detach(self):
+        self._chk(self._L.vxba_rccl_detach(self._h))
+
     def use_external_buffers(self, d_packed_ptr: int | None, d_scalar_ptr: int | None):
         self._chk(self._L.vxba_use_external_buffers(self._h, C.c_void_p(d_packed_ptr or 0), C.c_void_p(d_scalar_ptr or 0)))
 
@@ -334,6 +345,16 @@ def damping_iter_generic(win_size: int, x_stats, hess_fn, resid_fn, max_iter: in
     if rc != 0:
         raise VxbaError(f"vxba_damping_iter_generic failed: {_ERRNAMES.get(rc, rc)}")
     return dict(poses=Rp, hess=hess.T.copy(), resis=resis, trace=trace[: nt.value].copy(), is_converge=bool(conv.value))
+
+
+def rccl_unique_id(librccl_path: str) -> bytes:
+    """128-byte ncclUniqueId from the given librccl.so (call on one rank, broadcast to the others)."""
+    L = load_library()
+    buf = C.create_string_buffer(128)
+    rc = L.vxba_rccl_unique_id(librccl_path.encode(), C.cast(buf, C.c_void_p))
+    if rc != 0:
+        raise VxbaError(f"vxba_rccl_unique_id failed: {_ERRNAMES.get(rc, rc)}")
+    return buf.raw
 
 
 def plane_fit(clusters, device: int = 0):
