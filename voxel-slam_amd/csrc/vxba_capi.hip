@@ -215,8 +215,11 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, const double* d_Rp, vxk:
   const int nv = vxk::k3_nv(f->W);
   const int nbatches = (end - 1) / nv - head / nv + 1;
   const int nblocks = std::max(1, std::min(vxk::k3_grid_blocks(f->cus), (nbatches + 3) / 4));
-  {
-    ScopedKernelTimer t(f, 0);
+  if (f->profiling & 1) {   // events bound to the dispatch itself: same interval as the profiler's kernel duration
+    hipEvent_t a = get_event(f), b = get_event(f);
+    vxk::launch_k3_hessian(fv, pa, d_Rp, gate, cache_src, head, end, f->d_partial3, nblocks, f->stream, a, b);
+    if (a && b) f->pending.push_back({a, b, 0});
+  } else {
     vxk::launch_k3_hessian(fv, pa, d_Rp, gate, cache_src, head, end, f->d_partial3, nblocks, f->stream);
   }
   {
@@ -234,8 +237,11 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, const double* d_Rp, 
   if (Rp) fill_poses(f, Rp, pa); else std::memset(&pa, 0, sizeof pa);
   const FactorView fv = view(f);
   int nparts;
-  {
-    ScopedKernelTimer t(f, 1);
+  if (f->profiling & 2) {
+    hipEvent_t a = get_event(f), b = get_event(f);
+    nparts = vxk::launch_k2_residual(fv, pa, d_Rp, gate, gate_mode, head, end, f->d_partial2, f->stream, a, b);
+    if (a && b) f->pending.push_back({a, b, 1});
+  } else {
     nparts = vxk::launch_k2_residual(fv, pa, d_Rp, gate, gate_mode, head, end, f->d_partial2, f->stream);
   }
   if (nparts_out) *nparts_out = nparts;

@@ -72,7 +72,7 @@ inline size_t k3_partial_len(int W) { return (size_t)k3_num_tile_pairs(W) * 256 
 // d_Rp (device pointer, W*12 f64) overrides the by-value poses when non-null; gate (device int pointer) skips the
 // launch's work on the GPU when gate[gate_idx] evaluates to "do not run": K2 runs iff !done, K3 iff calc_hess && !done.
 int launch_k2_residual(const FactorView& fv, const PoseArg& poses, const double* d_Rp, const LMState* gate, int gate_mode, int head,
-                       int end, double* d_partial, hipStream_t s);
+                       int end, double* d_partial, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // Deterministic sum of n partials into d_out[0].
 void launch_sum_partials(const double* d_partial, int n, double* d_out, hipStream_t s);
 // Derive aux (gap scales) from eigval for voxels [head,end) (after a caller-seeded cache).
@@ -82,8 +82,11 @@ void launch_seed_aux(const FactorView& fv, int head, int end, hipStream_t s);
 int k3_grid_blocks(int device_cus);
 // cache_src (nullable): read the (lambda, U, merged, aux) cache planes from this base instead of fv's live cache --
 // used to start a new window from the snapshot without copying it back first.
+// ev_start / ev_stop (nullable): events tied to this dispatch's own begin / end timestamps (hipExtLaunchKernel), i.e.
+// the same interval rocprofv3 reports for the kernel -- events recorded around a launch also count the dispatch gap.
 int launch_k3_hessian(const FactorView& fv, const PoseArg& poses, const double* d_Rp, const LMState* gate, const double* cache_src,
-                      int head, int end, double* d_partial, int nblocks, hipStream_t s);
+                      int head, int end, double* d_partial, int nblocks, hipStream_t s, hipEvent_t ev_start = nullptr,
+                      hipEvent_t ev_stop = nullptr);
 // Cross-workgroup reduction + assembly of the packed [Hess (6W)^2 col-major | JacT 6W | residual] buffer.
 void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* gate, double* d_packed, hipStream_t s);
 

@@ -13,6 +13,8 @@
 // tree, so results are run-to-run bitwise reproducible for a given launch geometry.
 #include "vxba_kernels.h"
 
+#include <hip/hip_ext.h>
+
 #include <cstdlib>
 #include <cstring>
 
@@ -902,13 +904,16 @@ void launch_mfma_probe(const double* dA, const double* dB, double* dD, hipStream
   }
 
 int launch_k2_residual(const FactorView& fv, const PoseArg& poses, const double* d_Rp, const LMState* gate, int gate_mode, int head,
-                       int end, double* d_partial, hipStream_t s) {
+                       int end, double* d_partial, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int nblocks = (end - head + 63) / 64;
   if (nblocks <= 0) return 0;
   static int dbg = -1;
   if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
   if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, d_Rp, gate, gate_mode, head, end, d_partial)); }
-  else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, d_Rp, gate, gate_mode, head, end, d_partial)); }
+  else if (ev_start) {
+    VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), dim3(nblocks), dim3(64), 0, s, ev_start, ev_stop, 0, fv, poses, d_Rp, gate,
+                                                gate_mode, head, end, d_partial));
+  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, d_Rp, gate, gate_mode, head, end, d_partial)); }
   return nblocks;
 }
 
@@ -924,7 +929,7 @@ void launch_seed_aux(const FactorView& fv, int head, int end, hipStream_t s) {
 int k3_grid_blocks(int device_cus) { return device_cus; }  // one 4-wave workgroup per CU = one wave per SIMD (the kernel needs > 256 VGPRs)
 
 int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, const double* d_Rp, const LMState* gate, const double* cache_src,
-                      int head, int end, double* d_partial, int nblocks, hipStream_t s) {
+                      int head, int end, double* d_partial, int nblocks, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   FactorView fv = fv_in;
   if (cache_src) {   // eigval(3) eigvec(9) merged(10) aux(4): 26 consecutive planes
     const size_t VS = (size_t)fv.VS;
@@ -946,6 +951,9 @@ int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, const doubl
       attr_set = true;
     }
     if (dbg) k3_hessian_kernel<WW, true><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, d_Rp, gate, head, end, d_partial);
+    else if (ev_start)
+      hipExtLaunchKernelGGL((k3_hessian_kernel<WW, false>), dim3(nblocks), dim3(K3_BLOCK), (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, fv, poses, d_Rp, gate,
+                            head, end, d_partial);
     else k3_hessian_kernel<WW, false><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, d_Rp, gate, head, end, d_partial);
   });
   return nblocks;
