@@ -342,6 +342,30 @@ def test_error_conventions(vx):
         vx.Lidar_BA_Optimizer().damping_iter(np.zeros((5, 12)), f)   # empty factor
 
 
+def test_concurrent_subrange_calls_from_threads_like_divide_thread(vx):
+    """The reference's divide_thread / only_residual call the sweeps from several std::threads on ONE factor with disjoint
+    ranges and private outputs (voxel_map.hpp:318-332, 350-361); entry points serialise internally, results must match."""
+    import threading
+    sc = synth.make_scene(win_size=6, pts_per_scan=12000, n_voxels=1200, seed=91)
+    fo, fg = seeded_pair(vx, sc)
+    thd = 5
+    part = sc.n_voxels / thd
+    outs = [None] * thd
+    def work(i):
+        outs[i] = fg.acc_evaluate2(sc.poses_init, int(part * i), int(part * (i + 1)))
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(thd)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    H = sum(o[0] for o in outs); J = sum(o[1] for o in outs); r = sum(o[2] for o in outs)
+    H_ref, J_ref, r_ref = fo.divide_thread(sc.poses_init, thd_num=thd)
+    assert relerr(H, H_ref) < 1e-9 and relerr(J, J_ref) < 1e-9 and abs(r - r_ref) < 1e-9 * abs(r_ref)
+    res = [None] * thd
+    def work2(i):
+        res[i] = fg.evaluate_only_residual(sc.poses_gt, int(part * i), int(part * (i + 1)))
+    ts = [threading.Thread(target=work2, args=(i,)) for i in range(thd)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert abs(sum(res) - fo.only_residual(sc.poses_gt, thd_num=thd)) < 1e-9 * abs(sum(res))
+
+
 def test_allreduce_hook_is_called_on_the_packed_device_buffer(vx):
     sc = synth.make_scene(win_size=4, pts_per_scan=2000, n_voxels=200, seed=6)
     _, f = seeded_pair(vx, sc)

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -64,9 +65,14 @@ struct vxba_factor {
   double ms_sum[4] = {0, 0, 0, 0};
   int64_t calls[4] = {0, 0, 0, 0};
   std::string err;
+  // The reference calls the two sweeps from several std::threads on one LidarFactor with disjoint [head,end)
+  // (voxel_map.hpp:318-332); entry points serialise on this lock so such callers stay correct.
+  std::recursive_mutex mtx;
 };
 
 namespace {
+
+#define VX_LOCK(f) std::unique_lock<std::recursive_mutex> lk__; if (f) lk__ = std::unique_lock<std::recursive_mutex>((f)->mtx)
 
 #define VX_HIP(f, call)                                                                              \
   do {                                                                                               \
@@ -360,6 +366,7 @@ int vxba_destroy(vxba_factor* f) {
 }
 
 int vxba_clear(vxba_factor* f) {
+  VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
   f->V = 0;
   f->snapshot_v = 0;
@@ -367,6 +374,7 @@ int vxba_clear(vxba_factor* f) {
 }
 
 int vxba_set_win_size(vxba_factor* f, int win_size) {
+  VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
   if (win_size < 1 || win_size > VXBA_MAX_WIN) return fail(f, VXBA_ERR_UNSUPPORTED, "win_size outside [1, VXBA_MAX_WIN]");
   if (win_size == f->W) return VXBA_OK;
@@ -384,6 +392,7 @@ size_t vxba_packed_len(const vxba_factor* f) { return f ? (size_t)36 * f->W * f-
 const char* vxba_last_error(const vxba_factor* f) { return f ? f->err.c_str() : "null factor"; }
 
 int vxba_set_stream(vxba_factor* f, void* hip_stream) {
+  VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
   hipSetDevice(f->device);
   VX_HIP(f, hipStreamSynchronize(f->stream));
@@ -392,12 +401,14 @@ int vxba_set_stream(vxba_factor* f, void* hip_stream) {
 }
 
 int vxba_reserve(vxba_factor* f, int n_voxels) {
+  VX_LOCK(f);
   if (!f || n_voxels < 0) return VXBA_ERR_ARG;
   hipSetDevice(f->device);
   return ensure_capacity(f, n_voxels);
 }
 
 int vxba_set_allreduce(vxba_factor* f, vxba_allreduce_fn fn, void* ctx) {
+  VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
   f->allreduce = fn;
   f->allreduce_ctx = ctx;
@@ -421,6 +432,7 @@ int vxba_rccl_unique_id(const char* librccl_path, void* out) {
 }
 
 int vxba_rccl_attach(vxba_factor* f, const char* librccl_path, int nranks, int rank, const void* unique_id) {
+  VX_LOCK(f);
   if (!f || !unique_id || nranks < 1 || rank < 0 || rank >= nranks) return fail(f, VXBA_ERR_ARG, "rccl_attach: bad argument");
   if (f->rccl_comm) return fail(f, VXBA_ERR_STATE, "rccl_attach: already attached");
   hipSetDevice(f->device);
@@ -438,6 +450,7 @@ int vxba_rccl_attach(vxba_factor* f, const char* librccl_path, int nranks, int r
 }
 
 int vxba_rccl_detach(vxba_factor* f) {
+  VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
   if (f->rccl_comm) {
     hipSetDevice(f->device);
@@ -449,6 +462,7 @@ int vxba_rccl_detach(vxba_factor* f) {
 }
 
 int vxba_use_external_buffers(vxba_factor* f, double* d_packed, double* d_scalar) {
+  VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
   hipSetDevice(f->device);
   VX_HIP(f, hipStreamSynchronize(f->stream));
@@ -459,6 +473,7 @@ int vxba_use_external_buffers(vxba_factor* f, double* d_packed, double* d_scalar
 
 int vxba_push_voxels(vxba_factor* f, int n, const double* clusters, const double* fix, const double* coe, const double* eig_val,
                      const double* eig_vec, const double* merged) {
+  VX_LOCK(f);
   if (!f || n < 0 || (n > 0 && (!clusters || !fix || !coe))) return fail(f, VXBA_ERR_ARG, "push_voxels: null input");
   if (n == 0) return VXBA_OK;
   for (int a = 0; a < n; a++)
@@ -481,6 +496,7 @@ int vxba_push_voxels(vxba_factor* f, int n, const double* clusters, const double
 
 int vxba_push_points(vxba_factor* f, int n_voxels, int64_t n_points, const double* xyz_body, const int64_t* cell_ptr, const double* fix,
                      const double* coe) {
+  VX_LOCK(f);
   if (!f || n_voxels < 0 || n_points < 0 || !cell_ptr || (n_points > 0 && !xyz_body)) return fail(f, VXBA_ERR_ARG, "push_points: null input");
   if (n_voxels == 0) return VXBA_OK;
   const int64_t ncells = (int64_t)n_voxels * f->W;
@@ -516,6 +532,7 @@ int vxba_push_points(vxba_factor* f, int n_voxels, int64_t n_points, const doubl
 }
 
 int vxba_read_clusters(vxba_factor* f, int head, int end, double* clusters) {
+  VX_LOCK(f);
   if (!f || !clusters) return VXBA_ERR_ARG;
   int rc = check_range(f, head, end);
   if (rc) return rc;
@@ -532,6 +549,7 @@ int vxba_read_clusters(vxba_factor* f, int head, int end, double* clusters) {
 }
 
 int vxba_acc_evaluate2(vxba_factor* f, const double* Rp, int head, int end, double* Hess, double* JacT, double* residual) {
+  VX_LOCK(f);
   if (!f || !Rp || !Hess || !JacT || !residual) return fail(f, VXBA_ERR_ARG, "acc_evaluate2: null argument");
   int rc = check_range(f, head, end);
   if (rc) return rc;
@@ -546,6 +564,7 @@ int vxba_acc_evaluate2(vxba_factor* f, const double* Rp, int head, int end, doub
 }
 
 int vxba_evaluate_only_residual(vxba_factor* f, const double* Rp, int head, int end, double* residual) {
+  VX_LOCK(f);
   if (!f || !Rp || !residual) return fail(f, VXBA_ERR_ARG, "evaluate_only_residual: null argument");
   int rc = check_range(f, head, end);
   if (rc) return rc;
@@ -554,6 +573,7 @@ int vxba_evaluate_only_residual(vxba_factor* f, const double* Rp, int head, int 
 }
 
 int vxba_acc_evaluate2_device(vxba_factor* f, const double* Rp, int head, int end, double* d_out) {
+  VX_LOCK(f);
   if (!f || !Rp || !d_out) return fail(f, VXBA_ERR_ARG, "acc_evaluate2_device: null argument");
   int rc = check_range(f, head, end);
   if (rc) return rc;
@@ -562,6 +582,7 @@ int vxba_acc_evaluate2_device(vxba_factor* f, const double* Rp, int head, int en
 }
 
 int vxba_evaluate_only_residual_device(vxba_factor* f, const double* Rp, int head, int end, double* d_out) {
+  VX_LOCK(f);
   if (!f || !Rp || !d_out) return fail(f, VXBA_ERR_ARG, "evaluate_only_residual_device: null argument");
   int rc = check_range(f, head, end);
   if (rc) return rc;
@@ -570,6 +591,7 @@ int vxba_evaluate_only_residual_device(vxba_factor* f, const double* Rp, int hea
 }
 
 int vxba_read_cache(vxba_factor* f, int head, int end, double* eig_val, double* eig_vec, double* merged) {
+  VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
   int rc = check_range(f, head, end);
   if (rc) return rc;
@@ -599,6 +621,7 @@ int vxba_read_cache(vxba_factor* f, int head, int end, double* eig_val, double* 
 }
 
 int vxba_snapshot_cache(vxba_factor* f) {
+  VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
   if (f->V == 0) return fail(f, VXBA_ERR_STATE, "snapshot_cache on an empty factor");
   hipSetDevice(f->device);
@@ -613,6 +636,7 @@ int vxba_snapshot_cache(vxba_factor* f) {
 }
 
 int vxba_restore_cache(vxba_factor* f) {
+  VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
   if (!f->snapshot || f->snapshot_v != f->V || f->snapshot_vs != f->VS) return fail(f, VXBA_ERR_STATE, "no matching cache snapshot");
   hipSetDevice(f->device);
@@ -679,6 +703,7 @@ int vxba_build_clusters(int device, int64_t n_cells, int64_t n_points, const dou
 // where the reference branches (is_calc_hess, the early break).  One D2H copy + one sync at the end.
 int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out, double* resis_out, double* trace_out, int* n_trace,
                       int* is_converge) {
+  VX_LOCK(f);
   if (!f || !Rp || max_iter < 0 || max_iter > vxk::LM_MAX_ITER) return fail(f, VXBA_ERR_ARG, "damping_iter: bad argument (max_iter <= 64)");
   if (f->V == 0) return fail(f, VXBA_ERR_STATE, "damping_iter on an empty factor");
   hipSetDevice(f->device);
@@ -754,6 +779,7 @@ int vxba_damping_iter_generic(int W, double* Rp, int max_iter, vxba_hess_fn hess
 
 int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_per_solve, double* Rp_out, double* last_resis,
                   int64_t* stats_out) {
+  VX_LOCK(f);
   if (!f || !Rp_init || n_steps < 0 || steps_per_solve < 1) return fail(f, VXBA_ERR_ARG, "lm_steps: bad argument");
   if (f->V == 0) return fail(f, VXBA_ERR_STATE, "lm_steps on an empty factor");
   hipSetDevice(f->device);
@@ -805,12 +831,14 @@ int vxba_debug_stamps(int clear, unsigned long long* out, size_t n) {
 }
 
 int vxba_set_profiling(vxba_factor* f, int on) {
+  VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
   f->profiling = on;
   return VXBA_OK;
 }
 
 int vxba_get_kernel_times(vxba_factor* f, double ms_sum[4], int64_t calls[4], int reset) {
+  VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
   hipSetDevice(f->device);
   int rc = drain_events(f);
@@ -824,6 +852,7 @@ int vxba_get_kernel_times(vxba_factor* f, double ms_sum[4], int64_t calls[4], in
 }
 
 int vxba_nnz(vxba_factor* f, int64_t* nnz) {
+  VX_LOCK(f);
   if (!f || !nnz) return VXBA_ERR_ARG;
   *nnz = 0;
   if (f->V == 0) return VXBA_OK;
@@ -838,6 +867,7 @@ int vxba_nnz(vxba_factor* f, int64_t* nnz) {
 }
 
 int vxba_algorithmic_bytes(const vxba_factor* f, double bytes[2]) {
+  VX_LOCK(const_cast<vxba_factor*>(f));
   if (!f || !bytes) return VXBA_ERR_ARG;
   int64_t nnz = 0;
   int rc = vxba_nnz(const_cast<vxba_factor*>(f), &nnz);
