@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-FP64_MFMA_MEASURED_TFLOPS = 45.0   # v_mfma_f64_16x16x4_f64, two waves per SIMD, scripts/ubench/fp64_peaks.hip on MI355X
+FP64_MFMA_MEASURED_TFLOPS = 73.0   # v_mfma_f64_16x16x4_f64 issue-bound rate, scripts/ubench/mfma_f64_sweep.hip on MI355X
 FP64_SPEC_TFLOPS = 78.6            # vendor figure (not in the local guide)
 
 

@@ -33,6 +33,9 @@ if which != "k2":
     top = it[ok][:, 0:14:2]; ready = it[ok][:, 1:14:2]
     print("loop iterations: wait-for-loads cycles (median per iteration):", np.median(ready - top, axis=0))
     print("iteration period cycles (median):", np.median(np.diff(top, axis=1), axis=0))
+    ph = full[ok][:, 28:32]
+    okp = ph[:, 3] > 0
+    print("one loop iteration split (cycles, median): MFMA tile %.0f | phase A %.0f | LDS stores %.0f" % tuple(np.median(np.diff(ph[okp], axis=1), axis=0)))
 t0 = st[:, 0].min()
 rel = (st - t0) / 100.0     # s_memtime ticks at 100 MHz -> us
 print(which, "waves", n, "kernel span us:", (st[:, -1].max() - t0) / 100.0)

@@ -272,14 +272,15 @@ __device__ __forceinline__ void k3_mfma_tile(const double* ldsb, int lrow, int l
 //       ~340 cycles of a ~6200-cycle iteration, i.e. HBM latency is hidden),
 //   (2) the f64 MFMAs of batch b-1, fed from LDS buffer (b-1)&1, and
 //   (3) the phase-A VALU work of batch b, written to LDS buffer b&1.
-// Measured on MI355X (scripts/ubench/fp64_peaks.hip): one wave issues v_mfma_f64_16x16x4_f64 every ~139 cycles (~97
-// with two waves per SIMD, i.e. ~45 TFLOP/s chip-wide), f64 VALU FMA issues every 4.45 cycles (~56-61 TFLOP/s), and the
-// two do NOT overlap: pinning one MFMA between every ~9 VALU ops with sched_barrier made this kernel slower, so the
-// loop is bound by the sum of both fp64 instruction streams.
-// Also tried and rejected: doing the contraction on the VALU instead (one lane per 6x6 frame-pair block, exact upper
+// Measured on MI355X (scripts/ubench/mfma_f64_sweep.hip, mfma_valu_overlap.hip): v_mfma_f64_16x16x4_f64 issues every 64
+// cycles from a single wave (70-74 TFLOP/s chip-wide, independent of occupancy), f64 VALU FMA every ~4.3 cycles, and inside a
+// SIMD the two are strictly additive (1 MFMA + n FMA = 64 + 4.5 n cycles): they share the fp64 datapath, so pinning one
+// MFMA between every ~9 VALU ops (tried with sched_barrier) cannot hide phase A and only made this kernel slower.
+// One loop iteration is therefore ~3800 cycles of MFMA tile (50 x 64 + LDS operand reads) + ~1500 of phase A + ~800 of
+// stores / address math / waits = ~6100 cycles (s_memtime stamps, scripts/dbg_timeline.py).
+// Also tried and rejected: the contraction on the VALU instead (one lane per 6x6 frame-pair block, exact upper
 // triangle, 36 FMAs per row).  It needs 12 LDS doubles per 36 FMAs -- 216 doubles per lane and batch against the
-// MFMA form's 20 -- and ran LDS-bandwidth-bound at 45.8 us vs 32-33 us: the matrix core's operand reuse wins even
-// though its raw f64 rate is lower than the VALU's.
+// MFMA form's 20 -- and ran LDS-bandwidth-bound at 45.8 us vs 32-33 us: the matrix core's operand reuse wins.
 template <int W, bool DBG = false>
 __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, PoseArg poses, const double* __restrict__ d_Rp,
                                                                  const LMState* __restrict__ gate, int head, int end,
@@ -336,10 +337,14 @@ __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, 
       if (DBG && it_dbg < 10) { dbg_stamp(true, gw, 8 + 2 * it_dbg); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 9 + 2 * it_dbg); it_dbg++; }
       // batch b sits in e1: prefetch b + nw into e0, MFMAs of the previous batch (lds0), phase A of b -> lds1
       k3_load_entry<W>(fv, head, end, b1, b + nw, active, vl, lane, e0);
+      if (DBG && it_dbg == 3) { __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 28); __builtin_amdgcn_sched_barrier(0); }
       k3_mfma_tile<W>(lds0, lrow, lcol, acc);
+      if (DBG && it_dbg == 3) { __builtin_amdgcn_sched_barrier(0); asm volatile("" :: "v"(acc[0][0]), "v"(acc[9][3])); asm volatile("s_nop 0" ::: "memory"); dbg_stamp(true, gw, 29); __builtin_amdgcn_sched_barrier(0); }
       k3_phase_a(e1, fi, R, p, rows, dacc);
+      if (DBG && it_dbg == 3) { __builtin_amdgcn_sched_barrier(0); asm volatile("" :: "v"(rows[0][0]), "v"(rows[2][5]), "v"(dacc[26])); dbg_stamp(true, gw, 30); __builtin_amdgcn_sched_barrier(0); }
       k3_store_rows<W>(lds1, active, vl, fi, rows);
       __builtin_amdgcn_wave_barrier();
+      if (DBG && it_dbg == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 31); }
       b += nw;
       pending = 1;
       if (b > b1) break;
