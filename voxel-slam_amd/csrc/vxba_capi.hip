@@ -206,10 +206,11 @@ int shard_allreduce(vxba_factor* f, double* d_buf, size_t count) {
 }
 
 // ---- sweeps (asynchronous on f->stream; results in device memory) ----
-// Poses come either by value (Rp, host pointer -> kernel argument) or from device memory (d_Rp, e.g. the LM state);
-// `gate` lets the GPU skip the work when the device-resident LM loop does not need it.
-int sweep_hess_device(vxba_factor* f, const double* Rp, const double* d_Rp, vxk::LMState* gate, int head, int end, double* d_out,
-                      const double* cache_src = nullptr) {
+// Stand-alone mode: poses by value (Rp, host pointer -> kernel argument), lm == nullptr.
+// LM mode (lm != nullptr): the sweep's prologue takes the pending accept/reject decision from ctl[*c] (and flips *c),
+// reads the poses from the control block and skips the work when the loop does not need it; Rp carries the restart poses.
+int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c, const vxk::LMPending* pend, int head, int end,
+                      double* d_out, const double* cache_src = nullptr) {
   const size_t plen = vxba_packed_len(f);
   if (end == head) { VX_HIP(f, hipMemsetAsync(d_out, 0, plen * sizeof(double), f->stream)); return VXBA_OK; }
   int rc = ensure_partials3(f);
@@ -221,23 +222,29 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, const double* d_Rp, vxk:
   const int nv = vxk::k3_nv(f->W);
   const int nbatches = (end - 1) / nv - head / nv + 1;
   const int nblocks = std::max(1, std::min(vxk::k3_grid_blocks(f->cus), (nbatches + 3) / 4));
+  vxk::LMPending none;
+  std::memset(&none, 0, sizeof none);
+  const vxk::LMPending& pd = pend ? *pend : none;
+  const int c_in = c ? *c : 0;
+  if (lm && pd.pending) *c ^= 1;   // the prologue persists the decision into the other control block
+  const int c_now = c ? *c : 0;
   if (f->profiling & 1) {   // events bound to the dispatch itself: same interval as the profiler's kernel duration
     hipEvent_t a = get_event(f), b = get_event(f);
-    vxk::launch_k3_hessian(fv, pa, d_Rp, gate, cache_src, head, end, f->d_partial3, nblocks, f->stream, a, b);
+    vxk::launch_k3_hessian(fv, pa, lm, c_in, pd, cache_src, head, end, f->d_partial3, nblocks, f->stream, a, b);
     if (a && b) f->pending.push_back({a, b, 0});
   } else {
-    vxk::launch_k3_hessian(fv, pa, d_Rp, gate, cache_src, head, end, f->d_partial3, nblocks, f->stream);
+    vxk::launch_k3_hessian(fv, pa, lm, c_in, pd, cache_src, head, end, f->d_partial3, nblocks, f->stream);
   }
   {
     ScopedKernelTimer t(f, 2);
-    vxk::launch_k3_finalize(f->d_partial3, nblocks, f->W, gate, d_out, f->stream);
+    vxk::launch_k3_finalize(f->d_partial3, nblocks, f->W, lm, c_now, d_out, f->stream);
   }
   VX_HIP(f, hipGetLastError());
   return shard_allreduce(f, d_out, plen);
 }
 
-int sweep_residual_device(vxba_factor* f, const double* Rp, const double* d_Rp, const vxk::LMState* gate, int gate_mode, int head, int end,
-                          double* d_out, int* nparts_out = nullptr) {
+int sweep_residual_device(vxba_factor* f, const double* Rp, const vxk::LMState* lm, int c, int head, int end, double* d_out,
+                          int* nparts_out = nullptr) {
   if (end == head) { if (d_out) VX_HIP(f, hipMemsetAsync(d_out, 0, sizeof(double), f->stream)); return VXBA_OK; }
   PoseArg pa;
   if (Rp) fill_poses(f, Rp, pa); else std::memset(&pa, 0, sizeof pa);
@@ -245,10 +252,10 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, const double* d_Rp, 
   int nparts;
   if (f->profiling & 2) {
     hipEvent_t a = get_event(f), b = get_event(f);
-    nparts = vxk::launch_k2_residual(fv, pa, d_Rp, gate, gate_mode, head, end, f->d_partial2, f->stream, a, b);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, head, end, f->d_partial2, f->stream, a, b);
     if (a && b) f->pending.push_back({a, b, 1});
   } else {
-    nparts = vxk::launch_k2_residual(fv, pa, d_Rp, gate, gate_mode, head, end, f->d_partial2, f->stream);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, head, end, f->d_partial2, f->stream);
   }
   if (nparts_out) *nparts_out = nparts;
   if (d_out) {
@@ -260,14 +267,14 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, const double* d_Rp, 
 }
 
 int sweep_hess_host(vxba_factor* f, const double* Rp, int head, int end) {
-  int rc = sweep_hess_device(f, Rp, nullptr, nullptr, head, end, f->d_packed);
+  int rc = sweep_hess_device(f, Rp, nullptr, nullptr, nullptr, head, end, f->d_packed);
   if (rc) return rc;
   VX_HIP(f, hipMemcpyAsync(f->h_packed, f->d_packed, vxba_packed_len(f) * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   VX_HIP(f, hipStreamSynchronize(f->stream));
   return VXBA_OK;
 }
 int sweep_residual_host(vxba_factor* f, const double* Rp, int head, int end, double* residual) {
-  int rc = sweep_residual_device(f, Rp, nullptr, nullptr, 0, head, end, f->d_scalar);
+  int rc = sweep_residual_device(f, Rp, nullptr, 0, head, end, f->d_scalar);
   if (rc) return rc;
   VX_HIP(f, hipMemcpyAsync(f->h_scalar, f->d_scalar, sizeof(double), hipMemcpyDeviceToHost, f->stream));
   VX_HIP(f, hipStreamSynchronize(f->stream));
@@ -578,7 +585,7 @@ int vxba_acc_evaluate2_device(vxba_factor* f, const double* Rp, int head, int en
   int rc = check_range(f, head, end);
   if (rc) return rc;
   hipSetDevice(f->device);
-  return sweep_hess_device(f, Rp, nullptr, nullptr, head, end, d_out);
+  return sweep_hess_device(f, Rp, nullptr, nullptr, nullptr, head, end, d_out);
 }
 
 int vxba_evaluate_only_residual_device(vxba_factor* f, const double* Rp, int head, int end, double* d_out) {
@@ -587,7 +594,7 @@ int vxba_evaluate_only_residual_device(vxba_factor* f, const double* Rp, int hea
   int rc = check_range(f, head, end);
   if (rc) return rc;
   hipSetDevice(f->device);
-  return sweep_residual_device(f, Rp, nullptr, nullptr, 0, head, end, d_out);
+  return sweep_residual_device(f, Rp, nullptr, 0, head, end, d_out);
 }
 
 int vxba_read_cache(vxba_factor* f, int head, int end, double* eig_val, double* eig_vec, double* merged) {
@@ -711,25 +718,33 @@ int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out
   PoseArg x0;
   fill_poses(f, Rp, x0);
   vxk::launch_lm_init(f->d_lm, x0, W, 0, f->stream);
+  // The accept/reject step of iteration i is taken in the prologue of iteration i+1's Hessian sweep (every workgroup
+  // recomputes it from ctl[c]; workgroup 0 persists it into ctl[c^1]); a stand-alone decision kernel closes the loop.
+  int c = 0;
+  vxk::LMPending pend;
+  std::memset(&pend, 0, sizeof pend);
   for (int i = 0; i < max_iter; i++) {
-    int rc = sweep_hess_device(f, nullptr, f->d_lm->x, f->d_lm, 0, f->V, f->d_packed);
+    int rc = sweep_hess_device(f, Rp, f->d_lm, &c, &pend, 0, f->V, f->d_packed);
     if (rc) return rc;
-    vxk::launch_lm_solve(f->d_lm, f->d_packed, W, f->stream);
-    // residual sweep at the trial state; without a collective its wave partials are summed inside the update kernel
+    vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
+    // residual sweep at the trial state; without a collective its wave partials are summed by whoever takes the decision
     int nparts = 0;
-    rc = sweep_residual_device(f, nullptr, f->d_lm->xt, f->d_lm, 0, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts);
+    rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts);
     if (rc) return rc;
-    vxk::launch_lm_update(f->d_lm, has_collective(f) ? f->d_scalar : nullptr, f->d_partial2, nparts, f->d_scalar, W, nullptr, f->stream);
+    pend.pending = 1; pend.restart = 0;
+    pend.d_scalar = has_collective(f) ? f->d_scalar : nullptr;
+    pend.partial = f->d_partial2; pend.nparts = nparts;
   }
+  if (pend.pending) { vxk::launch_lm_update(f->d_lm, c, pend, x0, W, f->stream); c ^= 1; }
   VX_HIP(f, hipGetLastError());
   VX_HIP(f, hipMemcpyAsync(f->h_lm, f->d_lm, sizeof(vxk::LMState), hipMemcpyDeviceToHost, f->stream));
   VX_HIP(f, hipStreamSynchronize(f->stream));
-  const vxk::LMState& st = *f->h_lm;
+  const vxk::LMCtl& st = f->h_lm->ctl[c];
   std::memcpy(Rp, st.x, sizeof(double) * 12 * W);
-  if (hess_out) std::memcpy(hess_out, st.hess_out, sizeof(double) * n * n);
+  if (hess_out) std::memcpy(hess_out, f->h_lm->hess_out, sizeof(double) * n * n);
   if (resis_out) { resis_out[0] = st.resis[0]; resis_out[1] = st.resis[1]; }
   const int nt = std::min(st.iter, vxk::LM_MAX_ITER);
-  if (trace_out) std::memcpy(trace_out, st.trace, sizeof(double) * VXBA_TRACE_COLS * nt);
+  if (trace_out) std::memcpy(trace_out, f->h_lm->trace, sizeof(double) * VXBA_TRACE_COLS * nt);
   if (n_trace) *n_trace = nt;
   if (is_converge) *is_converge = st.converge;
   return VXBA_OK;
@@ -788,26 +803,33 @@ int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_
   fill_poses(f, Rp_init, x0);
   if (!f->snapshot || f->snapshot_v != f->V || f->snapshot_vs != f->VS) return fail(f, VXBA_ERR_STATE, "lm_steps needs vxba_snapshot_cache first");
   vxk::launch_lm_init(f->d_lm, x0, W, 1, f->stream);
+  int c = 0;
+  vxk::LMPending pend;
+  std::memset(&pend, 0, sizeof pend);
   for (int s = 0; s < n_steps; s++) {
     // a new window every steps_per_solve steps: its first Hessian sweep reads the SNAPSHOT cache directly (the re-seeded
-    // cache of a new window -- no copy), the residual sweeps keep writing the live cache; the previous step's update
-    // kernel already reset poses and damping
+    // cache of a new window -- no copy) and its prologue resets poses and damping (pend.restart of the previous step);
+    // the residual sweeps keep writing the live cache
     const bool first = (s % steps_per_solve) == 0;
     const bool last = ((s + 1) % steps_per_solve) == 0 && s + 1 < n_steps;
-    int rc = sweep_hess_device(f, nullptr, f->d_lm->x, f->d_lm, 0, f->V, f->d_packed, first ? f->snapshot : nullptr);
+    int rc = sweep_hess_device(f, Rp_init, f->d_lm, &c, &pend, 0, f->V, f->d_packed, first ? f->snapshot : nullptr);
     if (rc) return rc;
-    vxk::launch_lm_solve(f->d_lm, f->d_packed, W, f->stream);
+    vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
     int nparts = 0;
-    rc = sweep_residual_device(f, nullptr, f->d_lm->xt, f->d_lm, 0, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts);
+    rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts);
     if (rc) return rc;
-    vxk::launch_lm_update(f->d_lm, has_collective(f) ? f->d_scalar : nullptr, f->d_partial2, nparts, f->d_scalar, W, last ? &x0 : nullptr, f->stream);
+    pend.pending = 1; pend.restart = last ? 1 : 0;
+    pend.d_scalar = has_collective(f) ? f->d_scalar : nullptr;
+    pend.partial = f->d_partial2; pend.nparts = nparts;
   }
+  if (pend.pending) { vxk::launch_lm_update(f->d_lm, c, pend, x0, W, f->stream); c ^= 1; }
   VX_HIP(f, hipGetLastError());
   VX_HIP(f, hipMemcpyAsync(f->h_lm, f->d_lm, sizeof(vxk::LMState), hipMemcpyDeviceToHost, f->stream));
   VX_HIP(f, hipStreamSynchronize(f->stream));
-  if (Rp_out) std::memcpy(Rp_out, f->h_lm->x, sizeof(double) * 12 * W);
-  if (last_resis) { last_resis[0] = f->h_lm->residual1; last_resis[1] = f->h_lm->residual2; }
-  if (stats_out) { stats_out[0] = f->h_lm->iter; stats_out[1] = f->h_lm->n_accept; stats_out[2] = f->h_lm->n_reject; }
+  const vxk::LMCtl& st = f->h_lm->ctl[c];
+  if (Rp_out) std::memcpy(Rp_out, st.x, sizeof(double) * 12 * W);
+  if (last_resis) { last_resis[0] = st.residual1; last_resis[1] = st.residual2; }
+  if (stats_out) { stats_out[0] = st.iter; stats_out[1] = st.n_accept; stats_out[2] = st.n_reject; }
   return VXBA_OK;
 }
 

@@ -38,8 +38,12 @@ struct FactorView {
 
 // Device-resident state of the LM shell (Lidar_BA_Optimizer::damping_iter, voxel_map.hpp:367-442): the sweeps read
 // their poses and their run/skip gates from here, so a whole damping_iter is enqueued without a host round trip.
+// The small control block is double-buffered: the accept/reject decision of iteration i is taken in the PROLOGUE of
+// iteration i+1's Hessian sweep (every workgroup recomputes it from ctl[c] and the residual sweep's output while its
+// first loads are in flight; workgroup 0 persists the result into ctl[c^1]), which saves a kernel and a boundary per
+// iteration without any inter-workgroup synchronisation.
 constexpr int LM_MAX_ITER = 64;
-struct LMState {
+struct LMCtl {
   double x[12 * MAXW];        // accepted poses            (x_stats)
   double xt[12 * MAXW];       // trial poses               (x_stats_temp)
   double u, v;                // damping
@@ -52,11 +56,22 @@ struct LMState {
   int rejected;               // last step rejected
   int bench_mode;             // 1: never take the early break, so exactly n_steps iterations run (vxba_lm_steps)
   int n_accept, n_reject;     // running totals over all iterations of this init
+};
+struct LMState {
+  LMCtl ctl[2];
   double trace[LM_MAX_ITER * 8];
   double Jwork[6 * MAXW];                 // gauge-fixed gradient kept across rejected steps
   double dxi[6 * MAXW];
   double Hwork[36 * MAXW * MAXW];         // gauge-fixed Hessian kept across rejected steps
   double hess_out[36 * MAXW * MAXW];      // *hess, exported before the gauge fix (voxel_map.hpp:391)
+};
+// What a sweep needs to take the pending accept/reject decision in its prologue.
+struct LMPending {
+  int pending;                // 1: ctl[c] awaits the decision of the step whose residual sweep just ran
+  int restart;                // 1: after the decision start a new window from restart_x0 (bench driver)
+  const double* d_scalar;     // all-reduced residual2, or null: sum the nparts wave partials
+  const double* partial;
+  int nparts;
 };
 
 inline int k3_num_tiles(int W) { return (6 * W + 15) / 16; }
@@ -69,10 +84,9 @@ inline size_t k3_partial_len(int W) { return (size_t)k3_num_tile_pairs(W) * 256 
 
 // K2: residual sweep over voxels [head,end): merge + covariance + eigen-decomposition, writes the cache,
 // block partials of sum coe*lambda_0 into d_partial[0..nblocks).  Returns the number of partials.
-// d_Rp (device pointer, W*12 f64) overrides the by-value poses when non-null; gate (device int pointer) skips the
-// launch's work on the GPU when gate[gate_idx] evaluates to "do not run": K2 runs iff !done, K3 iff calc_hess && !done.
-int launch_k2_residual(const FactorView& fv, const PoseArg& poses, const double* d_Rp, const LMState* gate, int gate_mode, int head,
-                       int end, double* d_partial, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// st != null: LM mode -- poses are ctl[c].xt and the sweep skips itself on the GPU once the loop is done; else `poses`.
+int launch_k2_residual(const FactorView& fv, const PoseArg& poses, const LMState* st, int c, int head, int end, double* d_partial,
+                       hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // Deterministic sum of n partials into d_out[0].
 void launch_sum_partials(const double* d_partial, int n, double* d_out, hipStream_t s);
 // Derive aux (gap scales) from eigval for voxels [head,end) (after a caller-seeded cache).
@@ -84,19 +98,20 @@ int k3_grid_blocks(int device_cus);
 // used to start a new window from the snapshot without copying it back first.
 // ev_start / ev_stop (nullable): events tied to this dispatch's own begin / end timestamps (hipExtLaunchKernel), i.e.
 // the same interval rocprofv3 reports for the kernel -- events recorded around a launch also count the dispatch gap.
-int launch_k3_hessian(const FactorView& fv, const PoseArg& poses, const double* d_Rp, const LMState* gate, const double* cache_src,
+// st != null: LM mode -- the sweep first takes the pending accept/reject decision (LMPending) from ctl[c_in] into
+// ctl[c_in ^ 1] (if pend.pending; else it runs on ctl[c_in] as is), linearises at the decided poses and skips itself
+// when the decision says so (rejected step / loop done).  `poses` doubles as the restart poses of the bench driver.
+int launch_k3_hessian(const FactorView& fv, const PoseArg& poses, LMState* st, int c_in, const LMPending& pend, const double* cache_src,
                       int head, int end, double* d_partial, int nblocks, hipStream_t s, hipEvent_t ev_start = nullptr,
                       hipEvent_t ev_stop = nullptr);
 // Cross-workgroup reduction + assembly of the packed [Hess (6W)^2 col-major | JacT 6W | residual] buffer.
-void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* gate, double* d_packed, hipStream_t s);
+void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, double* d_packed, hipStream_t s);
 
-// LM shell on the device: init (poses, damping, flags), damped solve + trial state, accept/reject.
+// LM shell on the device: init (poses, damping, flags into ctl[0]), damped solve + trial state on ctl[c], and the
+// stand-alone decision kernel that closes the loop (ctl[c_in] -> ctl[c_in ^ 1]).
 void launch_lm_init(LMState* st, const PoseArg& x0, int W, int bench_mode, hipStream_t s);
-void launch_lm_solve(LMState* st, const double* d_packed, int W, hipStream_t s);
-// d_scalar != null: use that (all-reduced) residual; else sum the nparts wave partials of the residual sweep here.
-// restart_x0 != null: after the decision, start a new window (poses <- x0, fresh damping) -- the bench driver's solve boundary.
-void launch_lm_update(LMState* st, const double* d_scalar, const double* d_partial, int nparts, double* d_scalar_out, int W,
-                      const PoseArg* restart_x0, hipStream_t s);
+void launch_lm_solve(LMState* st, int c, int W, hipStream_t s);
+void launch_lm_update(LMState* st, int c_in, const LMPending& pend, const PoseArg& restart_x0, int W, hipStream_t s);
 
 // K1: clusters of n_voxels*W cells from bucketed points (cell = frame*n_voxels + voxel), written to the
 // frame-major planes at voxel offset v0.

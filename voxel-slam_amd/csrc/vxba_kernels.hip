@@ -32,6 +32,111 @@ __device__ __forceinline__ void dbg_stamp(bool on, int wave_id, int slot) {
   if (on && wave_id < DBG_WAVES && (threadIdx.x & 63) == 0) g_dbg[wave_id * DBG_SLOTS + slot] = __builtin_readcyclecounter();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Accept / reject + damping schedule of one LM step (voxel_map.hpp:411-439) as a pure function of the control
+// block and residual2.  Called by the stand-alone decision kernel and by the prologue of every Hessian-sweep
+// workgroup (all compute the same bits from the same inputs).
+// ------------------------------------------------------------------------------------------------
+struct LMDecision {
+  int accept;
+  double u, v, r2, q;
+  int calc_hess, done, converge, rejected, iter, n_accept, n_reject;
+};
+__device__ __forceinline__ LMDecision lm_decide(const LMCtl& in, double r2, int restart) {
+  LMDecision d;
+  const double r1 = in.residual1, q1 = in.q1;
+  d.r2 = r2;
+  d.q = r1 - r2;
+  d.accept = d.q > 0;
+  d.converge = in.converge;
+  d.n_accept = in.n_accept;
+  d.n_reject = in.n_reject;
+  if (d.accept) {
+    const double one_three = 1.0 / 3;
+    const double rho = d.q / q1;
+    const double t = 2 * rho - 1;
+    const double g = 1 - t * t * t;   // pow(t, 3) upstream; a plain cube keeps the decision off the slow path (differs by <= 1 ulp in u)
+    d.v = 2;
+    d.u = in.u * (g < one_three ? one_three : g);
+    d.calc_hess = 1;
+    d.rejected = 0;
+    d.n_accept += 1;
+  } else {
+    d.u = in.u * in.v;
+    d.v = 2 * in.v;
+    d.calc_hess = 0;
+    d.converge = 0;
+    d.rejected = 1;
+    d.n_reject += 1;
+  }
+  d.iter = in.iter + 1;
+  d.done = in.done;
+  if (!in.bench_mode && fabs((r1 - r2) / r1) < 1e-6) d.done = 1;
+  if (restart) { d.u = 0.01; d.v = 2.0; d.calc_hess = 1; d.rejected = 0; }
+  return d;
+}
+// Deterministic residual2: the all-reduced scalar if supplied, else the sum of the residual sweep's wave partials.
+// Every wave of every caller adds the same values in the same order (16 independent loads per lane and chunk, a
+// fixed in-lane tree, an xor butterfly across the wave): no LDS, no barrier, identical bits everywhere.
+__device__ __forceinline__ double lm_residual2(const LMPending& pend) {
+  if (pend.d_scalar) return pend.d_scalar[0];
+  const int lane = threadIdx.x & 63;
+  const double* __restrict__ p = pend.partial;
+  const int n = pend.nparts;
+  double total = 0.0;
+  for (int base = 0; base < n; base += 1024) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int i = base + 64 * k + lane;
+      v[k] = i < n ? p[i] : 0.0;
+    }
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+      for (int k = 0; k < w; k++) v[k] += v[k + w];
+    total += v[0];
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) total += __shfl_xor(total, m, 64);
+  return total;
+}
+// Loop already left: the control block moves to the other slot unchanged (one workgroup).
+__device__ __forceinline__ void lm_carry(LMState* st, int c_in, int W) {
+  LMCtl& out = st->ctl[c_in ^ 1];
+  const LMCtl& in = st->ctl[c_in];
+  const int tid = threadIdx.x;
+  if (tid < 12 * W) { out.x[tid] = in.x[tid]; out.xt[tid] = in.xt[tid]; }
+  if (tid == 0) {
+    out.u = in.u; out.v = in.v; out.residual1 = in.residual1; out.residual2 = in.residual2; out.q1 = in.q1;
+    out.resis[0] = in.resis[0]; out.resis[1] = in.resis[1];
+    out.calc_hess = in.calc_hess; out.done = in.done; out.iter = in.iter; out.converge = in.converge; out.rejected = in.rejected;
+    out.bench_mode = in.bench_mode; out.n_accept = in.n_accept; out.n_reject = in.n_reject;
+  }
+}
+// Persist the decided control block (one workgroup).  Poses: restart ? x0 : accept ? xt : x.
+__device__ __forceinline__ void lm_persist(LMState* st, int c_in, const LMDecision& d, int restart, const PoseArg& x0, int W) {
+  const LMCtl& in = st->ctl[c_in];
+  LMCtl& out = st->ctl[c_in ^ 1];
+  const int tid = threadIdx.x;
+  if (tid < 12 * W) {
+    const double xn = restart ? x0.Rp[tid] : (d.accept ? in.xt[tid] : in.x[tid]);
+    out.x[tid] = xn;
+    out.xt[tid] = restart ? x0.Rp[tid] : in.xt[tid];
+  }
+  if (tid == 0) {
+    const int it = in.iter;
+    double* tr = st->trace + 8 * (it < LM_MAX_ITER ? it : LM_MAX_ITER - 1);
+    tr[0] = in.residual1; tr[1] = d.r2; tr[2] = in.u; tr[3] = in.v; tr[4] = d.q; tr[5] = in.q1; tr[6] = d.accept ? 1.0 : 0.0; tr[7] = in.calc_hess;
+    out.u = d.u; out.v = d.v;
+    out.residual1 = in.residual1; out.residual2 = d.r2; out.q1 = in.q1;
+    out.resis[0] = in.resis[0]; out.resis[1] = d.r2;
+    out.calc_hess = d.calc_hess; out.done = d.done; out.iter = d.iter; out.converge = d.converge; out.rejected = d.rejected;
+    out.bench_mode = in.bench_mode; out.n_accept = d.n_accept; out.n_reject = d.n_reject;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2 -- residual sweep.  One lane per voxel, frames unrolled: every load is a 512 B contiguous row of a
 // frame-major plane, poses are wave-uniform (scalar loads), no cross-lane traffic until the final residual
@@ -42,12 +147,11 @@ __device__ __forceinline__ void dbg_stamp(bool on, int wave_id, int slot) {
 // than the hidden dependency stalls buy, because all workgroups start together and sit in the same phase.
 // ------------------------------------------------------------------------------------------------
 template <int W, bool DBG = false>
-__global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, const double* __restrict__ d_Rp,
-                                                         const LMState* __restrict__ gate, int gate_mode, int head, int end,
+__global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, const LMState* __restrict__ st, int c, int head, int end,
                                                          double* __restrict__ partial) {
-  // gate_mode 0: skip once the LM loop is done; 1: run only after a rejected step (bench-mode cache refresh)
-  if (gate && (gate_mode == 0 ? gate->done != 0 : gate->rejected == 0)) return;
-  const double* __restrict__ Rp = d_Rp ? d_Rp : poses.Rp;
+  // LM mode: trial poses of ctl[c]; nothing to do once the loop is done
+  if (st && st->ctl[c].done) return;
+  const double* __restrict__ Rp = st ? st->ctl[c].xt : poses.Rp;
   const int lane = threadIdx.x;
   const int a = head + blockIdx.x * 64 + lane;
   const size_t VS = (size_t)fv.VS;
@@ -282,28 +386,16 @@ __device__ __forceinline__ void k3_mfma_tile(const double* ldsb, int lrow, int l
 // triangle, 36 FMAs per row).  It needs 12 LDS doubles per 36 FMAs -- 216 doubles per lane and batch against the
 // MFMA form's 20 -- and ran LDS-bandwidth-bound at 45.8 us vs 32-33 us: the matrix core's operand reuse wins.
 template <int W, bool DBG = false>
-__global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, PoseArg poses, const double* __restrict__ d_Rp,
-                                                                 const LMState* __restrict__ gate, int head, int end,
-                                                                 double* __restrict__ partial) {
+__global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c_in,
+                                                                 LMPending pend, int head, int end, double* __restrict__ partial) {
   using C = K3Cfg<W>;
-  if (gate && (gate->done || !gate->calc_hess)) return;
-  const double* __restrict__ Rp = d_Rp ? d_Rp : poses.Rp;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // [4 waves][2 buffers][WAVE_LDS]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double* ldsw = lds + (size_t)wave * 2 * C::WAVE_LDS;
-  for (int k = lane; k < 2 * C::WAVE_LDS; k += 64) ldsw[k] = 0.0;  // pad rows / pad columns stay zero forever
 
   const bool active = lane < C::NACT;
   const int vl = active ? lane / W : 0;
   const int fi = active ? lane % W : 0;
-  double R[9], p[3];
-#pragma unroll
-  for (int r = 0; r < 3; r++)
-#pragma unroll
-    for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = Rp[12 * fi + 3 * cc + r];
-#pragma unroll
-  for (int k = 0; k < 3; k++) p[k] = Rp[12 * fi + 9 + k];
-
   v4d acc[C::NTP];
 #pragma unroll
   for (int t = 0; t < C::NTP; t++) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -317,14 +409,65 @@ __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, 
   const int lrow = lane >> 4, lcol = lane & 15;
   dbg_stamp(DBG, gw, 0);
 
-  if (b0 + gw <= b1) {
+  // The first two batches are requested before anything else: they do not depend on the poses, so the LM decision
+  // below (a few dependent global reads + an LDS tree) runs in the shadow of these loads.
+  const bool has_work = b0 + gw <= b1;
+  K3Entry e0, e1;
+  if (has_work) {
+    k3_load_entry<W>(fv, head, end, b1, b0 + gw, active, vl, lane, e0);
+    k3_load_entry<W>(fv, head, end, b1, b0 + gw + nw, active, vl, lane, e1);
+  }
+  // LM mode: take the pending accept/reject decision.  Every wave computes accept / done from the same inputs; both
+  // pose candidates (current, trial) are requested together with the partials so the choice costs one memory latency;
+  // the last workgroup also works out the damping update and persists the control block for the kernels that follow.
+  double R[9], p[3];
+  if (st) {
+    const LMCtl& in = st->ctl[c_in];
+    const int in_done = in.done, in_calc = in.calc_hess, bench = in.bench_mode;
+    const double r1 = in.residual1;
+    const double* __restrict__ xa_src = (pend.pending && pend.restart) ? poses.Rp : in.x;
+    double xa[12], xb[12] = {};
+#pragma unroll
+    for (int k = 0; k < 12; k++) xa[k] = xa_src[12 * fi + k];
+    bool use_b = false;
+    if (pend.pending) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) xb[k] = in.xt[12 * fi + k];
+      if (in_done) { if (blockIdx.x == gridDim.x - 1) lm_carry(st, c_in, W); return; }
+      const double r2 = lm_residual2(pend);
+      const bool accept = (r1 - r2) > 0;
+      const bool done = !bench && fabs((r1 - r2) / r1) < 1e-6;
+      if (blockIdx.x == gridDim.x - 1) {
+        const LMDecision d = lm_decide(in, r2, pend.restart);
+        lm_persist(st, c_in, d, pend.restart, poses, W);
+      }
+      if (done || !(accept || pend.restart)) return;
+      use_b = accept && !pend.restart;
+    } else {
+      if (in_done || !in_calc) return;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = use_b ? xb[3 * cc + r] : xa[3 * cc + r];
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = use_b ? xb[9 + k] : xa[9 + k];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = poses.Rp[12 * fi + 3 * cc + r];
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = poses.Rp[12 * fi + 9 + k];
+  }
+  // wave-private tiles: pad rows / pad columns stay zero forever
+  for (int k = lane; k < 2 * C::WAVE_LDS; k += 64) ldsw[k] = 0.0;
+
+  if (has_work) {
     // two entry register sets in ping-pong (loop unrolled by two: no register copies, LDS buffer index is static)
-    K3Entry e0, e1;
     double rows[3][6];
     double* lds0 = ldsw;
     double* lds1 = ldsw + C::WAVE_LDS;
-    k3_load_entry<W>(fv, head, end, b1, b0 + gw, active, vl, lane, e0);
-    k3_load_entry<W>(fv, head, end, b1, b0 + gw + nw, active, vl, lane, e1);
     if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 1); }
     k3_phase_a(e0, fi, R, p, rows, dacc);
     k3_store_rows<W>(lds0, active, vl, fi, rows);
@@ -411,10 +554,10 @@ __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, 
 __device__ __forceinline__ int sym6_index(int a, int b) { return a == 0 ? b : (a == 1 ? 2 + b : 5); }  // a <= b
 
 template <int W>
-__global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restrict__ partial, int nblocks, LMState* __restrict__ gate,
+__global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restrict__ partial, int nblocks, LMState* __restrict__ gate, int cb,
                                                            double* __restrict__ packed) {
   using C = K3Cfg<W>;
-  if (gate && (gate->done || !gate->calc_hess)) return;
+  if (gate && (gate->ctl[cb].done || !gate->ctl[cb].calc_hess)) return;
   constexpr int n = 6 * W;
   constexpr int NTILE = C::NTP * 256;
   constexpr int PLEN = NTILE + W * DACC;
@@ -479,7 +622,7 @@ __global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restr
       packed[lin] = t0;
       if (gate) {   // LM state: gauge-fixed gradient (voxel_map.hpp:400), residual1 (:388)
         if (lin < n * n + n) gate->Jwork[lin - n * n] = (lin - n * n < 6) ? 0.0 : t0;
-        else { gate->residual1 = t0; if (gate->iter == 0) gate->resis[0] = t0; }
+        else { gate->ctl[cb].residual1 = t0; if (gate->ctl[cb].iter == 0) gate->ctl[cb].resis[0] = t0; }
       }
     } else {
       const double h = t1 - t0;
@@ -675,7 +818,8 @@ __device__ __forceinline__ void lm_right_multiply_exp(const double* Rin, const d
   for (int q = 0; q < 9; q++) Rout[q] = out[q];
 }
 
-__global__ __launch_bounds__(256) void lm_init_kernel(LMState* st, PoseArg x0, int W, int bench_mode) {
+__global__ __launch_bounds__(256) void lm_init_kernel(LMState* stp, PoseArg x0, int W, int bench_mode) {
+  LMCtl* st = &stp->ctl[0];
   const int t = threadIdx.x;
   if (t < 12 * W) { st->x[t] = x0.Rp[t]; st->xt[t] = x0.Rp[t]; }
   if (t == 0) {
@@ -744,15 +888,16 @@ struct LmElim {
 // diagonal, voxel_map.hpp:403; both give the same step to round-off on such systems).  Rows/columns 0..5 are the
 // gauge (identity rows, zero right-hand side) and are skipped.
 template <int W, bool DBG = false>
-__global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, const double* __restrict__ packed) {
+__global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, int c) {
   dbg_stamp(DBG, 4000, 0);
-  if (st->done) return;
+  LMCtl& ctl = st->ctl[c];
+  if (ctl.done) return;
   dbg_stamp(DBG, 4000, 1);
   constexpr int n = 6 * W;
   const int lane = threadIdx.x;
   __shared__ double colbuf[64];
   __shared__ double xs[64];
-  const double u = st->u;
+  const double u = ctl.u;
   const bool row_ok = lane < n;
   const int i = row_ok ? lane : 0;
 
@@ -767,7 +912,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, const double*
   {
     const int fl = lane < W ? lane : 0;
 #pragma unroll
-    for (int k = 0; k < 12; k++) xcur[k] = st->x[12 * fl + k];
+    for (int k = 0; k < 12; k++) xcur[k] = ctl.x[12 * fl + k];
   }
   // my diagonal and gradient entry, kept for q1
   double hii = 0.0;
@@ -799,71 +944,24 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, const double*
     double xn[9];
     lm_right_multiply_exp(xcur, dl, xn);
 #pragma unroll
-    for (int k = 0; k < 9; k++) st->xt[12 * lane + k] = xn[k];
+    for (int k = 0; k < 9; k++) ctl.xt[12 * lane + k] = xn[k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) st->xt[12 * lane + 9 + k] = xcur[9 + k] + dl[3 + k];
+    for (int k = 0; k < 3; k++) ctl.xt[12 * lane + 9 + k] = xcur[9 + k] + dl[3 + k];
   }
   double part = row_ok ? x * (u * hii * x - gi) : 0.0;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
-  if (lane == 0) st->q1 = 0.5 * part;
+  if (lane == 0) ctl.q1 = 0.5 * part;
   if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, 4000, 5); }
 }
 
-// accept / reject + damping schedule (voxel_map.hpp:411-439).  One workgroup: first the deterministic sum of the
-// residual sweep's wave partials (unless an all-reduced scalar is supplied), then the decision in one lane.
-__global__ __launch_bounds__(256) void lm_update_kernel(LMState* st, const double* __restrict__ d_scalar, const double* __restrict__ partial,
-                                                        int nparts, double* __restrict__ scalar_out, int W, int restart, PoseArg x0) {
-  if (st->done) return;
-  __shared__ double red[256];
-  const int tid = threadIdx.x;
-  double r2;
-  if (d_scalar) r2 = d_scalar[0];
-  else {
-    double sum = 0.0;
-    for (int k = tid; k < nparts; k += 256) sum += partial[k];
-    red[tid] = sum;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (tid < off) red[tid] += red[tid + off];
-      __syncthreads();
-    }
-    r2 = red[0];
-    if (tid == 0 && scalar_out) scalar_out[0] = r2;
-  }
-  const double r1 = st->residual1, q1 = st->q1, u = st->u, v = st->v;
-  const int it = st->iter, calc = st->calc_hess, bench = st->bench_mode;
-  const double q = r1 - r2;
-  const bool accept = q > 0;
-  __syncthreads();
-  if (restart) {   // bench driver: the next step starts a new window from the initial guess
-    if (tid < 12 * W) { st->x[tid] = x0.Rp[tid]; st->xt[tid] = x0.Rp[tid]; }
-  } else if (accept && tid < 12 * W) st->x[tid] = st->xt[tid];
-  if (tid != 0) return;
-  double* tr = st->trace + 8 * (it < LM_MAX_ITER ? it : LM_MAX_ITER - 1);
-  tr[0] = r1; tr[1] = r2; tr[2] = u; tr[3] = v; tr[4] = q; tr[5] = q1; tr[6] = accept ? 1.0 : 0.0; tr[7] = calc;
-  st->residual2 = r2;
-  if (accept) {
-    const double one_three = 1.0 / 3;
-    const double rho = q / q1;
-    const double g = 1 - pow(2 * rho - 1, 3);
-    st->v = 2;
-    st->u = u * (g < one_three ? one_three : g);
-    st->calc_hess = 1;
-    st->rejected = 0;
-    st->n_accept += 1;
-  } else {
-    st->u = u * v;
-    st->v = 2 * v;
-    st->calc_hess = 0;
-    st->converge = 0;
-    st->rejected = 1;
-    st->n_reject += 1;
-  }
-  st->iter = it + 1;
-  st->resis[1] = r2;
-  if (!bench && fabs((r1 - r2) / r1) < 1e-6) st->done = 1;
-  if (restart) { st->u = 0.01; st->v = 2.0; st->calc_hess = 1; st->rejected = 0; }
+// Stand-alone decision kernel that closes the loop after the last residual sweep (inside the loop the decision is
+// taken in the prologue of the next Hessian sweep).  One workgroup.
+__global__ __launch_bounds__(256) void lm_update_kernel(LMState* st, int c_in, LMPending pend, PoseArg x0, int W) {
+  if (st->ctl[c_in].done) { lm_carry(st, c_in, W); return; }
+  const double r2 = lm_residual2(pend);
+  const LMDecision d = lm_decide(st->ctl[c_in], r2, pend.restart);
+  lm_persist(st, c_in, d, pend.restart, x0, W);
 }
 
 // Layout probe for v_mfma_f64_16x16x4_f64 (used by a GPU unit test): D(16x16) = A(16x4) B(4x16) with the operand /
@@ -908,17 +1006,17 @@ void launch_mfma_probe(const double* dA, const double* dB, double* dD, hipStream
     default: break;                                            \
   }
 
-int launch_k2_residual(const FactorView& fv, const PoseArg& poses, const double* d_Rp, const LMState* gate, int gate_mode, int head,
-                       int end, double* d_partial, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+int launch_k2_residual(const FactorView& fv, const PoseArg& poses, const LMState* st, int c, int head, int end, double* d_partial,
+                       hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int nblocks = (end - head + 63) / 64;
   if (nblocks <= 0) return 0;
   static int dbg = -1;
   if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
-  if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, d_Rp, gate, gate_mode, head, end, d_partial)); }
+  if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, st, c, head, end, d_partial)); }
   else if (ev_start) {
-    VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), dim3(nblocks), dim3(64), 0, s, ev_start, ev_stop, 0, fv, poses, d_Rp, gate,
-                                                gate_mode, head, end, d_partial));
-  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, d_Rp, gate, gate_mode, head, end, d_partial)); }
+    VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), dim3(nblocks), dim3(64), 0, s, ev_start, ev_stop, 0, fv, poses, st, c, head, end,
+                                                d_partial));
+  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, st, c, head, end, d_partial)); }
   return nblocks;
 }
 
@@ -933,7 +1031,7 @@ void launch_seed_aux(const FactorView& fv, int head, int end, hipStream_t s) {
 
 int k3_grid_blocks(int device_cus) { return device_cus; }  // one 4-wave workgroup per CU = one wave per SIMD (the kernel needs > 256 VGPRs)
 
-int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, const double* d_Rp, const LMState* gate, const double* cache_src,
+int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, LMState* st, int c_in, const LMPending& pend, const double* cache_src,
                       int head, int end, double* d_partial, int nblocks, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   FactorView fv = fv_in;
   if (cache_src) {   // eigval(3) eigvec(9) merged(10) aux(4): 26 consecutive planes
@@ -955,18 +1053,18 @@ int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, const doubl
       dbg = (ev && ev[0] == '1') ? 1 : 0;
       attr_set = true;
     }
-    if (dbg) k3_hessian_kernel<WW, true><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, d_Rp, gate, head, end, d_partial);
+    if (dbg) k3_hessian_kernel<WW, true><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, st, c_in, pend, head, end, d_partial);
     else if (ev_start)
-      hipExtLaunchKernelGGL((k3_hessian_kernel<WW, false>), dim3(nblocks), dim3(K3_BLOCK), (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, fv, poses, d_Rp, gate,
-                            head, end, d_partial);
-    else k3_hessian_kernel<WW, false><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, d_Rp, gate, head, end, d_partial);
+      hipExtLaunchKernelGGL((k3_hessian_kernel<WW, false>), dim3(nblocks), dim3(K3_BLOCK), (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, fv, poses, st, c_in, pend, head,
+                            end, d_partial);
+    else k3_hessian_kernel<WW, false><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, st, c_in, pend, head, end, d_partial);
   });
   return nblocks;
 }
 
-void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* gate, double* d_packed, hipStream_t s) {
+void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, double* d_packed, hipStream_t s) {
   const int plen = (int)k3_partial_len(W);
-  VXK_DISPATCH_W(W, k3_finalize_kernel<WW><<<dim3((plen + 63) / 64), dim3(1024), 0, s>>>(d_partial, nblocks, gate, d_packed));
+  VXK_DISPATCH_W(W, k3_finalize_kernel<WW><<<dim3((plen + 63) / 64), dim3(1024), 0, s>>>(d_partial, nblocks, st, c, d_packed));
 }
 
 void launch_k1_build(const double* d_xyz, const int64_t* d_cell_ptr, int n_voxels, int W, const FactorView& fv, int v0, hipStream_t s) {
@@ -1028,17 +1126,14 @@ void launch_count_nnz(const FactorView& fv, int V, unsigned long long* d_out, hi
 void launch_lm_init(LMState* st, const PoseArg& x0, int W, int bench_mode, hipStream_t s) {
   lm_init_kernel<<<dim3(1), dim3(256), 0, s>>>(st, x0, W, bench_mode);
 }
-void launch_lm_solve(LMState* st, const double* d_packed, int W, hipStream_t s) {
+void launch_lm_solve(LMState* st, int c, int W, hipStream_t s) {
   static int dbg = -1;
   if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
-  if (dbg) { VXK_DISPATCH_W(W, lm_solve_kernel<WW, true><<<dim3(1), dim3(64), 0, s>>>(st, d_packed)); }
-  else { VXK_DISPATCH_W(W, lm_solve_kernel<WW><<<dim3(1), dim3(64), 0, s>>>(st, d_packed)); }
+  if (dbg) { VXK_DISPATCH_W(W, lm_solve_kernel<WW, true><<<dim3(1), dim3(64), 0, s>>>(st, c)); }
+  else { VXK_DISPATCH_W(W, lm_solve_kernel<WW><<<dim3(1), dim3(64), 0, s>>>(st, c)); }
 }
-void launch_lm_update(LMState* st, const double* d_scalar, const double* d_partial, int nparts, double* d_scalar_out, int W,
-                      const PoseArg* restart_x0, hipStream_t s) {
-  PoseArg x0;
-  if (restart_x0) x0 = *restart_x0; else memset(&x0, 0, sizeof x0);
-  lm_update_kernel<<<dim3(1), dim3(256), 0, s>>>(st, d_scalar, d_partial, nparts, d_scalar_out, W, restart_x0 ? 1 : 0, x0);
+void launch_lm_update(LMState* st, int c_in, const LMPending& pend, const PoseArg& restart_x0, int W, hipStream_t s) {
+  lm_update_kernel<<<dim3(1), dim3(256), 0, s>>>(st, c_in, pend, restart_x0, W);
 }
 
 }  // namespace vxk

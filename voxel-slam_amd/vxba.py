@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvxba.so")
+LIB_PATH = os.environ.get("VXBA_LIB") or os.path.join(_HERE, "csrc", "libvxba.so")   # VXBA_LIB: A/B runs of two builds
 MAX_WIN = 10
 TRACE_COLS = 8
 
