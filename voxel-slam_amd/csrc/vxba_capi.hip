@@ -135,7 +135,7 @@ int ensure_capacity(vxba_factor* f, int n_total) {
   f->planes = np;
   f->clb = nclb;
   f->VS = want;
-  const size_t p2 = (size_t)want / 64 + 1;   // one partial per wave of 64 voxels
+  const size_t p2 = (size_t)want / 32 + 2;   // one partial per workgroup of 32..64 voxels (vxk::k2_voxels_per_block)
   if (p2 > f->partial2_len) {
     if (f->d_partial2) VX_HIP(f, hipFree(f->d_partial2));
     VX_HIP(f, hipMalloc((void**)&f->d_partial2, p2 * sizeof(double)));
@@ -252,10 +252,10 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, const vxk::LMState* 
   int nparts;
   if (f->profiling & 2) {
     hipEvent_t a = get_event(f), b = get_event(f);
-    nparts = vxk::launch_k2_residual(fv, pa, lm, c, head, end, f->d_partial2, f->stream, a, b);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, head, end, f->d_partial2, f->cus, f->stream, a, b);
     if (a && b) f->pending.push_back({a, b, 1});
   } else {
-    nparts = vxk::launch_k2_residual(fv, pa, lm, c, head, end, f->d_partial2, f->stream);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, head, end, f->d_partial2, f->cus, f->stream);
   }
   if (nparts_out) *nparts_out = nparts;
   if (d_out) {

@@ -85,7 +85,9 @@ inline size_t k3_partial_len(int W) { return (size_t)k3_num_tile_pairs(W) * 256 
 // K2: residual sweep over voxels [head,end): merge + covariance + eigen-decomposition, writes the cache,
 // block partials of sum coe*lambda_0 into d_partial[0..nblocks).  Returns the number of partials.
 // st != null: LM mode -- poses are ctl[c].xt and the sweep skips itself on the GPU once the loop is done; else `poses`.
-int launch_k2_residual(const FactorView& fv, const PoseArg& poses, const LMState* st, int c, int head, int end, double* d_partial,
+// One lane per voxel, k2_voxels_per_block(...) in [32, 64] voxels per 64-lane workgroup (balanced over `cus` CUs).
+int k2_voxels_per_block(int nvox, int cus);
+int launch_k2_residual(const FactorView& fv, const PoseArg& poses, const LMState* st, int c, int head, int end, double* d_partial, int cus,
                        hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // Deterministic sum of n partials into d_out[0].
 void launch_sum_partials(const double* d_partial, int n, double* d_out, hipStream_t s);

@@ -148,16 +148,16 @@ __device__ __forceinline__ void lm_persist(LMState* st, int c_in, const LMDecisi
 // ------------------------------------------------------------------------------------------------
 template <int W, bool DBG = false>
 __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, const LMState* __restrict__ st, int c, int head, int end,
-                                                         double* __restrict__ partial) {
+                                                         int VPB, double* __restrict__ partial) {
   // LM mode: trial poses of ctl[c]; nothing to do once the loop is done
   if (st && st->ctl[c].done) return;
-  const double* __restrict__ Rp = st ? st->ctl[c].xt : poses.Rp;
   const int lane = threadIdx.x;
-  const int a = head + blockIdx.x * 64 + lane;
+  const int a = head + blockIdx.x * VPB + lane;
+  const double* __restrict__ Rp = st ? st->ctl[c].xt : poses.Rp;
   const size_t VS = (size_t)fv.VS;
   double res = 0.0;
   dbg_stamp(DBG, blockIdx.x, 0);
-  if (a < end) {
+  if (lane < VPB && a < end) {
     // issue every load of this voxel up front (10 + 10 W independent 512 B rows per wave): with < 1 wave per
     // SIMD at 50k voxels the sweep is latency-bound unless all of them are in flight together
     double fx[10], c[W][10], Up[9];
@@ -553,18 +553,26 @@ __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, 
 // the residual.  Output buffer: Hess (6W)^2 column-major | JacT 6W | residual.
 __device__ __forceinline__ int sym6_index(int a, int b) { return a == 0 ? b : (a == 1 ? 2 + b : 5); }  // a <= b
 
+constexpr int FIN_EL = 16, FIN_SL = 64;   // FIN_EL * FIN_SL == 1024 threads
 template <int W>
 __global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restrict__ partial, int nblocks, LMState* __restrict__ gate, int cb,
                                                            double* __restrict__ packed) {
   using C = K3Cfg<W>;
-  if (gate && (gate->ctl[cb].done || !gate->ctl[cb].calc_hess)) return;
+  // LM flags: requested now (vector loads: lane-dependent zero offset), tested after the partials are in flight
+  const int zoff = threadIdx.x >> 30;
+  int f_done = gate ? (&gate->ctl[cb].done)[zoff] : 0;
+  int f_calc = gate ? (&gate->ctl[cb].calc_hess)[zoff] : 1;
   constexpr int n = 6 * W;
   constexpr int NTILE = C::NTP * 256;
   constexpr int PLEN = NTILE + W * DACC;
-  __shared__ double red0[16][64];
-  __shared__ double red1[16][64];
-  const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + el;
+  // FIN_EL elements x FIN_SL slices of the workgroup partials per block: many small blocks, because one CU cannot pull
+  // more than ~10 B/clk from L2/HBM -- 64 elements per block (45 blocks) left the reduction bound by 45 CUs' load paths
+  __shared__ double red0[FIN_SL][FIN_EL];
+  __shared__ double red1[FIN_SL][FIN_EL];
+  __shared__ double mid0[8][FIN_EL];
+  __shared__ double mid1[8][FIN_EL];
+  const int el = threadIdx.x % FIN_EL, slice = threadIdx.x / FIN_EL;
+  const int e = blockIdx.x * FIN_EL + el;
   int off1 = -1;        // second stream: block-diagonal D element that lands on the same Hessian entry
   int r = -1, c = -1;   // Hessian entry of a tile element
   int lin = -1;         // output index of a linear element (JacT / residual)
@@ -591,33 +599,49 @@ __global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restr
   }
   const bool need0 = (r >= 0) || (lin >= 0);
   double s0 = 0.0, s1 = 0.0;
+  bool flags_checked = false;
   if (need0) {
-    // issue the loads of 8 partials at a time (independent), add in fixed order
+    // the loads of 4 partials are issued together (independent), added in fixed order
     int b = slice;
-    for (; b + 16 * 7 < nblocks; b += 16 * 8) {
-      double v0[8], v1[8];
+    for (; b + FIN_SL * 3 < nblocks; b += FIN_SL * 4) {
+      double v0[4], v1[4];
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const double* pb = partial + (size_t)(b + 16 * q) * PLEN;
+      for (int q = 0; q < 4; q++) {
+        const double* pb = partial + (size_t)(b + FIN_SL * q) * PLEN;
         v0[q] = pb[e];
         v1[q] = off1 >= 0 ? pb[off1] : 0.0;
       }
+      if (!flags_checked) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(f_done), "+v"(f_calc));
+        flags_checked = true;
+      }
 #pragma unroll
-      for (int q = 0; q < 8; q++) { s0 += v0[q]; s1 += v1[q]; }
+      for (int q = 0; q < 4; q++) { s0 += v0[q]; s1 += v1[q]; }
     }
-    for (; b < nblocks; b += 16) {
+    for (; b < nblocks; b += FIN_SL) {
       const double* pb = partial + (size_t)b * PLEN;
       s0 += pb[e];
       if (off1 >= 0) s1 += pb[off1];
     }
   }
+  if (!flags_checked) asm volatile("" : "+v"(f_done), "+v"(f_calc));
+  if (f_done || !f_calc) return;   // uniform over the grid
   red0[slice][el] = s0;
   red1[slice][el] = s1;
+  __syncthreads();
+  if (slice < 8) {
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < FIN_SL / 8; k++) { t0 += red0[slice * (FIN_SL / 8) + k][el]; t1 += red1[slice * (FIN_SL / 8) + k][el]; }
+    mid0[slice][el] = t0;
+    mid1[slice][el] = t1;
+  }
   __syncthreads();
   if (slice == 0 && need0) {
     double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) { t0 += red0[k][el]; t1 += red1[k][el]; }
+    for (int k = 0; k < 8; k++) { t0 += mid0[k][el]; t1 += mid1[k][el]; }
     if (lin >= 0) {
       packed[lin] = t0;
       if (gate) {   // LM state: gauge-fixed gradient (voxel_map.hpp:400), residual1 (:388)
@@ -1006,17 +1030,27 @@ void launch_mfma_probe(const double* dA, const double* dB, double* dD, hipStream
     default: break;                                            \
   }
 
-int launch_k2_residual(const FactorView& fv, const PoseArg& poses, const LMState* st, int c, int head, int end, double* d_partial,
+int k2_voxels_per_block(int nvox, int cus) {
+  // One lane per voxel, full waves.  Tried: ceil(V / (k * cus)) voxels per workgroup so that every CU owns the same
+  // number of voxels (49 instead of 64 at cfg2, 4 workgroups on every CU): 20.0 us instead of 18.0 -- the partly
+  // filled waves cost more than the ragged last round.  VXBA_K2_VPB (32..64) keeps the experiment reproducible.
+  static int forced = -1;
+  if (forced < 0) { const char* ev = getenv("VXBA_K2_VPB"); forced = ev ? atoi(ev) : 0; }
+  if (forced >= 32 && forced <= 64) return forced;
+  return 64;
+}
+int launch_k2_residual(const FactorView& fv, const PoseArg& poses, const LMState* st, int c, int head, int end, double* d_partial, int cus,
                        hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  const int nblocks = (end - head + 63) / 64;
+  const int vpb = k2_voxels_per_block(end - head, cus);
+  const int nblocks = (end - head + vpb - 1) / vpb;
   if (nblocks <= 0) return 0;
   static int dbg = -1;
   if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
-  if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, st, c, head, end, d_partial)); }
+  if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, st, c, head, end, vpb, d_partial)); }
   else if (ev_start) {
     VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), dim3(nblocks), dim3(64), 0, s, ev_start, ev_stop, 0, fv, poses, st, c, head, end,
-                                                d_partial));
-  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, st, c, head, end, d_partial)); }
+                                                vpb, d_partial));
+  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, st, c, head, end, vpb, d_partial)); }
   return nblocks;
 }
 
@@ -1064,7 +1098,7 @@ int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, LMState* st
 
 void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, double* d_packed, hipStream_t s) {
   const int plen = (int)k3_partial_len(W);
-  VXK_DISPATCH_W(W, k3_finalize_kernel<WW><<<dim3((plen + 63) / 64), dim3(1024), 0, s>>>(d_partial, nblocks, st, c, d_packed));
+  VXK_DISPATCH_W(W, k3_finalize_kernel<WW><<<dim3((plen + FIN_EL - 1) / FIN_EL), dim3(FIN_EL * FIN_SL), 0, s>>>(d_partial, nblocks, st, c, d_packed));
 }
 
 void launch_k1_build(const double* d_xyz, const int64_t* d_cell_ptr, int n_voxels, int W, const FactorView& fv, int v0, hipStream_t s) {
