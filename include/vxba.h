@@ -166,6 +166,42 @@ int vxba_damping_iter_generic(int win_size, double* Rp, int max_iter, vxba_hess_
 int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_per_solve, double* Rp_out,
                   double* last_resis, int64_t* stats_out);
 
+/* ---- inertial half of the LiDAR-inertial BA (host code; runs while the GPU sweeps) ------------------- */
+/* Flat formats, every matrix column-major:
+ *   state (VXBA_STATE_LEN f64) = the IMUST fields the BA touches (tools.hpp:135-199): [R 9 | p 3 | v 3 | bg 3 | ba 3 | g 3]
+ *   imu   (VXBA_IMU_LEN f64)   = IMU_PRE (preintegration.hpp:11-30): [R_delta 9 | p_delta 3 | v_delta 3 | bg 3 | ba 3 |
+ *       R_bg 9 | p_bg 9 | p_ba 9 | v_bg 9 | v_ba 9 | dtime | dbg 3 | dba 3 | dbg_buf 3 | dba_buf 3 | cov 15x15]
+ * Tangent order per frame: [dphi dp dv dbg dba] (15), LiDAR block = the first 6. */
+#define VXBA_STATE_LEN 24
+#define VXBA_IMU_LEN 304
+#define VXBA_LI_DIM 15
+
+/* IMU_PRE::IMU_PRE(bg, ba) (preintegration.hpp:32-48); bg / ba may be NULL (zero). */
+int vxba_imu_init(double* imu, const double* bg, const double* ba);
+/* IMU_PRE::add_imu (preintegration.hpp:75-135): one mid-point, bias-corrected sample (what push_imu :50-73 feeds it).
+ * noise_meas / noise_walk: the reference's 6x6 `noiseMeas` / `noiseWalk` (preintegration.hpp:9, voxelslam.cpp:828-833). */
+int vxba_imu_add(double* imu, const double* gyr, const double* acc, double dt, const double* noise_meas, const double* noise_walk);
+/* IMU_PRE::give_evaluate (preintegration.hpp:137-212): *residual = r^T cov^-1 r; with jac_enable also jtj (30x30) and gg (30). */
+int vxba_imu_evaluate(const double* imu, const double* st1, const double* st2, int jac_enable, double* jtj, double* gg, double* residual);
+/* IMU_PRE::update_state (preintegration.hpp:296-303). */
+int vxba_imu_update_state(double* imu, const double* dxi15);
+/* LI_BA_Optimizer::hess_plus (voxel_map.hpp:455-463): scatter-add the (6W) LiDAR system into the (15W) one. */
+int vxba_hess_plus(int win_size, double* Hess15, double* JacT15, const double* Hess6, const double* JacT6);
+
+/* LI_BA_Optimizer::divide_thread (voxel_map.hpp:465-523): Hess (15W)^2 col-major and JacT (15W) of the joint system
+ * (imu_coef * IMU blocks + scattered LiDAR blocks), *residual = imu_coef/2 * sum r^T cov^-1 r + LiDAR residual.
+ * states W*VXBA_STATE_LEN, imus (W-1)*VXBA_IMU_LEN.  The Hessian sweep runs on the GPU, the IMU blocks on the host
+ * meanwhile. */
+int vxba_li_evaluate(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* Hess, double* JacT,
+                     double* residual);
+/* LI_BA_Optimizer::only_residual (voxel_map.hpp:525-560). */
+int vxba_li_only_residual(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* residual);
+/* LI_BA_Optimizer::damping_iter (voxel_map.hpp:562-653; three iterations upstream).  states and imus are in/out (the
+ * factors' dbg / dba and their _buf copies move with every step and roll back on a rejected one, :608-609, 639-643).
+ * hess_out (15W)^2 = `*hess`, exported before the gauge fix (:588).  trace_out max_iter*VXBA_TRACE_COLS, may be NULL. */
+int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out,
+                         double* trace_out, int* n_trace);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* Bit mask of kernels to bracket with hipEvents on the launch stream: 1 = Hessian sweep (K3), 2 = residual sweep (K2),
  * 4 = K3 cross-block reduction, 8 = cluster build (K1); 0 = off. */

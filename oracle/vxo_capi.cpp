@@ -11,6 +11,7 @@
 #include <cstdint>
 
 #include "vxo_ba.hpp"
+#include "vxo_imu.hpp"
 
 using namespace vxo;
 
@@ -44,6 +45,46 @@ void pack_poses(const std::vector<Pose>& xs, double* Rp) {
     for (int k = 0; k < 3; k++) Rp[12 * i + 9 + k] = xs[i].p[k];
   }
 }
+
+
+// ---- inertial half: flat formats shared with include/vxba.h -------------------------------------------------
+//   state : 24 f64  [R col-major (9) | p | v | bg | ba | g]
+//   imu   : 304 f64 [R_delta 9 | p_delta 3 | v_delta 3 | bg 3 | ba 3 | R_bg 9 | p_bg 9 | p_ba 9 | v_bg 9 | v_ba 9 |
+//                    dtime 1 | dbg 3 | dba 3 | dbg_buf 3 | dba_buf 3 | cov 225 col-major]
+constexpr int ST = 24, IM = 304;
+V3 unpack_v3(const double* a) { return v3(a[0], a[1], a[2]); }
+void pack_v3(const V3& a, double* o) { for (int k = 0; k < 3; k++) o[k] = a[k]; }
+ImuState unpack_state(const double* s) {
+  ImuState x;
+  x.R = unpack_m3_colmajor(s);
+  x.p = unpack_v3(s + 9); x.v = unpack_v3(s + 12); x.bg = unpack_v3(s + 15); x.ba = unpack_v3(s + 18); x.g = unpack_v3(s + 21);
+  return x;
+}
+void pack_state(const ImuState& x, double* s) {
+  pack_m3_colmajor(x.R, s);
+  pack_v3(x.p, s + 9); pack_v3(x.v, s + 12); pack_v3(x.bg, s + 15); pack_v3(x.ba, s + 18); pack_v3(x.g, s + 21);
+}
+IMU_PRE unpack_imu(const double* b) {
+  IMU_PRE f;
+  f.R_delta = unpack_m3_colmajor(b);
+  f.p_delta = unpack_v3(b + 9); f.v_delta = unpack_v3(b + 12); f.bg = unpack_v3(b + 15); f.ba = unpack_v3(b + 18);
+  f.R_bg = unpack_m3_colmajor(b + 21); f.p_bg = unpack_m3_colmajor(b + 30); f.p_ba = unpack_m3_colmajor(b + 39);
+  f.v_bg = unpack_m3_colmajor(b + 48); f.v_ba = unpack_m3_colmajor(b + 57);
+  f.dtime = b[66];
+  f.dbg = unpack_v3(b + 67); f.dba = unpack_v3(b + 70); f.dbg_buf = unpack_v3(b + 73); f.dba_buf = unpack_v3(b + 76);
+  for (int k = 0; k < 225; k++) f.cov.a[k] = b[79 + k];
+  return f;
+}
+void pack_imu(const IMU_PRE& f, double* b) {
+  pack_m3_colmajor(f.R_delta, b);
+  pack_v3(f.p_delta, b + 9); pack_v3(f.v_delta, b + 12); pack_v3(f.bg, b + 15); pack_v3(f.ba, b + 18);
+  pack_m3_colmajor(f.R_bg, b + 21); pack_m3_colmajor(f.p_bg, b + 30); pack_m3_colmajor(f.p_ba, b + 39);
+  pack_m3_colmajor(f.v_bg, b + 48); pack_m3_colmajor(f.v_ba, b + 57);
+  b[66] = f.dtime;
+  pack_v3(f.dbg, b + 67); pack_v3(f.dba, b + 70); pack_v3(f.dbg_buf, b + 73); pack_v3(f.dba_buf, b + 76);
+  for (int k = 0; k < 225; k++) b[79 + k] = f.cov.a[k];
+}
+MatX unpack_mat(const double* a, int r, int c) { MatX m(r, c); for (int k = 0; k < r * c; k++) m.a[k] = a[k]; return m; }
 
 struct Handle {
   LidarFactor factor;
@@ -224,6 +265,90 @@ void vxo_plane_fit(int64_t n, const double* clusters, double* eig_val, double* e
     for (int i = 0; i < 3; i++) eig_val[3 * a + i] = l[i];
     pack_m3_colmajor(U, eig_vec + 9 * a);
   }
+}
+
+// ---- inertial half ----
+void vxo_jr(const double* vec, double* out_colmajor) { pack_m3_colmajor(jr(unpack_v3(vec)), out_colmajor); }
+void vxo_jr_inv(const double* R_colmajor, double* out_colmajor) { pack_m3_colmajor(jr_inv(unpack_m3_colmajor(R_colmajor)), out_colmajor); }
+void vxo_mat_inverse(int n, const double* A_colmajor, double* out) {
+  MatX inv = mat_inverse(unpack_mat(A_colmajor, n, n));
+  std::memcpy(out, inv.a.data(), sizeof(double) * n * n);
+}
+// IMU_PRE::IMU_PRE(bg, ba) + add_imu (preintegration.hpp:32-48, 75-135)
+void vxo_imu_init(double* blob, const double* bg, const double* ba) { pack_imu(IMU_PRE(unpack_v3(bg), unpack_v3(ba)), blob); }
+void vxo_imu_add(double* blob, const double* gyr, const double* acc, double dt, const double* noiseMeas36, const double* noiseWalk36) {
+  IMU_PRE f = unpack_imu(blob);
+  f.add_imu(unpack_v3(gyr), unpack_v3(acc), dt, unpack_mat(noiseMeas36, 6, 6), unpack_mat(noiseWalk36, 6, 6));
+  pack_imu(f, blob);
+}
+// IMU_PRE::give_evaluate (:137-212): returns r^T cov^-1 r; jtj 30x30 col-major, gg 30 (written when jac_enable)
+double vxo_imu_evaluate(const double* blob, const double* st1, const double* st2, double* jtj, double* gg, int jac_enable) {
+  IMU_PRE f = unpack_imu(blob);
+  MatX J(2 * DIM, 2 * DIM);
+  std::vector<double> g(2 * DIM, 0.0);
+  const double r = f.give_evaluate(unpack_state(st1), unpack_state(st2), J, g, jac_enable != 0);
+  if (jac_enable) {
+    if (jtj) std::memcpy(jtj, J.a.data(), sizeof(double) * 900);
+    if (gg) std::memcpy(gg, g.data(), sizeof(double) * 30);
+  }
+  return r;
+}
+namespace {
+struct LiCtx {
+  std::vector<ImuState> xs;
+  std::vector<IMU_PRE> store;
+  std::deque<IMU_PRE*> imus;
+  LiCtx(const double* states, const double* blobs, int W) {
+    xs.resize(W);
+    for (int i = 0; i < W; i++) xs[i] = unpack_state(states + ST * i);
+    store.resize(W - 1);
+    for (int i = 0; i < W - 1; i++) store[i] = unpack_imu(blobs + IM * i);
+    for (int i = 0; i < W - 1; i++) imus.push_back(&store[i]);
+  }
+};
+}  // namespace
+// LI_BA_Optimizer::divide_thread (voxel_map.hpp:465-523): Hess (15W)^2 col-major, JacT 15W; returns the residual
+double vxo_li_divide_thread(void* h, const double* states, const double* blobs, int thd_num, double imu_coef, double* Hess, double* JacT) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  LiCtx c(states, blobs, f.win_size);
+  LI_BA_Optimizer opt;
+  opt.thd_num = thd_num; opt.imu_coef = imu_coef;
+  opt.win_size = f.win_size; opt.jac_leng = 6 * f.win_size; opt.imu_leng = DIM * f.win_size;
+  MatX H(opt.imu_leng, opt.imu_leng);
+  std::vector<double> J(opt.imu_leng);
+  const double r = opt.divide_thread(c.xs, f, c.imus, H, J);
+  std::memcpy(Hess, H.a.data(), sizeof(double) * H.a.size());
+  std::memcpy(JacT, J.data(), sizeof(double) * J.size());
+  return r;
+}
+double vxo_li_only_residual(void* h, const double* states, const double* blobs, int thd_num, double imu_coef) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  LiCtx c(states, blobs, f.win_size);
+  LI_BA_Optimizer opt;
+  opt.thd_num = thd_num; opt.imu_coef = imu_coef;
+  opt.win_size = f.win_size; opt.jac_leng = 6 * f.win_size; opt.imu_leng = DIM * f.win_size;
+  return opt.only_residual(c.xs, f, c.imus);
+}
+// LI_BA_Optimizer::damping_iter (:562-653).  states / blobs are in/out (dbg, dba and their _buf copies change).
+void vxo_li_damping_iter(void* h, double* states, double* blobs, int thd_num, double imu_coef, int max_iter, double* hess_out,
+                         double* trace_out, int* n_trace) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  const int W = f.win_size;
+  LiCtx c(states, blobs, W);
+  LI_BA_Optimizer opt;
+  opt.thd_num = thd_num; opt.imu_coef = imu_coef;
+  MatX hess;
+  opt.damping_iter(c.xs, f, c.imus, &hess, max_iter);
+  for (int i = 0; i < W; i++) pack_state(c.xs[i], states + ST * i);
+  for (int i = 0; i < W - 1; i++) pack_imu(c.store[i], blobs + IM * i);
+  if (hess_out) std::memcpy(hess_out, hess.a.data(), sizeof(double) * hess.a.size());
+  if (n_trace) *n_trace = (int)opt.trace.size();
+  if (trace_out)
+    for (size_t i = 0; i < opt.trace.size(); i++) {
+      const LMTraceEntry& t = opt.trace[i];
+      double* o = trace_out + 8 * i;
+      o[0] = t.residual1; o[1] = t.residual2; o[2] = t.u; o[3] = t.v; o[4] = t.q; o[5] = t.q1; o[6] = t.accepted; o[7] = t.recomputed_hess;
+    }
 }
 
 }  // extern "C"

@@ -48,6 +48,18 @@ def lib():
     L.vxo_cluster_transform.argtypes = [f64p, f64p, f64p]
     L.vxo_build_clusters.argtypes = [C.c_int64, i64p, f64p, f64p]
     L.vxo_plane_fit.argtypes = [C.c_int64, f64p, f64p, f64p]
+    L.vxo_jr.argtypes = [f64p, f64p]
+    L.vxo_jr_inv.argtypes = [f64p, f64p]
+    L.vxo_mat_inverse.argtypes = [C.c_int, f64p, f64p]
+    L.vxo_imu_init.argtypes = [f64p, f64p, f64p]
+    L.vxo_imu_add.argtypes = [f64p, f64p, f64p, C.c_double, f64p, f64p]
+    L.vxo_imu_evaluate.restype = C.c_double
+    L.vxo_imu_evaluate.argtypes = [f64p, f64p, f64p, f64p, f64p, C.c_int]
+    L.vxo_li_divide_thread.restype = C.c_double
+    L.vxo_li_divide_thread.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double, f64p, f64p]
+    L.vxo_li_only_residual.restype = C.c_double
+    L.vxo_li_only_residual.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double]
+    L.vxo_li_damping_iter.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double, C.c_int, f64p, f64p, C.POINTER(C.c_int)]
     _LIB = L
     return L
 
@@ -162,3 +174,69 @@ def plane_fit(clusters):
     ev = np.zeros((n, 3)); U = np.zeros((n, 9))
     lib().vxo_plane_fit(n, clusters, ev, U)
     return ev, U
+
+
+# ---- inertial half ------------------------------------------------------------------------------------------
+IMU_LEN, STATE_LEN, LI_DIM = 304, 24, 15
+
+
+def jr(v):
+    out = np.zeros(9); lib().vxo_jr(_c(v), out)
+    return out.reshape(3, 3).T.copy()
+
+
+def jr_inv(R):
+    out = np.zeros(9); lib().vxo_jr_inv(_c(np.asarray(R).T.reshape(9)), out)
+    return out.reshape(3, 3).T.copy()
+
+
+def mat_inverse(A):
+    A = np.asarray(A, dtype=np.float64); n = A.shape[0]
+    out = np.zeros(n * n); lib().vxo_mat_inverse(n, _c(A.T.reshape(-1)), out)
+    return out.reshape(n, n).T.copy()
+
+
+def imu_init(bg=None, ba=None):
+    blob = np.zeros(IMU_LEN)
+    lib().vxo_imu_init(blob, _c(np.zeros(3) if bg is None else bg), _c(np.zeros(3) if ba is None else ba))
+    return blob
+
+
+def imu_add(blob, gyr, acc, dt, noise_meas, noise_walk):
+    lib().vxo_imu_add(blob, _c(gyr), _c(acc), float(dt), _c(np.asarray(noise_meas).T), _c(np.asarray(noise_walk).T))
+
+
+def imu_preintegrate(samples, noise_meas, noise_walk, bg=None, ba=None):
+    """(W-1, 304) blobs from synth.make_imu(...).samples through the oracle's add_imu."""
+    blobs = []
+    for gyr, acc, dts in samples:
+        b = imu_init(bg, ba)
+        for g, a, dt in zip(gyr, acc, dts):
+            imu_add(b, g, a, dt, noise_meas, noise_walk)
+        blobs.append(b)
+    return np.stack(blobs) if blobs else np.zeros((0, IMU_LEN))
+
+
+def imu_evaluate(blob, st1, st2, jac_enable=True):
+    jtj = np.zeros((30, 30)); gg = np.zeros(30)
+    r = lib().vxo_imu_evaluate(_c(blob), _c(st1), _c(st2), jtj, gg, 1 if jac_enable else 0)
+    return r, jtj.T.copy(), gg
+
+
+def li_divide_thread(o, states, blobs, thd_num=5, imu_coef=1e-4):
+    n = LI_DIM * o.win_size
+    H = np.zeros((n, n)); J = np.zeros(n)
+    r = lib().vxo_li_divide_thread(o._h, _c(states), _c(blobs), thd_num, imu_coef, H, J)
+    return H.T.copy(), J, r
+
+
+def li_only_residual(o, states, blobs, thd_num=5, imu_coef=1e-4):
+    return lib().vxo_li_only_residual(o._h, _c(states), _c(blobs), thd_num, imu_coef)
+
+
+def li_damping_iter(o, states, blobs, max_iter=3, thd_num=5, imu_coef=1e-4):
+    st = _c(states).copy(); bl = _c(blobs).copy()
+    n = LI_DIM * o.win_size
+    hess = np.zeros((n, n)); trace = np.zeros((max(max_iter, 1), 8)); nt = C.c_int(0)
+    lib().vxo_li_damping_iter(o._h, st, bl, thd_num, imu_coef, max_iter, hess, trace, C.byref(nt))
+    return dict(states=st, imus=bl, hess=hess.T.copy(), trace=trace[: nt.value].copy())

@@ -1,0 +1,87 @@
+"""GPU parity of the LiDAR-inertial BA (LI_BA_Optimizer, voxel_map.hpp:446-655): voxel sweeps on the GPU + the host-side
+inertial half, against the CPU oracle's LI_BA_Optimizer on the same window, IMU stream and initial states.
+Tolerances as in test_gpu_parity.py; the IMU information matrices (condition ~1e9) bound the joint system at ~1e-6."""
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+from voxel_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vx():
+    from voxel_slam_amd import vxba
+    vxba.load_library()
+    return vxba
+
+
+def build(vx, W, V, pts, seed, p_obs=1.0):
+    sc = synth.make_scene(win_size=W, pts_per_scan=pts, n_voxels=V, p_obs=p_obs, seed=seed)
+    iw = synth.make_imu(sc, seed=seed + 1)
+    bg, ba = iw.states_init[0, 15:18], iw.states_init[0, 18:21]
+    blobs = O.imu_preintegrate(iw.samples, iw.noise_meas, iw.noise_walk, bg, ba)
+    facs = []
+    for gyr, acc, dts in iw.samples:
+        f = vx.IMU_PRE(bg, ba)
+        for g, a, dt in zip(gyr, acc, dts):
+            f.add_imu(g, a, dt, iw.noise_meas, iw.noise_walk)
+        facs.append(f)
+    fo = O.Oracle(W); fo.push_voxels(sc.clusters, sc.fix, sc.coe); fo.evaluate_only_residual(sc.poses_init)
+    fg = vx.LidarFactor(W); fg.push_voxels(sc.clusters, sc.fix, sc.coe); fg.evaluate_only_residual(sc.poses_init)
+    return sc, iw, blobs, facs, fo, fg
+
+
+@pytest.mark.parametrize("W,V,pts", [(5, 500, 6000), (10, 3000, 40000), (2, 200, 3000)])
+def test_joint_system_matches_oracle(vx, W, V, pts):
+    sc, iw, blobs, facs, fo, fg = build(vx, W, V, pts, seed=500 + W)
+    opt = vx.LI_BA_Optimizer(imu_coef=1e-4)
+    H, J, r = opt.divide_thread(iw.states_init, fg, facs)
+    Hr, Jr, rr = O.li_divide_thread(fo, iw.states_init, blobs, thd_num=5, imu_coef=1e-4)
+    assert H.shape == (15 * W, 15 * W)
+    assert np.allclose(H, H.T, rtol=1e-9, atol=1e-9 * np.abs(H).max())
+    assert np.allclose(H, Hr, rtol=1e-6, atol=1e-8 * np.abs(Hr).max())
+    assert np.allclose(J, Jr, rtol=1e-6, atol=1e-8 * np.abs(Jr).max())
+    assert np.isclose(r, rr, rtol=1e-9)
+    # the LiDAR blocks alone are reproduced to sweep precision
+    lid = np.array([15 * i + k for i in range(W) for k in range(6)])
+    H6, J6, r6 = fo.divide_thread(sc.poses_init, thd_num=5)
+    Himu = np.zeros_like(H)
+    for i in range(W - 1):
+        _, jtj, _ = O.imu_evaluate(blobs[i], iw.states_init[i], iw.states_init[i + 1])
+        Himu[15 * i:15 * i + 30, 15 * i:15 * i + 30] += 1e-4 * jtj
+    assert np.allclose((H - Himu)[np.ix_(lid, lid)], H6, rtol=1e-7, atol=1e-7 * np.abs(H6).max())
+    r2 = opt.only_residual(iw.states_init, fg, facs)
+    assert np.isclose(r2, O.li_only_residual(fo, iw.states_init, blobs, 5, 1e-4), rtol=1e-10)
+
+
+@pytest.mark.parametrize("W,V,pts,iters", [(5, 800, 8000, 3), (10, 3000, 40000, 6)])
+def test_li_damping_iter_matches_oracle(vx, W, V, pts, iters):
+    sc, iw, blobs, facs, fo, fg = build(vx, W, V, pts, seed=600 + W)
+    ref = O.li_damping_iter(fo, iw.states_init, blobs, max_iter=iters, thd_num=5, imu_coef=1e-4)
+    got = vx.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(iw.states_init, fg, facs, max_iter=iters)
+    assert got["trace"].shape == ref["trace"].shape
+    assert np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:])                 # accept / reject / recompute sequence
+    assert np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-7)          # residual1 / residual2
+    assert np.allclose(got["trace"][:, 2:4], ref["trace"][:, 2:4], rtol=1e-4)        # damping trajectory
+    et, er = synth.pose_errors(got["states"][:, :12], ref["states"][:, :12])
+    assert et < 1e-7 and er < 1e-7, (et, er)                                         # north_star: 1e-4 m / 1e-4 rad
+    assert np.allclose(got["states"][:, 12:21], ref["states"][:, 12:21], atol=1e-6)  # v, bg, ba
+    assert np.array_equal(got["states"][:, 21:], iw.states_init[:, 21:])             # gravity is not optimised
+    gi = np.stack([f.blob for f in facs])
+    assert np.allclose(gi[:, 67:79], ref["imus"][:, 67:79], atol=1e-7)               # dbg, dba and their _buf copies
+    assert np.allclose(got["hess"], ref["hess"], rtol=1e-5, atol=1e-7 * np.abs(ref["hess"]).max())
+    # the cache afterwards describes the last evaluated trial state, as upstream
+    ev_g, _, m_g = fg.read_cache(); ev_o, _, m_o = fo.read_cache()
+    assert np.allclose(m_g, m_o, rtol=1e-9, atol=1e-9) and np.allclose(ev_g, ev_o, rtol=1e-6, atol=1e-11)
+
+
+def test_li_ba_improves_on_lidar_only_velocity_and_bias(vx):
+    """The inertial terms make velocity / bias observable: after LI-BA they are closer to the truth than the initial guess."""
+    sc, iw, blobs, facs, fo, fg = build(vx, 10, 3000, 40000, seed=777)
+    got = vx.LI_BA_Optimizer().damping_iter(iw.states_init, fg, facs, max_iter=8)
+    e0 = synth.pose_errors(iw.states_init[:, :12], iw.states_gt[:, :12])
+    e1 = synth.pose_errors(got["states"][:, :12], iw.states_gt[:, :12])
+    assert e1[0] < e0[0] and e1[1] < e0[1]
+    assert np.array_equal(got["states"][0], iw.states_init[0])

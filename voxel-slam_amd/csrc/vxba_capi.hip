@@ -13,6 +13,7 @@
 
 #include "../../include/vxba.h"
 #include "vxba_host.hpp"
+#include "vxba_imu.hpp"
 #include "vxba_kernels.h"
 
 using vxk::FactorView;
@@ -830,6 +831,155 @@ int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_
   if (Rp_out) std::memcpy(Rp_out, st.x, sizeof(double) * 12 * W);
   if (last_resis) { last_resis[0] = st.residual1; last_resis[1] = st.residual2; }
   if (stats_out) { stats_out[0] = st.iter; stats_out[1] = st.n_accept; stats_out[2] = st.n_reject; }
+  return VXBA_OK;
+}
+
+// ---- inertial half (host) -------------------------------------------------------------------------------------
+int vxba_imu_init(double* imu, const double* bg, const double* ba) {
+  if (!imu) return VXBA_ERR_ARG;
+  vxi::imu_init(imu, bg, ba);
+  return VXBA_OK;
+}
+int vxba_imu_add(double* imu, const double* gyr, const double* acc, double dt, const double* noise_meas, const double* noise_walk) {
+  if (!imu || !gyr || !acc || !noise_meas || !noise_walk) return VXBA_ERR_ARG;
+  vxi::imu_add(imu, gyr, acc, dt, noise_meas, noise_walk);
+  return VXBA_OK;
+}
+int vxba_imu_evaluate(const double* imu, const double* st1, const double* st2, int jac_enable, double* jtj, double* gg, double* residual) {
+  if (!imu || !st1 || !st2 || !residual || (jac_enable && (!jtj || !gg))) return VXBA_ERR_ARG;
+  vxi::ImuWork w;
+  bool ok = true;
+  *residual = vxi::imu_evaluate(imu, st1, st2, jac_enable != 0, jtj, gg, w, &ok);
+  return ok ? VXBA_OK : VXBA_ERR_STATE;   // singular covariance (a factor without samples)
+}
+int vxba_imu_update_state(double* imu, const double* dxi15) {
+  if (!imu || !dxi15) return VXBA_ERR_ARG;
+  vxi::imu_update_state(imu, dxi15);
+  return VXBA_OK;
+}
+int vxba_hess_plus(int W, double* Hess15, double* JacT15, const double* Hess6, const double* JacT6) {
+  if (W < 1 || !Hess15 || !JacT15 || !Hess6 || !JacT6) return VXBA_ERR_ARG;
+  vxi::li_hess_plus(W, Hess15, JacT15, Hess6, JacT6);
+  return VXBA_OK;
+}
+
+namespace {
+void states_to_poses(int W, const double* states, double* Rp) {
+  for (int i = 0; i < W; i++) std::memcpy(Rp + 12 * i, states + vxi::STATE_LEN * i, sizeof(double) * 12);   // [R | p] lead the state
+}
+// divide_thread: the Hessian sweep is queued first, the IMU blocks are built on the host while it runs
+int li_joint_system(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* Hess, double* JacT, double* residual) {
+  const int W = f->W, n = vxi::DIM * W, m = 6 * W;
+  std::vector<double> Rp(12 * W);
+  states_to_poses(W, states, Rp.data());
+  int rc = sweep_hess_device(f, Rp.data(), nullptr, nullptr, nullptr, 0, f->V, f->d_packed);
+  if (rc) return rc;
+  VX_HIP(f, hipMemcpyAsync(f->h_packed, f->d_packed, vxba_packed_len(f) * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  std::memset(Hess, 0, sizeof(double) * n * n);
+  std::memset(JacT, 0, sizeof(double) * n);
+  vxi::ImuWork w;
+  bool ok = true;
+  double res = vxi::li_add_imu_blocks(W, states, imus, imu_coef, true, Hess, JacT, w, &ok);
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  if (!ok) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
+  vxi::li_hess_plus(W, Hess, JacT, f->h_packed, f->h_packed + (size_t)m * m);
+  *residual = res + f->h_packed[(size_t)m * m + m];
+  return VXBA_OK;
+}
+int li_joint_residual(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* residual) {
+  const int W = f->W;
+  std::vector<double> Rp(12 * W);
+  states_to_poses(W, states, Rp.data());
+  int rc = sweep_residual_device(f, Rp.data(), nullptr, 0, 0, f->V, f->d_scalar);
+  if (rc) return rc;
+  VX_HIP(f, hipMemcpyAsync(f->h_scalar, f->d_scalar, sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  vxi::ImuWork w;
+  bool ok = true;
+  const double r1 = vxi::li_add_imu_blocks(W, states, imus, imu_coef, false, nullptr, nullptr, w, &ok);
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  if (!ok) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
+  *residual = r1 + f->h_scalar[0];
+  return VXBA_OK;
+}
+}  // namespace
+
+int vxba_li_evaluate(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* Hess, double* JacT, double* residual) {
+  VX_LOCK(f);
+  if (!f || !states || (!imus && f->W > 1) || !Hess || !JacT || !residual) return fail(f, VXBA_ERR_ARG, "li_evaluate: null argument");
+  if (f->V == 0) return fail(f, VXBA_ERR_STATE, "li_evaluate on an empty factor");
+  hipSetDevice(f->device);
+  return li_joint_system(f, states, imus, imu_coef, Hess, JacT, residual);
+}
+int vxba_li_only_residual(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* residual) {
+  VX_LOCK(f);
+  if (!f || !states || (!imus && f->W > 1) || !residual) return fail(f, VXBA_ERR_ARG, "li_only_residual: null argument");
+  if (f->V == 0) return fail(f, VXBA_ERR_STATE, "li_only_residual on an empty factor");
+  hipSetDevice(f->device);
+  return li_joint_residual(f, states, imus, imu_coef, residual);
+}
+
+// LI_BA_Optimizer::damping_iter (voxel_map.hpp:562-653): the voxel sweeps on the GPU, the 15W-dimensional shell on the host.
+int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out, double* trace_out,
+                         int* n_trace) {
+  VX_LOCK(f);
+  if (!f || !states || (!imus && f->W > 1) || max_iter < 0) return fail(f, VXBA_ERR_ARG, "li_damping_iter: bad argument");
+  if (f->V == 0) return fail(f, VXBA_ERR_STATE, "li_damping_iter on an empty factor");
+  hipSetDevice(f->device);
+  const int W = f->W, n = vxi::DIM * W, SL = vxi::STATE_LEN;
+  double u = 0.01, v = 2;
+  std::vector<double> Hess((size_t)n * n), A((size_t)n * n), JacT(n), D(n), rhs(n), dxi(n), work(n), x_temp(states, states + (size_t)SL * W);
+  std::vector<int> perm(n);
+  double residual1 = 0, residual2 = 0;
+  bool is_calc_hess = true;
+  int nt = 0;
+  for (int it = 0; it < max_iter; it++) {
+    const bool recomputed = is_calc_hess;
+    if (is_calc_hess) {
+      int rc = li_joint_system(f, states, imus, imu_coef, Hess.data(), JacT.data(), &residual1);
+      if (rc) return rc;
+      if (hess_out) std::memcpy(hess_out, Hess.data(), sizeof(double) * n * n);   // *hess = Hess, before the gauge fix (:588)
+    }
+    // gauge: frame 0's 15 rows / columns (:591-594)
+    for (int c = 0; c < n; c++)
+      for (int r = 0; r < vxi::DIM; r++) { Hess[(size_t)c * n + r] = 0.0; Hess[(size_t)r * n + c] = 0.0; }
+    for (int r = 0; r < vxi::DIM; r++) { Hess[(size_t)r * n + r] = 1.0; JacT[r] = 0.0; }
+    for (int r = 0; r < n; r++) D[r] = Hess[(size_t)r * n + r];
+    A = Hess;
+    for (int r = 0; r < n; r++) { A[(size_t)r * n + r] += u * D[r]; rhs[r] = -JacT[r]; }
+    vxh::ldlt_solve_inplace(n, A.data(), rhs.data(), dxi.data(), perm.data(), work.data());
+    // trial state (:599-606) and the factors' bias deltas (:608-609)
+    for (int j = 0; j < W; j++) {
+      const double* d = &dxi[(size_t)vxi::DIM * j];
+      const double* s = states + (size_t)SL * j;
+      double* t = &x_temp[(size_t)SL * j];
+      vxh::right_multiply_exp(s, d, t);
+      for (int k = 0; k < 12; k++) t[9 + k] = s[9 + k] + d[3 + k];   // p, v, bg, ba
+      for (int k = 0; k < 3; k++) t[21 + k] = s[21 + k];             // g is not optimised
+    }
+    for (int j = 0; j < W - 1; j++) vxi::imu_update_state(imus + (size_t)vxi::IMU_LEN * j, &dxi[(size_t)vxi::DIM * j]);
+    double q1 = 0.0;
+    for (int r = 0; r < n; r++) q1 += dxi[r] * (u * D[r] * dxi[r] - JacT[r]);
+    q1 *= 0.5;
+    int rc = li_joint_residual(f, x_temp.data(), imus, imu_coef, &residual2);
+    if (rc) return rc;
+    const double q = residual1 - residual2;
+    const double u_used = u, v_used = v;
+    const bool accepted = vxh::lm_update_damping(residual1, residual2, q1, u, v);
+    if (accepted) {
+      std::memcpy(states, x_temp.data(), sizeof(double) * SL * W);
+      is_calc_hess = true;
+    } else {
+      is_calc_hess = false;
+      for (int j = 0; j < W - 1; j++) vxi::imu_rollback(imus + (size_t)vxi::IMU_LEN * j);
+    }
+    if (trace_out) {
+      double* o = trace_out + (size_t)VXBA_TRACE_COLS * nt;
+      o[0] = residual1; o[1] = residual2; o[2] = u_used; o[3] = v_used; o[4] = q; o[5] = q1; o[6] = accepted; o[7] = recomputed;
+    }
+    nt++;
+    if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
+  }
+  if (n_trace) *n_trace = nt;
   return VXBA_OK;
 }
 

@@ -203,3 +203,79 @@ def pose_errors(Rp_a: np.ndarray, Rp_b: np.ndarray):
         s = 0.5 * np.linalg.norm([S[2, 1] - S[1, 2], S[0, 2] - S[2, 0], S[1, 0] - S[0, 1]])
         dr.append(np.arctan2(s, c))
     return float(np.sqrt(np.mean(dt ** 2))), float(np.sqrt(np.mean(np.square(dr))))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Inertial side of a window: a smooth trajectory through the scene's ground-truth poses, an IMU sample stream
+# measured along it, and the 15-dimensional window states (R, p, v, bg, ba | g) the LiDAR-inertial BA optimises.
+# ------------------------------------------------------------------------------------------------------------
+GRAVITY = np.array([0.0, 0.0, -9.8])          # G_m_s2 of the reference (tools.hpp), world frame
+STATE_LEN = 24
+
+
+def so3_log(R: np.ndarray) -> np.ndarray:
+    """Rotation vector of R (angle < pi); atan2 form, accurate for tiny angles too."""
+    K = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    sn = np.linalg.norm(K)
+    th = np.arctan2(sn, 0.5 * (np.trace(R) - 1))
+    return K if sn < 1e-12 else (th / sn) * K
+
+
+def pack_states(Rs, ps, vs, bg, ba, g=GRAVITY) -> np.ndarray:
+    W = len(Rs)
+    out = np.zeros((W, STATE_LEN))
+    for i in range(W):
+        out[i, :9] = np.asarray(Rs[i]).T.reshape(9)
+        out[i, 9:12] = ps[i]; out[i, 12:15] = vs[i]; out[i, 15:18] = bg; out[i, 18:21] = ba; out[i, 21:24] = g
+    return out
+
+
+@dataclasses.dataclass
+class ImuWindow:
+    states_gt: np.ndarray      # (W, 24)
+    states_init: np.ndarray    # (W, 24): scene.poses_init + perturbed velocities + the bias estimate
+    samples: list              # W-1 entries of (gyr (K,3), acc (K,3), dt (K,)): mid-point, bias-estimate-corrected samples
+    noise_meas: np.ndarray     # (6,6)
+    noise_walk: np.ndarray     # (6,6)
+    dt_frame: float
+
+
+def make_imu(scene: Scene, rate_hz=200.0, frame_dt=0.1, gyr_sigma=1e-3, acc_sigma=1e-2, bias_g=(0.002, -0.001, 0.0015),
+             bias_a=(0.02, 0.01, -0.015), bias_est_err=0.3, vel_sigma=0.02, cov_gyr=0.01, cov_acc=1.0, rdw_gyr=1e-4, rdw_acc=1e-4,
+             seed=MASTER_SEED + 77) -> ImuWindow:
+    """IMU stream consistent with ``scene.poses_gt``: between frames the body turns with a constant body rate and moves
+    with a constant world acceleration (so frame poses are hit exactly); the accelerometer reads R^T (a - g) + ba + noise,
+    the gyro w + bg + noise.  The bias *estimate* used for preintegration is off by ``bias_est_err`` (relative), which is
+    what the BA's bias states have to absorb.  Noise densities default to the reference's LocalBA settings
+    (config/avia.yaml:39-42)."""
+    rng = np.random.Generator(np.random.PCG64([seed, 4242]))
+    W = scene.win_size
+    Rs, ps = unpack_poses(scene.poses_gt)
+    K = int(round(rate_hz * frame_dt))
+    h = frame_dt / K
+    bg_true = np.asarray(bias_g, dtype=np.float64); ba_true = np.asarray(bias_a, dtype=np.float64)
+    bg_est = bg_true * (1 - bias_est_err); ba_est = ba_true * (1 - bias_est_err)
+    # velocities at the frames: v_{i+1} = 2 (p_{i+1} - p_i) / T - v_i  (constant acceleration per interval)
+    vs = np.zeros((W, 3))
+    vs[0] = (ps[1] - ps[0]) / frame_dt if W > 1 else 0.0
+    samples = []
+    for i in range(W - 1):
+        a_w = 2 * (ps[i + 1] - ps[i] - vs[i] * frame_dt) / frame_dt ** 2
+        vs[i + 1] = vs[i] + a_w * frame_dt
+        w_b = so3_log(Rs[i].T @ Rs[i + 1]) / frame_dt
+        t = np.arange(K + 1) * h
+        gyr_raw = np.zeros((K + 1, 3)); acc_raw = np.zeros((K + 1, 3))
+        for k in range(K + 1):
+            Rt = Rs[i] @ rodrigues(w_b * t[k])
+            gyr_raw[k] = w_b + bg_true + rng.normal(0, gyr_sigma, 3)
+            acc_raw[k] = Rt.T @ (a_w - GRAVITY) + ba_true + rng.normal(0, acc_sigma, 3)
+        gyr = 0.5 * (gyr_raw[:-1] + gyr_raw[1:]) - bg_est        # push_imu: mid-point, minus the factor's bias (preintegration.hpp:58-69)
+        acc = 0.5 * (acc_raw[:-1] + acc_raw[1:]) - ba_est
+        samples.append((gyr, acc, np.full(K, h)))
+    Ri, pi = unpack_poses(scene.poses_init)
+    vi = vs + rng.normal(0, vel_sigma, size=vs.shape)
+    vi[0] = vs[0]
+    noise_meas = np.diag([cov_gyr] * 3 + [cov_acc] * 3).astype(np.float64)
+    noise_walk = np.diag([rdw_gyr] * 3 + [rdw_acc] * 3).astype(np.float64)
+    return ImuWindow(states_gt=pack_states(Rs, ps, vs, bg_true, ba_true), states_init=pack_states(Ri, pi, vi, bg_est, ba_est),
+                     samples=samples, noise_meas=noise_meas, noise_walk=noise_walk, dt_frame=frame_dt)

@@ -30,6 +30,8 @@ EXPORTS = [
     "vxba_evaluate_only_residual", "vxba_acc_evaluate2_device", "vxba_evaluate_only_residual_device", "vxba_packed_len",
     "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_plane_fit_judge", "vxba_build_clusters", "vxba_set_allreduce",
     "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_detach", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps",
+    "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_li_evaluate",
+    "vxba_li_only_residual", "vxba_li_damping_iter",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -90,6 +92,14 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_nnz.argtypes = [vp, C.POINTER(C.c_int64)]
     L.vxba_debug_mfma_probe.argtypes = [ci, _f64p, _f64p, _f64p]
     L.vxba_debug_stamps.argtypes = [ci, vp, C.c_size_t]
+    L.vxba_imu_init.argtypes = [_f64p, vp, vp]
+    L.vxba_imu_add.argtypes = [_f64p, _f64p, _f64p, cd, _f64p, _f64p]
+    L.vxba_imu_evaluate.argtypes = [_f64p, _f64p, _f64p, ci, vp, vp, C.POINTER(cd)]
+    L.vxba_imu_update_state.argtypes = [_f64p, _f64p]
+    L.vxba_hess_plus.argtypes = [ci, _f64p, _f64p, _f64p, _f64p]
+    L.vxba_li_evaluate.argtypes = [vp, _f64p, _f64p, cd, _f64p, _f64p, C.POINTER(cd)]
+    L.vxba_li_only_residual.argtypes = [vp, _f64p, _f64p, cd, C.POINTER(cd)]
+    L.vxba_li_damping_iter.argtypes = [vp, _f64p, _f64p, cd, ci, vp, vp, C.POINTER(ci)]
     _lib = L
     return L
 
@@ -305,6 +315,114 @@ class Lidar_BA_Optimizer:
         nt = C.c_int(0); conv = C.c_int(0)
         voxhess._chk(voxhess._L.vxba_damping_iter(voxhess.handle, Rp, int(max_iter), hess, resis, trace, C.byref(nt), C.byref(conv)))
         return dict(poses=Rp, hess=hess.T.copy(), resis=resis, trace=trace[: nt.value].copy(), is_converge=bool(conv.value))
+
+
+STATE_LEN, IMU_LEN, LI_DIM = 24, 304, 15
+
+
+def pack_state(R, p, v=None, bg=None, ba=None, g=None):
+    """One window state in the flat C-ABI format [R col-major | p | v | bg | ba | g] (tools.hpp:135-199)."""
+    z = np.zeros(3)
+    return np.concatenate([np.asarray(R, dtype=np.float64).T.reshape(9), p, z if v is None else v, z if bg is None else bg,
+                           z if ba is None else ba, z if g is None else g]).astype(np.float64)
+
+
+class IMU_PRE:
+    """Preintegrated IMU factor between two consecutive frames (reference: preintegration.hpp:11-310), host-side.
+    ``blob`` is the flat VXBA_IMU_LEN record; fields are views into it."""
+
+    _FIELDS = dict(R_delta=(0, 9), p_delta=(9, 3), v_delta=(12, 3), bg=(15, 3), ba=(18, 3), R_bg=(21, 9), p_bg=(30, 9), p_ba=(39, 9),
+                   v_bg=(48, 9), v_ba=(57, 9), dtime=(66, 1), dbg=(67, 3), dba=(70, 3), dbg_buf=(73, 3), dba_buf=(76, 3), cov=(79, 225))
+
+    def __init__(self, bg=None, ba=None, blob=None):
+        self._L = load_library()
+        if blob is not None:
+            self.blob = _c(blob).copy()
+            assert self.blob.shape == (IMU_LEN,)
+        else:
+            self.blob = np.zeros(IMU_LEN)
+            pb, kb = _opt(bg); pa, ka = _opt(ba)
+            rc = self._L.vxba_imu_init(self.blob, pb, pa)
+            if rc:
+                raise VxbaError(f"vxba_imu_init failed ({rc})")
+
+    def field(self, name):
+        o, n = self._FIELDS[name]
+        a = self.blob[o:o + n]
+        if n == 9:
+            return a.reshape(3, 3).T
+        if n == 225:
+            return a.reshape(15, 15).T
+        return a[0] if n == 1 else a
+
+    def add_imu(self, cur_gyr, cur_acc, dt, noise_meas, noise_walk):
+        """One bias-corrected mid-point sample (preintegration.hpp:75-135); noise_* are the 6x6 noiseMeas / noiseWalk."""
+        rc = self._L.vxba_imu_add(self.blob, _c(cur_gyr), _c(cur_acc), float(dt), _c(np.asarray(noise_meas).T), _c(np.asarray(noise_walk).T))
+        if rc:
+            raise VxbaError(f"vxba_imu_add failed ({rc})")
+
+    def give_evaluate(self, st1, st2, jac_enable=True):
+        """Returns (residual, jtj (30,30), gg (30,)) -- jtj/gg are None without jac_enable (preintegration.hpp:137-212)."""
+        r = C.c_double(0)
+        if jac_enable:
+            jtj = np.zeros((30, 30)); gg = np.zeros(30)
+            rc = self._L.vxba_imu_evaluate(self.blob, _c(st1), _c(st2), 1, jtj.ctypes.data_as(C.c_void_p), gg.ctypes.data_as(C.c_void_p), C.byref(r))
+            if rc:
+                raise VxbaError(f"vxba_imu_evaluate failed ({_ERRNAMES.get(rc, rc)})")
+            return r.value, jtj.T.copy(), gg
+        rc = self._L.vxba_imu_evaluate(self.blob, _c(st1), _c(st2), 0, None, None, C.byref(r))
+        if rc:
+            raise VxbaError(f"vxba_imu_evaluate failed ({_ERRNAMES.get(rc, rc)})")
+        return r.value, None, None
+
+    def update_state(self, dxi15):
+        self._L.vxba_imu_update_state(self.blob, _c(dxi15))
+
+
+def hess_plus(win_size, Hess15, JacT15, Hess6, JacT6):
+    """LI_BA_Optimizer::hess_plus (voxel_map.hpp:455-463) on (r, c)-indexed numpy arrays; returns the updated copies."""
+    H = _c(np.asarray(Hess15).T).copy(); J = _c(JacT15).copy()
+    rc = load_library().vxba_hess_plus(int(win_size), H, J, _c(np.asarray(Hess6).T), _c(JacT6))
+    if rc:
+        raise VxbaError(f"vxba_hess_plus failed ({rc})")
+    return H.T.copy(), J
+
+
+class LI_BA_Optimizer:
+    """The LiDAR-inertial LM shell (reference: voxel_map.hpp:446-655): 15 unknowns per frame, IMU factors between
+    consecutive frames, voxel sweeps on the GPU."""
+
+    def __init__(self, imu_coef: float = 1e-4):
+        self.imu_coef = float(imu_coef)
+
+    @staticmethod
+    def _blobs(imus_factor):
+        return _c(np.stack([f.blob for f in imus_factor])) if len(imus_factor) else np.zeros((0, IMU_LEN))
+
+    def divide_thread(self, x_stats, voxhess: LidarFactor, imus_factor):
+        """Returns (Hess (15W,15W), JacT (15W,), residual)."""
+        n = LI_DIM * voxhess.win_size
+        H = np.zeros((n, n)); J = np.zeros(n); r = C.c_double(0)
+        voxhess._chk(voxhess._L.vxba_li_evaluate(voxhess.handle, _c(x_stats), self._blobs(imus_factor), self.imu_coef, H, J, C.byref(r)))
+        return H.T.copy(), J, r.value
+
+    def only_residual(self, x_stats, voxhess: LidarFactor, imus_factor):
+        r = C.c_double(0)
+        voxhess._chk(voxhess._L.vxba_li_only_residual(voxhess.handle, _c(x_stats), self._blobs(imus_factor), self.imu_coef, C.byref(r)))
+        return r.value
+
+    def damping_iter(self, x_stats, voxhess: LidarFactor, imus_factor, max_iter: int = 3):
+        """Returns dict(states, hess, trace); the IMU factors' dbg/dba are updated in place like upstream (:608-609)."""
+        W = voxhess.win_size
+        n = LI_DIM * W
+        st = _c(x_stats).copy()
+        blobs = self._blobs(imus_factor)
+        hess = np.zeros((n, n)); trace = np.zeros((max(max_iter, 1), TRACE_COLS)); nt = C.c_int(0)
+        voxhess._chk(voxhess._L.vxba_li_damping_iter(voxhess.handle, st, blobs, self.imu_coef, int(max_iter), hess.ctypes.data_as(C.c_void_p),
+                                                     trace.ctypes.data_as(C.c_void_p), C.byref(nt)))
+        for f, b in zip(imus_factor, blobs):
+            f.blob[:] = b
+        return dict(states=st, hess=hess.T.copy(), trace=trace[: nt.value].copy())
 
 
 def damping_iter_generic(win_size: int, x_stats, hess_fn, resid_fn, max_iter: int = 3):
