@@ -183,6 +183,9 @@ int vxba_imu_init(double* imu, const double* bg, const double* ba);
 int vxba_imu_add(double* imu, const double* gyr, const double* acc, double dt, const double* noise_meas, const double* noise_walk);
 /* IMU_PRE::give_evaluate (preintegration.hpp:137-212): *residual = r^T cov^-1 r; with jac_enable also jtj (30x30) and gg (30). */
 int vxba_imu_evaluate(const double* imu, const double* st1, const double* st2, int jac_enable, double* jtj, double* gg, double* residual);
+/* IMU_PRE::give_evaluate_g (preintegration.hpp:214-294): as above with three more Jacobian columns for the gravity
+ * vector -- jtj 33x33, gg 33. */
+int vxba_imu_evaluate_g(const double* imu, const double* st1, const double* st2, int jac_enable, double* jtj, double* gg, double* residual);
 /* IMU_PRE::update_state (preintegration.hpp:296-303). */
 int vxba_imu_update_state(double* imu, const double* dxi15);
 /* LI_BA_Optimizer::hess_plus (voxel_map.hpp:455-463): scatter-add the (6W) LiDAR system into the (15W) one. */
@@ -201,6 +204,12 @@ int vxba_li_only_residual(vxba_factor* f, const double* states, const double* im
  * hess_out (15W)^2 = `*hess`, exported before the gauge fix (:588).  trace_out max_iter*VXBA_TRACE_COLS, may be NULL. */
 int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out,
                          double* trace_out, int* n_trace);
+
+/* LI_BA_OptimizerGravity::damping_iter (voxel_map.hpp:775-862; max_iter = 5 at its call site voxelslam.cpp:1644): the
+ * gravity vector (states[21..23] of every frame, kept equal) joins the unknowns at the tail of the system; hess_out is
+ * (15W+3)^2; only frame 0's pose is gauge-fixed.  resis_out[2] = residual before / after. */
+int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out,
+                                 double* resis_out, double* trace_out, int* n_trace);
 
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* Bit mask of kernels to bracket with hipEvents on the launch stream: 1 = Hessian sweep (K3), 2 = residual sweep (K2),

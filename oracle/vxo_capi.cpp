@@ -351,4 +351,40 @@ void vxo_li_damping_iter(void* h, double* states, double* blobs, int thd_num, do
     }
 }
 
+// IMU_PRE::give_evaluate_g (:214-294): jtj 33x33, gg 33
+double vxo_imu_evaluate_g(const double* blob, const double* st1, const double* st2, double* jtj, double* gg, int jac_enable) {
+  IMU_PRE f = unpack_imu(blob);
+  MatX J(2 * DIM + 3, 2 * DIM + 3);
+  std::vector<double> g(2 * DIM + 3, 0.0);
+  const double r = f.give_evaluate_g(unpack_state(st1), unpack_state(st2), J, g, jac_enable != 0);
+  if (jac_enable) {
+    if (jtj) std::memcpy(jtj, J.a.data(), sizeof(double) * 33 * 33);
+    if (gg) std::memcpy(gg, g.data(), sizeof(double) * 33);
+  }
+  return r;
+}
+// LI_BA_OptimizerGravity::damping_iter (voxel_map.hpp:775-862): hess_out (15W+3)^2, resis_out[2]
+void vxo_li_damping_iter_gravity(void* h, double* states, double* blobs, int thd_num, double imu_coef, int max_iter, double* hess_out,
+                                 double* resis_out, double* trace_out, int* n_trace) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  const int W = f.win_size;
+  LiCtx c(states, blobs, W);
+  LI_BA_OptimizerGravity opt;
+  opt.thd_num = thd_num; opt.imu_coef = imu_coef;
+  MatX hess;
+  std::vector<double> resis;
+  opt.damping_iter(c.xs, f, c.imus, resis, &hess, max_iter);
+  for (int i = 0; i < W; i++) pack_state(c.xs[i], states + ST * i);
+  for (int i = 0; i < W - 1; i++) pack_imu(c.store[i], blobs + IM * i);
+  if (hess_out) std::memcpy(hess_out, hess.a.data(), sizeof(double) * hess.a.size());
+  if (resis_out && resis.size() >= 2) { resis_out[0] = resis[0]; resis_out[1] = resis[1]; }
+  if (n_trace) *n_trace = (int)opt.trace.size();
+  if (trace_out)
+    for (size_t i = 0; i < opt.trace.size(); i++) {
+      const LMTraceEntry& t = opt.trace[i];
+      double* o = trace_out + 8 * i;
+      o[0] = t.residual1; o[1] = t.residual2; o[2] = t.u; o[3] = t.v; o[4] = t.q; o[5] = t.q1; o[6] = t.accepted; o[7] = t.recomputed_hess;
+    }
+}
+
 }  // extern "C"

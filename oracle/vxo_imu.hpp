@@ -198,6 +198,13 @@ class IMU_PRE {
 
   // :137-212.  jtj (30x30) / gg (30) are written only when jac_enable.
   double give_evaluate(const ImuState& st1, const ImuState& st2, MatX& jtj, std::vector<double>& gg, bool jac_enable) const {
+    return evaluate(st1, st2, jtj, gg, jac_enable, false);
+  }
+  // :214-294.  Same residual; the Jacobian gets three more columns for the gravity vector: jtj 33x33, gg 33.
+  double give_evaluate_g(const ImuState& st1, const ImuState& st2, MatX& jtj, std::vector<double>& gg, bool jac_enable) const {
+    return evaluate(st1, st2, jtj, gg, jac_enable, true);
+  }
+  double evaluate(const ImuState& st1, const ImuState& st2, MatX& jtj, std::vector<double>& gg, bool jac_enable, bool with_g) const {
     MatX joca(DIM, DIM), jocb(DIM, DIM);
     std::vector<double> rr(DIM, 0.0);
 
@@ -245,13 +252,18 @@ class IMU_PRE {
       set_block(jocb, 9, 9, b_wei * eye33());
       set_block(jocb, 12, 12, b_wei * eye33());
 
-      MatX joc(DIM, 2 * DIM);
+      const int nc = 2 * DIM + (with_g ? 3 : 0);
+      MatX joc(DIM, nc);
       for (int c = 0; c < DIM; c++)
         for (int r = 0; r < DIM; r++) { joc(r, c) = joca(r, c); joc(r, DIM + c) = jocb(r, c); }
-      const MatX jt_ci = mat_mul(mat_t(joc), cov_inv);   // 30 x 15
+      if (with_g) {   // :277-278
+        set_block(joc, 3, 2 * DIM, R1t * (-0.5 * dtime * dtime));
+        set_block(joc, 6, 2 * DIM, R1t * (-dtime));
+      }
+      const MatX jt_ci = mat_mul(mat_t(joc), cov_inv);   // nc x 15
       jtj = mat_mul(jt_ci, joc);
-      gg.assign(2 * DIM, 0.0);
-      for (int i = 0; i < 2 * DIM; i++) {
+      gg.assign(nc, 0.0);
+      for (int i = 0; i < nc; i++) {
         double s = 0;
         for (int k = 0; k < DIM; k++) s += jt_ci(i, k) * rr[k];
         gg[i] = s;
@@ -445,6 +457,142 @@ class LI_BA_Optimizer {
       trace.push_back(te);
       if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
     }
+  }
+};
+
+// voxel_map.hpp:658-864.  Three gravity unknowns appended at the tail of the 15W system; only frame 0's POSE (6) is
+// gauge-fixed (:800-803); x_stats_temp is never reset from x_stats, so the gravity of a rejected trial is kept and the
+// next increment is added on top of it (:813) -- reproduced as is.
+class LI_BA_OptimizerGravity {
+ public:
+  int win_size = 0, jac_leng = 0, imu_leng = 0, thd_num = 5;
+  double imu_coef = 1e-4;
+  std::vector<LMTraceEntry> trace;
+
+  double divide_thread(std::vector<ImuState>& x_stats, LidarFactor& voxhess, std::deque<IMU_PRE*>& imus_factor, MatX& Hess,
+                       std::vector<double>& JacT) {
+    double residual = 0;
+    Hess.setZero();
+    std::fill(JacT.begin(), JacT.end(), 0.0);
+    std::vector<MatX> hessians(thd_num);
+    std::vector<std::vector<double>> jacobins(thd_num);
+    std::vector<double> resis(thd_num, 0);
+    for (int i = 0; i < thd_num; i++) { hessians[i].resize(jac_leng, jac_leng); jacobins[i].assign(jac_leng, 0.0); }
+    int tthd_num = thd_num;
+    const int g_size = (int)voxhess.plvec_voxels.size();
+    if (g_size < tthd_num) tthd_num = 1;
+    const double part = 1.0 * g_size / tthd_num;
+    const std::vector<Pose> poses = LI_BA_Optimizer::poses_of(x_stats);
+    std::vector<std::thread*> mthreads(tthd_num, nullptr);
+    for (int i = 1; i < tthd_num; i++)
+      mthreads[i] = new std::thread(&LidarFactor::acc_evaluate2, &voxhess, poses, (int)(part * i), (int)(part * (i + 1)),
+                                    std::ref(hessians[i]), std::ref(jacobins[i]), std::ref(resis[i]));
+    MatX jtj(2 * DIM + 3, 2 * DIM + 3);
+    std::vector<double> gg(2 * DIM + 3);
+    const int gq = imu_leng - 3;
+    for (int i = 0; i < win_size - 1; i++) {
+      residual += imus_factor[i]->give_evaluate_g(x_stats[i], x_stats[i + 1], jtj, gg, true);
+      for (int c = 0; c < 2 * DIM; c++)
+        for (int r = 0; r < 2 * DIM; r++) Hess(i * DIM + r, i * DIM + c) += jtj(r, c);
+      for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 2 * DIM; r++) { Hess(i * DIM + r, gq + c) += jtj(r, 2 * DIM + c); Hess(gq + c, i * DIM + r) += jtj(2 * DIM + c, r); }
+      for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) Hess(gq + r, gq + c) += jtj(2 * DIM + r, 2 * DIM + c);
+      for (int r = 0; r < 2 * DIM; r++) JacT[i * DIM + r] += gg[r];
+      for (int r = 0; r < 3; r++) JacT[gq + r] += gg[2 * DIM + r];
+    }
+    for (double& h : Hess.a) h *= imu_coef;
+    for (double& j : JacT) j *= imu_coef;
+    residual *= (imu_coef * 0.5);
+    for (int i = 0; i < tthd_num; i++) {
+      if (i != 0) mthreads[i]->join();
+      else voxhess.acc_evaluate2(poses, 0, (int)part, hessians[0], jacobins[0], resis[0]);
+      for (int a = 0; a < win_size; a++) {     // hess_plus :663-671
+        for (int k = 0; k < DVEL; k++) JacT[a * DIM + k] += jacobins[i][a * DVEL + k];
+        for (int b = 0; b < win_size; b++)
+          for (int c = 0; c < DVEL; c++)
+            for (int r = 0; r < DVEL; r++) Hess(a * DIM + r, b * DIM + c) += hessians[i](a * DVEL + r, b * DVEL + c);
+      }
+      residual += resis[i];
+      delete mthreads[i];
+    }
+    return residual;
+  }
+
+  double only_residual(std::vector<ImuState>& x_stats, LidarFactor& voxhess, std::deque<IMU_PRE*>& imus_factor) {
+    LI_BA_Optimizer o;   // same arithmetic: give_evaluate_g without Jacobian == give_evaluate without Jacobian (:738-773)
+    o.win_size = win_size; o.jac_leng = jac_leng; o.imu_leng = imu_leng; o.thd_num = thd_num; o.imu_coef = imu_coef;
+    return o.only_residual(x_stats, voxhess, imus_factor);
+  }
+
+  void damping_iter(std::vector<ImuState>& x_stats, LidarFactor& voxhess, std::deque<IMU_PRE*>& imus_factor, std::vector<double>& resis,
+                    MatX* hess, int max_iter = 2) {
+    win_size = voxhess.win_size;
+    jac_leng = win_size * 6;
+    imu_leng = win_size * DIM + 3;
+    trace.clear();
+    double u = 0.01, v = 2;
+    MatX D(imu_leng, imu_leng), Hess(imu_leng, imu_leng);
+    std::vector<double> JacT(imu_leng), dxi(imu_leng);
+    double residual1 = 0, residual2 = 0, q;
+    bool is_calc_hess = true;
+    std::vector<ImuState> x_stats_temp = x_stats;
+    for (int i = 0; i < max_iter; i++) {
+      LMTraceEntry te{};
+      te.recomputed_hess = is_calc_hess;
+      if (is_calc_hess) {
+        residual1 = divide_thread(x_stats, voxhess, imus_factor, Hess, JacT);
+        *hess = Hess;
+      }
+      if (i == 0) resis.push_back(residual1);
+      for (int r = 0; r < 6; r++) for (int c = 0; c < imu_leng; c++) Hess(r, c) = 0.0;
+      for (int c = 0; c < 6; c++) for (int r = 0; r < imu_leng; r++) Hess(r, c) = 0.0;
+      for (int r = 0; r < 6; r++) { Hess(r, r) = 1.0; JacT[r] = 0.0; }
+      for (int r = 0; r < imu_leng; r++) D(r, r) = Hess(r, r);
+      MatX A(imu_leng, imu_leng);
+      for (int c = 0; c < imu_leng; c++)
+        for (int r = 0; r < imu_leng; r++) A(r, c) = Hess(r, c) + (r == c ? u * D(r, r) : 0.0);
+      std::vector<double> rhs(imu_leng);
+      for (int r = 0; r < imu_leng; r++) rhs[r] = -JacT[r];
+      dxi = ldlt_solve(A, rhs);
+
+      x_stats_temp[0].g = x_stats_temp[0].g + v3(dxi[imu_leng - 3], dxi[imu_leng - 2], dxi[imu_leng - 1]);
+      for (int j = 0; j < win_size; j++) {
+        const double* d = &dxi[DIM * j];
+        x_stats_temp[j].R = x_stats[j].R * Exp(v3(d[0], d[1], d[2]));
+        x_stats_temp[j].p = x_stats[j].p + v3(d[3], d[4], d[5]);
+        x_stats_temp[j].v = x_stats[j].v + v3(d[6], d[7], d[8]);
+        x_stats_temp[j].bg = x_stats[j].bg + v3(d[9], d[10], d[11]);
+        x_stats_temp[j].ba = x_stats[j].ba + v3(d[12], d[13], d[14]);
+        x_stats_temp[j].g = x_stats_temp[0].g;
+      }
+      for (int j = 0; j < win_size - 1; j++) imus_factor[j]->update_state(&dxi[DIM * j]);
+      double q1 = 0;
+      for (int r = 0; r < imu_leng; r++) q1 += dxi[r] * (u * D(r, r) * dxi[r] - JacT[r]);
+      q1 *= 0.5;
+      residual2 = only_residual(x_stats_temp, voxhess, imus_factor);
+      q = residual1 - residual2;
+      te.residual1 = residual1; te.residual2 = residual2; te.u = u; te.v = v; te.q = q; te.q1 = q1;
+      if (q > 0) {
+        x_stats = x_stats_temp;
+        const double one_three = 1.0 / 3;
+        q = q / q1;
+        v = 2;
+        q = 1 - std::pow(2 * q - 1, 3);
+        u *= (q < one_three ? one_three : q);
+        is_calc_hess = true;
+        te.accepted = 1;
+      } else {
+        u = u * v;
+        v = 2 * v;
+        is_calc_hess = false;
+        te.accepted = 0;
+        for (int j = 0; j < win_size - 1; j++) { imus_factor[j]->dbg = imus_factor[j]->dbg_buf; imus_factor[j]->dba = imus_factor[j]->dba_buf; }
+      }
+      trace.push_back(te);
+      if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
+    }
+    resis.push_back(residual2);
   }
 };
 

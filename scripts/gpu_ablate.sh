@@ -3,7 +3,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 for v in ${VARIANTS:-0 2 3 4}; do
   echo "== VXBA_K3_SGB=$v"
-  VXBA_K3_SGB=$v timeout 600 python bench.py --steps ${STEPS:-90} --warmup 9 --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | python -c "
+  VXBA_K3_SGB=$v timeout 600 python bench.py --steps ${STEPS:-90} --warmup 9 --no-cpu-baseline --no-li-ba 2>&1 | grep -v amdgpu.ids | python -c "
 import sys, json
 for l in sys.stdin:
     try: d = json.loads(l)

@@ -6,7 +6,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | tail -5
 for v in ${VARIANTS:-0}; do
   echo "== VXBA_K3_SGB=$v"
-  VXBA_K3_SGB=$v timeout 600 python bench.py --steps ${STEPS:-150} --warmup 15 --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | python -c "
+  VXBA_K3_SGB=$v timeout 600 python bench.py --steps ${STEPS:-150} --warmup 15 --no-cpu-baseline --no-li-ba 2>&1 | grep -v amdgpu.ids | python -c "
 import sys, json
 for l in sys.stdin:
     try: d = json.loads(l)

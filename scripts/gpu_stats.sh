@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; rm -rf gpurun_out/prof_trace
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_trace" -o t -- python "$GRAFT_REPO_ROOT/bench.py" --steps ${STEPS:-90} --warmup 9 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_trace.log" 2>&1 )
+( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_trace" -o t -- python "$GRAFT_REPO_ROOT/bench.py" --steps ${STEPS:-90} --warmup 9 --no-cpu-baseline --no-li-ba > "$GRAFT_REPO_ROOT/gpurun_out/prof_trace.log" 2>&1 )
 grep -v amdgpu.ids gpurun_out/prof_trace.log | tail -1 | cut -c1-400
 python - <<'PY'
 import csv

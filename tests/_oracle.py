@@ -60,6 +60,9 @@ def lib():
     L.vxo_li_only_residual.restype = C.c_double
     L.vxo_li_only_residual.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double]
     L.vxo_li_damping_iter.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double, C.c_int, f64p, f64p, C.POINTER(C.c_int)]
+    L.vxo_imu_evaluate_g.restype = C.c_double
+    L.vxo_imu_evaluate_g.argtypes = [f64p, f64p, f64p, f64p, f64p, C.c_int]
+    L.vxo_li_damping_iter_gravity.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double, C.c_int, f64p, f64p, f64p, C.POINTER(C.c_int)]
     _LIB = L
     return L
 
@@ -240,3 +243,17 @@ def li_damping_iter(o, states, blobs, max_iter=3, thd_num=5, imu_coef=1e-4):
     hess = np.zeros((n, n)); trace = np.zeros((max(max_iter, 1), 8)); nt = C.c_int(0)
     lib().vxo_li_damping_iter(o._h, st, bl, thd_num, imu_coef, max_iter, hess, trace, C.byref(nt))
     return dict(states=st, imus=bl, hess=hess.T.copy(), trace=trace[: nt.value].copy())
+
+
+def imu_evaluate_g(blob, st1, st2):
+    jtj = np.zeros((33, 33)); gg = np.zeros(33)
+    r = lib().vxo_imu_evaluate_g(_c(blob), _c(st1), _c(st2), jtj, gg, 1)
+    return r, jtj.T.copy(), gg
+
+
+def li_damping_iter_gravity(o, states, blobs, max_iter=2, thd_num=5, imu_coef=1e-4):
+    st = _c(states).copy(); bl = _c(blobs).copy()
+    n = LI_DIM * o.win_size + 3
+    hess = np.zeros((n, n)); resis = np.zeros(2); trace = np.zeros((max(max_iter, 1), 8)); nt = C.c_int(0)
+    lib().vxo_li_damping_iter_gravity(o._h, st, bl, thd_num, imu_coef, max_iter, hess, resis, trace, C.byref(nt))
+    return dict(states=st, imus=bl, hess=hess.T.copy(), resis=resis, trace=trace[: nt.value].copy())

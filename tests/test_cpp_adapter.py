@@ -13,17 +13,23 @@ EXE = os.path.join(ROOT, "tests", "cpp", "adapter_demo")
 LIBDIR = os.path.join(ROOT, "voxel-slam_amd", "csrc")
 
 
-def build():
-    deps = [SRC, os.path.join(ROOT, "include", "vxba_lidar_factor.hpp"), os.path.join(ROOT, "include", "vxba.h")]
-    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++14", "-I", os.path.join(ROOT, "include"), SRC, "-o", EXE, "-L", LIBDIR, "-lvxba",
+LI_SRC = os.path.join(ROOT, "tests", "cpp", "li_adapter_demo.cpp")
+LI_EXE = os.path.join(ROOT, "tests", "cpp", "li_adapter_demo")
+
+
+def build(src=SRC, exe=EXE):
+    deps = [src] + [os.path.join(ROOT, "include", h) for h in ("vxba_lidar_factor.hpp", "vxba_li_optimizer.hpp", "vxba.h")]
+    so = os.path.join(LIBDIR, "libvxba.so")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps + [so]):
+        subprocess.check_call(["g++", "-O2", "-std=c++14", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", LIBDIR, "-lvxba",
                                "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"])
-    return EXE
+    return exe
 
 
 def test_adapter_compiles_and_links_as_cxx14():
     """The reference builds with -std=c++14 (VoxelSLAM/CMakeLists.txt:4-15); the adapter must too."""
     assert os.path.exists(build())
+    assert os.path.exists(build(LI_SRC, LI_EXE))
 
 
 @pytest.mark.gpu
@@ -53,3 +59,31 @@ def test_adapter_end_to_end_matches_oracle(tmp_path):
     assert bool(conv) == ref["is_converge"]
     assert abs(lam0_first - ev[0, 0]) < 1e-9 and n_first == m[0, 9]
     assert abs(h66 - ref["hess"][6, 6]) < 1e-8 * abs(ref["hess"][6, 6])
+
+
+@pytest.mark.gpu
+def test_li_adapter_end_to_end_matches_oracle(tmp_path):
+    """LI_BA_Optimizer::damping_iter through the C++ adapter (struct fields in, struct fields out) vs the oracle."""
+    from tests import _oracle as O
+    from voxel_slam_amd import synth
+    exe = build(LI_SRC, LI_EXE)
+    sc = synth.make_scene(win_size=7, pts_per_scan=6000, n_voxels=500, p_obs=0.9, seed=78)
+    iw = synth.make_imu(sc, seed=79)
+    blobs = O.imu_preintegrate(iw.samples, iw.noise_meas, iw.noise_walk, iw.states_init[0, 15:18], iw.states_init[0, 18:21])
+    scene = tmp_path / "li.bin"; out = tmp_path / "li_out.bin"
+    with open(scene, "wb") as fh:
+        np.array([sc.win_size, sc.n_voxels], dtype=np.float64).tofile(fh)
+        sc.clusters.tofile(fh); sc.fix.tofile(fh); sc.coe.tofile(fh); iw.states_init.tofile(fh); blobs.tofile(fh)
+    subprocess.check_call([exe, str(scene), str(out)])
+    res = np.fromfile(out, dtype=np.float64)
+    W = sc.win_size
+    st = res[: 21 * W].reshape(W, 21)
+    dbg = res[21 * W: 21 * W + 3 * (W - 1)].reshape(W - 1, 3)
+    h2020, imu_leng = res[-2:]
+    f = O.Oracle(W); f.push_voxels(sc.clusters, sc.fix, sc.coe); f.evaluate_only_residual(sc.poses_init)
+    ref = O.li_damping_iter(f, iw.states_init, blobs, max_iter=3, thd_num=5, imu_coef=1e-4)
+    et, er = synth.pose_errors(st[:, :12], ref["states"][:, :12])
+    assert et < 1e-7 and er < 1e-7
+    assert np.allclose(st[:, 12:21], ref["states"][:, 12:21], atol=1e-6)
+    assert np.allclose(dbg, ref["imus"][:, 67:70], atol=1e-7)
+    assert imu_leng == 15 * W and abs(h2020 - ref["hess"][20, 20]) < 1e-5 * abs(ref["hess"][20, 20])

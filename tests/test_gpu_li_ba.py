@@ -85,3 +85,23 @@ def test_li_ba_improves_on_lidar_only_velocity_and_bias(vx):
     e1 = synth.pose_errors(got["states"][:, :12], iw.states_gt[:, :12])
     assert e1[0] < e0[0] and e1[1] < e0[1]
     assert np.array_equal(got["states"][0], iw.states_init[0])
+
+
+@pytest.mark.parametrize("W,V,pts,iters", [(5, 800, 8000, 5), (10, 3000, 40000, 5)])
+def test_gravity_variant_matches_oracle(vx, W, V, pts, iters):
+    """LI_BA_OptimizerGravity (voxel_map.hpp:658-864), max_iter = 5 as at its call site (voxelslam.cpp:1644)."""
+    sc, iw, blobs, facs, fo, fg = build(vx, W, V, pts, seed=700 + W)
+    st = iw.states_init.copy()
+    st[:, 21:24] += [0.05, -0.03, 0.08]
+    ref = O.li_damping_iter_gravity(fo, st, blobs, max_iter=iters, thd_num=5, imu_coef=1e-4)
+    opt = vx.LI_BA_OptimizerGravity(imu_coef=1e-4)
+    got = opt.damping_iter(st, fg, facs, max_iter=iters)
+    assert got["hess"].shape == (15 * W + 3, 15 * W + 3)
+    assert got["trace"].shape == ref["trace"].shape
+    assert np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:])
+    assert np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-7)
+    assert np.allclose(got["resis"], ref["resis"], rtol=1e-7)
+    et, er = synth.pose_errors(got["states"][:, :12], ref["states"][:, :12])
+    assert et < 1e-7 and er < 1e-7, (et, er)
+    assert np.allclose(got["states"][:, 12:24], ref["states"][:, 12:24], atol=1e-6)   # v, bg, ba, g
+    assert np.allclose(got["hess"], ref["hess"], rtol=1e-5, atol=1e-7 * np.abs(ref["hess"]).max())

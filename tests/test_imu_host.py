@@ -66,6 +66,11 @@ def test_factor_evaluation_matches_oracle(vx, window):
         assert np.allclose(gg, gg_ref, rtol=1e-6, atol=1e-6 * np.abs(gg_ref).max())
         r0, j0, g0 = f.give_evaluate(s1, s2, jac_enable=False)
         assert r0 == r and j0 is None and g0 is None
+        rg, jg, gg_g = f.give_evaluate_g(s1, s2)                     # gravity columns (preintegration.hpp:214-294)
+        rg_ref, jg_ref, gg_ref2 = O.imu_evaluate_g(f.blob, s1, s2)
+        assert rg == r and jg.shape == (33, 33)
+        assert np.allclose(jg, jg_ref, rtol=1e-6, atol=1e-6 * np.abs(jg_ref).max())
+        assert np.allclose(gg_g, gg_ref2, rtol=1e-6, atol=1e-6 * np.abs(gg_ref2).max())
 
 
 def test_update_state_and_error_paths(vx, window):

@@ -198,3 +198,36 @@ def test_li_damping_iter_reduces_cost_and_error(window):
     assert np.array_equal(out["states"][0], iw.states_init[0])        # gauge: frame 0 untouched
     # accepted steps leave the factors' bias deltas moved; dbg_buf holds the previous value
     assert np.any(out["imus"][:, 67:73] != 0)
+
+
+def test_gravity_columns_against_finite_differences(window):
+    """give_evaluate_g: the three extra Jacobian columns are the derivative of the residual w.r.t. frame 1's gravity."""
+    sc, iw, blobs = window
+    s1, s2 = iw.states_init[1], iw.states_init[2]
+    r, jtj, gg = O.imu_evaluate_g(blobs[1], s1, s2)
+    r0, jtj0, gg0 = O.imu_evaluate(blobs[1], s1, s2)
+    assert r == r0 and np.array_equal(jtj[:30, :30], jtj0) and np.array_equal(gg[:30], gg0)
+    num = np.zeros(3); h = 1e-6
+    for k in range(3):
+        v = []
+        for sgn in (+1, -1):
+            a = s1.copy(); a[21 + k] += sgn * h
+            v.append(_half_cost(blobs[1], a, s2))
+        num[k] = (v[0] - v[1]) / (2 * h)
+    assert np.allclose(gg[30:], num, rtol=1e-5)
+
+
+def test_gravity_optimizer_reduces_cost(window):
+    sc, iw, blobs = window
+    o = O.Oracle(sc.win_size)
+    o.push_voxels(sc.clusters, sc.fix, sc.coe)
+    o.evaluate_only_residual(sc.poses_init)
+    st = iw.states_init.copy()
+    st[:, 21:24] += [0.05, -0.03, 0.08]                  # a wrong gravity estimate shared by all frames
+    out = O.li_damping_iter_gravity(o, st, blobs, max_iter=5)
+    assert out["hess"].shape == (15 * sc.win_size + 3,) * 2
+    assert out["resis"][1] < out["resis"][0]
+    g = out["states"][:, 21:24]
+    assert np.all(g == g[0])                             # one gravity vector, copied to every frame (:823)
+    assert np.array_equal(out["states"][0, :12], st[0, :12])          # pose gauge on frame 0 ...
+    assert not np.array_equal(out["states"][0, 12:21], st[0, 12:21])  # ... but its velocity / biases move (:800-803)

@@ -10,10 +10,20 @@
 
 namespace vxh {
 
-// Column-major dense solve of the symmetric system A x = b by LDL^T with symmetric diagonal pivoting
-// (the reference uses Eigen's LDLT, voxel_map.hpp:403).  A (n x n, lower triangle read) is overwritten.
+// Dense solve of the symmetric system A x = b by LDL^T with symmetric diagonal pivoting (the reference uses Eigen's LDLT,
+// voxel_map.hpp:403, 597, 811).  A must hold the FULL symmetric matrix (both triangles); it is overwritten.  The factor is
+// built in the triangle whose rows are contiguous in memory (for a symmetric column-major matrix the upper triangle read
+// row-wise IS the lower triangle), so every inner product below walks unit-stride memory; four independent partial sums
+// break the FMA dependency chain (fixed order: deterministic).
+inline double dot4(const double* a, const double* b, int n) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int j = 0;
+  for (; j + 3 < n; j += 4) { s0 += a[j] * b[j]; s1 += a[j + 1] * b[j + 1]; s2 += a[j + 2] * b[j + 2]; s3 += a[j + 3] * b[j + 3]; }
+  for (; j < n; ++j) s0 += a[j] * b[j];
+  return (s0 + s1) + (s2 + s3);
+}
 inline void ldlt_solve_inplace(int n, double* A, const double* b, double* x, int* perm, double* work) {
-  auto at = [&](int r, int c) -> double& { return A[(size_t)c * n + r]; };
+  auto at = [&](int r, int c) -> double& { return A[(size_t)r * n + c]; };   // (r, c) with r >= c; row r is contiguous
   for (int k = 0; k < n; ++k) {
     int piv = k;
     double best = std::fabs(at(k, k));
@@ -28,29 +38,25 @@ inline void ldlt_solve_inplace(int n, double* A, const double* b, double* x, int
       std::swap(at(k, k), at(piv, piv));
       for (int i = k + 1; i < piv; ++i) std::swap(at(i, k), at(piv, i));
     }
-    for (int j = 0; j < k; ++j) work[j] = at(j, j) * at(k, j);
-    double d = at(k, k);
-    for (int j = 0; j < k; ++j) d -= at(k, j) * work[j];
+    const double* rk = &at(k, 0);
+    for (int j = 0; j < k; ++j) work[j] = at(j, j) * rk[j];
+    const double d = at(k, k) - dot4(rk, work, k);
     at(k, k) = d;
+    const bool nz = std::fabs(d) > 0.0;
     for (int i = k + 1; i < n; ++i) {
-      double s = at(i, k);
-      for (int j = 0; j < k; ++j) s -= at(i, j) * work[j];
-      at(i, k) = (std::fabs(d) > 0.0) ? s / d : s;
+      const double s = at(i, k) - dot4(&at(i, 0), work, k);
+      at(i, k) = nz ? s / d : s;
     }
   }
   for (int i = 0; i < n; ++i) x[i] = b[i];
   for (int k = 0; k < n; ++k) std::swap(x[k], x[perm[k]]);
-  for (int i = 0; i < n; ++i) {
-    double s = x[i];
-    for (int j = 0; j < i; ++j) s -= at(i, j) * x[j];
-    x[i] = s;
-  }
+  for (int i = 0; i < n; ++i) x[i] -= dot4(&at(i, 0), x, i);
   const double tol = 1.0 / std::numeric_limits<double>::max();
   for (int i = 0; i < n; ++i) x[i] = (std::fabs(at(i, i)) > tol) ? x[i] / at(i, i) : 0.0;
-  for (int i = n - 1; i >= 0; --i) {
-    double s = x[i];
-    for (int j = i + 1; j < n; ++j) s -= at(j, i) * x[j];
-    x[i] = s;
+  for (int i = n - 1; i >= 0; --i) {          // L^T x = y, column-oriented so that row i of L is read contiguously
+    const double xi = x[i];
+    const double* ri = &at(i, 0);
+    for (int j = 0; j < i; ++j) x[j] -= ri[j] * xi;
   }
   for (int k = n - 1; k >= 0; --k) std::swap(x[k], x[perm[k]]);
 }

@@ -253,15 +253,20 @@ inline void imu_add(double* f, const double* gyr, const double* acc, double dt, 
   std::memcpy(Rd, T1, sizeof T1);
 }
 
+constexpr int NCG = 2 * DIM + 3;  // Jacobian columns with the gravity block (give_evaluate_g)
 struct ImuWork {
-  double joc[DIM * 2 * DIM];      // 15 x 30
+  double joc[DIM * NCG];          // 15 x 30 (or 15 x 33 with gravity)
   double cov_inv[DIM * DIM], lu[DIM * DIM];
-  double ci_j[DIM * 2 * DIM];     // cov^-1 J
+  double ci_j[DIM * NCG];         // cov^-1 J
   int perm[DIM];
 };
 
-// r^T cov^-1 r; with jac: jtj (30x30) = J^T cov^-1 J, gg (30) = J^T cov^-1 r   (preintegration.hpp:137-212)
-inline double imu_evaluate(const double* f, const double* s1, const double* s2, bool jac, double* jtj, double* gg, ImuWork& w, bool* ok = nullptr) {
+// r^T cov^-1 r; with jac: jtj (30x30) = J^T cov^-1 J, gg (30) = J^T cov^-1 r   (preintegration.hpp:137-212).
+// with_g: give_evaluate_g (:214-294) -- three more Jacobian columns for the gravity vector, jtj 33x33, gg 33.
+// cov_inv_cached: the factor's 15x15 information matrix if the caller already inverted cov (it does not change while an LM
+// loop runs; upstream re-inverts it in every evaluation).
+inline double imu_evaluate(const double* f, const double* s1, const double* s2, bool jac, double* jtj, double* gg, ImuWork& w, bool* ok = nullptr,
+                           bool with_g = false, const double* cov_inv_cached = nullptr) {
   const double* R1 = s1 + S_R; const double* R2 = s2 + S_R;
   const double dt = f[O_DT];
   double rb[3], Eb[9], Rc[9], tc[3], vc[3], t3[3], u3[3];
@@ -289,7 +294,9 @@ inline double imu_evaluate(const double* f, const double* s1, const double* s2, 
     rr[9 + k] = s2[S_BG + k] - s1[S_BG + k];
     rr[12 + k] = s2[S_BA + k] - s1[S_BA + k];
   }
-  const bool inv_ok = dm_inverse(DIM, f + O_COV, w.cov_inv, w.lu, w.perm);
+  bool inv_ok = true;
+  if (cov_inv_cached) std::memcpy(w.cov_inv, cov_inv_cached, sizeof w.cov_inv);
+  else inv_ok = dm_inverse(DIM, f + O_COV, w.cov_inv, w.lu, w.perm);
   if (ok) *ok = inv_ok;
 
   if (jac) {
@@ -323,11 +330,16 @@ inline double imu_evaluate(const double* f, const double* s1, const double* s2, 
     put33(J, DIM, 12, 12, I3, -1.0);
     put33(J, DIM, 9, DIM + 9, I3);
     put33(J, DIM, 12, DIM + 12, I3);
+    const int nc = with_g ? NCG : 2 * DIM;
+    if (with_g) {   // preintegration.hpp:277-278
+      put33(J, DIM, 3, 2 * DIM, R1t, -0.5 * dt * dt);
+      put33(J, DIM, 6, 2 * DIM, R1t, -dt);
+    }
 
-    dm_mul(DIM, DIM, 2 * DIM, w.cov_inv, J, w.ci_j);                // cov^-1 J   (15 x 30)
-    dm_tmul(DIM, 2 * DIM, 2 * DIM, J, w.ci_j, jtj);                 // J^T cov^-1 J
+    dm_mul(DIM, DIM, nc, w.cov_inv, J, w.ci_j);                     // cov^-1 J   (15 x nc)
+    dm_tmul(DIM, nc, nc, J, w.ci_j, jtj);                           // J^T cov^-1 J
     // gg = (cov^-1 J)^T r  -- cov^-1 is symmetric up to round-off; the reference forms J^T cov^-1 r
-    for (int i = 0; i < 2 * DIM; i++) {
+    for (int i = 0; i < nc; i++) {
       double s = 0.0;
       for (int a = 0; a < DIM; a++) {
         double t = 0.0;                                             // (J^T cov^-1)(i, a) = sum_b J(b,i) cov_inv(b,a)
@@ -358,21 +370,33 @@ inline void imu_rollback(double* f) {   // voxel_map.hpp:639-643
   for (int k = 0; k < 3; k++) { f[O_DBG + k] = f[O_DBGB + k]; f[O_DBA + k] = f[O_DBAB + k]; }
 }
 
-// Hess (15W x 15W, zeroed by the caller) += imu blocks, then everything scaled by imu_coef; returns the scaled residual
+// Hess (n x n, n = 15W [+3 with gravity], zeroed by the caller) += imu blocks, then everything scaled by imu_coef; returns
+// the scaled residual.  with_g: the gravity rows / columns sit at the tail (voxel_map.hpp:700-711).
 inline double li_add_imu_blocks(int W, const double* states, const double* imus, double imu_coef, bool jac, double* Hess, double* JacT,
-                                ImuWork& w, bool* ok) {
-  const int n = DIM * W;
-  double jtj[4 * DIM * DIM], gg[2 * DIM];
+                                ImuWork& w, bool* ok, bool with_g = false, const double* cov_invs = nullptr /* (W-1) x 225 */) {
+  const int n = DIM * W + (with_g ? 3 : 0), nc = with_g ? NCG : 2 * DIM, gq = DIM * W;
+  double jtj[NCG * NCG], gg[NCG];
   double residual = 0.0;
   bool all_ok = true;
   for (int i = 0; i < W - 1; i++) {
     bool one_ok = true;
-    residual += imu_evaluate(imus + (size_t)IMU_LEN * i, states + STATE_LEN * i, states + STATE_LEN * (i + 1), jac, jtj, gg, w, &one_ok);
+    residual += imu_evaluate(imus + (size_t)IMU_LEN * i, states + STATE_LEN * i, states + STATE_LEN * (i + 1), jac, jtj, gg, w, &one_ok, with_g,
+                             cov_invs ? cov_invs + (size_t)DIM * DIM * i : nullptr);
     all_ok = all_ok && one_ok;
     if (jac) {
       for (int c = 0; c < 2 * DIM; c++)
-        for (int r = 0; r < 2 * DIM; r++) Hess[(size_t)(i * DIM + c) * n + i * DIM + r] += jtj[(size_t)c * 2 * DIM + r];
+        for (int r = 0; r < 2 * DIM; r++) Hess[(size_t)(i * DIM + c) * n + i * DIM + r] += jtj[(size_t)c * nc + r];
       for (int r = 0; r < 2 * DIM; r++) JacT[i * DIM + r] += gg[r];
+      if (with_g) {
+        for (int c = 0; c < 3; c++)
+          for (int r = 0; r < 2 * DIM; r++) {
+            Hess[(size_t)(gq + c) * n + i * DIM + r] += jtj[(size_t)(2 * DIM + c) * nc + r];
+            Hess[(size_t)(i * DIM + r) * n + gq + c] += jtj[(size_t)r * nc + 2 * DIM + c];
+          }
+        for (int c = 0; c < 3; c++)
+          for (int r = 0; r < 3; r++) Hess[(size_t)(gq + c) * n + gq + r] += jtj[(size_t)(2 * DIM + c) * nc + 2 * DIM + r];
+        for (int r = 0; r < 3; r++) JacT[gq + r] += gg[2 * DIM + r];
+      }
     }
   }
   if (jac) {
@@ -383,9 +407,19 @@ inline double li_add_imu_blocks(int W, const double* states, const double* imus,
   return residual * (imu_coef * 0.5);
 }
 
-// scatter the 6W LiDAR system into the 15W one (voxel_map.hpp:455-463)
-inline void li_hess_plus(int W, double* Hess, double* JacT, const double* hs, const double* js) {
-  const int n = DIM * W, m = DVEL * W;
+// information matrices of all factors of a window, once per LM loop; false if one covariance is singular
+inline bool li_invert_covariances(int W, const double* imus, double* cov_invs) {
+  double lu[DIM * DIM];
+  int perm[DIM];
+  bool ok = true;
+  for (int i = 0; i < W - 1; i++) ok = dm_inverse(DIM, imus + (size_t)IMU_LEN * i + O_COV, cov_invs + (size_t)DIM * DIM * i, lu, perm) && ok;
+  return ok;
+}
+
+// scatter the 6W LiDAR system into the 15W (+3) one (voxel_map.hpp:455-463, 663-671); n = leading dimension of Hess
+inline void li_hess_plus(int W, double* Hess, double* JacT, const double* hs, const double* js, int n = 0) {
+  const int m = DVEL * W;
+  if (n == 0) n = DIM * W;
   for (int i = 0; i < W; i++) {
     for (int k = 0; k < DVEL; k++) JacT[i * DIM + k] += js[i * DVEL + k];
     for (int j = 0; j < W; j++)

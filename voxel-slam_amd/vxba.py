@@ -31,7 +31,7 @@ EXPORTS = [
     "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_plane_fit_judge", "vxba_build_clusters", "vxba_set_allreduce",
     "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_detach", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps",
     "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_li_evaluate",
-    "vxba_li_only_residual", "vxba_li_damping_iter",
+    "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -100,6 +100,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_li_evaluate.argtypes = [vp, _f64p, _f64p, cd, _f64p, _f64p, C.POINTER(cd)]
     L.vxba_li_only_residual.argtypes = [vp, _f64p, _f64p, cd, C.POINTER(cd)]
     L.vxba_li_damping_iter.argtypes = [vp, _f64p, _f64p, cd, ci, vp, vp, C.POINTER(ci)]
+    L.vxba_imu_evaluate_g.argtypes = [_f64p, _f64p, _f64p, ci, vp, vp, C.POINTER(cd)]
+    L.vxba_li_damping_iter_gravity.argtypes = [vp, _f64p, _f64p, cd, ci, vp, _f64p, vp, C.POINTER(ci)]
     _lib = L
     return L
 
@@ -375,6 +377,15 @@ class IMU_PRE:
             raise VxbaError(f"vxba_imu_evaluate failed ({_ERRNAMES.get(rc, rc)})")
         return r.value, None, None
 
+    def give_evaluate_g(self, st1, st2):
+        """give_evaluate with the gravity columns (preintegration.hpp:214-294): (residual, jtj (33,33), gg (33,))."""
+        r = C.c_double(0)
+        jtj = np.zeros((33, 33)); gg = np.zeros(33)
+        rc = self._L.vxba_imu_evaluate_g(self.blob, _c(st1), _c(st2), 1, jtj.ctypes.data_as(C.c_void_p), gg.ctypes.data_as(C.c_void_p), C.byref(r))
+        if rc:
+            raise VxbaError(f"vxba_imu_evaluate_g failed ({_ERRNAMES.get(rc, rc)})")
+        return r.value, jtj.T.copy(), gg
+
     def update_state(self, dxi15):
         self._L.vxba_imu_update_state(self.blob, _c(dxi15))
 
@@ -423,6 +434,22 @@ class LI_BA_Optimizer:
         for f, b in zip(imus_factor, blobs):
             f.blob[:] = b
         return dict(states=st, hess=hess.T.copy(), trace=trace[: nt.value].copy())
+
+
+class LI_BA_OptimizerGravity(LI_BA_Optimizer):
+    """LI_BA_Optimizer with the gravity vector as three more unknowns (reference: voxel_map.hpp:658-864)."""
+
+    def damping_iter(self, x_stats, voxhess: LidarFactor, imus_factor, max_iter: int = 2):
+        W = voxhess.win_size
+        n = LI_DIM * W + 3
+        st = _c(x_stats).copy()
+        blobs = self._blobs(imus_factor)
+        hess = np.zeros((n, n)); resis = np.zeros(2); trace = np.zeros((max(max_iter, 1), TRACE_COLS)); nt = C.c_int(0)
+        voxhess._chk(voxhess._L.vxba_li_damping_iter_gravity(voxhess.handle, st, blobs, self.imu_coef, int(max_iter), hess.ctypes.data_as(C.c_void_p),
+                                                             resis, trace.ctypes.data_as(C.c_void_p), C.byref(nt)))
+        for f, b in zip(imus_factor, blobs):
+            f.blob[:] = b
+        return dict(states=st, hess=hess.T.copy(), resis=resis, trace=trace[: nt.value].copy())
 
 
 def damping_iter_generic(win_size: int, x_stats, hess_fn, resid_fn, max_iter: int = 3):
