@@ -21,6 +21,19 @@ if which == "solve":
     st = vxba.debug_stamps(4001).astype(np.int64)[4000, :6]
     print("solve kernel stamps (cycles since start):", st - st[0])
     sys.exit(0)
+if which == "fused":
+    from voxel_slam_amd.vxba import Lidar_BA_Optimizer
+    Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=1)
+    full = vxba.debug_stamps(4001).astype(np.int64)
+    sol = full[4000, :6]
+    n = (sc.n_voxels + 63) // 64
+    k2 = full[:n, :6]
+    t0 = min(sol[0], k2[:, 0].min())
+    print("solver stamps (cycles since kernel start): start %d, done-checked %d, loaded %d, eliminated %d, back-substituted %d, end %d" % tuple(sol - t0))
+    names = ["start", "loads landed", "cov done", "eig done", "end", "flag seen"]
+    for k in (0, 1, 5, 2, 3, 4):
+        print("voxel waves %-13s min %7d  median %7d  max %7d" % (names[k], k2[:, k].min() - t0, np.median(k2[:, k]) - t0, k2[:, k].max() - t0))
+    sys.exit(0)
 if which == "k2":
     f.evaluate_only_residual(sc.poses_init); n = (sc.n_voxels + 63) // 64; ns = 5
 else:

@@ -1,10 +1,9 @@
 #!/bin/bash
-# within-run A/B of two builds of libvxba.so (box-to-box variance is larger than most kernel changes):
-#   gpurun_ab/libvxba_base.so  vs  voxel-slam_amd/csrc/libvxba.so, alternating, ROUNDS times
+# within-run comparison of N builds: LIBS="a.so b.so ..." (paths relative to the repo root)
 cd "$GRAFT_REPO_ROOT" || exit 1
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-for r in $(seq 1 ${ROUNDS:-3}); do
-  for lib in gpurun_ab/libvxba_base.so voxel-slam_amd/csrc/libvxba.so; do
+for r in $(seq 1 ${ROUNDS:-2}); do
+  for lib in $LIBS; do
     VXBA_LIB=$PWD/$lib timeout 600 python bench.py --steps ${STEPS:-300} --warmup 30 --no-cpu-baseline --no-li-ba 2>&1 | grep -v amdgpu.ids | python -c "
 import sys, json
 for l in sys.stdin:

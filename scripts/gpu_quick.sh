@@ -12,6 +12,6 @@ for l in sys.stdin:
     try: d = json.loads(l)
     except Exception: print(l.rstrip()); continue
     r = d['roofline']
-    print('it/s %.0f  ms/step %.4f  k3 %.2f us (%.1f%% hbm)  k2 %.2f us (%.1f%%)  k3fin %.2f us' % (d['value'], d['ms_per_step'], r['avg_launch_ms']*1e3, 100*r['frac'], r['k2_residual']['avg_launch_ms']*1e3, 100*r['k2_residual']['frac'], r['k3_finalize_avg_ms']*1e3))
+    print('it/s %.0f  ms/step %.4f  k3 %.2f us (%.1f%% hbm)  k2 %.2f us (%.1f%%)  k3fin %.2f us  solve+k2 %.2f us' % (d['value'], d['ms_per_step'], r['avg_launch_ms']*1e3, 100*r['frac'], r['k2_residual']['avg_launch_ms']*1e3, 100*r['k2_residual']['frac'], r['k3_finalize_avg_ms']*1e3, 1e3*r.get('solve_plus_k2_launch_avg_ms', 0)))
 "
 done

@@ -399,3 +399,16 @@ def test_bench_rccl_plumbing_single_rank():
         assert a["config"]["lm_steps_accepted"] == b["config"]["lm_steps_accepted"] == 30
         assert abs(a["config"]["final_residual"] - b["config"]["final_residual"]) <= 1e-12 * abs(a["config"]["final_residual"])
         assert "RCCL" in b["config"]["parallelism"] and b["value"] > 0
+
+
+def test_lm_loop_with_more_residual_workgroups_than_the_chip_holds(vx):
+    """120k voxels -> 1876 residual-sweep workgroups + the in-launch solve workgroup: more than can be resident at once
+    (the voxel workgroups wait for workgroup 0, so dispatch order matters here).  Trace and poses must still match the oracle."""
+    sc = synth.make_scene(win_size=10, pts_per_scan=250_000, n_voxels=120_000, p_obs=0.6, seed=4242)
+    fo, fg = seeded_pair(vx, sc)
+    ref = fo.damping_iter(sc.poses_init, max_iter=3, thd_num=8)
+    got = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=3)
+    assert np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:])
+    assert np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-9)
+    et, er = synth.pose_errors(got["poses"], ref["poses"])
+    assert et < 1e-7 and er < 1e-7, (et, er)

@@ -55,6 +55,7 @@ struct vxba_factor {
   double* h_scalar = nullptr;    // pinned
   vxk::LMState* d_lm = nullptr;  // device-resident LM shell state
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
+  unsigned lm_seq = 0;           // sequence numbers of solves published inside residual-sweep launches (never 0)
   vxba_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
   // direct RCCL path: entry points resolved from the librccl.so the process already uses
@@ -208,6 +209,11 @@ int shard_allreduce(vxba_factor* f, double* d_buf, size_t count) {
   return VXBA_OK;
 }
 
+bool fused_solve() {
+  static const bool on = [] { const char* e = getenv("VXBA_FUSED_SOLVE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 // ---- sweeps (asynchronous on f->stream; results in device memory) ----
 // Stand-alone mode: poses by value (Rp, host pointer -> kernel argument), lm == nullptr.
 // LM mode (lm != nullptr): the sweep's prologue takes the pending accept/reject decision from ctl[*c] (and flips *c),
@@ -246,8 +252,8 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c
   return shard_allreduce(f, d_out, plen);
 }
 
-int sweep_residual_device(vxba_factor* f, const double* Rp, const vxk::LMState* lm, int c, int head, int end, double* d_out,
-                          int* nparts_out = nullptr) {
+int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int c, int head, int end, double* d_out,
+                          int* nparts_out = nullptr, unsigned fused_seq = 0) {
   if (end == head) { if (d_out) VX_HIP(f, hipMemsetAsync(d_out, 0, sizeof(double), f->stream)); return VXBA_OK; }
   PoseArg pa;
   if (Rp) fill_poses(f, Rp, pa); else std::memset(&pa, 0, sizeof pa);
@@ -255,10 +261,10 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, const vxk::LMState* 
   int nparts;
   if (f->profiling & 2) {
     hipEvent_t a = get_event(f), b = get_event(f);
-    nparts = vxk::launch_k2_residual(fv, pa, lm, c, head, end, f->d_partial2, f->cus, f->stream, a, b);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, f->d_partial2, f->cus, f->stream, a, b);
     if (a && b) f->pending.push_back({a, b, 1});
   } else {
-    nparts = vxk::launch_k2_residual(fv, pa, lm, c, head, end, f->d_partial2, f->cus, f->stream);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, f->d_partial2, f->cus, f->stream);
   }
   if (nparts_out) *nparts_out = nparts;
   if (d_out) {
@@ -352,6 +358,7 @@ int vxba_create(int win_size, int device, vxba_factor** out) {
   if ((e = hipHostMalloc((void**)&f->h_packed, plen * sizeof(double), hipHostMallocDefault)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc((void**)&f->h_scalar, 2 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return bail(e);
   if ((e = hipMalloc((void**)&f->d_lm, sizeof(vxk::LMState))) != hipSuccess) return bail(e);
+  if ((e = hipMemset(f->d_lm, 0, sizeof(vxk::LMState))) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc((void**)&f->h_lm, sizeof(vxk::LMState), hipHostMallocDefault)) != hipSuccess) return bail(e);
   *out = f;
   return VXBA_OK;
@@ -729,10 +736,12 @@ int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out
   for (int i = 0; i < max_iter; i++) {
     int rc = sweep_hess_device(f, Rp, f->d_lm, &c, &pend, 0, f->V, f->d_packed);
     if (rc) return rc;
-    vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
-    // residual sweep at the trial state; without a collective its wave partials are summed by whoever takes the decision
+    // damped solve + residual sweep at the trial state: one launch (the solve is workgroup 0 of the sweep) unless
+    // VXBA_FUSED_SOLVE=0; without a collective the sweep's wave partials are summed by whoever takes the decision
+    const unsigned seq = fused_solve() ? ++f->lm_seq : 0u;
+    if (!seq) vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
     int nparts = 0;
-    rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts);
+    rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts, seq);
     if (rc) return rc;
     pend.pending = 1; pend.restart = 0;
     pend.d_scalar = has_collective(f) ? f->d_scalar : nullptr;
@@ -742,6 +751,7 @@ int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out
   VX_HIP(f, hipGetLastError());
   VX_HIP(f, hipMemcpyAsync(f->h_lm, f->d_lm, sizeof(vxk::LMState), hipMemcpyDeviceToHost, f->stream));
   VX_HIP(f, hipStreamSynchronize(f->stream));
+  if (f->h_lm->error) return fail(f, VXBA_ERR_STATE, "damping_iter: a residual-sweep workgroup timed out waiting for the in-launch solve");
   const vxk::LMCtl& st = f->h_lm->ctl[c];
   std::memcpy(Rp, st.x, sizeof(double) * 12 * W);
   if (hess_out) std::memcpy(hess_out, f->h_lm->hess_out, sizeof(double) * n * n);
@@ -817,9 +827,10 @@ int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_
     const bool last = ((s + 1) % steps_per_solve) == 0 && s + 1 < n_steps;
     int rc = sweep_hess_device(f, Rp_init, f->d_lm, &c, &pend, 0, f->V, f->d_packed, first ? f->snapshot : nullptr);
     if (rc) return rc;
-    vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
+    const unsigned seq = fused_solve() ? ++f->lm_seq : 0u;
+    if (!seq) vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
     int nparts = 0;
-    rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts);
+    rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts, seq);
     if (rc) return rc;
     pend.pending = 1; pend.restart = last ? 1 : 0;
     pend.d_scalar = has_collective(f) ? f->d_scalar : nullptr;
@@ -829,6 +840,7 @@ int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_
   VX_HIP(f, hipGetLastError());
   VX_HIP(f, hipMemcpyAsync(f->h_lm, f->d_lm, sizeof(vxk::LMState), hipMemcpyDeviceToHost, f->stream));
   VX_HIP(f, hipStreamSynchronize(f->stream));
+  if (f->h_lm->error) return fail(f, VXBA_ERR_STATE, "lm_steps: a residual-sweep workgroup timed out waiting for the in-launch solve");
   const vxk::LMCtl& st = f->h_lm->ctl[c];
   if (Rp_out) std::memcpy(Rp_out, st.x, sizeof(double) * 12 * W);
   if (last_resis) { last_resis[0] = st.residual1; last_resis[1] = st.residual2; }

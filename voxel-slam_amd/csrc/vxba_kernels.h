@@ -64,6 +64,8 @@ struct LMState {
   double dxi[6 * MAXW];
   double Hwork[36 * MAXW * MAXW];         // gauge-fixed Hessian kept across rejected steps
   double hess_out[36 * MAXW * MAXW];      // *hess, exported before the gauge fix (voxel_map.hpp:391)
+  unsigned solve_seq;                     // sequence number of the last solve published inside a residual-sweep launch
+  int error;                              // 1: a voxel workgroup gave up waiting for the solve (never observed)
 };
 // What a sweep needs to take the pending accept/reject decision in its prologue.
 struct LMPending {
@@ -87,8 +89,10 @@ inline size_t k3_partial_len(int W) { return (size_t)k3_num_tile_pairs(W) * 256 
 // st != null: LM mode -- poses are ctl[c].xt and the sweep skips itself on the GPU once the loop is done; else `poses`.
 // One lane per voxel, k2_voxels_per_block(...) in [32, 64] voxels per 64-lane workgroup (balanced over `cus` CUs).
 int k2_voxels_per_block(int nvox, int cus);
-int launch_k2_residual(const FactorView& fv, const PoseArg& poses, const LMState* st, int c, int head, int end, double* d_partial, int cus,
-                       hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// fused_seq != 0 (LM mode only): workgroup 0 of the launch runs the damped solve of this iteration and publishes `fused_seq`;
+// the voxel workgroups wait for it after requesting their cluster rows.  Must be unique per launch and non-zero.
+int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, int c, unsigned fused_seq, int head, int end, double* d_partial,
+                       int cus, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // Deterministic sum of n partials into d_out[0].
 void launch_sum_partials(const double* d_partial, int n, double* d_out, hipStream_t s);
 // Derive aux (gap scales) from eigval for voxels [head,end) (after a caller-seeded cache).

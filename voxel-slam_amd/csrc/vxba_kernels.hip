@@ -146,21 +146,47 @@ __device__ __forceinline__ void lm_persist(LMState* st, int c_in, const LMDecisi
 // 27-29 us against 17.5 us for this version: the extra pose loads / redundant fp64 work / barrier skew cost more
 // than the hidden dependency stalls buy, because all workgroups start together and sit in the same phase.
 // ------------------------------------------------------------------------------------------------
+template <int W, bool DBG>
+__device__ __forceinline__ void lm_solve_body(LMState* st, int c, double* colbuf, double* xs);
+
+// LM mode with seq != 0: workgroup 0 of the grid is not a voxel workgroup but the damped SOLVE of this iteration
+// (lm_solve_body, one wave).  The voxel workgroups request their cluster rows first -- those do not depend on the poses --
+// and only then wait for workgroup 0 to publish the trial poses (release store of `seq` to st->solve_seq, acquire spin
+// here), so the 6-7 us load phase of the sweep and one kernel launch disappear behind the 16 us solve.  Deadlock-free:
+// workgroups are dispatched in index order, so workgroup 0 is resident before any workgroup that could wait for it.
+constexpr unsigned K2_SPIN_LIMIT = 1u << 22;
+#ifndef K2_HEAD_START
+#define K2_HEAD_START 100   // x 64 cycles
+#endif
 template <int W, bool DBG = false>
-__global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, const LMState* __restrict__ st, int c, int head, int end,
+__global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c, unsigned seq, int head, int end,
                                                          int VPB, double* __restrict__ partial) {
+  __shared__ double pose_lds[12 * W];
+  __shared__ double solve_lds[128];
   // LM mode: trial poses of ctl[c]; nothing to do once the loop is done
   if (st && st->ctl[c].done) return;
   const int lane = threadIdx.x;
-  const int a = head + blockIdx.x * VPB + lane;
-  const double* __restrict__ Rp = st ? st->ctl[c].xt : poses.Rp;
+  int vb = blockIdx.x;
+  if (st && seq != 0) {
+    if (blockIdx.x == 0) {
+      lm_solve_body<W, DBG>(st, c, solve_lds, solve_lds + 64);
+      __threadfence();
+      if (lane == 0) __hip_atomic_store(&st->solve_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    vb = blockIdx.x - 1;
+    // let the solver's first (dependent) loads through before 780 waves put 50 MB of requests in front of them
+    __builtin_amdgcn_s_sleep(K2_HEAD_START);
+  }
+  const int a = head + vb * VPB + lane;
+  const bool valid = lane < VPB && a < end;
   const size_t VS = (size_t)fv.VS;
   double res = 0.0;
-  dbg_stamp(DBG, blockIdx.x, 0);
-  if (lane < VPB && a < end) {
-    // issue every load of this voxel up front (10 + 10 W independent 512 B rows per wave): with < 1 wave per
-    // SIMD at 50k voxels the sweep is latency-bound unless all of them are in flight together
-    double fx[10], c[W][10], Up[9];
+  dbg_stamp(DBG, vb, 0);
+  // issue every load of this voxel up front (10 + 10 W independent 512 B rows per wave): with < 1 wave per
+  // SIMD at 50k voxels the sweep is latency-bound unless all of them are in flight together
+  double fx[10], cl[W][10], Up[9];
+  if (valid) {
 #pragma unroll
     for (int k = 0; k < 10; k++) fx[k] = fv.fix[k * VS + a];
     // previous eigenvectors (plane 3*col+row -> row-major): warm start of the eigensolver
@@ -171,9 +197,34 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
 #pragma unroll
     for (int i = 0; i < W; i++)
 #pragma unroll
-      for (int k = 0; k < 10; k++) c[i][k] = fv.cl[((size_t)i * 10 + k) * VS + a];
+      for (int k = 0; k < 10; k++) cl[i][k] = fv.cl[((size_t)i * 10 + k) * VS + a];
+  }
+  // poses -> LDS (wave-uniform operands of the transform).  LM mode reads the trial poses with coherent loads, after
+  // the solve has published them when it runs inside this launch.
+  {
+    if (st) {
+      if (seq != 0) {
+        // relaxed polls and no acquire fence (either would invalidate caches chip-wide, 780 times over): the trial poses
+        // are fetched below with system-coherent (volatile) loads, issued in program order after the poll that saw `seq`
+        unsigned spins = 0;
+        while (__hip_atomic_load(&st->solve_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+          __builtin_amdgcn_s_sleep(16);
+          if (++spins > K2_SPIN_LIMIT) { if (lane == 0) st->error = 1; return; }   // never observed; a hang would cost the GPU
+        }
+        if (DBG) dbg_stamp(true, vb, 5);
+      }
+      const volatile double* xt = st->ctl[c].xt;
+      if (lane < 12 * W) pose_lds[lane] = xt[lane];
+      if (lane + 64 < 12 * W) pose_lds[lane + 64] = xt[lane + 64];
+    } else {
+      if (lane < 12 * W) pose_lds[lane] = poses.Rp[lane];
+      if (lane + 64 < 12 * W) pose_lds[lane + 64] = poses.Rp[lane + 64];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (valid) {
     double SP[6], Sv[3], SN;
-    if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, blockIdx.x, 1); }
+    if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, vb, 1); }
 #pragma unroll
     for (int k = 0; k < 6; k++) SP[k] = fx[k];
 #pragma unroll
@@ -182,23 +233,23 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
 #pragma unroll
     for (int i = 0; i < W; i++) {
       // N == 0 <=> frame i did not observe this voxel (voxel_map.hpp:258): contributes nothing
-      const bool obs = c[i][9] != 0.0;
+      const bool obs = cl[i][9] != 0.0;
 #pragma unroll
-      for (int k = 0; k < 10; k++) c[i][k] = obs ? c[i][k] : 0.0;
+      for (int k = 0; k < 10; k++) cl[i][k] = obs ? cl[i][k] : 0.0;
       double R[9], p[3];
 #pragma unroll
       for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = Rp[12 * i + 3 * cc + r];
+        for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = pose_lds[12 * i + 3 * cc + r];
 #pragma unroll
-      for (int k = 0; k < 3; k++) p[k] = Rp[12 * i + 9 + k];
-      vxm::transform_accumulate(c[i], c[i] + 6, c[i][9], R, p, SP, Sv, SN);
+      for (int k = 0; k < 3; k++) p[k] = pose_lds[12 * i + 9 + k];
+      vxm::transform_accumulate(cl[i], cl[i] + 6, cl[i][9], R, p, SP, Sv, SN);
     }
     double C[6], lam[3], U[9];
     vxm::cluster_cov(SP, Sv, SN, C);
-    if (DBG) { asm volatile("" :: "v"(C[0]), "v"(C[3]), "v"(C[5])); dbg_stamp(true, blockIdx.x, 2); }
+    if (DBG) { asm volatile("" :: "v"(C[0]), "v"(C[3]), "v"(C[5])); dbg_stamp(true, vb, 2); }
     vxm::eig_sym3_warm(C, Up, lam, U);
-    if (DBG) { asm volatile("" :: "v"(lam[0]), "v"(U[0]), "v"(U[8])); dbg_stamp(true, blockIdx.x, 3); }
+    if (DBG) { asm volatile("" :: "v"(lam[0]), "v"(U[0]), "v"(U[8])); dbg_stamp(true, vb, 3); }
 #pragma unroll
     for (int k = 0; k < 3; k++) fv.eigval[k * VS + a] = lam[k];
 #pragma unroll
@@ -222,8 +273,8 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
   // fixed-tree wave reduction
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) res += __shfl_down(res, off);
-  if (lane == 0) partial[blockIdx.x] = res;
-  if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, blockIdx.x, 4); }
+  if (lane == 0) partial[vb] = res;
+  if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, vb, 4); }
 }
 
 __global__ __launch_bounds__(1024) void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
@@ -911,16 +962,14 @@ struct LmElim {
 // boosted and positive definite wherever LM accepts steps (the reference's Eigen::LDLT pivots on the largest
 // diagonal, voxel_map.hpp:403; both give the same step to round-off on such systems).  Rows/columns 0..5 are the
 // gauge (identity rows, zero right-hand side) and are skipped.
-template <int W, bool DBG = false>
-__global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, int c) {
+template <int W, bool DBG>
+__device__ __forceinline__ void lm_solve_body(LMState* st, int c, double* colbuf, double* xs) {
   dbg_stamp(DBG, 4000, 0);
   LMCtl& ctl = st->ctl[c];
   if (ctl.done) return;
   dbg_stamp(DBG, 4000, 1);
   constexpr int n = 6 * W;
   const int lane = threadIdx.x;
-  __shared__ double colbuf[64];
-  __shared__ double xs[64];
   const double u = ctl.u;
   const bool row_ok = lane < n;
   const int i = row_ok ? lane : 0;
@@ -977,6 +1026,13 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, int c) {
   for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
   if (lane == 0) ctl.q1 = 0.5 * part;
   if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, 4000, 5); }
+}
+// stand-alone launch of the solve (VXBA_FUSED_SOLVE=0; the default runs it as workgroup 0 of the residual sweep)
+template <int W, bool DBG = false>
+__global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, int c) {
+  __shared__ double colbuf[64];
+  __shared__ double xs[64];
+  lm_solve_body<W, DBG>(st, c, colbuf, xs);
 }
 
 // Stand-alone decision kernel that closes the loop after the last residual sweep (inside the loop the decision is
@@ -1039,18 +1095,20 @@ int k2_voxels_per_block(int nvox, int cus) {
   if (forced >= 32 && forced <= 64) return forced;
   return 64;
 }
-int launch_k2_residual(const FactorView& fv, const PoseArg& poses, const LMState* st, int c, int head, int end, double* d_partial, int cus,
-                       hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, int c, unsigned fused_seq, int head, int end, double* d_partial,
+                       int cus, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int vpb = k2_voxels_per_block(end - head, cus);
   const int nblocks = (end - head + vpb - 1) / vpb;
   if (nblocks <= 0) return 0;
+  const unsigned seq = st ? fused_seq : 0u;
+  const int grid = nblocks + (seq != 0 ? 1 : 0);   // + the solve workgroup
   static int dbg = -1;
   if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
-  if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, st, c, head, end, vpb, d_partial)); }
+  if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb, d_partial)); }
   else if (ev_start) {
-    VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), dim3(nblocks), dim3(64), 0, s, ev_start, ev_stop, 0, fv, poses, st, c, head, end,
-                                                vpb, d_partial));
-  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(nblocks), dim3(64), 0, s>>>(fv, poses, st, c, head, end, vpb, d_partial)); }
+    VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), dim3(grid), dim3(64), 0, s, ev_start, ev_stop, 0, fv, poses, st, c, seq, head,
+                                                end, vpb, d_partial));
+  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb, d_partial)); }
   return nblocks;
 }
 
