@@ -162,14 +162,14 @@ template <int W, bool DBG = false>
 __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c, unsigned seq, int head, int end,
                                                          int VPB, double* __restrict__ partial) {
   __shared__ double pose_lds[12 * W];
-  __shared__ double solve_lds[128];
+  __shared__ double solve_lds[192];
   // LM mode: trial poses of ctl[c]; nothing to do once the loop is done
   if (st && st->ctl[c].done) return;
   const int lane = threadIdx.x;
   int vb = blockIdx.x;
   if (st && seq != 0) {
     if (blockIdx.x == 0) {
-      lm_solve_body<W, DBG>(st, c, solve_lds, solve_lds + 64);
+      lm_solve_body<W, DBG>(st, c, solve_lds, solve_lds + 128);
       __threadfence();
       if (lane == 0) __hip_atomic_store(&st->solve_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       return;
@@ -919,29 +919,52 @@ __device__ __forceinline__ double fast_rcp_f64(double d) {
   return r;
 }
 
+constexpr int LM_PRE = 12;   // pivot-column values fetched one step ahead
 template <int K, int N>
 struct LmElim {
-  static __device__ __forceinline__ void forward(double (&A)[N > 6 ? N : 7], double& b, double& my_invd, double* colbuf, double* xs, int lane, bool row_ok) {
+  // Forward elimination step K with one step of look-ahead.  On entry the (final) column K of the trailing matrix already
+  // sits in LDS buffer K & 1, its first LM_PRE entries below the diagonal are in `pre`, and 1/pivot and the pivot's
+  // right-hand side are known.  The step updates column K+1 FIRST, publishes it (other LDS buffer), fetches the head of
+  // it and starts the next reciprocal -- all of which then complete in the shadow of the remaining rank-1 update,
+  // instead of costing an LDS round trip + a division chain per step on the critical path (54 dependent steps).
+  // Measured and rejected on top of this: masking rows with exec (real branches) instead of selects, 1/pivot and the
+  // solution through LDS, damping added at the pivot read -- 1100 fewer instructions, but 31k instead of 26k cycles: the
+  // wave is bound by the LDS queue order and dependent latencies, not by instruction count or cold instruction fetch
+  // (a second pass over the same code with a warm I-cache is only 10 % faster).
+  static __device__ __forceinline__ void forward(double (&A)[N > 6 ? N : 7], double& b, double& my_invd, double* colbuf, int lane, bool row_ok,
+                                                 double invd, double bk, double (&pre)[LM_PRE]) {
     if constexpr (K < N) {
-      colbuf[lane] = A[K];          // lane j publishes A(j,K); symmetric, so this is also row K
-      const double d = readlane_f64(A[K], K);   // pivot and its right-hand side straight from lane K's registers
-      const double bk = readlane_f64(b, K);
-      __builtin_amdgcn_wave_barrier();
-      // all broadcast reads of the pivot column are issued back to back (the scheduler otherwise pairs every
-      // ds_read with its FMA and exposes the LDS latency 26 times per step), the reciprocal runs in their shadow
-      double col[N - K > 1 ? N - K - 1 : 1];
+      constexpr int M = N - K - 1;            // columns j = K+1 .. N-1 take the rank-1 update
+      const double* cur = colbuf + 64 * (K & 1);
+      double* nxt = colbuf + 64 * ((K + 1) & 1);
+      double col[M > LM_PRE ? M - LM_PRE : 1];
 #pragma unroll
-      for (int j = K + 1; j < N; j++) col[j - K - 1] = colbuf[j];
-      const double invd = fast_rcp_f64(d);
+      for (int j = LM_PRE; j < M; j++) col[j - LM_PRE] = cur[K + 1 + j];   // the tail of column K: broadcast reads, back to back
+      __builtin_amdgcn_sched_barrier(0);
       my_invd = (lane == K) ? invd : my_invd;
       const double l = (lane > K && row_ok) ? A[K] * invd : 0.0;
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = K + 1; j < N; j++) A[j] -= l * col[j - K - 1];
       b -= l * bk;
-      __builtin_amdgcn_wave_barrier();
+      double invd_n = 0.0, bk_n = 0.0;
+      double pre_n[LM_PRE];
+#pragma unroll
+      for (int j = 0; j < LM_PRE; j++) pre_n[j] = 0.0;
+      if constexpr (M > 0) {
+        A[K + 1] -= l * pre[0];
+        nxt[lane] = A[K + 1];                 // lane j publishes A(j,K+1); symmetric, so this is also row K+1
+        const double d_n = readlane_f64(A[K + 1], K + 1);
+        bk_n = readlane_f64(b, K + 1);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < LM_PRE && j < M - 1; j++) pre_n[j] = nxt[K + 2 + j];
+        __builtin_amdgcn_sched_barrier(0);
+        invd_n = fast_rcp_f64(d_n);
+#pragma unroll
+        for (int j = 1; j < LM_PRE && j < M; j++) A[K + 1 + j] -= l * pre[j];
+#pragma unroll
+        for (int j = LM_PRE; j < M; j++) A[K + 1 + j] -= l * col[j - LM_PRE];
+      }
       __builtin_amdgcn_sched_barrier(0);
-      LmElim<K + 1, N>::forward(A, b, my_invd, colbuf, xs, lane, row_ok);
+      LmElim<K + 1, N>::forward(A, b, my_invd, colbuf, lane, row_ok, invd_n, bk_n, pre_n);
     }
   }
   static __device__ __forceinline__ void backward(double (&A)[N > 6 ? N : 7], double& b, const double my_invd, double& x, double* xs, int lane) {
@@ -1001,7 +1024,18 @@ __device__ __forceinline__ void lm_solve_body(LMState* st, int c, double* colbuf
   // row stays in registers (static indices only)
   double my_invd = 1.0;   // 1 / pivot of my row, captured when the row is eliminated
   if (DBG) { asm volatile("" :: "v"(A[0]), "v"(A[n - 1]), "v"(b)); dbg_stamp(true, 4000, 2); }
-  LmElim<6, n>::forward(A, b, my_invd, colbuf, xs, lane, row_ok);
+  {
+    // prologue of the look-ahead pipeline: publish column 6, fetch its head, start its reciprocal
+    colbuf[lane] = A[6];
+    const double d6 = readlane_f64(A[6], 6);
+    const double bk6 = readlane_f64(b, 6);
+    __builtin_amdgcn_wave_barrier();
+    double pre[LM_PRE];
+#pragma unroll
+    for (int j = 0; j < LM_PRE; j++) pre[j] = (7 + j < n) ? colbuf[7 + j] : 0.0;
+    const double invd6 = fast_rcp_f64(d6);
+    LmElim<6, n>::forward(A, b, my_invd, colbuf, lane, row_ok, invd6, bk6, pre);
+  }
   if (DBG) { asm volatile("" :: "v"(A[n - 1]), "v"(b)); dbg_stamp(true, 4000, 3); }
   double x = 0.0;
   LmElim<n - 1, n>::backward(A, b, my_invd, x, xs, lane);
@@ -1030,7 +1064,7 @@ __device__ __forceinline__ void lm_solve_body(LMState* st, int c, double* colbuf
 // stand-alone launch of the solve (VXBA_FUSED_SOLVE=0; the default runs it as workgroup 0 of the residual sweep)
 template <int W, bool DBG = false>
 __global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, int c) {
-  __shared__ double colbuf[64];
+  __shared__ double colbuf[128];   // two pivot-column buffers (look-ahead)
   __shared__ double xs[64];
   lm_solve_body<W, DBG>(st, c, colbuf, xs);
 }
