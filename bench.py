@@ -209,6 +209,7 @@ def main():
                                    "achieved_GBs": (24.0 * npts + 80.0 * W * V) / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0}
         if world == 1 and not args.no_li_ba:
             out["li_ba"] = li_ba_rate(sc, f)
+            out["voxelize"] = voxelize_rate(W, local_rank, with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, f, args.cpu_seconds)
         print(json.dumps(out), flush=True)
@@ -255,6 +256,33 @@ def li_ba_rate(sc, f, solves=20):
     med = float(np.median(per_solve))
     return {"iterations_per_s": it_per_solve / med, "ms_per_iteration": 1e3 * med / it_per_solve, "solves": solves, "iterations": iters,
             "pose_rmse_vs_truth_m_rad": [et, er], "where": "sweeps on GPU; IMU factors + 150x150 LDL^T on host"}
+
+
+def voxelize_rate(W, device, with_cpu):
+    """Batch factor construction from raw scans (voxel hash -> octree -> plane test -> factor, OctreeGBA::cut_voxel + recut):
+    W scans of 100k points on the GPU (host buffers in, factor resident in HBM out), with the CPU oracle beside it."""
+    import numpy as np
+    from voxel_slam_amd import synth, vxba
+    xyz, fp, poses, _ = synth.make_scans(win_size=W, pts_per_scan=100_000, extent=60.0)
+    P = vxba.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
+    ts = []
+    n = 0
+    for k in range(6):
+        fv = vxba.LidarFactor(W, device=device)
+        t0 = time.perf_counter()
+        n = fv.voxelize_push(xyz, fp, poses, P, want_ids=False)
+        ts.append(time.perf_counter() - t0)
+        fv.close()
+    med = float(np.median(ts[1:]))
+    out = {"points": int(xyz.shape[0]), "factor_voxels": int(n), "ms": 1e3 * med, "points_per_s": xyz.shape[0] / med,
+           "includes": "H2D of the points (24 MB), 3 octree layers, append to the factor planes"}
+    if with_cpu:
+        from tests import _oracle as O
+        t0 = time.perf_counter()
+        r = O.voxelize(W, xyz, fp, poses, P.as_array())
+        out["cpu_oracle_ms"] = 1e3 * (time.perf_counter() - t0)
+        out["cpu_oracle_factor_voxels"] = int(r["node_id"].shape[0])
+    return out
 
 
 def cpu_baseline(sc, f, budget_s):

@@ -166,6 +166,28 @@ int vxba_damping_iter_generic(int win_size, double* Rp, int max_iter, vxba_hess_
 int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_per_solve, double* Rp_out,
                   double* last_resis, int64_t* stats_out);
 
+/* ---- batch factor construction: points of a window -> voxel hash -> octree subdivision -> plane test -> factor -------- */
+/* OctreeGBA::cut_voxel + subdivide + recut (loop_refine.hpp:273-476), the per-round re-voxelisation of the hierarchical BA
+ * (voxelslam.cpp:2374-2379), as sorts and segmented sums on the GPU.  A voxel becomes a factor at the coarsest octree layer
+ * where it has more than min_points points (10 upstream), passes plane_judge (lambda0 < min_eigen_value and
+ * lambda0/lambda2 < eigen_ratio[layer], the already inverted GBA/eigen_value_array), is seen from >= 2 frames and has
+ * lambda0/lambda1 <= factor_ratio_max (0.12); non-planes are subdivided while layer < max_layer (<= 3). */
+typedef struct vxba_voxelize_params {
+  double voxel_size;
+  int max_layer;
+  int min_points;
+  double min_eigen_value;
+  double eigen_ratio[4];
+  double factor_ratio_max;
+} vxba_voxelize_params;
+/* xyz_local: n_points x 3 body-frame points, frame by frame in cloud order; frame_ptr: win_size + 1 offsets; Rp: win_size*12.
+ * Appends the factor voxels to f (coe = 1, no fix cluster, cache seeded with (lambda, U, world cluster) as recut's push_voxel
+ * does) and returns their number in *n_pushed.  node_ids (optional, ids_capacity entries) receives one id per pushed voxel,
+ * [x:16 | y:16 | z:16 | octant path:9 | 0:4 | layer:3] with the voxel coordinates offset by 32768, in push order (by layer,
+ * ascending id inside a layer).  Voxel coordinates must stay within +-32768. */
+int vxba_voxelize_push(vxba_factor* f, int64_t n_points, const double* xyz_local, const int64_t* frame_ptr, const double* Rp,
+                       const vxba_voxelize_params* params, int64_t* n_pushed, uint64_t* node_ids, int64_t ids_capacity);
+
 /* ---- inertial half of the LiDAR-inertial BA (host code; runs while the GPU sweeps) ------------------- */
 /* Flat formats, every matrix column-major:
  *   state (VXBA_STATE_LEN f64) = the IMUST fields the BA touches (tools.hpp:135-199): [R 9 | p 3 | v 3 | bg 3 | ba 3 | g 3]

@@ -12,6 +12,7 @@
 
 #include "vxo_ba.hpp"
 #include "vxo_imu.hpp"
+#include "vxo_voxelize.hpp"
 
 using namespace vxo;
 
@@ -385,6 +386,33 @@ void vxo_li_damping_iter_gravity(void* h, double* states, double* blobs, int thd
       double* o = trace_out + 8 * i;
       o[0] = t.residual1; o[1] = t.residual2; o[2] = t.u; o[3] = t.v; o[4] = t.q; o[5] = t.q1; o[6] = t.accepted; o[7] = t.recomputed_hess;
     }
+}
+
+// OctreeGBA::cut_voxel + recut (loop_refine.hpp:358-405, 446-476; voxelslam.cpp:2374-2379).
+// params = [voxel_size, max_layer, min_points, min_eigen_value, ratio0, ratio1, ratio2, ratio3, factor_ratio_max].
+// Returns the number of factor voxels (canonical order) or -1 if a point leaves the id range; fills up to `capacity` of them.
+int64_t vxo_voxelize(int W, int64_t n_points, const double* xyz_local, const int64_t* frame_ptr, const double* Rp, const double* params,
+                     int64_t capacity, uint64_t* node_id, double* clusters, double* eig_val, double* eig_vec, double* merged) {
+  VoxelizeParams p;
+  p.voxel_size = params[0]; p.max_layer = (int)params[1]; p.min_points = (int)params[2]; p.min_eigen_value = params[3];
+  for (int k = 0; k < 4; k++) p.eigen_ratio[k] = params[4 + k];
+  p.factor_ratio_max = params[8];
+  std::vector<std::vector<V3>> clouds(W);
+  for (int i = 0; i < W; i++)
+    for (int64_t q = frame_ptr[i]; q < frame_ptr[i + 1]; q++) clouds[i].push_back(v3(xyz_local[3 * q], xyz_local[3 * q + 1], xyz_local[3 * q + 2]));
+  (void)n_points;
+  std::vector<FactorVoxel> out;
+  if (!voxelize(W, clouds, unpack_poses(Rp, W), p, out)) return -1;
+  const int64_t n = (int64_t)out.size();
+  for (int64_t a = 0; a < n && a < capacity; a++) {
+    const FactorVoxel& f = out[a];
+    node_id[a] = f.node_id;
+    for (int i = 0; i < W; i++) pack_cluster(f.pcrs[i], clusters + ((size_t)a * W + i) * 10);
+    for (int k = 0; k < 3; k++) eig_val[3 * a + k] = f.eig_value[k];
+    pack_m3_colmajor(f.eig_vector, eig_vec + 9 * a);
+    pack_cluster(f.pcr_add, merged + 10 * a);
+  }
+  return n;
 }
 
 }  // extern "C"

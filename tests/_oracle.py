@@ -63,6 +63,9 @@ def lib():
     L.vxo_imu_evaluate_g.restype = C.c_double
     L.vxo_imu_evaluate_g.argtypes = [f64p, f64p, f64p, f64p, f64p, C.c_int]
     L.vxo_li_damping_iter_gravity.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double, C.c_int, f64p, f64p, f64p, C.POINTER(C.c_int)]
+    L.vxo_voxelize.restype = C.c_int64
+    L.vxo_voxelize.argtypes = [C.c_int, C.c_int64, f64p, i64p, f64p, f64p, C.c_int64, np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS"),
+                               f64p, f64p, f64p, f64p]
     _LIB = L
     return L
 
@@ -257,3 +260,16 @@ def li_damping_iter_gravity(o, states, blobs, max_iter=2, thd_num=5, imu_coef=1e
     hess = np.zeros((n, n)); resis = np.zeros(2); trace = np.zeros((max(max_iter, 1), 8)); nt = C.c_int(0)
     lib().vxo_li_damping_iter_gravity(o._h, st, bl, thd_num, imu_coef, max_iter, hess, resis, trace, C.byref(nt))
     return dict(states=st, imus=bl, hess=hess.T.copy(), resis=resis, trace=trace[: nt.value].copy())
+
+
+def voxelize(W, xyz_local, frame_ptr, Rp, params9):
+    """OctreeGBA::cut_voxel + recut on the CPU: dict(node_id, clusters (n,W,10), eig_val, eig_vec, merged), canonical order."""
+    xyz = _c(xyz_local).reshape(-1, 3)
+    fp = np.ascontiguousarray(frame_ptr, dtype=np.int64)
+    cap = xyz.shape[0] // 11 + 16
+    ids = np.zeros(cap, dtype=np.uint64); cl = np.zeros((cap, W, 10)); ev = np.zeros((cap, 3)); U = np.zeros((cap, 9)); m = np.zeros((cap, 10))
+    n = lib().vxo_voxelize(W, xyz.shape[0], xyz, fp, _c(Rp), _c(params9), cap, ids, cl, ev, U, m)
+    if n < 0:
+        raise ValueError("voxel coordinates out of range")
+    assert n <= cap
+    return dict(node_id=ids[:n].copy(), clusters=cl[:n].copy(), eig_val=ev[:n].copy(), eig_vec=U[:n].copy(), merged=m[:n].copy())

@@ -16,6 +16,7 @@
 #include "../../include/vxba.h"
 #include "vxba_host.hpp"
 #include "vxba_imu.hpp"
+#include "vxba_voxelize.h"
 #include "vxba_kernels.h"
 
 using vxk::FactorView;
@@ -1092,6 +1093,75 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
   }
   if (resis_out) resis_out[1] = residual2;
   if (n_trace) *n_trace = nt;
+  return VXBA_OK;
+}
+
+// OctreeGBA::cut_voxel + recut on the GPU (vxba_voxelize.hip); the accepted voxels go straight from the staging arrays into
+// the factor's planes -- nothing returns to the host except their count (and the ids, if asked for).
+int vxba_voxelize_push(vxba_factor* f, int64_t n_points, const double* xyz_local, const int64_t* frame_ptr, const double* Rp,
+                       const vxba_voxelize_params* params, int64_t* n_pushed, uint64_t* node_ids, int64_t ids_capacity) {
+  VX_LOCK(f);
+  if (!f || n_points < 0 || !frame_ptr || !Rp || !params || !n_pushed || (n_points > 0 && !xyz_local))
+    return fail(f, VXBA_ERR_ARG, "voxelize_push: null argument");
+  if (params->max_layer < 0 || params->max_layer > 3 || !(params->voxel_size > 0)) return fail(f, VXBA_ERR_ARG, "voxelize_push: max_layer in 0..3, voxel_size > 0");
+  if (frame_ptr[0] != 0 || frame_ptr[f->W] != n_points) return fail(f, VXBA_ERR_ARG, "voxelize_push: frame_ptr must span [0, n_points]");
+  if (n_points > 0xffffffffll) return fail(f, VXBA_ERR_UNSUPPORTED, "voxelize_push: more than 2^32 points");
+  *n_pushed = 0;
+  if (n_points == 0) return VXBA_OK;
+  hipSetDevice(f->device);
+  const int W = f->W;
+  const int64_t cap = n_points / (std::max(params->min_points, 0) + 1) + 1;   // a factor owns > min_points points, and no point twice
+  struct Bufs {
+    std::vector<void*> p;
+    ~Bufs() { for (void* q : p) hipFree(q); }
+  } bufs;
+  auto dalloc = [&](void** ptr, size_t bytes) { hipError_t e = hipMalloc(ptr, std::max<size_t>(bytes, 8)); if (e == hipSuccess) bufs.p.push_back(*ptr); return e; };
+  double *d_xyz, *d_cl, *d_ev, *d_evec, *d_m, *d_fix, *d_coe;
+  long long* d_fp;
+  unsigned long long* d_id;
+  VX_HIP(f, dalloc((void**)&d_xyz, (size_t)n_points * 3 * sizeof(double)));
+  VX_HIP(f, dalloc((void**)&d_fp, (size_t)(W + 1) * sizeof(long long)));
+  VX_HIP(f, dalloc((void**)&d_cl, (size_t)cap * W * 10 * sizeof(double)));
+  VX_HIP(f, dalloc((void**)&d_ev, (size_t)cap * 3 * sizeof(double)));
+  VX_HIP(f, dalloc((void**)&d_evec, (size_t)cap * 9 * sizeof(double)));
+  VX_HIP(f, dalloc((void**)&d_m, (size_t)cap * 10 * sizeof(double)));
+  VX_HIP(f, dalloc((void**)&d_id, (size_t)cap * sizeof(unsigned long long)));
+  VX_HIP(f, hipMemcpyAsync(d_xyz, xyz_local, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  VX_HIP(f, hipMemcpyAsync(d_fp, frame_ptr, (size_t)(W + 1) * sizeof(long long), hipMemcpyHostToDevice, f->stream));
+  PoseArg pa;
+  fill_poses(f, Rp, pa);
+  vxv::VoxelizeParams vp;
+  vp.voxel_size = params->voxel_size; vp.max_layer = params->max_layer; vp.min_points = params->min_points;
+  vp.min_eigen_value = params->min_eigen_value; vp.factor_ratio_max = params->factor_ratio_max;
+  for (int k = 0; k < 4; k++) vp.eigen_ratio[k] = params->eigen_ratio[k];
+  vxv::VoxelizeOutput out{cap, d_cl, d_ev, d_evec, d_m, d_id};
+  const char* emsg = nullptr;
+  const long long n = vxv::voxelize(W, n_points, d_xyz, d_fp, pa, vp, f->stream, &out, &emsg);
+  if (n < 0) return fail(f, VXBA_ERR_STATE, emsg ? emsg : "voxelize failed");
+  if (n > 0) {
+    int rc = ensure_capacity(f, f->V + (int)n);
+    if (rc) return rc;
+    const FactorView fv = view(f);
+    const int v0 = f->V;
+    VX_HIP(f, dalloc((void**)&d_fix, (size_t)n * 10 * sizeof(double)));
+    VX_HIP(f, dalloc((void**)&d_coe, (size_t)n * sizeof(double)));
+    vxv::fill(d_fix, n * 10, 0.0, f->stream);
+    vxv::fill(d_coe, n, 1.0, f->stream);
+    vxk::launch_scatter_clusters(d_cl, fv, v0, (int)n, f->stream);
+    vxk::launch_build_clb(fv, v0, (int)n, f->stream);
+    vxk::launch_scatter_rows(d_fix, fv.fix, f->VS, v0, (int)n, 10, f->stream);
+    vxk::launch_scatter_rows(d_coe, fv.coe, f->VS, v0, (int)n, 1, f->stream);
+    vxk::launch_scatter_rows(d_ev, fv.eigval, f->VS, v0, (int)n, 3, f->stream);
+    vxk::launch_scatter_rows(d_evec, fv.eigvec, f->VS, v0, (int)n, 9, f->stream);
+    vxk::launch_scatter_rows(d_m, fv.merged, f->VS, v0, (int)n, 10, f->stream);
+    vxk::launch_seed_aux(fv, v0, v0 + (int)n, f->stream);
+    if (node_ids && ids_capacity > 0)
+      VX_HIP(f, hipMemcpyAsync(node_ids, d_id, (size_t)std::min<int64_t>(n, ids_capacity) * sizeof(uint64_t), hipMemcpyDeviceToHost, f->stream));
+    VX_HIP(f, hipStreamSynchronize(f->stream));
+    VX_HIP(f, hipGetLastError());
+    f->V += (int)n;
+  }
+  *n_pushed = n;
   return VXBA_OK;
 }
 

@@ -1,0 +1,34 @@
+// Launch interface of the batch factor construction (vxba_voxelize.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vxba_kernels.h"
+
+namespace vxv {
+
+struct VoxelizeParams {
+  double voxel_size;
+  int max_layer;               // 0..3
+  int min_points;              // a node needs N > min_points
+  double min_eigen_value;      // plane_judge: lambda0 < min_eigen_value ...
+  double eigen_ratio[4];       // ... && lambda0 / lambda2 < eigen_ratio[layer]
+  double factor_ratio_max;     // factor filter: lambda0 / lambda1 <= factor_ratio_max
+};
+
+// Device staging arrays for the accepted voxels (AoS, the formats of vxba_push_voxels), capacity in voxels.
+struct VoxelizeOutput {
+  long long capacity;
+  double* d_clusters;          // [n][W][10]
+  double* d_eigval;            // [n][3]
+  double* d_eigvec;            // [n][9] column-major
+  double* d_merged;            // [n][10]
+  unsigned long long* d_node_id;   // [n] canonical id: [x:16 | y:16 | z:16 | path:9 | pad:4 | layer:3]
+};
+
+// Returns the number of factor voxels written (grouped by layer, ascending node key inside a layer) or -1 (*err set).
+long long voxelize(int W, long long n_points, const double* d_xyz_local, const long long* d_frame_ptr, const vxk::PoseArg& poses, const VoxelizeParams& p,
+                   hipStream_t s, VoxelizeOutput* out, const char** err);
+
+void fill(double* d, long long n, double v, hipStream_t s);
+
+}  // namespace vxv

@@ -1,0 +1,289 @@
+// Batch factor construction on the GPU: points of a window -> voxel hash -> octree subdivision -> plane test -> BA factor.
+// The reference does this with an unordered_map of octree nodes walked on the host (OctreeGBA::cut_voxel / subdivide /
+// recut, loop_refine.hpp:273-476; call site voxelslam.cpp:2374-2379).  Here it is a sort:
+//
+//   every point gets one 64-bit key  [ x:16 | y:16 | z:16 | octant path: 3 bits per layer, 9 | frame: 7 ]
+//   (root voxel exactly as upstream: float quotient, "-1 if negative", truncation; octants by strict '>' against the node
+//   centres, which are carried along with upstream's float quarter lengths), and for each octree layer l one stable radix
+//   sort of (key truncated to layer l, frame) makes every (node, frame) cell and every node a contiguous point range, in
+//   the order upstream pushes the points (frame by frame, cloud order) -- so the cluster sums are bit-identical to
+//   PointCluster::push.  Nodes are then judged top-down (N > 10, plane_judge, >= 2 observing frames, lambda0/lambda1 <=
+//   0.12; non-planes are subdivided while layer < max_layer), and the accepted ones are appended to the factor's planes
+//   on the device, cache seeded with (lambda, U, world cluster) like recut's push_voxel does.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "vxba_kernels.h"
+#include "vxba_math.hpp"
+#include "vxba_voxelize.h"
+
+namespace vxv {
+
+constexpr int FRAME_BITS = 7, PATH_BITS = 9;
+
+__global__ void key_kernel(const double* __restrict__ xyz, const long long* __restrict__ frame_ptr, int W, vxk::PoseArg poses, VoxelizeParams p,
+                           long long n, double* __restrict__ world, unsigned long long* __restrict__ key, int* __restrict__ err) {
+#pragma clang fp contract(off)
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  int f = 0;
+  while (f + 1 < W && q >= frame_ptr[f + 1]) f++;
+  const double* Rp = poses.Rp + 12 * f;
+  const double x = xyz[3 * q], y = xyz[3 * q + 1], z = xyz[3 * q + 2];
+  double w[3];
+  for (int r = 0; r < 3; r++) w[r] = Rp[r] * x + Rp[3 + r] * y + Rp[6 + r] * z + Rp[9 + r];   // R * local + p, left to right
+  unsigned long long root = 0;
+  double centre[3];
+  for (int j = 0; j < 3; j++) {
+    float loc = (float)(w[j] / p.voxel_size);
+    if (loc < 0) loc -= 1.0f;
+    const long long pos = (long long)loc;
+    if (pos < -32768 || pos > 32767) { *err = 1; return; }
+    root = (root << 16) | (unsigned long long)(pos + 32768);
+    centre[j] = (0.5 + (double)pos) * p.voxel_size;
+  }
+  float quarter = (float)(p.voxel_size / 4.0);
+  unsigned long long path = 0;
+  for (int l = 0; l < 3; l++) {
+    int b[3];
+    for (int k = 0; k < 3; k++) b[k] = w[k] > centre[k] ? 1 : 0;
+    path = (path << 3) | (unsigned long long)(4 * b[0] + 2 * b[1] + b[2]);
+    for (int k = 0; k < 3; k++) centre[k] = centre[k] + (double)((float)(2 * b[k] - 1) * quarter);
+    quarter = quarter / 2;
+  }
+  world[3 * q] = w[0]; world[3 * q + 1] = w[1]; world[3 * q + 2] = w[2];
+  key[q] = (root << (PATH_BITS + FRAME_BITS)) | (path << FRAME_BITS) | (unsigned long long)f;
+}
+
+// key of the (node at layer l, frame) cell: the octant bits below layer l are cleared
+__global__ void layer_key_kernel(const unsigned long long* __restrict__ key, long long n, int layer, unsigned long long* __restrict__ out,
+                                 unsigned int* __restrict__ idx) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const unsigned long long keep = ~(((1ull << (3 * (3 - layer))) - 1ull) << FRAME_BITS);
+  out[q] = key[q] & keep;
+  idx[q] = (unsigned int)q;
+}
+__global__ void gather3_kernel(const double* __restrict__ src, const unsigned int* __restrict__ idx, long long n, double* __restrict__ dst) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const unsigned int s = idx[q];
+  dst[3 * q] = src[3 * s]; dst[3 * q + 1] = src[3 * s + 1]; dst[3 * q + 2] = src[3 * s + 2];
+}
+__global__ void shift_key_kernel(const unsigned long long* __restrict__ in, long long n, unsigned long long* __restrict__ out) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) out[q] = in[q] >> FRAME_BITS;
+}
+// cell_ptr[c] (exclusive scan of the cell sizes) -> node_ptr[j] = cell_ptr[node_cell_ptr[j]]
+__global__ void node_ptr_kernel(const long long* __restrict__ cell_ptr, const long long* __restrict__ node_cell_ptr, long long n_nodes,
+                                long long* __restrict__ node_ptr) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j <= n_nodes) node_ptr[j] = cell_ptr[node_cell_ptr[j]];
+}
+__global__ void widen_kernel(const unsigned int* __restrict__ in, long long n, long long* __restrict__ out) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) out[q] = (long long)in[q];
+}
+
+enum NodeState : unsigned char { DEAD = 0, FACTOR = 1, SUBDIVIDE = 2 };
+
+// One thread per node of layer l: parent must have been subdivided; then loop_refine.hpp:358-405.
+__global__ void judge_kernel(const unsigned long long* __restrict__ node_key, const double* __restrict__ node_cluster, const unsigned int* __restrict__ n_frames,
+                             long long n_nodes, int layer, VoxelizeParams p, const unsigned long long* __restrict__ parent_key,
+                             const unsigned char* __restrict__ parent_state, long long n_parents, unsigned char* __restrict__ state,
+                             double* __restrict__ eigval, double* __restrict__ eigvec) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_nodes) return;
+  unsigned char st = DEAD;
+  bool alive = true;
+  if (layer > 0) {
+    // the parent's key: same root, octant bits of this layer cleared
+    const unsigned long long pk = node_key[j] & ~(7ull << (3 * (3 - layer)));
+    long long lo = 0, hi = n_parents - 1;
+    alive = false;
+    while (lo <= hi) {
+      const long long mid = (lo + hi) >> 1;
+      const unsigned long long v = parent_key[mid];
+      if (v == pk) { alive = parent_state[mid] == SUBDIVIDE; break; }
+      if (v < pk) lo = mid + 1; else hi = mid - 1;
+    }
+  }
+  const double* c = node_cluster + 10 * j;
+  if (alive && (int)c[9] > p.min_points) {
+    double Cm[6], lam[3], U[9];
+    vxm::cluster_cov(c, c + 6, c[9], Cm);
+    vxm::eig_sym3(Cm, lam, U);
+    const bool is_plane = lam[0] < p.min_eigen_value && (lam[0] / lam[2]) < p.eigen_ratio[layer];
+    if (is_plane) {
+      if (n_frames[j] > 1 && !(lam[0] / lam[1] > p.factor_ratio_max)) st = FACTOR;
+    } else if (layer < p.max_layer) {
+      st = SUBDIVIDE;
+    }
+    for (int k = 0; k < 3; k++) eigval[3 * j + k] = lam[k];
+    for (int col = 0; col < 3; col++)
+      for (int row = 0; row < 3; row++) eigvec[9 * j + 3 * col + row] = U[3 * row + col];
+  }
+  state[j] = st;
+}
+
+__global__ void flag_kernel(const unsigned char* __restrict__ state, long long n, unsigned int* __restrict__ flag) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) flag[j] = state[j] == FACTOR ? 1u : 0u;
+}
+// accepted node j -> slot pos[j] of the AoS staging arrays [n][W][10], [n][3], [n][9], [n][10], ids
+__global__ void emit_kernel(const unsigned char* __restrict__ state, const unsigned int* __restrict__ pos, long long n_nodes, int W, int layer,
+                            const unsigned long long* __restrict__ node_key, const long long* __restrict__ node_cell_ptr,
+                            const unsigned long long* __restrict__ cell_key, const double* __restrict__ cell_cluster,
+                            const double* __restrict__ node_cluster, const double* __restrict__ eigval, const double* __restrict__ eigvec,
+                            long long out_base, double* __restrict__ o_clusters, double* __restrict__ o_eigval, double* __restrict__ o_eigvec,
+                            double* __restrict__ o_merged, unsigned long long* __restrict__ o_id) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_nodes || state[j] != FACTOR) return;
+  const long long o = out_base + pos[j];
+  double* oc = o_clusters + (size_t)o * W * 10;
+  for (int k = 0; k < W * 10; k++) oc[k] = 0.0;
+  for (long long cc = node_cell_ptr[j]; cc < node_cell_ptr[j + 1]; cc++) {
+    const int f = (int)(cell_key[cc] & ((1ull << FRAME_BITS) - 1ull));
+    for (int k = 0; k < 10; k++) oc[f * 10 + k] = cell_cluster[10 * cc + k];
+  }
+  for (int k = 0; k < 3; k++) o_eigval[3 * o + k] = eigval[3 * j + k];
+  for (int k = 0; k < 9; k++) o_eigvec[9 * o + k] = eigvec[9 * j + k];
+  for (int k = 0; k < 10; k++) o_merged[10 * o + k] = node_cluster[10 * j + k];
+  const unsigned long long nk = node_key[j];                 // [root48 | path9]
+  o_id[o] = ((nk >> PATH_BITS) << 16) | ((nk & 511ull) << 7) | (unsigned long long)layer;
+}
+
+__global__ void fill_kernel(double* __restrict__ p, long long n, double v) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) p[q] = v;
+}
+void fill(double* d, long long n, double v, hipStream_t s) {
+  if (n > 0) fill_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(d, n, v);
+}
+
+struct DevBuf {
+  std::vector<void*> ptrs;
+  ~DevBuf() { for (void* p : ptrs) hipFree(p); }
+  template <class T>
+  hipError_t alloc(T** p, size_t n) {
+    hipError_t e = hipMalloc((void**)p, (n > 0 ? n : 1) * sizeof(T));
+    if (e == hipSuccess) ptrs.push_back(*p);
+    return e;
+  }
+};
+
+#define VV(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { *err_out = hipGetErrorString(e_); return -1; } } while (0)
+
+static inline unsigned grid_for(long long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
+
+long long voxelize(int W, long long n_points, const double* d_xyz_local, const long long* d_frame_ptr, const vxk::PoseArg& poses, const VoxelizeParams& p,
+                   hipStream_t s, VoxelizeOutput* out, const char** err_out) {
+  static const char* range_msg = "voxelize: a point lies outside the +-32768-voxel range of the 16-bit voxel coordinates";
+  static const char* cap_msg = "voxelize: more factor voxels than the caller's capacity";
+  DevBuf B;
+  const long long n = n_points;
+  double *d_world, *d_loc_s, *d_wld_s;
+  unsigned long long *d_key, *d_lkey, *d_lkey_s;
+  unsigned int *d_idx, *d_idx_s;
+  int* d_err;
+  VV(B.alloc(&d_world, 3 * n)); VV(B.alloc(&d_loc_s, 3 * n)); VV(B.alloc(&d_wld_s, 3 * n));
+  VV(B.alloc(&d_key, n)); VV(B.alloc(&d_lkey, n)); VV(B.alloc(&d_lkey_s, n));
+  VV(B.alloc(&d_idx, n)); VV(B.alloc(&d_idx_s, n)); VV(B.alloc(&d_err, 1));
+  VV(hipMemsetAsync(d_err, 0, sizeof(int), s));
+  if (n > 0) key_kernel<<<grid_for(n), 256, 0, s>>>(d_xyz_local, d_frame_ptr, W, poses, p, n, d_world, d_key, d_err);
+
+  // per-layer scratch (sized for the worst case: every point its own cell)
+  unsigned long long *d_cell_key, *d_cell_node, *d_node_key[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned int *d_cell_cnt, *d_node_ncell, *d_runs, *d_flag, *d_pos;
+  long long *d_cell_ptr, *d_node_cell_ptr, *d_node_ptr, *d_tmp64;
+  double *d_cell_cl, *d_node_cl, *d_eigval, *d_eigvec;
+  unsigned char* d_state[4] = {nullptr, nullptr, nullptr, nullptr};
+  VV(B.alloc(&d_cell_key, n)); VV(B.alloc(&d_cell_node, n)); VV(B.alloc(&d_cell_cnt, n)); VV(B.alloc(&d_node_ncell, n)); VV(B.alloc(&d_runs, 1));
+  VV(B.alloc(&d_flag, n)); VV(B.alloc(&d_pos, n));
+  VV(B.alloc(&d_cell_ptr, n + 1)); VV(B.alloc(&d_node_cell_ptr, n + 1)); VV(B.alloc(&d_node_ptr, n + 1)); VV(B.alloc(&d_tmp64, n + 1));
+  VV(B.alloc(&d_cell_cl, 10 * n)); VV(B.alloc(&d_node_cl, 10 * n)); VV(B.alloc(&d_eigval, 3 * n)); VV(B.alloc(&d_eigvec, 9 * n));
+  long long n_nodes_l[4] = {0, 0, 0, 0};
+
+  // rocPRIM temporary storage: query the largest need once
+  size_t tb_sort = 0, tb_rle = 0, tb_scan = 0, tb_scan32 = 0;
+  VV(rocprim::radix_sort_pairs(nullptr, tb_sort, d_lkey, d_lkey_s, d_idx, d_idx_s, (size_t)n, 0, 64, s));
+  VV(rocprim::run_length_encode(nullptr, tb_rle, d_lkey_s, (size_t)n, d_cell_key, d_cell_cnt, d_runs, s));
+  VV(rocprim::exclusive_scan(nullptr, tb_scan, d_tmp64, d_cell_ptr, 0ll, (size_t)n + 1, rocprim::plus<long long>(), s));
+  VV(rocprim::exclusive_scan(nullptr, tb_scan32, d_flag, d_pos, 0u, (size_t)n, rocprim::plus<unsigned int>(), s));
+  size_t tb = tb_sort;
+  if (tb_rle > tb) tb = tb_rle;
+  if (tb_scan > tb) tb = tb_scan;
+  if (tb_scan32 > tb) tb = tb_scan32;
+  char* d_temp;
+  VV(B.alloc(&d_temp, tb));
+
+  int h_err = 0;
+  VV(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+  VV(hipStreamSynchronize(s));
+  if (h_err) { *err_out = range_msg; return -1; }
+
+  long long total = 0;
+  for (int layer = 0; layer <= p.max_layer && n > 0; layer++) {
+    layer_key_kernel<<<grid_for(n), 256, 0, s>>>(d_key, n, layer, d_lkey, d_idx);
+    size_t t = tb;
+    VV(rocprim::radix_sort_pairs(d_temp, t, d_lkey, d_lkey_s, d_idx, d_idx_s, (size_t)n, 0, 64, s));
+    // (node, frame) cells
+    t = tb;
+    VV(rocprim::run_length_encode(d_temp, t, d_lkey_s, (size_t)n, d_cell_key, d_cell_cnt, d_runs, s));
+    unsigned int n_cells = 0;
+    VV(hipMemcpyAsync(&n_cells, d_runs, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    VV(hipStreamSynchronize(s));
+    widen_kernel<<<grid_for(n_cells), 256, 0, s>>>(d_cell_cnt, n_cells, d_tmp64);
+    t = tb;
+    VV(rocprim::exclusive_scan(d_temp, t, d_tmp64, d_cell_ptr, 0ll, (size_t)n_cells + 1, rocprim::plus<long long>(), s));
+    // nodes = runs of cells with the same key above the frame bits
+    shift_key_kernel<<<grid_for(n_cells), 256, 0, s>>>(d_cell_key, n_cells, d_cell_node);
+    VV(B.alloc(&d_node_key[layer], n_cells));
+    t = tb;
+    VV(rocprim::run_length_encode(d_temp, t, d_cell_node, (size_t)n_cells, d_node_key[layer], d_node_ncell, d_runs, s));
+    unsigned int n_nodes = 0;
+    VV(hipMemcpyAsync(&n_nodes, d_runs, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    VV(hipStreamSynchronize(s));
+    n_nodes_l[layer] = n_nodes;
+    widen_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_node_ncell, n_nodes, d_tmp64);
+    t = tb;
+    VV(rocprim::exclusive_scan(d_temp, t, d_tmp64, d_node_cell_ptr, 0ll, (size_t)n_nodes + 1, rocprim::plus<long long>(), s));
+    node_ptr_kernel<<<grid_for(n_nodes + 1), 256, 0, s>>>(d_cell_ptr, d_node_cell_ptr, n_nodes, d_node_ptr);
+    // clusters: body-frame per cell, world per node -- sequential sums in upstream's push order
+    gather3_kernel<<<grid_for(n), 256, 0, s>>>(d_xyz_local, d_idx_s, n, d_loc_s);
+    gather3_kernel<<<grid_for(n), 256, 0, s>>>(d_world, d_idx_s, n, d_wld_s);
+    vxk::launch_k1_build_aos(d_loc_s, (const int64_t*)d_cell_ptr, n_cells, d_cell_cl, s);
+    vxk::launch_k1_build_aos(d_wld_s, (const int64_t*)d_node_ptr, n_nodes, d_node_cl, s);
+    // verdicts
+    VV(B.alloc(&d_state[layer], n_nodes));
+    judge_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_node_key[layer], d_node_cl, d_node_ncell, n_nodes, layer, p, layer ? d_node_key[layer - 1] : nullptr,
+                                                  layer ? d_state[layer - 1] : nullptr, layer ? n_nodes_l[layer - 1] : 0, d_state[layer], d_eigval, d_eigvec);
+    flag_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_state[layer], n_nodes, d_flag);
+    t = tb;
+    VV(rocprim::exclusive_scan(d_temp, t, d_flag, d_pos, 0u, (size_t)n_nodes, rocprim::plus<unsigned int>(), s));
+    unsigned int last_pos = 0, last_flag = 0;
+    if (n_nodes > 0) {
+      VV(hipMemcpyAsync(&last_pos, d_pos + n_nodes - 1, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+      VV(hipMemcpyAsync(&last_flag, d_flag + n_nodes - 1, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+      VV(hipStreamSynchronize(s));
+    }
+    const long long n_acc = (long long)last_pos + last_flag;
+    if (total + n_acc > out->capacity) { *err_out = cap_msg; return -1; }
+    if (n_acc > 0)
+      emit_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_state[layer], d_pos, n_nodes, W, layer, d_node_key[layer], d_node_cell_ptr, d_cell_key, d_cell_cl, d_node_cl,
+                                                   d_eigval, d_eigvec, total, out->d_clusters, out->d_eigval, out->d_eigvec, out->d_merged, out->d_node_id);
+    total += n_acc;
+  }
+  VV(hipStreamSynchronize(s));
+  VV(hipGetLastError());
+  return total;
+}
+
+}  // namespace vxv

@@ -279,3 +279,52 @@ def make_imu(scene: Scene, rate_hz=200.0, frame_dt=0.1, gyr_sigma=1e-3, acc_sigm
     noise_walk = np.diag([rdw_gyr] * 3 + [rdw_acc] * 3).astype(np.float64)
     return ImuWindow(states_gt=pack_states(Rs, ps, vs, bg_true, ba_true), states_init=pack_states(Ri, pi, vi, bg_est, ba_est),
                      samples=samples, noise_meas=noise_meas, noise_walk=noise_walk, dt_frame=frame_dt)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Raw scans for the batch factor construction (voxel hash -> octree -> plane test): a few large planar walls / floors
+# plus clutter, sampled by every frame, NOT aligned with the voxel grid -- so root voxels contain one plane, two planes
+# (edges: subdivided), or clutter (rejected), like a real scene.
+# ------------------------------------------------------------------------------------------------------------
+def make_scans(win_size=5, pts_per_scan=20_000, extent=20.0, noise=0.01, clutter_frac=0.1, seed=MASTER_SEED + 555, rot_sigma_deg=0.0,
+               trans_sigma=0.0):
+    """Returns (xyz_local (N,3) frame-major, frame_ptr (W+1,), poses (W,12)).  Points are expressed in their frame's body
+    coordinates with the returned poses (optionally perturbed away from the poses the scans were taken at)."""
+    rng = np.random.Generator(np.random.PCG64([seed, 99]))
+    W = win_size
+    axis = np.array([0.2, 0.1, 1.0]); axis /= np.linalg.norm(axis)
+    Rs = np.stack([rodrigues(0.03 * i * axis) for i in range(W)])
+    ps = np.stack([np.array([0.4 * i, 0.1 * np.sin(i), 0.02 * i]) for i in range(W)])
+    # planes: point + two in-plane unit vectors + size
+    planes = []
+    for k in range(8):
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        if k < 3:
+            n = np.eye(3)[k] + 0.05 * rng.normal(size=3); n /= np.linalg.norm(n)
+        a = np.cross(n, [0.3, 0.5, 0.8]); a /= np.linalg.norm(a)
+        b = np.cross(n, a)
+        c = rng.uniform(-extent / 2, extent / 2, size=3)
+        planes.append((c, a, b, n, rng.uniform(extent / 4, extent / 2)))
+    clouds = []
+    for i in range(W):
+        n_cl = int(pts_per_scan * clutter_frac)
+        n_pl = pts_per_scan - n_cl
+        which = rng.integers(0, len(planes), size=n_pl)
+        w = np.zeros((n_pl, 3))
+        for k, (c, a, b, n, sz) in enumerate(planes):
+            sel = np.nonzero(which == k)[0]
+            # a fixed lattice of surface samples per plane, so every frame revisits the same surface patches
+            u = rng.uniform(-sz, sz, size=sel.size); v = rng.uniform(-sz, sz, size=sel.size)
+            w[sel] = c + u[:, None] * a + v[:, None] * b + rng.normal(0, noise, size=sel.size)[:, None] * n
+        cl = rng.uniform(-extent / 2, extent / 2, size=(n_cl, 3))
+        world = np.concatenate([w, cl])[rng.permutation(pts_per_scan)]
+        clouds.append(np.einsum("ji,nj->ni", Rs[i], world - ps[i]))
+    xyz = np.ascontiguousarray(np.concatenate(clouds))
+    frame_ptr = np.arange(W + 1, dtype=np.int64) * pts_per_scan
+    Rs2, ps2 = Rs.copy(), ps.copy()
+    for i in range(1, W):
+        if rot_sigma_deg > 0:
+            Rs2[i] = Rs[i] @ rodrigues(rng.normal(0, np.deg2rad(rot_sigma_deg), size=3))
+        if trans_sigma > 0:
+            ps2[i] = ps[i] + rng.normal(0, trans_sigma, size=3)
+    return xyz, frame_ptr, pack_poses(Rs2, ps2), pack_poses(Rs, ps)

@@ -31,7 +31,7 @@ EXPORTS = [
     "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_plane_fit_judge", "vxba_build_clusters", "vxba_set_allreduce",
     "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_detach", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps",
     "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_li_evaluate",
-    "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity",
+    "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity", "vxba_voxelize_push",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -39,6 +39,19 @@ _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA
 
 class VxbaError(RuntimeError):
     pass
+
+
+class VoxelizeParams(C.Structure):
+    """vxba_voxelize_params: the knobs of OctreeGBA::recut (loop_refine.hpp:311-315, 358-378) and of the voxel grid."""
+    _fields_ = [("voxel_size", C.c_double), ("max_layer", C.c_int), ("min_points", C.c_int), ("min_eigen_value", C.c_double),
+                ("eigen_ratio", C.c_double * 4), ("factor_ratio_max", C.c_double)]
+
+    def __init__(self, voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 16, 1 / 16),
+                 factor_ratio_max=0.12):
+        super().__init__(voxel_size, max_layer, min_points, min_eigen_value, (C.c_double * 4)(*eigen_ratio), factor_ratio_max)
+
+    def as_array(self):
+        return np.array([self.voxel_size, self.max_layer, self.min_points, self.min_eigen_value, *self.eigen_ratio, self.factor_ratio_max])
 
 
 _lib = None
@@ -100,6 +113,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_li_evaluate.argtypes = [vp, _f64p, _f64p, cd, _f64p, _f64p, C.POINTER(cd)]
     L.vxba_li_only_residual.argtypes = [vp, _f64p, _f64p, cd, C.POINTER(cd)]
     L.vxba_li_damping_iter.argtypes = [vp, _f64p, _f64p, cd, ci, vp, vp, C.POINTER(ci)]
+    L.vxba_voxelize_push.argtypes = [vp, C.c_int64, _f64p, _i64p, _f64p, C.POINTER(VoxelizeParams), C.POINTER(C.c_int64), vp, C.c_int64]
     L.vxba_imu_evaluate_g.argtypes = [_f64p, _f64p, _f64p, ci, vp, vp, C.POINTER(cd)]
     L.vxba_li_damping_iter_gravity.argtypes = [vp, _f64p, _f64p, cd, ci, vp, _f64p, vp, C.POINTER(ci)]
     _lib = L
@@ -196,6 +210,18 @@ class LidarFactor:
         pf, kf = _opt(fix)
         pc, kc = _opt(coe)
         self._chk(self._L.vxba_push_points(self._h, int(n_voxels), xyz.shape[0], xyz, ptr, pf, pc))
+
+    def voxelize_push(self, xyz_local, frame_ptr, xs, params: "VoxelizeParams", want_ids=True):
+        """OctreeGBA::cut_voxel + recut on the GPU (loop_refine.hpp:273-476): appends the factor voxels found in the window's
+        points; returns their canonical node ids (uint64) in push order (or just the count)."""
+        xyz = _c(xyz_local).reshape(-1, 3)
+        fp = np.ascontiguousarray(frame_ptr, dtype=np.int64)
+        n = C.c_int64(0)
+        cap = xyz.shape[0] // (max(params.min_points, 0) + 1) + 1 if want_ids else 0
+        ids = np.zeros(max(cap, 1), dtype=np.uint64)
+        self._chk(self._L.vxba_voxelize_push(self._h, xyz.shape[0], xyz, fp, _c(xs), C.byref(params), C.byref(n),
+                                             ids.ctypes.data_as(C.c_void_p) if want_ids else None, cap))
+        return ids[: n.value].copy() if want_ids else n.value
 
     def read_clusters(self, head=0, end=None):
         end = self.size() if end is None else end
