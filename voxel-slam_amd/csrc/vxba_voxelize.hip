@@ -168,14 +168,22 @@ void fill(double* d, long long n, double v, hipStream_t s) {
   if (n > 0) fill_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(d, n, v);
 }
 
+// One device allocation for all temporaries of a call (hipMalloc/hipFree cost ~0.1-1 ms each; there are ~30 arrays).
 struct DevBuf {
-  std::vector<void*> ptrs;
-  ~DevBuf() { for (void* p : ptrs) hipFree(p); }
+  char* base = nullptr;
+  size_t cap = 0, used = 0;
+  ~DevBuf() { if (base) hipFree(base); }
+  hipError_t reserve(size_t bytes) {
+    cap = bytes;
+    return hipMalloc((void**)&base, bytes);
+  }
   template <class T>
   hipError_t alloc(T** p, size_t n) {
-    hipError_t e = hipMalloc((void**)p, (n > 0 ? n : 1) * sizeof(T));
-    if (e == hipSuccess) ptrs.push_back(*p);
-    return e;
+    const size_t bytes = (((n > 0 ? n : 1) * sizeof(T)) + 255) & ~(size_t)255;
+    if (used + bytes > cap) return hipErrorOutOfMemory;
+    *p = (T*)(base + used);
+    used += bytes;
+    return hipSuccess;
   }
 };
 
@@ -189,6 +197,22 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
   static const char* cap_msg = "voxelize: more factor voxels than the caller's capacity";
   DevBuf B;
   const long long n = n_points;
+  // rocPRIM temporary storage: query the largest need first (size queries do not touch the pointers)
+  size_t tb = 0;
+  {
+    size_t tb_sort = 0, tb_rle = 0, tb_scan = 0, tb_scan32 = 0;
+    unsigned long long* k0 = nullptr; unsigned int* v0 = nullptr; long long* l0 = nullptr;
+    VV(rocprim::radix_sort_pairs(nullptr, tb_sort, k0, k0, v0, v0, (size_t)n, 0, 64, s));
+    VV(rocprim::run_length_encode(nullptr, tb_rle, k0, (size_t)n, k0, v0, v0, s));
+    VV(rocprim::exclusive_scan(nullptr, tb_scan, l0, l0, 0ll, (size_t)n + 1, rocprim::plus<long long>(), s));
+    VV(rocprim::exclusive_scan(nullptr, tb_scan32, v0, v0, 0u, (size_t)n, rocprim::plus<unsigned int>(), s));
+    tb = tb_sort;
+    if (tb_rle > tb) tb = tb_rle;
+    if (tb_scan > tb) tb = tb_scan;
+    if (tb_scan32 > tb) tb = tb_scan32;
+  }
+  // worst case (every point its own cell): < 0.5 KB of scratch per point
+  VV(B.reserve((size_t)(n + 64) * 512 + tb + (size_t)(1 << 20)));
   double *d_world, *d_loc_s, *d_wld_s;
   unsigned long long *d_key, *d_lkey, *d_lkey_s;
   unsigned int *d_idx, *d_idx_s;
@@ -211,16 +235,6 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
   VV(B.alloc(&d_cell_cl, 10 * n)); VV(B.alloc(&d_node_cl, 10 * n)); VV(B.alloc(&d_eigval, 3 * n)); VV(B.alloc(&d_eigvec, 9 * n));
   long long n_nodes_l[4] = {0, 0, 0, 0};
 
-  // rocPRIM temporary storage: query the largest need once
-  size_t tb_sort = 0, tb_rle = 0, tb_scan = 0, tb_scan32 = 0;
-  VV(rocprim::radix_sort_pairs(nullptr, tb_sort, d_lkey, d_lkey_s, d_idx, d_idx_s, (size_t)n, 0, 64, s));
-  VV(rocprim::run_length_encode(nullptr, tb_rle, d_lkey_s, (size_t)n, d_cell_key, d_cell_cnt, d_runs, s));
-  VV(rocprim::exclusive_scan(nullptr, tb_scan, d_tmp64, d_cell_ptr, 0ll, (size_t)n + 1, rocprim::plus<long long>(), s));
-  VV(rocprim::exclusive_scan(nullptr, tb_scan32, d_flag, d_pos, 0u, (size_t)n, rocprim::plus<unsigned int>(), s));
-  size_t tb = tb_sort;
-  if (tb_rle > tb) tb = tb_rle;
-  if (tb_scan > tb) tb = tb_scan;
-  if (tb_scan32 > tb) tb = tb_scan32;
   char* d_temp;
   VV(B.alloc(&d_temp, tb));
 
