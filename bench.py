@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-li-ba", action="store_true", help="skip the secondary LiDAR-inertial BA figure")
+    ap.add_argument("--precision", choices=["f64", "mixed"], default="f64",
+                    help="mixed = BASELINE configs[2]: f32 Hessian products on the matrix cores, f64 accumulation (use with --config cfg3)")
     ap.add_argument("--hook-allreduce", action="store_true", help="use the torch.distributed hook instead of direct RCCL calls")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-reduce path even with one rank (plumbing test)")
     args = ap.parse_args()
@@ -106,6 +108,7 @@ def main():
             _keep = vdist.attach_allreduce(f)              # exchange buffers become torch tensors, collective via a host hook
         else:
             vdist.attach_rccl(f)                           # ncclAllReduce issued directly from the C++ loop
+    f.set_precision(args.precision)
     f.evaluate_only_residual(sc.poses_init)                # seeds the (lambda, U, merged) cache (recut's eig)
     f.snapshot_cache()
     abytes = f.algorithmic_bytes()
@@ -168,7 +171,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if args.precision == "f64" else "f32 products / f64 accumulation (Hessian sweep), f64 elsewhere",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: W={W}, {sc.points_body.shape[0] // W} pts/scan, {V} voxels per GPU, nnz={nnz}",

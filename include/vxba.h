@@ -233,6 +233,15 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
 int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out,
                                  double* resis_out, double* trace_out, int* n_trace);
 
+/* Arithmetic of the Hessian sweep (BASELINE.json configs[2], the mixed-precision tolerance study).  F64 (default): fp64
+ * throughout, like the reference.  MIXED: the rank-3 rows of every voxel ("Jacobian") are rounded to f32 and multiplied on the
+ * f32 matrix cores, summed in f32 inside one wave (<= 72 voxels) and accumulated in f64 across waves, workgroups and GPUs;
+ * gradient, block-diagonal terms, residuals, eigen-decompositions and the solve stay fp64.  The gradient is exact, so the LM
+ * fixed point is unchanged; only the step direction carries ~1e-7 relative error. */
+#define VXBA_PRECISION_F64 0
+#define VXBA_PRECISION_MIXED 1
+int vxba_set_precision(vxba_factor* f, int mode);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* Bit mask of kernels to bracket with hipEvents on the launch stream: 1 = Hessian sweep (K3), 2 = residual sweep (K2),
  * 4 = K3 cross-block reduction, 8 = cluster build (K1); 0 = off. */

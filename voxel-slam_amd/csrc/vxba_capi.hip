@@ -56,6 +56,7 @@ struct vxba_factor {
   double* h_scalar = nullptr;    // pinned
   vxk::LMState* d_lm = nullptr;  // device-resident LM shell state
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
+  int precision = 0;             // 0: fp64 throughout; 1: Hessian products in f32 on the matrix cores, f64 accumulation
   unsigned lm_seq = 0;           // sequence numbers of solves published inside residual-sweep launches (never 0)
   vxba_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
@@ -240,10 +241,10 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c
   const int c_now = c ? *c : 0;
   if (f->profiling & 1) {   // events bound to the dispatch itself: same interval as the profiler's kernel duration
     hipEvent_t a = get_event(f), b = get_event(f);
-    vxk::launch_k3_hessian(fv, pa, lm, c_in, pd, cache_src, head, end, f->d_partial3, nblocks, f->stream, a, b);
+    vxk::launch_k3_hessian(fv, pa, lm, c_in, pd, cache_src, head, end, f->d_partial3, nblocks, f->precision, f->stream, a, b);
     if (a && b) f->pending.push_back({a, b, 0});
   } else {
-    vxk::launch_k3_hessian(fv, pa, lm, c_in, pd, cache_src, head, end, f->d_partial3, nblocks, f->stream);
+    vxk::launch_k3_hessian(fv, pa, lm, c_in, pd, cache_src, head, end, f->d_partial3, nblocks, f->precision, f->stream);
   }
   {
     ScopedKernelTimer t(f, 2);
@@ -1181,6 +1182,13 @@ int vxba_debug_mfma_probe(int device, const double* A16x4, const double* B4x16, 
 int vxba_debug_stamps(int clear, unsigned long long* out, size_t n) {
   if (clear) vxk::debug_clear_stamps();
   if (out && n) { (void)hipDeviceSynchronize(); vxk::debug_read_stamps(out, n); }
+  return VXBA_OK;
+}
+
+int vxba_set_precision(vxba_factor* f, int mode) {
+  VX_LOCK(f);
+  if (!f || (mode != VXBA_PRECISION_F64 && mode != VXBA_PRECISION_MIXED)) return fail(f, VXBA_ERR_ARG, "set_precision: mode must be VXBA_PRECISION_F64 or VXBA_PRECISION_MIXED");
+  f->precision = mode;
   return VXBA_OK;
 }
 

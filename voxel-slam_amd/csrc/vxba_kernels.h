@@ -105,10 +105,11 @@ int k3_grid_blocks(int device_cus);
 // ev_start / ev_stop (nullable): events tied to this dispatch's own begin / end timestamps (hipExtLaunchKernel), i.e.
 // the same interval rocprofv3 reports for the kernel -- events recorded around a launch also count the dispatch gap.
 // st != null: LM mode -- the sweep first takes the pending accept/reject decision (LMPending) from ctl[c_in] into
+// mixed != 0: f32 products on the matrix cores, f64 accumulation (BASELINE configs[2]).
 // ctl[c_in ^ 1] (if pend.pending; else it runs on ctl[c_in] as is), linearises at the decided poses and skips itself
 // when the decision says so (rejected step / loop done).  `poses` doubles as the restart poses of the bench driver.
 int launch_k3_hessian(const FactorView& fv, const PoseArg& poses, LMState* st, int c_in, const LMPending& pend, const double* cache_src,
-                      int head, int end, double* d_partial, int nblocks, hipStream_t s, hipEvent_t ev_start = nullptr,
+                      int head, int end, double* d_partial, int nblocks, int mixed, hipStream_t s, hipEvent_t ev_start = nullptr,
                       hipEvent_t ev_stop = nullptr);
 // Cross-workgroup reduction + assembly of the packed [Hess (6W)^2 col-major | JacT 6W | residual] buffer.
 void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, double* d_packed, hipStream_t s);

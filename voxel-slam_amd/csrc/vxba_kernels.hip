@@ -402,6 +402,17 @@ __device__ __forceinline__ void k3_store_rows(double* ldsb, bool active, int vl,
     for (int k = 0; k < 6; k++) dst[k] = rows[r][k];
   }
 }
+// mixed precision (BASELINE configs[2]): the rows are rounded to f32 on the way into the tile (same tile geometry, in floats)
+template <int W>
+__device__ __forceinline__ void k3_store_rows_f32(float* ldsb, bool active, int vl, int fi, const double rows[3][6]) {
+  using C = K3Cfg<W>;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    float* dst = ldsb + (active ? (3 * vl + r) * C::RS + 6 * fi : C::ROWS * C::RS);
+#pragma unroll
+    for (int k = 0; k < 6; k++) dst[k] = (float)rows[r][k];
+  }
+}
 
 template <int W>
 __device__ __forceinline__ void k3_mfma_tile(const double* ldsb, int lrow, int lcol, v4d* acc) {
@@ -433,10 +444,41 @@ __device__ __forceinline__ void k3_mfma_tile(const double* ldsb, int lrow, int l
 // MFMA between every ~9 VALU ops (tried with sched_barrier) cannot hide phase A and only made this kernel slower.
 // One loop iteration is therefore ~3800 cycles of MFMA tile (50 x 64 + LDS operand reads) + ~1500 of phase A + ~800 of
 // stores / address math / waits = ~6100 cycles (s_memtime stamps, scripts/dbg_timeline.py).
+// Mixed precision: f32 products on v_mfma_f32_16x16x4_f32 (32 cycles per instruction instead of 64), summed in f32 over the
+// <= 9 batches (<= 72 voxels) of ONE wave, then carried in f64 through the workgroup epilogue, the cross-workgroup
+// reduction and the all-reduce -- "fp32 Jacobian, fp64 Hessian accumulation".  (Flushing to f64 after every batch was
+// measured first: the 80 extra f64 accumulators no longer live in the MFMA's own AGPRs and the copies ate the whole gain.)
+// The f32 instruction leaves D(4 (l/16) + r, l % 16) in register r of lane l, the f64 one D((l/16) + 4 r, l % 16); feeding
+// the A operand with the rows permuted by  m -> (m >> 2) + 4 (m & 3)  makes the two maps coincide, so the epilogue and the
+// cross-workgroup reduction are shared with the f64 path.
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int W>
+__device__ __forceinline__ void k3_mfma_tile_f32(const float* ldsb, int lrow, int lcol, v4f* af) {
+  using C = K3Cfg<W>;
+  const int pcol = (lcol >> 2) + 4 * (lcol & 3);
+#pragma unroll
+  for (int kk = 0; kk < C::KSTEPS; kk++) {
+    float xa[C::NT], xb[C::NT];
+#pragma unroll
+    for (int c = 0; c < C::NT; c++) {
+      xb[c] = ldsb[(4 * kk + lrow) * C::RS + 16 * c + lcol];
+      xa[c] = ldsb[(4 * kk + lrow) * C::RS + 16 * c + pcol];
+    }
+    int t = 0;
+#pragma unroll
+    for (int I = 0; I < C::NT; I++)
+#pragma unroll
+      for (int J = I; J < C::NT; J++) {
+        af[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[I], xb[J], af[t], 0, 0, 0);
+        t++;
+      }
+  }
+}
+
 // Also tried and rejected: the contraction on the VALU instead (one lane per 6x6 frame-pair block, exact upper
 // triangle, 36 FMAs per row).  It needs 12 LDS doubles per 36 FMAs -- 216 doubles per lane and batch against the
 // MFMA form's 20 -- and ran LDS-bandwidth-bound at 45.8 us vs 32-33 us: the matrix core's operand reuse wins.
-template <int W, bool DBG = false>
+template <int W, bool DBG = false, bool MIXED = false>
 __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c_in,
                                                                  LMPending pend, int head, int end, double* __restrict__ partial) {
   using C = K3Cfg<W>;
@@ -450,6 +492,9 @@ __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, 
   v4d acc[C::NTP];
 #pragma unroll
   for (int t = 0; t < C::NTP; t++) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  v4f af[MIXED ? C::NTP : 1];   // mixed precision: the wave's f32 accumulators, widened into acc after the last batch
+#pragma unroll
+  for (int t = 0; t < (MIXED ? C::NTP : 1); t++) af[t] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
   double dacc[DACC];
 #pragma unroll
   for (int k = 0; k < DACC; k++) dacc[k] = 0.0;
@@ -521,7 +566,7 @@ __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, 
     double* lds1 = ldsw + C::WAVE_LDS;
     if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 1); }
     k3_phase_a(e0, fi, R, p, rows, dacc);
-    k3_store_rows<W>(lds0, active, vl, fi, rows);
+    if (MIXED) k3_store_rows_f32<W>((float*)lds0, active, vl, fi, rows); else k3_store_rows<W>(lds0, active, vl, fi, rows);
     __builtin_amdgcn_wave_barrier();
     if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 2); }
     int pending = 0;   // LDS buffer holding the rows whose MFMAs are still to run
@@ -532,11 +577,11 @@ __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, 
       // batch b sits in e1: prefetch b + nw into e0, MFMAs of the previous batch (lds0), phase A of b -> lds1
       k3_load_entry<W>(fv, head, end, b1, b + nw, active, vl, lane, e0);
       if (DBG && it_dbg == 3) { __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 28); __builtin_amdgcn_sched_barrier(0); }
-      k3_mfma_tile<W>(lds0, lrow, lcol, acc);
+      if (MIXED) k3_mfma_tile_f32<W>((const float*)lds0, lrow, lcol, af); else k3_mfma_tile<W>(lds0, lrow, lcol, acc);
       if (DBG && it_dbg == 3) { __builtin_amdgcn_sched_barrier(0); asm volatile("" :: "v"(acc[0][0]), "v"(acc[9][3])); asm volatile("s_nop 0" ::: "memory"); dbg_stamp(true, gw, 29); __builtin_amdgcn_sched_barrier(0); }
       k3_phase_a(e1, fi, R, p, rows, dacc);
       if (DBG && it_dbg == 3) { __builtin_amdgcn_sched_barrier(0); asm volatile("" :: "v"(rows[0][0]), "v"(rows[2][5]), "v"(dacc[26])); dbg_stamp(true, gw, 30); __builtin_amdgcn_sched_barrier(0); }
-      k3_store_rows<W>(lds1, active, vl, fi, rows);
+      if (MIXED) k3_store_rows_f32<W>((float*)lds1, active, vl, fi, rows); else k3_store_rows<W>(lds1, active, vl, fi, rows);
       __builtin_amdgcn_wave_barrier();
       if (DBG && it_dbg == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 31); }
       b += nw;
@@ -545,15 +590,23 @@ __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, 
       if (DBG && it_dbg < 10) { dbg_stamp(true, gw, 8 + 2 * it_dbg); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 9 + 2 * it_dbg); it_dbg++; }
       // batch b sits in e0: prefetch into e1, MFMAs of lds1, phase A -> lds0
       k3_load_entry<W>(fv, head, end, b1, b + nw, active, vl, lane, e1);
-      k3_mfma_tile<W>(lds1, lrow, lcol, acc);
+      if (MIXED) k3_mfma_tile_f32<W>((const float*)lds1, lrow, lcol, af); else k3_mfma_tile<W>(lds1, lrow, lcol, acc);
       k3_phase_a(e0, fi, R, p, rows, dacc);
-      k3_store_rows<W>(lds0, active, vl, fi, rows);
+      if (MIXED) k3_store_rows_f32<W>((float*)lds0, active, vl, fi, rows); else k3_store_rows<W>(lds0, active, vl, fi, rows);
       __builtin_amdgcn_wave_barrier();
       b += nw;
       pending = 0;
     }
-    if (pending) k3_mfma_tile<W>(lds1, lrow, lcol, acc);
-    else k3_mfma_tile<W>(lds0, lrow, lcol, acc);
+    double* ldsl = pending ? lds1 : lds0;
+    if (MIXED) {
+      k3_mfma_tile_f32<W>((const float*)ldsl, lrow, lcol, af);
+#pragma unroll
+      for (int t = 0; t < C::NTP; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[t][r] = (double)af[t][r];
+    } else {
+      k3_mfma_tile<W>(ldsl, lrow, lcol, acc);
+    }
     if (DBG) { asm volatile("" :: "v"(acc[0][0])); dbg_stamp(true, gw, 3); }
   }
 
@@ -1158,7 +1211,7 @@ void launch_seed_aux(const FactorView& fv, int head, int end, hipStream_t s) {
 int k3_grid_blocks(int device_cus) { return device_cus; }  // one 4-wave workgroup per CU = one wave per SIMD (the kernel needs > 256 VGPRs)
 
 int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, LMState* st, int c_in, const LMPending& pend, const double* cache_src,
-                      int head, int end, double* d_partial, int nblocks, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                      int head, int end, double* d_partial, int nblocks, int mixed, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   FactorView fv = fv_in;
   if (cache_src) {   // eigval(3) eigvec(9) merged(10) aux(4): 26 consecutive planes
     const size_t VS = (size_t)fv.VS;
@@ -1175,11 +1228,17 @@ int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, LMState* st
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)k3_hessian_kernel<WW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       (void)hipFuncSetAttribute((const void*)k3_hessian_kernel<WW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      (void)hipFuncSetAttribute((const void*)k3_hessian_kernel<WW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       const char* ev = getenv("VXBA_DBG");
       dbg = (ev && ev[0] == '1') ? 1 : 0;
       attr_set = true;
     }
-    if (dbg) k3_hessian_kernel<WW, true><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, st, c_in, pend, head, end, d_partial);
+    if (mixed) {
+      if (ev_start)
+        hipExtLaunchKernelGGL((k3_hessian_kernel<WW, false, true>), dim3(nblocks), dim3(K3_BLOCK), (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, fv, poses, st, c_in,
+                              pend, head, end, d_partial);
+      else k3_hessian_kernel<WW, false, true><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, st, c_in, pend, head, end, d_partial);
+    } else if (dbg) k3_hessian_kernel<WW, true><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, st, c_in, pend, head, end, d_partial);
     else if (ev_start)
       hipExtLaunchKernelGGL((k3_hessian_kernel<WW, false>), dim3(nblocks), dim3(K3_BLOCK), (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, fv, poses, st, c_in, pend, head,
                             end, d_partial);

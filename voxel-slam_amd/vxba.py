@@ -31,7 +31,7 @@ EXPORTS = [
     "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_plane_fit_judge", "vxba_build_clusters", "vxba_set_allreduce",
     "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_detach", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps",
     "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_li_evaluate",
-    "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity", "vxba_voxelize_push",
+    "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity", "vxba_voxelize_push", "vxba_set_precision",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -100,6 +100,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_damping_iter_generic.argtypes = [ci, _f64p, ci, _HESS_FN, _RESID_FN, vp, _f64p, _f64p, _f64p, C.POINTER(ci), C.POINTER(ci)]
     L.vxba_lm_steps.argtypes = [vp, _f64p, ci, ci, _f64p, _f64p, _i64p]
     L.vxba_set_profiling.argtypes = [vp, ci]
+    L.vxba_set_precision.argtypes = [vp, ci]
     L.vxba_get_kernel_times.argtypes = [vp, _f64p, _i64p, ci]
     L.vxba_algorithmic_bytes.argtypes = [vp, _f64p]
     L.vxba_nnz.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -304,6 +305,10 @@ class LidarFactor:
         self._chk(self._L.vxba_use_external_buffers(self._h, C.c_void_p(d_packed_ptr or 0), C.c_void_p(d_scalar_ptr or 0)))
 
     # -- measurement ----------------------------------------------------------------------------
+    def set_precision(self, mode: str):
+        """'f64' (default) or 'mixed' (f32 products on the matrix cores, f64 accumulation; BASELINE configs[2])."""
+        self._chk(self._L.vxba_set_precision(self._h, {"f64": 0, "mixed": 1}[mode]))
+
     def set_profiling(self, mask: int):
         """Bit mask of kernels to time with events: 1 K3, 2 K2, 4 K3 finalize, 8 K1 (0 = off)."""
         self._chk(self._L.vxba_set_profiling(self._h, int(mask)))
