@@ -475,6 +475,10 @@ __device__ __forceinline__ void k3_mfma_tile_f32(const float* ldsb, int lrow, in
   }
 }
 
+// Tried and rejected: stacking the rows of TWO batches in one tile so that the K padding (18 -> 20 rows at W = 10) is paid
+// once per pair (36 rows = 9 K-steps instead of 2 x 5, 10 % fewer MFMAs).  Correct, but 37.5 us instead of 34.8: with both
+// entry register sets, the rows and the 28 linear accumulators live across the longer MFMA phase the allocator shuttles
+// ~650 values through AGPRs per pair, which costs more than the 10 MFMAs save.
 // Also tried and rejected: the contraction on the VALU instead (one lane per 6x6 frame-pair block, exact upper
 // triangle, 36 FMAs per row).  It needs 12 LDS doubles per 36 FMAs -- 216 doubles per lane and batch against the
 // MFMA form's 20 -- and ran LDS-bandwidth-bound at 45.8 us vs 32-33 us: the matrix core's operand reuse wins.
