@@ -107,7 +107,18 @@ def main():
         if args.hook_allreduce:
             _keep = vdist.attach_allreduce(f)              # exchange buffers become torch tensors, collective via a host hook
         else:
-            vdist.attach_rccl(f)                           # ncclAllReduce issued directly from the C++ loop
+            try:
+                vdist.attach_rccl(f)                       # ncclAllReduce issued directly from the C++ loop
+                ok = 1
+            except Exception as exc:                       # noqa: BLE001 -- any failure here must not take the other ranks down
+                print(f"[bench rank {rank}] direct RCCL attach failed ({exc}); using the torch.distributed hook", file=sys.stderr)
+                ok = 0
+            okt = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)     # all ranks take the same path
+            if int(okt.item()) == 0:
+                if ok:
+                    f.rccl_detach()
+                _keep = vdist.attach_allreduce(f)
     f.set_precision(args.precision)
     f.evaluate_only_residual(sc.poses_init)                # seeds the (lambda, U, merged) cache (recut's eig)
     f.snapshot_cache()
