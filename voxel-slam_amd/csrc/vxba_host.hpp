@@ -2,6 +2,9 @@
 // Lidar_BA_Optimizer::damping_iter (voxel_map.hpp:367-442): gauge fix, damped solve, trial-state update,
 // gain ratio and damping schedule.  Dense math on (6W)^2 systems, W <= 10 -> 60x60.
 #pragma once
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -22,6 +25,58 @@ inline double dot4(const double* a, const double* b, int n) {
   for (; j < n; ++j) s0 += a[j] * b[j];
   return (s0 + s1) + (s2 + s3);
 }
+#if defined(__x86_64__)
+// The library is built for baseline x86-64 (like the reference, VoxelSLAM/CMakeLists.txt: no -march); the one hot host loop
+// -- the inner product of the 15W-dimensional LDL^T -- gets an AVX2/FMA body chosen at run time.
+__attribute__((target("avx2,fma"))) inline double dot_avx2(const double* a, const double* b, int n) {
+  __m256d s0 = _mm256_setzero_pd(), s1 = _mm256_setzero_pd();
+  int j = 0;
+  for (; j + 7 < n; j += 8) {
+    s0 = _mm256_fmadd_pd(_mm256_loadu_pd(a + j), _mm256_loadu_pd(b + j), s0);
+    s1 = _mm256_fmadd_pd(_mm256_loadu_pd(a + j + 4), _mm256_loadu_pd(b + j + 4), s1);
+  }
+  for (; j + 3 < n; j += 4) s0 = _mm256_fmadd_pd(_mm256_loadu_pd(a + j), _mm256_loadu_pd(b + j), s0);
+  s0 = _mm256_add_pd(s0, s1);
+  double t[4];
+  _mm256_storeu_pd(t, s0);
+  double s = (t[0] + t[1]) + (t[2] + t[3]);
+  for (; j < n; ++j) s += a[j] * b[j];
+  return s;
+}
+inline bool cpu_has_avx2_fma() {
+  static const bool has = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+  return has;
+}
+// four inner products against the same vector (rows r0 .. r0+3 of a row-major matrix with leading dimension ld)
+__attribute__((target("avx2,fma"))) inline void dot4rows_avx2(const double* r0, size_t ld, const double* w, int n, double out[4]) {
+  __m256d s0 = _mm256_setzero_pd(), s1 = _mm256_setzero_pd(), s2 = _mm256_setzero_pd(), s3 = _mm256_setzero_pd();
+  const double *a0 = r0, *a1 = r0 + ld, *a2 = r0 + 2 * ld, *a3 = r0 + 3 * ld;
+  int j = 0;
+  for (; j + 3 < n; j += 4) {
+    const __m256d wv = _mm256_loadu_pd(w + j);
+    s0 = _mm256_fmadd_pd(_mm256_loadu_pd(a0 + j), wv, s0);
+    s1 = _mm256_fmadd_pd(_mm256_loadu_pd(a1 + j), wv, s1);
+    s2 = _mm256_fmadd_pd(_mm256_loadu_pd(a2 + j), wv, s2);
+    s3 = _mm256_fmadd_pd(_mm256_loadu_pd(a3 + j), wv, s3);
+  }
+  double t[4];
+  _mm256_storeu_pd(t, s0); out[0] = (t[0] + t[1]) + (t[2] + t[3]);
+  _mm256_storeu_pd(t, s1); out[1] = (t[0] + t[1]) + (t[2] + t[3]);
+  _mm256_storeu_pd(t, s2); out[2] = (t[0] + t[1]) + (t[2] + t[3]);
+  _mm256_storeu_pd(t, s3); out[3] = (t[0] + t[1]) + (t[2] + t[3]);
+  for (; j < n; ++j) { out[0] += a0[j] * w[j]; out[1] += a1[j] * w[j]; out[2] += a2[j] * w[j]; out[3] += a3[j] * w[j]; }
+}
+inline double dotp(const double* a, const double* b, int n) { return cpu_has_avx2_fma() ? dot_avx2(a, b, n) : dot4(a, b, n); }
+inline void dot4rows(const double* r0, size_t ld, const double* w, int n, double out[4]) {
+  if (cpu_has_avx2_fma()) { dot4rows_avx2(r0, ld, w, n, out); return; }
+  for (int q = 0; q < 4; q++) out[q] = dot4(r0 + q * ld, w, n);
+}
+#else
+inline double dotp(const double* a, const double* b, int n) { return dot4(a, b, n); }
+inline void dot4rows(const double* r0, size_t ld, const double* w, int n, double out[4]) {
+  for (int q = 0; q < 4; q++) out[q] = dot4(r0 + q * ld, w, n);
+}
+#endif
 inline void ldlt_solve_inplace(int n, double* A, const double* b, double* x, int* perm, double* work) {
   auto at = [&](int r, int c) -> double& { return A[(size_t)r * n + c]; };   // (r, c) with r >= c; row r is contiguous
   for (int k = 0; k < n; ++k) {
@@ -40,17 +95,23 @@ inline void ldlt_solve_inplace(int n, double* A, const double* b, double* x, int
     }
     const double* rk = &at(k, 0);
     for (int j = 0; j < k; ++j) work[j] = at(j, j) * rk[j];
-    const double d = at(k, k) - dot4(rk, work, k);
+    const double d = at(k, k) - dotp(rk, work, k);
     at(k, k) = d;
     const bool nz = std::fabs(d) > 0.0;
-    for (int i = k + 1; i < n; ++i) {
-      const double s = at(i, k) - dot4(&at(i, 0), work, k);
+    int i = k + 1;
+    for (; i + 3 < n; i += 4) {   // four rows share the loads of `work`
+      double dots[4];
+      dot4rows(&at(i, 0), (size_t)n, work, k, dots);
+      for (int q = 0; q < 4; q++) { const double s = at(i + q, k) - dots[q]; at(i + q, k) = nz ? s / d : s; }
+    }
+    for (; i < n; ++i) {
+      const double s = at(i, k) - dotp(&at(i, 0), work, k);
       at(i, k) = nz ? s / d : s;
     }
   }
   for (int i = 0; i < n; ++i) x[i] = b[i];
   for (int k = 0; k < n; ++k) std::swap(x[k], x[perm[k]]);
-  for (int i = 0; i < n; ++i) x[i] -= dot4(&at(i, 0), x, i);
+  for (int i = 0; i < n; ++i) x[i] -= dotp(&at(i, 0), x, i);
   const double tol = 1.0 / std::numeric_limits<double>::max();
   for (int i = 0; i < n; ++i) x[i] = (std::fabs(at(i, i)) > tol) ? x[i] / at(i, i) : 0.0;
   for (int i = n - 1; i >= 0; --i) {          // L^T x = y, column-oriented so that row i of L is read contiguously
