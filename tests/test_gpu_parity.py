@@ -456,3 +456,79 @@ def test_mixed_precision_lm_meets_the_pose_tolerance(vx):
     assert et < 1e-6 and er < 1e-6, (et, er)
     e0 = synth.pose_errors(sc.poses_init, sc.poses_gt); e1 = synth.pose_errors(got["poses"], sc.poses_gt)
     assert e1[0] < 0.2 * e0[0]
+
+
+def test_two_voxel_shards_with_a_real_cross_shard_sum(vx):
+    """The N > 1 device-resident loop with N = 2 on ONE GPU: two factors hold the two halves of the window's voxels, run
+    Lidar_BA_Optimizer::damping_iter concurrently (one host thread and one stream each), and the all-reduce hook really adds
+    the two exchange buffers.  Each 'rank' must take the same steps as the oracle on the whole window -- which only works if
+    the solve reads the REDUCED system, the decision the reduced residual, and skipped sweeps do not corrupt the state."""
+    import threading
+    import torch
+    # far enough from the optimum that the schedule contains rejected steps as well
+    sc = synth.make_scene(win_size=10, pts_per_scan=40_000, n_voxels=3000, p_obs=0.8, fix_frac=0.1, seed=31337, rot_sigma_deg=0.6, trans_sigma=0.15)
+    fo = O.Oracle(sc.win_size)
+    fo.push_voxels(sc.clusters, sc.fix, sc.coe)
+    fo.evaluate_only_residual(sc.poses_init)
+    iters = 8
+    ref = fo.damping_iter(sc.poses_init, max_iter=iters, thd_num=4)
+    cut = sc.n_voxels // 2 + 7
+    parts = [(0, cut), (cut, sc.n_voxels)]
+    facs, bufs, streams = [], [], []
+    for lo, hi in parts:
+        f = vx.LidarFactor(sc.win_size)
+        f.push_voxels(sc.clusters[lo:hi], sc.fix[lo:hi], sc.coe[lo:hi])
+        f.evaluate_only_residual(sc.poses_init)
+        st = torch.cuda.Stream()
+        f.set_stream(st.cuda_stream)
+        n = f.packed_len()
+        xb = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+        f.use_external_buffers(xb[:n].data_ptr(), xb[n:].data_ptr())
+        facs.append(f); bufs.append((xb[:n], xb[n:], xb)); streams.append(st)
+    barrier = threading.Barrier(2, timeout=120)
+    tmp = [None, None]
+    calls = [0, 0]
+
+    def make_hook(k):
+        def hook(_ptr, count, _stream):
+            which = 0 if count > 1 else 1
+            torch.cuda.synchronize()                 # my share is complete
+            barrier.wait()
+            tmp[k] = bufs[0][which] + bufs[1][which]  # same operand order on both ranks: identical bits
+            torch.cuda.synchronize()
+            barrier.wait()                           # both sums taken before anybody overwrites an operand
+            bufs[k][which].copy_(tmp[k])
+            torch.cuda.synchronize()
+            calls[k] += 1
+        return hook
+
+    out = [None, None]
+    errs = []
+
+    def run(k):
+        try:
+            facs[k].set_allreduce(make_hook(k))
+            out[k] = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, facs[k], max_iter=iters)
+        except Exception as exc:      # noqa: BLE001
+            errs.append(exc)
+            barrier.abort()
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    a, b = out
+    assert 0 in ref["trace"][:, 6]                                    # the schedule really contains a rejected step
+    assert np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["trace"], b["trace"])   # the ranks stay in lockstep, bit for bit
+    assert np.array_equal(a["hess"], b["hess"])
+    assert a["trace"].shape == ref["trace"].shape and np.array_equal(a["trace"][:, 6:], ref["trace"][:, 6:])
+    assert np.allclose(a["trace"][:, :2], ref["trace"][:, :2], rtol=1e-9)
+    assert relerr(a["hess"], ref["hess"]) < 1e-9
+    et, er = synth.pose_errors(a["poses"], ref["poses"])
+    assert et < 1e-7 and er < 1e-7, (et, er)
+    assert calls[0] == calls[1] >= 2 * a["trace"].shape[0]
+    for f in facs:
+        f.set_allreduce(None)
+        f.use_external_buffers(None, None)

@@ -248,10 +248,14 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c
   }
   {
     ScopedKernelTimer t(f, 2);
-    vxk::launch_k3_finalize(f->d_partial3, nblocks, f->W, lm, c_now, d_out, f->stream);
+    // with a collective the LM state is filled after the all-reduce, from the reduced buffer
+    vxk::launch_k3_finalize(f->d_partial3, nblocks, f->W, lm, c_now, has_collective(f) ? 0 : 1, d_out, f->stream);
   }
   VX_HIP(f, hipGetLastError());
-  return shard_allreduce(f, d_out, plen);
+  rc = shard_allreduce(f, d_out, plen);
+  if (rc) return rc;
+  if (lm && has_collective(f)) vxk::launch_lm_unpack(lm, c_now, d_out, f->W, f->stream);
+  return VXBA_OK;
 }
 
 int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int c, int head, int end, double* d_out,

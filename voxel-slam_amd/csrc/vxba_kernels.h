@@ -112,7 +112,10 @@ int launch_k3_hessian(const FactorView& fv, const PoseArg& poses, LMState* st, i
                       int head, int end, double* d_partial, int nblocks, int mixed, hipStream_t s, hipEvent_t ev_start = nullptr,
                       hipEvent_t ev_stop = nullptr);
 // Cross-workgroup reduction + assembly of the packed [Hess (6W)^2 col-major | JacT 6W | residual] buffer.
-void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, double* d_packed, hipStream_t s);
+void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, int write_state, double* d_packed, hipStream_t s);
+// Voxel-sharded LM loop: fill the LM state (Hwork, Jwork, hess_out, residual1) from the ALL-REDUCED packed buffer (write_state
+// = 0 above); gated on the state's flags like the sweep itself.
+void launch_lm_unpack(LMState* st, int c, const double* d_packed, int W, hipStream_t s);
 
 // LM shell on the device: init (poses, damping, flags into ctl[0]), damped solve + trial state on ctl[c], and the
 // stand-alone decision kernel that closes the loop (ctl[c_in] -> ctl[c_in ^ 1]).

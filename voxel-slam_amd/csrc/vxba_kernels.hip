@@ -664,7 +664,7 @@ __device__ __forceinline__ int sym6_index(int a, int b) { return a == 0 ? b : (a
 constexpr int FIN_EL = 16, FIN_SL = 64;   // FIN_EL * FIN_SL == 1024 threads
 template <int W>
 __global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restrict__ partial, int nblocks, LMState* __restrict__ gate, int cb,
-                                                           double* __restrict__ packed) {
+                                                           int write_state, double* __restrict__ packed) {
   using C = K3Cfg<W>;
   // LM flags: requested now (vector loads: lane-dependent zero offset), tested after the partials are in flight
   const int zoff = threadIdx.x >> 30;
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restr
     for (int k = 0; k < 8; k++) { t0 += mid0[k][el]; t1 += mid1[k][el]; }
     if (lin >= 0) {
       packed[lin] = t0;
-      if (gate) {   // LM state: gauge-fixed gradient (voxel_map.hpp:400), residual1 (:388)
+      if (gate && write_state) {   // LM state: gauge-fixed gradient (voxel_map.hpp:400), residual1 (:388)
         if (lin < n * n + n) gate->Jwork[lin - n * n] = (lin - n * n < 6) ? 0.0 : t0;
         else { gate->ctl[cb].residual1 = t0; if (gate->ctl[cb].iter == 0) gate->ctl[cb].resis[0] = t0; }
       }
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restr
       const double h = t1 - t0;
       packed[(size_t)c * n + r] = h;
       packed[(size_t)r * n + c] = h;
-      if (gate) {   // LM state: *hess = Hess before the gauge fix (:391) and the gauge-fixed working copy (:397-400)
+      if (gate && write_state) {   // LM state: *hess = Hess before the gauge fix (:391) and the gauge-fixed working copy (:397-400)
         gate->hess_out[(size_t)c * n + r] = h;
         gate->hess_out[(size_t)r * n + c] = h;
         const double hw = (r < 6 || c < 6) ? ((r == c) ? 1.0 : 0.0) : h;
@@ -768,6 +768,27 @@ __global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restr
         gate->Hwork[(size_t)r * n + c] = hw;
       }
     }
+  }
+}
+
+// Voxel-sharded runs: k3_finalize only produced this rank's share of the packed buffer; after the all-reduce the LM state
+// (what the solve reads) is filled from the REDUCED buffer here.  Gated like the sweep itself: when the sweep was skipped
+// (rejected step, loop done) the buffer holds stale data that has just been summed again -- and is ignored.
+__global__ __launch_bounds__(256) void lm_unpack_kernel(LMState* __restrict__ st, int cb, const double* __restrict__ packed, int n) {
+  if (st->ctl[cb].done || !st->ctl[cb].calc_hess) return;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n * n) {
+    const int r = e % n, c = e / n;
+    const double h = packed[e];
+    st->hess_out[e] = h;
+    st->Hwork[e] = (r < 6 || c < 6) ? ((r == c) ? 1.0 : 0.0) : h;
+  } else if (e < n * n + n) {
+    const int i = e - n * n;
+    st->Jwork[i] = i < 6 ? 0.0 : packed[e];
+  } else if (e == n * n + n) {
+    const double t0 = packed[e];
+    st->ctl[cb].residual1 = t0;
+    if (st->ctl[cb].iter == 0) st->ctl[cb].resis[0] = t0;
   }
 }
 
@@ -1251,9 +1272,13 @@ int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, LMState* st
   return nblocks;
 }
 
-void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, double* d_packed, hipStream_t s) {
+void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, int write_state, double* d_packed, hipStream_t s) {
   const int plen = (int)k3_partial_len(W);
-  VXK_DISPATCH_W(W, k3_finalize_kernel<WW><<<dim3((plen + FIN_EL - 1) / FIN_EL), dim3(FIN_EL * FIN_SL), 0, s>>>(d_partial, nblocks, st, c, d_packed));
+  VXK_DISPATCH_W(W, k3_finalize_kernel<WW><<<dim3((plen + FIN_EL - 1) / FIN_EL), dim3(FIN_EL * FIN_SL), 0, s>>>(d_partial, nblocks, st, c, write_state, d_packed));
+}
+void launch_lm_unpack(LMState* st, int c, const double* d_packed, int W, hipStream_t s) {
+  const int n = 6 * W, total = n * n + n + 1;
+  lm_unpack_kernel<<<dim3((total + 255) / 256), dim3(256), 0, s>>>(st, c, d_packed, n);
 }
 
 void launch_k1_build(const double* d_xyz, const int64_t* d_cell_ptr, int n_voxels, int W, const FactorView& fv, int v0, hipStream_t s) {
