@@ -1,0 +1,50 @@
+"""One hierarchical-BA window (HBA_add_edge's loop, voxelslam.cpp:2320-2430) end to end: GPU path vs the same schedule on
+the CPU oracle, from raw scans and perturbed keyframe poses to refined poses and pose-graph edge weights."""
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+from voxel_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+class _OracleOpt:
+    def damping_iter(self, xs, f, max_iter=4):
+        return f.damping_iter(xs, max_iter=max_iter, thd_num=4)
+
+
+def _oracle_voxelize(W):
+    def go(xyz, fp, xs, params):
+        r = O.voxelize(W, xyz, fp, xs, params.as_array())
+        f = O.Oracle(W)
+        n = r["node_id"].size
+        # the GPU pushes layer by layer, ascending id inside a layer: same order here, so both LM runs sum in the same voxel order
+        order = np.lexsort((r["node_id"], (r["node_id"] & np.uint64(7)).astype(np.int64)))
+        f.push_voxels(r["clusters"][order], np.zeros((n, 10)), np.ones(n), r["eig_val"][order], r["eig_vec"][order], r["merged"][order])
+        return f, n
+    return go
+
+
+def test_hba_window_matches_oracle_schedule_and_recovers_poses():
+    from voxel_slam_amd import hba, vxba
+    W = 10
+    xyz, fp, poses, gt = synth.make_scans(win_size=W, pts_per_scan=30_000, extent=24.0, noise=0.005, seed=synth.MASTER_SEED + 900,
+                                          rot_sigma_deg=0.15, trans_sigma=0.03)
+    coarse = vxba.VoxelizeParams(voxel_size=2.0, max_layer=2, min_points=10, min_eigen_value=0.02, eigen_ratio=(1 / 9, 1 / 9, 1 / 9, 1 / 9))
+    fine = vxba.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
+    got = hba.window_refine(xyz, fp, poses, coarse, fine, max_iter=6)
+    ref = hba.window_refine(xyz, fp, poses, coarse, fine, max_iter=6, optimizer=_OracleOpt(), voxelize=_oracle_voxelize(W))
+    assert len(got["rounds"]) == len(ref["rounds"]) >= 2
+    for a, b in zip(got["rounds"], ref["rounds"]):
+        assert a["n_voxels"] == b["n_voxels"] and a["fine"] == b["fine"] and a["converged"] == b["converged"]
+        assert np.allclose(a["resis"], b["resis"], rtol=1e-7)
+    assert got["rounds"][-1]["fine"]                                   # the last round runs with the odometry's parameters
+    et, er = synth.pose_errors(got["poses"], ref["poses"])
+    assert et < 1e-6 and er < 1e-6, (et, er)                           # several re-voxelisations deep; contract 1e-4
+    e0 = synth.pose_errors(poses, gt); e1 = synth.pose_errors(got["poses"], gt)
+    assert e1[0] < 0.2 * e0[0] and e1[1] < 0.2 * e0[1]
+    ge = hba.edges_from_hessian(got["poses"], got["hess"]); re_ = hba.edges_from_hessian(ref["poses"], ref["hess"])
+    assert len(ge) == len(re_) > 0
+    for a, b in zip(ge, re_):
+        assert (a["i"], a["j"]) == (b["i"], b["j"]) and np.allclose(a["v6"], b["v6"], rtol=1e-5) and np.allclose(a["tra"], b["tra"], atol=1e-6)

@@ -1,0 +1,61 @@
+"""One window of the hierarchical / global BA (reference: ``HBA_add_edge``, voxelslam.cpp:2320-2430) on top of the C ABI:
+repeat { re-voxelise the window's scans at the current poses (OctreeGBA::cut_voxel + recut -> vxba_voxelize_push), run
+Lidar_BA_Optimizer::damping_iter with up to 4 iterations } with the reference's convergence schedule (coarse voxel
+parameters first, the odometry's finer ones for the last round), then turn the off-diagonal 6x6 blocks of the final Hessian
+into pose-graph edge weights.  Host orchestration only -- the per-round work (hashing, octree, plane tests, sweeps, solve)
+runs on the GPU; this file is the harness-level mirror used by the tests and as an integration example (config 5's bottom
+level: windows of 10 keyframes; the top level needs W > VXBA_MAX_WIN and is not covered)."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import vxba
+
+
+def window_refine(xyz_local, frame_ptr, poses, coarse: "vxba.VoxelizeParams", fine: "vxba.VoxelizeParams", max_iter: int = 10, up: int = 4,
+                  device: int = 0, factor_cls=None, optimizer=None, voxelize=None):
+    """Returns dict(poses, hess, rounds, n_voxels, resis).  ``factor_cls`` / ``optimizer`` / ``voxelize`` let the tests run the
+    same schedule on the CPU oracle (defaults: the GPU path)."""
+    W = poses.shape[0]
+    xs = np.ascontiguousarray(poses, dtype=np.float64).copy()
+    converge_flag, converge_thre = 0, 0.05
+    hess = None
+    log = []
+    for it in range(max_iter):
+        params = fine if (converge_flag == 1 or it == max_iter - 1) else coarse          # voxelslam.cpp:2362-2372
+        if voxelize is None:
+            f = vxba.LidarFactor(W, device=device) if factor_cls is None else factor_cls(W)
+            n_vox = f.voxelize_push(xyz_local, frame_ptr, xs, params, want_ids=False)
+        else:
+            f, n_vox = voxelize(xyz_local, frame_ptr, xs, params)
+        opt = vxba.Lidar_BA_Optimizer() if optimizer is None else optimizer
+        out = opt.damping_iter(xs, f, max_iter=up)
+        xs = out["poses"]
+        hess = out["hess"]
+        r0, r1 = out["resis"]
+        log.append(dict(round=it, n_voxels=int(n_vox), resis=(float(r0), float(r1)), converged=bool(out["is_converge"]), fine=params is fine))
+        if hasattr(f, "close"):
+            f.close()
+        if (abs(r0 - r1) / r0 < converge_thre and out["is_converge"]) or (it == max_iter - 2 and converge_flag == 0):   # :2387-2398
+            converge_thre = 0.01
+            if converge_flag == 0:
+                converge_flag = 1
+            elif converge_flag == 1:
+                break
+    return dict(poses=xs, hess=hess, rounds=log)
+
+
+def edges_from_hessian(poses, hess, min_abs: float = 1e-6):
+    """Pose-graph edges of a refined window (voxelslam.cpp:2405-2427): for every frame pair whose six Hessian entries
+    hess(6i+k, 6j+k) all exceed ``min_abs`` in magnitude, the relative pose and the weights v6 = 1 / |hess(6i+k, 6j+k)|."""
+    W = poses.shape[0]
+    R = poses[:, :9].reshape(W, 3, 3).transpose(0, 2, 1)
+    p = poses[:, 9:12]
+    out = []
+    for i in range(W - 1):
+        for j in range(i + 1, W):
+            hc = np.abs(np.array([hess[6 * i + k, 6 * j + k] for k in range(6)]))
+            if np.any(hc < min_abs):
+                continue
+            out.append(dict(i=i, j=j, rot=R[i].T @ R[j], tra=R[i].T @ (p[j] - p[i]), v6=1.0 / hc))
+    return out
