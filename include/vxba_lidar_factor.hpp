@@ -45,7 +45,7 @@ class LidarFactorT {
   int win_size;
 
   explicit LidarFactorT(int w, int device = 0) : win_size(w) {
-    if (vxba_create(w, device, &h_) != VXBA_OK) throw std::runtime_error("vxba_create failed (needs a gfx950 GPU, win_size <= 10)");
+    if (vxba_create(w, device, &h_) != VXBA_OK) throw std::runtime_error("vxba_create failed (needs a gfx950 GPU, win_size <= 128)");
   }
   ~LidarFactorT() { vxba_destroy(h_); }
   LidarFactorT(const LidarFactorT&) = delete;

@@ -320,7 +320,7 @@ def test_cfg2_lm_matches_oracle_poses(vx, cfg2):
 # ---------------------------------------------------------------------------------------- boundary behaviour
 def test_error_conventions(vx):
     with pytest.raises(vx.VxbaError):
-        vx.LidarFactor(11)                                  # > VXBA_MAX_WIN
+        vx.LidarFactor(129)                                 # > VXBA_MAX_WIN_WIDE
     with pytest.raises(vx.VxbaError):
         vx.LidarFactor(0)
     f = vx.LidarFactor(3)

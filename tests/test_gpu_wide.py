@@ -1,0 +1,84 @@
+"""Wide windows (win_size > VXBA_MAX_WIN; the top level of the hierarchical BA optimises ~100 submap poses): the
+sparse-incidence sweeps of vxba_wide.hip and the host-side LM shell against the CPU oracle.  The Hessian is accumulated with f64
+atomics there, so agreement is to round-off (not bitwise), run to run as well."""
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+from voxel_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vx():
+    from voxel_slam_amd import vxba
+    vxba.load_library()
+    return vxba
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def pair(vx, sc):
+    fo = O.Oracle(sc.win_size); fo.push_voxels(sc.clusters, sc.fix, sc.coe); fo.evaluate_only_residual(sc.poses_init)
+    fg = vx.LidarFactor(sc.win_size); fg.push_voxels(sc.clusters, sc.fix, sc.coe); fg.evaluate_only_residual(sc.poses_init)
+    return fo, fg
+
+
+@pytest.mark.parametrize("W,V,pts,p_obs", [(11, 600, 5000, 0.5), (16, 1500, 8000, 0.3), (40, 2500, 6000, 0.1), (100, 3000, 4000, 0.04), (128, 500, 1500, 0.05), (12, 300, 6000, 1.0)])
+def test_wide_sweeps_match_oracle(vx, W, V, pts, p_obs):
+    sc = synth.make_scene(win_size=W, pts_per_scan=pts, n_voxels=V, p_obs=p_obs, fix_frac=0.2, seed=1200 + W)
+    fo, fg = pair(vx, sc)
+    assert fg.win_size == W and fg.size() == V
+    assert np.array_equal(fg.read_clusters(), sc.clusters)
+    # residual sweep + cache
+    r_o = fo.evaluate_only_residual(sc.poses_gt); r_g = fg.evaluate_only_residual(sc.poses_gt)
+    assert abs(r_g - r_o) <= 1e-10 * abs(r_o)
+    ev_o, U_o, m_o = fo.read_cache(); ev_g, U_g, m_g = fg.read_cache()
+    assert np.allclose(m_g, m_o, rtol=1e-12, atol=1e-9)
+    scale = (np.abs(m_o[:, :6]).max(axis=1) / m_o[:, 9] + 1.0)[:, None]
+    assert np.all(np.abs(ev_g - ev_o) <= 1e-13 * scale)
+    # Hessian sweep at other poses, on the cache just written
+    Ho, Jo, ro = fo.acc_evaluate2(sc.poses_init); Hg, Jg, rg = fg.acc_evaluate2(sc.poses_init)
+    assert Hg.shape == (6 * W, 6 * W) and np.array_equal(Hg, Hg.T)
+    assert relerr(Hg, Ho) < 1e-9 and relerr(Jg, Jo) < 1e-9 and abs(rg - ro) <= 1e-10 * abs(ro)
+    # sub-ranges add up; empty range is zero
+    Ha, Ja, ra = fg.acc_evaluate2(sc.poses_init, 0, V // 3); Hb, Jb, rb = fg.acc_evaluate2(sc.poses_init, V // 3, V)
+    assert relerr(Ha + Hb, Ho) < 1e-9 and abs(ra + rb - ro) <= 1e-10 * abs(ro)
+    He, Je, re_ = fg.acc_evaluate2(sc.poses_init, 5, 5)
+    assert not He.any() and not Je.any() and re_ == 0.0
+
+
+@pytest.mark.parametrize("W,V,pts,p_obs", [(24, 3000, 8000, 0.2), (64, 4000, 5000, 0.06)])
+def test_wide_lm_matches_oracle(vx, W, V, pts, p_obs):
+    sc = synth.make_scene(win_size=W, pts_per_scan=pts, n_voxels=V, p_obs=p_obs, seed=1300 + W, rot_sigma_deg=0.1, trans_sigma=0.03)
+    fo, fg = pair(vx, sc)
+    ref = fo.damping_iter(sc.poses_init, max_iter=5, thd_num=4)
+    got = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=5)
+    assert got["trace"].shape == ref["trace"].shape and np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:])
+    assert np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-9)
+    et, er = synth.pose_errors(got["poses"], ref["poses"])
+    assert et < 1e-7 and er < 1e-7, (et, er)
+    assert relerr(got["hess"], ref["hess"]) < 1e-8
+    e0 = synth.pose_errors(sc.poses_init, sc.poses_gt); e1 = synth.pose_errors(got["poses"], sc.poses_gt)
+    assert e1[0] < 0.5 * e0[0]
+
+
+def test_wide_voxelize_and_unsupported_entry_points(vx):
+    W = 20
+    xyz, fp, poses, gt = synth.make_scans(win_size=W, pts_per_scan=6000, seed=synth.MASTER_SEED + 1400)
+    P = vx.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
+    ref = O.voxelize(W, xyz, fp, poses, P.as_array())
+    f = vx.LidarFactor(W)
+    ids = f.voxelize_push(xyz, fp, poses, P)
+    order = np.argsort(ids, kind="stable")
+    assert np.array_equal(ids[order], ref["node_id"]) and ids.size > 100
+    assert np.array_equal(f.read_clusters()[order], ref["clusters"])
+    with pytest.raises(vx.VxbaError, match="win_size"):
+        f.lm_steps(poses, 3)
+    with pytest.raises(vx.VxbaError, match="win_size"):
+        f.set_precision("mixed")
+    with pytest.raises(vx.VxbaError):
+        vx.LidarFactor(129)

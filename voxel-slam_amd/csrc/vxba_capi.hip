@@ -17,6 +17,7 @@
 #include "vxba_host.hpp"
 #include "vxba_imu.hpp"
 #include "vxba_voxelize.h"
+#include "vxba_wide.h"
 #include "vxba_kernels.h"
 
 using vxk::FactorView;
@@ -56,6 +57,9 @@ struct vxba_factor {
   double* h_scalar = nullptr;    // pinned
   vxk::LMState* d_lm = nullptr;  // device-resident LM shell state
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
+  double* d_poses = nullptr;     // wide windows: W*12 poses on the device (the MFMA kernels take them by value)
+  double* h_poses = nullptr;     // pinned staging for the above
+  size_t xlen = 0;               // doubles the exchange buffers (own_packed, h_packed) hold
   int precision = 0;             // 0: fp64 throughout; 1: Hessian products in f32 on the matrix cores, f64 accumulation
   unsigned lm_seq = 0;           // sequence numbers of solves published inside residual-sweep launches (never 0)
   vxba_allreduce_fn allreduce = nullptr;
@@ -95,6 +99,26 @@ int fail(vxba_factor* f, int code, const char* msg) {
 }
 
 int n_planes(const vxba_factor* f) { return 10 * f->W + N_META_PLANES; }
+// win_size above VXBA_MAX_WIN: the sparse-incidence sweeps of vxba_wide.hip and the host-side LM shell
+bool is_wide(const vxba_factor* f) { return f->W > VXBA_MAX_WIN; }
+#define VX_NARROW_ONLY(f, what) \
+  do { if (is_wide(f)) return fail(f, VXBA_ERR_UNSUPPORTED, what ": only for win_size <= VXBA_MAX_WIN"); } while (0)
+
+// exchange buffers sized for the current win_size (packed [Hess | JacT | residual])
+int ensure_exchange(vxba_factor* f) {
+  const size_t need = (size_t)36 * f->W * f->W + 6 * f->W + 1;
+  if (need <= f->xlen) return VXBA_OK;
+  if (f->stream) VX_HIP(f, hipStreamSynchronize(f->stream));
+  const bool own = f->d_packed == f->own_packed;
+  if (f->own_packed) VX_HIP(f, hipFree(f->own_packed));
+  if (f->h_packed) VX_HIP(f, hipHostFree(f->h_packed));
+  f->own_packed = nullptr; f->h_packed = nullptr; f->xlen = 0;
+  VX_HIP(f, hipMalloc((void**)&f->own_packed, need * sizeof(double)));
+  VX_HIP(f, hipHostMalloc((void**)&f->h_packed, need * sizeof(double), hipHostMallocDefault));
+  if (own || !f->d_packed) f->d_packed = f->own_packed;
+  f->xlen = need;
+  return VXBA_OK;
+}
 
 FactorView view(const vxba_factor* f) {
   FactorView fv;
@@ -132,12 +156,14 @@ int ensure_capacity(vxba_factor* f, int n_total) {
   VX_HIP(f, hipMemsetAsync(np, 0, bytes, f->stream));
   if (f->planes && f->V > 0) vxk::launch_copy_planes(f->planes, f->VS, np, want, n_planes(f), f->V, f->stream);
   double* nclb = nullptr;
-  const size_t clb_bytes = vxk::k3_clb_len(f->W, want) * sizeof(double);
-  VX_HIP(f, hipMalloc((void**)&nclb, clb_bytes));
-  VX_HIP(f, hipMemsetAsync(nclb, 0, clb_bytes, f->stream));
-  if (f->clb && f->V > 0)   // batches are absolute, so the old copy is a prefix of the new one
-    VX_HIP(f, hipMemcpyAsync(nclb, f->clb, vxk::k3_clb_len(f->W, f->V) * sizeof(double), hipMemcpyDeviceToDevice, f->stream));
-  if (f->planes) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->planes)); VX_HIP(f, hipFree(f->clb)); }
+  if (!is_wide(f)) {   // the batch-major copy feeds the MFMA sweep only
+    const size_t clb_bytes = vxk::k3_clb_len(f->W, want) * sizeof(double);
+    VX_HIP(f, hipMalloc((void**)&nclb, clb_bytes));
+    VX_HIP(f, hipMemsetAsync(nclb, 0, clb_bytes, f->stream));
+    if (f->clb && f->V > 0)   // batches are absolute, so the old copy is a prefix of the new one
+      VX_HIP(f, hipMemcpyAsync(nclb, f->clb, vxk::k3_clb_len(f->W, f->V) * sizeof(double), hipMemcpyDeviceToDevice, f->stream));
+  }
+  if (f->planes) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->planes)); if (f->clb) VX_HIP(f, hipFree(f->clb)); }
   f->planes = np;
   f->clb = nclb;
   f->VS = want;
@@ -216,6 +242,12 @@ bool fused_solve() {
   return on;
 }
 
+int upload_poses(vxba_factor* f, const double* Rp) {
+  std::memcpy(f->h_poses, Rp, sizeof(double) * 12 * f->W);
+  VX_HIP(f, hipMemcpyAsync(f->d_poses, f->h_poses, sizeof(double) * 12 * f->W, hipMemcpyHostToDevice, f->stream));
+  return VXBA_OK;
+}
+
 // ---- sweeps (asynchronous on f->stream; results in device memory) ----
 // Stand-alone mode: poses by value (Rp, host pointer -> kernel argument), lm == nullptr.
 // LM mode (lm != nullptr): the sweep's prologue takes the pending accept/reject decision from ctl[*c] (and flips *c),
@@ -224,6 +256,17 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c
                       double* d_out, const double* cache_src = nullptr) {
   const size_t plen = vxba_packed_len(f);
   if (end == head) { VX_HIP(f, hipMemsetAsync(d_out, 0, plen * sizeof(double), f->stream)); return VXBA_OK; }
+  if (is_wide(f)) {   // sparse-incidence sweep, host-driven LM only (lm == nullptr)
+    if (lm || !Rp) return fail(f, VXBA_ERR_UNSUPPORTED, "device-resident LM loop: only for win_size <= VXBA_MAX_WIN");
+    int rcw = upload_poses(f, Rp);
+    if (rcw) return rcw;
+    {
+      ScopedKernelTimer t(f, 0);
+      vxw::launch_k3_wide(view(f), f->d_poses, head, end, d_out, f->stream);
+    }
+    VX_HIP(f, hipGetLastError());
+    return shard_allreduce(f, d_out, plen);
+  }
   int rc = ensure_partials3(f);
   if (rc) return rc;
   PoseArg pa;
@@ -261,6 +304,20 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c
 int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int c, int head, int end, double* d_out,
                           int* nparts_out = nullptr, unsigned fused_seq = 0) {
   if (end == head) { if (d_out) VX_HIP(f, hipMemsetAsync(d_out, 0, sizeof(double), f->stream)); return VXBA_OK; }
+  if (is_wide(f)) {
+    if (lm || !Rp || !d_out) return fail(f, VXBA_ERR_UNSUPPORTED, "device-resident LM loop: only for win_size <= VXBA_MAX_WIN");
+    int rcw = upload_poses(f, Rp);
+    if (rcw) return rcw;
+    int np;
+    {
+      ScopedKernelTimer t(f, 1);
+      np = vxw::launch_k2_wide(view(f), f->d_poses, head, end, f->d_partial2, f->stream);
+    }
+    if (nparts_out) *nparts_out = np;
+    vxk::launch_sum_partials(f->d_partial2, np, d_out, f->stream);
+    VX_HIP(f, hipGetLastError());
+    return shard_allreduce(f, d_out, 1);
+  }
   PoseArg pa;
   if (Rp) fill_poses(f, Rp, pa); else std::memset(&pa, 0, sizeof pa);
   const FactorView fv = view(f);
@@ -339,7 +396,7 @@ extern "C" {
 int vxba_create(int win_size, int device, vxba_factor** out) {
   if (!out) return VXBA_ERR_ARG;
   *out = nullptr;
-  if (win_size < 1 || win_size > VXBA_MAX_WIN) return VXBA_ERR_UNSUPPORTED;
+  if (win_size < 1 || win_size > VXBA_MAX_WIN_WIDE) return VXBA_ERR_UNSUPPORTED;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VXBA_ERR_NODEV;
   if (device < 0 || device >= ndev) return VXBA_ERR_NODEV;
@@ -355,13 +412,12 @@ int vxba_create(int win_size, int device, vxba_factor** out) {
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e);
   f->stream = f->own_stream;
-  const size_t plen = (size_t)36 * VXBA_MAX_WIN * VXBA_MAX_WIN + 6 * VXBA_MAX_WIN + 1;
-  if ((e = hipMalloc((void**)&f->own_packed, plen * sizeof(double))) != hipSuccess) return bail(e);
+  if (ensure_exchange(f) != VXBA_OK) return bail(hipErrorOutOfMemory);
   if ((e = hipMalloc((void**)&f->own_scalar, sizeof(double))) != hipSuccess) return bail(e);
-  f->d_packed = f->own_packed;
   f->d_scalar = f->own_scalar;
   if ((e = hipMalloc((void**)&f->d_count, sizeof(unsigned long long))) != hipSuccess) return bail(e);
-  if ((e = hipHostMalloc((void**)&f->h_packed, plen * sizeof(double), hipHostMallocDefault)) != hipSuccess) return bail(e);
+  if ((e = hipMalloc((void**)&f->d_poses, sizeof(double) * 12 * VXBA_MAX_WIN_WIDE)) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc((void**)&f->h_poses, sizeof(double) * 12 * VXBA_MAX_WIN_WIDE, hipHostMallocDefault)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc((void**)&f->h_scalar, 2 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return bail(e);
   if ((e = hipMalloc((void**)&f->d_lm, sizeof(vxk::LMState))) != hipSuccess) return bail(e);
   if ((e = hipMemset(f->d_lm, 0, sizeof(vxk::LMState))) != hipSuccess) return bail(e);
@@ -378,7 +434,8 @@ int vxba_destroy(vxba_factor* f) {
   for (auto& ep : f->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   for (auto e : f->free_events) hipEventDestroy(e);
   hipFree(f->planes); hipFree(f->clb); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2);
-  hipFree(f->own_packed); hipFree(f->own_scalar); hipFree(f->d_count);
+  hipFree(f->own_packed); hipFree(f->own_scalar); hipFree(f->d_count); hipFree(f->d_poses);
+  if (f->h_poses) hipHostFree(f->h_poses);
   if (f->h_packed) hipHostFree(f->h_packed);
   if (f->h_scalar) hipHostFree(f->h_scalar);
   hipFree(f->d_lm);
@@ -399,14 +456,14 @@ int vxba_clear(vxba_factor* f) {
 int vxba_set_win_size(vxba_factor* f, int win_size) {
   VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
-  if (win_size < 1 || win_size > VXBA_MAX_WIN) return fail(f, VXBA_ERR_UNSUPPORTED, "win_size outside [1, VXBA_MAX_WIN]");
+  if (win_size < 1 || win_size > VXBA_MAX_WIN_WIDE) return fail(f, VXBA_ERR_UNSUPPORTED, "win_size outside [1, VXBA_MAX_WIN_WIDE]");
   if (win_size == f->W) return VXBA_OK;
   if (f->V != 0) return fail(f, VXBA_ERR_STATE, "win_size can only change on an empty factor");
   hipSetDevice(f->device);
-  if (f->planes) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->planes)); VX_HIP(f, hipFree(f->clb)); f->planes = nullptr; f->clb = nullptr; }
+  if (f->planes) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->planes)); if (f->clb) VX_HIP(f, hipFree(f->clb)); f->planes = nullptr; f->clb = nullptr; }
   f->VS = 0;
   f->W = win_size;
-  return VXBA_OK;
+  return ensure_exchange(f);
 }
 
 int vxba_win_size(const vxba_factor* f) { return f ? f->W : 0; }
@@ -509,7 +566,7 @@ int vxba_push_voxels(vxba_factor* f, int n, const double* clusters, const double
   if (rc) return rc;
   VX_HIP(f, hipMemcpyAsync(f->staging, clusters, ncl * sizeof(double), hipMemcpyHostToDevice, f->stream));
   vxk::launch_scatter_clusters(f->staging, view(f), f->V, n, f->stream);
-  vxk::launch_build_clb(view(f), f->V, n, f->stream);
+  if (!is_wide(f)) vxk::launch_build_clb(view(f), f->V, n, f->stream);
   VX_HIP(f, hipStreamSynchronize(f->stream));
   rc = append_meta(f, f->V, n, fix, coe, eig_val, eig_vec, merged);
   if (rc) return rc;
@@ -543,7 +600,7 @@ int vxba_push_points(vxba_factor* f, int n_voxels, int64_t n_points, const doubl
     ScopedKernelTimer t(f, 3);
     vxk::launch_k1_build(d_xyz, d_ptr, n_voxels, f->W, view(f), f->V, f->stream);
   }
-  vxk::launch_build_clb(view(f), f->V, n_voxels, f->stream);
+  if (!is_wide(f)) vxk::launch_build_clb(view(f), f->V, n_voxels, f->stream);
   e = hipStreamSynchronize(f->stream);
   if (e == hipSuccess) e = hipGetLastError();
   cleanup();
@@ -730,6 +787,22 @@ int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out
   if (!f || !Rp || max_iter < 0 || max_iter > vxk::LM_MAX_ITER) return fail(f, VXBA_ERR_ARG, "damping_iter: bad argument (max_iter <= 64)");
   if (f->V == 0) return fail(f, VXBA_ERR_STATE, "damping_iter on an empty factor");
   hipSetDevice(f->device);
+  if (is_wide(f)) {
+    // wide window: sweeps on the GPU, the (6W)-dimensional LM shell on the host (Eigen-style pivoted LDL^T), as the reference
+    // runs it (voxel_map.hpp:367-442); 2 syncs + 2 small D2H per iteration
+    auto hess_cb = [](void* ctx, const double* xs, double* packed) -> int {
+      vxba_factor* g = (vxba_factor*)ctx;
+      if (sweep_hess_host(g, xs, 0, g->V) != VXBA_OK) return 1;
+      std::memcpy(packed, g->h_packed, vxba_packed_len(g) * sizeof(double));
+      return 0;
+    };
+    auto resid_cb = [](void* ctx, const double* xs, double* r) -> int {
+      vxba_factor* g = (vxba_factor*)ctx;
+      return sweep_residual_host(g, xs, 0, g->V, r) == VXBA_OK ? 0 : 1;
+    };
+    const int rcw = vxba_damping_iter_generic(f->W, Rp, max_iter, hess_cb, resid_cb, f, hess_out, resis_out, trace_out, n_trace, is_converge);
+    return rcw == VXBA_OK ? VXBA_OK : (f->err.empty() ? fail(f, rcw, "damping_iter (wide): sweep failed") : rcw);
+  }
   const int W = f->W, n = 6 * W;
   PoseArg x0;
   fill_poses(f, Rp, x0);
@@ -816,6 +889,7 @@ int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_
   VX_LOCK(f);
   if (!f || !Rp_init || n_steps < 0 || steps_per_solve < 1) return fail(f, VXBA_ERR_ARG, "lm_steps: bad argument");
   if (f->V == 0) return fail(f, VXBA_ERR_STATE, "lm_steps on an empty factor");
+  VX_NARROW_ONLY(f, "lm_steps");
   hipSetDevice(f->device);
   const int W = f->W;
   PoseArg x0;
@@ -936,6 +1010,7 @@ int vxba_li_evaluate(vxba_factor* f, const double* states, const double* imus, d
   VX_LOCK(f);
   if (!f || !states || (!imus && f->W > 1) || !Hess || !JacT || !residual) return fail(f, VXBA_ERR_ARG, "li_evaluate: null argument");
   if (f->V == 0) return fail(f, VXBA_ERR_STATE, "li_evaluate on an empty factor");
+  VX_NARROW_ONLY(f, "li_evaluate");
   hipSetDevice(f->device);
   return li_joint_system(f, states, imus, imu_coef, Hess, JacT, residual);
 }
@@ -943,6 +1018,7 @@ int vxba_li_only_residual(vxba_factor* f, const double* states, const double* im
   VX_LOCK(f);
   if (!f || !states || (!imus && f->W > 1) || !residual) return fail(f, VXBA_ERR_ARG, "li_only_residual: null argument");
   if (f->V == 0) return fail(f, VXBA_ERR_STATE, "li_only_residual on an empty factor");
+  VX_NARROW_ONLY(f, "li_only_residual");
   hipSetDevice(f->device);
   return li_joint_residual(f, states, imus, imu_coef, residual);
 }
@@ -953,6 +1029,7 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
   VX_LOCK(f);
   if (!f || !states || (!imus && f->W > 1) || max_iter < 0) return fail(f, VXBA_ERR_ARG, "li_damping_iter: bad argument");
   if (f->V == 0) return fail(f, VXBA_ERR_STATE, "li_damping_iter on an empty factor");
+  VX_NARROW_ONLY(f, "li_damping_iter");
   hipSetDevice(f->device);
   const int W = f->W, n = vxi::DIM * W, SL = vxi::STATE_LEN;
   double u = 0.01, v = 2;
@@ -1039,6 +1116,7 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
   VX_LOCK(f);
   if (!f || !states || (!imus && f->W > 1) || max_iter < 0) return fail(f, VXBA_ERR_ARG, "li_damping_iter_gravity: bad argument");
   if (f->V == 0) return fail(f, VXBA_ERR_STATE, "li_damping_iter_gravity on an empty factor");
+  VX_NARROW_ONLY(f, "li_damping_iter_gravity");
   hipSetDevice(f->device);
   const int W = f->W, n = vxi::DIM * W + 3, SL = vxi::STATE_LEN;
   double u = 0.01, v = 2;
@@ -1133,15 +1211,15 @@ int vxba_voxelize_push(vxba_factor* f, int64_t n_points, const double* xyz_local
   VX_HIP(f, dalloc((void**)&d_id, (size_t)cap * sizeof(unsigned long long)));
   VX_HIP(f, hipMemcpyAsync(d_xyz, xyz_local, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
   VX_HIP(f, hipMemcpyAsync(d_fp, frame_ptr, (size_t)(W + 1) * sizeof(long long), hipMemcpyHostToDevice, f->stream));
-  PoseArg pa;
-  fill_poses(f, Rp, pa);
+  int rcp = upload_poses(f, Rp);
+  if (rcp) return rcp;
   vxv::VoxelizeParams vp;
   vp.voxel_size = params->voxel_size; vp.max_layer = params->max_layer; vp.min_points = params->min_points;
   vp.min_eigen_value = params->min_eigen_value; vp.factor_ratio_max = params->factor_ratio_max;
   for (int k = 0; k < 4; k++) vp.eigen_ratio[k] = params->eigen_ratio[k];
   vxv::VoxelizeOutput out{cap, d_cl, d_ev, d_evec, d_m, d_id};
   const char* emsg = nullptr;
-  const long long n = vxv::voxelize(W, n_points, d_xyz, d_fp, pa, vp, f->stream, &out, &emsg);
+  const long long n = vxv::voxelize(W, n_points, d_xyz, d_fp, f->d_poses, vp, f->stream, &out, &emsg);
   if (n < 0) return fail(f, VXBA_ERR_STATE, emsg ? emsg : "voxelize failed");
   if (n > 0) {
     int rc = ensure_capacity(f, f->V + (int)n);
@@ -1153,7 +1231,7 @@ int vxba_voxelize_push(vxba_factor* f, int64_t n_points, const double* xyz_local
     vxv::fill(d_fix, n * 10, 0.0, f->stream);
     vxv::fill(d_coe, n, 1.0, f->stream);
     vxk::launch_scatter_clusters(d_cl, fv, v0, (int)n, f->stream);
-    vxk::launch_build_clb(fv, v0, (int)n, f->stream);
+    if (!is_wide(f)) vxk::launch_build_clb(fv, v0, (int)n, f->stream);
     vxk::launch_scatter_rows(d_fix, fv.fix, f->VS, v0, (int)n, 10, f->stream);
     vxk::launch_scatter_rows(d_coe, fv.coe, f->VS, v0, (int)n, 1, f->stream);
     vxk::launch_scatter_rows(d_ev, fv.eigval, f->VS, v0, (int)n, 3, f->stream);
@@ -1192,6 +1270,7 @@ int vxba_debug_stamps(int clear, unsigned long long* out, size_t n) {
 int vxba_set_precision(vxba_factor* f, int mode) {
   VX_LOCK(f);
   if (!f || (mode != VXBA_PRECISION_F64 && mode != VXBA_PRECISION_MIXED)) return fail(f, VXBA_ERR_ARG, "set_precision: mode must be VXBA_PRECISION_F64 or VXBA_PRECISION_MIXED");
+  if (mode != VXBA_PRECISION_F64) VX_NARROW_ONLY(f, "mixed precision");
   f->precision = mode;
   return VXBA_OK;
 }

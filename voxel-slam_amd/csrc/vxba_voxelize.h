@@ -26,7 +26,7 @@ struct VoxelizeOutput {
 };
 
 // Returns the number of factor voxels written (grouped by layer, ascending node key inside a layer) or -1 (*err set).
-long long voxelize(int W, long long n_points, const double* d_xyz_local, const long long* d_frame_ptr, const vxk::PoseArg& poses, const VoxelizeParams& p,
+long long voxelize(int W, long long n_points, const double* d_xyz_local, const long long* d_frame_ptr, const double* d_poses /* W*12 */, const VoxelizeParams& p,
                    hipStream_t s, VoxelizeOutput* out, const char** err);
 
 void fill(double* d, long long n, double v, hipStream_t s);

@@ -28,14 +28,14 @@ namespace vxv {
 
 constexpr int FRAME_BITS = 7, PATH_BITS = 9;
 
-__global__ void key_kernel(const double* __restrict__ xyz, const long long* __restrict__ frame_ptr, int W, vxk::PoseArg poses, VoxelizeParams p,
+__global__ void key_kernel(const double* __restrict__ xyz, const long long* __restrict__ frame_ptr, int W, const double* __restrict__ poses, VoxelizeParams p,
                            long long n, double* __restrict__ world, unsigned long long* __restrict__ key, int* __restrict__ err) {
 #pragma clang fp contract(off)
   const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
   int f = 0;
   while (f + 1 < W && q >= frame_ptr[f + 1]) f++;
-  const double* Rp = poses.Rp + 12 * f;
+  const double* Rp = poses + 12 * f;
   const double x = xyz[3 * q], y = xyz[3 * q + 1], z = xyz[3 * q + 2];
   double w[3];
   for (int r = 0; r < 3; r++) w[r] = Rp[r] * x + Rp[3 + r] * y + Rp[6 + r] * z + Rp[9 + r];   // R * local + p, left to right
@@ -191,7 +191,7 @@ struct DevBuf {
 
 static inline unsigned grid_for(long long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
-long long voxelize(int W, long long n_points, const double* d_xyz_local, const long long* d_frame_ptr, const vxk::PoseArg& poses, const VoxelizeParams& p,
+long long voxelize(int W, long long n_points, const double* d_xyz_local, const long long* d_frame_ptr, const double* d_poses, const VoxelizeParams& p,
                    hipStream_t s, VoxelizeOutput* out, const char** err_out) {
   static const char* range_msg = "voxelize: a point lies outside the +-32768-voxel range of the 16-bit voxel coordinates";
   static const char* cap_msg = "voxelize: more factor voxels than the caller's capacity";
@@ -221,7 +221,7 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
   VV(B.alloc(&d_key, n)); VV(B.alloc(&d_lkey, n)); VV(B.alloc(&d_lkey_s, n));
   VV(B.alloc(&d_idx, n)); VV(B.alloc(&d_idx_s, n)); VV(B.alloc(&d_err, 1));
   VV(hipMemsetAsync(d_err, 0, sizeof(int), s));
-  if (n > 0) key_kernel<<<grid_for(n), 256, 0, s>>>(d_xyz_local, d_frame_ptr, W, poses, p, n, d_world, d_key, d_err);
+  if (n > 0) key_kernel<<<grid_for(n), 256, 0, s>>>(d_xyz_local, d_frame_ptr, W, d_poses, p, n, d_world, d_key, d_err);
 
   // per-layer scratch (sized for the worst case: every point its own cell)
   unsigned long long *d_cell_key, *d_cell_node, *d_node_key[4] = {nullptr, nullptr, nullptr, nullptr};

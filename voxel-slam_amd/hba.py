@@ -4,7 +4,8 @@ Lidar_BA_Optimizer::damping_iter with up to 4 iterations } with the reference's 
 parameters first, the odometry's finer ones for the last round), then turn the off-diagonal 6x6 blocks of the final Hessian
 into pose-graph edge weights.  Host orchestration only -- the per-round work (hashing, octree, plane tests, sweeps, solve)
 runs on the GPU; this file is the harness-level mirror used by the tests and as an integration example (config 5's bottom
-level: windows of 10 keyframes; the top level needs W > VXBA_MAX_WIN and is not covered)."""
+level: windows of 10 keyframes on the MFMA path; the top level's ~100 submap poses go through the same calls on the wide-window
+path, VXBA_MAX_WIN < W <= VXBA_MAX_WIN_WIDE)."""
 from __future__ import annotations
 
 import numpy as np

@@ -15,6 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VXBA_LIB") or os.path.join(_HERE, "csrc", "libvxba.so")   # VXBA_LIB: A/B runs of two builds
 MAX_WIN = 10
+MAX_WIN_WIDE = 128
 TRACE_COLS = 8
 
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
