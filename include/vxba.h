@@ -1,8 +1,10 @@
 /* vxba.h -- C ABI of the MI355X-native LiDAR bundle-adjustment factor (libvxba.so).
  *
  * Drop-in boundary for the local-mapping BA hot path of hku-mars/Voxel-SLAM: everything
- * `class LidarFactor` (VoxelSLAM/src/voxel_map.hpp:109-290) does, plus the optimizer shell that
- * owns the loop (`Lidar_BA_Optimizer`, voxel_map.hpp:293-444), behind plain pointers and sizes.
+ * `class LidarFactor` (VoxelSLAM/src/voxel_map.hpp:109-290) does, plus the optimizer shells that
+ * own the loop (`Lidar_BA_Optimizer` voxel_map.hpp:293-444, `LI_BA_Optimizer[Gravity]` :446-864 with the
+ * `IMU_PRE` factor of preintegration.hpp), plus the batch factor construction of the hierarchical BA
+ * (`OctreeGBA`, loop_refine.hpp:273-476), behind plain pointers and sizes.
  * The reference has no FFI; these are the entry points a binding of that class would need
  * (INTEGRATION.md shows the adapter a maintainer would add to voxel_map.hpp).
  *
@@ -41,7 +43,7 @@ enum {
   VXBA_ERR_UNSUPPORTED = 5
 };
 
-/* Largest window the current kernels accept (6W <= 64 columns of the MFMA accumulator tile set). */
+/* Largest window of the MFMA sweeps and the device-resident LM loop (6W <= 64 columns of the accumulator tile set). */
 #define VXBA_MAX_WIN 10
 /* Wide windows (VXBA_MAX_WIN < win_size <= VXBA_MAX_WIN_WIDE; the top level of the hierarchical BA optimises ~100 submap poses,
  * voxelslam.cpp:2485-2595): same entry points, sparse-incidence sweeps (one wave per voxel, f64 atomics into the (6W)^2 Hessian, so
