@@ -46,9 +46,9 @@ enum {
 /* Largest window of the MFMA sweeps and the device-resident LM loop (6W <= 64 columns of the accumulator tile set). */
 #define VXBA_MAX_WIN 10
 /* Wide windows (VXBA_MAX_WIN < win_size <= VXBA_MAX_WIN_WIDE; the top level of the hierarchical BA optimises ~100 submap poses,
- * voxelslam.cpp:2485-2595): same entry points, sparse-incidence sweeps (one wave per voxel, f64 atomics into the (6W)^2 Hessian, so
- * the last bits vary from run to run), LM shell on the host.  Not available there: vxba_lm_steps, the LiDAR-inertial shells, mixed
- * precision. */
+ * voxelslam.cpp:2485-2595): same entry points, sparse-incidence sweeps (pair-major Hessian assembly over an incidence index built
+ * once per factor content; deterministic), LM shell on the host.  Not available there: vxba_lm_steps, the LiDAR-inertial shells,
+ * mixed precision. */
 #define VXBA_MAX_WIN_WIDE 128
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

@@ -1,6 +1,6 @@
 """Wide windows (win_size > VXBA_MAX_WIN; the top level of the hierarchical BA optimises ~100 submap poses): the
-sparse-incidence sweeps of vxba_wide.hip and the host-side LM shell against the CPU oracle.  The Hessian is accumulated with f64
-atomics there, so agreement is to round-off (not bitwise), run to run as well."""
+sparse-incidence sweeps of vxba_wide.hip (pair-major Hessian assembly, no atomics) and the host-side LM shell against the
+CPU oracle."""
 import numpy as np
 import pytest
 
@@ -49,6 +49,15 @@ def test_wide_sweeps_match_oracle(vx, W, V, pts, p_obs):
     assert relerr(Ha + Hb, Ho) < 1e-9 and abs(ra + rb - ro) <= 1e-10 * abs(ro)
     He, Je, re_ = fg.acc_evaluate2(sc.poses_init, 5, 5)
     assert not He.any() and not Je.any() and re_ == 0.0
+    # every Hessian block is owned by one wave and summed in a fixed order: bitwise reproducible, also after the index is rebuilt
+    H2, J2, r2 = fg.acc_evaluate2(sc.poses_init)
+    assert np.array_equal(H2, Hg) and np.array_equal(J2, Jg) and r2 == rg
+    f2 = vx.LidarFactor(W)
+    f2.push_voxels(sc.clusters[: V // 2], sc.fix[: V // 2], sc.coe[: V // 2])
+    f2.push_voxels(sc.clusters[V // 2:], sc.fix[V // 2:], sc.coe[V // 2:])     # second push invalidates the incidence index
+    f2.evaluate_only_residual(sc.poses_gt)
+    H3, J3, r3 = f2.acc_evaluate2(sc.poses_init)
+    assert np.array_equal(H3, Hg) and np.array_equal(J3, Jg) and r3 == rg
 
 
 @pytest.mark.parametrize("W,V,pts,p_obs", [(24, 3000, 8000, 0.2), (64, 4000, 5000, 0.06)])

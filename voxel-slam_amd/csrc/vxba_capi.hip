@@ -57,6 +57,8 @@ struct vxba_factor {
   double* h_scalar = nullptr;    // pinned
   vxk::LMState* d_lm = nullptr;  // device-resident LM shell state
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
+  vxw::WideIndex wide;           // wide windows: incidence structure (entries, entry pairs per Hessian block), rebuilt after a push
+  bool wide_dirty = true;
   double* d_poses = nullptr;     // wide windows: W*12 poses on the device (the MFMA kernels take them by value)
   double* h_poses = nullptr;     // pinned staging for the above
   size_t xlen = 0;               // doubles the exchange buffers (own_packed, h_packed) hold
@@ -260,9 +262,14 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c
     if (lm || !Rp) return fail(f, VXBA_ERR_UNSUPPORTED, "device-resident LM loop: only for win_size <= VXBA_MAX_WIN");
     int rcw = upload_poses(f, Rp);
     if (rcw) return rcw;
+    if (f->wide_dirty || f->wide.V != f->V) {
+      const char* emsg = nullptr;
+      if (vxw::build_index(view(f), f->V, f->wide, f->stream, &emsg) != 0) return fail(f, VXBA_ERR_HIP, emsg ? emsg : "wide index build failed");
+      f->wide_dirty = false;
+    }
     {
       ScopedKernelTimer t(f, 0);
-      vxw::launch_k3_wide(view(f), f->d_poses, head, end, d_out, f->stream);
+      vxw::launch_k3_wide(view(f), f->d_poses, f->wide, head, end, d_out, f->d_partial2, f->stream);
     }
     VX_HIP(f, hipGetLastError());
     return shard_allreduce(f, d_out, plen);
@@ -434,6 +441,7 @@ int vxba_destroy(vxba_factor* f) {
   for (auto& ep : f->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   for (auto e : f->free_events) hipEventDestroy(e);
   hipFree(f->planes); hipFree(f->clb); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2);
+  vxw::free_index(f->wide);
   hipFree(f->own_packed); hipFree(f->own_scalar); hipFree(f->d_count); hipFree(f->d_poses);
   if (f->h_poses) hipHostFree(f->h_poses);
   if (f->h_packed) hipHostFree(f->h_packed);
@@ -449,6 +457,7 @@ int vxba_clear(vxba_factor* f) {
   VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
   f->V = 0;
+  f->wide_dirty = true;
   f->snapshot_v = 0;
   return VXBA_OK;
 }
@@ -571,6 +580,7 @@ int vxba_push_voxels(vxba_factor* f, int n, const double* clusters, const double
   rc = append_meta(f, f->V, n, fix, coe, eig_val, eig_vec, merged);
   if (rc) return rc;
   f->V += n;
+  f->wide_dirty = true;
   return VXBA_OK;
 }
 
@@ -608,6 +618,7 @@ int vxba_push_points(vxba_factor* f, int n_voxels, int64_t n_points, const doubl
   rc = append_meta(f, f->V, n_voxels, fix, coe, nullptr, nullptr, nullptr);
   if (rc) return rc;
   f->V += n_voxels;
+  f->wide_dirty = true;
   return VXBA_OK;
 }
 
@@ -1243,6 +1254,7 @@ int vxba_voxelize_push(vxba_factor* f, int64_t n_points, const double* xyz_local
     VX_HIP(f, hipStreamSynchronize(f->stream));
     VX_HIP(f, hipGetLastError());
     f->V += (int)n;
+    f->wide_dirty = true;
   }
   *n_pushed = n;
   return VXBA_OK;

@@ -5,7 +5,13 @@
 // mapping.  Storage is unchanged (frame-major planes, N == 0 marks an unobserved frame).
 #include "vxba_wide.h"
 
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "vxba_math.hpp"
 
@@ -79,18 +85,88 @@ __global__ __launch_bounds__(64) void k2_wide_kernel(FactorView fv, const double
 
 __device__ __forceinline__ int sym6(int a, int b) { return a == 0 ? b : (a == 1 ? 2 + b : 5); }   // a <= b < 3
 
-constexpr int K3W_WAVES = 4;
-__global__ __launch_bounds__(64 * K3W_WAVES) void k3_wide_kernel(FactorView fv, const double* __restrict__ poses, int head, int end, double* __restrict__ packed) {
+// ------------------------------------------------------------------------------------------------------------------
+// Pair-major Hessian assembly (deterministic, no atomics).
+// The incidence structure of a wide factor -- which (voxel, frame) entries exist and which entry PAIRS share a voxel --
+// depends on the clusters only, not on the poses, so it is built once per factor content (WideIndex, rebuilt after a push):
+//   entries  e -> (voxel, frame), voxel-major, frames ascending
+//   pairs    (e_i, e_j) of one voxel with frame_i <= frame_j, keyed by frame_i * W + frame_j, stably radix-sorted by key:
+//            every 6x6 block of the Hessian becomes one contiguous run of pair records, in voxel order.
+// A sweep is then (A) one lane per entry: the rank-3 rows and the gradient / block-diagonal terms (vxm::k3_entry) into a row
+// buffer, (B) one wave per Hessian block: the lanes stride over the block's pair records, each accumulating the 36 products
+// in registers, a fixed butterfly adds the lanes, and the block (and its mirror image) is written -- each block is owned by
+// exactly one wave, so the result is bitwise reproducible.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int ROWLEN = 45;   // per entry: rows 18 | g 6 | Drr 6 | Drt 9 | Dtt 6
+
+__global__ void wi_count_kernel(FactorView fv, int V, int* __restrict__ cnt) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= V) return;
+  int k = 0;
+  for (int f = 0; f < fv.W; f++) k += fv.cl[((size_t)f * 10 + 9) * fv.VS + a] != 0.0 ? 1 : 0;
+  cnt[a] = k;
+}
+__global__ void wi_paircount_kernel(const int* __restrict__ cnt, int V, long long* __restrict__ pc) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < V) pc[a] = (long long)cnt[a] * (cnt[a] + 1) / 2;
+}
+// entries of voxel a at entry_ptr[a]..; its pairs at pair_ptr[a]..
+__global__ void wi_fill_kernel(FactorView fv, int V, const long long* __restrict__ entry_ptr, const long long* __restrict__ pair_ptr,
+                               int* __restrict__ entry_voxel, int* __restrict__ entry_frame, unsigned int* __restrict__ pair_key,
+                               unsigned int* __restrict__ pair_idx) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= V) return;
+  const long long e0 = entry_ptr[a];
+  int k = 0;
+  for (int f = 0; f < fv.W; f++)
+    if (fv.cl[((size_t)f * 10 + 9) * fv.VS + a] != 0.0) { entry_voxel[e0 + k] = a; entry_frame[e0 + k] = f; k++; }
+  long long p = pair_ptr[a];
+  for (int i = 0; i < k; i++)
+    for (int j = i; j < k; j++) {
+      pair_key[p] = (unsigned int)(entry_frame[e0 + i] * fv.W + entry_frame[e0 + j]);
+      pair_idx[p] = (unsigned int)p;      // payload of the sort: the record's original position (-> entries via pair_e)
+      p++;
+    }
+}
+__global__ void wi_pair_entries_kernel(int V, const int* __restrict__ cnt, const long long* __restrict__ entry_ptr, const long long* __restrict__ pair_ptr,
+                                       unsigned int* __restrict__ pair_ei, unsigned int* __restrict__ pair_ej) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= V) return;
+  const int k = cnt[a];
+  const long long e0 = entry_ptr[a];
+  long long p = pair_ptr[a];
+  for (int i = 0; i < k; i++)
+    for (int j = i; j < k; j++) { pair_ei[p] = (unsigned int)(e0 + i); pair_ej[p] = (unsigned int)(e0 + j); p++; }
+}
+__global__ void wi_gather_kernel(const unsigned int* __restrict__ order, long long np, const unsigned int* __restrict__ ei, const unsigned int* __restrict__ ej,
+                                 unsigned int* __restrict__ sei, unsigned int* __restrict__ sej) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < np) { sei[q] = ei[order[q]]; sej[q] = ej[order[q]]; }
+}
+__global__ void wi_widen_kernel(const unsigned int* __restrict__ in, long long n, long long* __restrict__ out) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) out[q] = (long long)in[q];
+}
+__global__ void wi_widen_int_kernel(const int* __restrict__ in, long long n, long long* __restrict__ out) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) out[q] = (long long)in[q];
+}
+
+// (A) one lane per entry
+__global__ __launch_bounds__(256) void k3w_rows_kernel(FactorView fv, const double* __restrict__ poses, const int* __restrict__ entry_voxel,
+                                                       const int* __restrict__ entry_frame, long long nnz, int head, int end, double* __restrict__ rowbuf) {
   __shared__ double pl[12 * WIDE_MAXW];
-  __shared__ double rows_s[K3W_WAVES][WIDE_MAXW][18];
-  __shared__ int frame_s[K3W_WAVES][WIDE_MAXW];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, W = fv.W, n = 6 * W;
-  for (int k = tid; k < 12 * W; k += blockDim.x) pl[k] = poses[k];
+  for (int k = threadIdx.x; k < 12 * fv.W; k += blockDim.x) pl[k] = poses[k];
   __syncthreads();
-  const int a = head + blockIdx.x * K3W_WAVES + wave;
-  if (a >= end) return;                  // whole wave
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nnz) return;
+  const int a = entry_voxel[e], f = entry_frame[e];
+  double* out = rowbuf + (size_t)e * ROWLEN;
+  if (a < head || a >= end) {           // outside the requested voxel range: contributes nothing
+    for (int k = 0; k < ROWLEN; k++) out[k] = 0.0;
+    return;
+  }
   const size_t VS = (size_t)fv.VS;
-  // the voxel's cached plane: every lane holds a copy (broadcast loads)
   vxm::VoxelCache vc;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -98,83 +174,117 @@ __global__ __launch_bounds__(64 * K3W_WAVES) void k3_wide_kernel(FactorView fv, 
     vc.u1[k] = fv.eigvec[(size_t)(3 + k) * VS + a];
     vc.u2[k] = fv.eigvec[(size_t)(6 + k) * VS + a];
   }
-  vc.s1 = fv.aux[a];
-  vc.s2 = fv.aux[VS + a];
-  vc.invN = fv.aux[2 * VS + a];
-  vc.sc = fv.aux[3 * VS + a];
-  vc.coe = fv.coe[a];
+  vc.s1 = fv.aux[a]; vc.s2 = fv.aux[VS + a]; vc.invN = fv.aux[2 * VS + a]; vc.sc = fv.aux[3 * VS + a]; vc.coe = fv.coe[a];
 #pragma unroll
   for (int k = 0; k < 3; k++) vc.vbar[k] = fv.merged[(size_t)(6 + k) * VS + a] * vc.invN;
-  if (lane == 0) unsafeAtomicAdd(&packed[(size_t)n * n + n], vc.coe * fv.eigval[a]);   // residual += coe * lambda0 (voxel_map.hpp:234)
+  double c[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) c[k] = fv.cl[((size_t)f * 10 + k) * VS + a];
+  double R[9], p[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = pl[12 * f + 3 * cc + r];
+#pragma unroll
+  for (int k = 0; k < 3; k++) p[k] = pl[12 * f + 9 + k];
+  double rows[3][6], acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; k++) acc[k] = 0.0;
+  vxm::k3_entry(c, c + 6, c[9], R, p, vc, rows, acc);
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int k = 0; k < 6; k++) out[6 * r + k] = rows[r][k];
+#pragma unroll
+  for (int k = 0; k < 27; k++) out[18 + k] = acc[k];
+}
 
-  // one lane per observed entry (two rounds cover W <= 128); compacted into LDS in frame order
-  int k_total = 0;
-  for (int base = 0; base < W; base += 64) {
-    const int f = base + lane;
-    double nn = 0.0;
-    if (f < W) nn = fv.cl[((size_t)f * 10 + 9) * VS + a];
-    const bool obs = nn != 0.0;
-    const unsigned long long m = __ballot(obs);
-    const int slot = k_total + __popcll(m & ((1ull << lane) - 1ull));
-    if (obs) {
-      double c[10];
+// (B) one wave per Hessian block (= run of pair records with one key)
+__global__ __launch_bounds__(256) void k3w_blocks_kernel(const unsigned int* __restrict__ key_list, const long long* __restrict__ key_ptr, int nkeys,
+                                                         const unsigned int* __restrict__ sei, const unsigned int* __restrict__ sej,
+                                                         const double* __restrict__ rowbuf, int W, double* __restrict__ packed) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int kq = blockIdx.x * 4 + wave;
+  if (kq >= nkeys) return;
+  const int n = 6 * W;
+  const unsigned int key = key_list[kq];
+  const int fi = (int)(key / (unsigned)W), fj = (int)(key % (unsigned)W);
+  const bool diag = fi == fj;
+  double s[36];
 #pragma unroll
-      for (int k = 0; k < 9; k++) c[k] = fv.cl[((size_t)f * 10 + k) * VS + a];
-      c[9] = nn;
-      double R[9], p[3];
+  for (int e = 0; e < 36; e++) s[e] = 0.0;
+  double g[6] = {0, 0, 0, 0, 0, 0};
+  for (long long q = key_ptr[kq] + lane; q < key_ptr[kq + 1]; q += 64) {
+    const double* ri = rowbuf + (size_t)sei[q] * ROWLEN;
+    const double* rj = rowbuf + (size_t)sej[q] * ROWLEN;
+    double a0[18], b0[18];
 #pragma unroll
-      for (int r = 0; r < 3; r++)
+    for (int k = 0; k < 18; k++) { a0[k] = ri[k]; b0[k] = rj[k]; }
 #pragma unroll
-        for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = pl[12 * f + 3 * cc + r];
+    for (int x = 0; x < 6; x++)
 #pragma unroll
-      for (int k = 0; k < 3; k++) p[k] = pl[12 * f + 9 + k];
-      double rows[3][6], acc[27];
+      for (int y = 0; y < 6; y++) s[6 * x + y] -= a0[x] * b0[y] + a0[6 + x] * b0[6 + y] + a0[12 + x] * b0[12 + y];
+    if (diag) {          // self pair of an entry: its gradient and block-diagonal terms ride along
 #pragma unroll
-      for (int k = 0; k < 27; k++) acc[k] = 0.0;
-      vxm::k3_entry(c, c + 6, c[9], R, p, vc, rows, acc);
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int k = 0; k < 6; k++) rows_s[wave][slot][6 * r + k] = rows[r][k];
-      frame_s[wave][slot] = f;
-      // gradient and the block-diagonal part D_i (upper triangle of the 6x6 diagonal block)
-      double* J = packed + (size_t)n * n + 6 * f;
-#pragma unroll
-      for (int d = 0; d < 6; d++) unsafeAtomicAdd(&J[d], acc[d]);
+      for (int d = 0; d < 6; d++) g[d] += ri[18 + d];
 #pragma unroll
       for (int x = 0; x < 3; x++)
 #pragma unroll
         for (int y = 0; y < 3; y++) {
-          if (x <= y) {
-            unsafeAtomicAdd(&packed[(size_t)(6 * f + y) * n + 6 * f + x], acc[6 + sym6(x, y)]);           // rotation-rotation
-            unsafeAtomicAdd(&packed[(size_t)(6 * f + 3 + y) * n + 6 * f + 3 + x], acc[21 + sym6(x, y)]);  // translation-translation
-          }
-          unsafeAtomicAdd(&packed[(size_t)(6 * f + 3 + y) * n + 6 * f + x], acc[12 + 3 * x + y]);         // rotation-translation
+          const double rr = ri[24 + (x <= y ? sym6(x, y) : sym6(y, x))], tt = ri[39 + (x <= y ? sym6(x, y) : sym6(y, x))], rt = ri[30 + 3 * x + y];
+          s[6 * x + y] += rr;
+          s[6 * (3 + x) + 3 + y] += tt;
+          s[6 * x + 3 + y] += rt;
+          s[6 * (3 + y) + x] += rt;
         }
     }
-    k_total += __popcll(m);
   }
-  __builtin_amdgcn_wave_barrier();
-  // -G^T G over the observed pairs i <= j (frames ascending, so every element lands in the upper triangle)
-  for (int i = 0; i < k_total; i++) {
-    const int fi = frame_s[wave][i];
-    const double* ri = rows_s[wave][i];
-    const int items = (k_total - i) * 36;
-    for (int it = lane; it < items; it += 64) {
-      const int j = i + it / 36, e = it % 36, x = e / 6, y = e % 6;
-      if (j == i && x > y) continue;
-      const double* rj = rows_s[wave][j];
-      const double v = ri[x] * rj[y] + ri[6 + x] * rj[6 + y] + ri[12 + x] * rj[12 + y];
-      unsafeAtomicAdd(&packed[(size_t)(6 * frame_s[wave][j] + y) * n + 6 * fi + x], -v);
-    }
+  // fixed butterfly over the wave: every lane ends with the same bits
+#pragma unroll
+  for (int e = 0; e < 36; e++)
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) s[e] += __shfl_xor(s[e], m, 64);
+  if (diag) {
+#pragma unroll
+    for (int d = 0; d < 6; d++)
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) g[d] += __shfl_xor(g[d], m, 64);
+  }
+  if (lane < 36) {
+    const int x = lane / 6, y = lane % 6;
+    double v = 0.0;
+#pragma unroll
+    for (int e = 0; e < 36; e++) v = (e == lane) ? s[e] : v;
+    packed[(size_t)(6 * fj + y) * n + 6 * fi + x] = v;            // block (fi, fj) ...
+    if (!diag) packed[(size_t)(6 * fi + x) * n + 6 * fj + y] = v;  // ... and its mirror image (voxel_map.hpp:237-239)
+  } else if (diag && lane < 42) {
+    const int d = lane - 36;
+    double v = 0.0;
+#pragma unroll
+    for (int e = 0; e < 6; e++) v = (e == d) ? g[e] : v;
+    packed[(size_t)n * n + 6 * fi + d] = v;
   }
 }
 
-__global__ void mirror_kernel(double* __restrict__ packed, int n) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)n * n) return;
-  const int r = (int)(t % n), c = (int)(t / n);
-  if (r > c) packed[(size_t)c * n + r] = packed[(size_t)r * n + c];   // (voxel_map.hpp:237-239)
+// residual = sum coe * lambda0 over [head, end): wave partials, summed by sum kernel in fixed order
+__global__ __launch_bounds__(64) void k3w_residual_kernel(FactorView fv, int head, int end, double* __restrict__ partial) {
+  const int a = head + blockIdx.x * 64 + threadIdx.x;
+  double r = a < end ? fv.coe[a] * fv.eigval[a] : 0.0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(256) void k3w_residual_sum_kernel(const double* __restrict__ partial, int nparts, double* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < nparts; k += 256) s += partial[k];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
 }
 
 int launch_k2_wide(const FactorView& fv, const double* d_poses, int head, int end, double* d_partial, hipStream_t s) {
@@ -184,15 +294,101 @@ int launch_k2_wide(const FactorView& fv, const double* d_poses, int head, int en
   return nblocks;
 }
 
-void launch_k3_wide(const FactorView& fv, const double* d_poses, int head, int end, double* d_packed, hipStream_t s) {
+void free_index(WideIndex& wi) {
+  void* ptrs[] = {wi.entry_voxel, wi.entry_frame, wi.sei, wi.sej, wi.key_list, wi.key_ptr, wi.rowbuf};
+  for (void* q : ptrs) if (q) (void)hipFree(q);
+  wi = WideIndex();
+}
+
+#define WV(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { *err = hipGetErrorString(e_); return -1; } } while (0)
+
+int build_index(const FactorView& fv, int V, WideIndex& wi, hipStream_t s, const char** err) {
+  free_index(wi);
+  wi.V = V;
+  if (V == 0) return 0;
+  struct Tmp { std::vector<void*> p; ~Tmp() { for (void* q : p) (void)hipFree(q); } } tmp;
+  auto talloc = [&](void** q, size_t bytes) { hipError_t e = hipMalloc(q, bytes ? bytes : 8); if (e == hipSuccess) tmp.p.push_back(*q); return e; };
+  const unsigned gV = (unsigned)((V + 255) / 256);
+  int* cnt; long long *pc, *entry_ptr, *pair_ptr, *wide64;
+  WV(talloc((void**)&cnt, sizeof(int) * V));
+  WV(talloc((void**)&pc, sizeof(long long) * (V + 1)));
+  WV(talloc((void**)&wide64, sizeof(long long) * (V + 1)));
+  WV(talloc((void**)&entry_ptr, sizeof(long long) * (V + 1)));
+  WV(talloc((void**)&pair_ptr, sizeof(long long) * (V + 1)));
+  wi_count_kernel<<<gV, 256, 0, s>>>(fv, V, cnt);
+  wi_paircount_kernel<<<gV, 256, 0, s>>>(cnt, V, pc);
+  wi_widen_int_kernel<<<gV, 256, 0, s>>>(cnt, V, wide64);
+  size_t tb = 0, t1 = 0;
+  WV(rocprim::exclusive_scan(nullptr, tb, wide64, entry_ptr, 0ll, (size_t)V + 1, rocprim::plus<long long>(), s));
+  char* d_temp;
+  WV(talloc((void**)&d_temp, tb));
+  t1 = tb;
+  WV(rocprim::exclusive_scan(d_temp, t1, wide64, entry_ptr, 0ll, (size_t)V + 1, rocprim::plus<long long>(), s));
+  t1 = tb;
+  WV(rocprim::exclusive_scan(d_temp, t1, pc, pair_ptr, 0ll, (size_t)V + 1, rocprim::plus<long long>(), s));
+  long long tot[2];
+  WV(hipMemcpyAsync(&tot[0], entry_ptr + V, sizeof(long long), hipMemcpyDeviceToHost, s));
+  WV(hipMemcpyAsync(&tot[1], pair_ptr + V, sizeof(long long), hipMemcpyDeviceToHost, s));
+  WV(hipStreamSynchronize(s));
+  wi.nnz = tot[0];
+  wi.np = tot[1];
+  if (wi.np >= 0xffffffffll) { *err = "wide index: more than 2^32 entry pairs"; return -1; }
+  if (wi.nnz == 0) return 0;
+  WV(hipMalloc((void**)&wi.entry_voxel, sizeof(int) * wi.nnz));
+  WV(hipMalloc((void**)&wi.entry_frame, sizeof(int) * wi.nnz));
+  WV(hipMalloc((void**)&wi.sei, sizeof(unsigned int) * wi.np));
+  WV(hipMalloc((void**)&wi.sej, sizeof(unsigned int) * wi.np));
+  WV(hipMalloc((void**)&wi.rowbuf, sizeof(double) * ROWLEN * wi.nnz));
+  unsigned int *pkey, *pidx, *pkey_s, *pidx_s, *pei, *pej, *kcnt, *nruns;
+  WV(talloc((void**)&pkey, sizeof(unsigned int) * wi.np)); WV(talloc((void**)&pidx, sizeof(unsigned int) * wi.np));
+  WV(talloc((void**)&pkey_s, sizeof(unsigned int) * wi.np)); WV(talloc((void**)&pidx_s, sizeof(unsigned int) * wi.np));
+  WV(talloc((void**)&pei, sizeof(unsigned int) * wi.np)); WV(talloc((void**)&pej, sizeof(unsigned int) * wi.np));
+  const size_t maxkeys = (size_t)fv.W * fv.W;
+  WV(talloc((void**)&kcnt, sizeof(unsigned int) * maxkeys)); WV(talloc((void**)&nruns, sizeof(unsigned int)));
+  wi_fill_kernel<<<gV, 256, 0, s>>>(fv, V, entry_ptr, pair_ptr, wi.entry_voxel, wi.entry_frame, pkey, pidx);
+  wi_pair_entries_kernel<<<gV, 256, 0, s>>>(V, cnt, entry_ptr, pair_ptr, pei, pej);
+  int key_bits = 1;
+  while ((1u << key_bits) < maxkeys) key_bits++;
+  size_t tb2 = 0;
+  WV(rocprim::radix_sort_pairs(nullptr, tb2, pkey, pkey_s, pidx, pidx_s, (size_t)wi.np, 0, key_bits, s));
+  char* d_temp2;
+  WV(talloc((void**)&d_temp2, tb2));
+  WV(rocprim::radix_sort_pairs(d_temp2, tb2, pkey, pkey_s, pidx, pidx_s, (size_t)wi.np, 0, key_bits, s));   // stable: voxel order inside a key
+  wi_gather_kernel<<<(unsigned)((wi.np + 255) / 256), 256, 0, s>>>(pidx_s, wi.np, pei, pej, wi.sei, wi.sej);
+  WV(hipMalloc((void**)&wi.key_list, sizeof(unsigned int) * maxkeys));
+  size_t tb3 = 0;
+  WV(rocprim::run_length_encode(nullptr, tb3, pkey_s, (size_t)wi.np, wi.key_list, kcnt, nruns, s));
+  char* d_temp3;
+  WV(talloc((void**)&d_temp3, tb3));
+  WV(rocprim::run_length_encode(d_temp3, tb3, pkey_s, (size_t)wi.np, wi.key_list, kcnt, nruns, s));
+  unsigned int h_runs = 0;
+  WV(hipMemcpyAsync(&h_runs, nruns, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+  WV(hipStreamSynchronize(s));
+  wi.nkeys = (int)h_runs;
+  WV(hipMalloc((void**)&wi.key_ptr, sizeof(long long) * (wi.nkeys + 1)));
+  long long* kc64;
+  WV(talloc((void**)&kc64, sizeof(long long) * (wi.nkeys + 1)));
+  wi_widen_kernel<<<(unsigned)((wi.nkeys + 255) / 256), 256, 0, s>>>(kcnt, wi.nkeys, kc64);
+  size_t tb4 = 0;
+  WV(rocprim::exclusive_scan(nullptr, tb4, kc64, wi.key_ptr, 0ll, (size_t)wi.nkeys + 1, rocprim::plus<long long>(), s));
+  char* d_temp4;
+  WV(talloc((void**)&d_temp4, tb4));
+  WV(rocprim::exclusive_scan(d_temp4, tb4, kc64, wi.key_ptr, 0ll, (size_t)wi.nkeys + 1, rocprim::plus<long long>(), s));
+  WV(hipStreamSynchronize(s));
+  WV(hipGetLastError());
+  return 0;
+}
+
+void launch_k3_wide(const FactorView& fv, const double* d_poses, const WideIndex& wi, int head, int end, double* d_packed, double* d_partial,
+                    hipStream_t s) {
   const int n = 6 * fv.W;
   (void)hipMemsetAsync(d_packed, 0, ((size_t)n * n + n + 1) * sizeof(double), s);
-  if (end > head) {
-    const int nblocks = (end - head + K3W_WAVES - 1) / K3W_WAVES;
-    k3_wide_kernel<<<dim3(nblocks), dim3(64 * K3W_WAVES), 0, s>>>(fv, d_poses, head, end, d_packed);
-    const long long nn = (long long)n * n;
-    mirror_kernel<<<dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s>>>(d_packed, n);
-  }
+  if (end <= head || wi.nnz == 0) return;
+  k3w_rows_kernel<<<dim3((unsigned)((wi.nnz + 255) / 256)), dim3(256), 0, s>>>(fv, d_poses, wi.entry_voxel, wi.entry_frame, wi.nnz, head, end, wi.rowbuf);
+  k3w_blocks_kernel<<<dim3((unsigned)((wi.nkeys + 3) / 4)), dim3(256), 0, s>>>(wi.key_list, wi.key_ptr, wi.nkeys, wi.sei, wi.sej, wi.rowbuf, fv.W, d_packed);
+  const int nparts = (end - head + 63) / 64;
+  k3w_residual_kernel<<<dim3(nparts), dim3(64), 0, s>>>(fv, head, end, d_partial);
+  k3w_residual_sum_kernel<<<dim3(1), dim3(256), 0, s>>>(d_partial, nparts, d_packed + (size_t)n * n + n);
 }
 
 }  // namespace vxw
