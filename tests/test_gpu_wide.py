@@ -55,7 +55,7 @@ def test_wide_sweeps_match_oracle(vx, W, V, pts, p_obs):
     f2 = vx.LidarFactor(W)
     f2.push_voxels(sc.clusters[: V // 2], sc.fix[: V // 2], sc.coe[: V // 2])
     f2.push_voxels(sc.clusters[V // 2:], sc.fix[V // 2:], sc.coe[V // 2:])     # second push invalidates the incidence index
-    f2.evaluate_only_residual(sc.poses_gt)
+    f2.evaluate_only_residual(sc.poses_init); f2.evaluate_only_residual(sc.poses_gt)   # same cache history (warm-started eigensolver)
     H3, J3, r3 = f2.acc_evaluate2(sc.poses_init)
     assert np.array_equal(H3, Hg) and np.array_equal(J3, Jg) and r3 == rg
 
