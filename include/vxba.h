@@ -144,7 +144,10 @@ int vxba_rccl_attach(vxba_factor* f, const char* librccl_path, int nranks, int r
 int vxba_rccl_detach(vxba_factor* f);
 
 /* Let the caller own the exchange buffers the sweeps reduce into (e.g. a torch tensor, so torch.distributed /
- * RCCL can all-reduce it): d_packed holds vxba_packed_len() f64, d_scalar 1 f64.  NULL restores the internal ones. */
+ * RCCL can all-reduce it): d_packed holds vxba_packed_len() f64, d_scalar 1 f64.  NULL restores the internal ones.
+ * If d_scalar == d_packed + vxba_packed_len() (one allocation of vxba_packed_len() + 1 doubles; the internal buffers are laid
+ * out like that) the device-resident LM loop reduces both with ONE collective per iteration of count vxba_packed_len() + 1
+ * (speculative form: the next Hessian sweep runs at the trial poses and is discarded if the step is rejected). */
 int vxba_use_external_buffers(vxba_factor* f, double* d_packed, double* d_scalar);
 
 /* One LM trace row: [residual1 residual2 u v q q1 accepted recomputed_hess] */

@@ -106,19 +106,27 @@ bool is_wide(const vxba_factor* f) { return f->W > VXBA_MAX_WIN; }
 #define VX_NARROW_ONLY(f, what) \
   do { if (is_wide(f)) return fail(f, VXBA_ERR_UNSUPPORTED, what ": only for win_size <= VXBA_MAX_WIN"); } while (0)
 
-// exchange buffers sized for the current win_size (packed [Hess | JacT | residual])
+// exchange buffers sized for the current win_size: packed [Hess | JacT | residual] and, directly behind it, the scalar of the
+// residual sweep -- contiguous so that the sharded loop can reduce both with one collective
 int ensure_exchange(vxba_factor* f) {
-  const size_t need = (size_t)36 * f->W * f->W + 6 * f->W + 1;
-  if (need <= f->xlen) return VXBA_OK;
+  const size_t plen = (size_t)36 * f->W * f->W + 6 * f->W + 1;
+  if (plen + 1 <= f->xlen) {
+    if (f->d_scalar == f->own_scalar) f->d_scalar = f->own_packed + plen;
+    f->own_scalar = f->own_packed + plen;
+    return VXBA_OK;
+  }
   if (f->stream) VX_HIP(f, hipStreamSynchronize(f->stream));
-  const bool own = f->d_packed == f->own_packed;
+  const bool own_p = !f->d_packed || f->d_packed == f->own_packed;
+  const bool own_s = !f->d_scalar || f->d_scalar == f->own_scalar;
   if (f->own_packed) VX_HIP(f, hipFree(f->own_packed));
   if (f->h_packed) VX_HIP(f, hipHostFree(f->h_packed));
-  f->own_packed = nullptr; f->h_packed = nullptr; f->xlen = 0;
-  VX_HIP(f, hipMalloc((void**)&f->own_packed, need * sizeof(double)));
-  VX_HIP(f, hipHostMalloc((void**)&f->h_packed, need * sizeof(double), hipHostMallocDefault));
-  if (own || !f->d_packed) f->d_packed = f->own_packed;
-  f->xlen = need;
+  f->own_packed = nullptr; f->own_scalar = nullptr; f->h_packed = nullptr; f->xlen = 0;
+  VX_HIP(f, hipMalloc((void**)&f->own_packed, (plen + 1) * sizeof(double)));
+  VX_HIP(f, hipHostMalloc((void**)&f->h_packed, (plen + 1) * sizeof(double), hipHostMallocDefault));
+  f->own_scalar = f->own_packed + plen;
+  if (own_p) f->d_packed = f->own_packed;
+  if (own_s) f->d_scalar = f->own_scalar;
+  f->xlen = plen + 1;
   return VXBA_OK;
 }
 
@@ -345,6 +353,67 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, in
   return VXBA_OK;
 }
 
+// Sharded (collective) LM loop, speculative form: ONE all-reduce per iteration.  The Hessian sweep of iteration i+1 linearises at
+// the trial poses of iteration i before anybody knows whether they are accepted; its reduction also carries the trial residual
+// (the residual sweep's partial sums) in the slot behind the packed buffer; after the single all-reduce a small kernel takes the
+// accept/reject decision from the reduced residual and adopts the reduced system if the step was accepted.  A rejected step wastes
+// that sweep (the reference recomputes nothing then); in exchange every iteration saves one latency-bound collective and the
+// partial-sum kernel.  Needs the scalar exchange buffer directly behind the packed one (true for the factor's own buffers and for
+// dist.attach_allreduce's tensor); VXBA_SPEC_COLLECTIVE=0 falls back to the two-collective loop.
+bool spec_collective(const vxba_factor* f) {
+  static const bool on = [] { const char* e = getenv("VXBA_SPEC_COLLECTIVE"); return !(e && e[0] == '0'); }();
+  return on && has_collective(f) && !is_wide(f) && f->d_scalar == f->d_packed + vxba_packed_len(f);
+}
+
+int spec_hess_phase(vxba_factor* f, const double* Rp0, int* c, bool first_of_solve, bool has_pending, bool restart, const double* cache_src,
+                    int k2_nparts) {
+  int rc = ensure_partials3(f);
+  if (rc) return rc;
+  PoseArg pa;
+  fill_poses(f, Rp0, pa);
+  const FactorView fv = view(f);
+  const int nv = vxk::k3_nv(f->W);
+  const int nbatches = (f->V - 1) / nv + 1;
+  const int nblocks = std::max(1, std::min(vxk::k3_grid_blocks(f->cus), (nbatches + 3) / 4));
+  vxk::LMPending pd;
+  std::memset(&pd, 0, sizeof pd);
+  pd.pending = first_of_solve ? 3 : 2;
+  if (f->profiling & 1) {
+    hipEvent_t a = get_event(f), b = get_event(f);
+    vxk::launch_k3_hessian(fv, pa, f->d_lm, *c, pd, cache_src, 0, f->V, f->d_partial3, nblocks, f->precision, f->stream, a, b);
+    if (a && b) f->pending.push_back({a, b, 0});
+  } else {
+    vxk::launch_k3_hessian(fv, pa, f->d_lm, *c, pd, cache_src, 0, f->V, f->d_partial3, nblocks, f->precision, f->stream);
+  }
+  {
+    ScopedKernelTimer t(f, 2);
+    vxk::launch_k3_finalize(f->d_partial3, nblocks, f->W, f->d_lm, *c, 0, f->d_packed, f->stream, 1, has_pending ? f->d_partial2 : nullptr, k2_nparts);
+  }
+  VX_HIP(f, hipGetLastError());
+  rc = shard_allreduce(f, f->d_packed, vxba_packed_len(f) + 1);
+  if (rc) return rc;
+  vxk::launch_lm_spec_unpack(f->d_lm, *c, f->d_packed, f->W, has_pending ? 1 : 0, restart ? 1 : 0, pa, f->stream);
+  if (has_pending) *c ^= 1;
+  return VXBA_OK;
+}
+
+// closes a speculative loop: the last trial's residual still needs its own (scalar) all-reduce and decision
+int spec_final_decision(vxba_factor* f, const double* Rp0, int* c, int k2_nparts) {
+  vxk::launch_sum_partials(f->d_partial2, k2_nparts, f->d_scalar, f->stream);
+  VX_HIP(f, hipGetLastError());
+  int rc = shard_allreduce(f, f->d_scalar, 1);
+  if (rc) return rc;
+  PoseArg pa;
+  fill_poses(f, Rp0, pa);
+  vxk::LMPending pend;
+  std::memset(&pend, 0, sizeof pend);
+  pend.pending = 1;
+  pend.d_scalar = f->d_scalar;
+  vxk::launch_lm_update(f->d_lm, *c, pend, pa, f->W, f->stream);
+  *c ^= 1;
+  return VXBA_OK;
+}
+
 int sweep_hess_host(vxba_factor* f, const double* Rp, int head, int end) {
   int rc = sweep_hess_device(f, Rp, nullptr, nullptr, nullptr, head, end, f->d_packed);
   if (rc) return rc;
@@ -420,8 +489,6 @@ int vxba_create(int win_size, int device, vxba_factor** out) {
   if ((e = hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e);
   f->stream = f->own_stream;
   if (ensure_exchange(f) != VXBA_OK) return bail(hipErrorOutOfMemory);
-  if ((e = hipMalloc((void**)&f->own_scalar, sizeof(double))) != hipSuccess) return bail(e);
-  f->d_scalar = f->own_scalar;
   if ((e = hipMalloc((void**)&f->d_count, sizeof(unsigned long long))) != hipSuccess) return bail(e);
   if ((e = hipMalloc((void**)&f->d_poses, sizeof(double) * 12 * VXBA_MAX_WIN_WIDE)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc((void**)&f->h_poses, sizeof(double) * 12 * VXBA_MAX_WIN_WIDE, hipHostMallocDefault)) != hipSuccess) return bail(e);
@@ -442,7 +509,7 @@ int vxba_destroy(vxba_factor* f) {
   for (auto e : f->free_events) hipEventDestroy(e);
   hipFree(f->planes); hipFree(f->clb); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2);
   vxw::free_index(f->wide);
-  hipFree(f->own_packed); hipFree(f->own_scalar); hipFree(f->d_count); hipFree(f->d_poses);
+  hipFree(f->own_packed); hipFree(f->d_count); hipFree(f->d_poses);
   if (f->h_poses) hipHostFree(f->h_poses);
   if (f->h_packed) hipHostFree(f->h_packed);
   if (f->h_scalar) hipHostFree(f->h_scalar);
@@ -823,7 +890,18 @@ int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out
   int c = 0;
   vxk::LMPending pend;
   std::memset(&pend, 0, sizeof pend);
-  for (int i = 0; i < max_iter; i++) {
+  const bool spec = spec_collective(f);
+  int spec_nparts = 0;
+  for (int i = 0; spec && i < max_iter; i++) {
+    int rc = spec_hess_phase(f, Rp, &c, i == 0, i > 0, false, nullptr, spec_nparts);
+    if (rc) return rc;
+    const unsigned seq = fused_solve() ? ++f->lm_seq : 0u;
+    if (!seq) vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
+    rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, nullptr, &spec_nparts, seq);
+    if (rc) return rc;
+  }
+  if (spec && max_iter > 0) { int rc = spec_final_decision(f, Rp, &c, spec_nparts); if (rc) return rc; }
+  for (int i = 0; !spec && i < max_iter; i++) {
     int rc = sweep_hess_device(f, Rp, f->d_lm, &c, &pend, 0, f->V, f->d_packed);
     if (rc) return rc;
     // damped solve + residual sweep at the trial state: one launch (the solve is workgroup 0 of the sweep) unless
@@ -910,7 +988,22 @@ int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_
   int c = 0;
   vxk::LMPending pend;
   std::memset(&pend, 0, sizeof pend);
-  for (int s = 0; s < n_steps; s++) {
+  const bool spec = spec_collective(f);
+  int spec_nparts = 0;
+  bool prev_last = false;
+  for (int s = 0; spec && s < n_steps; s++) {
+    const bool first = (s % steps_per_solve) == 0;
+    const bool last = ((s + 1) % steps_per_solve) == 0 && s + 1 < n_steps;
+    int rc = spec_hess_phase(f, Rp_init, &c, first, s > 0, prev_last, first ? f->snapshot : nullptr, spec_nparts);
+    if (rc) return rc;
+    const unsigned seq = fused_solve() ? ++f->lm_seq : 0u;
+    if (!seq) vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
+    rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, nullptr, &spec_nparts, seq);
+    if (rc) return rc;
+    prev_last = last;
+  }
+  if (spec && n_steps > 0) { int rc = spec_final_decision(f, Rp_init, &c, spec_nparts); if (rc) return rc; }
+  for (int s = 0; !spec && s < n_steps; s++) {
     // a new window every steps_per_solve steps: its first Hessian sweep reads the SNAPSHOT cache directly (the re-seeded
     // cache of a new window -- no copy) and its prologue resets poses and damping (pend.restart of the previous step);
     // the residual sweeps keep writing the live cache

@@ -69,7 +69,9 @@ struct LMState {
 };
 // What a sweep needs to take the pending accept/reject decision in its prologue.
 struct LMPending {
-  int pending;                // 1: ctl[c] awaits the decision of the step whose residual sweep just ran
+  int pending;                // 1: ctl[c] awaits the decision of the step whose residual sweep just ran (taken in the sweep's prologue);
+                              // 2 / 3: sharded speculative loop -- no decision in the sweep, linearise at the trial poses (2) or at the
+                              // kernel-argument poses (3)
   int restart;                // 1: after the decision start a new window from restart_x0 (bench driver)
   const double* d_scalar;     // all-reduced residual2, or null: sum the nparts wave partials
   const double* partial;
@@ -112,7 +114,12 @@ int launch_k3_hessian(const FactorView& fv, const PoseArg& poses, LMState* st, i
                       int head, int end, double* d_partial, int nblocks, int mixed, hipStream_t s, hipEvent_t ev_start = nullptr,
                       hipEvent_t ev_stop = nullptr);
 // Cross-workgroup reduction + assembly of the packed [Hess (6W)^2 col-major | JacT 6W | residual] buffer.
-void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, int write_state, double* d_packed, hipStream_t s);
+// force: run even when the state says the sweep was not needed (sharded speculative loop); k2_partial: also leave the sum of the
+// residual sweep's wave partials in d_packed[(6W)^2 + 6W + 1].
+void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, int write_state, double* d_packed, hipStream_t s, int force = 0,
+                        const double* k2_partial = nullptr, int k2_nparts = 0);
+// Sharded speculative loop: decision for the pending trial from the reduced residual slot (into ctl[c_in ^ 1]) + adoption of the reduced system.
+void launch_lm_spec_unpack(LMState* st, int c_in, const double* d_packed, int W, int has_pending, int restart, const PoseArg& x0, hipStream_t s);
 // Voxel-sharded LM loop: fill the LM state (Hwork, Jwork, hess_out, residual1) from the ALL-REDUCED packed buffer (write_state
 // = 0 above); gated on the state's flags like the sweep itself.
 void launch_lm_unpack(LMState* st, int c, const double* d_packed, int W, hipStream_t s);

@@ -525,12 +525,16 @@ __global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, 
     const LMCtl& in = st->ctl[c_in];
     const int in_done = in.done, in_calc = in.calc_hess, bench = in.bench_mode;
     const double r1 = in.residual1;
-    const double* __restrict__ xa_src = (pend.pending && pend.restart) ? poses.Rp : in.x;
+    // pending: 0 none (linearise at in.x), 1 decide here, 2 / 3 sharded speculative loop: no decision here -- linearise at the
+    // trial poses (2) or at the kernel-argument poses (3, first sweep of a solve / window), skip only when the loop is done
+    const double* __restrict__ xa_src = ((pend.pending == 1 && pend.restart) || pend.pending == 3) ? poses.Rp : (pend.pending == 2 ? in.xt : in.x);
     double xa[12], xb[12] = {};
 #pragma unroll
     for (int k = 0; k < 12; k++) xa[k] = xa_src[12 * fi + k];
     bool use_b = false;
-    if (pend.pending) {
+    if (pend.pending >= 2) {
+      if (in_done) return;
+    } else if (pend.pending) {
 #pragma unroll
       for (int k = 0; k < 12; k++) xb[k] = in.xt[12 * fi + k];
       if (in_done) { if (blockIdx.x == gridDim.x - 1) lm_carry(st, c_in, W); return; }
@@ -664,7 +668,8 @@ __device__ __forceinline__ int sym6_index(int a, int b) { return a == 0 ? b : (a
 constexpr int FIN_EL = 16, FIN_SL = 64;   // FIN_EL * FIN_SL == 1024 threads
 template <int W>
 __global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restrict__ partial, int nblocks, LMState* __restrict__ gate, int cb,
-                                                           int write_state, double* __restrict__ packed) {
+                                                           int write_state, double* __restrict__ packed, int force, const double* __restrict__ k2_partial,
+                                                           int k2_nparts) {
   using C = K3Cfg<W>;
   // LM flags: requested now (vector loads: lane-dependent zero offset), tested after the partials are in flight
   const int zoff = threadIdx.x >> 30;
@@ -734,7 +739,22 @@ __global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restr
     }
   }
   if (!flags_checked) asm volatile("" : "+v"(f_done), "+v"(f_calc));
-  if (f_done || !f_calc) return;   // uniform over the grid
+  if (f_done || (!f_calc && !force)) return;   // uniform over the grid
+  // sharded speculative loop: the residual of the trial state (the residual sweep's wave partials) rides in the slot behind the
+  // packed buffer, so that ONE all-reduce carries the system and the number the accept/reject test needs
+  if (k2_partial && blockIdx.x == gridDim.x - 1) {
+    double sum = 0.0;
+    for (int k = threadIdx.x; k < k2_nparts; k += FIN_EL * FIN_SL) sum += k2_partial[k];
+    double* red = &red0[0][0];
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = (FIN_EL * FIN_SL) >> 1; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) packed[n * n + n + 1] = red[0];
+    __syncthreads();
+  }
   red0[slice][el] = s0;
   red1[slice][el] = s1;
   __syncthreads();
@@ -789,6 +809,47 @@ __global__ __launch_bounds__(256) void lm_unpack_kernel(LMState* __restrict__ st
     const double t0 = packed[e];
     st->ctl[cb].residual1 = t0;
     if (st->ctl[cb].iter == 0) st->ctl[cb].resis[0] = t0;
+  }
+}
+
+// Sharded speculative loop: the Hessian sweep that just ran linearised at the TRIAL poses without knowing whether they would be
+// accepted; the reduced buffer carries the system there AND (slot n^2+n+1) the trial residual.  Here the pending accept/reject
+// decision is taken (into the other control block) and the system is adopted if the step was accepted (or a new window starts,
+// or this is the first sweep of a solve); after a rejection the kept system stays and the sweep's work is discarded.
+__global__ __launch_bounds__(256) void lm_spec_unpack_kernel(LMState* __restrict__ st, int c_in, const double* __restrict__ packed, int W, int has_pending,
+                                                            int restart, PoseArg x0) {
+  const int n = 6 * W;
+  const LMCtl& in = st->ctl[c_in];
+  if (in.done) { if (has_pending && blockIdx.x == 0) lm_carry(st, c_in, W); return; }
+  // every workgroup takes the same decision from the same inputs; workgroup 0 persists it (into the other control block,
+  // so nobody reads what it writes)
+  int c_out = c_in;
+  bool adopt = true;
+  if (has_pending) {
+    const LMDecision d = lm_decide(in, packed[n * n + n + 1], restart);
+    if (blockIdx.x == 0) lm_persist(st, c_in, d, restart, x0, W);
+    adopt = (d.accept || restart) && !d.done;
+    c_out = c_in ^ 1;
+  }
+  if (!adopt) return;
+  if (blockIdx.x == 0) {
+    __syncthreads();   // lm_persist copied the old residual1 first
+    if (threadIdx.x == 0) {
+      const double t0 = packed[n * n + n];
+      st->ctl[c_out].residual1 = t0;
+      if (st->ctl[c_out].iter == 0) st->ctl[c_out].resis[0] = t0;
+    }
+  }
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n * n + n; e += gridDim.x * 256) {
+    if (e < n * n) {
+      const int r = e % n, c = e / n;
+      const double h = packed[e];
+      st->hess_out[e] = h;
+      st->Hwork[e] = (r < 6 || c < 6) ? ((r == c) ? 1.0 : 0.0) : h;
+    } else {
+      const int i = e - n * n;
+      st->Jwork[i] = i < 6 ? 0.0 : packed[e];
+    }
   }
 }
 
@@ -1272,9 +1333,15 @@ int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, LMState* st
   return nblocks;
 }
 
-void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, int write_state, double* d_packed, hipStream_t s) {
+void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, int write_state, double* d_packed, hipStream_t s, int force,
+                        const double* k2_partial, int k2_nparts) {
   const int plen = (int)k3_partial_len(W);
-  VXK_DISPATCH_W(W, k3_finalize_kernel<WW><<<dim3((plen + FIN_EL - 1) / FIN_EL), dim3(FIN_EL * FIN_SL), 0, s>>>(d_partial, nblocks, st, c, write_state, d_packed));
+  VXK_DISPATCH_W(W, k3_finalize_kernel<WW><<<dim3((plen + FIN_EL - 1) / FIN_EL), dim3(FIN_EL * FIN_SL), 0, s>>>(d_partial, nblocks, st, c, write_state, d_packed,
+                                                                                                           force, k2_partial, k2_nparts));
+}
+void launch_lm_spec_unpack(LMState* st, int c_in, const double* d_packed, int W, int has_pending, int restart, const PoseArg& x0, hipStream_t s) {
+  const int n = 6 * W;
+  lm_spec_unpack_kernel<<<dim3((n * n + n + 255) / 256), dim3(256), 0, s>>>(st, c_in, d_packed, W, has_pending, restart, x0);
 }
 void launch_lm_unpack(LMState* st, int c, const double* d_packed, int W, hipStream_t s) {
   const int n = 6 * W, total = n * n + n + 1;

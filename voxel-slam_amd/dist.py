@@ -35,7 +35,9 @@ def attach_allreduce(factor, group=None):
     factor.use_external_buffers(packed_t.data_ptr(), scalar_t.data_ptr())
 
     def hook(_ptr, count, _stream):
-        dist.all_reduce(packed_t if count > 1 else scalar_t, group=group)
+        # count == 1: the residual scalar; count == n: the packed system; count == n + 1: both in one collective (the scalar
+        # sits directly behind the packed buffer, which is what lets the device-resident loop merge them)
+        dist.all_reduce(scalar_t if count == 1 else xbuf[:count], group=group)
 
     factor.set_allreduce(hook)
     return xbuf, packed_t, scalar_t
