@@ -57,6 +57,8 @@ struct vxba_factor {
   double* h_scalar = nullptr;    // pinned
   vxk::LMState* d_lm = nullptr;  // device-resident LM shell state
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
+  vxw::DenseSolver* wide_solver = nullptr;   // wide windows: device Cholesky of the (6W)-dimensional LM step (hipSOLVER, loaded on first use)
+  bool wide_solver_tried = false;
   vxw::WideIndex wide;           // wide windows: incidence structure (entries, entry pairs per Hessian block), rebuilt after a push
   bool wide_dirty = true;
   double* d_poses = nullptr;     // wide windows: W*12 poses on the device (the MFMA kernels take them by value)
@@ -509,6 +511,7 @@ int vxba_destroy(vxba_factor* f) {
   for (auto e : f->free_events) hipEventDestroy(e);
   hipFree(f->planes); hipFree(f->clb); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2);
   vxw::free_index(f->wide);
+  vxw::wide_solver_free(f->wide_solver);
   hipFree(f->own_packed); hipFree(f->d_count); hipFree(f->d_poses);
   if (f->h_poses) hipHostFree(f->h_poses);
   if (f->h_packed) hipHostFree(f->h_packed);
@@ -866,20 +869,79 @@ int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out
   if (f->V == 0) return fail(f, VXBA_ERR_STATE, "damping_iter on an empty factor");
   hipSetDevice(f->device);
   if (is_wide(f)) {
-    // wide window: sweeps on the GPU, the (6W)-dimensional LM shell on the host (Eigen-style pivoted LDL^T), as the reference
-    // runs it (voxel_map.hpp:367-442); 2 syncs + 2 small D2H per iteration
-    auto hess_cb = [](void* ctx, const double* xs, double* packed) -> int {
-      vxba_factor* g = (vxba_factor*)ctx;
-      if (sweep_hess_host(g, xs, 0, g->V) != VXBA_OK) return 1;
-      std::memcpy(packed, g->h_packed, vxba_packed_len(g) * sizeof(double));
-      return 0;
-    };
-    auto resid_cb = [](void* ctx, const double* xs, double* r) -> int {
-      vxba_factor* g = (vxba_factor*)ctx;
-      return sweep_residual_host(g, xs, 0, g->V, r) == VXBA_OK ? 0 : 1;
-    };
-    const int rcw = vxba_damping_iter_generic(f->W, Rp, max_iter, hess_cb, resid_cb, f, hess_out, resis_out, trace_out, n_trace, is_converge);
-    return rcw == VXBA_OK ? VXBA_OK : (f->err.empty() ? fail(f, rcw, "damping_iter (wide): sweep failed") : rcw);
+    // wide window (voxel_map.hpp:367-442 unchanged in structure): sweeps on the GPU; the damped (6W)-dimensional step by a dense
+    // device Cholesky (only dxi, q1 and residual1 come back: ~5 KB) or, if that is unavailable / the system is not positive
+    // definite, by the host's pivoted LDL^T on the downloaded system; accept/reject on the host.
+    const int W = f->W, n = 6 * W;
+    if (!f->wide_solver && !f->wide_solver_tried) {
+      // opt-in: the first use pulls hipSOLVER + rocSOLVER + rocBLAS into the process, which costs seconds when they are warm and
+      // minutes when they come off a cold disk -- worth it for a long-running mapper, not for a default
+      const char* wenv = getenv("VXBA_WIDE_DEVICE_SOLVE");
+      const bool allow = wenv && wenv[0] == '1';
+      if (allow) f->wide_solver = vxw::wide_solver_create(n, f->stream);
+      f->wide_solver_tried = true;
+    }
+    double u = 0.01, v = 2;
+    std::vector<double> x(Rp, Rp + 12 * W), x_temp(x), dxi(n), Hh, Jh;
+    vxh::LMWorkspace ws;
+    double residual1 = 0, residual2 = 0, q1 = 0;
+    bool is_calc_hess = true, converge = true, host_copy_valid = false;
+    int nt = 0;
+    for (int i = 0; i < max_iter; i++) {
+      const bool recomputed = is_calc_hess;
+      if (is_calc_hess) {
+        int rc = sweep_hess_device(f, x.data(), nullptr, nullptr, nullptr, 0, f->V, f->d_packed);
+        if (rc) return rc;
+        host_copy_valid = false;
+      }
+      bool on_device = false;
+      if (f->wide_solver) {
+        double r1 = 0;
+        on_device = vxw::wide_solver_step(f->wide_solver, f->d_packed, u, f->stream, dxi.data(), &q1, &r1) == 0;
+        if (on_device) {
+          if (is_calc_hess) residual1 = r1;
+          for (int j = 0; j < W; j++) {
+            vxh::right_multiply_exp(&x[12 * j], &dxi[6 * j], &x_temp[12 * j]);
+            for (int k = 0; k < 3; k++) x_temp[12 * j + 9 + k] = x[12 * j + 9 + k] + dxi[6 * j + 3 + k];
+          }
+        }
+      }
+      if (!on_device) {
+        if (!host_copy_valid) {
+          VX_HIP(f, hipMemcpyAsync(f->h_packed, f->d_packed, vxba_packed_len(f) * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+          VX_HIP(f, hipStreamSynchronize(f->stream));
+          Hh.assign(f->h_packed, f->h_packed + (size_t)n * n);
+          Jh.assign(f->h_packed + (size_t)n * n, f->h_packed + (size_t)n * n + n);
+          if (is_calc_hess) residual1 = f->h_packed[(size_t)n * n + n];
+          host_copy_valid = true;
+        }
+        q1 = vxh::lm_damped_step(W, Hh.data(), Jh.data(), u, x.data(), x_temp.data(), ws);
+      }
+      if (i == 0 && resis_out) resis_out[0] = residual1;
+      int rc = sweep_residual_host(f, x_temp.data(), 0, f->V, &residual2);
+      if (rc) return rc;
+      const double q = residual1 - residual2;
+      const double u_used = u, v_used = v;
+      const bool accepted = vxh::lm_update_damping(residual1, residual2, q1, u, v);
+      if (accepted) { x = x_temp; is_calc_hess = true; }
+      else { is_calc_hess = false; converge = false; }
+      if (trace_out) {
+        double* o = trace_out + (size_t)VXBA_TRACE_COLS * nt;
+        o[0] = residual1; o[1] = residual2; o[2] = u_used; o[3] = v_used; o[4] = q; o[5] = q1; o[6] = accepted; o[7] = recomputed;
+      }
+      nt++;
+      if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
+    }
+    if (hess_out) {   // *hess = the last Hessian that was computed, before the gauge fix (voxel_map.hpp:391)
+      VX_HIP(f, hipMemcpyAsync(f->h_packed, f->d_packed, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+      VX_HIP(f, hipStreamSynchronize(f->stream));
+      std::memcpy(hess_out, f->h_packed, sizeof(double) * n * n);
+    }
+    if (resis_out) resis_out[1] = residual2;
+    if (n_trace) *n_trace = nt;
+    if (is_converge) *is_converge = converge ? 1 : 0;
+    std::memcpy(Rp, x.data(), sizeof(double) * 12 * W);
+    return VXBA_OK;
   }
   const int W = f->W, n = 6 * W;
   PoseArg x0;

@@ -36,4 +36,11 @@ void free_index(WideIndex& wi);
 void launch_k3_wide(const vxk::FactorView& fv, const double* d_poses, const WideIndex& wi, int head, int end, double* d_packed, double* d_partial,
                     hipStream_t s);
 
+// Device-side damped step of the wide LM shell ((H + u D) dxi = -JacT after the gauge fix; dense Cholesky from hipSOLVER, loaded on
+// first use).  create returns nullptr if the library cannot be used; step returns non-zero if this step must be taken on the host.
+struct DenseSolver;
+DenseSolver* wide_solver_create(int n, hipStream_t s);
+void wide_solver_free(DenseSolver*& ds);
+int wide_solver_step(DenseSolver* ds, const double* d_packed, double u, hipStream_t s, double* dxi, double* q1, double* residual1);
+
 }  // namespace vxw

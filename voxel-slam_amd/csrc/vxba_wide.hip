@@ -7,6 +7,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <dlfcn.h>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -389,6 +390,126 @@ void launch_k3_wide(const FactorView& fv, const double* d_poses, const WideIndex
   const int nparts = (end - head + 63) / 64;
   k3w_residual_kernel<<<dim3(nparts), dim3(64), 0, s>>>(fv, head, end, d_partial);
   k3w_residual_sum_kernel<<<dim3(1), dim3(256), 0, s>>>(d_partial, nparts, d_packed + (size_t)n * n + n);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Dense solve of the wide LM step on the device: (H + u D) dxi = -JacT with the gauge rows / columns replaced by identity,
+// n = 6W up to 768.  A plain dense Cholesky -- taken from the vendor library (hipSOLVER potrf / potrs, resolved with dlopen on
+// first use so that narrow-window users never load it); the assembly of the damped system, the gain-ratio denominator q1 and the
+// checks stay here.  Falls back to the host LDL^T when the library is missing or the factorisation reports a non-positive pivot.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void wide_prepare_kernel(const double* __restrict__ packed, int n, double u, double* __restrict__ A, double* __restrict__ b, double* __restrict__ dvec) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (long long)n * n) {
+    const int r = (int)(t % n), c = (int)(t / n);
+    double h = (r < 6 || c < 6) ? ((r == c) ? 1.0 : 0.0) : packed[t];     // gauge fix on frame 0 (voxel_map.hpp:397-400)
+    if (r == c) { dvec[r] = h; h += u * h; }                                // D = diag(H), A = H + u D (:402-403)
+    A[t] = h;
+  } else if (t < (long long)n * n + n) {
+    const int i = (int)(t - (long long)n * n);
+    b[i] = i < 6 ? 0.0 : -packed[t];
+  }
+}
+// out[0..n) = dxi, out[n] = q1 = 0.5 dxi . (u D dxi - JacT), out[n+1] = residual1 (packed's last slot)
+__global__ __launch_bounds__(256) void wide_q1_kernel(const double* __restrict__ packed, const double* __restrict__ dxi, const double* __restrict__ dvec, int n,
+                                                      double u, double* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const double d = dxi[r];
+    out[r] = d;
+    const double j = r < 6 ? 0.0 : packed[(size_t)n * n + r];
+    s += d * (u * dvec[r] * d - j);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[n] = 0.5 * red[0]; out[n + 1] = packed[(size_t)n * n + n]; }
+}
+
+typedef int (*fn_create)(void**);
+typedef int (*fn_destroy)(void*);
+typedef int (*fn_setstream)(void*, hipStream_t);
+typedef int (*fn_potrf_bs)(void*, int, int, double*, int, int*);
+typedef int (*fn_potrf)(void*, int, int, double*, int, double*, int, int*);
+typedef int (*fn_potrs)(void*, int, int, int, const double*, int, double*, int, int*);
+
+struct DenseSolver {
+  void* lib = nullptr;
+  void* handle = nullptr;
+  fn_destroy destroy = nullptr;
+  fn_setstream setstream = nullptr;
+  fn_potrf_bs potrf_bs = nullptr;
+  fn_potrf potrf = nullptr;
+  fn_potrs potrs = nullptr;
+  double *d_A = nullptr, *d_b = nullptr, *d_dvec = nullptr, *d_work = nullptr, *d_out = nullptr, *h_out = nullptr;
+  int* d_info = nullptr;
+  int* h_info = nullptr;
+  int n = 0, lwork = 0;
+};
+
+void wide_solver_free(DenseSolver*& ds) {
+  if (!ds) return;
+  if (ds->handle && ds->destroy) ds->destroy(ds->handle);
+  void* ptrs[] = {ds->d_A, ds->d_b, ds->d_dvec, ds->d_work, ds->d_out, ds->d_info};
+  for (void* q : ptrs) if (q) (void)hipFree(q);
+  if (ds->h_out) (void)hipHostFree(ds->h_out);
+  if (ds->h_info) (void)hipHostFree(ds->h_info);
+  if (ds->lib) dlclose(ds->lib);
+  delete ds;
+  ds = nullptr;
+}
+
+// nullptr if the library cannot be used (caller falls back to the host solve)
+DenseSolver* wide_solver_create(int n, hipStream_t s) {
+  DenseSolver* ds = new DenseSolver();
+  ds->n = n;
+  ds->lib = dlopen("libhipsolver.so", RTLD_NOW | RTLD_LOCAL);
+  if (!ds->lib) ds->lib = dlopen("/opt/rocm/lib/libhipsolver.so", RTLD_NOW | RTLD_LOCAL);
+  if (!ds->lib) { wide_solver_free(ds); return nullptr; }
+  fn_create create = (fn_create)dlsym(ds->lib, "hipsolverDnCreate");
+  ds->destroy = (fn_destroy)dlsym(ds->lib, "hipsolverDnDestroy");
+  ds->setstream = (fn_setstream)dlsym(ds->lib, "hipsolverDnSetStream");
+  ds->potrf_bs = (fn_potrf_bs)dlsym(ds->lib, "hipsolverDnDpotrf_bufferSize");
+  ds->potrf = (fn_potrf)dlsym(ds->lib, "hipsolverDnDpotrf");
+  ds->potrs = (fn_potrs)dlsym(ds->lib, "hipsolverDnDpotrs");
+  if (!create || !ds->destroy || !ds->setstream || !ds->potrf_bs || !ds->potrf || !ds->potrs || create(&ds->handle) != 0) { wide_solver_free(ds); return nullptr; }
+  bool ok = ds->setstream(ds->handle, s) == 0;
+  ok = ok && hipMalloc((void**)&ds->d_A, sizeof(double) * n * n) == hipSuccess && hipMalloc((void**)&ds->d_b, sizeof(double) * n) == hipSuccess &&
+       hipMalloc((void**)&ds->d_dvec, sizeof(double) * n) == hipSuccess && hipMalloc((void**)&ds->d_out, sizeof(double) * (n + 2)) == hipSuccess &&
+       hipMalloc((void**)&ds->d_info, sizeof(int)) == hipSuccess && hipHostMalloc((void**)&ds->h_out, sizeof(double) * (n + 2), hipHostMallocDefault) == hipSuccess &&
+       hipHostMalloc((void**)&ds->h_info, sizeof(int), hipHostMallocDefault) == hipSuccess;
+  constexpr int FILL_LOWER = 122;   // HIPBLAS_FILL_MODE_LOWER
+  ok = ok && ds->potrf_bs(ds->handle, FILL_LOWER, n, ds->d_A, n, &ds->lwork) == 0;
+  ok = ok && hipMalloc((void**)&ds->d_work, sizeof(double) * (ds->lwork > 0 ? ds->lwork : 1)) == hipSuccess;
+  if (!ok) { wide_solver_free(ds); return nullptr; }
+  return ds;
+}
+
+// One damped step from the packed buffer on the device.  Host outputs: dxi (n), *q1, *residual1.  Returns 0, or 1 if the
+// factorisation failed (not positive definite) / a library call failed -- the caller then takes the host path for this step.
+int wide_solver_step(DenseSolver* ds, const double* d_packed, double u, hipStream_t s, double* dxi, double* q1, double* residual1) {
+  const int n = ds->n;
+  constexpr int FILL_LOWER = 122;
+  const long long tot = (long long)n * n + n;
+  wide_prepare_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s>>>(d_packed, n, u, ds->d_A, ds->d_b, ds->d_dvec);
+  if (ds->setstream(ds->handle, s) != 0) return 1;
+  if (ds->potrf(ds->handle, FILL_LOWER, n, ds->d_A, n, ds->d_work, ds->lwork, ds->d_info) != 0) return 1;
+  if (hipMemcpyAsync(ds->h_info, ds->d_info, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
+  if (ds->potrs(ds->handle, FILL_LOWER, n, 1, ds->d_A, n, ds->d_b, n, ds->d_info) != 0) return 1;
+  wide_q1_kernel<<<dim3(1), dim3(256), 0, s>>>(d_packed, ds->d_b, ds->d_dvec, n, u, ds->d_out);
+  if (hipMemcpyAsync(ds->h_out, ds->d_out, sizeof(double) * (n + 2), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
+  if (hipStreamSynchronize(s) != hipSuccess) return 1;
+  if (*ds->h_info != 0) return 1;
+  std::memcpy(dxi, ds->h_out, sizeof(double) * n);
+  *q1 = ds->h_out[n];
+  *residual1 = ds->h_out[n + 1];
+  for (int r = 0; r < n; r++) if (!(dxi[r] == dxi[r])) return 1;   // NaN guard
+  return 0;
 }
 
 }  // namespace vxw
