@@ -252,6 +252,57 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
 #define VXBA_PRECISION_MIXED 1
 int vxba_set_precision(vxba_factor* f, int mode);
 
+/* ---- odometry: point-to-plane state estimation against the voxel plane map ---------------- */
+/* Replaces `lio_state_estimation` (voxelslam.cpp:855-958): per EKF iteration every scan point is transformed with the
+ * current pose, matched to the plane of the octree leaf it falls into (`match`, voxel_map.hpp:1335-1392, 1674-1698) and
+ * the matched points' information is summed into HTH (6x6), HTz (6) and nnt (3x3).  The map walk (float-typed voxel index,
+ * `wld > voxel_center` descent, float-typed distance tests, the per-point node cache `octos[i]` + `inside` :1471-1480) is
+ * reproduced exactly, on a flattened map held in GPU memory.  The 15-dimensional EKF algebra between the sweeps runs on
+ * the host.  No CPU fallback.
+ *   state : VXBA_STATE_LEN f64 as above [R 9 col-major | p 3 | v 3 | bg 3 | ba 3 | g 3]      <- IMUST, tools.hpp:135-199
+ *   cov   : 15x15 f64 col-major, tangent order [dphi dp dv dbg dba]                          <- IMUST::cov
+ *   sweep : VXBA_LIO_SWEEP_LEN f64 = [HTH 36 col-major | HTz 6 | nnt 9 col-major | match_num] */
+typedef struct vxba_lio vxba_lio; /* opaque: one plane map (`surf_map`) + the current scan (`pptr`) */
+#define VXBA_LIO_SWEEP_LEN 52
+#define VXBA_LIO_MAX_ITER 4 /* num_max_iter, voxelslam.cpp:859 */
+
+/* voxel_size / max_layer: the reference's globals (voxel_map.hpp:86-88; max_layer <= 3 here). */
+int vxba_lio_create(double voxel_size, int max_layer, int device, vxba_lio** out);
+int vxba_lio_destroy(vxba_lio* h);
+const char* vxba_lio_last_error(const vxba_lio* h);
+
+/* The plane map, flattened: one entry per octree leaf (OctoTree with octo_state == 0) that the walk can reach.
+ *   loc n*3       root voxel, the VOXEL_LOC key of `surf_map` (tools.hpp:24-35); |index| < 2^20
+ *   layer n       depth of the leaf, 0 = the root voxel itself
+ *   path n        `leafnum` taken at each level on the way down (voxel_map.hpp:1371), 3 bits per level, first level lowest
+ *   is_plane n    Plane::is_plane; 0 removes the leaf's plane (NULL = all ones)
+ *   center, normal n*3, plane_var n*36 col-major, radius n  <- struct Plane (voxel_map.hpp:66-80; radius is a float there)
+ * Upsert: a leaf seen before has its plane replaced.  When the host tree splits a leaf, remove it (is_plane = 0) in an
+ * earlier call than the one that adds its children.  Plane records are reclaimed by vxba_lio_map_clear only. */
+int vxba_lio_map_update(vxba_lio* h, int64_t n, const int64_t* loc, const int32_t* layer, const int32_t* path, const int32_t* is_plane,
+                        const double* center, const double* normal, const double* plane_var, const double* radius);
+int vxba_lio_map_clear(vxba_lio* h);
+int vxba_lio_map_size(const vxba_lio* h, int64_t* n_roots, int64_t* n_planes);
+
+/* The scan.  _raw = var_init (voxelslam.hpp:187-201): sensor-frame float points -> calcBodyVar (:164-185; dept_err / beam_err are
+ * narrowed to float as there) -> extrinsic ext = [R 9 col-major | p 3] (NULL = identity).  _set takes ready pointVar arrays
+ * (pnt n*3, var n*9 col-major; voxel_map.hpp:14-19).  _read returns what the sweeps use. */
+int vxba_lio_scan_raw(vxba_lio* h, int64_t n, const float* xyz, const double* ext, double dept_err, double beam_err);
+int vxba_lio_scan_set(vxba_lio* h, int64_t n, const double* pnt, const double* var);
+int64_t vxba_lio_scan_size(const vxba_lio* h);
+int vxba_lio_scan_read(vxba_lio* h, double* pnt, double* var);
+
+/* One pass of the loop body voxelslam.cpp:873-919 under (state, cov).  reset_cache != 0 forgets the per-point node cache first
+ * (the reference starts every lio_state_estimation call with an empty one).  plane_of_point (index of the matched leaf's plane
+ * record = order of first insertion, -1 = no match) and sigma_of_point may both be NULL. */
+int vxba_lio_sweep(vxba_lio* h, const double* state, const double* cov, int reset_cache, double* sweep, int32_t* plane_of_point,
+                   double* sigma_of_point);
+/* lio_state_estimation: state and cov in/out (x_curr).  info[4] = [ok (nnt's smallest eigenvalue >= 14, :951-957), iterations,
+ * match_num of the last sweep, that eigenvalue]; sweeps_out VXBA_LIO_MAX_ITER * VXBA_LIO_SWEEP_LEN.  Both may be NULL. */
+int vxba_lio_state_estimation(vxba_lio* h, double* state, double* cov, double* info, double* sweeps_out);
+/* pvec_update (voxelslam.hpp:203-215): world points (n*3) and world covariances (n*9 col-major) of the scan under (state, cov). */
+int vxba_lio_pvec_update(vxba_lio* h, const double* state, const double* cov, double* pwld, double* var);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* Bit mask of kernels to bracket with hipEvents on the launch stream: 1 = Hessian sweep (K3), 2 = residual sweep (K2),
  * 4 = K3 cross-block reduction, 8 = cluster build (K1); 0 = off. */

@@ -12,6 +12,7 @@
 
 #include "vxo_ba.hpp"
 #include "vxo_imu.hpp"
+#include "vxo_lio.hpp"
 #include "vxo_voxelize.hpp"
 
 using namespace vxo;
@@ -413,6 +414,125 @@ int64_t vxo_voxelize(int W, int64_t n_points, const double* xyz_local, const int
     pack_cluster(f.pcr_add, merged + 10 * a);
   }
   return n;
+}
+
+// ---- odometry point-to-plane update (vxo_lio.hpp) ------------------------------------------------------------------------
+namespace {
+struct LioHandle {
+  PlaneMap map;
+  std::vector<PointVar> pts;
+  std::vector<OctoNode*> octos;
+};
+void pack_sweep(const LioSweep& sw, double* out) {   // [HTH 36 col-major | HTz 6 | nnt 9 col-major | match_num]
+  std::memcpy(out, sw.HTH, sizeof(double) * 36);
+  std::memcpy(out + 36, sw.HTz, sizeof(double) * 6);
+  std::memcpy(out + 42, sw.nnt, sizeof(double) * 9);
+  out[51] = (double)sw.match_num;
+}
+M3 block33(const double* cov225, int r0) { M3 m; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) m(r, c) = cov225[15 * (r0 + c) + r0 + r]; return m; }
+}  // namespace
+
+void* vxo_lio_create(double voxel_size, int max_layer) {
+  LioHandle* h = new LioHandle();
+  h->map.prm.voxel_size = voxel_size; h->map.prm.max_layer = max_layer;
+  return h;
+}
+void vxo_lio_destroy(void* h) { delete (LioHandle*)h; }
+void vxo_lio_map_add(void* hv, int64_t n, const int64_t* loc, const int32_t* layer, const int32_t* path, const int32_t* is_plane, const double* center,
+                     const double* normal, const double* plane_var, const double* radius) {
+  LioHandle* h = (LioHandle*)hv;
+  for (int64_t i = 0; i < n; i++) h->map.add_leaf(loc + 3 * i, layer[i], path[i], is_plane ? is_plane[i] : 1, center + 3 * i, normal + 3 * i, plane_var + 36 * i, radius[i]);
+}
+void vxo_lio_scan_set(void* hv, int64_t n, const double* pnt, const double* var9) {
+  LioHandle* h = (LioHandle*)hv;
+  h->pts.resize(n);
+  for (int64_t i = 0; i < n; i++) { h->pts[i].pnt = unpack_v3(pnt + 3 * i); h->pts[i].var = unpack_m3_colmajor(var9 + 9 * i); }
+  h->octos.assign(n, nullptr);
+}
+void vxo_lio_scan_raw(void* hv, int64_t n, const float* xyz, const double* ext12, double dept_err, double beam_err) {
+  LioHandle* h = (LioHandle*)hv;
+  var_init(unpack_m3_colmajor(ext12), unpack_v3(ext12 + 9), n, xyz, (float)dept_err, (float)beam_err, h->pts);
+  h->octos.assign(n, nullptr);
+}
+int64_t vxo_lio_scan_size(void* hv) { return (int64_t)((LioHandle*)hv)->pts.size(); }
+void vxo_lio_scan_read(void* hv, double* pnt, double* var9) {
+  LioHandle* h = (LioHandle*)hv;
+  for (size_t i = 0; i < h->pts.size(); i++) {
+    for (int k = 0; k < 3; k++) pnt[3 * i + k] = h->pts[i].pnt[k];
+    pack_m3_colmajor(h->pts[i].var, var9 + 9 * i);
+  }
+}
+// one pass of voxelslam.cpp:873-919; state = VXBA state layout [R 9 | p 3 | ...], cov 15x15 col-major
+void vxo_lio_sweep(void* hv, const double* state, const double* cov225, int reset_cache, double* out52, int32_t* plane_of_point, double* sigma_of_point) {
+  LioHandle* h = (LioHandle*)hv;
+  if (reset_cache) h->octos.assign(h->pts.size(), nullptr);
+  ImuState x = unpack_state(state);
+  LioSweep sw;
+  std::vector<int> pop(h->pts.size(), -1);
+  std::vector<double> sig(h->pts.size(), 0.0);
+  lio_sweep(h->map, h->pts, x, block33(cov225, 0), block33(cov225, 3), h->octos, sw, &pop, &sig);
+  pack_sweep(sw, out52);
+  if (plane_of_point) for (size_t i = 0; i < pop.size(); i++) plane_of_point[i] = pop[i];
+  if (sigma_of_point) for (size_t i = 0; i < sig.size(); i++) sigma_of_point[i] = sig[i];
+}
+// lio_state_estimation (voxelslam.cpp:855-958).  info = [ok, iterations, match_num, min eigenvalue of nnt]; sweeps_out 4 x 52.
+void vxo_lio_state_estimation(void* hv, double* state, double* cov225, double* info, double* sweeps_out, int32_t* plane_of_point, double* sigma_of_point) {
+  LioHandle* h = (LioHandle*)hv;
+  LioState st;
+  st.x = unpack_state(state);
+  std::memcpy(st.cov.a.data(), cov225, sizeof(double) * 225);
+  LioResult r = lio_state_estimation(h->map, h->pts, st);
+  pack_state(st.x, state);
+  std::memcpy(cov225, st.cov.a.data(), sizeof(double) * 225);
+  info[0] = r.ok ? 1.0 : 0.0; info[1] = r.iterations; info[2] = r.match_num; info[3] = r.min_eig;
+  if (sweeps_out) for (size_t k = 0; k < r.sweeps.size(); k++) pack_sweep(r.sweeps[k], sweeps_out + 52 * k);
+  if (plane_of_point) for (size_t i = 0; i < r.plane_of_point.size(); i++) plane_of_point[i] = r.plane_of_point[i];
+  if (sigma_of_point) for (size_t i = 0; i < r.sigma_of_point.size(); i++) sigma_of_point[i] = r.sigma_of_point[i];
+}
+double vxo_time_lio_state_estimation(void* hv, const double* state, const double* cov225, int reps) {
+  LioHandle* h = (LioHandle*)hv;
+  double best = 1e300;
+  for (int k = 0; k < reps; k++) {
+    LioState st;
+    st.x = unpack_state(state);
+    std::memcpy(st.cov.a.data(), cov225, sizeof(double) * 225);
+    auto t0 = std::chrono::steady_clock::now();
+    LioResult r = lio_state_estimation(h->map, h->pts, st);
+    best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    if (r.iterations < 0) return -1;
+  }
+  return best;
+}
+void vxo_lio_pvec_update(void* hv, const double* state, const double* cov225, double* pwld, double* var9) {
+  LioHandle* h = (LioHandle*)hv;
+  std::vector<PointVar> w;
+  pvec_update(h->pts, unpack_state(state), block33(cov225, 0), block33(cov225, 3), w);
+  for (size_t i = 0; i < w.size(); i++) {
+    for (int k = 0; k < 3; k++) pwld[3 * i + k] = w[i].pnt[k];
+    pack_m3_colmajor(w[i].var, var9 + 9 * i);
+  }
+}
+// cov_add of OctoTree::push (voxel_map.hpp:990-992): sum of Bf_var over the points of each cell, 81 f64 col-major per cell
+void vxo_cov_add_build(int64_t n_cells, const int64_t* cell_ptr, const double* xyz_world, const double* var9, double* cov_add) {
+  for (int64_t c = 0; c < n_cells; c++) {
+    double acc[81] = {0}, b[81];
+    for (int64_t q = cell_ptr[c]; q < cell_ptr[c + 1]; q++) {
+      bf_var(unpack_m3_colmajor(var9 + 9 * q), unpack_v3(xyz_world + 3 * q), b);
+      for (int i = 0; i < 81; i++) acc[i] += b[i];
+    }
+    std::memcpy(cov_add + 81 * c, acc, sizeof acc);
+  }
+}
+// OctoTree::plane_update (voxel_map.hpp:1118-1146), batched
+void vxo_plane_update(int64_t n, const double* clusters, const double* eig_val, const double* eig_vec, const double* cov_add, double* center, double* normal,
+                      double* plane_var, double* radius) {
+  for (int64_t a = 0; a < n; a++) {
+    PointCluster pc = unpack_cluster(clusters + 10 * a);
+    float rad;
+    plane_update(pc.P, pc.v, (double)pc.N, unpack_v3(eig_val + 3 * a), unpack_m3_colmajor(eig_vec + 9 * a), cov_add + 81 * a, center + 3 * a, normal + 3 * a,
+                 plane_var + 36 * a, rad);
+    radius[a] = rad;
+  }
 }
 
 }  // extern "C"

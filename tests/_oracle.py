@@ -66,6 +66,24 @@ def lib():
     L.vxo_voxelize.restype = C.c_int64
     L.vxo_voxelize.argtypes = [C.c_int, C.c_int64, f64p, i64p, f64p, f64p, C.c_int64, np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS"),
                                f64p, f64p, f64p, f64p]
+    i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    vp = C.c_void_p
+    L.vxo_lio_create.restype = vp
+    L.vxo_lio_create.argtypes = [C.c_double, C.c_int]
+    L.vxo_lio_destroy.argtypes = [vp]
+    L.vxo_lio_map_add.argtypes = [vp, C.c_int64, i64p, i32p, i32p, vp, f64p, f64p, f64p, f64p]
+    L.vxo_lio_scan_set.argtypes = [vp, C.c_int64, f64p, f64p]
+    L.vxo_lio_scan_raw.argtypes = [vp, C.c_int64, np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS"), f64p, C.c_double, C.c_double]
+    L.vxo_lio_scan_size.restype = C.c_int64
+    L.vxo_lio_scan_size.argtypes = [vp]
+    L.vxo_lio_scan_read.argtypes = [vp, f64p, f64p]
+    L.vxo_lio_sweep.argtypes = [vp, f64p, f64p, C.c_int, f64p, i32p, f64p]
+    L.vxo_lio_state_estimation.argtypes = [vp, f64p, f64p, f64p, f64p, i32p, f64p]
+    L.vxo_time_lio_state_estimation.restype = C.c_double
+    L.vxo_time_lio_state_estimation.argtypes = [vp, f64p, f64p, C.c_int]
+    L.vxo_lio_pvec_update.argtypes = [vp, f64p, f64p, f64p, f64p]
+    L.vxo_cov_add_build.argtypes = [C.c_int64, i64p, f64p, f64p, f64p]
+    L.vxo_plane_update.argtypes = [C.c_int64, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p]
     _LIB = L
     return L
 
@@ -273,3 +291,100 @@ def voxelize(W, xyz_local, frame_ptr, Rp, params9):
         raise ValueError("voxel coordinates out of range")
     assert n <= cap
     return dict(node_id=ids[:n].copy(), clusters=cl[:n].copy(), eig_val=ev[:n].copy(), eig_vec=U[:n].copy(), merged=m[:n].copy())
+
+
+def _unpack_sweep(sw):
+    return {"HTH": sw[:36].reshape(6, 6).T.copy(), "HTz": sw[36:42].copy(), "nnt": sw[42:51].reshape(3, 3).T.copy(), "match_num": int(sw[51])}
+
+
+class LioOracle:
+    """lio_state_estimation + match on the CPU (oracle/vxo_lio.hpp), same call shapes as vxba.LioEstimator."""
+
+    def __init__(self, voxel_size=1.0, max_layer=2):
+        self._h = C.c_void_p(lib().vxo_lio_create(float(voxel_size), int(max_layer)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().vxo_lio_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def map_update(self, loc, layer, path, center, normal, plane_var, radius, is_plane=None):
+        loc = np.ascontiguousarray(loc, dtype=np.int64).reshape(-1, 3)
+        n = loc.shape[0]
+        pv = np.ascontiguousarray(np.transpose(np.asarray(plane_var, dtype=np.float64).reshape(n, 6, 6), (0, 2, 1)))
+        isp = None if is_plane is None else np.ascontiguousarray(is_plane, dtype=np.int32)
+        lib().vxo_lio_map_add(self._h, n, loc, np.ascontiguousarray(layer, dtype=np.int32), np.ascontiguousarray(path, dtype=np.int32),
+                              None if isp is None else isp.ctypes.data_as(C.c_void_p), _c(center), _c(normal), pv, _c(radius))
+
+    def var_init(self, xyz, ext_R=None, ext_p=None, dept_err=0.02, beam_err=0.05):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        R = np.eye(3) if ext_R is None else np.asarray(ext_R, dtype=np.float64)
+        ext = np.concatenate([R.T.reshape(9), np.zeros(3) if ext_p is None else np.asarray(ext_p, dtype=np.float64)])
+        lib().vxo_lio_scan_raw(self._h, xyz.shape[0], xyz, ext, float(dept_err), float(beam_err))
+
+    def set_points(self, pnt, var):
+        pnt = _c(pnt).reshape(-1, 3)
+        var = np.ascontiguousarray(np.transpose(np.asarray(var, dtype=np.float64).reshape(-1, 3, 3), (0, 2, 1)))
+        lib().vxo_lio_scan_set(self._h, pnt.shape[0], pnt, var)
+
+    def scan_size(self):
+        return int(lib().vxo_lio_scan_size(self._h))
+
+    def read_points(self):
+        n = self.scan_size()
+        pnt = np.zeros((n, 3)); var = np.zeros((n, 9))
+        lib().vxo_lio_scan_read(self._h, pnt, var)
+        return pnt, np.transpose(var.reshape(n, 3, 3), (0, 2, 1)).copy()
+
+    @staticmethod
+    def _cov(cov):
+        return np.ascontiguousarray(np.asarray(cov, dtype=np.float64).reshape(15, 15).T)
+
+    def sweep(self, state, cov, reset_cache=True, want_points=False):
+        out = np.zeros(52); n = self.scan_size()
+        pop = np.zeros(n, dtype=np.int32); sig = np.zeros(n)
+        lib().vxo_lio_sweep(self._h, _c(state), self._cov(cov), 1 if reset_cache else 0, out, pop, sig)
+        res = _unpack_sweep(out)
+        if want_points:
+            res["plane_of_point"] = pop; res["sigma_of_point"] = sig
+        return res
+
+    def lio_state_estimation(self, state, cov):
+        st = _c(state).copy(); cv = self._cov(cov).copy()
+        n = self.scan_size()
+        info = np.zeros(4); sweeps = np.zeros((4, 52)); pop = np.zeros(n, dtype=np.int32); sig = np.zeros(n)
+        lib().vxo_lio_state_estimation(self._h, st, cv, info, sweeps, pop, sig)
+        it = int(info[1])
+        return {"ok": bool(info[0]), "state": st, "cov": cv.T.copy(), "iterations": it, "match_num": int(info[2]), "min_eig": float(info[3]),
+                "sweeps": [_unpack_sweep(sweeps[k]) for k in range(it)], "plane_of_point": pop, "sigma_of_point": sig}
+
+    def time_state_estimation(self, state, cov, reps=3):
+        return float(lib().vxo_time_lio_state_estimation(self._h, _c(state), self._cov(cov), int(reps)))
+
+    def pvec_update(self, state, cov):
+        n = self.scan_size()
+        pw = np.zeros((n, 3)); var = np.zeros((n, 9))
+        lib().vxo_lio_pvec_update(self._h, _c(state), self._cov(cov), pw, var)
+        return pw, np.transpose(var.reshape(n, 3, 3), (0, 2, 1)).copy()
+
+
+def cov_add_build(xyz_world, var, cell_ptr):
+    """Sum of Bf_var over the points of each cell (voxel_map.hpp:91-106, 990-992): n_cells x 9 x 9."""
+    cp = np.ascontiguousarray(cell_ptr, dtype=np.int64)
+    n = cp.shape[0] - 1
+    var9 = np.ascontiguousarray(np.transpose(np.asarray(var, dtype=np.float64).reshape(-1, 3, 3), (0, 2, 1)))
+    out = np.zeros((n, 81))
+    lib().vxo_cov_add_build(n, cp, _c(xyz_world).reshape(-1, 3), var9, out)
+    return np.transpose(out.reshape(n, 9, 9), (0, 2, 1)).copy()
+
+
+def plane_update(clusters, eig_val, eig_vec, cov_add):
+    """OctoTree::plane_update (voxel_map.hpp:1118-1146) batched: dict(center, normal, plane_var n x 6 x 6, radius)."""
+    cl = _c(clusters).reshape(-1, 10); n = cl.shape[0]
+    ca = np.ascontiguousarray(np.transpose(np.asarray(cov_add, dtype=np.float64).reshape(n, 9, 9), (0, 2, 1)))
+    center = np.zeros((n, 3)); normal = np.zeros((n, 3)); pv = np.zeros((n, 36)); rad = np.zeros(n)
+    lib().vxo_plane_update(n, cl, _c(eig_val).reshape(n, 3), _c(eig_vec).reshape(n, 9), ca, center, normal, pv, rad)
+    return dict(center=center, normal=normal, plane_var=np.transpose(pv.reshape(n, 6, 6), (0, 2, 1)).copy(), radius=rad)

@@ -328,3 +328,96 @@ def make_scans(win_size=5, pts_per_scan=20_000, extent=20.0, noise=0.01, clutter
         if trans_sigma > 0:
             ps2[i] = ps[i] + rng.normal(0, trans_sigma, size=3)
     return xyz, frame_ptr, pack_poses(Rs2, ps2), pack_poses(Rs, ps)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Odometry: a voxel plane map as the reference's `surf_map` would hold it after some scans -- root voxels that
+# are one plane, or are subdivided once / twice with planes, plane-less leaves and missing children below -- flattened to its
+# leaves, and one scan that sees those planes from a pose near the true one.
+# ------------------------------------------------------------------------------------------------------------
+@dataclasses.dataclass
+class PlaneMapData:
+    voxel_size: float
+    max_layer: int
+    loc: np.ndarray        # (n,3) int64  root voxel
+    layer: np.ndarray      # (n,)  int32
+    path: np.ndarray       # (n,)  int32  leafnum per level, 3 bits each, first level lowest
+    is_plane: np.ndarray   # (n,)  int32
+    center: np.ndarray     # (n,3)
+    normal: np.ndarray     # (n,3)
+    plane_var: np.ndarray  # (n,6,6)
+    radius: np.ndarray     # (n,)  float32-representable
+    box_center: np.ndarray  # (n,3) centre of the leaf's cell
+    box_half: np.ndarray   # (n,)
+
+    def args(self):
+        return self.loc, self.layer, self.path, self.center, self.normal, self.plane_var, self.radius, self.is_plane
+
+
+def make_plane_map(n_roots=2000, extent=12, voxel_size=1.0, max_layer=2, seed=MASTER_SEED + 900) -> PlaneMapData:
+    rng = np.random.Generator(np.random.PCG64([seed, 31]))
+    side = 2 * extent
+    flat = rng.choice(side ** 3, size=n_roots, replace=False)
+    roots = np.stack([flat // (side * side), (flat // side) % side, flat % side], axis=1).astype(np.int64) - extent
+    rows = []
+
+    def leaf(loc, layer, path, c_box, half, plane):
+        if plane:
+            fam = np.eye(3)[rng.integers(0, 3)] * rng.choice([-1.0, 1.0])
+            n = fam + 0.15 * rng.normal(size=3); n /= np.linalg.norm(n)
+            c = c_box + rng.uniform(-0.3, 0.3, size=3) * half
+            B = rng.normal(size=(6, 6)) * 3e-3
+            rows.append((loc, layer, path, 1, c, n, B @ B.T, np.float32((2 * half) ** 2 / 12 * rng.uniform(0.6, 1.2)), c_box, half))
+        else:
+            rows.append((loc, layer, path, 0, c_box, np.array([0.0, 0.0, 1.0]), np.zeros((6, 6)), np.float32(0.0), c_box, half))
+
+    def grow(loc, layer, path, c_box, half):
+        # a node at `layer`: leaf (plane or not) or subdivided
+        p_split = 0.0 if layer >= max_layer else (0.4 if layer == 0 else 0.3)
+        if rng.random() < p_split:
+            for leafnum in range(8):
+                if rng.random() < 0.65:
+                    sgn = np.array([(leafnum >> 2) & 1, (leafnum >> 1) & 1, leafnum & 1]) * 2 - 1
+                    grow(loc, layer + 1, path | (leafnum << (3 * layer)), c_box + sgn * half / 2, half / 2)
+        else:
+            leaf(loc, layer, path, c_box, half, rng.random() < 0.9)
+
+    for loc in roots:
+        grow(loc, 0, 0, (loc + 0.5) * voxel_size, voxel_size / 2)
+    cols = list(zip(*rows))
+    return PlaneMapData(voxel_size, max_layer, np.array(cols[0], dtype=np.int64), np.array(cols[1], dtype=np.int32), np.array(cols[2], dtype=np.int32),
+                        np.array(cols[3], dtype=np.int32), np.array(cols[4]), np.array(cols[5]), np.array(cols[6]), np.array(cols[7], dtype=np.float64),
+                        np.array(cols[8]), np.array(cols[9]))
+
+
+@dataclasses.dataclass
+class LioScan:
+    xyz: np.ndarray        # (n,3) float32, sensor (= IMU) frame
+    state_gt: np.ndarray   # VXBA state vector of the pose the scan was taken at
+    state_init: np.ndarray  # the propagated guess lio_state_estimation starts from
+    cov: np.ndarray        # 15x15
+
+
+def make_lio_scan(pm: PlaneMapData, n_points=20_000, noise=0.02, clutter_frac=0.05, rot_sigma_deg=0.3, trans_sigma=0.03, seed=MASTER_SEED + 901) -> LioScan:
+    rng = np.random.Generator(np.random.PCG64([seed, 32]))
+    R_gt = rodrigues(np.array([0.02, -0.03, 0.4])); p_gt = np.array([0.3, -0.2, 0.1])
+    planes = np.nonzero(pm.is_plane == 1)[0]
+    n_cl = int(n_points * clutter_frac); n_pl = n_points - n_cl
+    k = planes[rng.integers(0, planes.size, size=n_pl)]
+    n = pm.normal[k]
+    a = np.cross(n, np.array([0.31, 0.52, 0.79])); a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = np.cross(n, a)
+    h = pm.box_half[k][:, None]
+    w = pm.center[k] + rng.uniform(-1, 1, size=(n_pl, 1)) * h * a + rng.uniform(-1, 1, size=(n_pl, 1)) * h * b + rng.normal(0, noise, size=(n_pl, 1)) * n
+    lo = pm.loc.min(axis=0) * pm.voxel_size; hi = (pm.loc.max(axis=0) + 1) * pm.voxel_size
+    cl = rng.uniform(lo, hi, size=(n_cl, 3))
+    world = np.concatenate([w, cl])[rng.permutation(n_points)]
+    xyz = np.ascontiguousarray(((world - p_gt) @ R_gt).astype(np.float32))
+    R0 = R_gt @ rodrigues(rng.normal(0, np.deg2rad(rot_sigma_deg), size=3)); p0 = p_gt + rng.normal(0, trans_sigma, size=3)
+    v = np.array([0.5, 0.1, 0.0]); g = np.array([0.0, 0.0, -9.8])
+    st = lambda R, p: np.concatenate([R.T.reshape(9), p, v, np.zeros(3), np.zeros(3), g])
+    cov = np.eye(15) * 1e-4
+    cov[9:, 9:] = np.eye(6) * 1e-5
+    M = rng.normal(size=(15, 15)) * 1e-3       # a propagated covariance is not diagonal
+    cov = cov + 0.02 * (M @ M.T)
+    return LioScan(xyz, st(R_gt, p_gt), st(R0, p0), cov)

@@ -33,6 +33,8 @@ EXPORTS = [
     "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_detach", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps",
     "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_li_evaluate",
     "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity", "vxba_voxelize_push", "vxba_set_precision",
+    "vxba_lio_create", "vxba_lio_destroy", "vxba_lio_last_error", "vxba_lio_map_update", "vxba_lio_map_clear", "vxba_lio_map_size", "vxba_lio_scan_raw",
+    "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -118,6 +120,22 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_voxelize_push.argtypes = [vp, C.c_int64, _f64p, _i64p, _f64p, C.POINTER(VoxelizeParams), C.POINTER(C.c_int64), vp, C.c_int64]
     L.vxba_imu_evaluate_g.argtypes = [_f64p, _f64p, _f64p, ci, vp, vp, C.POINTER(cd)]
     L.vxba_li_damping_iter_gravity.argtypes = [vp, _f64p, _f64p, cd, ci, vp, _f64p, vp, C.POINTER(ci)]
+    i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    L.vxba_lio_create.argtypes = [cd, ci, ci, C.POINTER(vp)]
+    L.vxba_lio_destroy.argtypes = [vp]
+    L.vxba_lio_last_error.argtypes = [vp]
+    L.vxba_lio_last_error.restype = C.c_char_p
+    L.vxba_lio_map_update.argtypes = [vp, C.c_int64, _i64p, i32p, i32p, vp, _f64p, _f64p, _f64p, _f64p]
+    L.vxba_lio_map_clear.argtypes = [vp]
+    L.vxba_lio_map_size.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.vxba_lio_scan_raw.argtypes = [vp, C.c_int64, np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS"), vp, cd, cd]
+    L.vxba_lio_scan_set.argtypes = [vp, C.c_int64, _f64p, _f64p]
+    L.vxba_lio_scan_size.argtypes = [vp]
+    L.vxba_lio_scan_size.restype = C.c_int64
+    L.vxba_lio_scan_read.argtypes = [vp, _f64p, _f64p]
+    L.vxba_lio_sweep.argtypes = [vp, _f64p, _f64p, ci, _f64p, vp, vp]
+    L.vxba_lio_state_estimation.argtypes = [vp, _f64p, _f64p, vp, vp]
+    L.vxba_lio_pvec_update.argtypes = [vp, _f64p, _f64p, _f64p, _f64p]
     _lib = L
     return L
 
@@ -522,6 +540,121 @@ def damping_iter_generic(win_size: int, x_stats, hess_fn, resid_fn, max_iter: in
     if rc != 0:
         raise VxbaError(f"vxba_damping_iter_generic failed: {_ERRNAMES.get(rc, rc)}")
     return dict(poses=Rp, hess=hess.T.copy(), resis=resis, trace=trace[: nt.value].copy(), is_converge=bool(conv.value))
+
+
+LIO_SWEEP_LEN = 52
+LIO_MAX_ITER = 4
+
+
+def unpack_sweep(sw):
+    """One sweep record -> dict(HTH 6x6, HTz 6, nnt 3x3, match_num)."""
+    sw = np.asarray(sw)
+    return {"HTH": sw[:36].reshape(6, 6).T.copy(), "HTz": sw[36:42].copy(), "nnt": sw[42:51].reshape(3, 3).T.copy(), "match_num": int(sw[51])}
+
+
+class LioEstimator:
+    """The odometry's point-to-plane update on the GPU: the plane map (``surf_map`` flattened to its leaves), the current scan
+    (``pptr``) and ``lio_state_estimation`` (voxelslam.cpp:855-958) with ``match`` (voxel_map.hpp:1335-1392, 1674-1698).
+    States are the flat VXBA state vectors of :func:`pack_state`, covariances 15x15 (tangent order [dphi dp dv dbg dba])."""
+
+    def __init__(self, voxel_size: float = 1.0, max_layer: int = 2, device: int = 0):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        rc = self._L.vxba_lio_create(float(voxel_size), int(max_layer), int(device), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise VxbaError(f"vxba_lio_create failed: {_ERRNAMES.get(rc, rc)} (no CPU fallback exists; an MI355X is required)")
+        self.voxel_size, self.max_layer = float(voxel_size), int(max_layer)
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self._L.vxba_lio_last_error(self._h)
+            raise VxbaError(f"{_ERRNAMES.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vxba_lio_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- map ------------------------------------------------------------------------------------------------------------
+    def map_update(self, loc, layer, path, center, normal, plane_var, radius, is_plane=None):
+        """Upsert leaves.  plane_var: n x 6 x 6 (numpy order; symmetric up to round-off, sent column-major)."""
+        loc = np.ascontiguousarray(loc, dtype=np.int64).reshape(-1, 3)
+        n = loc.shape[0]
+        layer = np.ascontiguousarray(layer, dtype=np.int32); path = np.ascontiguousarray(path, dtype=np.int32)
+        pv = np.ascontiguousarray(np.transpose(np.asarray(plane_var, dtype=np.float64).reshape(n, 6, 6), (0, 2, 1)))
+        isp = None if is_plane is None else np.ascontiguousarray(is_plane, dtype=np.int32)
+        self._chk(self._L.vxba_lio_map_update(self._h, n, loc, layer, path, None if isp is None else isp.ctypes.data_as(C.c_void_p), _c(center), _c(normal), pv, _c(radius)))
+
+    def map_clear(self):
+        self._chk(self._L.vxba_lio_map_clear(self._h))
+
+    def map_size(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._chk(self._L.vxba_lio_map_size(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # -- scan -----------------------------------------------------------------------------------------------------------
+    def var_init(self, xyz, ext_R=None, ext_p=None, dept_err=0.02, beam_err=0.05):
+        """``var_init`` (voxelslam.hpp:187-201) on sensor-frame float32 points."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        ext = None
+        if ext_R is not None:
+            ext = np.concatenate([np.asarray(ext_R, dtype=np.float64).T.reshape(9), np.zeros(3) if ext_p is None else np.asarray(ext_p, dtype=np.float64)])
+        self._chk(self._L.vxba_lio_scan_raw(self._h, xyz.shape[0], xyz, None if ext is None else ext.ctypes.data_as(C.c_void_p), float(dept_err), float(beam_err)))
+
+    def set_points(self, pnt, var):
+        """Ready ``pointVar`` arrays: pnt n x 3, var n x 3 x 3."""
+        pnt = _c(pnt).reshape(-1, 3)
+        var = np.ascontiguousarray(np.transpose(np.asarray(var, dtype=np.float64).reshape(-1, 3, 3), (0, 2, 1)))
+        self._chk(self._L.vxba_lio_scan_set(self._h, pnt.shape[0], pnt, var))
+
+    def scan_size(self) -> int:
+        return int(self._L.vxba_lio_scan_size(self._h))
+
+    def read_points(self):
+        n = self.scan_size()
+        pnt = np.zeros((n, 3)); var = np.zeros((n, 9))
+        self._chk(self._L.vxba_lio_scan_read(self._h, pnt, var))
+        return pnt, np.transpose(var.reshape(n, 3, 3), (0, 2, 1)).copy()
+
+    # -- the path -------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _cov(cov):
+        return np.ascontiguousarray(np.asarray(cov, dtype=np.float64).reshape(15, 15).T)
+
+    def sweep(self, state, cov, reset_cache=True, want_points=False):
+        out = np.zeros(LIO_SWEEP_LEN)
+        n = self.scan_size()
+        pop = np.zeros(n, dtype=np.int32) if want_points else None
+        sig = np.zeros(n) if want_points else None
+        self._chk(self._L.vxba_lio_sweep(self._h, _c(state), self._cov(cov), 1 if reset_cache else 0, out,
+                                         None if pop is None else pop.ctypes.data_as(C.c_void_p), None if sig is None else sig.ctypes.data_as(C.c_void_p)))
+        res = unpack_sweep(out)
+        if want_points:
+            res["plane_of_point"] = pop; res["sigma_of_point"] = sig
+        return res
+
+    def lio_state_estimation(self, state, cov):
+        """Returns dict(ok, state, cov, iterations, match_num, min_eig, sweeps)."""
+        st = _c(state).copy(); cv = self._cov(cov).copy()
+        info = np.zeros(4); sweeps = np.zeros((LIO_MAX_ITER, LIO_SWEEP_LEN))
+        self._chk(self._L.vxba_lio_state_estimation(self._h, st, cv, info.ctypes.data_as(C.c_void_p), sweeps.ctypes.data_as(C.c_void_p)))
+        it = int(info[1])
+        return {"ok": bool(info[0]), "state": st, "cov": cv.T.copy(), "iterations": it, "match_num": int(info[2]), "min_eig": float(info[3]),
+                "sweeps": [unpack_sweep(sweeps[k]) for k in range(it)]}
+
+    def pvec_update(self, state, cov):
+        n = self.scan_size()
+        pw = np.zeros((n, 3)); var = np.zeros((n, 9))
+        self._chk(self._L.vxba_lio_pvec_update(self._h, _c(state), self._cov(cov), pw, var))
+        return pw, np.transpose(var.reshape(n, 3, 3), (0, 2, 1)).copy()
 
 
 def rccl_unique_id(librccl_path: str) -> bytes:
