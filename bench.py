@@ -224,6 +224,7 @@ def main():
         if world == 1 and not args.no_li_ba:
             out["li_ba"] = li_ba_rate(sc, f)
             out["voxelize"] = voxelize_rate(W, local_rank, with_cpu=not args.no_cpu_baseline)
+            out["lio"] = lio_rate(local_rank, with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, f, args.cpu_seconds)
         print(json.dumps(out), flush=True)
@@ -296,6 +297,43 @@ def voxelize_rate(W, device, with_cpu):
         r = O.voxelize(W, xyz, fp, poses, P.as_array())
         out["cpu_oracle_ms"] = 1e3 * (time.perf_counter() - t0)
         out["cpu_oracle_factor_voxels"] = int(r["node_id"].shape[0])
+    return out
+
+
+def lio_rate(device, with_cpu, n_points=100_000, n_roots=20_000):
+    """Odometry state estimation (lio_state_estimation, voxelslam.cpp:855-958): one 100k-point scan against a plane map of
+    n_roots root voxels, scan and map resident in HBM, state / covariance crossing the boundary as host arrays like upstream.
+    Secondary figure with the CPU oracle beside it."""
+    import numpy as np
+    from voxel_slam_amd import synth, vxba
+    pm = synth.make_plane_map(n_roots=n_roots, extent=20, seed=synth.MASTER_SEED + 910)
+    sc = synth.make_lio_scan(pm, n_points=n_points, seed=synth.MASTER_SEED + 911)
+    g = vxba.LioEstimator(pm.voxel_size, pm.max_layer, device=device)
+    t0 = time.perf_counter(); g.map_update(*pm.args()); t_map = time.perf_counter() - t0
+    t0 = time.perf_counter(); g.var_init(sc.xyz); t_scan = time.perf_counter() - t0
+    ts, its = [], 0
+    res = None
+    for k in range(22):
+        t0 = time.perf_counter()
+        res = g.lio_state_estimation(sc.state_init, sc.cov)
+        ts.append(time.perf_counter() - t0)
+        its = res["iterations"]
+    tsw = []
+    for k in range(22):
+        t0 = time.perf_counter(); g.sweep(sc.state_init, sc.cov); tsw.append(time.perf_counter() - t0)
+    med = float(np.median(ts[2:])); msw = float(np.median(tsw[2:]))
+    et, er = synth.pose_errors(res["state"][None, :12], sc.state_gt[None, :12])
+    out = {"points": n_points, "map_planes": int(g.map_size()[1]), "map_roots": int(g.map_size()[0]), "iterations": its, "matched": res["match_num"],
+           "ms_per_scan": 1e3 * med, "scans_per_s": 1.0 / med, "ms_per_sweep_call": 1e3 * msw, "points_per_s_sweep": n_points / msw,
+           "sweep_algorithmic_GBs": 72.0 * n_points / msw / 1e9, "map_upload_ms": 1e3 * t_map, "var_init_ms": 1e3 * t_scan,
+           "pose_error_vs_truth_m_rad": [et, er], "where": "match + sums on GPU; 15x15 EKF algebra on host between sweeps"}
+    g.close()
+    if with_cpu:
+        from tests import _oracle as O
+        o = O.LioOracle(pm.voxel_size, pm.max_layer); o.map_update(*pm.args()); o.var_init(sc.xyz)
+        out["cpu_oracle_ms_per_scan"] = 1e3 * o.time_state_estimation(sc.state_init, sc.cov, 3)
+        ref = o.lio_state_estimation(sc.state_init, sc.cov)
+        out["pose_diff_vs_oracle_m_rad"] = list(synth.pose_errors(res["state"][None, :12], ref["state"][None, :12]))
     return out
 
 

@@ -12,8 +12,11 @@
 // operation by operation, so a point lands on the same leaf as in the reference -- including the ~1e-6 of points whose float
 // voxel index rounds across a voxel face -- and so is the per-point node cache (`octos[i]` + `inside`) that the reference keeps
 // across the iterations of one call.  One lane per point; 34 running sums (HTH upper triangle, HTz, nnt upper triangle, count)
-// are reduced butterfly -> LDS -> one partial per workgroup -> the last workgroup to finish adds the partials in index order and
-// writes the result straight into pinned host memory.  No float atomics: bitwise reproducible.
+// are reduce-scattered over the wave -> LDS -> one 272-byte partial per workgroup, stored straight into pinned host memory; the
+// caller adds the <= 256 partials in index order (the EKF algebra that consumes them runs there anyway).  No float atomics, no
+// device-wide fence: bitwise reproducible.  (A first version finished the sum on the device -- last workgroup to arrive, found via an
+// atomic ticket; 391 workgroups each executing __threadfence() cost 3/4 of its 141 us, and even with agent-scope relaxed stores
+// instead of fences the ticket + the last workgroup's round trips were 6 of 24 us.  64-lane butterflies of all 34 sums were another 8.)
 //
 // Bound: HBM in principle (72 B per point + the plane records, which stay in L2), launch/latency in practice -- a 100k-point
 // scan is 7 MB.  The 15x15 EKF algebra stays on the host between sweeps (4 sweeps per scan upstream).
@@ -38,7 +41,8 @@ constexpr int NSUM = 34;         // HTH 21 | HTz 6 | nnt 6 | count
 constexpr int SWEEP_OUT = 52;    // HTH 36 col-major | HTz 6 | nnt 9 col-major | match_num
 constexpr unsigned long long EMPTY_KEY = ~0ull;
 constexpr long long LOC_OFF = 1ll << 20;   // root voxel indices in [-2^20, 2^20)
-constexpr int BLOCK = 256;
+constexpr int BLOCK = 512;        // 8 waves; one point per lane and pass
+constexpr int MAX_GRID = 256;     // one workgroup per CU; larger scans loop inside the lanes
 
 struct MapView {
   const unsigned long long* keys;
@@ -119,13 +123,8 @@ __device__ inline int map_lookup(const MapView& m, const double w[3]) {
   const long long lx = voxel_index(w[0], m.voxel_size), ly = voxel_index(w[1], m.voxel_size), lz = voxel_index(w[2], m.voxel_size);
   unsigned long long key;
   if (!pack_key(lx, ly, lz, key)) return -1;
-  unsigned long long slot = mix64(key) & m.cap_mask;
-  while (true) {
-    const unsigned long long k = m.keys[slot];
-    if (k == key) break;
-    if (k == EMPTY_KEY) return -1;
-    slot = (slot + 1) & m.cap_mask;
-  }
+  // the descent does not depend on the table, so the finest cell is known before the probe and the cell entry is fetched together
+  // with the key it belongs to (one dependent round trip instead of two when the first probe hits, which it mostly does at load <= 1/2)
   double c[3] = {(0.5 + (double)lx) * m.voxel_size, (0.5 + (double)ly) * m.voxel_size, (0.5 + (double)lz) * m.voxel_size};   // cut_voxel :1531-1533
   float ql = (float)(m.voxel_size / 4.0);                                                                                 // :1534
   int cell = 0;
@@ -135,26 +134,47 @@ __device__ inline int map_lookup(const MapView& m, const double w[3]) {
     c[0] += (double)((float)(2 * x0 - 1) * ql); c[1] += (double)((float)(2 * x1 - 1) * ql); c[2] += (double)((float)(2 * x2 - 1) * ql);   // allocate :1039-1042
     ql = ql / 2;
   }
-  return m.cells[slot * (unsigned long long)m.cells_per_root + cell];
+  unsigned long long slot = mix64(key) & m.cap_mask;
+  while (true) {
+    const unsigned long long k = m.keys[slot];
+    const int rec = m.cells[slot * (unsigned long long)m.cells_per_root + cell];
+    if (k == key) return rec;
+    if (k == EMPTY_KEY) return -1;
+    slot = (slot + 1) & m.cap_mask;
+  }
 }
 
-__device__ inline double wave_sum(double v) {
+// Reduce-scatter of N running sums over the 64 lanes of a wave: at every butterfly step a lane keeps one half of its sums and
+// hands the other half to its partner, so 17+9+5+3+2+1 = 37 doubles cross lanes instead of 34*6.  Afterwards lane l holds the wave
+// total of column `col` if `real >= 1` (34 of the 64 lanes do).  Fixed data flow: bitwise reproducible.
+template <int N, int OFF>
+__device__ __forceinline__ double wave_reduce_scatter(const double (&v)[N], int lane, int& col, int& real) {
+  if constexpr (OFF == 0) {
+    return v[0];
+  } else {
+    constexpr int M = (N + 1) / 2;
+    const bool up = (lane & OFF) != 0;
+    double keep[M];
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+    for (int j = 0; j < M; j++) {
+      const double lo = v[j];
+      const double hi = (M + j < N) ? v[M + j] : 0.0;
+      keep[j] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, OFF, 64);
+    }
+    if (up) { col += M; real -= M; } else { real = real < M ? real : M; }
+    return wave_reduce_scatter<M, OFF / 2>(keep, lane, col, real);
+  }
 }
 
 // One pass of voxelslam.cpp:873-919.  pts: SoA planes [pnt 3 | var upper triangle 6] of stride `n_stride`.
 __global__ __launch_bounds__(BLOCK) void lio_sweep_kernel(MapView m, SweepArg a, const double* __restrict__ pts, long long n, long long n_stride, int* __restrict__ cache,
-                                                          int use_cache, double* __restrict__ partials, unsigned int* __restrict__ ticket, double* __restrict__ out,
+                                                          int use_cache, double* __restrict__ partials,
                                                           int* __restrict__ plane_of_point, double* __restrict__ sigma_of_point) {
   __shared__ double red[BLOCK / 64][NSUM];
-  __shared__ bool is_last;
-  const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   double s[NSUM];
 #pragma unroll
   for (int k = 0; k < NSUM; k++) s[k] = 0.0;
-  if (i < n) {
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) {
     double pnt[3], var[6];
 #pragma unroll
     for (int k = 0; k < 3; k++) pnt[k] = pts[k * n_stride + i];
@@ -185,51 +205,28 @@ __global__ __launch_bounds__(BLOCK) void lio_sweep_kernel(MapView m, SweepArg a,
 #pragma unroll
       for (int r = 0; r < 6; r++)
 #pragma unroll
-        for (int c = r; c < 6; c++, k++) s[k] = R_inv * jac[r] * jac[c];
+        for (int c = r; c < 6; c++, k++) s[k] += R_inv * jac[r] * jac[c];
 #pragma unroll
-      for (int r = 0; r < 6; r++) s[21 + r] = -(R_inv * jac[r] * resi);
-      s[27] = nrm[0] * nrm[0]; s[28] = nrm[0] * nrm[1]; s[29] = nrm[0] * nrm[2]; s[30] = nrm[1] * nrm[1]; s[31] = nrm[1] * nrm[2]; s[32] = nrm[2] * nrm[2];
-      s[33] = 1.0;
+      for (int r = 0; r < 6; r++) s[21 + r] -= R_inv * jac[r] * resi;
+      s[27] += nrm[0] * nrm[0]; s[28] += nrm[0] * nrm[1]; s[29] += nrm[0] * nrm[2]; s[30] += nrm[1] * nrm[1]; s[31] += nrm[1] * nrm[2]; s[32] += nrm[2] * nrm[2];
+      s[33] += 1.0;
     } else if (!use_cache) {
       cache[i] = -1;
     }
     if (plane_of_point) { plane_of_point[i] = flag ? pid : -1; sigma_of_point[i] = flag ? sigma_d : 0.0; }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < NSUM; k++) {
-    const double t = wave_sum(s[k]);
-    if (lane == 0) red[wv][k] = t;
+  {
+    int col = 0, real = NSUM;
+    const double t = wave_reduce_scatter<NSUM, 32>(s, lane, col, real);
+    if (real >= 1) red[wv][col] = t;
   }
   __syncthreads();
   if (threadIdx.x < NSUM) {
     double t = red[0][threadIdx.x];
 #pragma unroll
     for (int q = 1; q < BLOCK / 64; q++) t += red[q][threadIdx.x];
-    partials[(size_t)blockIdx.x * NSUM + threadIdx.x] = t;
-  }
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
-  if (threadIdx.x < NSUM) {
-    double t = 0.0;
-    for (unsigned b = 0; b < gridDim.x; b++) t += __builtin_nontemporal_load(&partials[(size_t)b * NSUM + threadIdx.x]);
-    red[0][threadIdx.x] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int k = 0;
-    for (int r = 0; r < 6; r++)
-      for (int c = r; c < 6; c++, k++) { out[6 * c + r] = red[0][k]; out[6 * r + c] = red[0][k]; }
-    for (int r = 0; r < 6; r++) out[36 + r] = red[0][21 + r];
-    const double* nn = &red[0][27];
-    out[42] = nn[0]; out[43] = nn[1]; out[44] = nn[2]; out[45] = nn[1]; out[46] = nn[3]; out[47] = nn[4]; out[48] = nn[2]; out[49] = nn[4]; out[50] = nn[5];
-    out[51] = red[0][33];
-    *ticket = 0u;
-    __threadfence_system();
+    partials[(size_t)blockIdx.x * NSUM + threadIdx.x] = t;   // host-mapped: 272 contiguous bytes per workgroup, summed by the caller
   }
 }
 
@@ -417,11 +414,9 @@ struct vxba_lio {
   long long n_pts = 0, pts_stride = 0, pts_cap = 0;
   int* d_cache = nullptr;
   bool cache_valid = false;
-  double* d_partials = nullptr;
-  long long partial_blocks = 0;
-  unsigned int* d_ticket = nullptr;
-  double* h_out = nullptr;      // pinned, mapped: the sweep's 52 numbers land here
-  double* d_out = nullptr;      // device alias of h_out
+  double* h_partials = nullptr;  // pinned, mapped: one 34-number partial per workgroup lands here (zero-copy stores)
+  double* d_partials = nullptr;  // device alias of h_partials
+  double h_out[vxl::SWEEP_OUT];  // the sweep's 52 numbers, assembled on the host
   std::string err;
   std::recursive_mutex mtx;
 };
@@ -486,14 +481,12 @@ int lio_map_reserve(vxba_lio* h, long long more) {
 
 int lio_scan_reserve(vxba_lio* h, long long n) {
   if (n > h->pts_cap) {
-    if (h->d_pts) { LIO_HIP(h, hipStreamSynchronize(h->stream)); LIO_HIP(h, hipFree(h->d_pts)); LIO_HIP(h, hipFree(h->d_cache)); LIO_HIP(h, hipFree(h->d_partials)); }
-    h->d_pts = nullptr; h->d_cache = nullptr; h->d_partials = nullptr;
+    if (h->d_pts) { LIO_HIP(h, hipStreamSynchronize(h->stream)); LIO_HIP(h, hipFree(h->d_pts)); LIO_HIP(h, hipFree(h->d_cache)); }
+    h->d_pts = nullptr; h->d_cache = nullptr;
     long long cap = std::max<long long>(n, 2 * h->pts_cap);
     cap = (cap + 255) / 256 * 256;
     LIO_HIP(h, hipMalloc((void**)&h->d_pts, (size_t)cap * 9 * sizeof(double)));
     LIO_HIP(h, hipMalloc((void**)&h->d_cache, (size_t)cap * sizeof(int)));
-    h->partial_blocks = cap / vxl::BLOCK;
-    LIO_HIP(h, hipMalloc((void**)&h->d_partials, (size_t)h->partial_blocks * vxl::NSUM * sizeof(double)));
     h->pts_cap = cap;
   }
   h->n_pts = n;
@@ -521,7 +514,7 @@ vxl::SweepArg sweep_arg(const double* state, const double* cov225) {
   return a;
 }
 
-// enqueue one sweep and wait for its 52 numbers (h->h_out)
+// enqueue one sweep, wait, and assemble its 52 numbers in h->h_out
 int lio_sweep(vxba_lio* h, const double* state, const double* cov225, bool reset_cache, int* d_plane_of_point, double* d_sigma_of_point) {
   if (h->n_pts == 0) {
     std::memset(h->h_out, 0, sizeof(double) * vxl::SWEEP_OUT);
@@ -532,11 +525,27 @@ int lio_sweep(vxba_lio* h, const double* state, const double* cov225, bool reset
     if (rc != VXBA_OK) return rc;
   }
   const bool use_cache = h->cache_valid && !reset_cache;
-  vxl::lio_sweep_kernel<<<grid_for(h->n_pts, vxl::BLOCK), vxl::BLOCK, 0, h->stream>>>(map_view(h), sweep_arg(state, cov225), h->d_pts, h->n_pts, h->pts_stride, h->d_cache,
-                                                                                   use_cache ? 1 : 0, h->d_partials, h->d_ticket, h->d_out, d_plane_of_point, d_sigma_of_point);
+  const unsigned grid = std::min<unsigned>(grid_for(h->n_pts, vxl::BLOCK), vxl::MAX_GRID);
+  vxl::lio_sweep_kernel<<<grid, vxl::BLOCK, 0, h->stream>>>(map_view(h), sweep_arg(state, cov225), h->d_pts, h->n_pts, h->pts_stride, h->d_cache, use_cache ? 1 : 0, h->d_partials,
+                                                            d_plane_of_point, d_sigma_of_point);
   LIO_HIP(h, hipGetLastError());
-  LIO_HIP(h, hipStreamSynchronize(h->stream));
+  // the kernel is ~10 us: poll for its completion instead of sleeping on it (hipStreamSynchronize's wake-up costs more than the kernel)
+  hipError_t q;
+  while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) {}
+  LIO_HIP(h, q);
   h->cache_valid = true;
+  // the per-workgroup partials, added in workgroup order (fixed for a given scan size: bitwise reproducible)
+  double t[vxl::NSUM];
+  for (int k = 0; k < vxl::NSUM; k++) t[k] = 0.0;
+  for (unsigned b = 0; b < grid; b++)
+    for (int k = 0; k < vxl::NSUM; k++) t[k] += h->h_partials[(size_t)b * vxl::NSUM + k];
+  double* o = h->h_out;
+  int k = 0;
+  for (int r = 0; r < 6; r++)
+    for (int c = r; c < 6; c++, k++) { o[6 * c + r] = t[k]; o[6 * r + c] = t[k]; }
+  for (int r = 0; r < 6; r++) o[36 + r] = t[21 + r];
+  o[42] = t[27]; o[43] = t[28]; o[44] = t[29]; o[45] = t[28]; o[46] = t[30]; o[47] = t[31]; o[48] = t[29]; o[49] = t[31]; o[50] = t[32];
+  o[51] = t[33];
   return VXBA_OK;
 }
 
@@ -556,10 +565,8 @@ int vxba_lio_create(double voxel_size, int max_layer, int device, vxba_lio** out
   h->own_stream = e == hipSuccess;
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_counters, 2 * sizeof(int));
   if (e == hipSuccess) e = hipMemset(h->d_counters, 0, 2 * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc((void**)&h->d_ticket, sizeof(unsigned int));
-  if (e == hipSuccess) e = hipMemset(h->d_ticket, 0, sizeof(unsigned int));
-  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_out, vxl::SWEEP_OUT * sizeof(double), hipHostMallocMapped);
-  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_out, h->h_out, 0);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_partials, (size_t)vxl::MAX_GRID * vxl::NSUM * sizeof(double), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_partials, h->h_partials, 0);
   if (e != hipSuccess) { vxba_lio_destroy(h); return VXBA_ERR_HIP; }
   *out = h;
   return VXBA_OK;
@@ -570,8 +577,8 @@ int vxba_lio_destroy(vxba_lio* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   hipFree(h->d_keys); hipFree(h->d_cells); hipFree(h->d_planes); hipFree(h->d_plane_tag); hipFree(h->d_counters);
-  hipFree(h->d_pts); hipFree(h->d_cache); hipFree(h->d_partials); hipFree(h->d_ticket);
-  if (h->h_out) hipHostFree(h->h_out);
+  hipFree(h->d_pts); hipFree(h->d_cache);
+  if (h->h_partials) hipHostFree(h->h_partials);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
   return VXBA_OK;
