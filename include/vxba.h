@@ -303,6 +303,15 @@ int vxba_lio_state_estimation(vxba_lio* h, double* state, double* cov, double* i
 /* pvec_update (voxelslam.hpp:203-215): world points (n*3) and world covariances (n*9 col-major) of the scan under (state, cov). */
 int vxba_lio_pvec_update(vxba_lio* h, const double* state, const double* cov, double* pwld, double* var);
 
+/* The map-side producers of those plane records (f2's arithmetic; the host tree decides which leaves exist):
+ * cov_add of OctoTree::push (voxel_map.hpp:990-992) = sum over a cell's points of Bf_var (:91-106), n_cells x 81 col-major 9x9, from
+ * world points (n*3), their world covariances (n*9 col-major, e.g. vxba_lio_pvec_update's) and bucket offsets (n_cells + 1);
+ * OctoTree::plane_update (:1118-1146) batched: world cluster (10), its eigen-decomposition (vxba_plane_fit) and cov_add ->
+ * center / normal n*3, plane_var n*36 col-major, radius n (rounded to float as upstream). */
+int vxba_cov_add_build(int device, int64_t n_cells, int64_t n_points, const double* xyz_world, const double* var, const int64_t* cell_ptr, double* cov_add);
+int vxba_plane_update(int device, int64_t n, const double* clusters, const double* eig_val, const double* eig_vec, const double* cov_add, double* center,
+                      double* normal, double* plane_var, double* radius);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* Bit mask of kernels to bracket with hipEvents on the launch stream: 1 = Hessian sweep (K3), 2 = residual sweep (K2),
  * 4 = K3 cross-block reduction, 8 = cluster build (K1); 0 = off. */

@@ -187,3 +187,53 @@ def test_lio_edge_cases_and_errors(vx):
         vx.LioEstimator(1.0, 4)
     with pytest.raises(vx.VxbaError):
         g.lio_state_estimation(st, np.zeros((15, 15)))
+
+
+def test_plane_records_built_on_the_gpu_match_oracle(vx):
+    """The producers of the plane map: world points + covariances per leaf -> cluster (K1) -> eigen-decomposition (K4) -> cov_add
+    (sum of Bf_var) -> plane_update, all on the GPU, against the oracle; then a state estimation on the map so built."""
+    pm = synth.make_plane_map(n_roots=1200, extent=6, seed=2600)
+    carry = np.nonzero(pm.is_plane == 1)[0]
+    rng = np.random.default_rng(2601)
+    counts = rng.integers(12, 60, size=carry.size)
+    cell_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    k = np.repeat(carry, counts)
+    n = pm.normal[k]
+    a = np.cross(n, np.array([0.31, 0.52, 0.79])); a /= np.linalg.norm(a, axis=1, keepdims=True); b = np.cross(n, a)
+    h = pm.box_half[k][:, None] * 0.9
+    world = pm.center[k] + rng.uniform(-1, 1, (k.size, 1)) * h * a + rng.uniform(-1, 1, (k.size, 1)) * h * b + rng.normal(0, 0.02, (k.size, 1)) * n
+    # world covariances of those points as pvec_update leaves them (seen from the origin under a small pose covariance)
+    st = np.concatenate([np.eye(3).reshape(9), np.zeros(15)])
+    o = O.LioOracle(); o.var_init(world.astype(np.float32))
+    g = vx.LioEstimator(); g.var_init(world.astype(np.float32))
+    cov = np.eye(15) * 1e-6
+    pw_o, var_o = o.pvec_update(st, cov); pw_g, var_g = g.pvec_update(st, cov)
+    assert np.allclose(pw_g, pw_o, rtol=1e-14) and np.allclose(var_g, var_o, rtol=1e-11, atol=1e-20)
+    cl_g = vx.build_clusters(pw_g, cell_ptr); cl_o = O.build_clusters(pw_o, cell_ptr)
+    assert np.array_equal(cl_g, cl_o)
+    ev_g, U_g = vx.plane_fit(cl_g); ev_o, U_o = O.plane_fit(cl_o)
+    assert np.allclose(ev_g, ev_o, rtol=1e-9, atol=1e-13)
+    ca_g = vx.cov_add_build(pw_g, var_g, cell_ptr); ca_o = O.cov_add_build(pw_o, var_o, cell_ptr)
+    assert np.allclose(ca_g, ca_o, rtol=1e-12, atol=1e-22) and np.allclose(ca_g, np.transpose(ca_g, (0, 2, 1)), rtol=1e-12, atol=1e-22)
+    # plane_update is quadratic in the eigenvectors: signs cancel, so both sides may use their own decomposition
+    pl_g = vx.plane_update(cl_g, ev_g, U_g, ca_g); pl_o = O.plane_update(cl_o, ev_o, U_o, ca_o)
+    sgn = np.sign(np.sum(pl_g["normal"] * pl_o["normal"], axis=1))
+    assert np.all(np.abs(sgn) == 1) and np.allclose(pl_g["normal"] * sgn[:, None], pl_o["normal"], atol=1e-9)
+    assert np.allclose(pl_g["center"], pl_o["center"], rtol=1e-15) and np.array_equal(pl_g["radius"], pl_o["radius"])
+    S = np.ones((carry.size, 6)); S[:, :3] = sgn[:, None]
+    pv_g = pl_g["plane_var"] * S[:, :, None] * S[:, None, :]
+    scale = np.abs(pl_o["plane_var"]).max(axis=(1, 2), keepdims=True)
+    assert np.all(np.abs(pv_g - pl_o["plane_var"]) <= 1e-7 * scale)       # 1/(lambda_0 - lambda_k) amplifies the eigen-solvers' 1e-13
+    # the fitted planes recover the generating ones, and a scan is localised against the GPU-built map
+    assert np.median(np.abs(np.sum(pl_g["normal"] * pm.normal[carry], axis=1))) > 0.99
+    g2 = vx.LioEstimator(pm.voxel_size, pm.max_layer); o2 = O.LioOracle(pm.voxel_size, pm.max_layer)
+    for e, pl in ((g2, pl_g), (o2, pl_o)):
+        e.map_update(pm.loc[carry], pm.layer[carry], pm.path[carry], pl["center"], pl["normal"], pl["plane_var"], pl["radius"])
+    sc = synth.make_lio_scan(pm, n_points=15000, seed=2602)
+    g2.var_init(sc.xyz); o2.var_init(sc.xyz)
+    rg = g2.lio_state_estimation(sc.state_init, sc.cov); ro = o2.lio_state_estimation(sc.state_init, sc.cov)
+    assert rg["iterations"] == ro["iterations"] and abs(rg["match_num"] - ro["match_num"]) <= 2
+    et, er = synth.pose_errors(rg["state"][None, :12], ro["state"][None, :12])
+    assert et < 1e-6 and er < 1e-6
+    e0 = synth.pose_errors(sc.state_init[None, :12], sc.state_gt[None, :12]); e1 = synth.pose_errors(rg["state"][None, :12], sc.state_gt[None, :12])
+    assert e1[0] < 0.3 * e0[0]

@@ -305,6 +305,104 @@ __global__ void lio_pvec_update_kernel(const double* __restrict__ pts, long long
   for (int k = 0; k < 3; k++) pwld[3 * i + k] = a.R[k] * pnt[0] + a.R[3 + k] * pnt[1] + a.R[6 + k] * pnt[2] + a.p[k];
 }
 
+// ---- plane covariance: the map-side producers of the records above (f2's arithmetic) ----------------------------------------
+// cov_add of OctoTree::push (voxel_map.hpp:990-992): sum over a cell's points of Bf_var (:91-106), the 9x9 covariance of the
+// cluster's (P upper triangle, v) induced by the point covariance.  One lane per cell, points in input order.
+__global__ void lio_cov_add_kernel(const double* __restrict__ xyz, const double* __restrict__ var9, const long long* __restrict__ cell_ptr, long long n_cells,
+                                   double* __restrict__ cov_add) {
+  const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cells) return;
+  double acc[81];
+#pragma unroll
+  for (int k = 0; k < 81; k++) acc[k] = 0.0;
+  for (long long q = cell_ptr[c]; q < cell_ptr[c + 1]; q++) {
+    const double x = xyz[3 * q], y = xyz[3 * q + 1], z = xyz[3 * q + 2];
+    const double* V = var9 + 9 * q;   // column-major 3x3
+    const double Bi[6][3] = {{2 * x, 0, 0}, {y, x, 0}, {z, 0, x}, {0, 2 * y, 0}, {0, z, y}, {0, 0, 2 * z}};
+    double Biup[6][3];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) Biup[r][k] = Bi[r][0] * V[3 * k] + Bi[r][1] * V[3 * k + 1] + Bi[r][2] * V[3 * k + 2];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc[9 * k + r] += Biup[r][0] * Bi[k][0] + Biup[r][1] * Bi[k][1] + Biup[r][2] * Bi[k][2];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) { acc[9 * (6 + k) + r] += Biup[r][k]; acc[9 * r + 6 + k] += Biup[r][k]; }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) acc[9 * (6 + k) + 6 + r] += V[3 * k + r];
+  }
+  double* o = cov_add + 81 * c;
+#pragma unroll
+  for (int k = 0; k < 81; k++) o[k] = acc[k];
+}
+
+// OctoTree::plane_update (voxel_map.hpp:1118-1146): centre, normal, radius and the 6x6 covariance of (normal, centre) by first-order
+// propagation of cov_add through the eigenvector derivative.  One lane per plane.
+__global__ void lio_plane_update_kernel(long long n, const double* __restrict__ clusters, const double* __restrict__ eig_val, const double* __restrict__ eig_vec,
+                                        const double* __restrict__ cov_add, double* __restrict__ center, double* __restrict__ normal, double* __restrict__ plane_var,
+                                        double* __restrict__ radius) {
+  const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  const double N = clusters[10 * a + 9];
+  const double nv = 1.0 / N;
+  const double c[3] = {clusters[10 * a + 6] / N, clusters[10 * a + 7] / N, clusters[10 * a + 8] / N};
+  const double* U = eig_vec + 9 * a;   // column k = eigenvector k
+  const double* lam = eig_val + 3 * a;
+  double u_c[3][9];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int q = 0; q < 9; q++) u_c[r][q] = 0.0;
+  const double* ul = U;                // l = 0
+#pragma unroll
+  for (int k = 1; k < 3; k++) {
+    const double* uk = U + 3 * k;
+    // ukl = u_k u_l^T ; fkl = [ukl(0,0), ukl(1,0)+ukl(0,1), ukl(2,0)+ukl(0,2), ukl(1,1), ukl(1,2)+ukl(2,1), ukl(2,2) | -(u_k.c u_l + u_l.c u_k)]
+    const double kc = uk[0] * c[0] + uk[1] * c[1] + uk[2] * c[2], lc = ul[0] * c[0] + ul[1] * c[1] + ul[2] * c[2];
+    const double fkl[9] = {uk[0] * ul[0], uk[1] * ul[0] + uk[0] * ul[1], uk[2] * ul[0] + uk[0] * ul[2], uk[1] * ul[1], uk[1] * ul[2] + uk[2] * ul[1], uk[2] * ul[2],
+                           -(kc * ul[0] + lc * uk[0]), -(kc * ul[1] + lc * uk[1]), -(kc * ul[2] + lc * uk[2])};
+    const double sc = nv / (lam[0] - lam[k]);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int q = 0; q < 9; q++) u_c[r][q] += sc * uk[r] * fkl[q];
+  }
+  const double* CA = cov_add + 81 * a;  // column-major 9x9
+  double Jc[3][9];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; k++) t += u_c[r][k] * CA[9 * q + k];
+      Jc[r][q] = t;
+    }
+  double* P = plane_var + 36 * a;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; k++) t += Jc[r][k] * u_c[q][k];
+      P[6 * q + r] = t;
+      const double jn = nv * Jc[r][6 + q];
+      P[6 * (3 + q) + r] = jn;
+      P[6 * r + 3 + q] = jn;
+      P[6 * (3 + q) + 3 + r] = nv * nv * CA[9 * (6 + q) + 6 + r];
+    }
+#pragma unroll
+  for (int k = 0; k < 3; k++) { center[3 * a + k] = c[k]; normal[3 * a + k] = ul[k]; }
+  radius[a] = (double)(float)lam[2];
+}
+
 // ---- map maintenance ---------------------------------------------------------------------------------------------------
 __global__ void lio_fill_u64_kernel(unsigned long long* p, long long n, unsigned long long v) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -828,6 +926,62 @@ int vxba_lio_state_estimation(vxba_lio* h, double* state, double* cov, double* i
   vxm::eig_sym3(C6, lam, U);
   if (info) { info[0] = lam[0] < 14 ? 0.0 : 1.0; info[1] = iterations; info[2] = o[51]; info[3] = lam[0]; }
   return VXBA_OK;
+}
+
+// Stand-alone, like vxba_plane_fit: cov_add of OctoTree::push for n_cells buckets of world points.
+int vxba_cov_add_build(int device, int64_t n_cells, int64_t n_points, const double* xyz_world, const double* var, const int64_t* cell_ptr, double* cov_add) {
+  if (n_cells < 0 || n_points < 0 || !cell_ptr || !cov_add || (n_points > 0 && (!xyz_world || !var))) return VXBA_ERR_ARG;
+  if (n_cells == 0) return VXBA_OK;
+  if (cell_ptr[0] != 0 || cell_ptr[n_cells] != n_points) return VXBA_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VXBA_ERR_NODEV;
+  if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_HIP;
+  double *d_xyz = nullptr, *d_var = nullptr, *d_out = nullptr;
+  long long* d_ptr = nullptr;
+  hipError_t e = hipMalloc((void**)&d_xyz, std::max<size_t>(1, (size_t)n_points * 3) * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_var, std::max<size_t>(1, (size_t)n_points * 9) * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_ptr, (size_t)(n_cells + 1) * sizeof(long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_out, (size_t)n_cells * 81 * sizeof(double));
+  if (e == hipSuccess && n_points) e = hipMemcpy(d_xyz, xyz_world, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess && n_points) e = hipMemcpy(d_var, var, (size_t)n_points * 9 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_ptr, cell_ptr, (size_t)(n_cells + 1) * sizeof(long long), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    vxl::lio_cov_add_kernel<<<grid_for(n_cells, 64), 64>>>(d_xyz, d_var, d_ptr, n_cells, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(cov_add, d_out, (size_t)n_cells * 81 * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(d_xyz); hipFree(d_var); hipFree(d_ptr); hipFree(d_out);
+  return e == hipSuccess ? VXBA_OK : VXBA_ERR_HIP;
+}
+
+// OctoTree::plane_update (voxel_map.hpp:1118-1146), batched.
+int vxba_plane_update(int device, int64_t n, const double* clusters, const double* eig_val, const double* eig_vec, const double* cov_add, double* center, double* normal,
+                      double* plane_var, double* radius) {
+  if (n < 0 || (n > 0 && (!clusters || !eig_val || !eig_vec || !cov_add || !center || !normal || !plane_var || !radius))) return VXBA_ERR_ARG;
+  if (n == 0) return VXBA_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VXBA_ERR_NODEV;
+  if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_HIP;
+  const size_t in_len = (size_t)n * (10 + 3 + 9 + 81), out_len = (size_t)n * (3 + 3 + 36 + 1);
+  double *d_in = nullptr, *d_out = nullptr;
+  hipError_t e = hipMalloc((void**)&d_in, in_len * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_out, out_len * sizeof(double));
+  double *d_cl = d_in, *d_ev = d_cl + 10 * n, *d_U = d_ev + 3 * n, *d_ca = d_U + 9 * n;
+  double *d_c = d_out, *d_n = d_c + 3 * n, *d_pv = d_n + 3 * n, *d_r = d_pv + 36 * n;
+  if (e == hipSuccess) e = hipMemcpy(d_cl, clusters, (size_t)n * 10 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_ev, eig_val, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_U, eig_vec, (size_t)n * 9 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_ca, cov_add, (size_t)n * 81 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    vxl::lio_plane_update_kernel<<<grid_for(n, 64), 64>>>(n, d_cl, d_ev, d_U, d_ca, d_c, d_n, d_pv, d_r);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(center, d_c, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(normal, d_n, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(plane_var, d_pv, (size_t)n * 36 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(radius, d_r, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(d_in); hipFree(d_out);
+  return e == hipSuccess ? VXBA_OK : VXBA_ERR_HIP;
 }
 
 }  // extern "C"

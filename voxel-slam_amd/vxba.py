@@ -34,7 +34,7 @@ EXPORTS = [
     "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_li_evaluate",
     "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity", "vxba_voxelize_push", "vxba_set_precision",
     "vxba_lio_create", "vxba_lio_destroy", "vxba_lio_last_error", "vxba_lio_map_update", "vxba_lio_map_clear", "vxba_lio_map_size", "vxba_lio_scan_raw",
-    "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update",
+    "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_cov_add_build", "vxba_plane_update",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -136,6 +136,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_lio_sweep.argtypes = [vp, _f64p, _f64p, ci, _f64p, vp, vp]
     L.vxba_lio_state_estimation.argtypes = [vp, _f64p, _f64p, vp, vp]
     L.vxba_lio_pvec_update.argtypes = [vp, _f64p, _f64p, _f64p, _f64p]
+    L.vxba_cov_add_build.argtypes = [ci, C.c_int64, C.c_int64, _f64p, _f64p, _i64p, _f64p]
+    L.vxba_plane_update.argtypes = [ci, C.c_int64, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p]
     _lib = L
     return L
 
@@ -655,6 +657,31 @@ class LioEstimator:
         pw = np.zeros((n, 3)); var = np.zeros((n, 9))
         self._chk(self._L.vxba_lio_pvec_update(self._h, _c(state), self._cov(cov), pw, var))
         return pw, np.transpose(var.reshape(n, 3, 3), (0, 2, 1)).copy()
+
+
+def cov_add_build(xyz_world, var, cell_ptr, device: int = 0):
+    """cov_add of OctoTree::push (voxel_map.hpp:91-106, 990-992) per cell: n_cells x 9 x 9."""
+    L = load_library()
+    cp = np.ascontiguousarray(cell_ptr, dtype=np.int64); n = cp.shape[0] - 1
+    xyz = _c(xyz_world).reshape(-1, 3)
+    var9 = np.ascontiguousarray(np.transpose(np.asarray(var, dtype=np.float64).reshape(-1, 3, 3), (0, 2, 1)))
+    out = np.zeros((n, 81))
+    rc = L.vxba_cov_add_build(device, n, xyz.shape[0], xyz, var9, cp, out)
+    if rc != 0:
+        raise VxbaError(f"vxba_cov_add_build: {_ERRNAMES.get(rc, rc)}")
+    return np.transpose(out.reshape(n, 9, 9), (0, 2, 1)).copy()
+
+
+def plane_update(clusters, eig_val, eig_vec, cov_add, device: int = 0):
+    """OctoTree::plane_update (voxel_map.hpp:1118-1146) batched: dict(center, normal, plane_var n x 6 x 6, radius)."""
+    L = load_library()
+    cl = _c(clusters).reshape(-1, 10); n = cl.shape[0]
+    ca = np.ascontiguousarray(np.transpose(np.asarray(cov_add, dtype=np.float64).reshape(n, 9, 9), (0, 2, 1))).reshape(n, 81)
+    center = np.zeros((n, 3)); normal = np.zeros((n, 3)); pv = np.zeros((n, 36)); rad = np.zeros(n)
+    rc = L.vxba_plane_update(device, n, cl, _c(eig_val).reshape(n, 3), _c(eig_vec).reshape(n, 9), ca, center, normal, pv, rad)
+    if rc != 0:
+        raise VxbaError(f"vxba_plane_update: {_ERRNAMES.get(rc, rc)}")
+    return dict(center=center, normal=normal, plane_var=np.transpose(pv.reshape(n, 6, 6), (0, 2, 1)).copy(), radius=rad)
 
 
 def rccl_unique_id(librccl_path: str) -> bytes:
