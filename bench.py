@@ -325,7 +325,8 @@ def lio_rate(device, with_cpu, n_points=100_000, n_roots=20_000):
     et, er = synth.pose_errors(res["state"][None, :12], sc.state_gt[None, :12])
     out = {"points": n_points, "map_planes": int(g.map_size()[1]), "map_roots": int(g.map_size()[0]), "iterations": its, "matched": res["match_num"],
            "ms_per_scan": 1e3 * med, "scans_per_s": 1.0 / med, "ms_per_sweep_call": 1e3 * msw, "points_per_s_sweep": n_points / msw,
-           "sweep_algorithmic_GBs": 72.0 * n_points / msw / 1e9, "map_upload_ms": 1e3 * t_map, "var_init_ms": 1e3 * t_scan,
+           # per point: 72 B (pnt + covariance) + 12 B (key + cell entry), and the 256 B plane record for every point that reaches a plane
+           "sweep_algorithmic_bytes": 84.0 * n_points + 256.0 * res["match_num"], "map_upload_ms": 1e3 * t_map, "var_init_ms": 1e3 * t_scan,
            "pose_error_vs_truth_m_rad": [et, er], "where": "match + sums on GPU; 15x15 EKF algebra on host between sweeps"}
     g.close()
     if with_cpu:
