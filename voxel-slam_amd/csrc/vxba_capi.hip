@@ -53,7 +53,8 @@ struct vxba_factor {
   double* own_packed = nullptr;
   double* own_scalar = nullptr;
   unsigned long long* d_count = nullptr;
-  double* h_packed = nullptr;    // pinned
+  double* h_packed = nullptr;    // pinned, mapped
+  double* zc_packed = nullptr;   // device alias of h_packed: kernels of host-driven loops write their result straight into host memory
   double* h_scalar = nullptr;    // pinned
   vxk::LMState* d_lm = nullptr;  // device-resident LM shell state
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
@@ -122,9 +123,10 @@ int ensure_exchange(vxba_factor* f) {
   const bool own_s = !f->d_scalar || f->d_scalar == f->own_scalar;
   if (f->own_packed) VX_HIP(f, hipFree(f->own_packed));
   if (f->h_packed) VX_HIP(f, hipHostFree(f->h_packed));
-  f->own_packed = nullptr; f->own_scalar = nullptr; f->h_packed = nullptr; f->xlen = 0;
+  f->own_packed = nullptr; f->own_scalar = nullptr; f->h_packed = nullptr; f->zc_packed = nullptr; f->xlen = 0;
   VX_HIP(f, hipMalloc((void**)&f->own_packed, (plen + 1) * sizeof(double)));
-  VX_HIP(f, hipHostMalloc((void**)&f->h_packed, (plen + 1) * sizeof(double), hipHostMallocDefault));
+  VX_HIP(f, hipHostMalloc((void**)&f->h_packed, (plen + 1) * sizeof(double), hipHostMallocMapped));
+  VX_HIP(f, hipHostGetDevicePointer((void**)&f->zc_packed, f->h_packed, 0));
   f->own_scalar = f->own_packed + plen;
   if (own_p) f->d_packed = f->own_packed;
   if (own_s) f->d_scalar = f->own_scalar;
@@ -1135,20 +1137,32 @@ void states_to_poses(int W, const double* states, double* Rp) {
   for (int i = 0; i < W; i++) std::memcpy(Rp + 12 * i, states + vxi::STATE_LEN * i, sizeof(double) * 12);   // [R | p] lead the state
 }
 // divide_thread: the Hessian sweep is queued first, the IMU blocks are built on the host while it runs
+// completion of everything queued on the factor's stream, by polling: the sweeps are tens of microseconds, less than what waking
+// up from hipStreamSynchronize costs
+int wait_stream(vxba_factor* f) {
+  hipError_t q;
+  while ((q = hipStreamQuery(f->stream)) == hipErrorNotReady) {}
+  VX_HIP(f, q);
+  return VXBA_OK;
+}
 int li_joint_system(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* Hess, double* JacT, double* residual,
                     bool with_g = false, const double* cov_invs = nullptr) {
   const int W = f->W, n = vxi::DIM * W + (with_g ? 3 : 0), m = 6 * W;
   std::vector<double> Rp(12 * W);
   states_to_poses(W, states, Rp.data());
-  int rc = sweep_hess_device(f, Rp.data(), nullptr, nullptr, nullptr, 0, f->V, f->d_packed);
+  // single GPU: the reduction kernel writes the packed system straight into pinned host memory (no copy to enqueue) and the host
+  // polls for completion after its own half of the work; with a collective the reduced device buffer is copied as before
+  const bool zc = !has_collective(f);
+  int rc = sweep_hess_device(f, Rp.data(), nullptr, nullptr, nullptr, 0, f->V, zc ? f->zc_packed : f->d_packed);
   if (rc) return rc;
-  VX_HIP(f, hipMemcpyAsync(f->h_packed, f->d_packed, vxba_packed_len(f) * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  if (!zc) VX_HIP(f, hipMemcpyAsync(f->h_packed, f->d_packed, vxba_packed_len(f) * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   std::memset(Hess, 0, sizeof(double) * n * n);
   std::memset(JacT, 0, sizeof(double) * n);
   vxi::ImuWork w;
   bool ok = true;
   double res = vxi::li_add_imu_blocks(W, states, imus, imu_coef, true, Hess, JacT, w, &ok, with_g, cov_invs);
-  VX_HIP(f, hipStreamSynchronize(f->stream));
+  rc = wait_stream(f);
+  if (rc) return rc;
   if (!ok) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
   vxi::li_hess_plus(W, Hess, JacT, f->h_packed, f->h_packed + (size_t)m * m, n);
   *residual = res + f->h_packed[(size_t)m * m + m];
@@ -1159,15 +1173,18 @@ int li_joint_residual(vxba_factor* f, const double* states, const double* imus, 
   const int W = f->W;
   std::vector<double> Rp(12 * W);
   states_to_poses(W, states, Rp.data());
-  int rc = sweep_residual_device(f, Rp.data(), nullptr, 0, 0, f->V, f->d_scalar);
+  const bool zc = !has_collective(f);
+  const size_t plen = vxba_packed_len(f);
+  int rc = sweep_residual_device(f, Rp.data(), nullptr, 0, 0, f->V, zc ? f->zc_packed + plen : f->d_scalar);
   if (rc) return rc;
-  VX_HIP(f, hipMemcpyAsync(f->h_scalar, f->d_scalar, sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  if (!zc) VX_HIP(f, hipMemcpyAsync(f->h_scalar, f->d_scalar, sizeof(double), hipMemcpyDeviceToHost, f->stream));
   vxi::ImuWork w;
   bool ok = true;
   const double r1 = vxi::li_add_imu_blocks(W, states, imus, imu_coef, false, nullptr, nullptr, w, &ok, false, cov_invs);
-  VX_HIP(f, hipStreamSynchronize(f->stream));
+  rc = wait_stream(f);
+  if (rc) return rc;
   if (!ok) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
-  *residual = r1 + f->h_scalar[0];
+  *residual = r1 + (zc ? f->h_packed[plen] : f->h_scalar[0]);
   return VXBA_OK;
 }
 }  // namespace

@@ -137,6 +137,24 @@ inline void dm_mul(int m, int k, int n, const double* A, const double* B, double
     }
   }
 }
+// C (k x n) = A^T (A is m x k) * B (m x n) for an A with many exact zeros (the IMU Jacobian: 18 of its 50 3x3 blocks are set):
+// every dot product runs over the non-zero entries of A's column only, in the same order as the dense loop -- the skipped terms
+// are exact zeros, so the result is bit-identical.  m <= 16.
+inline void dm_tmul_sparse_a(int m, int k, int n, const double* A, const double* B, double* C) {
+  for (int i = 0; i < k; i++) {
+    const double* ai = A + (size_t)i * m;
+    int idx[16], cnt = 0;
+    double val[16];
+    for (int p = 0; p < m; p++)
+      if (ai[p] != 0.0) { idx[cnt] = p; val[cnt] = ai[p]; cnt++; }
+    for (int j = 0; j < n; j++) {
+      const double* bj = B + (size_t)j * m;
+      double s = 0.0;
+      for (int q = 0; q < cnt; q++) s += val[q] * bj[idx[q]];
+      C[(size_t)j * k + i] = s;
+    }
+  }
+}
 // C (k x n) = A^T (A is m x k) * B (m x n)
 inline void dm_tmul(int m, int k, int n, const double* A, const double* B, double* C) {
   for (int j = 0; j < n; j++)
@@ -337,7 +355,7 @@ inline double imu_evaluate(const double* f, const double* s1, const double* s2, 
     }
 
     dm_mul(DIM, DIM, nc, w.cov_inv, J, w.ci_j);                     // cov^-1 J   (15 x nc)
-    dm_tmul(DIM, nc, nc, J, w.ci_j, jtj);                           // J^T cov^-1 J
+    dm_tmul_sparse_a(DIM, nc, nc, J, w.ci_j, jtj);                  // J^T cov^-1 J
     // gg = (cov^-1 J)^T r  -- cov^-1 is symmetric up to round-off; the reference forms J^T cov^-1 r
     for (int i = 0; i < nc; i++) {
       double s = 0.0;
