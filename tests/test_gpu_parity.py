@@ -458,20 +458,11 @@ def test_mixed_precision_lm_meets_the_pose_tolerance(vx):
     assert e1[0] < 0.2 * e0[0]
 
 
-def test_two_voxel_shards_with_a_real_cross_shard_sum(vx):
-    """The N > 1 device-resident loop with N = 2 on ONE GPU: two factors hold the two halves of the window's voxels, run
-    Lidar_BA_Optimizer::damping_iter concurrently (one host thread and one stream each), and the all-reduce hook really adds
-    the two exchange buffers.  Each 'rank' must take the same steps as the oracle on the whole window -- which only works if
-    the solve reads the REDUCED system, the decision the reduced residual, and skipped sweeps do not corrupt the state."""
+def run_two_shards(vx, sc, iters):
+    """Two factors holding the two halves of the window's voxels, one host thread + one stream each, an all-reduce hook that really
+    adds the two exchange buffers.  Returns (outputs, hook call counts, factors)."""
     import threading
     import torch
-    # far enough from the optimum that the schedule contains rejected steps as well
-    sc = synth.make_scene(win_size=10, pts_per_scan=40_000, n_voxels=3000, p_obs=0.8, fix_frac=0.1, seed=31337, rot_sigma_deg=0.6, trans_sigma=0.15)
-    fo = O.Oracle(sc.win_size)
-    fo.push_voxels(sc.clusters, sc.fix, sc.coe)
-    fo.evaluate_only_residual(sc.poses_init)
-    iters = 8
-    ref = fo.damping_iter(sc.poses_init, max_iter=iters, thd_num=4)
     cut = sc.n_voxels // 2 + 7
     parts = [(0, cut), (cut, sc.n_voxels)]
     facs, bufs, streams = [], [], []
@@ -522,6 +513,22 @@ def test_two_voxel_shards_with_a_real_cross_shard_sum(vx):
     for t in th:
         t.join(timeout=300)
     assert not errs, errs
+    return out, calls, facs
+
+
+def test_two_voxel_shards_with_a_real_cross_shard_sum(vx):
+    """The N > 1 device-resident loop with N = 2 on ONE GPU: two factors hold the two halves of the window's voxels, run
+    Lidar_BA_Optimizer::damping_iter concurrently (one host thread and one stream each), and the all-reduce hook really adds
+    the two exchange buffers.  Each 'rank' must take the same steps as the oracle on the whole window -- which only works if
+    the solve reads the REDUCED system, the decision the reduced residual, and skipped sweeps do not corrupt the state."""
+    # far enough from the optimum that the schedule contains rejected steps as well
+    sc = synth.make_scene(win_size=10, pts_per_scan=40_000, n_voxels=3000, p_obs=0.8, fix_frac=0.1, seed=31337, rot_sigma_deg=0.6, trans_sigma=0.15)
+    fo = O.Oracle(sc.win_size)
+    fo.push_voxels(sc.clusters, sc.fix, sc.coe)
+    fo.evaluate_only_residual(sc.poses_init)
+    iters = 8
+    ref = fo.damping_iter(sc.poses_init, max_iter=iters, thd_num=4)
+    out, calls, facs = run_two_shards(vx, sc, iters)
     a, b = out
     assert 0 in ref["trace"][:, 6]                                    # the schedule really contains a rejected step
     assert np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["trace"], b["trace"])   # the ranks stay in lockstep, bit for bit
@@ -533,6 +540,28 @@ def test_two_voxel_shards_with_a_real_cross_shard_sum(vx):
     assert et < 1e-7 and er < 1e-7, (et, er)
     # single-collective loop: one all-reduce per iteration (system + trial residual) + the last trial's scalar
     assert calls[0] == calls[1] == a["trace"].shape[0] + 1
+    for f in facs:
+        f.set_allreduce(None)
+        f.use_external_buffers(None, None)
+
+
+def test_two_voxel_shards_of_a_wide_window(vx):
+    """The same emulation for a wide window (top level of the hierarchical BA, SURVEY 8e: the 6W x 6W system is what crosses the
+    links there): every Hessian sweep and every residual sweep is followed by one all-reduce, both ranks take the oracle's steps."""
+    sc = synth.make_scene(win_size=24, pts_per_scan=8000, n_voxels=3000, p_obs=0.2, seed=4242, rot_sigma_deg=0.1, trans_sigma=0.03)
+    fo = O.Oracle(sc.win_size)
+    fo.push_voxels(sc.clusters, sc.fix, sc.coe)
+    fo.evaluate_only_residual(sc.poses_init)
+    iters = 4
+    ref = fo.damping_iter(sc.poses_init, max_iter=iters, thd_num=4)
+    out, calls, facs = run_two_shards(vx, sc, iters)
+    a, b = out
+    assert np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["trace"], b["trace"]) and np.array_equal(a["hess"], b["hess"])
+    assert a["trace"].shape == ref["trace"].shape and np.array_equal(a["trace"][:, 6:], ref["trace"][:, 6:])
+    assert np.allclose(a["trace"][:, :2], ref["trace"][:, :2], rtol=1e-9) and relerr(a["hess"], ref["hess"]) < 1e-8
+    et, er = synth.pose_errors(a["poses"], ref["poses"])
+    assert et < 1e-7 and er < 1e-7, (et, er)
+    assert calls[0] == calls[1] and calls[0] >= a["trace"].shape[0]
     for f in facs:
         f.set_allreduce(None)
         f.use_external_buffers(None, None)
