@@ -312,6 +312,13 @@ int vxba_cov_add_build(int device, int64_t n_cells, int64_t n_points, const doub
 int vxba_plane_update(int device, int64_t n, const double* clusters, const double* eig_val, const double* eig_vec, const double* cov_add, double* center,
                       double* normal, double* plane_var, double* radius);
 
+/* down_sampling_voxel (tools.hpp:201-238): the voxel-grid filter upstream runs on every raw scan before the odometry
+ * (voxelslam.cpp:1236, 1577-1583) and on every merged submap of the hierarchical BA (:2447).  One point per occupied voxel = the
+ * running mean of its points in cloud order, in float and unfused like upstream (bit-identical means); voxel index = upstream's
+ * float quotient / "-1 if negative" / truncation, |index| < 2^20.  xyz n*3 float, out_xyz capacity n*3; output ordered by ascending
+ * (x, y, z) voxel index (upstream: unordered_map iteration order).  voxel_size < 0.001 copies the cloud through, like upstream. */
+int vxba_down_sampling_voxel(int device, int64_t n, const float* xyz, double voxel_size, float* out_xyz, int64_t* n_out);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* Bit mask of kernels to bracket with hipEvents on the launch stream: 1 = Hessian sweep (K3), 2 = residual sweep (K2),
  * 4 = K3 cross-block reduction, 8 = cluster build (K1); 0 = off. */

@@ -535,4 +535,11 @@ void vxo_plane_update(int64_t n, const double* clusters, const double* eig_val, 
   }
 }
 
+int64_t vxo_down_sampling_voxel(int64_t n, const float* xyz, double voxel_size, float* out) {
+  std::vector<float> v(xyz, xyz + 3 * n);
+  down_sampling_voxel(v, voxel_size);
+  std::memcpy(out, v.data(), v.size() * sizeof(float));
+  return (int64_t)(v.size() / 3);
+}
+
 }  // extern "C"

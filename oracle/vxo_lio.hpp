@@ -12,6 +12,7 @@
 // the float-typed voxel index, the float-typed distance tests and the per-point node cache across EKF iterations are the
 // reference's own.  DEG2RAD is PCL's macro ((x)*0.017453293, pcl/pcl_macros.h, PCL 1.10 per README.md:25).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <memory>
@@ -394,6 +395,42 @@ inline void plane_update(const M3& /*P*/, const V3& v, double N, const V3& eig_v
     }
   for (int k = 0; k < 3; k++) { center[k] = c[k]; normal[k] = u[0][k]; }
   radius = (float)eig_value[2];
+}
+
+// down_sampling_voxel (tools.hpp:201-238): running mean per voxel in cloud order, float arithmetic.  Upstream emits the voxels in
+// unordered_map iteration order; this restatement emits them in ascending (x, y, z) voxel index so that outputs can be compared.
+inline void down_sampling_voxel(std::vector<float>& xyz, double voxel_size) {
+  if (voxel_size < 0.001) return;
+  struct Acc { float x, y, z, curvature; };
+  std::unordered_map<LocKey, Acc, LocHash> feat_map;
+  float loc_xyz[3];
+  const size_t n = xyz.size() / 3;
+  for (size_t i = 0; i < n; i++) {
+    const float* p_c = &xyz[3 * i];
+    for (int j = 0; j < 3; j++) {
+      loc_xyz[j] = p_c[j] / voxel_size;
+      if (loc_xyz[j] < 0) loc_xyz[j] -= 1.0;
+    }
+    LocKey position{(int64_t)loc_xyz[0], (int64_t)loc_xyz[1], (int64_t)loc_xyz[2]};
+    auto iter = feat_map.find(position);
+    if (iter == feat_map.end()) {
+      feat_map[position] = Acc{p_c[0], p_c[1], p_c[2], 1};
+    } else {
+      Acc& pp = iter->second;
+      pp.x = (pp.x * pp.curvature + p_c[0]) / (pp.curvature + 1);
+      pp.y = (pp.y * pp.curvature + p_c[1]) / (pp.curvature + 1);
+      pp.z = (pp.z * pp.curvature + p_c[2]) / (pp.curvature + 1);
+      pp.curvature += 1;
+    }
+  }
+  std::vector<std::pair<LocKey, Acc>> cells(feat_map.begin(), feat_map.end());
+  std::sort(cells.begin(), cells.end(), [](const std::pair<LocKey, Acc>& a, const std::pair<LocKey, Acc>& b) {
+    if (a.first.x != b.first.x) return a.first.x < b.first.x;
+    if (a.first.y != b.first.y) return a.first.y < b.first.y;
+    return a.first.z < b.first.z;
+  });
+  xyz.clear();
+  for (auto& c : cells) { xyz.push_back(c.second.x); xyz.push_back(c.second.y); xyz.push_back(c.second.z); }
 }
 
 }  // namespace vxo

@@ -83,6 +83,9 @@ def lib():
     L.vxo_time_lio_state_estimation.argtypes = [vp, f64p, f64p, C.c_int]
     L.vxo_lio_pvec_update.argtypes = [vp, f64p, f64p, f64p, f64p]
     L.vxo_cov_add_build.argtypes = [C.c_int64, i64p, f64p, f64p, f64p]
+    f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+    L.vxo_down_sampling_voxel.restype = C.c_int64
+    L.vxo_down_sampling_voxel.argtypes = [C.c_int64, f32p, C.c_double, f32p]
     L.vxo_plane_update.argtypes = [C.c_int64, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p]
     _LIB = L
     return L
@@ -388,3 +391,11 @@ def plane_update(clusters, eig_val, eig_vec, cov_add):
     center = np.zeros((n, 3)); normal = np.zeros((n, 3)); pv = np.zeros((n, 36)); rad = np.zeros(n)
     lib().vxo_plane_update(n, cl, _c(eig_val).reshape(n, 3), _c(eig_vec).reshape(n, 9), ca, center, normal, pv, rad)
     return dict(center=center, normal=normal, plane_var=np.transpose(pv.reshape(n, 6, 6), (0, 2, 1)).copy(), radius=rad)
+
+
+def down_sampling_voxel(xyz, voxel_size):
+    """down_sampling_voxel (tools.hpp:201-238) on the CPU; output in ascending voxel index."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros_like(xyz)
+    n = lib().vxo_down_sampling_voxel(xyz.shape[0], xyz, float(voxel_size), out)
+    return out[:n].copy()

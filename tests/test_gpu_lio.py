@@ -237,3 +237,22 @@ def test_plane_records_built_on_the_gpu_match_oracle(vx):
     assert et < 1e-6 and er < 1e-6
     e0 = synth.pose_errors(sc.state_init[None, :12], sc.state_gt[None, :12]); e1 = synth.pose_errors(rg["state"][None, :12], sc.state_gt[None, :12])
     assert e1[0] < 0.3 * e0[0]
+
+
+def test_down_sampling_voxel_is_bit_identical(vx):
+    """The voxel-grid filter run on every raw scan and every merged submap: same voxels, same float running means, bit for bit."""
+    rng = np.random.default_rng(2700)
+    for n, size, scale in ((200_000, 0.1, 30.0), (50_000, 0.125, 5.0), (3000, 2.0, 100.0), (1, 0.5, 1.0)):
+        xyz = (rng.normal(size=(n, 3)) * scale).astype(np.float32)
+        xyz[: n // 10] = np.round(xyz[: n // 10] / size) * size            # points sitting on voxel faces, also at negative integers
+        got = vx.down_sampling_voxel(xyz, size); ref = O.down_sampling_voxel(xyz, size)
+        assert got.shape == ref.shape and got.shape[0] <= n
+        assert np.array_equal(got, ref)
+    # dense duplicates: long running-mean chains
+    xyz = np.repeat(rng.uniform(-1, 1, (50, 3)).astype(np.float32), 400, axis=0) + rng.normal(0, 1e-3, (20000, 3)).astype(np.float32)
+    assert np.array_equal(vx.down_sampling_voxel(xyz, 0.5), O.down_sampling_voxel(xyz, 0.5))
+    # pass-through below 1 mm, empty input, index range
+    assert np.array_equal(vx.down_sampling_voxel(xyz[:100], 1e-4), xyz[:100])
+    assert vx.down_sampling_voxel(np.zeros((0, 3), dtype=np.float32), 0.5).shape == (0, 3)
+    with pytest.raises(vx.VxbaError):
+        vx.down_sampling_voxel(np.array([[3e6, 0, 0]], dtype=np.float32), 0.5)

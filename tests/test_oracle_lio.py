@@ -201,3 +201,17 @@ def test_plane_update_is_first_order_covariance_propagation():
         B = np.array([[2 * x[0], 0, 0], [x[1], x[0], 0], [x[2], 0, x[0]], [0, 2 * x[1], 0], [0, x[2], x[1]], [0, 0, 2 * x[2]], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
         expect += B @ V @ B.T
     assert np.allclose(ca, expect, rtol=1e-12)
+
+
+def test_down_sampling_voxel_running_mean():
+    rng = np.random.default_rng(77)
+    xyz = rng.uniform(-20, 20, size=(20000, 3)).astype(np.float32)
+    out = O.down_sampling_voxel(xyz, 0.5)
+    # one point per occupied voxel (float-typed index as upstream), each inside its voxel, close to the plain mean
+    loc = (xyz.astype(np.float64) / 0.5).astype(np.float32); loc = np.where(loc < 0, loc - np.float32(1.0), loc).astype(np.int64)
+    uniq, inv, cnt = np.unique(loc, axis=0, return_inverse=True, return_counts=True)
+    assert out.shape[0] == uniq.shape[0]
+    mean = np.zeros((uniq.shape[0], 3)); np.add.at(mean, inv.ravel(), xyz.astype(np.float64)); mean /= cnt[:, None]
+    assert np.allclose(out, mean, atol=2e-5)                         # np.unique sorts rows lexicographically = the oracle's order
+    # voxel sizes below 1 mm leave the cloud alone (tools.hpp:203)
+    assert np.array_equal(O.down_sampling_voxel(xyz[:50], 1e-4), xyz[:50])

@@ -1,0 +1,131 @@
+// Voxel-grid down-sampling on the GPU: `down_sampling_voxel` (VoxelSLAM/src/tools.hpp:201-238), the filter the reference runs on
+// every raw scan before the odometry (voxelslam.cpp:1236, 1577-1583) and on every merged submap of the hierarchical BA (:2447).
+// Upstream: an unordered_map from voxel index to a running mean, updated point by point in cloud order, in float.  Here: one key
+// per point (upstream's float-typed voxel index), one stable radix sort, run-length encode + scan for the cell table, and one lane
+// per occupied voxel that replays the running-mean recurrence over its points in cloud order with unfused float arithmetic -- the
+// means are bit-identical to upstream's.  Output order is ascending (x, y, z) voxel index (upstream: hash-map iteration order,
+// which is implementation-defined).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "../../include/vxba.h"
+
+namespace vxd {
+
+constexpr long long OFF = 1ll << 20;   // voxel indices in [-2^20, 2^20)
+
+__global__ void ds_key_kernel(const float* __restrict__ xyz, long long n, double voxel_size, unsigned long long* __restrict__ key, unsigned int* __restrict__ idx,
+                              int* __restrict__ err) {
+#pragma clang fp contract(off)
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  unsigned long long k = 0;
+  for (int j = 0; j < 3; j++) {
+    float loc = (float)((double)xyz[3 * q + j] / voxel_size);   // loc_xyz[j] = p_c.data[j] / voxel_size   (:211)
+    if (loc < 0) loc = (float)((double)loc - 1.0);              // loc_xyz[j] -= 1.0                         (:212-213)
+    const long long pos = (long long)loc;
+    if (pos < -OFF || pos >= OFF) { *err = 1; return; }
+    k = (k << 21) | (unsigned long long)(pos + OFF);
+  }
+  key[q] = k;
+  idx[q] = (unsigned int)q;
+}
+
+// pp = (pp * curvature + p) / (curvature + 1), curvature += 1   (:227-230), float, unfused, in cloud order
+__global__ void ds_mean_kernel(const float* __restrict__ xyz, const unsigned int* __restrict__ idx_sorted, const long long* __restrict__ cell_ptr, long long n_cells,
+                               float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cells) return;
+  long long q = cell_ptr[c];
+  const long long end = cell_ptr[c + 1];
+  unsigned int i = idx_sorted[q];
+  float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2], cur = 1.0f;
+  for (q++; q < end; q++) {
+    i = idx_sorted[q];
+    const float d = cur + 1.0f;
+    x = (x * cur + xyz[3 * (size_t)i]) / d;
+    y = (y * cur + xyz[3 * (size_t)i + 1]) / d;
+    z = (z * cur + xyz[3 * (size_t)i + 2]) / d;
+    cur = d;
+  }
+  out[3 * c] = x; out[3 * c + 1] = y; out[3 * c + 2] = z;
+}
+
+__global__ void ds_widen_kernel(const unsigned int* __restrict__ cnt, long long n, long long* __restrict__ out) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) out[q] = (long long)cnt[q];
+  if (q == n) out[q] = 0;
+}
+
+}  // namespace vxd
+
+extern "C" int vxba_down_sampling_voxel(int device, int64_t n, const float* xyz, double voxel_size, float* out_xyz, int64_t* n_out) {
+  if (n < 0 || !n_out || (n > 0 && (!xyz || !out_xyz)) || n >= (1ll << 32)) return VXBA_ERR_ARG;
+  *n_out = 0;
+  if (n == 0) return VXBA_OK;
+  if (voxel_size < 0.001) {   // upstream returns the cloud untouched (:203)
+    std::memcpy(out_xyz, xyz, (size_t)n * 3 * sizeof(float));
+    *n_out = n;
+    return VXBA_OK;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VXBA_ERR_NODEV;
+  if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_HIP;
+  hipStream_t s = nullptr;
+  float *d_xyz = nullptr, *d_out = nullptr;
+  unsigned long long *d_key = nullptr, *d_key_s = nullptr, *d_ukey = nullptr;
+  unsigned int *d_idx = nullptr, *d_idx_s = nullptr, *d_cnt = nullptr, *d_runs = nullptr;
+  long long* d_ptr = nullptr;
+  int* d_err = nullptr;
+  void* d_temp = nullptr;
+  size_t t_sort = 0, t_rle = 0, t_scan = 0;
+  int rc = VXBA_OK;
+  unsigned int runs = 0;
+  int err = 0;
+  const unsigned grid = (unsigned)((n + 255) / 256), grid1 = (unsigned)((n + 256) / 256);
+#define DS(call) do { if ((call) != hipSuccess) { rc = VXBA_ERR_HIP; goto done; } } while (0)
+  DS(hipMalloc((void**)&d_xyz, (size_t)n * 3 * sizeof(float)));
+  DS(hipMalloc((void**)&d_out, (size_t)n * 3 * sizeof(float)));
+  DS(hipMalloc((void**)&d_key, (size_t)n * 8)); DS(hipMalloc((void**)&d_key_s, (size_t)n * 8)); DS(hipMalloc((void**)&d_ukey, (size_t)n * 8));
+  DS(hipMalloc((void**)&d_idx, (size_t)n * 4)); DS(hipMalloc((void**)&d_idx_s, (size_t)n * 4)); DS(hipMalloc((void**)&d_cnt, (size_t)n * 4));
+  DS(hipMalloc((void**)&d_runs, 4)); DS(hipMalloc((void**)&d_ptr, (size_t)(n + 1) * 8)); DS(hipMalloc((void**)&d_err, 4));
+  DS(hipMemset(d_err, 0, 4));
+  DS(rocprim::radix_sort_pairs(nullptr, t_sort, d_key, d_key_s, d_idx, d_idx_s, (size_t)n, 0, 63, s));
+  DS(rocprim::run_length_encode(nullptr, t_rle, d_key_s, (size_t)n, d_ukey, d_cnt, d_runs, s));
+  DS(rocprim::exclusive_scan(nullptr, t_scan, d_ptr, d_ptr, 0ll, (size_t)n + 1, rocprim::plus<long long>(), s));
+  {
+    size_t t = t_sort > t_rle ? t_sort : t_rle;
+    if (t_scan > t) t = t_scan;
+    DS(hipMalloc(&d_temp, t ? t : 8));
+    DS(hipMemcpy(d_xyz, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    vxd::ds_key_kernel<<<grid, 256, 0, s>>>(d_xyz, n, voxel_size, d_key, d_idx, d_err);
+    DS(hipGetLastError());
+    DS(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
+    if (err) { rc = VXBA_ERR_ARG; goto done; }   // a voxel index outside [-2^20, 2^20)
+    size_t tt = t;
+    DS(rocprim::radix_sort_pairs(d_temp, tt, d_key, d_key_s, d_idx, d_idx_s, (size_t)n, 0, 63, s));
+    tt = t;
+    DS(rocprim::run_length_encode(d_temp, tt, d_key_s, (size_t)n, d_ukey, d_cnt, d_runs, s));
+    DS(hipMemcpy(&runs, d_runs, 4, hipMemcpyDeviceToHost));
+    vxd::ds_widen_kernel<<<grid1, 256, 0, s>>>(d_cnt, (long long)runs, d_ptr);
+    DS(hipGetLastError());
+    tt = t;
+    DS(rocprim::exclusive_scan(d_temp, tt, d_ptr, d_ptr, 0ll, (size_t)runs + 1, rocprim::plus<long long>(), s));
+    vxd::ds_mean_kernel<<<(unsigned)((runs + 63) / 64), 64, 0, s>>>(d_xyz, d_idx_s, d_ptr, (long long)runs, d_out);
+    DS(hipGetLastError());
+    DS(hipMemcpy(out_xyz, d_out, (size_t)runs * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    *n_out = (int64_t)runs;
+  }
+done:
+#undef DS
+  hipFree(d_xyz); hipFree(d_out); hipFree(d_key); hipFree(d_key_s); hipFree(d_ukey); hipFree(d_idx); hipFree(d_idx_s); hipFree(d_cnt);
+  hipFree(d_runs); hipFree(d_ptr); hipFree(d_err); hipFree(d_temp);
+  return rc;
+}

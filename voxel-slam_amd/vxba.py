@@ -34,7 +34,7 @@ EXPORTS = [
     "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_li_evaluate",
     "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity", "vxba_voxelize_push", "vxba_set_precision",
     "vxba_lio_create", "vxba_lio_destroy", "vxba_lio_last_error", "vxba_lio_map_update", "vxba_lio_map_clear", "vxba_lio_map_size", "vxba_lio_scan_raw",
-    "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_cov_add_build", "vxba_plane_update",
+    "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_cov_add_build", "vxba_plane_update", "vxba_down_sampling_voxel",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -137,6 +137,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_lio_state_estimation.argtypes = [vp, _f64p, _f64p, vp, vp]
     L.vxba_lio_pvec_update.argtypes = [vp, _f64p, _f64p, _f64p, _f64p]
     L.vxba_cov_add_build.argtypes = [ci, C.c_int64, C.c_int64, _f64p, _f64p, _i64p, _f64p]
+    L.vxba_down_sampling_voxel.argtypes = [ci, C.c_int64, np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS"), cd,
+                                           np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS"), C.POINTER(C.c_int64)]
     L.vxba_plane_update.argtypes = [ci, C.c_int64, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p]
     _lib = L
     return L
@@ -657,6 +659,18 @@ class LioEstimator:
         pw = np.zeros((n, 3)); var = np.zeros((n, 9))
         self._chk(self._L.vxba_lio_pvec_update(self._h, _c(state), self._cov(cov), pw, var))
         return pw, np.transpose(var.reshape(n, 3, 3), (0, 2, 1)).copy()
+
+
+def down_sampling_voxel(xyz, voxel_size: float, device: int = 0):
+    """``down_sampling_voxel`` (tools.hpp:201-238) on float32 points; one point per occupied voxel, ascending voxel index."""
+    L = load_library()
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros_like(xyz)
+    n_out = C.c_int64()
+    rc = L.vxba_down_sampling_voxel(device, xyz.shape[0], xyz, float(voxel_size), out, C.byref(n_out))
+    if rc != 0:
+        raise VxbaError(f"vxba_down_sampling_voxel: {_ERRNAMES.get(rc, rc)}")
+    return out[: n_out.value].copy()
 
 
 def cov_add_build(xyz_world, var, cell_ptr, device: int = 0):
