@@ -48,3 +48,33 @@ def test_hba_window_matches_oracle_schedule_and_recovers_poses():
     assert len(ge) == len(re_) > 0
     for a, b in zip(ge, re_):
         assert (a["i"], a["j"]) == (b["i"], b["j"]) and np.allclose(a["v6"], b["v6"], rtol=1e-5) and np.allclose(a["tra"], b["tra"], atol=1e-6)
+
+
+@pytest.mark.parametrize("K,wdsize,mgsize", [(18, 6, 3), (45, 6, 3)])
+def test_hierarchical_pass_matches_oracle(K, wdsize, mgsize):
+    """Bottom-up pass over a session: windows -> one HBA_add_edge round each -> merged + voxel-filtered submaps -> top-level
+    HBA_add_edge over the submap poses (5 of them: MFMA path; 14 of them: wide-window path).  GPU vs the same orchestration on the
+    CPU oracle: same submap sizes, same factor counts, same edges."""
+    from voxel_slam_amd import hba, vxba
+    xyz, fp, poses, gt = synth.make_scans(win_size=K, pts_per_scan=5000, extent=24.0, noise=0.005, seed=synth.MASTER_SEED + 950 + K,
+                                          rot_sigma_deg=0.1, trans_sigma=0.02)
+    clouds = [xyz[fp[i]:fp[i + 1]].astype(np.float32) for i in range(K)]
+    coarse = vxba.VoxelizeParams(voxel_size=2.0, max_layer=2, min_points=10, min_eigen_value=0.02, eigen_ratio=(1 / 9, 1 / 9, 1 / 9, 1 / 9))
+    fine = vxba.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
+    got = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=wdsize, mgsize=mgsize, top_max_iter=2)
+    ref = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=wdsize, mgsize=mgsize, top_max_iter=2, optimizer=_OracleOpt(), voxelize=_oracle_voxelize,
+                              downsample=O.down_sampling_voxel)
+    S = (K - wdsize) // mgsize + 1
+    assert got["submap_ids"] == ref["submap_ids"] and len(got["submap_ids"]) == S
+    assert got["submap_sizes"] == ref["submap_sizes"]
+    assert [r["n_voxels"] for r in got["top_rounds"]] == [r["n_voxels"] for r in ref["top_rounds"]]
+    et, er = synth.pose_errors(got["submap_poses"], ref["submap_poses"])
+    assert et < 1e-6 and er < 1e-6, (et, er)
+    for key in ("edges1", "edges2"):
+        assert len(got[key]) == len(ref[key]) > 0
+        for a, b in zip(got[key], ref[key]):
+            assert (a["i"], a["j"]) == (b["i"], b["j"]) and np.allclose(a["v6"], b["v6"], rtol=1e-4) and np.allclose(a["tra"], b["tra"], atol=1e-6)
+    # the top level pulls the submap anchors towards the truth
+    ids = got["submap_ids"]
+    e0 = synth.pose_errors(poses[ids], gt[ids]); e1 = synth.pose_errors(got["submap_poses"], gt[ids])
+    assert e1[0] < e0[0]

@@ -60,3 +60,47 @@ def edges_from_hessian(poses, hess, min_abs: float = 1e-6):
                 continue
             out.append(dict(i=i, j=j, rot=R[i].T @ R[j], tra=R[i].T @ (p[j] - p[i]), v6=1.0 / hc))
     return out
+
+
+def merge_submap(clouds, poses, voxel_size: float, downsample=None, device: int = 0):
+    """Tail of ``HBA_add_edge`` (voxelslam.cpp:2430-2450): the window's scans expressed in the FIRST frame's coordinates
+    (dR = R0^T Ri, dp = R0^T (pi - p0)), stored as float like ``PointType``, then ``down_sampling_voxel(pl, voxel_size / 8)``."""
+    W = poses.shape[0]
+    R = poses[:, :9].reshape(W, 3, 3).transpose(0, 2, 1)
+    p = poses[:, 9:12]
+    parts = []
+    for i in range(W):
+        dR = R[0].T @ R[i]; dp = R[0].T @ (p[i] - p[0])
+        parts.append((np.asarray(clouds[i], dtype=np.float64) @ dR.T + dp).astype(np.float32))
+    pl = np.ascontiguousarray(np.concatenate(parts))
+    ds = (lambda x, s: vxba.down_sampling_voxel(x, s, device=device)) if downsample is None else downsample
+    return ds(pl, voxel_size / 8)
+
+
+def hierarchical_ba(clouds, poses, coarse: "vxba.VoxelizeParams", fine: "vxba.VoxelizeParams", wdsize: int = 10, mgsize: int = 5, top_max_iter: int = 1,
+                    device: int = 0, optimizer=None, voxelize=None, downsample=None):
+    """Bottom-up pass of the global mapping thread (``thd_globalmapping``, voxelslam.cpp:2485-2595) over one session: windows of
+    ``wdsize`` keyframes, stride ``mgsize``, each refined by one round of ``HBA_add_edge`` (max_iter = 1: the odometry's voxel
+    parameters straight away, :2362-2372) and merged into a submap anchored at its first keyframe; then one ``HBA_add_edge`` over all
+    submap poses (the top level, up to VXBA_MAX_WIN_WIDE of them) with ``top_max_iter`` rounds.  Returns the pose-graph edges of both
+    levels (the GTSAM optimisation that consumes them is outside this library) and the refined submap poses.
+    ``clouds``: list of (n_i, 3) arrays in keyframe coordinates; ``poses``: (K, 12).  The keyword hooks run the same schedule on the
+    CPU oracle in the tests."""
+    K = poses.shape[0]
+    sub_clouds, sub_ids, edges1 = [], [], []
+    for base in range(0, K - wdsize + 1, mgsize):
+        ids = list(range(base, base + wdsize))
+        xyz = np.ascontiguousarray(np.concatenate([np.asarray(clouds[i], dtype=np.float64) for i in ids]))
+        fp = np.concatenate([[0], np.cumsum([len(clouds[i]) for i in ids])]).astype(np.int64)
+        r = window_refine(xyz, fp, poses[ids], coarse, fine, max_iter=1, device=device, optimizer=optimizer, voxelize=None if voxelize is None else voxelize(wdsize))
+        for e in edges_from_hessian(r["poses"], r["hess"]):
+            edges1.append(dict(e, i=ids[e["i"]], j=ids[e["j"]]))
+        sub_clouds.append(merge_submap([clouds[i] for i in ids], r["poses"], fine.voxel_size, downsample=downsample, device=device))
+        sub_ids.append(base)
+    S = len(sub_ids)
+    top_xyz = np.ascontiguousarray(np.concatenate(sub_clouds).astype(np.float64))
+    top_fp = np.concatenate([[0], np.cumsum([len(c) for c in sub_clouds])]).astype(np.int64)
+    top = window_refine(top_xyz, top_fp, poses[sub_ids], coarse, fine, max_iter=top_max_iter, device=device, optimizer=optimizer,
+                        voxelize=None if voxelize is None else voxelize(S))
+    edges2 = [dict(e, i=sub_ids[e["i"]], j=sub_ids[e["j"]]) for e in edges_from_hessian(top["poses"], top["hess"])]
+    return dict(edges1=edges1, edges2=edges2, submap_ids=sub_ids, submap_poses=top["poses"], submap_sizes=[len(c) for c in sub_clouds], top_rounds=top["rounds"])
