@@ -512,6 +512,8 @@ struct vxba_lio {
   long long n_pts = 0, pts_stride = 0, pts_cap = 0;
   int* d_cache = nullptr;
   bool cache_valid = false;
+  char* d_stage = nullptr;       // grow-only device staging for host arrays crossing the boundary (no hipMalloc / hipFree per call)
+  size_t stage_cap = 0;
   double* h_partials = nullptr;  // pinned, mapped: one 34-number partial per workgroup lands here (zero-copy stores)
   double* d_partials = nullptr;  // device alias of h_partials
   double h_out[vxl::SWEEP_OUT];  // the sweep's 52 numbers, assembled on the host
@@ -574,6 +576,20 @@ int lio_map_reserve(vxba_lio* h, long long more) {
     if (h->d_planes) { LIO_HIP(h, hipFree(h->d_planes)); LIO_HIP(h, hipFree(h->d_plane_tag)); }
     h->d_planes = np; h->d_plane_tag = nt; h->plane_cap = ncap;
   }
+  return VXBA_OK;
+}
+
+// device staging of at least `bytes` (grow-only; contents are not preserved)
+int lio_stage(vxba_lio* h, size_t bytes, char** out) {
+  if (bytes > h->stage_cap) {
+    if (h->d_stage) { LIO_HIP(h, hipStreamSynchronize(h->stream)); LIO_HIP(h, hipFree(h->d_stage)); }
+    h->d_stage = nullptr; h->stage_cap = 0;
+    size_t cap = std::max<size_t>(bytes, (size_t)1 << 20);
+    cap += cap / 4;
+    LIO_HIP(h, hipMalloc((void**)&h->d_stage, cap));
+    h->stage_cap = cap;
+  }
+  *out = h->d_stage;
   return VXBA_OK;
 }
 
@@ -675,7 +691,7 @@ int vxba_lio_destroy(vxba_lio* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   hipFree(h->d_keys); hipFree(h->d_cells); hipFree(h->d_planes); hipFree(h->d_plane_tag); hipFree(h->d_counters);
-  hipFree(h->d_pts); hipFree(h->d_cache);
+  hipFree(h->d_pts); hipFree(h->d_cache); hipFree(h->d_stage);
   if (h->h_partials) hipHostFree(h->h_partials);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -717,7 +733,8 @@ int vxba_lio_map_update(vxba_lio* h, int64_t n, const int64_t* loc, const int32_
   const size_t b_loc = (size_t)n * 3 * sizeof(int64_t), b_i = (size_t)n * sizeof(int32_t), b_3 = (size_t)n * 3 * sizeof(double), b_36 = (size_t)n * 36 * sizeof(double), b_1 = (size_t)n * sizeof(double);
   const size_t total = b_loc + 3 * ((b_i + 7) / 8 * 8) + 2 * b_3 + b_36 + b_1;
   char* d = nullptr;
-  LIO_HIP(h, hipMalloc((void**)&d, total));
+  rc = lio_stage(h, total, &d);
+  if (rc != VXBA_OK) return rc;
   char* q = d;
   auto put = [&](const void* src, size_t bytes, size_t slot_bytes) -> hipError_t { hipError_t e = hipMemcpyAsync(q, src, bytes, hipMemcpyHostToDevice, h->stream); q += slot_bytes; return e; };
   const long long* d_loc = (const long long*)q; hipError_t e = put(loc, b_loc, b_loc);
@@ -736,7 +753,6 @@ int vxba_lio_map_update(vxba_lio* h, int64_t n, const int64_t* loc, const int32_
   int cnt[2] = {0, 0};
   if (e == hipSuccess) e = hipMemcpyAsync(cnt, h->d_counters, sizeof cnt, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  hipFree(d);
   if (e != hipSuccess) { h->err = std::string("vxba_lio_map_update: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
   h->n_roots = cnt[0]; h->n_planes = cnt[1];
   h->cache_valid = false;   // plane indices held in the per-point cache may be stale
@@ -757,7 +773,8 @@ int vxba_lio_scan_set(vxba_lio* h, int64_t n, const double* pnt, const double* v
   int rc = lio_scan_reserve(h, n);
   if (rc != VXBA_OK || n == 0) return rc;
   double* d = nullptr;
-  LIO_HIP(h, hipMalloc((void**)&d, (size_t)n * 12 * sizeof(double)));
+  rc = lio_stage(h, (size_t)n * 12 * sizeof(double), (char**)&d);
+  if (rc != VXBA_OK) return rc;
   hipError_t e = hipMemcpyAsync(d, pnt, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d + 3 * n, var, (size_t)n * 9 * sizeof(double), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) {
@@ -765,7 +782,6 @@ int vxba_lio_scan_set(vxba_lio* h, int64_t n, const double* pnt, const double* v
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  hipFree(d);
   if (e != hipSuccess) { h->err = std::string("vxba_lio_scan_set: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
   return VXBA_OK;
 }
@@ -783,14 +799,14 @@ int vxba_lio_scan_raw(vxba_lio* h, int64_t n, const float* xyz, const double* ex
   const float range_inc = (float)dept_err, degree_inc = (float)beam_err;       // calcBodyVar takes them as float (voxelslam.hpp:164)
   const double dir_var = std::pow(std::sin((degree_inc) * 0.017453293), 2);   // pow(sin(DEG2RAD(degree_inc)), 2), PCL's DEG2RAD
   float* d = nullptr;
-  LIO_HIP(h, hipMalloc((void**)&d, (size_t)n * 3 * sizeof(float)));
+  rc = lio_stage(h, (size_t)n * 3 * sizeof(float), (char**)&d);
+  if (rc != VXBA_OK) return rc;
   hipError_t e = hipMemcpyAsync(d, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) {
     vxl::lio_var_init_kernel<<<grid_for(n), 256, 0, h->stream>>>(d, n, h->pts_stride, e12, range_inc, dir_var, h->d_pts);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  hipFree(d);
   if (e != hipSuccess) { h->err = std::string("vxba_lio_scan_raw: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
   return VXBA_OK;
 }
@@ -804,13 +820,15 @@ int vxba_lio_scan_read(vxba_lio* h, double* pnt, double* var) {
   LIO_HIP(h, hipSetDevice(h->device));
   const long long n = h->n_pts;
   double* d = nullptr;
-  LIO_HIP(h, hipMalloc((void**)&d, (size_t)n * 12 * sizeof(double)));
+  {
+    int rcs = lio_stage(h, (size_t)n * 12 * sizeof(double), (char**)&d);
+    if (rcs != VXBA_OK) return rcs;
+  }
   vxl::lio_scan_unpack_kernel<<<grid_for(n), 256, 0, h->stream>>>(h->d_pts, n, h->pts_stride, d, d + 3 * n);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(pnt, d, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(var, d + 3 * n, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  hipFree(d);
   if (e != hipSuccess) { h->err = std::string("vxba_lio_scan_read: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
   return VXBA_OK;
 }
@@ -822,13 +840,15 @@ int vxba_lio_pvec_update(vxba_lio* h, const double* state, const double* cov, do
   LIO_HIP(h, hipSetDevice(h->device));
   const long long n = h->n_pts;
   double* d = nullptr;
-  LIO_HIP(h, hipMalloc((void**)&d, (size_t)n * 12 * sizeof(double)));
+  {
+    int rcs = lio_stage(h, (size_t)n * 12 * sizeof(double), (char**)&d);
+    if (rcs != VXBA_OK) return rcs;
+  }
   vxl::lio_pvec_update_kernel<<<grid_for(n), 256, 0, h->stream>>>(h->d_pts, n, h->pts_stride, sweep_arg(state, cov), d, d + 3 * n);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(pwld, d, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(var, d + 3 * n, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  hipFree(d);
   if (e != hipSuccess) { h->err = std::string("vxba_lio_pvec_update: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
   return VXBA_OK;
 }
@@ -841,9 +861,10 @@ int vxba_lio_sweep(vxba_lio* h, const double* state, const double* cov, int rese
   int* d_pop = nullptr; double* d_sig = nullptr;
   const long long n = h->n_pts;
   if (plane_of_point && n) {
-    LIO_HIP(h, hipMalloc((void**)&d_pop, (size_t)n * sizeof(int)));
-    hipError_t e = hipMalloc((void**)&d_sig, (size_t)n * sizeof(double));
-    if (e != hipSuccess) { hipFree(d_pop); h->err = "vxba_lio_sweep: hipMalloc"; return VXBA_ERR_HIP; }
+    char* st = nullptr;
+    int rcs = lio_stage(h, (size_t)n * (sizeof(double) + sizeof(int)), &st);
+    if (rcs != VXBA_OK) return rcs;
+    d_sig = (double*)st; d_pop = (int*)(st + (size_t)n * sizeof(double));
   }
   int rc = lio_sweep(h, state, cov, reset_cache != 0, d_pop, d_sig);
   if (rc == VXBA_OK && d_pop) {
@@ -851,7 +872,6 @@ int vxba_lio_sweep(vxba_lio* h, const double* state, const double* cov, int rese
     if (e == hipSuccess) e = hipMemcpy(sigma_of_point, d_sig, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
     if (e != hipSuccess) { h->err = std::string("vxba_lio_sweep: ") + hipGetErrorString(e); rc = VXBA_ERR_HIP; }
   }
-  hipFree(d_pop); hipFree(d_sig);
   if (rc == VXBA_OK) std::memcpy(out, h->h_out, sizeof(double) * vxl::SWEEP_OUT);
   return rc;
 }
