@@ -27,6 +27,9 @@ CONFIGS = {
     "cfg2": dict(win_size=10, pts_per_scan=100_000, n_voxels=50_000),
     "cfg3": dict(win_size=10, pts_per_scan=200_000, n_voxels=100_000),
     "cfg4": dict(win_size=10, pts_per_scan=1_000_000, n_voxels=400_000),
+    # SURVEY 8d's secondary runs of cfg2: half the (voxel, frame) incidences missing; 30 % of the voxels with a world-frame fix cluster
+    "cfg2_sparse": dict(win_size=10, pts_per_scan=100_000, n_voxels=50_000, p_obs=0.5),
+    "cfg2_fix": dict(win_size=10, pts_per_scan=100_000, n_voxels=50_000, fix_frac=0.3),
 }
 
 
