@@ -42,7 +42,7 @@ constexpr int SWEEP_OUT = 52;    // HTH 36 col-major | HTz 6 | nnt 9 col-major |
 constexpr unsigned long long EMPTY_KEY = ~0ull;
 constexpr long long LOC_OFF = 1ll << 20;   // root voxel indices in [-2^20, 2^20)
 constexpr int BLOCK = 512;        // 8 waves; one point per lane and pass
-constexpr int MAX_GRID = 256;     // one workgroup per CU; larger scans loop inside the lanes
+constexpr int MAX_GRID = 256;     // one workgroup per CU; larger scans loop inside the lanes (multiple of 8: see the XCD mapping)
 
 struct MapView {
   const unsigned long long* keys;
@@ -174,7 +174,12 @@ __global__ __launch_bounds__(BLOCK) void lio_sweep_kernel(MapView m, SweepArg a,
   double s[NSUM];
 #pragma unroll
   for (int k = 0; k < NSUM; k++) s[k] = 0.0;
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) {
+  // XCD-aware: workgroups are dealt round-robin to the 8 XCDs, each with its own L2; giving XCD x the x-th contiguous eighth of the
+  // scan keeps neighbouring returns -- which hit the same plane records -- behind one L2 instead of spreading every record over all eight
+  const unsigned per = gridDim.x / 8;   // the launch rounds the grid up to a multiple of 8
+  const unsigned vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  const unsigned nvb = gridDim.x;
+  for (long long i = (long long)vb * BLOCK + threadIdx.x; i < n; i += (long long)nvb * BLOCK) {
     double pnt[3], var[6];
 #pragma unroll
     for (int k = 0; k < 3; k++) pnt[k] = pts[k * n_stride + i];
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(BLOCK) void lio_sweep_kernel(MapView m, SweepArg a,
     double t = red[0][threadIdx.x];
 #pragma unroll
     for (int q = 1; q < BLOCK / 64; q++) t += red[q][threadIdx.x];
-    partials[(size_t)blockIdx.x * NSUM + threadIdx.x] = t;   // host-mapped: 272 contiguous bytes per workgroup, summed by the caller
+    partials[(size_t)vb * NSUM + threadIdx.x] = t;   // host-mapped: 272 contiguous bytes per workgroup, summed by the caller
   }
 }
 
@@ -639,7 +644,7 @@ int lio_sweep(vxba_lio* h, const double* state, const double* cov225, bool reset
     if (rc != VXBA_OK) return rc;
   }
   const bool use_cache = h->cache_valid && !reset_cache;
-  const unsigned grid = std::min<unsigned>(grid_for(h->n_pts, vxl::BLOCK), vxl::MAX_GRID);
+  const unsigned grid = std::min<unsigned>((grid_for(h->n_pts, vxl::BLOCK) + 7) / 8 * 8, vxl::MAX_GRID);   // a multiple of 8: one contiguous share of the scan per XCD
   vxl::lio_sweep_kernel<<<grid, vxl::BLOCK, 0, h->stream>>>(map_view(h), sweep_arg(state, cov225), h->d_pts, h->n_pts, h->pts_stride, h->d_cache, use_cache ? 1 : 0, h->d_partials,
                                                             d_plane_of_point, d_sigma_of_point);
   LIO_HIP(h, hipGetLastError());

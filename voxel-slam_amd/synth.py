@@ -401,10 +401,15 @@ class LioScan:
     cov: np.ndarray        # 15x15
 
 
-def make_lio_scan(pm: PlaneMapData, n_points=20_000, noise=0.02, clutter_frac=0.05, rot_sigma_deg=0.3, trans_sigma=0.03, seed=MASTER_SEED + 901) -> LioScan:
+def make_lio_scan(pm: PlaneMapData, n_points=20_000, noise=0.02, clutter_frac=0.05, rot_sigma_deg=0.3, trans_sigma=0.03, seed=MASTER_SEED + 901,
+                  coherent=False, planes_hit=None) -> LioScan:
+    """coherent: points ordered along the voxel grid (a spinning LiDAR's neighbouring returns fall on neighbouring surfaces) instead of
+    shuffled; planes_hit: restrict the scan to that many of the map's planes (a real scan sees a small part of the map, many points each)."""
     rng = np.random.Generator(np.random.PCG64([seed, 32]))
     R_gt = rodrigues(np.array([0.02, -0.03, 0.4])); p_gt = np.array([0.3, -0.2, 0.1])
     planes = np.nonzero(pm.is_plane == 1)[0]
+    if planes_hit is not None and planes_hit < planes.size:
+        planes = planes[rng.choice(planes.size, size=planes_hit, replace=False)]
     n_cl = int(n_points * clutter_frac); n_pl = n_points - n_cl
     k = planes[rng.integers(0, planes.size, size=n_pl)]
     n = pm.normal[k]
@@ -415,6 +420,9 @@ def make_lio_scan(pm: PlaneMapData, n_points=20_000, noise=0.02, clutter_frac=0.
     lo = pm.loc.min(axis=0) * pm.voxel_size; hi = (pm.loc.max(axis=0) + 1) * pm.voxel_size
     cl = rng.uniform(lo, hi, size=(n_cl, 3))
     world = np.concatenate([w, cl])[rng.permutation(n_points)]
+    if coherent:
+        cell = np.floor(world / pm.voxel_size).astype(np.int64)
+        world = world[np.lexsort((cell[:, 2], cell[:, 1], cell[:, 0]))]
     xyz = np.ascontiguousarray(((world - p_gt) @ R_gt).astype(np.float32))
     R0 = R_gt @ rodrigues(rng.normal(0, np.deg2rad(rot_sigma_deg), size=3)); p0 = p_gt + rng.normal(0, trans_sigma, size=3)
     v = np.array([0.5, 0.1, 0.0]); g = np.array([0.0, 0.0, -9.8])
