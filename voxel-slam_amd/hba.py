@@ -14,9 +14,11 @@ from . import vxba
 
 
 def window_refine(xyz_local, frame_ptr, poses, coarse: "vxba.VoxelizeParams", fine: "vxba.VoxelizeParams", max_iter: int = 10, up: int = 4,
-                  device: int = 0, factor_cls=None, optimizer=None, voxelize=None):
+                  device: int = 0, factor_cls=None, optimizer=None, voxelize=None, factor=None):
     """Returns dict(poses, hess, rounds, n_voxels, resis).  ``factor_cls`` / ``optimizer`` / ``voxelize`` let the tests run the
-    same schedule on the CPU oracle (defaults: the GPU path)."""
+    same schedule on the CPU oracle (defaults: the GPU path).  ``factor``: a LidarFactor of the right win_size to reuse (cleared
+    before every round) instead of creating one per round -- what a long-running mapper does (the reference constructs a
+    LidarFactor per round, voxelslam.cpp:2378; here that would be a dozen device allocations each time)."""
     W = poses.shape[0]
     xs = np.ascontiguousarray(poses, dtype=np.float64).copy()
     converge_flag, converge_thre = 0, 0.05
@@ -25,7 +27,11 @@ def window_refine(xyz_local, frame_ptr, poses, coarse: "vxba.VoxelizeParams", fi
     for it in range(max_iter):
         params = fine if (converge_flag == 1 or it == max_iter - 1) else coarse          # voxelslam.cpp:2362-2372
         if voxelize is None:
-            f = vxba.LidarFactor(W, device=device) if factor_cls is None else factor_cls(W)
+            if factor is not None:
+                f = factor
+                f.clear()
+            else:
+                f = vxba.LidarFactor(W, device=device) if factor_cls is None else factor_cls(W)
             n_vox = f.voxelize_push(xyz_local, frame_ptr, xs, params, want_ids=False)
         else:
             f, n_vox = voxelize(xyz_local, frame_ptr, xs, params)
@@ -35,7 +41,7 @@ def window_refine(xyz_local, frame_ptr, poses, coarse: "vxba.VoxelizeParams", fi
         hess = out["hess"]
         r0, r1 = out["resis"]
         log.append(dict(round=it, n_voxels=int(n_vox), resis=(float(r0), float(r1)), converged=bool(out["is_converge"]), fine=params is fine))
-        if hasattr(f, "close"):
+        if factor is None and hasattr(f, "close"):
             f.close()
         if (abs(r0 - r1) / r0 < converge_thre and out["is_converge"]) or (it == max_iter - 2 and converge_flag == 0):   # :2387-2398
             converge_thre = 0.01
@@ -88,15 +94,19 @@ def hierarchical_ba(clouds, poses, coarse: "vxba.VoxelizeParams", fine: "vxba.Vo
     CPU oracle in the tests."""
     K = poses.shape[0]
     sub_clouds, sub_ids, edges1 = [], [], []
+    bottom = vxba.LidarFactor(wdsize, device=device) if voxelize is None else None   # one factor for all bottom-level windows
     for base in range(0, K - wdsize + 1, mgsize):
         ids = list(range(base, base + wdsize))
         xyz = np.ascontiguousarray(np.concatenate([np.asarray(clouds[i], dtype=np.float64) for i in ids]))
         fp = np.concatenate([[0], np.cumsum([len(clouds[i]) for i in ids])]).astype(np.int64)
-        r = window_refine(xyz, fp, poses[ids], coarse, fine, max_iter=1, device=device, optimizer=optimizer, voxelize=None if voxelize is None else voxelize(wdsize))
+        r = window_refine(xyz, fp, poses[ids], coarse, fine, max_iter=1, device=device, optimizer=optimizer, voxelize=None if voxelize is None else voxelize(wdsize),
+                          factor=bottom)
         for e in edges_from_hessian(r["poses"], r["hess"]):
             edges1.append(dict(e, i=ids[e["i"]], j=ids[e["j"]]))
         sub_clouds.append(merge_submap([clouds[i] for i in ids], r["poses"], fine.voxel_size, downsample=downsample, device=device))
         sub_ids.append(base)
+    if bottom is not None:
+        bottom.close()
     S = len(sub_ids)
     top_xyz = np.ascontiguousarray(np.concatenate(sub_clouds).astype(np.float64))
     top_fp = np.concatenate([[0], np.cumsum([len(c) for c in sub_clouds])]).astype(np.int64)
