@@ -18,6 +18,7 @@
 #include "vxba_imu.hpp"
 #include "vxba_voxelize.h"
 #include "vxba_wide.h"
+#include "vxba_li_device.h"
 #include "vxba_kernels.h"
 
 using vxk::FactorView;
@@ -57,6 +58,8 @@ struct vxba_factor {
   double* zc_packed = nullptr;   // device alias of h_packed: kernels of host-driven loops write their result straight into host memory
   double* h_scalar = nullptr;    // pinned
   vxk::LMState* d_lm = nullptr;  // device-resident LM shell state
+  vxli::LIState* d_li = nullptr; // device-resident LiDAR-inertial loop state (allocated on first use)
+  double* d_li_hess = nullptr;   // (15W)^2 export of that loop's *hess
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
   vxw::DenseSolver* wide_solver = nullptr;   // wide windows: device Cholesky of the (6W)-dimensional LM step (hipSOLVER, loaded on first use)
   bool wide_solver_tried = false;
@@ -518,7 +521,7 @@ int vxba_destroy(vxba_factor* f) {
   if (f->h_poses) hipHostFree(f->h_poses);
   if (f->h_packed) hipHostFree(f->h_packed);
   if (f->h_scalar) hipHostFree(f->h_scalar);
-  hipFree(f->d_lm);
+  hipFree(f->d_lm); hipFree(f->d_li); hipFree(f->d_li_hess);
   if (f->h_lm) hipHostFree(f->h_lm);
   if (f->own_stream) hipStreamDestroy(f->own_stream);
   delete f;
@@ -1207,6 +1210,63 @@ int vxba_li_only_residual(vxba_factor* f, const double* states, const double* im
 }
 
 // LI_BA_Optimizer::damping_iter (voxel_map.hpp:562-653): the voxel sweeps on the GPU, the 15W-dimensional shell on the host.
+// LI_BA_Optimizer::damping_iter with the whole loop on the device (vxba_li_device.hip): per iteration IMU factors -> Hessian sweep ->
+// joint system -> Schur solve + trial state -> residual sweep + IMU residuals -> accept / reject, all enqueued up front; one D2H at the end.
+// Single GPU, win_size <= VXBA_MAX_WIN.
+static int li_damping_iter_device(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out, double* trace_out, int* n_trace,
+                           const double* cov_invs) {
+  const int W = f->W, n = vxi::DIM * W;
+  if (max_iter > vxk::LM_MAX_ITER) max_iter = vxk::LM_MAX_ITER;
+  if (!f->d_li) {
+    VX_HIP(f, hipMalloc((void**)&f->d_li, sizeof(vxli::LIState)));
+    VX_HIP(f, hipMalloc((void**)&f->d_li_hess, sizeof(double) * 225 * vxli::LI_MAXW * vxli::LI_MAXW));
+  }
+  int rc = ensure_exchange(f);
+  if (rc) return rc;
+  vxli::LIState* li = f->d_li;
+  hipStream_t s = f->stream;
+  VX_HIP(f, hipMemcpyAsync(li->states, states, sizeof(double) * vxi::STATE_LEN * W, hipMemcpyHostToDevice, s));
+  if (W > 1) {
+    VX_HIP(f, hipMemcpyAsync(li->imus, imus, sizeof(double) * vxi::IMU_LEN * (W - 1), hipMemcpyHostToDevice, s));
+    VX_HIP(f, hipMemcpyAsync(li->cov_inv, cov_invs, sizeof(double) * 225 * (W - 1), hipMemcpyHostToDevice, s));
+  }
+  vxli::launch_li_init(li, f->d_lm, W, imu_coef, s);
+  vxk::LMPending none;
+  std::memset(&none, 0, sizeof none);
+  for (int it = 0; it < max_iter; it++) {
+    int c = 0;
+    vxli::launch_li_imu(li, W, 0, s);
+    rc = sweep_hess_device(f, nullptr, f->d_lm, &c, &none, 0, f->V, f->d_packed);
+    if (rc) return rc;
+    vxli::launch_li_assemble(li, f->d_packed, W, hess_out ? f->d_li_hess : nullptr, s);
+    vxli::launch_li_solve(li, f->d_lm, W, s);
+    int nparts = 0;
+    rc = sweep_residual_device(f, nullptr, f->d_lm, 0, 0, f->V, nullptr, &nparts, 0);
+    if (rc) return rc;
+    vxli::launch_li_imu(li, W, 1, s);
+    vxli::launch_li_decide(li, f->d_lm, f->d_partial2, nparts, W, s);
+  }
+  VX_HIP(f, hipGetLastError());
+  // results: states, factors (their dbg / dba bookkeeping moved), trace, iteration count, *hess
+  struct Tail { double u, v, residual1, residual2, q1, imu_coef; int calc_hess, done, iter, pad; } tail;
+  std::vector<double> tr((size_t)vxk::LM_MAX_ITER * 8);
+  VX_HIP(f, hipMemcpyAsync(states, li->states, sizeof(double) * vxi::STATE_LEN * W, hipMemcpyDeviceToHost, s));
+  if (W > 1) VX_HIP(f, hipMemcpyAsync(imus, li->imus, sizeof(double) * vxi::IMU_LEN * (W - 1), hipMemcpyDeviceToHost, s));
+  VX_HIP(f, hipMemcpyAsync(&tail, &li->u, sizeof tail, hipMemcpyDeviceToHost, s));
+  VX_HIP(f, hipMemcpyAsync(tr.data(), li->trace, sizeof(double) * 8 * max_iter, hipMemcpyDeviceToHost, s));
+  if (hess_out) VX_HIP(f, hipMemcpyAsync(hess_out, f->d_li_hess, sizeof(double) * n * n, hipMemcpyDeviceToHost, s));
+  VX_HIP(f, hipStreamSynchronize(s));
+  if (trace_out) std::memcpy(trace_out, tr.data(), sizeof(double) * 8 * tail.iter);
+  if (n_trace) *n_trace = tail.iter;
+  if (getenv("VXBA_LI_DBG")) {   // development: phases of the last solve kernel, shader clocks
+    long long d[16];
+    if (hipMemcpy(d, li->dbg, sizeof d, hipMemcpyDeviceToHost) == hipSuccess)
+      std::fprintf(stderr, "[vxba li solve] stage %lld thomas-fwd %lld thomas-bwd %lld schur %lld dense %lld dy %lld q1 %lld update %lld\n", d[1] - d[0], d[2] - d[1], d[3] - d[2],
+                   d[4] - d[3], d[5] - d[4], d[6] - d[5], 0ll, d[7] - d[6]);
+  }
+  return VXBA_OK;
+}
+
 int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out, double* trace_out,
                          int* n_trace) {
   VX_LOCK(f);
@@ -1220,6 +1280,10 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
   std::vector<int> perm(n);
   std::vector<double> cov_invs((size_t)225 * (W > 1 ? W - 1 : 0));   // cov is constant during the loop: invert once
   if (!vxi::li_invert_covariances(W, imus, cov_invs.data())) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
+  {   // the loop on the device (VXBA_LI_DEVICE=0: the host shell below); sharded runs keep the host shell
+    const char* e = getenv("VXBA_LI_DEVICE");
+    if (e && e[0] == '1' && !has_collective(f)) return li_damping_iter_device(f, states, imus, imu_coef, max_iter, hess_out, trace_out, n_trace, cov_invs.data());
+  }
   double residual1 = 0, residual2 = 0;
   bool is_calc_hess = true;
   int nt = 0;

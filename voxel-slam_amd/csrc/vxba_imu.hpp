@@ -15,6 +15,13 @@
 #include <cmath>
 #include <cstring>
 
+// the small fixed-size pieces are also used by the device-resident LiDAR-inertial loop (vxba_li_device.hip)
+#if defined(__HIPCC__)
+#define VXI_FN __host__ __device__ inline
+#else
+#define VXI_FN inline
+#endif
+
 namespace vxi {
 
 constexpr int DIM = 15, DVEL = 6, STATE_LEN = 24, IMU_LEN = 304;
@@ -23,33 +30,33 @@ enum ImuOff { O_RD = 0, O_PD = 9, O_VD = 12, O_BG = 15, O_BA = 18, O_RBG = 21, O
 enum StOff { S_R = 0, S_P = 9, S_V = 12, S_BG = 15, S_BA = 18, S_G = 21 };
 
 // ---- 3x3 column-major kernels: element (r, c) at [3 c + r] ----
-inline void m3_mul(const double* A, const double* B, double* C) {   // C = A B  (C may not alias)
+VXI_FN void m3_mul(const double* A, const double* B, double* C) {   // C = A B  (C may not alias)
   for (int c = 0; c < 3; c++)
     for (int r = 0; r < 3; r++) C[3 * c + r] = A[r] * B[3 * c] + A[3 + r] * B[3 * c + 1] + A[6 + r] * B[3 * c + 2];
 }
-inline void m3_tmul(const double* A, const double* B, double* C) {  // C = A^T B
+VXI_FN void m3_tmul(const double* A, const double* B, double* C) {  // C = A^T B
   for (int c = 0; c < 3; c++)
     for (int r = 0; r < 3; r++) C[3 * c + r] = A[3 * r] * B[3 * c] + A[3 * r + 1] * B[3 * c + 1] + A[3 * r + 2] * B[3 * c + 2];
 }
-inline void m3_vec(const double* A, const double* x, double* y) {   // y = A x
+VXI_FN void m3_vec(const double* A, const double* x, double* y) {   // y = A x
   for (int r = 0; r < 3; r++) y[r] = A[r] * x[0] + A[3 + r] * x[1] + A[6 + r] * x[2];
 }
-inline void m3_tvec(const double* A, const double* x, double* y) {  // y = A^T x
+VXI_FN void m3_tvec(const double* A, const double* x, double* y) {  // y = A^T x
   for (int r = 0; r < 3; r++) y[r] = A[3 * r] * x[0] + A[3 * r + 1] * x[1] + A[3 * r + 2] * x[2];
 }
-inline void m3_t(const double* A, double* T) {
+VXI_FN void m3_t(const double* A, double* T) {
   for (int c = 0; c < 3; c++)
     for (int r = 0; r < 3; r++) T[3 * c + r] = A[3 * r + c];
 }
-inline void m3_hat(const double* v, double* H) {
+VXI_FN void m3_hat(const double* v, double* H) {
   H[0] = 0; H[3] = -v[2]; H[6] = v[1];
   H[1] = v[2]; H[4] = 0; H[7] = -v[0];
   H[2] = -v[1]; H[5] = v[0]; H[8] = 0;
 }
-inline void m3_eye(double* I) { std::memset(I, 0, 9 * sizeof(double)); I[0] = I[4] = I[8] = 1.0; }
+VXI_FN void m3_eye(double* I) { std::memset(I, 0, 9 * sizeof(double)); I[0] = I[4] = I[8] = 1.0; }
 
 // I + sin(a) K + (1 - cos a) K^2 for unit axis k, angle a
-inline void rodrigues_axis_angle(const double* k, double a, double* R) {
+VXI_FN void rodrigues_axis_angle(const double* k, double a, double* R) {
   double K[9], K2[9];
   m3_hat(k, K);
   m3_mul(K, K, K2);
@@ -58,19 +65,19 @@ inline void rodrigues_axis_angle(const double* k, double a, double* R) {
   for (int q = 0; q < 9; q++) R[q] += s * K[q] + c1 * K2[q];
 }
 // tools.hpp:51-66
-inline void so3_exp(const double* w, double* R) {
+VXI_FN void so3_exp(const double* w, double* R) {
   const double n = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
   if (n >= 1e-11) { const double k[3] = {w[0] / n, w[1] / n, w[2] / n}; rodrigues_axis_angle(k, n, R); }
   else m3_eye(R);
 }
 // tools.hpp:68-84 (angular velocity * dt, cut-off on the velocity norm)
-inline void so3_exp_dt(const double* w, double dt, double* R) {
+VXI_FN void so3_exp_dt(const double* w, double dt, double* R) {
   const double n = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
   if (n > 1e-7) { const double k[3] = {w[0] / n, w[1] / n, w[2] / n}; rodrigues_axis_angle(k, n * dt, R); }
   else m3_eye(R);
 }
 // tools.hpp:86-91
-inline void so3_log(const double* R, double* w) {
+VXI_FN void so3_log(const double* R, double* w) {
   const double tr = R[0] + R[4] + R[8];
   const double theta = (tr > 3.0 - 1e-6) ? 0.0 : std::acos(0.5 * (tr - 1));
   const double K[3] = {R[3 * 1 + 2] - R[3 * 2 + 1], R[3 * 2 + 0] - R[3 * 0 + 2], R[3 * 0 + 1] - R[3 * 1 + 0]};
@@ -78,7 +85,7 @@ inline void so3_log(const double* R, double* w) {
   for (int k = 0; k < 3; k++) w[k] = f * K[k];
 }
 // right Jacobian of SO(3), tools.hpp:102-116
-inline void so3_jr(const double* v, double* J) {
+VXI_FN void so3_jr(const double* v, double* J) {
   const double a = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
   if (a < 1e-9) { m3_eye(J); return; }
   const double k[3] = {v[0] / a, v[1] / a, v[2] / a};
@@ -91,7 +98,7 @@ inline void so3_jr(const double* v, double* J) {
 // inverse right Jacobian from the rotation matrix, tools.hpp:118-133.  Angle / axis are taken through a unit
 // quaternion (angle = 2 atan2(|q_v|, |q_w|) in [0, pi], axis = q_v / |q_v| with the sign of q_w), the convention
 // of the reference's Eigen::AngleAxisd(Matrix3d).
-inline void so3_jr_inv(const double* R, double* J) {
+VXI_FN void so3_jr_inv(const double* R, double* J) {
   auto E = [&](int r, int c) { return R[3 * c + r]; };
   double q[4];  // x y z w
   const double t = E(0, 0) + E(1, 1) + E(2, 2);
@@ -205,7 +212,7 @@ inline bool dm_inverse(int n, const double* A, double* inv, double* lu /* n*n */
   }
   return true;
 }
-inline void put33(double* M, int ld, int r0, int c0, const double* B, double scale = 1.0) {
+VXI_FN void put33(double* M, int ld, int r0, int c0, const double* B, double scale = 1.0) {
   for (int c = 0; c < 3; c++)
     for (int r = 0; r < 3; r++) M[(size_t)(c0 + c) * ld + r0 + r] = scale * B[3 * c + r];
 }
@@ -283,8 +290,9 @@ struct ImuWork {
 // with_g: give_evaluate_g (:214-294) -- three more Jacobian columns for the gravity vector, jtj 33x33, gg 33.
 // cov_inv_cached: the factor's 15x15 information matrix if the caller already inverted cov (it does not change while an LM
 // loop runs; upstream re-inverts it in every evaluation).
-inline double imu_evaluate(const double* f, const double* s1, const double* s2, bool jac, double* jtj, double* gg, ImuWork& w, bool* ok = nullptr,
-                           bool with_g = false, const double* cov_inv_cached = nullptr) {
+// The fixed-size part of give_evaluate[_g]: the 15-dimensional residual rr and, with jac, the 15 x nc Jacobian J (column-major, ld 15;
+// nc = 30, or 33 with the gravity columns) -- preintegration.hpp:137-201 / 214-283.  Shared by the host shell and the device loop.
+VXI_FN void imu_residual_jac(const double* f, const double* s1, const double* s2, bool jac, bool with_g, double* rr, double* J) {
   const double* R1 = s1 + S_R; const double* R2 = s2 + S_R;
   const double dt = f[O_DT];
   double rb[3], Eb[9], Rc[9], tc[3], vc[3], t3[3], u3[3];
@@ -296,7 +304,7 @@ inline double imu_evaluate(const double* f, const double* s1, const double* s2, 
   m3_vec(f + O_VBG, f + O_DBG, t3); m3_vec(f + O_VBA, f + O_DBA, u3);
   for (int k = 0; k < 3; k++) vc[k] = f[O_VD + k] + t3[k] + u3[k];
 
-  double R12[9], res_r[9], dv[3], dp[3], exp_v[3], exp_t[3], rr[DIM];
+  double R12[9], res_r[9], dv[3], dp[3], exp_v[3], exp_t[3];
   m3_tmul(R1, R2, R12);
   m3_tmul(Rc, R12, res_r);
   for (int k = 0; k < 3; k++) {
@@ -312,14 +320,9 @@ inline double imu_evaluate(const double* f, const double* s1, const double* s2, 
     rr[9 + k] = s2[S_BG + k] - s1[S_BG + k];
     rr[12 + k] = s2[S_BA + k] - s1[S_BA + k];
   }
-  bool inv_ok = true;
-  if (cov_inv_cached) std::memcpy(w.cov_inv, cov_inv_cached, sizeof w.cov_inv);
-  else inv_ok = dm_inverse(DIM, f + O_COV, w.cov_inv, w.lu, w.perm);
-  if (ok) *ok = inv_ok;
-
   if (jac) {
-    double* J = w.joc;   // column block a = st1 (cols 0..14), b = st2 (cols 15..29); ld = 15
-    std::memset(J, 0, sizeof w.joc);
+    // column block a = st1 (cols 0..14), b = st2 (cols 15..29); ld = 15
+    for (int q = 0; q < DIM * (with_g ? NCG : 2 * DIM); q++) J[q] = 0.0;
     double Jri[9], T1[9], T2[9], R1t[9], rrT[9], Jrb[9], H[9], I3[9];
     m3_eye(I3);
     so3_jr_inv(res_r, Jri);
@@ -348,12 +351,26 @@ inline double imu_evaluate(const double* f, const double* s1, const double* s2, 
     put33(J, DIM, 12, 12, I3, -1.0);
     put33(J, DIM, 9, DIM + 9, I3);
     put33(J, DIM, 12, DIM + 12, I3);
-    const int nc = with_g ? NCG : 2 * DIM;
     if (with_g) {   // preintegration.hpp:277-278
       put33(J, DIM, 3, 2 * DIM, R1t, -0.5 * dt * dt);
       put33(J, DIM, 6, 2 * DIM, R1t, -dt);
     }
 
+  }
+}
+
+inline double imu_evaluate(const double* f, const double* s1, const double* s2, bool jac, double* jtj, double* gg, ImuWork& w, bool* ok = nullptr,
+                           bool with_g = false, const double* cov_inv_cached = nullptr) {
+  double rr[DIM];
+  imu_residual_jac(f, s1, s2, jac, with_g, rr, w.joc);
+  bool inv_ok = true;
+  if (cov_inv_cached) std::memcpy(w.cov_inv, cov_inv_cached, sizeof w.cov_inv);
+  else inv_ok = dm_inverse(DIM, f + O_COV, w.cov_inv, w.lu, w.perm);
+  if (ok) *ok = inv_ok;
+
+  if (jac) {
+    double* J = w.joc;
+    const int nc = with_g ? NCG : 2 * DIM;
     dm_mul(DIM, DIM, nc, w.cov_inv, J, w.ci_j);                     // cov^-1 J   (15 x nc)
     dm_tmul_sparse_a(DIM, nc, nc, J, w.ci_j, jtj);                  // J^T cov^-1 J
     // gg = (cov^-1 J)^T r  -- cov^-1 is symmetric up to round-off; the reference forms J^T cov^-1 r
@@ -376,7 +393,7 @@ inline double imu_evaluate(const double* f, const double* s1, const double* s2, 
   return res;
 }
 
-inline void imu_update_state(double* f, const double* dxi15) {
+VXI_FN void imu_update_state(double* f, const double* dxi15) {
   for (int k = 0; k < 3; k++) {
     f[O_DBGB + k] = f[O_DBG + k];
     f[O_DBAB + k] = f[O_DBA + k];
@@ -384,7 +401,7 @@ inline void imu_update_state(double* f, const double* dxi15) {
     f[O_DBA + k] += dxi15[12 + k];
   }
 }
-inline void imu_rollback(double* f) {   // voxel_map.hpp:639-643
+VXI_FN void imu_rollback(double* f) {   // voxel_map.hpp:639-643
   for (int k = 0; k < 3; k++) { f[O_DBG + k] = f[O_DBGB + k]; f[O_DBA + k] = f[O_DBAB + k]; }
 }
 

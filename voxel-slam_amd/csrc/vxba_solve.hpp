@@ -1,0 +1,131 @@
+// Device-side building blocks of the damped solves (included by vxba_kernels.hip and vxba_li_device.hip): the one-wave dense
+// elimination with look-ahead, lane broadcasts, the fast reciprocal, R <- R Exp(dphi).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace vxk {
+
+__device__ __forceinline__ void lm_right_multiply_exp(const double* Rin, const double* dphi, double* Rout) {
+  // R <- R Exp(dphi), column-major 3x3; Rodrigues with the reference's 1e-11 cut-off (tools.hpp:51-66)
+  const double th = sqrt(dphi[0] * dphi[0] + dphi[1] * dphi[1] + dphi[2] * dphi[2]);
+  double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (th >= 1e-11) {
+    const double ith = 1.0 / th;
+    const double k0 = dphi[0] * ith, k1 = dphi[1] * ith, k2 = dphi[2] * ith;
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    const double c1 = 1.0 - cs;
+    // E = I + sin K + (1 - cos) K^2,  K = hat(k):  K^2 = k k^T - I (|k| = 1)
+    E[0] = 1.0 + c1 * (k0 * k0 - 1.0); E[1] = -sn * k2 + c1 * k0 * k1;      E[2] = sn * k1 + c1 * k0 * k2;
+    E[3] = sn * k2 + c1 * k0 * k1;      E[4] = 1.0 + c1 * (k1 * k1 - 1.0); E[5] = -sn * k0 + c1 * k1 * k2;
+    E[6] = -sn * k1 + c1 * k0 * k2;     E[7] = sn * k0 + c1 * k1 * k2;      E[8] = 1.0 + c1 * (k2 * k2 - 1.0);
+  }
+  double out[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) out[3 * c + r] = Rin[r] * E[c] + Rin[3 + r] * E[3 + c] + Rin[6 + r] * E[6 + c];
+#pragma unroll
+  for (int q = 0; q < 9; q++) Rout[q] = out[q];
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+// 1/d to fp64 round-off: hardware estimate + two Newton steps (the IEEE division sequence is ~3x longer and sits on
+// the critical path of every elimination step)
+__device__ __forceinline__ double fast_rcp_f64(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
+constexpr int LM_PRE = 12;   // pivot-column values fetched one step ahead
+template <int K, int N>
+struct LmElim {
+  // Forward elimination step K with one step of look-ahead.  On entry the (final) column K of the trailing matrix already
+  // sits in LDS buffer K & 1, its first LM_PRE entries below the diagonal are in `pre`, and 1/pivot and the pivot's
+  // right-hand side are known.  The step updates column K+1 FIRST, publishes it (other LDS buffer), fetches the head of
+  // it and starts the next reciprocal -- all of which then complete in the shadow of the remaining rank-1 update,
+  // instead of costing an LDS round trip + a division chain per step on the critical path (54 dependent steps).
+  // Measured and rejected on top of this: masking rows with exec (real branches) instead of selects, 1/pivot and the
+  // solution through LDS, damping added at the pivot read -- 1100 fewer instructions, but 31k instead of 26k cycles: the
+  // wave is bound by the LDS queue order and dependent latencies, not by instruction count or cold instruction fetch
+  // (a second pass over the same code with a warm I-cache is only 10 % faster).
+  static __device__ __forceinline__ void forward(double (&A)[N > 6 ? N : 7], double& b, double& my_invd, double* colbuf, int lane, bool row_ok,
+                                                 double invd, double bk, double (&pre)[LM_PRE]) {
+    if constexpr (K < N) {
+      constexpr int M = N - K - 1;            // columns j = K+1 .. N-1 take the rank-1 update
+      const double* cur = colbuf + 64 * (K & 1);
+      double* nxt = colbuf + 64 * ((K + 1) & 1);
+      double col[M > LM_PRE ? M - LM_PRE : 1];
+#pragma unroll
+      for (int j = LM_PRE; j < M; j++) col[j - LM_PRE] = cur[K + 1 + j];   // the tail of column K: broadcast reads, back to back
+      __builtin_amdgcn_sched_barrier(0);
+      my_invd = (lane == K) ? invd : my_invd;
+      const double l = (lane > K && row_ok) ? A[K] * invd : 0.0;
+      b -= l * bk;
+      double invd_n = 0.0, bk_n = 0.0;
+      double pre_n[LM_PRE];
+#pragma unroll
+      for (int j = 0; j < LM_PRE; j++) pre_n[j] = 0.0;
+      if constexpr (M > 0) {
+        A[K + 1] -= l * pre[0];
+        nxt[lane] = A[K + 1];                 // lane j publishes A(j,K+1); symmetric, so this is also row K+1
+        const double d_n = readlane_f64(A[K + 1], K + 1);
+        bk_n = readlane_f64(b, K + 1);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < LM_PRE && j < M - 1; j++) pre_n[j] = nxt[K + 2 + j];
+        __builtin_amdgcn_sched_barrier(0);
+        invd_n = fast_rcp_f64(d_n);
+#pragma unroll
+        for (int j = 1; j < LM_PRE && j < M; j++) A[K + 1 + j] -= l * pre[j];
+#pragma unroll
+        for (int j = LM_PRE; j < M; j++) A[K + 1 + j] -= l * col[j - LM_PRE];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      LmElim<K + 1, N>::forward(A, b, my_invd, colbuf, lane, row_ok, invd_n, bk_n, pre_n);
+    }
+  }
+  static __device__ __forceinline__ void backward(double (&A)[N > 6 ? N : 7], double& b, const double my_invd, double& x, double* xs, int lane) {
+    if constexpr (K >= 6) {
+      const double xk = readlane_f64(b * my_invd, K);   // x_K = y_K / pivot_K, broadcast from lane K
+      x = (lane == K) ? xk : x;
+      b -= (lane < K) ? A[K] * xk : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      LmElim<K - 1, N>::backward(A, b, my_invd, x, xs, lane);
+    }
+  }
+};
+
+
+// Rows 6 .. N-1 of a symmetric positive definite system, row i in lane i's registers (A, right-hand side b; damping already
+// applied; rows / columns 0..5 are the gauge and are neither read nor written): returns the solution component of this lane
+// (0 for lanes < 6 and lanes >= N).  colbuf: 128 doubles of LDS.  One wave.
+template <int N>
+__device__ __forceinline__ double dense_solve_rows(double (&A)[N > 6 ? N : 7], double b, double* colbuf, int lane) {
+  const bool row_ok = lane < N;
+  double my_invd = 1.0;
+  if constexpr (N > 6) {
+    colbuf[lane] = A[6];
+    const double d6 = readlane_f64(A[6], 6);
+    const double bk6 = readlane_f64(b, 6);
+    __builtin_amdgcn_wave_barrier();
+    double pre[LM_PRE];
+#pragma unroll
+    for (int j = 0; j < LM_PRE; j++) pre[j] = (7 + j < N) ? colbuf[7 + j] : 0.0;
+    const double invd6 = fast_rcp_f64(d6);
+    LmElim<6, N>::forward(A, b, my_invd, colbuf, lane, row_ok, invd6, bk6, pre);
+  }
+  double x = 0.0;
+  LmElim<N - 1, N>::backward(A, b, my_invd, x, nullptr, lane);
+  return x;
+}
+
+}  // namespace vxk
