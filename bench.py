@@ -80,13 +80,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # development switches for exercising the multi-process path on a box with ONE GPU (never set by the driver): all ranks on
+    # device VXBA_BENCH_DEVICE, collectives through VXBA_BENCH_BACKEND=gloo (RCCL refuses two ranks on one device)
+    backend = os.environ.get("VXBA_BENCH_BACKEND", "nccl")
+    if os.environ.get("VXBA_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["VXBA_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            args.hook_allreduce = True
 
     # ---- synthetic window: every rank builds its own voxel shard of one shared window ------------
     base_seed = synth.MASTER_SEED + list(synth.CONFIGS).index(args.config) + 1
@@ -113,7 +122,7 @@ def main():
             except Exception as exc:                       # noqa: BLE001 -- any failure here must not take the other ranks down
                 print(f"[bench rank {rank}] direct RCCL attach failed ({exc}); using the torch.distributed hook", file=sys.stderr)
                 ok = 0
-            okt = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            okt = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)     # all ranks take the same path
             if int(okt.item()) == 0:
                 if ok:
@@ -143,7 +152,7 @@ def main():
     f.set_profiling(0)
     elapsed = t1 - t0
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kt = f.kernel_times(reset=True)

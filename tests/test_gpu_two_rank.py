@@ -1,0 +1,33 @@
+"""The multi-process path with two REAL ranks on one GPU (torch.distributed over gloo, exchange buffers reduced through host memory --
+RCCL refuses two ranks on one device): each rank owns a voxel shard, and the sharded damping_iter / lm_steps must reproduce the
+single-factor run on the whole window.  Complements the in-process two-shard emulation: here ranks are processes, the collective is
+torch.distributed's, and a missing stream ordering or a stale buffer that is summed again shows (neither does with one rank)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("spec", ["1", "0"])
+def test_two_process_ranks_reproduce_the_single_factor_run(spec):
+    env = dict(os.environ, VXBA_SPEC_COLLECTIVE=spec, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29560 + int(spec)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "scripts", "dbg_two_rank.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if re.match(r"rank \d (damping_iter|lm_steps):", ln)]
+    assert len(lines) == 4, out.stdout[-2000:]
+    for ln in lines:
+        m = re.search(r"pose diff ([0-9.e+-]+) ([0-9.e+-]+)", ln)
+        assert m and float(m.group(1)) < 1e-9 and float(m.group(2)) < 1e-9, ln
+        if "damping_iter" in ln:
+            a, b = re.search(r"trace accept (\[[^\]]*\]) vs (\[[^\]]*\])", ln).groups()
+            assert a == b and "1." in a and "0." in a, ln          # same schedule, with rejected and accepted steps in it
+        else:
+            a, b = re.search(r"stats (\{[^}]*\}) vs (\{[^}]*\})", ln).groups()
+            assert a == b, ln

@@ -31,16 +31,29 @@ def attach_allreduce(factor, group=None):
     n = factor.packed_len()
     xbuf = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
     packed_t, scalar_t = xbuf[:n], xbuf[n:]
-    factor.set_stream(torch.cuda.current_stream().cuda_stream)
+    # A dedicated stream shared by the factor's kernels and the collectives.  torch's default stream will not do: its handle is 0,
+    # which vxba_set_stream reads as "back to the factor's own (non-blocking) stream" -- the collective would then run unordered
+    # against the kernels that fill and read the exchange buffer (invisible with one rank, garbage with two).
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    factor.set_stream(stream.cuda_stream)
     factor.use_external_buffers(packed_t.data_ptr(), scalar_t.data_ptr())
+    staged = dist.get_backend(group) == "gloo"   # plumbing runs of the multi-process path without RCCL: reduce through host memory
 
     def hook(_ptr, count, _stream):
         # count == 1: the residual scalar; count == n: the packed system; count == n + 1: both in one collective (the scalar
         # sits directly behind the packed buffer, which is what lets the device-resident loop merge them)
-        dist.all_reduce(scalar_t if count == 1 else xbuf[:count], group=group)
+        t = scalar_t if count == 1 else xbuf[:count]
+        with torch.cuda.stream(stream):
+            if staged:
+                h = t.cpu()                          # synchronises with the stream that filled the buffer
+                dist.all_reduce(h, group=group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, group=group)
 
     factor.set_allreduce(hook)
-    return xbuf, packed_t, scalar_t
+    return xbuf, packed_t, scalar_t, stream
 
 
 def attach_rccl(factor, group=None):
