@@ -62,7 +62,9 @@ int vxba_set_win_size(vxba_factor* f, int win_size);
 int vxba_win_size(const vxba_factor* f);
 /* plvec_voxels.size()                                   voxel_map.hpp:314,344 */
 int vxba_size(const vxba_factor* f);
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the factor's own. */
+/* Run on a caller-owned hipStream_t instead of the factor's own (non-blocking) stream.  NULL selects the factor's own stream again --
+ * so the legacy default stream (handle 0, e.g. torch's default current stream) cannot be chosen: work queued there is NOT ordered with the
+ * factor's kernels; share a created stream instead (voxel_slam_amd/dist.py does). */
 int vxba_set_stream(vxba_factor* f, void* hip_stream);
 int vxba_reserve(vxba_factor* f, int n_voxels);
 const char* vxba_last_error(const vxba_factor* f);

@@ -71,8 +71,7 @@ def attach_rccl(factor, group=None):
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     obj = [vxba.rccl_unique_id(lib) if rank == 0 else None]
     dist.broadcast_object_list(obj, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    factor.set_stream(torch.cuda.current_stream().cuda_stream)
-    factor.rccl_attach(lib, world, rank, obj[0])
+    factor.rccl_attach(lib, world, rank, obj[0])   # collectives are issued on the factor's own stream, in order with its kernels
 
 
 def damping_iter_sharded(win_size: int, x_stats, local_hess, local_resid, max_iter: int = 3, group=None):
