@@ -20,9 +20,11 @@ def test_two_process_ranks_reproduce_the_single_factor_run(spec):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                           os.path.join(ROOT, "scripts", "dbg_two_rank.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if re.match(r"rank \d (damping_iter|lm_steps):", ln)]
-    assert len(lines) == 4, out.stdout[-2000:]
-    for ln in lines:
+    # the ranks print concurrently: records may share a line, so split on the record header rather than on newlines
+    recs = re.split(r"(?=rank \d (?:damping_iter|lm_steps):)", out.stdout)
+    recs = [r for r in recs if re.match(r"rank \d (damping_iter|lm_steps):", r)]
+    assert len(recs) == 4, out.stdout[-2000:]
+    for ln in recs:
         m = re.search(r"pose diff ([0-9.e+-]+) ([0-9.e+-]+)", ln)
         assert m and float(m.group(1)) < 1e-9 and float(m.group(2)) < 1e-9, ln
         if "damping_iter" in ln:

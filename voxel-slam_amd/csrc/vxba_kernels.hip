@@ -163,14 +163,14 @@ template <int W, bool DBG = false>
 __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c, unsigned seq, int head, int end,
                                                          int VPB, double* __restrict__ partial) {
   __shared__ double pose_lds[12 * W];
-  __shared__ double solve_lds[192];
+  __shared__ double solve_lds[SOLVE_LDS + 64];
   // LM mode: trial poses of ctl[c]; nothing to do once the loop is done
   if (st && st->ctl[c].done) return;
   const int lane = threadIdx.x;
   int vb = blockIdx.x;
   if (st && seq != 0) {
     if (blockIdx.x == 0) {
-      lm_solve_body<W, DBG>(st, c, solve_lds, solve_lds + 128);
+      lm_solve_body<W, DBG>(st, c, solve_lds, solve_lds + SOLVE_LDS);
       __threadfence();
       if (lane == 0) __hip_atomic_store(&st->solve_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       return;
@@ -1063,23 +1063,8 @@ __device__ __forceinline__ void lm_solve_body(LMState* st, int c, double* colbuf
 
   // forward elimination (rows k = 6 .. n-1) and back substitution, fully unrolled at compile time so that the
   // row stays in registers (static indices only)
-  double my_invd = 1.0;   // 1 / pivot of my row, captured when the row is eliminated
   if (DBG) { asm volatile("" :: "v"(A[0]), "v"(A[n - 1]), "v"(b)); dbg_stamp(true, 4000, 2); }
-  {
-    // prologue of the look-ahead pipeline: publish column 6, fetch its head, start its reciprocal
-    colbuf[lane] = A[6];
-    const double d6 = readlane_f64(A[6], 6);
-    const double bk6 = readlane_f64(b, 6);
-    __builtin_amdgcn_wave_barrier();
-    double pre[LM_PRE];
-#pragma unroll
-    for (int j = 0; j < LM_PRE; j++) pre[j] = (7 + j < n) ? colbuf[7 + j] : 0.0;
-    const double invd6 = fast_rcp_f64(d6);
-    LmElim<6, n>::forward(A, b, my_invd, colbuf, lane, row_ok, invd6, bk6, pre);
-  }
-  if (DBG) { asm volatile("" :: "v"(A[n - 1]), "v"(b)); dbg_stamp(true, 4000, 3); }
-  double x = 0.0;
-  LmElim<n - 1, n>::backward(A, b, my_invd, x, xs, lane);
+  const double x = dense_solve_rows<n>(A, b, colbuf, lane);
   if (DBG) { asm volatile("" :: "v"(x)); dbg_stamp(true, 4000, 4); }
   // dxi, trial state (voxel_map.hpp:405-409), q1 = 0.5 dxi . (u D dxi - JacT) (:410)
   if (row_ok) st->dxi[i] = x;
@@ -1105,7 +1090,7 @@ __device__ __forceinline__ void lm_solve_body(LMState* st, int c, double* colbuf
 // stand-alone launch of the solve (VXBA_FUSED_SOLVE=0; the default runs it as workgroup 0 of the residual sweep)
 template <int W, bool DBG = false>
 __global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, int c) {
-  __shared__ double colbuf[128];   // two pivot-column buffers (look-ahead)
+  __shared__ double colbuf[SOLVE_LDS];   // pivot-column buffers (look-ahead)
   __shared__ double xs[64];
   lm_solve_body<W, DBG>(st, c, colbuf, xs);
 }

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void li_assemble_kernel(LIState* __restrict__ 
 template <int W>
 __global__ __launch_bounds__(64) void li_solve_kernel(LIState* __restrict__ li, LMState* __restrict__ lm) {
   constexpr int n6 = 6 * W, NC = n6 + 1, NF = W > 1 ? W : 2, NT = (9 * NC + 63) / 64;
-  __shared__ double colbuf[128];
+  __shared__ double colbuf[vxk::SOLVE_LDS];
   __shared__ double Rr[NF - 1][9][NC];   // frame j at index j - 1 (frame 0 is the gauge);    // right-hand sides [H_yx | g_y] of the block-tridiagonal solve, overwritten by Z = C^-1 [...]
   __shared__ double Ci[NF][81];       // inverses of the eliminated diagonal blocks
   __shared__ double Lk[81], Tm[81];

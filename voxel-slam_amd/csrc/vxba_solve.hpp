@@ -105,12 +105,20 @@ struct LmElim {
 };
 
 
+// Measured and rejected: the same elimination two pivots at a time (2x2 diagonal blocks inverted in closed form, both columns
+// published and fetched together, one rank-2 update per row) to halve the number of dependent publish -> fetch -> reciprocal
+// chains.  Same-box A/B at W = 10: solve + residual-sweep launch 34.8 us instead of 28.4 us -- the block step's own chain (two
+// products for the multipliers, the determinant, twice the LDS reads in the queue ahead of the next fetch) is longer than two
+// scalar steps with look-ahead.
+constexpr int SOLVE_LDS = 128;   // doubles of LDS the solve needs (two pivot-column buffers)
+
 // Rows 6 .. N-1 of a symmetric positive definite system, row i in lane i's registers (A, right-hand side b; damping already
 // applied; rows / columns 0..5 are the gauge and are neither read nor written): returns the solution component of this lane
-// (0 for lanes < 6 and lanes >= N).  colbuf: 128 doubles of LDS.  One wave.
+// (0 for lanes < 6 and lanes >= N).  colbuf: SOLVE_LDS doubles of LDS.  One wave.
 template <int N>
 __device__ __forceinline__ double dense_solve_rows(double (&A)[N > 6 ? N : 7], double b, double* colbuf, int lane) {
   const bool row_ok = lane < N;
+  double x = 0.0;
   double my_invd = 1.0;
   if constexpr (N > 6) {
     colbuf[lane] = A[6];
@@ -123,7 +131,6 @@ __device__ __forceinline__ double dense_solve_rows(double (&A)[N > 6 ? N : 7], d
     const double invd6 = fast_rcp_f64(d6);
     LmElim<6, N>::forward(A, b, my_invd, colbuf, lane, row_ok, invd6, bk6, pre);
   }
-  double x = 0.0;
   LmElim<N - 1, N>::backward(A, b, my_invd, x, nullptr, lane);
   return x;
 }
