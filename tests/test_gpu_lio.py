@@ -256,3 +256,39 @@ def test_down_sampling_voxel_is_bit_identical(vx):
     assert vx.down_sampling_voxel(np.zeros((0, 3), dtype=np.float32), 0.5).shape == (0, 3)
     with pytest.raises(vx.VxbaError):
         vx.down_sampling_voxel(np.array([[3e6, 0, 0]], dtype=np.float32), 0.5)
+
+
+def test_map_random_update_sequences_match_a_rebuilt_oracle_map(vx):
+    """Random upsert / remove / re-insert batches (table growth and re-hashing in between, records reused and appended): after every
+    batch the GPU map must behave like an oracle map rebuilt from the surviving leaves."""
+    pm = synth.make_plane_map(n_roots=3000, extent=8, seed=2800)
+    sc = synth.make_lio_scan(pm, n_points=12000, seed=2801)
+    n = len(pm.layer)
+    rng = np.random.default_rng(2802)
+    g = vx.LioEstimator(pm.voxel_size, pm.max_layer); g.var_init(sc.xyz)
+    pnt, var = g.read_points()
+    alive = np.zeros(n, dtype=bool)
+    center = pm.center.copy()
+    order = rng.permutation(n)
+    cuts = [0, 5, 400, 1500, 1501, 4000, n]
+    for step, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        batch = order[a:b]
+        # new leaves, plus an in-place update of some old ones and the removal of others
+        upd = rng.choice(np.nonzero(alive)[0], size=min(200, int(alive.sum())), replace=False) if alive.any() else np.zeros(0, dtype=int)
+        rem = rng.choice(np.nonzero(alive)[0], size=min(150, int(alive.sum())), replace=False) if alive.any() else np.zeros(0, dtype=int)
+        rem = np.setdiff1d(rem, upd)
+        center[upd] += 1e-3
+        idx = np.concatenate([batch, upd, rem]).astype(int)
+        isp = pm.is_plane[idx].copy(); isp[len(batch) + len(upd):] = 0
+        g.map_update(pm.loc[idx], pm.layer[idx], pm.path[idx], center[idx], pm.normal[idx], pm.plane_var[idx], pm.radius[idx], isp)
+        alive[batch] = pm.is_plane[batch] == 1
+        alive[rem] = False
+        keep = np.nonzero(alive)[0]
+        o = O.LioOracle(pm.voxel_size, pm.max_layer)
+        o.map_update(pm.loc[keep], pm.layer[keep], pm.path[keep], center[keep], pm.normal[keep], pm.plane_var[keep], pm.radius[keep])
+        o.set_points(pnt, var)
+        ro = o.sweep(sc.state_gt, sc.cov, want_points=True); rg = g.sweep(sc.state_gt, sc.cov, want_points=True)
+        assert np.array_equal(ro["plane_of_point"] >= 0, rg["plane_of_point"] >= 0), step
+        if ro["match_num"]:
+            check_sweep(rg, ro)
+    assert g.map_size()[0] <= 3000
