@@ -17,8 +17,12 @@ LI_SRC = os.path.join(ROOT, "tests", "cpp", "li_adapter_demo.cpp")
 LI_EXE = os.path.join(ROOT, "tests", "cpp", "li_adapter_demo")
 
 
+LIO_SRC = os.path.join(ROOT, "tests", "cpp", "lio_adapter_demo.cpp")
+LIO_EXE = os.path.join(ROOT, "tests", "cpp", "lio_adapter_demo")
+
+
 def build(src=SRC, exe=EXE):
-    deps = [src] + [os.path.join(ROOT, "include", h) for h in ("vxba_lidar_factor.hpp", "vxba_li_optimizer.hpp", "vxba.h")]
+    deps = [src] + [os.path.join(ROOT, "include", h) for h in ("vxba_lidar_factor.hpp", "vxba_li_optimizer.hpp", "vxba_lio_estimator.hpp", "vxba.h")]
     so = os.path.join(LIBDIR, "libvxba.so")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps + [so]):
         subprocess.check_call(["g++", "-O2", "-std=c++14", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", LIBDIR, "-lvxba",
@@ -30,6 +34,7 @@ def test_adapter_compiles_and_links_as_cxx14():
     """The reference builds with -std=c++14 (VoxelSLAM/CMakeLists.txt:4-15); the adapter must too."""
     assert os.path.exists(build())
     assert os.path.exists(build(LI_SRC, LI_EXE))
+    assert os.path.exists(build(LIO_SRC, LIO_EXE))
 
 
 @pytest.mark.gpu
@@ -87,3 +92,36 @@ def test_li_adapter_end_to_end_matches_oracle(tmp_path):
     assert np.allclose(st[:, 12:21], ref["states"][:, 12:21], atol=1e-6)
     assert np.allclose(dbg, ref["imus"][:, 67:70], atol=1e-7)
     assert imu_leng == 15 * W and abs(h2020 - ref["hess"][20, 20]) < 1e-5 * abs(ref["hess"][20, 20])
+
+
+@pytest.mark.gpu
+def test_lio_adapter_end_to_end_matches_oracle(tmp_path):
+    """lio_state_estimation + pvec_update through the C++ adapter: the demo rebuilds a pointer octree like `surf_map`, the adapter
+    flattens it by walking it, and the estimate must equal the oracle's walk of its own tree."""
+    from tests import _oracle as O
+    from voxel_slam_amd import synth
+    exe = build(LIO_SRC, LIO_EXE)
+    pm = synth.make_plane_map(n_roots=900, extent=6, seed=81)
+    sc = synth.make_lio_scan(pm, n_points=9000, seed=82)
+    o = O.LioOracle(pm.voxel_size, pm.max_layer); o.map_update(*pm.args()); o.var_init(sc.xyz)
+    pnt, var = o.read_points()
+    n = len(pm.layer)
+    leaf = np.concatenate([pm.loc.astype(np.float64), pm.layer[:, None].astype(np.float64), pm.path[:, None].astype(np.float64), pm.is_plane[:, None].astype(np.float64),
+                           pm.center, pm.normal, np.transpose(pm.plane_var, (0, 2, 1)).reshape(n, 36), pm.radius[:, None]], axis=1)
+    pts = np.concatenate([pnt, np.transpose(var, (0, 2, 1)).reshape(-1, 9)], axis=1)
+    scene = tmp_path / "lio.bin"; out = tmp_path / "lio_out.bin"
+    with open(scene, "wb") as fh:
+        np.array([pm.voxel_size, pm.max_layer, n, pnt.shape[0]], dtype=np.float64).tofile(fh)
+        np.ascontiguousarray(leaf).tofile(fh); np.ascontiguousarray(pts).tofile(fh); sc.state_init.tofile(fh); np.ascontiguousarray(sc.cov.T).tofile(fh)
+    subprocess.check_call([exe, str(scene), str(out)])
+    res = np.fromfile(out, dtype=np.float64)
+    ref = o.lio_state_estimation(sc.state_init, sc.cov)
+    et, er = synth.pose_errors(res[None, :12], ref["state"][None, :12])
+    assert et < 1e-9 and er < 1e-9
+    assert np.allclose(res[12:21], ref["state"][12:21], atol=1e-10)
+    cov = res[21:246].reshape(15, 15).T
+    assert np.abs(cov - ref["cov"]).max() < 1e-8 * np.abs(ref["cov"]).max()
+    ok, match_num, iters = res[246:249]
+    assert bool(ok) == ref["ok"] and int(match_num) == ref["match_num"] and int(iters) == ref["iterations"]
+    pw, vw = o.pvec_update(ref["state"], ref["cov"])
+    assert np.allclose(res[249:252], pw[0], atol=1e-9) and abs(res[252] - vw[-1][2, 1]) < 1e-12 + 1e-6 * abs(vw[-1][2, 1])
