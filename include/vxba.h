@@ -191,6 +191,11 @@ typedef struct vxba_voxelize_params {
   double min_eigen_value;
   double eigen_ratio[4];
   double factor_ratio_max;
+  /* OctoTree's variant of the same construction -- the map build of motion_init (cut_voxel for every scan of the window, then one
+   * recut + tras_opt, voxelslam.cpp:606-625; OctoTree::recut voxel_map.hpp:1148-1194, tras_opt :1308-1333): the point-count floor
+   * depends on the layer (min_point[layer], voxelslam.cpp:812) and a single observing frame is enough. */
+  int min_points_layer[4]; /* > 0: overrides min_points for that layer */
+  int min_frames;          /* a factor needs at least this many observing frames: 2 for OctreeGBA (loop_refine.hpp:371-376), 0 for OctoTree */
 } vxba_voxelize_params;
 /* xyz_local: n_points x 3 body-frame points, frame by frame in cloud order; frame_ptr: win_size + 1 offsets; Rp: win_size*12.
  * Appends the factor voxels to f (coe = 1, no fix cluster, cache seeded with (lambda, U, world cluster) as recut's push_voxel

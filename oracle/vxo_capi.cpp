@@ -398,6 +398,8 @@ int64_t vxo_voxelize(int W, int64_t n_points, const double* xyz_local, const int
   p.voxel_size = params[0]; p.max_layer = (int)params[1]; p.min_points = (int)params[2]; p.min_eigen_value = params[3];
   for (int k = 0; k < 4; k++) p.eigen_ratio[k] = params[4 + k];
   p.factor_ratio_max = params[8];
+  for (int k = 0; k < 4; k++) p.min_points_layer[k] = (int)params[9 + k];
+  p.min_frames = (int)params[13];
   std::vector<std::vector<V3>> clouds(W);
   for (int i = 0; i < W; i++)
     for (int64_t q = frame_ptr[i]; q < frame_ptr[i + 1]; q++) clouds[i].push_back(v3(xyz_local[3 * q], xyz_local[3 * q + 1], xyz_local[3 * q + 2]));

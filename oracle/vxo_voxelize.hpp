@@ -26,6 +26,10 @@ struct VoxelizeParams {
   double min_eigen_value = 0.01;  // gba_min_eigen_value
   double eigen_ratio[4] = {1.0 / 16, 1.0 / 16, 1.0 / 16, 1.0 / 16};   // gba_eigen_value_array (already inverted, voxelslam.cpp:2490)
   double factor_ratio_max = 0.12; // lambda0 / lambda1 > 0.12 -> return
+  // OctoTree's variant (motion_init's map build: cut_voxel for every scan, then recut + tras_opt, voxelslam.cpp:606-625;
+  // OctoTree::recut voxel_map.hpp:1148-1194: N <= min_point[layer] -> no plane, no subdivision; tras_opt :1308-1333: no frame count)
+  int min_points_layer[4] = {0, 0, 0, 0};   // > 0: min_point[layer]
+  int min_frames = 2;                       // OctreeGBA: `if(exi <= 1) return` (loop_refine.hpp:371-376); OctoTree: 0
 };
 
 struct FactorVoxel {
@@ -71,7 +75,7 @@ struct GbaNode {
       }
   }
   void recut(const VoxelizeParams& p, std::vector<FactorVoxel>& out) {
-    if (pcr_add.N <= p.min_points) return;
+    if (pcr_add.N <= (p.min_points_layer[layer] > 0 ? p.min_points_layer[layer] : p.min_points)) return;
     V3 eig_value; M3 eig_vector;
     eig_sym3(pcr_add.cov(), eig_value, eig_vector);
     const bool is_plane = eig_value[0] < p.min_eigen_value && (eig_value[0] / eig_value[2]) < p.eigen_ratio[layer];
@@ -79,7 +83,7 @@ struct GbaNode {
       int exi = 0;
       for (int i = 0; i < wdsize; i++)
         if (!locals[i].empty()) exi++;
-      if (exi <= 1) return;
+      if (exi < p.min_frames) return;
       if (eig_value[0] / eig_value[1] > p.factor_ratio_max) return;
       FactorVoxel fv;
       fv.node_id = (root48 << 16) | (path << 7) | (uint64_t)layer;

@@ -287,7 +287,9 @@ def voxelize(W, xyz_local, frame_ptr, Rp, params9):
     """OctreeGBA::cut_voxel + recut on the CPU: dict(node_id, clusters (n,W,10), eig_val, eig_vec, merged), canonical order."""
     xyz = _c(xyz_local).reshape(-1, 3)
     fp = np.ascontiguousarray(frame_ptr, dtype=np.int64)
-    cap = xyz.shape[0] // 11 + 16
+    pr = _c(params9)
+    floor_pts = int(min([pr[2]] + [v for v in pr[9:13] if v > 0])) if pr.shape[0] >= 13 else int(pr[2])
+    cap = xyz.shape[0] // (max(floor_pts, 0) + 1) + 16
     ids = np.zeros(cap, dtype=np.uint64); cl = np.zeros((cap, W, 10)); ev = np.zeros((cap, 3)); U = np.zeros((cap, 9)); m = np.zeros((cap, 10))
     n = lib().vxo_voxelize(W, xyz.shape[0], xyz, fp, _c(Rp), _c(params9), cap, ids, cl, ev, U, m)
     if n < 0:

@@ -107,3 +107,33 @@ def test_ba_on_voxelized_window_matches_oracle_and_recovers_poses(vx):
     assert et < 1e-7 and er < 1e-7
     e0 = synth.pose_errors(poses, gt); e1 = synth.pose_errors(g["poses"], gt)
     assert e1[0] < 0.5 * e0[0] and e1[1] < 0.5 * e0[1]
+
+
+@pytest.mark.parametrize("W,pts,seed", [(5, 30_000, 11), (10, 40_000, 12)])
+def test_octotree_batch_build_matches_oracle(vx, W, pts, seed):
+    """OctoTree's criteria instead of OctreeGBA's: the map build of motion_init (cut_voxel for every scan, one recut + tras_opt,
+    voxelslam.cpp:606-625) -- point-count floor per layer (min_point[layer]), a single observing frame is enough."""
+    P = vx.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=20, min_eigen_value=0.02, eigen_ratio=(1 / 4, 1 / 4, 1 / 4, 1 / 4),
+                          min_points_layer=(20, 20, 15, 10), min_frames=0)
+    xyz, fp, poses, gt = synth.make_scans(win_size=W, pts_per_scan=pts, seed=synth.MASTER_SEED + 700 + seed)
+    # a wall only the last frame sees: single-frame voxels, factors for OctoTree, not for the GBA
+    rng = np.random.default_rng(seed)
+    wall = np.stack([rng.uniform(40, 46, 4000), rng.uniform(-3, 3, 4000), np.full(4000, 30.0) + rng.normal(0, 0.005, 4000)], axis=1)
+    R = poses[W - 1, :9].reshape(3, 3).T; t = poses[W - 1, 9:12]
+    xyz = np.ascontiguousarray(np.concatenate([xyz, (wall - t) @ R]))
+    fp = fp.copy(); fp[W] += 4000
+    ref = O.voxelize(W, xyz, fp, poses, P.as_array())
+    f = vx.LidarFactor(W); ids = f.voxelize_push(xyz, fp, poses, P)
+    assert ids.shape[0] > 100 and np.array_equal(np.sort(ids), ref["node_id"])
+    order = np.argsort(ids)
+    assert np.array_equal(f.read_clusters()[order], ref["clusters"])
+    _, _, merged = f.read_cache()
+    assert np.array_equal(merged[order], ref["merged"])
+    n_obs = (ref["clusters"][:, :, 9] > 0).sum(axis=1)
+    layers = (ref["node_id"] & np.uint64(7)).astype(int)
+    assert (n_obs == 1).sum() >= 10                                      # the single-frame wall became factors ...
+    assert ((ref["merged"][:, 9] <= 20) & (layers == 2)).any()           # ... and layer 2 accepts leaves under the layer-0 floor
+    G = vx.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=20, min_eigen_value=0.02, eigen_ratio=(1 / 4, 1 / 4, 1 / 4, 1 / 4))
+    f2 = vx.LidarFactor(W); ids2 = f2.voxelize_push(xyz, fp, poses, G)
+    refg = O.voxelize(W, xyz, fp, poses, G.as_array())
+    assert np.array_equal(np.sort(ids2), refg["node_id"]) and not set(ids[n_obs[np.argsort(np.argsort(ids))] == 1].tolist()) & set(ids2.tolist())

@@ -1440,7 +1440,10 @@ int vxba_voxelize_push(vxba_factor* f, int64_t n_points, const double* xyz_local
   if (n_points == 0) return VXBA_OK;
   hipSetDevice(f->device);
   const int W = f->W;
-  const int64_t cap = n_points / (std::max(params->min_points, 0) + 1) + 1;   // a factor owns > min_points points, and no point twice
+  int floor_pts = params->min_points;
+  for (int k = 0; k <= params->max_layer; k++)
+    if (params->min_points_layer[k] > 0) floor_pts = std::min(floor_pts, params->min_points_layer[k]);
+  const int64_t cap = n_points / (std::max(floor_pts, 0) + 1) + 1;   // a factor owns > min_points points, and no point twice
   struct Bufs {
     std::vector<void*> p;
     ~Bufs() { for (void* q : p) hipFree(q); }
@@ -1463,7 +1466,8 @@ int vxba_voxelize_push(vxba_factor* f, int64_t n_points, const double* xyz_local
   vxv::VoxelizeParams vp;
   vp.voxel_size = params->voxel_size; vp.max_layer = params->max_layer; vp.min_points = params->min_points;
   vp.min_eigen_value = params->min_eigen_value; vp.factor_ratio_max = params->factor_ratio_max;
-  for (int k = 0; k < 4; k++) vp.eigen_ratio[k] = params->eigen_ratio[k];
+  for (int k = 0; k < 4; k++) { vp.eigen_ratio[k] = params->eigen_ratio[k]; vp.min_points_layer[k] = params->min_points_layer[k]; }
+  vp.min_frames = params->min_frames;
   vxv::VoxelizeOutput out{cap, d_cl, d_ev, d_evec, d_m, d_id};
   const char* emsg = nullptr;
   const long long n = vxv::voxelize(W, n_points, d_xyz, d_fp, f->d_poses, vp, f->stream, &out, &emsg);

@@ -13,6 +13,8 @@ struct VoxelizeParams {
   double min_eigen_value;      // plane_judge: lambda0 < min_eigen_value ...
   double eigen_ratio[4];       // ... && lambda0 / lambda2 < eigen_ratio[layer]
   double factor_ratio_max;     // factor filter: lambda0 / lambda1 <= factor_ratio_max
+  int min_points_layer[4];     // > 0: per-layer override of min_points (OctoTree's min_point[layer])
+  int min_frames;              // observing frames a factor needs (OctreeGBA: 2, OctoTree: 0)
 };
 
 // Device staging arrays for the accepted voxels (AoS, the formats of vxba_push_voxels), capacity in voxels.

@@ -116,13 +116,14 @@ __global__ void judge_kernel(const unsigned long long* __restrict__ node_key, co
     }
   }
   const double* c = node_cluster + 10 * j;
-  if (alive && (int)c[9] > p.min_points) {
+  const int minp = p.min_points_layer[layer] > 0 ? p.min_points_layer[layer] : p.min_points;
+  if (alive && (int)c[9] > minp) {
     double Cm[6], lam[3], U[9];
     vxm::cluster_cov(c, c + 6, c[9], Cm);
     vxm::eig_sym3(Cm, lam, U);
     const bool is_plane = lam[0] < p.min_eigen_value && (lam[0] / lam[2]) < p.eigen_ratio[layer];
     if (is_plane) {
-      if (n_frames[j] > 1 && !(lam[0] / lam[1] > p.factor_ratio_max)) st = FACTOR;
+      if ((int)n_frames[j] >= p.min_frames && !(lam[0] / lam[1] > p.factor_ratio_max)) st = FACTOR;
     } else if (layer < p.max_layer) {
       st = SUBDIVIDE;
     }

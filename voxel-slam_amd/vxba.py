@@ -47,14 +47,17 @@ class VxbaError(RuntimeError):
 class VoxelizeParams(C.Structure):
     """vxba_voxelize_params: the knobs of OctreeGBA::recut (loop_refine.hpp:311-315, 358-378) and of the voxel grid."""
     _fields_ = [("voxel_size", C.c_double), ("max_layer", C.c_int), ("min_points", C.c_int), ("min_eigen_value", C.c_double),
-                ("eigen_ratio", C.c_double * 4), ("factor_ratio_max", C.c_double)]
+                ("eigen_ratio", C.c_double * 4), ("factor_ratio_max", C.c_double), ("min_points_layer", C.c_int * 4), ("min_frames", C.c_int)]
 
     def __init__(self, voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 16, 1 / 16),
-                 factor_ratio_max=0.12):
-        super().__init__(voxel_size, max_layer, min_points, min_eigen_value, (C.c_double * 4)(*eigen_ratio), factor_ratio_max)
+                 factor_ratio_max=0.12, min_points_layer=(0, 0, 0, 0), min_frames=2):
+        """Defaults: OctreeGBA.  OctoTree's batch build (motion_init): min_points_layer=min_point[layer], min_frames=0."""
+        super().__init__(voxel_size, max_layer, min_points, min_eigen_value, (C.c_double * 4)(*eigen_ratio), factor_ratio_max,
+                         (C.c_int * 4)(*min_points_layer), min_frames)
 
     def as_array(self):
-        return np.array([self.voxel_size, self.max_layer, self.min_points, self.min_eigen_value, *self.eigen_ratio, self.factor_ratio_max])
+        return np.array([self.voxel_size, self.max_layer, self.min_points, self.min_eigen_value, *self.eigen_ratio, self.factor_ratio_max,
+                         *self.min_points_layer, self.min_frames], dtype=np.float64)
 
 
 _lib = None
