@@ -109,3 +109,44 @@ def test_gravity_variant_matches_oracle(vx, W, V, pts, iters):
     assert et < 1e-7 and er < 1e-7, (et, er)
     assert np.allclose(got["states"][:, 12:24], ref["states"][:, 12:24], atol=1e-6)   # v, bg, ba, g
     assert np.allclose(got["hess"], ref["hess"], rtol=1e-5, atol=1e-7 * np.abs(ref["hess"]).max())
+
+
+def test_motion_init_round_from_raw_scans_matches_oracle(vx):
+    """One round of motion_init (voxelslam.cpp:596-640) end to end: the window's raw scans -> OctoTree-criteria batch map build ->
+    factor -> LI_BA_OptimizerGravity::damping_iter(3), on the GPU path and on the oracle; then the normals' spread test (:651-657)."""
+    import types
+    W = 6
+    xyz, fp, poses, gt = synth.make_scans(win_size=W, pts_per_scan=25_000, extent=24.0, noise=0.005, seed=synth.MASTER_SEED + 880, rot_sigma_deg=0.05, trans_sigma=0.02)
+    iw = synth.make_imu(types.SimpleNamespace(poses_gt=gt, poses_init=poses, win_size=W), seed=881)
+    st = iw.states_init.copy()
+    st[:, 21:24] += [0.05, -0.03, 0.08]
+    bg, ba = st[0, 15:18], st[0, 18:21]
+    blobs = O.imu_preintegrate(iw.samples, iw.noise_meas, iw.noise_walk, bg, ba)
+    facs = []
+    for gyr, acc, dts in iw.samples:
+        f = vx.IMU_PRE(bg, ba)
+        for g, a, dt in zip(gyr, acc, dts):
+            f.add_imu(g, a, dt, iw.noise_meas, iw.noise_walk)
+        facs.append(f)
+    P = vx.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=20, min_eigen_value=0.02, eigen_ratio=(1 / 4, 1 / 4, 1 / 4, 1 / 4),
+                          min_points_layer=(20, 20, 15, 10), min_frames=0)                     # motion_init's first-phase thresholds (:570-574)
+    fg = vx.LidarFactor(W)
+    ids = fg.voxelize_push(xyz, fp, st[:, :12].copy(), P)
+    r = O.voxelize(W, xyz, fp, st[:, :12].copy(), P.as_array())
+    order = np.lexsort((r["node_id"], (r["node_id"] & np.uint64(7)).astype(np.int64)))       # the GPU's push order
+    assert np.array_equal(ids, r["node_id"][order]) and ids.size >= 10                          # `if(voxhess.plvec_voxels.size() < 10) break;`
+    fo = O.Oracle(W)
+    n = ids.size
+    fo.push_voxels(r["clusters"][order], np.zeros((n, 10)), np.ones(n), r["eig_val"][order], r["eig_vec"][order], r["merged"][order])
+    ref = O.li_damping_iter_gravity(fo, st, blobs, max_iter=3, thd_num=5, imu_coef=1e-4)
+    got = vx.LI_BA_OptimizerGravity(imu_coef=1e-4).damping_iter(st, fg, facs, max_iter=3)
+    assert np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:]) and np.allclose(got["resis"], ref["resis"], rtol=1e-7)
+    et, er = synth.pose_errors(got["states"][:, :12], ref["states"][:, :12])
+    assert et < 1e-7 and er < 1e-7, (et, er)
+    assert np.allclose(got["states"][:, 12:24], ref["states"][:, 12:24], atol=1e-6)
+    # degeneracy test on the factors' plane normals (voxhess.eig_vectors, :651-657)
+    _, U_g, _ = fg.read_cache(); _, U_o, _ = fo.read_cache()
+    n_g = U_g.reshape(n, 3, 3).transpose(0, 2, 1)[:, :, 0]          # eig_vectors[k].col(0): the plane normals (column-major 3x3 per voxel)
+    n_o = U_o.reshape(n, 3, 3).transpose(0, 2, 1)[:, :, 0]
+    nn_g = n_g.T @ n_g; nn_o = n_o.T @ n_o
+    assert np.allclose(np.linalg.eigvalsh(nn_g), np.linalg.eigvalsh(nn_o), rtol=1e-6) and np.linalg.eigvalsh(nn_g)[0] > 15
