@@ -860,6 +860,10 @@ __global__ __launch_bounds__(256) void lm_spec_unpack_kernel(LMState* __restrict
 // unfused multiply/add, i.e. exactly PointCluster::push (tools.hpp:326-331) -- bit-identical to the CPU.
 // ------------------------------------------------------------------------------------------------
 constexpr int K1_CHUNK = 1024;  // points per LDS stage (24 KB)
+// Cells longer than this are not folded by one lane (a 100k-point node of a coarse top-level voxelisation took 95 ms that way) but by
+// a whole workgroup (k1_long_cells_kernel).  Up to this length the sum is the reference's sequential one, bit for bit; beyond it the
+// order is a different fixed one (deterministic, ~1e-16 relative from the sequential sum).
+constexpr long long K1_LONG = 2048;
 
 template <bool AOS>
 __global__ __launch_bounds__(256) void k1_build_kernel(const double* __restrict__ xyz, const long long* __restrict__ cell_ptr,
@@ -874,9 +878,32 @@ __global__ __launch_bounds__(256) void k1_build_kernel(const double* __restrict_
   const long long p_begin = cell_ptr[c0], p_end = cell_ptr[cend];
   long long lo = p_end, hi = p_end;
   if (c < ncells) { lo = cell_ptr[c]; hi = cell_ptr[c + 1]; }
+  const bool is_long = AOS && hi - lo > K1_LONG;     // left to k1_long_cells_kernel
+  if (is_long) lo = hi;
   double P0 = 0, P1 = 0, P2 = 0, P3 = 0, P4 = 0, P5 = 0, vx = 0, vy = 0, vz = 0, N = 0;
+  // Staging pays when the workgroup's 256 cells are small (a stage then feeds every lane).  With big cells (hundreds of points each:
+  // the world clusters of whole nodes) a stage overlaps one or two cells, the other lanes idle through every stage, and the workgroup
+  // degenerates into ONE lane folding all its points (21 ms for a coarse top-level layer).  There every lane streams its own cell
+  // straight from memory instead -- same sequential sum per cell, all lanes busy.
+  if (AOS && p_end - p_begin > 256 * 24) {
+    for (long long q = lo; q < hi; q++) {
+      const double x = xyz[3 * q], y = xyz[3 * q + 1], z = xyz[3 * q + 2];
+      N += 1.0;
+      P0 += x * x; P1 += x * y; P2 += x * z; P3 += y * y; P4 += y * z; P5 += z * z;
+      vx += x; vy += y; vz += z;
+    }
+    if (c < ncells && !is_long) {
+      double* o = aos + 10 * c;
+      o[0] = P0; o[1] = P1; o[2] = P2; o[3] = P3; o[4] = P4; o[5] = P5; o[6] = vx; o[7] = vy; o[8] = vz; o[9] = N;
+    }
+    return;
+  }
   for (long long chunk = p_begin; chunk < p_end; chunk += K1_CHUNK) {
     const int cnt = (int)((p_end - chunk < K1_CHUNK) ? (p_end - chunk) : K1_CHUNK);
+    if (AOS) {   // stages that lie entirely inside long cells are not loaded
+      const int need = lo < chunk + cnt && hi > chunk;
+      if (!__syncthreads_or(need)) continue;
+    }
     const double* src = xyz + 3 * chunk;
     for (int k = tid; k < 3 * cnt; k += 256) pts[k] = src[k];
     __syncthreads();
@@ -892,7 +919,7 @@ __global__ __launch_bounds__(256) void k1_build_kernel(const double* __restrict_
     __syncthreads();
   }
   if (AOS) {
-    if (c < ncells) {
+    if (c < ncells && !is_long) {
       double* o = aos + 10 * c;
       o[0] = P0; o[1] = P1; o[2] = P2; o[3] = P3; o[4] = P4; o[5] = P5; o[6] = vx; o[7] = vy; o[8] = vz; o[9] = N;
     }
@@ -903,6 +930,71 @@ __global__ __launch_bounds__(256) void k1_build_kernel(const double* __restrict_
     double* o = fv.cl + (size_t)i * 10 * VS + a;
     o[0] = P0; o[VS] = P1; o[2 * VS] = P2; o[3 * VS] = P3; o[4 * VS] = P4; o[5 * VS] = P5;
     o[6 * VS] = vx; o[7 * VS] = vy; o[8 * VS] = vz; o[9 * VS] = N;
+  }
+}
+
+// Long cells (> K1_LONG points): one workgroup per cell, points staged through LDS tile by tile, thread t folds points 4t .. 4t+3 of
+// every tile, fixed-order tree over the 256 partial clusters.
+__global__ __launch_bounds__(256) void k1_long_cells_kernel(const double* __restrict__ xyz, const long long* __restrict__ cell_ptr, long long ncells,
+                                                            double* __restrict__ aos) {
+#pragma clang fp contract(off)
+  __shared__ double pts[3 * K1_CHUNK];
+  __shared__ double red[10][256];
+  __shared__ unsigned long long mask_s;
+  const int tid = threadIdx.x;
+  // tiles of 64 cells (one ballot), dealt round-robin to the workgroups: consecutive long cells spread over many workgroups
+  const long long ntiles = (ncells + 63) / 64;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (tid < 64) {
+      const long long c = tile * 64 + tid;
+      bool lng = false;
+      if (c < ncells) lng = cell_ptr[c + 1] - cell_ptr[c] > K1_LONG;
+      const unsigned long long m = __ballot(lng);
+      if (tid == 0) mask_s = m;
+    }
+    __syncthreads();
+    {
+      unsigned long long mm = mask_s;
+      while (mm) {
+        const int bit = __ffsll((long long)mm) - 1;
+        mm &= mm - 1;
+        const long long cc = tile * 64 + bit;
+        const long long lo = cell_ptr[cc], hi = cell_ptr[cc + 1];
+        double a[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) a[k] = 0.0;
+        for (long long chunk = lo; chunk < hi; chunk += K1_CHUNK) {
+          const int cnt = (int)((hi - chunk < K1_CHUNK) ? (hi - chunk) : K1_CHUNK);
+          const double* src = xyz + 3 * chunk;
+          __syncthreads();
+          for (int k = tid; k < 3 * cnt; k += 256) pts[k] = src[k];
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < K1_CHUNK / 256; j++) {
+            const int q = (K1_CHUNK / 256) * tid + j;
+            if (q < cnt) {
+              const double x = pts[3 * q], y = pts[3 * q + 1], z = pts[3 * q + 2];
+              a[9] += 1.0;
+              a[0] += x * x; a[1] += x * y; a[2] += x * z; a[3] += y * y; a[4] += y * z; a[5] += z * z;
+              a[6] += x; a[7] += y; a[8] += z;
+            }
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 10; k++) red[k][tid] = a[k];
+        __syncthreads();
+        for (int step = 128; step >= 1; step >>= 1) {
+          if (tid < step) {
+#pragma unroll
+            for (int k = 0; k < 10; k++) red[k][tid] += red[k][tid + step];
+          }
+          __syncthreads();
+        }
+        if (tid < 10) aos[10 * cc + tid] = red[tid][0];
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -1251,6 +1343,8 @@ void launch_k1_build_aos(const double* d_xyz, const int64_t* d_cell_ptr, int64_t
   if (n_cells <= 0) return;
   FactorView fv{};
   k1_build_kernel<true><<<dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s>>>(d_xyz, (const long long*)d_cell_ptr, 0, 0, fv, 0, d_clusters, (long long)n_cells);
+  const long long tiles = (n_cells + 63) / 64;
+  k1_long_cells_kernel<<<dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, s>>>(d_xyz, (const long long*)d_cell_ptr, (long long)n_cells, d_clusters);
 }
 
 static inline unsigned nblk(long long n, int b) { return (unsigned)((n + b - 1) / b); }
