@@ -1,0 +1,37 @@
+"""Create / use / destroy the library's handles many times and watch the device's free memory (run on the GPU box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from voxel_slam_amd import synth, vxba
+
+def free_mb():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0] / 2**20
+
+sc = synth.make_scene(win_size=10, pts_per_scan=20000, n_voxels=3000, seed=3)
+xyz, fp, poses, _ = synth.make_scans(win_size=6, pts_per_scan=20000)
+P = vxba.VoxelizeParams()
+pm = synth.make_plane_map(n_roots=1500, extent=6, seed=4); ls = synth.make_lio_scan(pm, n_points=8000, seed=5)
+iw = synth.make_imu(sc)
+marks = []
+for rep in range(60):
+    f = vxba.LidarFactor(10); f.push_points(sc.n_voxels, sc.points_body, sc.cell_ptr); f.evaluate_only_residual(sc.poses_init)
+    vxba.Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=3)
+    facs = []
+    for gyr, acc, dts in iw.samples:
+        fac = vxba.IMU_PRE(iw.states_init[0, 15:18], iw.states_init[0, 18:21])
+        for g, a, dt in zip(gyr[:5], acc[:5], dts[:5]):
+            fac.add_imu(g, a, dt, iw.noise_meas, iw.noise_walk)
+        facs.append(fac)
+    os.environ["VXBA_LI_DEVICE"] = "1" if rep % 2 else "0"
+    vxba.LI_BA_Optimizer().damping_iter(iw.states_init, f, facs, max_iter=2)
+    f.close()
+    f2 = vxba.LidarFactor(6); f2.voxelize_push(xyz, fp, poses, P, want_ids=False); f2.close()
+    w = vxba.LidarFactor(24); scw = None
+    g = vxba.LioEstimator(pm.voxel_size, pm.max_layer); g.map_update(*pm.args()); g.var_init(ls.xyz); g.lio_state_estimation(ls.state_init, ls.cov); g.close(); w.close()
+    vxba.down_sampling_voxel(ls.xyz, 0.2)
+    if rep % 10 == 9:
+        marks.append(free_mb())
+        print("after %3d rounds: free %.1f MB" % (rep + 1, marks[-1]), flush=True)
+print("drift over the last 40 rounds: %.1f MB" % (marks[1] - marks[-1]))
