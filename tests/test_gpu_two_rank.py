@@ -21,15 +21,19 @@ def test_two_process_ranks_reproduce_the_single_factor_run(spec):
                           os.path.join(ROOT, "scripts", "dbg_two_rank.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     # the ranks print concurrently: records may share a line, so split on the record header rather than on newlines
-    recs = re.split(r"(?=rank \d (?:damping_iter|lm_steps):)", out.stdout)
-    recs = [r for r in recs if re.match(r"rank \d (damping_iter|lm_steps):", r)]
-    assert len(recs) == 4, out.stdout[-2000:]
+    recs = re.split(r"(?=rank \d (?:damping_iter|lm_steps|lm_steps_easy|li_damping_iter|wide damping_iter):)", out.stdout)
+    recs = [r for r in recs if re.match(r"rank \d (damping_iter|lm_steps|lm_steps_easy|li_damping_iter|wide damping_iter):", r)]
+    assert len(recs) == 10, out.stdout[-2000:]
     for ln in recs:
         m = re.search(r"pose diff ([0-9.e+-]+) ([0-9.e+-]+)", ln)
         assert m and float(m.group(1)) < 1e-9 and float(m.group(2)) < 1e-9, ln
         if "damping_iter" in ln:
             a, b = re.search(r"trace accept (\[[^\]]*\]) vs (\[[^\]]*\])", ln).groups()
-            assert a == b and "1." in a and "0." in a, ln          # same schedule, with rejected and accepted steps in it
+            assert a == b and "1." in a, ln                        # same schedule, with accepted steps in it ...
+            if re.match(r"rank \d damping_iter:", ln):
+                assert "0." in a, ln                               # ... and, on the hard window, rejected ones
         else:
             a, b = re.search(r"stats (\{[^}]*\}) vs (\{[^}]*\})", ln).groups()
             assert a == b, ln
+            if "lm_steps_easy" in ln:
+                assert "'rejected': 0" in a, ln
