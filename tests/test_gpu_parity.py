@@ -565,3 +565,41 @@ def test_two_voxel_shards_of_a_wide_window(vx):
     for f in facs:
         f.set_allreduce(None)
         f.use_external_buffers(None, None)
+
+
+def test_cfg4_size_properties_on_one_gpu(vx):
+    """BASELINE.json configs[3]'s window (10 frames, 1M points per scan, 400k voxels -- there sharded over 8 GPUs) on ONE GPU, through
+    size-independent properties: point checksum of K1, the eight shard ranges of an 8-GPU run add up to the whole, bitwise determinism,
+    K3's residual equals K2's, the gradient is the derivative of the cost, LM decreases it."""
+    sc = synth.make_config("cfg4")
+    V, W = sc.n_voxels, sc.win_size
+    f = vx.LidarFactor(W)
+    f.push_points(V, sc.points_body, sc.cell_ptr)
+    assert f.size() == V == 400_000 and sc.points_body.shape[0] == 10_000_000
+    cl = f.read_clusters()
+    assert cl[:, :, 9].sum() == sc.points_body.shape[0]
+    assert np.allclose(cl[:, :, 6:9].sum(axis=(0, 1)), sc.points_body.sum(axis=0), rtol=1e-9)
+    del cl
+    r0 = f.evaluate_only_residual(sc.poses_init)
+    H, J, r = f.acc_evaluate2(sc.poses_init)
+    assert abs(r - r0) <= 1e-12 * r0 and np.array_equal(H, H.T)
+    H2, J2, r2 = f.acc_evaluate2(sc.poses_init)
+    assert np.array_equal(H2, H) and np.array_equal(J2, J) and r2 == r
+    from voxel_slam_amd import dist as vdist
+    Hs = np.zeros_like(H); Js = np.zeros_like(J); rs = 0.0
+    for k in range(8):
+        lo, hi = vdist.shard_bounds(V, 8, k)
+        h, j, rr = f.acc_evaluate2(sc.poses_init, lo, hi)
+        Hs += h; Js += j; rs += rr
+    assert relerr(Hs, H) < 1e-11 and relerr(Js, J) < 1e-11 and abs(rs - r) < 1e-11 * r
+    rng = np.random.default_rng(4)
+    from tests.test_oracle_math import perturb
+    d = rng.normal(size=6 * W); d /= np.linalg.norm(d)
+    h = 1e-5
+    fd = (f.evaluate_only_residual(perturb(sc.poses_init, h * d)) - f.evaluate_only_residual(perturb(sc.poses_init, -h * d))) / (2 * h)
+    assert abs(fd - J @ d) < 1e-5 * np.abs(J).max()
+    f.evaluate_only_residual(sc.poses_init)
+    out = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=4)
+    assert out["resis"][1] < out["resis"][0] and out["trace"][:, 6].sum() >= 1
+    e0 = synth.pose_errors(sc.poses_init, sc.poses_gt); e1 = synth.pose_errors(out["poses"], sc.poses_gt)
+    assert e1[0] < e0[0]
