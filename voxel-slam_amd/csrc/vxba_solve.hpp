@@ -109,7 +109,9 @@ struct LmElim {
 // published and fetched together, one rank-2 update per row) to halve the number of dependent publish -> fetch -> reciprocal
 // chains.  Same-box A/B at W = 10: solve + residual-sweep launch 34.8 us instead of 28.4 us -- the block step's own chain (two
 // products for the multipliers, the determinant, twice the LDS reads in the queue ahead of the next fetch) is longer than two
-// scalar steps with look-ahead.
+// scalar steps with look-ahead.  Also rejected: no LDS at all -- by symmetry the pivot column is lane K's own row, so every entry can
+// be broadcast with v_readlane (static lane and register) and used as the scalar operand of the update; no publish -> fetch round trip,
+// but 2 x 27 readlanes per step: 35.4 us in the same A/B.
 constexpr int SOLVE_LDS = 128;   // doubles of LDS the solve needs (two pivot-column buffers)
 
 // Rows 6 .. N-1 of a symmetric positive definite system, row i in lane i's registers (A, right-hand side b; damping already
