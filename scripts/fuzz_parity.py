@@ -1,0 +1,98 @@
+"""Randomised GPU-vs-oracle sweep over the library's paths (run on the GPU box): random window sizes, voxel counts, incidences, fix
+clusters, perturbations.  Prints one line per case and a summary; exits non-zero on the first mismatch."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa: F401
+from tests import _oracle as O
+from voxel_slam_amd import synth, vxba
+
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+rng = np.random.default_rng(seed0)
+fails = 0
+
+def check(cond, msg):
+    global fails
+    if not cond:
+        fails += 1
+        print("  MISMATCH:", msg, flush=True)
+
+t0 = time.time()
+for case in range(n_cases):
+    kind = ["lm", "lm", "wide", "li", "li_dev", "lio", "vox", "vox_octo", "ds"][case % 9]
+    s = int(rng.integers(1, 1 << 30))
+    if kind in ("lm", "wide", "li", "li_dev"):
+        W = int(rng.integers(11, 40)) if kind == "wide" else int(rng.integers(2, 11))
+        V = int(rng.integers(150, 3000)); pts = int(rng.integers(3000, 30000))
+        p_obs = float(rng.choice([1.0, 0.8, 0.4])) if kind != "wide" else float(rng.uniform(0.1, 0.4))
+        sc = synth.make_scene(win_size=W, pts_per_scan=pts, n_voxels=V, p_obs=p_obs, fix_frac=float(rng.choice([0.0, 0.3])), seed=s,
+                              rot_sigma_deg=float(rng.choice([0.05, 0.2, 0.5])), trans_sigma=float(rng.choice([0.02, 0.08])))
+        fo = O.Oracle(W); fo.push_voxels(sc.clusters, sc.fix, sc.coe); fo.evaluate_only_residual(sc.poses_init)
+        fg = vxba.LidarFactor(W); fg.push_voxels(sc.clusters, sc.fix, sc.coe); fg.evaluate_only_residual(sc.poses_init)
+        iters = int(rng.integers(2, 8))
+        if kind in ("lm", "wide"):
+            ref = fo.damping_iter(sc.poses_init, max_iter=iters, thd_num=3)
+            got = vxba.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=iters)
+            et, er = synth.pose_errors(got["poses"], ref["poses"])
+            check(got["trace"].shape == ref["trace"].shape and np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:]), "%s trace W=%d V=%d seed=%d" % (kind, W, V, s))
+            check(et < 1e-7 and er < 1e-7, "%s poses %.2e %.2e W=%d V=%d seed=%d" % (kind, et, er, W, V, s))
+            desc = "W=%d V=%d p_obs=%.1f iters=%d acc=%s pose diff %.1e/%.1e" % (W, V, p_obs, iters, got["trace"][:, 6].astype(int), et, er)
+        else:
+            os.environ["VXBA_LI_DEVICE"] = "1" if kind == "li_dev" else "0"
+            iw = synth.make_imu(sc, seed=s + 1)
+            bg, ba = iw.states_init[0, 15:18], iw.states_init[0, 18:21]
+            blobs = O.imu_preintegrate(iw.samples, iw.noise_meas, iw.noise_walk, bg, ba)
+            facs = []
+            for gyr, acc, dts in iw.samples:
+                fac = vxba.IMU_PRE(bg, ba)
+                for g, a, dt in zip(gyr, acc, dts):
+                    fac.add_imu(g, a, dt, iw.noise_meas, iw.noise_walk)
+                facs.append(fac)
+            iters = min(iters, 5)
+            ref = O.li_damping_iter(fo, iw.states_init, blobs, max_iter=iters, thd_num=5, imu_coef=1e-4)
+            got = vxba.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(iw.states_init, fg, facs, max_iter=iters)
+            et, er = synth.pose_errors(got["states"][:, :12], ref["states"][:, :12])
+            check(got["trace"].shape == ref["trace"].shape and np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:]), "%s trace W=%d V=%d seed=%d" % (kind, W, V, s))
+            check(et < 1e-7 and er < 1e-7 and np.allclose(got["states"][:, 12:21], ref["states"][:, 12:21], atol=1e-6), "%s states %.2e %.2e W=%d V=%d seed=%d" % (kind, et, er, W, V, s))
+            desc = "W=%d V=%d iters=%d acc=%s pose diff %.1e/%.1e" % (W, V, iters, got["trace"][:, 6].astype(int), et, er)
+        fg.close()
+    elif kind == "lio":
+        ml = int(rng.integers(0, 4)); vs = float(rng.choice([0.5, 1.0, 2.0]))
+        ext = int(rng.integers(6, 10))
+        pm = synth.make_plane_map(n_roots=int(rng.integers(200, int(0.5 * (2 * ext) ** 3))), extent=ext, voxel_size=vs, max_layer=ml, seed=s)
+        sc = synth.make_lio_scan(pm, n_points=int(rng.integers(2000, 40000)), seed=s + 1, rot_sigma_deg=float(rng.choice([0.1, 0.5])), trans_sigma=float(rng.choice([0.02, 0.06])))
+        o = O.LioOracle(vs, ml); o.map_update(*pm.args()); o.var_init(sc.xyz)
+        g = vxba.LioEstimator(vs, ml); g.map_update(*pm.args()); g.var_init(sc.xyz)
+        ref = o.lio_state_estimation(sc.state_init, sc.cov); got = g.lio_state_estimation(sc.state_init, sc.cov)
+        et, er = synth.pose_errors(got["state"][None, :12], ref["state"][None, :12])
+        check(got["iterations"] == ref["iterations"] and got["match_num"] == ref["match_num"] and got["ok"] == ref["ok"], "lio counts seed=%d" % s)
+        check(et < 1e-8 and er < 1e-8, "lio pose %.2e %.2e seed=%d" % (et, er, s))
+        desc = "max_layer=%d vs=%.1f planes=%d pts=%d matched=%d it=%d pose diff %.1e/%.1e" % (ml, vs, g.map_size()[1], sc.xyz.shape[0], got["match_num"], got["iterations"], et, er)
+        g.close()
+    elif kind in ("vox", "vox_octo"):
+        W = int(rng.integers(2, 12)); pts = int(rng.integers(4000, 40000)); ml = int(rng.integers(0, 4)); vs = float(rng.choice([0.5, 1.0, 2.0]))
+        xyz, fp, poses, _ = synth.make_scans(win_size=W, pts_per_scan=pts, seed=s)
+        if kind == "vox":
+            P = vxba.VoxelizeParams(voxel_size=vs, max_layer=ml, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
+        else:
+            P = vxba.VoxelizeParams(voxel_size=vs, max_layer=ml, min_points=20, min_eigen_value=0.02, eigen_ratio=(1 / 4,) * 4, min_points_layer=(20, 20, 15, 10), min_frames=0)
+        ref = O.voxelize(W, xyz, fp, poses, P.as_array())
+        f = vxba.LidarFactor(W); ids = f.voxelize_push(xyz, fp, poses, P)
+        check(np.array_equal(np.sort(ids), ref["node_id"]), "%s factor set W=%d seed=%d (%d vs %d)" % (kind, W, s, ids.size, ref["node_id"].size))
+        if ids.size and ids.size == ref["node_id"].size:
+            order = np.argsort(ids)
+            cl = f.read_clusters()[order]
+            short = ref["clusters"][:, :, 9] <= 2048
+            check(np.array_equal(cl[short], ref["clusters"][short]) and np.allclose(cl, ref["clusters"], rtol=1e-12, atol=0), "%s clusters W=%d seed=%d" % (kind, W, s))
+        desc = "W=%d pts=%d max_layer=%d vs=%.1f factors=%d" % (W, pts, ml, vs, ids.size)
+        f.close()
+    else:
+        n = int(rng.integers(1, 300000)); size = float(rng.choice([0.05, 0.1, 0.25, 1.0])); scale = float(rng.choice([2.0, 30.0]))
+        xyz = (rng.normal(size=(n, 3)) * scale).astype(np.float32)
+        got = vxba.down_sampling_voxel(xyz, size); ref = O.down_sampling_voxel(xyz, size)
+        check(got.shape == ref.shape and np.array_equal(got, ref), "downsample n=%d size=%.2f" % (n, size))
+        desc = "n=%d size=%.2f -> %d" % (n, size, got.shape[0])
+    print("case %3d %-8s %s" % (case, kind, desc), flush=True)
+print("%d cases, %d mismatches, %.1f s" % (n_cases, fails, time.time() - t0))
+sys.exit(1 if fails else 0)
