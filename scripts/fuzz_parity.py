@@ -24,7 +24,7 @@ for case in range(n_cases):
     s = int(rng.integers(1, 1 << 30))
     if kind in ("lm", "wide", "li", "li_dev"):
         W = int(rng.integers(11, 40)) if kind == "wide" else int(rng.integers(2, 11))
-        V = int(rng.integers(150, 3000)); pts = int(rng.integers(3000, 30000))
+        V = int(rng.integers(150, 3000)); pts = int(V * rng.uniform(8, 20))   # >= 8 points per (voxel, frame): fewer make rank-deficient voxels no map would hand over
         p_obs = float(rng.choice([1.0, 0.8, 0.4])) if kind != "wide" else float(rng.uniform(0.1, 0.4))
         sc = synth.make_scene(win_size=W, pts_per_scan=pts, n_voxels=V, p_obs=p_obs, fix_frac=float(rng.choice([0.0, 0.3])), seed=s,
                               rot_sigma_deg=float(rng.choice([0.05, 0.2, 0.5])), trans_sigma=float(rng.choice([0.02, 0.08])))
@@ -36,6 +36,22 @@ for case in range(n_cases):
             got = vxba.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=iters)
             et, er = synth.pose_errors(got["poses"], ref["poses"])
             check(got["trace"].shape == ref["trace"].shape and np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:]), "%s trace W=%d V=%d seed=%d" % (kind, W, V, s))
+            if not (et < 1e-7 and er < 1e-7):   # how much of it is conditioning?
+                Hf = ref["hess"][6:, 6:]
+                ev = np.linalg.eigvalsh(Hf)
+                fo2 = O.Oracle(W); fo2.push_voxels(sc.clusters, sc.fix, sc.coe); fo2.evaluate_only_residual(sc.poses_init)
+                fg2 = vxba.LidarFactor(W); fg2.push_voxels(sc.clusters, sc.fix, sc.coe); fg2.evaluate_only_residual(sc.poses_init)
+                evo = fo2.read_cache()[0]
+                gap = (evo[:, 1] - evo[:, 0]) / evo[:, 1]
+                worst = np.argsort(gap)[:3]
+                Ho, Jo, ro = fo2.acc_evaluate2(sc.poses_init); Hg, Jg, rg = fg2.acc_evaluate2(sc.poses_init)
+                a = int(worst[0])
+                Hox = fo2.acc_evaluate2(sc.poses_init, 0, a)[0] + fo2.acc_evaluate2(sc.poses_init, a + 1, V)[0]
+                Hgx = fg2.acc_evaluate2(sc.poses_init, 0, a)[0] + fg2.acc_evaluate2(sc.poses_init, a + 1, V)[0]
+                print("  diag: smallest eigen-gaps (l1-l0)/l1 %s at voxels %s (eigvals %s); H rel diff at the initial poses %.1e, without voxel %d: %.1e" % (
+                      gap[worst], worst, evo[a], np.abs(Hg - Ho).max() / np.abs(Ho).max(), a, np.abs(Hgx - Hox).max() / np.abs(Hox).max()), flush=True)
+                print("  diag: cond(H_free) %.2e, eig min %.3e max %.3e, r2 rel diff per iter %s, hess rel diff %.1e" % (ev[-1] / ev[0], ev[0], ev[-1],
+                      np.abs(got["trace"][:, 1] / ref["trace"][:, 1] - 1), np.abs(got["hess"] - ref["hess"]).max() / np.abs(ref["hess"]).max()), flush=True)
             check(et < 1e-7 and er < 1e-7, "%s poses %.2e %.2e W=%d V=%d seed=%d" % (kind, et, er, W, V, s))
             desc = "W=%d V=%d p_obs=%.1f iters=%d acc=%s pose diff %.1e/%.1e" % (W, V, p_obs, iters, got["trace"][:, 6].astype(int), et, er)
         else:
