@@ -159,6 +159,9 @@ constexpr unsigned K2_SPIN_LIMIT = 1u << 22;
 #ifndef K2_HEAD_START
 #define K2_HEAD_START 100   // x 64 cycles
 #endif
+#ifndef VXBA_PUBLISH_FENCE
+#define VXBA_PUBLISH_FENCE 0
+#endif
 template <int W, bool DBG = false>
 __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c, unsigned seq, int head, int end,
                                                          int VPB, double* __restrict__ partial) {
@@ -171,8 +174,16 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
   if (st && seq != 0) {
     if (blockIdx.x == 0) {
       lm_solve_body<W, DBG>(st, c, solve_lds, solve_lds + SOLVE_LDS);
+#if VXBA_PUBLISH_FENCE
       __threadfence();
       if (lane == 0) __hip_atomic_store(&st->solve_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+      // the trial poses went out as written-through agent-scope stores: wait for their acknowledgement, then publish -- no L2
+      // write-back + invalidate on the critical path (everything else the solve wrote is only read by later kernels)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) __hip_atomic_store(&st->solve_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
       return;
     }
     vb = blockIdx.x - 1;
@@ -1168,10 +1179,12 @@ __device__ __forceinline__ void lm_solve_body(LMState* st, int c, double* colbuf
     for (int k = 0; k < 6; k++) dl[k] = xs[6 * lane + k];
     double xn[9];
     lm_right_multiply_exp(xcur, dl, xn);
+    // agent-scope stores (written through): when the solve runs inside the residual-sweep launch, the waiting workgroups read these
+    // right after the sequence number -- no device-wide fence on the publishing side
 #pragma unroll
-    for (int k = 0; k < 9; k++) ctl.xt[12 * lane + k] = xn[k];
+    for (int k = 0; k < 9; k++) __hip_atomic_store(&ctl.xt[12 * lane + k], xn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-    for (int k = 0; k < 3; k++) ctl.xt[12 * lane + 9 + k] = xcur[9 + k] + dl[3 + k];
+    for (int k = 0; k < 3; k++) __hip_atomic_store(&ctl.xt[12 * lane + 9 + k], xcur[9 + k] + dl[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   double part = row_ok ? x * (u * hii * x - gi) : 0.0;
 #pragma unroll
