@@ -204,6 +204,10 @@ typedef struct vxba_voxelize_params {
  * ascending id inside a layer).  Voxel coordinates must stay within +-32768. */
 int vxba_voxelize_push(vxba_factor* f, int64_t n_points, const double* xyz_local, const int64_t* frame_ptr, const double* Rp,
                        const vxba_voxelize_params* params, int64_t* n_pushed, uint64_t* node_ids, int64_t ids_capacity);
+/* The same with the points already in device memory (n_points x 3 f64 on the factor's device; frame_ptr, Rp and params stay host
+ * arrays): nothing but a few counters crosses PCIe.  The buffer must stay valid and unchanged until the call returns. */
+int vxba_voxelize_push_device(vxba_factor* f, int64_t n_points, const double* d_xyz_local, const int64_t* frame_ptr, const double* Rp,
+                              const vxba_voxelize_params* params, int64_t* n_pushed, uint64_t* node_ids, int64_t ids_capacity);
 
 /* ---- inertial half of the LiDAR-inertial BA (host code; runs while the GPU sweeps) ------------------- */
 /* Flat formats, every matrix column-major:

@@ -156,3 +156,23 @@ def test_cluster_build_with_very_long_cells(vx):
     assert np.array_equal(got[:, 9], ref[:, 9])
     assert np.allclose(got[~short], ref[~short], rtol=1e-12, atol=0)
     assert np.array_equal(vx.build_clusters(xyz, cell_ptr), got)            # deterministic
+
+
+def test_voxelize_from_device_memory_and_repeated_calls(vx):
+    """vxba_voxelize_push_device on a torch tensor gives the same factor as the host-pointer call; repeated calls on one factor
+    (clear in between) reuse the scratch and stay exact."""
+    import torch
+    W = 6
+    P = vx.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
+    f = vx.LidarFactor(W); f2 = vx.LidarFactor(W)
+    for rep, pts in enumerate((20_000, 45_000, 8_000)):
+        xyz, fp, poses, _ = synth.make_scans(win_size=W, pts_per_scan=pts, seed=synth.MASTER_SEED + 780 + rep)
+        f.clear(); f2.clear()
+        ids = f.voxelize_push(xyz, fp, poses, P)
+        t = torch.from_numpy(xyz).cuda()
+        ids2 = f2.voxelize_push_device(t.data_ptr(), xyz.shape[0], fp, poses, P)
+        ref = O.voxelize(W, xyz, fp, poses, P.as_array())
+        assert np.array_equal(ids, ids2) and np.array_equal(np.sort(ids), ref["node_id"])
+        assert np.array_equal(f.read_clusters(), f2.read_clusters())
+        m1 = f.read_cache()[2]; m2 = f2.read_cache()[2]
+        assert np.array_equal(m1, m2) and np.array_equal(m1[np.argsort(ids)], ref["merged"])

@@ -58,6 +58,8 @@ struct vxba_factor {
   double* zc_packed = nullptr;   // device alias of h_packed: kernels of host-driven loops write their result straight into host memory
   double* h_scalar = nullptr;    // pinned
   vxk::LMState* d_lm = nullptr;  // device-resident LM shell state
+  char* d_scratch = nullptr;     // grow-only device scratch of the batch factor construction (staging of points and accepted voxels)
+  size_t scratch_cap = 0;
   vxli::LIState* d_li = nullptr; // device-resident LiDAR-inertial loop state (allocated on first use)
   double* d_li_hess = nullptr;   // (15W)^2 export of that loop's *hess
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
@@ -521,7 +523,7 @@ int vxba_destroy(vxba_factor* f) {
   if (f->h_poses) hipHostFree(f->h_poses);
   if (f->h_packed) hipHostFree(f->h_packed);
   if (f->h_scalar) hipHostFree(f->h_scalar);
-  hipFree(f->d_lm); hipFree(f->d_li); hipFree(f->d_li_hess);
+  hipFree(f->d_lm); hipFree(f->d_li); hipFree(f->d_li_hess); hipFree(f->d_scratch);
   if (f->h_lm) hipHostFree(f->h_lm);
   if (f->own_stream) hipStreamDestroy(f->own_stream);
   delete f;
@@ -1428,8 +1430,8 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
 
 // OctreeGBA::cut_voxel + recut on the GPU (vxba_voxelize.hip); the accepted voxels go straight from the staging arrays into
 // the factor's planes -- nothing returns to the host except their count (and the ids, if asked for).
-int vxba_voxelize_push(vxba_factor* f, int64_t n_points, const double* xyz_local, const int64_t* frame_ptr, const double* Rp,
-                       const vxba_voxelize_params* params, int64_t* n_pushed, uint64_t* node_ids, int64_t ids_capacity) {
+static int voxelize_push_impl(vxba_factor* f, int64_t n_points, const double* xyz_local, bool xyz_on_device, const int64_t* frame_ptr, const double* Rp,
+                              const vxba_voxelize_params* params, int64_t* n_pushed, uint64_t* node_ids, int64_t ids_capacity) {
   VX_LOCK(f);
   if (!f || n_points < 0 || !frame_ptr || !Rp || !params || !n_pushed || (n_points > 0 && !xyz_local))
     return fail(f, VXBA_ERR_ARG, "voxelize_push: null argument");
@@ -1444,22 +1446,29 @@ int vxba_voxelize_push(vxba_factor* f, int64_t n_points, const double* xyz_local
   for (int k = 0; k <= params->max_layer; k++)
     if (params->min_points_layer[k] > 0) floor_pts = std::min(floor_pts, params->min_points_layer[k]);
   const int64_t cap = n_points / (std::max(floor_pts, 0) + 1) + 1;   // a factor owns > min_points points, and no point twice
-  struct Bufs {
-    std::vector<void*> p;
-    ~Bufs() { for (void* q : p) hipFree(q); }
-  } bufs;
-  auto dalloc = [&](void** ptr, size_t bytes) { hipError_t e = hipMalloc(ptr, std::max<size_t>(bytes, 8)); if (e == hipSuccess) bufs.p.push_back(*ptr); return e; };
-  double *d_xyz, *d_cl, *d_ev, *d_evec, *d_m, *d_fix, *d_coe;
-  long long* d_fp;
-  unsigned long long* d_id;
-  VX_HIP(f, dalloc((void**)&d_xyz, (size_t)n_points * 3 * sizeof(double)));
-  VX_HIP(f, dalloc((void**)&d_fp, (size_t)(W + 1) * sizeof(long long)));
-  VX_HIP(f, dalloc((void**)&d_cl, (size_t)cap * W * 10 * sizeof(double)));
-  VX_HIP(f, dalloc((void**)&d_ev, (size_t)cap * 3 * sizeof(double)));
-  VX_HIP(f, dalloc((void**)&d_evec, (size_t)cap * 9 * sizeof(double)));
-  VX_HIP(f, dalloc((void**)&d_m, (size_t)cap * 10 * sizeof(double)));
-  VX_HIP(f, dalloc((void**)&d_id, (size_t)cap * sizeof(unsigned long long)));
-  VX_HIP(f, hipMemcpyAsync(d_xyz, xyz_local, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  // one grow-only scratch allocation per factor, carved up here (a hipMalloc / hipFree pair per buffer and call cost more than the sorts)
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t b_xyz = xyz_on_device ? 0 : up((size_t)n_points * 3 * sizeof(double)), b_fp = up((size_t)(W + 1) * sizeof(long long)),
+               b_cl = up((size_t)cap * W * 10 * sizeof(double)), b_ev = up((size_t)cap * 3 * sizeof(double)), b_evec = up((size_t)cap * 9 * sizeof(double)),
+               b_m = up((size_t)cap * 10 * sizeof(double)), b_id = up((size_t)cap * sizeof(unsigned long long)), b_fix = up((size_t)cap * 10 * sizeof(double)),
+               b_coe = up((size_t)cap * sizeof(double));
+  const size_t need = b_xyz + b_fp + b_cl + b_ev + b_evec + b_m + b_id + b_fix + b_coe;
+  if (need > f->scratch_cap) {
+    VX_HIP(f, hipStreamSynchronize(f->stream));
+    if (f->d_scratch) VX_HIP(f, hipFree(f->d_scratch));
+    f->d_scratch = nullptr; f->scratch_cap = 0;
+    VX_HIP(f, hipMalloc((void**)&f->d_scratch, need + need / 4));
+    f->scratch_cap = need + need / 4;
+  }
+  char* q = f->d_scratch;
+  auto carve = [&](size_t bytes) { char* r = q; q += bytes; return r; };
+  double* d_xyz_own = (double*)carve(b_xyz);
+  long long* d_fp = (long long*)carve(b_fp);
+  double* d_cl = (double*)carve(b_cl); double* d_ev = (double*)carve(b_ev); double* d_evec = (double*)carve(b_evec); double* d_m = (double*)carve(b_m);
+  unsigned long long* d_id = (unsigned long long*)carve(b_id);
+  double* d_fix = (double*)carve(b_fix); double* d_coe = (double*)carve(b_coe);
+  const double* d_xyz = xyz_on_device ? xyz_local : d_xyz_own;
+  if (!xyz_on_device) VX_HIP(f, hipMemcpyAsync(d_xyz_own, xyz_local, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
   VX_HIP(f, hipMemcpyAsync(d_fp, frame_ptr, (size_t)(W + 1) * sizeof(long long), hipMemcpyHostToDevice, f->stream));
   int rcp = upload_poses(f, Rp);
   if (rcp) return rcp;
@@ -1477,8 +1486,6 @@ int vxba_voxelize_push(vxba_factor* f, int64_t n_points, const double* xyz_local
     if (rc) return rc;
     const FactorView fv = view(f);
     const int v0 = f->V;
-    VX_HIP(f, dalloc((void**)&d_fix, (size_t)n * 10 * sizeof(double)));
-    VX_HIP(f, dalloc((void**)&d_coe, (size_t)n * sizeof(double)));
     vxv::fill(d_fix, n * 10, 0.0, f->stream);
     vxv::fill(d_coe, n, 1.0, f->stream);
     vxk::launch_scatter_clusters(d_cl, fv, v0, (int)n, f->stream);
@@ -1498,6 +1505,15 @@ int vxba_voxelize_push(vxba_factor* f, int64_t n_points, const double* xyz_local
   }
   *n_pushed = n;
   return VXBA_OK;
+}
+
+int vxba_voxelize_push(vxba_factor* f, int64_t n_points, const double* xyz_local, const int64_t* frame_ptr, const double* Rp,
+                       const vxba_voxelize_params* params, int64_t* n_pushed, uint64_t* node_ids, int64_t ids_capacity) {
+  return voxelize_push_impl(f, n_points, xyz_local, false, frame_ptr, Rp, params, n_pushed, node_ids, ids_capacity);
+}
+int vxba_voxelize_push_device(vxba_factor* f, int64_t n_points, const double* d_xyz_local, const int64_t* frame_ptr, const double* Rp,
+                              const vxba_voxelize_params* params, int64_t* n_pushed, uint64_t* node_ids, int64_t ids_capacity) {
+  return voxelize_push_impl(f, n_points, d_xyz_local, true, frame_ptr, Rp, params, n_pushed, node_ids, ids_capacity);
 }
 
 int vxba_debug_mfma_probe(int device, const double* A16x4, const double* B4x16, double* D16x16) {

@@ -34,7 +34,7 @@ EXPORTS = [
     "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_li_evaluate",
     "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity", "vxba_voxelize_push", "vxba_set_precision",
     "vxba_lio_create", "vxba_lio_destroy", "vxba_lio_last_error", "vxba_lio_map_update", "vxba_lio_map_clear", "vxba_lio_map_size", "vxba_lio_scan_raw",
-    "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_cov_add_build", "vxba_plane_update", "vxba_down_sampling_voxel",
+    "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_cov_add_build", "vxba_plane_update", "vxba_down_sampling_voxel", "vxba_voxelize_push_device",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -121,6 +121,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_li_only_residual.argtypes = [vp, _f64p, _f64p, cd, C.POINTER(cd)]
     L.vxba_li_damping_iter.argtypes = [vp, _f64p, _f64p, cd, ci, vp, vp, C.POINTER(ci)]
     L.vxba_voxelize_push.argtypes = [vp, C.c_int64, _f64p, _i64p, _f64p, C.POINTER(VoxelizeParams), C.POINTER(C.c_int64), vp, C.c_int64]
+    L.vxba_voxelize_push_device.argtypes = [vp, C.c_int64, vp, _i64p, _f64p, C.POINTER(VoxelizeParams), C.POINTER(C.c_int64), vp, C.c_int64]
     L.vxba_imu_evaluate_g.argtypes = [_f64p, _f64p, _f64p, ci, vp, vp, C.POINTER(cd)]
     L.vxba_li_damping_iter_gravity.argtypes = [vp, _f64p, _f64p, cd, ci, vp, _f64p, vp, C.POINTER(ci)]
     i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -244,10 +245,26 @@ class LidarFactor:
         xyz = _c(xyz_local).reshape(-1, 3)
         fp = np.ascontiguousarray(frame_ptr, dtype=np.int64)
         n = C.c_int64(0)
-        cap = xyz.shape[0] // (max(params.min_points, 0) + 1) + 1 if want_ids else 0
+        cap = self._ids_cap(xyz.shape[0], params) if want_ids else 0
         ids = np.zeros(max(cap, 1), dtype=np.uint64)
         self._chk(self._L.vxba_voxelize_push(self._h, xyz.shape[0], xyz, fp, _c(xs), C.byref(params), C.byref(n),
                                              ids.ctypes.data_as(C.c_void_p) if want_ids else None, cap))
+        return ids[: n.value].copy() if want_ids else n.value
+
+    @staticmethod
+    def _ids_cap(n_points, params):
+        floor_pts = min([params.min_points] + [v for v in params.min_points_layer[: params.max_layer + 1] if v > 0])
+        return n_points // (max(floor_pts, 0) + 1) + 1
+
+    def voxelize_push_device(self, d_xyz_ptr: int, n_points: int, frame_ptr, xs, params: "VoxelizeParams", want_ids=True):
+        """:meth:`voxelize_push` on points that already live in device memory (``d_xyz_ptr``: n_points x 3 float64, e.g. a torch
+        tensor's ``data_ptr()``)."""
+        fp = np.ascontiguousarray(frame_ptr, dtype=np.int64)
+        n = C.c_int64(0)
+        cap = self._ids_cap(n_points, params) if want_ids else 0
+        ids = np.zeros(max(cap, 1), dtype=np.uint64)
+        self._chk(self._L.vxba_voxelize_push_device(self._h, int(n_points), C.c_void_p(d_xyz_ptr), fp, _c(xs), C.byref(params), C.byref(n),
+                                                    ids.ctypes.data_as(C.c_void_p) if want_ids else None, cap))
         return ids[: n.value].copy() if want_ids else n.value
 
     def read_clusters(self, head=0, end=None):
