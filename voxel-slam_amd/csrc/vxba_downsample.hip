@@ -9,6 +9,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_run_length_encode.hpp>
@@ -90,20 +91,41 @@ extern "C" int vxba_down_sampling_voxel(int device, int64_t n, const float* xyz,
   unsigned int runs = 0;
   int err = 0;
   const unsigned grid = (unsigned)((n + 255) / 256), grid1 = (unsigned)((n + 256) / 256);
+  // one grow-only scratch per device for this stand-alone entry point (it runs once per scan: a dozen hipMalloc / hipFree pairs per
+  // call cost more than the sort); calls are serialised on it
+  static std::mutex mtx;
+  static char* scratch[16] = {nullptr};
+  static size_t scratch_cap[16] = {0};
+  std::lock_guard<std::mutex> lock(mtx);
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
 #define DS(call) do { if ((call) != hipSuccess) { rc = VXBA_ERR_HIP; goto done; } } while (0)
-  DS(hipMalloc((void**)&d_xyz, (size_t)n * 3 * sizeof(float)));
-  DS(hipMalloc((void**)&d_out, (size_t)n * 3 * sizeof(float)));
-  DS(hipMalloc((void**)&d_key, (size_t)n * 8)); DS(hipMalloc((void**)&d_key_s, (size_t)n * 8)); DS(hipMalloc((void**)&d_ukey, (size_t)n * 8));
-  DS(hipMalloc((void**)&d_idx, (size_t)n * 4)); DS(hipMalloc((void**)&d_idx_s, (size_t)n * 4)); DS(hipMalloc((void**)&d_cnt, (size_t)n * 4));
-  DS(hipMalloc((void**)&d_runs, 4)); DS(hipMalloc((void**)&d_ptr, (size_t)(n + 1) * 8)); DS(hipMalloc((void**)&d_err, 4));
-  DS(hipMemset(d_err, 0, 4));
   DS(rocprim::radix_sort_pairs(nullptr, t_sort, d_key, d_key_s, d_idx, d_idx_s, (size_t)n, 0, 63, s));
   DS(rocprim::run_length_encode(nullptr, t_rle, d_key_s, (size_t)n, d_ukey, d_cnt, d_runs, s));
   DS(rocprim::exclusive_scan(nullptr, t_scan, d_ptr, d_ptr, 0ll, (size_t)n + 1, rocprim::plus<long long>(), s));
   {
+    size_t tmax = t_sort > t_rle ? t_sort : t_rle;
+    if (t_scan > tmax) tmax = t_scan;
+    const size_t b_f = up((size_t)n * 3 * sizeof(float)), b_k = up((size_t)n * 8), b_i = up((size_t)n * 4), b_p = up((size_t)(n + 1) * 8), b_t = up(tmax ? tmax : 8);
+    const size_t need = 2 * b_f + 3 * b_k + 3 * b_i + 256 + b_p + 256 + b_t;
+    const int dv = device < 16 ? device : 15;
+    if (need > scratch_cap[dv] || device >= 16) {
+      if (scratch[dv]) { hipDeviceSynchronize(); hipFree(scratch[dv]); }
+      scratch[dv] = nullptr; scratch_cap[dv] = 0;
+      DS(hipMalloc((void**)&scratch[dv], need + need / 4));
+      scratch_cap[dv] = need + need / 4;
+    }
+    char* q = scratch[dv];
+    auto carve = [&](size_t bytes) { char* r = q; q += bytes; return r; };
+    d_xyz = (float*)carve(b_f); d_out = (float*)carve(b_f);
+    d_key = (unsigned long long*)carve(b_k); d_key_s = (unsigned long long*)carve(b_k); d_ukey = (unsigned long long*)carve(b_k);
+    d_idx = (unsigned int*)carve(b_i); d_idx_s = (unsigned int*)carve(b_i); d_cnt = (unsigned int*)carve(b_i);
+    d_runs = (unsigned int*)carve(256); d_ptr = (long long*)carve(b_p); d_err = (int*)carve(256); d_temp = carve(b_t);
+  }
+  DS(hipMemset(d_err, 0, 4));
+  {
     size_t t = t_sort > t_rle ? t_sort : t_rle;
     if (t_scan > t) t = t_scan;
-    DS(hipMalloc(&d_temp, t ? t : 8));
+    if (!t) t = 8;
     DS(hipMemcpy(d_xyz, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
     vxd::ds_key_kernel<<<grid, 256, 0, s>>>(d_xyz, n, voxel_size, d_key, d_idx, d_err);
     DS(hipGetLastError());
@@ -125,7 +147,5 @@ extern "C" int vxba_down_sampling_voxel(int device, int64_t n, const float* xyz,
   }
 done:
 #undef DS
-  hipFree(d_xyz); hipFree(d_out); hipFree(d_key); hipFree(d_key_s); hipFree(d_ukey); hipFree(d_idx); hipFree(d_idx_s); hipFree(d_cnt);
-  hipFree(d_runs); hipFree(d_ptr); hipFree(d_err); hipFree(d_temp);
   return rc;
 }
