@@ -14,6 +14,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -169,14 +170,41 @@ void fill(double* d, long long n, double v, hipStream_t s) {
   if (n > 0) fill_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(d, n, v);
 }
 
-// One device allocation for all temporaries of a call (hipMalloc/hipFree cost ~0.1-1 ms each; there are ~30 arrays).
+// One device allocation for all temporaries of a call (hipMalloc/hipFree cost ~0.1-1 ms each; there are ~30 arrays), kept per
+// device between calls and only ever grown (a window is re-voxelised every BA round); calls on one device take turns on it.
+struct ArenaSlot {
+  std::mutex mtx;
+  char* base = nullptr;
+  size_t cap = 0;
+};
+static ArenaSlot g_arena[16];
 struct DevBuf {
   char* base = nullptr;
   size_t cap = 0, used = 0;
-  ~DevBuf() { if (base) hipFree(base); }
+  ArenaSlot* slot = nullptr;
+  bool own = false;
+  ~DevBuf() {
+    if (own && base) hipFree(base);
+    if (slot) slot->mtx.unlock();
+  }
   hipError_t reserve(size_t bytes) {
-    cap = bytes;
-    return hipMalloc((void**)&base, bytes);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || bytes > ((size_t)2 << 30)) {   // no cache slot / too big to keep: private to this call
+      own = true; cap = bytes;
+      return hipMalloc((void**)&base, bytes);
+    }
+    slot = &g_arena[dev];
+    slot->mtx.lock();
+    if (bytes > slot->cap) {
+      if (slot->base) { hipDeviceSynchronize(); hipFree(slot->base); }
+      slot->base = nullptr; slot->cap = 0;
+      const size_t want = bytes + bytes / 4;
+      hipError_t e = hipMalloc((void**)&slot->base, want);
+      if (e != hipSuccess) return e;
+      slot->cap = want;
+    }
+    base = slot->base; cap = slot->cap;
+    return hipSuccess;
   }
   template <class T>
   hipError_t alloc(T** p, size_t n) {
