@@ -19,6 +19,7 @@
 #include "vxba_voxelize.h"
 #include "vxba_wide.h"
 #include "vxba_li_device.h"
+#include "vxba_scratch.hpp"
 #include "vxba_kernels.h"
 
 using vxk::FactorView;
@@ -819,12 +820,14 @@ int vxba_plane_fit_judge(int device, int64_t n, const double* clusters, int min_
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VXBA_ERR_NODEV;
   if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_HIP;
-  double *d_c = nullptr, *d_l = nullptr, *d_u = nullptr;
-  unsigned char* d_f = nullptr;
-  hipError_t e = hipMalloc((void**)&d_c, (size_t)n * 10 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_l, (size_t)n * 3 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_u, (size_t)n * 9 * sizeof(double));
-  if (e == hipSuccess && flags) e = hipMalloc((void**)&d_f, (size_t)n);
+  using vxs::Lease;
+  Lease lease(device, Lease::padded((size_t)n * 10 * 8) + Lease::padded((size_t)n * 3 * 8) + Lease::padded((size_t)n * 9 * 8) + Lease::padded((size_t)n));
+  if (!lease.ok()) return VXBA_ERR_HIP;
+  double* d_c = lease.take<double>((size_t)n * 10 * 8);
+  double* d_l = lease.take<double>((size_t)n * 3 * 8);
+  double* d_u = lease.take<double>((size_t)n * 9 * 8);
+  unsigned char* d_f = flags ? lease.take<unsigned char>((size_t)n) : nullptr;
+  hipError_t e = hipSuccess;
   if (e == hipSuccess) e = hipMemcpy(d_c, clusters, (size_t)n * 10 * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     vxk::PlaneCriteria pc{min_point, min_eigen_value, eigen_ratio_thre, factor_ratio_max};
@@ -834,7 +837,6 @@ int vxba_plane_fit_judge(int device, int64_t n, const double* clusters, int min_
   if (e == hipSuccess) e = hipMemcpy(eig_val, d_l, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(eig_vec, d_u, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost);
   if (e == hipSuccess && flags) e = hipMemcpy(flags, d_f, (size_t)n, hipMemcpyDeviceToHost);
-  hipFree(d_c); hipFree(d_l); hipFree(d_u); hipFree(d_f);
   return e == hipSuccess ? VXBA_OK : VXBA_ERR_HIP;
 }
 
@@ -849,11 +851,13 @@ int vxba_build_clusters(int device, int64_t n_cells, int64_t n_points, const dou
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VXBA_ERR_NODEV;
   if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_HIP;
-  double *d_xyz = nullptr, *d_cl = nullptr;
-  int64_t* d_ptr = nullptr;
-  hipError_t e = hipMalloc((void**)&d_xyz, std::max<size_t>(1, (size_t)n_points * 3) * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_ptr, (size_t)(n_cells + 1) * sizeof(int64_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_cl, (size_t)n_cells * 10 * sizeof(double));
+  using vxs::Lease;
+  Lease lease(device, Lease::padded((size_t)n_points * 3 * 8) + Lease::padded((size_t)(n_cells + 1) * 8) + Lease::padded((size_t)n_cells * 10 * 8));
+  if (!lease.ok()) return VXBA_ERR_HIP;
+  double* d_xyz = lease.take<double>((size_t)n_points * 3 * 8);
+  int64_t* d_ptr = lease.take<int64_t>((size_t)(n_cells + 1) * 8);
+  double* d_cl = lease.take<double>((size_t)n_cells * 10 * 8);
+  hipError_t e = hipSuccess;
   if (e == hipSuccess && n_points) e = hipMemcpy(d_xyz, xyz, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_ptr, cell_ptr, (size_t)(n_cells + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
@@ -861,7 +865,6 @@ int vxba_build_clusters(int device, int64_t n_cells, int64_t n_points, const dou
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(clusters, d_cl, (size_t)n_cells * 10 * sizeof(double), hipMemcpyDeviceToHost);
-  hipFree(d_xyz); hipFree(d_ptr); hipFree(d_cl);
   return e == hipSuccess ? VXBA_OK : VXBA_ERR_HIP;
 }
 

@@ -33,6 +33,7 @@
 #include "../../include/vxba.h"
 #include "vxba_imu.hpp"
 #include "vxba_math.hpp"
+#include "vxba_scratch.hpp"
 
 namespace vxl {
 
@@ -961,12 +962,14 @@ int vxba_cov_add_build(int device, int64_t n_cells, int64_t n_points, const doub
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VXBA_ERR_NODEV;
   if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_HIP;
-  double *d_xyz = nullptr, *d_var = nullptr, *d_out = nullptr;
-  long long* d_ptr = nullptr;
-  hipError_t e = hipMalloc((void**)&d_xyz, std::max<size_t>(1, (size_t)n_points * 3) * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_var, std::max<size_t>(1, (size_t)n_points * 9) * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_ptr, (size_t)(n_cells + 1) * sizeof(long long));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_out, (size_t)n_cells * 81 * sizeof(double));
+  using vxs::Lease;
+  Lease lease(device, Lease::padded((size_t)n_points * 3 * 8) + Lease::padded((size_t)n_points * 9 * 8) + Lease::padded((size_t)(n_cells + 1) * 8) + Lease::padded((size_t)n_cells * 81 * 8));
+  if (!lease.ok()) return VXBA_ERR_HIP;
+  double* d_xyz = lease.take<double>((size_t)n_points * 3 * 8);
+  double* d_var = lease.take<double>((size_t)n_points * 9 * 8);
+  long long* d_ptr = lease.take<long long>((size_t)(n_cells + 1) * 8);
+  double* d_out = lease.take<double>((size_t)n_cells * 81 * 8);
+  hipError_t e = hipSuccess;
   if (e == hipSuccess && n_points) e = hipMemcpy(d_xyz, xyz_world, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess && n_points) e = hipMemcpy(d_var, var, (size_t)n_points * 9 * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_ptr, cell_ptr, (size_t)(n_cells + 1) * sizeof(long long), hipMemcpyHostToDevice);
@@ -975,7 +978,6 @@ int vxba_cov_add_build(int device, int64_t n_cells, int64_t n_points, const doub
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(cov_add, d_out, (size_t)n_cells * 81 * sizeof(double), hipMemcpyDeviceToHost);
-  hipFree(d_xyz); hipFree(d_var); hipFree(d_ptr); hipFree(d_out);
   return e == hipSuccess ? VXBA_OK : VXBA_ERR_HIP;
 }
 
@@ -988,9 +990,12 @@ int vxba_plane_update(int device, int64_t n, const double* clusters, const doubl
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VXBA_ERR_NODEV;
   if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_HIP;
   const size_t in_len = (size_t)n * (10 + 3 + 9 + 81), out_len = (size_t)n * (3 + 3 + 36 + 1);
-  double *d_in = nullptr, *d_out = nullptr;
-  hipError_t e = hipMalloc((void**)&d_in, in_len * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_out, out_len * sizeof(double));
+  using vxs::Lease;
+  Lease lease(device, Lease::padded(in_len * 8) + Lease::padded(out_len * 8));
+  if (!lease.ok()) return VXBA_ERR_HIP;
+  double* d_in = lease.take<double>(in_len * 8);
+  double* d_out = lease.take<double>(out_len * 8);
+  hipError_t e = hipSuccess;
   double *d_cl = d_in, *d_ev = d_cl + 10 * n, *d_U = d_ev + 3 * n, *d_ca = d_U + 9 * n;
   double *d_c = d_out, *d_n = d_c + 3 * n, *d_pv = d_n + 3 * n, *d_r = d_pv + 36 * n;
   if (e == hipSuccess) e = hipMemcpy(d_cl, clusters, (size_t)n * 10 * sizeof(double), hipMemcpyHostToDevice);
@@ -1005,7 +1010,6 @@ int vxba_plane_update(int device, int64_t n, const double* clusters, const doubl
   if (e == hipSuccess) e = hipMemcpy(normal, d_n, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(plane_var, d_pv, (size_t)n * 36 * sizeof(double), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(radius, d_r, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
-  hipFree(d_in); hipFree(d_out);
   return e == hipSuccess ? VXBA_OK : VXBA_ERR_HIP;
 }
 
