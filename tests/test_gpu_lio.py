@@ -115,8 +115,12 @@ def test_var_init_and_pvec_update(vx):
     assert np.allclose(wg, wo, rtol=1e-14, atol=1e-14) and np.allclose(wvg, wvo, rtol=1e-11, atol=1e-18)
 
 
+@pytest.mark.parametrize("device_ekf", ["1", "0"])
 @pytest.mark.parametrize("seed,n_roots,n_points,raw", [(2400, 3000, 40000, True), (2410, 800, 6000, False), (2420, 6000, 100000, True)])
-def test_state_estimation_matches_oracle(vx, seed, n_roots, n_points, raw):
+def test_state_estimation_matches_oracle(vx, seed, n_roots, n_points, raw, device_ekf, monkeypatch):
+    """device_ekf: the 15-dimensional EKF algebra between the sweeps as a kernel, all iterations enqueued up front (default), or on the
+    host with a round trip per iteration (VXBA_LIO_DEVICE_EKF=0)."""
+    monkeypatch.setenv("VXBA_LIO_DEVICE_EKF", device_ekf)
     pm = synth.make_plane_map(n_roots=n_roots, extent=10, seed=seed)
     sc = synth.make_lio_scan(pm, n_points=n_points, seed=seed + 1)
     o, g = both(vx, pm, sc, raw=raw)

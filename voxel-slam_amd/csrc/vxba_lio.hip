@@ -34,6 +34,7 @@
 #include "vxba_imu.hpp"
 #include "vxba_math.hpp"
 #include "vxba_scratch.hpp"
+#include "vxba_solve.hpp"
 
 namespace vxl {
 
@@ -60,6 +61,16 @@ struct SweepArg {
   double p[3];
   double rot_var[9];  // cov.block<3,3>(0,0), column-major
   double tsl_var[9];  // cov.block<3,3>(3,3)
+};
+
+// State of one lio_state_estimation call when the EKF algebra runs on the device too (all iterations enqueued up front).
+struct LioCtl {
+  double state[24], x_prop[24];   // x_curr (in/out) and the propagated state the call started from
+  double cov[225], cov_inv[225];  // x_curr.cov (in/out), its inverse at entry
+  double G[90];                   // G.block<15,6>(0,0) of the last iteration
+  double sweeps[4 * SWEEP_OUT];
+  double info[4];                 // ok, iterations, match_num, smallest eigenvalue of nnt
+  int rematch_num, iter, done, pad;
 };
 
 __host__ __device__ inline unsigned long long mix64(unsigned long long x) {
@@ -170,8 +181,20 @@ __device__ __forceinline__ double wave_reduce_scatter(const double (&v)[N], int 
 // One pass of voxelslam.cpp:873-919.  pts: SoA planes [pnt 3 | var upper triangle 6] of stride `n_stride`.
 __global__ __launch_bounds__(BLOCK) void lio_sweep_kernel(MapView m, SweepArg a, const double* __restrict__ pts, long long n, long long n_stride, int* __restrict__ cache,
                                                           int use_cache, double* __restrict__ partials,
-                                                          int* __restrict__ plane_of_point, double* __restrict__ sigma_of_point) {
+                                                          int* __restrict__ plane_of_point, double* __restrict__ sigma_of_point, const LioCtl* __restrict__ ctl) {
   __shared__ double red[BLOCK / 64][NSUM];
+  if (ctl) {   // device-resident estimation: pose and covariance blocks come from the control block, the loop may already be over
+    if (ctl->done) return;
+#pragma unroll
+    for (int k = 0; k < 9; k++) a.R[k] = ctl->state[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) a.p[k] = ctl->state[9 + k];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int r = 0; r < 3; r++) { a.rot_var[3 * c + r] = ctl->cov[15 * c + r]; a.tsl_var[3 * c + r] = ctl->cov[15 * (3 + c) + 3 + r]; }
+    use_cache = ctl->iter > 0;
+  }
   double s[NSUM];
 #pragma unroll
   for (int k = 0; k < NSUM; k++) s[k] = 0.0;
@@ -233,6 +256,126 @@ __global__ __launch_bounds__(BLOCK) void lio_sweep_kernel(MapView m, SweepArg a,
 #pragma unroll
     for (int q = 1; q < BLOCK / 64; q++) t += red[q][threadIdx.x];
     partials[(size_t)vb * NSUM + threadIdx.x] = t;   // host-mapped: 272 contiguous bytes per workgroup, summed by the caller
+  }
+}
+
+// The iterated-EKF update between two sweeps (voxelslam.cpp:921-947), one workgroup: sum of the sweep's per-workgroup partials, K_1 =
+// (H^T H + cov^-1)^-1 by Gauss-Jordan in LDS (symmetric positive definite: no pivoting), G, the step, x_curr (+)= step, the
+// convergence / rematch schedule, and on the last iteration cov = (I - G) cov and the degeneracy test on nnt.
+__global__ __launch_bounds__(256) void lio_ekf_kernel(LioCtl* __restrict__ ctl, const double* __restrict__ partials, int grid) {
+  constexpr int D = 15, CH = 7, PER = 37;   // 7 chains x 37 partials >= MAX_GRID
+  __shared__ double fin[CH][NSUM], tot[NSUM], S[D * D], HTH[36], HTz[6], vec[D], sol[D], Gs[D * 6];
+  __shared__ int finish;
+  if (ctl->done) return;
+  const int tid = threadIdx.x;
+  if (tid < CH * NSUM) {
+    const int col = tid % NSUM, ch = tid / NSUM;
+    double v[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const int b = ch + q * CH;
+      v[q] = b < grid ? partials[(size_t)b * NSUM + col] : 0.0;
+    }
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < PER; q++) t += v[q];
+    fin[ch][col] = t;
+  }
+  __syncthreads();
+  if (tid < NSUM) {
+    double t = fin[0][tid];
+#pragma unroll
+    for (int q = 1; q < CH; q++) t += fin[q][tid];
+    tot[tid] = t;
+  }
+  __syncthreads();
+  const int it = ctl->iter;
+  if (tid < SWEEP_OUT) {   // the sweep record, as the host path assembles it
+    int src;
+    if (tid < 36) { const int r = tid % 6, c = tid / 6, lo = r < c ? r : c, hi = r < c ? c : r; src = lo * 6 - lo * (lo - 1) / 2 + (hi - lo); }
+    else if (tid < 42) src = 21 + (tid - 36);
+    else if (tid < 51) { const int r = (tid - 42) % 3, c = (tid - 42) / 3, lo = r < c ? r : c, hi = r < c ? c : r; src = 27 + lo * 3 - lo * (lo - 1) / 2 + (hi - lo); }
+    else src = 33;
+    const double v = tot[src];
+    ctl->sweeps[SWEEP_OUT * it + tid] = v;
+    if (tid < 36) HTH[tid] = v;
+    else if (tid < 42) HTz[tid - 36] = v;
+  }
+  if (tid < D * D) S[tid] = ctl->cov_inv[tid];
+  if (tid == 255) {   // vec = x_prop - x_curr (IMUST::operator-, tools.hpp:164-173), on a lane the inversion does not use
+    double dR[9], w[3];
+    vxi::m3_tmul(ctl->state, ctl->x_prop, dR);
+    vxi::so3_log(dR, w);
+    for (int k = 0; k < 3; k++) vec[k] = w[k];
+    for (int k = 0; k < 12; k++) vec[3 + k] = ctl->x_prop[9 + k] - ctl->state[9 + k];
+  }
+  __syncthreads();
+  if (tid < 36) S[D * (tid / 6) + tid % 6] += HTH[tid];
+  __syncthreads();
+  // Gauss-Jordan inverse of S (15x15) in place, one entry per thread (a one-wave version with four entries per lane and wave
+  // barriers was slower: 14.7 instead of 10.4 us for the kernel)
+  for (int p = 0; p < D; p++) {
+    double nv = 0.0;
+    const double ip = vxk::fast_rcp_f64(S[p * D + p]);
+    if (tid < D * D) {
+      const int r = tid % D, c = tid / D;
+      if (r == p && c == p) nv = ip;
+      else if (r == p) nv = S[c * D + p] * ip;
+      else if (c == p) nv = -S[p * D + r] * ip;
+      else nv = S[c * D + r] - S[p * D + r] * S[c * D + p] * ip;
+    }
+    __syncthreads();
+    if (tid < D * D) S[tid] = nv;
+    __syncthreads();
+  }
+  if (tid < D * 6) {   // G.block<15,6>(0,0) = K_1.block<15,6>(0,0) * HTH   (K_1 = S now)
+    const int r = tid % D, c = tid / D;
+    double g = 0.0;
+    for (int k = 0; k < 6; k++) g += S[D * k + r] * HTH[6 * c + k];
+    Gs[tid] = g;
+    ctl->G[tid] = g;
+  }
+  __syncthreads();
+  if (tid < D) {
+    double t = 0.0;
+    for (int k = 0; k < 6; k++) t += S[D * k + tid] * HTz[k];
+    t += vec[tid];
+    for (int k = 0; k < 6; k++) t -= Gs[D * k + tid] * vec[k];
+    sol[tid] = t;
+  }
+  __syncthreads();
+  if (tid == 0) {   // x_curr += solution; convergence / rematch schedule (voxelslam.cpp:930-946)
+    double E[9], Rn[9];
+    vxi::so3_exp(sol, E);
+    vxi::m3_mul(ctl->state, E, Rn);
+    for (int k = 0; k < 9; k++) ctl->state[k] = Rn[k];
+    for (int k = 0; k < 12; k++) ctl->state[9 + k] += sol[3 + k];
+    const double rot_add = sqrt(sol[0] * sol[0] + sol[1] * sol[1] + sol[2] * sol[2]);
+    const double tra_add = sqrt(sol[3] * sol[3] + sol[4] * sol[4] + sol[5] * sol[5]);
+    const bool converged = (rot_add * 57.3 < 0.01) && (tra_add * 100 < 0.015);
+    int rematch = ctl->rematch_num;
+    if (converged || ((rematch == 0) && (it == 4 - 2))) rematch++;
+    ctl->rematch_num = rematch;
+    ctl->iter = it + 1;
+    finish = (rematch >= 2 || it == 4 - 1) ? 1 : 0;
+    if (finish) {
+      const double C6[6] = {tot[27], tot[28], tot[29], tot[30], tot[31], tot[32]};
+      double lam[3], U[9];
+      vxm::eig_sym3(C6, lam, U);
+      ctl->info[0] = lam[0] < 14 ? 0.0 : 1.0; ctl->info[1] = it + 1; ctl->info[2] = tot[33]; ctl->info[3] = lam[0];
+      ctl->done = 1;
+    }
+  }
+  __syncthreads();
+  if (finish) {   // cov = (I - G) cov, G zero beyond its first six columns
+    double g = 0.0;
+    if (tid < D * D) {
+      const int r = tid % D, c = tid / D;
+      g = ctl->cov[D * c + r];
+      for (int k = 0; k < 6; k++) g -= Gs[D * k + r] * ctl->cov[D * c + k];
+    }
+    __syncthreads();
+    if (tid < D * D) ctl->cov[tid] = g;
   }
 }
 
@@ -523,6 +666,8 @@ struct vxba_lio {
   double* h_partials = nullptr;  // pinned, mapped: one 34-number partial per workgroup lands here (zero-copy stores)
   double* d_partials = nullptr;  // device alias of h_partials
   double h_out[vxl::SWEEP_OUT];  // the sweep's 52 numbers, assembled on the host
+  vxl::LioCtl* d_ctl = nullptr;  // device-resident estimation: control block + per-workgroup partials in device memory
+  double* d_partials_dev = nullptr;
   std::string err;
   std::recursive_mutex mtx;
 };
@@ -647,7 +792,7 @@ int lio_sweep(vxba_lio* h, const double* state, const double* cov225, bool reset
   const bool use_cache = h->cache_valid && !reset_cache;
   const unsigned grid = std::min<unsigned>((grid_for(h->n_pts, vxl::BLOCK) + 7) / 8 * 8, vxl::MAX_GRID);   // a multiple of 8: one contiguous share of the scan per XCD
   vxl::lio_sweep_kernel<<<grid, vxl::BLOCK, 0, h->stream>>>(map_view(h), sweep_arg(state, cov225), h->d_pts, h->n_pts, h->pts_stride, h->d_cache, use_cache ? 1 : 0, h->d_partials,
-                                                            d_plane_of_point, d_sigma_of_point);
+                                                            d_plane_of_point, d_sigma_of_point, nullptr);
   LIO_HIP(h, hipGetLastError());
   // the kernel is ~10 us: poll for its completion instead of sleeping on it (hipStreamSynchronize's wake-up costs more than the kernel)
   hipError_t q;
@@ -687,6 +832,8 @@ int vxba_lio_create(double voxel_size, int max_layer, int device, vxba_lio** out
   if (e == hipSuccess) e = hipMemset(h->d_counters, 0, 2 * sizeof(int));
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_partials, (size_t)vxl::MAX_GRID * vxl::NSUM * sizeof(double), hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_partials, h->h_partials, 0);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_ctl, sizeof(vxl::LioCtl));
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_partials_dev, (size_t)vxl::MAX_GRID * vxl::NSUM * sizeof(double));
   if (e != hipSuccess) { vxba_lio_destroy(h); return VXBA_ERR_HIP; }
   *out = h;
   return VXBA_OK;
@@ -697,7 +844,7 @@ int vxba_lio_destroy(vxba_lio* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   hipFree(h->d_keys); hipFree(h->d_cells); hipFree(h->d_planes); hipFree(h->d_plane_tag); hipFree(h->d_counters);
-  hipFree(h->d_pts); hipFree(h->d_cache); hipFree(h->d_stage);
+  hipFree(h->d_pts); hipFree(h->d_cache); hipFree(h->d_stage); hipFree(h->d_ctl); hipFree(h->d_partials_dev);
   if (h->h_partials) hipHostFree(h->h_partials);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -893,6 +1040,34 @@ int vxba_lio_state_estimation(vxba_lio* h, double* state, double* cov, double* i
   double cov_inv[D * D], lu[D * D], S[D * D], K1[D * D], G[D * 6];
   int perm[D];
   if (!vxi::dm_inverse(D, cov, cov_inv, lu, perm)) return lio_fail(h, VXBA_ERR_ARG, "vxba_lio_state_estimation: singular state covariance");
+  {   // the whole call on the device: sweeps and EKF updates enqueued back to back, one copy each way (VXBA_LIO_DEVICE_EKF=0: host algebra)
+    const char* e = getenv("VXBA_LIO_DEVICE_EKF");
+    if (!(e && e[0] == '0') && h->n_pts > 0) {
+      if (h->cap == 0) { int rc = lio_map_reserve(h, 0); if (rc != VXBA_OK) return rc; }
+      static thread_local vxl::LioCtl hc;
+      std::memset(&hc, 0, sizeof hc);
+      std::memcpy(hc.state, state, sizeof hc.state); std::memcpy(hc.x_prop, state, sizeof hc.x_prop);
+      std::memcpy(hc.cov, cov, sizeof hc.cov); std::memcpy(hc.cov_inv, cov_inv, sizeof hc.cov_inv);
+      LIO_HIP(h, hipMemcpyAsync(h->d_ctl, &hc, sizeof hc, hipMemcpyHostToDevice, h->stream));
+      const unsigned grid = std::min<unsigned>((grid_for(h->n_pts, vxl::BLOCK) + 7) / 8 * 8, vxl::MAX_GRID);
+      vxl::SweepArg none;
+      std::memset(&none, 0, sizeof none);
+      for (int it = 0; it < VXBA_LIO_MAX_ITER; it++) {
+        vxl::lio_sweep_kernel<<<grid, vxl::BLOCK, 0, h->stream>>>(map_view(h), none, h->d_pts, h->n_pts, h->pts_stride, h->d_cache, 0, h->d_partials_dev, nullptr, nullptr, h->d_ctl);
+        vxl::lio_ekf_kernel<<<1, 256, 0, h->stream>>>(h->d_ctl, h->d_partials_dev, (int)grid);
+      }
+      LIO_HIP(h, hipGetLastError());
+      LIO_HIP(h, hipMemcpyAsync(&hc, h->d_ctl, sizeof hc, hipMemcpyDeviceToHost, h->stream));
+      hipError_t q;
+      while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) {}
+      LIO_HIP(h, q);
+      h->cache_valid = true;
+      std::memcpy(state, hc.state, sizeof hc.state); std::memcpy(cov, hc.cov, sizeof hc.cov);
+      if (info) std::memcpy(info, hc.info, sizeof hc.info);
+      if (sweeps_out) std::memcpy(sweeps_out, hc.sweeps, sizeof(double) * vxl::SWEEP_OUT * (int)hc.info[1]);
+      return VXBA_OK;
+    }
+  }
   const int num_max_iter = 4;
   int rematch_num = 0, iterations = 0;
   const double* o = h->h_out;
