@@ -103,9 +103,12 @@ class Oracle:
         self._h = lib().vxo_create(self.win_size)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().vxo_destroy(self._h)
-            self._h = None
+        try:                                   # at interpreter shutdown the module globals may already be gone
+            if getattr(self, "_h", None):
+                lib().vxo_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     def clear(self):
         lib().vxo_clear(self._h)
