@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--steps-per-solve", type=int, default=3)
+    ap.add_argument("--prewarm-seconds", type=float, default=0.35, help="untimed run of the loop before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-li-ba", action="store_true", help="skip the secondary LiDAR-inertial BA figure")
@@ -145,6 +146,12 @@ def main():
         torch.cuda.synchronize()
 
     sps = args.steps_per_solve
+    # Clock ramp: the timed loop is ~20 ms and would otherwise be the first sustained GPU work of the process -- on some boxes it then
+    # runs at half speed (same binary 7.6k vs 14k it/s; everything measured later in the same process was at full speed).  A third of a
+    # second of the same loop first, untimed, then the W warm-up steps the contract asks for.
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_seconds:
+        f.lm_steps(sc.poses_init, 300, sps)
     if args.warmup > 0:
         f.lm_steps(sc.poses_init, args.warmup, sps)
     f.kernel_times(reset=True)
