@@ -20,9 +20,9 @@ def check(cond, msg):
 
 t0 = time.time()
 for case in range(n_cases):
-    kind = ["lm", "lm", "wide", "li", "li_dev", "lio", "vox", "vox_octo", "ds"][case % 9]
+    kind = ["lm", "mixed", "wide", "li", "li_dev", "gravity", "lio", "vox", "vox_octo", "ds", "planes"][case % 11]
     s = int(rng.integers(1, 1 << 30))
-    if kind in ("lm", "wide", "li", "li_dev"):
+    if kind in ("lm", "mixed", "wide", "li", "li_dev", "gravity"):
         W = int(rng.integers(11, 40)) if kind == "wide" else int(rng.integers(2, 11))
         V = int(rng.integers(150, 3000)); pts = int(V * rng.uniform(8, 20))   # >= 8 points per (voxel, frame): fewer make rank-deficient voxels no map would hand over
         p_obs = float(rng.choice([1.0, 0.8, 0.4])) if kind != "wide" else float(rng.uniform(0.1, 0.4))
@@ -31,7 +31,16 @@ for case in range(n_cases):
         fo = O.Oracle(W); fo.push_voxels(sc.clusters, sc.fix, sc.coe); fo.evaluate_only_residual(sc.poses_init)
         fg = vxba.LidarFactor(W); fg.push_voxels(sc.clusters, sc.fix, sc.coe); fg.evaluate_only_residual(sc.poses_init)
         iters = int(rng.integers(2, 8))
-        if kind in ("lm", "wide"):
+        if kind == "mixed":
+            # f32 products on the matrix cores, f64 accumulation: same schedule, poses within 1e-5 of the fp64 oracle (contract 1e-4)
+            fg.set_precision("mixed")
+            ref = fo.damping_iter(sc.poses_init, max_iter=iters, thd_num=3)
+            got = vxba.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=iters)
+            et, er = synth.pose_errors(got["poses"], ref["poses"])
+            check(got["trace"].shape == ref["trace"].shape and np.array_equal(got["trace"][:, 6], ref["trace"][:, 6]), "mixed trace W=%d V=%d seed=%d" % (W, V, s))
+            check(et < 1e-5 and er < 1e-5, "mixed poses %.2e %.2e W=%d V=%d seed=%d" % (et, er, W, V, s))
+            desc = "W=%d V=%d iters=%d acc=%s pose diff %.1e/%.1e" % (W, V, iters, got["trace"][:, 6].astype(int), et, er)
+        elif kind in ("lm", "wide"):
             ref = fo.damping_iter(sc.poses_init, max_iter=iters, thd_num=3)
             got = vxba.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=iters)
             et, er = synth.pose_errors(got["poses"], ref["poses"])
@@ -66,8 +75,14 @@ for case in range(n_cases):
                     fac.add_imu(g, a, dt, iw.noise_meas, iw.noise_walk)
                 facs.append(fac)
             iters = min(iters, 5)
-            ref = O.li_damping_iter(fo, iw.states_init, blobs, max_iter=iters, thd_num=5, imu_coef=1e-4)
-            got = vxba.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(iw.states_init, fg, facs, max_iter=iters)
+            if kind == "gravity":
+                st0 = iw.states_init.copy(); st0[:, 21:24] += rng.normal(0, 0.05, 3)
+                ref = O.li_damping_iter_gravity(fo, st0, blobs, max_iter=iters, thd_num=5, imu_coef=1e-4)
+                got = vxba.LI_BA_OptimizerGravity(imu_coef=1e-4).damping_iter(st0, fg, facs, max_iter=iters)
+                check(np.allclose(got["states"][:, 21:24], ref["states"][:, 21:24], atol=1e-6), "gravity vector W=%d V=%d seed=%d" % (W, V, s))
+            else:
+                ref = O.li_damping_iter(fo, iw.states_init, blobs, max_iter=iters, thd_num=5, imu_coef=1e-4)
+                got = vxba.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(iw.states_init, fg, facs, max_iter=iters)
             et, er = synth.pose_errors(got["states"][:, :12], ref["states"][:, :12])
             check(got["trace"].shape == ref["trace"].shape and np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:]), "%s trace W=%d V=%d seed=%d" % (kind, W, V, s))
             check(et < 1e-7 and er < 1e-7 and np.allclose(got["states"][:, 12:21], ref["states"][:, 12:21], atol=1e-6), "%s states %.2e %.2e W=%d V=%d seed=%d" % (kind, et, er, W, V, s))
@@ -103,6 +118,30 @@ for case in range(n_cases):
             check(np.array_equal(cl[short], ref["clusters"][short]) and np.allclose(cl, ref["clusters"], rtol=1e-12, atol=0), "%s clusters W=%d seed=%d" % (kind, W, s))
         desc = "W=%d pts=%d max_layer=%d vs=%.1f factors=%d" % (W, pts, ml, vs, ids.size)
         f.close()
+    elif kind == "planes":
+        # per-leaf producers of the plane map: clusters, eigen-decomposition, cov_add, plane_update
+        n_leaf = int(rng.integers(50, 3000))
+        counts = rng.integers(8, 80, size=n_leaf)
+        cell_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        nrm = rng.normal(size=(n_leaf, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        a = np.cross(nrm, [0.3, 0.5, 0.8]); a /= np.linalg.norm(a, axis=1, keepdims=True); b = np.cross(nrm, a)
+        cen = rng.uniform(-30, 30, size=(n_leaf, 3))
+        k = np.repeat(np.arange(n_leaf), counts)
+        xyz = cen[k] + rng.uniform(-0.4, 0.4, (k.size, 1)) * a[k] + rng.uniform(-0.4, 0.4, (k.size, 1)) * b[k] + rng.normal(0, 0.01, (k.size, 1)) * nrm[k]
+        M = rng.normal(size=(k.size, 3, 3)) * 0.01; var = M @ np.transpose(M, (0, 2, 1)) + np.eye(3) * 1e-5
+        cl_g = vxba.build_clusters(xyz, cell_ptr); cl_o = O.build_clusters(xyz, cell_ptr)
+        ev_g, U_g = vxba.plane_fit(cl_g); ev_o, U_o = O.plane_fit(cl_o)
+        ca_g = vxba.cov_add_build(xyz, var, cell_ptr); ca_o = O.cov_add_build(xyz, var, cell_ptr)
+        pl_g = vxba.plane_update(cl_g, ev_g, U_g, ca_g); pl_o = O.plane_update(cl_o, ev_o, U_o, ca_o)
+        sgn = np.sign(np.sum(pl_g["normal"] * pl_o["normal"], axis=1))
+        S = np.ones((n_leaf, 6)); S[:, :3] = sgn[:, None]
+        scale_pv = np.abs(pl_o["plane_var"]).max(axis=(1, 2), keepdims=True)
+        check(np.array_equal(cl_g, cl_o), "planes clusters n=%d" % n_leaf)
+        ca_scale = np.abs(ca_o).max(axis=(1, 2), keepdims=True)
+        ca_err = float((np.abs(ca_g - ca_o) / ca_scale).max())
+        check(ca_err < 1e-11, "planes cov_add n=%d rel %.2e" % (n_leaf, ca_err))          # per-cell scale: single entries cancel
+        check(np.all(np.abs(pl_g["plane_var"] * S[:, :, None] * S[:, None, :] - pl_o["plane_var"]) <= 1e-6 * scale_pv) and np.array_equal(pl_g["radius"], pl_o["radius"]), "planes plane_update n=%d seed=%d" % (n_leaf, s))
+        desc = "leaves=%d points=%d cov_add rel %.1e" % (n_leaf, k.size, ca_err)
     else:
         n = int(rng.integers(1, 300000)); size = float(rng.choice([0.05, 0.1, 0.25, 1.0])); scale = float(rng.choice([2.0, 30.0]))
         xyz = (rng.normal(size=(n, 3)) * scale).astype(np.float32)
