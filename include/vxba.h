@@ -311,8 +311,16 @@ int vxba_lio_sweep(vxba_lio* h, const double* state, const double* cov, int rese
 /* lio_state_estimation: state and cov in/out (x_curr).  info[4] = [ok (nnt's smallest eigenvalue >= 14, :951-957), iterations,
  * match_num of the last sweep, that eigenvalue]; sweeps_out VXBA_LIO_MAX_ITER * VXBA_LIO_SWEEP_LEN.  Both may be NULL. */
 int vxba_lio_state_estimation(vxba_lio* h, double* state, double* cov, double* info, double* sweeps_out);
-/* pvec_update (voxelslam.hpp:203-215): world points (n*3) and world covariances (n*9 col-major) of the scan under (state, cov). */
+/* pvec_update (voxelslam.hpp:203-215): world points (n*3) and world covariances (n*9 col-major) of the scan under (state, cov).
+ * Both also stay on the device for vxba_lio_leaf_stats until the scan is replaced; var may be NULL (not downloaded: the host tree
+ * needs the world points to bucket them into leaves, the 72 bytes of covariance per point only feed cov_add). */
 int vxba_lio_pvec_update(vxba_lio* h, const double* state, const double* cov, double* pwld, double* var);
+/* What cut_voxel adds to the leaves this scan touches (OctoTree::push, voxel_map.hpp:969-993: pcr_add.push(pw), cov_add += Bf_var),
+ * from the resident result of the last vxba_lio_pvec_update.  The host tree's bucketing comes in as indices: leaf c owns the scan
+ * points order[cell_ptr[c] .. cell_ptr[c+1]) in push order.  Out: clusters n_cells x 10 (the PointCluster of the new points,
+ * bit-identical to sequential push) and cov_add n_cells x 81 col-major -- increments the caller adds to its nodes.
+ * VXBA_ERR_STATE without a preceding pvec_update of the current scan. */
+int vxba_lio_leaf_stats(vxba_lio* h, int64_t n_cells, const int64_t* cell_ptr, const int32_t* order, double* clusters, double* cov_add);
 
 /* The map-side producers of those plane records (f2's arithmetic; the host tree decides which leaves exist):
  * cov_add of OctoTree::push (voxel_map.hpp:990-992) = sum over a cell's points of Bf_var (:91-106), n_cells x 81 col-major 9x9, from

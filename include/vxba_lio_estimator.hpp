@@ -105,6 +105,27 @@ class LioEstimatorT {
       for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) world_var[i].var(r, c) = var_[9 * i + 3 * c + r];
     }
   }
+  // the same, world points only: the covariances stay on the device for leaf_stats (72 of the 96 bytes per point never cross PCIe)
+  template <class V3>
+  void pvec_update_points(const StateT& x_curr, std::vector<V3>& pwld) {
+    double st[VXBA_STATE_LEN], cov[225];
+    pack(x_curr, st, cov);
+    const size_t n = (size_t)vxba_lio_scan_size(h_);
+    pnt_.resize(3 * n);
+    check(vxba_lio_pvec_update(h_, st, cov, pnt_.data(), nullptr));
+    pwld.resize(n);
+    for (size_t i = 0; i < n; i++) for (int k = 0; k < 3; k++) pwld[i][k] = pnt_[3 * i + k];
+  }
+  // What cut_voxel adds to the leaves the scan touched (OctoTree::push, voxel_map.hpp:969-993): leaf c owns the scan points
+  // order[cell_ptr[c] .. cell_ptr[c+1]) in push order.  clusters[10c..] = P (xx xy xz yy yz zz), v, N of those points -- add to
+  // pcr_add; cov_add[81c..] (col-major 9x9) -- add to the node's cov_add.
+  void leaf_stats(const std::vector<int64_t>& cell_ptr, const std::vector<int32_t>& order, std::vector<double>& clusters, std::vector<double>& cov_add) {
+    if (cell_ptr.empty()) throw std::invalid_argument("leaf_stats: cell_ptr needs n_cells + 1 entries");
+    const size_t n = cell_ptr.size() - 1;
+    if ((int64_t)order.size() != cell_ptr.back()) throw std::invalid_argument("leaf_stats: order must hold cell_ptr.back() indices");
+    clusters.assign(10 * n, 0.0); cov_add.assign(81 * n, 0.0);
+    check(vxba_lio_leaf_stats(h_, (int64_t)n, cell_ptr.data(), order.data(), clusters.data(), cov_add.data()));
+  }
 
   int match_num = 0, iterations = 0;
   double min_eigen = 0.0;

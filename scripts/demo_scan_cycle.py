@@ -34,6 +34,10 @@ nleaf = cell_ptr.shape[0] - 1
 ms, cl = timed(lambda: vxba.build_clusters(pw_s, cell_ptr)); rows.append(("cluster build for %d touched leaves" % nleaf, ms))
 ms, (ev, U, flags) = timed(lambda: vxba.plane_fit_judge(cl, min_point=5, min_eigen_value=0.0025, eigen_ratio_thre=0.05)); rows.append(("plane fit + plane_judge", ms))
 ms, ca = timed(lambda: vxba.cov_add_build(pw_s, vw_s, cell_ptr)); rows.append(("cov_add (sum of Bf_var)", ms))
+# the same three stages with the covariances left on the device: world points only -> the host's bucketing as indices -> per-leaf increments
+ms, pw2 = timed(lambda: est.pvec_update(res["state"], res["cov"], with_var=False)); rows.append(("  resident variant: pvec_update, world points only", ms))
+ms, (cl2, ca2) = timed(lambda: est.leaf_stats(cell_ptr, order)); rows.append(("  resident variant: leaf_stats (clusters + cov_add of the touched leaves)", ms))
+assert np.array_equal(pw2, pw) and np.array_equal(cl2, cl) and np.all(np.abs(ca2 - ca) <= 1e-11 * np.abs(ca).max(axis=(1, 2), keepdims=True))
 good = (flags & 3) == 3
 ms, pl = timed(lambda: vxba.plane_update(cl[good], ev[good], U[good], ca[good])); rows.append(("plane_update (%d planes)" % int(good.sum()), ms))
 loc = cell[order][np.sort(first)][good]

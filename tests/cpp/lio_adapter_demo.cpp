@@ -80,6 +80,16 @@ int main(int argc, char** argv) {
   out.push_back(ok ? 1.0 : 0.0); out.push_back(est.match_num); out.push_back(est.iterations);
   for (int k = 0; k < 3; k++) out.push_back(pwld[0][k]);
   out.push_back(wv[n_pts - 1].var(2, 1));
+  // cut_voxel's increments for two leaves holding scan points {4, 2, 9} and {0 .. 6}, covariances left on the device
+  std::vector<Vec3> pw2;
+  est.pvec_update_points(x, pw2);
+  std::vector<int64_t> cell_ptr = {0, 3, 10};
+  std::vector<int32_t> order = {4, 2, 9, 0, 1, 2, 3, 4, 5, 6};
+  std::vector<double> cl, ca;
+  est.leaf_stats(cell_ptr, order, cl, ca);
+  out.push_back(pw2[0][1] == pwld[0][1] ? 1.0 : 0.0);
+  for (int k = 0; k < 20; k++) out.push_back(cl[k]);
+  out.push_back(ca[0]); out.push_back(ca[81 + 9 * 7 + 2]);
   std::fwrite(out.data(), 8, out.size(), fo);
   std::fclose(fo);
   return 0;

@@ -125,3 +125,8 @@ def test_lio_adapter_end_to_end_matches_oracle(tmp_path):
     assert bool(ok) == ref["ok"] and int(match_num) == ref["match_num"] and int(iters) == ref["iterations"]
     pw, vw = o.pvec_update(ref["state"], ref["cov"])
     assert np.allclose(res[249:252], pw[0], atol=1e-9) and abs(res[252] - vw[-1][2, 1]) < 1e-12 + 1e-6 * abs(vw[-1][2, 1])
+    # leaf_stats through the adapter: two leaves over the resident world points
+    order = np.array([4, 2, 9, 0, 1, 2, 3, 4, 5, 6]); cp = np.array([0, 3, 10], dtype=np.int64)
+    cl = O.build_clusters(np.ascontiguousarray(pw[order]), cp); ca = O.cov_add_build(np.ascontiguousarray(pw[order]), np.ascontiguousarray(vw[order]), cp)
+    assert res[253] == 1.0 and np.allclose(res[254:274], cl.reshape(-1), rtol=1e-9) and res[263] == 3 and res[273] == 7
+    assert abs(res[274] - ca[0, 0, 0]) <= 1e-6 * abs(ca[0, 0, 0]) and abs(res[275] - ca[1, 2, 7]) <= 1e-6 * np.abs(ca[1]).max()

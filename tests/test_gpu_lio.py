@@ -296,3 +296,44 @@ def test_map_random_update_sequences_match_a_rebuilt_oracle_map(vx):
         if ro["match_num"]:
             check_sweep(rg, ro)
     assert g.map_size()[0] <= 3000
+
+
+def test_leaf_stats_from_the_resident_scan_match_the_staged_chain(vx):
+    """cut_voxel's per-leaf increments (PointCluster of the new points, cov_add) computed from the world points / covariances pvec_update
+    left on the device, with only the host tree's bucketing crossing the boundary: identical to pvec_update -> gather -> K1 -> cov_add on
+    the oracle, for a shuffled bucketing with empty leaves and points that belong to no leaf."""
+    pm = synth.make_plane_map(n_roots=1500, extent=8, seed=2700)
+    sc = synth.make_lio_scan(pm, n_points=40000, seed=2701)
+    g = vx.LioEstimator(pm.voxel_size, pm.max_layer); o = O.LioOracle(pm.voxel_size, pm.max_layer)
+    with pytest.raises(vx.VxbaError):
+        g.leaf_stats(np.array([0, 0]), np.zeros(0, dtype=np.int32))                    # no scan, no world points yet
+    g.var_init(sc.xyz); o.var_init(sc.xyz)
+    with pytest.raises(vx.VxbaError):
+        g.leaf_stats(np.array([0, 1]), np.zeros(1, dtype=np.int32))                    # scan loaded but pvec_update not called
+    cov = sc.cov
+    pw_o, var_o = o.pvec_update(sc.state_gt, cov)
+    pw_g = g.pvec_update(sc.state_gt, cov, with_var=False)
+    assert np.allclose(pw_g, pw_o, rtol=1e-14, atol=1e-14)
+    rng = np.random.default_rng(2702)
+    n = pw_g.shape[0]
+    cell = np.floor(pw_g / pm.voxel_size).astype(np.int64)
+    keep = rng.random(n) < 0.9                                                           # a tenth of the points land in no leaf
+    idx = np.nonzero(keep)[0]
+    perm = idx[np.lexsort((rng.random(idx.size), cell[idx, 2], cell[idx, 1], cell[idx, 0]))]   # bucketed by voxel, shuffled inside a bucket
+    _, first = np.unique(cell[perm], axis=0, return_index=True)
+    starts = np.sort(first)
+    cell_ptr = np.concatenate([starts, [perm.size]]).astype(np.int64)
+    cell_ptr = np.insert(cell_ptr, [3, 3, len(cell_ptr) - 1], [cell_ptr[3], cell_ptr[3], cell_ptr[-1]])   # three empty leaves
+    cl_g, ca_g = g.leaf_stats(cell_ptr, perm)
+    cl_o = O.build_clusters(np.ascontiguousarray(pw_g[perm]), cell_ptr)
+    ca_o = O.cov_add_build(np.ascontiguousarray(pw_o[perm]), np.ascontiguousarray(var_o[perm]), cell_ptr)
+    assert np.array_equal(cl_g, cl_o)                                                    # sequential unfused sums: bit-identical
+    scale = np.maximum(np.abs(ca_o).max(axis=(1, 2), keepdims=True), 1e-300)
+    assert np.all(np.abs(ca_g - ca_o) <= 1e-11 * scale)
+    empty = np.diff(cell_ptr) == 0
+    assert empty.sum() == 3 and np.all(cl_g[empty] == 0) and np.all(ca_g[empty] == 0)
+    with pytest.raises(vx.VxbaError):
+        g.leaf_stats(np.array([0, 1]), np.array([n], dtype=np.int32))                  # index outside the scan
+    g.var_init(sc.xyz[:100])                                                             # a new scan invalidates the resident world points
+    with pytest.raises(vx.VxbaError):
+        g.leaf_stats(np.array([0, 1]), np.zeros(1, dtype=np.int32))

@@ -84,6 +84,20 @@ __host__ __device__ inline bool pack_key(long long x, long long y, long long z, 
   return true;
 }
 
+// a*b rounded, then added / subtracted: what the reference's host build (x86-64 without FMA) computes.  The __fmul_rn / __dmul_rn
+// intrinsics are plain operators in this toolchain and get contracted into v_fma after inlining; the pragma clears the contract
+// flag on exactly these two instructions and survives inlining (checked in the ISA).
+__device__ __forceinline__ float mul_sub_unfused(float c, float a, float b) {
+#pragma clang fp contract(off)
+  const float p = a * b;
+  return c - p;
+}
+__device__ __forceinline__ double mul_add_unfused(double acc, double a, double b) {
+#pragma clang fp contract(off)
+  const double p = a * b;
+  return acc + p;
+}
+
 // the float-typed voxel index of match() (voxel_map.hpp:1678-1685): double division, rounded to float, `-= 1` in float below zero,
 // truncated to int64
 __device__ inline long long voxel_index(double w, double voxel_size) {
@@ -100,7 +114,7 @@ __device__ inline bool plane_test(const double* __restrict__ pl, const double w[
   resi = nrm[0] * d0 + nrm[1] * d1 + nrm[2] * d2;
   const float dis_to_plane = (float)fabs(resi);
   const float dis_to_center = (float)(d0 * d0 + d1 * d1 + d2 * d2);
-  const float range_dis = __fsub_rn(dis_to_center, __fmul_rn(dis_to_plane, dis_to_plane));
+  const float range_dis = mul_sub_unfused(dis_to_center, dis_to_plane, dis_to_plane);
   const float radius = (float)pl[6];
   if (!(range_dis <= __fmul_rn(9.0f, radius))) return false;
   // J plane_var J^T with J = [d, -n]; the record holds the symmetrised upper triangle
@@ -457,38 +471,66 @@ __global__ void lio_pvec_update_kernel(const double* __restrict__ pts, long long
 // ---- plane covariance: the map-side producers of the records above (f2's arithmetic) ----------------------------------------
 // cov_add of OctoTree::push (voxel_map.hpp:990-992): sum over a cell's points of Bf_var (:91-106), the 9x9 covariance of the
 // cluster's (P upper triangle, v) induced by the point covariance.  One lane per cell, points in input order.
-__global__ void lio_cov_add_kernel(const double* __restrict__ xyz, const double* __restrict__ var9, const long long* __restrict__ cell_ptr, long long n_cells,
+__device__ __forceinline__ void cov_add_point(double (&acc)[81], double x, double y, double z, const double* __restrict__ V /* column-major 3x3 */) {
+  const double Bi[6][3] = {{2 * x, 0, 0}, {y, x, 0}, {z, 0, x}, {0, 2 * y, 0}, {0, z, y}, {0, 0, 2 * z}};
+  double Biup[6][3];
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) Biup[r][k] = Bi[r][0] * V[3 * k] + Bi[r][1] * V[3 * k + 1] + Bi[r][2] * V[3 * k + 2];
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc[9 * k + r] += Biup[r][0] * Bi[k][0] + Biup[r][1] * Bi[k][1] + Biup[r][2] * Bi[k][2];
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) { acc[9 * (6 + k) + r] += Biup[r][k]; acc[9 * r + 6 + k] += Biup[r][k]; }
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) acc[9 * (6 + k) + 6 + r] += V[3 * k + r];
+}
+
+__global__ __launch_bounds__(64) void lio_cov_add_kernel(const double* __restrict__ xyz, const double* __restrict__ var9, const long long* __restrict__ cell_ptr, long long n_cells,
                                    double* __restrict__ cov_add) {
   const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cells) return;
   double acc[81];
 #pragma unroll
   for (int k = 0; k < 81; k++) acc[k] = 0.0;
-  for (long long q = cell_ptr[c]; q < cell_ptr[c + 1]; q++) {
-    const double x = xyz[3 * q], y = xyz[3 * q + 1], z = xyz[3 * q + 2];
-    const double* V = var9 + 9 * q;   // column-major 3x3
-    const double Bi[6][3] = {{2 * x, 0, 0}, {y, x, 0}, {z, 0, x}, {0, 2 * y, 0}, {0, z, y}, {0, 0, 2 * z}};
-    double Biup[6][3];
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-      for (int k = 0; k < 3; k++) Biup[r][k] = Bi[r][0] * V[3 * k] + Bi[r][1] * V[3 * k + 1] + Bi[r][2] * V[3 * k + 2];
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-      for (int k = 0; k < 6; k++) acc[9 * k + r] += Biup[r][0] * Bi[k][0] + Biup[r][1] * Bi[k][1] + Biup[r][2] * Bi[k][2];
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-      for (int k = 0; k < 3; k++) { acc[9 * (6 + k) + r] += Biup[r][k]; acc[9 * r + 6 + k] += Biup[r][k]; }
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int k = 0; k < 3; k++) acc[9 * (6 + k) + 6 + r] += V[3 * k + r];
-  }
+  for (long long q = cell_ptr[c]; q < cell_ptr[c + 1]; q++) cov_add_point(acc, xyz[3 * q], xyz[3 * q + 1], xyz[3 * q + 2], var9 + 9 * q);
   double* o = cov_add + 81 * c;
 #pragma unroll
   for (int k = 0; k < 81; k++) o[k] = acc[k];
+}
+
+// What cut_voxel adds to the leaves a scan touches (OctoTree::push, voxel_map.hpp:969-993), from the world points and covariances
+// the last pvec_update left on the device: per leaf the PointCluster of its new points (sequential sums in the order given,
+// unfused -- bit-identical to PointCluster::push) and their cov_add.  The host tree's bucketing comes in as (cell_ptr, order):
+// leaf c owns scan points order[cell_ptr[c] .. cell_ptr[c+1]).  One lane per leaf.
+__global__ __launch_bounds__(64) void lio_leaf_stats_kernel(const double* __restrict__ pwld, const double* __restrict__ var9, const long long* __restrict__ cell_ptr,
+                                      const int* __restrict__ order, long long n_cells, double* __restrict__ clusters, double* __restrict__ cov_add) {
+  const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cells) return;
+  double acc[81];
+#pragma unroll
+  for (int k = 0; k < 81; k++) acc[k] = 0.0;
+  double P0 = 0, P1 = 0, P2 = 0, P3 = 0, P4 = 0, P5 = 0, vx = 0, vy = 0, vz = 0, N = 0;
+  for (long long q = cell_ptr[c]; q < cell_ptr[c + 1]; q++) {
+    const long long i = order[q];
+    const double x = pwld[3 * i], y = pwld[3 * i + 1], z = pwld[3 * i + 2];
+    N += 1.0;     // products rounded before the add, as the host compiler does for PointCluster::push
+    P0 = mul_add_unfused(P0, x, x); P1 = mul_add_unfused(P1, x, y); P2 = mul_add_unfused(P2, x, z);
+    P3 = mul_add_unfused(P3, y, y); P4 = mul_add_unfused(P4, y, z); P5 = mul_add_unfused(P5, z, z);
+    vx += x; vy += y; vz += z;
+    cov_add_point(acc, x, y, z, var9 + 9 * i);
+  }
+  double* o = clusters + 10 * c;
+  o[0] = P0; o[1] = P1; o[2] = P2; o[3] = P3; o[4] = P4; o[5] = P5; o[6] = vx; o[7] = vy; o[8] = vz; o[9] = N;
+  double* oc = cov_add + 81 * c;
+#pragma unroll
+  for (int k = 0; k < 81; k++) oc[k] = acc[k];
 }
 
 // OctoTree::plane_update (voxel_map.hpp:1118-1146): centre, normal, radius and the 6x6 covariance of (normal, centre) by first-order
@@ -661,6 +703,9 @@ struct vxba_lio {
   long long n_pts = 0, pts_stride = 0, pts_cap = 0;
   int* d_cache = nullptr;
   bool cache_valid = false;
+  double* d_world = nullptr;     // world points (3n) + world covariances (9n) of the resident scan, as the last pvec_update left them
+  long long world_cap = 0;
+  bool world_valid = false;
   char* d_stage = nullptr;       // grow-only device staging for host arrays crossing the boundary (no hipMalloc / hipFree per call)
   size_t stage_cap = 0;
   double* h_partials = nullptr;  // pinned, mapped: one 34-number partial per workgroup lands here (zero-copy stores)
@@ -757,6 +802,7 @@ int lio_scan_reserve(vxba_lio* h, long long n) {
   h->n_pts = n;
   h->pts_stride = h->pts_cap;
   h->cache_valid = false;
+  h->world_valid = false;
   return VXBA_OK;
 }
 
@@ -844,7 +890,7 @@ int vxba_lio_destroy(vxba_lio* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   hipFree(h->d_keys); hipFree(h->d_cells); hipFree(h->d_planes); hipFree(h->d_plane_tag); hipFree(h->d_counters);
-  hipFree(h->d_pts); hipFree(h->d_cache); hipFree(h->d_stage); hipFree(h->d_ctl); hipFree(h->d_partials_dev);
+  hipFree(h->d_pts); hipFree(h->d_cache); hipFree(h->d_world); hipFree(h->d_stage); hipFree(h->d_ctl); hipFree(h->d_partials_dev);
   if (h->h_partials) hipHostFree(h->h_partials);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -987,22 +1033,61 @@ int vxba_lio_scan_read(vxba_lio* h, double* pnt, double* var) {
 }
 
 int vxba_lio_pvec_update(vxba_lio* h, const double* state, const double* cov, double* pwld, double* var) {
-  if (!h || !state || !cov || !pwld || !var) return VXBA_ERR_ARG;
+  if (!h || !state || !cov || !pwld) return VXBA_ERR_ARG;
   LIO_LOCK(h);
   if (h->n_pts == 0) return VXBA_OK;
   LIO_HIP(h, hipSetDevice(h->device));
   const long long n = h->n_pts;
-  double* d = nullptr;
-  {
-    int rcs = lio_stage(h, (size_t)n * 12 * sizeof(double), (char**)&d);
-    if (rcs != VXBA_OK) return rcs;
+  if (n > h->world_cap) {
+    if (h->d_world) { LIO_HIP(h, hipStreamSynchronize(h->stream)); LIO_HIP(h, hipFree(h->d_world)); }
+    h->d_world = nullptr; h->world_cap = 0;
+    LIO_HIP(h, hipMalloc((void**)&h->d_world, (size_t)h->pts_cap * 12 * sizeof(double)));
+    h->world_cap = h->pts_cap;
   }
+  double* d = h->d_world;
+  h->world_valid = false;
   vxl::lio_pvec_update_kernel<<<grid_for(n), 256, 0, h->stream>>>(h->d_pts, n, h->pts_stride, sweep_arg(state, cov), d, d + 3 * n);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(pwld, d, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(var, d + 3 * n, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess && var) e = hipMemcpyAsync(var, d + 3 * n, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) { h->err = std::string("vxba_lio_pvec_update: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
+  h->world_valid = true;
+  return VXBA_OK;
+}
+
+int vxba_lio_leaf_stats(vxba_lio* h, int64_t n_cells, const int64_t* cell_ptr, const int32_t* order, double* clusters, double* cov_add) {
+  if (!h || n_cells < 0 || !cell_ptr || !clusters || !cov_add) return VXBA_ERR_ARG;
+  LIO_LOCK(h);
+  if (n_cells == 0) return VXBA_OK;
+  if (!h->world_valid) return lio_fail(h, VXBA_ERR_STATE, "vxba_lio_leaf_stats: no world points on the device (call vxba_lio_pvec_update after loading the scan)");
+  const long long m = cell_ptr[n_cells];
+  if (cell_ptr[0] != 0 || m < 0 || (m > 0 && !order)) return lio_fail(h, VXBA_ERR_ARG, "vxba_lio_leaf_stats: cell_ptr must start at 0 and order must cover cell_ptr[n_cells] entries");
+  for (int64_t c = 0; c < n_cells; c++)
+    if (cell_ptr[c + 1] < cell_ptr[c]) return lio_fail(h, VXBA_ERR_ARG, "vxba_lio_leaf_stats: cell_ptr must be non-decreasing");
+  for (long long q = 0; q < m; q++)
+    if (order[q] < 0 || order[q] >= h->n_pts) return lio_fail(h, VXBA_ERR_ARG, "vxba_lio_leaf_stats: order holds an index outside the resident scan");
+  LIO_HIP(h, hipSetDevice(h->device));
+  const size_t b_ptr = ((size_t)(n_cells + 1) * 8 + 255) & ~(size_t)255, b_ord = ((size_t)m * 4 + 255) & ~(size_t)255, b_cl = ((size_t)n_cells * 80 + 255) & ~(size_t)255;
+  char* d = nullptr;
+  {
+    int rcs = lio_stage(h, b_ptr + b_ord + b_cl + (size_t)n_cells * 81 * 8, &d);
+    if (rcs != VXBA_OK) return rcs;
+  }
+  long long* d_ptr = (long long*)d;
+  int* d_ord = (int*)(d + b_ptr);
+  double* d_cl = (double*)(d + b_ptr + b_ord);
+  double* d_ca = (double*)(d + b_ptr + b_ord + b_cl);
+  hipError_t e = hipMemcpyAsync(d_ptr, cell_ptr, (size_t)(n_cells + 1) * 8, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess && m) e = hipMemcpyAsync(d_ord, order, (size_t)m * 4, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    vxl::lio_leaf_stats_kernel<<<grid_for(n_cells, 64), 64, 0, h->stream>>>(h->d_world, h->d_world + 3 * h->n_pts, d_ptr, d_ord, n_cells, d_cl, d_ca);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(clusters, d_cl, (size_t)n_cells * 80, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(cov_add, d_ca, (size_t)n_cells * 81 * 8, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) { h->err = std::string("vxba_lio_leaf_stats: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
   return VXBA_OK;
 }
 

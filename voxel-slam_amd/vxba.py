@@ -34,7 +34,7 @@ EXPORTS = [
     "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_li_evaluate",
     "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity", "vxba_voxelize_push", "vxba_set_precision",
     "vxba_lio_create", "vxba_lio_destroy", "vxba_lio_last_error", "vxba_lio_map_update", "vxba_lio_map_clear", "vxba_lio_map_size", "vxba_lio_scan_raw",
-    "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_cov_add_build", "vxba_plane_update", "vxba_down_sampling_voxel", "vxba_voxelize_push_device",
+    "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_lio_leaf_stats", "vxba_cov_add_build", "vxba_plane_update", "vxba_down_sampling_voxel", "vxba_voxelize_push_device",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -139,7 +139,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_lio_scan_read.argtypes = [vp, _f64p, _f64p]
     L.vxba_lio_sweep.argtypes = [vp, _f64p, _f64p, ci, _f64p, vp, vp]
     L.vxba_lio_state_estimation.argtypes = [vp, _f64p, _f64p, vp, vp]
-    L.vxba_lio_pvec_update.argtypes = [vp, _f64p, _f64p, _f64p, _f64p]
+    L.vxba_lio_pvec_update.argtypes = [vp, _f64p, _f64p, _f64p, vp]
+    L.vxba_lio_leaf_stats.argtypes = [vp, C.c_int64, _i64p, vp, _f64p, _f64p]
     L.vxba_cov_add_build.argtypes = [ci, C.c_int64, C.c_int64, _f64p, _f64p, _i64p, _f64p]
     L.vxba_down_sampling_voxel.argtypes = [ci, C.c_int64, np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS"), cd,
                                            np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS"), C.POINTER(C.c_int64)]
@@ -674,11 +675,27 @@ class LioEstimator:
         return {"ok": bool(info[0]), "state": st, "cov": cv.T.copy(), "iterations": it, "match_num": int(info[2]), "min_eig": float(info[3]),
                 "sweeps": [unpack_sweep(sweeps[k]) for k in range(it)]}
 
-    def pvec_update(self, state, cov):
+    def pvec_update(self, state, cov, with_var: bool = True):
+        """World points (and, unless ``with_var`` is False, world covariances n x 3 x 3) of the scan; both stay on the device for leaf_stats."""
         n = self.scan_size()
-        pw = np.zeros((n, 3)); var = np.zeros((n, 9))
-        self._chk(self._L.vxba_lio_pvec_update(self._h, _c(state), self._cov(cov), pw, var))
+        pw = np.zeros((n, 3))
+        if not with_var:
+            self._chk(self._L.vxba_lio_pvec_update(self._h, _c(state), self._cov(cov), pw, None))
+            return pw
+        var = np.zeros((n, 9))
+        self._chk(self._L.vxba_lio_pvec_update(self._h, _c(state), self._cov(cov), pw, var.ctypes.data_as(C.c_void_p)))
         return pw, np.transpose(var.reshape(n, 3, 3), (0, 2, 1)).copy()
+
+    def leaf_stats(self, cell_ptr, order):
+        """Per-leaf increments of ``cut_voxel`` (OctoTree::push, voxel_map.hpp:969-993) from the resident world points / covariances of the
+        last pvec_update: leaf c owns scan points ``order[cell_ptr[c]:cell_ptr[c+1]]``.  Returns clusters (n_cells x 10), cov_add (n_cells x 9 x 9)."""
+        cp = np.ascontiguousarray(cell_ptr, dtype=np.int64); n = cp.shape[0] - 1
+        od = np.ascontiguousarray(order, dtype=np.int32)
+        if n < 0 or (n >= 0 and od.shape[0] != (cp[-1] if cp.size else 0)):
+            raise VxbaError("leaf_stats: order must hold cell_ptr[-1] indices")
+        cl = np.zeros((max(n, 0), 10)); ca = np.zeros((max(n, 0), 81))
+        self._chk(self._L.vxba_lio_leaf_stats(self._h, n, cp, od.ctypes.data_as(C.c_void_p), cl, ca))
+        return cl, ca.reshape(-1, 9, 9)          # symmetric: column-major == row-major, no transpose needed
 
 
 def down_sampling_voxel(xyz, voxel_size: float, device: int = 0):
