@@ -17,6 +17,7 @@ Launch: ``python bench.py`` (N=1) or
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N``.
 """
 import argparse
+import math
 import json
 import os
 import sys
@@ -149,9 +150,14 @@ def main():
     # Clock ramp: the timed loop is ~20 ms and would otherwise be the first sustained GPU work of the process -- on some boxes it then
     # runs at half speed (same binary 7.6k vs 14k it/s; everything measured later in the same process was at full speed).  A third of a
     # second of the same loop first, untimed, then the W warm-up steps the contract asks for.
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm_seconds:
-        f.lm_steps(sc.poses_init, 300, sps)
+    if use_dist:
+        # every rank must issue the same number of collectives: a fixed count (a 300-step call is ~25-40 ms), never a wall-clock loop
+        for _ in range(int(math.ceil(args.prewarm_seconds / 0.03))):
+            f.lm_steps(sc.poses_init, 300, sps)
+    else:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.prewarm_seconds:
+            f.lm_steps(sc.poses_init, 300, sps)
     if args.warmup > 0:
         f.lm_steps(sc.poses_init, args.warmup, sps)
     f.kernel_times(reset=True)
