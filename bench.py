@@ -355,7 +355,7 @@ def lio_rate(device, with_cpu, n_points=100_000, n_roots=20_000):
            "ms_per_scan": 1e3 * med, "scans_per_s": 1.0 / med, "ms_per_sweep_call": 1e3 * msw, "points_per_s_sweep": n_points / msw,
            # per point: 72 B (pnt + covariance) + 12 B (key + cell entry), and the 256 B plane record for every point that reaches a plane
            "sweep_algorithmic_bytes": 84.0 * n_points + 256.0 * res["match_num"], "map_upload_ms": 1e3 * t_map, "var_init_ms": 1e3 * t_scan,
-           "pose_error_vs_truth_m_rad": [et, er], "where": "match + sums on GPU; 15x15 EKF algebra on host between sweeps"}
+           "pose_error_vs_truth_m_rad": [et, er], "where": "match + sums and the 15x15 EKF update on GPU (4 x (sweep, update) enqueued at once)" if os.environ.get("VXBA_LIO_DEVICE_EKF", "1") != "0" else "match + sums on GPU; 15x15 EKF algebra on host between sweeps"}
     g.close()
     if with_cpu:
         from tests import _oracle as O

@@ -390,6 +390,7 @@ def test_bench_rccl_plumbing_single_rank():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     def run(extra):
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "cfg1", "--steps", "30", "--warmup", "3",
+                              "--prewarm-seconds", "0",          # same calls before the timed one in every mode: the eigen warm start carries over
                               "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
