@@ -13,6 +13,7 @@
 #include "vxo_ba.hpp"
 #include "vxo_imu.hpp"
 #include "vxo_lio.hpp"
+#include "vxo_octree.hpp"
 #include "vxo_voxelize.hpp"
 
 using namespace vxo;
@@ -544,4 +545,77 @@ int64_t vxo_down_sampling_voxel(int64_t n, const float* xyz, double voxel_size, 
   return (int64_t)(v.size() / 3);
 }
 
+
+// ---- incremental local map (vxo_octree.hpp) ----
+// params = [voxel_size, max_layer, min_point[4], min_eigen_value, plane_eigen_value_thre[4], max_points, win_size, thread_num]
+void* vxo_localmap_create(const double* p) {
+  LocalMapParams q;
+  q.voxel_size = p[0]; q.max_layer = (int)p[1];
+  for (int k = 0; k < 4; k++) q.min_point[k] = p[2 + k];
+  q.min_eigen_value = p[6];
+  for (int k = 0; k < 4; k++) q.plane_eigen_value_thre[k] = p[7 + k];
+  q.max_points = (int)p[11]; q.win_size = (int)p[12]; q.thread_num = (int)p[13];
+  return new LocalMap(q);
+}
+void vxo_localmap_destroy(void* m) { delete (LocalMap*)m; }
+// scan `ord` of the window: body points (n*3), their WORLD covariances (n*9 col-major, as pvec_update leaves them), world points (n*3)
+void vxo_localmap_cut_voxel(void* m, int ord, int64_t n, const double* pnt, const double* var, const double* pwld) {
+  std::vector<PointVar> pv((size_t)n);
+  std::vector<V3> pw((size_t)n);
+  for (int64_t i = 0; i < n; i++) {
+    pv[i].pnt = v3(pnt[3 * i], pnt[3 * i + 1], pnt[3 * i + 2]);
+    pv[i].var = unpack_m3_colmajor(var + 9 * i);
+    pw[i] = v3(pwld[3 * i], pwld[3 * i + 1], pwld[3 * i + 2]);
+  }
+  ((LocalMap*)m)->cut_voxel(ord, pv, pw);
+}
+// multi_recut: recut + tras_opt into the factor of an oracle handle (vxo_create)
+void vxo_localmap_recut(void* m, int win_count, const double* Rp, void* factor) {
+  ((LocalMap*)m)->recut(win_count, unpack_poses(Rp, win_count), ((Handle*)factor)->factor);
+}
+// multi_margi with mgsize = 1; the factor is the one tras_opt filled (its pcr_adds / eig_* as the optimiser left them)
+int vxo_localmap_margi(void* m, int win_count, const double* Rp, void* factor) {
+  try { ((LocalMap*)m)->margi(win_count, unpack_poses(Rp, win_count), ((Handle*)factor)->factor); } catch (const std::exception&) { return -1; }
+  return 0;
+}
+void vxo_localmap_slide(void* m, int mgsize) { ((LocalMap*)m)->slide(mgsize); }
+void vxo_localmap_counts(void* m, int64_t* out) {   // [roots, roots in the slide map, leaves, mp[0]]
+  LocalMap* lm = (LocalMap*)m;
+  std::vector<LeafView> lv;
+  lm->leaves(lv);
+  out[0] = (int64_t)lm->surf_map.size(); out[1] = (int64_t)lm->slide_order.size(); out[2] = (int64_t)lv.size(); out[3] = lm->mp[0];
+}
+// Every leaf (octo_state == 0).  ints: n x 8 = [layer, isexist, is_plane, has_sw, opt_state, last_num, point_fix.size(), root in slide map];
+// dbl: n x (156 + 11 W) = [pcr_add 10 | pcr_fix 10 | eig_value 3 | eig_vector 9 col-major | center 3 | normal 3 | radius | plane_var 36
+// col-major | cov_add 81 col-major | pcrs_local W x 10 in window order | points kept per window slot W].  Returns the leaf count, -1 if a
+// root lies outside the id range.
+int64_t vxo_localmap_leaves(void* m, int64_t capacity, uint64_t* ids, int32_t* ints, double* dbl) {
+  LocalMap* lm = (LocalMap*)m;
+  std::vector<LeafView> lv;
+  if (!lm->leaves(lv)) return -1;
+  const int W = lm->prm.win_size;
+  const size_t rec = 156 + 11 * (size_t)W;
+  for (int64_t a = 0; a < (int64_t)lv.size() && a < capacity; a++) {
+    const TreeNode* n = lv[a].node;
+    ids[a] = lv[a].node_id;
+    const uint64_t r = lv[a].node_id >> 16;
+    const LocKey key{(int64_t)((r >> 32) & 0xffff) - 32768, (int64_t)((r >> 16) & 0xffff) - 32768, (int64_t)(r & 0xffff) - 32768};
+    int32_t* I = ints + 8 * a;
+    I[0] = n->layer; I[1] = n->isexist; I[2] = n->plane.is_plane; I[3] = n->has_sw; I[4] = n->opt_state; I[5] = n->last_num;
+    I[6] = (int32_t)n->point_fix.size(); I[7] = (int32_t)lm->slide_set.count(key);
+    double* D = dbl + rec * a;
+    pack_cluster(n->pcr_add, D); pack_cluster(n->pcr_fix, D + 10);
+    for (int k = 0; k < 3; k++) D[20 + k] = n->eig_value[k];
+    pack_m3_colmajor(n->eig_vector, D + 23);
+    for (int k = 0; k < 3; k++) { D[32 + k] = n->plane.center[k]; D[35 + k] = n->plane.normal[k]; }
+    D[38] = n->plane.radius;
+    for (int k = 0; k < 36; k++) D[39 + k] = n->plane.is_plane ? n->plane.plane_var[k] : 0.0;
+    for (int k = 0; k < 81; k++) D[75 + k] = n->cov_add[k];
+    for (int i = 0; i < W; i++) {
+      if (n->has_sw) { pack_cluster(n->pcrs_local[lm->mp[i]], D + 156 + 10 * i); D[156 + 10 * W + i] = (double)n->points[lm->mp[i]].size(); }
+      else { for (int k = 0; k < 10; k++) D[156 + 10 * i + k] = 0; D[156 + 10 * W + i] = 0; }
+    }
+  }
+  return (int64_t)lv.size();
+}
 }  // extern "C"

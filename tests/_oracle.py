@@ -87,6 +87,17 @@ def lib():
     L.vxo_down_sampling_voxel.restype = C.c_int64
     L.vxo_down_sampling_voxel.argtypes = [C.c_int64, f32p, C.c_double, f32p]
     L.vxo_plane_update.argtypes = [C.c_int64, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p]
+    u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+    L.vxo_localmap_create.restype = vp
+    L.vxo_localmap_create.argtypes = [f64p]
+    L.vxo_localmap_destroy.argtypes = [vp]
+    L.vxo_localmap_cut_voxel.argtypes = [vp, C.c_int, C.c_int64, f64p, f64p, f64p]
+    L.vxo_localmap_recut.argtypes = [vp, C.c_int, f64p, vp]
+    L.vxo_localmap_margi.argtypes = [vp, C.c_int, f64p, vp]
+    L.vxo_localmap_slide.argtypes = [vp, C.c_int]
+    L.vxo_localmap_counts.argtypes = [vp, i64p]
+    L.vxo_localmap_leaves.restype = C.c_int64
+    L.vxo_localmap_leaves.argtypes = [vp, C.c_int64, u64p, i32p, f64p]
     _LIB = L
     return L
 
@@ -404,3 +415,57 @@ def down_sampling_voxel(xyz, voxel_size):
     out = np.zeros_like(xyz)
     n = lib().vxo_down_sampling_voxel(xyz.shape[0], xyz, float(voxel_size), out)
     return out[:n].copy()
+
+
+class LocalMapOracle:
+    """The incremental local map on the CPU (oracle/vxo_octree.hpp): `surf_map` / `surf_map_slide` driven scan by scan the way the
+    local-mapping thread drives them (cut_voxel_multi -> multi_recut (+ tras_opt) -> BA -> multi_margi -> ring shift)."""
+
+    def __init__(self, voxel_size=1.0, max_layer=2, min_point=(5, 5, 5, 5), min_eigen_value=0.0025, plane_eigen_value_thre=(0.25, 0.25, 0.25, 0.25),
+                 max_points=100, win_size=10, thread_num=5):
+        self.win_size = int(win_size)
+        prm = np.array([voxel_size, max_layer, *min_point, min_eigen_value, *plane_eigen_value_thre, max_points, win_size, thread_num], dtype=np.float64)
+        self._h = C.c_void_p(lib().vxo_localmap_create(prm))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().vxo_localmap_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def cut_voxel(self, ord_, pnt_body, var_world, pwld):
+        pnt = _c(pnt_body).reshape(-1, 3)
+        var = np.ascontiguousarray(np.transpose(np.asarray(var_world, dtype=np.float64).reshape(-1, 3, 3), (0, 2, 1)))
+        lib().vxo_localmap_cut_voxel(self._h, int(ord_), pnt.shape[0], pnt, var, _c(pwld).reshape(-1, 3))
+
+    def recut(self, win_count, poses, factor: "Oracle"):
+        """multi_recut: recut + tras_opt into ``factor`` (an ``Oracle``, cleared by the caller like voxhess.clear())."""
+        lib().vxo_localmap_recut(self._h, int(win_count), _c(poses)[:win_count], factor._h)
+
+    def margi(self, win_count, poses, factor: "Oracle"):
+        if lib().vxo_localmap_margi(self._h, int(win_count), _c(poses)[:win_count], factor._h) != 0:
+            raise RuntimeError("margi: opt_state beyond the factor")
+
+    def slide(self, mgsize=1):
+        lib().vxo_localmap_slide(self._h, int(mgsize))
+
+    def counts(self):
+        out = np.zeros(4, dtype=np.int64)
+        lib().vxo_localmap_counts(self._h, out)
+        return dict(roots=int(out[0]), slide=int(out[1]), leaves=int(out[2]), mp0=int(out[3]))
+
+    def leaves(self):
+        W = self.win_size
+        n = self.counts()["leaves"]
+        ids = np.zeros(n, dtype=np.uint64); ints = np.zeros((n, 8), dtype=np.int32); d = np.zeros((n, 156 + 11 * W))
+        got = lib().vxo_localmap_leaves(self._h, n, ids, ints, d)
+        if got < 0:
+            raise ValueError("root voxel outside the id range")
+        assert got == n
+        return dict(node_id=ids, layer=ints[:, 0], isexist=ints[:, 1].astype(bool), is_plane=ints[:, 2].astype(bool), has_sw=ints[:, 3].astype(bool),
+                    opt_state=ints[:, 4], last_num=ints[:, 5], n_point_fix=ints[:, 6], in_slide=ints[:, 7].astype(bool),
+                    pcr_add=d[:, 0:10], pcr_fix=d[:, 10:20], eig_val=d[:, 20:23], eig_vec=d[:, 23:32], center=d[:, 32:35], normal=d[:, 35:38],
+                    radius=d[:, 38], plane_var=np.transpose(d[:, 39:75].reshape(n, 6, 6), (0, 2, 1)), cov_add=np.transpose(d[:, 75:156].reshape(n, 9, 9), (0, 2, 1)),
+                    pcrs_local=d[:, 156:156 + 10 * W].reshape(n, W, 10), n_points=d[:, 156 + 10 * W:].astype(np.int64))
