@@ -662,6 +662,20 @@ int vxba_push_voxels(vxba_factor* f, int n, const double* clusters, const double
   return VXBA_OK;
 }
 
+namespace {
+// the factor's grow-only device scratch (staging of host arrays on their way into the planes): no hipMalloc / hipFree per call
+int ensure_scratch(vxba_factor* f, size_t need) {
+  if (need > f->scratch_cap) {
+    VX_HIP(f, hipStreamSynchronize(f->stream));
+    if (f->d_scratch) VX_HIP(f, hipFree(f->d_scratch));
+    f->d_scratch = nullptr; f->scratch_cap = 0;
+    VX_HIP(f, hipMalloc((void**)&f->d_scratch, need + need / 4));
+    f->scratch_cap = need + need / 4;
+  }
+  return VXBA_OK;
+}
+}  // namespace
+
 int vxba_push_points(vxba_factor* f, int n_voxels, int64_t n_points, const double* xyz_body, const int64_t* cell_ptr, const double* fix,
                      const double* coe) {
   VX_LOCK(f);
@@ -675,12 +689,13 @@ int vxba_push_points(vxba_factor* f, int n_voxels, int64_t n_points, const doubl
   hipSetDevice(f->device);
   int rc = ensure_capacity(f, f->V + n_voxels);
   if (rc) return rc;
-  double* d_xyz = nullptr;
-  int64_t* d_ptr = nullptr;
-  VX_HIP(f, hipMalloc((void**)&d_xyz, std::max<size_t>(1, (size_t)n_points * 3) * sizeof(double)));
-  hipError_t e = hipMalloc((void**)&d_ptr, (size_t)(ncells + 1) * sizeof(int64_t));
-  if (e != hipSuccess) { hipFree(d_xyz); f->err = std::string("hipMalloc cell_ptr: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
-  auto cleanup = [&]() { hipFree(d_xyz); hipFree(d_ptr); };
+  const size_t b_xyz = ((std::max<size_t>(1, (size_t)n_points * 3) * sizeof(double)) + 255) / 256 * 256;
+  rc = ensure_scratch(f, b_xyz + (size_t)(ncells + 1) * sizeof(int64_t));
+  if (rc) return rc;
+  double* d_xyz = (double*)f->d_scratch;
+  int64_t* d_ptr = (int64_t*)(f->d_scratch + b_xyz);
+  hipError_t e = hipSuccess;
+  auto cleanup = [&]() {};
   if (n_points) e = hipMemcpyAsync(d_xyz, xyz_body, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_ptr, cell_ptr, (size_t)(ncells + 1) * sizeof(int64_t), hipMemcpyHostToDevice, f->stream);
   if (e != hipSuccess) { cleanup(); f->err = std::string("push_points H2D: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
@@ -1456,12 +1471,9 @@ static int voxelize_push_impl(vxba_factor* f, int64_t n_points, const double* xy
                b_m = up((size_t)cap * 10 * sizeof(double)), b_id = up((size_t)cap * sizeof(unsigned long long)), b_fix = up((size_t)cap * 10 * sizeof(double)),
                b_coe = up((size_t)cap * sizeof(double));
   const size_t need = b_xyz + b_fp + b_cl + b_ev + b_evec + b_m + b_id + b_fix + b_coe;
-  if (need > f->scratch_cap) {
-    VX_HIP(f, hipStreamSynchronize(f->stream));
-    if (f->d_scratch) VX_HIP(f, hipFree(f->d_scratch));
-    f->d_scratch = nullptr; f->scratch_cap = 0;
-    VX_HIP(f, hipMalloc((void**)&f->d_scratch, need + need / 4));
-    f->scratch_cap = need + need / 4;
+  {
+    int rcs = ensure_scratch(f, need);
+    if (rcs) return rcs;
   }
   char* q = f->d_scratch;
   auto carve = [&](size_t bytes) { char* r = q; q += bytes; return r; };
