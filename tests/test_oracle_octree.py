@@ -120,10 +120,23 @@ def internal_prefixes(node_id, layer):
 def test_sliding_window_conserves_points_and_clusters():
     win = 5
     prev_internal = set()
-    steps = 0
+    prev_ids = None
+    steps = born_with_fix = 0
     for st in run_stream(S=12, win=win, pts=4000, seed=3):
         lv = st["leaves"]; xs = st["x_buf"]
         steps += 1
+        # children created by a subdivision of a leaf that already held marginalised points start with their share of them (fix_divide),
+        # and their world cluster is again fix + window
+        if prev_ids is not None:
+            for a in np.nonzero((lv["layer"] > 0) & (lv["pcr_fix"][:, 9] > 0))[0]:
+                if int(lv["node_id"][a]) not in prev_ids:
+                    born_with_fix += 1
+                    acc = lv["pcr_fix"][a].copy()
+                    for i in range(win):
+                        if lv["pcrs_local"][a, i, 9] > 0:
+                            acc += transform_cluster(lv["pcrs_local"][a, i], xs[i])
+                    assert np.allclose(acc, lv["pcr_add"][a], rtol=1e-9, atol=1e-9)
+        prev_ids = set(lv["node_id"].tolist())
         # leaf by leaf: points in the world cluster = marginalised points + points still in the window
         assert np.array_equal(lv["pcr_add"][:, 9], lv["pcr_fix"][:, 9] + lv["pcrs_local"][:, :, 9].sum(axis=1))
         # slot 0 has just been marginalised in every leaf margi visited
@@ -155,7 +168,7 @@ def test_sliding_window_conserves_points_and_clusters():
             assert np.allclose(pl["center"], lv["center"][fresh], rtol=1e-14) and np.allclose(pl["normal"], lv["normal"][fresh], atol=1e-15)
             assert np.allclose(pl["plane_var"], lv["plane_var"][fresh], rtol=1e-9, atol=1e-16) and np.array_equal(pl["radius"].astype(np.float32), lv["radius"][fresh].astype(np.float32))
         assert st["map"].counts()["mp0"] == (steps - 1) % win
-    assert steps == 8
+    assert steps == 8 and born_with_fix > 100
 
 
 def test_tras_opt_hands_over_the_planes_and_margi_adopts_the_optimisers_cache():
