@@ -24,6 +24,11 @@ def lib():
     path = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(path):
         build_oracle()
+    else:
+        try:                                   # a stale checker (sources newer than the .so) is rebuilt; a box without make keeps what it has
+            build_oracle()
+        except (OSError, subprocess.CalledProcessError):
+            pass
     L = C.CDLL(path)
     L.vxo_create.restype = C.c_void_p
     L.vxo_create.argtypes = [C.c_int]
