@@ -1,0 +1,76 @@
+"""The BA inside the local-mapping cycle it lives in upstream (voxelslam.cpp:1592-1700): scan by scan `cut_voxel_multi` -> `multi_recut` +
+`tras_opt` -> `Lidar_BA_Optimizer::damping_iter` -> `multi_margi` (which adopts the optimiser's pcr_adds / eig_values / eig_vectors,
+voxel_map.hpp:1216-1229) -> window shift.  The tree bookkeeping is the oracle's restatement of `OctoTree` in both runs (standing in for the
+host tree, which this library does not own); the optimiser is the oracle in one run and the GPU in the other.  The two maps must evolve
+identically: same leaves and plane flags after every window, clusters and poses equal to rounding."""
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+from tests.test_oracle_octree import PRM, point_vars, to_world
+from voxel_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def factor_arrays(lv, win):
+    """What tras_opt pushed, in push order."""
+    fac = np.nonzero(lv["opt_state"] >= 0)[0]
+    fac = fac[np.argsort(lv["opt_state"][fac])]
+    return fac, lv["pcrs_local"][fac], lv["pcr_fix"][fac], lv["eig_val"][fac], lv["eig_vec"][fac], lv["pcr_add"][fac]
+
+
+def test_map_evolves_identically_with_the_gpu_optimiser_in_the_loop():
+    from voxel_slam_amd import vxba
+    vxba.load_library()
+    S, win, pts, seed = 9, 4, 20000, 6
+    xyz, fp, poses_gt, _ = synth.make_scans(win_size=S, pts_per_scan=pts, seed=synth.MASTER_SEED + 900 + seed)
+    rng = np.random.default_rng(seed)
+    var = point_vars(xyz.shape[0], seed)
+    maps = [O.LocalMapOracle(win_size=win, **PRM), O.LocalMapOracle(win_size=win, **PRM)]          # [oracle BA, GPU BA]
+    facs = [O.Oracle(win), O.Oracle(win)]
+    gf = vxba.LidarFactor(win)
+    x_bufs = [[], []]
+    win_count = 0
+    windows = 0
+    for k in range(S):
+        pose = poses_gt[k].copy(); pose[9:12] += rng.normal(0, 0.01, 3)
+        s = slice(fp[k], fp[k + 1])
+        win_count += 1
+        for m, f, xb in zip(maps, facs, x_bufs):
+            xb.append(pose.copy())
+            f.clear()
+            m.cut_voxel(win_count - 1, xyz[s], var[s], to_world(xb[-1], xyz[s]))
+            m.recut(win_count, np.stack(xb), f)
+        if win_count < win:
+            continue
+        windows += 1
+        # run 0: the oracle optimises its own factor
+        out0 = facs[0].damping_iter(np.stack(x_bufs[0]), max_iter=3, thd_num=2)
+        # run 1: the same factor content goes to the GPU, the optimiser's cache comes back into the container margi reads
+        lv1 = maps[1].leaves()
+        fac, cl, fix, ev, U, merged = factor_arrays(lv1, win)
+        assert fac.size == facs[1].size() > 500
+        gf.clear(); gf.push_voxels(cl, fix, np.ones(fac.size), ev, U, merged)
+        out1 = vxba.Lidar_BA_Optimizer().damping_iter(np.stack(x_bufs[1]), gf, max_iter=3)
+        assert out1["trace"].shape == out0["trace"].shape and np.array_equal(out1["trace"][:, 6], out0["trace"][:, 6])     # accept / reject
+        et, er = synth.pose_errors(out1["poses"], out0["poses"])
+        assert et < 1e-7 and er < 1e-7
+        ev_g, U_g, merged_g = gf.read_cache()
+        facs[1].clear(); facs[1].push_voxels(cl, fix, np.ones(fac.size), ev_g, U_g, merged_g)
+        for m, f, xb, out in zip(maps, facs, x_bufs, (out0, out1)):
+            xs = out["poses"]
+            m.margi(win_count, xs, f)
+            m.slide(1)
+            xb[:] = [p for p in xs[1:]]
+        win_count -= 1
+        a, b = maps[0].leaves(), maps[1].leaves()
+        assert np.array_equal(a["node_id"], b["node_id"]) and np.array_equal(a["is_plane"], b["is_plane"]) and np.array_equal(a["isexist"], b["isexist"])
+        assert np.array_equal(a["pcr_add"][:, 9], b["pcr_add"][:, 9]) and np.array_equal(a["pcr_fix"][:, 9], b["pcr_fix"][:, 9])
+        for key in ("pcr_add", "pcr_fix"):
+            scale = np.abs(a[key]).max(axis=1, keepdims=True) + 1e-300
+            assert np.all(np.abs(a[key] - b[key]) <= 1e-9 * scale), key
+        pl = a["is_plane"] & (a["last_num"] == a["pcr_add"][:, 9])
+        sgn = np.sign(np.sum(a["normal"][pl] * b["normal"][pl], axis=1))
+        assert np.allclose(a["normal"][pl], b["normal"][pl] * sgn[:, None], atol=1e-7) and np.allclose(a["center"][pl], b["center"][pl], atol=1e-8)
+    assert windows == 6
