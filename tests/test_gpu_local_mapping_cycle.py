@@ -74,3 +74,80 @@ def test_map_evolves_identically_with_the_gpu_optimiser_in_the_loop():
         sgn = np.sign(np.sum(a["normal"][pl] * b["normal"][pl], axis=1))
         assert np.allclose(a["normal"][pl], b["normal"][pl] * sgn[:, None], atol=1e-7) and np.allclose(a["center"][pl], b["center"][pl], atol=1e-8)
     assert windows == 6
+
+
+def lio_leaf_args(lv):
+    """Plane-carrying leaves of the tree as vxba_lio_map_update takes them (path: first subdivision in the low bits)."""
+    sel = np.nonzero(lv["is_plane"] & (lv["last_num"] > 0))[0]
+    nid = lv["node_id"][sel]
+    r = nid >> np.uint64(16)
+    loc = np.stack([((r >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64) - 32768, ((r >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.int64) - 32768,
+                    (r & np.uint64(0xFFFF)).astype(np.int64) - 32768], axis=1)
+    p = ((nid >> np.uint64(7)) & np.uint64(0x1FF)).astype(np.int64)
+    path = ((p >> 6) & 7) | (((p >> 3) & 7) << 3)
+    return loc, lv["layer"][sel].astype(np.int32), path.astype(np.int32), lv["center"][sel], lv["normal"][sel], lv["plane_var"][sel], lv["radius"][sel]
+
+
+def test_odometry_and_ba_on_the_evolving_map_match_the_oracle_step_by_step():
+    """The whole per-scan cycle with the oracle driving (teacher forcing): at every step the GPU entry points get exactly the oracle's
+    inputs -- the plane map as the tree holds it at that moment (subdivided voxels, planes refreshed by margi, voxels that left the
+    window), the raw scan, the window's factor -- and must return the oracle's outputs: var_init + lio_state_estimation, pvec_update,
+    damping_iter, read_cache."""
+    from voxel_slam_amd import vxba
+    vxba.load_library()
+    S, win, pts, seed = 9, 4, 20000, 7
+    xyz, fp, poses_gt, _ = synth.make_scans(win_size=S, pts_per_scan=pts, seed=synth.MASTER_SEED + 900 + seed)
+    rng = np.random.default_rng(seed)
+    m = O.LocalMapOracle(win_size=win, **PRM)
+    f = O.Oracle(win)
+    gf = vxba.LidarFactor(win)
+    ge = vxba.LioEstimator(PRM["voxel_size"], PRM["max_layer"])
+    x_buf = []
+    win_count = 0
+    estimated = 0
+    cov = np.eye(15) * 1e-4
+    for k in range(S):
+        s = slice(fp[k], fp[k + 1])
+        scan32 = xyz[s].astype(np.float32)
+        prior = np.concatenate([poses_gt[k][:9], poses_gt[k][9:12] + rng.normal(0, 0.02, 3), np.zeros(9), [0, 0, -9.8]])
+        oe = O.LioOracle(PRM["voxel_size"], PRM["max_layer"])
+        oe.var_init(scan32); ge.var_init(scan32)
+        state, cv = prior, cov
+        lv = m.leaves() if k else None
+        if lv is not None and (lv["is_plane"] & (lv["last_num"] > 0)).sum() > 200:
+            args = lio_leaf_args(lv)
+            oe.map_update(*args); ge.map_clear(); ge.map_update(*args)
+            ro = oe.lio_state_estimation(prior, cov); rg = ge.lio_state_estimation(prior, cov)
+            assert ro["iterations"] == rg["iterations"] and abs(ro["match_num"] - rg["match_num"]) <= 2 and ro["match_num"] > 0.3 * pts
+            et, er = synth.pose_errors(rg["state"][None, :12], ro["state"][None, :12])
+            assert et < 1e-8 and er < 1e-8 and np.allclose(rg["state"][12:21], ro["state"][12:21], atol=1e-9)
+            assert np.abs(rg["cov"] - ro["cov"]).max() < 1e-7 * np.abs(ro["cov"]).max()
+            # the update pulls the perturbed prior towards the pose the scan was taken at
+            assert np.linalg.norm(ro["state"][9:12] - poses_gt[k][9:12]) < 0.5 * np.linalg.norm(prior[9:12] - poses_gt[k][9:12])
+            state, cv = ro["state"], ro["cov"]
+            estimated += 1
+        pw_o, var_o = oe.pvec_update(state, cv); pw_g, var_g = ge.pvec_update(state, cv)
+        assert np.allclose(pw_g, pw_o, rtol=1e-13, atol=1e-13) and np.allclose(var_g, var_o, rtol=1e-9, atol=1e-18)
+        pnt_body, _ = oe.read_points()
+        win_count += 1
+        x_buf.append(state[:12].copy())
+        f.clear()
+        m.cut_voxel(win_count - 1, pnt_body, var_o, pw_o)
+        m.recut(win_count, np.stack(x_buf), f)
+        if win_count < win:
+            continue
+        fac, cl, fix, ev, U, merged = factor_arrays(m.leaves(), win)
+        xs = np.stack(x_buf)
+        out_o = f.damping_iter(xs, max_iter=3, thd_num=2)
+        gf.clear(); gf.push_voxels(cl, fix, np.ones(fac.size), ev, U, merged)
+        out_g = vxba.Lidar_BA_Optimizer().damping_iter(xs, gf, max_iter=3)
+        assert np.array_equal(out_g["trace"][:, 6], out_o["trace"][:, 6])
+        et, er = synth.pose_errors(out_g["poses"], out_o["poses"])
+        assert et < 1e-7 and er < 1e-7
+        ev_o, U_o, mg_o = f.read_cache(); ev_g, U_g, mg_g = gf.read_cache()
+        assert np.allclose(mg_g, mg_o, rtol=1e-9, atol=1e-9) and np.allclose(ev_g, ev_o, rtol=1e-7, atol=1e-10)
+        m.margi(win_count, out_o["poses"], f)
+        m.slide(1)
+        x_buf = [p for p in out_o["poses"][1:]]
+        win_count -= 1
+    assert estimated >= 4
