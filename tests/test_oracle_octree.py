@@ -221,3 +221,68 @@ def test_fewer_touched_roots_than_threads_pushes_nothing():
     m2 = O.LocalMapOracle(win_size=3, thread_num=2, **PRM)
     m2.cut_voxel(0, pts, np.tile(np.eye(3) * 1e-4, (4, 1, 1)), pts)
     assert sorted(m2.leaves()["pcr_add"][:, 9].tolist()) == [1, 1, 2]
+
+
+def test_cut_voxel_as_sort_and_segmented_continuation():
+    """The data-parallel formulation planned for the device-resident map (DESIGN.md section 7, step ii), spelled out in numpy and checked
+    against the tree walk: leaf id per point by descending a FLAT table of node ids (root key by the float-typed index, octants by strict
+    '>' against centres rebuilt with the float quarter lengths), one STABLE sort of the scan by leaf id, then every touched leaf continues
+    its running sums over its segment in scan order.  Same leaves (including the ones the scan creates), and pcr_add / pcrs_local equal to
+    the oracle's per-point `allocate` bit for bit."""
+    win = 4
+    states = list(run_stream(S=7, win=win, pts=6000, seed=8))
+    m = states[-1]["map"]                                   # a map with subdivided voxels, fix clusters and a shifted slot ring
+    before = m.leaves()
+    xyz, fp, poses, _ = synth.make_scans(win_size=8, pts_per_scan=6000, seed=synth.MASTER_SEED + 900 + 8)
+    s = slice(fp[7], fp[8])
+    pnt = xyz[s]; pw = to_world(poses[7], pnt); var = point_vars(pnt.shape[0], 99)
+    ord_ = win - 1                                          # the scan enters the last window position
+    m.cut_voxel(ord_, pnt, var, pw)
+    after = m.leaves()
+
+    vs = PRM["voxel_size"]; max_layer = PRM["max_layer"]
+    leaf_ids = set(before["node_id"].tolist())
+    # --- kernel 1: leaf id per point -------------------------------------------------------------------------------------------
+    loc = (pw / vs).astype(np.float32)
+    loc = np.where(loc < 0, loc - np.float32(1), loc).astype(np.int64)
+    root48 = ((loc[:, 0] + 32768) << 32) | ((loc[:, 1] + 32768) << 16) | (loc[:, 2] + 32768)
+    internal = set()                                         # subdivided nodes = proper prefixes of the leaves
+    for i in leaf_ids:
+        r, p, l = i >> 16, (i >> 7) & 0x1FF, i & 7
+        if l >= 1: internal.add((r << 16) | 0)
+        if l >= 2: internal.add((r << 16) | ((p & 0x1C0) << 7) | 1)
+    ids = np.zeros(pnt.shape[0], dtype=np.uint64)
+    for i in range(pnt.shape[0]):
+        r = int(root48[i]); path = 0; layer = 0
+        centre = (0.5 + loc[i]) * vs; ql = np.float32(vs / 4.0)
+        while ((r << 16) | (path << 7) | layer) in internal:   # a node that is neither leaf nor internal is allocated here, as a leaf
+            oct_ = [int(pw[i, k] > centre[k]) for k in range(3)]
+            path |= (4 * oct_[0] + 2 * oct_[1] + oct_[2]) << (3 * (2 - layer))
+            centre = centre + (2 * np.array(oct_) - 1) * float(ql); ql = np.float32(ql / np.float32(2)); layer += 1
+        ids[i] = (r << 16) | (path << 7) | layer
+    # --- kernel 2: stable sort by leaf id; kernel 3: one lane per touched leaf continues the sums in scan order ---------------------
+    order = np.argsort(ids, kind="stable")
+    sid = ids[order]
+    starts = np.concatenate([[0], np.nonzero(sid[1:] != sid[:-1])[0] + 1, [sid.size]])
+    row_before = {int(i): a for a, i in enumerate(before["node_id"].tolist())}
+    row_after = {int(i): a for a, i in enumerate(after["node_id"].tolist())}
+    assert set(row_after) == set(row_before) | set(sid.tolist())          # the same leaves exist afterwards, new ones included
+    new_leaves = 0
+    for a, b in zip(starts[:-1], starts[1:]):
+        nid = int(sid[a]); seg = order[a:b]
+        if nid in row_before:
+            add = before["pcr_add"][row_before[nid]].copy(); loc_cl = before["pcrs_local"][row_before[nid], ord_].copy()
+        else:
+            add = np.zeros(10); loc_cl = np.zeros(10); new_leaves += 1
+        for q in seg:                                          # PointCluster::push: P += v v^T (upper triangle), v += v, N += 1
+            for acc, v in ((add, pw[q]), (loc_cl, pnt[q])):
+                acc[0] += v[0] * v[0]; acc[1] += v[0] * v[1]; acc[2] += v[0] * v[2]; acc[3] += v[1] * v[1]; acc[4] += v[1] * v[2]; acc[5] += v[2] * v[2]
+                acc[6] += v[0]; acc[7] += v[1]; acc[8] += v[2]; acc[9] += 1
+        ra = row_after[nid]
+        assert np.array_equal(add, after["pcr_add"][ra]) and np.array_equal(loc_cl, after["pcrs_local"][ra, ord_])
+        kept = 0 if after["layer"][ra] == max_layer else seg.size
+        assert after["n_points"][ra, ord_] == (before["n_points"][row_before[nid], ord_] if nid in row_before else 0) + kept
+    assert new_leaves > 20 and len(starts) - 1 > 500
+    # untouched leaves did not change
+    untouched = [i for i in row_before if i not in set(sid.tolist())]
+    assert np.array_equal(before["pcr_add"][[row_before[i] for i in untouched]], after["pcr_add"][[row_after[i] for i in untouched]])
