@@ -389,6 +389,21 @@ def cpu_baseline(sc, f, budget_s):
     if wide > nthreads:
         tw, _, _ = fo.time_ba_iteration(sc.poses_init, wide, warmup=1, iters=max(2, min(20, int(budget_s / max(t1, 1e-3)))))
         out["all_cores"] = {"value": 1.0 / tw, "unit": "iterations/s", "cores": wide}
+    # the other half of BASELINE's metric ("pose RMSE vs ref"): one 3-iteration damping_iter of this window on the GPU and on the oracle
+    # from the same initial guess and cache.  Outside the timed region; never allowed to take the bench line down.
+    try:
+        import numpy as np
+        from voxel_slam_amd import synth, vxba
+        f.restore_cache()
+        got = vxba.Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=3)
+        fo.evaluate_only_residual(sc.poses_init)
+        ref = fo.damping_iter(sc.poses_init, max_iter=3, thd_num=wide)
+        et, er = synth.pose_errors(got["poses"], ref["poses"])
+        out["pose_rmse_vs_oracle_m_rad"] = [float(et), float(er)]
+        out["lm_trace_identical"] = bool(got["trace"].shape == ref["trace"].shape and np.array_equal(got["trace"][:, 6], ref["trace"][:, 6]))
+    except Exception as exc:   # noqa: BLE001
+        out["pose_rmse_vs_oracle_m_rad"] = None
+        out["parity_error"] = repr(exc)
     return out
 
 
