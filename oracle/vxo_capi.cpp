@@ -618,4 +618,25 @@ int64_t vxo_localmap_leaves(void* m, int64_t capacity, uint64_t* ids, int32_t* i
   }
   return (int64_t)lv.size();
 }
+
+// The points a leaf keeps for a later subdivision: which = -1 -> point_fix (world frame), which = i >= 0 -> the window's i-th scan
+// (sw->points[mp[i]], body frame).  out: n x 12 = [pnt 3 | var 9 col-major].  Returns the count (fills up to `capacity`), -1 if no such leaf.
+int64_t vxo_localmap_leaf_points(void* m, uint64_t node_id, int which, int64_t capacity, double* out) {
+  LocalMap* lm = (LocalMap*)m;
+  std::vector<LeafView> lv;
+  lm->leaves(lv);
+  for (const LeafView& v : lv) {
+    if (v.node_id != node_id) continue;
+    const std::vector<PointVar>* src = nullptr;
+    static const std::vector<PointVar> none;
+    if (which < 0) src = &v.node->point_fix;
+    else src = v.node->has_sw ? &v.node->points[lm->mp[which]] : &none;
+    for (int64_t i = 0; i < (int64_t)src->size() && i < capacity; i++) {
+      for (int k = 0; k < 3; k++) out[12 * i + k] = (*src)[i].pnt[k];
+      pack_m3_colmajor((*src)[i].var, out + 12 * i + 3);
+    }
+    return (int64_t)src->size();
+  }
+  return -1;
+}
 }  // extern "C"

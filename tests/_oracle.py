@@ -103,6 +103,8 @@ def lib():
     L.vxo_localmap_counts.argtypes = [vp, i64p]
     L.vxo_localmap_leaves.restype = C.c_int64
     L.vxo_localmap_leaves.argtypes = [vp, C.c_int64, u64p, i32p, f64p]
+    L.vxo_localmap_leaf_points.restype = C.c_int64
+    L.vxo_localmap_leaf_points.argtypes = [vp, C.c_uint64, C.c_int, C.c_int64, f64p]
     _LIB = L
     return L
 
@@ -455,6 +457,16 @@ class LocalMapOracle:
 
     def slide(self, mgsize=1):
         lib().vxo_localmap_slide(self._h, int(mgsize))
+
+    def leaf_points(self, node_id, which, cap=4096):
+        """Points a leaf keeps for a later subdivision: which = -1 the fix points (world), which = i the window's i-th scan (body): (n,3), (n,3,3)."""
+        buf = np.zeros((cap, 12))
+        n = lib().vxo_localmap_leaf_points(self._h, int(node_id), int(which), cap, buf)
+        if n < 0:
+            raise KeyError(node_id)
+        if n > cap:
+            return self.leaf_points(node_id, which, cap=int(n))
+        return buf[:n, :3].copy(), np.transpose(buf[:n, 3:].reshape(n, 3, 3), (0, 2, 1)).copy()
 
     def counts(self):
         out = np.zeros(4, dtype=np.int64)

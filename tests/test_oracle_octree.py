@@ -286,3 +286,103 @@ def test_cut_voxel_as_sort_and_segmented_continuation():
     # untouched leaves did not change
     untouched = [i for i in row_before if i not in set(sid.tolist())]
     assert np.array_equal(before["pcr_add"][[row_before[i] for i in untouched]], after["pcr_add"][[row_after[i] for i in untouched]])
+
+
+def push_seq(acc, v):
+    """PointCluster::push on the packed (P upper triangle, v, N) record, the oracle's operation order."""
+    acc[0] += v[0] * v[0]; acc[1] += v[0] * v[1]; acc[2] += v[0] * v[2]; acc[3] += v[1] * v[1]; acc[4] += v[1] * v[2]; acc[5] += v[2] * v[2]
+    acc[6] += v[0]; acc[7] += v[1]; acc[8] += v[2]; acc[9] += 1
+
+
+def node_centre(nid, vs):
+    """Centre and float quarter length of a node from its id, by the recurrences of cut_voxel / allocate."""
+    r = nid >> 16; path = (nid >> 7) & 0x1FF; layer = nid & 7
+    loc = np.array([((r >> 32) & 0xFFFF) - 32768, ((r >> 16) & 0xFFFF) - 32768, (r & 0xFFFF) - 32768], dtype=np.float64)
+    centre = (0.5 + loc) * vs; ql = np.float32(vs / 4.0)
+    for l in range(layer):
+        o = (path >> (3 * (2 - l))) & 7
+        centre = centre + (2 * np.array([(o >> 2) & 1, (o >> 1) & 1, o & 1]) - 1) * float(ql); ql = np.float32(ql / np.float32(2))
+    return centre, ql
+
+
+def test_recut_layer_by_layer_as_rebucketing():
+    """Step iii of the planned device formulation in numpy against the recursive `recut`: layer by layer, every leaf is
+    judged (point floor, eigen-decomposition, plane_judge); the ones that split hand their points to children by octant -- the fix points
+    first, then the window's scans in window order, each in stored order -- which is one stable sort of that sequence by child; the
+    children's running sums over their segments then equal the recursive walk bit for bit, flags included."""
+    win = 4
+    states = list(run_stream(S=7, win=win, pts=6000, seed=9))
+    m = states[-1]["map"]; x_buf = [p for p in states[-1]["x_buf"][1:]]
+    xyz, fp, poses, _ = synth.make_scans(win_size=8, pts_per_scan=6000, seed=synth.MASTER_SEED + 900 + 9)
+    s = slice(fp[7], fp[8])
+    pw = to_world(poses[7], xyz[s])
+    m.cut_voxel(win - 1, xyz[s], point_vars(pw.shape[0], 5), pw)
+    x_buf.append(poses[7].copy()); xs = np.stack(x_buf); win_count = win
+    before = m.leaves()
+    pts_of = {}
+    for a in np.nonzero((before["layer"] < 2) & before["has_sw"] & before["in_slide"])[0]:
+        nid = int(before["node_id"][a])
+        pts_of[nid] = [m.leaf_points(nid, -1)[0]] + [m.leaf_points(nid, i)[0] for i in range(win_count)]
+    f = O.Oracle(win)
+    m.recut(win_count, xs, f)
+    after = m.leaves()
+    row_after = {int(i): a for a, i in enumerate(after["node_id"].tolist())}
+
+    vs = PRM["voxel_size"]; max_layer = PRM["max_layer"]
+    # the work list of a layer: leaves as records (id, pcr_add, pcr_fix, window clusters, point lists [fix, scan 0, scan 1, ...])
+    work = []
+    for a in np.nonzero(before["in_slide"])[0]:
+        nid = int(before["node_id"][a])
+        work.append(dict(id=nid, add=before["pcr_add"][a].copy(), fix=before["pcr_fix"][a].copy(), loc=before["pcrs_local"][a].copy(),
+                         isexist=bool(before["isexist"][a]), has_sw=bool(before["has_sw"][a]), was_plane=bool(before["is_plane"][a]), pts=pts_of.get(nid)))
+    split_total = 0
+    checked = 0
+    while work:
+        nxt = []
+        ev_all, _ = O.plane_fit(np.stack([w["add"] for w in work]))
+        for w, ev in zip(work, ev_all):
+            layer = w["id"] & 7
+            N = w["add"][9]
+            ra = row_after.get(w["id"])
+            if N <= PRM["min_point"][layer]:
+                assert ra is not None and not after["is_plane"][ra]; checked += 1
+                continue
+            if not w["isexist"] or not w["has_sw"]:
+                assert ra is not None and after["is_plane"][ra] == w["was_plane"]; checked += 1
+                continue
+            plane = bool(ev[0] < PRM["min_eigen_value"] and ev[0] / ev[2] < PRM["plane_eigen_value_thre"][layer])
+            if plane or layer >= max_layer:
+                assert ra is not None and bool(after["is_plane"][ra]) == plane; checked += 1
+                assert np.array_equal(after["pcr_add"][ra], w["add"]) and np.array_equal(after["pcr_fix"][ra], w["fix"]) and np.array_equal(after["pcrs_local"][ra], w["loc"])
+                continue
+            # --- split: one sequence [fix | scan 0 | scan 1 | ...], child id per element, stable sort, segmented sums ---------------
+            assert ra is None                                                   # the node is internal afterwards
+            split_total += 1
+            centre, ql = node_centre(w["id"], vs)
+            seq_w, seq_b, seq_src = [], [], []
+            for src, P in enumerate(w["pts"]):                                  # src 0 = fix (world), src i+1 = scan i of the window (body)
+                if P.shape[0] == 0:
+                    continue
+                W_ = P if src == 0 else to_world(xs[src - 1], P)
+                seq_w.append(W_); seq_b.append(P); seq_src.append(np.full(P.shape[0], src))
+            W_ = np.concatenate(seq_w); B_ = np.concatenate(seq_b); SRC = np.concatenate(seq_src)
+            octant = 4 * (W_[:, 0] > centre[0]) + 2 * (W_[:, 1] > centre[1]) + (W_[:, 2] > centre[2])
+            order = np.argsort(octant, kind="stable")
+            for o in np.unique(octant):
+                seg = order[octant[order] == o]
+                r = w["id"] >> 16; path = ((w["id"] >> 7) & 0x1FF) | (int(o) << (3 * (2 - layer)))
+                cid = (r << 16) | (path << 7) | (layer + 1)
+                child = dict(id=cid, add=np.zeros(10), fix=np.zeros(10), loc=np.zeros((win, 10)), isexist=False, has_sw=False, was_plane=False,
+                             pts=[[] for _ in range(win_count + 1)])
+                for q in seg:
+                    if SRC[q] == 0:                                             # push_fix: pcr_fix and pcr_add take the world point
+                        push_seq(child["fix"], W_[q]); push_seq(child["add"], W_[q])
+                    else:                                                       # push: window cluster takes the body point, pcr_add the world point
+                        push_seq(child["loc"][SRC[q] - 1], B_[q]); push_seq(child["add"], W_[q])
+                        child["isexist"] = True; child["has_sw"] = True
+                    if layer + 1 < max_layer:
+                        child["pts"][SRC[q]].append(W_[q] if SRC[q] == 0 else B_[q])
+                child["pts"] = [np.array(p).reshape(-1, 3) for p in child["pts"]]
+                nxt.append(child)
+        work = nxt
+    assert split_total > 20 and checked > 1000
