@@ -99,7 +99,7 @@ class LidarFactor {
       M3 ukukT = outer(uk, uk);
       M3 umumT = zero33();
       for (int i = 0; i < 3; i++)
-        if (i != kk) umumT = umumT + (2.0 / (lmbd[kk] - lmbd[i])) * outer(u[i], u[i]);
+        if (i != kk) umumT = umumT + outer((2.0 / (lmbd[kk] - lmbd[i])) * u[i], u[i]);   // (s * u_i) * u_i^T, the reference's association (:172)
 
       for (int i = 0; i < win_size; i++)
         if (sig_orig[i].N != 0) {
@@ -136,7 +136,8 @@ class LidarFactor {
           M3 HRt = (2.0 / NN * (1.0 - ni / NN)) * viRiTukukT[i];
           double Hb[6][6];
           aT_m_b(Auk[i].a, umumT, Auk[i].a, Hb);
-          M3 blk = (2.0 / NN) * ((combo1 - RiTukhat * Pi) * RiTukhat) - (2.0 / NN / NN) * outer(viRiTuk[i], viRiTuk[i]) -
+          // :208, associated as the expression text is: ((2/NN) * (..)) * RiTukhat  and  ((2/NN/NN) * v) * v^T
+          M3 blk = ((2.0 / NN) * (combo1 - RiTukhat * Pi)) * RiTukhat - outer((2.0 / NN / NN) * viRiTuk[i], viRiTuk[i]) -
                    0.5 * hat(v3(jjt[0], jjt[1], jjt[2]));
           for (int r = 0; r < 3; r++)
             for (int c = 0; c < 3; c++) {
@@ -157,10 +158,10 @@ class LidarFactor {
               double nj = sig_orig[j].N;
               double Hb[6][6];
               aT_m_b(Auk[i].a, umumT, Auk[j].a, Hb);
-              M3 ww = outer(viRiTuk[i], viRiTuk[j]);
+              M3 ww = outer((-2.0 / NN / NN) * viRiTuk[i], viRiTuk[j]);   // ((-2/NN/NN) * v_i) * v_j^T (:225)
               for (int r = 0; r < 3; r++)
                 for (int c = 0; c < 3; c++) {
-                  Hb[r][c] += -2.0 / NN / NN * ww(r, c);
+                  Hb[r][c] += ww(r, c);
                   Hb[r][c + 3] += -2.0 * nj / NN / NN * viRiTukukT[i](r, c);
                   Hb[r + 3][c] += -2.0 * ni / NN / NN * viRiTukukT[j](c, r);
                   Hb[r + 3][c + 3] += -2.0 * ni * nj / NN / NN * ukukT(r, c);

@@ -85,7 +85,7 @@ inline M3 Exp(const V3& ang_vel, double dt) {
     const V3 axis = ang_vel / n;
     const M3 K = hat(axis);
     const double a = n * dt;
-    return eye33() + std::sin(a) * K + (1.0 - std::cos(a)) * (K * K);
+    return eye33() + std::sin(a) * K + ((1.0 - std::cos(a)) * K) * K;
   }
   return eye33();
 }
@@ -95,7 +95,7 @@ inline M3 jr(V3 vec) {
   if (ang < 1e-9) return eye33();
   vec = vec / ang;
   const double ra = std::sin(ang) / ang;
-  return ra * eye33() + (1 - ra) * outer(vec, vec) - ((1 - std::cos(ang)) / ang) * hat(vec);
+  return ra * eye33() + outer((1 - ra) * vec, vec) - ((1 - std::cos(ang)) / ang) * hat(vec);   // ((1-ra)*vec)*vec^T, as the reference's text associates
 }
 // rotation matrix -> (angle in [0, pi], unit axis), the way Eigen's AngleAxisd(Matrix3d) gets there
 inline void angle_axis(const M3& R, double& angle, V3& axis) {
@@ -136,7 +136,7 @@ inline M3 jr_inv(const M3& rotR) {
   angle_axis(rotR, ang, axi);
   if (ang < 1e-9) return eye33();
   const double ctt = ang / 2 / std::tan(ang / 2);
-  return ctt * eye33() + (1 - ctt) * outer(axi, axi) + (ang / 2) * hat(axi);
+  return ctt * eye33() + outer((1 - ctt) * axi, axi) + (ang / 2) * hat(axi);
 }
 
 // tools.hpp:135-199 (the fields the BA touches)

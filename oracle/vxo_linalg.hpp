@@ -84,7 +84,7 @@ inline M3 Exp(const V3& ang) {
   if (ang_norm >= 1e-11) {
     V3 axis = ang / ang_norm;
     M3 K = hat(axis);
-    return eye33() + std::sin(ang_norm) * K + (1.0 - std::cos(ang_norm)) * (K * K);
+    return eye33() + std::sin(ang_norm) * K + ((1.0 - std::cos(ang_norm)) * K) * K;   // the reference's association: (s*K)*K
   }
   return eye33();
 }

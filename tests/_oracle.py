@@ -8,20 +8,44 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = None
+# tests/_ref.py loads a second instance of this module with these three overridden: the same wrapper then drives
+# oracle/_ref/libref.so (the reference's own headers compiled in place), which exports the same vxo_* names for the part it covers.
+LIB_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
+MAKE_TARGET = "all"
+PARTIAL = False
 
 f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 
 
 def build_oracle():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), MAKE_TARGET])
+
+
+class _Partial:
+    """CDLL proxy for a library that exports only part of the surface: prototypes of missing symbols are dropped silently,
+    calling one raises AttributeError."""
+
+    class _Sink:
+        pass
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._cdll, name)
+        except AttributeError:
+            if name.startswith("vxo_"):
+                return _Partial._Sink()
+            raise
 
 
 def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    path = LIB_PATH
     if not os.path.exists(path):
         build_oracle()
     else:
@@ -30,6 +54,8 @@ def lib():
         except (OSError, subprocess.CalledProcessError):
             pass
     L = C.CDLL(path)
+    if PARTIAL:
+        L = _Partial(L)
     L.vxo_create.restype = C.c_void_p
     L.vxo_create.argtypes = [C.c_int]
     L.vxo_destroy.argtypes = [C.c_void_p]
