@@ -49,27 +49,94 @@ inline void unpack_imu_bias_deltas(const double* b, ImuT& f) {   // the only fie
   get3(b + 67, f.dbg); get3(b + 70, f.dba); get3(b + 73, f.dbg_buf); get3(b + 76, f.dba_buf);
 }
 
-template <class StateT, class ImuT, class MatXT, class LidarFactorAdapter>
+template <class StateT, class ImuT>
+struct LiPack {
+  std::vector<double> st, im;
+  int W;
+  LiPack(const std::vector<StateT>& x_stats, const std::deque<ImuT*>& imus_factor, int win_size) : W(win_size) {
+    st.resize((size_t)VXBA_STATE_LEN * W);
+    im.resize((size_t)VXBA_IMU_LEN * (W > 1 ? W - 1 : 0));
+    for (int i = 0; i < W; i++) pack_state(x_stats[i], &st[(size_t)VXBA_STATE_LEN * i]);
+    for (int i = 0; i + 1 < W; i++) pack_imu(*imus_factor[i], &im[(size_t)VXBA_IMU_LEN * i]);
+  }
+  void unpack(std::vector<StateT>& x_stats, std::deque<ImuT*>& imus_factor, bool with_gravity) {
+    for (int i = 0; i < W; i++) {
+      unpack_state(&st[(size_t)VXBA_STATE_LEN * i], x_stats[i]);
+      if (with_gravity) get3(&st[(size_t)VXBA_STATE_LEN * i + 21], x_stats[i].g);
+    }
+    for (int i = 0; i + 1 < W; i++) unpack_imu_bias_deltas(&im[(size_t)VXBA_IMU_LEN * i], *imus_factor[i]);
+  }
+};
+
+inline void li_check(vxba_factor* h, int rc) {
+  if (rc != VXBA_OK) throw std::runtime_error(std::string("vxba: ") + vxba_last_error(h));
+}
+
+template <class StateT, class ImuT, class MatXT, class VecXT, class LidarFactorAdapter>
 class LI_BA_OptimizerT {
  public:
   int win_size = 0, jac_leng = 0, imu_leng = 0;
   double imu_coef = 1e-4;   // the reference's file-scope `imu_coef` (voxel_map.hpp:446, voxelslam.cpp:822)
   int max_iter = 3;         // hard-coded upstream (:580)
 
+  // voxel_map.hpp:455-463
+  void hess_plus(MatXT& Hess, VecXT& JacT, MatXT& hs, VecXT& js) { vxba_hess_plus(win_size, Hess.data(), JacT.data(), hs.data(), js.data()); }
+
+  // voxel_map.hpp:465-523: the joint (15W) system; Hess / JacT pre-sized by the caller as upstream
+  double divide_thread(std::vector<StateT>& x_stats, LidarFactorAdapter& voxhess, std::deque<ImuT*>& imus_factor, MatXT& Hess, VecXT& JacT) {
+    vxba_factor* h = voxhess.handle();
+    win_size = voxhess.win_size; jac_leng = 6 * win_size; imu_leng = VXBA_LI_DIM * win_size;
+    LiPack<StateT, ImuT> pk(x_stats, imus_factor, win_size);
+    double residual = 0;
+    li_check(h, vxba_li_evaluate(h, pk.st.data(), pk.im.data(), imu_coef, Hess.data(), JacT.data(), &residual));
+    return residual;
+  }
+  // voxel_map.hpp:525-560
+  double only_residual(std::vector<StateT>& x_stats, LidarFactorAdapter& voxhess, std::deque<ImuT*>& imus_factor) {
+    vxba_factor* h = voxhess.handle();
+    win_size = voxhess.win_size; jac_leng = 6 * win_size; imu_leng = VXBA_LI_DIM * win_size;
+    LiPack<StateT, ImuT> pk(x_stats, imus_factor, win_size);
+    double residual = 0;
+    li_check(h, vxba_li_only_residual(h, pk.st.data(), pk.im.data(), imu_coef, &residual));
+    voxhess.invalidate_cache();
+    return residual;
+  }
   // voxel_map.hpp:562-653
   void damping_iter(std::vector<StateT>& x_stats, LidarFactorAdapter& voxhess, std::deque<ImuT*>& imus_factor, MatXT* hess) {
     vxba_factor* h = voxhess.handle();   // uploads staged voxels
     win_size = voxhess.win_size;
     jac_leng = 6 * win_size;
     imu_leng = VXBA_LI_DIM * win_size;
-    std::vector<double> st((size_t)VXBA_STATE_LEN * win_size), im((size_t)VXBA_IMU_LEN * (win_size > 1 ? win_size - 1 : 0));
-    for (int i = 0; i < win_size; i++) pack_state(x_stats[i], &st[(size_t)VXBA_STATE_LEN * i]);
-    for (int i = 0; i + 1 < win_size; i++) pack_imu(*imus_factor[i], &im[(size_t)VXBA_IMU_LEN * i]);
+    LiPack<StateT, ImuT> pk(x_stats, imus_factor, win_size);
     hess->resize(imu_leng, imu_leng);
-    if (vxba_li_damping_iter(h, st.data(), im.data(), imu_coef, max_iter, hess->data(), nullptr, nullptr) != VXBA_OK)
-      throw std::runtime_error(std::string("vxba: ") + vxba_last_error(h));
-    for (int i = 0; i < win_size; i++) unpack_state(&st[(size_t)VXBA_STATE_LEN * i], x_stats[i]);
-    for (int i = 0; i + 1 < win_size; i++) unpack_imu_bias_deltas(&im[(size_t)VXBA_IMU_LEN * i], *imus_factor[i]);
+    li_check(h, vxba_li_damping_iter(h, pk.st.data(), pk.im.data(), imu_coef, max_iter, hess->data(), nullptr, nullptr));
+    pk.unpack(x_stats, imus_factor, false);
+    voxhess.invalidate_cache();
+  }
+};
+
+// LI_BA_OptimizerGravity (voxel_map.hpp:659-864): the gravity vector joins the unknowns (15W + 3); every frame's g leaves equal.
+template <class StateT, class ImuT, class MatXT, class VecXT, class LidarFactorAdapter>
+class LI_BA_OptimizerGravityT {
+ public:
+  int win_size = 0, jac_leng = 0, imu_leng = 0;
+  double imu_coef = 1e-4;
+
+  // voxel_map.hpp:775-862.  Upstream never resizes *hess (the caller's matrix already has the shape); it is resized here if it has not.
+  void damping_iter(std::vector<StateT>& x_stats, LidarFactorAdapter& voxhess, std::deque<ImuT*>& imus_factor, std::vector<double>& resis,
+                    MatXT* hess, int max_iter = 2) {
+    vxba_factor* h = voxhess.handle();
+    win_size = voxhess.win_size;
+    jac_leng = 6 * win_size;
+    imu_leng = VXBA_LI_DIM * win_size + 3;
+    LiPack<StateT, ImuT> pk(x_stats, imus_factor, win_size);
+    if ((int)hess->rows() != imu_leng || (int)hess->cols() != imu_leng) hess->resize(imu_leng, imu_leng);
+    double rs[2] = {0, 0};
+    li_check(h, vxba_li_damping_iter_gravity(h, pk.st.data(), pk.im.data(), imu_coef, max_iter, hess->data(), rs, nullptr, nullptr));
+    pk.unpack(x_stats, imus_factor, true);
+    resis.push_back(rs[0]);
+    resis.push_back(rs[1]);
+    voxhess.invalidate_cache();
   }
 };
 

@@ -159,7 +159,9 @@ void write_trace(const std::vector<vxref::TraceRow>& tr, double* trace_out, int*
 extern "C" {
 
 const char* vxo_backend() {
-#ifdef VXO_EIGEN_SHIM
+#if defined(VXREF_DROPIN)
+  return "reference OctoTree / OctreeGBA / call sites + vxba_voxel_map.hpp (LidarFactor and the three optimizers on libvxba.so)";
+#elif defined(VXO_EIGEN_SHIM)
   return "reference headers (unmodified) + Eigen API shim";
 #else
   return "reference headers (unmodified) + real Eigen";

@@ -15,26 +15,49 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libref.so")
+DROPIN_LIB = os.path.join(ROOT, "oracle", "_ref", "libdropin.so")
 _BACKEND = None
+_DROPIN = None
 
 
 def available():
     return backend() is not None
 
 
-def backend():
-    global _BACKEND
-    if _BACKEND is not None:
-        return _BACKEND or None
-    spec = importlib.util.spec_from_file_location("tests._ref_backend", os.path.join(_HERE, "_oracle.py"))
+def _load(name, path, target):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(_HERE, "_oracle.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    mod.LIB_PATH = REF_LIB
-    mod.MAKE_TARGET = "ref"
+    mod.LIB_PATH = path
+    mod.MAKE_TARGET = target
     mod.PARTIAL = True
     try:
         mod.lib()
     except (OSError, Exception):
+        return None
+    return mod
+
+
+def dropin():
+    """The reference's OctoTree / OctreeGBA / call sequences compiled on top of include/vxba_voxel_map.hpp (`make -C oracle dropin`):
+    same wrapper again, but every LidarFactor / optimizer call lands in libvxba.so -- needs the GPU."""
+    global _DROPIN
+    if _DROPIN is None:
+        mod = _load("tests._dropin_backend", DROPIN_LIB, "dropin")
+        if mod is not None:
+            L = mod.lib()
+            L.vxo_backend.restype = C.c_char_p
+            mod.BACKEND_NAME = L.vxo_backend().decode()
+        _DROPIN = mod or False
+    return _DROPIN or None
+
+
+def backend():
+    global _BACKEND
+    if _BACKEND is not None:
+        return _BACKEND or None
+    mod = _load("tests._ref_backend", REF_LIB, "ref")
+    if mod is None:
         _BACKEND = False
         return None
     L = mod.lib()

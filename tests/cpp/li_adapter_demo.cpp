@@ -36,7 +36,7 @@ struct IMU_PRE {                                                                
 };
 
 using LidarFactor = vxba::LidarFactorT<PointCluster, IMUST, Vec3, Mat3, MatX, VecX>;
-using LI_BA_Optimizer = vxba::LI_BA_OptimizerT<IMUST, IMU_PRE, MatX, LidarFactor>;
+using LI_BA_Optimizer = vxba::LI_BA_OptimizerT<IMUST, IMU_PRE, MatX, VecX, LidarFactor>;
 
 static PointCluster unpack(const double* c) {
   PointCluster pc;

@@ -82,8 +82,9 @@ def test_cfg3_fp64_lm_matches_the_checkers(vx):
 
 
 def test_cfg2_window_with_rejected_steps_matches_the_checkers(vx):
-    """SURVEY 8d's own initial-guess recipe (0.5 deg / 0.03 m) on the cfg2 window: with voxels up to 100 m from the sensor the first
-    trial steps overshoot and are rejected (u *= v, v *= 2, no Hessian recompute, cache left at the rejected trial state), later ones
-    are accepted."""
-    sc = synth.make_config("cfg2", rot_sigma_deg=0.5, trans_sigma=0.03)
-    run_case(vx, sc, iters=7, need_reject=True)
+    """A cfg2 window started 0.2 deg / 0.03 m off (4x the bench's perturbation): the first four trial steps overshoot and are rejected
+    (u *= v, v *= 2, no Hessian recompute, cache left at the rejected trial state), the next four are accepted.  (SURVEY 8d's 0.5 deg
+    is outside the basin at this size -- voxels up to 100 m from the sensor: the reference's own LM rejects every step until the
+    relative-change test stops it; checked on the oracle, nine iterations.)"""
+    sc = synth.make_config("cfg2", rot_sigma_deg=0.2, trans_sigma=0.03)
+    run_case(vx, sc, iters=8, need_reject=True)
