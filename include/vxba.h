@@ -254,6 +254,19 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
 int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out,
                                  double* resis_out, double* trace_out, int* n_trace);
 
+/* ---- execution options (per handle; none of them changes results beyond rounding) -----------------------------------------
+ * Every switch that used to be an environment variable is a setter.  The environment variables of the same name
+ * (VXBA_FUSED_SOLVE, VXBA_SPEC_COLLECTIVE, VXBA_WIDE_DEVICE_SOLVE, VXBA_LI_DEVICE, VXBA_K2_VPB, VXBA_LIO_DEVICE_EKF) still give the
+ * INITIAL value of a new handle -- for A/B scripts -- and nothing reads them after vxba_create / vxba_lio_create. */
+#define VXBA_OPT_FUSED_SOLVE 0        /* 1 (default): the 6W damped solve runs as workgroup 0 of the residual-sweep launch; 0: own launch */
+#define VXBA_OPT_SPEC_COLLECTIVE 1    /* 1 (default): sharded LM loop with ONE all-reduce per iteration (speculative Hessian sweep at the trial poses) */
+#define VXBA_OPT_WIDE_DEVICE_SOLVE 2  /* 0 (default): host pivoted LDL^T for W > 10; 1: hipSOLVER Cholesky on the device (loads hipSOLVER on first use) */
+#define VXBA_OPT_LI_DEVICE_LOOP 3     /* LI_BA_Optimizer loop: 0 = host shell between the GPU sweeps, 1 = whole loop device-resident */
+#define VXBA_OPT_K2_VOXELS_PER_BLOCK 4 /* 64 (default) or 32..63: voxels per residual-sweep workgroup (tuning experiment) */
+#define VXBA_OPT_COUNT 5
+int vxba_set_option(vxba_factor* f, int option, int value);
+int vxba_get_option(const vxba_factor* f, int option, int* value);
+
 /* Arithmetic of the Hessian sweep (BASELINE.json configs[2], the mixed-precision tolerance study).  F64 (default): fp64
  * throughout, like the reference.  MIXED: the rank-3 rows of every voxel ("Jacobian") are rounded to f32 and multiplied on the
  * f32 matrix cores, summed in f32 inside one wave (<= 72 voxels) and accumulated in f64 across waves, workgroups and GPUs;
@@ -279,6 +292,10 @@ typedef struct vxba_lio vxba_lio; /* opaque: one plane map (`surf_map`) + the cu
 
 /* voxel_size / max_layer: the reference's globals (voxel_map.hpp:86-88; max_layer <= 3 here). */
 int vxba_lio_create(double voxel_size, int max_layer, int device, vxba_lio** out);
+/* VXBA_LIO_OPT_DEVICE_EKF: 1 (default) = the 15x15 EKF update between sweeps runs as a kernel, whole state estimation enqueued
+ * up front; 0 = the algebra on the host between sweeps. */
+#define VXBA_LIO_OPT_DEVICE_EKF 0
+int vxba_lio_set_option(vxba_lio* h, int option, int value);
 int vxba_lio_destroy(vxba_lio* h);
 const char* vxba_lio_last_error(const vxba_lio* h);
 

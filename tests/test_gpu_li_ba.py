@@ -58,11 +58,12 @@ def test_joint_system_matches_oracle(vx, W, V, pts):
 
 @pytest.mark.parametrize("device_loop", [False, True])
 @pytest.mark.parametrize("W,V,pts,iters", [(5, 800, 8000, 3), (10, 3000, 40000, 6), (2, 300, 4000, 4)])
-def test_li_damping_iter_matches_oracle(vx, W, V, pts, iters, device_loop, monkeypatch):
+def test_li_damping_iter_matches_oracle(vx, W, V, pts, iters, device_loop):
     """device_loop: the whole loop enqueued on the GPU (IMU factor kernels, Schur solve over the block-tridiagonal velocity-bias part,
-    accept / reject on the device; VXBA_LI_DEVICE=1) instead of the host shell between the sweeps -- same contract."""
-    monkeypatch.setenv("VXBA_LI_DEVICE", "1" if device_loop else "0")
+    accept / reject on the device; vxba_set_option(VXBA_OPT_LI_DEVICE_LOOP, 1)) instead of the host shell between the sweeps -- same contract."""
     sc, iw, blobs, facs, fo, fg = build(vx, W, V, pts, seed=600 + W)
+    fg.set_option("li_device_loop", 1 if device_loop else 0)
+    assert fg.get_option("li_device_loop") == (1 if device_loop else 0)
     ref = O.li_damping_iter(fo, iw.states_init, blobs, max_iter=iters, thd_num=5, imu_coef=1e-4)
     got = vx.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(iw.states_init, fg, facs, max_iter=iters)
     assert got["trace"].shape == ref["trace"].shape

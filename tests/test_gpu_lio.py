@@ -117,13 +117,13 @@ def test_var_init_and_pvec_update(vx):
 
 @pytest.mark.parametrize("device_ekf", ["1", "0"])
 @pytest.mark.parametrize("seed,n_roots,n_points,raw", [(2400, 3000, 40000, True), (2410, 800, 6000, False), (2420, 6000, 100000, True)])
-def test_state_estimation_matches_oracle(vx, seed, n_roots, n_points, raw, device_ekf, monkeypatch):
+def test_state_estimation_matches_oracle(vx, seed, n_roots, n_points, raw, device_ekf):
     """device_ekf: the 15-dimensional EKF algebra between the sweeps as a kernel, all iterations enqueued up front (default), or on the
-    host with a round trip per iteration (VXBA_LIO_DEVICE_EKF=0)."""
-    monkeypatch.setenv("VXBA_LIO_DEVICE_EKF", device_ekf)
+    host with a round trip per iteration (vxba_lio_set_option(VXBA_LIO_OPT_DEVICE_EKF, 0))."""
     pm = synth.make_plane_map(n_roots=n_roots, extent=10, seed=seed)
     sc = synth.make_lio_scan(pm, n_points=n_points, seed=seed + 1)
     o, g = both(vx, pm, sc, raw=raw)
+    g.set_option("device_ekf", int(device_ekf))
     ref = o.lio_state_estimation(sc.state_init, sc.cov); got = g.lio_state_estimation(sc.state_init, sc.cov)
     assert got["iterations"] == ref["iterations"] and got["ok"] == ref["ok"] and got["match_num"] == ref["match_num"]
     for a, b in zip(got["sweeps"], ref["sweeps"]):

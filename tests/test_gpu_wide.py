@@ -75,13 +75,13 @@ def test_wide_lm_matches_oracle(vx, W, V, pts, p_obs):
     assert e1[0] < 0.5 * e0[0]
 
 
-def test_wide_lm_device_cholesky_opt_in(vx, monkeypatch):
-    """VXBA_WIDE_DEVICE_SOLVE=1: the damped system is factorised on the GPU (hipSOLVER potrf/potrs on the assembled 6W x 6W
+def test_wide_lm_device_cholesky_opt_in(vx):
+    """vxba_set_option(VXBA_OPT_WIDE_DEVICE_SOLVE, 1): the damped system is factorised on the GPU (hipSOLVER potrf/potrs on the assembled 6W x 6W
     matrix) instead of the host LDLT; same decisions, same poses.  Off by default because of its one-off library load."""
-    monkeypatch.setenv("VXBA_WIDE_DEVICE_SOLVE", "1")
     W, V = 48, 3000
     sc = synth.make_scene(win_size=W, pts_per_scan=5000, n_voxels=V, p_obs=0.08, seed=1350, rot_sigma_deg=0.1, trans_sigma=0.03)
     fo, fg = pair(vx, sc)
+    fg.set_option("wide_device_solve", 1)
     ref = fo.damping_iter(sc.poses_init, max_iter=4, thd_num=4)
     got = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=4)
     assert np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:]) and np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-9)

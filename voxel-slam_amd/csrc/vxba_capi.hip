@@ -66,6 +66,7 @@ struct vxba_factor {
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
   vxw::DenseSolver* wide_solver = nullptr;   // wide windows: device Cholesky of the (6W)-dimensional LM step (hipSOLVER, loaded on first use)
   bool wide_solver_tried = false;
+  int opt[VXBA_OPT_COUNT] = {1, 1, 0, 0, 64};   // vxba_set_option; initial values may come from the environment (see vxba.h)
   vxw::WideIndex wide;           // wide windows: incidence structure (entries, entry pairs per Hessian block), rebuilt after a push
   bool wide_dirty = true;
   double* d_poses = nullptr;     // wide windows: W*12 poses on the device (the MFMA kernels take them by value)
@@ -257,9 +258,16 @@ int shard_allreduce(vxba_factor* f, double* d_buf, size_t count) {
   return VXBA_OK;
 }
 
-bool fused_solve() {
-  static const bool on = [] { const char* e = getenv("VXBA_FUSED_SOLVE"); return !(e && e[0] == '0'); }();
-  return on;
+bool fused_solve(const vxba_factor* f) { return f->opt[VXBA_OPT_FUSED_SOLVE] != 0; }
+void options_from_env(vxba_factor* f) {   // initial values only; vxba_set_option is the interface
+  auto flag = [](const char* name, int dflt) { const char* e = getenv(name); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : dflt; };
+  f->opt[VXBA_OPT_FUSED_SOLVE] = flag("VXBA_FUSED_SOLVE", 1);
+  f->opt[VXBA_OPT_SPEC_COLLECTIVE] = flag("VXBA_SPEC_COLLECTIVE", 1);
+  f->opt[VXBA_OPT_WIDE_DEVICE_SOLVE] = flag("VXBA_WIDE_DEVICE_SOLVE", 0);
+  f->opt[VXBA_OPT_LI_DEVICE_LOOP] = flag("VXBA_LI_DEVICE", 0);
+  const char* e = getenv("VXBA_K2_VPB");
+  const int v = e ? atoi(e) : 64;
+  f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] = (v >= 32 && v <= 64) ? v : 64;
 }
 
 int upload_poses(vxba_factor* f, const double* Rp) {
@@ -349,10 +357,10 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, in
   int nparts;
   if (f->profiling & 2) {
     hipEvent_t a = get_event(f), b = get_event(f);
-    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, f->d_partial2, f->cus, f->stream, a, b);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, f->d_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK], f->stream, a, b);
     if (a && b) f->pending.push_back({a, b, 1});
   } else {
-    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, f->d_partial2, f->cus, f->stream);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, f->d_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK], f->stream);
   }
   if (nparts_out) *nparts_out = nparts;
   if (d_out) {
@@ -371,8 +379,7 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, in
 // partial-sum kernel.  Needs the scalar exchange buffer directly behind the packed one (true for the factor's own buffers and for
 // dist.attach_allreduce's tensor); VXBA_SPEC_COLLECTIVE=0 falls back to the two-collective loop.
 bool spec_collective(const vxba_factor* f) {
-  static const bool on = [] { const char* e = getenv("VXBA_SPEC_COLLECTIVE"); return !(e && e[0] == '0'); }();
-  return on && has_collective(f) && !is_wide(f) && f->d_scalar == f->d_packed + vxba_packed_len(f);
+  return f->opt[VXBA_OPT_SPEC_COLLECTIVE] != 0 && has_collective(f) && !is_wide(f) && f->d_scalar == f->d_packed + vxba_packed_len(f);
 }
 
 int spec_hess_phase(vxba_factor* f, const double* Rp0, int* c, bool first_of_solve, bool has_pending, bool restart, const double* cache_src,
@@ -494,6 +501,7 @@ int vxba_create(int win_size, int device, vxba_factor** out) {
   f->W = win_size;
   f->device = device;
   f->cus = prop.multiProcessorCount;
+  options_from_env(f);
   auto bail = [&](hipError_t) { vxba_destroy(f); return VXBA_ERR_HIP; };
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e);
@@ -901,8 +909,7 @@ int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out
     if (!f->wide_solver && !f->wide_solver_tried) {
       // opt-in: the first use pulls hipSOLVER + rocSOLVER + rocBLAS into the process, which costs seconds when they are warm and
       // minutes when they come off a cold disk -- worth it for a long-running mapper, not for a default
-      const char* wenv = getenv("VXBA_WIDE_DEVICE_SOLVE");
-      const bool allow = wenv && wenv[0] == '1';
+      const bool allow = f->opt[VXBA_OPT_WIDE_DEVICE_SOLVE] != 0;
       if (allow) f->wide_solver = vxw::wide_solver_create(n, f->stream);
       f->wide_solver_tried = true;
     }
@@ -982,7 +989,7 @@ int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out
   for (int i = 0; spec && i < max_iter; i++) {
     int rc = spec_hess_phase(f, Rp, &c, i == 0, i > 0, false, nullptr, spec_nparts);
     if (rc) return rc;
-    const unsigned seq = fused_solve() ? ++f->lm_seq : 0u;
+    const unsigned seq = fused_solve(f) ? ++f->lm_seq : 0u;
     if (!seq) vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
     rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, nullptr, &spec_nparts, seq);
     if (rc) return rc;
@@ -993,7 +1000,7 @@ int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out
     if (rc) return rc;
     // damped solve + residual sweep at the trial state: one launch (the solve is workgroup 0 of the sweep) unless
     // VXBA_FUSED_SOLVE=0; without a collective the sweep's wave partials are summed by whoever takes the decision
-    const unsigned seq = fused_solve() ? ++f->lm_seq : 0u;
+    const unsigned seq = fused_solve(f) ? ++f->lm_seq : 0u;
     if (!seq) vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
     int nparts = 0;
     rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts, seq);
@@ -1083,7 +1090,7 @@ int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_
     const bool last = ((s + 1) % steps_per_solve) == 0 && s + 1 < n_steps;
     int rc = spec_hess_phase(f, Rp_init, &c, first, s > 0, prev_last, first ? f->snapshot : nullptr, spec_nparts);
     if (rc) return rc;
-    const unsigned seq = fused_solve() ? ++f->lm_seq : 0u;
+    const unsigned seq = fused_solve(f) ? ++f->lm_seq : 0u;
     if (!seq) vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
     rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, nullptr, &spec_nparts, seq);
     if (rc) return rc;
@@ -1098,7 +1105,7 @@ int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_
     const bool last = ((s + 1) % steps_per_solve) == 0 && s + 1 < n_steps;
     int rc = sweep_hess_device(f, Rp_init, f->d_lm, &c, &pend, 0, f->V, f->d_packed, first ? f->snapshot : nullptr);
     if (rc) return rc;
-    const unsigned seq = fused_solve() ? ++f->lm_seq : 0u;
+    const unsigned seq = fused_solve(f) ? ++f->lm_seq : 0u;
     if (!seq) vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
     int nparts = 0;
     rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts, seq);
@@ -1301,8 +1308,7 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
   std::vector<double> cov_invs((size_t)225 * (W > 1 ? W - 1 : 0));   // cov is constant during the loop: invert once
   if (!vxi::li_invert_covariances(W, imus, cov_invs.data())) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
   {   // the loop on the device (VXBA_LI_DEVICE=0: the host shell below); sharded runs keep the host shell
-    const char* e = getenv("VXBA_LI_DEVICE");
-    if (e && e[0] == '1' && !has_collective(f)) return li_damping_iter_device(f, states, imus, imu_coef, max_iter, hess_out, trace_out, n_trace, cov_invs.data());
+    if (f->opt[VXBA_OPT_LI_DEVICE_LOOP] != 0 && !has_collective(f)) return li_damping_iter_device(f, states, imus, imu_coef, max_iter, hess_out, trace_out, n_trace, cov_invs.data());
   }
   double residual1 = 0, residual2 = 0;
   bool is_calc_hess = true;
@@ -1547,6 +1553,27 @@ int vxba_debug_mfma_probe(int device, const double* A16x4, const double* B4x16, 
 int vxba_debug_stamps(int clear, unsigned long long* out, size_t n) {
   if (clear) vxk::debug_clear_stamps();
   if (out && n) { (void)hipDeviceSynchronize(); vxk::debug_read_stamps(out, n); }
+  return VXBA_OK;
+}
+
+int vxba_set_option(vxba_factor* f, int option, int value) {
+  if (!f) return VXBA_ERR_ARG;
+  VX_LOCK(f);
+  switch (option) {
+    case VXBA_OPT_FUSED_SOLVE: case VXBA_OPT_SPEC_COLLECTIVE: case VXBA_OPT_WIDE_DEVICE_SOLVE: case VXBA_OPT_LI_DEVICE_LOOP:
+      if (value != 0 && value != 1) return fail(f, VXBA_ERR_ARG, "vxba_set_option: this option takes 0 or 1");
+      break;
+    case VXBA_OPT_K2_VOXELS_PER_BLOCK:
+      if (value < 32 || value > 64) return fail(f, VXBA_ERR_ARG, "vxba_set_option: voxels per block must be in [32, 64]");
+      break;
+    default: return fail(f, VXBA_ERR_ARG, "vxba_set_option: unknown option");
+  }
+  f->opt[option] = value;
+  return VXBA_OK;
+}
+int vxba_get_option(const vxba_factor* f, int option, int* value) {
+  if (!f || !value || option < 0 || option >= VXBA_OPT_COUNT) return VXBA_ERR_ARG;
+  *value = f->opt[option];
   return VXBA_OK;
 }
 

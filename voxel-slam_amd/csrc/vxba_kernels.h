@@ -94,7 +94,7 @@ int k2_voxels_per_block(int nvox, int cus);
 // fused_seq != 0 (LM mode only): workgroup 0 of the launch runs the damped solve of this iteration and publishes `fused_seq`;
 // the voxel workgroups wait for it after requesting their cluster rows.  Must be unique per launch and non-zero.
 int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, int c, unsigned fused_seq, int head, int end, double* d_partial,
-                       int cus, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                       int voxels_per_block, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // Deterministic sum of n partials into d_out[0].
 void launch_sum_partials(const double* d_partial, int n, double* d_out, hipStream_t s);
 // Derive aux (gap scales) from eigval for voxels [head,end) (after a caller-seeded cache).

@@ -1251,18 +1251,12 @@ void launch_mfma_probe(const double* dA, const double* dB, double* dD, hipStream
     default: break;                                            \
   }
 
-int k2_voxels_per_block(int nvox, int cus) {
-  // One lane per voxel, full waves.  Tried: ceil(V / (k * cus)) voxels per workgroup so that every CU owns the same
-  // number of voxels (49 instead of 64 at cfg2, 4 workgroups on every CU): 20.0 us instead of 18.0 -- the partly
-  // filled waves cost more than the ragged last round.  VXBA_K2_VPB (32..64) keeps the experiment reproducible.
-  static int forced = -1;
-  if (forced < 0) { const char* ev = getenv("VXBA_K2_VPB"); forced = ev ? atoi(ev) : 0; }
-  if (forced >= 32 && forced <= 64) return forced;
-  return 64;
-}
+// Voxels per residual-sweep workgroup.  One lane per voxel, full waves (64) by default.  Tried: ceil(V / (k * cus)) voxels per
+// workgroup so that every CU owns the same number of voxels (49 instead of 64 at cfg2, 4 workgroups on every CU): 20.0 us instead of
+// 18.0 -- the partly filled waves cost more than the ragged last round.  VXBA_OPT_K2_VOXELS_PER_BLOCK keeps the experiment reproducible.
 int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, int c, unsigned fused_seq, int head, int end, double* d_partial,
-                       int cus, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  const int vpb = k2_voxels_per_block(end - head, cus);
+                       int voxels_per_block, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  const int vpb = (voxels_per_block >= 32 && voxels_per_block <= 64) ? voxels_per_block : 64;
   const int nblocks = (end - head + vpb - 1) / vpb;
   if (nblocks <= 0) return 0;
   const unsigned seq = st ? fused_seq : 0u;

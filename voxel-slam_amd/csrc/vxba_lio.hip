@@ -684,6 +684,7 @@ __global__ void lio_rehash_kernel(const unsigned long long* __restrict__ old_key
 // ---- host side -----------------------------------------------------------------------------------------------------------
 struct vxba_lio {
   int device = 0;
+  int opt_device_ekf = 1;   // vxba_lio_set_option(VXBA_LIO_OPT_DEVICE_EKF); initial value may come from VXBA_LIO_DEVICE_EKF
   double voxel_size = 1.0;
   int max_layer = 2;
   int cells_per_root = 64;
@@ -872,6 +873,7 @@ int vxba_lio_create(double voxel_size, int max_layer, int device, vxba_lio** out
   if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_HIP;
   vxba_lio* h = new vxba_lio();
   h->device = device; h->voxel_size = voxel_size; h->max_layer = max_layer; h->cells_per_root = 1 << (3 * max_layer);
+  { const char* ev = getenv("VXBA_LIO_DEVICE_EKF"); h->opt_device_ekf = !(ev && ev[0] == '0'); }   // initial value only (vxba.h)
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   h->own_stream = e == hipSuccess;
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_counters, 2 * sizeof(int));
@@ -882,6 +884,12 @@ int vxba_lio_create(double voxel_size, int max_layer, int device, vxba_lio** out
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_partials_dev, (size_t)vxl::MAX_GRID * vxl::NSUM * sizeof(double));
   if (e != hipSuccess) { vxba_lio_destroy(h); return VXBA_ERR_HIP; }
   *out = h;
+  return VXBA_OK;
+}
+
+int vxba_lio_set_option(vxba_lio* h, int option, int value) {
+  if (!h || option != VXBA_LIO_OPT_DEVICE_EKF || (value != 0 && value != 1)) return VXBA_ERR_ARG;
+  h->opt_device_ekf = value;
   return VXBA_OK;
 }
 
@@ -1126,8 +1134,7 @@ int vxba_lio_state_estimation(vxba_lio* h, double* state, double* cov, double* i
   int perm[D];
   if (!vxi::dm_inverse(D, cov, cov_inv, lu, perm)) return lio_fail(h, VXBA_ERR_ARG, "vxba_lio_state_estimation: singular state covariance");
   {   // the whole call on the device: sweeps and EKF updates enqueued back to back, one copy each way (VXBA_LIO_DEVICE_EKF=0: host algebra)
-    const char* e = getenv("VXBA_LIO_DEVICE_EKF");
-    if (!(e && e[0] == '0') && h->n_pts > 0) {
+    if (h->opt_device_ekf != 0 && h->n_pts > 0) {
       if (h->cap == 0) { int rc = lio_map_reserve(h, 0); if (rc != VXBA_OK) return rc; }
       static thread_local vxl::LioCtl hc;
       std::memset(&hc, 0, sizeof hc);

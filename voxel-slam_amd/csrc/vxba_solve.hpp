@@ -44,6 +44,15 @@ __device__ __forceinline__ double fast_rcp_f64(double d) {
   return r;
 }
 
+// Reciprocal of an elimination pivot with Eigen's rule for null pivots (LDLT::solve zeroes the components whose pivot is not
+// above 1/highest()): a frame without any observation in the factor has an all-zero block row, damping u*diag(H) does not lift
+// it, and the reference then returns dxi = 0 for that frame while the rest of the window moves.  With inv = 0 the step eliminates
+// nothing (multipliers 0) and back substitution yields x = 0 for the row -- the same answer, instead of inf / NaN poses.
+__device__ __forceinline__ double pivot_rcp_f64(double d) {
+  const double r = fast_rcp_f64(d);
+  return fabs(d) > 1e-300 ? r : 0.0;
+}
+
 constexpr int LM_PRE = 12;   // pivot-column values fetched one step ahead
 template <int K, int N>
 struct LmElim {
@@ -82,7 +91,7 @@ struct LmElim {
 #pragma unroll
         for (int j = 0; j < LM_PRE && j < M - 1; j++) pre_n[j] = nxt[K + 2 + j];
         __builtin_amdgcn_sched_barrier(0);
-        invd_n = fast_rcp_f64(d_n);
+        invd_n = pivot_rcp_f64(d_n);
 #pragma unroll
         for (int j = 1; j < LM_PRE && j < M; j++) A[K + 1 + j] -= l * pre[j];
 #pragma unroll
@@ -130,7 +139,7 @@ __device__ __forceinline__ double dense_solve_rows(double (&A)[N > 6 ? N : 7], d
     double pre[LM_PRE];
 #pragma unroll
     for (int j = 0; j < LM_PRE; j++) pre[j] = (7 + j < N) ? colbuf[7 + j] : 0.0;
-    const double invd6 = fast_rcp_f64(d6);
+    const double invd6 = pivot_rcp_f64(d6);
     LmElim<6, N>::forward(A, b, my_invd, colbuf, lane, row_ok, invd6, bk6, pre);
   }
   LmElim<N - 1, N>::backward(A, b, my_invd, x, nullptr, lane);

@@ -35,6 +35,7 @@ EXPORTS = [
     "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity", "vxba_voxelize_push", "vxba_set_precision",
     "vxba_lio_create", "vxba_lio_destroy", "vxba_lio_last_error", "vxba_lio_map_update", "vxba_lio_map_clear", "vxba_lio_map_size", "vxba_lio_scan_raw",
     "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_lio_leaf_stats", "vxba_cov_add_build", "vxba_plane_update", "vxba_down_sampling_voxel", "vxba_voxelize_push_device",
+    "vxba_set_option", "vxba_get_option", "vxba_lio_set_option",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -349,6 +350,17 @@ class LidarFactor:
         self._chk(self._L.vxba_use_external_buffers(self._h, C.c_void_p(d_packed_ptr or 0), C.c_void_p(d_scalar_ptr or 0)))
 
     # -- measurement ----------------------------------------------------------------------------
+    OPTIONS = {"fused_solve": 0, "spec_collective": 1, "wide_device_solve": 2, "li_device_loop": 3, "k2_voxels_per_block": 4}
+
+    def set_option(self, name: str, value: int):
+        """Execution options of include/vxba.h (VXBA_OPT_*): fused_solve, spec_collective, wide_device_solve, li_device_loop, k2_voxels_per_block."""
+        self._chk(self._L.vxba_set_option(self._h, self.OPTIONS[name], int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        self._chk(self._L.vxba_get_option(self._h, self.OPTIONS[name], C.byref(v)))
+        return v.value
+
     def set_precision(self, mode: str):
         """'f64' (default) or 'mixed' (f32 products on the matrix cores, f64 accumulation; BASELINE configs[2])."""
         self._chk(self._L.vxba_set_precision(self._h, {"f64": 0, "mixed": 1}[mode]))
@@ -590,6 +602,10 @@ class LioEstimator:
             self._h = None
             raise VxbaError(f"vxba_lio_create failed: {_ERRNAMES.get(rc, rc)} (no CPU fallback exists; an MI355X is required)")
         self.voxel_size, self.max_layer = float(voxel_size), int(max_layer)
+
+    def set_option(self, name: str, value: int):
+        """VXBA_LIO_OPT_*: 'device_ekf' (1 = EKF update as a kernel, default; 0 = host algebra between sweeps)."""
+        self._chk(self._L.vxba_lio_set_option(self._h, {"device_ekf": 0}[name], int(value)))
 
     def _chk(self, rc):
         if rc != 0:
