@@ -254,6 +254,50 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
 int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out,
                                  double* resis_out, double* trace_out, int* n_trace);
 
+/* ---- the incremental local map, resident on the GPU -------------------------------------------------------
+ * `surf_map` / `surf_map_slide` of OctoTree nodes with their sliding windows (voxel_map.hpp:896-1639), driven the way the
+ * local-mapping thread drives them (voxelslam.cpp:1592-1700).  Each entry point replaces one call of that thread; the tree, the
+ * window clusters, the stored scan points, the fix clusters and the plane records never leave the device, and tras_opt writes the
+ * factor's planes in place -- a scan cycle moves the scan up and the poses down.  Parameters are the reference's globals
+ * (voxel_map.hpp:83-89, voxelslam.cpp:795-812). */
+typedef struct vxba_map vxba_map;
+typedef struct vxba_map_params {
+  double voxel_size;                 /* voxel_size */
+  int max_layer;                     /* max_layer (0..2) */
+  double min_point[4];               /* min_point[layer]: a leaf is tested for planarity when N > min_point[layer] */
+  double min_eigen_value;            /* plane_judge: lambda0 < min_eigen_value && lambda0 / lambda2 < plane_eigen_value_thre[layer] */
+  double plane_eigen_value_thre[4];
+  int max_points;                    /* fix cluster cap (voxel_map.hpp:86) */
+  int win_size;                      /* <= 16 */
+  int thread_num;                    /* only for upstream's `if(g_size < thd_num) return;` early returns (voxel_map.hpp:1603, voxelslam.cpp:1406, 1337) */
+} vxba_map_params;
+int vxba_map_create(const vxba_map_params* params, int device, vxba_map** out);
+int vxba_map_destroy(vxba_map* m);
+const char* vxba_map_last_error(const vxba_map* m);
+/* cut_voxel_multi(surf_map, pvec, ord, surf_map_slide, win_size, pwld, sws) (voxel_map.hpp:1545-1639, call site voxelslam.cpp:1609):
+ * scan `ord` of the window (= win_count - 1): n body-frame points (n x 3), their covariances as pvec_update left them (n x 9
+ * column-major), their world coordinates (n x 3).  The _device variant takes device pointers (e.g. the arrays vxba_lio_pvec_update
+ * keeps resident). */
+int vxba_map_cut_voxel(vxba_map* m, int ord, int64_t n, const double* pnt_body, const double* var_world, const double* pwld);
+int vxba_map_cut_voxel_device(vxba_map* m, int ord, int64_t n, const double* d_pnt_body, const double* d_var_world, const double* d_pwld);
+/* multi_recut (voxelslam.cpp:1396-1453, OctoTree::recut voxel_map.hpp:1148-1194) followed by tras_opt (:1308-1333) straight into
+ * `factor` (cleared by the caller, as voxhess.clear(); same win_size).  Rp: win_count poses.  Factor voxels are ordered by node id;
+ * *n_pushed (optional) receives their number. */
+int vxba_map_recut(vxba_map* m, int win_count, const double* Rp, vxba_factor* factor, int64_t* n_pushed);
+/* multi_margi (voxelslam.cpp:1321-1394, OctoTree::margi voxel_map.hpp:1196-1305, mgsize = 1) with the optimised poses; reads the
+ * cache the optimiser left in `factor` (pcr_adds / eig_values / eig_vectors) on the device. */
+int vxba_map_margi(vxba_map* m, int win_count, const double* Rp, vxba_factor* factor);
+/* The ring of window slots moves on by mgsize (voxelslam.cpp:1683-1687). */
+int vxba_map_slide(vxba_map* m, int mgsize);
+/* out = [roots, roots in the slide map, leaves, mp[0]] */
+int vxba_map_counts(vxba_map* m, int64_t out[4]);
+/* Every leaf (octo_state == 0), unordered.  ids: [x:16 | y:16 | z:16 | octant path:9 | 0:4 | layer:3] (as vxba_voxelize_push);
+ * ints n x 8 = [layer, isexist, is_plane, has window, opt_state, last_num, stored fix points, root in slide map]; dbl n x (156 + 11 W) =
+ * [pcr_add 10 | pcr_fix 10 | eig_value 3 | eig_vector 9 | plane centre 3 | normal 3 | radius | plane_var 36 | cov_add 81 | window
+ * clusters W x 10 in window order | stored points per window slot W], matrices column-major.  *n_out = number of leaves (fills up to
+ * `capacity`; pass NULL arrays to query the count). */
+int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints, double* dbl, int64_t* n_out);
+
 /* ---- execution options (per handle; none of them changes results beyond rounding) -----------------------------------------
  * Every switch that used to be an environment variable is a setter.  The environment variables of the same name
  * (VXBA_FUSED_SOLVE, VXBA_SPEC_COLLECTIVE, VXBA_WIDE_DEVICE_SOLVE, VXBA_LI_DEVICE, VXBA_K2_VPB, VXBA_LIO_DEVICE_EKF) still give the

@@ -20,6 +20,7 @@
 #include "vxba_wide.h"
 #include "vxba_li_device.h"
 #include "vxba_scratch.hpp"
+#include "vxba_internal.h"
 #include "vxba_kernels.h"
 
 using vxk::FactorView;
@@ -1553,6 +1554,41 @@ int vxba_debug_mfma_probe(int device, const double* A16x4, const double* B4x16, 
 int vxba_debug_stamps(int clear, unsigned long long* out, size_t n) {
   if (clear) vxk::debug_clear_stamps();
   if (out && n) { (void)hipDeviceSynchronize(); vxk::debug_read_stamps(out, n); }
+  return VXBA_OK;
+}
+
+// ---- links for vxba_map.hip (vxba_internal.h) ----
+int vxba_internal_push_voxels_device(vxba_factor* f, int n, const double* d_clusters, const double* d_fix, const double* d_coe, const double* d_eigval,
+                                     const double* d_eigvec, const double* d_merged) {
+  VX_LOCK(f);
+  if (!f || n < 0 || (n > 0 && (!d_clusters || !d_fix || !d_coe || !d_eigval || !d_eigvec || !d_merged))) return fail(f, VXBA_ERR_ARG, "push_voxels_device: null argument");
+  if (n == 0) return VXBA_OK;
+  hipSetDevice(f->device);
+  int rc = ensure_capacity(f, f->V + n);
+  if (rc) return rc;
+  const FactorView fv = view(f);
+  const int v0 = f->V;
+  vxk::launch_scatter_clusters(d_clusters, fv, v0, n, f->stream);
+  if (!is_wide(f)) vxk::launch_build_clb(fv, v0, n, f->stream);
+  vxk::launch_scatter_rows(d_fix, fv.fix, f->VS, v0, n, 10, f->stream);
+  vxk::launch_scatter_rows(d_coe, fv.coe, f->VS, v0, n, 1, f->stream);
+  vxk::launch_scatter_rows(d_eigval, fv.eigval, f->VS, v0, n, 3, f->stream);
+  vxk::launch_scatter_rows(d_eigvec, fv.eigvec, f->VS, v0, n, 9, f->stream);
+  vxk::launch_scatter_rows(d_merged, fv.merged, f->VS, v0, n, 10, f->stream);
+  vxk::launch_seed_aux(fv, v0, v0 + n, f->stream);
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  VX_HIP(f, hipGetLastError());
+  f->V += n;
+  f->wide_dirty = true;
+  return VXBA_OK;
+}
+int vxba_internal_cache_view(vxba_factor* f, const double** eigval, const double** eigvec, const double** merged, int* VS, int* V) {
+  VX_LOCK(f);
+  if (!f || !eigval || !eigvec || !merged || !VS || !V) return VXBA_ERR_ARG;
+  hipSetDevice(f->device);
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  const FactorView fv = view(f);
+  *eigval = fv.eigval; *eigvec = fv.eigvec; *merged = fv.merged; *VS = f->VS; *V = f->V;
   return VXBA_OK;
 }
 

@@ -1,0 +1,1073 @@
+// vxba_map.hip -- the incremental local map resident on the GPU: the reference's `surf_map` / `surf_map_slide`
+// of OctoTree nodes with their sliding windows, driven scan by scan the way the local-mapping thread drives it
+//     cut_voxel_multi  voxel_map.hpp:1545-1639      OctoTree::push / allocate   :969-1046
+//     multi_recut      voxelslam.cpp:1396-1453      OctoTree::recut / fix_divide / subdivide   voxel_map.hpp:1074-1116, 1148-1194
+//     tras_opt         voxel_map.hpp:1308-1333      (writes the factor's planes on the device, no host copy of the factor)
+//     multi_margi      voxelslam.cpp:1321-1394      OctoTree::margi / plane_update   voxel_map.hpp:1118-1146, 1196-1305
+//     ring shift       voxelslam.cpp:1683-1687
+// from scratch as flat arrays and kernels -- no pointers, no per-voxel mutex, no host octree:
+//
+//   node pool (structure of arrays, zero-initialised, bump-allocated with one atomic cursor): layer, state (0 leaf / 1 subdivided),
+//     8 child indices (+1, 0 = none), centre, quater_length (float, as upstream), isexist / has_sw / is_plane / last_num / opt_state,
+//     pcr_add, pcr_fix, cov_add (9x9), eigen-decomposition, plane record, the W window clusters, and per window slot an index range;
+//   roots are found through an open-addressing table of packed voxel coordinates (atomicCAS insert);
+//   a node's `sw->points[slot]` is not a copy: scan points are immutable, so each window slot keeps its scan (body point + world
+//     covariance as pvec_update left it) plus one permutation of its point indices in which every leaf owns a contiguous range in
+//     scan order -- cut_voxel = leaf id per point -> stable radix sort -> one lane per touched leaf continues the leaf's running sums
+//     over its range (the accumulator starts from the stored value, so the sums stay bit-identical to sequential push());
+//   recut works layer by layer: a judge kernel (eigen-decomposition + plane_judge) marks the leaves that split; eight lanes per
+//     splitting leaf (one per octant) then replay [fix points | scan 0 | scan 1 | ...] in the reference's order, each keeping the
+//     points of its octant -- children get their sums in the order fix_divide / subdivide push them -- and re-bucket the parent's
+//     index ranges by octant;
+//   margi is one lane per leaf on clusters; the oldest slot's points move to a per-leaf world-frame fix pool until max_points.
+// Arithmetic that decides tree structure or feeds running sums (world point, octant test, cluster push) is written unfused, as the
+// reference's x86-64 build computes it; everything else follows vxba_math.hpp.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/vxba.h"
+#include "vxba_internal.h"
+#include "vxba_math.hpp"
+
+namespace vxmap {
+
+constexpr int MAXW = 16;
+constexpr unsigned long long EMPTY_KEY = ~0ull;
+constexpr long long LOC_OFF = 32768;   // root coordinates within +-32768: the node ids of the batch voxeliser
+
+struct Params {
+  double voxel_size;
+  int max_layer;
+  double min_point[4];
+  double min_eigen_value;
+  double thre[4];
+  int max_points, win_size, thread_num;
+};
+
+struct PoseArg { double Rp[MAXW * 12]; };   // R column-major | p, window order
+struct RingArg { int mp[MAXW]; };
+
+struct Nodes {
+  int cap;
+  int *layer, *state, *child, *root, *isexist, *has_sw, *is_plane, *last_num, *opt_state, *in_slide, *stamp, *path;
+  unsigned long long* key;     // root key (x,y,z offset by LOC_OFF, 16 bits each)
+  double *center, *pcr_add, *pcr_fix, *cov_add, *eigval, *eigvec, *pl_center, *pl_normal, *pl_radius, *pl_var, *pcrs_local;
+  float* ql;
+  int *pt_start, *pt_count;    // [node][slot]
+  long long* fix_start;
+  int *fix_count, *fix_cap;
+};
+
+struct Counters {   // device block of counters, read back after each stage
+  int n_nodes, n_roots, n_touched, n_slide_new, n_split, n_fac, n_removed, pad;
+  long long fix_cursor, fix_need;
+};
+
+// ---- unfused helpers --------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double madd_u(double acc, double a, double b) {
+#pragma clang fp contract(off)
+  const double p = a * b;
+  return acc + p;
+}
+__device__ __forceinline__ double mul_u(double a, double b) {
+#pragma clang fp contract(off)
+  const double p = a * b;
+  return p;
+}
+// xx.R * pv.pnt + xx.p (voxel_map.hpp:1100, 1264): (R(r,0) x + R(r,1) y) + R(r,2) z, then + p
+__device__ __forceinline__ void to_world(const double* Rp, const double* x, double* w) {
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    double s = mul_u(Rp[r], x[0]);
+    s = madd_u(s, Rp[3 + r], x[1]);
+    s = madd_u(s, Rp[6 + r], x[2]);
+    w[r] = s + Rp[9 + r];
+  }
+}
+// PointCluster::push (tools.hpp:326-331) on the packed cluster [Pxx Pxy Pxz Pyy Pyz Pzz vx vy vz N]
+__device__ __forceinline__ void cl_push(double* c, const double* x) {
+  c[9] += 1.0;
+  c[0] = madd_u(c[0], x[0], x[0]); c[1] = madd_u(c[1], x[0], x[1]); c[2] = madd_u(c[2], x[0], x[2]);
+  c[3] = madd_u(c[3], x[1], x[1]); c[4] = madd_u(c[4], x[1], x[2]); c[5] = madd_u(c[5], x[2], x[2]);
+  c[6] += x[0]; c[7] += x[1]; c[8] += x[2];
+}
+// cov_add += Bf_var(pv, vec) (voxel_map.hpp:91-106), column-major 9x9; Biup = Bi * var evaluated as the text does
+__device__ __forceinline__ void cov_add_point(double* acc, const double* x, const double* V /* column-major 3x3 */) {
+  const double Bi[6][3] = {{2 * x[0], 0, 0}, {x[1], x[0], 0}, {x[2], 0, x[0]}, {0, 2 * x[1], 0}, {0, x[2], x[1]}, {0, 0, 2 * x[2]}};
+  double Biup[6][3];
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) Biup[r][k] = madd_u(madd_u(mul_u(Bi[r][0], V[3 * k]), Bi[r][1], V[3 * k + 1]), Bi[r][2], V[3 * k + 2]);
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc[9 * k + r] += madd_u(madd_u(mul_u(Biup[r][0], Bi[k][0]), Biup[r][1], Bi[k][1]), Biup[r][2], Bi[k][2]);
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) { acc[9 * (6 + k) + r] += Biup[r][k]; acc[9 * r + 6 + k] += Biup[r][k]; }
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) acc[9 * (6 + k) + 6 + r] += V[3 * k + r];
+}
+// the float-typed voxel index of cut_voxel (voxel_map.hpp:1553-1560)
+__device__ __forceinline__ long long voxel_index(double w, double voxel_size) {
+  float loc = (float)(w / voxel_size);
+  if (loc < 0.0f) loc = __fsub_rn(loc, 1.0f);
+  return (long long)loc;
+}
+__device__ __forceinline__ int octant_of(const double* w, const double* c) {
+  return 4 * (w[0] > c[0] ? 1 : 0) + 2 * (w[1] > c[1] ? 1 : 0) + (w[2] > c[2] ? 1 : 0);
+}
+__host__ __device__ inline unsigned long long mix64(unsigned long long x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+__device__ __forceinline__ void init_child(const Nodes& nd, int c, int parent, int oct) {
+  nd.layer[c] = nd.layer[parent] + 1;
+  nd.root[c] = nd.root[parent];
+  nd.key[c] = nd.key[parent];
+  nd.path[c] = nd.path[parent] | (oct << (3 * (2 - nd.layer[parent])));
+  const float ql = nd.ql[parent];
+  const int xyz[3] = {(oct >> 2) & 1, (oct >> 1) & 1, oct & 1};
+#pragma unroll
+  for (int k = 0; k < 3; k++) nd.center[3 * (size_t)c + k] = nd.center[3 * (size_t)parent + k] + (double)((float)(2 * xyz[k] - 1) * ql);
+  nd.ql[c] = ql / 2;
+  nd.opt_state[c] = -1;
+}
+
+// ---- cut_voxel ---------------------------------------------------------------------------------------------------------------
+// A: root voxel of every point, find-or-insert (voxel_map.hpp:1553-1582)
+__global__ void map_roots_kernel(Nodes nd, Params prm, unsigned long long* keys, int* vals, unsigned long long cap_mask, const double* __restrict__ pwld, int n,
+                                 int* __restrict__ slot_of_point, Counters* cnt, int serial, int* err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long x = voxel_index(pwld[3 * i], prm.voxel_size), y = voxel_index(pwld[3 * i + 1], prm.voxel_size), z = voxel_index(pwld[3 * i + 2], prm.voxel_size);
+  const long long a = x + LOC_OFF, b = y + LOC_OFF, c = z + LOC_OFF;
+  if ((a | b | c) < 0 || a >= 2 * LOC_OFF || b >= 2 * LOC_OFF || c >= 2 * LOC_OFF) { *err = 1; slot_of_point[i] = -1; return; }
+  const unsigned long long key = ((unsigned long long)a << 32) | ((unsigned long long)b << 16) | (unsigned long long)c;
+  unsigned long long h = mix64(key) & cap_mask;
+  for (;;) {
+    const unsigned long long old = atomicCAS(&keys[h], EMPTY_KEY, key);
+    if (old == EMPTY_KEY) {                                   // new root (voxel_map.hpp:1571-1581)
+      const int idx = atomicAdd(&cnt->n_nodes, 1);
+      atomicAdd(&cnt->n_roots, 1);
+      nd.layer[idx] = 0; nd.root[idx] = idx; nd.key[idx] = key; nd.path[idx] = 0; nd.opt_state[idx] = -1;
+      nd.center[3 * (size_t)idx] = (0.5 + (double)x) * prm.voxel_size;
+      nd.center[3 * (size_t)idx + 1] = (0.5 + (double)y) * prm.voxel_size;
+      nd.center[3 * (size_t)idx + 2] = (0.5 + (double)z) * prm.voxel_size;
+      nd.ql[idx] = (float)(prm.voxel_size / 4.0);
+      __threadfence();
+      atomicExch(&vals[h], idx + 1);
+      break;
+    }
+    if (old == key) break;
+    h = (h + 1) & cap_mask;
+  }
+  slot_of_point[i] = (int)h;
+}
+// B: every point walks down from its root: leaf -> stop, subdivided -> octant, no child there -> allocate it (OctoTree::allocate
+// voxel_map.hpp:1021-1046).  A lane that finds the child being allocated by another lane reports (parent, octant) for kernel C.
+__global__ void map_descend_kernel(Nodes nd, const int* __restrict__ vals, const double* __restrict__ pwld, int n, const int* __restrict__ slot_of_point, int* __restrict__ leaf,
+                                   int* __restrict__ pend_parent, Counters* cnt, int serial) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = slot_of_point[i];
+  if (s < 0) { leaf[i] = 0x7fffffff; pend_parent[i] = -1; return; }
+  int node = vals[s] - 1;
+  if (atomicExch(&nd.stamp[node], serial) != serial) atomicAdd(&cnt->n_touched, 1);      // distinct roots this scan touches (:1603-1605)
+  if (atomicExch(&nd.in_slide[node], 1) == 0) atomicAdd(&cnt->n_slide_new, 1);         // feat_tem_map (:1566-1567, 1580)
+  const double w[3] = {pwld[3 * i], pwld[3 * i + 1], pwld[3 * i + 2]};
+  pend_parent[i] = -1;
+  while (nd.state[node] != 0) {
+    const int oct = octant_of(w, nd.center + 3 * (size_t)node);
+    int* slot = &nd.child[8 * (size_t)node + oct];
+    int c = atomicCAS(slot, 0, -1);
+    if (c == 0) {
+      const int idx = atomicAdd(&cnt->n_nodes, 1);
+      init_child(nd, idx, node, oct);
+      __threadfence();
+      atomicExch(slot, idx + 1);
+      node = idx;
+      break;
+    }
+    if (c < 0) { pend_parent[i] = node * 8 + oct; node = -1; break; }
+    node = c - 1;
+  }
+  leaf[i] = node;
+}
+__global__ void map_resolve_kernel(Nodes nd, int n, int* __restrict__ leaf, const int* __restrict__ pend_parent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || pend_parent[i] < 0) return;
+  leaf[i] = nd.child[pend_parent[i]] - 1;      // a freshly allocated child is a leaf
+}
+__global__ void map_iota_kernel(int* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+// One lane per head of a run of equal leaf ids in the sorted order: OctoTree::push (voxel_map.hpp:969-993) for the run, in scan order.
+__global__ __launch_bounds__(64) void map_push_kernel(Nodes nd, Params prm, const int* __restrict__ leaf_sorted, const int* __restrict__ perm, int n,
+                                                      const double* __restrict__ pnt, const double* __restrict__ var9, const double* __restrict__ pwld, int mord) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int node = leaf_sorted[q];
+  if (node == 0x7fffffff || (q > 0 && leaf_sorted[q - 1] == node)) return;
+  const int W = prm.win_size;
+  double cl[10], ca[10], acc[81];
+  double* g_cl = nd.pcrs_local + ((size_t)node * W + mord) * 10;
+  double* g_ca = nd.pcr_add + (size_t)node * 10;
+  double* g_acc = nd.cov_add + (size_t)node * 81;
+#pragma unroll
+  for (int k = 0; k < 10; k++) { cl[k] = g_cl[k]; ca[k] = g_ca[k]; }
+#pragma unroll
+  for (int k = 0; k < 81; k++) acc[k] = g_acc[k];
+  int cntp = 0;
+  for (int j = q; j < n && leaf_sorted[j] == node; j++) {
+    const int i = perm[j];
+    const double x[3] = {pnt[3 * (size_t)i], pnt[3 * (size_t)i + 1], pnt[3 * (size_t)i + 2]};
+    const double w[3] = {pwld[3 * (size_t)i], pwld[3 * (size_t)i + 1], pwld[3 * (size_t)i + 2]};
+    cl_push(cl, x);
+    cl_push(ca, w);
+    cov_add_point(acc, w, var9 + 9 * (size_t)i);
+    cntp++;
+  }
+#pragma unroll
+  for (int k = 0; k < 10; k++) { g_cl[k] = cl[k]; g_ca[k] = ca[k]; }
+#pragma unroll
+  for (int k = 0; k < 81; k++) g_acc[k] = acc[k];
+  nd.has_sw[node] = 1;
+  nd.isexist[node] = 1;
+  if (nd.layer[node] < prm.max_layer) { nd.pt_start[(size_t)node * W + mord] = q; nd.pt_count[(size_t)node * W + mord] = cntp; }
+}
+// `iter->second->isexist = true` for roots that already existed (voxel_map.hpp:1565) -- marked through the stamp of this scan
+__global__ void map_mark_existing_roots_kernel(Nodes nd, int n_nodes_before, int serial) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_nodes_before && nd.layer[i] == 0 && nd.root[i] == i && nd.stamp[i] == serial) nd.isexist[i] = 1;
+}
+
+// ---- recut -------------------------------------------------------------------------------------------------------------------
+// OctoTree::recut's leaf branch (voxel_map.hpp:1150-1172) for every leaf of layer L under a root of the slide map
+__global__ void map_judge_kernel(Nodes nd, Params prm, int n_nodes, int L, int* __restrict__ split_list, Counters* cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes || nd.layer[i] != L || nd.state[i] != 0 || !nd.in_slide[nd.root[i]]) return;
+  nd.opt_state[i] = -1;
+  const double* c = nd.pcr_add + (size_t)i * 10;
+  if (c[9] <= prm.min_point[L]) { nd.is_plane[i] = 0; return; }
+  if (!nd.isexist[i] || !nd.has_sw[i]) return;
+  double Cm[6], lam[3], U[9];
+  vxm::cluster_cov(c, c + 6, c[9], Cm);
+  vxm::eig_sym3(Cm, lam, U);
+  for (int k = 0; k < 3; k++) nd.eigval[3 * (size_t)i + k] = lam[k];
+  for (int col = 0; col < 3; col++)
+    for (int row = 0; row < 3; row++) nd.eigvec[9 * (size_t)i + 3 * col + row] = U[3 * row + col];
+  const int plane = (lam[0] < prm.min_eigen_value && (lam[0] / lam[2]) < prm.thre[L]) ? 1 : 0;
+  nd.is_plane[i] = plane;
+  if (plane || L >= prm.max_layer) return;
+  const int k = atomicAdd(&cnt->n_split, 1);
+  split_list[k] = i;
+  if (nd.pcr_fix[(size_t)i * 10 + 9] != 0.0) atomicAdd((unsigned long long*)&cnt->fix_need, (unsigned long long)nd.fix_count[i]);
+}
+// fix_divide + subdivide(0 .. win_count-1) of one splitting leaf (voxel_map.hpp:1074-1116, 1174-1188): lane c of the node's eight
+// replays the reference's push sequence and keeps octant c.  64 lanes = 8 nodes.
+struct ScanSlot { const double* pnt; const double* var9; int* perm; int* tmp; int n; };
+struct ScanSlots { ScanSlot s[MAXW]; };
+__global__ __launch_bounds__(64) void map_subdivide_kernel(Nodes nd, Params prm, const int* __restrict__ split_list, int n_split, int win_count, PoseArg poses, RingArg ring,
+                                                           ScanSlots scans, double* __restrict__ fix_pnt, double* __restrict__ fix_var, Counters* cnt) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int sidx = t >> 3, oct = t & 7;
+  const bool live = sidx < n_split;
+  const int node = live ? split_list[sidx] : 0;
+  const int W = prm.win_size;
+  const int L = nd.layer[node];
+  const bool keep_pts = (L + 1) < prm.max_layer;
+  const double* ctr = nd.center + 3 * (size_t)node;
+  int child = -1;
+  double ca[10], cf[10], acc[81];
+#pragma unroll
+  for (int k = 0; k < 10; k++) { ca[k] = 0.0; cf[k] = 0.0; }
+#pragma unroll
+  for (int k = 0; k < 81; k++) acc[k] = 0.0;
+  auto get_child = [&]() {
+    if (child < 0) {
+      child = atomicAdd(&cnt->n_nodes, 1);
+      init_child(nd, child, node, oct);
+      nd.child[8 * (size_t)node + oct] = child + 1;
+    }
+  };
+  // fix_divide (voxel_map.hpp:1074-1094): only when pcr_fix.N != 0 (:1174)
+  const bool has_fix = live && nd.pcr_fix[(size_t)node * 10 + 9] != 0.0;
+  int nfix = 0;
+  if (has_fix) {
+    const long long f0 = nd.fix_start[node];
+    const int fc = nd.fix_count[node];
+    for (int j = 0; j < fc; j++) {
+      const double* x = fix_pnt + 3 * (size_t)(f0 + j);
+      if (octant_of(x, ctr) != oct) continue;
+      get_child();
+      cl_push(cf, x); cl_push(ca, x);
+      cov_add_point(acc, x, fix_var + 9 * (size_t)(f0 + j));
+      nfix++;
+    }
+    if (nfix > 0 && keep_pts) {      // push_fix keeps the point when layer < max_layer (voxel_map.hpp:998-999)
+      const long long dst = (long long)atomicAdd((unsigned long long*)&cnt->fix_cursor, (unsigned long long)nfix);
+      int k = 0;
+      for (int j = 0; j < fc; j++) {
+        const double* x = fix_pnt + 3 * (size_t)(f0 + j);
+        if (octant_of(x, ctr) != oct) continue;
+        for (int e = 0; e < 3; e++) fix_pnt[3 * (size_t)(dst + k) + e] = x[e];
+        for (int e = 0; e < 9; e++) fix_var[9 * (size_t)(dst + k) + e] = fix_var[9 * (size_t)(f0 + j) + e];
+        k++;
+      }
+      nd.fix_start[child] = dst; nd.fix_count[child] = nfix; nd.fix_cap[child] = nfix;
+    }
+  }
+  // subdivide(i) for the window's scans in order (voxel_map.hpp:1096-1116)
+  for (int i = 0; i < win_count; i++) {
+    const int slot = ring.mp[i];
+    const ScanSlot sc = scans.s[slot];
+    const int p0 = live ? nd.pt_start[(size_t)node * W + slot] : 0;
+    const int pc = live ? nd.pt_count[(size_t)node * W + slot] : 0;
+    double cl[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) cl[k] = 0.0;
+    int mine = 0;
+    for (int j = 0; j < pc; j++) {
+      const int pi = sc.perm[p0 + j];
+      const double* x = sc.pnt + 3 * (size_t)pi;
+      double w[3];
+      to_world(poses.Rp + 12 * i, x, w);
+      if (octant_of(w, ctr) != oct) continue;
+      get_child();
+      cl_push(cl, x); cl_push(ca, w);
+      cov_add_point(acc, w, sc.var9 + 9 * (size_t)pi);
+      mine++;
+    }
+    // stable re-bucketing of the parent's index range by octant: exclusive prefix of `mine` over the node's eight lanes
+    int before = 0;
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+      const int v = __shfl(mine, (threadIdx.x & ~7) + o);
+      if (o < oct) before += v;
+    }
+    if (mine > 0) {
+      double* g = nd.pcrs_local + ((size_t)child * W + slot) * 10;
+#pragma unroll
+      for (int k = 0; k < 10; k++) g[k] = cl[k];
+      if (keep_pts) {
+        int k = 0;
+        for (int j = 0; j < pc; j++) {
+          const int pi = sc.perm[p0 + j];
+          double w[3];
+          to_world(poses.Rp + 12 * i, sc.pnt + 3 * (size_t)pi, w);
+          if (octant_of(w, ctr) != oct) continue;
+          sc.tmp[p0 + before + k] = pi;
+          k++;
+        }
+        nd.pt_start[(size_t)child * W + slot] = p0 + before;
+        nd.pt_count[(size_t)child * W + slot] = mine;
+      }
+    }
+    __syncthreads();
+    if (keep_pts && live)
+      for (int j = oct; j < pc; j += 8) sc.perm[p0 + j] = sc.tmp[p0 + j];
+    __syncthreads();
+  }
+  if (child >= 0) {
+    double* g_ca = nd.pcr_add + (size_t)child * 10;
+    double* g_cf = nd.pcr_fix + (size_t)child * 10;
+    double* g_acc = nd.cov_add + (size_t)child * 81;
+#pragma unroll
+    for (int k = 0; k < 10; k++) { g_ca[k] = ca[k]; g_cf[k] = cf[k]; }
+#pragma unroll
+    for (int k = 0; k < 81; k++) g_acc[k] = acc[k];
+    if (ca[9] != cf[9]) { nd.has_sw[child] = 1; nd.isexist[child] = 1; }     // push() opened a window; push_fix alone does not
+  }
+  __syncthreads();
+  if (live && oct == 0) {      // sw->clear(); sws.push_back(sw); sw = nullptr; octo_state = 1  (voxel_map.hpp:1184-1187)
+    for (int s = 0; s < W; s++) {
+      nd.pt_count[(size_t)node * W + s] = 0;
+      for (int k = 0; k < 10; k++) nd.pcrs_local[((size_t)node * W + s) * 10 + k] = 0.0;
+    }
+    if (has_fix) { nd.fix_count[node] = 0; nd.fix_cap[node] = 0; }
+    nd.has_sw[node] = 0;
+    nd.state[node] = 1;
+  }
+}
+// tras_opt's filter (voxel_map.hpp:1312-1314): candidates with their node ids, to be ordered by id
+__global__ void map_factor_flag_kernel(Nodes nd, int n_nodes, unsigned long long* __restrict__ ids, int* __restrict__ nodes, Counters* cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes || nd.state[i] != 0 || !nd.in_slide[nd.root[i]]) return;
+  if (!(nd.isexist[i] && nd.is_plane[i] && nd.has_sw[i])) return;
+  if (nd.eigval[3 * (size_t)i] / nd.eigval[3 * (size_t)i + 1] > 0.12) return;
+  const int k = atomicAdd(&cnt->n_fac, 1);
+  ids[k] = (nd.key[i] << 16) | ((unsigned long long)nd.path[i] << 7) | (unsigned long long)nd.layer[i];
+  nodes[k] = i;
+}
+// pcrs[i] = sw->pcrs_local[mp[i]]; push_voxel(pcrs, pcr_fix, 1, eig_value, eig_vector, pcr_add)  (voxel_map.hpp:1316-1321)
+__global__ void map_factor_gather_kernel(Nodes nd, int W, RingArg ring, const int* __restrict__ nodes, int n, double* __restrict__ clusters, double* __restrict__ fix,
+                                         double* __restrict__ coe, double* __restrict__ eigval, double* __restrict__ eigvec, double* __restrict__ merged) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  const int i = nodes[a];
+  nd.opt_state[i] = a;
+  for (int s = 0; s < W; s++)
+    for (int k = 0; k < 10; k++) clusters[((size_t)a * W + s) * 10 + k] = nd.pcrs_local[((size_t)i * W + ring.mp[s]) * 10 + k];
+  for (int k = 0; k < 10; k++) { fix[10 * (size_t)a + k] = nd.pcr_fix[10 * (size_t)i + k]; merged[10 * (size_t)a + k] = nd.pcr_add[10 * (size_t)i + k]; }
+  coe[a] = 1.0;
+  for (int k = 0; k < 3; k++) eigval[3 * (size_t)a + k] = nd.eigval[3 * (size_t)i + k];
+  for (int k = 0; k < 9; k++) eigvec[9 * (size_t)a + k] = nd.eigvec[9 * (size_t)i + k];
+}
+
+// ---- margi -------------------------------------------------------------------------------------------------------------------
+// PointCluster::transform (tools.hpp:357-363) on packed clusters, pose R column-major | p
+__device__ __forceinline__ void cl_transform(const double* s, const double* Rp, double* o) {
+  const double N = s[9];
+  const double P[9] = {s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5]};   // symmetric, row r col c = P[3r+c]
+  double Rv[3], RP[9], out[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++) Rv[r] = Rp[r] * s[6] + Rp[3 + r] * s[7] + Rp[6 + r] * s[8];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) RP[3 * r + c] = Rp[r] * P[c] + Rp[3 + r] * P[3 + c] + Rp[6 + r] * P[6 + c];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const double rprt = RP[3 * r] * Rp[c] + RP[3 * r + 1] * Rp[3 + c] + RP[3 * r + 2] * Rp[6 + c];
+      out[3 * r + c] = ((rprt + Rv[r] * Rp[9 + c]) + Rv[c] * Rp[9 + r]) + (N * Rp[9 + r]) * Rp[9 + c];
+    }
+  o[0] = out[0]; o[1] = out[1]; o[2] = out[2]; o[3] = out[4]; o[4] = out[5]; o[5] = out[8];
+#pragma unroll
+  for (int r = 0; r < 3; r++) o[6 + r] = Rv[r] + N * Rp[9 + r];
+  o[9] = N;
+}
+// OctoTree::plane_update (voxel_map.hpp:1118-1146) of node i
+__device__ void plane_update_node(const Nodes& nd, int i) {
+  const double* cl = nd.pcr_add + 10 * (size_t)i;
+  const double N = cl[9];
+  const double nv = 1.0 / N;
+  const double c[3] = {cl[6] / N, cl[7] / N, cl[8] / N};
+  const double* U = nd.eigvec + 9 * (size_t)i;
+  const double* lam = nd.eigval + 3 * (size_t)i;
+  double u_c[3][9];
+  for (int r = 0; r < 3; r++)
+    for (int q = 0; q < 9; q++) u_c[r][q] = 0.0;
+  const double* ul = U;
+  for (int k = 1; k < 3; k++) {
+    const double* uk = U + 3 * k;
+    const double kc = uk[0] * c[0] + uk[1] * c[1] + uk[2] * c[2], lc = ul[0] * c[0] + ul[1] * c[1] + ul[2] * c[2];
+    const double fkl[9] = {uk[0] * ul[0], uk[1] * ul[0] + uk[0] * ul[1], uk[2] * ul[0] + uk[0] * ul[2], uk[1] * ul[1], uk[1] * ul[2] + uk[2] * ul[1], uk[2] * ul[2],
+                           -(kc * ul[0] + lc * uk[0]), -(kc * ul[1] + lc * uk[1]), -(kc * ul[2] + lc * uk[2])};
+    const double sc = nv / (lam[0] - lam[k]);
+    for (int r = 0; r < 3; r++)
+      for (int q = 0; q < 9; q++) u_c[r][q] += sc * uk[r] * fkl[q];
+  }
+  const double* CA = nd.cov_add + 81 * (size_t)i;
+  double Jc[3][9];
+  for (int r = 0; r < 3; r++)
+    for (int q = 0; q < 9; q++) {
+      double t = 0.0;
+      for (int k = 0; k < 9; k++) t += u_c[r][k] * CA[9 * q + k];
+      Jc[r][q] = t;
+    }
+  double* P = nd.pl_var + 36 * (size_t)i;
+  for (int r = 0; r < 3; r++)
+    for (int q = 0; q < 3; q++) {
+      double t = 0.0;
+      for (int k = 0; k < 9; k++) t += Jc[r][k] * u_c[q][k];
+      P[6 * q + r] = t;
+      const double jn = nv * Jc[r][6 + q];
+      P[6 * (3 + q) + r] = jn;
+      P[6 * r + 3 + q] = jn;
+      P[6 * (3 + q) + 3 + r] = nv * nv * CA[9 * (6 + q) + 6 + r];
+    }
+  for (int k = 0; k < 3; k++) { nd.pl_center[3 * (size_t)i + k] = c[k]; nd.pl_normal[3 * (size_t)i + k] = ul[k]; }
+  nd.pl_radius[i] = (double)(float)lam[2];
+}
+// OctoTree::margi's leaf branch with mgsize = 1 (voxel_map.hpp:1198-1290), one lane per leaf.  Pass 0 does the cluster work and
+// sizes the fix-pool growth; pass 1 (after the host made room) moves the oldest scan's points into the pool and clears the slot.
+__global__ void map_margi_kernel(Nodes nd, Params prm, int n_nodes, int win_count, PoseArg poses, RingArg ring, const double* __restrict__ f_eigval,
+                                 const double* __restrict__ f_eigvec, const double* __restrict__ f_merged, int f_VS, int f_V, int* __restrict__ work, Counters* cnt, int* err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  work[i] = 0;
+  if (nd.state[i] != 0 || !nd.in_slide[nd.root[i]]) return;
+  if (!nd.isexist[i] || !nd.has_sw[i]) return;
+  const int W = prm.win_size;
+  const int m0 = ring.mp[0];
+  double* add = nd.pcr_add + 10 * (size_t)i;
+  double* fixc = nd.pcr_fix + 10 * (size_t)i;
+  double w0[10];
+  for (int k = 0; k < 10; k++) w0[k] = 0.0;
+  const int os = nd.opt_state[i];
+  if (os >= f_V) { *err = 2; return; }
+  if (os >= 0) {                                     // adopt the optimiser's cache (:1217-1229)
+    for (int k = 0; k < 10; k++) add[k] = f_merged[(size_t)k * f_VS + os];
+    for (int k = 0; k < 3; k++) nd.eigval[3 * (size_t)i + k] = f_eigval[(size_t)k * f_VS + os];
+    for (int k = 0; k < 9; k++) nd.eigvec[9 * (size_t)i + k] = f_eigvec[(size_t)k * f_VS + os];
+    nd.opt_state[i] = -1;
+    const double* l0 = nd.pcrs_local + ((size_t)i * W + m0) * 10;
+    if (l0[9] != 0.0) cl_transform(l0, poses.Rp, w0);
+  } else {                                           // :1230-1247
+    double s[10];
+    for (int k = 0; k < 10; k++) s[k] = fixc[k];
+    for (int j = 0; j < win_count; j++) {
+      const double* lj = nd.pcrs_local + ((size_t)i * W + ring.mp[j]) * 10;
+      if (lj[9] == 0.0) continue;
+      double wj[10];
+      cl_transform(lj, poses.Rp + 12 * j, wj);
+      for (int k = 0; k < 10; k++) s[k] += wj[k];
+      if (j == 0) for (int k = 0; k < 10; k++) w0[k] = wj[k];
+    }
+    for (int k = 0; k < 10; k++) add[k] = s[k];
+    if (nd.is_plane[i]) {
+      double Cm[6], lam[3], U[9];
+      vxm::cluster_cov(s, s + 6, s[9], Cm);
+      vxm::eig_sym3(Cm, lam, U);
+      for (int k = 0; k < 3; k++) nd.eigval[3 * (size_t)i + k] = lam[k];
+      for (int col = 0; col < 3; col++)
+        for (int row = 0; row < 3; row++) nd.eigvec[9 * (size_t)i + 3 * col + row] = U[3 * row + col];
+    }
+  }
+  const int Nadd = (int)add[9], Nfix = (int)fixc[9];
+  if (Nfix < prm.max_points && nd.is_plane[i])
+    if (Nadd - nd.last_num[i] >= 5 || nd.last_num[i] <= 10) {
+      plane_update_node(nd, i);
+      nd.last_num[i] = Nadd;
+    }
+  int wk = 4;                                        // bit 2: the slot is cleared in pass 1
+  if (Nfix < prm.max_points) {
+    if (w0[9] != 0.0) {
+      for (int k = 0; k < 10; k++) fixc[k] += w0[k];
+      const int pc = nd.pt_count[(size_t)i * W + m0];
+      if (pc > 0) {
+        wk |= 1;                                     // append the slot's points to the fix pool
+        if (nd.fix_count[i] + pc > nd.fix_cap[i]) {
+          const int ncap = 2 * (nd.fix_count[i] + pc);
+          atomicAdd((unsigned long long*)&cnt->fix_need, (unsigned long long)ncap);
+          wk |= 2;                                   // needs a new region
+        }
+      }
+    }
+  } else {
+    if (w0[9] != 0.0) for (int k = 0; k < 10; k++) add[k] -= w0[k];
+    if (nd.fix_count[i] != 0) { nd.fix_count[i] = 0; nd.fix_cap[i] = 0; }
+  }
+  work[i] = wk;
+  nd.isexist[i] = (fixc[9] >= add[9]) ? 0 : 1;       // :1292-1295
+}
+__global__ void map_margi_points_kernel(Nodes nd, Params prm, int n_nodes, PoseArg poses, RingArg ring, ScanSlots scans, const int* __restrict__ work,
+                                        double* __restrict__ fix_pnt, double* __restrict__ fix_var, Counters* cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes || work[i] == 0) return;
+  const int W = prm.win_size, m0 = ring.mp[0];
+  const int wk = work[i];
+  if (wk & 1) {
+    const ScanSlot sc = scans.s[m0];
+    const int p0 = nd.pt_start[(size_t)i * W + m0], pc = nd.pt_count[(size_t)i * W + m0];
+    const int fc = nd.fix_count[i];
+    if (wk & 2) {
+      const int ncap = 2 * (fc + pc);
+      const long long dst = (long long)atomicAdd((unsigned long long*)&cnt->fix_cursor, (unsigned long long)ncap);
+      const long long src = nd.fix_start[i];
+      for (int j = 0; j < fc; j++) {
+        for (int e = 0; e < 3; e++) fix_pnt[3 * (size_t)(dst + j) + e] = fix_pnt[3 * (size_t)(src + j) + e];
+        for (int e = 0; e < 9; e++) fix_var[9 * (size_t)(dst + j) + e] = fix_var[9 * (size_t)(src + j) + e];
+      }
+      nd.fix_start[i] = dst; nd.fix_cap[i] = ncap;
+    }
+    const long long dst = nd.fix_start[i] + fc;
+    for (int j = 0; j < pc; j++) {                   // pv.pnt = R * pv.pnt + p; point_fix.push_back(pv)  (:1262-1266)
+      const int pi = sc.perm[p0 + j];
+      double w[3];
+      to_world(poses.Rp, sc.pnt + 3 * (size_t)pi, w);
+      for (int e = 0; e < 3; e++) fix_pnt[3 * (size_t)(dst + j) + e] = w[e];
+      for (int e = 0; e < 9; e++) fix_var[9 * (size_t)(dst + j) + e] = sc.var9[9 * (size_t)pi + e];
+    }
+    nd.fix_count[i] = fc + pc;
+  }
+  double* l0 = nd.pcrs_local + ((size_t)i * W + m0) * 10;      // :1283-1288
+  if (l0[9] != 0.0) {
+    for (int k = 0; k < 10; k++) l0[k] = 0.0;
+    nd.pt_count[(size_t)i * W + m0] = 0;
+  }
+}
+// internal nodes, one layer at a time from the bottom: isexist = any child (voxel_map.hpp:1297-1304)
+__global__ void map_margi_up_kernel(Nodes nd, int n_nodes, int L) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes || nd.layer[i] != L || nd.state[i] != 1 || !nd.in_slide[nd.root[i]]) return;
+  int e = 0;
+  for (int o = 0; o < 8; o++) {
+    const int c = nd.child[8 * (size_t)i + o] - 1;
+    if (c >= 0) e |= nd.isexist[c];
+  }
+  nd.isexist[i] = e;
+}
+// roots without live content leave the slide map: clear_slwd on the subtree (voxelslam.cpp:1384-1393, voxel_map.hpp:1482-1500)
+__global__ void map_release_kernel(Nodes nd, int W, int n_nodes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const int r = nd.root[i];
+  if (!nd.in_slide[r] || nd.isexist[r] || !nd.has_sw[i]) return;
+  for (int s = 0; s < W; s++) {
+    nd.pt_count[(size_t)i * W + s] = 0;
+    for (int k = 0; k < 10; k++) nd.pcrs_local[((size_t)i * W + s) * 10 + k] = 0.0;
+  }
+  nd.has_sw[i] = 0;
+}
+__global__ void map_leave_slide_kernel(Nodes nd, int n_nodes, Counters* cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes || nd.root[i] != i || nd.layer[i] != 0) return;
+  if (nd.in_slide[i] && !nd.isexist[i]) { nd.in_slide[i] = 0; atomicAdd(&cnt->n_removed, 1); }
+}
+
+// ---- export -----------------------------------------------------------------------------------------------------------------
+__global__ void map_leaf_flag_kernel(Nodes nd, int n_nodes, int* __restrict__ list, int* n_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes || nd.state[i] != 0) return;
+  list[atomicAdd(n_out, 1)] = i;
+}
+// the record layout documented at vxba_map_leaves (include/vxba.h): ints 8, doubles 156 + 11 W
+__global__ void map_leaf_export_kernel(Nodes nd, int W, RingArg ring, const int* __restrict__ list, int n, unsigned long long* __restrict__ ids, int* __restrict__ ints,
+                                       double* __restrict__ dbl) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  const int i = list[a];
+  ids[a] = (nd.key[i] << 16) | ((unsigned long long)nd.path[i] << 7) | (unsigned long long)nd.layer[i];
+  int* I = ints + 8 * (size_t)a;
+  I[0] = nd.layer[i]; I[1] = nd.isexist[i]; I[2] = nd.is_plane[i]; I[3] = nd.has_sw[i]; I[4] = nd.opt_state[i]; I[5] = nd.last_num[i]; I[6] = nd.fix_count[i];
+  I[7] = nd.in_slide[nd.root[i]];
+  const size_t rec = 156 + 11 * (size_t)W;
+  double* D = dbl + rec * a;
+  for (int k = 0; k < 10; k++) { D[k] = nd.pcr_add[10 * (size_t)i + k]; D[10 + k] = nd.pcr_fix[10 * (size_t)i + k]; }
+  for (int k = 0; k < 3; k++) D[20 + k] = nd.eigval[3 * (size_t)i + k];
+  for (int k = 0; k < 9; k++) D[23 + k] = nd.eigvec[9 * (size_t)i + k];
+  for (int k = 0; k < 3; k++) { D[32 + k] = nd.pl_center[3 * (size_t)i + k]; D[35 + k] = nd.pl_normal[3 * (size_t)i + k]; }
+  D[38] = nd.pl_radius[i];
+  for (int k = 0; k < 36; k++) D[39 + k] = nd.is_plane[i] ? nd.pl_var[36 * (size_t)i + k] : 0.0;
+  for (int k = 0; k < 81; k++) D[75 + k] = nd.cov_add[81 * (size_t)i + k];
+  for (int s = 0; s < W; s++) {
+    const int m = ring.mp[s];
+    for (int k = 0; k < 10; k++) D[156 + 10 * s + k] = nd.has_sw[i] ? nd.pcrs_local[((size_t)i * W + m) * 10 + k] : 0.0;
+    D[156 + 10 * W + s] = nd.has_sw[i] ? (double)nd.pt_count[(size_t)i * W + m] : 0.0;
+  }
+}
+__global__ void map_rehash_kernel(const unsigned long long* __restrict__ old_keys, const int* __restrict__ old_vals, long long old_cap, unsigned long long* keys, int* vals,
+                                  unsigned long long cap_mask) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= old_cap || old_keys[i] == EMPTY_KEY) return;
+  unsigned long long h = mix64(old_keys[i]) & cap_mask;
+  for (;;) {
+    if (atomicCAS(&keys[h], EMPTY_KEY, old_keys[i]) == EMPTY_KEY) { vals[h] = old_vals[i]; return; }
+    h = (h + 1) & cap_mask;
+  }
+}
+__global__ void map_fill_u64_kernel(unsigned long long* p, long long n, unsigned long long v) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace vxmap
+
+// =====================================================================================================================================
+struct vxba_map {
+  int device = 0;
+  vxmap::Params prm{};
+  hipStream_t stream = nullptr;
+  vxmap::Nodes nd{};
+  std::vector<void*> node_allocs;     // every array of `nd`, for growth / free
+  unsigned long long* keys = nullptr;
+  int* vals = nullptr;
+  long long table_cap = 0;
+  vxmap::Counters* d_cnt = nullptr;
+  vxmap::Counters* h_cnt = nullptr;   // pinned
+  int* d_err = nullptr;
+  int n_nodes = 0, n_roots = 0, n_slide = 0;
+  int serial = 0;
+  int mp[vxmap::MAXW];
+  // one resident scan per window slot
+  struct Scan { double* pnt = nullptr; double* var9 = nullptr; int* perm = nullptr; int* tmp = nullptr; int n = 0, cap = 0; } scan[vxmap::MAXW];
+  double* fix_pnt = nullptr; double* fix_var = nullptr; long long fix_cap = 0, fix_cursor = 0;
+  char* scratch = nullptr; size_t scratch_cap = 0;
+  std::string err;
+};
+
+namespace {
+using namespace vxmap;
+
+int mfail(vxba_map* m, int code, const char* msg) { if (m) m->err = msg; return code; }
+#define VM_HIP(m, call)                                                                     \
+  do {                                                                                      \
+    hipError_t e__ = (call);                                                                \
+    if (e__ != hipSuccess) { (m)->err = std::string(#call ": ") + hipGetErrorString(e__); return VXBA_ERR_HIP; } \
+  } while (0)
+inline int grid_for(long long n, int b = 256) { return (int)std::max<long long>(1, (n + b - 1) / b); }   // never a zero-sized launch: the kernels bound-check
+
+template <class T>
+int grow_array(vxba_map* m, T** p, size_t old_n, size_t new_n) {
+  T* q = nullptr;
+  VM_HIP(m, hipMalloc((void**)&q, new_n * sizeof(T)));
+  VM_HIP(m, hipMemsetAsync(q, 0, new_n * sizeof(T), m->stream));
+  if (*p && old_n) VM_HIP(m, hipMemcpyAsync(q, *p, old_n * sizeof(T), hipMemcpyDeviceToDevice, m->stream));
+  if (*p) { VM_HIP(m, hipStreamSynchronize(m->stream)); VM_HIP(m, hipFree(*p)); }
+  *p = q;
+  return VXBA_OK;
+}
+int ensure_nodes(vxba_map* m, long long want) {
+  Nodes& nd = m->nd;
+  if (want <= nd.cap) return VXBA_OK;
+  long long ncap = std::max<long long>(nd.cap ? 2ll * nd.cap : 1 << 16, want + want / 2);
+  const size_t o = nd.cap, n = (size_t)ncap, W = m->prm.win_size;
+  int rc;
+#define G(field, mult) if ((rc = grow_array(m, &nd.field, o * (mult), n * (mult)))) return rc;
+  G(layer, 1) G(state, 1) G(child, 8) G(root, 1) G(isexist, 1) G(has_sw, 1) G(is_plane, 1) G(last_num, 1) G(opt_state, 1) G(in_slide, 1) G(stamp, 1) G(path, 1)
+  G(key, 1) G(center, 3) G(pcr_add, 10) G(pcr_fix, 10) G(cov_add, 81) G(eigval, 3) G(eigvec, 9) G(pl_center, 3) G(pl_normal, 3) G(pl_radius, 1) G(pl_var, 36)
+  G(pcrs_local, 10 * W) G(ql, 1) G(pt_start, W) G(pt_count, W) G(fix_start, 1) G(fix_count, 1) G(fix_cap, 1)
+#undef G
+  nd.cap = (int)ncap;
+  return VXBA_OK;
+}
+int ensure_table(vxba_map* m, long long roots) {
+  if (m->table_cap >= 2 * roots && m->table_cap > 0) return VXBA_OK;
+  long long ncap = 1 << 12;
+  while (ncap < 4 * roots) ncap <<= 1;
+  unsigned long long* k = nullptr; int* v = nullptr;
+  VM_HIP(m, hipMalloc((void**)&k, ncap * sizeof(unsigned long long)));
+  VM_HIP(m, hipMalloc((void**)&v, ncap * sizeof(int)));
+  map_fill_u64_kernel<<<grid_for(ncap), 256, 0, m->stream>>>(k, ncap, EMPTY_KEY);
+  VM_HIP(m, hipMemsetAsync(v, 0, ncap * sizeof(int), m->stream));
+  if (m->keys) {
+    map_rehash_kernel<<<grid_for(m->table_cap), 256, 0, m->stream>>>(m->keys, m->vals, m->table_cap, k, v, (unsigned long long)ncap - 1);
+    VM_HIP(m, hipStreamSynchronize(m->stream));
+    hipFree(m->keys); hipFree(m->vals);
+  }
+  m->keys = k; m->vals = v; m->table_cap = ncap;
+  return VXBA_OK;
+}
+int ensure_fix(vxba_map* m, long long want) {
+  if (want <= m->fix_cap) return VXBA_OK;
+  const long long ncap = std::max<long long>(m->fix_cap ? 2 * m->fix_cap : 1 << 18, want + want / 4);
+  int rc;
+  if ((rc = grow_array(m, &m->fix_pnt, (size_t)m->fix_cap * 3, (size_t)ncap * 3))) return rc;
+  if ((rc = grow_array(m, &m->fix_var, (size_t)m->fix_cap * 9, (size_t)ncap * 9))) return rc;
+  m->fix_cap = ncap;
+  return VXBA_OK;
+}
+int ensure_scratch(vxba_map* m, size_t bytes) {
+  if (bytes <= m->scratch_cap) return VXBA_OK;
+  if (m->scratch) { VM_HIP(m, hipStreamSynchronize(m->stream)); hipFree(m->scratch); m->scratch = nullptr; m->scratch_cap = 0; }
+  const size_t want = bytes + bytes / 2;
+  VM_HIP(m, hipMalloc((void**)&m->scratch, want));
+  m->scratch_cap = want;
+  return VXBA_OK;
+}
+// counters: push the host view to the device before a stage, pull it back after
+int cnt_push(vxba_map* m) {
+  Counters& c = *m->h_cnt;
+  c.n_nodes = m->n_nodes; c.n_roots = m->n_roots; c.n_touched = 0; c.n_slide_new = 0; c.n_split = 0; c.n_fac = 0; c.n_removed = 0; c.fix_cursor = m->fix_cursor; c.fix_need = 0;
+  VM_HIP(m, hipMemcpyAsync(m->d_cnt, m->h_cnt, sizeof(Counters), hipMemcpyHostToDevice, m->stream));
+  return VXBA_OK;
+}
+int cnt_pull(vxba_map* m) {
+  VM_HIP(m, hipMemcpyAsync(m->h_cnt, m->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, m->stream));
+  VM_HIP(m, hipStreamSynchronize(m->stream));
+  VM_HIP(m, hipGetLastError());
+  m->n_nodes = m->h_cnt->n_nodes; m->n_roots = m->h_cnt->n_roots; m->fix_cursor = m->h_cnt->fix_cursor;
+  return VXBA_OK;
+}
+PoseArg make_poses(const double* Rp, int n) {
+  PoseArg p;
+  std::memset(&p, 0, sizeof p);
+  std::memcpy(p.Rp, Rp, sizeof(double) * 12 * n);
+  return p;
+}
+RingArg make_ring(const vxba_map* m) {
+  RingArg r;
+  for (int i = 0; i < MAXW; i++) r.mp[i] = i < m->prm.win_size ? m->mp[i] : 0;
+  return r;
+}
+ScanSlots make_scans(const vxba_map* m) {
+  ScanSlots s;
+  for (int i = 0; i < MAXW; i++) s.s[i] = ScanSlot{m->scan[i].pnt, m->scan[i].var9, m->scan[i].perm, m->scan[i].tmp, m->scan[i].n};
+  return s;
+}
+int check_err(vxba_map* m, const char* what) {
+  int e = 0;
+  VM_HIP(m, hipMemcpy(&e, m->d_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (e == 0) return VXBA_OK;
+  VM_HIP(m, hipMemset(m->d_err, 0, sizeof(int)));
+  if (e == 1) return mfail(m, VXBA_ERR_UNSUPPORTED, "vxba_map: a point lies outside the +-32768 voxel range");
+  if (e == 2) return mfail(m, VXBA_ERR_STATE, "vxba_map_margi: opt_state beyond the factor (the factor is not the one recut filled)");
+  return mfail(m, VXBA_ERR_STATE, what);
+}
+}  // namespace
+
+extern "C" {
+
+int vxba_map_create(const vxba_map_params* p, int device, vxba_map** out) {
+  if (!out || !p) return VXBA_ERR_ARG;
+  *out = nullptr;
+  if (!(p->voxel_size > 0) || p->max_layer < 0 || p->max_layer > 2 || p->win_size < 1 || p->win_size > vxmap::MAXW || p->thread_num < 1) return VXBA_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return VXBA_ERR_NODEV;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return VXBA_ERR_NODEV;
+  if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_HIP;
+  vxba_map* m = new vxba_map();
+  m->device = device;
+  m->prm.voxel_size = p->voxel_size; m->prm.max_layer = p->max_layer; m->prm.min_eigen_value = p->min_eigen_value;
+  for (int k = 0; k < 4; k++) { m->prm.min_point[k] = p->min_point[k]; m->prm.thre[k] = p->plane_eigen_value_thre[k]; }
+  m->prm.max_points = p->max_points; m->prm.win_size = p->win_size; m->prm.thread_num = p->thread_num;
+  for (int i = 0; i < vxmap::MAXW; i++) m->mp[i] = i;
+  bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipMalloc((void**)&m->d_cnt, sizeof(vxmap::Counters)) == hipSuccess && hipMalloc((void**)&m->d_err, sizeof(int)) == hipSuccess;
+  ok = ok && hipMemset(m->d_err, 0, sizeof(int)) == hipSuccess && hipHostMalloc((void**)&m->h_cnt, sizeof(vxmap::Counters), hipHostMallocDefault) == hipSuccess;
+  if (!ok || ensure_nodes(m, 1 << 16) != VXBA_OK || ensure_table(m, 1 << 10) != VXBA_OK || ensure_fix(m, 1 << 18) != VXBA_OK) { vxba_map_destroy(m); return VXBA_ERR_HIP; }
+  *out = m;
+  return VXBA_OK;
+}
+
+int vxba_map_destroy(vxba_map* m) {
+  if (!m) return VXBA_ERR_ARG;
+  hipSetDevice(m->device);
+  if (m->stream) hipStreamSynchronize(m->stream);
+  vxmap::Nodes& nd = m->nd;
+  void* arrs[] = {nd.layer, nd.state, nd.child, nd.root, nd.isexist, nd.has_sw, nd.is_plane, nd.last_num, nd.opt_state, nd.in_slide, nd.stamp, nd.path, nd.key, nd.center,
+                  nd.pcr_add, nd.pcr_fix, nd.cov_add, nd.eigval, nd.eigvec, nd.pl_center, nd.pl_normal, nd.pl_radius, nd.pl_var, nd.pcrs_local, nd.ql, nd.pt_start,
+                  nd.pt_count, nd.fix_start, nd.fix_count, nd.fix_cap};
+  for (void* a : arrs) if (a) hipFree(a);
+  for (auto& s : m->scan) { hipFree(s.pnt); hipFree(s.var9); hipFree(s.perm); hipFree(s.tmp); }
+  hipFree(m->keys); hipFree(m->vals); hipFree(m->d_cnt); hipFree(m->d_err); hipFree(m->fix_pnt); hipFree(m->fix_var); hipFree(m->scratch);
+  if (m->h_cnt) hipHostFree(m->h_cnt);
+  if (m->stream) hipStreamDestroy(m->stream);
+  delete m;
+  return VXBA_OK;
+}
+
+const char* vxba_map_last_error(const vxba_map* m) { return m ? m->err.c_str() : "null map"; }
+
+// cut_voxel_multi(surf_map, pvec, ord, surf_map_slide, win_size, pwld, sws)   (voxel_map.hpp:1545-1639; voxelslam.cpp:1609)
+static int map_cut_voxel_impl(vxba_map* m, int ord, int64_t n64, const double* pnt_body, const double* var_world, const double* pwld, bool on_device) {
+  if (!m || ord < 0 || ord >= m->prm.win_size || n64 < 0 || n64 > 0x3fffffff || (n64 > 0 && (!pnt_body || !var_world || !pwld))) return mfail(m, VXBA_ERR_ARG, "vxba_map_cut_voxel: bad argument");
+  hipSetDevice(m->device);
+  const int n = (int)n64;
+  const int slot = m->mp[ord];
+  vxba_map::Scan& sc = m->scan[slot];
+  if (n > sc.cap) {
+    VM_HIP(m, hipStreamSynchronize(m->stream));
+    hipFree(sc.pnt); hipFree(sc.var9); hipFree(sc.perm); hipFree(sc.tmp);
+    sc.pnt = sc.var9 = nullptr; sc.perm = sc.tmp = nullptr;
+    const size_t cap = (size_t)n + n / 4 + 64;
+    VM_HIP(m, hipMalloc((void**)&sc.pnt, cap * 3 * sizeof(double)));
+    VM_HIP(m, hipMalloc((void**)&sc.var9, cap * 9 * sizeof(double)));
+    VM_HIP(m, hipMalloc((void**)&sc.perm, cap * sizeof(int)));
+    VM_HIP(m, hipMalloc((void**)&sc.tmp, cap * sizeof(int)));
+    sc.cap = (int)cap;
+  }
+  sc.n = n;
+  if (n == 0) return VXBA_OK;
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  VM_HIP(m, hipMemcpyAsync(sc.pnt, pnt_body, (size_t)n * 3 * sizeof(double), kind, m->stream));
+  VM_HIP(m, hipMemcpyAsync(sc.var9, var_world, (size_t)n * 9 * sizeof(double), kind, m->stream));
+  // scratch: world points, table slot / leaf / pending / sorted leaf per point, radix-sort temporaries
+  size_t tb = 0;
+  rocprim::radix_sort_pairs(nullptr, tb, (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr, (size_t)n, 0, 32, m->stream);
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t b_w = up((size_t)n * 3 * sizeof(double)), b_i = up((size_t)n * sizeof(int));
+  int rc = ensure_scratch(m, b_w + 5 * b_i + up(tb));
+  if (rc) return rc;
+  char* q = m->scratch;
+  double* d_w = (double*)q; q += b_w;
+  int* d_slot = (int*)q; q += b_i;
+  int* d_leaf = (int*)q; q += b_i;
+  int* d_pend = (int*)q; q += b_i;
+  int* d_leaf_s = (int*)q; q += b_i;
+  int* d_iota = (int*)q; q += b_i;
+  void* d_tmp = q;
+  VM_HIP(m, hipMemcpyAsync(d_w, pwld, (size_t)n * 3 * sizeof(double), kind, m->stream));
+  if ((rc = ensure_table(m, (long long)m->n_roots + n))) return rc;
+  if ((rc = ensure_nodes(m, (long long)m->n_nodes + 2ll * n))) return rc;     // at most one new root and one new child per point
+  m->serial++;
+  const int nodes_before = m->n_nodes;
+  if ((rc = cnt_push(m))) return rc;
+  map_roots_kernel<<<grid_for(n), 256, 0, m->stream>>>(m->nd, m->prm, m->keys, m->vals, (unsigned long long)m->table_cap - 1, d_w, n, d_slot, m->d_cnt, m->serial, m->d_err);
+  map_descend_kernel<<<grid_for(n), 256, 0, m->stream>>>(m->nd, m->vals, d_w, n, d_slot, d_leaf, d_pend, m->d_cnt, m->serial);
+  if ((rc = cnt_pull(m))) return rc;
+  if ((rc = check_err(m, "vxba_map_cut_voxel"))) return rc;
+  m->n_slide += m->h_cnt->n_slide_new;
+  map_mark_existing_roots_kernel<<<grid_for(nodes_before), 256, 0, m->stream>>>(m->nd, nodes_before, m->serial);
+  // upstream quirk (voxel_map.hpp:1603-1605): fewer touched roots than threads -> nothing is pushed.  The children the descent above
+  // allocated are empty leaves then, which changes nothing observable (no window, no points, never a factor).
+  if (m->h_cnt->n_touched < m->prm.thread_num) { VM_HIP(m, hipStreamSynchronize(m->stream)); return VXBA_OK; }
+  map_resolve_kernel<<<grid_for(n), 256, 0, m->stream>>>(m->nd, n, d_leaf, d_pend);
+  map_iota_kernel<<<grid_for(n), 256, 0, m->stream>>>(d_iota, n);
+  VM_HIP(m, rocprim::radix_sort_pairs(d_tmp, tb, d_leaf, d_leaf_s, d_iota, sc.perm, (size_t)n, 0, 32, m->stream));
+  map_push_kernel<<<grid_for(n, 64), 64, 0, m->stream>>>(m->nd, m->prm, d_leaf_s, sc.perm, n, sc.pnt, sc.var9, d_w, slot);
+  VM_HIP(m, hipStreamSynchronize(m->stream));
+  VM_HIP(m, hipGetLastError());
+  return VXBA_OK;
+}
+int vxba_map_cut_voxel(vxba_map* m, int ord, int64_t n, const double* pnt_body, const double* var_world, const double* pwld) {
+  return map_cut_voxel_impl(m, ord, n, pnt_body, var_world, pwld, false);
+}
+int vxba_map_cut_voxel_device(vxba_map* m, int ord, int64_t n, const double* d_pnt_body, const double* d_var_world, const double* d_pwld) {
+  return map_cut_voxel_impl(m, ord, n, d_pnt_body, d_var_world, d_pwld, true);
+}
+
+// multi_recut (voxelslam.cpp:1396-1453): recut of every root of the slide map, then tras_opt into `factor` (cleared by the caller like
+// voxhess.clear(); its win_size must be the map's)
+int vxba_map_recut(vxba_map* m, int win_count, const double* Rp, vxba_factor* factor, int64_t* n_pushed) {
+  if (!m || !Rp || !factor || win_count < 1 || win_count > m->prm.win_size) return mfail(m, VXBA_ERR_ARG, "vxba_map_recut: bad argument");
+  if (vxba_win_size(factor) != m->prm.win_size) return mfail(m, VXBA_ERR_ARG, "vxba_map_recut: the factor's win_size differs from the map's");
+  hipSetDevice(m->device);
+  if (n_pushed) *n_pushed = 0;
+  if (m->n_slide < m->prm.thread_num) return VXBA_OK;                      // `if(g_size < thd_num) return;`
+  const PoseArg poses = make_poses(Rp, win_count);
+  const RingArg ring = make_ring(m);
+  int rc;
+  for (int L = 0; L <= m->prm.max_layer; L++) {
+    if ((rc = ensure_scratch(m, (size_t)m->n_nodes * sizeof(int)))) return rc;
+    int* d_split = (int*)m->scratch;
+    if ((rc = cnt_push(m))) return rc;
+    map_judge_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->prm, m->n_nodes, L, d_split, m->d_cnt);
+    if ((rc = cnt_pull(m))) return rc;
+    const int n_split = m->h_cnt->n_split;
+    if (n_split == 0) continue;
+    if ((rc = ensure_nodes(m, (long long)m->n_nodes + 8ll * n_split))) return rc;
+    if ((rc = ensure_fix(m, m->fix_cursor + m->h_cnt->fix_need))) return rc;
+    if ((rc = cnt_push(m))) return rc;
+    map_subdivide_kernel<<<grid_for(8ll * n_split, 64), 64, 0, m->stream>>>(m->nd, m->prm, d_split, n_split, win_count, poses, ring, make_scans(m), m->fix_pnt, m->fix_var, m->d_cnt);
+    if ((rc = cnt_pull(m))) return rc;
+  }
+  // tras_opt, ordered by node id so that the factor is the same from run to run
+  const size_t b_id = (size_t)m->n_nodes * sizeof(unsigned long long), b_nd = (size_t)m->n_nodes * sizeof(int);
+  size_t tb = 0;
+  rocprim::radix_sort_pairs(nullptr, tb, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr, (int*)nullptr, (size_t)m->n_nodes, 0, 64, m->stream);
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  if ((rc = ensure_scratch(m, 2 * up(b_id) + 2 * up(b_nd) + up(tb)))) return rc;
+  char* q = m->scratch;
+  unsigned long long* d_ids = (unsigned long long*)q; q += up(b_id);
+  unsigned long long* d_ids_s = (unsigned long long*)q; q += up(b_id);
+  int* d_nodes = (int*)q; q += up(b_nd);
+  int* d_nodes_s = (int*)q; q += up(b_nd);
+  void* d_tmp = q;
+  if ((rc = cnt_push(m))) return rc;
+  map_factor_flag_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, d_ids, d_nodes, m->d_cnt);
+  if ((rc = cnt_pull(m))) return rc;
+  const int nf = m->h_cnt->n_fac;
+  if (nf == 0) return VXBA_OK;
+  VM_HIP(m, rocprim::radix_sort_pairs(d_tmp, tb, d_ids, d_ids_s, d_nodes, d_nodes_s, (size_t)nf, 0, 64, m->stream));
+  const int W = m->prm.win_size;
+  double* d_stage = nullptr;
+  const size_t per = (size_t)W * 10 + 10 + 1 + 3 + 9 + 10;
+  VM_HIP(m, hipMalloc((void**)&d_stage, (size_t)nf * per * sizeof(double)));
+  double* d_cl = d_stage; double* d_fix = d_cl + (size_t)nf * W * 10; double* d_coe = d_fix + (size_t)nf * 10; double* d_ev = d_coe + nf;
+  double* d_evec = d_ev + (size_t)nf * 3; double* d_mg = d_evec + (size_t)nf * 9;
+  map_factor_gather_kernel<<<grid_for(nf), 256, 0, m->stream>>>(m->nd, W, ring, d_nodes_s, nf, d_cl, d_fix, d_coe, d_ev, d_evec, d_mg);
+  hipError_t e = hipStreamSynchronize(m->stream);
+  if (e == hipSuccess) rc = vxba_internal_push_voxels_device(factor, nf, d_cl, d_fix, d_coe, d_ev, d_evec, d_mg);
+  hipFree(d_stage);
+  if (e != hipSuccess) return mfail(m, VXBA_ERR_HIP, "vxba_map_recut: gather failed");
+  if (rc != VXBA_OK) return mfail(m, rc, vxba_last_error(factor));
+  if (n_pushed) *n_pushed = nf;
+  return VXBA_OK;
+}
+
+// multi_margi (voxelslam.cpp:1321-1394) with mgsize = 1: the factor is the one recut filled; its cache (pcr_adds, eig_values,
+// eig_vectors as the optimiser left them) is read on the device
+int vxba_map_margi(vxba_map* m, int win_count, const double* Rp, vxba_factor* factor) {
+  if (!m || !Rp || !factor || win_count < 1 || win_count > m->prm.win_size) return mfail(m, VXBA_ERR_ARG, "vxba_map_margi: bad argument");
+  hipSetDevice(m->device);
+  if (m->n_slide < m->prm.thread_num) return VXBA_OK;
+  const double *f_ev = nullptr, *f_evec = nullptr, *f_mg = nullptr;
+  int VS = 0, V = 0;
+  int rc = vxba_internal_cache_view(factor, &f_ev, &f_evec, &f_mg, &VS, &V);     // synchronises the factor's stream
+  if (rc != VXBA_OK) return mfail(m, rc, vxba_last_error(factor));
+  const PoseArg poses = make_poses(Rp, win_count);
+  const RingArg ring = make_ring(m);
+  if ((rc = ensure_scratch(m, (size_t)m->n_nodes * sizeof(int)))) return rc;
+  int* d_work = (int*)m->scratch;
+  if ((rc = cnt_push(m))) return rc;
+  map_margi_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->prm, m->n_nodes, win_count, poses, ring, f_ev, f_evec, f_mg, VS, V, d_work, m->d_cnt, m->d_err);
+  if ((rc = cnt_pull(m))) return rc;
+  if ((rc = check_err(m, "vxba_map_margi"))) return rc;
+  if ((rc = ensure_fix(m, m->fix_cursor + m->h_cnt->fix_need))) return rc;
+  if ((rc = cnt_push(m))) return rc;
+  map_margi_points_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->prm, m->n_nodes, poses, ring, make_scans(m), d_work, m->fix_pnt, m->fix_var, m->d_cnt);
+  for (int L = m->prm.max_layer - 1; L >= 0; L--) map_margi_up_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, L);
+  map_release_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->prm.win_size, m->n_nodes);
+  map_leave_slide_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, m->d_cnt);
+  if ((rc = cnt_pull(m))) return rc;
+  m->n_slide -= m->h_cnt->n_removed;
+  return VXBA_OK;
+}
+
+// voxelslam.cpp:1683-1687
+int vxba_map_slide(vxba_map* m, int mgsize) {
+  if (!m || mgsize < 0) return VXBA_ERR_ARG;
+  for (int i = 0; i < m->prm.win_size; i++) {
+    m->mp[i] += mgsize;
+    if (m->mp[i] >= m->prm.win_size) m->mp[i] -= m->prm.win_size;
+  }
+  return VXBA_OK;
+}
+
+int vxba_map_counts(vxba_map* m, int64_t out[4]) {
+  if (!m || !out) return VXBA_ERR_ARG;
+  hipSetDevice(m->device);
+  int* d_n = nullptr;
+  int rc = ensure_scratch(m, (size_t)(m->n_nodes + 64) * sizeof(int));
+  if (rc) return rc;
+  d_n = (int*)m->scratch;
+  VM_HIP(m, hipMemsetAsync(d_n, 0, sizeof(int), m->stream));
+  vxmap::map_leaf_flag_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, d_n + 64, d_n);
+  int nl = 0;
+  VM_HIP(m, hipMemcpyAsync(&nl, d_n, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+  VM_HIP(m, hipStreamSynchronize(m->stream));
+  out[0] = m->n_roots; out[1] = m->n_slide; out[2] = nl; out[3] = m->mp[0];
+  return VXBA_OK;
+}
+
+// Every leaf (octo_state == 0), in no particular order; record layout as documented in include/vxba.h.  Returns the count in *n_out.
+int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints, double* dbl, int64_t* n_out) {
+  if (!m || !n_out) return VXBA_ERR_ARG;
+  hipSetDevice(m->device);
+  const int W = m->prm.win_size;
+  const size_t rec = 156 + 11 * (size_t)W;
+  int rc = ensure_scratch(m, (size_t)(m->n_nodes + 64) * sizeof(int));
+  if (rc) return rc;
+  int* d_n = (int*)m->scratch;
+  int* d_list = d_n + 64;
+  VM_HIP(m, hipMemsetAsync(d_n, 0, sizeof(int), m->stream));
+  vxmap::map_leaf_flag_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, d_list, d_n);
+  int nl = 0;
+  VM_HIP(m, hipMemcpyAsync(&nl, d_n, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+  VM_HIP(m, hipStreamSynchronize(m->stream));
+  *n_out = nl;
+  if (!ids || !ints || !dbl || capacity <= 0) return VXBA_OK;
+  const int n = (int)std::min<int64_t>(nl, capacity);
+  if (n == 0) return VXBA_OK;
+  unsigned long long* d_ids = nullptr; int* d_ints = nullptr; double* d_dbl = nullptr;
+  VM_HIP(m, hipMalloc((void**)&d_ids, (size_t)n * sizeof(unsigned long long)));
+  VM_HIP(m, hipMalloc((void**)&d_ints, (size_t)n * 8 * sizeof(int)));
+  VM_HIP(m, hipMalloc((void**)&d_dbl, (size_t)n * rec * sizeof(double)));
+  vxmap::map_leaf_export_kernel<<<grid_for(n), 256, 0, m->stream>>>(m->nd, W, make_ring(m), d_list, n, d_ids, d_ints, d_dbl);
+  hipError_t e = hipMemcpyAsync(ids, d_ids, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(ints, d_ints, (size_t)n * 8 * sizeof(int), hipMemcpyDeviceToHost, m->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dbl, d_dbl, (size_t)n * rec * sizeof(double), hipMemcpyDeviceToHost, m->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+  hipFree(d_ids); hipFree(d_ints); hipFree(d_dbl);
+  return e == hipSuccess ? VXBA_OK : mfail(m, VXBA_ERR_HIP, "vxba_map_leaves: copy failed");
+}
+
+}  // extern "C"

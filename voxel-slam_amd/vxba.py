@@ -36,6 +36,8 @@ EXPORTS = [
     "vxba_lio_create", "vxba_lio_destroy", "vxba_lio_last_error", "vxba_lio_map_update", "vxba_lio_map_clear", "vxba_lio_map_size", "vxba_lio_scan_raw",
     "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_lio_leaf_stats", "vxba_cov_add_build", "vxba_plane_update", "vxba_down_sampling_voxel", "vxba_voxelize_push_device",
     "vxba_set_option", "vxba_get_option", "vxba_lio_set_option",
+    "vxba_map_create", "vxba_map_destroy", "vxba_map_last_error", "vxba_map_cut_voxel", "vxba_map_cut_voxel_device", "vxba_map_recut", "vxba_map_margi",
+    "vxba_map_slide", "vxba_map_counts", "vxba_map_leaves",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -62,6 +64,12 @@ class VoxelizeParams(C.Structure):
 
 
 _lib = None
+
+
+class MapParams(C.Structure):
+    """vxba_map_params (include/vxba.h)."""
+    _fields_ = [("voxel_size", C.c_double), ("max_layer", C.c_int), ("min_point", C.c_double * 4), ("min_eigen_value", C.c_double),
+                ("plane_eigen_value_thre", C.c_double * 4), ("max_points", C.c_int), ("win_size", C.c_int), ("thread_num", C.c_int)]
 
 
 def load_library(path: str = LIB_PATH) -> C.CDLL:
@@ -146,6 +154,20 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_down_sampling_voxel.argtypes = [ci, C.c_int64, np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS"), cd,
                                            np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS"), C.POINTER(C.c_int64)]
     L.vxba_plane_update.argtypes = [ci, C.c_int64, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p]
+    L.vxba_set_option.argtypes = [vp, ci, ci]
+    L.vxba_get_option.argtypes = [vp, ci, C.POINTER(ci)]
+    L.vxba_lio_set_option.argtypes = [vp, ci, ci]
+    L.vxba_map_create.argtypes = [C.POINTER(MapParams), ci, C.POINTER(vp)]
+    L.vxba_map_destroy.argtypes = [vp]
+    L.vxba_map_last_error.argtypes = [vp]
+    L.vxba_map_last_error.restype = C.c_char_p
+    L.vxba_map_cut_voxel.argtypes = [vp, ci, C.c_int64, _f64p, _f64p, _f64p]
+    L.vxba_map_cut_voxel_device.argtypes = [vp, ci, C.c_int64, vp, vp, vp]
+    L.vxba_map_recut.argtypes = [vp, ci, _f64p, vp, C.POINTER(C.c_int64)]
+    L.vxba_map_margi.argtypes = [vp, ci, _f64p, vp]
+    L.vxba_map_slide.argtypes = [vp, ci]
+    L.vxba_map_counts.argtypes = [vp, _i64p]
+    L.vxba_map_leaves.argtypes = [vp, C.c_int64, vp, vp, vp, C.POINTER(C.c_int64)]
     _lib = L
     return L
 
@@ -814,3 +836,76 @@ def debug_stamps(n_waves: int, clear: bool = False):
     out = np.zeros((n_waves, 32), dtype=np.uint64)
     L.vxba_debug_stamps(int(clear), out.ctypes.data_as(C.c_void_p), out.size)
     return out
+
+
+class LocalMap:
+    """The incremental local map on the GPU (include/vxba.h ``vxba_map_*``; reference: ``surf_map`` / ``surf_map_slide`` of OctoTree nodes,
+    voxel_map.hpp:896-1639, driven as voxelslam.cpp:1592-1700 does)."""
+
+    def __init__(self, voxel_size=1.0, max_layer=2, min_point=(5, 5, 5, 5), min_eigen_value=0.0025, plane_eigen_value_thre=(0.25, 0.25, 0.25, 0.25),
+                 max_points=100, win_size=10, thread_num=5, device=0):
+        self._L = load_library()
+        self.win_size = int(win_size)
+        p = MapParams(float(voxel_size), int(max_layer), (C.c_double * 4)(*min_point), float(min_eigen_value), (C.c_double * 4)(*plane_eigen_value_thre),
+                      int(max_points), int(win_size), int(thread_num))
+        self._h = C.c_void_p()
+        rc = self._L.vxba_map_create(C.byref(p), int(device), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise VxbaError(f"vxba_map_create failed: {_ERRNAMES.get(rc, rc)} (no CPU fallback exists; an MI355X is required)")
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self._L.vxba_map_last_error(self._h)
+            raise VxbaError(f"{_ERRNAMES.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vxba_map_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def cut_voxel(self, ord_, pnt_body, var_world, pwld):
+        pnt = np.ascontiguousarray(pnt_body, dtype=np.float64).reshape(-1, 3)
+        var = np.ascontiguousarray(np.transpose(np.asarray(var_world, dtype=np.float64).reshape(-1, 3, 3), (0, 2, 1)))
+        self._chk(self._L.vxba_map_cut_voxel(self._h, int(ord_), pnt.shape[0], pnt, var.reshape(-1, 9), np.ascontiguousarray(pwld, dtype=np.float64).reshape(-1, 3)))
+
+    def recut(self, win_count, poses, factor: "LidarFactor"):
+        n = C.c_int64(0)
+        self._chk(self._L.vxba_map_recut(self._h, int(win_count), np.ascontiguousarray(poses, dtype=np.float64)[:win_count], factor._h, C.byref(n)))
+        return int(n.value)
+
+    def margi(self, win_count, poses, factor: "LidarFactor"):
+        self._chk(self._L.vxba_map_margi(self._h, int(win_count), np.ascontiguousarray(poses, dtype=np.float64)[:win_count], factor._h))
+
+    def slide(self, mgsize=1):
+        self._chk(self._L.vxba_map_slide(self._h, int(mgsize)))
+
+    def counts(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._chk(self._L.vxba_map_counts(self._h, out))
+        return dict(roots=int(out[0]), slide=int(out[1]), leaves=int(out[2]), mp0=int(out[3]))
+
+    def leaves(self):
+        """Every leaf, sorted by node id, as a dictionary of arrays (fields of include/vxba.h ``vxba_map_leaves``)."""
+        W = self.win_size
+        n = C.c_int64(0)
+        self._chk(self._L.vxba_map_leaves(self._h, 0, None, None, None, C.byref(n)))
+        n = int(n.value)
+        ids = np.zeros(n, dtype=np.uint64); ints = np.zeros((n, 8), dtype=np.int32); d = np.zeros((n, 156 + 11 * W))
+        got = C.c_int64(0)
+        if n:
+            self._chk(self._L.vxba_map_leaves(self._h, n, ids.ctypes.data_as(C.c_void_p), ints.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), C.byref(got)))
+            assert got.value == n
+        o = np.argsort(ids, kind="stable")
+        ids, ints, d = ids[o], ints[o], d[o]
+        return dict(node_id=ids, layer=ints[:, 0], isexist=ints[:, 1].astype(bool), is_plane=ints[:, 2].astype(bool), has_sw=ints[:, 3].astype(bool),
+                    opt_state=ints[:, 4], last_num=ints[:, 5], n_point_fix=ints[:, 6], in_slide=ints[:, 7].astype(bool),
+                    pcr_add=d[:, 0:10], pcr_fix=d[:, 10:20], eig_val=d[:, 20:23], eig_vec=d[:, 23:32], center=d[:, 32:35], normal=d[:, 35:38],
+                    radius=d[:, 38], plane_var=np.transpose(d[:, 39:75].reshape(n, 6, 6), (0, 2, 1)), cov_add=np.transpose(d[:, 75:156].reshape(n, 9, 9), (0, 2, 1)),
+                    pcrs_local=d[:, 156:156 + 10 * W].reshape(n, W, 10), n_points=d[:, 156 + 10 * W:].astype(np.int64))
