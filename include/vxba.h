@@ -261,6 +261,7 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
  * factor's planes in place -- a scan cycle moves the scan up and the poses down.  Parameters are the reference's globals
  * (voxel_map.hpp:83-89, voxelslam.cpp:795-812). */
 typedef struct vxba_map vxba_map;
+typedef struct vxba_lio vxba_lio;   /* the odometry handle, declared below */
 typedef struct vxba_map_params {
   double voxel_size;                 /* voxel_size */
   int max_layer;                     /* max_layer (0..2) */
@@ -280,6 +281,9 @@ const char* vxba_map_last_error(const vxba_map* m);
  * keeps resident). */
 int vxba_map_cut_voxel(vxba_map* m, int ord, int64_t n, const double* pnt_body, const double* var_world, const double* pwld);
 int vxba_map_cut_voxel_device(vxba_map* m, int ord, int64_t n, const double* d_pnt_body, const double* d_var_world, const double* d_pwld);
+/* The same on the scan resident in an odometry handle after vxba_lio_pvec_update (body points, world points and world covariances
+ * are taken from the device: nothing crosses PCIe). */
+int vxba_map_cut_voxel_lio(vxba_map* m, int ord, vxba_lio* lio);
 /* multi_recut (voxelslam.cpp:1396-1453, OctoTree::recut voxel_map.hpp:1148-1194) followed by tras_opt (:1308-1333) straight into
  * `factor` (cleared by the caller, as voxhess.clear(); same win_size).  Rp: win_count poses.  Factor voxels are ordered by node id;
  * *n_pushed (optional) receives their number. */
@@ -287,6 +291,10 @@ int vxba_map_recut(vxba_map* m, int win_count, const double* Rp, vxba_factor* fa
 /* multi_margi (voxelslam.cpp:1321-1394, OctoTree::margi voxel_map.hpp:1196-1305, mgsize = 1) with the optimised poses; reads the
  * cache the optimiser left in `factor` (pcr_adds / eig_values / eig_vectors) on the device. */
 int vxba_map_margi(vxba_map* m, int win_count, const double* Rp, vxba_factor* factor);
+/* Brings the odometry's plane map (vxba_lio, what `match` walks, voxel_map.hpp:1335-1392) up to date with the tree, on the device: the
+ * plane records of every leaf -- and "no plane" for the empty octants of subdivided nodes -- under all roots that were in the slide map
+ * since the last export.  Same voxel_size / max_layer / device.  Call after recut / margi, before the next scan is matched. */
+int vxba_map_export_planes(vxba_map* m, vxba_lio* lio, int64_t* n_exported);
 /* The ring of window slots moves on by mgsize (voxelslam.cpp:1683-1687). */
 int vxba_map_slide(vxba_map* m, int mgsize);
 /* out = [roots, roots in the slide map, leaves, mp[0]] */

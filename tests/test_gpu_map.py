@@ -156,3 +156,62 @@ def test_thread_num_quirk_and_errors(vx):
         m.cut_voxel(0, pts, var, pts + 1e6)                                     # outside the +-32768 voxel range
     with pytest.raises(vx.VxbaError):
         m.recut(1, pose[None], vx.LidarFactor(4))                               # win_size mismatch
+
+
+def test_whole_scan_cycle_on_the_device_matches_the_oracle_cycle(vx):
+    """A scan cycle that moves only the raw scan up and the poses down: var_init -> lio_state_estimation against the plane map the
+    tree exported on the device -> pvec_update (resident) -> cut_voxel on the resident scan -> recut + tras_opt into the factor -> BA ->
+    margi on the factor's device cache -> ring shift -> plane export.  Free-running next to the same cycle on the oracle (whose odometry
+    gets the full plane map re-built from its tree every scan): the incremental export must keep the two plane maps equivalent."""
+    from tests.test_gpu_local_mapping_cycle import lio_leaf_args
+    S, win, pts, seed = 10, 4, 20000, 7
+    xyz, fp, poses_gt, _ = synth.make_scans(win_size=S, pts_per_scan=pts, seed=synth.MASTER_SEED + 900 + seed)
+    rng = np.random.default_rng(seed)
+    mo, mg = O.LocalMapOracle(win_size=win, **PRM), vx.LocalMap(win_size=win, **PRM)
+    fo, fg = O.Oracle(win), vx.LidarFactor(win)
+    ge = vx.LioEstimator(PRM["voxel_size"], PRM["max_layer"])
+    xo, xg = [], []
+    win_count = estimated = 0
+    cov = np.eye(15) * 1e-4
+    for k in range(S):
+        s = slice(fp[k], fp[k + 1])
+        scan32 = xyz[s].astype(np.float32)
+        prior = np.concatenate([poses_gt[k][:9], poses_gt[k][9:12] + rng.normal(0, 0.02, 3), np.zeros(9), [0, 0, -9.8]])
+        oe = O.LioOracle(PRM["voxel_size"], PRM["max_layer"])
+        oe.var_init(scan32); ge.var_init(scan32)
+        so, sg, co, cg = prior, prior, cov, cov
+        lv = mo.leaves() if k else None
+        if lv is not None and (lv["is_plane"] & (lv["last_num"] > 0)).sum() > 200:
+            oe.map_update(*lio_leaf_args(lv))
+            ro = oe.lio_state_estimation(prior, cov); rg = ge.lio_state_estimation(prior, cov)
+            assert ro["iterations"] == rg["iterations"] and abs(ro["match_num"] - rg["match_num"]) <= 3 and ro["match_num"] > 0.3 * pts
+            et, er = synth.pose_errors(rg["state"][None, :12], ro["state"][None, :12])
+            assert et < 1e-7 and er < 1e-7, (k, et, er)
+            so, co, sg, cg = ro["state"], ro["cov"], rg["state"], rg["cov"]
+            estimated += 1
+        pw_o, var_o = oe.pvec_update(so, co)
+        ge.pvec_update(sg, cg, resident=True)
+        pnt_body, _ = oe.read_points()
+        win_count += 1
+        xo.append(so[:12].copy()); xg.append(sg[:12].copy())
+        fo.clear(); fg.clear()
+        mo.cut_voxel(win_count - 1, pnt_body, var_o, pw_o)
+        mg.cut_voxel_lio(win_count - 1, ge)
+        mo.recut(win_count, np.stack(xo), fo); mg.recut(win_count, np.stack(xg), fg)
+        a, b = by_id(mo.leaves()), mg.leaves()
+        same_structure(a, b, ("recut", k))
+        assert rel(a["pcrs_local"], b["pcrs_local"]) < 1e-9 and fo.size() == fg.size()
+        if win_count >= win:
+            oo = fo.damping_iter(np.stack(xo), max_iter=3, thd_num=2)
+            gg = vx.Lidar_BA_Optimizer().damping_iter(np.stack(xg), fg, max_iter=3)
+            assert np.array_equal(oo["trace"][:, 6:], gg["trace"][:, 6:])
+            et, er = synth.pose_errors(gg["poses"], oo["poses"])
+            assert et < 1e-7 and er < 1e-7, (k, et, er)
+            mo.margi(win_count, oo["poses"], fo); mg.margi(win_count, gg["poses"], fg)
+            mo.slide(1); mg.slide(1)
+            xo[:] = [p for p in oo["poses"][1:]]; xg[:] = [p for p in gg["poses"][1:]]
+            win_count -= 1
+            same_structure(by_id(mo.leaves()), mg.leaves(), ("margi", k))
+        n_exp = mg.export_planes(ge)
+        assert n_exp > 0
+    assert estimated >= 4

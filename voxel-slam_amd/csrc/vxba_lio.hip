@@ -34,6 +34,7 @@
 #include "vxba_imu.hpp"
 #include "vxba_math.hpp"
 #include "vxba_scratch.hpp"
+#include "vxba_internal.h"
 #include "vxba_solve.hpp"
 
 namespace vxl {
@@ -966,6 +967,41 @@ int vxba_lio_map_update(vxba_lio* h, int64_t n, const int64_t* loc, const int32_
   return VXBA_OK;
 }
 
+// ---- links for vxba_map.hip (vxba_internal.h) ----
+int vxba_internal_lio_scan_view(vxba_lio* h, const double** d_pts_soa, long long* n, long long* stride, const double** d_world, int* world_valid) {
+  if (!h || !d_pts_soa || !n || !stride || !d_world || !world_valid) return VXBA_ERR_ARG;
+  LIO_LOCK(h);
+  LIO_HIP(h, hipSetDevice(h->device));
+  LIO_HIP(h, hipStreamSynchronize(h->stream));
+  *d_pts_soa = h->d_pts; *n = h->n_pts; *stride = h->pts_stride; *d_world = h->d_world; *world_valid = h->world_valid ? 1 : 0;
+  return VXBA_OK;
+}
+// vxba_lio_map_update with every array already on the device (loc / layer / path validated by the producer)
+int vxba_internal_lio_map_update_device(vxba_lio* h, long long n, const long long* d_loc, const int* d_layer, const int* d_path, const int* d_is_plane, const double* d_center,
+                                        const double* d_normal, const double* d_plane_var, const double* d_radius) {
+  if (!h || n < 0) return VXBA_ERR_ARG;
+  if (n == 0) return VXBA_OK;
+  LIO_LOCK(h);
+  LIO_HIP(h, hipSetDevice(h->device));
+  int rc = lio_map_reserve(h, n);
+  if (rc != VXBA_OK) return rc;
+  vxl::lio_map_update_kernel<<<grid_for(n), 256, 0, h->stream>>>(n, d_loc, d_layer, d_path, d_is_plane, d_center, d_normal, d_plane_var, d_radius, h->d_keys, (unsigned long long)h->cap - 1,
+                                                                 h->d_cells, h->cells_per_root, h->max_layer, h->voxel_size, h->d_planes, h->d_plane_tag, h->d_counters);
+  hipError_t e = hipGetLastError();
+  int cnt[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpyAsync(cnt, h->d_counters, sizeof cnt, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) { h->err = std::string("lio_map_update_device: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
+  h->n_roots = cnt[0]; h->n_planes = cnt[1];
+  h->cache_valid = false;
+  return VXBA_OK;
+}
+int vxba_internal_lio_geometry(const vxba_lio* h, double* voxel_size, int* max_layer, int* device) {
+  if (!h) return VXBA_ERR_ARG;
+  *voxel_size = h->voxel_size; *max_layer = h->max_layer; *device = h->device;
+  return VXBA_OK;
+}
+
 int vxba_lio_map_size(const vxba_lio* h, int64_t* n_roots, int64_t* n_planes) {
   if (!h) return VXBA_ERR_ARG;
   if (n_roots) *n_roots = h->n_roots;
@@ -1041,7 +1077,7 @@ int vxba_lio_scan_read(vxba_lio* h, double* pnt, double* var) {
 }
 
 int vxba_lio_pvec_update(vxba_lio* h, const double* state, const double* cov, double* pwld, double* var) {
-  if (!h || !state || !cov || !pwld) return VXBA_ERR_ARG;
+  if (!h || !state || !cov) return VXBA_ERR_ARG;     // pwld == NULL: the result only stays on the device (vxba_map_cut_voxel_lio, vxba_lio_leaf_stats)
   LIO_LOCK(h);
   if (h->n_pts == 0) return VXBA_OK;
   LIO_HIP(h, hipSetDevice(h->device));
@@ -1056,8 +1092,8 @@ int vxba_lio_pvec_update(vxba_lio* h, const double* state, const double* cov, do
   h->world_valid = false;
   vxl::lio_pvec_update_kernel<<<grid_for(n), 256, 0, h->stream>>>(h->d_pts, n, h->pts_stride, sweep_arg(state, cov), d, d + 3 * n);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(pwld, d, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess && var) e = hipMemcpyAsync(var, d + 3 * n, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess && pwld) e = hipMemcpyAsync(pwld, d, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess && pwld && var) e = hipMemcpyAsync(var, d + 3 * n, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) { h->err = std::string("vxba_lio_pvec_update: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
   h->world_valid = true;

@@ -25,6 +25,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -56,7 +59,7 @@ struct RingArg { int mp[MAXW]; };
 
 struct Nodes {
   int cap;
-  int *layer, *state, *child, *root, *isexist, *has_sw, *is_plane, *last_num, *opt_state, *in_slide, *stamp, *path;
+  int *layer, *state, *child, *root, *isexist, *has_sw, *is_plane, *last_num, *opt_state, *in_slide, *stamp, *path, *dirty;
   unsigned long long* key;     // root key (x,y,z offset by LOC_OFF, 16 bits each)
   double *center, *pcr_add, *pcr_fix, *cov_add, *eigval, *eigvec, *pl_center, *pl_normal, *pl_radius, *pl_var, *pcrs_local;
   float* ql;
@@ -186,6 +189,7 @@ __global__ void map_descend_kernel(Nodes nd, const int* __restrict__ vals, const
   int node = vals[s] - 1;
   if (atomicExch(&nd.stamp[node], serial) != serial) atomicAdd(&cnt->n_touched, 1);      // distinct roots this scan touches (:1603-1605)
   if (atomicExch(&nd.in_slide[node], 1) == 0) atomicAdd(&cnt->n_slide_new, 1);         // feat_tem_map (:1566-1567, 1580)
+  nd.dirty[node] = 1;
   const double w[3] = {pwld[3 * i], pwld[3 * i + 1], pwld[3 * i + 2]};
   pend_parent[i] = -1;
   while (nd.state[node] != 0) {
@@ -662,6 +666,50 @@ __global__ void map_leaf_export_kernel(Nodes nd, int W, RingArg ring, const int*
     D[156 + 10 * W + s] = nd.has_sw[i] ? (double)nd.pt_count[(size_t)i * W + m] : 0.0;
   }
 }
+// Plane records for the odometry's plane map (vxba_lio): every leaf under a root whose subtree may have changed since the last export,
+// plus an explicit "no plane here" entry for every octant of a subdivided node that has no child -- together they tile the root, so
+// the entries never overlap and one launch of the odometry's update kernel applies them race-free.
+__global__ void map_plane_export_kernel(Nodes nd, int n_nodes, int max_layer, long long* __restrict__ loc, int* __restrict__ layer, int* __restrict__ path, int* __restrict__ is_plane,
+                                        double* __restrict__ center, double* __restrict__ normal, double* __restrict__ plane_var, double* __restrict__ radius, int* n_out, int capacity) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes || !nd.dirty[nd.root[i]]) return;
+  const unsigned long long key = nd.key[i];
+  const long long lx = (long long)((key >> 32) & 0xffff) - LOC_OFF, ly = (long long)((key >> 16) & 0xffff) - LOC_OFF, lz = (long long)(key & 0xffff) - LOC_OFF;
+  const int L = nd.layer[i], p = nd.path[i];
+  auto lio_path = [](int p9, int lay) { int r = 0; for (int l = 0; l < lay; l++) r |= ((p9 >> (3 * (2 - l))) & 7) << (3 * l); return r; };
+  if (nd.state[i] == 0) {
+    const int k = atomicAdd(n_out, 1);
+    if (k >= capacity) return;
+    loc[3 * k] = lx; loc[3 * k + 1] = ly; loc[3 * k + 2] = lz;
+    layer[k] = L; path[k] = lio_path(p, L);
+    const int plane = (nd.is_plane[i] && nd.last_num[i] > 0) ? 1 : 0;     // a leaf that never saw plane_update holds an all-zero record: never matched
+    is_plane[k] = plane;
+    for (int e = 0; e < 3; e++) { center[3 * k + e] = nd.pl_center[3 * (size_t)i + e]; normal[3 * k + e] = nd.pl_normal[3 * (size_t)i + e]; }
+    for (int e = 0; e < 36; e++) plane_var[36 * (size_t)k + e] = nd.pl_var[36 * (size_t)i + e];
+    radius[k] = nd.pl_radius[i];
+  } else if (L < max_layer) {
+    for (int o = 0; o < 8; o++) {
+      if (nd.child[8 * (size_t)i + o] != 0) continue;
+      const int k = atomicAdd(n_out, 1);
+      if (k >= capacity) continue;        // the counting pass (capacity 0) must still see every empty octant
+      loc[3 * k] = lx; loc[3 * k + 1] = ly; loc[3 * k + 2] = lz;
+      layer[k] = L + 1; path[k] = lio_path(p | (o << (3 * (2 - L))), L + 1);
+      is_plane[k] = 0;
+      for (int e = 0; e < 3; e++) { center[3 * k + e] = 0; normal[3 * k + e] = 0; }
+      for (int e = 0; e < 36; e++) plane_var[36 * (size_t)k + e] = 0;
+      radius[k] = 0;
+    }
+  }
+}
+__global__ void map_dirty_reset_kernel(Nodes nd, int n_nodes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_nodes && nd.root[i] == i && nd.layer[i] == 0) nd.dirty[i] = nd.in_slide[i];     // roots still in the slide map keep changing
+}
+__global__ void map_gather_body_kernel(const double* __restrict__ soa, long long n, long long stride, double* __restrict__ pnt) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = 0; k < 3; k++) pnt[3 * i + k] = soa[k * stride + i];
+}
 __global__ void map_rehash_kernel(const unsigned long long* __restrict__ old_keys, const int* __restrict__ old_vals, long long old_cap, unsigned long long* keys, int* vals,
                                   unsigned long long cap_mask) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -730,7 +778,7 @@ int ensure_nodes(vxba_map* m, long long want) {
   const size_t o = nd.cap, n = (size_t)ncap, W = m->prm.win_size;
   int rc;
 #define G(field, mult) if ((rc = grow_array(m, &nd.field, o * (mult), n * (mult)))) return rc;
-  G(layer, 1) G(state, 1) G(child, 8) G(root, 1) G(isexist, 1) G(has_sw, 1) G(is_plane, 1) G(last_num, 1) G(opt_state, 1) G(in_slide, 1) G(stamp, 1) G(path, 1)
+  G(layer, 1) G(state, 1) G(child, 8) G(root, 1) G(isexist, 1) G(has_sw, 1) G(is_plane, 1) G(last_num, 1) G(opt_state, 1) G(in_slide, 1) G(stamp, 1) G(path, 1) G(dirty, 1)
   G(key, 1) G(center, 3) G(pcr_add, 10) G(pcr_fix, 10) G(cov_add, 81) G(eigval, 3) G(eigvec, 9) G(pl_center, 3) G(pl_normal, 3) G(pl_radius, 1) G(pl_var, 36)
   G(pcrs_local, 10 * W) G(ql, 1) G(pt_start, W) G(pt_count, W) G(fix_start, 1) G(fix_count, 1) G(fix_cap, 1)
 #undef G
@@ -842,7 +890,7 @@ int vxba_map_destroy(vxba_map* m) {
   hipSetDevice(m->device);
   if (m->stream) hipStreamSynchronize(m->stream);
   vxmap::Nodes& nd = m->nd;
-  void* arrs[] = {nd.layer, nd.state, nd.child, nd.root, nd.isexist, nd.has_sw, nd.is_plane, nd.last_num, nd.opt_state, nd.in_slide, nd.stamp, nd.path, nd.key, nd.center,
+  void* arrs[] = {nd.layer, nd.state, nd.child, nd.root, nd.isexist, nd.has_sw, nd.is_plane, nd.last_num, nd.opt_state, nd.in_slide, nd.stamp, nd.path, nd.dirty, nd.key, nd.center,
                   nd.pcr_add, nd.pcr_fix, nd.cov_add, nd.eigval, nd.eigvec, nd.pl_center, nd.pl_normal, nd.pl_radius, nd.pl_var, nd.pcrs_local, nd.ql, nd.pt_start,
                   nd.pt_count, nd.fix_start, nd.fix_count, nd.fix_cap};
   for (void* a : arrs) if (a) hipFree(a);
@@ -1068,6 +1116,73 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
   if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
   hipFree(d_ids); hipFree(d_ints); hipFree(d_dbl);
   return e == hipSuccess ? VXBA_OK : mfail(m, VXBA_ERR_HIP, "vxba_map_leaves: copy failed");
+}
+
+// cut_voxel_multi on the scan resident in an odometry handle after vxba_lio_pvec_update: nothing crosses PCIe.
+int vxba_map_cut_voxel_lio(vxba_map* m, int ord, vxba_lio* lio) {
+  if (!m || !lio) return mfail(m, VXBA_ERR_ARG, "vxba_map_cut_voxel_lio: null argument");
+  const double *soa = nullptr, *world = nullptr;
+  long long n = 0, stride = 0;
+  int valid = 0;
+  int rc = vxba_internal_lio_scan_view(lio, &soa, &n, &stride, &world, &valid);
+  if (rc != VXBA_OK) return mfail(m, rc, "vxba_map_cut_voxel_lio: cannot read the odometry handle");
+  if (n > 0 && !valid) return mfail(m, VXBA_ERR_STATE, "vxba_map_cut_voxel_lio: no world points on the device (call vxba_lio_pvec_update first)");
+  if (n == 0) return map_cut_voxel_impl(m, ord, 0, nullptr, nullptr, nullptr, true);
+  hipSetDevice(m->device);
+  double* d_pnt = nullptr;
+  VM_HIP(m, hipMalloc((void**)&d_pnt, (size_t)n * 3 * sizeof(double)));
+  vxmap::map_gather_body_kernel<<<grid_for(n), 256, 0, m->stream>>>(soa, n, stride, d_pnt);
+  rc = map_cut_voxel_impl(m, ord, n, d_pnt, world + 3 * n, world, true);
+  hipStreamSynchronize(m->stream);
+  hipFree(d_pnt);
+  return rc;
+}
+
+// The odometry's plane map (vxba_lio) brought up to date with the tree: the leaves (and empty octants) under every root that was in
+// the slide map since the last export.  Call after vxba_map_recut / vxba_map_margi, before the next scan is matched.
+int vxba_map_export_planes(vxba_map* m, vxba_lio* lio, int64_t* n_exported) {
+  if (!m || !lio) return mfail(m, VXBA_ERR_ARG, "vxba_map_export_planes: null argument");
+  double vs = 0; int ml = 0, dev = 0;
+  vxba_internal_lio_geometry(lio, &vs, &ml, &dev);
+  if (vs != m->prm.voxel_size || ml != m->prm.max_layer || dev != m->device) return mfail(m, VXBA_ERR_ARG, "vxba_map_export_planes: voxel_size / max_layer / device of the two handles differ");
+  hipSetDevice(m->device);
+  if (n_exported) *n_exported = 0;
+  if (m->n_nodes == 0) return VXBA_OK;
+  const long long cap = 8ll * m->n_nodes;
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t b_loc = up((size_t)cap * 3 * 8), b_i = up((size_t)cap * 4), b_3 = up((size_t)cap * 3 * 8), b_36 = up((size_t)cap * 36 * 8), b_1 = up((size_t)cap * 8);
+  // the worst case (every node exports eight entries) is far above what a map holds; size for it lazily: first pass counts
+  int rc = ensure_scratch(m, 256);
+  if (rc) return rc;
+  int* d_n = (int*)m->scratch;
+  VM_HIP(m, hipMemsetAsync(d_n, 0, sizeof(int), m->stream));
+  vxmap::map_plane_export_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, m->prm.max_layer, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_n, 0);
+  int n = 0;
+  VM_HIP(m, hipMemcpyAsync(&n, d_n, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+  VM_HIP(m, hipStreamSynchronize(m->stream));
+  (void)b_loc; (void)b_i; (void)b_3; (void)b_36; (void)b_1;
+  if (n == 0) return VXBA_OK;
+  const size_t c_loc = up((size_t)n * 3 * 8), c_i = up((size_t)n * 4), c_3 = up((size_t)n * 3 * 8), c_36 = up((size_t)n * 36 * 8), c_1 = up((size_t)n * 8);
+  if ((rc = ensure_scratch(m, 256 + c_loc + 3 * c_i + 2 * c_3 + c_36 + c_1))) return rc;
+  char* q = m->scratch;
+  d_n = (int*)q; q += 256;
+  long long* d_loc = (long long*)q; q += c_loc;
+  int* d_layer = (int*)q; q += c_i;
+  int* d_path = (int*)q; q += c_i;
+  int* d_isp = (int*)q; q += c_i;
+  double* d_center = (double*)q; q += c_3;
+  double* d_normal = (double*)q; q += c_3;
+  double* d_pvar = (double*)q; q += c_36;
+  double* d_radius = (double*)q;
+  VM_HIP(m, hipMemsetAsync(d_n, 0, sizeof(int), m->stream));
+  vxmap::map_plane_export_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, m->prm.max_layer, d_loc, d_layer, d_path, d_isp, d_center, d_normal, d_pvar, d_radius, d_n, n);
+  vxmap::map_dirty_reset_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes);
+  VM_HIP(m, hipStreamSynchronize(m->stream));
+  VM_HIP(m, hipGetLastError());
+  rc = vxba_internal_lio_map_update_device(lio, n, d_loc, d_layer, d_path, d_isp, d_center, d_normal, d_pvar, d_radius);
+  if (rc != VXBA_OK) return mfail(m, rc, vxba_lio_last_error(lio));
+  if (n_exported) *n_exported = n;
+  return VXBA_OK;
 }
 
 }  // extern "C"

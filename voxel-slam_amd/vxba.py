@@ -37,7 +37,7 @@ EXPORTS = [
     "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_lio_leaf_stats", "vxba_cov_add_build", "vxba_plane_update", "vxba_down_sampling_voxel", "vxba_voxelize_push_device",
     "vxba_set_option", "vxba_get_option", "vxba_lio_set_option",
     "vxba_map_create", "vxba_map_destroy", "vxba_map_last_error", "vxba_map_cut_voxel", "vxba_map_cut_voxel_device", "vxba_map_recut", "vxba_map_margi",
-    "vxba_map_slide", "vxba_map_counts", "vxba_map_leaves",
+    "vxba_map_slide", "vxba_map_counts", "vxba_map_leaves", "vxba_map_cut_voxel_lio", "vxba_map_export_planes",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -148,7 +148,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_lio_scan_read.argtypes = [vp, _f64p, _f64p]
     L.vxba_lio_sweep.argtypes = [vp, _f64p, _f64p, ci, _f64p, vp, vp]
     L.vxba_lio_state_estimation.argtypes = [vp, _f64p, _f64p, vp, vp]
-    L.vxba_lio_pvec_update.argtypes = [vp, _f64p, _f64p, _f64p, vp]
+    L.vxba_lio_pvec_update.argtypes = [vp, _f64p, _f64p, vp, vp]
     L.vxba_lio_leaf_stats.argtypes = [vp, C.c_int64, _i64p, vp, _f64p, _f64p]
     L.vxba_cov_add_build.argtypes = [ci, C.c_int64, C.c_int64, _f64p, _f64p, _i64p, _f64p]
     L.vxba_down_sampling_voxel.argtypes = [ci, C.c_int64, np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS"), cd,
@@ -163,6 +163,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_map_last_error.restype = C.c_char_p
     L.vxba_map_cut_voxel.argtypes = [vp, ci, C.c_int64, _f64p, _f64p, _f64p]
     L.vxba_map_cut_voxel_device.argtypes = [vp, ci, C.c_int64, vp, vp, vp]
+    L.vxba_map_cut_voxel_lio.argtypes = [vp, ci, vp]
+    L.vxba_map_export_planes.argtypes = [vp, vp, C.POINTER(C.c_int64)]
     L.vxba_map_recut.argtypes = [vp, ci, _f64p, vp, C.POINTER(C.c_int64)]
     L.vxba_map_margi.argtypes = [vp, ci, _f64p, vp]
     L.vxba_map_slide.argtypes = [vp, ci]
@@ -713,15 +715,19 @@ class LioEstimator:
         return {"ok": bool(info[0]), "state": st, "cov": cv.T.copy(), "iterations": it, "match_num": int(info[2]), "min_eig": float(info[3]),
                 "sweeps": [unpack_sweep(sweeps[k]) for k in range(it)]}
 
-    def pvec_update(self, state, cov, with_var: bool = True):
-        """World points (and, unless ``with_var`` is False, world covariances n x 3 x 3) of the scan; both stay on the device for leaf_stats."""
+    def pvec_update(self, state, cov, with_var: bool = True, resident: bool = False):
+        """World points (and, unless ``with_var`` is False, world covariances n x 3 x 3) of the scan; both stay on the device for leaf_stats
+        and LocalMap.cut_voxel_lio.  ``resident=True`` returns nothing: the result only stays on the device."""
         n = self.scan_size()
+        if resident:
+            self._chk(self._L.vxba_lio_pvec_update(self._h, _c(state), self._cov(cov), None, None))
+            return None
         pw = np.zeros((n, 3))
         if not with_var:
-            self._chk(self._L.vxba_lio_pvec_update(self._h, _c(state), self._cov(cov), pw, None))
+            self._chk(self._L.vxba_lio_pvec_update(self._h, _c(state), self._cov(cov), pw.ctypes.data_as(C.c_void_p), None))
             return pw
         var = np.zeros((n, 9))
-        self._chk(self._L.vxba_lio_pvec_update(self._h, _c(state), self._cov(cov), pw, var.ctypes.data_as(C.c_void_p)))
+        self._chk(self._L.vxba_lio_pvec_update(self._h, _c(state), self._cov(cov), pw.ctypes.data_as(C.c_void_p), var.ctypes.data_as(C.c_void_p)))
         return pw, np.transpose(var.reshape(n, 3, 3), (0, 2, 1)).copy()
 
     def leaf_stats(self, cell_ptr, order):
@@ -874,6 +880,16 @@ class LocalMap:
         pnt = np.ascontiguousarray(pnt_body, dtype=np.float64).reshape(-1, 3)
         var = np.ascontiguousarray(np.transpose(np.asarray(var_world, dtype=np.float64).reshape(-1, 3, 3), (0, 2, 1)))
         self._chk(self._L.vxba_map_cut_voxel(self._h, int(ord_), pnt.shape[0], pnt, var.reshape(-1, 9), np.ascontiguousarray(pwld, dtype=np.float64).reshape(-1, 3)))
+
+    def cut_voxel_lio(self, ord_, est: "LioEstimator"):
+        """cut_voxel_multi on the scan resident in the odometry handle after ``est.pvec_update(..., resident=True)``."""
+        self._chk(self._L.vxba_map_cut_voxel_lio(self._h, int(ord_), est._h))
+
+    def export_planes(self, est: "LioEstimator") -> int:
+        """Plane records of the changed part of the tree into the odometry's plane map, on the device."""
+        n = C.c_int64(0)
+        self._chk(self._L.vxba_map_export_planes(self._h, est._h, C.byref(n)))
+        return int(n.value)
 
     def recut(self, win_count, poses, factor: "LidarFactor"):
         n = C.c_int64(0)
