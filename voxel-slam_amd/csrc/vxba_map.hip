@@ -69,7 +69,9 @@ struct Nodes {
 };
 
 struct Counters {   // device block of counters, read back after each stage
-  int n_nodes, n_roots, n_touched, n_slide_new, n_split, n_fac, n_removed, pad;
+  int n_nodes, n_roots, n_touched, n_slide_new, n_split, n_fac, n_removed, err;
+  int n_split_l[4];
+  long long fix_need_l[4];
   long long fix_cursor, fix_need;
 };
 
@@ -151,12 +153,12 @@ __device__ __forceinline__ void init_child(const Nodes& nd, int c, int parent, i
 // ---- cut_voxel ---------------------------------------------------------------------------------------------------------------
 // A: root voxel of every point, find-or-insert (voxel_map.hpp:1553-1582)
 __global__ void map_roots_kernel(Nodes nd, Params prm, unsigned long long* keys, int* vals, unsigned long long cap_mask, const double* __restrict__ pwld, int n,
-                                 int* __restrict__ slot_of_point, Counters* cnt, int serial, int* err) {
+                                 int* __restrict__ slot_of_point, Counters* cnt, int serial) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const long long x = voxel_index(pwld[3 * i], prm.voxel_size), y = voxel_index(pwld[3 * i + 1], prm.voxel_size), z = voxel_index(pwld[3 * i + 2], prm.voxel_size);
   const long long a = x + LOC_OFF, b = y + LOC_OFF, c = z + LOC_OFF;
-  if ((a | b | c) < 0 || a >= 2 * LOC_OFF || b >= 2 * LOC_OFF || c >= 2 * LOC_OFF) { *err = 1; slot_of_point[i] = -1; return; }
+  if ((a | b | c) < 0 || a >= 2 * LOC_OFF || b >= 2 * LOC_OFF || c >= 2 * LOC_OFF) { cnt->err = 1; slot_of_point[i] = -1; return; }
   const unsigned long long key = ((unsigned long long)a << 32) | ((unsigned long long)b << 16) | (unsigned long long)c;
   unsigned long long h = mix64(key) & cap_mask;
   for (;;) {
@@ -260,9 +262,10 @@ __global__ void map_mark_existing_roots_kernel(Nodes nd, int n_nodes_before, int
 
 // ---- recut -------------------------------------------------------------------------------------------------------------------
 // OctoTree::recut's leaf branch (voxel_map.hpp:1150-1172) for every leaf of layer L under a root of the slide map
-__global__ void map_judge_kernel(Nodes nd, Params prm, int n_nodes, int L, int* __restrict__ split_list, Counters* cnt) {
+__global__ void map_judge_kernel(Nodes nd, Params prm, int n_bound, int L, int* __restrict__ split_list, Counters* cnt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_nodes || nd.layer[i] != L || nd.state[i] != 0 || !nd.in_slide[nd.root[i]]) return;
+  const int n_nodes = cnt->n_nodes;          // the previous layer's subdivision may have added nodes the host has not seen yet
+  if (i >= n_bound || i >= n_nodes || nd.layer[i] != L || nd.state[i] != 0 || !nd.in_slide[nd.root[i]]) return;
   nd.opt_state[i] = -1;
   const double* c = nd.pcr_add + (size_t)i * 10;
   if (c[9] <= prm.min_point[L]) { nd.is_plane[i] = 0; return; }
@@ -276,9 +279,9 @@ __global__ void map_judge_kernel(Nodes nd, Params prm, int n_nodes, int L, int* 
   const int plane = (lam[0] < prm.min_eigen_value && (lam[0] / lam[2]) < prm.thre[L]) ? 1 : 0;
   nd.is_plane[i] = plane;
   if (plane || L >= prm.max_layer) return;
-  const int k = atomicAdd(&cnt->n_split, 1);
+  const int k = atomicAdd(&cnt->n_split_l[L], 1);
   split_list[k] = i;
-  if (nd.pcr_fix[(size_t)i * 10 + 9] != 0.0) atomicAdd((unsigned long long*)&cnt->fix_need, (unsigned long long)nd.fix_count[i]);
+  if (nd.pcr_fix[(size_t)i * 10 + 9] != 0.0) atomicAdd((unsigned long long*)&cnt->fix_need_l[L], (unsigned long long)nd.fix_count[i]);
 }
 // fix_divide + subdivide(0 .. win_count-1) of one splitting leaf (voxel_map.hpp:1074-1116, 1174-1188): lane c of the node's eight
 // replays the reference's push sequence and keeps octant c.  64 lanes = 8 nodes.
@@ -407,9 +410,9 @@ __global__ __launch_bounds__(64) void map_subdivide_kernel(Nodes nd, Params prm,
   }
 }
 // tras_opt's filter (voxel_map.hpp:1312-1314): candidates with their node ids, to be ordered by id
-__global__ void map_factor_flag_kernel(Nodes nd, int n_nodes, unsigned long long* __restrict__ ids, int* __restrict__ nodes, Counters* cnt) {
+__global__ void map_factor_flag_kernel(Nodes nd, int n_bound, unsigned long long* __restrict__ ids, int* __restrict__ nodes, Counters* cnt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_nodes || nd.state[i] != 0 || !nd.in_slide[nd.root[i]]) return;
+  if (i >= n_bound || i >= cnt->n_nodes || nd.state[i] != 0 || !nd.in_slide[nd.root[i]]) return;
   if (!(nd.isexist[i] && nd.is_plane[i] && nd.has_sw[i])) return;
   if (nd.eigval[3 * (size_t)i] / nd.eigval[3 * (size_t)i + 1] > 0.12) return;
   const int k = atomicAdd(&cnt->n_fac, 1);
@@ -501,7 +504,7 @@ __device__ void plane_update_node(const Nodes& nd, int i) {
 // OctoTree::margi's leaf branch with mgsize = 1 (voxel_map.hpp:1198-1290), one lane per leaf.  Pass 0 does the cluster work and
 // sizes the fix-pool growth; pass 1 (after the host made room) moves the oldest scan's points into the pool and clears the slot.
 __global__ void map_margi_kernel(Nodes nd, Params prm, int n_nodes, int win_count, PoseArg poses, RingArg ring, const double* __restrict__ f_eigval,
-                                 const double* __restrict__ f_eigvec, const double* __restrict__ f_merged, int f_VS, int f_V, int* __restrict__ work, Counters* cnt, int* err) {
+                                 const double* __restrict__ f_eigvec, const double* __restrict__ f_merged, int f_VS, int f_V, int* __restrict__ work, Counters* cnt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes) return;
   work[i] = 0;
@@ -514,7 +517,7 @@ __global__ void map_margi_kernel(Nodes nd, Params prm, int n_nodes, int win_coun
   double w0[10];
   for (int k = 0; k < 10; k++) w0[k] = 0.0;
   const int os = nd.opt_state[i];
-  if (os >= f_V) { *err = 2; return; }
+  if (os >= f_V) { cnt->err = 2; return; }
   if (os >= 0) {                                     // adopt the optimiser's cache (:1217-1229)
     for (int k = 0; k < 10; k++) add[k] = f_merged[(size_t)k * f_VS + os];
     for (int k = 0; k < 3; k++) nd.eigval[3 * (size_t)i + k] = f_eigval[(size_t)k * f_VS + os];
@@ -739,7 +742,6 @@ struct vxba_map {
   long long table_cap = 0;
   vxmap::Counters* d_cnt = nullptr;
   vxmap::Counters* h_cnt = nullptr;   // pinned
-  int* d_err = nullptr;
   int n_nodes = 0, n_roots = 0, n_slide = 0;
   int serial = 0;
   int mp[vxmap::MAXW];
@@ -747,6 +749,7 @@ struct vxba_map {
   struct Scan { double* pnt = nullptr; double* var9 = nullptr; int* perm = nullptr; int* tmp = nullptr; int n = 0, cap = 0; } scan[vxmap::MAXW];
   double* fix_pnt = nullptr; double* fix_var = nullptr; long long fix_cap = 0, fix_cursor = 0;
   char* scratch = nullptr; size_t scratch_cap = 0;
+  char* stage = nullptr; size_t stage_cap = 0;    // second grow-only buffer: outputs that live next to the scratch of the same call
   std::string err;
 };
 
@@ -819,10 +822,18 @@ int ensure_scratch(vxba_map* m, size_t bytes) {
   m->scratch_cap = want;
   return VXBA_OK;
 }
+int ensure_stage(vxba_map* m, size_t bytes) {
+  if (bytes <= m->stage_cap) return VXBA_OK;
+  if (m->stage) { VM_HIP(m, hipStreamSynchronize(m->stream)); hipFree(m->stage); m->stage = nullptr; m->stage_cap = 0; }
+  const size_t want = bytes + bytes / 2;
+  VM_HIP(m, hipMalloc((void**)&m->stage, want));
+  m->stage_cap = want;
+  return VXBA_OK;
+}
 // counters: push the host view to the device before a stage, pull it back after
 int cnt_push(vxba_map* m) {
   Counters& c = *m->h_cnt;
-  c.n_nodes = m->n_nodes; c.n_roots = m->n_roots; c.n_touched = 0; c.n_slide_new = 0; c.n_split = 0; c.n_fac = 0; c.n_removed = 0; c.fix_cursor = m->fix_cursor; c.fix_need = 0;
+  c.n_nodes = m->n_nodes; c.n_roots = m->n_roots; c.n_touched = 0; c.n_slide_new = 0; c.n_split = 0; c.n_fac = 0; c.n_removed = 0; c.err = 0; for (int k = 0; k < 4; k++) { c.n_split_l[k] = 0; c.fix_need_l[k] = 0; } c.fix_cursor = m->fix_cursor; c.fix_need = 0;
   VM_HIP(m, hipMemcpyAsync(m->d_cnt, m->h_cnt, sizeof(Counters), hipMemcpyHostToDevice, m->stream));
   return VXBA_OK;
 }
@@ -849,11 +860,9 @@ ScanSlots make_scans(const vxba_map* m) {
   for (int i = 0; i < MAXW; i++) s.s[i] = ScanSlot{m->scan[i].pnt, m->scan[i].var9, m->scan[i].perm, m->scan[i].tmp, m->scan[i].n};
   return s;
 }
-int check_err(vxba_map* m, const char* what) {
-  int e = 0;
-  VM_HIP(m, hipMemcpy(&e, m->d_err, sizeof(int), hipMemcpyDeviceToHost));
+int check_err(vxba_map* m, const char* what) {     // after cnt_pull
+  const int e = m->h_cnt->err;
   if (e == 0) return VXBA_OK;
-  VM_HIP(m, hipMemset(m->d_err, 0, sizeof(int)));
   if (e == 1) return mfail(m, VXBA_ERR_UNSUPPORTED, "vxba_map: a point lies outside the +-32768 voxel range");
   if (e == 2) return mfail(m, VXBA_ERR_STATE, "vxba_map_margi: opt_state beyond the factor (the factor is not the one recut filled)");
   return mfail(m, VXBA_ERR_STATE, what);
@@ -878,8 +887,8 @@ int vxba_map_create(const vxba_map_params* p, int device, vxba_map** out) {
   m->prm.max_points = p->max_points; m->prm.win_size = p->win_size; m->prm.thread_num = p->thread_num;
   for (int i = 0; i < vxmap::MAXW; i++) m->mp[i] = i;
   bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipMalloc((void**)&m->d_cnt, sizeof(vxmap::Counters)) == hipSuccess && hipMalloc((void**)&m->d_err, sizeof(int)) == hipSuccess;
-  ok = ok && hipMemset(m->d_err, 0, sizeof(int)) == hipSuccess && hipHostMalloc((void**)&m->h_cnt, sizeof(vxmap::Counters), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipMalloc((void**)&m->d_cnt, sizeof(vxmap::Counters)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&m->h_cnt, sizeof(vxmap::Counters), hipHostMallocDefault) == hipSuccess;
   if (!ok || ensure_nodes(m, 1 << 16) != VXBA_OK || ensure_table(m, 1 << 10) != VXBA_OK || ensure_fix(m, 1 << 18) != VXBA_OK) { vxba_map_destroy(m); return VXBA_ERR_HIP; }
   *out = m;
   return VXBA_OK;
@@ -895,7 +904,7 @@ int vxba_map_destroy(vxba_map* m) {
                   nd.pt_count, nd.fix_start, nd.fix_count, nd.fix_cap};
   for (void* a : arrs) if (a) hipFree(a);
   for (auto& s : m->scan) { hipFree(s.pnt); hipFree(s.var9); hipFree(s.perm); hipFree(s.tmp); }
-  hipFree(m->keys); hipFree(m->vals); hipFree(m->d_cnt); hipFree(m->d_err); hipFree(m->fix_pnt); hipFree(m->fix_var); hipFree(m->scratch);
+  hipFree(m->keys); hipFree(m->vals); hipFree(m->d_cnt); hipFree(m->fix_pnt); hipFree(m->fix_var); hipFree(m->scratch); hipFree(m->stage);
   if (m->h_cnt) hipHostFree(m->h_cnt);
   if (m->stream) hipStreamDestroy(m->stream);
   delete m;
@@ -942,13 +951,14 @@ static int map_cut_voxel_impl(vxba_map* m, int ord, int64_t n64, const double* p
   int* d_leaf_s = (int*)q; q += b_i;
   int* d_iota = (int*)q; q += b_i;
   void* d_tmp = q;
-  VM_HIP(m, hipMemcpyAsync(d_w, pwld, (size_t)n * 3 * sizeof(double), kind, m->stream));
+  if (on_device) d_w = const_cast<double*>(pwld);      // only read during this call
+  else VM_HIP(m, hipMemcpyAsync(d_w, pwld, (size_t)n * 3 * sizeof(double), kind, m->stream));
   if ((rc = ensure_table(m, (long long)m->n_roots + n))) return rc;
   if ((rc = ensure_nodes(m, (long long)m->n_nodes + 2ll * n))) return rc;     // at most one new root and one new child per point
   m->serial++;
   const int nodes_before = m->n_nodes;
   if ((rc = cnt_push(m))) return rc;
-  map_roots_kernel<<<grid_for(n), 256, 0, m->stream>>>(m->nd, m->prm, m->keys, m->vals, (unsigned long long)m->table_cap - 1, d_w, n, d_slot, m->d_cnt, m->serial, m->d_err);
+  map_roots_kernel<<<grid_for(n), 256, 0, m->stream>>>(m->nd, m->prm, m->keys, m->vals, (unsigned long long)m->table_cap - 1, d_w, n, d_slot, m->d_cnt, m->serial);
   map_descend_kernel<<<grid_for(n), 256, 0, m->stream>>>(m->nd, m->vals, d_w, n, d_slot, d_leaf, d_pend, m->d_cnt, m->serial);
   if ((rc = cnt_pull(m))) return rc;
   if ((rc = check_err(m, "vxba_map_cut_voxel"))) return rc;
@@ -983,24 +993,25 @@ int vxba_map_recut(vxba_map* m, int win_count, const double* Rp, vxba_factor* fa
   const PoseArg poses = make_poses(Rp, win_count);
   const RingArg ring = make_ring(m);
   int rc;
+  if ((rc = cnt_push(m))) return rc;
+  int bound = m->n_nodes;                      // upper bound of the node count on the device
   for (int L = 0; L <= m->prm.max_layer; L++) {
-    if ((rc = ensure_scratch(m, (size_t)m->n_nodes * sizeof(int)))) return rc;
+    if ((rc = ensure_scratch(m, (size_t)bound * sizeof(int)))) return rc;
     int* d_split = (int*)m->scratch;
-    if ((rc = cnt_push(m))) return rc;
-    map_judge_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->prm, m->n_nodes, L, d_split, m->d_cnt);
-    if ((rc = cnt_pull(m))) return rc;
-    const int n_split = m->h_cnt->n_split;
+    map_judge_kernel<<<grid_for(bound), 256, 0, m->stream>>>(m->nd, m->prm, bound, L, d_split, m->d_cnt);
+    if (L >= m->prm.max_layer) break;          // leaves of the finest layer never split: nothing to read back
+    if ((rc = cnt_pull(m))) return rc;         // one read-back per layer: how many leaves split
+    const int n_split = m->h_cnt->n_split_l[L];
     if (n_split == 0) continue;
     if ((rc = ensure_nodes(m, (long long)m->n_nodes + 8ll * n_split))) return rc;
-    if ((rc = ensure_fix(m, m->fix_cursor + m->h_cnt->fix_need))) return rc;
-    if ((rc = cnt_push(m))) return rc;
+    if ((rc = ensure_fix(m, m->fix_cursor + m->h_cnt->fix_need_l[L]))) return rc;
     map_subdivide_kernel<<<grid_for(8ll * n_split, 64), 64, 0, m->stream>>>(m->nd, m->prm, d_split, n_split, win_count, poses, ring, make_scans(m), m->fix_pnt, m->fix_var, m->d_cnt);
-    if ((rc = cnt_pull(m))) return rc;
+    bound = m->n_nodes + 8 * n_split;
   }
   // tras_opt, ordered by node id so that the factor is the same from run to run
-  const size_t b_id = (size_t)m->n_nodes * sizeof(unsigned long long), b_nd = (size_t)m->n_nodes * sizeof(int);
+  const size_t b_id = (size_t)bound * sizeof(unsigned long long), b_nd = (size_t)bound * sizeof(int);
   size_t tb = 0;
-  rocprim::radix_sort_pairs(nullptr, tb, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr, (int*)nullptr, (size_t)m->n_nodes, 0, 64, m->stream);
+  rocprim::radix_sort_pairs(nullptr, tb, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr, (int*)nullptr, (size_t)bound, 0, 64, m->stream);
   auto up = [](size_t b) { return (b + 255) / 256 * 256; };
   if ((rc = ensure_scratch(m, 2 * up(b_id) + 2 * up(b_nd) + up(tb)))) return rc;
   char* q = m->scratch;
@@ -1009,22 +1020,20 @@ int vxba_map_recut(vxba_map* m, int win_count, const double* Rp, vxba_factor* fa
   int* d_nodes = (int*)q; q += up(b_nd);
   int* d_nodes_s = (int*)q; q += up(b_nd);
   void* d_tmp = q;
-  if ((rc = cnt_push(m))) return rc;
-  map_factor_flag_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, d_ids, d_nodes, m->d_cnt);
-  if ((rc = cnt_pull(m))) return rc;
+  map_factor_flag_kernel<<<grid_for(bound), 256, 0, m->stream>>>(m->nd, bound, d_ids, d_nodes, m->d_cnt);
+  if ((rc = cnt_pull(m))) return rc;           // also brings n_nodes / fix_cursor up to date
   const int nf = m->h_cnt->n_fac;
   if (nf == 0) return VXBA_OK;
   VM_HIP(m, rocprim::radix_sort_pairs(d_tmp, tb, d_ids, d_ids_s, d_nodes, d_nodes_s, (size_t)nf, 0, 64, m->stream));
   const int W = m->prm.win_size;
-  double* d_stage = nullptr;
   const size_t per = (size_t)W * 10 + 10 + 1 + 3 + 9 + 10;
-  VM_HIP(m, hipMalloc((void**)&d_stage, (size_t)nf * per * sizeof(double)));
+  if ((rc = ensure_stage(m, (size_t)nf * per * sizeof(double)))) return rc;
+  double* d_stage = (double*)m->stage;
   double* d_cl = d_stage; double* d_fix = d_cl + (size_t)nf * W * 10; double* d_coe = d_fix + (size_t)nf * 10; double* d_ev = d_coe + nf;
   double* d_evec = d_ev + (size_t)nf * 3; double* d_mg = d_evec + (size_t)nf * 9;
   map_factor_gather_kernel<<<grid_for(nf), 256, 0, m->stream>>>(m->nd, W, ring, d_nodes_s, nf, d_cl, d_fix, d_coe, d_ev, d_evec, d_mg);
   hipError_t e = hipStreamSynchronize(m->stream);
   if (e == hipSuccess) rc = vxba_internal_push_voxels_device(factor, nf, d_cl, d_fix, d_coe, d_ev, d_evec, d_mg);
-  hipFree(d_stage);
   if (e != hipSuccess) return mfail(m, VXBA_ERR_HIP, "vxba_map_recut: gather failed");
   if (rc != VXBA_OK) return mfail(m, rc, vxba_last_error(factor));
   if (n_pushed) *n_pushed = nf;
@@ -1046,7 +1055,7 @@ int vxba_map_margi(vxba_map* m, int win_count, const double* Rp, vxba_factor* fa
   if ((rc = ensure_scratch(m, (size_t)m->n_nodes * sizeof(int)))) return rc;
   int* d_work = (int*)m->scratch;
   if ((rc = cnt_push(m))) return rc;
-  map_margi_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->prm, m->n_nodes, win_count, poses, ring, f_ev, f_evec, f_mg, VS, V, d_work, m->d_cnt, m->d_err);
+  map_margi_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->prm, m->n_nodes, win_count, poses, ring, f_ev, f_evec, f_mg, VS, V, d_work, m->d_cnt);
   if ((rc = cnt_pull(m))) return rc;
   if ((rc = check_err(m, "vxba_map_margi"))) return rc;
   if ((rc = ensure_fix(m, m->fix_cursor + m->h_cnt->fix_need))) return rc;
@@ -1129,13 +1138,10 @@ int vxba_map_cut_voxel_lio(vxba_map* m, int ord, vxba_lio* lio) {
   if (n > 0 && !valid) return mfail(m, VXBA_ERR_STATE, "vxba_map_cut_voxel_lio: no world points on the device (call vxba_lio_pvec_update first)");
   if (n == 0) return map_cut_voxel_impl(m, ord, 0, nullptr, nullptr, nullptr, true);
   hipSetDevice(m->device);
-  double* d_pnt = nullptr;
-  VM_HIP(m, hipMalloc((void**)&d_pnt, (size_t)n * 3 * sizeof(double)));
+  if ((rc = ensure_stage(m, (size_t)n * 3 * sizeof(double)))) return rc;
+  double* d_pnt = (double*)m->stage;
   vxmap::map_gather_body_kernel<<<grid_for(n), 256, 0, m->stream>>>(soa, n, stride, d_pnt);
-  rc = map_cut_voxel_impl(m, ord, n, d_pnt, world + 3 * n, world, true);
-  hipStreamSynchronize(m->stream);
-  hipFree(d_pnt);
-  return rc;
+  return map_cut_voxel_impl(m, ord, n, d_pnt, world + 3 * n, world, true);
 }
 
 // The odometry's plane map (vxba_lio) brought up to date with the tree: the leaves (and empty octants) under every root that was in
