@@ -31,20 +31,39 @@ FP64_MFMA_MEASURED_TFLOPS = 73.0   # v_mfma_f64_16x16x4_f64 issue-bound rate, sc
 FP64_SPEC_TFLOPS = 78.6            # vendor figure (not in the local guide)
 
 
+KERNEL_SOURCES = ("vxba_kernels.hip", "vxba_kernels.h", "vxba_math.hpp", "vxba_solve.hpp")
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the sweep kernels (K1-K4, finalize, solve): what a PMC measurement is a measurement OF."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "voxel-slam_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def pmc_traffic_bytes(kernel_key):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/*/pmc_hbm_counters.json):
-    FETCH_SIZE x 2 (the guide's gfx950 correction for wide coalesced reads) + WRITE_SIZE, both reported in KB."""
+    FETCH_SIZE x 2 (the guide's gfx950 correction for wide coalesced reads) + WRITE_SIZE, both reported in KB.
+    The counters cannot be read inside this process (rocprofv3 wraps the command), so the file is tied to the binary instead:
+    scripts/collect_profile.py stamps it with the hash of the kernel sources it was collected from, and a file whose stamp is not
+    the hash of the sources in this tree is REFUSED (traffic = null) rather than quoted for a kernel it did not measure."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_counters.json")))
     if not files:
-        return None, None
+        return None, "no profiles/*/pmc_hbm_counters.json"
     d = json.load(open(files[-1]))
+    rel = os.path.relpath(files[-1], ROOT)
+    if d.get("kernel_source_sha256") != kernel_source_hash():
+        return None, f"{rel} was collected from other kernel sources (stamp {str(d.get('kernel_source_sha256'))[:12]} != {kernel_source_hash()[:12]}): re-run scripts/gpu_profile.sh"
     try:
         f = [v["mean"] for k, v in d["FETCH_SIZE_KB_mean_per_launch"].items() if kernel_key in k][0]
         w = [v["mean"] for k, v in d["WRITE_SIZE_KB_mean_per_launch"].items() if kernel_key in k][0]
     except (KeyError, IndexError):
-        return None, None
-    return (2.0 * f + w) * 1024.0, os.path.relpath(files[-1], ROOT)
+        return None, f"{rel} holds no counters for {kernel_key}"
+    return (2.0 * f + w) * 1024.0, rel
 
 
 def main():
@@ -65,6 +84,9 @@ def main():
     ap.add_argument("--no-li-ba", action="store_true", help="skip the secondary LiDAR-inertial BA figure")
     ap.add_argument("--precision", choices=["f64", "mixed"], default="f64",
                     help="mixed = BASELINE configs[2]: f32 Hessian products on the matrix cores, f64 accumulation (use with --config cfg3)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every GPU owns a full --config-sized voxel shard of an N-times larger window (BASELINE configs[3] at N = 8; "
+                         "value = N*K/time in shard-iterations/s); strong = ONE --config window split over the N GPUs (value = K/time)")
     ap.add_argument("--hook-allreduce", action="store_true", help="use the torch.distributed hook instead of direct RCCL calls")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-reduce path even with one rank (plumbing test)")
     args = ap.parse_args()
@@ -106,8 +128,10 @@ def main():
 
     # ---- synthetic window: every rank builds its own voxel shard of one shared window ------------
     base_seed = synth.MASTER_SEED + list(synth.CONFIGS).index(args.config) + 1
-    sc = synth.make_config(args.config, seed=base_seed + 1000 * rank, pose_seed=base_seed)
+    from voxel_slam_amd import dist as vdist_mod
+    sc = vdist_mod.rank_scene(dict(synth.CONFIGS[args.config], seed=base_seed), args.scaling, rank, world)
     W, V = sc.win_size, sc.n_voxels
+    global_voxels = V * world if args.scaling == "weak" else synth.CONFIGS[args.config]["n_voxels"]
 
     f = vxba.LidarFactor(W, device=local_rank)
     # the factor keeps its own non-blocking stream (torch's default stream has handle 0 = "the factor's own" for vxba_set_stream);
@@ -199,22 +223,26 @@ def main():
         nbatch = (V + 5) // 6 if W == 10 else 0
         k3_flops = nbatch * 50 * 2048.0 + nnz * 300.0 * 1.8 if W == 10 else None
         out = {
-            "metric": "BA iterations/sec (10-frame window, 100k pts/scan)",
-            "value": world * args.steps / elapsed,
+            # N > 1, weak scaling: every GPU iterates on its own cfg-sized shard of an N-times larger window, `value` counts
+            # shard-iterations (N per LM iteration of the big window; the iteration rate of that window is config.global_iterations_per_s).
+            # strong scaling: one cfg window split over the GPUs, value = its iteration rate.
+            "metric": "BA iterations/sec (10-frame window, 100k pts/scan)" + ("" if world == 1 or args.scaling == "strong" else
+                                                                           f" -- shard-iterations/s, {world} GPUs each on a 100k pts/scan shard of one {world}x larger window"),
+            "value": (world if args.scaling == "weak" else 1) * args.steps / elapsed,
             "unit": "iterations/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64" if args.precision == "f64" else "f32 products / f64 accumulation (Hessian sweep), f64 elsewhere",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: W={W}, {sc.points_body.shape[0] // W} pts/scan, {V} voxels per GPU, nnz={nnz}",
                 "steps_per_solve": sps,
-                "global_voxels": V * world,
+                "global_voxels": global_voxels,
                 "global_iterations_per_s": args.steps / elapsed,
                 "parallelism": f"voxel-shard x{world}" + (" + RCCL all-reduce of [Hess|JacT|res]" if use_dist else ""),
                 "final_residual": float(resis[1]),
@@ -249,7 +277,8 @@ def main():
         out["k1_cluster_build"] = {"avg_launch_ms": k1_ms, "points": npts, "points_per_s": npts / (k1_ms * 1e-3) if k1_ms > 0 else 0.0,
                                    "achieved_GBs": (24.0 * npts + 80.0 * W * V) / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0}
         if world == 1 and not args.no_li_ba:
-            out["li_ba"] = li_ba_rate(sc, f)
+            out["reject_window"] = reject_window_rate(args.config, base_seed, local_rank, sps=8)
+            out["li_ba"] = li_ba_rate(sc, f, with_cpu=not args.no_cpu_baseline)
             out["voxelize"] = voxelize_rate(W, local_rank, with_cpu=not args.no_cpu_baseline)
             out["lio"] = lio_rate(local_rank, with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
@@ -261,7 +290,29 @@ def main():
         dist.destroy_process_group()
 
 
-def li_ba_rate(sc, f, solves=20):
+def reject_window_rate(config, seed, device, sps=8, steps=240):
+    """The same loop on a window that starts 4x further from the optimum (0.2 deg / 0.03 m): its first four trial steps of every
+    solve are rejected (no Hessian recompute after a rejection, voxel_map.hpp:433), the next four accepted.  Secondary figure: the
+    headline window never rejects."""
+    from voxel_slam_amd import synth, vxba
+    sc = synth.make_config(config, seed=seed, pose_seed=seed, rot_sigma_deg=0.2, trans_sigma=0.03)
+    f = vxba.LidarFactor(sc.win_size, device=device)
+    f.push_points(sc.n_voxels, sc.points_body, sc.cell_ptr)
+    f.evaluate_only_residual(sc.poses_init)
+    f.snapshot_cache()
+    f.lm_steps(sc.poses_init, 2 * sps, sps)
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, resis, st = f.lm_steps(sc.poses_init, steps, sps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    f.close()
+    return {"iterations_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "steps_per_solve": sps,
+            "lm_steps_accepted": st["accepted"], "lm_steps_rejected": st["rejected"], "final_residual": float(resis[1])}
+
+
+def li_ba_rate(sc, f, solves=20, with_cpu=False):
     """LiDAR-inertial BA (LI_BA_Optimizer::damping_iter, the local-mapping entry point voxelslam.cpp:1651-1652) on the same
     window: voxel sweeps on the GPU, the 15W-dimensional shell (IMU factors, 150x150 LDL^T) on the host.  Secondary figure;
     the headline metric above is the LiDAR sweep + solve loop that is resident on the GPU."""
@@ -296,8 +347,27 @@ def li_ba_rate(sc, f, solves=20):
     # median over solves: a host-side loop is exposed to interpreter pauses (GC) that a mean would fold in
     it_per_solve = iters / len(per_solve)
     med = float(np.median(per_solve))
-    return {"iterations_per_s": it_per_solve / med, "ms_per_iteration": 1e3 * med / it_per_solve, "solves": solves, "iterations": iters,
-            "pose_rmse_vs_truth_m_rad": [et, er], "where": "sweeps on GPU; IMU factors + 150x150 LDL^T on host"}
+    out = {"iterations_per_s": it_per_solve / med, "ms_per_iteration": 1e3 * med / it_per_solve, "solves": solves, "iterations": iters,
+           "pose_rmse_vs_truth_m_rad": [et, er],
+           "where": "whole loop device-resident" if f.get_option("li_device_loop") else "sweeps on GPU; IMU factors + 150x150 LDL^T on host"}
+    if with_cpu:
+        # the LiDAR-inertial optimiser's own CPU baseline: LI_BA_Optimizer::damping_iter of the checker (5 std::threads, as upstream) on the
+        # same window, one solve; and the pose difference of the two results (outside any timed region)
+        try:
+            from tests import _oracle as O
+            fo = O.Oracle(sc.win_size)
+            fo.push_voxels(f.read_clusters(), sc.fix, sc.coe)
+            fo.evaluate_only_residual(sc.poses_init)
+            blobs = np.stack(blobs0)
+            t0 = time.perf_counter()
+            ref = O.li_damping_iter(fo, iw.states_init, blobs, max_iter=3, thd_num=5)
+            dt = time.perf_counter() - t0
+            n_it = max(1, ref["trace"].shape[0])
+            out["cpu_baseline"] = {"value": n_it / dt, "unit": "iterations/s", "cores": 5, "kind": "port", "sample": f"one 3-iteration LI_BA_Optimizer::damping_iter of the same window ({n_it} iterations, {dt:.2f} s)"}
+            out["pose_rmse_vs_oracle_m_rad"] = [float(x) for x in synth.pose_errors(final["states"][:, :12], ref["states"][:, :12])]
+        except Exception as exc:   # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(exc)}
+    return out
 
 
 def voxelize_rate(W, device, with_cpu):
@@ -355,7 +425,7 @@ def lio_rate(device, with_cpu, n_points=100_000, n_roots=20_000):
            "ms_per_scan": 1e3 * med, "scans_per_s": 1.0 / med, "ms_per_sweep_call": 1e3 * msw, "points_per_s_sweep": n_points / msw,
            # per point: 72 B (pnt + covariance) + 12 B (key + cell entry), and the 256 B plane record for every point that reaches a plane
            "sweep_algorithmic_bytes": 84.0 * n_points + 256.0 * res["match_num"], "map_upload_ms": 1e3 * t_map, "var_init_ms": 1e3 * t_scan,
-           "pose_error_vs_truth_m_rad": [et, er], "where": "match + sums and the 15x15 EKF update on GPU (4 x (sweep, update) enqueued at once)" if os.environ.get("VXBA_LIO_DEVICE_EKF", "1") != "0" else "match + sums on GPU; 15x15 EKF algebra on host between sweeps"}
+           "pose_error_vs_truth_m_rad": [et, er], "where": "match + sums and the 15x15 EKF update on GPU (4 x (sweep, update) enqueued at once)"}
     g.close()
     if with_cpu:
         from tests import _oracle as O
@@ -384,6 +454,23 @@ def cpu_baseline(sc, f, budget_s):
         "sample": f"full {sc.n_voxels}-voxel window, median of {iters} accepted-step iterations "
                   f"(Hessian sweep {th * 1e3:.1f} ms + residual sweep {tr * 1e3:.1f} ms), host has {ncpu} logical CPUs",
     }
+    # oracle/_ref/libref.so, when it travelled with the snapshot: the reference's own LidarFactor / Lidar_BA_Optimizer (unmodified
+    # voxel_map.hpp) timed the same way.  It runs on an Eigen API shim (no Eigen in the image: scalar, un-vectorised fixed-size
+    # algebra), so it is the SLOWER of the two CPU figures; `value` stays the faster restatement and this is reported beside it.
+    try:
+        from tests import _ref
+        R = _ref.backend()
+        if R is not None:
+            fr = R.Oracle(sc.win_size)
+            fr.push_voxels(clusters, sc.fix, sc.coe)
+            fr.evaluate_only_residual(sc.poses_init)
+            t1r, _, _ = fr.time_ba_iteration(sc.poses_init, nthreads, warmup=0, iters=1)
+            itr = int(max(2, min(10, 0.5 * budget_s / max(t1r, 1e-3))))
+            trf, thr, trr = fr.time_ba_iteration(sc.poses_init, nthreads, warmup=0, iters=itr)
+            out["reference"] = {"value": 1.0 / trf, "unit": "iterations/s", "cores": nthreads, "kind": "reference",
+                                "backend": R.BACKEND_NAME, "sample": f"same window, median of {itr} iterations (Hessian sweep {thr * 1e3:.1f} ms + residual sweep {trr * 1e3:.1f} ms)"}
+    except Exception as exc:   # noqa: BLE001
+        out["reference"] = {"error": repr(exc)}
     # the same restatement fanned out over the host's cores (SURVEY 8d "single-socket figure"; the reference itself stops at 5 threads)
     wide = int(max(nthreads, min(ncpu or nthreads, 64)))
     if wide > nthreads:

@@ -143,6 +143,10 @@ int vxba_set_allreduce(vxba_factor* f, vxba_allreduce_fn fn, void* ctx);
  * Collective: every rank of the group must call it.  Takes precedence over vxba_set_allreduce. */
 int vxba_rccl_unique_id(const char* librccl_path, void* unique_id_out_128);
 int vxba_rccl_attach(vxba_factor* f, const char* librccl_path, int nranks, int rank, const void* unique_id_128);
+/* The id exchange through a caller-supplied broadcast (MPI_Bcast, a socket ...): bcast(ctx, buf, nbytes, root) returns 0 after
+ * root's bytes are in every rank's buf.  librccl_path NULL: the RCCL the process already uses, else /opt/rocm/lib/librccl.so. */
+typedef int (*vxba_bcast_fn)(void* ctx, void* buf, size_t nbytes, int root);
+int vxba_rccl_attach_bcast(vxba_factor* f, const char* librccl_path, int nranks, int rank, vxba_bcast_fn bcast, void* ctx);
 int vxba_rccl_detach(vxba_factor* f);
 
 /* Let the caller own the exchange buffers the sweeps reduce into (e.g. a torch tensor, so torch.distributed /

@@ -21,6 +21,10 @@ for tag, counter in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE"))
             acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     res[f"{counter}_KB_mean_per_launch"] = {k: {"n": len(v), "mean": sum(v) / len(v)} for k, v in acc.items() if k.startswith("void vxk") or k.startswith("vxk")}
 if res:
+    sys.path.insert(0, ROOT)
+    import bench
+    res["kernel_source_sha256"] = bench.kernel_source_hash()      # bench.py refuses the file for any other kernel source
+    res["kernel_sources"] = list(bench.KERNEL_SOURCES)
     json.dump(res, open(os.path.join(out, "pmc_hbm_counters.json"), "w"), indent=1)
 if os.path.exists(bench):
     shutil.copy(bench, os.path.join(out, "bench.json"))

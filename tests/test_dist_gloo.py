@@ -30,6 +30,56 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
+def _scaling_worker(rank, world, port, outdir, scaling):
+    """What bench.py does per rank for --scaling weak / strong, with the oracle standing in for the GPU shard."""
+    import torch.distributed as dist
+    from tests import _oracle as O
+    from voxel_slam_amd import dist as vdist
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    kw = dict(win_size=4, pts_per_scan=3000, n_voxels=240, seed=91, rot_sigma_deg=0.1, trans_sigma=0.02)
+    sc = vdist.rank_scene(kw, scaling, rank, world)
+    f = O.Oracle(sc.win_size)
+    f.push_voxels(O.build_clusters(sc.points_body, sc.cell_ptr).reshape(sc.win_size, sc.n_voxels, 10).transpose(1, 0, 2), sc.fix, sc.coe)   # from the re-bucketed points
+    f.evaluate_only_residual(sc.poses_init)
+    out = vdist.damping_iter_sharded(sc.win_size, sc.poses_init, f.acc_evaluate2, f.evaluate_only_residual, max_iter=3)
+    np.savez(os.path.join(outdir, f"{scaling}{rank}.npz"), poses=out["poses"], trace=out["trace"], n_voxels=sc.n_voxels, clusters=sc.clusters,
+             poses_init=sc.poses_init)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_rank_weak_and_strong_scaling_shards(tmp_path, scaling):
+    """bench.py --scaling: strong = one window split by the reference's shard rule (the two shards ARE the window), weak = every rank
+    its own window-sized set of voxels of one shared trajectory (the global window is the union).  Either way the sharded LM equals
+    the single-process LM on the global window."""
+    import torch.multiprocessing as mp
+    from tests import _oracle as O
+    from voxel_slam_amd import dist as vdist, synth
+
+    world, port = 2, _free_port()
+    mp.spawn(_scaling_worker, args=(world, port, str(tmp_path), scaling), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"{scaling}{k}.npz") for k in range(world)]
+    assert np.array_equal(r[0]["poses"], r[1]["poses"]) and np.array_equal(r[0]["poses_init"], r[1]["poses_init"])
+    kw = dict(win_size=4, pts_per_scan=3000, n_voxels=240, seed=91, rot_sigma_deg=0.1, trans_sigma=0.02)
+    if scaling == "strong":
+        full = vdist.rank_scene(kw, "strong", 0, 1)
+        assert int(r[0]["n_voxels"]) + int(r[1]["n_voxels"]) == full.n_voxels == 240
+        assert np.array_equal(np.concatenate([r[0]["clusters"], r[1]["clusters"]]), full.clusters)
+        clusters, fix, coe = full.clusters, full.fix, full.coe
+    else:
+        assert int(r[0]["n_voxels"]) == int(r[1]["n_voxels"]) == 240 and not np.array_equal(r[0]["clusters"], r[1]["clusters"])
+        parts = [vdist.rank_scene(kw, "weak", k, world) for k in range(world)]
+        clusters = np.concatenate([p.clusters for p in parts]); fix = np.concatenate([p.fix for p in parts]); coe = np.concatenate([p.coe for p in parts])
+    f = O.Oracle(4)
+    f.push_voxels(clusters, fix, coe)
+    f.evaluate_only_residual(r[0]["poses_init"])
+    ref = f.damping_iter(r[0]["poses_init"], max_iter=3, thd_num=2)
+    assert np.array_equal(r[0]["trace"][:, 6:], ref["trace"][:, 6:])
+    et, er = synth.pose_errors(r[0]["poses"], ref["poses"])
+    assert et < 1e-10 and er < 1e-10
+
+
 def test_shard_bounds_follow_the_reference_rule():
     from voxel_slam_amd.dist import shard_bounds
     for V, world in [(401, 2), (50000, 8), (7, 3), (5, 5)]:

@@ -592,7 +592,13 @@ int vxba_set_allreduce(vxba_factor* f, vxba_allreduce_fn fn, void* ctx) {
 }
 
 namespace {
-void* open_rccl(const char* path) { return dlopen(path && path[0] ? path : "librccl.so", RTLD_NOW | RTLD_LOCAL); }
+// NULL / "": the RCCL the loader finds ("librccl.so", already mapped when the process uses one), else ROCm's own copy
+void* open_rccl(const char* path) {
+  if (path && path[0]) return dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  void* h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+  return h;
+}
 }  // namespace
 
 int vxba_rccl_unique_id(const char* librccl_path, void* out) {
@@ -623,6 +629,20 @@ int vxba_rccl_attach(vxba_factor* f, const char* librccl_path, int nranks, int r
   if (init(&f->rccl_comm, nranks, id, rank) != ncclSuccess) { f->rccl_comm = nullptr; return fail(f, VXBA_ERR_STATE, "ncclCommInitRank failed"); }
   f->rccl_lib = lib;
   return VXBA_OK;
+}
+
+// The same with the id exchange done through a caller-supplied broadcast (MPI_Bcast, a socket, a file ...): rank 0 creates the id,
+// bcast(ctx, buf, 128, root = 0) must leave rank 0's bytes in every rank's buf.  No torch, no Python.
+int vxba_rccl_attach_bcast(vxba_factor* f, const char* librccl_path, int nranks, int rank, vxba_bcast_fn bcast, void* ctx) {
+  if (!f || !bcast || nranks < 1 || rank < 0 || rank >= nranks) return fail(f, VXBA_ERR_ARG, "rccl_attach_bcast: bad argument");
+  unsigned char id[128];
+  std::memset(id, 0, sizeof id);
+  if (rank == 0) {
+    int rc = vxba_rccl_unique_id(librccl_path, id);
+    if (rc != VXBA_OK) return fail(f, rc, "rccl_attach_bcast: ncclGetUniqueId failed (librccl not found?)");
+  }
+  if (bcast(ctx, id, sizeof id, 0) != 0) return fail(f, VXBA_ERR_STATE, "rccl_attach_bcast: the broadcast callback failed");
+  return vxba_rccl_attach(f, librccl_path, nranks, rank, id);
 }
 
 int vxba_rccl_detach(vxba_factor* f) {

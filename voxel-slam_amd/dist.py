@@ -19,6 +19,38 @@ def shard_bounds(n_voxels: int, world: int, rank: int):
     return int(part * rank), int(part * (rank + 1))
 
 
+def rank_scene(make_kwargs: dict, scaling: str, rank: int, world: int):
+    """The voxel shard of ``rank`` for the two ways a window is spread over ``world`` GPUs (bench.py ``--scaling``):
+
+    * ``"weak"``   -- per-GPU work fixed: every rank generates its OWN ``make_kwargs``-sized set of voxels (seed offset by the rank)
+      of one shared window (same trajectory and initial guess: ``pose_seed``); the global window has ``world`` times the voxels
+      (BASELINE configs[3] = 8 x configs[1]).
+    * ``"strong"`` -- total work fixed: all ranks generate the SAME window and rank r keeps the contiguous voxel range the reference's
+      own shard rule gives it (``shard_bounds``, voxel_map.hpp:318-321).
+
+    Returns a ``synth.Scene`` holding only this rank's voxels (points re-bucketed per frame, clusters, fix clusters, weights)."""
+    from . import synth
+    kw = dict(make_kwargs)
+    seed = kw.pop("seed")
+    if scaling == "weak":
+        return synth.make_scene(seed=seed + 1000 * rank, pose_seed=seed, **kw)
+    if scaling != "strong":
+        raise ValueError("scaling must be 'weak' or 'strong'")
+    sc = synth.make_scene(seed=seed, pose_seed=seed, **kw)
+    if world == 1:
+        return sc
+    lo, hi = shard_bounds(sc.n_voxels, world, rank)
+    W, V = sc.win_size, sc.n_voxels
+    pts, ptr = [], [0]
+    for i in range(W):                               # cells are ordered frame-major: cell i * V + a
+        a, b = int(sc.cell_ptr[i * V + lo]), int(sc.cell_ptr[i * V + hi])
+        pts.append(sc.points_body[a:b])
+        ptr.extend((sc.cell_ptr[i * V + lo + 1: i * V + hi + 1] - a + ptr[-1]).tolist())
+    return synth.Scene(win_size=W, n_voxels=hi - lo, points_body=np.ascontiguousarray(np.concatenate(pts)), cell_ptr=np.asarray(ptr, dtype=np.int64),
+                       clusters=sc.clusters[lo:hi], fix=sc.fix[lo:hi], coe=sc.coe[lo:hi], poses_gt=sc.poses_gt, poses_init=sc.poses_init,
+                       normals=sc.normals[lo:hi])
+
+
 def attach_allreduce(factor, group=None):
     """GPU path: make the factor's device-resident LM loop all-reduce its exchange buffers over ``group``.
 
@@ -67,6 +99,8 @@ def attach_rccl(factor, group=None):
 
     from . import vxba
 
+    # inside a torch process the communicator comes from the librccl.so torch already loaded (one RCCL instance per process); a
+    # caller without torch passes NULL / "/opt/rocm/lib/librccl.so" to vxba_rccl_attach[_bcast] and exchanges the id itself
     lib = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     obj = [vxba.rccl_unique_id(lib) if rank == 0 else None]
