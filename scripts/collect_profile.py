@@ -22,12 +22,12 @@ for tag, counter in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE"))
     res[f"{counter}_KB_mean_per_launch"] = {k: {"n": len(v), "mean": sum(v) / len(v)} for k, v in acc.items() if k.startswith("void vxk") or k.startswith("vxk")}
 if res:
     sys.path.insert(0, ROOT)
-    import bench
-    res["kernel_source_sha256"] = bench.kernel_source_hash()      # bench.py refuses the file for any other kernel source
-    res["kernel_sources"] = list(bench.KERNEL_SOURCES)
+    import bench as bench_mod
+    res["kernel_source_sha256"] = bench_mod.kernel_source_hash()      # bench.py refuses the file for any other kernel source
+    res["kernel_sources"] = list(bench_mod.KERNEL_SOURCES)
     json.dump(res, open(os.path.join(out, "pmc_hbm_counters.json"), "w"), indent=1)
 if os.path.exists(bench):
     shutil.copy(bench, os.path.join(out, "bench.json"))
 for r in list(csv.DictReader(open(os.path.join(out, "kernel_stats.csv"))))[:8]:
     print("%-62s calls %5s avg %8.2f us %5s%%" % (r["Name"][:62], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
-print(json.dumps({k: {kk: round(vv["mean"], 1) for kk, vv in v.items() if "k3_hessian" in kk or "k2_residual" in kk} for k, v in res.items()}))
+print(json.dumps({k: {kk: round(vv["mean"], 1) for kk, vv in v.items() if "k3_hessian" in kk or "k2_residual" in kk} for k, v in res.items() if isinstance(v, dict)}))
