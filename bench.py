@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = every GPU owns a full --config-sized voxel shard of an N-times larger window (BASELINE configs[3] at N = 8; "
                          "value = N*K/time in shard-iterations/s); strong = ONE --config window split over the N GPUs (value = K/time)")
+    ap.add_argument("--collective", choices=["auto", "peer", "rccl", "hook"], default="auto",
+                    help="N > 1: how the 29 KB exchange buffer is summed.  auto = the one-shot all-reduce through hipIpc-mapped mailboxes over xGMI "
+                         "(vxba_peer_*, verified by a self-test at attach time), else ncclAllReduce issued from the C++ loop, else the torch.distributed hook")
     ap.add_argument("--hook-allreduce", action="store_true", help="use the torch.distributed hook instead of direct RCCL calls")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-reduce path even with one rank (plumbing test)")
     args = ap.parse_args()
@@ -123,8 +126,7 @@ def main():
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-            args.hook_allreduce = True
+            dist.init_process_group(backend, rank=rank, world_size=world)      # RCCL is out; the mailbox all-reduce and the hook remain
 
     # ---- synthetic window: every rank builds its own voxel shard of one shared window ------------
     base_seed = synth.MASTER_SEED + list(synth.CONFIGS).index(args.config) + 1
@@ -142,23 +144,44 @@ def main():
     f.push_points(V, sc.points_body, sc.cell_ptr)          # K1 on the GPU; data now resident in HBM
     f.set_profiling(0)
     k1 = f.kernel_times(reset=True)["k1_build"]
+    collective_used = None
     if use_dist:
         from voxel_slam_amd import dist as vdist
-        if args.hook_allreduce:
-            _keep = vdist.attach_allreduce(f)              # exchange buffers become torch tensors, collective via a host hook
-        else:
+        def all_agree(ok):                                 # every rank takes the same path
+            okt = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            return int(okt.item()) == 1
+        collective = "hook" if args.hook_allreduce else args.collective
+        used = None
+        if collective in ("auto", "peer") and W <= 10:
+            try:
+                vdist.attach_peer(f)                       # one-shot all-reduce over the peers' mailboxes (self-tested)
+                ok = 1
+            except Exception as exc:                       # noqa: BLE001 -- any failure here must not take the other ranks down
+                print(f"[bench rank {rank}] peer all-reduce not available ({exc})", file=sys.stderr)
+                ok = 0
+            if all_agree(ok):
+                used = "one-shot peer all-reduce (hipIpc mailboxes over xGMI)"
+            else:
+                try:
+                    f.peer_detach()
+                except Exception:                          # noqa: BLE001
+                    pass
+        if used is None and collective in ("auto", "rccl", "peer") and backend == "nccl":
             try:
                 vdist.attach_rccl(f)                       # ncclAllReduce issued directly from the C++ loop
                 ok = 1
-            except Exception as exc:                       # noqa: BLE001 -- any failure here must not take the other ranks down
+            except Exception as exc:                       # noqa: BLE001
                 print(f"[bench rank {rank}] direct RCCL attach failed ({exc}); using the torch.distributed hook", file=sys.stderr)
                 ok = 0
-            okt = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)     # all ranks take the same path
-            if int(okt.item()) == 0:
-                if ok:
-                    f.rccl_detach()
-                _keep = vdist.attach_allreduce(f)
+            if all_agree(ok):
+                used = "RCCL all-reduce issued from the C++ loop"
+            elif ok:
+                f.rccl_detach()
+        if used is None:
+            _keep = vdist.attach_allreduce(f)              # exchange buffers become torch tensors, collective via a host hook
+            used = "torch.distributed all-reduce through the host hook"
+        collective_used = used
     f.set_precision(args.precision)
     f.evaluate_only_residual(sc.poses_init)                # seeds the (lambda, U, merged) cache (recut's eig)
     f.snapshot_cache()
@@ -244,7 +267,7 @@ def main():
                 "steps_per_solve": sps,
                 "global_voxels": global_voxels,
                 "global_iterations_per_s": args.steps / elapsed,
-                "parallelism": f"voxel-shard x{world}" + (" + RCCL all-reduce of [Hess|JacT|res]" if use_dist else ""),
+                "parallelism": f"voxel-shard x{world}" + (f" + {collective_used} of [Hess|JacT|res]" if use_dist else ""),
                 "final_residual": float(resis[1]),
                 "lm_steps_accepted": lmstats["accepted"], "lm_steps_rejected": lmstats["rejected"],
             },

@@ -143,6 +143,20 @@ int vxba_set_allreduce(vxba_factor* f, vxba_allreduce_fn fn, void* ctx);
  * Collective: every rank of the group must call it.  Takes precedence over vxba_set_allreduce. */
 int vxba_rccl_unique_id(const char* librccl_path, void* unique_id_out_128);
 int vxba_rccl_attach(vxba_factor* f, const char* librccl_path, int nranks, int rank, const void* unique_id_128);
+/* One-shot all-reduce over the peers' mailboxes (point-to-point xGMI reads instead of a ring collective): at W <= 10 the exchange
+ * buffer is 29 KB and a ring is pure latency.  Every rank: vxba_peer_export -> 64-byte IPC handle of its mailbox; gather all handles
+ * (rank order) by any means; vxba_peer_attach.  From then on the sharded LM loop of vxba_damping_iter / vxba_lm_steps / the LI shells
+ * sums its exchange buffer through the mailboxes (fixed rank order: bit-identical results on all ranks); RCCL / the hook stay the
+ * fallback when this is not attached.  Needs peer access between the GPUs (one node) and HSA_ENABLE_IPC_MODE_LEGACY=0 in the
+ * environment.  vxba_peer_status reports a peer that never arrived (the kernel's bounded wait gave up). */
+#define VXBA_PEER_HANDLE_BYTES 64
+#define VXBA_PEER_MAX 16
+int vxba_peer_export(vxba_factor* f, void* handle_out);
+int vxba_peer_attach(vxba_factor* f, int nranks, int rank, const void* handles /* nranks x VXBA_PEER_HANDLE_BYTES */);
+int vxba_peer_detach(vxba_factor* f);
+int vxba_peer_status(vxba_factor* f, int* status);
+/* collective: one all-reduce of a known pattern through the mailboxes; *ok = 1 when every element came back as the exact sum */
+int vxba_peer_selftest(vxba_factor* f, int* ok);
 /* The id exchange through a caller-supplied broadcast (MPI_Bcast, a socket ...): bcast(ctx, buf, nbytes, root) returns 0 after
  * root's bytes are in every rank's buf.  librccl_path NULL: the RCCL the process already uses, else /opt/rocm/lib/librccl.so. */
 typedef int (*vxba_bcast_fn)(void* ctx, void* buf, size_t nbytes, int root);

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from voxel_slam_amd import synth, vxba
@@ -19,7 +19,7 @@ blobs0 = [x.blob.copy() for x in facs]
 opt = vxba.LI_BA_Optimizer()
 res = {}
 for mode in ("0", "1", "0", "1"):
-    os.environ["VXBA_LI_DEVICE"] = mode
+    f.set_option("li_device_loop", int(mode))
     ts = []
     for k in range(12):
         for x, b in zip(facs, blobs0): x.blob[:] = b

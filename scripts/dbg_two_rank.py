@@ -8,6 +8,12 @@ import torch.distributed as dist
 from voxel_slam_amd import synth, vxba, dist as vdist
 
 rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+COLLECTIVE = os.environ.get("VXBA_TWO_RANK_COLLECTIVE", "hook")      # "hook": torch.distributed through the host callback; "peer": one-shot mailbox all-reduce (hipIpc)
+def attach(fac):
+    if COLLECTIVE == "peer":
+        vdist.attach_peer(fac)
+        return None
+    return vdist.attach_allreduce(fac)
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 sc = synth.make_scene(win_size=10, pts_per_scan=40_000, n_voxels=6000, p_obs=0.9, seed=99, rot_sigma_deg=0.3, trans_sigma=0.08)
@@ -17,7 +23,7 @@ ref = vxba.Lidar_BA_Optimizer().damping_iter(sc.poses_init, full, max_iter=6)
 full.evaluate_only_residual(sc.poses_init); full.snapshot_cache()
 ref_p, ref_r, ref_s = full.lm_steps(sc.poses_init, 12, 3)
 f = vxba.LidarFactor(10); f.push_voxels(sc.clusters[lo:hi], sc.fix[lo:hi], sc.coe[lo:hi])
-keep = vdist.attach_allreduce(f)
+keep = attach(f)
 f.evaluate_only_residual(sc.poses_init)
 got = vxba.Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=6)
 et, er = synth.pose_errors(got["poses"], ref["poses"])
@@ -34,7 +40,7 @@ lo, hi = vdist.shard_bounds(sc.n_voxels, world, rank)
 full = vxba.LidarFactor(10); full.push_voxels(sc.clusters, sc.fix, sc.coe); full.evaluate_only_residual(sc.poses_init); full.snapshot_cache()
 ref_p, ref_r, ref_s = full.lm_steps(sc.poses_init, 12, 3)
 f = vxba.LidarFactor(10); f.push_voxels(sc.clusters[lo:hi], sc.fix[lo:hi], sc.coe[lo:hi])
-keep2 = vdist.attach_allreduce(f)
+keep2 = attach(f)
 f.evaluate_only_residual(sc.poses_init); f.snapshot_cache()
 p, r, s = f.lm_steps(sc.poses_init, 12, 3)
 et, er = synth.pose_errors(p, ref_p)
@@ -61,9 +67,11 @@ lo, hi = vdist.shard_bounds(scw.n_voxels, world, rank)
 fullw = vxba.LidarFactor(20); fullw.push_voxels(scw.clusters, scw.fix, scw.coe); fullw.evaluate_only_residual(scw.poses_init)
 refw = vxba.Lidar_BA_Optimizer().damping_iter(scw.poses_init, fullw, max_iter=4)
 fw = vxba.LidarFactor(20); fw.push_voxels(scw.clusters[lo:hi], scw.fix[lo:hi], scw.coe[lo:hi])
-keepw = vdist.attach_allreduce(fw)
+keepw = vdist.attach_allreduce(fw)      # wide windows always go through the collective library (2.9 MB buffers)
 fw.evaluate_only_residual(scw.poses_init)
 gotw = vxba.Lidar_BA_Optimizer().damping_iter(scw.poses_init, fw, max_iter=4)
 et, er = synth.pose_errors(gotw["poses"], refw["poses"])
 print("rank %d wide damping_iter: trace accept %s vs %s, pose diff %.2e %.2e" % (rank, gotw["trace"][:, 6], refw["trace"][:, 6], et, er), flush=True)
+if COLLECTIVE == "peer":
+    assert f.peer_status() == 0
 dist.barrier()

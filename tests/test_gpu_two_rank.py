@@ -13,10 +13,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("spec", ["1", "0"])
-def test_two_process_ranks_reproduce_the_single_factor_run(spec):
-    env = dict(os.environ, VXBA_SPEC_COLLECTIVE=spec, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29560 + int(spec)
+@pytest.mark.parametrize("spec,collective", [("1", "hook"), ("0", "hook"), ("1", "peer"), ("0", "peer")])
+def test_two_process_ranks_reproduce_the_single_factor_run(spec, collective):
+    """collective = "peer": the one-shot all-reduce through hipIpc-mapped mailboxes (vxba_peer_*) -- two processes mapping each other's
+    device memory and summing in rank order inside the device-resident loop; on an 8-GPU node the same reads cross xGMI."""
+    env = dict(os.environ, VXBA_SPEC_COLLECTIVE=spec, VXBA_TWO_RANK_COLLECTIVE=collective, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29560 + int(spec) + (2 if collective == "peer" else 0)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                           os.path.join(ROOT, "scripts", "dbg_two_rank.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]

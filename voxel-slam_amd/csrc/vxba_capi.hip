@@ -82,6 +82,15 @@ struct vxba_factor {
   ncclComm_t rccl_comm = nullptr;
   ncclResult_t (*p_ncclAllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*p_ncclCommDestroy)(ncclComm_t) = nullptr;
+  // one-shot peer all-reduce over xGMI (vxba_peer_*): every rank's mailbox mapped into every other rank through hipIpc
+  struct Peer {
+    int nranks = 0, rank = 0;
+    size_t len = 0;                       // doubles per mailbox slot
+    double* box = nullptr;                // own mailbox: [2][len] f64 + flags [2][PEER_WGS] u64 + status u64 (fine-grained device memory)
+    void* opened[VXBA_PEER_MAX] = {};     // hipIpcOpenMemHandle results (own entry stays null)
+    double* boxes[VXBA_PEER_MAX] = {};    // mailbox of rank p as seen from this process
+    unsigned long long seq = 0;
+  } peer;
   int profiling = 0;             // bit mask of kernel kinds to bracket with events: 1 K3, 2 K2, 4 K3 finalize, 8 K1
   std::vector<EventPair> pending;
   std::vector<hipEvent_t> free_events;
@@ -247,9 +256,64 @@ int drain_events(vxba_factor* f) {
   return VXBA_OK;
 }
 
-// Sum `count` f64 across the voxel shards, stream-ordered: direct RCCL if attached, else the caller's hook.
-bool has_collective(const vxba_factor* f) { return f->rccl_comm != nullptr || f->allreduce != nullptr; }
+// ---- one-shot all-reduce over the peers' mailboxes ---------------------------------------------------------------------------
+// The exchange buffer of the sharded LM loop is 29 KB: under a ring collective that is pure latency (2 (N - 1) hops).  Here every
+// rank publishes its buffer in its own mailbox and reads the N - 1 others directly over xGMI -- one hop, all links at once.
+// Workgroup w owns slice w of the buffer on every rank: it copies its slice into the local mailbox (slot = call parity), fences,
+// raises flag[slot][w] = call number, then waits for the same flag of every peer and adds the peers' slices in RANK ORDER (own
+// slice included, read back from the mailbox), so all ranks compute bit-identical sums.  Double buffering is enough: a rank can
+// only reach call k + 2 after every peer raised its flags for call k + 1, i.e. finished reading call k.  Mailboxes are fine-grained
+// device memory and are read with system-scope loads (no stale lines of call k - 2 from a non-coherent cache).
+constexpr int PEER_WGS = 8, PEER_THREADS = 256;
+struct PeerArgs { double* boxes[VXBA_PEER_MAX]; int nranks, rank; unsigned long long len; };
+__device__ __forceinline__ unsigned long long* peer_flags(double* box, unsigned long long len) { return reinterpret_cast<unsigned long long*>(box + 2 * len); }
+__global__ __launch_bounds__(PEER_THREADS) void peer_allreduce_kernel(PeerArgs a, double* __restrict__ buf, unsigned long long count, unsigned long long seq) {
+  const int w = blockIdx.x, tid = threadIdx.x;
+  const unsigned slot = (unsigned)(seq & 1);
+  const unsigned long long per = (count + PEER_WGS - 1) / PEER_WGS, lo = per * w, hi = lo + per < count ? lo + per : count;
+  double* mine = a.boxes[a.rank] + slot * a.len;
+  for (unsigned long long i = lo + tid; i < hi; i += PEER_THREADS) mine[i] = buf[i];
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(peer_flags(a.boxes[a.rank], a.len) + slot * PEER_WGS + w, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __shared__ int failed;
+  if (tid == 0) {
+    int bad = 0;
+    for (int p = 0; p < a.nranks && !bad; p++) {
+      const unsigned long long* fl = peer_flags(a.boxes[p], a.len) + slot * PEER_WGS + w;
+      long long spins = 0;
+      while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1ll << 23)) { bad = 1; break; }       // a peer that never arrives: a few seconds, then give up loudly
+      }
+    }
+    failed = bad;
+    if (bad) __hip_atomic_store(peer_flags(a.boxes[a.rank], a.len) + 2 * PEER_WGS, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // status word
+  }
+  __syncthreads();
+  if (failed) return;
+  for (unsigned long long i = lo + tid; i < hi; i += PEER_THREADS) {
+    double s = 0.0;
+    for (int p = 0; p < a.nranks; p++) {
+      const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.boxes[p] + slot * a.len + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      s += __longlong_as_double((long long)bits);
+    }
+    buf[i] = s;
+  }
+}
+bool has_peer(const vxba_factor* f) { return f->peer.nranks > 1; }
+
+// Sum `count` f64 across the voxel shards, stream-ordered: the peers' mailboxes if attached, else direct RCCL, else the caller's hook.
+bool has_collective(const vxba_factor* f) { return has_peer(f) || f->rccl_comm != nullptr || f->allreduce != nullptr; }
 int shard_allreduce(vxba_factor* f, double* d_buf, size_t count) {
+  if (has_peer(f)) {
+    if (count > f->peer.len) return fail(f, VXBA_ERR_STATE, "peer all-reduce: buffer larger than the mailbox");
+    PeerArgs a;
+    for (int p = 0; p < VXBA_PEER_MAX; p++) a.boxes[p] = f->peer.boxes[p];
+    a.nranks = f->peer.nranks; a.rank = f->peer.rank; a.len = f->peer.len;
+    peer_allreduce_kernel<<<PEER_WGS, PEER_THREADS, 0, f->stream>>>(a, d_buf, count, ++f->peer.seq);
+    return VXBA_OK;
+  }
   if (f->rccl_comm) {
     if (f->p_ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, f->rccl_comm, f->stream) != ncclSuccess)
       return fail(f, VXBA_ERR_STATE, "ncclAllReduce failed");
@@ -524,6 +588,8 @@ int vxba_destroy(vxba_factor* f) {
   hipSetDevice(f->device);
   if (f->stream) hipStreamSynchronize(f->stream);
   vxba_rccl_detach(f);
+  vxba_peer_detach(f);
+  if (f->peer.box) hipFree(f->peer.box);
   for (auto& ep : f->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   for (auto e : f->free_events) hipEventDestroy(e);
   hipFree(f->planes); hipFree(f->clb); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2);
@@ -654,6 +720,103 @@ int vxba_rccl_detach(vxba_factor* f) {
     f->p_ncclCommDestroy(f->rccl_comm);
     f->rccl_comm = nullptr;
   }
+  return VXBA_OK;
+}
+
+// ---- vxba_peer_*: the mailbox, its IPC handle, the peers' mappings ------------------------------------------------------------
+static size_t peer_box_bytes(size_t len) { return (2 * len + 2 * PEER_WGS + 1) * sizeof(double); }
+int vxba_peer_export(vxba_factor* f, void* handle_out) {
+  VX_LOCK(f);
+  if (!f || !handle_out) return fail(f, VXBA_ERR_ARG, "peer_export: null argument");
+  hipSetDevice(f->device);
+  if (!f->peer.box) {
+    const size_t len = vxba_packed_len(f) + 1;
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, peer_box_bytes(len), hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(f, VXBA_ERR_HIP, "peer_export: cannot allocate fine-grained device memory for the mailbox");
+    }
+    VX_HIP(f, hipMemset(p, 0, peer_box_bytes(len)));
+    f->peer.box = (double*)p;
+    f->peer.len = len;
+  }
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, f->peer.box) != hipSuccess) { (void)hipGetLastError(); return fail(f, VXBA_ERR_HIP, "peer_export: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)"); }
+  static_assert(sizeof h == VXBA_PEER_HANDLE_BYTES, "IPC handle size");
+  std::memcpy(handle_out, &h, sizeof h);
+  return VXBA_OK;
+}
+int vxba_peer_attach(vxba_factor* f, int nranks, int rank, const void* handles) {
+  VX_LOCK(f);
+  if (!f || !handles || nranks < 1 || nranks > VXBA_PEER_MAX || rank < 0 || rank >= nranks) return fail(f, VXBA_ERR_ARG, "peer_attach: bad argument");
+  if (!f->peer.box) return fail(f, VXBA_ERR_STATE, "peer_attach: call vxba_peer_export first");
+  if (f->peer.nranks) return fail(f, VXBA_ERR_STATE, "peer_attach: already attached");
+  if (is_wide(f)) return fail(f, VXBA_ERR_UNSUPPORTED, "peer_attach: windows wider than 10 frames use RCCL (2.9 MB buffers are bandwidth-bound)");
+  hipSetDevice(f->device);
+  for (int p = 0; p < nranks; p++) {
+    if (p == rank) { f->peer.boxes[p] = f->peer.box; continue; }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, (const char*)handles + (size_t)p * VXBA_PEER_HANDLE_BYTES, sizeof h);
+    void* q = nullptr;
+    if (hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+      (void)hipGetLastError();
+      for (int k = 0; k < p; k++) if (f->peer.opened[k]) { hipIpcCloseMemHandle(f->peer.opened[k]); f->peer.opened[k] = nullptr; }
+      return fail(f, VXBA_ERR_HIP, "peer_attach: hipIpcOpenMemHandle failed (peer not reachable / IPC disabled)");
+    }
+    f->peer.opened[p] = q;
+    f->peer.boxes[p] = (double*)q;
+  }
+  f->peer.nranks = nranks; f->peer.rank = rank; f->peer.seq = 0;
+  return VXBA_OK;
+}
+int vxba_peer_detach(vxba_factor* f) {
+  VX_LOCK(f);
+  if (!f) return VXBA_ERR_ARG;
+  hipSetDevice(f->device);
+  if (f->stream) hipStreamSynchronize(f->stream);
+  for (int p = 0; p < VXBA_PEER_MAX; p++) {
+    if (f->peer.opened[p]) hipIpcCloseMemHandle(f->peer.opened[p]);
+    f->peer.opened[p] = nullptr; f->peer.boxes[p] = nullptr;
+  }
+  f->peer.nranks = 0;
+  return VXBA_OK;
+}
+// Collective self-test (call on every rank after vxba_peer_attach, before trusting the link): every rank contributes rank + 1 in
+// every element of a full-length buffer and must read back N (N + 1) / 2.  *ok = 0 on a wrong sum or a peer that never arrived.
+int vxba_peer_selftest(vxba_factor* f, int* ok) {
+  VX_LOCK(f);
+  if (!f || !ok) return VXBA_ERR_ARG;
+  *ok = 0;
+  if (!has_peer(f)) return fail(f, VXBA_ERR_STATE, "peer_selftest: not attached");
+  hipSetDevice(f->device);
+  const size_t n = vxba_packed_len(f) + 1;
+  std::vector<double> h(n, (double)(f->peer.rank + 1));
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  VX_HIP(f, hipMemcpyAsync(f->own_packed, h.data(), n * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  int rc = shard_allreduce(f, f->own_packed, n);
+  if (rc) return rc;
+  VX_HIP(f, hipMemcpyAsync(h.data(), f->own_packed, n * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  int st = 0;
+  rc = vxba_peer_status(f, &st);
+  if (rc) return rc;
+  const double want = 0.5 * f->peer.nranks * (f->peer.nranks + 1);
+  bool good = st == 0;
+  for (size_t i = 0; i < n && good; i++) good = h[i] == want;
+  *ok = good ? 1 : 0;
+  return VXBA_OK;
+}
+// 0: fine; 1: a peer never raised its flag within the spin bound (results of that call are not a sum: the caller must stop)
+int vxba_peer_status(vxba_factor* f, int* status) {
+  VX_LOCK(f);
+  if (!f || !status) return VXBA_ERR_ARG;
+  *status = 0;
+  if (!f->peer.box) return VXBA_OK;
+  hipSetDevice(f->device);
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  unsigned long long st = 0;
+  VX_HIP(f, hipMemcpy(&st, f->peer.box + 2 * f->peer.len + 2 * PEER_WGS, sizeof st, hipMemcpyDeviceToHost));
+  *status = (int)st;
   return VXBA_OK;
 }
 
@@ -916,8 +1079,8 @@ int vxba_build_clusters(int device, int64_t n_cells, int64_t n_points, const dou
 // round trip: the LM state (poses, damping, accept/reject flags) lives in device memory (vxk::LMState), the solve and
 // the accept/reject step are single-workgroup kernels, and the sweeps gate themselves on the state's flags exactly
 // where the reference branches (is_calc_hess, the early break).  One D2H copy + one sync at the end.
-int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out, double* resis_out, double* trace_out, int* n_trace,
-                      int* is_converge) {
+static int damping_iter_impl(vxba_factor* f, double* Rp, int max_iter, double* hess_out, double* resis_out, double* trace_out, int* n_trace,
+                             int* is_converge) {
   VX_LOCK(f);
   if (!f || !Rp || max_iter < 0 || max_iter > vxk::LM_MAX_ITER) return fail(f, VXBA_ERR_ARG, "damping_iter: bad argument (max_iter <= 64)");
   if (f->V == 0) return fail(f, VXBA_ERR_STATE, "damping_iter on an empty factor");
@@ -1088,7 +1251,7 @@ int vxba_damping_iter_generic(int W, double* Rp, int max_iter, vxba_hess_fn hess
   return VXBA_OK;
 }
 
-int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_per_solve, double* Rp_out, double* last_resis,
+static int lm_steps_impl(vxba_factor* f, const double* Rp_init, int n_steps, int steps_per_solve, double* Rp_out, double* last_resis,
                   int64_t* stats_out) {
   VX_LOCK(f);
   if (!f || !Rp_init || n_steps < 0 || steps_per_solve < 1) return fail(f, VXBA_ERR_ARG, "lm_steps: bad argument");
@@ -1690,3 +1853,18 @@ int vxba_algorithmic_bytes(const vxba_factor* f, double bytes[2]) {
 }
 
 }  // extern "C"
+
+// ---- entry points that may have summed through the peers' mailboxes: a peer that never arrived must not pass silently ----
+static int peer_check(vxba_factor* f, int rc) {
+  if (rc != VXBA_OK || !f || !has_peer(f)) return rc;
+  int st = 0;
+  const int r2 = vxba_peer_status(f, &st);
+  if (r2 != VXBA_OK) return r2;
+  return st ? fail(f, VXBA_ERR_STATE, "peer all-reduce: a peer did not arrive within the wait bound (results are not a sum)") : VXBA_OK;
+}
+int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out, double* resis_out, double* trace_out, int* n_trace, int* is_converge) {
+  return peer_check(f, damping_iter_impl(f, Rp, max_iter, hess_out, resis_out, trace_out, n_trace, is_converge));
+}
+int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_per_solve, double* Rp_out, double* last_resis, int64_t* stats_out) {
+  return peer_check(f, lm_steps_impl(f, Rp_init, n_steps, steps_per_solve, Rp_out, last_resis, stats_out));
+}

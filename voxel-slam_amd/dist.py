@@ -108,6 +108,23 @@ def attach_rccl(factor, group=None):
     factor.rccl_attach(lib, world, rank, obj[0])   # collectives are issued on the factor's own stream, in order with its kernels
 
 
+def attach_peer(factor, group=None):
+    """One-shot all-reduce over the ranks' mailboxes (vxba_peer_*): point-to-point xGMI reads instead of a ring collective for the 29 KB
+    exchange buffer.  The 64-byte IPC handles travel over the existing torch.distributed group (any backend).  Collective.  Raises
+    VxbaError where IPC / peer access is not available -- fall back to attach_rccl then."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    mine = factor.peer_export()
+    handles = [None] * world
+    dist.all_gather_object(handles, mine, group=group)
+    factor.peer_attach(world, rank, handles)
+    dist.barrier(group=group)        # nobody starts a collective before every rank has mapped every mailbox
+    if not factor.peer_selftest():   # one all-reduce of a known pattern: a link that does not sum exactly is not used
+        factor.peer_detach()
+        raise RuntimeError("peer all-reduce self-test failed on rank %d" % rank)
+
+
 def damping_iter_sharded(win_size: int, x_stats, local_hess, local_resid, max_iter: int = 3, group=None):
     """``Lidar_BA_Optimizer::damping_iter`` over a voxel shard per rank, host-driven.
 

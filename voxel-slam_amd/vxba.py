@@ -30,7 +30,7 @@ EXPORTS = [
     "vxba_reserve", "vxba_last_error", "vxba_push_voxels", "vxba_push_points", "vxba_read_clusters", "vxba_acc_evaluate2",
     "vxba_evaluate_only_residual", "vxba_acc_evaluate2_device", "vxba_evaluate_only_residual_device", "vxba_packed_len",
     "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_plane_fit_judge", "vxba_build_clusters", "vxba_set_allreduce",
-    "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_attach_bcast", "vxba_rccl_detach", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps",
+    "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_attach_bcast", "vxba_rccl_detach", "vxba_peer_export", "vxba_peer_attach", "vxba_peer_detach", "vxba_peer_status", "vxba_peer_selftest", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps",
     "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_li_evaluate",
     "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity", "vxba_voxelize_push", "vxba_set_precision",
     "vxba_lio_create", "vxba_lio_destroy", "vxba_lio_last_error", "vxba_lio_map_update", "vxba_lio_map_clear", "vxba_lio_map_size", "vxba_lio_scan_raw",
@@ -154,6 +154,11 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_down_sampling_voxel.argtypes = [ci, C.c_int64, np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS"), cd,
                                            np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS"), C.POINTER(C.c_int64)]
     L.vxba_plane_update.argtypes = [ci, C.c_int64, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p]
+    L.vxba_peer_export.argtypes = [vp, vp]
+    L.vxba_peer_attach.argtypes = [vp, ci, ci, vp]
+    L.vxba_peer_detach.argtypes = [vp]
+    L.vxba_peer_status.argtypes = [vp, C.POINTER(ci)]
+    L.vxba_peer_selftest.argtypes = [vp, C.POINTER(ci)]
     L.vxba_set_option.argtypes = [vp, ci, ci]
     L.vxba_get_option.argtypes = [vp, ci, C.POINTER(ci)]
     L.vxba_lio_set_option.argtypes = [vp, ci, ci]
@@ -374,6 +379,31 @@ class LidarFactor:
         self._chk(self._L.vxba_use_external_buffers(self._h, C.c_void_p(d_packed_ptr or 0), C.c_void_p(d_scalar_ptr or 0)))
 
     # -- measurement ----------------------------------------------------------------------------
+    def peer_export(self) -> bytes:
+        """64-byte IPC handle of this factor's all-reduce mailbox (vxba_peer_export)."""
+        buf = C.create_string_buffer(64)
+        self._chk(self._L.vxba_peer_export(self._h, buf))
+        return buf.raw
+
+    def peer_attach(self, nranks: int, rank: int, handles):
+        """handles: the ranks' peer_export() results in rank order."""
+        blob = b"".join(handles)
+        assert len(blob) == 64 * nranks
+        self._chk(self._L.vxba_peer_attach(self._h, int(nranks), int(rank), C.c_char_p(blob)))
+
+    def peer_detach(self):
+        self._chk(self._L.vxba_peer_detach(self._h))
+
+    def peer_selftest(self) -> bool:
+        ok = C.c_int(0)
+        self._chk(self._L.vxba_peer_selftest(self._h, C.byref(ok)))
+        return bool(ok.value)
+
+    def peer_status(self) -> int:
+        st = C.c_int(0)
+        self._chk(self._L.vxba_peer_status(self._h, C.byref(st)))
+        return st.value
+
     OPTIONS = {"fused_solve": 0, "spec_collective": 1, "wide_device_solve": 2, "li_device_loop": 3, "k2_voxels_per_block": 4}
 
     def set_option(self, name: str, value: int):
