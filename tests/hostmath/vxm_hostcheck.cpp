@@ -48,9 +48,23 @@ void vxmh_k2(int V, int W, const double* clusters, const double* fix, const doub
 }
 
 // K3 on the host via the rank-3 rows: Hess (6W)^2 col-major, JacT 6W, residual
+// spare != 0: the narrow-window kernel's variant -- k3_entry<false> leaves Drt / Dtt out of the accumulators and the z row of
+// every voxel carries sqrt2 sqrt(coe) u in three extra columns, whose products with the frame columns ARE Drt / Dtt
+// (vxba_k3.hpp, K3Cfg::SPARE).
+static void vxmh_k3_impl(int V, int W, const double* clusters, const double* coe, const double* eig_val, const double* eig_vec,
+             const double* merged, const double* Rp, double* Hess, double* JacT, double* residual, int spare);
 void vxmh_k3(int V, int W, const double* clusters, const double* coe, const double* eig_val, const double* eig_vec,
              const double* merged, const double* Rp, double* Hess, double* JacT, double* residual) {
+  vxmh_k3_impl(V, W, clusters, coe, eig_val, eig_vec, merged, Rp, Hess, JacT, residual, 0);
+}
+void vxmh_k3_spare(int V, int W, const double* clusters, const double* coe, const double* eig_val, const double* eig_vec,
+             const double* merged, const double* Rp, double* Hess, double* JacT, double* residual) {
+  vxmh_k3_impl(V, W, clusters, coe, eig_val, eig_vec, merged, Rp, Hess, JacT, residual, 1);
+}
+static void vxmh_k3_impl(int V, int W, const double* clusters, const double* coe, const double* eig_val, const double* eig_vec,
+             const double* merged, const double* Rp, double* Hess, double* JacT, double* residual, int spare) {
   const int n = 6 * W;
+  std::vector<double> SP((size_t)n * 3, 0.0);           // S[x][6W + k]: products of the z row with the spare columns
   std::vector<double> S((size_t)n * n, 0.0);            // sum rows^T rows (row-major)
   std::vector<double> acc((size_t)W * 27, 0.0);
   double res = 0;
@@ -69,8 +83,13 @@ void vxmh_k3(int V, int W, const double* clusters, const double* coe, const doub
       if (c[9] == 0) continue;
       double R[9], p[3], rows[3][6];
       pose_rowmajor(Rp + 12 * i, R, p);
-      vxm::k3_entry(c, c + 6, c[9], R, p, vc, rows, acc.data() + 27 * i);
+      if (spare) vxm::k3_entry<false>(c, c + 6, c[9], R, p, vc, rows, acc.data() + 27 * i);
+      else vxm::k3_entry(c, c + 6, c[9], R, p, vc, rows, acc.data() + 27 * i);
       for (int r = 0; r < 3; r++) for (int k = 0; k < 6; k++) B[(size_t)r * n + 6 * i + k] = rows[r][k];
+    }
+    if (spare) {
+      const double ss = 1.4142135623730951 * vc.sc;
+      for (int x = 0; x < n; x++) for (int k = 0; k < 3; k++) SP[(size_t)x * 3 + k] += B[(size_t)2 * n + x] * (ss * vc.u0[k]);
     }
     for (int r = 0; r < 3; r++)
       for (int x = 0; x < n; x++) {
@@ -92,6 +111,13 @@ void vxmh_k3(int V, int W, const double* clusters, const double* coe, const doub
         Hess[(size_t)(6 * i + r) * n + 6 * i + 3 + c] += d[12 + 3 * r + c];      // transpose
         Hess[(size_t)(6 * i + 3 + c) * n + 6 * i + 3 + r] += d[21 + s6i[r][c]];
       }
+    if (spare)   // k3_finalize's rule: Hess(6i+a, 6i+b) += S[6i+a][6W + (b-3)] for b >= 3, a <= b, mirrored
+      for (int a = 0; a < 6; a++)
+        for (int b = (a < 3 ? 3 : a); b < 6; b++) {
+          const double v = SP[(size_t)(6 * i + a) * 3 + (b - 3)];
+          Hess[(size_t)(6 * i + b) * n + 6 * i + a] += v;
+          if (a != b) Hess[(size_t)(6 * i + a) * n + 6 * i + b] += v;
+        }
   }
   *residual = res;
 }

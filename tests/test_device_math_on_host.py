@@ -27,6 +27,7 @@ def hm():
     L.vxmh_eig_sym3_warm.argtypes = [f64p, f64p, f64p, f64p]
     L.vxmh_k2.argtypes = [C.c_int, C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, f64p, C.POINTER(C.c_double)]
     L.vxmh_k3.argtypes = [C.c_int, C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p, C.POINTER(C.c_double)]
+    L.vxmh_k3_spare.argtypes = L.vxmh_k3.argtypes
     return L
 
 
@@ -110,3 +111,10 @@ def test_k2_and_k3_lane_math_match_oracle(hm, p_obs, fix_frac):
     assert np.allclose(H, H_ref, rtol=1e-9, atol=1e-10 * np.abs(H_ref).max())
     assert np.allclose(J, J_ref, rtol=1e-9, atol=1e-11 * np.abs(J_ref).max())
     assert np.isclose(rr.value, res_ref, rtol=1e-13)
+    # the narrow-window kernel's variant: Drt / Dtt as products of the z row with the spare columns (sqrt2 sqrt(coe) u)
+    H2 = np.zeros((n, n)); J2 = np.zeros(n)
+    hm.vxmh_k3_spare(V, W, sc.clusters, coe, ev_ref, U_ref, m_ref, sc.poses_init, H2, J2, C.byref(rr))
+    H2 = H2.T
+    assert np.allclose(H2, H_ref, rtol=1e-9, atol=1e-10 * np.abs(H_ref).max())
+    assert np.allclose(H2, H2.T, rtol=0, atol=1e-12 * np.abs(H_ref).max())
+    assert np.allclose(J2, J_ref, rtol=1e-9, atol=1e-11 * np.abs(J_ref).max())

@@ -370,10 +370,10 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c
   PoseArg pa;
   if (Rp) fill_poses(f, Rp, pa); else std::memset(&pa, 0, sizeof pa);
   const FactorView fv = view(f);
-  // one wave per batch of NV voxels; never launch more workgroups than there are batches / 4
+  // one wave per batch of NV voxels, eight waves per workgroup; never launch more workgroups than there are steps of eight batches
   const int nv = vxk::k3_nv(f->W);
   const int nbatches = (end - 1) / nv - head / nv + 1;
-  const int nblocks = std::max(1, std::min(vxk::k3_grid_blocks(f->cus), (nbatches + 3) / 4));
+  const int nblocks = vxk::k3_blocks_for(nbatches, vxk::k3_grid_blocks(f->cus));
   vxk::LMPending none;
   std::memset(&none, 0, sizeof none);
   const vxk::LMPending& pd = pend ? *pend : none;
@@ -456,7 +456,7 @@ int spec_hess_phase(vxba_factor* f, const double* Rp0, int* c, bool first_of_sol
   const FactorView fv = view(f);
   const int nv = vxk::k3_nv(f->W);
   const int nbatches = (f->V - 1) / nv + 1;
-  const int nblocks = std::max(1, std::min(vxk::k3_grid_blocks(f->cus), (nbatches + 3) / 4));
+  const int nblocks = vxk::k3_blocks_for(nbatches, vxk::k3_grid_blocks(f->cus));
   vxk::LMPending pd;
   std::memset(&pd, 0, sizeof pd);
   pd.pending = first_of_solve ? 3 : 2;

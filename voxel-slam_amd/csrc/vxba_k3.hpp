@@ -1,0 +1,484 @@
+// K3 -- Hessian / gradient sweep (LidarFactor::acc_evaluate2, voxel_map.hpp:132-241).  Included by vxba_kernels.hip inside
+// namespace vxk, after the LM helpers (lm_decide / lm_residual2 / lm_carry / lm_persist) and dbg_stamp.
+//
+// Per voxel  H_a = -B_a^T B_a + blockdiag_i(D_{a,i})  with B_a the 3 x 6W matrix of SURVEY A.4, so the window Hessian is a
+// tall-skinny SYRK over the 3V stacked rows: v_mfma_f64_16x16x4_f64 accumulates the upper-triangular 16 x 16 tile pairs of
+// S = sum B^T B; gradient, block-diagonal terms and the residual are 28 linear accumulators per frame.
+//
+// Round-2 mapping: ONE 8-wave workgroup per CU, two waves per SIMD.  On this chip the f64 MFMA and the f64 VALU share one
+// datapath (strictly additive inside a SIMD, scripts/ubench/mfma_valu_overlap.hip), so the kernel is bound by its fp64 issue
+// count; what a second wave per SIMD buys is that everything that is NOT fp64 -- LDS operand reads and row stores, address
+// arithmetic, waits on global loads, the barrier -- runs under the other wave's fp64 work.  Two waves per SIMD means 256
+// registers per lane, which the round-1 kernel (80 accumulator registers + two entry sets) did not fit.  Here the eight
+// waves of the workgroup share the MFMA work of a STEP of eight batches instead of each wave doing all of its own:
+//   phase A  every wave turns its own batch (NV voxels x W frames, one lane per entry) into 3 NV rows of B and stores them
+//            in a workgroup-shared LDS tile of 8 x 3 NV rows (144 rows at W = 10: 36 K-steps, no K padding -- the round-1
+//            kernel padded each batch's 18 rows to 20);
+//   phase M  wave w owns tile set (w mod TSPLIT) -- half of the tile pairs at W >= 6 -- and the K range (w div TSPLIT) of the
+//            step: 45 MFMAs per wave and step at W = 10 (it was 50 per batch), 40 accumulator registers instead of 80.
+// The tile is double-buffered and the loop is skewed -- phase M of step s-1, then phase A of step s, then ONE barrier -- so a
+// wave leaves the barrier straight into MFMAs whose operands only need an LDS read.  A single entry register set suffices:
+// the loads of the next batch are issued right after phase A has consumed the current one and have the whole phase M to land.
+// Workgroups take contiguous, evenly sized runs of batches (32 or 33 at cfg2); the run's last, partly filled step only
+// covers the rows that exist (its K range is re-split over the waves), so the ragged end costs one phase A, not a step.
+// The cross-wave reduction of the epilogue and the workgroup partial (k3_finalize's input) are laid out as in round 1.
+// No float atomics: bitwise reproducible for a given launch geometry.
+#pragma once
+
+template <int W>
+struct K3Cfg {
+  static constexpr int NT = (6 * W + 15) / 16;        // 16-wide column tiles
+  static constexpr int NTP = NT * (NT + 1) / 2;       // upper-triangular tile pairs
+  static constexpr int NCOL = 16 * NT;
+  static constexpr int NVCAP = (NT <= 2) ? 12 : (NT == 3 ? 8 : 6);   // keeps two tile buffers of 8 batches within 144 KB of LDS
+  static constexpr int NV = (64 / W) < NVCAP ? (64 / W) : NVCAP;     // voxels per wave-batch (== k3_nv(W))
+  static constexpr int NACT = NV * W;                 // active lanes
+  static constexpr int R = 3 * NV;                    // rows of B per batch
+  static constexpr int WAVES = K3_BLOCK / 64;         // 8
+  static constexpr int ROWS = WAVES * R;              // rows per step: 288 / 192 / 144, always a multiple of 4
+  static constexpr int KS = ROWS / 4;                 // MFMA K-steps per full step
+  static constexpr int TSPLIT = (NTP >= 6) ? 2 : 1;   // tile sets
+  static constexpr int KSPLIT = WAVES / TSPLIT;       // K ranges
+  static constexpr int TPW = NTP / TSPLIT;            // tile pairs (accumulators) per wave: 1, 3, 3, 5
+  static constexpr int KPW = KS / KSPLIT;             // K-steps per wave and full step: 9, 9, 12, 9
+  // Tile layout: rows are stored in PAIRS, column tiles interleaved -- element (row, col) sits at
+  //   (row >> 1) * 2 NCOL + (col >> 4) * 32 + (row & 1) * 16 + (col & 15)
+  // so the two rows a half-wave reads for one MFMA operand (ds_read_b64 is served 32 lanes at a time over 64 banks) are 32
+  // CONTIGUOUS doubles: conflict-free without padding (which is what lets two buffers fit), and a lane's operand address is
+  // one register plus immediates for the K-step and the column tile.
+  // Spare (padding) columns 6W .. 6W+2 of the z rows carry sqrt2 sqrt(coe) u: the MFMA then delivers the block-diagonal
+  // terms Drt, Dtt in S[.][6W + k] for free (vxm::k3_entry<false>) -- 15 accumulators (30 registers) and 22 fp64 operations
+  // per entry less.  Window sizes without three spare columns (W = 5, 8) keep the register accumulators.
+  static constexpr bool SPARE = (NCOL - 6 * W) >= 3;
+  static constexpr int BUF = ROWS * NCOL;             // doubles (f64) or floats (mixed) per tile buffer
+  __host__ __device__ static constexpr int at(int row, int col) { return (row >> 1) * 2 * NCOL + (col >> 4) * 32 + (row & 1) * 16 + (col & 15); }
+  static_assert(ROWS % 4 == 0 && NTP % TSPLIT == 0 && KS % KSPLIT == 0, "step geometry");
+};
+
+// tile pair t (row-major over the upper triangle) -> (I, J)
+__host__ __device__ constexpr int k3_tile_I(int NT, int t) { int I = 0; while (t >= NT - I) { t -= NT - I; I++; } return I; }
+__host__ __device__ constexpr int k3_tile_J(int NT, int t) { int I = 0; while (t >= NT - I) { t -= NT - I; I++; } return I + t; }
+// column tiles touched by tile set SET as A (row) operand / as B (column) operand, one bit per column tile
+__host__ __device__ constexpr unsigned k3_need_rows(int NT, int TPW, int SET) { unsigned m = 0; for (int j = 0; j < TPW; j++) m |= 1u << k3_tile_I(NT, SET * TPW + j); return m; }
+__host__ __device__ constexpr unsigned k3_need_cols(int NT, int TPW, int SET) { unsigned m = 0; for (int j = 0; j < TPW; j++) m |= 1u << k3_tile_J(NT, SET * TPW + j); return m; }
+
+// Register image of one (voxel, frame) entry plus the voxel's cached plane parameters.
+struct K3Entry {
+  double c[10];      // body-frame cluster
+  double u[9];       // eigenvectors, plane 3*col+row
+  double s1, s2;     // gap scales
+  double invN, sc;   // 1 / merged count, sqrt(coe)
+  double mv[3];      // merged first moment
+  double coe, lam0;
+  bool ok;           // lane holds a real (voxel, frame) entry of [head,end)
+};
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Entry loads go through buffer descriptors: the address of every load is  descriptor base (SGPRs) + plane offset (one SGPR) +
+// one 32-bit lane offset (VGPR)  -- no 64-bit address arithmetic on the VALU and no address register pairs to carry.
+struct K3Planes {
+  __amdgpu_buffer_rsrc_t eigval, eigvec, merged, aux, coe;
+  const double* clb;
+  unsigned vs8;   // plane stride in bytes
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t k3_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)0xffffffff, 0x00020000);   // raw buffer, no range limit
+}
+__device__ __forceinline__ K3Planes k3_planes(const FactorView& fv) {
+  K3Planes pl;
+  pl.eigval = k3_rsrc(fv.eigval);
+  pl.eigvec = k3_rsrc(fv.eigvec);
+  pl.merged = k3_rsrc(fv.merged);
+  pl.aux = k3_rsrc(fv.aux);
+  pl.coe = k3_rsrc(fv.coe);
+  pl.clb = fv.clb;
+  pl.vs8 = (unsigned)fv.VS * 8u;
+  return pl;
+}
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double k3_ld64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+
+template <int W>
+__device__ __forceinline__ void k3_load_entry(const K3Planes& pl, int head, int end, int b, bool active, int vl, int lane, K3Entry& e) {
+  using C = K3Cfg<W>;
+  const int a = b * C::NV + vl;
+  e.ok = active && a >= head && a < end;
+  // clusters: five contiguous 1 KB rows per wave (batch-major copy)
+  const __amdgpu_buffer_rsrc_t rc = k3_rsrc(pl.clb + (size_t)b * 640);
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const v2d t = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rc, lane * 16, j * 1024, 0));
+    e.c[2 * j] = t[0];
+    e.c[2 * j + 1] = t[1];
+  }
+  // plane parameters of my voxel: each row of NV voxels sits in one or two cache lines
+  const unsigned off = (unsigned)(e.ok ? a : head) * 8u;
+  const unsigned vs8 = pl.vs8;
+#pragma unroll
+  for (int k = 0; k < 9; k++) e.u[k] = k3_ld64(pl.eigvec, off, k * vs8);
+  e.s1 = k3_ld64(pl.aux, off, 0);
+  e.s2 = k3_ld64(pl.aux, off, vs8);
+#pragma unroll
+  for (int k = 0; k < 3; k++) e.mv[k] = k3_ld64(pl.merged, off, (6 + k) * vs8);
+  e.invN = k3_ld64(pl.aux, off, 2 * vs8);
+  e.sc = k3_ld64(pl.aux, off, 3 * vs8);
+  e.coe = k3_ld64(pl.coe, off, 0);
+  e.lam0 = k3_ld64(pl.eigval, off, 0);
+}
+
+// Phase A of one entry: rows of B_a (3 x 6) and the per-frame linear accumulators, branch-free.
+template <bool RT>
+__device__ __forceinline__ void k3_phase_a(K3Entry& e, int fi, const double* __restrict__ pose, double rows[3][6], double dacc[DACC]) {
+  // pose of the lane's frame from LDS (R row-major | p): 24 registers less to carry through phase M
+  double R[9], p[3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = pose[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) p[k] = pose[9 + k];
+  const bool obs = e.ok && e.c[9] != 0.0;   // N == 0: frame did not observe the voxel (voxel_map.hpp:178)
+#pragma unroll
+  for (int k = 0; k < 10; k++) e.c[k] = obs ? e.c[k] : 0.0;
+  vxm::VoxelCache vc;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { vc.u0[k] = e.u[k]; vc.u1[k] = e.u[3 + k]; vc.u2[k] = e.u[6 + k]; }
+  vc.s1 = e.s1;
+  vc.s2 = e.s2;
+  vc.invN = e.invN;
+#pragma unroll
+  for (int k = 0; k < 3; k++) vc.vbar[k] = e.mv[k] * vc.invN;
+  vc.coe = obs ? e.coe : 0.0;
+  vc.sc = obs ? e.sc : 0.0;
+  dacc[27] += (e.ok && fi == 0) ? e.coe * e.lam0 : 0.0;  // residual += coe * lambda_0, once per voxel (voxel_map.hpp:234)
+  vxm::k3_entry<RT>(e.c, e.c + 6, e.c[9], R, p, vc, rows, dacc);
+}
+
+// Store addresses of a lane's three row pieces (element offsets inside a tile buffer): lane constants, kept as 3 row parts +
+// 3 column parts (at(row, col) separates) and added at store time.
+struct K3RowOfs {
+  int rp[3];   // row r of the lane's voxel
+  int cp[3];   // column pair j of the lane's frame
+};
+template <int W>
+__device__ __forceinline__ K3RowOfs k3_row_offsets(int wave, int vl, int fi) {
+  using C = K3Cfg<W>;
+  K3RowOfs ro;
+#pragma unroll
+  for (int r = 0; r < 3; r++) ro.rp[r] = C::at(wave * C::R + 3 * vl + r, 0);
+#pragma unroll
+  for (int j = 0; j < 3; j++) ro.cp[j] = C::at(0, 6 * fi + 2 * j);
+  return ro;
+}
+__device__ __forceinline__ void k3_store_rows(double* buf, const K3RowOfs& ro, const double rows[3][6]) {
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) *reinterpret_cast<v2d*>(buf + ro.rp[r] + ro.cp[j]) = (v2d){rows[r][2 * j], rows[r][2 * j + 1]};
+}
+// mixed precision (BASELINE configs[2]): the rows are rounded to f32 on the way into the tile (same geometry, in floats)
+__device__ __forceinline__ void k3_store_rows_f32(float* buf, const K3RowOfs& ro, const double rows[3][6]) {
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) *reinterpret_cast<v2f*>(buf + ro.rp[r] + ro.cp[j]) = (v2f){(float)rows[r][2 * j], (float)rows[r][2 * j + 1]};
+}
+
+// Phase M: K-steps [k0, k0 + nk) of the tile in `buf` into the accumulators of tile set SET.  Lane l supplies row 4k + l/16,
+// column 16c + l%16 of column tile c -- the SAME register serves as A and B operand.  FULL: nk == KPW at compile time.
+// (The tile indices are template constants: as plain constexpr calls inside the loop they were evaluated at run time.)
+template <int W, int SET, int J>
+__device__ __forceinline__ void k3_mfma_tiles(const double* x, v4d* acc) {
+  using C = K3Cfg<W>;
+  if constexpr (J < C::TPW) {
+    constexpr int t = SET * C::TPW + J, TI = k3_tile_I(C::NT, t), TJ = k3_tile_J(C::NT, t);
+    acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[TI], x[TJ], acc[J], 0, 0, 0);
+    k3_mfma_tiles<W, SET, J + 1>(x, acc);
+  }
+}
+template <int W, int SET, bool FULL>
+__device__ __forceinline__ void k3_mfma_phase(const double* buf, int k0, int nk, int lrow, int lcol, v4d* acc) {
+  using C = K3Cfg<W>;
+  constexpr unsigned NEED = k3_need_rows(C::NT, C::TPW, SET) | k3_need_cols(C::NT, C::TPW, SET);   // column tiles this set touches
+  const double* base = buf + C::at(4 * k0 + lrow, lcol);   // K-step kk: + kk * 4 NCOL, column tile c: + 32 c
+  if (FULL) {
+#pragma unroll
+    for (int kk = 0; kk < C::KPW; kk++) {
+      double x[C::NT];
+#pragma unroll
+      for (int c = 0; c < C::NT; c++) x[c] = ((NEED >> c) & 1) ? base[kk * 4 * C::NCOL + 32 * c] : 0.0;
+      k3_mfma_tiles<W, SET, 0>(x, acc);
+    }
+  } else {
+    for (int kk = 0; kk < nk; kk++) {
+      double x[C::NT];
+#pragma unroll
+      for (int c = 0; c < C::NT; c++) x[c] = ((NEED >> c) & 1) ? base[kk * 4 * C::NCOL + 32 * c] : 0.0;
+      k3_mfma_tiles<W, SET, 0>(x, acc);
+    }
+  }
+}
+// Mixed precision: f32 products on v_mfma_f32_16x16x4_f32 (32 cycles per instruction instead of 64), summed in f32 over the
+// steps of ONE wave (<= 5 steps x 9 K-steps x 4 rows at cfg2/cfg3 sizes), then carried in f64 through the workgroup epilogue,
+// the cross-workgroup reduction and the all-reduce -- "fp32 Jacobian, fp64 Hessian accumulation".  The f32 instruction leaves
+// D(4 (l/16) + r, l % 16) in register r of lane l, the f64 one D((l/16) + 4 r, l % 16); feeding the A operand with the rows
+// permuted by  m -> (m >> 2) + 4 (m & 3)  makes the two maps coincide, so the epilogue and k3_finalize are shared.
+template <int W, int SET, int J>
+__device__ __forceinline__ void k3_mfma_tiles_f32(const float* xa, const float* xb, v4f* af) {
+  using C = K3Cfg<W>;
+  if constexpr (J < C::TPW) {
+    constexpr int t = SET * C::TPW + J, TI = k3_tile_I(C::NT, t), TJ = k3_tile_J(C::NT, t);
+    af[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[TI], xb[TJ], af[J], 0, 0, 0);
+    k3_mfma_tiles_f32<W, SET, J + 1>(xa, xb, af);
+  }
+}
+template <int W, int SET, bool FULL>
+__device__ __forceinline__ void k3_mfma_phase_f32(const float* buf, int k0, int nk, int lrow, int lcol, v4f* af) {
+  using C = K3Cfg<W>;
+  constexpr unsigned NEEDA = k3_need_rows(C::NT, C::TPW, SET), NEEDB = k3_need_cols(C::NT, C::TPW, SET);
+  const int pcol = (lcol >> 2) + 4 * (lcol & 3);
+  const float* baseb = buf + C::at(4 * k0 + lrow, lcol);
+  const float* basea = buf + C::at(4 * k0 + lrow, pcol);
+  if (FULL) {
+#pragma unroll
+    for (int kk = 0; kk < C::KPW; kk++) {
+      float xa[C::NT], xb[C::NT];
+#pragma unroll
+      for (int c = 0; c < C::NT; c++) {
+        xb[c] = ((NEEDB >> c) & 1) ? baseb[kk * 4 * C::NCOL + 32 * c] : 0.0f;
+        xa[c] = ((NEEDA >> c) & 1) ? basea[kk * 4 * C::NCOL + 32 * c] : 0.0f;
+      }
+      k3_mfma_tiles_f32<W, SET, 0>(xa, xb, af);
+    }
+  } else {
+    for (int kk = 0; kk < nk; kk++) {
+      float xa[C::NT], xb[C::NT];
+#pragma unroll
+      for (int c = 0; c < C::NT; c++) {
+        xb[c] = ((NEEDB >> c) & 1) ? baseb[kk * 4 * C::NCOL + 32 * c] : 0.0f;
+        xa[c] = ((NEEDA >> c) & 1) ? basea[kk * 4 * C::NCOL + 32 * c] : 0.0f;
+      }
+      k3_mfma_tiles_f32<W, SET, 0>(xa, xb, af);
+    }
+  }
+}
+
+template <int W, bool DBG = false, bool MIXED = false>
+__global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c_in, LMPending pend, int head,
+                                                              int end, double* __restrict__ partial) {
+  using C = K3Cfg<W>;
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // two tile buffers; reused by the epilogue
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const bool active = lane < C::NACT;
+  const int vl = active ? lane / W : 0;
+  const int fi = active ? lane % W : 0;
+  const int lrow = lane >> 4, lcol = lane & 15;
+  const int set = wave % C::TSPLIT, kq = wave / C::TSPLIT;
+  const int gw = blockIdx.x * C::WAVES + wave;
+  dbg_stamp(DBG, gw, 0);
+
+  // this workgroup's run of batches (absolute: batch b = voxels [b NV, (b+1) NV), so the batch-major copy does not depend on `head`)
+  const int b0 = head / C::NV, b1 = (end - 1) / C::NV;
+  const int nb_all = b1 - b0 + 1, G = gridDim.x;
+  const int q = nb_all / G, rem = nb_all % G;
+  const int g = blockIdx.x;
+  const int cnt = q + (g < rem ? 1 : 0);
+  const int bs = b0 + g * q + (g < rem ? g : rem);
+  const int nsteps = (cnt + C::WAVES - 1) / C::WAVES;
+
+  // The first batch is requested before anything else: it does not depend on the poses, so the LM decision below (a few
+  // dependent global reads) runs in the shadow of these loads.
+  K3Entry e;
+  e.ok = false;
+  const K3Planes pl = k3_planes(fv);
+  if (wave < cnt) k3_load_entry<W>(pl, head, end, bs + wave, active, vl, lane, e);
+
+  // LM mode: take the pending accept/reject decision.  Every wave computes accept / done from the same inputs; both
+  // pose candidates (current, trial) are requested together with the partials so the choice costs one memory latency;
+  // the last workgroup also works out the damping update and persists the control block for the kernels that follow.
+  double R[9], p[3];
+  if (st) {
+    const LMCtl& in = st->ctl[c_in];
+    const int in_done = in.done, in_calc = in.calc_hess, bench = in.bench_mode;
+    const double r1 = in.residual1;
+    // pending: 0 none (linearise at in.x), 1 decide here, 2 / 3 sharded speculative loop: no decision here -- linearise at the
+    // trial poses (2) or at the kernel-argument poses (3, first sweep of a solve / window), skip only when the loop is done
+    const double* __restrict__ xa_src = ((pend.pending == 1 && pend.restart) || pend.pending == 3) ? poses.Rp : (pend.pending == 2 ? in.xt : in.x);
+    double xa[12], xb[12] = {};
+#pragma unroll
+    for (int k = 0; k < 12; k++) xa[k] = xa_src[12 * fi + k];
+    bool use_b = false;
+    if (pend.pending >= 2) {
+      if (in_done) return;
+    } else if (pend.pending) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) xb[k] = in.xt[12 * fi + k];
+      if (in_done) { if (blockIdx.x == gridDim.x - 1) lm_carry(st, c_in, W); return; }
+      const double r2 = lm_residual2(pend);
+      const bool accept = (r1 - r2) > 0;
+      const bool done = !bench && fabs((r1 - r2) / r1) < 1e-6;
+      if (blockIdx.x == gridDim.x - 1) {
+        const LMDecision d = lm_decide(in, r2, pend.restart);
+        lm_persist(st, c_in, d, pend.restart, poses, W);
+      }
+      if (done || !(accept || pend.restart)) return;
+      use_b = accept && !pend.restart;
+    } else {
+      if (in_done || !in_calc) return;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = use_b ? xb[3 * cc + r] : xa[3 * cc + r];
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = use_b ? xb[9 + k] : xa[9 + k];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = poses.Rp[12 * fi + 3 * cc + r];
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = poses.Rp[12 * fi + 9 + k];
+  }
+  dbg_stamp(DBG, gw, 1);
+
+  // both tile buffers start as zeros: padding columns (6W .. NCOL) are never written
+  {
+    constexpr int NZ = MIXED ? C::BUF : 2 * C::BUF;   // doubles
+    for (int k = tid; k < NZ; k += K3_BLOCK) lds[k] = 0.0;
+  }
+  // the decided poses move to LDS behind the tiles (every wave holds the same values; wave 0's lanes 0..W-1 store them)
+  double* pose_lds = lds + 2 * C::BUF;
+  if (wave == 0 && lane < W) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) pose_lds[12 * lane + k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pose_lds[12 * lane + 9 + k] = p[k];
+  }
+  const double* pose = pose_lds + 12 * fi;
+  v4d acc[C::TPW];
+#pragma unroll
+  for (int t = 0; t < C::TPW; t++) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  v4f af[MIXED ? C::TPW : 1];   // mixed precision: the wave's f32 accumulators, widened into acc after the last step
+#pragma unroll
+  for (int t = 0; t < (MIXED ? C::TPW : 1); t++) af[t] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+  double dacc[DACC];
+#pragma unroll
+  for (int k = 0; k < DACC; k++) dacc[k] = 0.0;
+  __syncthreads();
+
+  // step s: phase M of step s-1 (buffer (s-1)&1), phase A of step s (buffer s&1), one barrier
+  for (int s = 0; s <= nsteps; s++) {
+    if (s >= 1) {
+      const int nb_prev = cnt - (s - 1) * C::WAVES;   // batches of step s-1
+      const int bo = ((s - 1) & 1) * C::BUF;
+      if (nb_prev >= C::WAVES) {
+        const int k0 = kq * C::KPW;
+        if (MIXED) {
+          const float* bf = reinterpret_cast<const float*>(lds) + bo;
+          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase_f32<W, 0, true>(bf, k0, C::KPW, lrow, lcol, af);
+          else k3_mfma_phase_f32<W, C::TSPLIT - 1, true>(bf, k0, C::KPW, lrow, lcol, af);
+        } else {
+          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase<W, 0, true>(lds + bo, k0, C::KPW, lrow, lcol, acc);
+          else k3_mfma_phase<W, C::TSPLIT - 1, true>(lds + bo, k0, C::KPW, lrow, lcol, acc);
+        }
+      } else {
+        // ragged last step: only ceil(nb_prev R / 4) K-steps exist; re-split them over the K ranges
+        const int ks = (nb_prev * C::R + 3) >> 2;
+        const int k0 = (kq * ks) / C::KSPLIT, k1 = ((kq + 1) * ks) / C::KSPLIT;
+        if (MIXED) {
+          const float* bf = reinterpret_cast<const float*>(lds) + bo;
+          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase_f32<W, 0, false>(bf, k0, k1 - k0, lrow, lcol, af);
+          else k3_mfma_phase_f32<W, C::TSPLIT - 1, false>(bf, k0, k1 - k0, lrow, lcol, af);
+        } else {
+          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase<W, 0, false>(lds + bo, k0, k1 - k0, lrow, lcol, acc);
+          else k3_mfma_phase<W, C::TSPLIT - 1, false>(lds + bo, k0, k1 - k0, lrow, lcol, acc);
+        }
+      }
+    }
+    if (s == nsteps) break;
+    const int nb = cnt - s * C::WAVES;   // batches of this step (>= 1)
+    const int bo = (s & 1) * C::BUF;
+    if (wave < nb) {
+      double rows[3][6];
+      // voxel-level values for the spare columns, taken before phase A masks / consumes the entry
+      const double spare_s = 1.4142135623730951 * e.sc;
+      const double spare[3] = {spare_s * e.u[0], spare_s * e.u[1], spare_s * e.u[2]};
+      k3_phase_a<!C::SPARE>(e, fi, pose, rows, dacc);
+      if (active) {
+        // the nine store offsets are recomputed from (vl, fi) every step -- a handful of integer operations under the other
+        // wave's fp64 work -- instead of living in registers (or scratch) across phase M
+        int vl_ = vl, fi_ = fi;
+        asm volatile("" : "+v"(vl_), "+v"(fi_));
+        const K3RowOfs ro = k3_row_offsets<W>(wave, vl_, fi_);
+        if (MIXED) k3_store_rows_f32(reinterpret_cast<float*>(lds) + bo, ro, rows);
+        else k3_store_rows(lds + bo, ro, rows);
+        if (C::SPARE && fi_ == W - 1) {   // one lane per voxel: columns 6W .. 6W+2 of the z row
+          const int o = ro.rp[2] + C::at(0, 6 * W);
+          if (MIXED) {
+            float* zf = reinterpret_cast<float*>(lds) + bo + o;
+            *reinterpret_cast<v2f*>(zf) = (v2f){(float)spare[0], (float)spare[1]};
+            zf[2] = (float)spare[2];
+          } else {
+            double* zd = lds + bo + o;
+            *reinterpret_cast<v2d*>(zd) = (v2d){spare[0], spare[1]};
+            zd[2] = spare[2];
+          }
+        }
+      }
+      // next batch of this wave: in flight during the barrier and the whole of phase M
+      if (wave + (s + 1) * C::WAVES < cnt) k3_load_entry<W>(pl, head, end, bs + (s + 1) * C::WAVES + wave, active, vl, lane, e);
+    } else if (wave == nb) {
+      // first idle wave of the ragged step: the rows that round the step up to a whole K-step must read as zeros
+      if (MIXED) { float* z = reinterpret_cast<float*>(lds) + bo + C::at(nb * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0f; }
+      else { double* z = lds + bo + C::at(nb * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0; }
+    }
+    __syncthreads();
+    if (s < 6) dbg_stamp(DBG, gw, 8 + s);
+  }
+  if (MIXED) {
+#pragma unroll
+    for (int t = 0; t < C::TPW; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[t][r] = (double)af[t][r];
+  }
+  dbg_stamp(DBG, gw, 3);
+
+  // Deterministic in-block reduction through LDS (fixed order), one partial per workgroup:  [NTP tiles x 256 | W x DACC]
+  constexpr int PLEN = C::NTP * 256 + W * DACC;
+  constexpr int DS = DACC + 1;  // padded stride: conflict-free column reads
+  double* pout = partial + (size_t)blockIdx.x * PLEN;
+  __syncthreads();  // every wave is done with the tiles
+  // (1) per-frame linear accumulators: every lane parks its 28 values, then W*28 threads sum the 8*NV lanes of a frame
+#pragma unroll
+  for (int k = 0; k < DACC; k++) lds[(wave * 64 + lane) * DS + k] = dacc[k];
+  __syncthreads();
+  for (int el = tid; el < W * DACC; el += K3_BLOCK) {
+    const int i = el / DACC, k = el % DACC;
+    double sum = 0.0;
+    for (int w = 0; w < C::WAVES; w++)
+#pragma unroll
+      for (int v = 0; v < C::NV; v++) sum += lds[(w * 64 + v * W + i) * DS + k];
+    pout[C::NTP * 256 + el] = sum;
+  }
+  __syncthreads();
+  // (2) MFMA accumulator tiles: wave (kq, set) parks its TPW tiles, then tile t of set s is the sum over the K ranges
+#pragma unroll
+  for (int j = 0; j < C::TPW; j++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) lds[(wave * C::TPW + j) * 256 + r * 64 + lane] = acc[j][r];
+  __syncthreads();
+  for (int el = tid; el < C::NTP * 256; el += K3_BLOCK) {
+    const int t = el >> 8, x = el & 255;
+    const int ts = t / C::TPW, j = t % C::TPW;
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < C::KSPLIT; k++) sum += lds[((k * C::TSPLIT + ts) * C::TPW + j) * 256 + x];
+    pout[el] = sum;
+  }
+  dbg_stamp(DBG, gw, 6);
+}

@@ -6,7 +6,7 @@
 namespace vxk {
 
 constexpr int MAXW = 10;          // VXBA_MAX_WIN: 6W <= 64 accumulator columns
-constexpr int K3_BLOCK = 256;     // 4 waves per workgroup
+constexpr int K3_BLOCK = 512;     // 8 waves per workgroup, one workgroup per CU: two waves per SIMD
 constexpr int DACC = 28;          // per-frame linear accumulators: g(6) Drr(6) Drt(9) Dtt(6) residual(1)
 
 // Poses travel as a kernel argument (W*96 B <= 960 B): uniform scalar loads in K2, one vector load per lane in K3.
@@ -80,7 +80,7 @@ struct LMPending {
 
 inline int k3_num_tiles(int W) { return (6 * W + 15) / 16; }
 // voxels per wave-batch of the Hessian sweep (must match K3Cfg<W>::NV)
-inline int k3_nv(int W) { const int cap = k3_num_tiles(W) <= 2 ? 12 : 8; return (64 / W) < cap ? (64 / W) : cap; }
+inline int k3_nv(int W) { const int nt = k3_num_tiles(W); const int cap = nt <= 2 ? 12 : (nt == 3 ? 8 : 6); return (64 / W) < cap ? (64 / W) : cap; }
 inline size_t k3_clb_len(int W, int VS) { return (size_t)((VS + k3_nv(W) - 1) / k3_nv(W)) * 640; }
 inline int k3_num_tile_pairs(int W) { int nt = k3_num_tiles(W); return nt * (nt + 1) / 2; }
 // doubles per workgroup partial: MFMA accumulator tiles (register layout) + per-frame linear accumulators
@@ -102,6 +102,8 @@ void launch_seed_aux(const FactorView& fv, int head, int end, hipStream_t s);
 
 // K3: Hessian/gradient sweep over voxels [head,end) into per-workgroup partials; returns #workgroups.
 int k3_grid_blocks(int device_cus);
+// workgroups for a sweep over nbatches wave-batches: one 8-wave workgroup per CU, never more than there are steps of 8 batches
+inline int k3_blocks_for(int nbatches, int device_cus) { const int b = (nbatches + 7) / 8; return b < 1 ? 1 : (b < device_cus ? b : device_cus); }
 // cache_src (nullable): read the (lambda, U, merged, aux) cache planes from this base instead of fv's live cache --
 // used to start a new window from the snapshot without copying it back first.
 // ev_start / ev_stop (nullable): events tied to this dispatch's own begin / end timestamps (hipExtLaunchKernel), i.e.

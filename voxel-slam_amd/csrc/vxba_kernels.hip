@@ -15,6 +15,7 @@
 
 #include <hip/hip_ext.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -316,359 +317,10 @@ __global__ void seed_aux_kernel(FactorView fv, int head, int end) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3 -- Hessian / gradient sweep.
-//
-// Work mapping: one lane per (voxel, frame) entry, NV voxels x W frames per wave-batch, the lane's frame is
-// fixed for the whole kernel (pose lives in registers; the 27 linear accumulators g/D of that frame stay in
-// registers across batches).  Each entry emits three 6-wide row pieces of the per-voxel 3 x 6W matrix B_a
-// (vxm::k3_entry) into a wave-private LDS tile [rows][6W]; the wave then reads the tile back in
-// v_mfma_f64_16x16x4_f64 operand order (lane l: row 4kk + l/16, column 16c + l%16 -- the SAME register serves
-// as A and B operand) and accumulates  S += B^T B  over the upper-triangular 16x16 tile pairs of the 6W x 6W
-// window Hessian.  K (the MFMA reduction index) runs over the stacked rows of all voxels, so no per-voxel
-// padding is needed.  H = -S + blockdiag(D) is assembled by k3_finalize_kernel.
-// No block barrier in the main loop: LDS tiles are wave-private and DS ops of one wave execute in order.
+// K3 -- Hessian / gradient sweep: vxba_k3.hpp (work mapping, tile layout and the history of the design are described there).
+// H = -S + blockdiag(D) is assembled by k3_finalize_kernel below.
 // ------------------------------------------------------------------------------------------------
-template <int W>
-struct K3Cfg {
-  static constexpr int NT = (6 * W + 15) / 16;        // 16-wide column tiles
-  static constexpr int NTP = NT * (NT + 1) / 2;       // upper-triangular tile pairs = MFMA accumulators
-  static constexpr int NVCAP = (NT <= 2) ? 12 : 8;
-  static constexpr int NV = (64 / W) < NVCAP ? (64 / W) : NVCAP;  // voxels per wave-batch
-  static constexpr int NACT = NV * W;                 // active lanes
-  static constexpr int KSTEPS = (3 * NV + 3) / 4;     // MFMA K-steps per batch (K = 4 rows each)
-  static constexpr int ROWS = 4 * KSTEPS;
-  static constexpr int NCOL = 16 * NT;
-  static constexpr int RS = NCOL + ((NT & 1) ? 32 : 16);  // row stride == 16 (mod 32) doubles: conflict-free ds_read_b64
-  static constexpr int WAVE_LDS = (ROWS + 1) * RS;    // doubles; the extra row absorbs the stores of idle lanes
-};
-
-// Register image of one (voxel, frame) entry plus the voxel's cached plane parameters.
-struct K3Entry {
-  double c[10];      // body-frame cluster
-  double u[9];       // eigenvectors, plane 3*col+row
-  double s1, s2;     // gap scales
-  double invN, sc;   // 1 / merged count, sqrt(coe)
-  double mv[3];      // merged first moment
-  double coe, lam0;
-  bool ok;           // lane holds a real (voxel, frame) entry of [head,end)
-};
-
-typedef double v2d __attribute__((ext_vector_type(2)));
-
-template <int W>
-__device__ __forceinline__ void k3_load_entry(const FactorView& fv, int head, int end, int b1, int b, bool active, int vl, int lane, K3Entry& e) {
-  using C = K3Cfg<W>;
-  const size_t VS = (size_t)fv.VS;
-  const int bc = b <= b1 ? b : b1;  // branch-free: batches past the end re-read the last one and are masked to zero
-  const int a = bc * C::NV + vl;
-  e.ok = active && b <= b1 && a >= head && a < end;
-  // clusters: five contiguous 1 KB rows per wave (batch-major copy)
-  const v2d* cp = reinterpret_cast<const v2d*>(fv.clb) + (size_t)bc * 5 * 64 + lane;
-#pragma unroll
-  for (int j = 0; j < 5; j++) {
-    const v2d t = cp[j * 64];
-    e.c[2 * j] = t[0];
-    e.c[2 * j + 1] = t[1];
-  }
-  // plane parameters of my voxel: each row of six voxels sits in one cache line
-  const int ac = e.ok ? a : head;
-#pragma unroll
-  for (int k = 0; k < 9; k++) e.u[k] = fv.eigvec[(size_t)k * VS + ac];
-  e.s1 = fv.aux[ac];
-  e.s2 = fv.aux[VS + ac];
-#pragma unroll
-  for (int k = 0; k < 3; k++) e.mv[k] = fv.merged[(size_t)(6 + k) * VS + ac];
-  e.invN = fv.aux[2 * VS + ac];
-  e.sc = fv.aux[3 * VS + ac];
-  e.coe = fv.coe[ac];
-  e.lam0 = fv.eigval[ac];
-}
-
-// Phase A of one entry: rows of B_a (3 x 6) and the per-frame linear accumulators, branch-free.
-__device__ __forceinline__ void k3_phase_a(K3Entry& e, int fi, const double R[9], const double p[3], double rows[3][6], double dacc[DACC]) {
-  const bool obs = e.ok && e.c[9] != 0.0;   // N == 0: frame did not observe the voxel (voxel_map.hpp:178)
-#pragma unroll
-  for (int k = 0; k < 10; k++) e.c[k] = obs ? e.c[k] : 0.0;
-  vxm::VoxelCache vc;
-#pragma unroll
-  for (int k = 0; k < 3; k++) { vc.u0[k] = e.u[k]; vc.u1[k] = e.u[3 + k]; vc.u2[k] = e.u[6 + k]; }
-  vc.s1 = e.s1;
-  vc.s2 = e.s2;
-  vc.invN = e.invN;
-#pragma unroll
-  for (int k = 0; k < 3; k++) vc.vbar[k] = e.mv[k] * vc.invN;
-  vc.coe = obs ? e.coe : 0.0;
-  vc.sc = obs ? e.sc : 0.0;
-  dacc[27] += (e.ok && fi == 0) ? e.coe * e.lam0 : 0.0;  // residual += coe * lambda_0, once per voxel (voxel_map.hpp:234)
-  vxm::k3_entry(e.c, e.c + 6, e.c[9], R, p, vc, rows, dacc);
-}
-
-template <int W>
-__device__ __forceinline__ void k3_store_rows(double* ldsb, bool active, int vl, int fi, const double rows[3][6]) {
-  using C = K3Cfg<W>;
-  // branch-free: idle lanes (>= NV*W) store into the dump row behind the tile
-#pragma unroll
-  for (int r = 0; r < 3; r++) {
-    double* dst = ldsb + (active ? (3 * vl + r) * C::RS + 6 * fi : C::ROWS * C::RS);
-#pragma unroll
-    for (int k = 0; k < 6; k++) dst[k] = rows[r][k];
-  }
-}
-// mixed precision (BASELINE configs[2]): the rows are rounded to f32 on the way into the tile (same tile geometry, in floats)
-template <int W>
-__device__ __forceinline__ void k3_store_rows_f32(float* ldsb, bool active, int vl, int fi, const double rows[3][6]) {
-  using C = K3Cfg<W>;
-#pragma unroll
-  for (int r = 0; r < 3; r++) {
-    float* dst = ldsb + (active ? (3 * vl + r) * C::RS + 6 * fi : C::ROWS * C::RS);
-#pragma unroll
-    for (int k = 0; k < 6; k++) dst[k] = (float)rows[r][k];
-  }
-}
-
-template <int W>
-__device__ __forceinline__ void k3_mfma_tile(const double* ldsb, int lrow, int lcol, v4d* acc) {
-  using C = K3Cfg<W>;
-#pragma unroll
-  for (int kk = 0; kk < C::KSTEPS; kk++) {
-    double x[C::NT];
-#pragma unroll
-    for (int c = 0; c < C::NT; c++) x[c] = ldsb[(4 * kk + lrow) * C::RS + 16 * c + lcol];
-    int t = 0;
-#pragma unroll
-    for (int I = 0; I < C::NT; I++)
-#pragma unroll
-      for (int J = I; J < C::NT; J++) {
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[I], x[J], acc[t], 0, 0, 0);
-        t++;
-      }
-  }
-}
-
-// Software-pipelined main loop (one wave per SIMD, up to 512 VGPRs): one loop body holds
-//   (1) the global loads of batch b+1 (consumed one iteration later: measured wait at the top of the loop is
-//       ~340 cycles of a ~6200-cycle iteration, i.e. HBM latency is hidden),
-//   (2) the f64 MFMAs of batch b-1, fed from LDS buffer (b-1)&1, and
-//   (3) the phase-A VALU work of batch b, written to LDS buffer b&1.
-// Measured on MI355X (scripts/ubench/mfma_f64_sweep.hip, mfma_valu_overlap.hip): v_mfma_f64_16x16x4_f64 issues every 64
-// cycles from a single wave (70-74 TFLOP/s chip-wide, independent of occupancy), f64 VALU FMA every ~4.3 cycles, and inside a
-// SIMD the two are strictly additive (1 MFMA + n FMA = 64 + 4.5 n cycles): they share the fp64 datapath, so pinning one
-// MFMA between every ~9 VALU ops (tried with sched_barrier) cannot hide phase A and only made this kernel slower.
-// One loop iteration is therefore ~3800 cycles of MFMA tile (50 x 64 + LDS operand reads) + ~1500 of phase A + ~800 of
-// stores / address math / waits = ~6100 cycles (s_memtime stamps, scripts/dbg_timeline.py).
-// Mixed precision: f32 products on v_mfma_f32_16x16x4_f32 (32 cycles per instruction instead of 64), summed in f32 over the
-// <= 9 batches (<= 72 voxels) of ONE wave, then carried in f64 through the workgroup epilogue, the cross-workgroup
-// reduction and the all-reduce -- "fp32 Jacobian, fp64 Hessian accumulation".  (Flushing to f64 after every batch was
-// measured first: the 80 extra f64 accumulators no longer live in the MFMA's own AGPRs and the copies ate the whole gain.)
-// The f32 instruction leaves D(4 (l/16) + r, l % 16) in register r of lane l, the f64 one D((l/16) + 4 r, l % 16); feeding
-// the A operand with the rows permuted by  m -> (m >> 2) + 4 (m & 3)  makes the two maps coincide, so the epilogue and the
-// cross-workgroup reduction are shared with the f64 path.
-typedef float v4f __attribute__((ext_vector_type(4)));
-template <int W>
-__device__ __forceinline__ void k3_mfma_tile_f32(const float* ldsb, int lrow, int lcol, v4f* af) {
-  using C = K3Cfg<W>;
-  const int pcol = (lcol >> 2) + 4 * (lcol & 3);
-#pragma unroll
-  for (int kk = 0; kk < C::KSTEPS; kk++) {
-    float xa[C::NT], xb[C::NT];
-#pragma unroll
-    for (int c = 0; c < C::NT; c++) {
-      xb[c] = ldsb[(4 * kk + lrow) * C::RS + 16 * c + lcol];
-      xa[c] = ldsb[(4 * kk + lrow) * C::RS + 16 * c + pcol];
-    }
-    int t = 0;
-#pragma unroll
-    for (int I = 0; I < C::NT; I++)
-#pragma unroll
-      for (int J = I; J < C::NT; J++) {
-        af[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[I], xb[J], af[t], 0, 0, 0);
-        t++;
-      }
-  }
-}
-
-// Tried and rejected: stacking the rows of TWO batches in one tile so that the K padding (18 -> 20 rows at W = 10) is paid
-// once per pair (36 rows = 9 K-steps instead of 2 x 5, 10 % fewer MFMAs).  Correct, but 37.5 us instead of 34.8: with both
-// entry register sets, the rows and the 28 linear accumulators live across the longer MFMA phase the allocator shuttles
-// ~650 values through AGPRs per pair, which costs more than the 10 MFMAs save.
-// Also tried and rejected: the contraction on the VALU instead (one lane per 6x6 frame-pair block, exact upper
-// triangle, 36 FMAs per row).  It needs 12 LDS doubles per 36 FMAs -- 216 doubles per lane and batch against the
-// MFMA form's 20 -- and ran LDS-bandwidth-bound at 45.8 us vs 32-33 us: the matrix core's operand reuse wins.
-template <int W, bool DBG = false, bool MIXED = false>
-__global__ __launch_bounds__(K3_BLOCK, 1) void k3_hessian_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c_in,
-                                                                 LMPending pend, int head, int end, double* __restrict__ partial) {
-  using C = K3Cfg<W>;
-  extern __shared__ __attribute__((aligned(16))) double lds[];  // [4 waves][2 buffers][WAVE_LDS]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  double* ldsw = lds + (size_t)wave * 2 * C::WAVE_LDS;
-
-  const bool active = lane < C::NACT;
-  const int vl = active ? lane / W : 0;
-  const int fi = active ? lane % W : 0;
-  v4d acc[C::NTP];
-#pragma unroll
-  for (int t = 0; t < C::NTP; t++) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-  v4f af[MIXED ? C::NTP : 1];   // mixed precision: the wave's f32 accumulators, widened into acc after the last batch
-#pragma unroll
-  for (int t = 0; t < (MIXED ? C::NTP : 1); t++) af[t] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-  double dacc[DACC];
-#pragma unroll
-  for (int k = 0; k < DACC; k++) dacc[k] = 0.0;
-
-  // batches are absolute (batch b = voxels [b NV, (b+1) NV)) so the batch-major copy does not depend on `head`
-  const int b0 = head / C::NV, b1 = (end - 1) / C::NV;
-  const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-  const int lrow = lane >> 4, lcol = lane & 15;
-  dbg_stamp(DBG, gw, 0);
-
-  // The first two batches are requested before anything else: they do not depend on the poses, so the LM decision
-  // below (a few dependent global reads + an LDS tree) runs in the shadow of these loads.
-  const bool has_work = b0 + gw <= b1;
-  K3Entry e0, e1;
-  if (has_work) {
-    k3_load_entry<W>(fv, head, end, b1, b0 + gw, active, vl, lane, e0);
-    k3_load_entry<W>(fv, head, end, b1, b0 + gw + nw, active, vl, lane, e1);
-  }
-  // LM mode: take the pending accept/reject decision.  Every wave computes accept / done from the same inputs; both
-  // pose candidates (current, trial) are requested together with the partials so the choice costs one memory latency;
-  // the last workgroup also works out the damping update and persists the control block for the kernels that follow.
-  double R[9], p[3];
-  if (st) {
-    const LMCtl& in = st->ctl[c_in];
-    const int in_done = in.done, in_calc = in.calc_hess, bench = in.bench_mode;
-    const double r1 = in.residual1;
-    // pending: 0 none (linearise at in.x), 1 decide here, 2 / 3 sharded speculative loop: no decision here -- linearise at the
-    // trial poses (2) or at the kernel-argument poses (3, first sweep of a solve / window), skip only when the loop is done
-    const double* __restrict__ xa_src = ((pend.pending == 1 && pend.restart) || pend.pending == 3) ? poses.Rp : (pend.pending == 2 ? in.xt : in.x);
-    double xa[12], xb[12] = {};
-#pragma unroll
-    for (int k = 0; k < 12; k++) xa[k] = xa_src[12 * fi + k];
-    bool use_b = false;
-    if (pend.pending >= 2) {
-      if (in_done) return;
-    } else if (pend.pending) {
-#pragma unroll
-      for (int k = 0; k < 12; k++) xb[k] = in.xt[12 * fi + k];
-      if (in_done) { if (blockIdx.x == gridDim.x - 1) lm_carry(st, c_in, W); return; }
-      const double r2 = lm_residual2(pend);
-      const bool accept = (r1 - r2) > 0;
-      const bool done = !bench && fabs((r1 - r2) / r1) < 1e-6;
-      if (blockIdx.x == gridDim.x - 1) {
-        const LMDecision d = lm_decide(in, r2, pend.restart);
-        lm_persist(st, c_in, d, pend.restart, poses, W);
-      }
-      if (done || !(accept || pend.restart)) return;
-      use_b = accept && !pend.restart;
-    } else {
-      if (in_done || !in_calc) return;
-    }
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = use_b ? xb[3 * cc + r] : xa[3 * cc + r];
-#pragma unroll
-    for (int k = 0; k < 3; k++) p[k] = use_b ? xb[9 + k] : xa[9 + k];
-  } else {
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = poses.Rp[12 * fi + 3 * cc + r];
-#pragma unroll
-    for (int k = 0; k < 3; k++) p[k] = poses.Rp[12 * fi + 9 + k];
-  }
-  // wave-private tiles: pad rows / pad columns stay zero forever
-  for (int k = lane; k < 2 * C::WAVE_LDS; k += 64) ldsw[k] = 0.0;
-
-  if (has_work) {
-    // two entry register sets in ping-pong (loop unrolled by two: no register copies, LDS buffer index is static)
-    double rows[3][6];
-    double* lds0 = ldsw;
-    double* lds1 = ldsw + C::WAVE_LDS;
-    if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 1); }
-    k3_phase_a(e0, fi, R, p, rows, dacc);
-    if (MIXED) k3_store_rows_f32<W>((float*)lds0, active, vl, fi, rows); else k3_store_rows<W>(lds0, active, vl, fi, rows);
-    __builtin_amdgcn_wave_barrier();
-    if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 2); }
-    int pending = 0;   // LDS buffer holding the rows whose MFMAs are still to run
-    int it_dbg = 0;
-    int b = b0 + gw + nw;
-    while (b <= b1) {
-      if (DBG && it_dbg < 10) { dbg_stamp(true, gw, 8 + 2 * it_dbg); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 9 + 2 * it_dbg); it_dbg++; }
-      // batch b sits in e1: prefetch b + nw into e0, MFMAs of the previous batch (lds0), phase A of b -> lds1
-      k3_load_entry<W>(fv, head, end, b1, b + nw, active, vl, lane, e0);
-      if (DBG && it_dbg == 3) { __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 28); __builtin_amdgcn_sched_barrier(0); }
-      if (MIXED) k3_mfma_tile_f32<W>((const float*)lds0, lrow, lcol, af); else k3_mfma_tile<W>(lds0, lrow, lcol, acc);
-      if (DBG && it_dbg == 3) { __builtin_amdgcn_sched_barrier(0); asm volatile("" :: "v"(acc[0][0]), "v"(acc[9][3])); asm volatile("s_nop 0" ::: "memory"); dbg_stamp(true, gw, 29); __builtin_amdgcn_sched_barrier(0); }
-      k3_phase_a(e1, fi, R, p, rows, dacc);
-      if (DBG && it_dbg == 3) { __builtin_amdgcn_sched_barrier(0); asm volatile("" :: "v"(rows[0][0]), "v"(rows[2][5]), "v"(dacc[26])); dbg_stamp(true, gw, 30); __builtin_amdgcn_sched_barrier(0); }
-      if (MIXED) k3_store_rows_f32<W>((float*)lds1, active, vl, fi, rows); else k3_store_rows<W>(lds1, active, vl, fi, rows);
-      __builtin_amdgcn_wave_barrier();
-      if (DBG && it_dbg == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 31); }
-      b += nw;
-      pending = 1;
-      if (b > b1) break;
-      if (DBG && it_dbg < 10) { dbg_stamp(true, gw, 8 + 2 * it_dbg); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 9 + 2 * it_dbg); it_dbg++; }
-      // batch b sits in e0: prefetch into e1, MFMAs of lds1, phase A -> lds0
-      k3_load_entry<W>(fv, head, end, b1, b + nw, active, vl, lane, e1);
-      if (MIXED) k3_mfma_tile_f32<W>((const float*)lds1, lrow, lcol, af); else k3_mfma_tile<W>(lds1, lrow, lcol, acc);
-      k3_phase_a(e0, fi, R, p, rows, dacc);
-      if (MIXED) k3_store_rows_f32<W>((float*)lds0, active, vl, fi, rows); else k3_store_rows<W>(lds0, active, vl, fi, rows);
-      __builtin_amdgcn_wave_barrier();
-      b += nw;
-      pending = 0;
-    }
-    double* ldsl = pending ? lds1 : lds0;
-    if (MIXED) {
-      k3_mfma_tile_f32<W>((const float*)ldsl, lrow, lcol, af);
-#pragma unroll
-      for (int t = 0; t < C::NTP; t++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) acc[t][r] = (double)af[t][r];
-    } else {
-      k3_mfma_tile<W>(ldsl, lrow, lcol, acc);
-    }
-    if (DBG) { asm volatile("" :: "v"(acc[0][0])); dbg_stamp(true, gw, 3); }
-  }
-
-  // Deterministic in-block reduction through LDS (fixed order), one partial per workgroup.
-  constexpr int PLEN = C::NTP * 256 + W * DACC;
-  constexpr int DS = DACC + 1;  // padded stride: conflict-free column reads
-  double* pout = partial + (size_t)blockIdx.x * PLEN;
-  if (DBG) { asm volatile("" :: "v"(dacc[0])); dbg_stamp(true, gw, 4); }
-  __syncthreads();  // every wave is done with its main-loop tiles
-  dbg_stamp(DBG, gw, 5);
-  // (1) per-frame linear accumulators: every lane parks its 28 values, then W*28 threads sum the 4*NV lanes of a frame
-#pragma unroll
-  for (int k = 0; k < DACC; k++) lds[(wave * 64 + lane) * DS + k] = dacc[k];
-  __syncthreads();
-  for (int e = tid; e < W * DACC; e += K3_BLOCK) {
-    const int i = e / DACC, k = e % DACC;
-    double sum = 0.0;
-    for (int w = 0; w < 4; w++)
-#pragma unroll
-      for (int v = 0; v < C::NV; v++) sum += lds[(w * 64 + v * W + i) * DS + k];
-    pout[C::NTP * 256 + e] = sum;
-  }
-  __syncthreads();
-  // (2) MFMA accumulator tiles, TPR tiles per round
-  constexpr int TPR = C::NTP < 5 ? C::NTP : 5;
-#pragma unroll
-  for (int t0 = 0; t0 < C::NTP; t0 += TPR) {
-#pragma unroll
-    for (int tt = 0; tt < TPR; tt++)
-      if (t0 + tt < C::NTP) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) lds[(wave * TPR + tt) * 256 + j * 64 + lane] = acc[t0 + tt][j];
-      }
-    __syncthreads();
-#pragma unroll
-    for (int tt = 0; tt < TPR; tt++)
-      if (t0 + tt < C::NTP)
-        pout[(t0 + tt) * 256 + tid] = ((lds[tt * 256 + tid] + lds[(TPR + tt) * 256 + tid]) + lds[(2 * TPR + tt) * 256 + tid]) + lds[(3 * TPR + tt) * 256 + tid];
-    __syncthreads();
-  }
-  if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 6); }
-}
+#include "vxba_k3.hpp"
 
 // Cross-workgroup reduction + assembly.  One lane per PARTIAL element (consecutive lanes -> consecutive
 // addresses inside every workgroup partial: coalesced), 64 elements x 16 partial-slices per workgroup, fixed
@@ -711,11 +363,18 @@ __global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restr
     if (r >= n || c >= n || r > c) { r = -1; c = -1; }   // padding columns; lower half of a diagonal tile is a duplicate
     else if (r / 6 == c / 6) {
       const int i = r / 6, a = r % 6, b = c % 6;         // a <= b
-      int d;
-      if (b < 3) d = 6 + sym6_index(a, b);
-      else if (a < 3) d = 12 + 3 * a + (b - 3);
-      else d = 21 + sym6_index(a - 3, b - 3);
-      off1 = NTILE + i * DACC + d;
+      if (C::SPARE && b >= 3) {
+        // Drt / Dtt were accumulated by the matrix cores: S[r][6W + (b - 3)] (vxba_k3.hpp, K3Cfg::SPARE)
+        const int c2 = n + (b - 3), I2 = r >> 4, J2 = c2 >> 4;
+        const int t2 = I2 * C::NT - (I2 * (I2 - 1)) / 2 + (J2 - I2), row2 = r - 16 * I2, col2 = c2 - 16 * J2;
+        off1 = t2 * 256 + (row2 >> 2) * 64 + ((row2 & 3) << 4) + col2;
+      } else {
+        int d;
+        if (b < 3) d = 6 + sym6_index(a, b);
+        else if (a < 3) d = 12 + 3 * a + (b - 3);
+        else d = 21 + sym6_index(a - 3, b - 3);
+        off1 = NTILE + i * DACC + d;
+      }
     }
   } else if (e < PLEN) {
     const int q = e - NTILE, i = q / DACC, d = q % DACC;
@@ -1280,7 +939,17 @@ void launch_seed_aux(const FactorView& fv, int head, int end, hipStream_t s) {
   hipLaunchKernelGGL(seed_aux_kernel, dim3((end - head + 255) / 256), dim3(256), 0, s, fv, head, end);
 }
 
-int k3_grid_blocks(int device_cus) { return device_cus; }  // one 4-wave workgroup per CU = one wave per SIMD (the kernel needs > 256 VGPRs)
+int k3_grid_blocks(int device_cus) { return device_cus; }  // one 8-wave workgroup per CU = two waves per SIMD
+
+// dynamic LDS of the Hessian sweep: two tile buffers + the poses, or the epilogue's parking areas, whichever is larger
+template <int W>
+constexpr size_t k3_lds_bytes() {
+  using C = K3Cfg<W>;
+  constexpr size_t main_d = (size_t)2 * C::BUF + 12 * W;
+  constexpr size_t epi1 = (size_t)K3_BLOCK * (DACC + 1), epi2 = (size_t)C::WAVES * C::TPW * 256;
+  constexpr size_t m = main_d > epi1 ? (main_d > epi2 ? main_d : epi2) : (epi1 > epi2 ? epi1 : epi2);
+  return m * sizeof(double);
+}
 
 int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, LMState* st, int c_in, const LMPending& pend, const double* cache_src,
                       int head, int end, double* d_partial, int nblocks, int mixed, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -1292,29 +961,36 @@ int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, LMState* st
     fv.merged = fv.eigvec + 9 * VS;
     fv.aux = fv.merged + 10 * VS;
   }
+  static int dbg = -1;   // development knob: VXBA_DBG=1 runs the s_memtime-instrumented instantiation
+  if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
   VXK_DISPATCH_W(fv.W, {
-    constexpr size_t lds_main = (size_t)4 * 2 * K3Cfg<WW>::WAVE_LDS, lds_epi = (size_t)4 * 64 * (DACC + 1), lds_epi2 = (size_t)4 * 5 * 256;
-    constexpr size_t lds_bytes = (lds_main > lds_epi ? (lds_main > lds_epi2 ? lds_main : lds_epi2) : (lds_epi > lds_epi2 ? lds_epi : lds_epi2)) * sizeof(double);
-    static bool attr_set = false;   // > 64 KB of dynamic LDS must be opted into once per kernel
-    static int dbg = -1;            // development knob: VXBA_DBG=1 runs the s_memtime-instrumented instantiation
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)k3_hessian_kernel<WW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      (void)hipFuncSetAttribute((const void*)k3_hessian_kernel<WW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      (void)hipFuncSetAttribute((const void*)k3_hessian_kernel<WW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      const char* ev = getenv("VXBA_DBG");
-      dbg = (ev && ev[0] == '1') ? 1 : 0;
-      attr_set = true;
+    constexpr size_t lds_bytes = k3_lds_bytes<WW>();
+    static_assert(lds_bytes <= 160 * 1024, "K3 tile buffers exceed the CU's LDS");
+    // > 64 KB of dynamic LDS must be opted into per kernel AND per device: one bit per (device, variant), set atomically
+    // (a process-wide "done once" flag missed a second device and raced between factors on different threads)
+    static std::atomic<unsigned long long> opted{0ull};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int variant = mixed ? 2 : (dbg ? 1 : 0);
+    const unsigned long long bit = 1ull << ((3 * dev + variant) & 63);
+    if (!(opted.load(std::memory_order_relaxed) & bit) || dev > 20) {
+      const void* fn = mixed ? (const void*)k3_hessian_kernel<WW, false, true> : (dbg ? (const void*)k3_hessian_kernel<WW, true> : (const void*)k3_hessian_kernel<WW, false>);
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      opted.fetch_or(bit, std::memory_order_relaxed);
     }
     if (mixed) {
       if (ev_start)
         hipExtLaunchKernelGGL((k3_hessian_kernel<WW, false, true>), dim3(nblocks), dim3(K3_BLOCK), (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, fv, poses, st, c_in,
                               pend, head, end, d_partial);
       else k3_hessian_kernel<WW, false, true><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, st, c_in, pend, head, end, d_partial);
-    } else if (dbg) k3_hessian_kernel<WW, true><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, st, c_in, pend, head, end, d_partial);
-    else if (ev_start)
-      hipExtLaunchKernelGGL((k3_hessian_kernel<WW, false>), dim3(nblocks), dim3(K3_BLOCK), (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, fv, poses, st, c_in, pend, head,
-                            end, d_partial);
-    else k3_hessian_kernel<WW, false><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, st, c_in, pend, head, end, d_partial);
+    } else if (dbg) {
+      k3_hessian_kernel<WW, true><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, st, c_in, pend, head, end, d_partial);
+    } else {
+      if (ev_start)
+        hipExtLaunchKernelGGL((k3_hessian_kernel<WW, false>), dim3(nblocks), dim3(K3_BLOCK), (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, fv, poses, st, c_in, pend, head,
+                              end, d_partial);
+      else k3_hessian_kernel<WW, false><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, st, c_in, pend, head, end, d_partial);
+    }
   });
   return nblocks;
 }

@@ -220,8 +220,18 @@ VX_HD double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a
 // so that  H = -(sum_a rows^T rows) + blockdiag_i(D_i)   reproduces voxel_map.hpp:176-232.
 // A_i = (1/N)[ (R P + t v^T) hat(r) - R c1 | c2 u^T + (c2.u) I ],  r = R^T u, t = p - vbar,
 // c1 = hat(P r) + hat(v)(u.t), c2 = R v + n t, w = v x r.
-// Row vectors are evaluated without forming A_i:  y^T A_L N = m x r - q x Pr - (u.t) q x v  with
-// q = R^T y, m = P q + (y.t) v;   y^T A_R N = (y.c2) u^T + (c2.u) y^T.
+// Row vectors are evaluated without forming A_i.  With  z = P r + (u.t) v :
+//   y^T A_L N = m x r - q x z        (q = R^T y, m = P q + (y.t) v)      -- P r and v only ever enter through z,
+//   y^T A_R N = (y.c2) u^T + (c2.u) y^T,
+//   g_rot N/2 = z x r                (= P r x r + (u.t) w).
+// Block-diagonal correction (symmetric):
+//   Drr N/2 = sym(hat(z) hat(r)) - hat(r) P hat(r),    sym(hat(a) hat(b)) = (b a^T + a b^T)/2 - (a.b) I   (linear in a),
+//   and for symmetric P   -hat(r) P hat(r) = (r.r)(tr P I - P) - tr P r r^T + P r r^T + r (P r)^T - (r.P r) I,
+//   so with h = z + 2 P r - tr P r and c0 = (r.r) tr P - z.r - r.P r:
+//   Drr N/2 = (r h^T + h r^T)/2 - (r.r) P + c0 I        -- 31 operations instead of the 87 of forming hat(r) P hat(r);
+//   Drt = (2/N) w u^T ;  Dtt = (2 n / N) u u^T.
+// (Round 1 formed P hat(r) and hat(r) (P hat(r)) explicitly; the closed form is the same matrix -- checked against the
+// oracle's acc_evaluate2 in tests/test_device_math_on_host.py -- at 73 % of the fp64 operations, which is what bounds K3.)
 // ---------------------------------------------------------------------------------------------
 struct VoxelCache {
   double u0[3], u1[3], u2[3];
@@ -232,6 +242,28 @@ struct VoxelCache {
   double sc;         // sqrt(coe)
 };
 
+// one G row: y in {u1, u2}, scale sk
+VX_HD void k3_g_row(const double P[6], const double v[3], const double R[9], const double t[3], const double r[3], const double z[3], const double c2[3],
+                    double c2u, const double u[3], const double y[3], double sk, double row[6]) {
+  double q[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) q[j] = R[j] * y[0] + R[3 + j] * y[1] + R[6 + j] * y[2];
+  const double yt = dot3(y, t);
+  const double m[3] = {P[0] * q[0] + P[1] * q[1] + P[2] * q[2] + yt * v[0], P[1] * q[0] + P[3] * q[1] + P[4] * q[2] + yt * v[1],
+                       P[2] * q[0] + P[4] * q[1] + P[5] * q[2] + yt * v[2]};
+  // m x r - q x z
+  row[0] = sk * ((m[1] * r[2] - m[2] * r[1]) - (q[1] * z[2] - q[2] * z[1]));
+  row[1] = sk * ((m[2] * r[0] - m[0] * r[2]) - (q[2] * z[0] - q[0] * z[2]));
+  row[2] = sk * ((m[0] * r[1] - m[1] * r[0]) - (q[0] * z[1] - q[1] * z[0]));
+  const double yc2 = sk * dot3(y, c2), sc2u = sk * c2u;
+#pragma unroll
+  for (int j = 0; j < 3; j++) row[3 + j] = yc2 * u[j] + sc2u * y[j];
+}
+
+// RT = false: the caller obtains Drt and Dtt elsewhere (K3's narrow-window kernel reads them off spare columns of its
+// MFMA tile: with sqrt2 sqrt(coe) u in three padding columns of the z row, S[6i+j][pad+k] = sum_a (2 coe/N) w_j u_k = Drt
+// and S[6i+3+j][pad+k] = sum_a (2 coe n/N) u_j u_k = Dtt) and acc[12..26] stay untouched.
+template <bool RT = true>
 VX_HD void k3_entry(const double P[6], const double v[3], double n, const double R[9], const double p[3],
                     const VoxelCache& vc, double rows[3][6], double acc[27]) {
   const double* u = vc.u0;
@@ -244,66 +276,32 @@ VX_HD void k3_entry(const double P[6], const double v[3], double n, const double
 #pragma unroll
   for (int j = 0; j < 3; j++) t[j] = p[j] - vc.vbar[j];
   const double ut = dot3(u, t);
-  double Pr[3] = {P[0] * r[0] + P[1] * r[1] + P[2] * r[2], P[1] * r[0] + P[3] * r[1] + P[4] * r[2],
-                  P[2] * r[0] + P[4] * r[1] + P[5] * r[2]};
+  const double Pr[3] = {P[0] * r[0] + P[1] * r[1] + P[2] * r[2], P[1] * r[0] + P[3] * r[1] + P[4] * r[2],
+                        P[2] * r[0] + P[4] * r[1] + P[5] * r[2]};
+  double z[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) z[j] = Pr[j] + ut * v[j];
   double w[3];
   cross3(v, r, w);
   double c2[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) c2[i] = (R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2]) + n * t[i];
   const double c2u = dot3(c2, u);
-  // gradient block g = A^T u = (2/N) [ Pr x r + ut w ; c2u u ]
-  double prxr[3];
-  cross3(Pr, r, prxr);
+  // gradient block g = A^T u = (2/N) [ z x r ; c2u u ]
   const double two_invN = 2.0 * invN;
   const double cg = vc.coe * two_invN;
-#pragma unroll
-  for (int j = 0; j < 3; j++) acc[j] += cg * (prxr[j] + ut * w[j]);
+  acc[0] += cg * (z[1] * r[2] - z[2] * r[1]);
+  acc[1] += cg * (z[2] * r[0] - z[0] * r[2]);
+  acc[2] += cg * (z[0] * r[1] - z[1] * r[0]);
   const double cgu = cg * c2u;
 #pragma unroll
   for (int j = 0; j < 3; j++) acc[3 + j] += cgu * u[j];
 
-  // G rows for y = u1 (k = 0) and y = u2 (k = 1)
-  {
-    const double* y = vc.u1;
-    const double sk = vc.s1 * invN * sc;
-    double q[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) q[j] = R[j] * y[0] + R[3 + j] * y[1] + R[6 + j] * y[2];
-    const double yt = dot3(y, t);
-    double m[3] = {P[0] * q[0] + P[1] * q[1] + P[2] * q[2] + yt * v[0], P[1] * q[0] + P[3] * q[1] + P[4] * q[2] + yt * v[1],
-                   P[2] * q[0] + P[4] * q[1] + P[5] * q[2] + yt * v[2]};
-    double mxr[3], qxPr[3], qxv[3];
-    cross3(m, r, mxr);
-    cross3(q, Pr, qxPr);
-    cross3(q, v, qxv);
-    const double yc2 = dot3(y, c2);
-#pragma unroll
-    for (int j = 0; j < 3; j++) rows[0][j] = sk * ((mxr[j] - qxPr[j]) - ut * qxv[j]);
-#pragma unroll
-    for (int j = 0; j < 3; j++) rows[0][3 + j] = sk * (yc2 * u[j] + c2u * y[j]);
-  }
-  {
-    const double* y = vc.u2;
-    const double sk = vc.s2 * invN * sc;
-    double q[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) q[j] = R[j] * y[0] + R[3 + j] * y[1] + R[6 + j] * y[2];
-    const double yt = dot3(y, t);
-    double m[3] = {P[0] * q[0] + P[1] * q[1] + P[2] * q[2] + yt * v[0], P[1] * q[0] + P[3] * q[1] + P[4] * q[2] + yt * v[1],
-                   P[2] * q[0] + P[4] * q[1] + P[5] * q[2] + yt * v[2]};
-    double mxr[3], qxPr[3], qxv[3];
-    cross3(m, r, mxr);
-    cross3(q, Pr, qxPr);
-    cross3(q, v, qxv);
-    const double yc2 = dot3(y, c2);
-#pragma unroll
-    for (int j = 0; j < 3; j++) rows[1][j] = sk * ((mxr[j] - qxPr[j]) - ut * qxv[j]);
-#pragma unroll
-    for (int j = 0; j < 3; j++) rows[1][3 + j] = sk * (yc2 * u[j] + c2u * y[j]);
-  }
-  // z row
-  const double sz = 1.4142135623730951 * invN * sc;
+  // G rows for y = u1 and y = u2, z row
+  const double isc = invN * sc;
+  k3_g_row(P, v, R, t, r, z, c2, c2u, u, vc.u1, vc.s1 * isc, rows[0]);
+  k3_g_row(P, v, R, t, r, z, c2, c2u, u, vc.u2, vc.s2 * isc, rows[1]);
+  const double sz = 1.4142135623730951 * isc;
   const double szn = sz * n;
 #pragma unroll
   for (int j = 0; j < 3; j++) {
@@ -311,47 +309,37 @@ VX_HD void k3_entry(const double P[6], const double v[3], double n, const double
     rows[2][3 + j] = szn * u[j];
   }
 
-  // block-diagonal correction D_i (symmetric):
-  //  Drr = (2/N) [ sym(hat(Pr) hat(r)) + ut sym(hat(v) hat(r)) - hat(r) P hat(r) ],
-  //        sym(hat(a) hat(b)) = (b a^T + a b^T)/2 - (a.b) I
-  //  Drt = (2/N) w u^T ;  Dtt = (2 n / N) u u^T
-  const double Prr = dot3(Pr, r), vr = dot3(v, r);
-  // X = P hat(r): columns X0 = r2 P(:,1) - r1 P(:,2), X1 = -r2 P(:,0) + r0 P(:,2), X2 = r1 P(:,0) - r0 P(:,1)
-  const double Pc0[3] = {P[0], P[1], P[2]}, Pc1[3] = {P[1], P[3], P[4]}, Pc2[3] = {P[2], P[4], P[5]};
-  double X0[3], X1[3], X2[3];
+  // block-diagonal correction D_i
+  const double rr = dot3(r, r), trP = (P[0] + P[3]) + P[5];
+  const double c0 = (rr * trP - dot3(z, r)) - dot3(Pr, r);
+  double h[3];
 #pragma unroll
-  for (int i = 0; i < 3; i++) X0[i] = r[2] * Pc1[i] - r[1] * Pc2[i];
-#pragma unroll
-  for (int i = 0; i < 3; i++) X1[i] = r[0] * Pc2[i] - r[2] * Pc0[i];
-#pragma unroll
-  for (int i = 0; i < 3; i++) X2[i] = r[1] * Pc0[i] - r[0] * Pc1[i];
-  double S0[3], S1[3], S2[3];  // columns of hat(r) X
-  cross3(r, X0, S0);
-  cross3(r, X1, S1);
-  cross3(r, X2, S2);
-  const double cD = vc.coe * two_invN;
+  for (int j = 0; j < 3; j++) h[j] = (z[j] + 2.0 * Pr[j]) - trP * r[j];
+  const double cD = cg;   // coe * 2 / N
   // sym6 order xx xy xz yy yz zz
-  acc[6] += cD * ((r[0] * Pr[0] - Prr) + ut * (r[0] * v[0] - vr) - S0[0]);
-  acc[7] += cD * (0.5 * (r[0] * Pr[1] + Pr[0] * r[1]) + ut * 0.5 * (r[0] * v[1] + v[0] * r[1]) - 0.5 * (S1[0] + S0[1]));
-  acc[8] += cD * (0.5 * (r[0] * Pr[2] + Pr[0] * r[2]) + ut * 0.5 * (r[0] * v[2] + v[0] * r[2]) - 0.5 * (S2[0] + S0[2]));
-  acc[9] += cD * ((r[1] * Pr[1] - Prr) + ut * (r[1] * v[1] - vr) - S1[1]);
-  acc[10] += cD * (0.5 * (r[1] * Pr[2] + Pr[1] * r[2]) + ut * 0.5 * (r[1] * v[2] + v[1] * r[2]) - 0.5 * (S2[1] + S1[2]));
-  acc[11] += cD * ((r[2] * Pr[2] - Prr) + ut * (r[2] * v[2] - vr) - S2[2]);
-  const double cw[3] = {cD * w[0], cD * w[1], cD * w[2]};
+  acc[6] += cD * ((r[0] * h[0] - rr * P[0]) + c0);
+  acc[7] += cD * (0.5 * (r[0] * h[1] + r[1] * h[0]) - rr * P[1]);
+  acc[8] += cD * (0.5 * (r[0] * h[2] + r[2] * h[0]) - rr * P[2]);
+  acc[9] += cD * ((r[1] * h[1] - rr * P[3]) + c0);
+  acc[10] += cD * (0.5 * (r[1] * h[2] + r[2] * h[1]) - rr * P[4]);
+  acc[11] += cD * ((r[2] * h[2] - rr * P[5]) + c0);
+  if (RT) {
+    const double cw[3] = {cD * w[0], cD * w[1], cD * w[2]};
 #pragma unroll
-  for (int j = 0; j < 3; j++) acc[12 + j] += cw[0] * u[j];
+    for (int j = 0; j < 3; j++) acc[12 + j] += cw[0] * u[j];
 #pragma unroll
-  for (int j = 0; j < 3; j++) acc[15 + j] += cw[1] * u[j];
+    for (int j = 0; j < 3; j++) acc[15 + j] += cw[1] * u[j];
 #pragma unroll
-  for (int j = 0; j < 3; j++) acc[18 + j] += cw[2] * u[j];
-  const double cT = cD * n;
-  const double cu[3] = {cT * u[0], cT * u[1], cT * u[2]};
-  acc[21] += cu[0] * u[0];
-  acc[22] += cu[0] * u[1];
-  acc[23] += cu[0] * u[2];
-  acc[24] += cu[1] * u[1];
-  acc[25] += cu[1] * u[2];
-  acc[26] += cu[2] * u[2];
+    for (int j = 0; j < 3; j++) acc[18 + j] += cw[2] * u[j];
+    const double cT = cD * n;
+    const double cu[3] = {cT * u[0], cT * u[1], cT * u[2]};
+    acc[21] += cu[0] * u[0];
+    acc[22] += cu[0] * u[1];
+    acc[23] += cu[0] * u[2];
+    acc[24] += cu[1] * u[1];
+    acc[25] += cu[1] * u[2];
+    acc[26] += cu[2] * u[2];
+  }
 }
 
 }  // namespace vxm
