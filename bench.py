@@ -242,9 +242,10 @@ def main():
         k3f_ms = kt2["k3_finalize"]["ms_sum"] / max(1, kt2["k3_finalize"]["calls"])
         achieved = abytes["k3"] / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic_bytes("k3_hessian_kernel")
-        # fp64 work of one K3 launch: MFMA SYRK (batches x 50 x 16x16x4x2) + phase A (~300 f64 ops per entry)
+        # fp64 work of one K3 launch: MFMA SYRK (45 MFMAs of 16x16x4x2 flops per batch of 6 voxels: 10 tile pairs x 36 K-steps per
+        # 8 batches) + phase A (~232 f64 VALU instructions per entry, about 1.7 flops each)
         nbatch = (V + 5) // 6 if W == 10 else 0
-        k3_flops = nbatch * 50 * 2048.0 + nnz * 300.0 * 1.8 if W == 10 else None
+        k3_flops = nbatch * 45 * 2048.0 + nnz * 232.0 * 1.7 if W == 10 else None
         out = {
             # N > 1, weak scaling: every GPU iterates on its own cfg-sized shard of an N-times larger window, `value` counts
             # shard-iterations (N per LM iteration of the big window; the iteration rate of that window is config.global_iterations_per_s).

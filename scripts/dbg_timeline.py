@@ -37,18 +37,27 @@ if which == "fused":
 if which == "k2":
     f.evaluate_only_residual(sc.poses_init); n = (sc.n_voxels + 63) // 64; ns = 5
 else:
-    f.acc_evaluate2(sc.poses_init); n = 1024; ns = 7
+    # Hessian sweep (vxba_k3.hpp): 8 waves per workgroup; stamps 0 start, 1 poses decided, 8+s after the barrier of step s (s < 6),
+    # 3 step loop left, 6 partial written
+    f.acc_evaluate2(sc.poses_init)
+    full = vxba.debug_stamps(2048).astype(np.int64)
+    order = [0, 1, 8, 9, 10, 11, 12, 13, 3, 6]
+    names = ["start", "poses decided", "barrier 0 (phase A of step 0 done)", "barrier 1", "barrier 2", "barrier 3", "barrier 4", "barrier 5", "loop left", "end"]
+    live = full[:, 6] > 0
+    st = full[live][:, order]
+    t0 = st[:, 0].min()
+    print("k3: waves stamped", int(live.sum()), " kernel span %.2f us (s_memtime at 100 MHz)" % ((st[:, -1].max() - t0) / 100.0))
+    for k, nm in enumerate(names):
+        col = st[:, k]; ok = col > 0
+        if ok.any():
+            print("%-36s min %7.2f  median %7.2f  max %7.2f us   (%d waves)" % (nm, (col[ok].min() - t0) / 100.0, (np.median(col[ok]) - t0) / 100.0, (col[ok].max() - t0) / 100.0, int(ok.sum())))
+    per = np.diff(st[:, 2:7], axis=1) / 100.0
+    okp = (st[:, 2:7] > 0).all(axis=1)
+    if okp.any():
+        print("step period (barrier to barrier) us: median per step", np.round(np.median(per[okp], axis=0), 2))
+    sys.exit(0)
 full = vxba.debug_stamps(n).astype(np.int64)
 st = full[:, :ns]
-if which != "k2":
-    it = full[:, 8:28]
-    ok = it[:, 13] > 0          # waves with >= 7 loop iterations
-    top = it[ok][:, 0:14:2]; ready = it[ok][:, 1:14:2]
-    print("loop iterations: wait-for-loads cycles (median per iteration):", np.median(ready - top, axis=0))
-    print("iteration period cycles (median):", np.median(np.diff(top, axis=1), axis=0))
-    ph = full[ok][:, 28:32]
-    okp = ph[:, 3] > 0
-    print("one loop iteration split (cycles, median): MFMA tile %.0f | phase A %.0f | LDS stores %.0f" % tuple(np.median(np.diff(ph[okp], axis=1), axis=0)))
 t0 = st[:, 0].min()
 rel = (st - t0) / 100.0     # s_memtime ticks at 100 MHz -> us
 print(which, "waves", n, "kernel span us:", (st[:, -1].max() - t0) / 100.0)
@@ -57,6 +66,3 @@ for k in range(ns):
     print(k, "%.2f %.2f %.2f" % (rel[:, k].min(), np.median(rel[:, k]), rel[:, k].max()))
 d = np.diff(st, axis=1) / 100.0
 print("per-phase durations (us): median", np.median(d, axis=0), "max", d.max(axis=0))
-
-if which == "solve":
-    pass

@@ -206,12 +206,20 @@ __device__ __forceinline__ void k3_mfma_phase(const double* buf, int k0, int nk,
   constexpr unsigned NEED = k3_need_rows(C::NT, C::TPW, SET) | k3_need_cols(C::NT, C::TPW, SET);   // column tiles this set touches
   const double* base = buf + C::at(4 * k0 + lrow, lcol);   // K-step kk: + kk * 4 NCOL, column tile c: + 32 c
   if (FULL) {
+    // operands of K-step kk+1 are requested before the MFMAs of K-step kk are issued
+    double x[C::NT], xn[C::NT];
+#pragma unroll
+    for (int c = 0; c < C::NT; c++) x[c] = ((NEED >> c) & 1) ? base[32 * c] : 0.0;
 #pragma unroll
     for (int kk = 0; kk < C::KPW; kk++) {
-      double x[C::NT];
+      if (kk + 1 < C::KPW) {
 #pragma unroll
-      for (int c = 0; c < C::NT; c++) x[c] = ((NEED >> c) & 1) ? base[kk * 4 * C::NCOL + 32 * c] : 0.0;
+        for (int c = 0; c < C::NT; c++) xn[c] = ((NEED >> c) & 1) ? base[(kk + 1) * 4 * C::NCOL + 32 * c] : 0.0;
+        __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the MFMAs (the scheduler sinks them to their first use otherwise)
+      }
       k3_mfma_tiles<W, SET, 0>(x, acc);
+#pragma unroll
+      for (int c = 0; c < C::NT; c++) x[c] = xn[c];
     }
   } else {
     for (int kk = 0; kk < nk; kk++) {
@@ -272,7 +280,8 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
                                                               int end, double* __restrict__ partial) {
   using C = K3Cfg<W>;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // two tile buffers; reused by the epilogue
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // tell the compiler it is wave-uniform: scalar branches, descriptors in SGPRs
   const bool active = lane < C::NACT;
   const int vl = active ? lane / W : 0;
   const int fi = active ? lane % W : 0;
