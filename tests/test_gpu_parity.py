@@ -395,11 +395,14 @@ def test_bench_rccl_plumbing_single_rank():
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     a = run([])
-    for extra in (["--force-dist"], ["--force-dist", "--hook-allreduce"]):     # direct ncclAllReduce / torch.distributed hook
+    # direct ncclAllReduce / torch.distributed hook / one-shot peer all-reduce through the hipIpc mailboxes (bench --collective)
+    for extra, tag in ((["--force-dist", "--collective", "rccl"], "RCCL all-reduce issued from the C++ loop"),
+                       (["--force-dist", "--hook-allreduce"], "torch.distributed all-reduce"),
+                       (["--force-dist", "--collective", "peer"], "peer all-reduce")):
         b = run(extra)
         assert a["config"]["lm_steps_accepted"] == b["config"]["lm_steps_accepted"] == 30
         assert abs(a["config"]["final_residual"] - b["config"]["final_residual"]) <= 1e-12 * abs(a["config"]["final_residual"])
-        assert "RCCL" in b["config"]["parallelism"] and b["value"] > 0
+        assert tag in b["config"]["parallelism"] and b["value"] > 0, b["config"]["parallelism"]
 
 
 def test_lm_loop_with_more_residual_workgroups_than_the_chip_holds(vx):

@@ -104,20 +104,22 @@ __device__ __forceinline__ double k3_ld64(__amdgpu_buffer_rsrc_t r, unsigned vof
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
 }
 
-template <int W>
-__device__ __forceinline__ void k3_load_entry(const K3Planes& pl, int head, int end, int b, bool active, int vl, int lane, K3Entry& e) {
-  using C = K3Cfg<W>;
-  const int a = b * C::NV + vl;
-  e.ok = active && a >= head && a < end;
-  // clusters: five contiguous 1 KB rows per wave (batch-major copy)
+// clusters of batch b: five contiguous 1 KB rows per wave (batch-major copy) -- 83 % of an entry's bytes
+__device__ __forceinline__ void k3_load_clusters(const K3Planes& pl, int b, int lane, double c[10]) {
   const __amdgpu_buffer_rsrc_t rc = k3_rsrc(pl.clb + (size_t)b * 640);
 #pragma unroll
   for (int j = 0; j < 5; j++) {
     const v2d t = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rc, lane * 16, j * 1024, 0));
-    e.c[2 * j] = t[0];
-    e.c[2 * j + 1] = t[1];
+    c[2 * j] = t[0];
+    c[2 * j + 1] = t[1];
   }
-  // plane parameters of my voxel: each row of NV voxels sits in one or two cache lines
+}
+// plane parameters of the lane's voxel: each row of NV voxels sits in one or two cache lines
+template <int W>
+__device__ __forceinline__ void k3_load_params(const K3Planes& pl, int head, int end, int b, bool active, int vl, K3Entry& e) {
+  using C = K3Cfg<W>;
+  const int a = b * C::NV + vl;
+  e.ok = active && a >= head && a < end;
   const unsigned off = (unsigned)(e.ok ? a : head) * 8u;
   const unsigned vs8 = pl.vs8;
 #pragma unroll
@@ -135,10 +137,13 @@ __device__ __forceinline__ void k3_load_entry(const K3Planes& pl, int head, int 
 // Phase A of one entry: rows of B_a (3 x 6) and the per-frame linear accumulators, branch-free.
 template <bool RT>
 __device__ __forceinline__ void k3_phase_a(K3Entry& e, int fi, const double* __restrict__ pose, double rows[3][6], double dacc[DACC]) {
-  // pose of the lane's frame from LDS (R row-major | p): 24 registers less to carry through phase M
+  // pose of the lane's frame from LDS (C-ABI layout: R column-major | p), transposed on the way in: 24 registers less to
+  // carry through phase M
   double R[9], p[3];
 #pragma unroll
-  for (int k = 0; k < 9; k++) R[k] = pose[k];
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = pose[3 * cc + r];
 #pragma unroll
   for (int k = 0; k < 3; k++) p[k] = pose[9 + k];
   const bool obs = e.ok && e.c[9] != 0.0;   // N == 0: frame did not observe the voxel (voxel_map.hpp:178)
@@ -275,6 +280,31 @@ __device__ __forceinline__ void k3_mfma_phase_f32(const float* buf, int k0, int 
   }
 }
 
+// Epilogue geometry.  With the spare columns in use only 13 of the 28 linear accumulators exist (g 0..5, Drr 6..11, residual 27);
+// parked with stride 13 (odd: conflict-free column reads) they fit beside the parked MFMA accumulators, so the epilogue needs one
+// barrier instead of three.  Slots that are not in use are never written to the partial and never read by k3_finalize.
+template <int W>
+struct K3Epi {
+  using C = K3Cfg<W>;
+  static constexpr int NUSED = C::SPARE ? 13 : DACC;
+  static constexpr int DS = C::SPARE ? 13 : DACC + 1;
+  __host__ __device__ static constexpr int slot(int k) { return C::SPARE ? (k < 12 ? k : 27) : k; }
+  static constexpr bool ONE_PHASE = ((size_t)K3_BLOCK * DS + (size_t)C::WAVES * C::TPW * 256) * sizeof(double) <= 144 * 1024;
+};
+template <int W>
+__device__ __forceinline__ void k3_sum_linear(const double* park_d, double* out, int tid) {
+  using C = K3Cfg<W>;
+  using E = K3Epi<W>;
+  for (int el = tid; el < W * E::NUSED; el += K3_BLOCK) {
+    const int i = el / E::NUSED, k = el % E::NUSED;
+    double sum = 0.0;
+    for (int w = 0; w < C::WAVES; w++)
+#pragma unroll
+      for (int v = 0; v < C::NV; v++) sum += park_d[(w * 64 + v * W + i) * E::DS + k];
+    out[i * DACC + E::slot(k)] = sum;
+  }
+}
+
 template <int W, bool DBG = false, bool MIXED = false>
 __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c_in, LMPending pend, int head,
                                                               int end, double* __restrict__ partial) {
@@ -304,34 +334,62 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   K3Entry e;
   e.ok = false;
   const K3Planes pl = k3_planes(fv);
-  if (wave < cnt) k3_load_entry<W>(pl, head, end, bs + wave, active, vl, lane, e);
+  if (wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, active, vl, e); }
 
-  // LM mode: take the pending accept/reject decision.  Every wave computes accept / done from the same inputs; both
-  // pose candidates (current, trial) are requested together with the partials so the choice costs one memory latency;
-  // the last workgroup also works out the damping update and persists the control block for the kernels that follow.
-  double R[9], p[3];
-  if (st) {
-    const LMCtl& in = st->ctl[c_in];
-    const int in_done = in.done, in_calc = in.calc_hess, bench = in.bench_mode;
-    const double r1 = in.residual1;
-    // pending: 0 none (linearise at in.x), 1 decide here, 2 / 3 sharded speculative loop: no decision here -- linearise at the
-    // trial poses (2) or at the kernel-argument poses (3, first sweep of a solve / window), skip only when the loop is done
-    const double* __restrict__ xa_src = ((pend.pending == 1 && pend.restart) || pend.pending == 3) ? poses.Rp : (pend.pending == 2 ? in.xt : in.x);
-    double xa[12], xb[12] = {};
+  // LDS behind the two tile buffers: both pose candidates (raw C-ABI layout: R column-major | p per frame) and what the LM
+  // decision needs.  Only wave 0 of a workgroup talks to the control block: with all eight waves doing it (round 1 had every
+  // wave decide for itself) a CU opened the kernel with ~500 load instructions in its queue and the first phase A finished
+  // 14k cycles in (profiles/r02_v2); the other seven waves now only request their first batch and clear the tiles meanwhile.
+  double* poseA = lds + 2 * C::BUF;       // current / kernel-argument / trial poses (what `xa_src` selects)
+  double* poseB = poseA + 12 * W;         // trial poses (pending decision)
+  double* lmv = poseB + 12 * W;           // [0] done, [1] calc_hess, [2] bench_mode, [3] residual1, [4] residual2
+  if (wave == 0) {
+    const int fl = lane < W ? lane : 0;
+    if (st) {
+      const LMCtl& in = st->ctl[c_in];
+      // pending: 0 none (linearise at in.x), 1 decide here, 2 / 3 sharded speculative loop: no decision here -- linearise at the
+      // trial poses (2) or at the kernel-argument poses (3, first sweep of a solve / window), skip only when the loop is done
+      const double* __restrict__ xa_src = ((pend.pending == 1 && pend.restart) || pend.pending == 3) ? poses.Rp : (pend.pending == 2 ? in.xt : in.x);
+      double xa[12], xb[12] = {};
 #pragma unroll
-    for (int k = 0; k < 12; k++) xa[k] = xa_src[12 * fi + k];
-    bool use_b = false;
+      for (int k = 0; k < 12; k++) xa[k] = xa_src[12 * fl + k];
+      if (pend.pending == 1) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) xb[k] = in.xt[12 * fl + k];
+      }
+      const double v_done = in.done, v_calc = in.calc_hess, v_bench = in.bench_mode, r1 = in.residual1;
+      const double r2 = (pend.pending == 1 && !in.done) ? lm_residual2(pend) : 0.0;
+      if (lane < W) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) { poseA[12 * lane + k] = xa[k]; poseB[12 * lane + k] = xb[k]; }
+      }
+      if (lane == 0) { lmv[0] = v_done; lmv[1] = v_calc; lmv[2] = v_bench; lmv[3] = r1; lmv[4] = r2; }
+    } else if (lane < W) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) poseA[12 * lane + k] = poses.Rp[12 * lane + k];
+    }
+  }
+  // both tile buffers start as zeros: padding columns (6W .. NCOL) are never written
+  {
+    constexpr int NZ = MIXED ? C::BUF : 2 * C::BUF;   // doubles
+    for (int k = tid; k < NZ; k += K3_BLOCK) lds[k] = 0.0;
+  }
+  __syncthreads();
+  dbg_stamp(DBG, gw, 1);
+  // every thread takes the same decision from the same five numbers (the last workgroup also works out the damping update and
+  // persists the control block for the kernels that follow)
+  bool use_b = false;
+  if (st) {
+    const bool in_done = lmv[0] != 0.0, in_calc = lmv[1] != 0.0, bench = lmv[2] != 0.0;
+    const double r1 = lmv[3], r2 = lmv[4];
     if (pend.pending >= 2) {
       if (in_done) return;
     } else if (pend.pending) {
-#pragma unroll
-      for (int k = 0; k < 12; k++) xb[k] = in.xt[12 * fi + k];
       if (in_done) { if (blockIdx.x == gridDim.x - 1) lm_carry(st, c_in, W); return; }
-      const double r2 = lm_residual2(pend);
       const bool accept = (r1 - r2) > 0;
       const bool done = !bench && fabs((r1 - r2) / r1) < 1e-6;
       if (blockIdx.x == gridDim.x - 1) {
-        const LMDecision d = lm_decide(in, r2, pend.restart);
+        const LMDecision d = lm_decide(st->ctl[c_in], r2, pend.restart);
         lm_persist(st, c_in, d, pend.restart, poses, W);
       }
       if (done || !(accept || pend.restart)) return;
@@ -339,36 +397,8 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
     } else {
       if (in_done || !in_calc) return;
     }
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = use_b ? xb[3 * cc + r] : xa[3 * cc + r];
-#pragma unroll
-    for (int k = 0; k < 3; k++) p[k] = use_b ? xb[9 + k] : xa[9 + k];
-  } else {
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = poses.Rp[12 * fi + 3 * cc + r];
-#pragma unroll
-    for (int k = 0; k < 3; k++) p[k] = poses.Rp[12 * fi + 9 + k];
   }
-  dbg_stamp(DBG, gw, 1);
-
-  // both tile buffers start as zeros: padding columns (6W .. NCOL) are never written
-  {
-    constexpr int NZ = MIXED ? C::BUF : 2 * C::BUF;   // doubles
-    for (int k = tid; k < NZ; k += K3_BLOCK) lds[k] = 0.0;
-  }
-  // the decided poses move to LDS behind the tiles (every wave holds the same values; wave 0's lanes 0..W-1 store them)
-  double* pose_lds = lds + 2 * C::BUF;
-  if (wave == 0 && lane < W) {
-#pragma unroll
-    for (int k = 0; k < 9; k++) pose_lds[12 * lane + k] = R[k];
-#pragma unroll
-    for (int k = 0; k < 3; k++) pose_lds[12 * lane + 9 + k] = p[k];
-  }
-  const double* pose = pose_lds + 12 * fi;
+  const double* pose = (use_b ? poseB : poseA) + 12 * fi;
   v4d acc[C::TPW];
 #pragma unroll
   for (int t = 0; t < C::TPW; t++) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -378,10 +408,18 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   double dacc[DACC];
 #pragma unroll
   for (int k = 0; k < DACC; k++) dacc[k] = 0.0;
-  __syncthreads();
 
   // step s: phase M of step s-1 (buffer (s-1)&1), phase A of step s (buffer s&1), one barrier
+  double cn[10];   // clusters of the wave's NEXT batch
+#pragma unroll
+  for (int k = 0; k < 10; k++) cn[k] = 0.0;
   for (int s = 0; s <= nsteps; s++) {
+    // The cluster rows of step s+1 are requested a whole step ahead (second register set: 20 registers), the plane parameters
+    // (one sixth of the bytes, a handful of cache lines) after phase A has consumed the current ones.  With everything
+    // requested after phase A the 48 KB a CU needs per step did not land within phase M (a CU sustains ~10 B/clk from HBM)
+    // and every step stalled for ~3.4k of its ~12k cycles (profiles/r02_v2: s_memtime stamps).
+    const bool has_next = wave + (s + 1) * C::WAVES < cnt;
+    if (has_next) k3_load_clusters(pl, bs + (s + 1) * C::WAVES + wave, lane, cn);
     if (s >= 1) {
       const int nb_prev = cnt - (s - 1) * C::WAVES;   // batches of step s-1
       const int bo = ((s - 1) & 1) * C::BUF;
@@ -439,8 +477,13 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
           }
         }
       }
-      // next batch of this wave: in flight during the barrier and the whole of phase M
-      if (wave + (s + 1) * C::WAVES < cnt) k3_load_entry<W>(pl, head, end, bs + (s + 1) * C::WAVES + wave, active, vl, lane, e);
+      // next batch of this wave: its clusters have been in flight since the top of the step; the plane parameters are
+      // requested now and have the barrier and the whole of phase M to land
+      if (has_next) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) e.c[k] = cn[k];
+        k3_load_params<W>(pl, head, end, bs + (s + 1) * C::WAVES + wave, active, vl, e);
+      }
     } else if (wave == nb) {
       // first idle wave of the ragged step: the rows that round the step up to a whole K-step must read as zeros
       if (MIXED) { float* z = reinterpret_cast<float*>(lds) + bo + C::at(nb * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0f; }
@@ -458,35 +501,33 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   dbg_stamp(DBG, gw, 3);
 
   // Deterministic in-block reduction through LDS (fixed order), one partial per workgroup:  [NTP tiles x 256 | W x DACC]
+  using E = K3Epi<W>;
   constexpr int PLEN = C::NTP * 256 + W * DACC;
-  constexpr int DS = DACC + 1;  // padded stride: conflict-free column reads
   double* pout = partial + (size_t)blockIdx.x * PLEN;
+  double* park_d = lds;                                                   // [512 lanes][DS] linear accumulators
+  double* park_t = E::ONE_PHASE ? lds + (size_t)K3_BLOCK * E::DS : lds;   // [8 waves][TPW][256] MFMA accumulators
   __syncthreads();  // every wave is done with the tiles
-  // (1) per-frame linear accumulators: every lane parks its 28 values, then W*28 threads sum the 8*NV lanes of a frame
+  // (1) per-frame linear accumulators: every lane parks the ones in use, then one thread per (frame, slot) sums the 8*NV lanes
 #pragma unroll
-  for (int k = 0; k < DACC; k++) lds[(wave * 64 + lane) * DS + k] = dacc[k];
-  __syncthreads();
-  for (int el = tid; el < W * DACC; el += K3_BLOCK) {
-    const int i = el / DACC, k = el % DACC;
-    double sum = 0.0;
-    for (int w = 0; w < C::WAVES; w++)
-#pragma unroll
-      for (int v = 0; v < C::NV; v++) sum += lds[(w * 64 + v * W + i) * DS + k];
-    pout[C::NTP * 256 + el] = sum;
+  for (int k = 0; k < E::NUSED; k++) park_d[(wave * 64 + lane) * E::DS + k] = dacc[E::slot(k)];
+  if (!E::ONE_PHASE) {
+    __syncthreads();
+    k3_sum_linear<W>(park_d, pout + C::NTP * 256, tid);
+    __syncthreads();
   }
-  __syncthreads();
   // (2) MFMA accumulator tiles: wave (kq, set) parks its TPW tiles, then tile t of set s is the sum over the K ranges
 #pragma unroll
   for (int j = 0; j < C::TPW; j++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) lds[(wave * C::TPW + j) * 256 + r * 64 + lane] = acc[j][r];
+    for (int r = 0; r < 4; r++) park_t[(wave * C::TPW + j) * 256 + r * 64 + lane] = acc[j][r];
   __syncthreads();
+  if (E::ONE_PHASE) k3_sum_linear<W>(park_d, pout + C::NTP * 256, tid);
   for (int el = tid; el < C::NTP * 256; el += K3_BLOCK) {
     const int t = el >> 8, x = el & 255;
     const int ts = t / C::TPW, j = t % C::TPW;
     double sum = 0.0;
 #pragma unroll
-    for (int k = 0; k < C::KSPLIT; k++) sum += lds[((k * C::TSPLIT + ts) * C::TPW + j) * 256 + x];
+    for (int k = 0; k < C::KSPLIT; k++) sum += park_t[((k * C::TSPLIT + ts) * C::TPW + j) * 256 + x];
     pout[el] = sum;
   }
   dbg_stamp(DBG, gw, 6);

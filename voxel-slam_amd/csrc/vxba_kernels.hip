@@ -945,9 +945,11 @@ int k3_grid_blocks(int device_cus) { return device_cus; }  // one 8-wave workgro
 template <int W>
 constexpr size_t k3_lds_bytes() {
   using C = K3Cfg<W>;
-  constexpr size_t main_d = (size_t)2 * C::BUF + 12 * W;
-  constexpr size_t epi1 = (size_t)K3_BLOCK * (DACC + 1), epi2 = (size_t)C::WAVES * C::TPW * 256;
-  constexpr size_t m = main_d > epi1 ? (main_d > epi2 ? main_d : epi2) : (epi1 > epi2 ? epi1 : epi2);
+  constexpr size_t main_d = (size_t)2 * C::BUF + 24 * W + 8;   // tiles | two pose candidates | LM decision inputs
+  // epilogue: parked linear accumulators, then (or, when both fit, beside them) the parked MFMA accumulators
+  constexpr size_t epi1 = (size_t)K3_BLOCK * K3Epi<W>::DS, epi2 = (size_t)C::WAVES * C::TPW * 256;
+  constexpr size_t epi = K3Epi<W>::ONE_PHASE ? epi1 + epi2 : (epi1 > epi2 ? epi1 : epi2);
+  constexpr size_t m = main_d > epi ? main_d : epi;
   return m * sizeof(double);
 }
 
