@@ -317,6 +317,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   const int fi = active ? lane % W : 0;
   const int lrow = lane >> 4, lcol = lane & 15;
   const int set = wave % C::TSPLIT, kq = wave / C::TSPLIT;
+  const bool a_first = (wave >> 2) & 1;   // second wave of its SIMD: phase A before phase M
   const int gw = blockIdx.x * C::WAVES + wave;
   dbg_stamp(DBG, gw, 0);
 
@@ -410,85 +411,88 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   for (int k = 0; k < DACC; k++) dacc[k] = 0.0;
 
   // step s: phase M of step s-1 (buffer (s-1)&1), phase A of step s (buffer s&1), one barrier
-  double cn[10];   // clusters of the wave's NEXT batch
-#pragma unroll
-  for (int k = 0; k < 10; k++) cn[k] = 0.0;
   for (int s = 0; s <= nsteps; s++) {
-    // The cluster rows of step s+1 are requested a whole step ahead (second register set: 20 registers), the plane parameters
-    // (one sixth of the bytes, a handful of cache lines) after phase A has consumed the current ones.  With everything
-    // requested after phase A the 48 KB a CU needs per step did not land within phase M (a CU sustains ~10 B/clk from HBM)
-    // and every step stalled for ~3.4k of its ~12k cycles (profiles/r02_v2: s_memtime stamps).
     const bool has_next = wave + (s + 1) * C::WAVES < cnt;
-    if (has_next) k3_load_clusters(pl, bs + (s + 1) * C::WAVES + wave, lane, cn);
+    // Inside an iteration the order of phase M (step s-1) and phase A (step s) is free -- they touch different tile buffers -- so
+    // the two waves that share a SIMD (w and w + 4: a workgroup's waves are dealt to the SIMDs cyclically) take them in OPPOSITE
+    // order.  All eight waves in the same phase (the first version of this kernel) left the MFMA shadows empty during phase M
+    // and made the VALU the bottleneck during phase A: 11.8k cycles per step against 7.8k of fp64 work (profiles/r02_v2).
+    // A two-trip loop with a run-time order keeps one copy of each phase in the binary.
+#pragma nounroll
+    for (int half = 0; half < 2; half++) {
+      const bool do_m = (half == 0) != a_first;
+      if (do_m) {
     if (s >= 1) {
-      const int nb_prev = cnt - (s - 1) * C::WAVES;   // batches of step s-1
-      const int bo = ((s - 1) & 1) * C::BUF;
-      if (nb_prev >= C::WAVES) {
-        const int k0 = kq * C::KPW;
-        if (MIXED) {
-          const float* bf = reinterpret_cast<const float*>(lds) + bo;
-          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase_f32<W, 0, true>(bf, k0, C::KPW, lrow, lcol, af);
-          else k3_mfma_phase_f32<W, C::TSPLIT - 1, true>(bf, k0, C::KPW, lrow, lcol, af);
-        } else {
-          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase<W, 0, true>(lds + bo, k0, C::KPW, lrow, lcol, acc);
-          else k3_mfma_phase<W, C::TSPLIT - 1, true>(lds + bo, k0, C::KPW, lrow, lcol, acc);
+          const int nb_prev = cnt - (s - 1) * C::WAVES;   // batches of step s-1
+          const int bo = ((s - 1) & 1) * C::BUF;
+          if (nb_prev >= C::WAVES) {
+            const int k0 = kq * C::KPW;
+            if (MIXED) {
+              const float* bf = reinterpret_cast<const float*>(lds) + bo;
+              if (C::TSPLIT == 1 || set == 0) k3_mfma_phase_f32<W, 0, true>(bf, k0, C::KPW, lrow, lcol, af);
+              else k3_mfma_phase_f32<W, C::TSPLIT - 1, true>(bf, k0, C::KPW, lrow, lcol, af);
+            } else {
+              if (C::TSPLIT == 1 || set == 0) k3_mfma_phase<W, 0, true>(lds + bo, k0, C::KPW, lrow, lcol, acc);
+              else k3_mfma_phase<W, C::TSPLIT - 1, true>(lds + bo, k0, C::KPW, lrow, lcol, acc);
+            }
+          } else {
+            // ragged last step: only ceil(nb_prev R / 4) K-steps exist; re-split them over the K ranges
+            const int ks = (nb_prev * C::R + 3) >> 2;
+            const int k0 = (kq * ks) / C::KSPLIT, k1 = ((kq + 1) * ks) / C::KSPLIT;
+            if (MIXED) {
+              const float* bf = reinterpret_cast<const float*>(lds) + bo;
+              if (C::TSPLIT == 1 || set == 0) k3_mfma_phase_f32<W, 0, false>(bf, k0, k1 - k0, lrow, lcol, af);
+              else k3_mfma_phase_f32<W, C::TSPLIT - 1, false>(bf, k0, k1 - k0, lrow, lcol, af);
+            } else {
+              if (C::TSPLIT == 1 || set == 0) k3_mfma_phase<W, 0, false>(lds + bo, k0, k1 - k0, lrow, lcol, acc);
+              else k3_mfma_phase<W, C::TSPLIT - 1, false>(lds + bo, k0, k1 - k0, lrow, lcol, acc);
+            }
+          }
         }
-      } else {
-        // ragged last step: only ceil(nb_prev R / 4) K-steps exist; re-split them over the K ranges
-        const int ks = (nb_prev * C::R + 3) >> 2;
-        const int k0 = (kq * ks) / C::KSPLIT, k1 = ((kq + 1) * ks) / C::KSPLIT;
-        if (MIXED) {
-          const float* bf = reinterpret_cast<const float*>(lds) + bo;
-          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase_f32<W, 0, false>(bf, k0, k1 - k0, lrow, lcol, af);
-          else k3_mfma_phase_f32<W, C::TSPLIT - 1, false>(bf, k0, k1 - k0, lrow, lcol, af);
-        } else {
-          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase<W, 0, false>(lds + bo, k0, k1 - k0, lrow, lcol, acc);
-          else k3_mfma_phase<W, C::TSPLIT - 1, false>(lds + bo, k0, k1 - k0, lrow, lcol, acc);
+      } else if (s < nsteps) {
+        const int nb = cnt - s * C::WAVES;   // batches of this step (>= 1)
+        const int bo = (s & 1) * C::BUF;
+        if (wave < nb) {
+          double rows[3][6];
+          // voxel-level values for the spare columns, taken before phase A masks / consumes the entry
+          const double spare_s = 1.4142135623730951 * e.sc;
+          const double spare[3] = {spare_s * e.u[0], spare_s * e.u[1], spare_s * e.u[2]};
+          k3_phase_a<!C::SPARE>(e, fi, pose, rows, dacc);
+          if (active) {
+            // the nine store offsets are recomputed from (vl, fi) every step -- a handful of integer operations under the other
+            // wave's fp64 work -- instead of living in registers (or scratch) across phase M
+            int vl_ = vl, fi_ = fi;
+            asm volatile("" : "+v"(vl_), "+v"(fi_));
+            const K3RowOfs ro = k3_row_offsets<W>(wave, vl_, fi_);
+            if (MIXED) k3_store_rows_f32(reinterpret_cast<float*>(lds) + bo, ro, rows);
+            else k3_store_rows(lds + bo, ro, rows);
+            if (C::SPARE && fi_ == W - 1) {   // one lane per voxel: columns 6W .. 6W+2 of the z row
+              const int o = ro.rp[2] + C::at(0, 6 * W);
+              if (MIXED) {
+                float* zf = reinterpret_cast<float*>(lds) + bo + o;
+                *reinterpret_cast<v2f*>(zf) = (v2f){(float)spare[0], (float)spare[1]};
+                zf[2] = (float)spare[2];
+              } else {
+                double* zd = lds + bo + o;
+                *reinterpret_cast<v2d*>(zd) = (v2d){spare[0], spare[1]};
+                zd[2] = spare[2];
+              }
+            }
+          }
+          // next batch of this wave: in flight during the barrier and a whole phase M.  (Requesting the cluster rows a step
+          // earlier into a second register set was measured and changed nothing: the loads were not what the steps waited for.)
+          if (has_next) {
+            k3_load_clusters(pl, bs + (s + 1) * C::WAVES + wave, lane, e.c);
+            k3_load_params<W>(pl, head, end, bs + (s + 1) * C::WAVES + wave, active, vl, e);
+          }
+        } else if (wave == nb) {
+          // first idle wave of the ragged step: the rows that round the step up to a whole K-step must read as zeros
+          if (MIXED) { float* z = reinterpret_cast<float*>(lds) + bo + C::at(nb * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0f; }
+          else { double* z = lds + bo + C::at(nb * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0; }
         }
       }
     }
     if (s == nsteps) break;
-    const int nb = cnt - s * C::WAVES;   // batches of this step (>= 1)
-    const int bo = (s & 1) * C::BUF;
-    if (wave < nb) {
-      double rows[3][6];
-      // voxel-level values for the spare columns, taken before phase A masks / consumes the entry
-      const double spare_s = 1.4142135623730951 * e.sc;
-      const double spare[3] = {spare_s * e.u[0], spare_s * e.u[1], spare_s * e.u[2]};
-      k3_phase_a<!C::SPARE>(e, fi, pose, rows, dacc);
-      if (active) {
-        // the nine store offsets are recomputed from (vl, fi) every step -- a handful of integer operations under the other
-        // wave's fp64 work -- instead of living in registers (or scratch) across phase M
-        int vl_ = vl, fi_ = fi;
-        asm volatile("" : "+v"(vl_), "+v"(fi_));
-        const K3RowOfs ro = k3_row_offsets<W>(wave, vl_, fi_);
-        if (MIXED) k3_store_rows_f32(reinterpret_cast<float*>(lds) + bo, ro, rows);
-        else k3_store_rows(lds + bo, ro, rows);
-        if (C::SPARE && fi_ == W - 1) {   // one lane per voxel: columns 6W .. 6W+2 of the z row
-          const int o = ro.rp[2] + C::at(0, 6 * W);
-          if (MIXED) {
-            float* zf = reinterpret_cast<float*>(lds) + bo + o;
-            *reinterpret_cast<v2f*>(zf) = (v2f){(float)spare[0], (float)spare[1]};
-            zf[2] = (float)spare[2];
-          } else {
-            double* zd = lds + bo + o;
-            *reinterpret_cast<v2d*>(zd) = (v2d){spare[0], spare[1]};
-            zd[2] = spare[2];
-          }
-        }
-      }
-      // next batch of this wave: its clusters have been in flight since the top of the step; the plane parameters are
-      // requested now and have the barrier and the whole of phase M to land
-      if (has_next) {
-#pragma unroll
-        for (int k = 0; k < 10; k++) e.c[k] = cn[k];
-        k3_load_params<W>(pl, head, end, bs + (s + 1) * C::WAVES + wave, active, vl, e);
-      }
-    } else if (wave == nb) {
-      // first idle wave of the ragged step: the rows that round the step up to a whole K-step must read as zeros
-      if (MIXED) { float* z = reinterpret_cast<float*>(lds) + bo + C::at(nb * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0f; }
-      else { double* z = lds + bo + C::at(nb * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0; }
-    }
     __syncthreads();
     if (s < 6) dbg_stamp(DBG, gw, 8 + s);
   }
