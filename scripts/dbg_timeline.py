@@ -55,6 +55,14 @@ else:
     okp = (st[:, 2:7] > 0).all(axis=1)
     if okp.any():
         print("step period (barrier to barrier) us: median per step", np.round(np.median(per[okp], axis=0), 2))
+    # inside steps 1..3: barrier s-1 passed -> phase M done -> phase A done -> barrier s passed
+    for st_ in (1, 2, 3):
+        cols = full[live][:, [8 + st_ - 1, 13 + 3 * st_, 14 + 3 * st_, 8 + st_]]
+        okc = (cols > 0).all(axis=1)
+        if okc.any():
+            d = np.diff(cols[okc], axis=1)
+            print("step %d (cycles, median | max over waves): phase M %6.0f | %6.0f   phase A %6.0f | %6.0f   wait at barrier %6.0f | %6.0f" % (
+                st_, np.median(d[:, 0]), d[:, 0].max(), np.median(d[:, 1]), d[:, 1].max(), np.median(d[:, 2]), d[:, 2].max()))
     sys.exit(0)
 full = vxba.debug_stamps(n).astype(np.int64)
 st = full[:, :ns]

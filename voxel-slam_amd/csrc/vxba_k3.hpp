@@ -77,10 +77,19 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// Entry loads go through buffer descriptors: the address of every load is  descriptor base (SGPRs) + plane offset (one SGPR) +
-// one 32-bit lane offset (VGPR)  -- no 64-bit address arithmetic on the VALU and no address register pairs to carry.
+// Entry loads go through buffer descriptors: the address of every load is  descriptor base (SGPRs) + one 32-bit lane offset
+// (VGPR)  -- no 64-bit address arithmetic on the VALU and no address register pairs to carry.
+//
+// The 18 plane parameters of a voxel (9 eigenvector components, s1, s2, merged first moment, 1/N, sqrt(coe), lambda_0, coe) are
+// the same for the W lanes of the voxel.  Round 1 let every lane fetch them itself: 18 load instructions per wave and batch
+// whose 64 lanes read 6 distinct addresses.  The CU's one texture-addresser serialises vector-memory instructions at ~16 cycles
+// apiece whatever their width, and with eight waves per CU those 144 instructions per step became the longest part of
+// phase A (s_memtime stamps: phase A 4.9k cycles with the loads, 2.9k without).  Now the wave fetches the NV x 17 values of the
+// cache planes TRANSPOSED -- lane t takes (voxel t / 17, plane t % 17): two instructions at W = 10 -- plus one for coe, parks
+// them in registers during phase M (10 registers instead of 36), and redistributes them through a wave-private corner of LDS
+// at the start of phase A: 8 vector-memory instructions per wave and batch instead of 23.
 struct K3Planes {
-  __amdgpu_buffer_rsrc_t eigval, eigvec, merged, aux, coe;
+  __amdgpu_buffer_rsrc_t cache, coe;   // cache = eigval(3) | eigvec(9) | merged(10) | aux(4), consecutive planes (FactorView / snapshot)
   const double* clb;
   unsigned vs8;   // plane stride in bytes
 };
@@ -89,10 +98,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t k3_rsrc(const void* p) {
 }
 __device__ __forceinline__ K3Planes k3_planes(const FactorView& fv) {
   K3Planes pl;
-  pl.eigval = k3_rsrc(fv.eigval);
-  pl.eigvec = k3_rsrc(fv.eigvec);
-  pl.merged = k3_rsrc(fv.merged);
-  pl.aux = k3_rsrc(fv.aux);
+  pl.cache = k3_rsrc(fv.eigval);
   pl.coe = k3_rsrc(fv.coe);
   pl.clb = fv.clb;
   pl.vs8 = (unsigned)fv.VS * 8u;
@@ -114,24 +120,73 @@ __device__ __forceinline__ void k3_load_clusters(const K3Planes& pl, int b, int 
     c[2 * j + 1] = t[1];
   }
 }
-// plane parameters of the lane's voxel: each row of NV voxels sits in one or two cache lines
+
+// Order of a voxel's 18 parameters in the staging record, and the cache plane (relative to eigval) each one comes from.
+//   0..8 eigvec 0..8 | 9, 10 s1, s2 (aux 0, 1) | 11..13 merged first moment (merged 6..8) | 14 1/N (aux 2) | 15 sqrt(coe) (aux 3) |
+//   16 lambda_0 (eigval 0) | 17 coe (its own plane)
+__host__ __device__ constexpr int k3_param_plane(int k) {
+  return k < 9 ? 3 + k : (k < 11 ? 22 + (k - 9) : (k < 14 ? 12 + 6 + (k - 11) : (k == 14 ? 24 : (k == 15 ? 25 : 0))));
+}
 template <int W>
-__device__ __forceinline__ void k3_load_params(const K3Planes& pl, int head, int end, int b, bool active, int vl, K3Entry& e) {
+struct K3Stage {
+  static constexpr int NV = K3Cfg<W>::NV;
+  static constexpr int NITEM = NV * 17;            // transposed items of the cache planes
+  static constexpr int Q = (NITEM + 63) / 64;      // load instructions (2 at W = 10, 4 at NV = 12)
+  static constexpr int REC = 18;                   // doubles per voxel record in LDS
+  static constexpr int WAVE_DOUBLES = NV * REC;    // per-wave staging area
+  double v[Q];      // item lane + 64 q
+  double coe;       // lane < NV: coe of voxel slot `lane`
+};
+// request the plane parameters of batch b (transposed); voxels outside [head, end) read voxel `head` instead (masked later)
+template <int W>
+__device__ __forceinline__ void k3_load_params(const K3Planes& pl, int head, int end, int b, int lane, K3Stage<W>& st) {
+  using S = K3Stage<W>;
+#pragma unroll
+  for (int q = 0; q < S::Q; q++) {
+    const int t = lane + 64 * q;
+    const int tv = t < S::NITEM ? t : 0;             // idle lanes of the last instruction re-read item 0
+    const int v = tv / 17, k = tv - 17 * v;
+    int a = b * S::NV + v;
+    a = (a >= head && a < end) ? a : head;
+    // plane index of parameter k: a short select chain on a lane constant (hoisted out of the step loop by the compiler)
+    int plane = 0;
+#pragma unroll
+    for (int kk = 0; kk < 17; kk++) plane = (k == kk) ? k3_param_plane(kk) : plane;
+    st.v[q] = k3_ld64(pl.cache, (unsigned)plane * pl.vs8 + (unsigned)a * 8u, 0);
+  }
+  {
+    int a = b * S::NV + (lane < S::NV ? lane : 0);
+    a = (a >= head && a < end) ? a : head;
+    st.coe = k3_ld64(pl.coe, (unsigned)a * 8u, 0);
+  }
+}
+// park the staged values in the wave's LDS corner and read back the lane's own voxel record
+template <int W>
+__device__ __forceinline__ void k3_unstage_params(const K3Stage<W>& st, double* stage_lds, int head, int end, int b, bool active, int vl, int lane,
+                                                  K3Entry& e) {
+  using S = K3Stage<W>;
   using C = K3Cfg<W>;
+#pragma unroll
+  for (int q = 0; q < S::Q; q++) {
+    const int t = lane + 64 * q;
+    if (t < S::NITEM) {
+      const int v = t / 17, k = t - 17 * v;
+      stage_lds[v * S::REC + k] = st.v[q];
+    }
+  }
+  if (lane < S::NV) stage_lds[lane * S::REC + 17] = st.coe;
+  __builtin_amdgcn_wave_barrier();   // same wave, LDS operations execute in order: a scheduling fence is all that is needed
   const int a = b * C::NV + vl;
   e.ok = active && a >= head && a < end;
-  const unsigned off = (unsigned)(e.ok ? a : head) * 8u;
-  const unsigned vs8 = pl.vs8;
+  const v2d* rec = reinterpret_cast<const v2d*>(stage_lds + vl * S::REC);
+  double r[18];
 #pragma unroll
-  for (int k = 0; k < 9; k++) e.u[k] = k3_ld64(pl.eigvec, off, k * vs8);
-  e.s1 = k3_ld64(pl.aux, off, 0);
-  e.s2 = k3_ld64(pl.aux, off, vs8);
+  for (int j = 0; j < 9; j++) { const v2d t = rec[j]; r[2 * j] = t[0]; r[2 * j + 1] = t[1]; }
 #pragma unroll
-  for (int k = 0; k < 3; k++) e.mv[k] = k3_ld64(pl.merged, off, (6 + k) * vs8);
-  e.invN = k3_ld64(pl.aux, off, 2 * vs8);
-  e.sc = k3_ld64(pl.aux, off, 3 * vs8);
-  e.coe = k3_ld64(pl.coe, off, 0);
-  e.lam0 = k3_ld64(pl.eigval, off, 0);
+  for (int k = 0; k < 9; k++) e.u[k] = r[k];
+  e.s1 = r[9]; e.s2 = r[10];
+  e.mv[0] = r[11]; e.mv[1] = r[12]; e.mv[2] = r[13];
+  e.invN = r[14]; e.sc = r[15]; e.lam0 = r[16]; e.coe = r[17];
 }
 
 // Phase A of one entry: rows of B_a (3 x 6) and the per-frame linear accumulators, branch-free.
@@ -317,7 +372,6 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   const int fi = active ? lane % W : 0;
   const int lrow = lane >> 4, lcol = lane & 15;
   const int set = wave % C::TSPLIT, kq = wave / C::TSPLIT;
-  const bool a_first = (wave >> 2) & 1;   // second wave of its SIMD: phase A before phase M
   const int gw = blockIdx.x * C::WAVES + wave;
   dbg_stamp(DBG, gw, 0);
 
@@ -335,7 +389,11 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   K3Entry e;
   e.ok = false;
   const K3Planes pl = k3_planes(fv);
-  if (wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, active, vl, e); }
+  K3Stage<W> stg;
+#pragma unroll
+  for (int q = 0; q < K3Stage<W>::Q; q++) stg.v[q] = 0.0;
+  stg.coe = 0.0;
+  if (wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
 
   // LDS behind the two tile buffers: both pose candidates (raw C-ABI layout: R column-major | p per frame) and what the LM
   // decision needs.  Only wave 0 of a workgroup talks to the control block: with all eight waves doing it (round 1 had every
@@ -344,6 +402,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   double* poseA = lds + 2 * C::BUF;       // current / kernel-argument / trial poses (what `xa_src` selects)
   double* poseB = poseA + 12 * W;         // trial poses (pending decision)
   double* lmv = poseB + 12 * W;           // [0] done, [1] calc_hess, [2] bench_mode, [3] residual1, [4] residual2
+  double* stage_lds = lmv + 8 + wave * K3Stage<W>::WAVE_DOUBLES;   // this wave's corner for redistributing the plane parameters
   if (wave == 0) {
     const int fl = lane < W ? lane : 0;
     if (st) {
@@ -413,86 +472,78 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   // step s: phase M of step s-1 (buffer (s-1)&1), phase A of step s (buffer s&1), one barrier
   for (int s = 0; s <= nsteps; s++) {
     const bool has_next = wave + (s + 1) * C::WAVES < cnt;
-    // Inside an iteration the order of phase M (step s-1) and phase A (step s) is free -- they touch different tile buffers -- so
-    // the two waves that share a SIMD (w and w + 4: a workgroup's waves are dealt to the SIMDs cyclically) take them in OPPOSITE
-    // order.  All eight waves in the same phase (the first version of this kernel) left the MFMA shadows empty during phase M
-    // and made the VALU the bottleneck during phase A: 11.8k cycles per step against 7.8k of fp64 work (profiles/r02_v2).
-    // A two-trip loop with a run-time order keeps one copy of each phase in the binary.
-#pragma nounroll
-    for (int half = 0; half < 2; half++) {
-      const bool do_m = (half == 0) != a_first;
-      if (do_m) {
     if (s >= 1) {
-          const int nb_prev = cnt - (s - 1) * C::WAVES;   // batches of step s-1
-          const int bo = ((s - 1) & 1) * C::BUF;
-          if (nb_prev >= C::WAVES) {
-            const int k0 = kq * C::KPW;
-            if (MIXED) {
-              const float* bf = reinterpret_cast<const float*>(lds) + bo;
-              if (C::TSPLIT == 1 || set == 0) k3_mfma_phase_f32<W, 0, true>(bf, k0, C::KPW, lrow, lcol, af);
-              else k3_mfma_phase_f32<W, C::TSPLIT - 1, true>(bf, k0, C::KPW, lrow, lcol, af);
-            } else {
-              if (C::TSPLIT == 1 || set == 0) k3_mfma_phase<W, 0, true>(lds + bo, k0, C::KPW, lrow, lcol, acc);
-              else k3_mfma_phase<W, C::TSPLIT - 1, true>(lds + bo, k0, C::KPW, lrow, lcol, acc);
-            }
-          } else {
-            // ragged last step: only ceil(nb_prev R / 4) K-steps exist; re-split them over the K ranges
-            const int ks = (nb_prev * C::R + 3) >> 2;
-            const int k0 = (kq * ks) / C::KSPLIT, k1 = ((kq + 1) * ks) / C::KSPLIT;
-            if (MIXED) {
-              const float* bf = reinterpret_cast<const float*>(lds) + bo;
-              if (C::TSPLIT == 1 || set == 0) k3_mfma_phase_f32<W, 0, false>(bf, k0, k1 - k0, lrow, lcol, af);
-              else k3_mfma_phase_f32<W, C::TSPLIT - 1, false>(bf, k0, k1 - k0, lrow, lcol, af);
-            } else {
-              if (C::TSPLIT == 1 || set == 0) k3_mfma_phase<W, 0, false>(lds + bo, k0, k1 - k0, lrow, lcol, acc);
-              else k3_mfma_phase<W, C::TSPLIT - 1, false>(lds + bo, k0, k1 - k0, lrow, lcol, acc);
-            }
-          }
+      const int nb_prev = cnt - (s - 1) * C::WAVES;   // batches of step s-1
+      const int bo = ((s - 1) & 1) * C::BUF;
+      if (nb_prev >= C::WAVES) {
+        const int k0 = kq * C::KPW;
+        if (MIXED) {
+          const float* bf = reinterpret_cast<const float*>(lds) + bo;
+          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase_f32<W, 0, true>(bf, k0, C::KPW, lrow, lcol, af);
+          else k3_mfma_phase_f32<W, C::TSPLIT - 1, true>(bf, k0, C::KPW, lrow, lcol, af);
+        } else {
+          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase<W, 0, true>(lds + bo, k0, C::KPW, lrow, lcol, acc);
+          else k3_mfma_phase<W, C::TSPLIT - 1, true>(lds + bo, k0, C::KPW, lrow, lcol, acc);
         }
-      } else if (s < nsteps) {
-        const int nb = cnt - s * C::WAVES;   // batches of this step (>= 1)
-        const int bo = (s & 1) * C::BUF;
-        if (wave < nb) {
-          double rows[3][6];
-          // voxel-level values for the spare columns, taken before phase A masks / consumes the entry
-          const double spare_s = 1.4142135623730951 * e.sc;
-          const double spare[3] = {spare_s * e.u[0], spare_s * e.u[1], spare_s * e.u[2]};
-          k3_phase_a<!C::SPARE>(e, fi, pose, rows, dacc);
-          if (active) {
-            // the nine store offsets are recomputed from (vl, fi) every step -- a handful of integer operations under the other
-            // wave's fp64 work -- instead of living in registers (or scratch) across phase M
-            int vl_ = vl, fi_ = fi;
-            asm volatile("" : "+v"(vl_), "+v"(fi_));
-            const K3RowOfs ro = k3_row_offsets<W>(wave, vl_, fi_);
-            if (MIXED) k3_store_rows_f32(reinterpret_cast<float*>(lds) + bo, ro, rows);
-            else k3_store_rows(lds + bo, ro, rows);
-            if (C::SPARE && fi_ == W - 1) {   // one lane per voxel: columns 6W .. 6W+2 of the z row
-              const int o = ro.rp[2] + C::at(0, 6 * W);
-              if (MIXED) {
-                float* zf = reinterpret_cast<float*>(lds) + bo + o;
-                *reinterpret_cast<v2f*>(zf) = (v2f){(float)spare[0], (float)spare[1]};
-                zf[2] = (float)spare[2];
-              } else {
-                double* zd = lds + bo + o;
-                *reinterpret_cast<v2d*>(zd) = (v2d){spare[0], spare[1]};
-                zd[2] = spare[2];
-              }
-            }
-          }
-          // next batch of this wave: in flight during the barrier and a whole phase M.  (Requesting the cluster rows a step
-          // earlier into a second register set was measured and changed nothing: the loads were not what the steps waited for.)
-          if (has_next) {
-            k3_load_clusters(pl, bs + (s + 1) * C::WAVES + wave, lane, e.c);
-            k3_load_params<W>(pl, head, end, bs + (s + 1) * C::WAVES + wave, active, vl, e);
-          }
-        } else if (wave == nb) {
-          // first idle wave of the ragged step: the rows that round the step up to a whole K-step must read as zeros
-          if (MIXED) { float* z = reinterpret_cast<float*>(lds) + bo + C::at(nb * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0f; }
-          else { double* z = lds + bo + C::at(nb * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0; }
+      } else {
+        // ragged last step: only ceil(nb_prev R / 4) K-steps exist; re-split them over the K ranges
+        const int ks = (nb_prev * C::R + 3) >> 2;
+        const int k0 = (kq * ks) / C::KSPLIT, k1 = ((kq + 1) * ks) / C::KSPLIT;
+        if (MIXED) {
+          const float* bf = reinterpret_cast<const float*>(lds) + bo;
+          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase_f32<W, 0, false>(bf, k0, k1 - k0, lrow, lcol, af);
+          else k3_mfma_phase_f32<W, C::TSPLIT - 1, false>(bf, k0, k1 - k0, lrow, lcol, af);
+        } else {
+          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase<W, 0, false>(lds + bo, k0, k1 - k0, lrow, lcol, acc);
+          else k3_mfma_phase<W, C::TSPLIT - 1, false>(lds + bo, k0, k1 - k0, lrow, lcol, acc);
         }
       }
     }
+    if (s >= 1 && s <= 4) dbg_stamp(DBG, gw, 13 + 3 * s);   // phase M of step s-1 done: slots 16, 19, 22, 25
     if (s == nsteps) break;
+    const int nb = cnt - s * C::WAVES;   // batches of this step (>= 1)
+    const int bo = (s & 1) * C::BUF;
+    if (wave < nb) {
+      double rows[3][6];
+      k3_unstage_params<W>(stg, stage_lds, head, end, bs + s * C::WAVES + wave, active, vl, lane, e);
+      // voxel-level values for the spare columns, taken before phase A masks / consumes the entry
+      const double spare_s = 1.4142135623730951 * e.sc;
+      const double spare[3] = {spare_s * e.u[0], spare_s * e.u[1], spare_s * e.u[2]};
+      k3_phase_a<!C::SPARE>(e, fi, pose, rows, dacc);
+      if (active) {
+        // the nine store offsets are recomputed from (vl, fi) every step -- a handful of integer operations under the other
+        // wave's fp64 work -- instead of living in registers (or scratch) across phase M
+        int vl_ = vl, fi_ = fi;
+        asm volatile("" : "+v"(vl_), "+v"(fi_));
+        const K3RowOfs ro = k3_row_offsets<W>(wave, vl_, fi_);
+        if (MIXED) k3_store_rows_f32(reinterpret_cast<float*>(lds) + bo, ro, rows);
+        else k3_store_rows(lds + bo, ro, rows);
+        if (C::SPARE && fi_ == W - 1) {   // one lane per voxel: columns 6W .. 6W+2 of the z row
+          const int o = ro.rp[2] + C::at(0, 6 * W);
+          if (MIXED) {
+            float* zf = reinterpret_cast<float*>(lds) + bo + o;
+            *reinterpret_cast<v2f*>(zf) = (v2f){(float)spare[0], (float)spare[1]};
+            zf[2] = (float)spare[2];
+          } else {
+            double* zd = lds + bo + o;
+            *reinterpret_cast<v2d*>(zd) = (v2d){spare[0], spare[1]};
+            zd[2] = spare[2];
+          }
+        }
+      }
+      // next batch of this wave: in flight during the barrier and the whole of phase M.  Measured and rejected (round 2, same
+      // box): the cluster rows requested a step earlier into a second register set (no change: the steps do not wait for loads);
+      // the two waves of a SIMD taking phase M / phase A in opposite order (13.2k instead of 11.8k cycles per step).
+      if (has_next) {
+        k3_load_clusters(pl, bs + (s + 1) * C::WAVES + wave, lane, e.c);
+        k3_load_params<W>(pl, head, end, bs + (s + 1) * C::WAVES + wave, lane, stg);
+      }
+    } else if (wave == nb) {
+      // first idle wave of the ragged step: the rows that round the step up to a whole K-step must read as zeros
+      if (MIXED) { float* z = reinterpret_cast<float*>(lds) + bo + C::at(nb * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0f; }
+      else { double* z = lds + bo + C::at(nb * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0; }
+    }
+    if (s >= 1 && s <= 4) dbg_stamp(DBG, gw, 14 + 3 * s);   // phase A of step s done (before the barrier): slots 17, 20, 23, 26
     __syncthreads();
     if (s < 6) dbg_stamp(DBG, gw, 8 + s);
   }

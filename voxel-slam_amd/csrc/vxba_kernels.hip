@@ -945,7 +945,7 @@ int k3_grid_blocks(int device_cus) { return device_cus; }  // one 8-wave workgro
 template <int W>
 constexpr size_t k3_lds_bytes() {
   using C = K3Cfg<W>;
-  constexpr size_t main_d = (size_t)2 * C::BUF + 24 * W + 8;   // tiles | two pose candidates | LM decision inputs
+  constexpr size_t main_d = (size_t)2 * C::BUF + 24 * W + 8 + (size_t)C::WAVES * K3Stage<W>::WAVE_DOUBLES;   // tiles | two pose candidates | LM decision inputs | parameter staging
   // epilogue: parked linear accumulators, then (or, when both fit, beside them) the parked MFMA accumulators
   constexpr size_t epi1 = (size_t)K3_BLOCK * K3Epi<W>::DS, epi2 = (size_t)C::WAVES * C::TPW * 256;
   constexpr size_t epi = K3Epi<W>::ONE_PHASE ? epi1 + epi2 : (epi1 > epi2 ? epi1 : epi2);
@@ -962,6 +962,11 @@ int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, LMState* st
     fv.eigvec = fv.eigval + 3 * VS;
     fv.merged = fv.eigvec + 9 * VS;
     fv.aux = fv.merged + 10 * VS;
+  }
+  {  // the sweep addresses the cache as 26 consecutive planes behind eigval (one buffer descriptor): true for the factor's live
+     // cache and for snapshots; refuse anything else loudly rather than read the wrong plane
+    const size_t VS = (size_t)fv.VS;
+    if (fv.eigvec != fv.eigval + 3 * VS || fv.merged != fv.eigvec + 9 * VS || fv.aux != fv.merged + 10 * VS) return -1;
   }
   static int dbg = -1;   // development knob: VXBA_DBG=1 runs the s_memtime-instrumented instantiation
   if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
