@@ -35,12 +35,48 @@ class Cfg:
     def at(s, row, col):
         return (row >> 1) * 2 * s.NCOL + (col >> 4) * 32 + (row & 1) * 16 + (col & 15)
 
-    def tile_IJ(s, t):
+    def _upper(s, t):
         I = 0
         while t >= s.NT - I:
             t -= s.NT - I
             I += 1
         return I, I + t
+
+    # operand slots: tile j of a wave multiplies slot pa(j) (rows) with slot pb(j) (columns); the column tile a slot reads depends on the set
+    @property
+    def NSLOT(s):
+        return 4 if s.NT == 4 else (6 if s.NT == 3 else s.NT)
+
+    def pa(s, j):
+        return (j if j < 3 else j - 2) if s.NT == 4 else (2 * j if s.NT == 3 else s._upper(j)[0])
+
+    def pb(s, j):
+        return (j + 1 if j < 3 else j - 2) if s.NT == 4 else (2 * j + 1 if s.NT == 3 else s._upper(j)[1])
+
+    def slot_tile(s, st, k):
+        if s.NT == 4:
+            return k if st == 0 else (2, 0, 3, 1)[k]
+        if s.NT == 3:
+            return (0, 0, 0, 1, 1, 1)[k] if st == 0 else (2, 2, 0, 2, 1, 2)[k]
+        return k
+
+    def rowtile(s, t):
+        return s.slot_tile(t // s.TPW, s.pa(t % s.TPW))
+
+    def coltile(s, t):
+        return s.slot_tile(t // s.TPW, s.pb(t % s.TPW))
+
+    def elem_offset(s, r, c):
+        I, J = r >> 4, c >> 4
+        for t in range(s.NTP):
+            if s.rowtile(t) == I and s.coltile(t) == J:
+                row, col = r - 16 * I, c - 16 * J
+            elif s.rowtile(t) == J and s.coltile(t) == I:
+                row, col = c - 16 * J, r - 16 * I
+            else:
+                continue
+            return t * 256 + (row >> 2) * 64 + ((row & 3) << 4) + col
+        return -1
 
 
 def sym6_index(a, b):
@@ -101,64 +137,69 @@ def run_model(W, V, head, end, G, rng):
     for g in range(G):
         cnt = q + (1 if g < rem else 0)
         bs = b0 + g * q + min(g, rem)
-        nsteps = (cnt + WAVES - 1) // WAVES
         covered += list(range(bs, bs + cnt))
         lds = np.full((2, C.BUF), 0.0)
         acc = np.zeros((WAVES, C.TPW, 4, 64))          # [wave][tile j][register r][lane]
         dacc = np.zeros((WAVES, 64, DACC))
-        for s in range(nsteps + 1):
-            if s >= 1:
-                nb_prev = cnt - (s - 1) * WAVES
-                buf = lds[(s - 1) & 1]
-                for wave in range(WAVES):
-                    st, kq = wave % C.TSPLIT, wave // C.TSPLIT
-                    if nb_prev >= WAVES:
-                        k0, nk = kq * C.KPW, C.KPW
-                    else:
-                        ks = (nb_prev * C.R + 3) >> 2
-                        k0 = (kq * ks) // C.KSPLIT
-                        nk = ((kq + 1) * ks) // C.KSPLIT - k0
-                    for kk in range(nk):
-                        x = np.zeros((C.NT, 64))
-                        for lane in range(64):
-                            lrow, lcol = lane >> 4, lane & 15
-                            base = C.at(4 * k0 + lrow, lcol)
-                            for c in range(C.NT):
-                                x[c, lane] = buf[base + kk * 4 * C.NCOL + 32 * c]
-                        for j in range(C.TPW):
-                            I, Jt = C.tile_IJ(st * C.TPW + j)
-                            # v_mfma_f64_16x16x4: A[i][k] in lane 16k+i, B[k][jj] in lane 16k+jj, D[(l/16)+4r][l%16] in register r of lane l
-                            A = x[I].reshape(4, 16).T      # [i][k]
-                            Bm = x[Jt].reshape(4, 16)      # [k][jj]
-                            D = A @ Bm
-                            for lane in range(64):
-                                for r in range(4):
-                                    acc[wave, j, r, lane] += D[(lane >> 4) + 4 * r, lane & 15]
-            if s == nsteps:
-                break
-            nb = cnt - s * WAVES
-            buf = lds[s & 1]
+
+        def phase_m(buf, nb_prev):
             for wave in range(WAVES):
-                if wave < nb:
-                    b = bs + s * WAVES + wave
-                    for lane in range(C.NV * W):
-                        vl, fi = lane // W, lane % W
-                        a = b * C.NV + vl
-                        ok = head <= a < end
-                        rws = rows[a, fi] if ok and a < V else np.zeros((3, 6))
-                        if ok:
-                            dacc[wave, lane] += lin[a, fi]
-                        for r in range(3):
-                            for jj in range(3):
-                                o = C.at(wave * C.R + 3 * vl + r, 0) + C.at(0, 6 * fi + 2 * jj)
-                                buf[o] = rws[r, 2 * jj]; buf[o + 1] = rws[r, 2 * jj + 1]
-                        if C.SPARE and fi == W - 1:
-                            o = C.at(wave * C.R + 3 * vl + 2, 0) + C.at(0, 6 * W)
-                            sp = spare[a] if a < V else np.ones(3)    # an out-of-range slot carries some finite voxel's values
-                            buf[o], buf[o + 1], buf[o + 2] = sp
-                elif wave == nb:
-                    z0 = C.at(nb * C.R, 0)
+                st, kq = wave % C.TSPLIT, wave // C.TSPLIT
+                if nb_prev >= WAVES:
+                    k0, nk = kq * C.KPW, C.KPW
+                else:
+                    ks = (nb_prev * C.R + 3) >> 2
+                    k0 = (kq * ks) // C.KSPLIT
+                    nk = ((kq + 1) * ks) // C.KSPLIT - k0
+                for kk in range(nk):
+                    x = np.zeros((C.NSLOT, 64))
+                    for lane in range(64):
+                        lrow, lcol = lane >> 4, lane & 15
+                        for k in range(C.NSLOT):
+                            x[k, lane] = buf[C.at(4 * k0 + lrow, lcol) + 32 * C.slot_tile(st, k) + kk * 4 * C.NCOL]
+                    for j in range(C.TPW):
+                        # v_mfma_f64_16x16x4: A[i][k] in lane 16k+i, B[k][jj] in lane 16k+jj, D[(l/16)+4r][l%16] in register r of lane l
+                        A = x[C.pa(j)].reshape(4, 16).T      # [i][k]
+                        Bm = x[C.pb(j)].reshape(4, 16)       # [k][jj]
+                        D = A @ Bm
+                        for lane in range(64):
+                            for r in range(4):
+                                acc[wave, j, r, lane] += D[(lane >> 4) + 4 * r, lane & 15]
+
+        def phase_a(buf, wave, b):
+            for lane in range(C.NV * W):
+                vl, fi = lane // W, lane % W
+                a = b * C.NV + vl
+                ok = head <= a < end
+                rws = rows[a, fi] if ok and a < V else np.zeros((3, 6))
+                if ok:
+                    dacc[wave, lane] += lin[a, fi]
+                for r in range(3):
+                    for jj in range(3):
+                        o = C.at(wave * C.R + 3 * vl + r, 0) + C.at(0, 6 * fi + 2 * jj)
+                        buf[o] = rws[r, 2 * jj]; buf[o + 1] = rws[r, 2 * jj + 1]
+                if C.SPARE and fi == W - 1:
+                    o = C.at(wave * C.R + 3 * vl + 2, 0) + C.at(0, 6 * W)
+                    sp = spare[a] if a < V else np.ones(3)    # an out-of-range slot carries some finite voxel's values
+                    buf[o], buf[o + 1], buf[o + 2] = sp
+
+        nfull, nrag = cnt // WAVES, cnt % WAVES
+        for s in range(nfull + 1):
+            if s >= 1:
+                phase_m(lds[(s - 1) & 1], WAVES)
+            if s == nfull:
+                break
+            for wave in range(WAVES):
+                phase_a(lds[s & 1], wave, bs + s * WAVES + wave)
+        if nrag > 0:
+            buf = lds[nfull & 1]
+            for wave in range(WAVES):
+                if wave < nrag:
+                    phase_a(buf, wave, bs + nfull * WAVES + wave)
+                elif wave == nrag:
+                    z0 = C.at(nrag * C.R, 0)
                     buf[z0:z0 + 4 * C.NCOL] = 0.0
+            phase_m(buf, nrag)
         # epilogue
         pout = partial[g]
         for el in range(W * DACC):
@@ -177,18 +218,19 @@ def run_model(W, V, head, end, G, rng):
     for e in range(PLEN):
         if e < NTILE:
             t, j, l = e >> 8, (e >> 6) & 3, e & 63
-            I, Jt = C.tile_IJ(t)
-            r = 16 * I + (l >> 4) + 4 * j
-            c = 16 * Jt + (l & 15)
+            rt, ct = C.rowtile(t), C.coltile(t)
+            r = 16 * rt + (l >> 4) + 4 * j
+            c = 16 * ct + (l & 15)
+            if rt > ct:
+                r, c = c, r
             if r >= n or c >= n or r > c:
                 continue
             t1 = 0.0
             if r // 6 == c // 6:
                 i, a, b = r // 6, r % 6, c % 6
                 if C.SPARE and b >= 3:
-                    c2 = n + (b - 3); I2, J2 = r >> 4, c2 >> 4
-                    t2 = I2 * C.NT - (I2 * (I2 - 1)) // 2 + (J2 - I2); row2, col2 = r - 16 * I2, c2 - 16 * J2
-                    off1 = t2 * 256 + (row2 >> 2) * 64 + ((row2 & 3) << 4) + col2
+                    off1 = C.elem_offset(r, n + (b - 3))
+                    assert off1 >= 0
                 else:
                     if b < 3: d = 6 + sym6_index(a, b)
                     elif a < 3: d = 12 + 3 * a + (b - 3)

@@ -53,14 +53,42 @@ struct K3Cfg {
   static constexpr int BUF = ROWS * NCOL;             // doubles (f64) or floats (mixed) per tile buffer
   __host__ __device__ static constexpr int at(int row, int col) { return (row >> 1) * 2 * NCOL + (col >> 4) * 32 + (row & 1) * 16 + (col & 15); }
   static_assert(ROWS % 4 == 0 && NTP % TSPLIT == 0 && KS % KSPLIT == 0, "step geometry");
-};
 
-// tile pair t (row-major over the upper triangle) -> (I, J)
-__host__ __device__ constexpr int k3_tile_I(int NT, int t) { int I = 0; while (t >= NT - I) { t -= NT - I; I++; } return I; }
-__host__ __device__ constexpr int k3_tile_J(int NT, int t) { int I = 0; while (t >= NT - I) { t -= NT - I; I++; } return I + t; }
-// column tiles touched by tile set SET as A (row) operand / as B (column) operand, one bit per column tile
-__host__ __device__ constexpr unsigned k3_need_rows(int NT, int TPW, int SET) { unsigned m = 0; for (int j = 0; j < TPW; j++) m |= 1u << k3_tile_I(NT, SET * TPW + j); return m; }
-__host__ __device__ constexpr unsigned k3_need_cols(int NT, int TPW, int SET) { unsigned m = 0; for (int j = 0; j < TPW; j++) m |= 1u << k3_tile_J(NT, SET * TPW + j); return m; }
+  // Which tile pairs a wave multiplies.  Both tile sets run the SAME instruction stream: tile j of a wave multiplies operand
+  // slot pa(j) (rows) with operand slot pb(j) (columns); only the column tile an operand slot reads differs between the sets
+  // (a wave-uniform LDS offset).  With a run-time branch between two differently shaped sets the accumulators changed registers
+  // at every merge point -- ~100 v_mov_b64 per wave and step.
+  //   NT = 4: the six off-diagonal pairs of four column tiles split into two PATHS, 0-1-2-3 and 2-0-3-1 (the path graph on four
+  //           nodes is self-complementary), each set taking the diagonal tiles of its path's two inner nodes: slots a-b-c-d,
+  //           pairs (a,b) (b,c) (c,d) (b,b) (c,c).  Set 1 therefore holds (2,0) and (3,1) as LOWER tiles; k3_finalize and the
+  //           spare-column lookup go through rowtile() / coltile().
+  //   NT = 3: no symmetric split exists (three diagonal tiles); every tile gets its own two operand slots.
+  //   NT <= 2: one set, slots = column tiles.
+  static constexpr int NSLOT = (NT == 4) ? 4 : (NT == 3 ? 6 : NT);
+  __host__ __device__ static constexpr int pa(int j) { return NT == 4 ? (j < 3 ? j : j - 2) : (NT == 3 ? 2 * j : k3_tile_I_(NT, j)); }
+  __host__ __device__ static constexpr int pb(int j) { return NT == 4 ? (j < 3 ? j + 1 : j - 2) : (NT == 3 ? 2 * j + 1 : k3_tile_J_(NT, j)); }
+  __host__ __device__ static constexpr int slot_tile(int set, int k) {
+    if (NT == 4) return set == 0 ? k : (k == 0 ? 2 : (k == 1 ? 0 : (k == 2 ? 3 : 1)));
+    if (NT == 3) return set == 0 ? (k < 3 ? 0 : 1) : (k == 2 ? 0 : (k == 4 ? 1 : 2));   // set 0: (0,0) (0,1) (1,1); set 1: (2,2) (0,2) (1,2)
+    return k;
+  }
+  // tile t = set * TPW + j accumulates S[16 rowtile + i][16 coltile + jj]
+  __host__ __device__ static constexpr int rowtile(int t) { return slot_tile(t / TPW, pa(t % TPW)); }
+  __host__ __device__ static constexpr int coltile(int t) { return slot_tile(t / TPW, pb(t % TPW)); }
+  // offset inside a workgroup partial of S[r][c], r <= c (f64 MFMA accumulator layout: register (row >> 2), lane ((row & 3) << 4) | col)
+  __host__ __device__ static constexpr int elem_offset(int r, int c) {
+    const int I = r >> 4, J = c >> 4;
+    for (int t = 0; t < NTP; t++) {
+      int row = -1, col = -1;
+      if (rowtile(t) == I && coltile(t) == J) { row = r - 16 * I; col = c - 16 * J; }
+      else if (rowtile(t) == J && coltile(t) == I) { row = c - 16 * J; col = r - 16 * I; }
+      if (row >= 0) return t * 256 + (row >> 2) * 64 + ((row & 3) << 4) + col;
+    }
+    return -1;
+  }
+  __host__ __device__ static constexpr int k3_tile_I_(int nt, int t) { int I = 0; while (t >= nt - I) { t -= nt - I; I++; } return I; }
+  __host__ __device__ static constexpr int k3_tile_J_(int nt, int t) { int I = 0; while (t >= nt - I) { t -= nt - I; I++; } return I + t; }
+};
 
 // Register image of one (voxel, frame) entry plus the voxel's cached plane parameters.
 struct K3Entry {
@@ -248,45 +276,51 @@ __device__ __forceinline__ void k3_store_rows_f32(float* buf, const K3RowOfs& ro
     for (int j = 0; j < 3; j++) *reinterpret_cast<v2f*>(buf + ro.rp[r] + ro.cp[j]) = (v2f){(float)rows[r][2 * j], (float)rows[r][2 * j + 1]};
 }
 
-// Phase M: K-steps [k0, k0 + nk) of the tile in `buf` into the accumulators of tile set SET.  Lane l supplies row 4k + l/16,
-// column 16c + l%16 of column tile c -- the SAME register serves as A and B operand.  FULL: nk == KPW at compile time.
-// (The tile indices are template constants: as plain constexpr calls inside the loop they were evaluated at run time.)
-template <int W, int SET, int J>
+// Phase M: K-steps [k0, k0 + nk) of the tile in `buf` into the wave's accumulators.  Lane l supplies row 4k + l/16, column
+// 16c + l%16 of the column tile c its operand slot reads -- one register serves as A and as B operand.  FULL: nk == KPW at
+// compile time.  (The slot indices are template constants: as plain constexpr calls inside the loop they were evaluated at run time.)
+template <int W, int J>
 __device__ __forceinline__ void k3_mfma_tiles(const double* x, v4d* acc) {
   using C = K3Cfg<W>;
   if constexpr (J < C::TPW) {
-    constexpr int t = SET * C::TPW + J, TI = k3_tile_I(C::NT, t), TJ = k3_tile_J(C::NT, t);
-    acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[TI], x[TJ], acc[J], 0, 0, 0);
-    k3_mfma_tiles<W, SET, J + 1>(x, acc);
+    acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[C::pa(J)], x[C::pb(J)], acc[J], 0, 0, 0);
+    k3_mfma_tiles<W, J + 1>(x, acc);
   }
 }
-template <int W, int SET, bool FULL>
-__device__ __forceinline__ void k3_mfma_phase(const double* buf, int k0, int nk, int lrow, int lcol, v4d* acc) {
+// element offset of operand slot k's column tile for tile set `set` (wave-uniform select between two constants)
+template <int W>
+__device__ __forceinline__ int k3_slot_offset(int set, int k) {
   using C = K3Cfg<W>;
-  constexpr unsigned NEED = k3_need_rows(C::NT, C::TPW, SET) | k3_need_cols(C::NT, C::TPW, SET);   // column tiles this set touches
-  const double* base = buf + C::at(4 * k0 + lrow, lcol);   // K-step kk: + kk * 4 NCOL, column tile c: + 32 c
+  return 32 * (set == 0 ? C::slot_tile(0, k) : C::slot_tile(C::TSPLIT - 1, k));
+}
+template <int W, bool FULL>
+__device__ __forceinline__ void k3_mfma_phase(const double* buf, int set, int k0, int nk, int lrow, int lcol, v4d* acc) {
+  using C = K3Cfg<W>;
+  const double* bp[C::NSLOT];   // K-step kk: + kk * 4 NCOL
+#pragma unroll
+  for (int k = 0; k < C::NSLOT; k++) bp[k] = buf + C::at(4 * k0 + lrow, lcol) + k3_slot_offset<W>(set, k);
   if (FULL) {
     // operands of K-step kk+1 are requested before the MFMAs of K-step kk are issued
-    double x[C::NT], xn[C::NT];
+    double x[C::NSLOT], xn[C::NSLOT];
 #pragma unroll
-    for (int c = 0; c < C::NT; c++) x[c] = ((NEED >> c) & 1) ? base[32 * c] : 0.0;
+    for (int k = 0; k < C::NSLOT; k++) x[k] = bp[k][0];
 #pragma unroll
     for (int kk = 0; kk < C::KPW; kk++) {
       if (kk + 1 < C::KPW) {
 #pragma unroll
-        for (int c = 0; c < C::NT; c++) xn[c] = ((NEED >> c) & 1) ? base[(kk + 1) * 4 * C::NCOL + 32 * c] : 0.0;
+        for (int k = 0; k < C::NSLOT; k++) xn[k] = bp[k][(kk + 1) * 4 * C::NCOL];
         __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the MFMAs (the scheduler sinks them to their first use otherwise)
       }
-      k3_mfma_tiles<W, SET, 0>(x, acc);
+      k3_mfma_tiles<W, 0>(x, acc);
 #pragma unroll
-      for (int c = 0; c < C::NT; c++) x[c] = xn[c];
+      for (int k = 0; k < C::NSLOT; k++) x[k] = xn[k];
     }
   } else {
     for (int kk = 0; kk < nk; kk++) {
-      double x[C::NT];
+      double x[C::NSLOT];
 #pragma unroll
-      for (int c = 0; c < C::NT; c++) x[c] = ((NEED >> c) & 1) ? base[kk * 4 * C::NCOL + 32 * c] : 0.0;
-      k3_mfma_tiles<W, SET, 0>(x, acc);
+      for (int k = 0; k < C::NSLOT; k++) x[k] = bp[k][kk * 4 * C::NCOL];
+      k3_mfma_tiles<W, 0>(x, acc);
     }
   }
 }
@@ -295,42 +329,51 @@ __device__ __forceinline__ void k3_mfma_phase(const double* buf, int k0, int nk,
 // the cross-workgroup reduction and the all-reduce -- "fp32 Jacobian, fp64 Hessian accumulation".  The f32 instruction leaves
 // D(4 (l/16) + r, l % 16) in register r of lane l, the f64 one D((l/16) + 4 r, l % 16); feeding the A operand with the rows
 // permuted by  m -> (m >> 2) + 4 (m & 3)  makes the two maps coincide, so the epilogue and k3_finalize are shared.
-template <int W, int SET, int J>
+template <int W, int J>
 __device__ __forceinline__ void k3_mfma_tiles_f32(const float* xa, const float* xb, v4f* af) {
   using C = K3Cfg<W>;
   if constexpr (J < C::TPW) {
-    constexpr int t = SET * C::TPW + J, TI = k3_tile_I(C::NT, t), TJ = k3_tile_J(C::NT, t);
-    af[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[TI], xb[TJ], af[J], 0, 0, 0);
-    k3_mfma_tiles_f32<W, SET, J + 1>(xa, xb, af);
+    af[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[C::pa(J)], xb[C::pb(J)], af[J], 0, 0, 0);
+    k3_mfma_tiles_f32<W, J + 1>(xa, xb, af);
   }
 }
-template <int W, int SET, bool FULL>
-__device__ __forceinline__ void k3_mfma_phase_f32(const float* buf, int k0, int nk, int lrow, int lcol, v4f* af) {
+template <int W>
+__host__ __device__ constexpr unsigned k3_slots_as_a() { unsigned m = 0; for (int j = 0; j < K3Cfg<W>::TPW; j++) m |= 1u << K3Cfg<W>::pa(j); return m; }
+template <int W>
+__host__ __device__ constexpr unsigned k3_slots_as_b() { unsigned m = 0; for (int j = 0; j < K3Cfg<W>::TPW; j++) m |= 1u << K3Cfg<W>::pb(j); return m; }
+template <int W, bool FULL>
+__device__ __forceinline__ void k3_mfma_phase_f32(const float* buf, int set, int k0, int nk, int lrow, int lcol, v4f* af) {
   using C = K3Cfg<W>;
-  constexpr unsigned NEEDA = k3_need_rows(C::NT, C::TPW, SET), NEEDB = k3_need_cols(C::NT, C::TPW, SET);
+  constexpr unsigned NEEDA = k3_slots_as_a<W>(), NEEDB = k3_slots_as_b<W>();
   const int pcol = (lcol >> 2) + 4 * (lcol & 3);
-  const float* baseb = buf + C::at(4 * k0 + lrow, lcol);
-  const float* basea = buf + C::at(4 * k0 + lrow, pcol);
+  const float* bpa[C::NSLOT];
+  const float* bpb[C::NSLOT];
+#pragma unroll
+  for (int k = 0; k < C::NSLOT; k++) {
+    bpb[k] = buf + C::at(4 * k0 + lrow, lcol) + k3_slot_offset<W>(set, k);
+    bpa[k] = buf + C::at(4 * k0 + lrow, pcol) + k3_slot_offset<W>(set, k);
+  }
+  const int kend = FULL ? C::KPW : nk;
   if (FULL) {
 #pragma unroll
     for (int kk = 0; kk < C::KPW; kk++) {
-      float xa[C::NT], xb[C::NT];
+      float xa[C::NSLOT], xb[C::NSLOT];
 #pragma unroll
-      for (int c = 0; c < C::NT; c++) {
-        xb[c] = ((NEEDB >> c) & 1) ? baseb[kk * 4 * C::NCOL + 32 * c] : 0.0f;
-        xa[c] = ((NEEDA >> c) & 1) ? basea[kk * 4 * C::NCOL + 32 * c] : 0.0f;
+      for (int k = 0; k < C::NSLOT; k++) {
+        xb[k] = ((NEEDB >> k) & 1) ? bpb[k][kk * 4 * C::NCOL] : 0.0f;
+        xa[k] = ((NEEDA >> k) & 1) ? bpa[k][kk * 4 * C::NCOL] : 0.0f;
       }
-      k3_mfma_tiles_f32<W, SET, 0>(xa, xb, af);
+      k3_mfma_tiles_f32<W, 0>(xa, xb, af);
     }
   } else {
-    for (int kk = 0; kk < nk; kk++) {
-      float xa[C::NT], xb[C::NT];
+    for (int kk = 0; kk < kend; kk++) {
+      float xa[C::NSLOT], xb[C::NSLOT];
 #pragma unroll
-      for (int c = 0; c < C::NT; c++) {
-        xb[c] = ((NEEDB >> c) & 1) ? baseb[kk * 4 * C::NCOL + 32 * c] : 0.0f;
-        xa[c] = ((NEEDA >> c) & 1) ? basea[kk * 4 * C::NCOL + 32 * c] : 0.0f;
+      for (int k = 0; k < C::NSLOT; k++) {
+        xb[k] = ((NEEDB >> k) & 1) ? bpb[k][kk * 4 * C::NCOL] : 0.0f;
+        xa[k] = ((NEEDA >> k) & 1) ? bpa[k][kk * 4 * C::NCOL] : 0.0f;
       }
-      k3_mfma_tiles_f32<W, SET, 0>(xa, xb, af);
+      k3_mfma_tiles_f32<W, 0>(xa, xb, af);
     }
   }
 }
@@ -382,10 +425,11 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   const int g = blockIdx.x;
   const int cnt = q + (g < rem ? 1 : 0);
   const int bs = b0 + g * q + (g < rem ? g : rem);
-  const int nsteps = (cnt + C::WAVES - 1) / C::WAVES;
 
   // The first batch is requested before anything else: it does not depend on the poses, so the LM decision below (a few
-  // dependent global reads) runs in the shadow of these loads.
+  // dependent global reads) runs in the shadow of these loads.  Wave 0 is the exception: loads return in order, so it asks for
+  // the control block FIRST and for its batch afterwards -- behind 12 MB of cold first-batch requests from the whole chip its
+  // decision arrived 7.6k cycles into the kernel with every other wave waiting at the barrier.
   K3Entry e;
   e.ok = false;
   const K3Planes pl = k3_planes(fv);
@@ -393,7 +437,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
 #pragma unroll
   for (int q = 0; q < K3Stage<W>::Q; q++) stg.v[q] = 0.0;
   stg.coe = 0.0;
-  if (wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
+  if (wave != 0 && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
 
   // LDS behind the two tile buffers: both pose candidates (raw C-ABI layout: R column-major | p per frame) and what the LM
   // decision needs.  Only wave 0 of a workgroup talks to the control block: with all eight waves doing it (round 1 had every
@@ -428,6 +472,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
 #pragma unroll
       for (int k = 0; k < 12; k++) poseA[12 * lane + k] = poses.Rp[12 * lane + k];
     }
+    if (cnt > 0) { k3_load_clusters(pl, bs, lane, e.c); k3_load_params<W>(pl, head, end, bs, lane, stg); }
   }
   // both tile buffers start as zeros: padding columns (6W .. NCOL) are never written
   {
@@ -469,83 +514,77 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
 #pragma unroll
   for (int k = 0; k < DACC; k++) dacc[k] = 0.0;
 
-  // step s: phase M of step s-1 (buffer (s-1)&1), phase A of step s (buffer s&1), one barrier
-  for (int s = 0; s <= nsteps; s++) {
-    const bool has_next = wave + (s + 1) * C::WAVES < cnt;
+  // Phase A of the wave's batch b into tile buffer `bo`, then the requests for its next batch nb (nb < 0: none).
+  auto phase_a = [&](int b, int bo, int nb) {
+    double rows[3][6];
+    k3_unstage_params<W>(stg, stage_lds, head, end, b, active, vl, lane, e);
+    // voxel-level values for the spare columns, taken before phase A masks / consumes the entry
+    const double spare_s = 1.4142135623730951 * e.sc;
+    const double spare[3] = {spare_s * e.u[0], spare_s * e.u[1], spare_s * e.u[2]};
+    k3_phase_a<!C::SPARE>(e, fi, pose, rows, dacc);
+    if (active) {
+      // the nine store offsets are recomputed from (vl, fi) every step -- a handful of integer operations -- instead of living
+      // in registers (or scratch) across phase M
+      int vl_ = vl, fi_ = fi;
+      asm volatile("" : "+v"(vl_), "+v"(fi_));
+      const K3RowOfs ro = k3_row_offsets<W>(wave, vl_, fi_);
+      if (MIXED) k3_store_rows_f32(reinterpret_cast<float*>(lds) + bo, ro, rows);
+      else k3_store_rows(lds + bo, ro, rows);
+      if (C::SPARE && fi_ == W - 1) {   // one lane per voxel: columns 6W .. 6W+2 of the z row
+        const int o = ro.rp[2] + C::at(0, 6 * W);
+        if (MIXED) {
+          float* zf = reinterpret_cast<float*>(lds) + bo + o;
+          *reinterpret_cast<v2f*>(zf) = (v2f){(float)spare[0], (float)spare[1]};
+          zf[2] = (float)spare[2];
+        } else {
+          double* zd = lds + bo + o;
+          *reinterpret_cast<v2d*>(zd) = (v2d){spare[0], spare[1]};
+          zd[2] = spare[2];
+        }
+      }
+    }
+    // next batch of this wave: in flight during the barrier and the whole of phase M.  Measured and rejected (round 2, same
+    // box): the cluster rows requested a step earlier into a second register set (no change: the steps do not wait for loads);
+    // the two waves of a SIMD taking phase M / phase A in opposite order (13.2k instead of 11.8k cycles per step).
+    if (nb >= 0) {
+      k3_load_clusters(pl, nb, lane, e.c);
+      k3_load_params<W>(pl, head, end, nb, lane, stg);
+    }
+  };
+
+  // Full steps: step s = phase M of step s-1 (buffer (s-1)&1), phase A of step s (buffer s&1), one barrier.  The ragged last
+  // step (cnt mod 8 batches) is peeled off below, so inside the loop every wave has a batch and both phases are straight-line code.
+  const int nfull = cnt / C::WAVES, nrag = cnt - nfull * C::WAVES;
+  const int k0_full = kq * C::KPW;
+  for (int s = 0; s <= nfull; s++) {
     if (s >= 1) {
-      const int nb_prev = cnt - (s - 1) * C::WAVES;   // batches of step s-1
       const int bo = ((s - 1) & 1) * C::BUF;
-      if (nb_prev >= C::WAVES) {
-        const int k0 = kq * C::KPW;
-        if (MIXED) {
-          const float* bf = reinterpret_cast<const float*>(lds) + bo;
-          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase_f32<W, 0, true>(bf, k0, C::KPW, lrow, lcol, af);
-          else k3_mfma_phase_f32<W, C::TSPLIT - 1, true>(bf, k0, C::KPW, lrow, lcol, af);
-        } else {
-          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase<W, 0, true>(lds + bo, k0, C::KPW, lrow, lcol, acc);
-          else k3_mfma_phase<W, C::TSPLIT - 1, true>(lds + bo, k0, C::KPW, lrow, lcol, acc);
-        }
-      } else {
-        // ragged last step: only ceil(nb_prev R / 4) K-steps exist; re-split them over the K ranges
-        const int ks = (nb_prev * C::R + 3) >> 2;
-        const int k0 = (kq * ks) / C::KSPLIT, k1 = ((kq + 1) * ks) / C::KSPLIT;
-        if (MIXED) {
-          const float* bf = reinterpret_cast<const float*>(lds) + bo;
-          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase_f32<W, 0, false>(bf, k0, k1 - k0, lrow, lcol, af);
-          else k3_mfma_phase_f32<W, C::TSPLIT - 1, false>(bf, k0, k1 - k0, lrow, lcol, af);
-        } else {
-          if (C::TSPLIT == 1 || set == 0) k3_mfma_phase<W, 0, false>(lds + bo, k0, k1 - k0, lrow, lcol, acc);
-          else k3_mfma_phase<W, C::TSPLIT - 1, false>(lds + bo, k0, k1 - k0, lrow, lcol, acc);
-        }
-      }
+      if (MIXED) k3_mfma_phase_f32<W, true>(reinterpret_cast<const float*>(lds) + bo, set, k0_full, C::KPW, lrow, lcol, af);
+      else k3_mfma_phase<W, true>(lds + bo, set, k0_full, C::KPW, lrow, lcol, acc);
+      if (s <= 4) dbg_stamp(DBG, gw, 13 + 3 * s);   // phase M of step s-1 done: slots 16, 19, 22, 25
     }
-    if (s >= 1 && s <= 4) dbg_stamp(DBG, gw, 13 + 3 * s);   // phase M of step s-1 done: slots 16, 19, 22, 25
-    if (s == nsteps) break;
-    const int nb = cnt - s * C::WAVES;   // batches of this step (>= 1)
-    const int bo = (s & 1) * C::BUF;
-    if (wave < nb) {
-      double rows[3][6];
-      k3_unstage_params<W>(stg, stage_lds, head, end, bs + s * C::WAVES + wave, active, vl, lane, e);
-      // voxel-level values for the spare columns, taken before phase A masks / consumes the entry
-      const double spare_s = 1.4142135623730951 * e.sc;
-      const double spare[3] = {spare_s * e.u[0], spare_s * e.u[1], spare_s * e.u[2]};
-      k3_phase_a<!C::SPARE>(e, fi, pose, rows, dacc);
-      if (active) {
-        // the nine store offsets are recomputed from (vl, fi) every step -- a handful of integer operations under the other
-        // wave's fp64 work -- instead of living in registers (or scratch) across phase M
-        int vl_ = vl, fi_ = fi;
-        asm volatile("" : "+v"(vl_), "+v"(fi_));
-        const K3RowOfs ro = k3_row_offsets<W>(wave, vl_, fi_);
-        if (MIXED) k3_store_rows_f32(reinterpret_cast<float*>(lds) + bo, ro, rows);
-        else k3_store_rows(lds + bo, ro, rows);
-        if (C::SPARE && fi_ == W - 1) {   // one lane per voxel: columns 6W .. 6W+2 of the z row
-          const int o = ro.rp[2] + C::at(0, 6 * W);
-          if (MIXED) {
-            float* zf = reinterpret_cast<float*>(lds) + bo + o;
-            *reinterpret_cast<v2f*>(zf) = (v2f){(float)spare[0], (float)spare[1]};
-            zf[2] = (float)spare[2];
-          } else {
-            double* zd = lds + bo + o;
-            *reinterpret_cast<v2d*>(zd) = (v2d){spare[0], spare[1]};
-            zd[2] = spare[2];
-          }
-        }
-      }
-      // next batch of this wave: in flight during the barrier and the whole of phase M.  Measured and rejected (round 2, same
-      // box): the cluster rows requested a step earlier into a second register set (no change: the steps do not wait for loads);
-      // the two waves of a SIMD taking phase M / phase A in opposite order (13.2k instead of 11.8k cycles per step).
-      if (has_next) {
-        k3_load_clusters(pl, bs + (s + 1) * C::WAVES + wave, lane, e.c);
-        k3_load_params<W>(pl, head, end, bs + (s + 1) * C::WAVES + wave, lane, stg);
-      }
-    } else if (wave == nb) {
-      // first idle wave of the ragged step: the rows that round the step up to a whole K-step must read as zeros
-      if (MIXED) { float* z = reinterpret_cast<float*>(lds) + bo + C::at(nb * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0f; }
-      else { double* z = lds + bo + C::at(nb * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0; }
-    }
+    if (s == nfull) break;
+    const bool more = (s + 1 < nfull) || (wave < nrag);
+    phase_a(bs + s * C::WAVES + wave, (s & 1) * C::BUF, more ? bs + (s + 1) * C::WAVES + wave : -1);
     if (s >= 1 && s <= 4) dbg_stamp(DBG, gw, 14 + 3 * s);   // phase A of step s done (before the barrier): slots 17, 20, 23, 26
     __syncthreads();
     if (s < 6) dbg_stamp(DBG, gw, 8 + s);
+  }
+  if (nrag > 0) {
+    // ragged last step: nrag < 8 batches.  Only ceil(nrag R / 4) K-steps exist; they are re-split over the K ranges, and the first
+    // idle wave makes the rows that round the step up to a whole K-step read as zeros.
+    const int bo = (nfull & 1) * C::BUF;
+    if (wave < nrag) phase_a(bs + nfull * C::WAVES + wave, bo, -1);
+    else if (wave == nrag) {
+      if (MIXED) { float* z = reinterpret_cast<float*>(lds) + bo + C::at(nrag * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0f; }
+      else { double* z = lds + bo + C::at(nrag * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0; }
+    }
+    __syncthreads();
+    if (nfull < 6) dbg_stamp(DBG, gw, 8 + nfull);
+    const int ks = (nrag * C::R + 3) >> 2;
+    const int k0 = (kq * ks) / C::KSPLIT, k1 = ((kq + 1) * ks) / C::KSPLIT;
+    if (MIXED) k3_mfma_phase_f32<W, false>(reinterpret_cast<const float*>(lds) + bo, set, k0, k1 - k0, lrow, lcol, af);
+    else k3_mfma_phase<W, false>(lds + bo, set, k0, k1 - k0, lrow, lcol, acc);
   }
   if (MIXED) {
 #pragma unroll

@@ -355,19 +355,18 @@ __global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restr
   int lin = -1;         // output index of a linear element (JacT / residual)
   if (e < NTILE) {
     const int t = e >> 8, j = (e >> 6) & 3, l = e & 63;
-    int I = 0, rem = t;                      // invert t = I*NT - I(I-1)/2 + (J-I)
-    while (rem >= C::NT - I) { rem -= C::NT - I; I++; }
-    const int J = I + rem;
-    r = 16 * I + (l >> 4) + 4 * j;           // f64 MFMA C/D map: row = lane/16 + 4*reg, col = lane%16
-    c = 16 * J + (l & 15);
+    // tile t accumulates S[16 rowtile + row][16 coltile + col] (vxba_k3.hpp: K3Cfg::rowtile / coltile; tiles of the second set
+    // may be LOWER tiles); f64 MFMA C/D map: row = lane/16 + 4*reg, col = lane%16
+    const int rt = C::rowtile(t), ct = C::coltile(t);
+    r = 16 * rt + (l >> 4) + 4 * j;
+    c = 16 * ct + (l & 15);
+    if (rt > ct) { const int tmp = r; r = c; c = tmp; }  // lower tile: the same numbers, mirrored
     if (r >= n || c >= n || r > c) { r = -1; c = -1; }   // padding columns; lower half of a diagonal tile is a duplicate
     else if (r / 6 == c / 6) {
       const int i = r / 6, a = r % 6, b = c % 6;         // a <= b
       if (C::SPARE && b >= 3) {
         // Drt / Dtt were accumulated by the matrix cores: S[r][6W + (b - 3)] (vxba_k3.hpp, K3Cfg::SPARE)
-        const int c2 = n + (b - 3), I2 = r >> 4, J2 = c2 >> 4;
-        const int t2 = I2 * C::NT - (I2 * (I2 - 1)) / 2 + (J2 - I2), row2 = r - 16 * I2, col2 = c2 - 16 * J2;
-        off1 = t2 * 256 + (row2 >> 2) * 64 + ((row2 & 3) << 4) + col2;
+        off1 = C::elem_offset(r, n + (b - 3));
       } else {
         int d;
         if (b < 3) d = 6 + sym6_index(a, b);
