@@ -63,6 +63,12 @@ else:
             d = np.diff(cols[okc], axis=1)
             print("step %d (cycles, median | max over waves): phase M %6.0f | %6.0f   phase A %6.0f | %6.0f   wait at barrier %6.0f | %6.0f" % (
                 st_, np.median(d[:, 0]), d[:, 0].max(), np.median(d[:, 1]), d[:, 1].max(), np.median(d[:, 2]), d[:, 2].max()))
+    # the eight waves of three workgroups, step 2: cycles since barrier 1 was passed by the first of them (waves w and w + 4 share a SIMD)
+    for wg in (0, 100, 200):
+        blk = full[8 * wg:8 * wg + 8]
+        t0w = blk[:, 9].min()
+        print("workgroup %d, step 2:  wave: M done / A done / barrier 2 passed (cycles since the first wave left barrier 1)" % wg)
+        print("   " + "  ".join("w%d: %5d/%5d/%5d" % (w_, blk[w_, 19] - t0w, blk[w_, 20] - t0w, blk[w_, 10] - t0w) for w_ in range(8)))
     sys.exit(0)
 full = vxba.debug_stamps(n).astype(np.int64)
 st = full[:, :ns]

@@ -24,6 +24,7 @@
 // The cross-wave reduction of the epilogue and the workgroup partial (k3_finalize's input) are laid out as in round 1.
 // No float atomics: bitwise reproducible for a given launch geometry.
 #pragma once
+#include <type_traits>
 
 template <int W>
 struct K3Cfg {
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   for (int k = 0; k < DACC; k++) dacc[k] = 0.0;
 
   // Phase A of the wave's batch b into tile buffer `bo`, then the requests for its next batch nb (nb < 0: none).
-  auto phase_a = [&](int b, int bo, int nb) {
+  auto phase_a = [&](int b, int bo, int nb) __attribute__((always_inline)) {
     double rows[3][6];
     k3_unstage_params<W>(stg, stage_lds, head, end, b, active, vl, lane, e);
     // voxel-level values for the spare columns, taken before phase A masks / consumes the entry
@@ -556,20 +557,37 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   // step (cnt mod 8 batches) is peeled off below, so inside the loop every wave has a batch and both phases are straight-line code.
   const int nfull = cnt / C::WAVES, nrag = cnt - nfull * C::WAVES;
   const int k0_full = kq * C::KPW;
-  for (int s = 0; s <= nfull; s++) {
-    if (s >= 1) {
-      const int bo = ((s - 1) & 1) * C::BUF;
-      if (MIXED) k3_mfma_phase_f32<W, true>(reinterpret_cast<const float*>(lds) + bo, set, k0_full, C::KPW, lrow, lcol, af);
-      else k3_mfma_phase<W, true>(lds + bo, set, k0_full, C::KPW, lrow, lcol, acc);
-      if (s <= 4) dbg_stamp(DBG, gw, 13 + 3 * s);   // phase M of step s-1 done: slots 16, 19, 22, 25
+  // AF (experiment, -DK3_OPPOSITE=1): the second wave of every SIMD (w >= 4) takes phase A BEFORE phase M inside an iteration -- the
+  // two touch different tile buffers, so the order is free -- to put one wave's VALU work under the other's MFMAs.
+  auto full_steps = [&](auto af_tag) __attribute__((always_inline)) {
+    constexpr bool AF = decltype(af_tag)::value;
+    for (int s = 0; s <= nfull; s++) {
+      auto phase_m = [&]() __attribute__((always_inline)) {
+        const int bo = ((s - 1) & 1) * C::BUF;
+        if (MIXED) k3_mfma_phase_f32<W, true>(reinterpret_cast<const float*>(lds) + bo, set, k0_full, C::KPW, lrow, lcol, af);
+        else k3_mfma_phase<W, true>(lds + bo, set, k0_full, C::KPW, lrow, lcol, acc);
+      };
+      if (!AF && s >= 1) {
+        phase_m();
+        if (s <= 4) dbg_stamp(DBG, gw, 13 + 3 * s);   // phase M of step s-1 done: slots 16, 19, 22, 25
+      }
+      if (s < nfull) {
+        const bool more = (s + 1 < nfull) || (wave < nrag);
+        phase_a(bs + s * C::WAVES + wave, (s & 1) * C::BUF, more ? bs + (s + 1) * C::WAVES + wave : -1);
+        if (s >= 1 && s <= 4) dbg_stamp(DBG, gw, 14 + 3 * s);   // phase A of step s done: slots 17, 20, 23, 26
+      }
+      if (AF && s >= 1) phase_m();
+      if (s == nfull) break;
+      __syncthreads();
+      if (s < 6) dbg_stamp(DBG, gw, 8 + s);
     }
-    if (s == nfull) break;
-    const bool more = (s + 1 < nfull) || (wave < nrag);
-    phase_a(bs + s * C::WAVES + wave, (s & 1) * C::BUF, more ? bs + (s + 1) * C::WAVES + wave : -1);
-    if (s >= 1 && s <= 4) dbg_stamp(DBG, gw, 14 + 3 * s);   // phase A of step s done (before the barrier): slots 17, 20, 23, 26
-    __syncthreads();
-    if (s < 6) dbg_stamp(DBG, gw, 8 + s);
-  }
+  };
+#if defined(K3_OPPOSITE) && K3_OPPOSITE
+  if ((wave >> 2) & 1) full_steps(std::true_type{});
+  else full_steps(std::false_type{});
+#else
+  full_steps(std::false_type{});
+#endif
   if (nrag > 0) {
     // ragged last step: nrag < 8 batches.  Only ceil(nrag R / 4) K-steps exist; they are re-split over the K ranges, and the first
     // idle wave makes the rows that round the step up to a whole K-step read as zeros.
