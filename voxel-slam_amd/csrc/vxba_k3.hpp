@@ -230,9 +230,11 @@ __device__ __forceinline__ void k3_phase_a(K3Entry& e, int fi, const double* __r
     for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = pose[3 * cc + r];
 #pragma unroll
   for (int k = 0; k < 3; k++) p[k] = pose[9 + k];
-  const bool obs = e.ok && e.c[9] != 0.0;   // N == 0: frame did not observe the voxel (voxel_map.hpp:178)
-#pragma unroll
-  for (int k = 0; k < 10; k++) e.c[k] = obs ? e.c[k] : 0.0;
+  // N == 0: frame did not observe the voxel (voxel_map.hpp:178).  Masking the two scale factors is enough: every row entry and
+  // every accumulator increment carries sqrt(coe) or coe as a factor, and the cluster a masked lane holds is finite (a real
+  // cluster of a voxel outside [head, end), or the zeros of an unobserved frame), so the products are exact zeros -- 4 selects
+  // instead of 24 on a VALU that is the bottleneck of this phase.
+  const bool obs = e.ok && e.c[9] != 0.0;
   vxm::VoxelCache vc;
 #pragma unroll
   for (int k = 0; k < 3; k++) { vc.u0[k] = e.u[k]; vc.u1[k] = e.u[3 + k]; vc.u2[k] = e.u[6 + k]; }
@@ -515,6 +517,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
 #pragma unroll
   for (int k = 0; k < DACC; k++) dacc[k] = 0.0;
 
+  const K3RowOfs ro = k3_row_offsets<W>(wave, vl, fi);   // lane constants: where the lane's three row pieces go inside a tile buffer
   // Phase A of the wave's batch b into tile buffer `bo`, then the requests for its next batch nb (nb < 0: none).
   auto phase_a = [&](int b, int bo, int nb) __attribute__((always_inline)) {
     double rows[3][6];
@@ -524,11 +527,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
     const double spare[3] = {spare_s * e.u[0], spare_s * e.u[1], spare_s * e.u[2]};
     k3_phase_a<!C::SPARE>(e, fi, pose, rows, dacc);
     if (active) {
-      // the nine store offsets are recomputed from (vl, fi) every step -- a handful of integer operations -- instead of living
-      // in registers (or scratch) across phase M
-      int vl_ = vl, fi_ = fi;
-      asm volatile("" : "+v"(vl_), "+v"(fi_));
-      const K3RowOfs ro = k3_row_offsets<W>(wave, vl_, fi_);
+      const int fi_ = fi;
       if (MIXED) k3_store_rows_f32(reinterpret_cast<float*>(lds) + bo, ro, rows);
       else k3_store_rows(lds + bo, ro, rows);
       if (C::SPARE && fi_ == W - 1) {   // one lane per voxel: columns 6W .. 6W+2 of the z row
