@@ -31,7 +31,7 @@ FP64_MFMA_MEASURED_TFLOPS = 73.0   # v_mfma_f64_16x16x4_f64 issue-bound rate, sc
 FP64_SPEC_TFLOPS = 78.6            # vendor figure (not in the local guide)
 
 
-KERNEL_SOURCES = ("vxba_kernels.hip", "vxba_kernels.h", "vxba_math.hpp", "vxba_solve.hpp")
+KERNEL_SOURCES = ("vxba_kernels.hip", "vxba_kernels.h", "vxba_k3.hpp", "vxba_math.hpp", "vxba_solve.hpp")
 
 
 def kernel_source_hash():
