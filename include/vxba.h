@@ -333,7 +333,11 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
 #define VXBA_OPT_WIDE_DEVICE_SOLVE 2  /* 0 (default): host pivoted LDL^T for W > 10; 1: hipSOLVER Cholesky on the device (loads hipSOLVER on first use) */
 #define VXBA_OPT_LI_DEVICE_LOOP 3     /* LI_BA_Optimizer loop: 0 = host shell between the GPU sweeps, 1 = whole loop device-resident */
 #define VXBA_OPT_K2_VOXELS_PER_BLOCK 4 /* 64 (default) or 32..63: voxels per residual-sweep workgroup (tuning experiment) */
-#define VXBA_OPT_COUNT 5
+#define VXBA_OPT_DEBUG_SOLVE_TIMEOUT 5 /* test hook, 0 (default): with 1 the voxel workgroups of a fused launch give up waiting for the in-launch solve at
+                                         once, which exercises the transparent non-fused retry of vxba_damping_iter */
+#define VXBA_OPT_COUNT 6
+#define VXBA_STAT_FUSED_FALLBACKS 100 /* read-only (vxba_get_option): times vxba_damping_iter re-ran a call with the solve as its own launch after the
+                                         voxel workgroups of a fused launch had timed out waiting for it */
 int vxba_set_option(vxba_factor* f, int option, int value);
 int vxba_get_option(const vxba_factor* f, int option, int* value);
 

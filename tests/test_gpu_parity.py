@@ -407,6 +407,32 @@ def test_bench_rccl_plumbing_single_rank():
         assert tag in b["config"]["parallelism"] and b["value"] > 0, b["config"]["parallelism"]
 
 
+def test_timed_out_in_launch_solve_is_retried_without_fusion(vx):
+    """The in-launch solve (workgroup 0 of the residual sweep, the others polling) is a forward-progress assumption.  When the voxel
+    workgroups give up -- forced here through the test hook -- vxba_damping_iter must not fail: it rebuilds the entry cache and re-runs
+    the call with the solve as its own launch, and the result is the one of an undisturbed call."""
+    sc = synth.make_scene(win_size=10, pts_per_scan=20000, n_voxels=6000, seed=33)
+    f = vx.LidarFactor(sc.win_size)
+    f.push_voxels(sc.clusters, sc.fix, sc.coe)
+    f.evaluate_only_residual(sc.poses_init)
+    ref = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=4)
+    f.evaluate_only_residual(sc.poses_init)
+    f.set_option("debug_solve_timeout", 1)
+    before = f.get_option("stat_fused_fallbacks")
+    got = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=4)
+    assert f.get_option("stat_fused_fallbacks") == before + 1
+    f.set_option("debug_solve_timeout", 0)
+    et, er = synth.pose_errors(got["poses"], ref["poses"])
+    assert et < 1e-9 and er < 1e-9
+    assert np.array_equal(got["trace"][:, 6], ref["trace"][:, 6])      # same accept / reject decisions
+    assert np.allclose(got["resis"], ref["resis"], rtol=1e-10)
+    # and the factor keeps working fused afterwards
+    f.evaluate_only_residual(sc.poses_init)
+    again = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=4)
+    assert f.get_option("stat_fused_fallbacks") == before + 1
+    assert np.allclose(again["poses"], ref["poses"], atol=1e-9)
+
+
 def test_lm_loop_with_more_residual_workgroups_than_the_chip_holds(vx):
     """120k voxels -> 1876 residual-sweep workgroups + the in-launch solve workgroup: more than can be resident at once
     (the voxel workgroups wait for workgroup 0, so dispatch order matters here).  Trace and poses must still match the oracle."""

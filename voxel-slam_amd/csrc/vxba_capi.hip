@@ -67,14 +67,18 @@ struct vxba_factor {
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
   vxw::DenseSolver* wide_solver = nullptr;   // wide windows: device Cholesky of the (6W)-dimensional LM step (hipSOLVER, loaded on first use)
   bool wide_solver_tried = false;
-  int opt[VXBA_OPT_COUNT] = {1, 1, 0, 0, 64};   // vxba_set_option; initial values may come from the environment (see vxba.h)
+  int opt[VXBA_OPT_COUNT] = {1, 1, 0, 0, 64, 0};   // vxba_set_option; initial values may come from the environment (see vxba.h)
   vxw::WideIndex wide;           // wide windows: incidence structure (entries, entry pairs per Hessian block), rebuilt after a push
   bool wide_dirty = true;
   double* d_poses = nullptr;     // wide windows: W*12 poses on the device (the MFMA kernels take them by value)
-  double* h_poses = nullptr;     // pinned staging for the above
+  double* h_poses = nullptr;     // pinned staging for the above: a ring of POSE_SLOTS slots, each guarded by an event
+  hipEvent_t pose_ev[8] = {};
+  unsigned pose_slot = 0;
   size_t xlen = 0;               // doubles the exchange buffers (own_packed, h_packed) hold
   int precision = 0;             // 0: fp64 throughout; 1: Hessian products in f32 on the matrix cores, f64 accumulation
   unsigned lm_seq = 0;           // sequence numbers of solves published inside residual-sweep launches (never 0)
+  bool solve_timed_out = false;  // the last damping_iter failed because voxel workgroups gave up waiting for the in-launch solve
+  int fused_fallbacks = 0;       // times a call was transparently re-run with the solve as its own launch
   vxba_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
   // direct RCCL path: entry points resolved from the librccl.so the process already uses
@@ -335,9 +339,16 @@ void options_from_env(vxba_factor* f) {   // initial values only; vxba_set_optio
   f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] = (v >= 32 && v <= 64) ? v : 64;
 }
 
+// The sweeps are asynchronous: two calls in a row with different poses must not share one staging buffer (the second memcpy
+// would overwrite it before the first H2D copy has run).  Eight pinned slots, each reused only after its copy has completed.
 int upload_poses(vxba_factor* f, const double* Rp) {
-  std::memcpy(f->h_poses, Rp, sizeof(double) * 12 * f->W);
-  VX_HIP(f, hipMemcpyAsync(f->d_poses, f->h_poses, sizeof(double) * 12 * f->W, hipMemcpyHostToDevice, f->stream));
+  const unsigned slot = f->pose_slot++ & 7u;
+  if (!f->pose_ev[slot]) VX_HIP(f, hipEventCreateWithFlags(&f->pose_ev[slot], hipEventDisableTiming));
+  else VX_HIP(f, hipEventSynchronize(f->pose_ev[slot]));
+  double* h = f->h_poses + (size_t)slot * 12 * VXBA_MAX_WIN_WIDE;
+  std::memcpy(h, Rp, sizeof(double) * 12 * f->W);
+  VX_HIP(f, hipMemcpyAsync(f->d_poses, h, sizeof(double) * 12 * f->W, hipMemcpyHostToDevice, f->stream));
+  VX_HIP(f, hipEventRecord(f->pose_ev[slot], f->stream));
   return VXBA_OK;
 }
 
@@ -422,10 +433,10 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, in
   int nparts;
   if (f->profiling & 2) {
     hipEvent_t a = get_event(f), b = get_event(f);
-    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, f->d_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK], f->stream, a, b);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, f->d_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] ? 0x10000 : 0), f->stream, a, b);
     if (a && b) f->pending.push_back({a, b, 1});
   } else {
-    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, f->d_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK], f->stream);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, f->d_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] ? 0x10000 : 0), f->stream);
   }
   if (nparts_out) *nparts_out = nparts;
   if (d_out) {
@@ -574,7 +585,7 @@ int vxba_create(int win_size, int device, vxba_factor** out) {
   if (ensure_exchange(f) != VXBA_OK) return bail(hipErrorOutOfMemory);
   if ((e = hipMalloc((void**)&f->d_count, sizeof(unsigned long long))) != hipSuccess) return bail(e);
   if ((e = hipMalloc((void**)&f->d_poses, sizeof(double) * 12 * VXBA_MAX_WIN_WIDE)) != hipSuccess) return bail(e);
-  if ((e = hipHostMalloc((void**)&f->h_poses, sizeof(double) * 12 * VXBA_MAX_WIN_WIDE, hipHostMallocDefault)) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc((void**)&f->h_poses, sizeof(double) * 8 * 12 * VXBA_MAX_WIN_WIDE, hipHostMallocDefault)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc((void**)&f->h_scalar, 2 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return bail(e);
   if ((e = hipMalloc((void**)&f->d_lm, sizeof(vxk::LMState))) != hipSuccess) return bail(e);
   if ((e = hipMemset(f->d_lm, 0, sizeof(vxk::LMState))) != hipSuccess) return bail(e);
@@ -597,6 +608,7 @@ int vxba_destroy(vxba_factor* f) {
   vxw::wide_solver_free(f->wide_solver);
   hipFree(f->own_packed); hipFree(f->d_count); hipFree(f->d_poses);
   if (f->h_poses) hipHostFree(f->h_poses);
+  for (auto& ev : f->pose_ev) if (ev) hipEventDestroy(ev);
   if (f->h_packed) hipHostFree(f->h_packed);
   if (f->h_scalar) hipHostFree(f->h_scalar);
   hipFree(f->d_lm); hipFree(f->d_li); hipFree(f->d_li_hess); hipFree(f->d_scratch);
@@ -1197,7 +1209,10 @@ static int damping_iter_impl(vxba_factor* f, double* Rp, int max_iter, double* h
   VX_HIP(f, hipGetLastError());
   VX_HIP(f, hipMemcpyAsync(f->h_lm, f->d_lm, sizeof(vxk::LMState), hipMemcpyDeviceToHost, f->stream));
   VX_HIP(f, hipStreamSynchronize(f->stream));
-  if (f->h_lm->error) return fail(f, VXBA_ERR_STATE, "damping_iter: a residual-sweep workgroup timed out waiting for the in-launch solve");
+  if (f->h_lm->error) {
+    f->solve_timed_out = true;
+    return fail(f, VXBA_ERR_STATE, "damping_iter: a residual-sweep workgroup timed out waiting for the in-launch solve");
+  }
   const vxk::LMCtl& st = f->h_lm->ctl[c];
   std::memcpy(Rp, st.x, sizeof(double) * 12 * W);
   if (hess_out) std::memcpy(hess_out, f->h_lm->hess_out, sizeof(double) * n * n);
@@ -1780,6 +1795,7 @@ int vxba_set_option(vxba_factor* f, int option, int value) {
   VX_LOCK(f);
   switch (option) {
     case VXBA_OPT_FUSED_SOLVE: case VXBA_OPT_SPEC_COLLECTIVE: case VXBA_OPT_WIDE_DEVICE_SOLVE: case VXBA_OPT_LI_DEVICE_LOOP:
+    case VXBA_OPT_DEBUG_SOLVE_TIMEOUT:
       if (value != 0 && value != 1) return fail(f, VXBA_ERR_ARG, "vxba_set_option: this option takes 0 or 1");
       break;
     case VXBA_OPT_K2_VOXELS_PER_BLOCK:
@@ -1791,6 +1807,7 @@ int vxba_set_option(vxba_factor* f, int option, int value) {
   return VXBA_OK;
 }
 int vxba_get_option(const vxba_factor* f, int option, int* value) {
+  if (f && value && option == VXBA_STAT_FUSED_FALLBACKS) { *value = f->fused_fallbacks; return VXBA_OK; }
   if (!f || !value || option < 0 || option >= VXBA_OPT_COUNT) return VXBA_ERR_ARG;
   *value = f->opt[option];
   return VXBA_OK;
@@ -1863,7 +1880,23 @@ static int peer_check(vxba_factor* f, int rc) {
   return st ? fail(f, VXBA_ERR_STATE, "peer all-reduce: a peer did not arrive within the wait bound (results are not a sum)") : VXBA_OK;
 }
 int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out, double* resis_out, double* trace_out, int* n_trace, int* is_converge) {
-  return peer_check(f, damping_iter_impl(f, Rp, max_iter, hess_out, resis_out, trace_out, n_trace, is_converge));
+  int rc = damping_iter_impl(f, Rp, max_iter, hess_out, resis_out, trace_out, n_trace, is_converge);
+  if (rc == VXBA_ERR_STATE && f && f->solve_timed_out) {
+    // The in-launch solve relies on workgroup 0 of the residual sweep making progress while the others poll (bounded): true for
+    // in-order dispatch on an otherwise idle device, not guaranteed under CU masking / a serialising profiler / a co-resident
+    // kernel.  A timeout is therefore not an error of the caller's: run the same call again with the solve as its own launch.
+    // Rp is untouched on the failure path; the (lambda, U, merged) cache the first Hessian sweep needs is the one of the entry
+    // poses, which the failed attempt has overwritten -- rebuild it first.
+    f->solve_timed_out = false;
+    const int saved = f->opt[VXBA_OPT_FUSED_SOLVE];
+    f->opt[VXBA_OPT_FUSED_SOLVE] = 0;
+    double r = 0;
+    rc = vxba_evaluate_only_residual(f, Rp, 0, f->V, &r);
+    if (rc == VXBA_OK) rc = damping_iter_impl(f, Rp, max_iter, hess_out, resis_out, trace_out, n_trace, is_converge);
+    f->opt[VXBA_OPT_FUSED_SOLVE] = saved;
+    f->fused_fallbacks++;
+  }
+  return peer_check(f, rc);
 }
 int vxba_lm_steps(vxba_factor* f, const double* Rp_init, int n_steps, int steps_per_solve, double* Rp_out, double* last_resis, int64_t* stats_out) {
   return peer_check(f, lm_steps_impl(f, Rp_init, n_steps, steps_per_solve, Rp_out, last_resis, stats_out));

@@ -165,7 +165,8 @@ constexpr unsigned K2_SPIN_LIMIT = 1u << 22;
 #endif
 template <int W, bool DBG = false>
 __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c, unsigned seq, int head, int end,
-                                                         int VPB, double* __restrict__ partial) {
+                                                         int VPB_arg, double* __restrict__ partial) {
+  const int VPB = VPB_arg & 0xffff;
   __shared__ double pose_lds[12 * W];
   __shared__ double solve_lds[SOLVE_LDS + 64];
   // LM mode: trial poses of ctl[c]; nothing to do once the loop is done
@@ -220,9 +221,10 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
         // relaxed polls and no acquire fence (either would invalidate caches chip-wide, 780 times over): the trial poses
         // are fetched below with system-coherent (volatile) loads, issued in program order after the poll that saw `seq`
         unsigned spins = 0;
+        const unsigned spin_limit = (VPB_arg >> 16) ? 1u : K2_SPIN_LIMIT;   // bit 16 of VPB_arg: test hook (VXBA_OPT_DEBUG_SOLVE_TIMEOUT), give up at once
         while (__hip_atomic_load(&st->solve_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
           __builtin_amdgcn_s_sleep(16);
-          if (++spins > K2_SPIN_LIMIT) { if (lane == 0) st->error = 1; return; }   // never observed; a hang would cost the GPU
+          if (++spins > spin_limit) { if (lane == 0) st->error = 1; return; }   // never observed in production; a hang would cost the GPU
         }
         if (DBG) dbg_stamp(true, vb, 5);
       }
@@ -779,6 +781,7 @@ __global__ __launch_bounds__(256) void lm_init_kernel(LMState* stp, PoseArg x0, 
     st->residual1 = 0; st->residual2 = 0; st->q1 = 0; st->resis[0] = 0; st->resis[1] = 0;
     st->calc_hess = 1; st->done = 0; st->iter = 0; st->converge = 1; st->rejected = 0; st->bench_mode = bench_mode;
     st->n_accept = 0; st->n_reject = 0;
+    stp->error = 0;   // a timed-out in-launch solve of an earlier call must not fail this one (the host retries without fusion)
   }
 }
 // Damped solve (H + u D) dxi = -JacT on ONE wave: lane i owns row i of the system in registers, the pivot column is
@@ -914,18 +917,20 @@ void launch_mfma_probe(const double* dA, const double* dB, double* dD, hipStream
 // 18.0 -- the partly filled waves cost more than the ragged last round.  VXBA_OPT_K2_VOXELS_PER_BLOCK keeps the experiment reproducible.
 int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, int c, unsigned fused_seq, int head, int end, double* d_partial,
                        int voxels_per_block, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  const int vpb = (voxels_per_block >= 32 && voxels_per_block <= 64) ? voxels_per_block : 64;
+  const int vpb0 = voxels_per_block & 0xffff;
+  const int vpb = (vpb0 >= 32 && vpb0 <= 64) ? vpb0 : 64;
+  const int vpb_arg = vpb | (voxels_per_block & 0x10000);   // bit 16: the voxel workgroups do not wait for the in-launch solve (test hook)
   const int nblocks = (end - head + vpb - 1) / vpb;
   if (nblocks <= 0) return 0;
   const unsigned seq = st ? fused_seq : 0u;
   const int grid = nblocks + (seq != 0 ? 1 : 0);   // + the solve workgroup
   static int dbg = -1;
   if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
-  if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb, d_partial)); }
+  if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial)); }
   else if (ev_start) {
     VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), dim3(grid), dim3(64), 0, s, ev_start, ev_stop, 0, fv, poses, st, c, seq, head,
-                                                end, vpb, d_partial));
-  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb, d_partial)); }
+                                                end, vpb_arg, d_partial));
+  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial)); }
   return nblocks;
 }
 
