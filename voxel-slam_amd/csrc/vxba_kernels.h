@@ -102,8 +102,9 @@ void launch_seed_aux(const FactorView& fv, int head, int end, hipStream_t s);
 
 // K3: Hessian/gradient sweep over voxels [head,end) into per-workgroup partials; returns #workgroups.
 int k3_grid_blocks(int device_cus);
-// workgroups for a sweep over nbatches wave-batches: one 8-wave workgroup per CU, never more than there are steps of 8 batches
-inline int k3_blocks_for(int nbatches, int device_cus) { const int b = (nbatches + 7) / 8; return b < 1 ? 1 : (b < device_cus ? b : device_cus); }
+// workgroups for a sweep over nbatches wave-batches: one 8-wave workgroup per CU; small sweeps are spread over as many CUs as they
+// have pairs of batches (a workgroup with fewer than 8 batches runs them as one ragged step, whose MFMA work is re-split over its waves)
+inline int k3_blocks_for(int nbatches, int device_cus) { const int b = (nbatches + 1) / 2; return b < 1 ? 1 : (b < device_cus ? b : device_cus); }
 // cache_src (nullable): read the (lambda, U, merged, aux) cache planes from this base instead of fv's live cache --
 // used to start a new window from the snapshot without copying it back first.
 // ev_start / ev_stop (nullable): events tied to this dispatch's own begin / end timestamps (hipExtLaunchKernel), i.e.
