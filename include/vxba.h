@@ -335,7 +335,9 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
 #define VXBA_OPT_K2_VOXELS_PER_BLOCK 4 /* 64 (default) or 32..63: voxels per residual-sweep workgroup (tuning experiment) */
 #define VXBA_OPT_DEBUG_SOLVE_TIMEOUT 5 /* test hook, 0 (default): with 1 the voxel workgroups of a fused launch give up waiting for the in-launch solve at
                                          once, which exercises the transparent non-fused retry of vxba_damping_iter */
-#define VXBA_OPT_COUNT 6
+#define VXBA_OPT_LI_STRUCTURED_SOLVE 6 /* 1 (default): the host shells of LI_BA_Optimizer[Gravity] solve the damped 15W(+3) system by a band Cholesky of
+                                         the velocity/bias part + Schur complement onto the poses (3x fewer flops); 0: dense pivoted LDL^T */
+#define VXBA_OPT_COUNT 7
 #define VXBA_STAT_FUSED_FALLBACKS 100 /* read-only (vxba_get_option): times vxba_damping_iter re-ran a call with the solve as its own launch after the
                                          voxel workgroups of a fused launch had timed out waiting for it */
 int vxba_set_option(vxba_factor* f, int option, int value);
@@ -443,6 +445,10 @@ int vxba_nnz(vxba_factor* f, int64_t* nnz);
 /* Debug: D(16x16, row-major) = A(16x4) B(4x16) through one v_mfma_f64_16x16x4_f64 with the lane maps the Hessian
  * kernel relies on (unit-tested on the GPU so a wrong operand layout is caught in isolation). */
 int vxba_debug_mfma_probe(int device, const double* A16x4, const double* B4x16, double* D16x16);
+/* test access to the structured solve of the LiDAR-inertial system (host code, no GPU needed): A is m x m (full symmetric storage),
+ * m = lead_y + 15 nframes + tail_x, laid out [lead velocity/bias unknowns | nframes x (rot 3, pos 3, v 3, bg 3, ba 3) | tail]; solves A x = b.
+ * Returns VXBA_ERR_STATE when the banded part is not positive definite (the library then falls back to the dense pivoted LDL^T). */
+int vxba_debug_band_schur(int m, const double* A, const double* b, int nframes, int lead_y, int tail_x, double* x);
 
 /* Debug: per-wave s_memtime stamps written by the instrumented kernel instantiations (env VXBA_DBG=1 /
  * VXBA_K3_SGB=5); 8 slots per wave. */

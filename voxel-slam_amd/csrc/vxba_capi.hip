@@ -67,7 +67,7 @@ struct vxba_factor {
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
   vxw::DenseSolver* wide_solver = nullptr;   // wide windows: device Cholesky of the (6W)-dimensional LM step (hipSOLVER, loaded on first use)
   bool wide_solver_tried = false;
-  int opt[VXBA_OPT_COUNT] = {1, 1, 0, 0, 64, 0};   // vxba_set_option; initial values may come from the environment (see vxba.h)
+  int opt[VXBA_OPT_COUNT] = {1, 1, 0, 0, 64, 0, 1};   // vxba_set_option; initial values may come from the environment (see vxba.h)
   vxw::WideIndex wide;           // wide windows: incidence structure (entries, entry pairs per Hessian block), rebuilt after a push
   bool wide_dirty = true;
   double* d_poses = nullptr;     // wide windows: W*12 poses on the device (the MFMA kernels take them by value)
@@ -1512,6 +1512,8 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
   double residual1 = 0, residual2 = 0;
   bool is_calc_hess = true;
   int nt = 0;
+  vxh::LiIndexSets li_sets;
+  vxh::BandSchurWork bs_work;
   // development aid: VXBA_LI_TIMING=1 prints where the host time of one call goes
   static const bool timing = [] { const char* e = getenv("VXBA_LI_TIMING"); return e && e[0] == '1'; }();
   double t_sys = 0, t_solve = 0, t_res = 0;
@@ -1538,7 +1540,15 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
       for (int c = 0; c < m; c++) std::memcpy(&A[(size_t)c * m], &Hess[(size_t)(c + g) * n + g], sizeof(double) * m);
       for (int r = 0; r < m; r++) { A[(size_t)r * m + r] += u * D[r + g]; rhs[r] = -JacT[r + g]; }
       for (int r = 0; r < g; r++) dxi[r] = 0.0;
-      if (m > 0) vxh::ldlt_solve_inplace(m, A.data(), rhs.data(), dxi.data() + g, perm.data(), work.data());
+      // band Cholesky of the velocity / bias part + Schur complement onto the poses (vxba_host.hpp); dense pivoted LDL^T if a band
+      // pivot is not positive (or the option is off)
+      bool solved = false;
+      if (m > 0 && f->opt[VXBA_OPT_LI_STRUCTURED_SOLVE]) {
+        if (li_sets.Y.empty()) li_sets = vxh::li_index_sets(W - 1, 0, 0);
+        solved = vxh::band_schur_solve(m, A.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(), (int)li_sets.X.size(),
+                                       li_sets.xlo.data(), dxi.data() + g, bs_work);
+      }
+      if (m > 0 && !solved) vxh::ldlt_solve_inplace(m, A.data(), rhs.data(), dxi.data() + g, perm.data(), work.data());
     }
     // trial state (:599-606) and the factors' bias deltas (:608-609)
     for (int j = 0; j < W; j++) {
@@ -1599,6 +1609,9 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
   double residual1 = 0, residual2 = 0;
   bool is_calc_hess = true;
   int nt = 0;
+  vxh::LiIndexSets li_sets;
+  vxh::BandSchurWork bs_work;
+  std::vector<double> Ared;
   for (int it = 0; it < max_iter; it++) {
     const bool recomputed = is_calc_hess;
     if (is_calc_hess) {
@@ -1611,9 +1624,23 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
       for (int r = 0; r < 6; r++) { Hess[(size_t)c * n + r] = 0.0; Hess[(size_t)r * n + c] = 0.0; }
     for (int r = 0; r < 6; r++) { Hess[(size_t)r * n + r] = 1.0; JacT[r] = 0.0; }
     for (int r = 0; r < n; r++) D[r] = Hess[(size_t)r * n + r];
-    A = Hess;
-    for (int r = 0; r < n; r++) { A[(size_t)r * n + r] += u * D[r]; rhs[r] = -JacT[r]; }
-    vxh::ldlt_solve_inplace(n, A.data(), rhs.data(), dxi.data(), perm.data(), work.data());
+    bool solved = false;
+    if (f->opt[VXBA_OPT_LI_STRUCTURED_SOLVE] && W > 1) {
+      // without the six gauge rows (identity, dxi = 0): [v, bg, ba of frame 0 | frames 1 .. W-1 | g]
+      const int mr = n - 6;
+      Ared.resize((size_t)mr * mr);
+      for (int c = 0; c < mr; c++) std::memcpy(&Ared[(size_t)c * mr], &Hess[(size_t)(c + 6) * n + 6], sizeof(double) * mr);
+      for (int r = 0; r < mr; r++) { Ared[(size_t)r * mr + r] += u * D[r + 6]; rhs[r] = -JacT[r + 6]; }
+      if (li_sets.Y.empty()) li_sets = vxh::li_index_sets(W - 1, 9, 3);
+      for (int r = 0; r < 6; r++) dxi[r] = 0.0;
+      solved = vxh::band_schur_solve(mr, Ared.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(), (int)li_sets.X.size(),
+                                     li_sets.xlo.data(), dxi.data() + 6, bs_work);
+    }
+    if (!solved) {
+      A = Hess;
+      for (int r = 0; r < n; r++) { A[(size_t)r * n + r] += u * D[r]; rhs[r] = -JacT[r]; }
+      vxh::ldlt_solve_inplace(n, A.data(), rhs.data(), dxi.data(), perm.data(), work.data());
+    }
     for (int k = 0; k < 3; k++) x_temp[21 + k] += dxi[n - 3 + k];                 // x_stats_temp[0].g += dxi.tail(3)
     for (int j = 0; j < W; j++) {
       const double* d = &dxi[(size_t)vxi::DIM * j];
@@ -1790,12 +1817,20 @@ int vxba_internal_cache_view(vxba_factor* f, const double** eigval, const double
   return VXBA_OK;
 }
 
+// Test access to the structured LiDAR-inertial solve (host code, needs no GPU): A (m x m, full symmetric), b -> x.
+int vxba_debug_band_schur(int m, const double* A, const double* b, int nframes, int lead_y, int tail_x, double* x) {
+  if (!A || !b || !x || m != lead_y + 15 * nframes + tail_x) return VXBA_ERR_ARG;
+  const vxh::LiIndexSets s = vxh::li_index_sets(nframes, lead_y, tail_x);
+  vxh::BandSchurWork w;
+  return vxh::band_schur_solve(m, A, b, s.Y.data(), (int)s.Y.size(), s.bw, s.X.data(), (int)s.X.size(), s.xlo.data(), x, w) ? VXBA_OK : VXBA_ERR_STATE;
+}
+
 int vxba_set_option(vxba_factor* f, int option, int value) {
   if (!f) return VXBA_ERR_ARG;
   VX_LOCK(f);
   switch (option) {
     case VXBA_OPT_FUSED_SOLVE: case VXBA_OPT_SPEC_COLLECTIVE: case VXBA_OPT_WIDE_DEVICE_SOLVE: case VXBA_OPT_LI_DEVICE_LOOP:
-    case VXBA_OPT_DEBUG_SOLVE_TIMEOUT:
+    case VXBA_OPT_DEBUG_SOLVE_TIMEOUT: case VXBA_OPT_LI_STRUCTURED_SOLVE:
       if (value != 0 && value != 1) return fail(f, VXBA_ERR_ARG, "vxba_set_option: this option takes 0 or 1");
       break;
     case VXBA_OPT_K2_VOXELS_PER_BLOCK:

@@ -122,6 +122,156 @@ inline void ldlt_solve_inplace(int n, double* A, const double* b, double* x, int
   for (int k = n - 1; k >= 0; --k) std::swap(x[k], x[perm[k]]);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Structured solve of the damped LiDAR-inertial system (LI_BA_Optimizer / LI_BA_OptimizerGravity, voxel_map.hpp:597, 811).
+// Upstream hands the whole 15W (+3) system to a dense pivoted LDL^T.  Its structure is much thinner than that: the LiDAR factor only
+// fills the pose-pose blocks; velocities and biases (9 unknowns per frame: the set Y) meet each other and the poses only through the
+// IMU factors of CONSECUTIVE frames.  Listed frame by frame, A[Y][Y] is therefore banded (half-bandwidth 17) and a pose column
+// couples to the Y rows of three frames only.  So:  band Cholesky A[Y][Y] = L L^T;  W = L^-1 A[Y][X] (forward substitution, a column
+// starts at its first structural non-zero, and row a of W is non-zero on a PREFIX of the columns when X is listed by first row);
+// S = A[X][X] - W^T W;  the dense part S (poses [+ gravity]: 54 or 57 unknowns at W = 10) goes to the pivoted LDL^T as before;
+// y = L^-T (L^-1 b_Y - W x).  ~180k multiply-adds instead of 820k for the 135-unknown system.  The damped system is positive
+// definite wherever LM accepts steps; a non-positive band pivot returns false and the caller falls back to the dense solve, whose
+// pivoting and null-pivot rule are the reference's.
+//   A: m x m, full symmetric storage (row- == column-major), not modified.   Y[ny], X[nx]: the two index sets (disjoint, together
+//   all of 0..m-1), X sorted by xlo.   bw: half-bandwidth of A[Y][Y] in Y order.   xlo[p]: first Y position column X[p] couples to.
+struct BandSchurWork {
+  std::vector<double> L, Wm, S, wb, rx, xs, work;
+  std::vector<int> perm, qmax;
+};
+template <bool AVX>
+inline bool band_schur_solve_impl(int m, const double* A, const double* b, const int* Y, int ny, int bw, const int* X, int nx, const int* xlo, double* x,
+                                  BandSchurWork& ws) {
+  const int ld = bw + 1;                     // L band storage: row a holds columns a-bw .. a at [0 .. bw]
+  const int nc = (nx + 3) & ~3;              // padded row length of W
+  ws.L.assign((size_t)ny * ld, 0.0);
+  ws.Wm.assign((size_t)ny * nc, 0.0);
+  ws.wb.assign(ny, 0.0);
+  ws.qmax.assign(ny, 0);
+  double* L = ws.L.data();
+  auto Lat = [&](int a, int c) -> double& { return L[(size_t)a * ld + (c - (a - bw))]; };   // a - bw <= c <= a
+  // band Cholesky, row by row
+  for (int a = 0; a < ny; a++) {
+    const int c0 = a - bw > 0 ? a - bw : 0;
+    const double* Arow = A + (size_t)Y[a] * m;
+    for (int c = c0; c <= a; c++) {
+      const int k0 = c - bw > c0 ? c - bw : c0;
+      double sum = Arow[Y[c]];
+      const double* la = &Lat(a, k0);
+      const double* lc = &Lat(c, k0);
+      for (int k = 0; k < c - k0; k++) sum -= la[k] * lc[k];
+      if (c < a) Lat(a, c) = sum / Lat(c, c);
+      else {
+        if (!(sum > 0.0)) return false;
+        Lat(a, a) = std::sqrt(sum);
+      }
+    }
+  }
+  // W = L^-1 A[Y][X] and wb = L^-1 b_Y, row by row; row a is non-zero on the columns whose first row is <= a
+  {
+    int q = 0;
+    for (int a = 0; a < ny; a++) { while (q < nx && xlo[q] <= a) q++; ws.qmax[a] = q; }
+  }
+  for (int a = 0; a < ny; a++) {
+    const int c0 = a - bw > 0 ? a - bw : 0;
+    const int qa = ws.qmax[a];
+    double* wa = ws.Wm.data() + (size_t)a * nc;
+    const double* Arow = A + (size_t)Y[a] * m;
+    for (int q = 0; q < qa; q++) wa[q] = Arow[X[q]];
+    double sb = b[Y[a]];
+    for (int k = c0; k < a; k++) {
+      const double l = Lat(a, k);
+      const double* wk = ws.Wm.data() + (size_t)k * nc;
+      const int qk = ws.qmax[k];              // qk <= qa
+      for (int q = 0; q < qk; q++) wa[q] -= l * wk[q];
+      sb -= l * ws.wb[k];
+    }
+    const double inv = 1.0 / Lat(a, a);
+    for (int q = 0; q < qa; q++) wa[q] *= inv;
+    ws.wb[a] = sb * inv;
+  }
+  // S = A[X][X] - W^T W (lower triangle, then mirrored), rx = b_X - W^T wb
+  ws.S.assign((size_t)nx * nx, 0.0);
+  ws.rx.assign(nx, 0.0);
+  double* S = ws.S.data();
+  for (int p = 0; p < nx; p++) {
+    const double* Arow = A + (size_t)X[p] * m;
+    for (int q = 0; q <= p; q++) S[(size_t)p * nx + q] = Arow[X[q]];
+    ws.rx[p] = b[X[p]];
+  }
+  for (int a = 0; a < ny; a++) {
+    const double* wa = ws.Wm.data() + (size_t)a * nc;
+    const int qa = ws.qmax[a];
+    const double wba = ws.wb[a];
+    for (int p = 0; p < qa; p++) {
+      const double wp = wa[p];
+      double* sp = S + (size_t)p * nx;
+      for (int q = 0; q <= p; q++) sp[q] -= wp * wa[q];
+      ws.rx[p] -= wp * wba;
+    }
+  }
+  for (int p = 0; p < nx; p++)
+    for (int q = 0; q < p; q++) S[(size_t)q * nx + p] = S[(size_t)p * nx + q];
+  // dense part: the reference's pivoted LDL^T
+  ws.xs.assign(nx, 0.0); ws.work.assign(nx, 0.0); ws.perm.assign(nx, 0);
+  ldlt_solve_inplace(nx, S, ws.rx.data(), ws.xs.data(), ws.perm.data(), ws.work.data());
+  for (int p = 0; p < nx; p++) x[X[p]] = ws.xs[p];
+  // y = L^-T (wb - W x)
+  for (int a = 0; a < ny; a++) {
+    const double* wa = ws.Wm.data() + (size_t)a * nc;
+    double sacc = ws.wb[a];
+    for (int q = 0; q < ws.qmax[a]; q++) sacc -= wa[q] * ws.xs[q];
+    ws.wb[a] = sacc;
+  }
+  for (int a = ny - 1; a >= 0; a--) {
+    const double ya = ws.wb[a] / Lat(a, a);
+    ws.wb[a] = ya;
+    const int c0 = a - bw > 0 ? a - bw : 0;
+    for (int k = c0; k < a; k++) ws.wb[k] -= Lat(a, k) * ya;
+  }
+  for (int a = 0; a < ny; a++) x[Y[a]] = ws.wb[a];
+  return true;
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2,fma"))) inline bool band_schur_solve_avx2(int m, const double* A, const double* b, const int* Y, int ny, int bw, const int* X, int nx,
+                                                                      const int* xlo, double* x, BandSchurWork& ws) {
+  return band_schur_solve_impl<true>(m, A, b, Y, ny, bw, X, nx, xlo, x, ws);
+}
+#endif
+inline bool band_schur_solve(int m, const double* A, const double* b, const int* Y, int ny, int bw, const int* X, int nx, const int* xlo, double* x,
+                             BandSchurWork& ws) {
+#if defined(__x86_64__)
+  if (cpu_has_avx2_fma()) return band_schur_solve_avx2(m, A, b, Y, ny, bw, X, nx, xlo, x, ws);
+#endif
+  return band_schur_solve_impl<false>(m, A, b, Y, ny, bw, X, nx, xlo, x, ws);
+}
+
+// Index sets of the LiDAR-inertial system for band_schur_solve.  The system handed in holds frames f0 .. W-1 with 15 unknowns each
+// (rotation 3, position 3 | velocity 3, gyro bias 3, accelerometer bias 3), optionally preceded by `lead_y` loose velocity/bias unknowns
+// of frame f0 - 1 (the gravity variant fixes only frame 0's POSE) and followed by `tail_x` dense unknowns (gravity).
+struct LiIndexSets {
+  std::vector<int> Y, X, xlo;
+  int bw = 17;
+};
+inline LiIndexSets li_index_sets(int nframes, int lead_y, int tail_x) {
+  LiIndexSets s;
+  const int yoff = lead_y;   // Y positions of the lead block come first
+  for (int k = 0; k < lead_y; k++) s.Y.push_back(k);
+  for (int j = 0; j < nframes; j++)
+    for (int k = 6; k < 15; k++) s.Y.push_back(lead_y + 15 * j + k);
+  const int ny = (int)s.Y.size();
+  // dense unknowns sorted by their first Y row: the tail block (couples to everything) first, then the poses frame by frame
+  for (int k = 0; k < tail_x; k++) { s.X.push_back(lead_y + 15 * nframes + k); s.xlo.push_back(0); }
+  for (int j = 0; j < nframes; j++)
+    for (int k = 0; k < 6; k++) {
+      s.X.push_back(lead_y + 15 * j + k);
+      // pose of frame j couples to the velocity/bias unknowns of frames j-1 .. j+1 (the lead block counts as frame -1)
+      int lo = lead_y > 0 ? (j == 0 ? 0 : yoff + 9 * (j - 1)) : 9 * (j - 1);
+      s.xlo.push_back(lo < 0 ? 0 : (lo > ny ? ny : lo));
+    }
+  return s;
+}
+
 // R <- R * Exp(dphi), column-major 3x3 in/out; Rodrigues with the reference's 1e-11 cut-off (tools.hpp:51-66).
 inline void right_multiply_exp(const double* Rin, const double* dphi, double* Rout) {
   const double th = std::sqrt(dphi[0] * dphi[0] + dphi[1] * dphi[1] + dphi[2] * dphi[2]);
