@@ -88,3 +88,25 @@ def test_cfg2_window_with_rejected_steps_matches_the_checkers(vx):
     relative-change test stops it; checked on the oracle, nine iterations.)"""
     sc = synth.make_config("cfg2", rot_sigma_deg=0.2, trans_sigma=0.03)
     run_case(vx, sc, iters=8, need_reject=True)
+
+
+def test_cfg4_single_gpu_lm_matches_the_oracle(vx):
+    """BASELINE configs[3] is this 400k-voxel window sharded over eight GPUs; on one GPU it is the largest window the bench runs
+    (13 workgroup steps per CU in the Hessian sweep instead of four) -- two LM iterations against the oracle restatement."""
+    sc = synth.make_config("cfg4")
+    assert sc.n_voxels == 400_000
+    fg = vx.LidarFactor(sc.win_size)
+    fg.push_points(sc.n_voxels, sc.points_body, sc.cell_ptr, sc.fix, sc.coe)
+    clusters = fg.read_clusters()
+    fg.evaluate_only_residual(sc.poses_init)
+    got = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=2)
+    fo = O.Oracle(sc.win_size)
+    fo.push_voxels(clusters, sc.fix, sc.coe)
+    fo.evaluate_only_residual(sc.poses_init)
+    ref = fo.damping_iter(sc.poses_init, max_iter=2, thd_num=16)
+    assert np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:])
+    assert np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-9)
+    et, er = synth.pose_errors(got["poses"], ref["poses"])
+    assert et < 1e-7 and er < 1e-7, (et, er)
+    Hg = got["hess"]; Ho = ref["hess"]
+    assert np.allclose(Hg, Ho, rtol=0, atol=1e-9 * np.abs(Ho).max())
