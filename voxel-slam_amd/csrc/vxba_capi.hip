@@ -77,6 +77,7 @@ struct vxba_factor {
   size_t xlen = 0;               // doubles the exchange buffers (own_packed, h_packed) hold
   int precision = 0;             // 0: fp64 throughout; 1: Hessian products in f32 on the matrix cores, f64 accumulation
   unsigned lm_seq = 0;           // sequence numbers of solves published inside residual-sweep launches (never 0)
+  hipEvent_t li_ev = nullptr;    // marks the end of the residual sweep when a speculative Hessian sweep is queued behind it (LI host shells)
   bool solve_timed_out = false;  // the last damping_iter failed because voxel workgroups gave up waiting for the in-launch solve
   int fused_fallbacks = 0;       // times a call was transparently re-run with the solve as its own launch
   vxba_allreduce_fn allreduce = nullptr;
@@ -609,6 +610,7 @@ int vxba_destroy(vxba_factor* f) {
   hipFree(f->own_packed); hipFree(f->d_count); hipFree(f->d_poses);
   if (f->h_poses) hipHostFree(f->h_poses);
   for (auto& ev : f->pose_ev) if (ev) hipEventDestroy(ev);
+  if (f->li_ev) hipEventDestroy(f->li_ev);
   if (f->h_packed) hipHostFree(f->h_packed);
   if (f->h_scalar) hipHostFree(f->h_scalar);
   hipFree(f->d_lm); hipFree(f->d_li); hipFree(f->d_li_hess); hipFree(f->d_scratch);
@@ -1374,16 +1376,21 @@ int wait_stream(vxba_factor* f) {
   VX_HIP(f, q);
   return VXBA_OK;
 }
+// spec_queued: the Hessian sweep at exactly these states was queued speculatively behind the last residual sweep (li_joint_residual)
+// and is running or done -- nothing to launch.
 int li_joint_system(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* Hess, double* JacT, double* residual,
-                    bool with_g = false, const double* cov_invs = nullptr) {
+                    bool with_g = false, const double* cov_invs = nullptr, bool spec_queued = false) {
   const int W = f->W, n = vxi::DIM * W + (with_g ? 3 : 0), m = 6 * W;
   std::vector<double> Rp(12 * W);
   states_to_poses(W, states, Rp.data());
   // single GPU: the reduction kernel writes the packed system straight into pinned host memory (no copy to enqueue) and the host
   // polls for completion after its own half of the work; with a collective the reduced device buffer is copied as before
   const bool zc = !has_collective(f);
-  int rc = sweep_hess_device(f, Rp.data(), nullptr, nullptr, nullptr, 0, f->V, zc ? f->zc_packed : f->d_packed);
-  if (rc) return rc;
+  int rc = VXBA_OK;
+  if (!(spec_queued && zc)) {
+    rc = sweep_hess_device(f, Rp.data(), nullptr, nullptr, nullptr, 0, f->V, zc ? f->zc_packed : f->d_packed);
+    if (rc) return rc;
+  }
   if (!zc) VX_HIP(f, hipMemcpyAsync(f->h_packed, f->d_packed, vxba_packed_len(f) * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   std::memset(Hess, 0, sizeof(double) * n * n);
   std::memset(JacT, 0, sizeof(double) * n);
@@ -1397,8 +1404,12 @@ int li_joint_system(vxba_factor* f, const double* states, const double* imus, do
   *residual = res + f->h_packed[(size_t)m * m + m];
   return VXBA_OK;
 }
+// speculate (single GPU only): the Hessian sweep of the NEXT iteration -- at these trial states, on the cache this residual sweep leaves
+// -- is queued right behind it, before anybody knows whether the step will be accepted.  The host only waits for the residual (an
+// event), takes the decision, and if the step is accepted finds the next joint system already under way instead of paying a cold
+// launch and a round trip for it; a rejected step wastes the sweep (upstream recomputes nothing then either).
 int li_joint_residual(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* residual,
-                      const double* cov_invs = nullptr) {
+                      const double* cov_invs = nullptr, bool speculate = false) {
   const int W = f->W;
   std::vector<double> Rp(12 * W);
   states_to_poses(W, states, Rp.data());
@@ -1407,10 +1418,23 @@ int li_joint_residual(vxba_factor* f, const double* states, const double* imus, 
   int rc = sweep_residual_device(f, Rp.data(), nullptr, 0, 0, f->V, zc ? f->zc_packed + plen : f->d_scalar);
   if (rc) return rc;
   if (!zc) VX_HIP(f, hipMemcpyAsync(f->h_scalar, f->d_scalar, sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  const bool spec = speculate && zc;
+  if (spec) {
+    if (!f->li_ev) VX_HIP(f, hipEventCreateWithFlags(&f->li_ev, hipEventDisableTiming));
+    VX_HIP(f, hipEventRecord(f->li_ev, f->stream));
+    rc = sweep_hess_device(f, Rp.data(), nullptr, nullptr, nullptr, 0, f->V, f->zc_packed);
+    if (rc) return rc;
+  }
   vxi::ImuWork w;
   bool ok = true;
   const double r1 = vxi::li_add_imu_blocks(W, states, imus, imu_coef, false, nullptr, nullptr, w, &ok, false, cov_invs);
-  rc = wait_stream(f);
+  if (spec) {
+    hipError_t q;
+    while ((q = hipEventQuery(f->li_ev)) == hipErrorNotReady) {}
+    VX_HIP(f, q);
+  } else {
+    rc = wait_stream(f);
+  }
   if (rc) return rc;
   if (!ok) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
   *residual = r1 + (zc ? f->h_packed[plen] : f->h_scalar[0]);
@@ -1514,6 +1538,7 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
   int nt = 0;
   vxh::LiIndexSets li_sets;
   vxh::BandSchurWork bs_work;
+  bool spec_queued = false;
   // development aid: VXBA_LI_TIMING=1 prints where the host time of one call goes
   static const bool timing = [] { const char* e = getenv("VXBA_LI_TIMING"); return e && e[0] == '1'; }();
   double t_sys = 0, t_solve = 0, t_res = 0;
@@ -1523,7 +1548,8 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
     const bool recomputed = is_calc_hess;
     const auto t0 = now();
     if (is_calc_hess) {
-      int rc = li_joint_system(f, states, imus, imu_coef, Hess.data(), JacT.data(), &residual1, false, cov_invs.data());
+      int rc = li_joint_system(f, states, imus, imu_coef, Hess.data(), JacT.data(), &residual1, false, cov_invs.data(), spec_queued);
+      spec_queued = false;
       if (rc) return rc;
       if (hess_out) std::memcpy(hess_out, Hess.data(), sizeof(double) * n * n);   // *hess = Hess, before the gauge fix (:588)
     }
@@ -1564,8 +1590,10 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
     for (int r = 0; r < n; r++) q1 += dxi[r] * (u * D[r] * dxi[r] - JacT[r]);
     q1 *= 0.5;
     const auto t2 = now();
-    int rc = li_joint_residual(f, x_temp.data(), imus, imu_coef, &residual2, cov_invs.data());
+    const bool speculate = it + 1 < max_iter && !has_collective(f);
+    int rc = li_joint_residual(f, x_temp.data(), imus, imu_coef, &residual2, cov_invs.data(), speculate);
     if (rc) return rc;
+    spec_queued = speculate;     // only meaningful if the step is accepted (states <- x_temp); a rejected step never asks for the system
     const auto t3 = now();
     t_sys += us(t0, t1); t_solve += us(t1, t2); t_res += us(t2, t3);
     const double q = residual1 - residual2;
@@ -1612,10 +1640,12 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
   vxh::LiIndexSets li_sets;
   vxh::BandSchurWork bs_work;
   std::vector<double> Ared;
+  bool spec_queued = false;
   for (int it = 0; it < max_iter; it++) {
     const bool recomputed = is_calc_hess;
     if (is_calc_hess) {
-      int rc = li_joint_system(f, states, imus, imu_coef, Hess.data(), JacT.data(), &residual1, true, cov_invs.data());
+      int rc = li_joint_system(f, states, imus, imu_coef, Hess.data(), JacT.data(), &residual1, true, cov_invs.data(), spec_queued);
+      spec_queued = false;
       if (rc) return rc;
       if (hess_out) std::memcpy(hess_out, Hess.data(), sizeof(double) * n * n);
     }
@@ -1654,7 +1684,9 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
     double q1 = 0.0;
     for (int r = 0; r < n; r++) q1 += dxi[r] * (u * D[r] * dxi[r] - JacT[r]);
     q1 *= 0.5;
-    int rc = li_joint_residual(f, x_temp.data(), imus, imu_coef, &residual2, cov_invs.data());
+    const bool speculate = it + 1 < max_iter && !has_collective(f);
+    int rc = li_joint_residual(f, x_temp.data(), imus, imu_coef, &residual2, cov_invs.data(), speculate);
+    spec_queued = speculate;
     if (rc) return rc;
     const double q = residual1 - residual2;
     const double u_used = u, v_used = v;
