@@ -763,6 +763,13 @@ int mfail(vxba_map* m, int code, const char* msg) { if (m) m->err = msg; return 
     if (e__ != hipSuccess) { (m)->err = std::string(#call ": ") + hipGetErrorString(e__); return VXBA_ERR_HIP; } \
   } while (0)
 inline int grid_for(long long n, int b = 256) { return (int)std::max<long long>(1, (n + b - 1) / b); }   // never a zero-sized launch: the kernels bound-check
+// Completion of the map's stream by polling: the stages between two counter read-backs are tens of microseconds of kernels, less than
+// what waking up from hipStreamSynchronize costs (the same observation as in the LiDAR-inertial shell: ~25 us per wait).
+inline hipError_t map_wait(hipStream_t s) {
+  hipError_t q;
+  while ((q = hipStreamQuery(s)) == hipErrorNotReady) {}
+  return q;
+}
 
 template <class T>
 int grow_array(vxba_map* m, T** p, size_t old_n, size_t new_n) {
@@ -770,7 +777,7 @@ int grow_array(vxba_map* m, T** p, size_t old_n, size_t new_n) {
   VM_HIP(m, hipMalloc((void**)&q, new_n * sizeof(T)));
   VM_HIP(m, hipMemsetAsync(q, 0, new_n * sizeof(T), m->stream));
   if (*p && old_n) VM_HIP(m, hipMemcpyAsync(q, *p, old_n * sizeof(T), hipMemcpyDeviceToDevice, m->stream));
-  if (*p) { VM_HIP(m, hipStreamSynchronize(m->stream)); VM_HIP(m, hipFree(*p)); }
+  if (*p) { VM_HIP(m, map_wait(m->stream)); VM_HIP(m, hipFree(*p)); }
   *p = q;
   return VXBA_OK;
 }
@@ -799,7 +806,7 @@ int ensure_table(vxba_map* m, long long roots) {
   VM_HIP(m, hipMemsetAsync(v, 0, ncap * sizeof(int), m->stream));
   if (m->keys) {
     map_rehash_kernel<<<grid_for(m->table_cap), 256, 0, m->stream>>>(m->keys, m->vals, m->table_cap, k, v, (unsigned long long)ncap - 1);
-    VM_HIP(m, hipStreamSynchronize(m->stream));
+    VM_HIP(m, map_wait(m->stream));
     hipFree(m->keys); hipFree(m->vals);
   }
   m->keys = k; m->vals = v; m->table_cap = ncap;
@@ -816,7 +823,7 @@ int ensure_fix(vxba_map* m, long long want) {
 }
 int ensure_scratch(vxba_map* m, size_t bytes) {
   if (bytes <= m->scratch_cap) return VXBA_OK;
-  if (m->scratch) { VM_HIP(m, hipStreamSynchronize(m->stream)); hipFree(m->scratch); m->scratch = nullptr; m->scratch_cap = 0; }
+  if (m->scratch) { VM_HIP(m, map_wait(m->stream)); hipFree(m->scratch); m->scratch = nullptr; m->scratch_cap = 0; }
   const size_t want = bytes + bytes / 2;
   VM_HIP(m, hipMalloc((void**)&m->scratch, want));
   m->scratch_cap = want;
@@ -824,7 +831,7 @@ int ensure_scratch(vxba_map* m, size_t bytes) {
 }
 int ensure_stage(vxba_map* m, size_t bytes) {
   if (bytes <= m->stage_cap) return VXBA_OK;
-  if (m->stage) { VM_HIP(m, hipStreamSynchronize(m->stream)); hipFree(m->stage); m->stage = nullptr; m->stage_cap = 0; }
+  if (m->stage) { VM_HIP(m, map_wait(m->stream)); hipFree(m->stage); m->stage = nullptr; m->stage_cap = 0; }
   const size_t want = bytes + bytes / 2;
   VM_HIP(m, hipMalloc((void**)&m->stage, want));
   m->stage_cap = want;
@@ -839,7 +846,7 @@ int cnt_push(vxba_map* m) {
 }
 int cnt_pull(vxba_map* m) {
   VM_HIP(m, hipMemcpyAsync(m->h_cnt, m->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, m->stream));
-  VM_HIP(m, hipStreamSynchronize(m->stream));
+  VM_HIP(m, map_wait(m->stream));
   VM_HIP(m, hipGetLastError());
   m->n_nodes = m->h_cnt->n_nodes; m->n_roots = m->h_cnt->n_roots; m->fix_cursor = m->h_cnt->fix_cursor;
   return VXBA_OK;
@@ -921,7 +928,7 @@ static int map_cut_voxel_impl(vxba_map* m, int ord, int64_t n64, const double* p
   const int slot = m->mp[ord];
   vxba_map::Scan& sc = m->scan[slot];
   if (n > sc.cap) {
-    VM_HIP(m, hipStreamSynchronize(m->stream));
+    VM_HIP(m, map_wait(m->stream));
     hipFree(sc.pnt); hipFree(sc.var9); hipFree(sc.perm); hipFree(sc.tmp);
     sc.pnt = sc.var9 = nullptr; sc.perm = sc.tmp = nullptr;
     const size_t cap = (size_t)n + n / 4 + 64;
@@ -966,12 +973,12 @@ static int map_cut_voxel_impl(vxba_map* m, int ord, int64_t n64, const double* p
   map_mark_existing_roots_kernel<<<grid_for(nodes_before), 256, 0, m->stream>>>(m->nd, nodes_before, m->serial);
   // upstream quirk (voxel_map.hpp:1603-1605): fewer touched roots than threads -> nothing is pushed.  The children the descent above
   // allocated are empty leaves then, which changes nothing observable (no window, no points, never a factor).
-  if (m->h_cnt->n_touched < m->prm.thread_num) { VM_HIP(m, hipStreamSynchronize(m->stream)); return VXBA_OK; }
+  if (m->h_cnt->n_touched < m->prm.thread_num) { VM_HIP(m, map_wait(m->stream)); return VXBA_OK; }
   map_resolve_kernel<<<grid_for(n), 256, 0, m->stream>>>(m->nd, n, d_leaf, d_pend);
   map_iota_kernel<<<grid_for(n), 256, 0, m->stream>>>(d_iota, n);
   VM_HIP(m, rocprim::radix_sort_pairs(d_tmp, tb, d_leaf, d_leaf_s, d_iota, sc.perm, (size_t)n, 0, 32, m->stream));
   map_push_kernel<<<grid_for(n, 64), 64, 0, m->stream>>>(m->nd, m->prm, d_leaf_s, sc.perm, n, sc.pnt, sc.var9, d_w, slot);
-  VM_HIP(m, hipStreamSynchronize(m->stream));
+  VM_HIP(m, map_wait(m->stream));
   VM_HIP(m, hipGetLastError());
   return VXBA_OK;
 }
@@ -1032,7 +1039,7 @@ int vxba_map_recut(vxba_map* m, int win_count, const double* Rp, vxba_factor* fa
   double* d_cl = d_stage; double* d_fix = d_cl + (size_t)nf * W * 10; double* d_coe = d_fix + (size_t)nf * 10; double* d_ev = d_coe + nf;
   double* d_evec = d_ev + (size_t)nf * 3; double* d_mg = d_evec + (size_t)nf * 9;
   map_factor_gather_kernel<<<grid_for(nf), 256, 0, m->stream>>>(m->nd, W, ring, d_nodes_s, nf, d_cl, d_fix, d_coe, d_ev, d_evec, d_mg);
-  hipError_t e = hipStreamSynchronize(m->stream);
+  hipError_t e = map_wait(m->stream);
   if (e == hipSuccess) rc = vxba_internal_push_voxels_device(factor, nf, d_cl, d_fix, d_coe, d_ev, d_evec, d_mg);
   if (e != hipSuccess) return mfail(m, VXBA_ERR_HIP, "vxba_map_recut: gather failed");
   if (rc != VXBA_OK) return mfail(m, rc, vxba_last_error(factor));
@@ -1090,7 +1097,7 @@ int vxba_map_counts(vxba_map* m, int64_t out[4]) {
   vxmap::map_leaf_flag_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, d_n + 64, d_n);
   int nl = 0;
   VM_HIP(m, hipMemcpyAsync(&nl, d_n, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-  VM_HIP(m, hipStreamSynchronize(m->stream));
+  VM_HIP(m, map_wait(m->stream));
   out[0] = m->n_roots; out[1] = m->n_slide; out[2] = nl; out[3] = m->mp[0];
   return VXBA_OK;
 }
@@ -1109,7 +1116,7 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
   vxmap::map_leaf_flag_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, d_list, d_n);
   int nl = 0;
   VM_HIP(m, hipMemcpyAsync(&nl, d_n, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-  VM_HIP(m, hipStreamSynchronize(m->stream));
+  VM_HIP(m, map_wait(m->stream));
   *n_out = nl;
   if (!ids || !ints || !dbl || capacity <= 0) return VXBA_OK;
   const int n = (int)std::min<int64_t>(nl, capacity);
@@ -1122,7 +1129,7 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
   hipError_t e = hipMemcpyAsync(ids, d_ids, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(ints, d_ints, (size_t)n * 8 * sizeof(int), hipMemcpyDeviceToHost, m->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(dbl, d_dbl, (size_t)n * rec * sizeof(double), hipMemcpyDeviceToHost, m->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+  if (e == hipSuccess) e = map_wait(m->stream);
   hipFree(d_ids); hipFree(d_ints); hipFree(d_dbl);
   return e == hipSuccess ? VXBA_OK : mfail(m, VXBA_ERR_HIP, "vxba_map_leaves: copy failed");
 }
@@ -1165,7 +1172,7 @@ int vxba_map_export_planes(vxba_map* m, vxba_lio* lio, int64_t* n_exported) {
   vxmap::map_plane_export_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, m->prm.max_layer, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_n, 0);
   int n = 0;
   VM_HIP(m, hipMemcpyAsync(&n, d_n, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-  VM_HIP(m, hipStreamSynchronize(m->stream));
+  VM_HIP(m, map_wait(m->stream));
   (void)b_loc; (void)b_i; (void)b_3; (void)b_36; (void)b_1;
   if (n == 0) return VXBA_OK;
   const size_t c_loc = up((size_t)n * 3 * 8), c_i = up((size_t)n * 4), c_3 = up((size_t)n * 3 * 8), c_36 = up((size_t)n * 36 * 8), c_1 = up((size_t)n * 8);
@@ -1183,7 +1190,7 @@ int vxba_map_export_planes(vxba_map* m, vxba_lio* lio, int64_t* n_exported) {
   VM_HIP(m, hipMemsetAsync(d_n, 0, sizeof(int), m->stream));
   vxmap::map_plane_export_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, m->prm.max_layer, d_loc, d_layer, d_path, d_isp, d_center, d_normal, d_pvar, d_radius, d_n, n);
   vxmap::map_dirty_reset_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes);
-  VM_HIP(m, hipStreamSynchronize(m->stream));
+  VM_HIP(m, map_wait(m->stream));
   VM_HIP(m, hipGetLastError());
   rc = vxba_internal_lio_map_update_device(lio, n, d_loc, d_layer, d_path, d_isp, d_center, d_normal, d_pvar, d_radius);
   if (rc != VXBA_OK) return mfail(m, rc, vxba_lio_last_error(lio));
