@@ -2,7 +2,6 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch  # first: one HIP runtime in the process; its bundled hipSOLVER / rocBLAS are the ones that get loaded
 from voxel_slam_amd import synth, vxba
 from tests import _oracle as O
 W, V = 99, 100_000
@@ -20,10 +19,12 @@ f.set_profiling(3)
 for _ in range(5):
     f.acc_evaluate2(sc.poses_init); f.evaluate_only_residual(sc.poses_init)
 print(f.kernel_times(reset=True))
-for rep in range(3):
-    f.evaluate_only_residual(sc.poses_init)
-    t0 = time.perf_counter(); out = vxba.Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=4); dt = time.perf_counter() - t0
-    print("damping_iter(4) run %d: %.1f ms, %d iterations" % (rep, 1e3 * dt, out["trace"].shape[0]))
+for mode in (1, 0):
+    f.set_option("wide_device_solve", mode)
+    for rep in range(3):
+        f.evaluate_only_residual(sc.poses_init)
+        t0 = time.perf_counter(); out = vxba.Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=4); dt = time.perf_counter() - t0
+        print("damping_iter(4), %s solve, run %d: %.2f ms (%.2f ms per iteration), %d iterations" % ("device" if mode else "host", rep, 1e3 * dt, 1e3 * dt / out["trace"].shape[0], out["trace"].shape[0]))
 fo = O.Oracle(W); fo.push_voxels(sc.clusters, sc.fix, sc.coe); fo.evaluate_only_residual(sc.poses_init)
 t0 = time.perf_counter(); ref = fo.damping_iter(sc.poses_init, max_iter=4, thd_num=5); dto = time.perf_counter() - t0
 print("oracle damping_iter(4), 5 threads: %.1f ms" % (1e3 * dto), "pose diff", synth.pose_errors(out["poses"], ref["poses"]))

@@ -65,9 +65,9 @@ struct vxba_factor {
   vxli::LIState* d_li = nullptr; // device-resident LiDAR-inertial loop state (allocated on first use)
   double* d_li_hess = nullptr;   // (15W)^2 export of that loop's *hess
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
-  vxw::DenseSolver* wide_solver = nullptr;   // wide windows: device Cholesky of the (6W)-dimensional LM step (hipSOLVER, loaded on first use)
+  vxw::DenseSolver* wide_solver = nullptr;   // wide windows: device Cholesky of the (6W)-dimensional LM step (vxba_wide.hip)
   bool wide_solver_tried = false;
-  int opt[VXBA_OPT_COUNT] = {1, 1, 0, 0, 64, 0, 1};   // vxba_set_option; initial values may come from the environment (see vxba.h)
+  int opt[VXBA_OPT_COUNT] = {1, 1, 1, 0, 64, 0, 1};   // vxba_set_option; initial values may come from the environment (see vxba.h)
   vxw::WideIndex wide;           // wide windows: incidence structure (entries, entry pairs per Hessian block), rebuilt after a push
   bool wide_dirty = true;
   double* d_poses = nullptr;     // wide windows: W*12 poses on the device (the MFMA kernels take them by value)
@@ -333,7 +333,7 @@ void options_from_env(vxba_factor* f) {   // initial values only; vxba_set_optio
   auto flag = [](const char* name, int dflt) { const char* e = getenv(name); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : dflt; };
   f->opt[VXBA_OPT_FUSED_SOLVE] = flag("VXBA_FUSED_SOLVE", 1);
   f->opt[VXBA_OPT_SPEC_COLLECTIVE] = flag("VXBA_SPEC_COLLECTIVE", 1);
-  f->opt[VXBA_OPT_WIDE_DEVICE_SOLVE] = flag("VXBA_WIDE_DEVICE_SOLVE", 0);
+  f->opt[VXBA_OPT_WIDE_DEVICE_SOLVE] = flag("VXBA_WIDE_DEVICE_SOLVE", 1);
   f->opt[VXBA_OPT_LI_DEVICE_LOOP] = flag("VXBA_LI_DEVICE", 0);
   const char* e = getenv("VXBA_K2_VPB");
   const int v = e ? atoi(e) : 64;
@@ -1104,13 +1104,12 @@ static int damping_iter_impl(vxba_factor* f, double* Rp, int max_iter, double* h
     // device Cholesky (only dxi, q1 and residual1 come back: ~5 KB) or, if that is unavailable / the system is not positive
     // definite, by the host's pivoted LDL^T on the downloaded system; accept/reject on the host.
     const int W = f->W, n = 6 * W;
-    if (!f->wide_solver && !f->wide_solver_tried) {
-      // opt-in: the first use pulls hipSOLVER + rocSOLVER + rocBLAS into the process, which costs seconds when they are warm and
-      // minutes when they come off a cold disk -- worth it for a long-running mapper, not for a default
-      const bool allow = f->opt[VXBA_OPT_WIDE_DEVICE_SOLVE] != 0;
-      if (allow) f->wide_solver = vxw::wide_solver_create(n, f->stream);
+    if (!f->wide_solver && !f->wide_solver_tried && f->opt[VXBA_OPT_WIDE_DEVICE_SOLVE] != 0) {
+      // the library's own blocked Cholesky (vxba_wide.hip): a few device buffers, no third-party library to load
+      f->wide_solver = vxw::wide_solver_create(n, f->stream);
       f->wide_solver_tried = true;
     }
+    const bool use_device_solver = f->wide_solver && f->opt[VXBA_OPT_WIDE_DEVICE_SOLVE] != 0;
     double u = 0.01, v = 2;
     std::vector<double> x(Rp, Rp + 12 * W), x_temp(x), dxi(n), Hh, Jh;
     vxh::LMWorkspace ws;
@@ -1125,7 +1124,7 @@ static int damping_iter_impl(vxba_factor* f, double* Rp, int max_iter, double* h
         host_copy_valid = false;
       }
       bool on_device = false;
-      if (f->wide_solver) {
+      if (use_device_solver) {
         double r1 = 0;
         on_device = vxw::wide_solver_step(f->wide_solver, f->d_packed, u, f->stream, dxi.data(), &q1, &r1) == 0;
         if (on_device) {

@@ -7,7 +7,6 @@
 
 #include <cstdint>
 #include <cstring>
-#include <dlfcn.h>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -395,21 +394,142 @@ void launch_k3_wide(const FactorView& fv, const double* d_poses, const WideIndex
 
 // ------------------------------------------------------------------------------------------------------------------
 // Dense solve of the wide LM step on the device: (H + u D) dxi = -JacT with the gauge rows / columns replaced by identity,
-// n = 6W up to 768.  A plain dense Cholesky -- taken from the vendor library (hipSOLVER potrf / potrs, resolved with dlopen on
-// first use so that narrow-window users never load it); the assembly of the damped system, the gain-ratio denominator q1 and the
-// checks stay here.  Falls back to the host LDL^T when the library is missing or the factorisation reports a non-positive pivot.
+// n = 6W up to 768.  Round 1 took potrf / potrs from hipSOLVER (dlopen on first use: 0.3 s when the libraries were resident, minutes
+// off a cold disk, and 2 ms per factorisation at n = 594).  Round 2: a blocked right-looking Cholesky written for this size.
+//   * The matrix is stored column-major with ONE EXTRA ROW that holds the right-hand side: treating b^T as row n of the lower
+//     triangle makes the panel step compute L^-1 b along the way (forward substitution for free).
+//   * Block step k (32 columns): wchol_panel_kernel -- every workgroup factors the 32 x 32 diagonal block for itself in LDS (32
+//     pivots; cheaper than a launch and a device-wide hand-over) and forward-substitutes its 256 panel rows, one row per thread in
+//     registers, L_kk broadcast from LDS; then wchol_trailing_kernel -- one workgroup per 32 x 32 tile of the lower trailing matrix,
+//     A_ij -= L_i L_j^T with both 32 x 32 panels in LDS.  19 steps of two launches at n = 594.
+//   * wchol_backsolve_kernel: L^T x = y, blocked, one workgroup; dots over the later rows run down contiguous columns.
+// A non-positive pivot sets `info`; the caller then takes the host's pivoted LDL^T for this step (the reference's own solver).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void wide_prepare_kernel(const double* __restrict__ packed, int n, double u, double* __restrict__ A, double* __restrict__ b, double* __restrict__ dvec) {
+constexpr int WC_NB = 32;
+__global__ void wide_prepare_kernel(const double* __restrict__ packed, int n, double u, double* __restrict__ A, int lda, double* __restrict__ dvec, int* __restrict__ info) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) *info = 0;
   if (t < (long long)n * n) {
     const int r = (int)(t % n), c = (int)(t / n);
     double h = (r < 6 || c < 6) ? ((r == c) ? 1.0 : 0.0) : packed[t];     // gauge fix on frame 0 (voxel_map.hpp:397-400)
     if (r == c) { dvec[r] = h; h += u * h; }                                // D = diag(H), A = H + u D (:402-403)
-    A[t] = h;
+    A[(size_t)c * lda + r] = h;
   } else if (t < (long long)n * n + n) {
     const int i = (int)(t - (long long)n * n);
-    b[i] = i < 6 ? 0.0 : -packed[t];
+    A[(size_t)i * lda + n] = i < 6 ? 0.0 : -packed[t];                     // row n: the right-hand side
   }
+}
+// block step at column k0 (kb columns): diagonal factor (every workgroup, in LDS) + forward substitution of the rows below
+// (the factored diagonal block goes to a side buffer Lkk: writing it over A's diagonal block here would race with the workgroups that
+// have not read the unfactored block yet)
+__global__ __launch_bounds__(256) void wchol_panel_kernel(double* __restrict__ A, int lda, int nrows, int k0, int kb, double* __restrict__ Lkk, int* __restrict__ info) {
+  __shared__ double D[WC_NB][WC_NB + 1];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < kb * kb; e += 256) { const int r = e % kb, c = e / kb; D[r][c] = A[(size_t)(k0 + c) * lda + k0 + r]; }
+  __syncthreads();
+  for (int p = 0; p < kb; p++) {
+    if (tid == 0) {
+      double d = D[p][p];
+      if (!(d > 0.0)) { if (blockIdx.x == 0) atomicMax(info, k0 + p + 1); d = 1.0; }
+      D[p][p] = sqrt(d);
+    }
+    __syncthreads();
+    if (tid > p && tid < kb) D[tid][p] /= D[p][p];
+    __syncthreads();
+    // trailing update of the lower triangle inside the block
+    const int m = kb - p - 1;
+    for (int e = tid; e < m * m; e += 256) {
+      const int r = p + 1 + e % m, c = p + 1 + e / m;
+      if (r >= c) D[r][c] -= D[r][p] * D[c][p];
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0)
+    for (int e = tid; e < WC_NB * WC_NB; e += 256) { const int r = e % WC_NB, c = e / WC_NB; Lkk[e] = (r < kb && c < kb && r >= c) ? D[r][c] : 0.0; }   // [c][r]: column-major 32 x 32
+  const int r = k0 + kb + blockIdx.x * 256 + tid;
+  if (r < nrows) {
+    double l[WC_NB];
+#pragma unroll
+    for (int c = 0; c < WC_NB; c++) l[c] = c < kb ? A[(size_t)(k0 + c) * lda + r] : 0.0;
+#pragma unroll
+    for (int c = 0; c < WC_NB; c++) {
+      if (c < kb) {
+        double sum = l[c];
+#pragma unroll
+        for (int j = 0; j < c; j++) sum -= l[j] * D[c][j];
+        l[c] = sum / D[c][c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < WC_NB; c++) if (c < kb) A[(size_t)(k0 + c) * lda + r] = l[c];
+  }
+}
+// A[i][j] -= sum_c L[i][k0 + c] L[j][k0 + c] on the lower tiles of the trailing matrix (rows / columns from k0 + kb)
+__global__ __launch_bounds__(256) void wchol_trailing_kernel(double* __restrict__ A, int lda, int nrows, int ncols, int k0, int kb) {
+  const int I = blockIdx.y, J = blockIdx.x;
+  if (J > I) return;
+  __shared__ double Li[WC_NB][WC_NB + 1], Lj[WC_NB][WC_NB + 1];
+  const int base = k0 + kb, r0 = base + I * WC_NB, c0 = base + J * WC_NB;
+  if (c0 >= ncols) return;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < WC_NB * WC_NB; e += 256) {
+    const int rr = e % WC_NB, k = e / WC_NB;
+    Li[rr][k] = (k < kb && r0 + rr < nrows) ? A[(size_t)(k0 + k) * lda + r0 + rr] : 0.0;
+    Lj[rr][k] = (k < kb && c0 + rr < nrows) ? A[(size_t)(k0 + k) * lda + c0 + rr] : 0.0;
+  }
+  __syncthreads();
+  const int tx = tid & 15, ty = tid >> 4;    // 16 x 16 threads, 2 x 2 outputs each: rows tx, tx + 16; columns ty, ty + 16
+  double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+#pragma unroll 8
+  for (int k = 0; k < WC_NB; k++) {
+    const double i0 = Li[tx][k], i1 = Li[tx + 16][k], j0 = Lj[ty][k], j1 = Lj[ty + 16][k];
+    a00 += i0 * j0; a01 += i0 * j1; a10 += i1 * j0; a11 += i1 * j1;
+  }
+  auto upd = [&](int rr, int cc, double v) {
+    const int r = r0 + rr, c = c0 + cc;
+    if (r < nrows && c < ncols && r >= c) A[(size_t)c * lda + r] -= v;
+  };
+  upd(tx, ty, a00); upd(tx, ty + 16, a01); upd(tx + 16, ty, a10); upd(tx + 16, ty + 16, a11);
+}
+// L^T x = y with y = row n of the factored matrix; one workgroup of 1024 threads; x -> out[0..n)
+__global__ __launch_bounds__(1024) void wchol_backsolve_kernel(const double* __restrict__ A, int lda, int n, const double* __restrict__ Lkk_all, double* __restrict__ x_out) {
+  __shared__ double x[WIDE_MAXW * 6];
+  __shared__ double part[WC_NB][33];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += 1024) x[i] = A[(size_t)i * lda + n];
+  __syncthreads();
+  const int nblk = (n + WC_NB - 1) / WC_NB;
+  for (int blk = nblk - 1; blk >= 0; blk--) {
+    const int k0 = blk * WC_NB, kb = (n - k0 < WC_NB) ? n - k0 : WC_NB;
+    // (a) subtract what the later rows contribute: 32 threads per column walk down the (contiguous) column
+    const int c = tid >> 5, q = tid & 31;
+    double sum = 0.0;
+    if (c < kb) {
+      const double* col = A + (size_t)(k0 + c) * lda;
+      for (int i = k0 + kb + q; i < n; i += 32) sum += col[i] * x[i];
+    }
+    part[c][q] = sum;
+    __syncthreads();
+    if (tid < kb) {
+      double t = 0.0;
+      for (int j = 0; j < 32; j++) t += part[tid][j];
+      x[k0 + tid] -= t;
+    }
+    __syncthreads();
+    // (b) the block's own triangle, last column first
+    if (tid < 64) {
+      for (int cc = kb - 1; cc >= 0; cc--) {
+        const double* Lkk = Lkk_all + (size_t)blk * WC_NB * WC_NB;      // column-major: L(r, c) at [c * 32 + r]
+        const double xc = x[k0 + cc] / Lkk[cc * WC_NB + cc];
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) x[k0 + cc] = xc;
+        if (tid < cc) x[k0 + tid] -= Lkk[tid * WC_NB + cc] * xc;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += 1024) x_out[i] = x[i];
 }
 // out[0..n) = dxi, out[n] = q1 = 0.5 dxi . (u D dxi - JacT), out[n+1] = residual1 (packed's last slot)
 __global__ __launch_bounds__(256) void wide_q1_kernel(const double* __restrict__ packed, const double* __restrict__ dxi, const double* __restrict__ dvec, int n,
@@ -431,79 +551,55 @@ __global__ __launch_bounds__(256) void wide_q1_kernel(const double* __restrict__
   if (threadIdx.x == 0) { out[n] = 0.5 * red[0]; out[n + 1] = packed[(size_t)n * n + n]; }
 }
 
-typedef int (*fn_create)(void**);
-typedef int (*fn_destroy)(void*);
-typedef int (*fn_setstream)(void*, hipStream_t);
-typedef int (*fn_potrf_bs)(void*, int, int, double*, int, int*);
-typedef int (*fn_potrf)(void*, int, int, double*, int, double*, int, int*);
-typedef int (*fn_potrs)(void*, int, int, int, const double*, int, double*, int, int*);
-
 struct DenseSolver {
-  void* lib = nullptr;
-  void* handle = nullptr;
-  fn_destroy destroy = nullptr;
-  fn_setstream setstream = nullptr;
-  fn_potrf_bs potrf_bs = nullptr;
-  fn_potrf potrf = nullptr;
-  fn_potrs potrs = nullptr;
-  double *d_A = nullptr, *d_b = nullptr, *d_dvec = nullptr, *d_work = nullptr, *d_out = nullptr, *h_out = nullptr;
+  double *d_A = nullptr, *d_Lkk = nullptr, *d_x = nullptr, *d_dvec = nullptr, *d_out = nullptr, *h_out = nullptr;
   int* d_info = nullptr;
   int* h_info = nullptr;
-  int n = 0, lwork = 0;
+  int n = 0;
 };
 
 void wide_solver_free(DenseSolver*& ds) {
   if (!ds) return;
-  if (ds->handle && ds->destroy) ds->destroy(ds->handle);
-  void* ptrs[] = {ds->d_A, ds->d_b, ds->d_dvec, ds->d_work, ds->d_out, ds->d_info};
+  void* ptrs[] = {ds->d_A, ds->d_Lkk, ds->d_x, ds->d_dvec, ds->d_out, ds->d_info};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   if (ds->h_out) (void)hipHostFree(ds->h_out);
   if (ds->h_info) (void)hipHostFree(ds->h_info);
-  if (ds->lib) dlclose(ds->lib);
   delete ds;
   ds = nullptr;
 }
 
-// nullptr if the library cannot be used (caller falls back to the host solve)
-DenseSolver* wide_solver_create(int n, hipStream_t s) {
+// nullptr if the buffers cannot be allocated (caller falls back to the host solve)
+DenseSolver* wide_solver_create(int n, hipStream_t) {
   DenseSolver* ds = new DenseSolver();
   ds->n = n;
-  ds->lib = dlopen("libhipsolver.so", RTLD_NOW | RTLD_LOCAL);
-  if (!ds->lib) ds->lib = dlopen("/opt/rocm/lib/libhipsolver.so", RTLD_NOW | RTLD_LOCAL);
-  if (!ds->lib) { wide_solver_free(ds); return nullptr; }
-  fn_create create = (fn_create)dlsym(ds->lib, "hipsolverDnCreate");
-  ds->destroy = (fn_destroy)dlsym(ds->lib, "hipsolverDnDestroy");
-  ds->setstream = (fn_setstream)dlsym(ds->lib, "hipsolverDnSetStream");
-  ds->potrf_bs = (fn_potrf_bs)dlsym(ds->lib, "hipsolverDnDpotrf_bufferSize");
-  ds->potrf = (fn_potrf)dlsym(ds->lib, "hipsolverDnDpotrf");
-  ds->potrs = (fn_potrs)dlsym(ds->lib, "hipsolverDnDpotrs");
-  if (!create || !ds->destroy || !ds->setstream || !ds->potrf_bs || !ds->potrf || !ds->potrs || create(&ds->handle) != 0) { wide_solver_free(ds); return nullptr; }
-  bool ok = ds->setstream(ds->handle, s) == 0;
-  ok = ok && hipMalloc((void**)&ds->d_A, sizeof(double) * n * n) == hipSuccess && hipMalloc((void**)&ds->d_b, sizeof(double) * n) == hipSuccess &&
-       hipMalloc((void**)&ds->d_dvec, sizeof(double) * n) == hipSuccess && hipMalloc((void**)&ds->d_out, sizeof(double) * (n + 2)) == hipSuccess &&
-       hipMalloc((void**)&ds->d_info, sizeof(int)) == hipSuccess && hipHostMalloc((void**)&ds->h_out, sizeof(double) * (n + 2), hipHostMallocDefault) == hipSuccess &&
-       hipHostMalloc((void**)&ds->h_info, sizeof(int), hipHostMallocDefault) == hipSuccess;
-  constexpr int FILL_LOWER = 122;   // HIPBLAS_FILL_MODE_LOWER
-  ok = ok && ds->potrf_bs(ds->handle, FILL_LOWER, n, ds->d_A, n, &ds->lwork) == 0;
-  ok = ok && hipMalloc((void**)&ds->d_work, sizeof(double) * (ds->lwork > 0 ? ds->lwork : 1)) == hipSuccess;
+  const bool ok = hipMalloc((void**)&ds->d_A, sizeof(double) * (size_t)(n + 1) * n) == hipSuccess && hipMalloc((void**)&ds->d_x, sizeof(double) * n) == hipSuccess &&
+                  hipMalloc((void**)&ds->d_Lkk, sizeof(double) * (size_t)((n + WC_NB - 1) / WC_NB) * WC_NB * WC_NB) == hipSuccess &&
+                  hipMalloc((void**)&ds->d_dvec, sizeof(double) * n) == hipSuccess && hipMalloc((void**)&ds->d_out, sizeof(double) * (n + 2)) == hipSuccess &&
+                  hipMalloc((void**)&ds->d_info, sizeof(int)) == hipSuccess && hipHostMalloc((void**)&ds->h_out, sizeof(double) * (n + 2), hipHostMallocDefault) == hipSuccess &&
+                  hipHostMalloc((void**)&ds->h_info, sizeof(int), hipHostMallocDefault) == hipSuccess;
   if (!ok) { wide_solver_free(ds); return nullptr; }
   return ds;
 }
 
 // One damped step from the packed buffer on the device.  Host outputs: dxi (n), *q1, *residual1.  Returns 0, or 1 if the
-// factorisation failed (not positive definite) / a library call failed -- the caller then takes the host path for this step.
+// factorisation met a non-positive pivot / a call failed -- the caller then takes the host path for this step.
 int wide_solver_step(DenseSolver* ds, const double* d_packed, double u, hipStream_t s, double* dxi, double* q1, double* residual1) {
-  const int n = ds->n;
-  constexpr int FILL_LOWER = 122;
+  const int n = ds->n, lda = n + 1, nrows = n + 1;
   const long long tot = (long long)n * n + n;
-  wide_prepare_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s>>>(d_packed, n, u, ds->d_A, ds->d_b, ds->d_dvec);
-  if (ds->setstream(ds->handle, s) != 0) return 1;
-  if (ds->potrf(ds->handle, FILL_LOWER, n, ds->d_A, n, ds->d_work, ds->lwork, ds->d_info) != 0) return 1;
+  wide_prepare_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s>>>(d_packed, n, u, ds->d_A, lda, ds->d_dvec, ds->d_info);
+  for (int k0 = 0; k0 < n; k0 += WC_NB) {
+    const int kb = n - k0 < WC_NB ? n - k0 : WC_NB;
+    const int below = nrows - k0 - kb;                       // rows under the diagonal block (>= 1: the right-hand side row)
+    wchol_panel_kernel<<<dim3((unsigned)((below + 255) / 256)), dim3(256), 0, s>>>(ds->d_A, lda, nrows, k0, kb, ds->d_Lkk + (size_t)(k0 / WC_NB) * WC_NB * WC_NB, ds->d_info);
+    const int tr = (below + WC_NB - 1) / WC_NB, tc = (n - k0 - kb + WC_NB - 1) / WC_NB;
+    if (tc > 0) wchol_trailing_kernel<<<dim3((unsigned)tc, (unsigned)tr), dim3(256), 0, s>>>(ds->d_A, lda, nrows, n, k0, kb);
+  }
+  wchol_backsolve_kernel<<<dim3(1), dim3(1024), 0, s>>>(ds->d_A, lda, n, ds->d_Lkk, ds->d_x);
+  wide_q1_kernel<<<dim3(1), dim3(256), 0, s>>>(d_packed, ds->d_x, ds->d_dvec, n, u, ds->d_out);
   if (hipMemcpyAsync(ds->h_info, ds->d_info, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
-  if (ds->potrs(ds->handle, FILL_LOWER, n, 1, ds->d_A, n, ds->d_b, n, ds->d_info) != 0) return 1;
-  wide_q1_kernel<<<dim3(1), dim3(256), 0, s>>>(d_packed, ds->d_b, ds->d_dvec, n, u, ds->d_out);
   if (hipMemcpyAsync(ds->h_out, ds->d_out, sizeof(double) * (n + 2), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
   if (hipStreamSynchronize(s) != hipSuccess) return 1;
+  if (hipGetLastError() != hipSuccess) return 1;
   if (*ds->h_info != 0) return 1;
   std::memcpy(dxi, ds->h_out, sizeof(double) * n);
   *q1 = ds->h_out[n];
