@@ -419,33 +419,50 @@ __global__ void wide_prepare_kernel(const double* __restrict__ packed, int n, do
     A[(size_t)i * lda + n] = i < 6 ? 0.0 : -packed[t];                     // row n: the right-hand side
   }
 }
-// block step at column k0 (kb columns): diagonal factor (every workgroup, in LDS) + forward substitution of the rows below
+// block step at column k0 (kb columns): diagonal factor (every workgroup for itself) + forward substitution of the rows below.
+// The 32 x 32 diagonal block is factored by ONE wave, lane r holding row r in registers: per pivot the scaled column goes to LDS once
+// and comes back as broadcast reads -- no workgroup barrier inside the 32-step chain (a first version with all 256 threads, three
+// barriers and an integer division per pivot took 31 us per step; profiles/r02_v3).
 // (the factored diagonal block goes to a side buffer Lkk: writing it over A's diagonal block here would race with the workgroups that
 // have not read the unfactored block yet)
 __global__ __launch_bounds__(256) void wchol_panel_kernel(double* __restrict__ A, int lda, int nrows, int k0, int kb, double* __restrict__ Lkk, int* __restrict__ info) {
-  __shared__ double D[WC_NB][WC_NB + 1];
+  __shared__ double D[WC_NB][WC_NB + 1];     // D[c][r] = L(r, c): column c contiguous -> broadcast reads of a column's entries
+  __shared__ double colbuf[WC_NB];
   const int tid = threadIdx.x;
-  for (int e = tid; e < kb * kb; e += 256) { const int r = e % kb, c = e / kb; D[r][c] = A[(size_t)(k0 + c) * lda + k0 + r]; }
-  __syncthreads();
-  for (int p = 0; p < kb; p++) {
-    if (tid == 0) {
-      double d = D[p][p];
-      if (!(d > 0.0)) { if (blockIdx.x == 0) atomicMax(info, k0 + p + 1); d = 1.0; }
-      D[p][p] = sqrt(d);
+  if (tid < 64) {
+    const int r = tid;
+    const bool row = r < kb;
+    double d[WC_NB];
+#pragma unroll
+    for (int c = 0; c < WC_NB; c++) d[c] = (row && c <= r && c < kb) ? A[(size_t)(k0 + c) * lda + k0 + r] : 0.0;
+#pragma unroll
+    for (int p = 0; p < WC_NB; p++) {
+      if (p < kb) {
+        // pivot: lane p's d[p]
+        double piv = __shfl(d[p], p, 64);
+        if (!(piv > 0.0)) { if (blockIdx.x == 0 && tid == 0) atomicMax(info, k0 + p + 1); piv = 1.0; }
+        const double sq = sqrt(piv), inv = 1.0 / sq;
+        const double l = (r == p) ? sq : (r > p ? d[p] * inv : 0.0);
+        d[p] = l;
+        if (r < WC_NB) colbuf[r] = l;
+        __builtin_amdgcn_wave_barrier();
+        // rank-1 update of my row: d[c] -= l_r * l_c for p < c <= r
+#pragma unroll
+        for (int c = p + 1; c < WC_NB; c++) {
+          const double lc = colbuf[c];
+          d[c] -= (c <= r) ? l * lc : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
     }
-    __syncthreads();
-    if (tid > p && tid < kb) D[tid][p] /= D[p][p];
-    __syncthreads();
-    // trailing update of the lower triangle inside the block
-    const int m = kb - p - 1;
-    for (int e = tid; e < m * m; e += 256) {
-      const int r = p + 1 + e % m, c = p + 1 + e / m;
-      if (r >= c) D[r][c] -= D[r][p] * D[c][p];
+    if (r < WC_NB) {
+#pragma unroll
+      for (int c = 0; c < WC_NB; c++) D[c][r] = (row && c <= r) ? d[c] : 0.0;
     }
-    __syncthreads();
   }
+  __syncthreads();
   if (blockIdx.x == 0)
-    for (int e = tid; e < WC_NB * WC_NB; e += 256) { const int r = e % WC_NB, c = e / WC_NB; Lkk[e] = (r < kb && c < kb && r >= c) ? D[r][c] : 0.0; }   // [c][r]: column-major 32 x 32
+    for (int e = tid; e < WC_NB * WC_NB; e += 256) { const int r = e % WC_NB, c = e / WC_NB; Lkk[e] = D[c][r]; }   // [c][r]: column-major 32 x 32
   const int r = k0 + kb + blockIdx.x * 256 + tid;
   if (r < nrows) {
     double l[WC_NB];
@@ -456,7 +473,7 @@ __global__ __launch_bounds__(256) void wchol_panel_kernel(double* __restrict__ A
       if (c < kb) {
         double sum = l[c];
 #pragma unroll
-        for (int j = 0; j < c; j++) sum -= l[j] * D[c][j];
+        for (int j = 0; j < c; j++) sum -= l[j] * D[j][c];     // L(c, j)
         l[c] = sum / D[c][c];
       }
     }
@@ -491,41 +508,41 @@ __global__ __launch_bounds__(256) void wchol_trailing_kernel(double* __restrict_
   };
   upd(tx, ty, a00); upd(tx, ty + 16, a01); upd(tx + 16, ty, a10); upd(tx + 16, ty + 16, a11);
 }
-// L^T x = y with y = row n of the factored matrix; one workgroup of 1024 threads; x -> out[0..n)
+// L^T x = y with y = row n of the factored matrix; one workgroup of 1024 threads; x -> out[0..n).  Left-looking by blocks, last block
+// first: one wave solves the block's own 32 x 32 triangle, then every earlier unknown j subtracts what the block contributes to it,
+// sum_r L(k0 + r, j) x_(k0 + r) -- 32 CONTIGUOUS doubles of column j per thread, all loads independent.  (A first version let 32
+// threads walk down each column with one load in flight per thread: 173 us per solve.)
 __global__ __launch_bounds__(1024) void wchol_backsolve_kernel(const double* __restrict__ A, int lda, int n, const double* __restrict__ Lkk_all, double* __restrict__ x_out) {
   __shared__ double x[WIDE_MAXW * 6];
-  __shared__ double part[WC_NB][33];
   const int tid = threadIdx.x;
   for (int i = tid; i < n; i += 1024) x[i] = A[(size_t)i * lda + n];
   __syncthreads();
   const int nblk = (n + WC_NB - 1) / WC_NB;
   for (int blk = nblk - 1; blk >= 0; blk--) {
     const int k0 = blk * WC_NB, kb = (n - k0 < WC_NB) ? n - k0 : WC_NB;
-    // (a) subtract what the later rows contribute: 32 threads per column walk down the (contiguous) column
-    const int c = tid >> 5, q = tid & 31;
-    double sum = 0.0;
-    if (c < kb) {
-      const double* col = A + (size_t)(k0 + c) * lda;
-      for (int i = k0 + kb + q; i < n; i += 32) sum += col[i] * x[i];
-    }
-    part[c][q] = sum;
-    __syncthreads();
-    if (tid < kb) {
-      double t = 0.0;
-      for (int j = 0; j < 32; j++) t += part[tid][j];
-      x[k0 + tid] -= t;
-    }
-    __syncthreads();
-    // (b) the block's own triangle, last column first
     if (tid < 64) {
-      for (int cc = kb - 1; cc >= 0; cc--) {
-        const double* Lkk = Lkk_all + (size_t)blk * WC_NB * WC_NB;      // column-major: L(r, c) at [c * 32 + r]
-        const double xc = x[k0 + cc] / Lkk[cc * WC_NB + cc];
-        __builtin_amdgcn_wave_barrier();
-        if (tid == 0) x[k0 + cc] = xc;
-        if (tid < cc) x[k0 + tid] -= Lkk[tid * WC_NB + cc] * xc;
-        __builtin_amdgcn_wave_barrier();
+      const double* Lkk = Lkk_all + (size_t)blk * WC_NB * WC_NB;      // column-major: L(r, c) at [c * 32 + r]
+      double mine = tid < kb ? x[k0 + tid] : 0.0;                     // lane c owns x_(k0 + c)
+      double lrow[WC_NB];                                             // L(cc, tid) for cc > tid: column tid of the block, below the diagonal
+#pragma unroll
+      for (int cc = 0; cc < WC_NB; cc++) lrow[cc] = (tid < kb && cc < kb && cc >= tid) ? Lkk[tid * WC_NB + cc] : (cc == tid ? 1.0 : 0.0);
+#pragma unroll
+      for (int cc = WC_NB - 1; cc >= 0; cc--) {
+        if (cc < kb) {
+          const double xc = __shfl(mine, cc, 64) / __shfl(lrow[cc], cc, 64);   // x_cc = y_cc / L(cc, cc)
+          mine = (tid == cc) ? xc : (tid < cc ? mine - lrow[cc] * xc : mine);
+        }
       }
+      if (tid < kb) x[k0 + tid] = mine;
+    }
+    __syncthreads();
+    // earlier unknowns: j < k0
+    for (int j = tid; j < k0; j += 1024) {
+      const double* col = A + (size_t)j * lda + k0;
+      double sum = 0.0;
+#pragma unroll
+      for (int r = 0; r < WC_NB; r++) sum += (r < kb) ? col[r] * x[k0 + r] : 0.0;
+      x[j] -= sum;
     }
     __syncthreads();
   }
