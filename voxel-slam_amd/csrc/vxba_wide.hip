@@ -419,50 +419,63 @@ __global__ void wide_prepare_kernel(const double* __restrict__ packed, int n, do
     A[(size_t)i * lda + n] = i < 6 ? 0.0 : -packed[t];                     // row n: the right-hand side
   }
 }
-// block step at column k0 (kb columns): diagonal factor (every workgroup for itself) + forward substitution of the rows below.
-// The 32 x 32 diagonal block is factored by ONE wave, lane r holding row r in registers: per pivot the scaled column goes to LDS once
-// and comes back as broadcast reads -- no workgroup barrier inside the 32-step chain (a first version with all 256 threads, three
-// barriers and an integer division per pivot took 31 us per step; profiles/r02_v3).
-// (the factored diagonal block goes to a side buffer Lkk: writing it over A's diagonal block here would race with the workgroups that
-// have not read the unfactored block yet)
-__global__ __launch_bounds__(256) void wchol_panel_kernel(double* __restrict__ A, int lda, int nrows, int k0, int kb, double* __restrict__ Lkk, int* __restrict__ info) {
-  __shared__ double D[WC_NB][WC_NB + 1];     // D[c][r] = L(r, c): column c contiguous -> broadcast reads of a column's entries
-  __shared__ double colbuf[WC_NB];
-  const int tid = threadIdx.x;
-  if (tid < 64) {
-    const int r = tid;
-    const bool row = r < kb;
-    double d[WC_NB];
+// Cholesky factor of a kb x kb diagonal block (kb <= 32) by ONE wave, lane r holding row r of the lower triangle in registers.  Per
+// pivot: pivot by v_readlane, 1/sqrt by v_rsq_f64 + two Newton steps, the scaled column to LDS once and back as broadcast reads -- no
+// workgroup barrier inside the 32-step chain.  Result: Dout[c][r] = L(r, c) (zeros elsewhere).  A non-positive pivot is reported.
+__device__ __forceinline__ double wchol_readlane(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wchol_factor_block(double (&d)[WC_NB], int lane, int kb, int blk_base, double* colbuf, double (*Dout)[WC_NB + 1], int* info, bool report) {
+  const int r = lane;
 #pragma unroll
-    for (int c = 0; c < WC_NB; c++) d[c] = (row && c <= r && c < kb) ? A[(size_t)(k0 + c) * lda + k0 + r] : 0.0;
+  for (int p = 0; p < WC_NB; p++) {
+    if (p < kb) {
+      double piv = wchol_readlane(d[p], p);
+      if (!(piv > 0.0)) { if (report && lane == 0) atomicMax(info, blk_base + p + 1); piv = 1.0; }
+      double inv = __builtin_amdgcn_rsq(piv);
+      inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+      inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+      double sq = piv * inv;
+      sq = fma(fma(-sq, sq, piv), 0.5 * inv, sq);
+      const double l = (r == p) ? sq : (r > p ? d[p] * inv : 0.0);
+      d[p] = l;
+      if (r < WC_NB) colbuf[r] = l;
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int p = 0; p < WC_NB; p++) {
-      if (p < kb) {
-        // pivot: lane p's d[p]
-        double piv = __shfl(d[p], p, 64);
-        if (!(piv > 0.0)) { if (blockIdx.x == 0 && tid == 0) atomicMax(info, k0 + p + 1); piv = 1.0; }
-        const double sq = sqrt(piv), inv = 1.0 / sq;
-        const double l = (r == p) ? sq : (r > p ? d[p] * inv : 0.0);
-        d[p] = l;
-        if (r < WC_NB) colbuf[r] = l;
-        __builtin_amdgcn_wave_barrier();
-        // rank-1 update of my row: d[c] -= l_r * l_c for p < c <= r
-#pragma unroll
-        for (int c = p + 1; c < WC_NB; c++) {
-          const double lc = colbuf[c];
-          d[c] -= (c <= r) ? l * lc : 0.0;
-        }
-        __builtin_amdgcn_wave_barrier();
+      for (int c = p + 1; c < WC_NB; c++) {
+        const double lc = colbuf[c];
+        d[c] -= (c <= r) ? l * lc : 0.0;
       }
-    }
-    if (r < WC_NB) {
-#pragma unroll
-      for (int c = 0; c < WC_NB; c++) D[c][r] = (row && c <= r) ? d[c] : 0.0;
+      __builtin_amdgcn_wave_barrier();
     }
   }
+  if (r < WC_NB) {
+#pragma unroll
+    for (int c = 0; c < WC_NB; c++) Dout[c][r] = (r < kb && c <= r) ? d[c] : 0.0;
+  }
+}
+// the first diagonal block (the later ones are factored by the trailing update that completes them)
+__global__ __launch_bounds__(64) void wchol_diag0_kernel(const double* __restrict__ A, int lda, int kb, double* __restrict__ Lkk, int* __restrict__ info) {
+  __shared__ double D[WC_NB][WC_NB + 1];
+  __shared__ double colbuf[WC_NB];
+  const int r = threadIdx.x;
+  double d[WC_NB];
+#pragma unroll
+  for (int c = 0; c < WC_NB; c++) d[c] = (r < kb && c <= r) ? A[(size_t)c * lda + r] : 0.0;
+  wchol_factor_block(d, r, kb, 0, colbuf, D, info, true);
+  __builtin_amdgcn_wave_barrier();
+  for (int e = r; e < WC_NB * WC_NB; e += 64) { const int rr = e % WC_NB, c = e / WC_NB; Lkk[e] = D[c][rr]; }
+}
+// block step at column k0 (kb columns): forward substitution of the rows below the diagonal block against its factor Lkk (column-major
+// 32 x 32, in a side buffer: A keeps the unfactored diagonal blocks).  One row per thread in registers, L_kk broadcast from LDS.
+__global__ __launch_bounds__(256) void wchol_panel_kernel(double* __restrict__ A, int lda, int nrows, int k0, int kb, const double* __restrict__ Lkk) {
+  __shared__ double D[WC_NB][WC_NB + 1];     // D[c][r] = L(r, c)
+  const int tid = threadIdx.x;
+  for (int e = tid; e < WC_NB * WC_NB; e += 256) { const int r = e % WC_NB, c = e / WC_NB; D[c][r] = Lkk[e]; }
   __syncthreads();
-  if (blockIdx.x == 0)
-    for (int e = tid; e < WC_NB * WC_NB; e += 256) { const int r = e % WC_NB, c = e / WC_NB; Lkk[e] = D[c][r]; }   // [c][r]: column-major 32 x 32
   const int r = k0 + kb + blockIdx.x * 256 + tid;
   if (r < nrows) {
     double l[WC_NB];
@@ -481,11 +494,15 @@ __global__ __launch_bounds__(256) void wchol_panel_kernel(double* __restrict__ A
     for (int c = 0; c < WC_NB; c++) if (c < kb) A[(size_t)(k0 + c) * lda + r] = l[c];
   }
 }
-// A[i][j] -= sum_c L[i][k0 + c] L[j][k0 + c] on the lower tiles of the trailing matrix (rows / columns from k0 + kb)
-__global__ __launch_bounds__(256) void wchol_trailing_kernel(double* __restrict__ A, int lda, int nrows, int ncols, int k0, int kb) {
+// A[i][j] -= sum_c L[i][k0 + c] L[j][k0 + c] on the lower tiles of the trailing matrix (rows / columns from k0 + kb).  The workgroup of
+// tile (0, 0) -- the NEXT diagonal block, complete after this update -- factors it right away (one wave) into Lkk_next, so that the
+// 32-pivot chain runs beside the other tiles' updates instead of heading the next step.
+__global__ __launch_bounds__(256) void wchol_trailing_kernel(double* __restrict__ A, int lda, int nrows, int ncols, int k0, int kb, double* __restrict__ Lkk_next,
+                                                             int* __restrict__ info) {
   const int I = blockIdx.y, J = blockIdx.x;
   if (J > I) return;
   __shared__ double Li[WC_NB][WC_NB + 1], Lj[WC_NB][WC_NB + 1];
+  __shared__ double colbuf[WC_NB];
   const int base = k0 + kb, r0 = base + I * WC_NB, c0 = base + J * WC_NB;
   if (c0 >= ncols) return;
   const int tid = threadIdx.x;
@@ -502,11 +519,30 @@ __global__ __launch_bounds__(256) void wchol_trailing_kernel(double* __restrict_
     const double i0 = Li[tx][k], i1 = Li[tx + 16][k], j0 = Lj[ty][k], j1 = Lj[ty + 16][k];
     a00 += i0 * j0; a01 += i0 * j1; a10 += i1 * j0; a11 += i1 * j1;
   }
+  const bool diag = (I == 0 && J == 0);
+  __syncthreads();                            // Li is reused below as the updated diagonal block (tile (0, 0) only)
   auto upd = [&](int rr, int cc, double v) {
     const int r = r0 + rr, c = c0 + cc;
-    if (r < nrows && c < ncols && r >= c) A[(size_t)c * lda + r] -= v;
+    if (r < nrows && c < ncols && r >= c) {
+      const double nv = A[(size_t)c * lda + r] - v;
+      A[(size_t)c * lda + r] = nv;
+      if (diag) Li[rr][cc] = nv;              // rows / columns of the next diagonal block: r, c < base + 32 <= ...
+    }
   };
   upd(tx, ty, a00); upd(tx, ty + 16, a01); upd(tx + 16, ty, a10); upd(tx + 16, ty + 16, a11);
+  if (diag) {
+    __syncthreads();
+    if (tid < 64) {
+      const int kbn = ncols - base < WC_NB ? ncols - base : WC_NB;     // size of the next diagonal block
+      double d[WC_NB];
+#pragma unroll
+      for (int c = 0; c < WC_NB; c++) d[c] = (tid < kbn && c <= tid) ? Li[tid][c] : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      wchol_factor_block(d, tid, kbn, base, colbuf, Lj, info, true);     // Lj[c][r] = L(r, c)
+      __builtin_amdgcn_wave_barrier();
+      for (int e = tid; e < WC_NB * WC_NB; e += 64) { const int rr = e % WC_NB, c = e / WC_NB; Lkk_next[e] = Lj[c][rr]; }
+    }
+  }
 }
 // L^T x = y with y = row n of the factored matrix; one workgroup of 1024 threads; x -> out[0..n).  Left-looking by blocks, last block
 // first: one wave solves the block's own 32 x 32 triangle, then every earlier unknown j subtracts what the block contributes to it,
@@ -529,7 +565,7 @@ __global__ __launch_bounds__(1024) void wchol_backsolve_kernel(const double* __r
 #pragma unroll
       for (int cc = WC_NB - 1; cc >= 0; cc--) {
         if (cc < kb) {
-          const double xc = __shfl(mine, cc, 64) / __shfl(lrow[cc], cc, 64);   // x_cc = y_cc / L(cc, cc)
+          const double xc = wchol_readlane(mine, cc) / wchol_readlane(lrow[cc], cc);   // x_cc = y_cc / L(cc, cc)
           mine = (tid == cc) ? xc : (tid < cc ? mine - lrow[cc] * xc : mine);
         }
       }
@@ -604,12 +640,14 @@ int wide_solver_step(DenseSolver* ds, const double* d_packed, double u, hipStrea
   const int n = ds->n, lda = n + 1, nrows = n + 1;
   const long long tot = (long long)n * n + n;
   wide_prepare_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s>>>(d_packed, n, u, ds->d_A, lda, ds->d_dvec, ds->d_info);
+  wchol_diag0_kernel<<<dim3(1), dim3(64), 0, s>>>(ds->d_A, lda, n < WC_NB ? n : WC_NB, ds->d_Lkk, ds->d_info);
   for (int k0 = 0; k0 < n; k0 += WC_NB) {
     const int kb = n - k0 < WC_NB ? n - k0 : WC_NB;
     const int below = nrows - k0 - kb;                       // rows under the diagonal block (>= 1: the right-hand side row)
-    wchol_panel_kernel<<<dim3((unsigned)((below + 255) / 256)), dim3(256), 0, s>>>(ds->d_A, lda, nrows, k0, kb, ds->d_Lkk + (size_t)(k0 / WC_NB) * WC_NB * WC_NB, ds->d_info);
+    double* Lk = ds->d_Lkk + (size_t)(k0 / WC_NB) * WC_NB * WC_NB;
+    wchol_panel_kernel<<<dim3((unsigned)((below + 255) / 256)), dim3(256), 0, s>>>(ds->d_A, lda, nrows, k0, kb, Lk);
     const int tr = (below + WC_NB - 1) / WC_NB, tc = (n - k0 - kb + WC_NB - 1) / WC_NB;
-    if (tc > 0) wchol_trailing_kernel<<<dim3((unsigned)tc, (unsigned)tr), dim3(256), 0, s>>>(ds->d_A, lda, nrows, n, k0, kb);
+    if (tc > 0) wchol_trailing_kernel<<<dim3((unsigned)tc, (unsigned)tr), dim3(256), 0, s>>>(ds->d_A, lda, nrows, n, k0, kb, Lk + WC_NB * WC_NB, ds->d_info);
   }
   wchol_backsolve_kernel<<<dim3(1), dim3(1024), 0, s>>>(ds->d_A, lda, n, ds->d_Lkk, ds->d_x);
   wide_q1_kernel<<<dim3(1), dim3(256), 0, s>>>(d_packed, ds->d_x, ds->d_dvec, n, u, ds->d_out);
