@@ -72,6 +72,24 @@ __global__ void cross_k(double* out, int iters, unsigned long long* cyc) {
   if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;
 }
 
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction (256 multiply-adds against 1024 of the 16x16x4 form)
+__global__ void mfma4_k(double* out, int iters, unsigned long long* cyc) {
+  double acc[8];
+  for (int t = 0; t < 8; t++) acc[t] = 0;
+  const double a = threadIdx.x * 1e-6 + 1.0, b = 1.0 - threadIdx.x * 1e-7;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[t], 0, 0, 0);
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  double s = 0;
+  for (int t = 0; t < 8; t++) s += acc[t];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) cyc[threadIdx.x >> 6] = t1 - t0;
+}
+
 static double* out;
 static unsigned long long* cyc;
 
@@ -111,6 +129,13 @@ int main() {
   run_valu<4>("v_fma_f64 dependent chain");
   run_valu<5>("v_mov_b64");
   run_valu<6>("v_add_u32");
+  for (int threads : {256, 512}) {
+    mfma4_k<<<256, threads>>>(out, 10, cyc); hipDeviceSynchronize();
+    mfma4_k<<<256, threads>>>(out, 2000, cyc); hipDeviceSynchronize();
+    unsigned long long c[8]; hipMemcpy(c, cyc, sizeof c, hipMemcpyDeviceToHost);
+    printf("v_mfma_f64_4x4x4_4b_f64          %d wave(s)/SIMD: %6.2f cycles per wave-instruction (256 multiply-adds; the 16x16x4 form does 1024 in 64)\n", threads / 256,
+           (double)c[0] / (8.0 * 2000));
+  }
   run_cross<0>("MFMA stream alone (partner idle)");
   run_cross<3>("f64 FMA stream alone (partner idle)");
   run_cross<1>("MFMA stream | partner wave: f64 FMA stream");
