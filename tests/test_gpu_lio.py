@@ -36,7 +36,8 @@ def check_sweep(a, b, tol=1e-10):
     assert np.array_equal(a["HTH"], a["HTH"].T)
 
 
-@pytest.mark.parametrize("max_layer,voxel_size,n_roots,n_points", [(2, 1.0, 3000, 30000), (1, 2.0, 400, 8000), (3, 0.5, 2500, 20000), (0, 1.0, 500, 5000)])
+# the last case has the shape of a real scan -- many returns per plane (60k points on ~1.3k planes), records shared through L2
+@pytest.mark.parametrize("max_layer,voxel_size,n_roots,n_points", [(2, 1.0, 3000, 30000), (1, 2.0, 400, 8000), (3, 0.5, 2500, 20000), (0, 1.0, 500, 5000), (2, 1.0, 300, 60000)])
 def test_sweep_matches_oracle(vx, max_layer, voxel_size, n_roots, n_points):
     pm = synth.make_plane_map(n_roots=n_roots, extent=8 if n_roots > 1000 else 4, voxel_size=voxel_size, max_layer=max_layer, seed=2000 + max_layer)
     sc = synth.make_lio_scan(pm, n_points=n_points, seed=2100 + max_layer)
@@ -116,7 +117,7 @@ def test_var_init_and_pvec_update(vx):
 
 
 @pytest.mark.parametrize("device_ekf", ["1", "0"])
-@pytest.mark.parametrize("seed,n_roots,n_points,raw", [(2400, 3000, 40000, True), (2410, 800, 6000, False), (2420, 6000, 100000, True)])
+@pytest.mark.parametrize("seed,n_roots,n_points,raw", [(2400, 3000, 40000, True), (2410, 800, 6000, False), (2420, 6000, 100000, True), (2430, 400, 100000, True)])
 def test_state_estimation_matches_oracle(vx, seed, n_roots, n_points, raw, device_ekf):
     """device_ekf: the 15-dimensional EKF algebra between the sweeps as a kernel, all iterations enqueued up front (default), or on the
     host with a round trip per iteration (vxba_lio_set_option(VXBA_LIO_OPT_DEVICE_EKF, 0))."""
