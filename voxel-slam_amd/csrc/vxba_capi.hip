@@ -1553,27 +1553,28 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
       if (hess_out) std::memcpy(hess_out, Hess.data(), sizeof(double) * n * n);   // *hess = Hess, before the gauge fix (:588)
     }
     const auto t1 = now();
-    // gauge: frame 0's 15 rows / columns (:591-594)
-    for (int c = 0; c < n; c++)
-      for (int r = 0; r < vxi::DIM; r++) { Hess[(size_t)c * n + r] = 0.0; Hess[(size_t)r * n + c] = 0.0; }
-    for (int r = 0; r < vxi::DIM; r++) { Hess[(size_t)r * n + r] = 1.0; JacT[r] = 0.0; }
-    for (int r = 0; r < n; r++) D[r] = Hess[(size_t)r * n + r];
-    // (Hess + u D) dxi = -JacT.  The gauge rows are identity rows with a zero right-hand side: dxi = 0 there and they
-    // couple to nothing, so only the trailing (n - 15) system is factorised (same solution, 27 % fewer flops at W = 10).
+    // gauge: frame 0's 15 rows / columns become identity rows with a zero right-hand side (:591-594): dxi = 0 there and they couple
+    // to nothing, so the solve simply works on the trailing (n - 15) block of Hess (same solution, 27 % fewer flops at W = 10) --
+    // in place: neither the gauge rows nor a damped copy of the matrix are written out unless the dense fallback needs one
+    for (int r = 0; r < n; r++) D[r] = r < vxi::DIM ? 1.0 : Hess[(size_t)r * n + r];
+    for (int r = 0; r < vxi::DIM; r++) JacT[r] = 0.0;
     {
       const int g = vxi::DIM, m = n - g;
-      for (int c = 0; c < m; c++) std::memcpy(&A[(size_t)c * m], &Hess[(size_t)(c + g) * n + g], sizeof(double) * m);
-      for (int r = 0; r < m; r++) { A[(size_t)r * m + r] += u * D[r + g]; rhs[r] = -JacT[r + g]; }
+      for (int r = 0; r < m; r++) { rhs[r] = -JacT[r + g]; work[r] = u * D[r + g]; }     // work: the damping u D on the diagonal
       for (int r = 0; r < g; r++) dxi[r] = 0.0;
       // band Cholesky of the velocity / bias part + Schur complement onto the poses (vxba_host.hpp); dense pivoted LDL^T if a band
       // pivot is not positive (or the option is off)
       bool solved = false;
       if (m > 0 && f->opt[VXBA_OPT_LI_STRUCTURED_SOLVE]) {
         if (li_sets.Y.empty()) li_sets = vxh::li_index_sets(W - 1, 0, 0);
-        solved = vxh::band_schur_solve(m, A.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(), (int)li_sets.X.size(),
-                                       li_sets.xlo.data(), dxi.data() + g, bs_work);
+        solved = vxh::band_schur_solve(m, &Hess[(size_t)g * n + g], n, work.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(),
+                                       (int)li_sets.X.size(), li_sets.xlo.data(), dxi.data() + g, bs_work);
       }
-      if (m > 0 && !solved) vxh::ldlt_solve_inplace(m, A.data(), rhs.data(), dxi.data() + g, perm.data(), work.data());
+      if (m > 0 && !solved) {
+        for (int c = 0; c < m; c++) std::memcpy(&A[(size_t)c * m], &Hess[(size_t)(c + g) * n + g], sizeof(double) * m);
+        for (int r = 0; r < m; r++) A[(size_t)r * m + r] += u * D[r + g];
+        vxh::ldlt_solve_inplace(m, A.data(), rhs.data(), dxi.data() + g, perm.data(), work.data());
+      }
     }
     // trial state (:599-606) and the factors' bias deltas (:608-609)
     for (int j = 0; j < W; j++) {
@@ -1662,8 +1663,8 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
       for (int r = 0; r < mr; r++) { Ared[(size_t)r * mr + r] += u * D[r + 6]; rhs[r] = -JacT[r + 6]; }
       if (li_sets.Y.empty()) li_sets = vxh::li_index_sets(W - 1, 9, 3);
       for (int r = 0; r < 6; r++) dxi[r] = 0.0;
-      solved = vxh::band_schur_solve(mr, Ared.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(), (int)li_sets.X.size(),
-                                     li_sets.xlo.data(), dxi.data() + 6, bs_work);
+      solved = vxh::band_schur_solve(mr, Ared.data(), mr, nullptr, rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(),
+                                     (int)li_sets.X.size(), li_sets.xlo.data(), dxi.data() + 6, bs_work);
     }
     if (!solved) {
       A = Hess;
@@ -1853,7 +1854,7 @@ int vxba_debug_band_schur(int m, const double* A, const double* b, int nframes, 
   if (!A || !b || !x || m != lead_y + 15 * nframes + tail_x) return VXBA_ERR_ARG;
   const vxh::LiIndexSets s = vxh::li_index_sets(nframes, lead_y, tail_x);
   vxh::BandSchurWork w;
-  return vxh::band_schur_solve(m, A, b, s.Y.data(), (int)s.Y.size(), s.bw, s.X.data(), (int)s.X.size(), s.xlo.data(), x, w) ? VXBA_OK : VXBA_ERR_STATE;
+  return vxh::band_schur_solve(m, A, m, nullptr, b, s.Y.data(), (int)s.Y.size(), s.bw, s.X.data(), (int)s.X.size(), s.xlo.data(), x, w) ? VXBA_OK : VXBA_ERR_STATE;
 }
 
 int vxba_set_option(vxba_factor* f, int option, int value) {

@@ -139,9 +139,12 @@ struct BandSchurWork {
   std::vector<double> L, Wm, S, wb, rx, xs, work;
   std::vector<int> perm, qmax;
 };
+//   lda: row stride of A (>= m: A may be a window into a larger matrix).   dadd (nullable): added to the diagonal, dadd[i] for A(i, i)
+//   -- the LM damping u * diag(H), so that the caller need not build H + u D.
 template <bool AVX>
-inline bool band_schur_solve_impl(int m, const double* A, const double* b, const int* Y, int ny, int bw, const int* X, int nx, const int* xlo, double* x,
-                                  BandSchurWork& ws) {
+inline bool band_schur_solve_impl(int m, const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw, const int* X, int nx,
+                                  const int* xlo, double* x, BandSchurWork& ws) {
+  (void)m;
   const int ld = bw + 1;                     // L band storage: row a holds columns a-bw .. a at [0 .. bw]
   const int nc = (nx + 3) & ~3;              // padded row length of W
   ws.L.assign((size_t)ny * ld, 0.0);
@@ -153,10 +156,10 @@ inline bool band_schur_solve_impl(int m, const double* A, const double* b, const
   // band Cholesky, row by row
   for (int a = 0; a < ny; a++) {
     const int c0 = a - bw > 0 ? a - bw : 0;
-    const double* Arow = A + (size_t)Y[a] * m;
+    const double* Arow = A + (size_t)Y[a] * lda;
     for (int c = c0; c <= a; c++) {
       const int k0 = c - bw > c0 ? c - bw : c0;
-      double sum = Arow[Y[c]];
+      double sum = Arow[Y[c]] + ((c == a && dadd) ? dadd[Y[a]] : 0.0);
       const double* la = &Lat(a, k0);
       const double* lc = &Lat(c, k0);
       for (int k = 0; k < c - k0; k++) sum -= la[k] * lc[k];
@@ -176,7 +179,7 @@ inline bool band_schur_solve_impl(int m, const double* A, const double* b, const
     const int c0 = a - bw > 0 ? a - bw : 0;
     const int qa = ws.qmax[a];
     double* wa = ws.Wm.data() + (size_t)a * nc;
-    const double* Arow = A + (size_t)Y[a] * m;
+    const double* Arow = A + (size_t)Y[a] * lda;
     for (int q = 0; q < qa; q++) wa[q] = Arow[X[q]];
     double sb = b[Y[a]];
     for (int k = c0; k < a; k++) {
@@ -195,8 +198,9 @@ inline bool band_schur_solve_impl(int m, const double* A, const double* b, const
   ws.rx.assign(nx, 0.0);
   double* S = ws.S.data();
   for (int p = 0; p < nx; p++) {
-    const double* Arow = A + (size_t)X[p] * m;
+    const double* Arow = A + (size_t)X[p] * lda;
     for (int q = 0; q <= p; q++) S[(size_t)p * nx + q] = Arow[X[q]];
+    if (dadd) S[(size_t)p * nx + p] += dadd[X[p]];
     ws.rx[p] = b[X[p]];
   }
   for (int a = 0; a < ny; a++) {
@@ -233,17 +237,17 @@ inline bool band_schur_solve_impl(int m, const double* A, const double* b, const
   return true;
 }
 #if defined(__x86_64__)
-__attribute__((target("avx2,fma"))) inline bool band_schur_solve_avx2(int m, const double* A, const double* b, const int* Y, int ny, int bw, const int* X, int nx,
-                                                                      const int* xlo, double* x, BandSchurWork& ws) {
-  return band_schur_solve_impl<true>(m, A, b, Y, ny, bw, X, nx, xlo, x, ws);
+__attribute__((target("avx2,fma"))) inline bool band_schur_solve_avx2(int m, const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw,
+                                                                      const int* X, int nx, const int* xlo, double* x, BandSchurWork& ws) {
+  return band_schur_solve_impl<true>(m, A, lda, dadd, b, Y, ny, bw, X, nx, xlo, x, ws);
 }
 #endif
-inline bool band_schur_solve(int m, const double* A, const double* b, const int* Y, int ny, int bw, const int* X, int nx, const int* xlo, double* x,
-                             BandSchurWork& ws) {
+inline bool band_schur_solve(int m, const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw, const int* X, int nx,
+                             const int* xlo, double* x, BandSchurWork& ws) {
 #if defined(__x86_64__)
-  if (cpu_has_avx2_fma()) return band_schur_solve_avx2(m, A, b, Y, ny, bw, X, nx, xlo, x, ws);
+  if (cpu_has_avx2_fma()) return band_schur_solve_avx2(m, A, lda, dadd, b, Y, ny, bw, X, nx, xlo, x, ws);
 #endif
-  return band_schur_solve_impl<false>(m, A, b, Y, ny, bw, X, nx, xlo, x, ws);
+  return band_schur_solve_impl<false>(m, A, lda, dadd, b, Y, ny, bw, X, nx, xlo, x, ws);
 }
 
 // Index sets of the LiDAR-inertial system for band_schur_solve.  The system handed in holds frames f0 .. W-1 with 15 unknowns each
