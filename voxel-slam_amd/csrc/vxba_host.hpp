@@ -142,7 +142,7 @@ struct BandSchurWork {
 //   lda: row stride of A (>= m: A may be a window into a larger matrix).   dadd (nullable): added to the diagonal, dadd[i] for A(i, i)
 //   -- the LM damping u * diag(H), so that the caller need not build H + u D.
 template <bool AVX>
-inline bool band_schur_solve_impl(int m, const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw, const int* X, int nx,
+__attribute__((always_inline)) inline bool band_schur_solve_impl(int m, const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw, const int* X, int nx,
                                   const int* xlo, double* x, BandSchurWork& ws) {
   (void)m;
   const int ld = bw + 1;                     // L band storage: row a holds columns a-bw .. a at [0 .. bw]
