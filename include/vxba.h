@@ -77,6 +77,12 @@ const char* vxba_last_error(const vxba_factor* f);
  *   the cache is then undefined until vxba_evaluate_only_residual has run. */
 int vxba_push_voxels(vxba_factor* f, int n, const double* clusters, const double* fix, const double* coe,
                      const double* eig_val, const double* eig_vec, const double* merged);
+/* The same for sparse incidence (the hierarchical BA's top level, loop_refine.hpp:358-405, pushes voxels seen from a handful of
+ * ~100 poses): voxel a's observed frames are frame_idx[row_ptr[a] .. row_ptr[a + 1]) (strictly increasing, < win_size), their clusters
+ * clusters[e * 10 ..]; unlisted frames are unobserved.  row_ptr has n + 1 entries, row_ptr[0] = 0.  Works for any win_size; the planes
+ * are filled on the device, so no dense n x W x 10 array exists on the host or crosses PCIe. */
+int vxba_push_voxels_csr(vxba_factor* f, int n, const int64_t* row_ptr, const int32_t* frame_idx, const double* clusters, const double* fix, const double* coe,
+                         const double* eig_val, const double* eig_vec, const double* merged);
 
 /* K1 -- per-(voxel, frame) cluster accumulation from raw points, PointCluster::push (tools.hpp:326-331;
  * call sites voxel_map.hpp:988, loop_refine.hpp:383-385).  Appends n_voxels voxels whose body-frame

@@ -112,3 +112,35 @@ def test_wide_voxelize_and_unsupported_entry_points(vx):
         f.set_precision("mixed")
     with pytest.raises(vx.VxbaError):
         vx.LidarFactor(129)
+
+
+def dense_to_csr(clusters):
+    obs = clusters[:, :, 9] != 0
+    row_ptr = np.concatenate([[0], np.cumsum(obs.sum(axis=1))]).astype(np.int64)
+    v, fr = np.nonzero(obs)
+    return row_ptr, fr.astype(np.int32), clusters[v, fr]
+
+
+@pytest.mark.parametrize("W,V,p_obs", [(10, 3000, 0.5), (40, 2500, 0.1), (99, 2000, 0.05)])
+def test_push_voxels_csr_equals_the_dense_push(vx, W, V, p_obs):
+    """vxba_push_voxels_csr (sparse (voxel, frame) entries, planes filled on the device) builds the same factor as the dense push: same
+    clusters, same sweeps bit for bit, same LM result -- narrow (MFMA path) and wide windows; malformed rows are refused."""
+    sc = synth.make_scene(win_size=W, pts_per_scan=max(4000, 12 * V // 3), n_voxels=V, p_obs=p_obs, fix_frac=0.2, seed=1500 + W, rot_sigma_deg=0.1, trans_sigma=0.03)
+    fd = vx.LidarFactor(W); fd.push_voxels(sc.clusters, sc.fix, sc.coe)
+    rp, fr, cl = dense_to_csr(sc.clusters)
+    assert cl.shape[0] == sc.nnz
+    fc = vx.LidarFactor(W)
+    h = V // 3                                   # two appends: the second lands behind the first
+    fc.push_voxels_csr(rp[: h + 1], fr[: rp[h]], cl[: rp[h]], sc.fix[:h], sc.coe[:h])
+    fc.push_voxels_csr(rp[h:] - rp[h], fr[rp[h]:], cl[rp[h]:], sc.fix[h:], sc.coe[h:])
+    assert fc.size() == V and np.array_equal(fc.read_clusters(), fd.read_clusters())
+    rd = fd.evaluate_only_residual(sc.poses_init); rc = fc.evaluate_only_residual(sc.poses_init)
+    assert rd == rc
+    Hd, Jd, r1 = fd.acc_evaluate2(sc.poses_init); Hc, Jc, r2 = fc.acc_evaluate2(sc.poses_init)
+    assert np.array_equal(Hd, Hc) and np.array_equal(Jd, Jc) and r1 == r2
+    a = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fd, max_iter=3); b = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fc, max_iter=3)
+    assert np.array_equal(a["poses"], b["poses"])
+    bad_fr = fr.copy(); k = int(rp[5]); bad_fr[k + 1] = bad_fr[k] if rp[6] - rp[5] > 1 else W
+    with pytest.raises(vx.VxbaError):
+        fc.push_voxels_csr(rp, bad_fr, cl, sc.fix, sc.coe)
+    assert fc.size() == V

@@ -882,6 +882,52 @@ int ensure_scratch(vxba_factor* f, size_t need) {
 }
 }  // namespace
 
+// LidarFactor::push_voxel for sparse incidence (the top level of the hierarchical BA pushes voxels seen from a handful of ~100
+// submap poses, loop_refine.hpp:358-405): the caller lists only the observed (voxel, frame) entries.  The planes are filled on the
+// device, so neither a dense n x W x 10 host array (0.8 GB at n = 100k, W = 99) nor its PCIe transfer exists -- nnz x 88 bytes go up.
+int vxba_push_voxels_csr(vxba_factor* f, int n, const int64_t* row_ptr, const int32_t* frame_idx, const double* clusters, const double* fix, const double* coe,
+                         const double* eig_val, const double* eig_vec, const double* merged) {
+  VX_LOCK(f);
+  if (!f || n < 0 || (n > 0 && (!row_ptr || !fix || !coe))) return fail(f, VXBA_ERR_ARG, "push_voxels_csr: null input");
+  if (n == 0) return VXBA_OK;
+  if (row_ptr[0] != 0) return fail(f, VXBA_ERR_ARG, "push_voxels_csr: row_ptr[0] must be 0");
+  const int64_t nnz = row_ptr[n];
+  for (int a = 0; a < n; a++) {
+    if (row_ptr[a + 1] < row_ptr[a] || row_ptr[a + 1] - row_ptr[a] > f->W) return fail(f, VXBA_ERR_ARG, "push_voxels_csr: row_ptr must be non-decreasing with at most win_size entries per voxel");
+    if (!(coe[a] >= 0.0)) return fail(f, VXBA_ERR_ARG, "push_voxels_csr: coe must be >= 0");
+  }
+  if (nnz > 0 && (!frame_idx || !clusters)) return fail(f, VXBA_ERR_ARG, "push_voxels_csr: null entries");
+  hipSetDevice(f->device);
+  int rc = ensure_capacity(f, f->V + n);
+  if (rc) return rc;
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t b_ptr = up((size_t)(n + 1) * sizeof(int64_t)), b_fr = up((size_t)std::max<int64_t>(1, nnz) * sizeof(int32_t)), b_cl = up((size_t)std::max<int64_t>(1, nnz) * 10 * sizeof(double));
+  rc = ensure_scratch(f, b_ptr + b_fr + b_cl + 256);
+  if (rc) return rc;
+  char* q = f->d_scratch;
+  long long* d_ptr = (long long*)q; q += b_ptr;
+  int* d_fr = (int*)q; q += b_fr;
+  double* d_cl = (double*)q; q += b_cl;
+  int* d_bad = (int*)q;
+  VX_HIP(f, hipMemsetAsync(d_bad, 0, sizeof(int), f->stream));
+  VX_HIP(f, hipMemcpyAsync(d_ptr, row_ptr, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, f->stream));
+  if (nnz > 0) {
+    VX_HIP(f, hipMemcpyAsync(d_fr, frame_idx, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, f->stream));
+    VX_HIP(f, hipMemcpyAsync(d_cl, clusters, (size_t)nnz * 10 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  }
+  vxk::launch_scatter_clusters_csr(d_ptr, d_fr, d_cl, view(f), f->V, n, d_bad, f->stream);
+  if (!is_wide(f)) vxk::launch_build_clb(view(f), f->V, n, f->stream);
+  int bad = 0;
+  VX_HIP(f, hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  VX_HIP(f, hipStreamSynchronize(f->stream));
+  if (bad) return fail(f, VXBA_ERR_ARG, "push_voxels_csr: frame indices must be strictly increasing inside a voxel and below win_size (nothing was appended)");
+  rc = append_meta(f, f->V, n, fix, coe, eig_val, eig_vec, merged);
+  if (rc) return rc;
+  f->V += n;
+  f->wide_dirty = true;
+  return VXBA_OK;
+}
+
 int vxba_push_points(vxba_factor* f, int n_voxels, int64_t n_points, const double* xyz_body, const int64_t* cell_ptr, const double* fix,
                      const double* coe) {
   VX_LOCK(f);

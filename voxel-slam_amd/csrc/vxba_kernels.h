@@ -149,6 +149,10 @@ void launch_build_clb(const FactorView& fv, int v0, int n, hipStream_t s);
 
 // Layout plumbing between the C-ABI's packed AoS rows and the device planes.
 void launch_scatter_clusters(const double* d_src /*[n][W][10]*/, const FactorView& fv, int v0, int n, hipStream_t s);
+// CSR clusters (row_ptr n + 1, frame_idx nnz, clusters nnz x 10; frames strictly increasing per voxel) into the frame-major planes at v0;
+// *d_bad is set to 1 on a malformed row.
+void launch_scatter_clusters_csr(const long long* d_row_ptr, const int* d_frame_idx, const double* d_clusters, const FactorView& fv, int v0, int n, int* d_bad,
+                                 hipStream_t s);
 void launch_gather_clusters(const FactorView& fv, int head, int n, double* d_dst /*[n][W][10]*/, hipStream_t s);
 void launch_scatter_rows(const double* d_src /*[n][K]*/, double* planes, int VS, int v0, int n, int K, hipStream_t s);
 void launch_gather_rows(const double* planes, int VS, int head, int n, int K, double* d_dst /*[n][K]*/, hipStream_t s);

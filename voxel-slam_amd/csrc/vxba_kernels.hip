@@ -725,6 +725,30 @@ __global__ void scatter_clusters_kernel(const double* __restrict__ src, FactorVi
   double* o = fv.cl + (size_t)i * 10 * fv.VS + v0 + al;
   for (int k = 0; k < 10; k++) o[(size_t)k * fv.VS] = s[k];
 }
+// CSR input: entry e of voxel v0 + a (row_ptr[a] <= e < row_ptr[a + 1]) is the cluster of frame frame_idx[e]; frames that are not listed
+// are unobserved (all-zero cluster, N == 0).  One thread per (voxel, frame) slot zeroes it, then one thread per entry fills its slot.
+__global__ void csr_zero_kernel(FactorView fv, int v0, int n) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long tot = (long long)n * fv.W * 10;
+  if (t >= tot) return;
+  const int a = (int)(t % n);
+  const long long pk = t / n;                // plane index frame * 10 + k
+  fv.cl[(size_t)pk * fv.VS + v0 + a] = 0.0;
+}
+__global__ void csr_scatter_kernel(const long long* __restrict__ row_ptr, const int* __restrict__ frame_idx, const double* __restrict__ clusters, FactorView fv, int v0,
+                                   int n, int* __restrict__ bad) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  int prev = -1;
+  for (long long e = row_ptr[a]; e < row_ptr[a + 1]; e++) {
+    const int fr = frame_idx[e];
+    if (fr <= prev || fr >= fv.W) { atomicExch(bad, 1); return; }      // frames must be strictly increasing inside a voxel and < win_size
+    prev = fr;
+    const double* c = clusters + (size_t)e * 10;
+#pragma unroll
+    for (int k = 0; k < 10; k++) fv.cl[((size_t)fr * 10 + k) * fv.VS + v0 + a] = c[k];
+  }
+}
 __global__ void gather_clusters_kernel(FactorView fv, int head, int n, double* __restrict__ dst) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int W = fv.W;
@@ -1053,6 +1077,13 @@ void launch_build_clb(const FactorView& fv, int v0, int n, hipStream_t s) {
 void launch_scatter_clusters(const double* d_src, const FactorView& fv, int v0, int n, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(scatter_clusters_kernel, dim3(nblk((long long)n * fv.W, 256)), dim3(256), 0, s, d_src, fv, v0, n);
+}
+void launch_scatter_clusters_csr(const long long* d_row_ptr, const int* d_frame_idx, const double* d_clusters, const FactorView& fv, int v0, int n, int* d_bad,
+                                 hipStream_t s) {
+  if (n <= 0) return;
+  const long long tot = (long long)n * fv.W * 10;
+  csr_zero_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s>>>(fv, v0, n);
+  csr_scatter_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(d_row_ptr, d_frame_idx, d_clusters, fv, v0, n, d_bad);
 }
 void launch_gather_clusters(const FactorView& fv, int head, int n, double* d_dst, hipStream_t s) {
   if (n <= 0) return;

@@ -30,7 +30,7 @@ EXPORTS = [
     "vxba_reserve", "vxba_last_error", "vxba_push_voxels", "vxba_push_points", "vxba_read_clusters", "vxba_acc_evaluate2",
     "vxba_evaluate_only_residual", "vxba_acc_evaluate2_device", "vxba_evaluate_only_residual_device", "vxba_packed_len",
     "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_plane_fit_judge", "vxba_build_clusters", "vxba_set_allreduce",
-    "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_attach_bcast", "vxba_rccl_detach", "vxba_peer_export", "vxba_peer_attach", "vxba_peer_detach", "vxba_peer_status", "vxba_peer_selftest", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps", "vxba_debug_band_schur",
+    "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_attach_bcast", "vxba_rccl_detach", "vxba_peer_export", "vxba_peer_attach", "vxba_peer_detach", "vxba_peer_status", "vxba_peer_selftest", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps", "vxba_debug_band_schur", "vxba_push_voxels_csr",
     "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_li_evaluate",
     "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity", "vxba_voxelize_push", "vxba_set_precision",
     "vxba_lio_create", "vxba_lio_destroy", "vxba_lio_last_error", "vxba_lio_map_update", "vxba_lio_map_clear", "vxba_lio_map_size", "vxba_lio_scan_raw",
@@ -92,6 +92,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_last_error.argtypes = [vp]
     L.vxba_last_error.restype = C.c_char_p
     L.vxba_push_voxels.argtypes = [vp, ci, _f64p, _f64p, _f64p, vp, vp, vp]
+    L.vxba_push_voxels_csr.argtypes = [vp, ci, vp, vp, vp, _f64p, _f64p, vp, vp, vp]
     L.vxba_push_points.argtypes = [vp, ci, C.c_int64, _f64p, _i64p, vp, vp]
     L.vxba_read_clusters.argtypes = [vp, ci, ci, _f64p]
     L.vxba_acc_evaluate2.argtypes = [vp, _f64p, ci, ci, _f64p, _f64p, C.POINTER(cd)]
@@ -261,6 +262,20 @@ class LidarFactor:
         pu, ku = _opt(eig_vec)
         pm, km = _opt(merged)
         self._chk(self._L.vxba_push_voxels(self._h, n, clusters, _c(fix), _c(coe), pv, pu, pm))
+
+    def push_voxels_csr(self, row_ptr, frame_idx, clusters, fix, coe, eig_val=None, eig_vec=None, merged=None):
+        """push_voxels for sparse incidence: voxel a's observed frames are frame_idx[row_ptr[a]:row_ptr[a + 1]] (strictly increasing), their
+        clusters the matching rows of ``clusters`` (nnz, 10).  Nothing dense is built on the host or sent over PCIe."""
+        rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        fr = np.ascontiguousarray(frame_idx, dtype=np.int32)
+        cl = _c(clusters).reshape(-1, 10)
+        n = rp.size - 1
+        if n < 0 or cl.shape[0] != fr.size or (n >= 0 and rp.size and rp[-1] != fr.size):
+            raise VxbaError("push_voxels_csr: row_ptr[-1], frame_idx and clusters disagree on the number of entries")
+        pv, kv = _opt(eig_val)
+        pu, ku = _opt(eig_vec)
+        pm, km = _opt(merged)
+        self._chk(self._L.vxba_push_voxels_csr(self._h, n, rp.ctypes.data_as(C.c_void_p), fr.ctypes.data_as(C.c_void_p), cl.ctypes.data_as(C.c_void_p), _c(fix), _c(coe), pv, pu, pm))
 
     def push_points(self, n_voxels, xyz_body, cell_ptr, fix=None, coe=None):
         """K1: build the clusters of ``n_voxels`` voxels on the GPU from bucketed body-frame points."""
