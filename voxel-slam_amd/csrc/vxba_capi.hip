@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -67,6 +68,16 @@ struct vxba_factor {
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
   vxw::DenseSolver* wide_solver = nullptr;   // wide windows: device Cholesky of the (6W)-dimensional LM step (vxba_wide.hip)
   bool wide_solver_tried = false;
+  double li_wait_us = 0;         // development (VXBA_LI_TIMING): time the LI shells spent waiting for the Hessian sweep
+  struct LiScratch {             // host buffers of the LI shells, kept between calls (four (15W)^2 matrices: allocating and zeroing them
+    std::vector<double> Hess, HessN, A, JacT, JacTN, D, rhs, dxi, work, cov_invs;   // cost ~15 us of a ~300 us call)
+    std::vector<int> perm;
+    void size(int n, int nfac) {
+      Hess.resize((size_t)n * n); HessN.resize((size_t)n * n); JacT.resize(n); JacTN.resize(n); D.resize(n); rhs.resize(n); dxi.resize(n);
+      work.resize(n); perm.resize(n); cov_invs.resize((size_t)225 * nfac);
+    }
+  } li;
+  vxh::BandSchurWork li_bs;
   int opt[VXBA_OPT_COUNT] = {1, 1, 1, 0, 64, 0, 1};   // vxba_set_option; initial values may come from the environment (see vxba.h)
   vxw::WideIndex wide;           // wide windows: incidence structure (entries, entry pairs per Hessian block), rebuilt after a push
   bool wide_dirty = true;
@@ -1422,9 +1433,12 @@ int wait_stream(vxba_factor* f) {
   return VXBA_OK;
 }
 // spec_queued: the Hessian sweep at exactly these states was queued speculatively behind the last residual sweep (li_joint_residual)
-// and is running or done -- nothing to launch.
+// and is running or done -- nothing to launch.  imu_ready: likewise the IMU half (see li_joint_residual); points to its residual.
+// while_sweeping (optional): called once the IMU blocks are in Hess / JacT and before the host starts waiting for the sweep -- the
+// LiDAR factor only adds to the pose-pose blocks afterwards, so everything else of the system is final at that point.
 int li_joint_system(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* Hess, double* JacT, double* residual,
-                    bool with_g = false, const double* cov_invs = nullptr, bool spec_queued = false) {
+                    bool with_g = false, const double* cov_invs = nullptr, bool spec_queued = false, const std::function<void()>* while_sweeping = nullptr,
+                    const double* imu_ready = nullptr) {
   const int W = f->W, n = vxi::DIM * W + (with_g ? 3 : 0), m = 6 * W;
   std::vector<double> Rp(12 * W);
   states_to_poses(W, states, Rp.data());
@@ -1437,12 +1451,19 @@ int li_joint_system(vxba_factor* f, const double* states, const double* imus, do
     if (rc) return rc;
   }
   if (!zc) VX_HIP(f, hipMemcpyAsync(f->h_packed, f->d_packed, vxba_packed_len(f) * sizeof(double), hipMemcpyDeviceToHost, f->stream));
-  std::memset(Hess, 0, sizeof(double) * n * n);
-  std::memset(JacT, 0, sizeof(double) * n);
   vxi::ImuWork w;
   bool ok = true;
-  double res = vxi::li_add_imu_blocks(W, states, imus, imu_coef, true, Hess, JacT, w, &ok, with_g, cov_invs);
+  double res;
+  if (imu_ready) res = *imu_ready;   // Hess / JacT already hold the IMU blocks at these states (built during the last residual sweep)
+  else {
+    std::memset(Hess, 0, sizeof(double) * n * n);
+    std::memset(JacT, 0, sizeof(double) * n);
+    res = vxi::li_add_imu_blocks(W, states, imus, imu_coef, true, Hess, JacT, w, &ok, with_g, cov_invs);
+  }
+  if (while_sweeping && ok) (*while_sweeping)();
+  const auto t_w0 = std::chrono::steady_clock::now();
   rc = wait_stream(f);
+  f->li_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_w0).count();
   if (rc) return rc;
   if (!ok) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
   vxi::li_hess_plus(W, Hess, JacT, f->h_packed, f->h_packed + (size_t)m * m, n);
@@ -1453,8 +1474,11 @@ int li_joint_system(vxba_factor* f, const double* states, const double* imus, do
 // -- is queued right behind it, before anybody knows whether the step will be accepted.  The host only waits for the residual (an
 // event), takes the decision, and if the step is accepted finds the next joint system already under way instead of paying a cold
 // launch and a round trip for it; a rejected step wastes the sweep (upstream recomputes nothing then either).
+// next_Hess / next_JacT (with speculate): while the host would otherwise only poll for the sweep, it builds the IMU half of the NEXT joint
+// system at these trial states (the inertial residual falls out of the same evaluation); *imu_residual receives the IMU part alone.
 int li_joint_residual(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* residual,
-                      const double* cov_invs = nullptr, bool speculate = false) {
+                      const double* cov_invs = nullptr, bool speculate = false, double* next_Hess = nullptr, double* next_JacT = nullptr, bool with_g = false,
+                      double* imu_residual = nullptr) {
   const int W = f->W;
   std::vector<double> Rp(12 * W);
   states_to_poses(W, states, Rp.data());
@@ -1472,7 +1496,16 @@ int li_joint_residual(vxba_factor* f, const double* states, const double* imus, 
   }
   vxi::ImuWork w;
   bool ok = true;
-  const double r1 = vxi::li_add_imu_blocks(W, states, imus, imu_coef, false, nullptr, nullptr, w, &ok, false, cov_invs);
+  double r1;
+  if (spec && next_Hess && next_JacT) {
+    const int n = vxi::DIM * W + (with_g ? 3 : 0);
+    std::memset(next_Hess, 0, sizeof(double) * n * n);
+    std::memset(next_JacT, 0, sizeof(double) * n);
+    r1 = vxi::li_add_imu_blocks(W, states, imus, imu_coef, true, next_Hess, next_JacT, w, &ok, with_g, cov_invs);
+  } else {
+    r1 = vxi::li_add_imu_blocks(W, states, imus, imu_coef, false, nullptr, nullptr, w, &ok, false, cov_invs);
+  }
+  if (imu_residual) *imu_residual = r1;
   if (spec) {
     hipError_t q;
     while ((q = hipEventQuery(f->li_ev)) == hipErrorNotReady) {}
@@ -1571,32 +1604,58 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
   hipSetDevice(f->device);
   const int W = f->W, n = vxi::DIM * W, SL = vxi::STATE_LEN;
   double u = 0.01, v = 2;
-  std::vector<double> Hess((size_t)n * n), A((size_t)n * n), JacT(n), D(n), rhs(n), dxi(n), work(n), x_temp(states, states + (size_t)SL * W);
-  std::vector<int> perm(n);
-  std::vector<double> cov_invs((size_t)225 * (W > 1 ? W - 1 : 0));   // cov is constant during the loop: invert once
-  if (!vxi::li_invert_covariances(W, imus, cov_invs.data())) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
-  {   // the loop on the device (VXBA_LI_DEVICE=0: the host shell below); sharded runs keep the host shell
-    if (f->opt[VXBA_OPT_LI_DEVICE_LOOP] != 0 && !has_collective(f)) return li_damping_iter_device(f, states, imus, imu_coef, max_iter, hess_out, trace_out, n_trace, cov_invs.data());
+  const auto t_call0 = std::chrono::steady_clock::now();
+  const bool device_loop = f->opt[VXBA_OPT_LI_DEVICE_LOOP] != 0 && !has_collective(f);   // sharded runs keep the host shell
+  // the first Hessian sweep goes out before any host-side preparation (covariance inverses, buffers): it needs the poses only
+  bool first_sweep_queued = false;
+  if (!device_loop && max_iter > 0 && !has_collective(f)) {
+    double Rp0[12 * VXBA_MAX_WIN];
+    states_to_poses(W, states, Rp0);
+    int rc = sweep_hess_device(f, Rp0, nullptr, nullptr, nullptr, 0, f->V, f->zc_packed);
+    if (rc) return rc;
+    first_sweep_queued = true;
   }
+  f->li.size(n, W > 1 ? W - 1 : 0);
+  std::vector<double>&Hess = f->li.Hess, &A = f->li.A, &JacT = f->li.JacT, &D = f->li.D, &rhs = f->li.rhs, &dxi = f->li.dxi, &work = f->li.work;
+  std::vector<double>&HessN = f->li.HessN, &JacTN = f->li.JacTN;   // IMU half of the next joint system (speculative, see li_joint_residual)
+  std::vector<double>& cov_invs = f->li.cov_invs;                   // cov is constant during the loop: invert once
+  std::vector<int>& perm = f->li.perm;
+  std::vector<double> x_temp(states, states + (size_t)SL * W);
+  if (!vxi::li_invert_covariances(W, imus, cov_invs.data())) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
+  if (device_loop) return li_damping_iter_device(f, states, imus, imu_coef, max_iter, hess_out, trace_out, n_trace, cov_invs.data());
   double residual1 = 0, residual2 = 0;
   bool is_calc_hess = true;
   int nt = 0;
   vxh::LiIndexSets li_sets;
-  vxh::BandSchurWork bs_work;
+  vxh::BandSchurWork& bs_work = f->li_bs;
   bool spec_queued = false;
+  double imu_res_next = 0.0;
+  const double* last_hess = nullptr;   // buffer that holds the last complete joint Hessian (*hess = Hess, :588): copied out once, at the end
   // development aid: VXBA_LI_TIMING=1 prints where the host time of one call goes
   static const bool timing = [] { const char* e = getenv("VXBA_LI_TIMING"); return e && e[0] == '1'; }();
   double t_sys = 0, t_solve = 0, t_res = 0;
+  const double wait0 = f->li_wait_us;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
   for (int it = 0; it < max_iter; it++) {
     const bool recomputed = is_calc_hess;
     const auto t0 = now();
+    bool prepared = false;
     if (is_calc_hess) {
-      int rc = li_joint_system(f, states, imus, imu_coef, Hess.data(), JacT.data(), &residual1, false, cov_invs.data(), spec_queued);
-      spec_queued = false;
+      // the band half of the structured solve needs nothing from the LiDAR factor: it runs while the GPU is still sweeping
+      const std::function<void()> band_half = [&]() {
+        const int g = vxi::DIM, m = n - g;
+        if (m <= 0 || !f->opt[VXBA_OPT_LI_STRUCTURED_SOLVE]) return;
+        if (li_sets.Y.empty()) li_sets = vxh::li_index_sets(W - 1, 0, 0);
+        for (int y : li_sets.Y) { rhs[y] = -JacT[y + g]; work[y] = u * Hess[(size_t)(y + g) * n + y + g]; }
+        prepared = vxh::band_schur_prepare(&Hess[(size_t)g * n + g], n, work.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(),
+                                           (int)li_sets.X.size(), li_sets.xlo.data(), bs_work);
+      };
+      int rc = li_joint_system(f, states, imus, imu_coef, Hess.data(), JacT.data(), &residual1, false, cov_invs.data(), spec_queued || first_sweep_queued, &band_half,
+                               spec_queued ? &imu_res_next : nullptr);
+      spec_queued = false; first_sweep_queued = false;
       if (rc) return rc;
-      if (hess_out) std::memcpy(hess_out, Hess.data(), sizeof(double) * n * n);   // *hess = Hess, before the gauge fix (:588)
+      last_hess = Hess.data();   // *hess = Hess, before the gauge fix (:588) -- this shell never modifies the matrix
     }
     const auto t1 = now();
     // gauge: frame 0's 15 rows / columns become identity rows with a zero right-hand side (:591-594): dxi = 0 there and they couple
@@ -1613,10 +1672,15 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
       bool solved = false;
       if (m > 0 && f->opt[VXBA_OPT_LI_STRUCTURED_SOLVE]) {
         if (li_sets.Y.empty()) li_sets = vxh::li_index_sets(W - 1, 0, 0);
-        solved = vxh::band_schur_solve(m, &Hess[(size_t)g * n + g], n, work.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(),
-                                       (int)li_sets.X.size(), li_sets.xlo.data(), dxi.data() + g, bs_work);
+        // after a rejected step (same system, new damping) both halves run here
+        solved = prepared || vxh::band_schur_prepare(&Hess[(size_t)g * n + g], n, work.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw,
+                                                     li_sets.X.data(), (int)li_sets.X.size(), li_sets.xlo.data(), bs_work);
+        if (solved)
+          vxh::band_schur_finish(&Hess[(size_t)g * n + g], n, work.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(),
+                                 (int)li_sets.X.size(), dxi.data() + g, bs_work);
       }
       if (m > 0 && !solved) {
+        A.resize((size_t)n * n);
         for (int c = 0; c < m; c++) std::memcpy(&A[(size_t)c * m], &Hess[(size_t)(c + g) * n + g], sizeof(double) * m);
         for (int r = 0; r < m; r++) A[(size_t)r * m + r] += u * D[r + g];
         vxh::ldlt_solve_inplace(m, A.data(), rhs.data(), dxi.data() + g, perm.data(), work.data());
@@ -1637,7 +1701,7 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
     q1 *= 0.5;
     const auto t2 = now();
     const bool speculate = it + 1 < max_iter && !has_collective(f);
-    int rc = li_joint_residual(f, x_temp.data(), imus, imu_coef, &residual2, cov_invs.data(), speculate);
+    int rc = li_joint_residual(f, x_temp.data(), imus, imu_coef, &residual2, cov_invs.data(), speculate, HessN.data(), JacTN.data(), false, &imu_res_next);
     if (rc) return rc;
     spec_queued = speculate;     // only meaningful if the step is accepted (states <- x_temp); a rejected step never asks for the system
     const auto t3 = now();
@@ -1648,6 +1712,7 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
     if (accepted) {
       std::memcpy(states, x_temp.data(), sizeof(double) * SL * W);
       is_calc_hess = true;
+      if (spec_queued) { Hess.swap(HessN); JacT.swap(JacTN); }   // the IMU half of the next system, built during the residual sweep
     } else {
       is_calc_hess = false;
       for (int j = 0; j < W - 1; j++) vxi::imu_rollback(imus + (size_t)vxi::IMU_LEN * j);
@@ -1660,7 +1725,8 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
     if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
   }
   if (n_trace) *n_trace = nt;
-  if (timing) std::fprintf(stderr, "[vxba li] %d iterations: joint system %.0f us, solve+update %.0f us, joint residual %.0f us\n", nt, t_sys, t_solve, t_res);
+  if (hess_out && last_hess) std::memcpy(hess_out, last_hess, sizeof(double) * n * n);
+  if (timing) std::fprintf(stderr, "[vxba li] %d iterations, %.0f us in the call: joint system %.0f us (of which waiting for the sweep %.0f), solve+update %.0f us, joint residual %.0f us\n", nt, us(t_call0, now()), t_sys, f->li_wait_us - wait0, t_solve, t_res);
   return VXBA_OK;
 }
 
@@ -1676,44 +1742,70 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
   hipSetDevice(f->device);
   const int W = f->W, n = vxi::DIM * W + 3, SL = vxi::STATE_LEN;
   double u = 0.01, v = 2;
-  std::vector<double> Hess((size_t)n * n), A((size_t)n * n), JacT(n), D(n), rhs(n), dxi(n), work(n), x_temp(states, states + (size_t)SL * W);
-  std::vector<int> perm(n);
-  std::vector<double> cov_invs((size_t)225 * (W > 1 ? W - 1 : 0));
+  bool first_sweep_queued = false;   // as in vxba_li_damping_iter: the first sweep runs under the host-side preparation
+  if (max_iter > 0 && !has_collective(f)) {
+    double Rp0[12 * VXBA_MAX_WIN];
+    states_to_poses(W, states, Rp0);
+    int rc = sweep_hess_device(f, Rp0, nullptr, nullptr, nullptr, 0, f->V, f->zc_packed);
+    if (rc) return rc;
+    first_sweep_queued = true;
+  }
+  f->li.size(n, W > 1 ? W - 1 : 0);
+  std::vector<double>&Hess = f->li.Hess, &A = f->li.A, &JacT = f->li.JacT, &D = f->li.D, &rhs = f->li.rhs, &dxi = f->li.dxi, &work = f->li.work;
+  std::vector<double>&HessN = f->li.HessN, &JacTN = f->li.JacTN;   // IMU half of the next joint system (speculative, see li_joint_residual)
+  std::vector<double>& cov_invs = f->li.cov_invs;
+  std::vector<int>& perm = f->li.perm;
+  std::vector<double> x_temp(states, states + (size_t)SL * W);
   if (!vxi::li_invert_covariances(W, imus, cov_invs.data())) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
   double residual1 = 0, residual2 = 0;
   bool is_calc_hess = true;
   int nt = 0;
   vxh::LiIndexSets li_sets;
-  vxh::BandSchurWork bs_work;
-  std::vector<double> Ared;
+  vxh::BandSchurWork& bs_work = f->li_bs;
   bool spec_queued = false;
+  double imu_res_next = 0.0;
+  const double* last_hess = nullptr;   // buffer that holds the last complete joint Hessian: copied out once, at the end
   for (int it = 0; it < max_iter; it++) {
     const bool recomputed = is_calc_hess;
+    bool prepared = false;
+    const int mr = n - 6;   // without the six gauge rows (identity, dxi = 0): [v, bg, ba of frame 0 | frames 1 .. W-1 | g]
+    const bool structured = f->opt[VXBA_OPT_LI_STRUCTURED_SOLVE] && W > 1;
+    if (structured && li_sets.Y.empty()) li_sets = vxh::li_index_sets(W - 1, 9, 3);
     if (is_calc_hess) {
-      int rc = li_joint_system(f, states, imus, imu_coef, Hess.data(), JacT.data(), &residual1, true, cov_invs.data(), spec_queued);
-      spec_queued = false;
+      // the band half of the structured solve (velocities / biases: IMU terms only) runs while the GPU is still sweeping
+      const std::function<void()> band_half = [&]() {
+        if (!structured) return;
+        for (int y : li_sets.Y) { rhs[y] = -JacT[y + 6]; work[y] = u * Hess[(size_t)(y + 6) * n + y + 6]; }
+        prepared = vxh::band_schur_prepare(&Hess[(size_t)6 * n + 6], n, work.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(),
+                                           (int)li_sets.X.size(), li_sets.xlo.data(), bs_work);
+      };
+      int rc = li_joint_system(f, states, imus, imu_coef, Hess.data(), JacT.data(), &residual1, true, cov_invs.data(), spec_queued || first_sweep_queued, &band_half,
+                               spec_queued ? &imu_res_next : nullptr);
+      spec_queued = false; first_sweep_queued = false;
       if (rc) return rc;
-      if (hess_out) std::memcpy(hess_out, Hess.data(), sizeof(double) * n * n);
+      last_hess = Hess.data();
     }
     if (it == 0 && resis_out) resis_out[0] = residual1;
-    for (int c = 0; c < n; c++)
-      for (int r = 0; r < 6; r++) { Hess[(size_t)c * n + r] = 0.0; Hess[(size_t)r * n + c] = 0.0; }
-    for (int r = 0; r < 6; r++) { Hess[(size_t)r * n + r] = 1.0; JacT[r] = 0.0; }
-    for (int r = 0; r < n; r++) D[r] = Hess[(size_t)r * n + r];
+    // gauge (:801-806): the pose of frame 0 -- identity rows with a zero right-hand side.  The matrix itself is left alone (the
+    // structured solve works on the block behind those rows, the dense fallback applies them to its copy): *hess is copied out once
+    for (int r = 0; r < 6; r++) JacT[r] = 0.0;
+    for (int r = 0; r < n; r++) D[r] = r < 6 ? 1.0 : Hess[(size_t)r * n + r];
     bool solved = false;
-    if (f->opt[VXBA_OPT_LI_STRUCTURED_SOLVE] && W > 1) {
-      // without the six gauge rows (identity, dxi = 0): [v, bg, ba of frame 0 | frames 1 .. W-1 | g]
-      const int mr = n - 6;
-      Ared.resize((size_t)mr * mr);
-      for (int c = 0; c < mr; c++) std::memcpy(&Ared[(size_t)c * mr], &Hess[(size_t)(c + 6) * n + 6], sizeof(double) * mr);
-      for (int r = 0; r < mr; r++) { Ared[(size_t)r * mr + r] += u * D[r + 6]; rhs[r] = -JacT[r + 6]; }
-      if (li_sets.Y.empty()) li_sets = vxh::li_index_sets(W - 1, 9, 3);
+    if (structured) {
+      // in place on the trailing block of Hess (the gauge rows / columns lie outside it), damping handed over separately
+      for (int r = 0; r < mr; r++) { work[r] = u * D[r + 6]; rhs[r] = -JacT[r + 6]; }
       for (int r = 0; r < 6; r++) dxi[r] = 0.0;
-      solved = vxh::band_schur_solve(mr, Ared.data(), mr, nullptr, rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(),
-                                     (int)li_sets.X.size(), li_sets.xlo.data(), dxi.data() + 6, bs_work);
+      solved = prepared || vxh::band_schur_prepare(&Hess[(size_t)6 * n + 6], n, work.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw,
+                                                   li_sets.X.data(), (int)li_sets.X.size(), li_sets.xlo.data(), bs_work);
+      if (solved)
+        vxh::band_schur_finish(&Hess[(size_t)6 * n + 6], n, work.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(),
+                               (int)li_sets.X.size(), dxi.data() + 6, bs_work);
     }
     if (!solved) {
       A = Hess;
+      for (int c = 0; c < n; c++)
+        for (int r = 0; r < 6; r++) { A[(size_t)c * n + r] = 0.0; A[(size_t)r * n + c] = 0.0; }
+      for (int r = 0; r < 6; r++) A[(size_t)r * n + r] = 1.0;
       for (int r = 0; r < n; r++) { A[(size_t)r * n + r] += u * D[r]; rhs[r] = -JacT[r]; }
       vxh::ldlt_solve_inplace(n, A.data(), rhs.data(), dxi.data(), perm.data(), work.data());
     }
@@ -1731,7 +1823,7 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
     for (int r = 0; r < n; r++) q1 += dxi[r] * (u * D[r] * dxi[r] - JacT[r]);
     q1 *= 0.5;
     const bool speculate = it + 1 < max_iter && !has_collective(f);
-    int rc = li_joint_residual(f, x_temp.data(), imus, imu_coef, &residual2, cov_invs.data(), speculate);
+    int rc = li_joint_residual(f, x_temp.data(), imus, imu_coef, &residual2, cov_invs.data(), speculate, HessN.data(), JacTN.data(), true, &imu_res_next);
     spec_queued = speculate;
     if (rc) return rc;
     const double q = residual1 - residual2;
@@ -1740,6 +1832,7 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
     if (accepted) {
       std::memcpy(states, x_temp.data(), sizeof(double) * SL * W);
       is_calc_hess = true;
+      if (spec_queued) { Hess.swap(HessN); JacT.swap(JacTN); }   // the IMU half of the next system, built during the residual sweep
     } else {
       is_calc_hess = false;
       for (int j = 0; j < W - 1; j++) vxi::imu_rollback(imus + (size_t)vxi::IMU_LEN * j);
@@ -1753,6 +1846,7 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
   }
   if (resis_out) resis_out[1] = residual2;
   if (n_trace) *n_trace = nt;
+  if (hess_out && last_hess) std::memcpy(hess_out, last_hess, sizeof(double) * n * n);
   return VXBA_OK;
 }
 

@@ -136,83 +136,134 @@ inline void ldlt_solve_inplace(int n, double* A, const double* b, double* x, int
 //   A: m x m, full symmetric storage (row- == column-major), not modified.   Y[ny], X[nx]: the two index sets (disjoint, together
 //   all of 0..m-1), X sorted by xlo.   bw: half-bandwidth of A[Y][Y] in Y order.   xlo[p]: first Y position column X[p] couples to.
 struct BandSchurWork {
-  std::vector<double> L, Wm, S, wb, rx, xs, work;
+  std::vector<double> L, Lt, invd, Wm, wrow, S, S0, wb, yb, rx, rx0, xs, work;
   std::vector<int> perm, qmax;
 };
 //   lda: row stride of A (>= m: A may be a window into a larger matrix).   dadd (nullable): added to the diagonal, dadd[i] for A(i, i)
 //   -- the LM damping u * diag(H), so that the caller need not build H + u D.
+// The solve comes in two halves.  `prepare` touches A[Y][Y], A[Y][X], b[Y] and dadd[Y] only -- in the LiDAR-inertial system those
+// hold nothing but IMU terms, so the LI shells run it while the GPU is still sweeping the LiDAR Hessian -- and leaves L, W, L^-1 b_Y,
+// -W^T W and -W^T L^-1 b_Y in the workspace; `finish` adds A[X][X] (+ damping) and b[X], takes the dense step and substitutes back.
+// Layout of the workspace: L in row-band storage (row a holds columns a-bw .. a at [0 .. bw]) and, transposed, in column-band storage
+// (Lt: column c holds rows c .. c+bw) so that both sweeps of the factorisation run down contiguous memory; W and S0 with rows padded to
+// a multiple of 16 doubles (the Schur-complement loop works on 16-wide register blocks and may read / write the padding).
+constexpr int BS_MAXBW = 63;
+inline int band_schur_stride(int nx) { return (nx + 15) & ~15; }
 template <bool AVX>
-__attribute__((always_inline)) inline bool band_schur_solve_impl(int m, const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw, const int* X, int nx,
-                                  const int* xlo, double* x, BandSchurWork& ws) {
-  (void)m;
-  const int ld = bw + 1;                     // L band storage: row a holds columns a-bw .. a at [0 .. bw]
-  const int nc = (nx + 3) & ~3;              // padded row length of W
-  ws.L.assign((size_t)ny * ld, 0.0);
-  ws.Wm.assign((size_t)ny * nc, 0.0);
-  ws.wb.assign(ny, 0.0);
-  ws.qmax.assign(ny, 0);
-  double* L = ws.L.data();
-  auto Lat = [&](int a, int c) -> double& { return L[(size_t)a * ld + (c - (a - bw))]; };   // a - bw <= c <= a
-  // band Cholesky, row by row
+__attribute__((always_inline)) inline bool band_schur_prepare_impl(const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw, const int* X, int nx,
+                                  const int* xlo, BandSchurWork& ws) {
+  if (bw > BS_MAXBW) return false;
+  const int ld = bw + 1;
+  const int nc = band_schur_stride(nx);
+  ws.L.resize((size_t)ny * ld);
+  ws.Lt.resize((size_t)ny * ld);
+  ws.invd.resize(ny);
+  ws.Wm.resize((size_t)ny * nc);            // new elements are zero; whatever an earlier call left behind is finite
+  ws.S0.resize((size_t)nx * nc);
+  ws.wb.resize(ny);
+  ws.rx0.resize(nx);
+  ws.qmax.resize(ny);
+  ws.wrow.resize(nc);
+  double* __restrict L = ws.L.data();
+  double* __restrict Lt = ws.Lt.data();
+  double* __restrict invd = ws.invd.data();
+  // Band Cholesky, row by row.  Inside a row the substitution is right-looking: once L(a, c) is known it is taken out of the
+  // entries to its right with column c of L (contiguous in Lt) -- independent updates instead of one dependent sum per entry; every
+  // entry still receives its terms in ascending order of c.  Divisions by the pivots are multiplications by their reciprocals.
   for (int a = 0; a < ny; a++) {
-    const int c0 = a - bw > 0 ? a - bw : 0;
+    const int c0 = a - bw > 0 ? a - bw : 0, len = a - c0 + 1;
     const double* Arow = A + (size_t)Y[a] * lda;
-    for (int c = c0; c <= a; c++) {
-      const int k0 = c - bw > c0 ? c - bw : c0;
-      double sum = Arow[Y[c]] + ((c == a && dadd) ? dadd[Y[a]] : 0.0);
-      const double* la = &Lat(a, k0);
-      const double* lc = &Lat(c, k0);
-      for (int k = 0; k < c - k0; k++) sum -= la[k] * lc[k];
-      if (c < a) Lat(a, c) = sum / Lat(c, c);
-      else {
-        if (!(sum > 0.0)) return false;
-        Lat(a, a) = std::sqrt(sum);
-      }
+    double v[BS_MAXBW + 1];
+    for (int t = 0; t < len; t++) v[t] = Arow[Y[c0 + t]];
+    if (dadd) v[len - 1] += dadd[Y[a]];
+    for (int c = c0; c < a; c++) {
+      const double x = v[c - c0] * invd[c];
+      v[c - c0] = x;
+      const double* __restrict lt = Lt + (size_t)c * ld;   // lt[t] = L(c + t, c)
+      double* __restrict vr = v + (c - c0);
+      const int m = a - c;
+      for (int t = 1; t < m; t++) vr[t] -= x * lt[t];
+      vr[m] -= x * x;                                      // the diagonal entry: L(a, c)^2
     }
+    const double d = v[len - 1];
+    if (!(d > 0.0)) return false;
+    const double sd = std::sqrt(d);
+    v[len - 1] = sd;
+    invd[a] = 1.0 / sd;
+    double* la = L + (size_t)a * ld + (c0 - (a - bw));
+    for (int t = 0; t < len; t++) { la[t] = v[t]; Lt[(size_t)(c0 + t) * ld + (a - c0 - t)] = v[t]; }
   }
   // W = L^-1 A[Y][X] and wb = L^-1 b_Y, row by row; row a is non-zero on the columns whose first row is <= a
   {
     int q = 0;
     for (int a = 0; a < ny; a++) { while (q < nx && xlo[q] <= a) q++; ws.qmax[a] = q; }
   }
+  double* __restrict Wm = ws.Wm.data();
+  double* __restrict wbv = ws.wb.data();
   for (int a = 0; a < ny; a++) {
     const int c0 = a - bw > 0 ? a - bw : 0;
     const int qa = ws.qmax[a];
-    double* wa = ws.Wm.data() + (size_t)a * nc;
+    double* __restrict wa = ws.wrow.data();
     const double* Arow = A + (size_t)Y[a] * lda;
     for (int q = 0; q < qa; q++) wa[q] = Arow[X[q]];
     double sb = b[Y[a]];
+    const double* la = L + (size_t)a * ld - (a - bw);      // la[k] = L(a, k)
     for (int k = c0; k < a; k++) {
-      const double l = Lat(a, k);
-      const double* wk = ws.Wm.data() + (size_t)k * nc;
+      const double l = la[k];
+      const double* __restrict wk = Wm + (size_t)k * nc;
       const int qk = ws.qmax[k];              // qk <= qa
       for (int q = 0; q < qk; q++) wa[q] -= l * wk[q];
-      sb -= l * ws.wb[k];
+      sb -= l * wbv[k];
     }
-    const double inv = 1.0 / Lat(a, a);
-    for (int q = 0; q < qa; q++) wa[q] *= inv;
-    ws.wb[a] = sb * inv;
+    const double inv = invd[a];
+    double* __restrict wout = Wm + (size_t)a * nc;
+    for (int q = 0; q < qa; q++) wout[q] = wa[q] * inv;
+    wbv[a] = sb * inv;
   }
-  // S = A[X][X] - W^T W (lower triangle, then mirrored), rx = b_X - W^T wb
-  ws.S.assign((size_t)nx * nx, 0.0);
-  ws.rx.assign(nx, 0.0);
+  // S0 = -W^T W (lower triangle), 16 columns of one row at a time in registers, summed over the rows of W in ascending order;
+  // rx0 = -W^T wb
+  double* __restrict S0 = ws.S0.data();
+  for (int p = 0; p < nx; p++) {
+    const int lo = xlo[p] < ny ? xlo[p] : ny;
+    for (int q0 = 0; q0 <= p; q0 += 16) {
+      double acc[16];
+      for (int t = 0; t < 16; t++) acc[t] = 0.0;
+      for (int a = lo; a < ny; a++) {
+        const double* __restrict wa = Wm + (size_t)a * nc;
+        const double wp = wa[p];
+        for (int t = 0; t < 16; t++) acc[t] -= wp * wa[q0 + t];
+      }
+      double* sp = S0 + (size_t)p * nc + q0;
+      for (int t = 0; t < 16; t++) sp[t] = acc[t];
+    }
+  }
+  double* __restrict rx0 = ws.rx0.data();
+  for (int p = 0; p < nx; p++) rx0[p] = 0.0;
+  for (int a = 0; a < ny; a++) {
+    const double* __restrict wa = Wm + (size_t)a * nc;
+    const int qa = ws.qmax[a];
+    const double wba = wbv[a];
+    for (int p = 0; p < qa; p++) rx0[p] -= wa[p] * wba;
+  }
+  return true;
+}
+template <bool AVX>
+__attribute__((always_inline)) inline void band_schur_finish_impl(const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw, const int* X, int nx,
+                                  double* x, BandSchurWork& ws) {
+  const int ld = bw + 1;
+  const int nc = band_schur_stride(nx);
+  double* L = ws.L.data();
+  auto Lat = [&](int a, int c) -> double& { return L[(size_t)a * ld + (c - (a - bw))]; };
+  // S = A[X][X] (+ damping) - W^T W, mirrored; rx = b_X - W^T wb
+  ws.S.resize((size_t)nx * nx);
+  ws.rx.resize(nx);
   double* S = ws.S.data();
+  const double* S0 = ws.S0.data();
   for (int p = 0; p < nx; p++) {
     const double* Arow = A + (size_t)X[p] * lda;
-    for (int q = 0; q <= p; q++) S[(size_t)p * nx + q] = Arow[X[q]];
-    if (dadd) S[(size_t)p * nx + p] += dadd[X[p]];
-    ws.rx[p] = b[X[p]];
-  }
-  for (int a = 0; a < ny; a++) {
-    const double* wa = ws.Wm.data() + (size_t)a * nc;
-    const int qa = ws.qmax[a];
-    const double wba = ws.wb[a];
-    for (int p = 0; p < qa; p++) {
-      const double wp = wa[p];
-      double* sp = S + (size_t)p * nx;
-      for (int q = 0; q <= p; q++) sp[q] -= wp * wa[q];
-      ws.rx[p] -= wp * wba;
-    }
+    for (int q = 0; q <= p; q++) S[(size_t)p * nx + q] = Arow[X[q]] + S0[(size_t)p * nc + q];
+    if (dadd) S[(size_t)p * nx + p] = (Arow[X[p]] + dadd[X[p]]) + S0[(size_t)p * nc + p];
+    ws.rx[p] = b[X[p]] + ws.rx0[p];
   }
   for (int p = 0; p < nx; p++)
     for (int q = 0; q < p; q++) S[(size_t)q * nx + p] = S[(size_t)p * nx + q];
@@ -221,33 +272,53 @@ __attribute__((always_inline)) inline bool band_schur_solve_impl(int m, const do
   ldlt_solve_inplace(nx, S, ws.rx.data(), ws.xs.data(), ws.perm.data(), ws.work.data());
   for (int p = 0; p < nx; p++) x[X[p]] = ws.xs[p];
   // y = L^-T (wb - W x)
+  ws.yb.resize(ny);
   for (int a = 0; a < ny; a++) {
     const double* wa = ws.Wm.data() + (size_t)a * nc;
     double sacc = ws.wb[a];
     for (int q = 0; q < ws.qmax[a]; q++) sacc -= wa[q] * ws.xs[q];
-    ws.wb[a] = sacc;
+    ws.yb[a] = sacc;
   }
   for (int a = ny - 1; a >= 0; a--) {
-    const double ya = ws.wb[a] / Lat(a, a);
-    ws.wb[a] = ya;
+    const double ya = ws.yb[a] / Lat(a, a);
+    ws.yb[a] = ya;
     const int c0 = a - bw > 0 ? a - bw : 0;
-    for (int k = c0; k < a; k++) ws.wb[k] -= Lat(a, k) * ya;
+    for (int k = c0; k < a; k++) ws.yb[k] -= Lat(a, k) * ya;
   }
-  for (int a = 0; a < ny; a++) x[Y[a]] = ws.wb[a];
-  return true;
+  for (int a = 0; a < ny; a++) x[Y[a]] = ws.yb[a];
 }
 #if defined(__x86_64__)
-__attribute__((target("avx2,fma"))) inline bool band_schur_solve_avx2(int m, const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw,
-                                                                      const int* X, int nx, const int* xlo, double* x, BandSchurWork& ws) {
-  return band_schur_solve_impl<true>(m, A, lda, dadd, b, Y, ny, bw, X, nx, xlo, x, ws);
+__attribute__((target("avx2,fma"))) inline bool band_schur_prepare_avx2(const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw,
+                                                                        const int* X, int nx, const int* xlo, BandSchurWork& ws) {
+  return band_schur_prepare_impl<true>(A, lda, dadd, b, Y, ny, bw, X, nx, xlo, ws);
+}
+__attribute__((target("avx2,fma"))) inline void band_schur_finish_avx2(const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw,
+                                                                       const int* X, int nx, double* x, BandSchurWork& ws) {
+  band_schur_finish_impl<true>(A, lda, dadd, b, Y, ny, bw, X, nx, x, ws);
 }
 #endif
+// false: a band pivot was not positive (nothing usable in the workspace; the caller takes the dense solve)
+inline bool band_schur_prepare(const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw, const int* X, int nx, const int* xlo,
+                               BandSchurWork& ws) {
+#if defined(__x86_64__)
+  if (cpu_has_avx2_fma()) return band_schur_prepare_avx2(A, lda, dadd, b, Y, ny, bw, X, nx, xlo, ws);
+#endif
+  return band_schur_prepare_impl<false>(A, lda, dadd, b, Y, ny, bw, X, nx, xlo, ws);
+}
+// after a successful prepare on the same A[Y][.], b[Y], dadd[Y]
+inline void band_schur_finish(const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw, const int* X, int nx, double* x,
+                              BandSchurWork& ws) {
+#if defined(__x86_64__)
+  if (cpu_has_avx2_fma()) return band_schur_finish_avx2(A, lda, dadd, b, Y, ny, bw, X, nx, x, ws);
+#endif
+  band_schur_finish_impl<false>(A, lda, dadd, b, Y, ny, bw, X, nx, x, ws);
+}
 inline bool band_schur_solve(int m, const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw, const int* X, int nx,
                              const int* xlo, double* x, BandSchurWork& ws) {
-#if defined(__x86_64__)
-  if (cpu_has_avx2_fma()) return band_schur_solve_avx2(m, A, lda, dadd, b, Y, ny, bw, X, nx, xlo, x, ws);
-#endif
-  return band_schur_solve_impl<false>(m, A, lda, dadd, b, Y, ny, bw, X, nx, xlo, x, ws);
+  (void)m;
+  if (!band_schur_prepare(A, lda, dadd, b, Y, ny, bw, X, nx, xlo, ws)) return false;
+  band_schur_finish(A, lda, dadd, b, Y, ny, bw, X, nx, x, ws);
+  return true;
 }
 
 // Index sets of the LiDAR-inertial system for band_schur_solve.  The system handed in holds frames f0 .. W-1 with 15 unknowns each

@@ -144,24 +144,6 @@ inline void dm_mul(int m, int k, int n, const double* A, const double* B, double
     }
   }
 }
-// C (k x n) = A^T (A is m x k) * B (m x n) for an A with many exact zeros (the IMU Jacobian: 18 of its 50 3x3 blocks are set):
-// every dot product runs over the non-zero entries of A's column only, in the same order as the dense loop -- the skipped terms
-// are exact zeros, so the result is bit-identical.  m <= 16.
-inline void dm_tmul_sparse_a(int m, int k, int n, const double* A, const double* B, double* C) {
-  for (int i = 0; i < k; i++) {
-    const double* ai = A + (size_t)i * m;
-    int idx[16], cnt = 0;
-    double val[16];
-    for (int p = 0; p < m; p++)
-      if (ai[p] != 0.0) { idx[cnt] = p; val[cnt] = ai[p]; cnt++; }
-    for (int j = 0; j < n; j++) {
-      const double* bj = B + (size_t)j * m;
-      double s = 0.0;
-      for (int q = 0; q < cnt; q++) s += val[q] * bj[idx[q]];
-      C[(size_t)j * k + i] = s;
-    }
-  }
-}
 // C (k x n) = A^T (A is m x k) * B (m x n)
 inline void dm_tmul(int m, int k, int n, const double* A, const double* B, double* C) {
   for (int j = 0; j < n; j++)
@@ -359,38 +341,59 @@ VXI_FN void imu_residual_jac(const double* f, const double* s1, const double* s2
   }
 }
 
-inline double imu_evaluate(const double* f, const double* s1, const double* s2, bool jac, double* jtj, double* gg, ImuWork& w, bool* ok = nullptr,
+// The products of give_evaluate on top of (rr, J):  q = cov^-1 r,  M = cov^-1 J,  jtj = J^T M,  gg = J^T q,  returns r . q.
+// Fixed sizes and unit-stride inner loops (the compiler turns them into SSE2 / AVX2 code; vxi::li_add_imu_blocks picks an AVX2 + FMA
+// instance at run time): M column by column as a combination of the columns of cov^-1 that J's non-zeros select (18 of J's 50 3x3
+// blocks are set), jtj column by column as a combination of the ROWS of J.  Every sum runs over the same index in the same (ascending)
+// order as the plain triple loops; gg associates J^T (cov^-1 r) where upstream writes (J^T cov^-1) r -- round-off only.
+template <int NC>
+__attribute__((always_inline)) inline double imu_products(const double* J /* 15 x NC, column-major */, const double* ci /* 15 x 15 */, const double* rr, bool jac,
+                                                          double* jtj /* NC x NC, column-major */, double* gg) {
+  double q[DIM];
+  for (int i = 0; i < DIM; i++) q[i] = 0.0;
+  for (int k = 0; k < DIM; k++) {
+    const double r = rr[k];
+    const double* ck = ci + (size_t)k * DIM;
+    for (int i = 0; i < DIM; i++) q[i] += ck[i] * r;      // q(i) = sum_k cov_inv(i, k) r(k)
+  }
+  double res = 0.0;
+  for (int i = 0; i < DIM; i++) res += rr[i] * q[i];
+  if (!jac) return res;
+  double Jr[DIM][NC];                                       // rows of J
+  for (int j = 0; j < NC; j++)
+    for (int b = 0; b < DIM; b++) Jr[b][j] = J[(size_t)j * DIM + b];
+  for (int j = 0; j < NC; j++) {
+    double m[DIM];
+    for (int i = 0; i < DIM; i++) m[i] = 0.0;
+    const double* jc = J + (size_t)j * DIM;
+    double g = 0.0;
+    for (int p = 0; p < DIM; p++) {
+      const double b = jc[p];
+      if (b == 0.0) continue;
+      const double* cp = ci + (size_t)p * DIM;
+      for (int i = 0; i < DIM; i++) m[i] += cp[i] * b;      // M(:, j) = sum_p cov_inv(:, p) J(p, j)
+      g += b * q[p];
+    }
+    gg[j] = g;
+    double* out = jtj + (size_t)j * NC;
+    for (int i = 0; i < NC; i++) out[i] = 0.0;
+    for (int b = 0; b < DIM; b++) {
+      const double mb = m[b];
+      for (int i = 0; i < NC; i++) out[i] += Jr[b][i] * mb;  // jtj(:, j) = sum_b J(b, :)^T M(b, j)
+    }
+  }
+  return res;
+}
+
+__attribute__((always_inline)) inline double imu_evaluate(const double* f, const double* s1, const double* s2, bool jac, double* jtj, double* gg, ImuWork& w, bool* ok = nullptr,
                            bool with_g = false, const double* cov_inv_cached = nullptr) {
   double rr[DIM];
   imu_residual_jac(f, s1, s2, jac, with_g, rr, w.joc);
   bool inv_ok = true;
-  if (cov_inv_cached) std::memcpy(w.cov_inv, cov_inv_cached, sizeof w.cov_inv);
-  else inv_ok = dm_inverse(DIM, f + O_COV, w.cov_inv, w.lu, w.perm);
+  const double* ci = cov_inv_cached;
+  if (!ci) { inv_ok = dm_inverse(DIM, f + O_COV, w.cov_inv, w.lu, w.perm); ci = w.cov_inv; }
   if (ok) *ok = inv_ok;
-
-  if (jac) {
-    double* J = w.joc;
-    const int nc = with_g ? NCG : 2 * DIM;
-    dm_mul(DIM, DIM, nc, w.cov_inv, J, w.ci_j);                     // cov^-1 J   (15 x nc)
-    dm_tmul_sparse_a(DIM, nc, nc, J, w.ci_j, jtj);                  // J^T cov^-1 J
-    // gg = (cov^-1 J)^T r  -- cov^-1 is symmetric up to round-off; the reference forms J^T cov^-1 r
-    for (int i = 0; i < nc; i++) {
-      double s = 0.0;
-      for (int a = 0; a < DIM; a++) {
-        double t = 0.0;                                             // (J^T cov^-1)(i, a) = sum_b J(b,i) cov_inv(b,a)
-        for (int b = 0; b < DIM; b++) t += J[(size_t)i * DIM + b] * w.cov_inv[(size_t)a * DIM + b];
-        s += t * rr[a];
-      }
-      gg[i] = s;
-    }
-  }
-  double res = 0.0;
-  for (int i = 0; i < DIM; i++) {
-    double s = 0.0;
-    for (int k = 0; k < DIM; k++) s += w.cov_inv[(size_t)k * DIM + i] * rr[k];
-    res += rr[i] * s;
-  }
-  return res;
+  return with_g ? imu_products<NCG>(w.joc, ci, rr, jac, jtj, gg) : imu_products<2 * DIM>(w.joc, ci, rr, jac, jtj, gg);
 }
 
 VXI_FN void imu_update_state(double* f, const double* dxi15) {
@@ -407,8 +410,10 @@ VXI_FN void imu_rollback(double* f) {   // voxel_map.hpp:639-643
 
 // Hess (n x n, n = 15W [+3 with gravity], zeroed by the caller) += imu blocks, then everything scaled by imu_coef; returns
 // the scaled residual.  with_g: the gravity rows / columns sit at the tail (voxel_map.hpp:700-711).
-inline double li_add_imu_blocks(int W, const double* states, const double* imus, double imu_coef, bool jac, double* Hess, double* JacT,
-                                ImuWork& w, bool* ok, bool with_g = false, const double* cov_invs = nullptr /* (W-1) x 225 */) {
+// The scaling pass (upstream: Hess *= imu_coef over the whole matrix, :504) only visits what the factors can have touched: the
+// rows of frames j-1 .. j+1 in the columns of frame j, and the gravity rows / columns -- everything else is still the caller's zero.
+__attribute__((always_inline)) inline double li_add_imu_blocks_impl(int W, const double* states, const double* imus, double imu_coef, bool jac, double* Hess, double* JacT,
+                                                                    ImuWork& w, bool* ok, bool with_g, const double* cov_invs /* (W-1) x 225 */) {
   const int n = DIM * W + (with_g ? 3 : 0), nc = with_g ? NCG : 2 * DIM, gq = DIM * W;
   double jtj[NCG * NCG], gg[NCG];
   double residual = 0.0;
@@ -419,8 +424,11 @@ inline double li_add_imu_blocks(int W, const double* states, const double* imus,
                              cov_invs ? cov_invs + (size_t)DIM * DIM * i : nullptr);
     all_ok = all_ok && one_ok;
     if (jac) {
-      for (int c = 0; c < 2 * DIM; c++)
-        for (int r = 0; r < 2 * DIM; r++) Hess[(size_t)(i * DIM + c) * n + i * DIM + r] += jtj[(size_t)c * nc + r];
+      for (int c = 0; c < 2 * DIM; c++) {
+        double* hc = Hess + (size_t)(i * DIM + c) * n + i * DIM;
+        const double* jc = jtj + (size_t)c * nc;
+        for (int r = 0; r < 2 * DIM; r++) hc[r] += jc[r];
+      }
       for (int r = 0; r < 2 * DIM; r++) JacT[i * DIM + r] += gg[r];
       if (with_g) {
         for (int c = 0; c < 3; c++)
@@ -435,11 +443,35 @@ inline double li_add_imu_blocks(int W, const double* states, const double* imus,
     }
   }
   if (jac) {
-    for (size_t k = 0; k < (size_t)n * n; k++) Hess[k] *= imu_coef;
+    for (int c = 0; c < gq; c++) {
+      const int j = c / DIM;
+      const int r0 = (j > 0 ? j - 1 : 0) * DIM, r1 = (j + 2 < W ? j + 2 : W) * DIM;
+      double* hc = Hess + (size_t)c * n;
+      for (int r = r0; r < r1; r++) hc[r] *= imu_coef;
+      for (int r = gq; r < n; r++) hc[r] *= imu_coef;
+    }
+    for (int c = gq; c < n; c++) {
+      double* hc = Hess + (size_t)c * n;
+      for (int r = 0; r < n; r++) hc[r] *= imu_coef;
+    }
     for (int k = 0; k < n; k++) JacT[k] *= imu_coef;
   }
   if (ok) *ok = all_ok;
   return residual * (imu_coef * 0.5);
+}
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("avx2,fma"))) inline double li_add_imu_blocks_avx2(int W, const double* states, const double* imus, double imu_coef, bool jac, double* Hess,
+                                                                         double* JacT, ImuWork& w, bool* ok, bool with_g, const double* cov_invs) {
+  return li_add_imu_blocks_impl(W, states, imus, imu_coef, jac, Hess, JacT, w, ok, with_g, cov_invs);
+}
+#endif
+inline double li_add_imu_blocks(int W, const double* states, const double* imus, double imu_coef, bool jac, double* Hess, double* JacT,
+                                ImuWork& w, bool* ok, bool with_g = false, const double* cov_invs = nullptr /* (W-1) x 225 */) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  static const bool avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+  if (avx2) return li_add_imu_blocks_avx2(W, states, imus, imu_coef, jac, Hess, JacT, w, ok, with_g, cov_invs);
+#endif
+  return li_add_imu_blocks_impl(W, states, imus, imu_coef, jac, Hess, JacT, w, ok, with_g, cov_invs);
 }
 
 // information matrices of all factors of a window, once per LM loop; false if one covariance is singular

@@ -590,7 +590,7 @@ class LI_BA_Optimizer:
                                                      trace.ctypes.data_as(C.c_void_p), C.byref(nt)))
         for f, b in zip(imus_factor, blobs):
             f.blob[:] = b
-        return dict(states=st, hess=hess.T.copy(), trace=trace[: nt.value].copy())
+        return dict(states=st, hess=hess.T, trace=trace[: nt.value])   # hess: (r, c)-indexed view of the column-major output, no copy
 
 
 class LI_BA_OptimizerGravity(LI_BA_Optimizer):
@@ -606,7 +606,7 @@ class LI_BA_OptimizerGravity(LI_BA_Optimizer):
                                                              resis, trace.ctypes.data_as(C.c_void_p), C.byref(nt)))
         for f, b in zip(imus_factor, blobs):
             f.blob[:] = b
-        return dict(states=st, hess=hess.T.copy(), resis=resis, trace=trace[: nt.value].copy())
+        return dict(states=st, hess=hess.T, resis=resis, trace=trace[: nt.value])
 
 
 def damping_iter_generic(win_size: int, x_stats, hess_fn, resid_fn, max_iter: int = 3):
