@@ -51,6 +51,8 @@ struct vxba_factor {
   double* d_partial3 = nullptr;  // K3 workgroup partials
   size_t partial3_len = 0;
   double* d_partial2 = nullptr;  // K2 wave partials
+  double* h_partial2 = nullptr;  // the same in mapped host memory (LI shells: the host adds the partials up itself), zc_partial2 = its device address
+  double* zc_partial2 = nullptr;
   size_t partial2_len = 0;
   double* d_packed = nullptr;    // [Hess | JacT | residual] (points at own_packed or a caller buffer)
   double* d_scalar = nullptr;
@@ -218,6 +220,10 @@ int ensure_capacity(vxba_factor* f, int n_total) {
   if (p2 > f->partial2_len) {
     if (f->d_partial2) VX_HIP(f, hipFree(f->d_partial2));
     VX_HIP(f, hipMalloc((void**)&f->d_partial2, p2 * sizeof(double)));
+    if (f->h_partial2) VX_HIP(f, hipHostFree(f->h_partial2));
+    f->h_partial2 = nullptr; f->zc_partial2 = nullptr;
+    VX_HIP(f, hipHostMalloc((void**)&f->h_partial2, p2 * sizeof(double), hipHostMallocMapped));
+    VX_HIP(f, hipHostGetDevicePointer((void**)&f->zc_partial2, f->h_partial2, 0));
     f->partial2_len = p2;
   }
   return VXBA_OK;
@@ -422,8 +428,10 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c
   return VXBA_OK;
 }
 
+// partials_to_host: the block partials go straight to mapped host memory (h_partial2) and no sum is launched -- the caller adds them up
+// with host_sum_partials once the sweep is done (d_out is ignored).
 int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int c, int head, int end, double* d_out,
-                          int* nparts_out = nullptr, unsigned fused_seq = 0) {
+                          int* nparts_out = nullptr, unsigned fused_seq = 0, bool partials_to_host = false) {
   if (end == head) { if (d_out) VX_HIP(f, hipMemsetAsync(d_out, 0, sizeof(double), f->stream)); return VXBA_OK; }
   if (is_wide(f)) {
     if (lm || !Rp || !d_out) return fail(f, VXBA_ERR_UNSUPPORTED, "device-resident LM loop: only for win_size <= VXBA_MAX_WIN");
@@ -443,12 +451,14 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, in
   if (Rp) fill_poses(f, Rp, pa); else std::memset(&pa, 0, sizeof pa);
   const FactorView fv = view(f);
   int nparts;
+  double* const part = (partials_to_host && !is_wide(f)) ? f->zc_partial2 : f->d_partial2;
+  if (partials_to_host) d_out = nullptr;
   if (f->profiling & 2) {
     hipEvent_t a = get_event(f), b = get_event(f);
-    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, f->d_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] ? 0x10000 : 0), f->stream, a, b);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, part, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] ? 0x10000 : 0), f->stream, a, b);
     if (a && b) f->pending.push_back({a, b, 1});
   } else {
-    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, f->d_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] ? 0x10000 : 0), f->stream);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, part, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] ? 0x10000 : 0), f->stream);
   }
   if (nparts_out) *nparts_out = nparts;
   if (d_out) {
@@ -615,7 +625,7 @@ int vxba_destroy(vxba_factor* f) {
   if (f->peer.box) hipFree(f->peer.box);
   for (auto& ep : f->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   for (auto e : f->free_events) hipEventDestroy(e);
-  hipFree(f->planes); hipFree(f->clb); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2);
+  hipFree(f->planes); hipFree(f->clb); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2); if (f->h_partial2) hipHostFree(f->h_partial2);
   vxw::free_index(f->wide);
   vxw::wide_solver_free(f->wide_solver);
   hipFree(f->own_packed); hipFree(f->d_count); hipFree(f->d_poses);
@@ -1470,6 +1480,19 @@ int li_joint_system(vxba_factor* f, const double* states, const double* imus, do
   *residual = res + f->h_packed[(size_t)m * m + m];
   return VXBA_OK;
 }
+// sum_partials_kernel on the host, same order (thread t of 1024 adds the partials t, t + 1024, ...; then the halving tree): bitwise the
+// value the device reduction gives
+double host_sum_partials(const double* p, int n) {
+  double red[1024];
+  for (int t = 0; t < 1024; t++) {
+    double s = 0.0;
+    for (int k = t; k < n; k += 1024) s += p[k];
+    red[t] = s;
+  }
+  for (int off = 512; off > 0; off >>= 1)
+    for (int t = 0; t < off; t++) red[t] += red[t + off];
+  return red[0];
+}
 // speculate (single GPU only): the Hessian sweep of the NEXT iteration -- at these trial states, on the cache this residual sweep leaves
 // -- is queued right behind it, before anybody knows whether the step will be accepted.  The host only waits for the residual (an
 // event), takes the decision, and if the step is accepted finds the next joint system already under way instead of paying a cold
@@ -1484,7 +1507,9 @@ int li_joint_residual(vxba_factor* f, const double* states, const double* imus, 
   states_to_poses(W, states, Rp.data());
   const bool zc = !has_collective(f);
   const size_t plen = vxba_packed_len(f);
-  int rc = sweep_residual_device(f, Rp.data(), nullptr, 0, 0, f->V, zc ? f->zc_packed + plen : f->d_scalar);
+  // single GPU: the sweep writes its block partials straight into mapped host memory and the host adds them up (one launch less)
+  int nparts = 0;
+  int rc = sweep_residual_device(f, Rp.data(), nullptr, 0, 0, f->V, zc ? f->zc_packed + plen : f->d_scalar, &nparts, 0, zc);
   if (rc) return rc;
   if (!zc) VX_HIP(f, hipMemcpyAsync(f->h_scalar, f->d_scalar, sizeof(double), hipMemcpyDeviceToHost, f->stream));
   const bool spec = speculate && zc;
@@ -1515,7 +1540,7 @@ int li_joint_residual(vxba_factor* f, const double* states, const double* imus, 
   }
   if (rc) return rc;
   if (!ok) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
-  *residual = r1 + (zc ? f->h_packed[plen] : f->h_scalar[0]);
+  *residual = r1 + (zc ? host_sum_partials(f->h_partial2, nparts) : f->h_scalar[0]);
   return VXBA_OK;
 }
 }  // namespace

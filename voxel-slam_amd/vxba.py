@@ -585,7 +585,8 @@ class LI_BA_Optimizer:
         n = LI_DIM * W
         st = _c(x_stats).copy()
         blobs = self._blobs(imus_factor)
-        hess = np.zeros((n, n)); trace = np.zeros((max(max_iter, 1), TRACE_COLS)); nt = C.c_int(0)
+        hess = np.empty((n, n)) if max_iter > 0 else np.zeros((n, n))   # written in full by the library when an iteration runs
+        trace = np.zeros((max(max_iter, 1), TRACE_COLS)); nt = C.c_int(0)
         voxhess._chk(voxhess._L.vxba_li_damping_iter(voxhess.handle, st, blobs, self.imu_coef, int(max_iter), hess.ctypes.data_as(C.c_void_p),
                                                      trace.ctypes.data_as(C.c_void_p), C.byref(nt)))
         for f, b in zip(imus_factor, blobs):
@@ -601,7 +602,8 @@ class LI_BA_OptimizerGravity(LI_BA_Optimizer):
         n = LI_DIM * W + 3
         st = _c(x_stats).copy()
         blobs = self._blobs(imus_factor)
-        hess = np.zeros((n, n)); resis = np.zeros(2); trace = np.zeros((max(max_iter, 1), TRACE_COLS)); nt = C.c_int(0)
+        hess = np.empty((n, n)) if max_iter > 0 else np.zeros((n, n))
+        resis = np.zeros(2); trace = np.zeros((max(max_iter, 1), TRACE_COLS)); nt = C.c_int(0)
         voxhess._chk(voxhess._L.vxba_li_damping_iter_gravity(voxhess.handle, st, blobs, self.imu_coef, int(max_iter), hess.ctypes.data_as(C.c_void_p),
                                                              resis, trace.ctypes.data_as(C.c_void_p), C.byref(nt)))
         for f, b in zip(imus_factor, blobs):
