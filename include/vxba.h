@@ -448,6 +448,11 @@ int vxba_get_kernel_times(vxba_factor* f, double ms_sum[4], int64_t calls[4], in
 /* Algorithmic bytes of one full sweep over the current factor: 0 = K3, 1 = K2. */
 int vxba_algorithmic_bytes(const vxba_factor* f, double bytes[2]);
 int vxba_nnz(vxba_factor* f, int64_t* nnz);
+/* Device memory the factor holds right now, in bytes: [0] the factor itself (cluster storage -- frame-major planes, or the compressed
+ * rows of a window wider than VXBA_MAX_WIN -- per-voxel planes, batch-major copy, cache snapshot), [1] sweep work space (block
+ * partials, packed system; for wide windows the pair index, the row buffer and the dense solver), [2] grow-only staging / scratch
+ * left behind by the push calls, [3] the sum. */
+int vxba_device_bytes(const vxba_factor* f, int64_t bytes[4]);
 
 /* Debug: D(16x16, row-major) = A(16x4) B(4x16) through one v_mfma_f64_16x16x4_f64 with the lane maps the Hessian
  * kernel relies on (unit-tested on the GPU so a wrong operand layout is caught in isolation). */

@@ -144,3 +144,43 @@ def test_push_voxels_csr_equals_the_dense_push(vx, W, V, p_obs):
     with pytest.raises(vx.VxbaError):
         fc.push_voxels_csr(rp, bad_fr, cl, sc.fix, sc.coe)
     assert fc.size() == V
+
+
+def test_wide_factor_stores_compressed_rows(vx):
+    """A window wider than VXBA_MAX_WIN keeps its clusters as compressed rows over the observed (voxel, frame) entries: the footprint
+    follows nnz, not V x W; vxba_nnz counts the observed entries; the cell-table push (vxba_push_points, dense frame-major cells) lands
+    in the same store bit for bit; clear() empties it."""
+    W, V = 99, 6000
+    sc = synth.make_scene(win_size=W, pts_per_scan=9000, n_voxels=V, p_obs=0.05, fix_frac=0.1, seed=1777)
+    rp, fr, cl = dense_to_csr(sc.clusters)
+    f = vx.LidarFactor(W)
+    f.push_voxels_csr(rp, fr, cl, sc.fix, sc.coe)
+    assert f.nnz() == sc.nnz == cl.shape[0]
+    b = f.device_bytes()
+    dense_planes = V * W * 80
+    assert b["store"] < 0.35 * dense_planes, (b, dense_planes)          # 6000 x 99 x 80 B = 47.5 MB dense; ~30k entries + per-voxel planes here
+    assert b["total"] == b["store"] + b["work"] + b["scratch"]
+    f.evaluate_only_residual(sc.poses_init)
+    H, J, r = f.acc_evaluate2(sc.poses_init)
+    # the same window through the dense push and through the cell table
+    fd = vx.LidarFactor(W); fd.push_voxels(sc.clusters, sc.fix, sc.coe); fd.evaluate_only_residual(sc.poses_init)
+    Hd, Jd, rd = fd.acc_evaluate2(sc.poses_init)
+    assert np.array_equal(H, Hd) and np.array_equal(J, Jd) and r == rd
+    fp = vx.LidarFactor(W); fp.push_points(V, sc.points_body, sc.cell_ptr, sc.fix, sc.coe)
+    got = fp.read_clusters()
+    assert np.array_equal(got[:, :, 9], sc.clusters[:, :, 9]) and fp.nnz() == sc.nnz          # same incidence, same point counts
+    assert np.allclose(got, sc.clusters, rtol=1e-12, atol=1e-9)                               # sums in push order vs numpy's cumulative sums
+    fp.evaluate_only_residual(sc.poses_init)
+    Hp, Jp, rpp = fp.acc_evaluate2(sc.poses_init)
+    assert relerr(Hp, Hd) < 1e-9 and relerr(Jp, Jd) < 1e-9 and abs(rpp - rd) <= 1e-10 * abs(rd)
+    # growth across many small appends keeps rows and entries in place
+    fg = vx.LidarFactor(W)
+    for lo in range(0, V, 500):
+        hi = min(V, lo + 500)
+        fg.push_voxels_csr(rp[lo: hi + 1] - rp[lo], fr[rp[lo]: rp[hi]], cl[rp[lo]: rp[hi]], sc.fix[lo:hi], sc.coe[lo:hi])
+    assert np.array_equal(fg.read_clusters(), sc.clusters)
+    assert np.array_equal(fg.read_clusters(100, 137), sc.clusters[100:137])
+    f.clear()
+    assert f.size() == 0 and f.nnz() == 0
+    f.push_voxels_csr(rp[:101], fr[: rp[100]], cl[: rp[100]], sc.fix[:100], sc.coe[:100])
+    assert np.array_equal(f.read_clusters(), sc.clusters[:100])

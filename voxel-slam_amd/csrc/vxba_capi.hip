@@ -81,6 +81,7 @@ struct vxba_factor {
   } li;
   vxh::BandSchurWork li_bs;
   int opt[VXBA_OPT_COUNT] = {1, 1, 1, 0, 64, 0, 1};   // vxba_set_option; initial values may come from the environment (see vxba.h)
+  vxw::WideStore wstore;         // wide windows: the clusters, compressed rows over the observed (voxel, frame) entries (no cluster planes)
   vxw::WideIndex wide;           // wide windows: incidence structure (entries, entry pairs per Hessian block), rebuilt after a push
   bool wide_dirty = true;
   double* d_poses = nullptr;     // wide windows: W*12 poses on the device (the MFMA kernels take them by value)
@@ -138,7 +139,7 @@ int fail(vxba_factor* f, int code, const char* msg) {
   return code;
 }
 
-int n_planes(const vxba_factor* f) { return 10 * f->W + N_META_PLANES; }
+int n_planes(const vxba_factor* f) { return (f->W > VXBA_MAX_WIN ? 0 : 10 * f->W) + N_META_PLANES; }   // wide factors keep their clusters in f->wstore
 // win_size above VXBA_MAX_WIN: the sparse-incidence sweeps of vxba_wide.hip and the host-side LM shell
 bool is_wide(const vxba_factor* f) { return f->W > VXBA_MAX_WIN; }
 #define VX_NARROW_ONLY(f, what) \
@@ -174,7 +175,7 @@ FactorView view(const vxba_factor* f) {
   const size_t VS = (size_t)f->VS;
   double* p = f->planes;
   fv.clb = f->clb;
-  fv.cl = p;                     p += (size_t)10 * f->W * VS;
+  fv.cl = p;                     p += f->W > VXBA_MAX_WIN ? 0 : (size_t)10 * f->W * VS;   // wide: no cluster planes (never dereferenced)
   fv.fix = p;                    p += 10 * VS;
   fv.coe = p;                    p += VS;
   fv.eigval = p;                 p += 3 * VS;
@@ -185,6 +186,8 @@ FactorView view(const vxba_factor* f) {
   fv.W = f->W;
   return fv;
 }
+
+vxw::WideView wview(const vxba_factor* f) { return vxw::wide_view(view(f), f->wstore); }
 
 int ensure_staging(vxba_factor* f, size_t len) {
   if (len <= f->staging_len) return VXBA_OK;
@@ -216,6 +219,10 @@ int ensure_capacity(vxba_factor* f, int n_total) {
   f->planes = np;
   f->clb = nclb;
   f->VS = want;
+  if (is_wide(f)) {
+    const char* emsg = nullptr;
+    if (vxw::store_reserve(f->wstore, want, f->wstore.ES, f->V, f->stream, &emsg) != 0) return fail(f, VXBA_ERR_HIP, emsg ? emsg : "wide store: allocation failed");
+  }
   const size_t p2 = (size_t)want / 32 + 2;   // one partial per workgroup of 32..64 voxels (vxk::k2_voxels_per_block)
   if (p2 > f->partial2_len) {
     if (f->d_partial2) VX_HIP(f, hipFree(f->d_partial2));
@@ -384,12 +391,12 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c
     if (rcw) return rcw;
     if (f->wide_dirty || f->wide.V != f->V) {
       const char* emsg = nullptr;
-      if (vxw::build_index(view(f), f->V, f->wide, f->stream, &emsg) != 0) return fail(f, VXBA_ERR_HIP, emsg ? emsg : "wide index build failed");
+      if (vxw::build_index(wview(f), f->V, f->wide, f->stream, &emsg) != 0) return fail(f, VXBA_ERR_HIP, emsg ? emsg : "wide index build failed");
       f->wide_dirty = false;
     }
     {
       ScopedKernelTimer t(f, 0);
-      vxw::launch_k3_wide(view(f), f->d_poses, f->wide, head, end, d_out, f->d_partial2, f->stream);
+      vxw::launch_k3_wide(wview(f), f->d_poses, f->wide, head, end, d_out, f->d_partial2, f->stream);
     }
     VX_HIP(f, hipGetLastError());
     return shard_allreduce(f, d_out, plen);
@@ -440,7 +447,7 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, in
     int np;
     {
       ScopedKernelTimer t(f, 1);
-      np = vxw::launch_k2_wide(view(f), f->d_poses, head, end, f->d_partial2, f->stream);
+      np = vxw::launch_k2_wide(wview(f), f->d_poses, head, end, f->d_partial2, f->stream);
     }
     if (nparts_out) *nparts_out = np;
     vxk::launch_sum_partials(f->d_partial2, np, d_out, f->stream);
@@ -627,6 +634,7 @@ int vxba_destroy(vxba_factor* f) {
   for (auto e : f->free_events) hipEventDestroy(e);
   hipFree(f->planes); hipFree(f->clb); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2); if (f->h_partial2) hipHostFree(f->h_partial2);
   vxw::free_index(f->wide);
+  vxw::store_free(f->wstore);
   vxw::wide_solver_free(f->wide_solver);
   hipFree(f->own_packed); hipFree(f->d_count); hipFree(f->d_poses);
   if (f->h_poses) hipHostFree(f->h_poses);
@@ -645,6 +653,7 @@ int vxba_clear(vxba_factor* f) {
   VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
   f->V = 0;
+  f->wstore.nnz = 0;
   f->wide_dirty = true;
   f->snapshot_v = 0;
   return VXBA_OK;
@@ -659,6 +668,8 @@ int vxba_set_win_size(vxba_factor* f, int win_size) {
   hipSetDevice(f->device);
   if (f->planes) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->planes)); if (f->clb) VX_HIP(f, hipFree(f->clb)); f->planes = nullptr; f->clb = nullptr; }
   f->VS = 0;
+  vxw::store_free(f->wstore);
+  vxw::free_index(f->wide);
   f->W = win_size;
   return ensure_exchange(f);
 }
@@ -865,6 +876,17 @@ int vxba_use_external_buffers(vxba_factor* f, double* d_packed, double* d_scalar
   return VXBA_OK;
 }
 
+namespace {
+// wide factors: n voxels whose clusters sit densely on the device (d_dense[n][W][10], N == 0 = unobserved) -> appended to the store
+int wide_append_dense(vxba_factor* f, int n, const double* d_dense, int frame_major = 0) {
+  const char* emsg = nullptr;
+  const long long added = vxw::store_append_dense(f->wstore, f->V, n, d_dense, f->W, f->V, f->stream, &emsg, frame_major);
+  if (added < 0) return fail(f, VXBA_ERR_HIP, emsg ? emsg : "wide store: append failed");
+  f->wstore.nnz += added;
+  return VXBA_OK;
+}
+}  // namespace
+
 int vxba_push_voxels(vxba_factor* f, int n, const double* clusters, const double* fix, const double* coe, const double* eig_val,
                      const double* eig_vec, const double* merged) {
   VX_LOCK(f);
@@ -879,11 +901,15 @@ int vxba_push_voxels(vxba_factor* f, int n, const double* clusters, const double
   rc = ensure_staging(f, ncl);
   if (rc) return rc;
   VX_HIP(f, hipMemcpyAsync(f->staging, clusters, ncl * sizeof(double), hipMemcpyHostToDevice, f->stream));
-  vxk::launch_scatter_clusters(f->staging, view(f), f->V, n, f->stream);
-  if (!is_wide(f)) vxk::launch_build_clb(view(f), f->V, n, f->stream);
+  const long long nnz0 = f->wstore.nnz;
+  if (is_wide(f)) { rc = wide_append_dense(f, n, f->staging); if (rc) return rc; }
+  else {
+    vxk::launch_scatter_clusters(f->staging, view(f), f->V, n, f->stream);
+    vxk::launch_build_clb(view(f), f->V, n, f->stream);
+  }
   VX_HIP(f, hipStreamSynchronize(f->stream));
   rc = append_meta(f, f->V, n, fix, coe, eig_val, eig_vec, merged);
-  if (rc) return rc;
+  if (rc) { f->wstore.nnz = nnz0; return rc; }
   f->V += n;
   f->wide_dirty = true;
   return VXBA_OK;
@@ -936,14 +962,21 @@ int vxba_push_voxels_csr(vxba_factor* f, int n, const int64_t* row_ptr, const in
     VX_HIP(f, hipMemcpyAsync(d_fr, frame_idx, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, f->stream));
     VX_HIP(f, hipMemcpyAsync(d_cl, clusters, (size_t)nnz * 10 * sizeof(double), hipMemcpyHostToDevice, f->stream));
   }
-  vxk::launch_scatter_clusters_csr(d_ptr, d_fr, d_cl, view(f), f->V, n, d_bad, f->stream);
-  if (!is_wide(f)) vxk::launch_build_clb(view(f), f->V, n, f->stream);
+  if (is_wide(f)) {   // straight into the compressed-row store: nothing dense exists anywhere
+    const char* emsg = nullptr;
+    if (vxw::store_reserve(f->wstore, f->V + n, f->wstore.nnz + nnz, f->V, f->stream, &emsg) != 0) return fail(f, VXBA_ERR_HIP, emsg ? emsg : "wide store: allocation failed");
+    vxw::store_append_csr(f->wstore, f->V, n, d_ptr, d_fr, d_cl, nnz, f->W, d_bad, f->stream);
+  } else {
+    vxk::launch_scatter_clusters_csr(d_ptr, d_fr, d_cl, view(f), f->V, n, d_bad, f->stream);
+    vxk::launch_build_clb(view(f), f->V, n, f->stream);
+  }
   int bad = 0;
   VX_HIP(f, hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, f->stream));
   VX_HIP(f, hipStreamSynchronize(f->stream));
   if (bad) return fail(f, VXBA_ERR_ARG, "push_voxels_csr: frame indices must be strictly increasing inside a voxel and below win_size (nothing was appended)");
   rc = append_meta(f, f->V, n, fix, coe, eig_val, eig_vec, merged);
   if (rc) return rc;
+  if (is_wide(f)) f->wstore.nnz += nnz;
   f->V += n;
   f->wide_dirty = true;
   return VXBA_OK;
@@ -972,17 +1005,31 @@ int vxba_push_points(vxba_factor* f, int n_voxels, int64_t n_points, const doubl
   if (n_points) e = hipMemcpyAsync(d_xyz, xyz_body, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_ptr, cell_ptr, (size_t)(ncells + 1) * sizeof(int64_t), hipMemcpyHostToDevice, f->stream);
   if (e != hipSuccess) { cleanup(); f->err = std::string("push_points H2D: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
-  {
-    ScopedKernelTimer t(f, 3);
-    vxk::launch_k1_build(d_xyz, d_ptr, n_voxels, f->W, view(f), f->V, f->stream);
+  const long long nnz0 = f->wstore.nnz;
+  if (is_wide(f)) {
+    // cell sums (the caller's cell table is dense, frame-major: cell = frame * n_voxels + voxel) into a staging block of the same shape,
+    // from there into the compressed-row store
+    rc = ensure_staging(f, (size_t)n_voxels * f->W * 10);
+    if (rc) return rc;
+    {
+      ScopedKernelTimer t(f, 3);
+      vxk::launch_k1_build_aos(d_xyz, d_ptr, ncells, f->staging, f->stream);
+    }
+    rc = wide_append_dense(f, n_voxels, f->staging, 1);
+    if (rc) { f->wstore.nnz = nnz0; return rc; }
+  } else {
+    {
+      ScopedKernelTimer t(f, 3);
+      vxk::launch_k1_build(d_xyz, d_ptr, n_voxels, f->W, view(f), f->V, f->stream);
+    }
+    vxk::launch_build_clb(view(f), f->V, n_voxels, f->stream);
   }
-  if (!is_wide(f)) vxk::launch_build_clb(view(f), f->V, n_voxels, f->stream);
   e = hipStreamSynchronize(f->stream);
   if (e == hipSuccess) e = hipGetLastError();
   cleanup();
-  if (e != hipSuccess) { f->err = std::string("K1: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
+  if (e != hipSuccess) { f->wstore.nnz = nnz0; f->err = std::string("K1: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
   rc = append_meta(f, f->V, n_voxels, fix, coe, nullptr, nullptr, nullptr);
-  if (rc) return rc;
+  if (rc) { f->wstore.nnz = nnz0; return rc; }
   f->V += n_voxels;
   f->wide_dirty = true;
   return VXBA_OK;
@@ -999,7 +1046,8 @@ int vxba_read_clusters(vxba_factor* f, int head, int end, double* clusters) {
   const size_t len = (size_t)n * f->W * 10;
   rc = ensure_staging(f, len);
   if (rc) return rc;
-  vxk::launch_gather_clusters(view(f), head, n, f->staging, f->stream);
+  if (is_wide(f)) vxw::store_expand(f->wstore, head, n, f->W, f->staging, f->stream);
+  else vxk::launch_gather_clusters(view(f), head, n, f->staging, f->stream);
   VX_HIP(f, hipMemcpyAsync(clusters, f->staging, len * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   VX_HIP(f, hipStreamSynchronize(f->stream));
   return VXBA_OK;
@@ -1932,8 +1980,11 @@ static int voxelize_push_impl(vxba_factor* f, int64_t n_points, const double* xy
     const int v0 = f->V;
     vxv::fill(d_fix, n * 10, 0.0, f->stream);
     vxv::fill(d_coe, n, 1.0, f->stream);
-    vxk::launch_scatter_clusters(d_cl, fv, v0, (int)n, f->stream);
-    if (!is_wide(f)) vxk::launch_build_clb(fv, v0, (int)n, f->stream);
+    if (is_wide(f)) { rc = wide_append_dense(f, (int)n, d_cl); if (rc) return rc; }
+    else {
+      vxk::launch_scatter_clusters(d_cl, fv, v0, (int)n, f->stream);
+      vxk::launch_build_clb(fv, v0, (int)n, f->stream);
+    }
     vxk::launch_scatter_rows(d_fix, fv.fix, f->VS, v0, (int)n, 10, f->stream);
     vxk::launch_scatter_rows(d_coe, fv.coe, f->VS, v0, (int)n, 1, f->stream);
     vxk::launch_scatter_rows(d_ev, fv.eigval, f->VS, v0, (int)n, 3, f->stream);
@@ -1990,8 +2041,11 @@ int vxba_internal_push_voxels_device(vxba_factor* f, int n, const double* d_clus
   if (rc) return rc;
   const FactorView fv = view(f);
   const int v0 = f->V;
-  vxk::launch_scatter_clusters(d_clusters, fv, v0, n, f->stream);
-  if (!is_wide(f)) vxk::launch_build_clb(fv, v0, n, f->stream);
+  if (is_wide(f)) { rc = wide_append_dense(f, n, d_clusters); if (rc) return rc; }
+  else {
+    vxk::launch_scatter_clusters(d_clusters, fv, v0, n, f->stream);
+    vxk::launch_build_clb(fv, v0, n, f->stream);
+  }
   vxk::launch_scatter_rows(d_fix, fv.fix, f->VS, v0, n, 10, f->stream);
   vxk::launch_scatter_rows(d_coe, fv.coe, f->VS, v0, n, 1, f->stream);
   vxk::launch_scatter_rows(d_eigval, fv.eigval, f->VS, v0, n, 3, f->stream);
@@ -2080,12 +2134,33 @@ int vxba_nnz(vxba_factor* f, int64_t* nnz) {
   *nnz = 0;
   if (f->V == 0) return VXBA_OK;
   hipSetDevice(f->device);
+  if (is_wide(f)) {
+    const char* emsg = nullptr;
+    const long long c = vxw::store_count_observed(f->wstore, f->V, f->stream, &emsg);
+    if (c < 0) return fail(f, VXBA_ERR_HIP, emsg ? emsg : "nnz: count failed");
+    *nnz = c;
+    return VXBA_OK;
+  }
   VX_HIP(f, hipMemsetAsync(f->d_count, 0, sizeof(unsigned long long), f->stream));
   vxk::launch_count_nnz(view(f), f->V, f->d_count, f->stream);
   unsigned long long h = 0;
   VX_HIP(f, hipMemcpyAsync(&h, f->d_count, sizeof h, hipMemcpyDeviceToHost, f->stream));
   VX_HIP(f, hipStreamSynchronize(f->stream));
   *nnz = (int64_t)h;
+  return VXBA_OK;
+}
+
+int vxba_device_bytes(const vxba_factor* f, int64_t bytes[4]) {
+  VX_LOCK(const_cast<vxba_factor*>(f));
+  if (!f || !bytes) return VXBA_ERR_ARG;
+  const size_t d = sizeof(double);
+  size_t store = (size_t)n_planes(f) * f->VS * d + (f->snapshot ? (size_t)N_CACHE_PLANES * f->snapshot_vs * d : 0);
+  if (is_wide(f)) store += vxw::store_bytes(f->wstore);
+  else if (f->clb) store += vxk::k3_clb_len(f->W, f->VS) * d;
+  size_t work = f->partial2_len * d + f->partial3_len * d + f->xlen * d + sizeof(vxk::LMState);
+  if (is_wide(f)) work += vxw::index_bytes(f->wide, f->W) + vxw::wide_solver_bytes(f->wide_solver) + sizeof(double) * 12 * VXBA_MAX_WIN_WIDE;
+  const size_t scratch = f->staging_len * d + f->scratch_cap;
+  bytes[0] = (int64_t)store; bytes[1] = (int64_t)work; bytes[2] = (int64_t)scratch; bytes[3] = (int64_t)(store + work + scratch);
   return VXBA_OK;
 }
 

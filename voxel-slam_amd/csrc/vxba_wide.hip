@@ -2,9 +2,11 @@
 // (voxelslam.cpp:2485-2595, loop_refine.hpp:273-537) where a voxel is seen from a handful of the frames.  The MFMA kernels of
 // vxba_kernels.hip are built around 6W <= 64 dense columns; here the incidence is sparse, the Hessian is (6W)^2 = up to 768^2, and
 // the per-voxel work is sum over observed PAIRS -- so: same mathematics (vxm::k3_entry rows, H = blockdiag(D) - G^T G), different
-// mapping.  Storage is unchanged (frame-major planes, N == 0 marks an unobserved frame).
+// mapping.  Clusters live in a compressed-row store over the observed (voxel, frame) entries (WideStore, vxba_wide.h); the per-voxel
+// planes (fix, coe, cache) are those of every factor.
 #include "vxba_wide.h"
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -19,13 +21,14 @@ namespace vxw {
 
 using vxk::FactorView;
 
-__global__ __launch_bounds__(64) void k2_wide_kernel(FactorView fv, const double* __restrict__ poses, int head, int end, double* __restrict__ partial) {
+__global__ __launch_bounds__(64) void k2_wide_kernel(WideView wv, const double* __restrict__ poses, int head, int end, double* __restrict__ partial) {
   __shared__ double pl[12 * WIDE_MAXW];
+  const FactorView& fv = wv.fv;
   const int lane = threadIdx.x, W = fv.W;
   for (int k = lane; k < 12 * W; k += 64) pl[k] = poses[k];
   __syncthreads();
   const int a = head + blockIdx.x * 64 + lane;
-  const size_t VS = (size_t)fv.VS;
+  const size_t VS = (size_t)fv.VS, ES = (size_t)wv.ES;
   double res = 0.0;
   if (a < end) {
     double SP[6], Sv[3], SN, Up[9];
@@ -38,14 +41,13 @@ __global__ __launch_bounds__(64) void k2_wide_kernel(FactorView fv, const double
     for (int col = 0; col < 3; col++)
 #pragma unroll
       for (int row = 0; row < 3; row++) Up[3 * row + col] = fv.eigvec[(size_t)(3 * col + row) * VS + a];
-    for (int i = 0; i < W; i++) {
-      const double* c0 = fv.cl + (size_t)i * 10 * VS + a;
-      const double n = c0[9 * VS];
-      if (n == 0.0) continue;            // frame i did not observe this voxel (voxel_map.hpp:258)
+    const long long e1 = wv.eptr[a + 1];
+    for (long long e = wv.eptr[a]; e < e1; e++) {   // the voxel's observed frames, ascending (voxel_map.hpp:256-262)
+      const int i = wv.eframe[e];
       double c[10];
 #pragma unroll
-      for (int k = 0; k < 9; k++) c[k] = c0[(size_t)k * VS];
-      c[9] = n;
+      for (int k = 0; k < 10; k++) c[k] = wv.ecl[(size_t)k * ES + e];
+      if (c[9] == 0.0) continue;         // an entry without points contributes nothing (voxel_map.hpp:258)
       double R[9], p[3];
 #pragma unroll
       for (int r = 0; r < 3; r++)
@@ -99,44 +101,28 @@ __device__ __forceinline__ int sym6(int a, int b) { return a == 0 ? b : (a == 1 
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int ROWLEN = 45;   // per entry: rows 18 | g 6 | Drr 6 | Drt 9 | Dtt 6
 
-__global__ void wi_count_kernel(FactorView fv, int V, int* __restrict__ cnt) {
+__global__ void wi_paircount_kernel(const long long* __restrict__ eptr, int V, long long* __restrict__ pc) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < V) { const long long k = eptr[a + 1] - eptr[a]; pc[a] = k * (k + 1) / 2; }
+  if (a == V) pc[a] = 0;
+}
+// pairs of voxel a at pair_ptr[a]..: key, original position (payload of the sort) and the two entries
+__global__ void wi_fill_kernel(const long long* __restrict__ eptr, const int* __restrict__ eframe, int V, int W, const long long* __restrict__ pair_ptr,
+                               unsigned int* __restrict__ pair_key, unsigned int* __restrict__ pair_idx, unsigned int* __restrict__ pair_ei,
+                               unsigned int* __restrict__ pair_ej) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= V) return;
-  int k = 0;
-  for (int f = 0; f < fv.W; f++) k += fv.cl[((size_t)f * 10 + 9) * fv.VS + a] != 0.0 ? 1 : 0;
-  cnt[a] = k;
-}
-__global__ void wi_paircount_kernel(const int* __restrict__ cnt, int V, long long* __restrict__ pc) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a < V) pc[a] = (long long)cnt[a] * (cnt[a] + 1) / 2;
-}
-// entries of voxel a at entry_ptr[a]..; its pairs at pair_ptr[a]..
-__global__ void wi_fill_kernel(FactorView fv, int V, const long long* __restrict__ entry_ptr, const long long* __restrict__ pair_ptr,
-                               int* __restrict__ entry_voxel, int* __restrict__ entry_frame, unsigned int* __restrict__ pair_key,
-                               unsigned int* __restrict__ pair_idx) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= V) return;
-  const long long e0 = entry_ptr[a];
-  int k = 0;
-  for (int f = 0; f < fv.W; f++)
-    if (fv.cl[((size_t)f * 10 + 9) * fv.VS + a] != 0.0) { entry_voxel[e0 + k] = a; entry_frame[e0 + k] = f; k++; }
+  const long long e0 = eptr[a];
+  const int k = (int)(eptr[a + 1] - e0);
   long long p = pair_ptr[a];
   for (int i = 0; i < k; i++)
     for (int j = i; j < k; j++) {
-      pair_key[p] = (unsigned int)(entry_frame[e0 + i] * fv.W + entry_frame[e0 + j]);
-      pair_idx[p] = (unsigned int)p;      // payload of the sort: the record's original position (-> entries via pair_e)
+      pair_key[p] = (unsigned int)(eframe[e0 + i] * W + eframe[e0 + j]);
+      pair_idx[p] = (unsigned int)p;
+      pair_ei[p] = (unsigned int)(e0 + i);
+      pair_ej[p] = (unsigned int)(e0 + j);
       p++;
     }
-}
-__global__ void wi_pair_entries_kernel(int V, const int* __restrict__ cnt, const long long* __restrict__ entry_ptr, const long long* __restrict__ pair_ptr,
-                                       unsigned int* __restrict__ pair_ei, unsigned int* __restrict__ pair_ej) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= V) return;
-  const int k = cnt[a];
-  const long long e0 = entry_ptr[a];
-  long long p = pair_ptr[a];
-  for (int i = 0; i < k; i++)
-    for (int j = i; j < k; j++) { pair_ei[p] = (unsigned int)(e0 + i); pair_ej[p] = (unsigned int)(e0 + j); p++; }
 }
 __global__ void wi_gather_kernel(const unsigned int* __restrict__ order, long long np, const unsigned int* __restrict__ ei, const unsigned int* __restrict__ ej,
                                  unsigned int* __restrict__ sei, unsigned int* __restrict__ sej) {
@@ -147,22 +133,21 @@ __global__ void wi_widen_kernel(const unsigned int* __restrict__ in, long long n
   const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < n) out[q] = (long long)in[q];
 }
-__global__ void wi_widen_int_kernel(const int* __restrict__ in, long long n, long long* __restrict__ out) {
-  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < n) out[q] = (long long)in[q];
-}
 
 // (A) one lane per entry
-__global__ __launch_bounds__(256) void k3w_rows_kernel(FactorView fv, const double* __restrict__ poses, const int* __restrict__ entry_voxel,
-                                                       const int* __restrict__ entry_frame, long long nnz, int head, int end, double* __restrict__ rowbuf) {
+__global__ __launch_bounds__(256) void k3w_rows_kernel(WideView wv, const double* __restrict__ poses, int head, int end, double* __restrict__ rowbuf) {
   __shared__ double pl[12 * WIDE_MAXW];
+  const FactorView& fv = wv.fv;
   for (int k = threadIdx.x; k < 12 * fv.W; k += blockDim.x) pl[k] = poses[k];
   __syncthreads();
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nnz) return;
-  const int a = entry_voxel[e], f = entry_frame[e];
+  if (e >= wv.nnz) return;
+  const int a = wv.evoxel[e], f = wv.eframe[e];
   double* out = rowbuf + (size_t)e * ROWLEN;
-  if (a < head || a >= end) {           // outside the requested voxel range: contributes nothing
+  double c[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) c[k] = wv.ecl[(size_t)k * (size_t)wv.ES + e];   // consecutive lanes, consecutive entries: coalesced
+  if (a < head || a >= end || c[9] == 0.0) {   // outside the requested voxel range, or an entry without points: contributes nothing
     for (int k = 0; k < ROWLEN; k++) out[k] = 0.0;
     return;
   }
@@ -177,9 +162,6 @@ __global__ __launch_bounds__(256) void k3w_rows_kernel(FactorView fv, const doub
   vc.s1 = fv.aux[a]; vc.s2 = fv.aux[VS + a]; vc.invN = fv.aux[2 * VS + a]; vc.sc = fv.aux[3 * VS + a]; vc.coe = fv.coe[a];
 #pragma unroll
   for (int k = 0; k < 3; k++) vc.vbar[k] = fv.merged[(size_t)(6 + k) * VS + a] * vc.invN;
-  double c[10];
-#pragma unroll
-  for (int k = 0; k < 10; k++) c[k] = fv.cl[((size_t)f * 10 + k) * VS + a];
   double R[9], p[3];
 #pragma unroll
   for (int r = 0; r < 3; r++)
@@ -287,55 +269,52 @@ __global__ __launch_bounds__(256) void k3w_residual_sum_kernel(const double* __r
   if (threadIdx.x == 0) out[0] = red[0];
 }
 
-int launch_k2_wide(const FactorView& fv, const double* d_poses, int head, int end, double* d_partial, hipStream_t s) {
+int launch_k2_wide(const WideView& wv, const double* d_poses, int head, int end, double* d_partial, hipStream_t s) {
   const int nblocks = (end - head + 63) / 64;
   if (nblocks <= 0) return 0;
-  k2_wide_kernel<<<dim3(nblocks), dim3(64), 0, s>>>(fv, d_poses, head, end, d_partial);
+  k2_wide_kernel<<<dim3(nblocks), dim3(64), 0, s>>>(wv, d_poses, head, end, d_partial);
   return nblocks;
 }
 
 void free_index(WideIndex& wi) {
-  void* ptrs[] = {wi.entry_voxel, wi.entry_frame, wi.sei, wi.sej, wi.key_list, wi.key_ptr, wi.rowbuf};
+  void* ptrs[] = {wi.sei, wi.sej, wi.key_list, wi.key_ptr, wi.rowbuf};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   wi = WideIndex();
 }
 
+size_t index_bytes(const WideIndex& wi, int W) {
+  if (!wi.sei) return 0;
+  return (size_t)wi.np * 8 + (size_t)W * W * 4 + (size_t)(wi.nkeys + 1) * 8 + (size_t)wi.nnz * ROWLEN * 8;
+}
+size_t store_bytes(const WideStore& st) { return (size_t)st.ES * (80 + 8) + (st.eptr ? ((size_t)st.vcap + 1) * 8 : 0) + st.tmp_cap; }
+
 #define WV(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { *err = hipGetErrorString(e_); return -1; } } while (0)
 
-int build_index(const FactorView& fv, int V, WideIndex& wi, hipStream_t s, const char** err) {
+int build_index(const WideView& wv, int V, WideIndex& wi, hipStream_t s, const char** err) {
   free_index(wi);
   wi.V = V;
   if (V == 0) return 0;
   struct Tmp { std::vector<void*> p; ~Tmp() { for (void* q : p) (void)hipFree(q); } } tmp;
   auto talloc = [&](void** q, size_t bytes) { hipError_t e = hipMalloc(q, bytes ? bytes : 8); if (e == hipSuccess) tmp.p.push_back(*q); return e; };
-  const unsigned gV = (unsigned)((V + 255) / 256);
-  int* cnt; long long *pc, *entry_ptr, *pair_ptr, *wide64;
-  WV(talloc((void**)&cnt, sizeof(int) * V));
+  const unsigned gV = (unsigned)((V + 256) / 256);
+  const int W = wv.fv.W;
+  long long *pc, *pair_ptr;
   WV(talloc((void**)&pc, sizeof(long long) * (V + 1)));
-  WV(talloc((void**)&wide64, sizeof(long long) * (V + 1)));
-  WV(talloc((void**)&entry_ptr, sizeof(long long) * (V + 1)));
   WV(talloc((void**)&pair_ptr, sizeof(long long) * (V + 1)));
-  wi_count_kernel<<<gV, 256, 0, s>>>(fv, V, cnt);
-  wi_paircount_kernel<<<gV, 256, 0, s>>>(cnt, V, pc);
-  wi_widen_int_kernel<<<gV, 256, 0, s>>>(cnt, V, wide64);
+  wi_paircount_kernel<<<gV, 256, 0, s>>>(wv.eptr, V, pc);
   size_t tb = 0, t1 = 0;
-  WV(rocprim::exclusive_scan(nullptr, tb, wide64, entry_ptr, 0ll, (size_t)V + 1, rocprim::plus<long long>(), s));
+  WV(rocprim::exclusive_scan(nullptr, tb, pc, pair_ptr, 0ll, (size_t)V + 1, rocprim::plus<long long>(), s));
   char* d_temp;
   WV(talloc((void**)&d_temp, tb));
   t1 = tb;
-  WV(rocprim::exclusive_scan(d_temp, t1, wide64, entry_ptr, 0ll, (size_t)V + 1, rocprim::plus<long long>(), s));
-  t1 = tb;
   WV(rocprim::exclusive_scan(d_temp, t1, pc, pair_ptr, 0ll, (size_t)V + 1, rocprim::plus<long long>(), s));
-  long long tot[2];
-  WV(hipMemcpyAsync(&tot[0], entry_ptr + V, sizeof(long long), hipMemcpyDeviceToHost, s));
-  WV(hipMemcpyAsync(&tot[1], pair_ptr + V, sizeof(long long), hipMemcpyDeviceToHost, s));
+  long long tot = 0;
+  WV(hipMemcpyAsync(&tot, pair_ptr + V, sizeof(long long), hipMemcpyDeviceToHost, s));
   WV(hipStreamSynchronize(s));
-  wi.nnz = tot[0];
-  wi.np = tot[1];
-  if (wi.np >= 0xffffffffll) { *err = "wide index: more than 2^32 entry pairs"; return -1; }
+  wi.nnz = wv.nnz;
+  wi.np = tot;
+  if (wi.np >= 0xffffffffll || wi.nnz >= 0xffffffffll) { *err = "wide index: more than 2^32 entries or entry pairs"; return -1; }
   if (wi.nnz == 0) return 0;
-  WV(hipMalloc((void**)&wi.entry_voxel, sizeof(int) * wi.nnz));
-  WV(hipMalloc((void**)&wi.entry_frame, sizeof(int) * wi.nnz));
   WV(hipMalloc((void**)&wi.sei, sizeof(unsigned int) * wi.np));
   WV(hipMalloc((void**)&wi.sej, sizeof(unsigned int) * wi.np));
   WV(hipMalloc((void**)&wi.rowbuf, sizeof(double) * ROWLEN * wi.nnz));
@@ -343,10 +322,9 @@ int build_index(const FactorView& fv, int V, WideIndex& wi, hipStream_t s, const
   WV(talloc((void**)&pkey, sizeof(unsigned int) * wi.np)); WV(talloc((void**)&pidx, sizeof(unsigned int) * wi.np));
   WV(talloc((void**)&pkey_s, sizeof(unsigned int) * wi.np)); WV(talloc((void**)&pidx_s, sizeof(unsigned int) * wi.np));
   WV(talloc((void**)&pei, sizeof(unsigned int) * wi.np)); WV(talloc((void**)&pej, sizeof(unsigned int) * wi.np));
-  const size_t maxkeys = (size_t)fv.W * fv.W;
+  const size_t maxkeys = (size_t)W * W;
   WV(talloc((void**)&kcnt, sizeof(unsigned int) * maxkeys)); WV(talloc((void**)&nruns, sizeof(unsigned int)));
-  wi_fill_kernel<<<gV, 256, 0, s>>>(fv, V, entry_ptr, pair_ptr, wi.entry_voxel, wi.entry_frame, pkey, pidx);
-  wi_pair_entries_kernel<<<gV, 256, 0, s>>>(V, cnt, entry_ptr, pair_ptr, pei, pej);
+  wi_fill_kernel<<<gV, 256, 0, s>>>(wv.eptr, wv.eframe, V, W, pair_ptr, pkey, pidx, pei, pej);
   int key_bits = 1;
   while ((1u << key_bits) < maxkeys) key_bits++;
   size_t tb2 = 0;
@@ -379,18 +357,172 @@ int build_index(const FactorView& fv, int V, WideIndex& wi, hipStream_t s, const
   return 0;
 }
 
-void launch_k3_wide(const FactorView& fv, const double* d_poses, const WideIndex& wi, int head, int end, double* d_packed, double* d_partial,
+void launch_k3_wide(const WideView& wv, const double* d_poses, const WideIndex& wi, int head, int end, double* d_packed, double* d_partial,
                     hipStream_t s) {
+  const FactorView& fv = wv.fv;
   const int n = 6 * fv.W;
   (void)hipMemsetAsync(d_packed, 0, ((size_t)n * n + n + 1) * sizeof(double), s);
   if (end <= head || wi.nnz == 0) return;
-  k3w_rows_kernel<<<dim3((unsigned)((wi.nnz + 255) / 256)), dim3(256), 0, s>>>(fv, d_poses, wi.entry_voxel, wi.entry_frame, wi.nnz, head, end, wi.rowbuf);
+  k3w_rows_kernel<<<dim3((unsigned)((wi.nnz + 255) / 256)), dim3(256), 0, s>>>(wv, d_poses, head, end, wi.rowbuf);
   k3w_blocks_kernel<<<dim3((unsigned)((wi.nkeys + 3) / 4)), dim3(256), 0, s>>>(wi.key_list, wi.key_ptr, wi.nkeys, wi.sei, wi.sej, wi.rowbuf, fv.W, d_packed);
   const int nparts = (end - head + 63) / 64;
   k3w_residual_kernel<<<dim3(nparts), dim3(64), 0, s>>>(fv, head, end, d_partial);
   k3w_residual_sum_kernel<<<dim3(1), dim3(256), 0, s>>>(d_partial, nparts, d_packed + (size_t)n * n + n);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The compressed-row cluster store (WideStore, vxba_wide.h)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void st_copy_planes_kernel(const double* __restrict__ src, long long src_es, double* __restrict__ dst, long long dst_es, long long n) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) dst[(size_t)blockIdx.y * dst_es + e] = src[(size_t)blockIdx.y * src_es + e];
+}
+// one lane per new voxel: its entries from the caller's compressed rows; frames must rise strictly and stay below W
+__global__ void st_append_csr_kernel(const long long* __restrict__ ptr, const int* __restrict__ fr, const double* __restrict__ cl, int n, int W, int v0,
+                                     long long e_base, double* __restrict__ ecl, long long ES, long long* __restrict__ eptr, int* __restrict__ eframe,
+                                     int* __restrict__ evoxel, int* __restrict__ bad) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  const long long p0 = ptr[a], p1 = ptr[a + 1];
+  int prev = -1;
+  for (long long q = p0; q < p1; q++) {
+    const int f = fr[q];
+    if (f <= prev || f >= W) { atomicOr(bad, 1); return; }
+    prev = f;
+    const long long e = e_base + q;
+    eframe[e] = f;
+    evoxel[e] = v0 + a;
+#pragma unroll
+    for (int k = 0; k < 10; k++) ecl[(size_t)k * ES + e] = cl[(size_t)q * 10 + k];
+  }
+  eptr[v0 + a + 1] = e_base + p1;
+}
+// dense input: cluster of (voxel a, frame f) at dense[cell * 10], cell = a * W + f (voxel-major) or f * n + a (frame-major)
+__device__ __forceinline__ size_t st_cell(int a, int f, int n, int W, int frame_major) { return frame_major ? (size_t)f * n + a : (size_t)a * W + f; }
+__global__ void st_count_dense_kernel(const double* __restrict__ dense, int n, int W, int frame_major, long long* __restrict__ cnt) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a > n) return;
+  long long k = 0;
+  if (a < n)
+    for (int f = 0; f < W; f++) k += dense[st_cell(a, f, n, W, frame_major) * 10 + 9] != 0.0 ? 1 : 0;
+  cnt[a] = k;   // cnt[n] = 0: the scan leaves the total there
+}
+__global__ void st_append_dense_kernel(const double* __restrict__ dense, const long long* __restrict__ ptr, int n, int W, int frame_major, int v0, long long e_base,
+                                       double* __restrict__ ecl, long long ES, long long* __restrict__ eptr, int* __restrict__ eframe, int* __restrict__ evoxel) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  long long e = e_base + ptr[a];
+  for (int f = 0; f < W; f++) {
+    const double* c = dense + st_cell(a, f, n, W, frame_major) * 10;
+    if (c[9] == 0.0) continue;
+    eframe[e] = f;
+    evoxel[e] = v0 + a;
+#pragma unroll
+    for (int k = 0; k < 10; k++) ecl[(size_t)k * ES + e] = c[k];
+    e++;
+  }
+  eptr[v0 + a + 1] = e;
+}
+__global__ void st_expand_kernel(const double* __restrict__ ecl, long long ES, const long long* __restrict__ eptr, const int* __restrict__ eframe, int head, int n,
+                                 int W, double* __restrict__ dense) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  for (long long e = eptr[head + a]; e < eptr[head + a + 1]; e++) {
+    double* o = dense + ((size_t)a * W + eframe[e]) * 10;
+#pragma unroll
+    for (int k = 0; k < 10; k++) o[k] = ecl[(size_t)k * ES + e];
+  }
+}
+__global__ void st_count_observed_kernel(const double* __restrict__ npl, long long nnz, unsigned long long* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool one = e < nnz && npl[e] != 0.0;
+  const unsigned long long m = __ballot(one);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+
+void store_free(WideStore& st) {
+  void* ptrs[] = {st.ecl, st.eptr, st.eframe, st.evoxel, st.tmp};
+  for (void* q : ptrs) if (q) (void)hipFree(q);
+  st = WideStore();
+}
+static int store_tmp(WideStore& st, size_t bytes, hipStream_t s, const char** err) {
+  if (bytes <= st.tmp_cap) return 0;
+  WV(hipStreamSynchronize(s));
+  if (st.tmp) WV(hipFree(st.tmp));
+  st.tmp = nullptr; st.tmp_cap = 0;
+  WV(hipMalloc((void**)&st.tmp, bytes + bytes / 4));
+  st.tmp_cap = bytes + bytes / 4;
+  return 0;
+}
+int store_reserve(WideStore& st, int vcap, long long ecap, int V, hipStream_t s, const char** err) {
+  if (vcap > st.vcap || !st.eptr) {
+    const int want = std::max(std::max(vcap, 2 * st.vcap), 64);
+    long long* np = nullptr;
+    WV(hipMalloc((void**)&np, sizeof(long long) * ((size_t)want + 1)));
+    if (st.eptr) WV(hipMemcpyAsync(np, st.eptr, sizeof(long long) * ((size_t)V + 1), hipMemcpyDeviceToDevice, s));
+    else WV(hipMemsetAsync(np, 0, sizeof(long long), s));
+    if (st.eptr) { WV(hipStreamSynchronize(s)); WV(hipFree(st.eptr)); }
+    st.eptr = np;
+    st.vcap = want;
+  }
+  if (ecap > st.ES) {
+    const long long want = (std::max(std::max(ecap, 2 * st.ES), 1024ll) + 63) / 64 * 64;
+    double* ncl = nullptr; int *nf = nullptr, *nv = nullptr;
+    WV(hipMalloc((void**)&ncl, sizeof(double) * 10 * (size_t)want));
+    WV(hipMalloc((void**)&nf, sizeof(int) * (size_t)want));
+    WV(hipMalloc((void**)&nv, sizeof(int) * (size_t)want));
+    if (st.nnz > 0) {
+      st_copy_planes_kernel<<<dim3((unsigned)((st.nnz + 255) / 256), 10), 256, 0, s>>>(st.ecl, st.ES, ncl, want, st.nnz);
+      WV(hipMemcpyAsync(nf, st.eframe, sizeof(int) * (size_t)st.nnz, hipMemcpyDeviceToDevice, s));
+      WV(hipMemcpyAsync(nv, st.evoxel, sizeof(int) * (size_t)st.nnz, hipMemcpyDeviceToDevice, s));
+    }
+    if (st.ecl) { WV(hipStreamSynchronize(s)); WV(hipFree(st.ecl)); WV(hipFree(st.eframe)); WV(hipFree(st.evoxel)); }
+    st.ecl = ncl; st.eframe = nf; st.evoxel = nv;
+    st.ES = want;
+  }
+  return 0;
+}
+void store_append_csr(WideStore& st, int v0, int n, const long long* d_ptr, const int* d_fr, const double* d_cl, long long nnz_new, int W, int* d_bad,
+                      hipStream_t s) {
+  (void)nnz_new;
+  st_append_csr_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(d_ptr, d_fr, d_cl, n, W, v0, st.nnz, st.ecl, st.ES, st.eptr, st.eframe, st.evoxel, d_bad);
+}
+long long store_append_dense(WideStore& st, int v0, int n, const double* d_dense, int W, int V, hipStream_t s, const char** err, int frame_major) {
+  if (n <= 0) return 0;
+  size_t tb = 0;
+  long long* dummy = nullptr;
+  if (rocprim::exclusive_scan(nullptr, tb, dummy, dummy, 0ll, (size_t)n + 1, rocprim::plus<long long>(), s) != hipSuccess) { *err = "scan sizing failed"; return -1; }
+  const size_t b_cnt = (sizeof(long long) * ((size_t)n + 1) + 255) / 256 * 256;
+  if (store_tmp(st, 2 * b_cnt + tb + 256, s, err)) return -1;
+  long long* cnt = (long long*)st.tmp;
+  long long* ptr = (long long*)(st.tmp + b_cnt);
+  char* d_temp = st.tmp + 2 * b_cnt;
+  st_count_dense_kernel<<<(unsigned)((n + 256) / 256), 256, 0, s>>>(d_dense, n, W, frame_major, cnt);
+  if (rocprim::exclusive_scan(d_temp, tb, cnt, ptr, 0ll, (size_t)n + 1, rocprim::plus<long long>(), s) != hipSuccess) { *err = "scan failed"; return -1; }
+  long long tot = 0;
+  if (hipMemcpyAsync(&tot, ptr + n, sizeof(long long), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { *err = "append_dense: D2H failed"; return -1; }
+  if (store_reserve(st, v0 + n, st.nnz + tot, V, s, err)) return -1;
+  st_append_dense_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(d_dense, ptr, n, W, frame_major, v0, st.nnz, st.ecl, st.ES, st.eptr, st.eframe, st.evoxel);
+  return tot;
+}
+void store_expand(const WideStore& st, int head, int n, int W, double* d_dense, hipStream_t s) {
+  if (n <= 0) return;
+  (void)hipMemsetAsync(d_dense, 0, sizeof(double) * (size_t)n * W * 10, s);
+  st_expand_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(st.ecl, st.ES, st.eptr, st.eframe, head, n, W, d_dense);
+}
+long long store_count_observed(const WideStore& st, int V, hipStream_t s, const char** err) {
+  (void)V;
+  if (st.nnz == 0) return 0;
+  WideStore& mst = const_cast<WideStore&>(st);
+  if (store_tmp(mst, 256, s, err)) return -1;
+  unsigned long long* d = (unsigned long long*)mst.tmp;
+  unsigned long long h = 0;
+  if (hipMemsetAsync(d, 0, sizeof h, s) != hipSuccess) { *err = "count: memset failed"; return -1; }
+  st_count_observed_kernel<<<(unsigned)((st.nnz + 255) / 256), 256, 0, s>>>(st.ecl + (size_t)9 * st.ES, st.nnz, d);
+  if (hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { *err = "count: D2H failed"; return -1; }
+  return (long long)h;
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Dense solve of the wide LM step on the device: (H + u D) dxi = -JacT with the gauge rows / columns replaced by identity,
@@ -622,6 +754,11 @@ void wide_solver_free(DenseSolver*& ds) {
 }
 
 // nullptr if the buffers cannot be allocated (caller falls back to the host solve)
+size_t wide_solver_bytes(const DenseSolver* ds) {
+  if (!ds) return 0;
+  const size_t n = (size_t)ds->n;
+  return 8 * ((n + 1) * n + n + ((n + WC_NB - 1) / WC_NB) * WC_NB * WC_NB + n + n + 2) + 4;
+}
 DenseSolver* wide_solver_create(int n, hipStream_t) {
   DenseSolver* ds = new DenseSolver();
   ds->n = n;

@@ -30,7 +30,7 @@ EXPORTS = [
     "vxba_reserve", "vxba_last_error", "vxba_push_voxels", "vxba_push_points", "vxba_read_clusters", "vxba_acc_evaluate2",
     "vxba_evaluate_only_residual", "vxba_acc_evaluate2_device", "vxba_evaluate_only_residual_device", "vxba_packed_len",
     "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_plane_fit_judge", "vxba_build_clusters", "vxba_set_allreduce",
-    "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_attach_bcast", "vxba_rccl_detach", "vxba_peer_export", "vxba_peer_attach", "vxba_peer_detach", "vxba_peer_status", "vxba_peer_selftest", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_debug_mfma_probe", "vxba_debug_stamps", "vxba_debug_band_schur", "vxba_push_voxels_csr",
+    "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_attach_bcast", "vxba_rccl_detach", "vxba_peer_export", "vxba_peer_attach", "vxba_peer_detach", "vxba_peer_status", "vxba_peer_selftest", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_device_bytes", "vxba_debug_mfma_probe", "vxba_debug_stamps", "vxba_debug_band_schur", "vxba_push_voxels_csr",
     "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_li_evaluate",
     "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity", "vxba_voxelize_push", "vxba_set_precision",
     "vxba_lio_create", "vxba_lio_destroy", "vxba_lio_last_error", "vxba_lio_map_update", "vxba_lio_map_clear", "vxba_lio_map_size", "vxba_lio_scan_raw",
@@ -120,6 +120,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_get_kernel_times.argtypes = [vp, _f64p, _i64p, ci]
     L.vxba_algorithmic_bytes.argtypes = [vp, _f64p]
     L.vxba_nnz.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.vxba_device_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
     L.vxba_debug_mfma_probe.argtypes = [ci, _f64p, _f64p, _f64p]
     L.vxba_debug_stamps.argtypes = [ci, vp, C.c_size_t]
     L.vxba_imu_init.argtypes = [_f64p, vp, vp]
@@ -454,6 +455,12 @@ class LidarFactor:
         v = C.c_int64(0)
         self._chk(self._L.vxba_nnz(self._h, C.byref(v)))
         return v.value
+
+    def device_bytes(self):
+        """Device memory held by the factor: dict(store, work, scratch, total) in bytes (vxba_device_bytes)."""
+        b = (C.c_int64 * 4)()
+        self._chk(self._L.vxba_device_bytes(self._h, b))
+        return dict(store=int(b[0]), work=int(b[1]), scratch=int(b[2]), total=int(b[3]))
 
     def lm_steps(self, xs_init, n_steps, steps_per_solve=3):
         """Bench driver: returns (poses, [residual1, residual2] of the last step, dict(iters, accepted, rejected))."""
