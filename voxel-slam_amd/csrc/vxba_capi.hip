@@ -877,6 +877,15 @@ int vxba_use_external_buffers(vxba_factor* f, double* d_packed, double* d_scalar
 }
 
 namespace {
+// Wide factors are filled by a few big pushes (a top-level window of the hierarchical BA), not by a stream of small ones: the
+// grow-only staging / scratch buffers of the push calls are handed back afterwards when they are large (they would otherwise
+// outweigh the compressed-row store itself).
+void release_push_buffers(vxba_factor* f) {
+  if (!is_wide(f)) return;
+  const size_t keep = (size_t)16 << 20;
+  if (f->staging && f->staging_len * sizeof(double) > keep) { (void)hipStreamSynchronize(f->stream); (void)hipFree(f->staging); f->staging = nullptr; f->staging_len = 0; }
+  if (f->d_scratch && f->scratch_cap > keep) { (void)hipStreamSynchronize(f->stream); (void)hipFree(f->d_scratch); f->d_scratch = nullptr; f->scratch_cap = 0; }
+}
 // wide factors: n voxels whose clusters sit densely on the device (d_dense[n][W][10], N == 0 = unobserved) -> appended to the store
 int wide_append_dense(vxba_factor* f, int n, const double* d_dense, int frame_major = 0) {
   const char* emsg = nullptr;
@@ -912,6 +921,7 @@ int vxba_push_voxels(vxba_factor* f, int n, const double* clusters, const double
   if (rc) { f->wstore.nnz = nnz0; return rc; }
   f->V += n;
   f->wide_dirty = true;
+  release_push_buffers(f);
   return VXBA_OK;
 }
 
@@ -979,6 +989,7 @@ int vxba_push_voxels_csr(vxba_factor* f, int n, const int64_t* row_ptr, const in
   if (is_wide(f)) f->wstore.nnz += nnz;
   f->V += n;
   f->wide_dirty = true;
+  release_push_buffers(f);
   return VXBA_OK;
 }
 
@@ -1032,6 +1043,7 @@ int vxba_push_points(vxba_factor* f, int n_voxels, int64_t n_points, const doubl
   if (rc) { f->wstore.nnz = nnz0; return rc; }
   f->V += n_voxels;
   f->wide_dirty = true;
+  release_push_buffers(f);
   return VXBA_OK;
 }
 
@@ -1999,6 +2011,7 @@ static int voxelize_push_impl(vxba_factor* f, int64_t n_points, const double* xy
     f->wide_dirty = true;
   }
   *n_pushed = n;
+  release_push_buffers(f);
   return VXBA_OK;
 }
 

@@ -9,11 +9,12 @@ namespace vxw {
 constexpr int WIDE_MAXW = 128;
 
 // Cluster store of a wide factor: compressed rows (loop_refine.hpp:358-405 -- a voxel of the top-level window is seen from
-// a handful of ~100 submap poses).  Entries (voxel, frame) voxel-major, frames ascending inside a voxel; the ten cluster components as
-// planes over the ENTRIES (cl[k * ES + e]): nnz x 80 bytes instead of V x W x 80 (0.8 GB at V = 100k, W = 99; 40 MB at five
-// observers per voxel).  The per-voxel planes (fix, coe, cache) stay as they are.
+// a handful of ~100 submap poses).  Entries (voxel, frame) voxel-major, frames ascending inside a voxel; an entry's cluster is ten
+// consecutive doubles (ecl[10 e ..]: the Hessian sweep GATHERS entries, so a cluster should be one or two cache lines, not ten):
+// nnz x 80 bytes instead of V x W x 80 (0.8 GB at V = 100k, W = 99; 40 MB at five observers per voxel).  The per-voxel planes (fix,
+// coe, cache) stay as they are.
 struct WideStore {
-  double* ecl = nullptr;        // [10][ES]
+  double* ecl = nullptr;        // [ES][10]
   long long* eptr = nullptr;    // [vcap + 1]; eptr[V] == nnz
   int* eframe = nullptr;        // [ES]
   int* evoxel = nullptr;        // [ES]
@@ -56,14 +57,21 @@ int launch_k2_wide(const WideView& wv, const double* d_poses, int head, int end,
 
 // Incidence structure of a wide factor (depends on the clusters only, not on the poses): for every 6x6 block of the Hessian, the run
 // of entry pairs (entries = the store's) that contribute to it.  Device arrays owned by the index.
+constexpr long long WIDE_TASK_RECORDS = 512;   // pair records per wave of the Hessian sweep
+constexpr int WIDE_VREC = 18;                   // doubles of a voxel's packed record for the Hessian sweep
+constexpr int WIDE_TASK_OUT = 42;               // a task's partial: 6x6 block + 6 gradient components
+struct WideTask { long long lo, hi; int key, pad; };
 struct WideIndex {
-  int V = 0, nkeys = 0;
+  int V = 0, nkeys = 0, ntasks = 0;
   long long nnz = 0, np = 0;
   unsigned int* sei = nullptr;           // [np] first entry of a pair, sorted by block key (frame_i * W + frame_j), voxel order inside
   unsigned int* sej = nullptr;           // [np] second entry
   unsigned int* key_list = nullptr;      // [nkeys] block keys present
   long long* key_ptr = nullptr;          // [nkeys + 1] runs of sei / sej
-  double* rowbuf = nullptr;              // [nnz][45] per-entry rows + gradient / block-diagonal terms of the current sweep
+  WideTask* tasks = nullptr;             // [ntasks] pieces of the runs, key by key
+  int* key_task_ptr = nullptr;           // [nkeys + 1] tasks of a key
+  double* task_partial = nullptr;        // [ntasks][WIDE_TASK_OUT] work space of the sweep
+  double* vrec = nullptr;                // [V][WIDE_VREC] packed per-voxel records, refreshed by every sweep
 };
 int build_index(const WideView& wv, int V, WideIndex& wi, hipStream_t s, const char** err);
 size_t index_bytes(const WideIndex& wi, int W);

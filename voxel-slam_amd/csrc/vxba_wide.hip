@@ -21,6 +21,14 @@ namespace vxw {
 
 using vxk::FactorView;
 
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+// an entry's cluster: ten consecutive doubles (80 bytes, 16-byte aligned) -- five 16-byte loads, one or two cache lines
+__device__ __forceinline__ void load_entry(const double* __restrict__ ecl, long long e, double c[10]) {
+  const v2d_t* q = reinterpret_cast<const v2d_t*>(ecl + (size_t)e * 10);
+#pragma unroll
+  for (int k = 0; k < 5; k++) { const v2d_t t = q[k]; c[2 * k] = t.x; c[2 * k + 1] = t.y; }
+}
+
 __global__ __launch_bounds__(64) void k2_wide_kernel(WideView wv, const double* __restrict__ poses, int head, int end, double* __restrict__ partial) {
   __shared__ double pl[12 * WIDE_MAXW];
   const FactorView& fv = wv.fv;
@@ -28,7 +36,7 @@ __global__ __launch_bounds__(64) void k2_wide_kernel(WideView wv, const double* 
   for (int k = lane; k < 12 * W; k += 64) pl[k] = poses[k];
   __syncthreads();
   const int a = head + blockIdx.x * 64 + lane;
-  const size_t VS = (size_t)fv.VS, ES = (size_t)wv.ES;
+  const size_t VS = (size_t)fv.VS;
   double res = 0.0;
   if (a < end) {
     double SP[6], Sv[3], SN, Up[9];
@@ -45,8 +53,7 @@ __global__ __launch_bounds__(64) void k2_wide_kernel(WideView wv, const double* 
     for (long long e = wv.eptr[a]; e < e1; e++) {   // the voxel's observed frames, ascending (voxel_map.hpp:256-262)
       const int i = wv.eframe[e];
       double c[10];
-#pragma unroll
-      for (int k = 0; k < 10; k++) c[k] = wv.ecl[(size_t)k * ES + e];
+      load_entry(wv.ecl, e, c);
       if (c[9] == 0.0) continue;         // an entry without points contributes nothing (voxel_map.hpp:258)
       double R[9], p[3];
 #pragma unroll
@@ -99,7 +106,6 @@ __device__ __forceinline__ int sym6(int a, int b) { return a == 0 ? b : (a == 1 
 // in registers, a fixed butterfly adds the lanes, and the block (and its mirror image) is written -- each block is owned by
 // exactly one wave, so the result is bitwise reproducible.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int ROWLEN = 45;   // per entry: rows 18 | g 6 | Drr 6 | Drt 9 | Dtt 6
 
 __global__ void wi_paircount_kernel(const long long* __restrict__ eptr, int V, long long* __restrict__ pc) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -134,91 +140,107 @@ __global__ void wi_widen_kernel(const unsigned int* __restrict__ in, long long n
   if (q < n) out[q] = (long long)in[q];
 }
 
-// (A) one lane per entry
-__global__ __launch_bounds__(256) void k3w_rows_kernel(WideView wv, const double* __restrict__ poses, int head, int end, double* __restrict__ rowbuf) {
-  __shared__ double pl[12 * WIDE_MAXW];
-  const FactorView& fv = wv.fv;
-  for (int k = threadIdx.x; k < 12 * fv.W; k += blockDim.x) pl[k] = poses[k];
-  __syncthreads();
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= wv.nnz) return;
-  const int a = wv.evoxel[e], f = wv.eframe[e];
-  double* out = rowbuf + (size_t)e * ROWLEN;
-  double c[10];
-#pragma unroll
-  for (int k = 0; k < 10; k++) c[k] = wv.ecl[(size_t)k * (size_t)wv.ES + e];   // consecutive lanes, consecutive entries: coalesced
-  if (a < head || a >= end || c[9] == 0.0) {   // outside the requested voxel range, or an entry without points: contributes nothing
-    for (int k = 0; k < ROWLEN; k++) out[k] = 0.0;
-    return;
-  }
+// Per-voxel record of what the Hessian sweep needs from the cache, packed: [u0 3 | u1 3 | u2 3 | vbar 3 | s1 s2 1/N sqrt(coe) coe | pad]
+// = 144 contiguous bytes.  The pair records of a block hit voxels in no particular order; gathering the 26 cache values from their
+// planes cost a 64-byte sector apiece (3 KB of traffic per record with the clusters laid out the same way: the sweep ran at the
+// speed of that traffic), the record costs three.  Rebuilt from the planes at the start of every sweep (one coalesced pass, ~10 us
+// at 100k voxels): whoever wrote the cache -- a residual sweep, a push with a seeded cache, a restored snapshot -- it is current.
+__global__ __launch_bounds__(256) void k3w_vrec_kernel(FactorView fv, int head, int end, double* __restrict__ vrec) {
+  const int a = head + blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= end) return;
   const size_t VS = (size_t)fv.VS;
-  vxm::VoxelCache vc;
+  double* o = vrec + (size_t)a * WIDE_VREC;
+  const double invN = fv.aux[2 * VS + a];
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
-    vc.u0[k] = fv.eigvec[(size_t)k * VS + a];
-    vc.u1[k] = fv.eigvec[(size_t)(3 + k) * VS + a];
-    vc.u2[k] = fv.eigvec[(size_t)(6 + k) * VS + a];
-  }
-  vc.s1 = fv.aux[a]; vc.s2 = fv.aux[VS + a]; vc.invN = fv.aux[2 * VS + a]; vc.sc = fv.aux[3 * VS + a]; vc.coe = fv.coe[a];
+  for (int k = 0; k < 9; k++) o[k] = fv.eigvec[(size_t)k * VS + a];
 #pragma unroll
-  for (int k = 0; k < 3; k++) vc.vbar[k] = fv.merged[(size_t)(6 + k) * VS + a] * vc.invN;
-  double R[9], p[3];
+  for (int k = 0; k < 3; k++) o[9 + k] = fv.merged[(size_t)(6 + k) * VS + a] * invN;
+  o[12] = fv.aux[a]; o[13] = fv.aux[VS + a]; o[14] = invN; o[15] = fv.aux[3 * VS + a]; o[16] = fv.coe[a]; o[17] = 0.0;
+}
+
+// One wave per TASK = up to WIDE_TASK_RECORDS consecutive pair records of one Hessian block (the lanes take one record each, a
+// latency-serial loop of gathers: a block of 5 000 self-pairs on one wave was 79 such rounds and set the length of the whole sweep;
+// now the longest wave does 8), then k3w_combine_kernel adds a block's task partials in task order.  A record's two entries belong to the same voxel and to the
+// block's two frames, so the lanes compute their rank-3 rows right here (vxm::k3_entry: ~230 fp64 operations per entry against the
+// 368 bytes a record gathers -- clusters of both entries + the voxel's cache) instead of reading them back from a row buffer that
+// an extra kernel had to fill first: 45 doubles per entry, 180 MB at nnz = 500k, gone, together with that kernel.
+__device__ __forceinline__ void k3w_pose(const double* pl, int f, double R[9], double p[3]) {
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = pl[12 * f + 3 * cc + r];
 #pragma unroll
   for (int k = 0; k < 3; k++) p[k] = pl[12 * f + 9 + k];
-  double rows[3][6], acc[27];
-#pragma unroll
-  for (int k = 0; k < 27; k++) acc[k] = 0.0;
-  vxm::k3_entry(c, c + 6, c[9], R, p, vc, rows, acc);
-#pragma unroll
-  for (int r = 0; r < 3; r++)
-#pragma unroll
-    for (int k = 0; k < 6; k++) out[6 * r + k] = rows[r][k];
-#pragma unroll
-  for (int k = 0; k < 27; k++) out[18 + k] = acc[k];
 }
-
-// (B) one wave per Hessian block (= run of pair records with one key)
-__global__ __launch_bounds__(256) void k3w_blocks_kernel(const unsigned int* __restrict__ key_list, const long long* __restrict__ key_ptr, int nkeys,
-                                                         const unsigned int* __restrict__ sei, const unsigned int* __restrict__ sej,
-                                                         const double* __restrict__ rowbuf, int W, double* __restrict__ packed) {
+__global__ __launch_bounds__(256) void k3w_blocks_kernel(WideView wv, const double* __restrict__ poses, int head, int end, const unsigned int* __restrict__ key_list,
+                                                         const WideTask* __restrict__ tasks, int ntasks, const unsigned int* __restrict__ sei,
+                                                         const unsigned int* __restrict__ sej, const double* __restrict__ vrec, double* __restrict__ task_partial) {
+  __shared__ double pl[12 * WIDE_MAXW];
+  const FactorView& fv = wv.fv;
+  const int W = fv.W;
+  for (int k = threadIdx.x; k < 12 * W; k += blockDim.x) pl[k] = poses[k];
+  __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int kq = blockIdx.x * 4 + wave;
-  if (kq >= nkeys) return;
-  const int n = 6 * W;
-  const unsigned int key = key_list[kq];
+  const int tq = blockIdx.x * 4 + wave;
+  if (tq >= ntasks) return;
+  const WideTask task = tasks[tq];
+  const unsigned int key = key_list[task.key];
   const int fi = (int)(key / (unsigned)W), fj = (int)(key % (unsigned)W);
   const bool diag = fi == fj;
   double s[36];
 #pragma unroll
   for (int e = 0; e < 36; e++) s[e] = 0.0;
   double g[6] = {0, 0, 0, 0, 0, 0};
-  for (long long q = key_ptr[kq] + lane; q < key_ptr[kq + 1]; q += 64) {
-    const double* ri = rowbuf + (size_t)sei[q] * ROWLEN;
-    const double* rj = rowbuf + (size_t)sej[q] * ROWLEN;
-    double a0[18], b0[18];
+  for (long long q = task.lo + lane; q < task.hi; q += 64) {
+    const unsigned int ei = sei[q], ej = sej[q];
+    const int a = wv.evoxel[ei];
+    if (a < head || a >= end) continue;          // outside the requested voxel range: contributes nothing
+    double ci[10], cj[10];
+    load_entry(wv.ecl, ei, ci);
+    load_entry(wv.ecl, ej, cj);
+    if (ci[9] == 0.0 || cj[9] == 0.0) continue;   // an entry without points has all-zero rows and terms
+    vxm::VoxelCache vc;
+    {
+      double t[WIDE_VREC];
+      const v2d_t* q2 = reinterpret_cast<const v2d_t*>(vrec + (size_t)a * WIDE_VREC);
 #pragma unroll
-    for (int k = 0; k < 18; k++) { a0[k] = ri[k]; b0[k] = rj[k]; }
+      for (int k = 0; k < WIDE_VREC / 2; k++) { const v2d_t u = q2[k]; t[2 * k] = u.x; t[2 * k + 1] = u.y; }
 #pragma unroll
-    for (int x = 0; x < 6; x++)
+      for (int k = 0; k < 3; k++) { vc.u0[k] = t[k]; vc.u1[k] = t[3 + k]; vc.u2[k] = t[6 + k]; vc.vbar[k] = t[9 + k]; }
+      vc.s1 = t[12]; vc.s2 = t[13]; vc.invN = t[14]; vc.sc = t[15]; vc.coe = t[16];
+    }
+    double R[9], p[3], ri[3][6], acc[27];
 #pragma unroll
-      for (int y = 0; y < 6; y++) s[6 * x + y] -= a0[x] * b0[y] + a0[6 + x] * b0[6 + y] + a0[12 + x] * b0[12 + y];
+    for (int k = 0; k < 27; k++) acc[k] = 0.0;
+    k3w_pose(pl, fi, R, p);
+    vxm::k3_entry(ci, ci + 6, ci[9], R, p, vc, ri, acc);
     if (diag) {          // self pair of an entry: its gradient and block-diagonal terms ride along
 #pragma unroll
-      for (int d = 0; d < 6; d++) g[d] += ri[18 + d];
+      for (int x = 0; x < 6; x++)
+#pragma unroll
+        for (int y = 0; y < 6; y++) s[6 * x + y] -= ri[0][x] * ri[0][y] + ri[1][x] * ri[1][y] + ri[2][x] * ri[2][y];
+#pragma unroll
+      for (int d = 0; d < 6; d++) g[d] += acc[d];
 #pragma unroll
       for (int x = 0; x < 3; x++)
 #pragma unroll
         for (int y = 0; y < 3; y++) {
-          const double rr = ri[24 + (x <= y ? sym6(x, y) : sym6(y, x))], tt = ri[39 + (x <= y ? sym6(x, y) : sym6(y, x))], rt = ri[30 + 3 * x + y];
+          const double rr = acc[6 + (x <= y ? sym6(x, y) : sym6(y, x))], tt = acc[21 + (x <= y ? sym6(x, y) : sym6(y, x))], rt = acc[12 + 3 * x + y];
           s[6 * x + y] += rr;
           s[6 * (3 + x) + 3 + y] += tt;
           s[6 * x + 3 + y] += rt;
           s[6 * (3 + y) + x] += rt;
         }
+    } else {
+      double rj[3][6], accj[27];
+#pragma unroll
+      for (int k = 0; k < 27; k++) accj[k] = 0.0;   // not read: the compiler drops the terms
+      k3w_pose(pl, fj, R, p);
+      vxm::k3_entry(cj, cj + 6, cj[9], R, p, vc, rj, accj);
+#pragma unroll
+      for (int x = 0; x < 6; x++)
+#pragma unroll
+        for (int y = 0; y < 6; y++) s[6 * x + y] -= ri[0][x] * rj[0][y] + ri[1][x] * rj[1][y] + ri[2][x] * rj[2][y];
     }
   }
   // fixed butterfly over the wave: every lane ends with the same bits
@@ -232,19 +254,32 @@ __global__ __launch_bounds__(256) void k3w_blocks_kernel(const unsigned int* __r
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) g[d] += __shfl_xor(g[d], m, 64);
   }
+  // the task's partial block (and gradient piece): [36 | 6]
+  double v = 0.0;
+#pragma unroll
+  for (int e = 0; e < 36; e++) v = (e == lane) ? s[e] : v;
+#pragma unroll
+  for (int e = 0; e < 6; e++) v = (36 + e == lane) ? g[e] : v;
+  if (lane < WIDE_TASK_OUT) task_partial[(size_t)tq * WIDE_TASK_OUT + lane] = v;
+}
+// Sum of a block's task partials in task order (fixed), written as block (fi, fj) and its mirror image; diagonal blocks carry the
+// gradient piece.  One 64-lane workgroup per key.
+__global__ __launch_bounds__(64) void k3w_combine_kernel(const unsigned int* __restrict__ key_list, const int* __restrict__ key_task_ptr, int nkeys,
+                                                         const double* __restrict__ task_partial, int W, double* __restrict__ packed) {
+  const int kq = blockIdx.x, lane = threadIdx.x;
+  if (kq >= nkeys || lane >= WIDE_TASK_OUT) return;
+  const int n = 6 * W;
+  const unsigned int key = key_list[kq];
+  const int fi = (int)(key / (unsigned)W), fj = (int)(key % (unsigned)W);
+  const bool diag = fi == fj;
+  double v = 0.0;
+  for (int t = key_task_ptr[kq]; t < key_task_ptr[kq + 1]; t++) v += task_partial[(size_t)t * WIDE_TASK_OUT + lane];
   if (lane < 36) {
     const int x = lane / 6, y = lane % 6;
-    double v = 0.0;
-#pragma unroll
-    for (int e = 0; e < 36; e++) v = (e == lane) ? s[e] : v;
     packed[(size_t)(6 * fj + y) * n + 6 * fi + x] = v;            // block (fi, fj) ...
     if (!diag) packed[(size_t)(6 * fi + x) * n + 6 * fj + y] = v;  // ... and its mirror image (voxel_map.hpp:237-239)
-  } else if (diag && lane < 42) {
-    const int d = lane - 36;
-    double v = 0.0;
-#pragma unroll
-    for (int e = 0; e < 6; e++) v = (e == d) ? g[e] : v;
-    packed[(size_t)n * n + 6 * fi + d] = v;
+  } else if (diag) {
+    packed[(size_t)n * n + 6 * fi + (lane - 36)] = v;
   }
 }
 
@@ -277,14 +312,14 @@ int launch_k2_wide(const WideView& wv, const double* d_poses, int head, int end,
 }
 
 void free_index(WideIndex& wi) {
-  void* ptrs[] = {wi.sei, wi.sej, wi.key_list, wi.key_ptr, wi.rowbuf};
+  void* ptrs[] = {wi.sei, wi.sej, wi.key_list, wi.key_ptr, wi.tasks, wi.key_task_ptr, wi.task_partial, wi.vrec};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   wi = WideIndex();
 }
 
 size_t index_bytes(const WideIndex& wi, int W) {
   if (!wi.sei) return 0;
-  return (size_t)wi.np * 8 + (size_t)W * W * 4 + (size_t)(wi.nkeys + 1) * 8 + (size_t)wi.nnz * ROWLEN * 8;
+  return (size_t)wi.np * 8 + (size_t)W * W * 4 + (size_t)(wi.nkeys + 1) * 12 + (size_t)wi.ntasks * (sizeof(WideTask) + 8 * WIDE_TASK_OUT) + (size_t)wi.V * WIDE_VREC * 8;
 }
 size_t store_bytes(const WideStore& st) { return (size_t)st.ES * (80 + 8) + (st.eptr ? ((size_t)st.vcap + 1) * 8 : 0) + st.tmp_cap; }
 
@@ -317,7 +352,6 @@ int build_index(const WideView& wv, int V, WideIndex& wi, hipStream_t s, const c
   if (wi.nnz == 0) return 0;
   WV(hipMalloc((void**)&wi.sei, sizeof(unsigned int) * wi.np));
   WV(hipMalloc((void**)&wi.sej, sizeof(unsigned int) * wi.np));
-  WV(hipMalloc((void**)&wi.rowbuf, sizeof(double) * ROWLEN * wi.nnz));
   unsigned int *pkey, *pidx, *pkey_s, *pidx_s, *pei, *pej, *kcnt, *nruns;
   WV(talloc((void**)&pkey, sizeof(unsigned int) * wi.np)); WV(talloc((void**)&pidx, sizeof(unsigned int) * wi.np));
   WV(talloc((void**)&pkey_s, sizeof(unsigned int) * wi.np)); WV(talloc((void**)&pidx_s, sizeof(unsigned int) * wi.np));
@@ -352,6 +386,24 @@ int build_index(const WideView& wv, int V, WideIndex& wi, hipStream_t s, const c
   char* d_temp4;
   WV(talloc((void**)&d_temp4, tb4));
   WV(rocprim::exclusive_scan(d_temp4, tb4, kc64, wi.key_ptr, 0ll, (size_t)wi.nkeys + 1, rocprim::plus<long long>(), s));
+  // tasks: the runs cut into pieces of at most WIDE_TASK_RECORDS records (a fixed partition: the sums stay reproducible)
+  std::vector<long long> h_ptr((size_t)wi.nkeys + 1);
+  WV(hipMemcpyAsync(h_ptr.data(), wi.key_ptr, sizeof(long long) * h_ptr.size(), hipMemcpyDeviceToHost, s));
+  WV(hipStreamSynchronize(s));
+  std::vector<WideTask> h_tasks;
+  std::vector<int> h_ktp((size_t)wi.nkeys + 1, 0);
+  for (int k = 0; k < wi.nkeys; k++) {
+    h_ktp[k] = (int)h_tasks.size();
+    for (long long lo = h_ptr[k]; lo < h_ptr[k + 1]; lo += WIDE_TASK_RECORDS) h_tasks.push_back(WideTask{lo, std::min(lo + WIDE_TASK_RECORDS, h_ptr[k + 1]), k, 0});
+  }
+  h_ktp[wi.nkeys] = (int)h_tasks.size();
+  wi.ntasks = (int)h_tasks.size();
+  WV(hipMalloc((void**)&wi.tasks, sizeof(WideTask) * std::max<size_t>(1, h_tasks.size())));
+  WV(hipMalloc((void**)&wi.key_task_ptr, sizeof(int) * h_ktp.size()));
+  WV(hipMalloc((void**)&wi.task_partial, sizeof(double) * WIDE_TASK_OUT * std::max<size_t>(1, h_tasks.size())));
+  WV(hipMalloc((void**)&wi.vrec, sizeof(double) * WIDE_VREC * (size_t)V));
+  WV(hipMemcpyAsync(wi.tasks, h_tasks.data(), sizeof(WideTask) * h_tasks.size(), hipMemcpyHostToDevice, s));
+  WV(hipMemcpyAsync(wi.key_task_ptr, h_ktp.data(), sizeof(int) * h_ktp.size(), hipMemcpyHostToDevice, s));
   WV(hipStreamSynchronize(s));
   WV(hipGetLastError());
   return 0;
@@ -363,8 +415,10 @@ void launch_k3_wide(const WideView& wv, const double* d_poses, const WideIndex& 
   const int n = 6 * fv.W;
   (void)hipMemsetAsync(d_packed, 0, ((size_t)n * n + n + 1) * sizeof(double), s);
   if (end <= head || wi.nnz == 0) return;
-  k3w_rows_kernel<<<dim3((unsigned)((wi.nnz + 255) / 256)), dim3(256), 0, s>>>(wv, d_poses, head, end, wi.rowbuf);
-  k3w_blocks_kernel<<<dim3((unsigned)((wi.nkeys + 3) / 4)), dim3(256), 0, s>>>(wi.key_list, wi.key_ptr, wi.nkeys, wi.sei, wi.sej, wi.rowbuf, fv.W, d_packed);
+  k3w_vrec_kernel<<<dim3((unsigned)((end - head + 255) / 256)), dim3(256), 0, s>>>(fv, head, end, wi.vrec);
+  k3w_blocks_kernel<<<dim3((unsigned)((wi.ntasks + 3) / 4)), dim3(256), 0, s>>>(wv, d_poses, head, end, wi.key_list, wi.tasks, wi.ntasks, wi.sei, wi.sej, wi.vrec,
+                                                                               wi.task_partial);
+  k3w_combine_kernel<<<dim3((unsigned)wi.nkeys), dim3(64), 0, s>>>(wi.key_list, wi.key_task_ptr, wi.nkeys, wi.task_partial, fv.W, d_packed);
   const int nparts = (end - head + 63) / 64;
   k3w_residual_kernel<<<dim3(nparts), dim3(64), 0, s>>>(fv, head, end, d_partial);
   k3w_residual_sum_kernel<<<dim3(1), dim3(256), 0, s>>>(d_partial, nparts, d_packed + (size_t)n * n + n);
@@ -374,10 +428,6 @@ void launch_k3_wide(const WideView& wv, const double* d_poses, const WideIndex& 
 // ------------------------------------------------------------------------------------------------------------------
 // The compressed-row cluster store (WideStore, vxba_wide.h)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void st_copy_planes_kernel(const double* __restrict__ src, long long src_es, double* __restrict__ dst, long long dst_es, long long n) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n) dst[(size_t)blockIdx.y * dst_es + e] = src[(size_t)blockIdx.y * src_es + e];
-}
 // one lane per new voxel: its entries from the caller's compressed rows; frames must rise strictly and stay below W
 __global__ void st_append_csr_kernel(const long long* __restrict__ ptr, const int* __restrict__ fr, const double* __restrict__ cl, int n, int W, int v0,
                                      long long e_base, double* __restrict__ ecl, long long ES, long long* __restrict__ eptr, int* __restrict__ eframe,
@@ -394,7 +444,7 @@ __global__ void st_append_csr_kernel(const long long* __restrict__ ptr, const in
     eframe[e] = f;
     evoxel[e] = v0 + a;
 #pragma unroll
-    for (int k = 0; k < 10; k++) ecl[(size_t)k * ES + e] = cl[(size_t)q * 10 + k];
+    for (int k = 0; k < 10; k++) ecl[(size_t)e * 10 + k] = cl[(size_t)q * 10 + k];
   }
   eptr[v0 + a + 1] = e_base + p1;
 }
@@ -419,7 +469,7 @@ __global__ void st_append_dense_kernel(const double* __restrict__ dense, const l
     eframe[e] = f;
     evoxel[e] = v0 + a;
 #pragma unroll
-    for (int k = 0; k < 10; k++) ecl[(size_t)k * ES + e] = c[k];
+    for (int k = 0; k < 10; k++) ecl[(size_t)e * 10 + k] = c[k];
     e++;
   }
   eptr[v0 + a + 1] = e;
@@ -431,12 +481,12 @@ __global__ void st_expand_kernel(const double* __restrict__ ecl, long long ES, c
   for (long long e = eptr[head + a]; e < eptr[head + a + 1]; e++) {
     double* o = dense + ((size_t)a * W + eframe[e]) * 10;
 #pragma unroll
-    for (int k = 0; k < 10; k++) o[k] = ecl[(size_t)k * ES + e];
+    for (int k = 0; k < 10; k++) o[k] = ecl[(size_t)e * 10 + k];
   }
 }
 __global__ void st_count_observed_kernel(const double* __restrict__ npl, long long nnz, unsigned long long* __restrict__ out) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool one = e < nnz && npl[e] != 0.0;
+  const bool one = e < nnz && npl[(size_t)e * 10 + 9] != 0.0;
   const unsigned long long m = __ballot(one);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
 }
@@ -473,7 +523,7 @@ int store_reserve(WideStore& st, int vcap, long long ecap, int V, hipStream_t s,
     WV(hipMalloc((void**)&nf, sizeof(int) * (size_t)want));
     WV(hipMalloc((void**)&nv, sizeof(int) * (size_t)want));
     if (st.nnz > 0) {
-      st_copy_planes_kernel<<<dim3((unsigned)((st.nnz + 255) / 256), 10), 256, 0, s>>>(st.ecl, st.ES, ncl, want, st.nnz);
+      WV(hipMemcpyAsync(ncl, st.ecl, sizeof(double) * 10 * (size_t)st.nnz, hipMemcpyDeviceToDevice, s));
       WV(hipMemcpyAsync(nf, st.eframe, sizeof(int) * (size_t)st.nnz, hipMemcpyDeviceToDevice, s));
       WV(hipMemcpyAsync(nv, st.evoxel, sizeof(int) * (size_t)st.nnz, hipMemcpyDeviceToDevice, s));
     }
@@ -519,7 +569,7 @@ long long store_count_observed(const WideStore& st, int V, hipStream_t s, const 
   unsigned long long* d = (unsigned long long*)mst.tmp;
   unsigned long long h = 0;
   if (hipMemsetAsync(d, 0, sizeof h, s) != hipSuccess) { *err = "count: memset failed"; return -1; }
-  st_count_observed_kernel<<<(unsigned)((st.nnz + 255) / 256), 256, 0, s>>>(st.ecl + (size_t)9 * st.ES, st.nnz, d);
+  st_count_observed_kernel<<<(unsigned)((st.nnz + 255) / 256), 256, 0, s>>>(st.ecl, st.nnz, d);
   if (hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { *err = "count: D2H failed"; return -1; }
   return (long long)h;
 }
