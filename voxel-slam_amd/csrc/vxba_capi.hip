@@ -1955,11 +1955,14 @@ static int voxelize_push_impl(vxba_factor* f, int64_t n_points, const double* xy
   const int64_t cap = n_points / (std::max(floor_pts, 0) + 1) + 1;   // a factor owns > min_points points, and no point twice
   // one grow-only scratch allocation per factor, carved up here (a hipMalloc / hipFree pair per buffer and call cost more than the sorts)
   auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  // wide windows take the accepted voxels as compressed rows (a point belongs to at most one factor voxel: n_points entries suffice)
+  const bool csr = is_wide(f);
   const size_t b_xyz = xyz_on_device ? 0 : up((size_t)n_points * 3 * sizeof(double)), b_fp = up((size_t)(W + 1) * sizeof(long long)),
-               b_cl = up((size_t)cap * W * 10 * sizeof(double)), b_ev = up((size_t)cap * 3 * sizeof(double)), b_evec = up((size_t)cap * 9 * sizeof(double)),
+               b_cl = csr ? up((size_t)n_points * 10 * sizeof(double)) : up((size_t)cap * W * 10 * sizeof(double)),
+               b_rp = csr ? up((size_t)(cap + 1) * sizeof(long long)) : 0, b_ef = csr ? up((size_t)n_points * sizeof(int)) : 0, b_ev = up((size_t)cap * 3 * sizeof(double)), b_evec = up((size_t)cap * 9 * sizeof(double)),
                b_m = up((size_t)cap * 10 * sizeof(double)), b_id = up((size_t)cap * sizeof(unsigned long long)), b_fix = up((size_t)cap * 10 * sizeof(double)),
                b_coe = up((size_t)cap * sizeof(double));
-  const size_t need = b_xyz + b_fp + b_cl + b_ev + b_evec + b_m + b_id + b_fix + b_coe;
+  const size_t need = b_xyz + b_fp + b_cl + b_rp + b_ef + b_ev + b_evec + b_m + b_id + b_fix + b_coe + 256;
   {
     int rcs = ensure_scratch(f, need);
     if (rcs) return rcs;
@@ -1968,9 +1971,12 @@ static int voxelize_push_impl(vxba_factor* f, int64_t n_points, const double* xy
   auto carve = [&](size_t bytes) { char* r = q; q += bytes; return r; };
   double* d_xyz_own = (double*)carve(b_xyz);
   long long* d_fp = (long long*)carve(b_fp);
-  double* d_cl = (double*)carve(b_cl); double* d_ev = (double*)carve(b_ev); double* d_evec = (double*)carve(b_evec); double* d_m = (double*)carve(b_m);
+  double* d_cl = (double*)carve(b_cl);
+  long long* d_rp = (long long*)carve(b_rp); int* d_ef = (int*)carve(b_ef);
+  double* d_ev = (double*)carve(b_ev); double* d_evec = (double*)carve(b_evec); double* d_m = (double*)carve(b_m);
   unsigned long long* d_id = (unsigned long long*)carve(b_id);
   double* d_fix = (double*)carve(b_fix); double* d_coe = (double*)carve(b_coe);
+  int* d_bad = (int*)carve(256);
   const double* d_xyz = xyz_on_device ? xyz_local : d_xyz_own;
   if (!xyz_on_device) VX_HIP(f, hipMemcpyAsync(d_xyz_own, xyz_local, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
   VX_HIP(f, hipMemcpyAsync(d_fp, frame_ptr, (size_t)(W + 1) * sizeof(long long), hipMemcpyHostToDevice, f->stream));
@@ -1982,6 +1988,7 @@ static int voxelize_push_impl(vxba_factor* f, int64_t n_points, const double* xy
   for (int k = 0; k < 4; k++) { vp.eigen_ratio[k] = params->eigen_ratio[k]; vp.min_points_layer[k] = params->min_points_layer[k]; }
   vp.min_frames = params->min_frames;
   vxv::VoxelizeOutput out{cap, d_cl, d_ev, d_evec, d_m, d_id};
+  if (csr) { out.d_row_ptr = d_rp; out.d_eframe = d_ef; out.ecap = n_points; }
   const char* emsg = nullptr;
   const long long n = vxv::voxelize(W, n_points, d_xyz, d_fp, f->d_poses, vp, f->stream, &out, &emsg);
   if (n < 0) return fail(f, VXBA_ERR_STATE, emsg ? emsg : "voxelize failed");
@@ -1992,8 +1999,13 @@ static int voxelize_push_impl(vxba_factor* f, int64_t n_points, const double* xy
     const int v0 = f->V;
     vxv::fill(d_fix, n * 10, 0.0, f->stream);
     vxv::fill(d_coe, n, 1.0, f->stream);
-    if (is_wide(f)) { rc = wide_append_dense(f, (int)n, d_cl); if (rc) return rc; }
-    else {
+    if (csr) {
+      const char* em2 = nullptr;
+      if (vxw::store_reserve(f->wstore, f->V + (int)n, f->wstore.nnz + out.n_entries, f->V, f->stream, &em2) != 0) return fail(f, VXBA_ERR_HIP, em2 ? em2 : "wide store: allocation failed");
+      VX_HIP(f, hipMemsetAsync(d_bad, 0, sizeof(int), f->stream));   // rows the voxelisation wrote itself: never set
+      vxw::store_append_csr(f->wstore, f->V, (int)n, d_rp, d_ef, d_cl, out.n_entries, W, d_bad, f->stream);
+      f->wstore.nnz += out.n_entries;
+    } else {
       vxk::launch_scatter_clusters(d_cl, fv, v0, (int)n, f->stream);
       vxk::launch_build_clb(fv, v0, (int)n, f->stream);
     }

@@ -25,6 +25,14 @@ struct VoxelizeOutput {
   double* d_eigvec;            // [n][9] column-major
   double* d_merged;            // [n][10]
   unsigned long long* d_node_id;   // [n] canonical id: [x:16 | y:16 | z:16 | path:9 | pad:4 | layer:3]
+  // Compressed rows instead of the dense [n][W][10] block (wide windows: a voxel is seen from a handful of ~100 frames): when
+  // d_row_ptr is set, d_clusters is [ecap][10] over the observed (voxel, frame) entries, voxel by voxel with ascending frames,
+  // d_row_ptr[n + 1] (d_row_ptr[0] == 0) and d_eframe[ecap] describe them, and n_entries receives their number.  A point belongs to
+  // at most one factor voxel, so ecap = n_points is always enough.
+  long long* d_row_ptr = nullptr;
+  int* d_eframe = nullptr;
+  long long ecap = 0;
+  long long n_entries = 0;
 };
 
 // Returns the number of factor voxels written (grouped by layer, ascending node key inside a layer) or -1 (*err set).

@@ -162,6 +162,33 @@ __global__ void emit_kernel(const unsigned char* __restrict__ state, const unsig
   o_id[o] = ((nk >> PATH_BITS) << 16) | ((nk & 511ull) << 7) | (unsigned long long)layer;
 }
 
+// compressed-row variant: entries of accepted node j at e_base + epos[j] ..
+__global__ void entry_count_kernel(const unsigned char* __restrict__ state, const unsigned int* __restrict__ ncell, long long n_nodes, long long* __restrict__ cnt) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j <= n_nodes) cnt[j] = (j < n_nodes && state[j] == FACTOR) ? (long long)ncell[j] : 0ll;
+}
+__global__ void emit_csr_kernel(const unsigned char* __restrict__ state, const unsigned int* __restrict__ pos, const long long* __restrict__ epos, long long n_nodes,
+                                int layer, const unsigned long long* __restrict__ node_key, const long long* __restrict__ node_cell_ptr,
+                                const unsigned long long* __restrict__ cell_key, const double* __restrict__ cell_cluster,
+                                const double* __restrict__ node_cluster, const double* __restrict__ eigval, const double* __restrict__ eigvec,
+                                long long out_base, long long e_base, double* __restrict__ o_ecl, int* __restrict__ o_eframe, long long* __restrict__ o_row_ptr,
+                                double* __restrict__ o_eigval, double* __restrict__ o_eigvec, double* __restrict__ o_merged, unsigned long long* __restrict__ o_id) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_nodes || state[j] != FACTOR) return;
+  const long long o = out_base + pos[j];
+  long long e = e_base + epos[j];
+  for (long long cc = node_cell_ptr[j]; cc < node_cell_ptr[j + 1]; cc++, e++) {   // cells of a node: ascending frame (the key's low bits)
+    o_eframe[e] = (int)(cell_key[cc] & ((1ull << FRAME_BITS) - 1ull));
+    for (int k = 0; k < 10; k++) o_ecl[10 * e + k] = cell_cluster[10 * cc + k];
+  }
+  o_row_ptr[o + 1] = e;
+  for (int k = 0; k < 3; k++) o_eigval[3 * o + k] = eigval[3 * j + k];
+  for (int k = 0; k < 9; k++) o_eigvec[9 * o + k] = eigvec[9 * j + k];
+  for (int k = 0; k < 10; k++) o_merged[10 * o + k] = node_cluster[10 * j + k];
+  const unsigned long long nk = node_key[j];
+  o_id[o] = ((nk >> PATH_BITS) << 16) | ((nk & 511ull) << 7) | (unsigned long long)layer;
+}
+
 __global__ void fill_kernel(double* __restrict__ p, long long n, double v) {
   const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < n) p[q] = v;
@@ -272,7 +299,12 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
   VV(hipStreamSynchronize(s));
   if (h_err) { *err_out = range_msg; return -1; }
 
-  long long total = 0;
+  long long total = 0, total_entries = 0;
+  long long* d_epos = nullptr;
+  if (out->d_row_ptr) {
+    VV(B.alloc(&d_epos, n + 1));
+    VV(hipMemsetAsync(out->d_row_ptr, 0, sizeof(long long), s));
+  }
   for (int layer = 0; layer <= p.max_layer && n > 0; layer++) {
     layer_key_kernel<<<grid_for(n), 256, 0, s>>>(d_key, n, layer, d_lkey, d_idx);
     size_t t = tb;
@@ -319,11 +351,24 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
     }
     const long long n_acc = (long long)last_pos + last_flag;
     if (total + n_acc > out->capacity) { *err_out = cap_msg; return -1; }
-    if (n_acc > 0)
+    if (n_acc > 0 && out->d_row_ptr) {
+      entry_count_kernel<<<grid_for((long long)n_nodes + 1), 256, 0, s>>>(d_state[layer], d_node_ncell, n_nodes, d_tmp64);
+      t = tb;
+      VV(rocprim::exclusive_scan(d_temp, t, d_tmp64, d_epos, 0ll, (size_t)n_nodes + 1, rocprim::plus<long long>(), s));
+      long long n_ent = 0;
+      VV(hipMemcpyAsync(&n_ent, d_epos + n_nodes, sizeof(long long), hipMemcpyDeviceToHost, s));
+      VV(hipStreamSynchronize(s));
+      if (total_entries + n_ent > out->ecap) { *err_out = cap_msg; return -1; }
+      emit_csr_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_state[layer], d_pos, d_epos, n_nodes, layer, d_node_key[layer], d_node_cell_ptr, d_cell_key, d_cell_cl,
+                                                       d_node_cl, d_eigval, d_eigvec, total, total_entries, out->d_clusters, out->d_eframe, out->d_row_ptr,
+                                                       out->d_eigval, out->d_eigvec, out->d_merged, out->d_node_id);
+      total_entries += n_ent;
+    } else if (n_acc > 0)
       emit_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_state[layer], d_pos, n_nodes, W, layer, d_node_key[layer], d_node_cell_ptr, d_cell_key, d_cell_cl, d_node_cl,
                                                    d_eigval, d_eigvec, total, out->d_clusters, out->d_eigval, out->d_eigvec, out->d_merged, out->d_node_id);
     total += n_acc;
   }
+  out->n_entries = total_entries;
   VV(hipStreamSynchronize(s));
   VV(hipGetLastError());
   return total;
