@@ -588,19 +588,6 @@ long long store_count_observed(const WideStore& st, int V, hipStream_t s, const 
 // A non-positive pivot sets `info`; the caller then takes the host's pivoted LDL^T for this step (the reference's own solver).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int WC_NB = 32;
-__global__ void wide_prepare_kernel(const double* __restrict__ packed, int n, double u, double* __restrict__ A, int lda, double* __restrict__ dvec, int* __restrict__ info) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0) *info = 0;
-  if (t < (long long)n * n) {
-    const int r = (int)(t % n), c = (int)(t / n);
-    double h = (r < 6 || c < 6) ? ((r == c) ? 1.0 : 0.0) : packed[t];     // gauge fix on frame 0 (voxel_map.hpp:397-400)
-    if (r == c) { dvec[r] = h; h += u * h; }                                // D = diag(H), A = H + u D (:402-403)
-    A[(size_t)c * lda + r] = h;
-  } else if (t < (long long)n * n + n) {
-    const int i = (int)(t - (long long)n * n);
-    A[(size_t)i * lda + n] = i < 6 ? 0.0 : -packed[t];                     // row n: the right-hand side
-  }
-}
 // Cholesky factor of a kb x kb diagonal block (kb <= 32) by ONE wave, lane r holding row r of the lower triangle in registers.  Per
 // pivot: pivot by v_readlane, 1/sqrt by v_rsq_f64 + two Newton steps, the scaled column to LDS once and back as broadcast reads -- no
 // workgroup barrier inside the 32-step chain.  Result: Dout[c][r] = L(r, c) (zeros elsewhere).  A non-positive pivot is reported.
@@ -639,30 +626,24 @@ __device__ __forceinline__ void wchol_factor_block(double (&d)[WC_NB], int lane,
     for (int c = 0; c < WC_NB; c++) Dout[c][r] = (r < kb && c <= r) ? d[c] : 0.0;
   }
 }
-// the first diagonal block (the later ones are factored by the trailing update that completes them)
-__global__ __launch_bounds__(64) void wchol_diag0_kernel(const double* __restrict__ A, int lda, int kb, double* __restrict__ Lkk, int* __restrict__ info) {
-  __shared__ double D[WC_NB][WC_NB + 1];
-  __shared__ double colbuf[WC_NB];
-  const int r = threadIdx.x;
-  double d[WC_NB];
-#pragma unroll
-  for (int c = 0; c < WC_NB; c++) d[c] = (r < kb && c <= r) ? A[(size_t)c * lda + r] : 0.0;
-  wchol_factor_block(d, r, kb, 0, colbuf, D, info, true);
-  __builtin_amdgcn_wave_barrier();
-  for (int e = r; e < WC_NB * WC_NB; e += 64) { const int rr = e % WC_NB, c = e / WC_NB; Lkk[e] = D[c][rr]; }
-}
 // block step at column k0 (kb columns): forward substitution of the rows below the diagonal block against its factor Lkk (column-major
 // 32 x 32, in a side buffer: A keeps the unfactored diagonal blocks).  One row per thread in registers, L_kk broadcast from LDS.
-__global__ __launch_bounds__(256) void wchol_panel_kernel(double* __restrict__ A, int lda, int nrows, int k0, int kb, const double* __restrict__ Lkk) {
-  __shared__ double D[WC_NB][WC_NB + 1];     // D[c][r] = L(r, c)
-  const int tid = threadIdx.x;
-  for (int e = tid; e < WC_NB * WC_NB; e += 256) { const int r = e % WC_NB, c = e / WC_NB; D[c][r] = Lkk[e]; }
-  __syncthreads();
-  const int r = k0 + kb + blockIdx.x * 256 + tid;
+// The factorisation's workgroups hand data to each other inside one launch (L2 is per XCD, not coherent across them): everything they
+// share goes through agent-scope accesses -- stores written through, loads served from the coherent level -- so that a device-wide
+// barrier only has to wait for the store acknowledgements instead of writing back and invalidating L2 (measured: 39 us per barrier
+// with __threadfence() on both sides, 41 barriers per solve).
+__device__ __forceinline__ double wc_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wc_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wchol_load_lkk(const double* __restrict__ Lkk, double (*D)[WC_NB + 1]) {
+  for (int e = threadIdx.x; e < WC_NB * WC_NB; e += blockDim.x) { const int r = e % WC_NB, c = e / WC_NB; D[c][r] = wc_ld(Lkk + e); }
+}
+// rows k0 + kb + 256 chunk .. of the panel; D[c][r] = L(r, c) of the diagonal block
+__device__ __forceinline__ void wchol_panel_rows(double* __restrict__ A, int lda, int nrows, int k0, int kb, int chunk, const double (*D)[WC_NB + 1]) {
+  const int r = k0 + kb + chunk * 256 + threadIdx.x;
   if (r < nrows) {
     double l[WC_NB];
 #pragma unroll
-    for (int c = 0; c < WC_NB; c++) l[c] = c < kb ? A[(size_t)(k0 + c) * lda + r] : 0.0;
+    for (int c = 0; c < WC_NB; c++) l[c] = c < kb ? wc_ld(A + (size_t)(k0 + c) * lda + r) : 0.0;
 #pragma unroll
     for (int c = 0; c < WC_NB; c++) {
       if (c < kb) {
@@ -673,25 +654,20 @@ __global__ __launch_bounds__(256) void wchol_panel_kernel(double* __restrict__ A
       }
     }
 #pragma unroll
-    for (int c = 0; c < WC_NB; c++) if (c < kb) A[(size_t)(k0 + c) * lda + r] = l[c];
+    for (int c = 0; c < WC_NB; c++) if (c < kb) wc_st(A + (size_t)(k0 + c) * lda + r, l[c]);
   }
 }
 // A[i][j] -= sum_c L[i][k0 + c] L[j][k0 + c] on the lower tiles of the trailing matrix (rows / columns from k0 + kb).  The workgroup of
 // tile (0, 0) -- the NEXT diagonal block, complete after this update -- factors it right away (one wave) into Lkk_next, so that the
 // 32-pivot chain runs beside the other tiles' updates instead of heading the next step.
-__global__ __launch_bounds__(256) void wchol_trailing_kernel(double* __restrict__ A, int lda, int nrows, int ncols, int k0, int kb, double* __restrict__ Lkk_next,
-                                                             int* __restrict__ info) {
-  const int I = blockIdx.y, J = blockIdx.x;
-  if (J > I) return;
-  __shared__ double Li[WC_NB][WC_NB + 1], Lj[WC_NB][WC_NB + 1];
-  __shared__ double colbuf[WC_NB];
+__device__ __forceinline__ void wchol_trailing_tile(double* __restrict__ A, int lda, int nrows, int ncols, int k0, int kb, int I, int J, double* __restrict__ Lkk_next,
+                                                    int* __restrict__ info, double (*Li)[WC_NB + 1], double (*Lj)[WC_NB + 1], double* colbuf) {
   const int base = k0 + kb, r0 = base + I * WC_NB, c0 = base + J * WC_NB;
-  if (c0 >= ncols) return;
   const int tid = threadIdx.x;
   for (int e = tid; e < WC_NB * WC_NB; e += 256) {
     const int rr = e % WC_NB, k = e / WC_NB;
-    Li[rr][k] = (k < kb && r0 + rr < nrows) ? A[(size_t)(k0 + k) * lda + r0 + rr] : 0.0;
-    Lj[rr][k] = (k < kb && c0 + rr < nrows) ? A[(size_t)(k0 + k) * lda + c0 + rr] : 0.0;
+    Li[rr][k] = (k < kb && r0 + rr < nrows) ? wc_ld(A + (size_t)(k0 + k) * lda + r0 + rr) : 0.0;
+    Lj[rr][k] = (k < kb && c0 + rr < nrows) ? wc_ld(A + (size_t)(k0 + k) * lda + c0 + rr) : 0.0;
   }
   __syncthreads();
   const int tx = tid & 15, ty = tid >> 4;    // 16 x 16 threads, 2 x 2 outputs each: rows tx, tx + 16; columns ty, ty + 16
@@ -706,9 +682,9 @@ __global__ __launch_bounds__(256) void wchol_trailing_kernel(double* __restrict_
   auto upd = [&](int rr, int cc, double v) {
     const int r = r0 + rr, c = c0 + cc;
     if (r < nrows && c < ncols && r >= c) {
-      const double nv = A[(size_t)c * lda + r] - v;
-      A[(size_t)c * lda + r] = nv;
-      if (diag) Li[rr][cc] = nv;              // rows / columns of the next diagonal block: r, c < base + 32 <= ...
+      const double nv = wc_ld(A + (size_t)c * lda + r) - v;
+      wc_st(A + (size_t)c * lda + r, nv);
+      if (diag) Li[rr][cc] = nv;              // rows / columns of the next diagonal block
     }
   };
   upd(tx, ty, a00); upd(tx, ty + 16, a01); upd(tx + 16, ty, a10); upd(tx + 16, ty + 16, a11);
@@ -722,18 +698,18 @@ __global__ __launch_bounds__(256) void wchol_trailing_kernel(double* __restrict_
       __builtin_amdgcn_wave_barrier();
       wchol_factor_block(d, tid, kbn, base, colbuf, Lj, info, true);     // Lj[c][r] = L(r, c)
       __builtin_amdgcn_wave_barrier();
-      for (int e = tid; e < WC_NB * WC_NB; e += 64) { const int rr = e % WC_NB, c = e / WC_NB; Lkk_next[e] = Lj[c][rr]; }
+      for (int e = tid; e < WC_NB * WC_NB; e += 64) { const int rr = e % WC_NB, c = e / WC_NB; wc_st(Lkk_next + e, Lj[c][rr]); }
     }
   }
+  __syncthreads();                            // the tile buffers are free again
 }
 // L^T x = y with y = row n of the factored matrix; one workgroup of 1024 threads; x -> out[0..n).  Left-looking by blocks, last block
 // first: one wave solves the block's own 32 x 32 triangle, then every earlier unknown j subtracts what the block contributes to it,
 // sum_r L(k0 + r, j) x_(k0 + r) -- 32 CONTIGUOUS doubles of column j per thread, all loads independent.  (A first version let 32
 // threads walk down each column with one load in flight per thread: 173 us per solve.)
-__global__ __launch_bounds__(1024) void wchol_backsolve_kernel(const double* __restrict__ A, int lda, int n, const double* __restrict__ Lkk_all, double* __restrict__ x_out) {
-  __shared__ double x[WIDE_MAXW * 6];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < n; i += 1024) x[i] = A[(size_t)i * lda + n];
+__device__ __forceinline__ void wchol_backsolve(const double* __restrict__ A, int lda, int n, const double* __restrict__ Lkk_all, double* __restrict__ x_out, double* x) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < n; i += nt) x[i] = wc_ld(A + (size_t)i * lda + n);
   __syncthreads();
   const int nblk = (n + WC_NB - 1) / WC_NB;
   for (int blk = nblk - 1; blk >= 0; blk--) {
@@ -743,7 +719,7 @@ __global__ __launch_bounds__(1024) void wchol_backsolve_kernel(const double* __r
       double mine = tid < kb ? x[k0 + tid] : 0.0;                     // lane c owns x_(k0 + c)
       double lrow[WC_NB];                                             // L(cc, tid) for cc > tid: column tid of the block, below the diagonal
 #pragma unroll
-      for (int cc = 0; cc < WC_NB; cc++) lrow[cc] = (tid < kb && cc < kb && cc >= tid) ? Lkk[tid * WC_NB + cc] : (cc == tid ? 1.0 : 0.0);
+      for (int cc = 0; cc < WC_NB; cc++) lrow[cc] = (tid < kb && cc < kb && cc >= tid) ? wc_ld(Lkk + tid * WC_NB + cc) : (cc == tid ? 1.0 : 0.0);
 #pragma unroll
       for (int cc = WC_NB - 1; cc >= 0; cc--) {
         if (cc < kb) {
@@ -755,27 +731,27 @@ __global__ __launch_bounds__(1024) void wchol_backsolve_kernel(const double* __r
     }
     __syncthreads();
     // earlier unknowns: j < k0
-    for (int j = tid; j < k0; j += 1024) {
+    for (int j = tid; j < k0; j += nt) {
       const double* col = A + (size_t)j * lda + k0;
       double sum = 0.0;
 #pragma unroll
-      for (int r = 0; r < WC_NB; r++) sum += (r < kb) ? col[r] * x[k0 + r] : 0.0;
+      for (int r = 0; r < WC_NB; r++) sum += (r < kb) ? wc_ld(col + r) * x[k0 + r] : 0.0;
       x[j] -= sum;
     }
     __syncthreads();
   }
-  for (int i = tid; i < n; i += 1024) x_out[i] = x[i];
+  for (int i = tid; i < n; i += nt) x_out[i] = x[i];
+  __syncthreads();
 }
 // out[0..n) = dxi, out[n] = q1 = 0.5 dxi . (u D dxi - JacT), out[n+1] = residual1 (packed's last slot)
-__global__ __launch_bounds__(256) void wide_q1_kernel(const double* __restrict__ packed, const double* __restrict__ dxi, const double* __restrict__ dvec, int n,
-                                                      double u, double* __restrict__ out) {
-  __shared__ double red[256];
+__device__ __forceinline__ void wide_q1(const double* __restrict__ packed, const double* __restrict__ dxi, const double* __restrict__ dvec, int n, double u,
+                                        double* __restrict__ out, double* red) {
   double s = 0.0;
   for (int r = threadIdx.x; r < n; r += 256) {
     const double d = dxi[r];
     out[r] = d;
     const double j = r < 6 ? 0.0 : packed[(size_t)n * n + r];
-    s += d * (u * dvec[r] * d - j);
+    s += d * (u * wc_ld(dvec + r) * d - j);
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -786,16 +762,106 @@ __global__ __launch_bounds__(256) void wide_q1_kernel(const double* __restrict__
   if (threadIdx.x == 0) { out[n] = 0.5 * red[0]; out[n + 1] = packed[(size_t)n * n + n]; }
 }
 
+// Device-wide barrier of the persistent solve: a monotone arrival counter (zeroed by the host before the launch); shared data moves
+// through agent-scope accesses (wc_ld / wc_st), so arriving only takes the acknowledgement of this wave's stores.  All workgroups of the launch are resident (the grid is at most half the CUs and the sweeps before
+// it on the stream have finished); the wait is bounded all the same -- a barrier that gives up sets `info` and every later one falls
+// straight through, the host sees info != 0 and takes the step on the CPU.
+constexpr unsigned WC_SPIN_LIMIT = 1u << 20;
+__device__ __forceinline__ void wchol_grid_barrier(unsigned* counter, unsigned& target, unsigned nwg, int* info) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's written-through stores are acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    target += nwg;
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > WC_SPIN_LIMIT || __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) {
+        __hip_atomic_store(info, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// The whole damped step of a wide window in ONE launch: damping + gauge rows, blocked right-looking Cholesky with the right-hand side
+// as row n, back substitution, q1.  The same phases as before (they were ~42 launches of a few microseconds each on a GPU that idled
+// and clocked down between them: 0.9 of the 1.45 ms of a W = 99 iteration), now separated by device-wide barriers.
+__global__ __launch_bounds__(256) void wchol_persistent_kernel(const double* __restrict__ packed, int n, double u, double* __restrict__ A, double* __restrict__ Lkk_all,
+                                                               double* __restrict__ dvec, double* __restrict__ xbuf, double* __restrict__ out, int* __restrict__ info,
+                                                               unsigned* __restrict__ counter) {
+  __shared__ double Li[WC_NB][WC_NB + 1], Lj[WC_NB][WC_NB + 1];
+  __shared__ double colbuf[WC_NB];
+  __shared__ double xs[WIDE_MAXW * 6];
+  const int lda = n + 1, nrows = n + 1;
+  const unsigned nwg = gridDim.x, wg = blockIdx.x;
+  const int tid = threadIdx.x;
+  unsigned target = 0;
+  // A = H + u D with the gauge rows, right-hand side in row n
+  const long long tot = (long long)n * n + n;
+  for (long long t = (long long)wg * 256 + tid; t < tot; t += (long long)nwg * 256) {
+    if (t < (long long)n * n) {
+      const int r = (int)(t % n), c = (int)(t / n);
+      double h = (r < 6 || c < 6) ? ((r == c) ? 1.0 : 0.0) : packed[t];     // gauge fix on frame 0 (voxel_map.hpp:397-400)
+      if (r == c) { wc_st(dvec + r, h); h += u * h; }                         // D = diag(H), A = H + u D (:402-403)
+      wc_st(A + (size_t)c * lda + r, h);
+    } else {
+      const int i = (int)(t - (long long)n * n);
+      wc_st(A + (size_t)i * lda + n, i < 6 ? 0.0 : -packed[t]);              // row n: the right-hand side
+    }
+  }
+  wchol_grid_barrier(counter, target, nwg, info);
+  // first diagonal block (the later ones are factored by the trailing update that completes them)
+  if (wg == 0 && tid < 64) {
+    const int kb0 = n < WC_NB ? n : WC_NB;
+    double d[WC_NB];
+#pragma unroll
+    for (int c = 0; c < WC_NB; c++) d[c] = (tid < kb0 && c <= tid) ? wc_ld(A + (size_t)c * lda + tid) : 0.0;
+    wchol_factor_block(d, tid, kb0, 0, colbuf, Li, info, true);
+    __builtin_amdgcn_wave_barrier();
+    for (int e = tid; e < WC_NB * WC_NB; e += 64) { const int rr = e % WC_NB, c = e / WC_NB; wc_st(Lkk_all + e, Li[c][rr]); }
+  }
+  wchol_grid_barrier(counter, target, nwg, info);
+  for (int k0 = 0; k0 < n; k0 += WC_NB) {
+    const int kb = n - k0 < WC_NB ? n - k0 : WC_NB;
+    const int below = nrows - k0 - kb;                       // rows under the diagonal block (>= 1: the right-hand side row)
+    double* Lk = Lkk_all + (size_t)(k0 / WC_NB) * WC_NB * WC_NB;
+    const int nchunks = (below + 255) / 256;
+    if ((int)wg < nchunks) {
+      wchol_load_lkk(Lk, Li);
+      __syncthreads();
+      for (int chunk = wg; chunk < nchunks; chunk += nwg) wchol_panel_rows(A, lda, nrows, k0, kb, chunk, Li);
+      __syncthreads();
+    }
+    wchol_grid_barrier(counter, target, nwg, info);
+    const int tr = (below + WC_NB - 1) / WC_NB, tc = (n - k0 - kb + WC_NB - 1) / WC_NB;
+    if (tc > 0) {
+      for (int t = wg; t < tr * tc; t += nwg) {
+        const int I = t / tc, J = t % tc;
+        if (J <= I) wchol_trailing_tile(A, lda, nrows, n, k0, kb, I, J, Lk + WC_NB * WC_NB, info, Li, Lj, colbuf);
+      }
+      wchol_grid_barrier(counter, target, nwg, info);
+    }
+  }
+  if (wg == 0) {
+    wchol_backsolve(A, lda, n, Lkk_all, xbuf, xs);
+    __threadfence_block();
+    wide_q1(packed, xbuf, dvec, n, u, out, &Li[0][0]);
+  }
+}
+
 struct DenseSolver {
   double *d_A = nullptr, *d_Lkk = nullptr, *d_x = nullptr, *d_dvec = nullptr, *d_out = nullptr, *h_out = nullptr;
   int* d_info = nullptr;
   int* h_info = nullptr;
-  int n = 0;
+  unsigned* d_counter = nullptr;
+  int n = 0, nwg = 0;
 };
 
 void wide_solver_free(DenseSolver*& ds) {
   if (!ds) return;
-  void* ptrs[] = {ds->d_A, ds->d_Lkk, ds->d_x, ds->d_dvec, ds->d_out, ds->d_info};
+  void* ptrs[] = {ds->d_A, ds->d_Lkk, ds->d_x, ds->d_dvec, ds->d_out, ds->d_info, ds->d_counter};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   if (ds->h_out) (void)hipHostFree(ds->h_out);
   if (ds->h_info) (void)hipHostFree(ds->h_info);
@@ -815,7 +881,7 @@ DenseSolver* wide_solver_create(int n, hipStream_t) {
   const bool ok = hipMalloc((void**)&ds->d_A, sizeof(double) * (size_t)(n + 1) * n) == hipSuccess && hipMalloc((void**)&ds->d_x, sizeof(double) * n) == hipSuccess &&
                   hipMalloc((void**)&ds->d_Lkk, sizeof(double) * (size_t)((n + WC_NB - 1) / WC_NB) * WC_NB * WC_NB) == hipSuccess &&
                   hipMalloc((void**)&ds->d_dvec, sizeof(double) * n) == hipSuccess && hipMalloc((void**)&ds->d_out, sizeof(double) * (n + 2)) == hipSuccess &&
-                  hipMalloc((void**)&ds->d_info, sizeof(int)) == hipSuccess && hipHostMalloc((void**)&ds->h_out, sizeof(double) * (n + 2), hipHostMallocDefault) == hipSuccess &&
+                  hipMalloc((void**)&ds->d_info, sizeof(int)) == hipSuccess && hipMalloc((void**)&ds->d_counter, 64) == hipSuccess && hipHostMalloc((void**)&ds->h_out, sizeof(double) * (n + 2), hipHostMallocDefault) == hipSuccess &&
                   hipHostMalloc((void**)&ds->h_info, sizeof(int), hipHostMallocDefault) == hipSuccess;
   if (!ok) { wide_solver_free(ds); return nullptr; }
   return ds;
@@ -824,20 +890,15 @@ DenseSolver* wide_solver_create(int n, hipStream_t) {
 // One damped step from the packed buffer on the device.  Host outputs: dxi (n), *q1, *residual1.  Returns 0, or 1 if the
 // factorisation met a non-positive pivot / a call failed -- the caller then takes the host path for this step.
 int wide_solver_step(DenseSolver* ds, const double* d_packed, double u, hipStream_t s, double* dxi, double* q1, double* residual1) {
-  const int n = ds->n, lda = n + 1, nrows = n + 1;
-  const long long tot = (long long)n * n + n;
-  wide_prepare_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s>>>(d_packed, n, u, ds->d_A, lda, ds->d_dvec, ds->d_info);
-  wchol_diag0_kernel<<<dim3(1), dim3(64), 0, s>>>(ds->d_A, lda, n < WC_NB ? n : WC_NB, ds->d_Lkk, ds->d_info);
-  for (int k0 = 0; k0 < n; k0 += WC_NB) {
-    const int kb = n - k0 < WC_NB ? n - k0 : WC_NB;
-    const int below = nrows - k0 - kb;                       // rows under the diagonal block (>= 1: the right-hand side row)
-    double* Lk = ds->d_Lkk + (size_t)(k0 / WC_NB) * WC_NB * WC_NB;
-    wchol_panel_kernel<<<dim3((unsigned)((below + 255) / 256)), dim3(256), 0, s>>>(ds->d_A, lda, nrows, k0, kb, Lk);
-    const int tr = (below + WC_NB - 1) / WC_NB, tc = (n - k0 - kb + WC_NB - 1) / WC_NB;
-    if (tc > 0) wchol_trailing_kernel<<<dim3((unsigned)tc, (unsigned)tr), dim3(256), 0, s>>>(ds->d_A, lda, nrows, n, k0, kb, Lk + WC_NB * WC_NB, ds->d_info);
+  const int n = ds->n;
+  if (ds->nwg == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+    const int tiles = ((n + WC_NB) / WC_NB) * ((n + WC_NB - 1) / WC_NB) / 2 + 1;     // lower tiles of the first trailing update
+    ds->nwg = std::max(1, std::min(std::min(prop.multiProcessorCount / 2, 128), tiles));
   }
-  wchol_backsolve_kernel<<<dim3(1), dim3(1024), 0, s>>>(ds->d_A, lda, n, ds->d_Lkk, ds->d_x);
-  wide_q1_kernel<<<dim3(1), dim3(256), 0, s>>>(d_packed, ds->d_x, ds->d_dvec, n, u, ds->d_out);
+  if (hipMemsetAsync(ds->d_counter, 0, sizeof(unsigned), s) != hipSuccess || hipMemsetAsync(ds->d_info, 0, sizeof(int), s) != hipSuccess) return 1;
+  wchol_persistent_kernel<<<dim3((unsigned)ds->nwg), dim3(256), 0, s>>>(d_packed, n, u, ds->d_A, ds->d_Lkk, ds->d_dvec, ds->d_x, ds->d_out, ds->d_info, ds->d_counter);
   if (hipMemcpyAsync(ds->h_info, ds->d_info, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
   if (hipMemcpyAsync(ds->h_out, ds->d_out, sizeof(double) * (n + 2), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
   if (hipStreamSynchronize(s) != hipSuccess) return 1;
