@@ -373,7 +373,7 @@ def li_ba_rate(sc, f, solves=20, with_cpu=False):
     med = float(np.median(per_solve))
     out = {"iterations_per_s": it_per_solve / med, "ms_per_iteration": 1e3 * med / it_per_solve, "solves": solves, "iterations": iters,
            "pose_rmse_vs_truth_m_rad": [et, er],
-           "where": "whole loop device-resident" if f.get_option("li_device_loop") else "sweeps on GPU; IMU factors + 150x150 LDL^T on host"}
+           "where": "whole loop device-resident" if f.get_option("li_device_loop") else "sweeps on GPU; IMU factors + structured (band Cholesky + Schur complement) solve on the host, overlapped with the sweeps"}
     if with_cpu:
         # the LiDAR-inertial optimiser's own CPU baseline: LI_BA_Optimizer::damping_iter of the checker (5 std::threads, as upstream) on the
         # same window, one solve; and the pose difference of the two results (outside any timed region)
