@@ -733,6 +733,7 @@ __global__ void map_fill_u64_kernel(unsigned long long* p, long long n, unsigned
 // =====================================================================================================================================
 struct vxba_map {
   int device = 0;
+  long long export_cap = 0;           // entries the plane-export buffers are sized for (from the last export)
   vxmap::Params prm{};
   hipStream_t stream = nullptr;
   vxmap::Nodes nd{};
@@ -1161,36 +1162,38 @@ int vxba_map_export_planes(vxba_map* m, vxba_lio* lio, int64_t* n_exported) {
   hipSetDevice(m->device);
   if (n_exported) *n_exported = 0;
   if (m->n_nodes == 0) return VXBA_OK;
-  const long long cap = 8ll * m->n_nodes;
   auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-  const size_t b_loc = up((size_t)cap * 3 * 8), b_i = up((size_t)cap * 4), b_3 = up((size_t)cap * 3 * 8), b_36 = up((size_t)cap * 36 * 8), b_1 = up((size_t)cap * 8);
-  // the worst case (every node exports eight entries) is far above what a map holds; size for it lazily: first pass counts
-  int rc = ensure_scratch(m, 256);
-  if (rc) return rc;
-  int* d_n = (int*)m->scratch;
-  VM_HIP(m, hipMemsetAsync(d_n, 0, sizeof(int), m->stream));
-  vxmap::map_plane_export_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, m->prm.max_layer, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_n, 0);
-  int n = 0;
-  VM_HIP(m, hipMemcpyAsync(&n, d_n, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-  VM_HIP(m, map_wait(m->stream));
-  (void)b_loc; (void)b_i; (void)b_3; (void)b_36; (void)b_1;
+  // The worst case (every node exports eight entries) is far above what a scan changes, so the buffers are sized from the LAST
+  // export (x 1.5): one pass that writes what fits and counts everything; only a first call or a jump in the number of changed leaves
+  // pays a second pass.  (Until the end of round 2 every export was a counting pass + a host round trip + the real pass.)
+  int rc = VXBA_OK, n = 0;
+  long long* d_loc = nullptr; int *d_layer = nullptr, *d_path = nullptr, *d_isp = nullptr, *d_n = nullptr;
+  double *d_center = nullptr, *d_normal = nullptr, *d_pvar = nullptr, *d_radius = nullptr;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const long long capn = m->export_cap;
+    const size_t c_loc = up((size_t)capn * 3 * 8), c_i = up((size_t)capn * 4), c_3 = up((size_t)capn * 3 * 8), c_36 = up((size_t)capn * 36 * 8), c_1 = up((size_t)capn * 8);
+    if ((rc = ensure_scratch(m, 256 + c_loc + 3 * c_i + 2 * c_3 + c_36 + c_1))) return rc;
+    char* q = m->scratch;
+    d_n = (int*)q; q += 256;
+    d_loc = (long long*)q; q += c_loc;
+    d_layer = (int*)q; q += c_i;
+    d_path = (int*)q; q += c_i;
+    d_isp = (int*)q; q += c_i;
+    d_center = (double*)q; q += c_3;
+    d_normal = (double*)q; q += c_3;
+    d_pvar = (double*)q; q += c_36;
+    d_radius = (double*)q;
+    VM_HIP(m, hipMemsetAsync(d_n, 0, sizeof(int), m->stream));
+    vxmap::map_plane_export_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, m->prm.max_layer, d_loc, d_layer, d_path, d_isp, d_center, d_normal, d_pvar, d_radius, d_n,
+                                                                                  (int)capn);
+    VM_HIP(m, hipMemcpyAsync(&n, d_n, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    VM_HIP(m, map_wait(m->stream));
+    if (n <= capn) break;
+    m->export_cap = (long long)n + n / 2 + 1024;      // everything was counted, not everything written: once more with room
+  }
+  if (m->export_cap < (long long)n + n / 2) m->export_cap = (long long)n + n / 2 + 1024;
   if (n == 0) return VXBA_OK;
-  const size_t c_loc = up((size_t)n * 3 * 8), c_i = up((size_t)n * 4), c_3 = up((size_t)n * 3 * 8), c_36 = up((size_t)n * 36 * 8), c_1 = up((size_t)n * 8);
-  if ((rc = ensure_scratch(m, 256 + c_loc + 3 * c_i + 2 * c_3 + c_36 + c_1))) return rc;
-  char* q = m->scratch;
-  d_n = (int*)q; q += 256;
-  long long* d_loc = (long long*)q; q += c_loc;
-  int* d_layer = (int*)q; q += c_i;
-  int* d_path = (int*)q; q += c_i;
-  int* d_isp = (int*)q; q += c_i;
-  double* d_center = (double*)q; q += c_3;
-  double* d_normal = (double*)q; q += c_3;
-  double* d_pvar = (double*)q; q += c_36;
-  double* d_radius = (double*)q;
-  VM_HIP(m, hipMemsetAsync(d_n, 0, sizeof(int), m->stream));
-  vxmap::map_plane_export_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, m->prm.max_layer, d_loc, d_layer, d_path, d_isp, d_center, d_normal, d_pvar, d_radius, d_n, n);
   vxmap::map_dirty_reset_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes);
-  VM_HIP(m, map_wait(m->stream));
   VM_HIP(m, hipGetLastError());
   rc = vxba_internal_lio_map_update_device(lio, n, d_loc, d_layer, d_path, d_isp, d_center, d_normal, d_pvar, d_radius);
   if (rc != VXBA_OK) return mfail(m, rc, vxba_lio_last_error(lio));
