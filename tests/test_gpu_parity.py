@@ -433,6 +433,55 @@ def test_timed_out_in_launch_solve_is_retried_without_fusion(vx):
     assert np.allclose(again["poses"], ref["poses"], atol=1e-9)
 
 
+def test_in_launch_solve_with_competing_kernels_resident(vx):
+    """The forward-progress assumption of the in-launch solve under contention: while another stream keeps the GPU full (long fp64
+    matrix products from torch, plus a second factor's sweeps from another host thread), the LM loop of this factor must give the
+    result of an undisturbed run -- through the fused path, or through its timed-out-and-retried fallback, never by hanging."""
+    import threading
+    import torch
+    sc = synth.make_scene(win_size=10, pts_per_scan=60000, n_voxels=30000, seed=77)
+    f = vx.LidarFactor(sc.win_size)
+    f.push_voxels(sc.clusters, sc.fix, sc.coe)
+    f.evaluate_only_residual(sc.poses_init)
+    ref = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=4)
+    sc2 = synth.make_scene(win_size=10, pts_per_scan=60000, n_voxels=30000, seed=78)
+    f2 = vx.LidarFactor(sc2.win_size)
+    f2.push_voxels(sc2.clusters, sc2.fix, sc2.coe)
+    f2.evaluate_only_residual(sc2.poses_init)
+    ref2 = vx.Lidar_BA_Optimizer().damping_iter(sc2.poses_init, f2, max_iter=4)
+    side = torch.cuda.Stream()
+    a = torch.randn(6144, 6144, dtype=torch.float64, device="cuda")
+    stop = threading.Event()
+    out2 = []
+
+    def other_factor():
+        while not stop.is_set():
+            f2.evaluate_only_residual(sc2.poses_init)
+            out2.append(vx.Lidar_BA_Optimizer().damping_iter(sc2.poses_init, f2, max_iter=4)["poses"])
+
+    th = threading.Thread(target=other_factor)
+    th.start()
+    try:
+        for rep in range(6):
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    b = a @ a                                   # ~0.5 TFLOP of fp64 each: the chip stays busy for tens of milliseconds
+            f.evaluate_only_residual(sc.poses_init)
+            got = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=4)
+            et, er = synth.pose_errors(got["poses"], ref["poses"])
+            assert et < 1e-9 and er < 1e-9, (rep, et, er)
+            assert np.array_equal(got["trace"][:, 6], ref["trace"][:, 6])
+    finally:
+        stop.set()
+        th.join(timeout=60)
+        torch.cuda.synchronize()
+    assert not th.is_alive() and len(out2) > 0
+    for p2 in out2:
+        et, er = synth.pose_errors(p2, ref2["poses"])
+        assert et < 1e-9 and er < 1e-9
+    del b
+
+
 def test_lm_loop_with_more_residual_workgroups_than_the_chip_holds(vx):
     """120k voxels -> 1876 residual-sweep workgroups + the in-launch solve workgroup: more than can be resident at once
     (the voxel workgroups wait for workgroup 0, so dispatch order matters here).  Trace and poses must still match the oracle."""
