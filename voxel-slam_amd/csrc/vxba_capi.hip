@@ -1,138 +1,8 @@
 // C-ABI implementation (include/vxba.h): device memory, streams, launch sequencing and the host part of
 // the LM shell.  No CPU fallback anywhere: without a gfx950 device every entry point fails loudly.
-#include <hip/hip_runtime.h>
-#include <dlfcn.h>
-#include <rccl/rccl.h>
+#include "vxba_factor.hpp"
 
-#include <algorithm>
-#include <cstdio>
-#include <chrono>
-#include <cstdio>
-#include <cstring>
-#include <functional>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../include/vxba.h"
-#include "vxba_host.hpp"
-#include "vxba_imu.hpp"
-#include "vxba_voxelize.h"
-#include "vxba_wide.h"
-#include "vxba_li_device.h"
-#include "vxba_scratch.hpp"
-#include "vxba_internal.h"
-#include "vxba_kernels.h"
-
-using vxk::FactorView;
-using vxk::PoseArg;
-
-namespace {
-
-constexpr int N_META_PLANES = 10 + 1 + 3 + 9 + 10 + 4;  // fix, coe, eigval, eigvec, merged, aux
-constexpr int N_CACHE_PLANES = 3 + 9 + 10 + 4;          // eigval, eigvec, merged, aux (contiguous at the tail)
-
-struct EventPair { hipEvent_t a, b; int kind; };
-
-}  // namespace
-
-struct vxba_factor {
-  int W = 0, device = 0;
-  int V = 0;        // voxels in the factor
-  int VS = 0;       // plane stride (capacity, multiple of 64)
-  int cus = 0;
-  hipStream_t stream = nullptr, own_stream = nullptr;
-  double* planes = nullptr;      // [(10W + N_META_PLANES)][VS]
-  double* clb = nullptr;         // batch-major copy of the clusters for the Hessian sweep
-  double* snapshot = nullptr;    // [N_CACHE_PLANES][snapshot_vs]
-  int snapshot_vs = 0, snapshot_v = 0;
-  double* staging = nullptr;     // device scratch for uploads / read-backs
-  size_t staging_len = 0;
-  double* d_partial3 = nullptr;  // K3 workgroup partials
-  size_t partial3_len = 0;
-  double* d_partial2 = nullptr;  // K2 wave partials
-  double* h_partial2 = nullptr;  // the same in mapped host memory (LI shells: the host adds the partials up itself), zc_partial2 = its device address
-  double* zc_partial2 = nullptr;
-  size_t partial2_len = 0;
-  double* d_packed = nullptr;    // [Hess | JacT | residual] (points at own_packed or a caller buffer)
-  double* d_scalar = nullptr;
-  double* own_packed = nullptr;
-  double* own_scalar = nullptr;
-  unsigned long long* d_count = nullptr;
-  double* h_packed = nullptr;    // pinned, mapped
-  double* zc_packed = nullptr;   // device alias of h_packed: kernels of host-driven loops write their result straight into host memory
-  double* h_scalar = nullptr;    // pinned
-  vxk::LMState* d_lm = nullptr;  // device-resident LM shell state
-  char* d_scratch = nullptr;     // grow-only device scratch of the batch factor construction (staging of points and accepted voxels)
-  size_t scratch_cap = 0;
-  vxli::LIState* d_li = nullptr; // device-resident LiDAR-inertial loop state (allocated on first use)
-  double* d_li_hess = nullptr;   // (15W)^2 export of that loop's *hess
-  vxk::LMState* h_lm = nullptr;  // pinned read-back copy
-  vxw::DenseSolver* wide_solver = nullptr;   // wide windows: device Cholesky of the (6W)-dimensional LM step (vxba_wide.hip)
-  bool wide_solver_tried = false;
-  double li_wait_us = 0;         // development (VXBA_LI_TIMING): time the LI shells spent waiting for the Hessian sweep
-  struct LiScratch {             // host buffers of the LI shells, kept between calls (four (15W)^2 matrices: allocating and zeroing them
-    std::vector<double> Hess, HessN, A, JacT, JacTN, D, rhs, dxi, work, cov_invs;   // cost ~15 us of a ~300 us call)
-    std::vector<int> perm;
-    void size(int n, int nfac) {
-      Hess.resize((size_t)n * n); HessN.resize((size_t)n * n); JacT.resize(n); JacTN.resize(n); D.resize(n); rhs.resize(n); dxi.resize(n);
-      work.resize(n); perm.resize(n); cov_invs.resize((size_t)225 * nfac);
-    }
-  } li;
-  vxh::BandSchurWork li_bs;
-  int opt[VXBA_OPT_COUNT] = {1, 1, 1, 0, 64, 0, 1};   // vxba_set_option; initial values may come from the environment (see vxba.h)
-  vxw::WideStore wstore;         // wide windows: the clusters, compressed rows over the observed (voxel, frame) entries (no cluster planes)
-  vxw::WideIndex wide;           // wide windows: incidence structure (entries, entry pairs per Hessian block), rebuilt after a push
-  bool wide_dirty = true;
-  double* d_poses = nullptr;     // wide windows: W*12 poses on the device (the MFMA kernels take them by value)
-  double* h_poses = nullptr;     // pinned staging for the above: a ring of POSE_SLOTS slots, each guarded by an event
-  hipEvent_t pose_ev[8] = {};
-  unsigned pose_slot = 0;
-  size_t xlen = 0;               // doubles the exchange buffers (own_packed, h_packed) hold
-  int precision = 0;             // 0: fp64 throughout; 1: Hessian products in f32 on the matrix cores, f64 accumulation
-  unsigned lm_seq = 0;           // sequence numbers of solves published inside residual-sweep launches (never 0)
-  hipEvent_t li_ev = nullptr;    // marks the end of the residual sweep when a speculative Hessian sweep is queued behind it (LI host shells)
-  bool solve_timed_out = false;  // the last damping_iter failed because voxel workgroups gave up waiting for the in-launch solve
-  int fused_fallbacks = 0;       // times a call was transparently re-run with the solve as its own launch
-  vxba_allreduce_fn allreduce = nullptr;
-  void* allreduce_ctx = nullptr;
-  // direct RCCL path: entry points resolved from the librccl.so the process already uses
-  void* rccl_lib = nullptr;
-  ncclComm_t rccl_comm = nullptr;
-  ncclResult_t (*p_ncclAllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*p_ncclCommDestroy)(ncclComm_t) = nullptr;
-  // one-shot peer all-reduce over xGMI (vxba_peer_*): every rank's mailbox mapped into every other rank through hipIpc
-  struct Peer {
-    int nranks = 0, rank = 0;
-    size_t len = 0;                       // doubles per mailbox slot
-    double* box = nullptr;                // own mailbox: [2][len] f64 + flags [2][PEER_WGS] u64 + status u64 (fine-grained device memory)
-    void* opened[VXBA_PEER_MAX] = {};     // hipIpcOpenMemHandle results (own entry stays null)
-    double* boxes[VXBA_PEER_MAX] = {};    // mailbox of rank p as seen from this process
-    unsigned long long seq = 0;
-  } peer;
-  int profiling = 0;             // bit mask of kernel kinds to bracket with events: 1 K3, 2 K2, 4 K3 finalize, 8 K1
-  std::vector<EventPair> pending;
-  std::vector<hipEvent_t> free_events;
-  double ms_sum[4] = {0, 0, 0, 0};
-  int64_t calls[4] = {0, 0, 0, 0};
-  std::string err;
-  // The reference calls the two sweeps from several std::threads on one LidarFactor with disjoint [head,end)
-  // (voxel_map.hpp:318-332); entry points serialise on this lock so such callers stay correct.
-  std::recursive_mutex mtx;
-};
-
-namespace {
-
-#define VX_LOCK(f) std::unique_lock<std::recursive_mutex> lk__; if (f) lk__ = std::unique_lock<std::recursive_mutex>((f)->mtx)
-
-#define VX_HIP(f, call)                                                                              \
-  do {                                                                                               \
-    hipError_t e__ = (call);                                                                         \
-    if (e__ != hipSuccess) {                                                                         \
-      (f)->err = std::string(#call) + ": " + hipGetErrorString(e__);                                 \
-      return VXBA_ERR_HIP;                                                                           \
-    }                                                                                                \
-  } while (0)
+namespace vxc {
 
 int fail(vxba_factor* f, int code, const char* msg) {
   if (f) f->err = msg;
@@ -142,8 +12,6 @@ int fail(vxba_factor* f, int code, const char* msg) {
 int n_planes(const vxba_factor* f) { return (f->W > VXBA_MAX_WIN ? 0 : 10 * f->W) + N_META_PLANES; }   // wide factors keep their clusters in f->wstore
 // win_size above VXBA_MAX_WIN: the sparse-incidence sweeps of vxba_wide.hip and the host-side LM shell
 bool is_wide(const vxba_factor* f) { return f->W > VXBA_MAX_WIN; }
-#define VX_NARROW_ONLY(f, what) \
-  do { if (is_wide(f)) return fail(f, VXBA_ERR_UNSUPPORTED, what ": only for win_size <= VXBA_MAX_WIN"); } while (0)
 
 // exchange buffers sized for the current win_size: packed [Hess | JacT | residual] and, directly behind it, the scalar of the
 // residual sweep -- contiguous so that the sharded loop can reduce both with one collective
@@ -382,7 +250,7 @@ int upload_poses(vxba_factor* f, const double* Rp) {
 // LM mode (lm != nullptr): the sweep's prologue takes the pending accept/reject decision from ctl[*c] (and flips *c),
 // reads the poses from the control block and skips the work when the loop does not need it; Rp carries the restart poses.
 int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c, const vxk::LMPending* pend, int head, int end,
-                      double* d_out, const double* cache_src = nullptr) {
+                      double* d_out, const double* cache_src) {
   const size_t plen = vxba_packed_len(f);
   if (end == head) { VX_HIP(f, hipMemsetAsync(d_out, 0, plen * sizeof(double), f->stream)); return VXBA_OK; }
   if (is_wide(f)) {   // sparse-incidence sweep, host-driven LM only (lm == nullptr)
@@ -438,7 +306,7 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c
 // partials_to_host: the block partials go straight to mapped host memory (h_partial2) and no sum is launched -- the caller adds them up
 // with host_sum_partials once the sweep is done (d_out is ignored).
 int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int c, int head, int end, double* d_out,
-                          int* nparts_out = nullptr, unsigned fused_seq = 0, bool partials_to_host = false) {
+                          int* nparts_out, unsigned fused_seq, bool partials_to_host) {
   if (end == head) { if (d_out) VX_HIP(f, hipMemsetAsync(d_out, 0, sizeof(double), f->stream)); return VXBA_OK; }
   if (is_wide(f)) {
     if (lm || !Rp || !d_out) return fail(f, VXBA_ERR_UNSUPPORTED, "device-resident LM loop: only for win_size <= VXBA_MAX_WIN");
@@ -587,7 +455,8 @@ int append_meta(vxba_factor* f, int v0, int n, const double* fix, const double* 
   return VXBA_OK;
 }
 
-}  // namespace
+}  // namespace vxc
+using namespace vxc;
 
 extern "C" {
 
@@ -1450,488 +1319,6 @@ static int lm_steps_impl(vxba_factor* f, const double* Rp_init, int n_steps, int
   if (Rp_out) std::memcpy(Rp_out, st.x, sizeof(double) * 12 * W);
   if (last_resis) { last_resis[0] = st.residual1; last_resis[1] = st.residual2; }
   if (stats_out) { stats_out[0] = st.iter; stats_out[1] = st.n_accept; stats_out[2] = st.n_reject; }
-  return VXBA_OK;
-}
-
-// ---- inertial half (host) -------------------------------------------------------------------------------------
-int vxba_imu_init(double* imu, const double* bg, const double* ba) {
-  if (!imu) return VXBA_ERR_ARG;
-  vxi::imu_init(imu, bg, ba);
-  return VXBA_OK;
-}
-int vxba_imu_add(double* imu, const double* gyr, const double* acc, double dt, const double* noise_meas, const double* noise_walk) {
-  if (!imu || !gyr || !acc || !noise_meas || !noise_walk) return VXBA_ERR_ARG;
-  vxi::imu_add(imu, gyr, acc, dt, noise_meas, noise_walk);
-  return VXBA_OK;
-}
-int vxba_imu_evaluate(const double* imu, const double* st1, const double* st2, int jac_enable, double* jtj, double* gg, double* residual) {
-  if (!imu || !st1 || !st2 || !residual || (jac_enable && (!jtj || !gg))) return VXBA_ERR_ARG;
-  vxi::ImuWork w;
-  bool ok = true;
-  *residual = vxi::imu_evaluate(imu, st1, st2, jac_enable != 0, jtj, gg, w, &ok);
-  return ok ? VXBA_OK : VXBA_ERR_STATE;   // singular covariance (a factor without samples)
-}
-int vxba_imu_evaluate_g(const double* imu, const double* st1, const double* st2, int jac_enable, double* jtj, double* gg, double* residual) {
-  if (!imu || !st1 || !st2 || !residual || (jac_enable && (!jtj || !gg))) return VXBA_ERR_ARG;
-  vxi::ImuWork w;
-  bool ok = true;
-  *residual = vxi::imu_evaluate(imu, st1, st2, jac_enable != 0, jtj, gg, w, &ok, true);
-  return ok ? VXBA_OK : VXBA_ERR_STATE;
-}
-int vxba_imu_update_state(double* imu, const double* dxi15) {
-  if (!imu || !dxi15) return VXBA_ERR_ARG;
-  vxi::imu_update_state(imu, dxi15);
-  return VXBA_OK;
-}
-int vxba_hess_plus(int W, double* Hess15, double* JacT15, const double* Hess6, const double* JacT6) {
-  if (W < 1 || !Hess15 || !JacT15 || !Hess6 || !JacT6) return VXBA_ERR_ARG;
-  vxi::li_hess_plus(W, Hess15, JacT15, Hess6, JacT6);
-  return VXBA_OK;
-}
-
-namespace {
-void states_to_poses(int W, const double* states, double* Rp) {
-  for (int i = 0; i < W; i++) std::memcpy(Rp + 12 * i, states + vxi::STATE_LEN * i, sizeof(double) * 12);   // [R | p] lead the state
-}
-// divide_thread: the Hessian sweep is queued first, the IMU blocks are built on the host while it runs
-// completion of everything queued on the factor's stream, by polling: the sweeps are tens of microseconds, less than what waking
-// up from hipStreamSynchronize costs
-int wait_stream(vxba_factor* f) {
-  hipError_t q;
-  while ((q = hipStreamQuery(f->stream)) == hipErrorNotReady) {}
-  VX_HIP(f, q);
-  return VXBA_OK;
-}
-// spec_queued: the Hessian sweep at exactly these states was queued speculatively behind the last residual sweep (li_joint_residual)
-// and is running or done -- nothing to launch.  imu_ready: likewise the IMU half (see li_joint_residual); points to its residual.
-// while_sweeping (optional): called once the IMU blocks are in Hess / JacT and before the host starts waiting for the sweep -- the
-// LiDAR factor only adds to the pose-pose blocks afterwards, so everything else of the system is final at that point.
-int li_joint_system(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* Hess, double* JacT, double* residual,
-                    bool with_g = false, const double* cov_invs = nullptr, bool spec_queued = false, const std::function<void()>* while_sweeping = nullptr,
-                    const double* imu_ready = nullptr) {
-  const int W = f->W, n = vxi::DIM * W + (with_g ? 3 : 0), m = 6 * W;
-  std::vector<double> Rp(12 * W);
-  states_to_poses(W, states, Rp.data());
-  // single GPU: the reduction kernel writes the packed system straight into pinned host memory (no copy to enqueue) and the host
-  // polls for completion after its own half of the work; with a collective the reduced device buffer is copied as before
-  const bool zc = !has_collective(f);
-  int rc = VXBA_OK;
-  if (!(spec_queued && zc)) {
-    rc = sweep_hess_device(f, Rp.data(), nullptr, nullptr, nullptr, 0, f->V, zc ? f->zc_packed : f->d_packed);
-    if (rc) return rc;
-  }
-  if (!zc) VX_HIP(f, hipMemcpyAsync(f->h_packed, f->d_packed, vxba_packed_len(f) * sizeof(double), hipMemcpyDeviceToHost, f->stream));
-  vxi::ImuWork w;
-  bool ok = true;
-  double res;
-  if (imu_ready) res = *imu_ready;   // Hess / JacT already hold the IMU blocks at these states (built during the last residual sweep)
-  else {
-    std::memset(Hess, 0, sizeof(double) * n * n);
-    std::memset(JacT, 0, sizeof(double) * n);
-    res = vxi::li_add_imu_blocks(W, states, imus, imu_coef, true, Hess, JacT, w, &ok, with_g, cov_invs);
-  }
-  if (while_sweeping && ok) (*while_sweeping)();
-  const auto t_w0 = std::chrono::steady_clock::now();
-  rc = wait_stream(f);
-  f->li_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_w0).count();
-  if (rc) return rc;
-  if (!ok) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
-  vxi::li_hess_plus(W, Hess, JacT, f->h_packed, f->h_packed + (size_t)m * m, n);
-  *residual = res + f->h_packed[(size_t)m * m + m];
-  return VXBA_OK;
-}
-// sum_partials_kernel on the host, same order (thread t of 1024 adds the partials t, t + 1024, ...; then the halving tree): bitwise the
-// value the device reduction gives
-double host_sum_partials(const double* p, int n) {
-  double red[1024];
-  for (int t = 0; t < 1024; t++) {
-    double s = 0.0;
-    for (int k = t; k < n; k += 1024) s += p[k];
-    red[t] = s;
-  }
-  for (int off = 512; off > 0; off >>= 1)
-    for (int t = 0; t < off; t++) red[t] += red[t + off];
-  return red[0];
-}
-// speculate (single GPU only): the Hessian sweep of the NEXT iteration -- at these trial states, on the cache this residual sweep leaves
-// -- is queued right behind it, before anybody knows whether the step will be accepted.  The host only waits for the residual (an
-// event), takes the decision, and if the step is accepted finds the next joint system already under way instead of paying a cold
-// launch and a round trip for it; a rejected step wastes the sweep (upstream recomputes nothing then either).
-// next_Hess / next_JacT (with speculate): while the host would otherwise only poll for the sweep, it builds the IMU half of the NEXT joint
-// system at these trial states (the inertial residual falls out of the same evaluation); *imu_residual receives the IMU part alone.
-int li_joint_residual(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* residual,
-                      const double* cov_invs = nullptr, bool speculate = false, double* next_Hess = nullptr, double* next_JacT = nullptr, bool with_g = false,
-                      double* imu_residual = nullptr) {
-  const int W = f->W;
-  std::vector<double> Rp(12 * W);
-  states_to_poses(W, states, Rp.data());
-  const bool zc = !has_collective(f);
-  const size_t plen = vxba_packed_len(f);
-  // single GPU: the sweep writes its block partials straight into mapped host memory and the host adds them up (one launch less)
-  int nparts = 0;
-  int rc = sweep_residual_device(f, Rp.data(), nullptr, 0, 0, f->V, zc ? f->zc_packed + plen : f->d_scalar, &nparts, 0, zc);
-  if (rc) return rc;
-  if (!zc) VX_HIP(f, hipMemcpyAsync(f->h_scalar, f->d_scalar, sizeof(double), hipMemcpyDeviceToHost, f->stream));
-  const bool spec = speculate && zc;
-  if (spec) {
-    if (!f->li_ev) VX_HIP(f, hipEventCreateWithFlags(&f->li_ev, hipEventDisableTiming));
-    VX_HIP(f, hipEventRecord(f->li_ev, f->stream));
-    rc = sweep_hess_device(f, Rp.data(), nullptr, nullptr, nullptr, 0, f->V, f->zc_packed);
-    if (rc) return rc;
-  }
-  vxi::ImuWork w;
-  bool ok = true;
-  double r1;
-  if (spec && next_Hess && next_JacT) {
-    const int n = vxi::DIM * W + (with_g ? 3 : 0);
-    std::memset(next_Hess, 0, sizeof(double) * n * n);
-    std::memset(next_JacT, 0, sizeof(double) * n);
-    r1 = vxi::li_add_imu_blocks(W, states, imus, imu_coef, true, next_Hess, next_JacT, w, &ok, with_g, cov_invs);
-  } else {
-    r1 = vxi::li_add_imu_blocks(W, states, imus, imu_coef, false, nullptr, nullptr, w, &ok, false, cov_invs);
-  }
-  if (imu_residual) *imu_residual = r1;
-  if (spec) {
-    hipError_t q;
-    while ((q = hipEventQuery(f->li_ev)) == hipErrorNotReady) {}
-    VX_HIP(f, q);
-  } else {
-    rc = wait_stream(f);
-  }
-  if (rc) return rc;
-  if (!ok) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
-  *residual = r1 + (zc ? host_sum_partials(f->h_partial2, nparts) : f->h_scalar[0]);
-  return VXBA_OK;
-}
-}  // namespace
-
-int vxba_li_evaluate(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* Hess, double* JacT, double* residual) {
-  VX_LOCK(f);
-  if (!f || !states || (!imus && f->W > 1) || !Hess || !JacT || !residual) return fail(f, VXBA_ERR_ARG, "li_evaluate: null argument");
-  if (f->V == 0) return fail(f, VXBA_ERR_STATE, "li_evaluate on an empty factor");
-  VX_NARROW_ONLY(f, "li_evaluate");
-  hipSetDevice(f->device);
-  return li_joint_system(f, states, imus, imu_coef, Hess, JacT, residual);
-}
-int vxba_li_only_residual(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* residual) {
-  VX_LOCK(f);
-  if (!f || !states || (!imus && f->W > 1) || !residual) return fail(f, VXBA_ERR_ARG, "li_only_residual: null argument");
-  if (f->V == 0) return fail(f, VXBA_ERR_STATE, "li_only_residual on an empty factor");
-  VX_NARROW_ONLY(f, "li_only_residual");
-  hipSetDevice(f->device);
-  return li_joint_residual(f, states, imus, imu_coef, residual);
-}
-
-// LI_BA_Optimizer::damping_iter (voxel_map.hpp:562-653): the voxel sweeps on the GPU, the 15W-dimensional shell on the host.
-// LI_BA_Optimizer::damping_iter with the whole loop on the device (vxba_li_device.hip): per iteration IMU factors -> Hessian sweep ->
-// joint system -> Schur solve + trial state -> residual sweep + IMU residuals -> accept / reject, all enqueued up front; one D2H at the end.
-// Single GPU, win_size <= VXBA_MAX_WIN.
-static int li_damping_iter_device(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out, double* trace_out, int* n_trace,
-                           const double* cov_invs) {
-  const int W = f->W, n = vxi::DIM * W;
-  if (max_iter > vxk::LM_MAX_ITER) max_iter = vxk::LM_MAX_ITER;
-  if (!f->d_li) {
-    VX_HIP(f, hipMalloc((void**)&f->d_li, sizeof(vxli::LIState)));
-    VX_HIP(f, hipMalloc((void**)&f->d_li_hess, sizeof(double) * 225 * vxli::LI_MAXW * vxli::LI_MAXW));
-  }
-  int rc = ensure_exchange(f);
-  if (rc) return rc;
-  vxli::LIState* li = f->d_li;
-  hipStream_t s = f->stream;
-  VX_HIP(f, hipMemcpyAsync(li->states, states, sizeof(double) * vxi::STATE_LEN * W, hipMemcpyHostToDevice, s));
-  if (W > 1) {
-    VX_HIP(f, hipMemcpyAsync(li->imus, imus, sizeof(double) * vxi::IMU_LEN * (W - 1), hipMemcpyHostToDevice, s));
-    VX_HIP(f, hipMemcpyAsync(li->cov_inv, cov_invs, sizeof(double) * 225 * (W - 1), hipMemcpyHostToDevice, s));
-  }
-  vxli::launch_li_init(li, f->d_lm, W, imu_coef, s);
-  vxk::LMPending none;
-  std::memset(&none, 0, sizeof none);
-  for (int it = 0; it < max_iter; it++) {
-    int c = 0;
-    vxli::launch_li_imu(li, W, 0, s);
-    rc = sweep_hess_device(f, nullptr, f->d_lm, &c, &none, 0, f->V, f->d_packed);
-    if (rc) return rc;
-    vxli::launch_li_assemble(li, f->d_packed, W, hess_out ? f->d_li_hess : nullptr, s);
-    vxli::launch_li_solve(li, f->d_lm, W, s);
-    int nparts = 0;
-    rc = sweep_residual_device(f, nullptr, f->d_lm, 0, 0, f->V, nullptr, &nparts, 0);
-    if (rc) return rc;
-    vxli::launch_li_imu(li, W, 1, s);
-    vxli::launch_li_decide(li, f->d_lm, f->d_partial2, nparts, W, s);
-  }
-  VX_HIP(f, hipGetLastError());
-  // results: states, factors (their dbg / dba bookkeeping moved), trace, iteration count, *hess
-  struct Tail { double u, v, residual1, residual2, q1, imu_coef; int calc_hess, done, iter, pad; } tail;
-  std::vector<double> tr((size_t)vxk::LM_MAX_ITER * 8);
-  VX_HIP(f, hipMemcpyAsync(states, li->states, sizeof(double) * vxi::STATE_LEN * W, hipMemcpyDeviceToHost, s));
-  if (W > 1) VX_HIP(f, hipMemcpyAsync(imus, li->imus, sizeof(double) * vxi::IMU_LEN * (W - 1), hipMemcpyDeviceToHost, s));
-  VX_HIP(f, hipMemcpyAsync(&tail, &li->u, sizeof tail, hipMemcpyDeviceToHost, s));
-  VX_HIP(f, hipMemcpyAsync(tr.data(), li->trace, sizeof(double) * 8 * max_iter, hipMemcpyDeviceToHost, s));
-  if (hess_out) VX_HIP(f, hipMemcpyAsync(hess_out, f->d_li_hess, sizeof(double) * n * n, hipMemcpyDeviceToHost, s));
-  VX_HIP(f, hipStreamSynchronize(s));
-  if (trace_out) std::memcpy(trace_out, tr.data(), sizeof(double) * 8 * tail.iter);
-  if (n_trace) *n_trace = tail.iter;
-  if (getenv("VXBA_LI_DBG")) {   // development: phases of the last solve kernel, shader clocks
-    long long d[16];
-    if (hipMemcpy(d, li->dbg, sizeof d, hipMemcpyDeviceToHost) == hipSuccess)
-      std::fprintf(stderr, "[vxba li solve] stage %lld thomas-fwd %lld thomas-bwd %lld schur %lld dense %lld dy %lld q1 %lld update %lld\n", d[1] - d[0], d[2] - d[1], d[3] - d[2],
-                   d[4] - d[3], d[5] - d[4], d[6] - d[5], 0ll, d[7] - d[6]);
-  }
-  return VXBA_OK;
-}
-
-int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out, double* trace_out,
-                         int* n_trace) {
-  VX_LOCK(f);
-  if (!f || !states || (!imus && f->W > 1) || max_iter < 0) return fail(f, VXBA_ERR_ARG, "li_damping_iter: bad argument");
-  if (f->V == 0) return fail(f, VXBA_ERR_STATE, "li_damping_iter on an empty factor");
-  VX_NARROW_ONLY(f, "li_damping_iter");
-  hipSetDevice(f->device);
-  const int W = f->W, n = vxi::DIM * W, SL = vxi::STATE_LEN;
-  double u = 0.01, v = 2;
-  const auto t_call0 = std::chrono::steady_clock::now();
-  const bool device_loop = f->opt[VXBA_OPT_LI_DEVICE_LOOP] != 0 && !has_collective(f);   // sharded runs keep the host shell
-  // the first Hessian sweep goes out before any host-side preparation (covariance inverses, buffers): it needs the poses only
-  bool first_sweep_queued = false;
-  if (!device_loop && max_iter > 0 && !has_collective(f)) {
-    double Rp0[12 * VXBA_MAX_WIN];
-    states_to_poses(W, states, Rp0);
-    int rc = sweep_hess_device(f, Rp0, nullptr, nullptr, nullptr, 0, f->V, f->zc_packed);
-    if (rc) return rc;
-    first_sweep_queued = true;
-  }
-  f->li.size(n, W > 1 ? W - 1 : 0);
-  std::vector<double>&Hess = f->li.Hess, &A = f->li.A, &JacT = f->li.JacT, &D = f->li.D, &rhs = f->li.rhs, &dxi = f->li.dxi, &work = f->li.work;
-  std::vector<double>&HessN = f->li.HessN, &JacTN = f->li.JacTN;   // IMU half of the next joint system (speculative, see li_joint_residual)
-  std::vector<double>& cov_invs = f->li.cov_invs;                   // cov is constant during the loop: invert once
-  std::vector<int>& perm = f->li.perm;
-  std::vector<double> x_temp(states, states + (size_t)SL * W);
-  if (!vxi::li_invert_covariances(W, imus, cov_invs.data())) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
-  if (device_loop) return li_damping_iter_device(f, states, imus, imu_coef, max_iter, hess_out, trace_out, n_trace, cov_invs.data());
-  double residual1 = 0, residual2 = 0;
-  bool is_calc_hess = true;
-  int nt = 0;
-  vxh::LiIndexSets li_sets;
-  vxh::BandSchurWork& bs_work = f->li_bs;
-  bool spec_queued = false;
-  double imu_res_next = 0.0;
-  const double* last_hess = nullptr;   // buffer that holds the last complete joint Hessian (*hess = Hess, :588): copied out once, at the end
-  // development aid: VXBA_LI_TIMING=1 prints where the host time of one call goes
-  static const bool timing = [] { const char* e = getenv("VXBA_LI_TIMING"); return e && e[0] == '1'; }();
-  double t_sys = 0, t_solve = 0, t_res = 0;
-  const double wait0 = f->li_wait_us;
-  auto now = [] { return std::chrono::steady_clock::now(); };
-  auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-  for (int it = 0; it < max_iter; it++) {
-    const bool recomputed = is_calc_hess;
-    const auto t0 = now();
-    bool prepared = false;
-    if (is_calc_hess) {
-      // the band half of the structured solve needs nothing from the LiDAR factor: it runs while the GPU is still sweeping
-      const std::function<void()> band_half = [&]() {
-        const int g = vxi::DIM, m = n - g;
-        if (m <= 0 || !f->opt[VXBA_OPT_LI_STRUCTURED_SOLVE]) return;
-        if (li_sets.Y.empty()) li_sets = vxh::li_index_sets(W - 1, 0, 0);
-        for (int y : li_sets.Y) { rhs[y] = -JacT[y + g]; work[y] = u * Hess[(size_t)(y + g) * n + y + g]; }
-        prepared = vxh::band_schur_prepare(&Hess[(size_t)g * n + g], n, work.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(),
-                                           (int)li_sets.X.size(), li_sets.xlo.data(), bs_work);
-      };
-      int rc = li_joint_system(f, states, imus, imu_coef, Hess.data(), JacT.data(), &residual1, false, cov_invs.data(), spec_queued || first_sweep_queued, &band_half,
-                               spec_queued ? &imu_res_next : nullptr);
-      spec_queued = false; first_sweep_queued = false;
-      if (rc) return rc;
-      last_hess = Hess.data();   // *hess = Hess, before the gauge fix (:588) -- this shell never modifies the matrix
-    }
-    const auto t1 = now();
-    // gauge: frame 0's 15 rows / columns become identity rows with a zero right-hand side (:591-594): dxi = 0 there and they couple
-    // to nothing, so the solve simply works on the trailing (n - 15) block of Hess (same solution, 27 % fewer flops at W = 10) --
-    // in place: neither the gauge rows nor a damped copy of the matrix are written out unless the dense fallback needs one
-    for (int r = 0; r < n; r++) D[r] = r < vxi::DIM ? 1.0 : Hess[(size_t)r * n + r];
-    for (int r = 0; r < vxi::DIM; r++) JacT[r] = 0.0;
-    {
-      const int g = vxi::DIM, m = n - g;
-      for (int r = 0; r < m; r++) { rhs[r] = -JacT[r + g]; work[r] = u * D[r + g]; }     // work: the damping u D on the diagonal
-      for (int r = 0; r < g; r++) dxi[r] = 0.0;
-      // band Cholesky of the velocity / bias part + Schur complement onto the poses (vxba_host.hpp); dense pivoted LDL^T if a band
-      // pivot is not positive (or the option is off)
-      bool solved = false;
-      if (m > 0 && f->opt[VXBA_OPT_LI_STRUCTURED_SOLVE]) {
-        if (li_sets.Y.empty()) li_sets = vxh::li_index_sets(W - 1, 0, 0);
-        // after a rejected step (same system, new damping) both halves run here
-        solved = prepared || vxh::band_schur_prepare(&Hess[(size_t)g * n + g], n, work.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw,
-                                                     li_sets.X.data(), (int)li_sets.X.size(), li_sets.xlo.data(), bs_work);
-        if (solved)
-          vxh::band_schur_finish(&Hess[(size_t)g * n + g], n, work.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(),
-                                 (int)li_sets.X.size(), dxi.data() + g, bs_work);
-      }
-      if (m > 0 && !solved) {
-        A.resize((size_t)n * n);
-        for (int c = 0; c < m; c++) std::memcpy(&A[(size_t)c * m], &Hess[(size_t)(c + g) * n + g], sizeof(double) * m);
-        for (int r = 0; r < m; r++) A[(size_t)r * m + r] += u * D[r + g];
-        vxh::ldlt_solve_inplace(m, A.data(), rhs.data(), dxi.data() + g, perm.data(), work.data());
-      }
-    }
-    // trial state (:599-606) and the factors' bias deltas (:608-609)
-    for (int j = 0; j < W; j++) {
-      const double* d = &dxi[(size_t)vxi::DIM * j];
-      const double* s = states + (size_t)SL * j;
-      double* t = &x_temp[(size_t)SL * j];
-      vxh::right_multiply_exp(s, d, t);
-      for (int k = 0; k < 12; k++) t[9 + k] = s[9 + k] + d[3 + k];   // p, v, bg, ba
-      for (int k = 0; k < 3; k++) t[21 + k] = s[21 + k];             // g is not optimised
-    }
-    for (int j = 0; j < W - 1; j++) vxi::imu_update_state(imus + (size_t)vxi::IMU_LEN * j, &dxi[(size_t)vxi::DIM * j]);
-    double q1 = 0.0;
-    for (int r = 0; r < n; r++) q1 += dxi[r] * (u * D[r] * dxi[r] - JacT[r]);
-    q1 *= 0.5;
-    const auto t2 = now();
-    const bool speculate = it + 1 < max_iter && !has_collective(f);
-    int rc = li_joint_residual(f, x_temp.data(), imus, imu_coef, &residual2, cov_invs.data(), speculate, HessN.data(), JacTN.data(), false, &imu_res_next);
-    if (rc) return rc;
-    spec_queued = speculate;     // only meaningful if the step is accepted (states <- x_temp); a rejected step never asks for the system
-    const auto t3 = now();
-    t_sys += us(t0, t1); t_solve += us(t1, t2); t_res += us(t2, t3);
-    const double q = residual1 - residual2;
-    const double u_used = u, v_used = v;
-    const bool accepted = vxh::lm_update_damping(residual1, residual2, q1, u, v);
-    if (accepted) {
-      std::memcpy(states, x_temp.data(), sizeof(double) * SL * W);
-      is_calc_hess = true;
-      if (spec_queued) { Hess.swap(HessN); JacT.swap(JacTN); }   // the IMU half of the next system, built during the residual sweep
-    } else {
-      is_calc_hess = false;
-      for (int j = 0; j < W - 1; j++) vxi::imu_rollback(imus + (size_t)vxi::IMU_LEN * j);
-    }
-    if (trace_out) {
-      double* o = trace_out + (size_t)VXBA_TRACE_COLS * nt;
-      o[0] = residual1; o[1] = residual2; o[2] = u_used; o[3] = v_used; o[4] = q; o[5] = q1; o[6] = accepted; o[7] = recomputed;
-    }
-    nt++;
-    if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
-  }
-  if (n_trace) *n_trace = nt;
-  if (hess_out && last_hess) std::memcpy(hess_out, last_hess, sizeof(double) * n * n);
-  if (timing) std::fprintf(stderr, "[vxba li] %d iterations, %.0f us in the call: joint system %.0f us (of which waiting for the sweep %.0f), solve+update %.0f us, joint residual %.0f us\n", nt, us(t_call0, now()), t_sys, f->li_wait_us - wait0, t_solve, t_res);
-  return VXBA_OK;
-}
-
-// LI_BA_OptimizerGravity::damping_iter (voxel_map.hpp:775-862): three gravity unknowns at the tail, only frame 0's pose
-// is gauge-fixed.  The trial state is never reset from the accepted one upstream (x_stats_temp, :813): the gravity of a
-// rejected trial stays and the next increment lands on top of it -- kept.
-int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out,
-                                 double* resis_out, double* trace_out, int* n_trace) {
-  VX_LOCK(f);
-  if (!f || !states || (!imus && f->W > 1) || max_iter < 0) return fail(f, VXBA_ERR_ARG, "li_damping_iter_gravity: bad argument");
-  if (f->V == 0) return fail(f, VXBA_ERR_STATE, "li_damping_iter_gravity on an empty factor");
-  VX_NARROW_ONLY(f, "li_damping_iter_gravity");
-  hipSetDevice(f->device);
-  const int W = f->W, n = vxi::DIM * W + 3, SL = vxi::STATE_LEN;
-  double u = 0.01, v = 2;
-  bool first_sweep_queued = false;   // as in vxba_li_damping_iter: the first sweep runs under the host-side preparation
-  if (max_iter > 0 && !has_collective(f)) {
-    double Rp0[12 * VXBA_MAX_WIN];
-    states_to_poses(W, states, Rp0);
-    int rc = sweep_hess_device(f, Rp0, nullptr, nullptr, nullptr, 0, f->V, f->zc_packed);
-    if (rc) return rc;
-    first_sweep_queued = true;
-  }
-  f->li.size(n, W > 1 ? W - 1 : 0);
-  std::vector<double>&Hess = f->li.Hess, &A = f->li.A, &JacT = f->li.JacT, &D = f->li.D, &rhs = f->li.rhs, &dxi = f->li.dxi, &work = f->li.work;
-  std::vector<double>&HessN = f->li.HessN, &JacTN = f->li.JacTN;   // IMU half of the next joint system (speculative, see li_joint_residual)
-  std::vector<double>& cov_invs = f->li.cov_invs;
-  std::vector<int>& perm = f->li.perm;
-  std::vector<double> x_temp(states, states + (size_t)SL * W);
-  if (!vxi::li_invert_covariances(W, imus, cov_invs.data())) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
-  double residual1 = 0, residual2 = 0;
-  bool is_calc_hess = true;
-  int nt = 0;
-  vxh::LiIndexSets li_sets;
-  vxh::BandSchurWork& bs_work = f->li_bs;
-  bool spec_queued = false;
-  double imu_res_next = 0.0;
-  const double* last_hess = nullptr;   // buffer that holds the last complete joint Hessian: copied out once, at the end
-  for (int it = 0; it < max_iter; it++) {
-    const bool recomputed = is_calc_hess;
-    bool prepared = false;
-    const int mr = n - 6;   // without the six gauge rows (identity, dxi = 0): [v, bg, ba of frame 0 | frames 1 .. W-1 | g]
-    const bool structured = f->opt[VXBA_OPT_LI_STRUCTURED_SOLVE] && W > 1;
-    if (structured && li_sets.Y.empty()) li_sets = vxh::li_index_sets(W - 1, 9, 3);
-    if (is_calc_hess) {
-      // the band half of the structured solve (velocities / biases: IMU terms only) runs while the GPU is still sweeping
-      const std::function<void()> band_half = [&]() {
-        if (!structured) return;
-        for (int y : li_sets.Y) { rhs[y] = -JacT[y + 6]; work[y] = u * Hess[(size_t)(y + 6) * n + y + 6]; }
-        prepared = vxh::band_schur_prepare(&Hess[(size_t)6 * n + 6], n, work.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(),
-                                           (int)li_sets.X.size(), li_sets.xlo.data(), bs_work);
-      };
-      int rc = li_joint_system(f, states, imus, imu_coef, Hess.data(), JacT.data(), &residual1, true, cov_invs.data(), spec_queued || first_sweep_queued, &band_half,
-                               spec_queued ? &imu_res_next : nullptr);
-      spec_queued = false; first_sweep_queued = false;
-      if (rc) return rc;
-      last_hess = Hess.data();
-    }
-    if (it == 0 && resis_out) resis_out[0] = residual1;
-    // gauge (:801-806): the pose of frame 0 -- identity rows with a zero right-hand side.  The matrix itself is left alone (the
-    // structured solve works on the block behind those rows, the dense fallback applies them to its copy): *hess is copied out once
-    for (int r = 0; r < 6; r++) JacT[r] = 0.0;
-    for (int r = 0; r < n; r++) D[r] = r < 6 ? 1.0 : Hess[(size_t)r * n + r];
-    bool solved = false;
-    if (structured) {
-      // in place on the trailing block of Hess (the gauge rows / columns lie outside it), damping handed over separately
-      for (int r = 0; r < mr; r++) { work[r] = u * D[r + 6]; rhs[r] = -JacT[r + 6]; }
-      for (int r = 0; r < 6; r++) dxi[r] = 0.0;
-      solved = prepared || vxh::band_schur_prepare(&Hess[(size_t)6 * n + 6], n, work.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw,
-                                                   li_sets.X.data(), (int)li_sets.X.size(), li_sets.xlo.data(), bs_work);
-      if (solved)
-        vxh::band_schur_finish(&Hess[(size_t)6 * n + 6], n, work.data(), rhs.data(), li_sets.Y.data(), (int)li_sets.Y.size(), li_sets.bw, li_sets.X.data(),
-                               (int)li_sets.X.size(), dxi.data() + 6, bs_work);
-    }
-    if (!solved) {
-      A = Hess;
-      for (int c = 0; c < n; c++)
-        for (int r = 0; r < 6; r++) { A[(size_t)c * n + r] = 0.0; A[(size_t)r * n + c] = 0.0; }
-      for (int r = 0; r < 6; r++) A[(size_t)r * n + r] = 1.0;
-      for (int r = 0; r < n; r++) { A[(size_t)r * n + r] += u * D[r]; rhs[r] = -JacT[r]; }
-      vxh::ldlt_solve_inplace(n, A.data(), rhs.data(), dxi.data(), perm.data(), work.data());
-    }
-    for (int k = 0; k < 3; k++) x_temp[21 + k] += dxi[n - 3 + k];                 // x_stats_temp[0].g += dxi.tail(3)
-    for (int j = 0; j < W; j++) {
-      const double* d = &dxi[(size_t)vxi::DIM * j];
-      const double* s = states + (size_t)SL * j;
-      double* t = &x_temp[(size_t)SL * j];
-      vxh::right_multiply_exp(s, d, t);
-      for (int k = 0; k < 12; k++) t[9 + k] = s[9 + k] + d[3 + k];
-      for (int k = 0; k < 3; k++) t[21 + k] = x_temp[21 + k];
-    }
-    for (int j = 0; j < W - 1; j++) vxi::imu_update_state(imus + (size_t)vxi::IMU_LEN * j, &dxi[(size_t)vxi::DIM * j]);
-    double q1 = 0.0;
-    for (int r = 0; r < n; r++) q1 += dxi[r] * (u * D[r] * dxi[r] - JacT[r]);
-    q1 *= 0.5;
-    const bool speculate = it + 1 < max_iter && !has_collective(f);
-    int rc = li_joint_residual(f, x_temp.data(), imus, imu_coef, &residual2, cov_invs.data(), speculate, HessN.data(), JacTN.data(), true, &imu_res_next);
-    spec_queued = speculate;
-    if (rc) return rc;
-    const double q = residual1 - residual2;
-    const double u_used = u, v_used = v;
-    const bool accepted = vxh::lm_update_damping(residual1, residual2, q1, u, v);
-    if (accepted) {
-      std::memcpy(states, x_temp.data(), sizeof(double) * SL * W);
-      is_calc_hess = true;
-      if (spec_queued) { Hess.swap(HessN); JacT.swap(JacTN); }   // the IMU half of the next system, built during the residual sweep
-    } else {
-      is_calc_hess = false;
-      for (int j = 0; j < W - 1; j++) vxi::imu_rollback(imus + (size_t)vxi::IMU_LEN * j);
-    }
-    if (trace_out) {
-      double* o = trace_out + (size_t)VXBA_TRACE_COLS * nt;
-      o[0] = residual1; o[1] = residual2; o[2] = u_used; o[3] = v_used; o[4] = q; o[5] = q1; o[6] = accepted; o[7] = recomputed;
-    }
-    nt++;
-    if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
-  }
-  if (resis_out) resis_out[1] = residual2;
-  if (n_trace) *n_trace = nt;
-  if (hess_out && last_hess) std::memcpy(hess_out, last_hess, sizeof(double) * n * n);
   return VXBA_OK;
 }
 

@@ -1,0 +1,153 @@
+// The factor object behind the C ABI (include/vxba.h) and what the translation units of the ABI share: vxba_capi.hip (storage, sweeps,
+// the LiDAR-only LM shell, options, measurement) and vxba_capi_li.hip (the inertial half: IMU_PRE wrappers, the LiDAR-inertial shells).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vxba.h"
+#include "vxba_host.hpp"
+#include "vxba_imu.hpp"
+#include "vxba_voxelize.h"
+#include "vxba_wide.h"
+#include "vxba_li_device.h"
+#include "vxba_scratch.hpp"
+#include "vxba_internal.h"
+#include "vxba_kernels.h"
+
+using vxk::FactorView;
+using vxk::PoseArg;
+
+namespace vxc {
+
+constexpr int N_META_PLANES = 10 + 1 + 3 + 9 + 10 + 4;  // fix, coe, eigval, eigvec, merged, aux
+constexpr int N_CACHE_PLANES = 3 + 9 + 10 + 4;          // eigval, eigvec, merged, aux (contiguous at the tail)
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+}  // namespace vxc
+using vxc::EventPair;
+using vxc::N_META_PLANES;
+using vxc::N_CACHE_PLANES;
+
+struct vxba_factor {
+  int W = 0, device = 0;
+  int V = 0;        // voxels in the factor
+  int VS = 0;       // plane stride (capacity, multiple of 64)
+  int cus = 0;
+  hipStream_t stream = nullptr, own_stream = nullptr;
+  double* planes = nullptr;      // [(10W + N_META_PLANES)][VS]
+  double* clb = nullptr;         // batch-major copy of the clusters for the Hessian sweep
+  double* snapshot = nullptr;    // [N_CACHE_PLANES][snapshot_vs]
+  int snapshot_vs = 0, snapshot_v = 0;
+  double* staging = nullptr;     // device scratch for uploads / read-backs
+  size_t staging_len = 0;
+  double* d_partial3 = nullptr;  // K3 workgroup partials
+  size_t partial3_len = 0;
+  double* d_partial2 = nullptr;  // K2 wave partials
+  double* h_partial2 = nullptr;  // the same in mapped host memory (LI shells: the host adds the partials up itself), zc_partial2 = its device address
+  double* zc_partial2 = nullptr;
+  size_t partial2_len = 0;
+  double* d_packed = nullptr;    // [Hess | JacT | residual] (points at own_packed or a caller buffer)
+  double* d_scalar = nullptr;
+  double* own_packed = nullptr;
+  double* own_scalar = nullptr;
+  unsigned long long* d_count = nullptr;
+  double* h_packed = nullptr;    // pinned, mapped
+  double* zc_packed = nullptr;   // device alias of h_packed: kernels of host-driven loops write their result straight into host memory
+  double* h_scalar = nullptr;    // pinned
+  vxk::LMState* d_lm = nullptr;  // device-resident LM shell state
+  char* d_scratch = nullptr;     // grow-only device scratch of the batch factor construction (staging of points and accepted voxels)
+  size_t scratch_cap = 0;
+  vxli::LIState* d_li = nullptr; // device-resident LiDAR-inertial loop state (allocated on first use)
+  double* d_li_hess = nullptr;   // (15W)^2 export of that loop's *hess
+  vxk::LMState* h_lm = nullptr;  // pinned read-back copy
+  vxw::DenseSolver* wide_solver = nullptr;   // wide windows: device Cholesky of the (6W)-dimensional LM step (vxba_wide.hip)
+  bool wide_solver_tried = false;
+  double li_wait_us = 0;         // development (VXBA_LI_TIMING): time the LI shells spent waiting for the Hessian sweep
+  struct LiScratch {             // host buffers of the LI shells, kept between calls (four (15W)^2 matrices: allocating and zeroing them
+    std::vector<double> Hess, HessN, A, JacT, JacTN, D, rhs, dxi, work, cov_invs;   // cost ~15 us of a ~300 us call)
+    std::vector<int> perm;
+    void size(int n, int nfac) {
+      Hess.resize((size_t)n * n); HessN.resize((size_t)n * n); JacT.resize(n); JacTN.resize(n); D.resize(n); rhs.resize(n); dxi.resize(n);
+      work.resize(n); perm.resize(n); cov_invs.resize((size_t)225 * nfac);
+    }
+  } li;
+  vxh::BandSchurWork li_bs;
+  int opt[VXBA_OPT_COUNT] = {1, 1, 1, 0, 64, 0, 1};   // vxba_set_option; initial values may come from the environment (see vxba.h)
+  vxw::WideStore wstore;         // wide windows: the clusters, compressed rows over the observed (voxel, frame) entries (no cluster planes)
+  vxw::WideIndex wide;           // wide windows: incidence structure (entries, entry pairs per Hessian block), rebuilt after a push
+  bool wide_dirty = true;
+  double* d_poses = nullptr;     // wide windows: W*12 poses on the device (the MFMA kernels take them by value)
+  double* h_poses = nullptr;     // pinned staging for the above: a ring of POSE_SLOTS slots, each guarded by an event
+  hipEvent_t pose_ev[8] = {};
+  unsigned pose_slot = 0;
+  size_t xlen = 0;               // doubles the exchange buffers (own_packed, h_packed) hold
+  int precision = 0;             // 0: fp64 throughout; 1: Hessian products in f32 on the matrix cores, f64 accumulation
+  unsigned lm_seq = 0;           // sequence numbers of solves published inside residual-sweep launches (never 0)
+  hipEvent_t li_ev = nullptr;    // marks the end of the residual sweep when a speculative Hessian sweep is queued behind it (LI host shells)
+  bool solve_timed_out = false;  // the last damping_iter failed because voxel workgroups gave up waiting for the in-launch solve
+  int fused_fallbacks = 0;       // times a call was transparently re-run with the solve as its own launch
+  vxba_allreduce_fn allreduce = nullptr;
+  void* allreduce_ctx = nullptr;
+  // direct RCCL path: entry points resolved from the librccl.so the process already uses
+  void* rccl_lib = nullptr;
+  ncclComm_t rccl_comm = nullptr;
+  ncclResult_t (*p_ncclAllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*p_ncclCommDestroy)(ncclComm_t) = nullptr;
+  // one-shot peer all-reduce over xGMI (vxba_peer_*): every rank's mailbox mapped into every other rank through hipIpc
+  struct Peer {
+    int nranks = 0, rank = 0;
+    size_t len = 0;                       // doubles per mailbox slot
+    double* box = nullptr;                // own mailbox: [2][len] f64 + flags [2][PEER_WGS] u64 + status u64 (fine-grained device memory)
+    void* opened[VXBA_PEER_MAX] = {};     // hipIpcOpenMemHandle results (own entry stays null)
+    double* boxes[VXBA_PEER_MAX] = {};    // mailbox of rank p as seen from this process
+    unsigned long long seq = 0;
+  } peer;
+  int profiling = 0;             // bit mask of kernel kinds to bracket with events: 1 K3, 2 K2, 4 K3 finalize, 8 K1
+  std::vector<EventPair> pending;
+  std::vector<hipEvent_t> free_events;
+  double ms_sum[4] = {0, 0, 0, 0};
+  int64_t calls[4] = {0, 0, 0, 0};
+  std::string err;
+  // The reference calls the two sweeps from several std::threads on one LidarFactor with disjoint [head,end)
+  // (voxel_map.hpp:318-332); entry points serialise on this lock so such callers stay correct.
+  std::recursive_mutex mtx;
+};
+
+#define VX_LOCK(f) std::unique_lock<std::recursive_mutex> lk__; if (f) lk__ = std::unique_lock<std::recursive_mutex>((f)->mtx)
+
+#define VX_HIP(f, call)                                                                              \
+  do {                                                                                               \
+    hipError_t e__ = (call);                                                                         \
+    if (e__ != hipSuccess) {                                                                         \
+      (f)->err = std::string(#call) + ": " + hipGetErrorString(e__);                                 \
+      return VXBA_ERR_HIP;                                                                           \
+    }                                                                                                \
+  } while (0)
+#define VX_NARROW_ONLY(f, what) \
+  do { if (vxc::is_wide(f)) return vxc::fail(f, VXBA_ERR_UNSUPPORTED, what ": only for win_size <= VXBA_MAX_WIN"); } while (0)
+
+namespace vxc {
+// helpers defined in vxba_capi.hip
+int fail(vxba_factor* f, int code, const char* msg);
+bool is_wide(const vxba_factor* f);
+bool has_collective(const vxba_factor* f);
+vxk::FactorView view(const vxba_factor* f);
+int ensure_exchange(vxba_factor* f);
+// asynchronous sweeps on f->stream, results in device (or mapped host) memory
+int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c, const vxk::LMPending* pend, int head, int end, double* d_out,
+                      const double* cache_src = nullptr);
+int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int c, int head, int end, double* d_out, int* nparts_out = nullptr,
+                          unsigned fused_seq = 0, bool partials_to_host = false);
+}  // namespace vxc
