@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -587,7 +588,11 @@ long long store_count_observed(const WideStore& st, int V, hipStream_t s, const 
 //   * wchol_backsolve_kernel: L^T x = y, blocked, one workgroup; dots over the later rows run down contiguous columns.
 // A non-positive pivot sets `info`; the caller then takes the host's pivoted LDL^T for this step (the reference's own solver).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int WC_NB = 32;
+#ifndef VXBA_WC_NB
+#define VXBA_WC_NB 32   // measured at n = 594: 32 -> 0.75 ms per solve, 64 -> 1.2 ms (half the barriers, but the 64-pivot chain and the 3-workgroup panel phase grow faster)
+#endif
+constexpr int WC_NB = VXBA_WC_NB;      // block size of the wide Cholesky (a multiple of 16, at most 64: one wave factors a diagonal block)
+constexpr size_t WC_LDS_BYTES = sizeof(double) * (2 * WC_NB * (WC_NB + 1) + WC_NB + WIDE_MAXW * 6);
 // Cholesky factor of a kb x kb diagonal block (kb <= 32) by ONE wave, lane r holding row r of the lower triangle in registers.  Per
 // pivot: pivot by v_readlane, 1/sqrt by v_rsq_f64 + two Newton steps, the scaled column to LDS once and back as broadcast reads -- no
 // workgroup barrier inside the 32-step chain.  Result: Dout[c][r] = L(r, c) (zeros elsewhere).  A non-positive pivot is reported.
@@ -670,12 +675,22 @@ __device__ __forceinline__ void wchol_trailing_tile(double* __restrict__ A, int 
     Lj[rr][k] = (k < kb && c0 + rr < nrows) ? wc_ld(A + (size_t)(k0 + k) * lda + c0 + rr) : 0.0;
   }
   __syncthreads();
-  const int tx = tid & 15, ty = tid >> 4;    // 16 x 16 threads, 2 x 2 outputs each: rows tx, tx + 16; columns ty, ty + 16
-  double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+  const int tx = tid & 15, ty = tid >> 4;    // 16 x 16 threads, Q x Q outputs each: rows tx + 16 a, columns ty + 16 b
+  constexpr int Q = WC_NB / 16;
+  double acc[Q][Q];
+#pragma unroll
+  for (int a = 0; a < Q; a++)
+#pragma unroll
+    for (int b = 0; b < Q; b++) acc[a][b] = 0.0;
 #pragma unroll 8
   for (int k = 0; k < WC_NB; k++) {
-    const double i0 = Li[tx][k], i1 = Li[tx + 16][k], j0 = Lj[ty][k], j1 = Lj[ty + 16][k];
-    a00 += i0 * j0; a01 += i0 * j1; a10 += i1 * j0; a11 += i1 * j1;
+    double iv[Q], jv[Q];
+#pragma unroll
+    for (int a = 0; a < Q; a++) { iv[a] = Li[tx + 16 * a][k]; jv[a] = Lj[ty + 16 * a][k]; }
+#pragma unroll
+    for (int a = 0; a < Q; a++)
+#pragma unroll
+      for (int b = 0; b < Q; b++) acc[a][b] += iv[a] * jv[b];
   }
   const bool diag = (I == 0 && J == 0);
   __syncthreads();                            // Li is reused below as the updated diagonal block (tile (0, 0) only)
@@ -687,7 +702,10 @@ __device__ __forceinline__ void wchol_trailing_tile(double* __restrict__ A, int 
       if (diag) Li[rr][cc] = nv;              // rows / columns of the next diagonal block
     }
   };
-  upd(tx, ty, a00); upd(tx, ty + 16, a01); upd(tx + 16, ty, a10); upd(tx + 16, ty + 16, a11);
+#pragma unroll
+  for (int a = 0; a < Q; a++)
+#pragma unroll
+    for (int b = 0; b < Q; b++) upd(tx + 16 * a, ty + 16 * b, acc[a][b]);
   if (diag) {
     __syncthreads();
     if (tid < 64) {
@@ -791,9 +809,11 @@ __device__ __forceinline__ void wchol_grid_barrier(unsigned* counter, unsigned& 
 __global__ __launch_bounds__(256) void wchol_persistent_kernel(const double* __restrict__ packed, int n, double u, double* __restrict__ A, double* __restrict__ Lkk_all,
                                                                double* __restrict__ dvec, double* __restrict__ xbuf, double* __restrict__ out, int* __restrict__ info,
                                                                unsigned* __restrict__ counter) {
-  __shared__ double Li[WC_NB][WC_NB + 1], Lj[WC_NB][WC_NB + 1];
-  __shared__ double colbuf[WC_NB];
-  __shared__ double xs[WIDE_MAXW * 6];
+  extern __shared__ __attribute__((aligned(16))) double wc_lds[];     // two tile buffers, the pivot column, the solution (WC_LDS_BYTES)
+  double (*Li)[WC_NB + 1] = reinterpret_cast<double (*)[WC_NB + 1]>(wc_lds);
+  double (*Lj)[WC_NB + 1] = reinterpret_cast<double (*)[WC_NB + 1]>(wc_lds + WC_NB * (WC_NB + 1));
+  double* colbuf = wc_lds + 2 * WC_NB * (WC_NB + 1);
+  double* xs = colbuf + WC_NB;
   const int lda = n + 1, nrows = n + 1;
   const unsigned nwg = gridDim.x, wg = blockIdx.x;
   const int tid = threadIdx.x;
@@ -895,10 +915,14 @@ int wide_solver_step(DenseSolver* ds, const double* d_packed, double u, hipStrea
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
     const int tiles = ((n + WC_NB) / WC_NB) * ((n + WC_NB - 1) / WC_NB) / 2 + 1;     // lower tiles of the first trailing update
-    ds->nwg = std::max(1, std::min(std::min(prop.multiProcessorCount / 2, 128), tiles));
+    int cap = 128;
+    if (const char* e = getenv("VXBA_WIDE_NWG")) cap = std::max(1, atoi(e));     // development: workgroups of the persistent solve
+    ds->nwg = std::max(1, std::min(std::min(prop.multiProcessorCount / 2, cap), tiles));
   }
   if (hipMemsetAsync(ds->d_counter, 0, sizeof(unsigned), s) != hipSuccess || hipMemsetAsync(ds->d_info, 0, sizeof(int), s) != hipSuccess) return 1;
-  wchol_persistent_kernel<<<dim3((unsigned)ds->nwg), dim3(256), 0, s>>>(d_packed, n, u, ds->d_A, ds->d_Lkk, ds->d_dvec, ds->d_x, ds->d_out, ds->d_info, ds->d_counter);
+  static bool attr_set = false;      // idempotent; the launch fails loudly if the limit was not raised
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wchol_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_LDS_BYTES); attr_set = true; }
+  wchol_persistent_kernel<<<dim3((unsigned)ds->nwg), dim3(256), WC_LDS_BYTES, s>>>(d_packed, n, u, ds->d_A, ds->d_Lkk, ds->d_dvec, ds->d_x, ds->d_out, ds->d_info, ds->d_counter);
   if (hipMemcpyAsync(ds->h_info, ds->d_info, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
   if (hipMemcpyAsync(ds->h_out, ds->d_out, sizeof(double) * (n + 2), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
   if (hipStreamSynchronize(s) != hipSuccess) return 1;
