@@ -283,48 +283,102 @@ __global__ void map_judge_kernel(Nodes nd, Params prm, int n_bound, int L, int* 
   split_list[k] = i;
   if (nd.pcr_fix[(size_t)i * 10 + 9] != 0.0) atomicAdd((unsigned long long*)&cnt->fix_need_l[L], (unsigned long long)nd.fix_count[i]);
 }
-// fix_divide + subdivide(0 .. win_count-1) of one splitting leaf (voxel_map.hpp:1074-1116, 1174-1188): lane c of the node's eight
-// replays the reference's push sequence and keeps octant c.  64 lanes = 8 nodes.
 struct ScanSlot { const double* pnt; const double* var9; int* perm; int* tmp; int n; };
 struct ScanSlots { ScanSlot s[MAXW]; };
-__global__ __launch_bounds__(64) void map_subdivide_kernel(Nodes nd, Params prm, const int* __restrict__ split_list, int n_split, int win_count, PoseArg poses, RingArg ring,
-                                                           ScanSlots scans, double* __restrict__ fix_pnt, double* __restrict__ fix_var, Counters* cnt) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int sidx = t >> 3, oct = t & 7;
-  const bool live = sidx < n_split;
-  const int node = live ? split_list[sidx] : 0;
+// fix_divide + subdivide(0 .. win_count-1) of one splitting leaf (voxel_map.hpp:1074-1116, 1174-1188), one 64-lane workgroup per leaf:
+// lane = (octant, part).  Every accumulator of an octant is one
+// sequential sum over the leaf's points in the reference's push order -- that is what makes the sums bit-identical -- but the ~100
+// accumulators of an octant (two world clusters, the per-scan local cluster, the 9x9 covariance sum) are dealt to eight lanes instead of
+// sitting in one, and the classification (gather the point, transform it, find its octant) is done ONCE per point, cooperatively, 128
+// points per round through LDS, instead of once per octant lane.  (Until the end of round 2 eight lanes per leaf each replayed every
+// point with all the octant's accumulators in one lane: 160 us per call, the longest kernel of the scan cycle; now ~60.)
+//   part 0..5  row r = part of the covariance sum's 6x6 block and of its two 6x3 borders (12 accumulators); part 0 also owns the child
+//              node, the counts and the stable re-bucketing of the point lists
+//   part 6     the 3x3 variance block (9) + the per-scan local cluster (10)
+//   part 7     the two world clusters pcr_add / pcr_fix (20)
+constexpr int SUB_TILE = 128;
+struct SubStage {
+  double w[SUB_TILE][3];     // world point (what the octant test and the world-frame sums see)
+  double x[SUB_TILE][3];     // body-frame point (the per-scan local cluster)
+  double V[SUB_TILE][9];     // its 3x3 variance, column-major
+  int pi[SUB_TILE];
+  int code[SUB_TILE];
+};
+__device__ __forceinline__ void sub_accumulate(int part, const double* w, const double* x, const double* V, bool with_local, bool with_fix, double (&a)[20]) {
+  if (part < 6) {
+    const double Bi[6][3] = {{2 * w[0], 0, 0}, {w[1], w[0], 0}, {w[2], 0, w[0]}, {0, 2 * w[1], 0}, {0, w[2], w[1]}, {0, 0, 2 * w[2]}};
+    double br[3] = {0.0, 0.0, 0.0};      // row `part` of Bi
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) br[k] = (r == part) ? Bi[r][k] : br[k];
+    double up[3];                         // Biup[part][k]
+#pragma unroll
+    for (int k = 0; k < 3; k++) up[k] = madd_u(madd_u(mul_u(br[0], V[3 * k]), br[1], V[3 * k + 1]), br[2], V[3 * k + 2]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) a[k] += madd_u(madd_u(mul_u(up[0], Bi[k][0]), up[1], Bi[k][1]), up[2], Bi[k][2]);   // acc[9 k + part]
+#pragma unroll
+    for (int k = 0; k < 3; k++) { a[6 + k] += up[k]; a[9 + k] += up[k]; }      // acc[9 (6 + k) + part], acc[9 part + 6 + k]
+  } else if (part == 6) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) a[k] += V[k];                                  // acc[9 (6 + k/3) + 6 + k%3] += V[3 (k/3) + k%3]
+    if (with_local) cl_push(a + 10, x);
+  } else {
+    cl_push(a, w);                                                             // pcr_add
+    if (with_fix) cl_push(a + 10, w);                                          // pcr_fix
+  }
+}
+__global__ __launch_bounds__(64) void map_subdivide_wave_kernel(Nodes nd, Params prm, const int* __restrict__ split_list, int n_split, int win_count, PoseArg poses,
+                                                                RingArg ring, ScanSlots scans, double* __restrict__ fix_pnt, double* __restrict__ fix_var, Counters* cnt) {
+  __shared__ SubStage st;
+  const int node = split_list[blockIdx.x];
+  const int lane = threadIdx.x, oct = lane >> 3, part = lane & 7;
   const int W = prm.win_size;
   const int L = nd.layer[node];
   const bool keep_pts = (L + 1) < prm.max_layer;
-  const double* ctr = nd.center + 3 * (size_t)node;
-  int child = -1;
-  double ca[10], cf[10], acc[81];
+  const double ctr[3] = {nd.center[3 * (size_t)node], nd.center[3 * (size_t)node + 1], nd.center[3 * (size_t)node + 2]};
+  int child = -1;                 // meaningful in part 0 until it is broadcast
+  double a[20];
 #pragma unroll
-  for (int k = 0; k < 10; k++) { ca[k] = 0.0; cf[k] = 0.0; }
-#pragma unroll
-  for (int k = 0; k < 81; k++) acc[k] = 0.0;
+  for (int k = 0; k < 20; k++) a[k] = 0.0;
   auto get_child = [&]() {
-    if (child < 0) {
+    if (part == 0 && child < 0) {
       child = atomicAdd(&cnt->n_nodes, 1);
       init_child(nd, child, node, oct);
       nd.child[8 * (size_t)node + oct] = child + 1;
     }
   };
+  // one round: `count` staged points, every lane folds the ones of its octant, in order
+  auto fold = [&](int count, bool with_local, bool with_fix, int& mine) {
+    for (int j = 0; j < count; j++) {
+      if (st.code[j] != oct) continue;
+      get_child();
+      sub_accumulate(part, st.w[j], st.x[j], st.V[j], with_local, with_fix, a);
+      mine++;
+    }
+  };
   // fix_divide (voxel_map.hpp:1074-1094): only when pcr_fix.N != 0 (:1174)
-  const bool has_fix = live && nd.pcr_fix[(size_t)node * 10 + 9] != 0.0;
-  int nfix = 0;
+  const bool has_fix = nd.pcr_fix[(size_t)node * 10 + 9] != 0.0;
   if (has_fix) {
     const long long f0 = nd.fix_start[node];
     const int fc = nd.fix_count[node];
-    for (int j = 0; j < fc; j++) {
-      const double* x = fix_pnt + 3 * (size_t)(f0 + j);
-      if (octant_of(x, ctr) != oct) continue;
-      get_child();
-      cl_push(cf, x); cl_push(ca, x);
-      cov_add_point(acc, x, fix_var + 9 * (size_t)(f0 + j));
-      nfix++;
+    int nfix = 0;
+    for (int t0 = 0; t0 < fc; t0 += SUB_TILE) {
+      const int cntp = fc - t0 < SUB_TILE ? fc - t0 : SUB_TILE;
+      for (int j = lane; j < cntp; j += 64) {
+        const double* x = fix_pnt + 3 * (size_t)(f0 + t0 + j);
+        const double* v = fix_var + 9 * (size_t)(f0 + t0 + j);
+#pragma unroll
+        for (int e = 0; e < 3; e++) { st.w[j][e] = x[e]; st.x[j][e] = x[e]; }
+#pragma unroll
+        for (int e = 0; e < 9; e++) st.V[j][e] = v[e];
+        st.code[j] = octant_of(x, ctr);
+      }
+      __syncthreads();
+      fold(cntp, false, true, nfix);
+      __syncthreads();
     }
-    if (nfix > 0 && keep_pts) {      // push_fix keeps the point when layer < max_layer (voxel_map.hpp:998-999)
+    if (part == 0 && nfix > 0 && keep_pts) {      // push_fix keeps the point when layer < max_layer (voxel_map.hpp:998-999)
       const long long dst = (long long)atomicAdd((unsigned long long*)&cnt->fix_cursor, (unsigned long long)nfix);
       int k = 0;
       for (int j = 0; j < fc; j++) {
@@ -341,68 +395,99 @@ __global__ __launch_bounds__(64) void map_subdivide_kernel(Nodes nd, Params prm,
   for (int i = 0; i < win_count; i++) {
     const int slot = ring.mp[i];
     const ScanSlot sc = scans.s[slot];
-    const int p0 = live ? nd.pt_start[(size_t)node * W + slot] : 0;
-    const int pc = live ? nd.pt_count[(size_t)node * W + slot] : 0;
-    double cl[10];
+    const int p0 = nd.pt_start[(size_t)node * W + slot];
+    const int pc = nd.pt_count[(size_t)node * W + slot];
+    const double* Rp = poses.Rp + 12 * i;
+    if (part == 6) {
 #pragma unroll
-    for (int k = 0; k < 10; k++) cl[k] = 0.0;
+      for (int k = 10; k < 20; k++) a[k] = 0.0;      // this scan's local cluster
+    }
     int mine = 0;
-    for (int j = 0; j < pc; j++) {
-      const int pi = sc.perm[p0 + j];
-      const double* x = sc.pnt + 3 * (size_t)pi;
-      double w[3];
-      to_world(poses.Rp + 12 * i, x, w);
-      if (octant_of(w, ctr) != oct) continue;
-      get_child();
-      cl_push(cl, x); cl_push(ca, w);
-      cov_add_point(acc, w, sc.var9 + 9 * (size_t)pi);
-      mine++;
-    }
-    // stable re-bucketing of the parent's index range by octant: exclusive prefix of `mine` over the node's eight lanes
-    int before = 0;
+    for (int t0 = 0; t0 < pc; t0 += SUB_TILE) {
+      const int cntp = pc - t0 < SUB_TILE ? pc - t0 : SUB_TILE;
+      for (int j = lane; j < cntp; j += 64) {
+        const int pi = sc.perm[p0 + t0 + j];
+        const double* x = sc.pnt + 3 * (size_t)pi;
+        const double* v = sc.var9 + 9 * (size_t)pi;
+        double xb[3] = {x[0], x[1], x[2]}, w[3];
+        to_world(Rp, xb, w);
 #pragma unroll
-    for (int o = 0; o < 8; o++) {
-      const int v = __shfl(mine, (threadIdx.x & ~7) + o);
-      if (o < oct) before += v;
-    }
-    if (mine > 0) {
-      double* g = nd.pcrs_local + ((size_t)child * W + slot) * 10;
+        for (int e = 0; e < 3; e++) { st.w[j][e] = w[e]; st.x[j][e] = xb[e]; }
 #pragma unroll
-      for (int k = 0; k < 10; k++) g[k] = cl[k];
-      if (keep_pts) {
-        int k = 0;
-        for (int j = 0; j < pc; j++) {
-          const int pi = sc.perm[p0 + j];
-          double w[3];
-          to_world(poses.Rp + 12 * i, sc.pnt + 3 * (size_t)pi, w);
-          if (octant_of(w, ctr) != oct) continue;
-          sc.tmp[p0 + before + k] = pi;
-          k++;
+        for (int e = 0; e < 9; e++) st.V[j][e] = v[e];
+        st.pi[j] = pi;
+        st.code[j] = octant_of(w, ctr);
+      }
+      __syncthreads();
+      fold(cntp, true, false, mine);
+      __syncthreads();
+    }
+    const int child_o = __shfl(child, lane & ~7);            // the octant's node (allocated by part 0 at its first point)
+    if (part == 6 && mine > 0) {
+      double* g = nd.pcrs_local + ((size_t)child_o * W + slot) * 10;
+#pragma unroll
+      for (int k = 0; k < 10; k++) g[k] = a[10 + k];
+    }
+    if (keep_pts) {
+      // stable re-bucketing of the parent's index range by octant: exclusive prefix of `mine` over the eight octants
+      int before = 0;
+#pragma unroll
+      for (int o = 0; o < 8; o++) {
+        const int v = __shfl(mine, 8 * o);
+        if (o < oct) before += v;
+      }
+      int k = 0;
+      for (int t0 = 0; t0 < pc; t0 += SUB_TILE) {
+        const int cntp = pc - t0 < SUB_TILE ? pc - t0 : SUB_TILE;
+        for (int j = lane; j < cntp; j += 64) {
+          const int pi = sc.perm[p0 + t0 + j];
+          const double* x = sc.pnt + 3 * (size_t)pi;
+          double xb[3] = {x[0], x[1], x[2]}, w[3];
+          to_world(Rp, xb, w);
+          st.pi[j] = pi;
+          st.code[j] = octant_of(w, ctr);
         }
+        __syncthreads();
+        if (part == 0 && mine > 0)
+          for (int j = 0; j < cntp; j++)
+            if (st.code[j] == oct) { sc.tmp[p0 + before + k] = st.pi[j]; k++; }
+        __syncthreads();
+      }
+      if (part == 0 && mine > 0) {
         nd.pt_start[(size_t)child * W + slot] = p0 + before;
         nd.pt_count[(size_t)child * W + slot] = mine;
       }
+      __syncthreads();
+      for (int j = lane; j < pc; j += 64) sc.perm[p0 + j] = sc.tmp[p0 + j];
+      __syncthreads();
     }
-    __syncthreads();
-    if (keep_pts && live)
-      for (int j = oct; j < pc; j += 8) sc.perm[p0 + j] = sc.tmp[p0 + j];
-    __syncthreads();
   }
-  if (child >= 0) {
-    double* g_ca = nd.pcr_add + (size_t)child * 10;
-    double* g_cf = nd.pcr_fix + (size_t)child * 10;
-    double* g_acc = nd.cov_add + (size_t)child * 81;
+  const int child_o = __shfl(child, lane & ~7);
+  if (child_o >= 0) {
+    double* g_acc = nd.cov_add + (size_t)child_o * 81;
+    if (part < 6) {
 #pragma unroll
-    for (int k = 0; k < 10; k++) { g_ca[k] = ca[k]; g_cf[k] = cf[k]; }
+      for (int k = 0; k < 6; k++) g_acc[9 * k + part] = a[k];
 #pragma unroll
-    for (int k = 0; k < 81; k++) g_acc[k] = acc[k];
-    if (ca[9] != cf[9]) { nd.has_sw[child] = 1; nd.isexist[child] = 1; }     // push() opened a window; push_fix alone does not
+      for (int k = 0; k < 3; k++) { g_acc[9 * (6 + k) + part] = a[6 + k]; g_acc[9 * part + 6 + k] = a[9 + k]; }
+    } else if (part == 6) {
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) g_acc[9 * (6 + k) + 6 + r] = a[3 * k + r];
+    } else {
+      double* g_ca = nd.pcr_add + (size_t)child_o * 10;
+      double* g_cf = nd.pcr_fix + (size_t)child_o * 10;
+#pragma unroll
+      for (int k = 0; k < 10; k++) { g_ca[k] = a[k]; g_cf[k] = a[10 + k]; }
+      if (a[9] != a[19]) { nd.has_sw[child_o] = 1; nd.isexist[child_o] = 1; }     // push() opened a window; push_fix alone does not
+    }
   }
   __syncthreads();
-  if (live && oct == 0) {      // sw->clear(); sws.push_back(sw); sw = nullptr; octo_state = 1  (voxel_map.hpp:1184-1187)
-    for (int s = 0; s < W; s++) {
-      nd.pt_count[(size_t)node * W + s] = 0;
-      for (int k = 0; k < 10; k++) nd.pcrs_local[((size_t)node * W + s) * 10 + k] = 0.0;
+  if (lane == 0) {      // sw->clear(); sws.push_back(sw); sw = nullptr; octo_state = 1  (voxel_map.hpp:1184-1187)
+    for (int s2 = 0; s2 < W; s2++) {
+      nd.pt_count[(size_t)node * W + s2] = 0;
+      for (int k = 0; k < 10; k++) nd.pcrs_local[((size_t)node * W + s2) * 10 + k] = 0.0;
     }
     if (has_fix) { nd.fix_count[node] = 0; nd.fix_cap[node] = 0; }
     nd.has_sw[node] = 0;
@@ -1013,7 +1098,7 @@ int vxba_map_recut(vxba_map* m, int win_count, const double* Rp, vxba_factor* fa
     if (n_split == 0) continue;
     if ((rc = ensure_nodes(m, (long long)m->n_nodes + 8ll * n_split))) return rc;
     if ((rc = ensure_fix(m, m->fix_cursor + m->h_cnt->fix_need_l[L]))) return rc;
-    map_subdivide_kernel<<<grid_for(8ll * n_split, 64), 64, 0, m->stream>>>(m->nd, m->prm, d_split, n_split, win_count, poses, ring, make_scans(m), m->fix_pnt, m->fix_var, m->d_cnt);
+    map_subdivide_wave_kernel<<<dim3((unsigned)n_split), 64, 0, m->stream>>>(m->nd, m->prm, d_split, n_split, win_count, poses, ring, make_scans(m), m->fix_pnt, m->fix_var, m->d_cnt);
     bound = m->n_nodes + 8 * n_split;
   }
   // tras_opt, ordered by node id so that the factor is the same from run to run
