@@ -904,6 +904,12 @@ DenseSolver* wide_solver_create(int n, hipStream_t) {
                   hipMalloc((void**)&ds->d_info, sizeof(int)) == hipSuccess && hipMalloc((void**)&ds->d_counter, 64) == hipSuccess && hipHostMalloc((void**)&ds->h_out, sizeof(double) * (n + 2), hipHostMallocDefault) == hipSuccess &&
                   hipHostMalloc((void**)&ds->h_info, sizeof(int), hipHostMallocDefault) == hipSuccess;
   if (!ok) { wide_solver_free(ds); return nullptr; }
+  // dynamic LDS above 64 KB (block sizes over 32) needs the opt-in on THIS device; per solver, i.e. per factor: no process-wide flag
+  if (WC_LDS_BYTES > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&wchol_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_LDS_BYTES) != hipSuccess) {
+    wide_solver_free(ds);
+    return nullptr;
+  }
   return ds;
 }
 
@@ -920,8 +926,6 @@ int wide_solver_step(DenseSolver* ds, const double* d_packed, double u, hipStrea
     ds->nwg = std::max(1, std::min(std::min(prop.multiProcessorCount / 2, cap), tiles));
   }
   if (hipMemsetAsync(ds->d_counter, 0, sizeof(unsigned), s) != hipSuccess || hipMemsetAsync(ds->d_info, 0, sizeof(int), s) != hipSuccess) return 1;
-  static bool attr_set = false;      // idempotent; the launch fails loudly if the limit was not raised
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wchol_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_LDS_BYTES); attr_set = true; }
   wchol_persistent_kernel<<<dim3((unsigned)ds->nwg), dim3(256), WC_LDS_BYTES, s>>>(d_packed, n, u, ds->d_A, ds->d_Lkk, ds->d_dvec, ds->d_x, ds->d_out, ds->d_info, ds->d_counter);
   if (hipMemcpyAsync(ds->h_info, ds->d_info, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
   if (hipMemcpyAsync(ds->h_out, ds->d_out, sizeof(double) * (n + 2), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
