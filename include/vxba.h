@@ -347,6 +347,8 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
 #define VXBA_OPT_COUNT 7
 #define VXBA_STAT_FUSED_FALLBACKS 100 /* read-only (vxba_get_option): times vxba_damping_iter re-ran a call with the solve as its own launch after the
                                          voxel workgroups of a fused launch had timed out waiting for it */
+#define VXBA_STAT_LI_LAST_CALL_US 101 /* read-only (vxba_get_option): wall time of the last vxba_li_damping_iter[_gravity] call, microseconds,
+                                         * measured inside the library (what a C caller sees; the Python mirror adds its array handling) */
 int vxba_set_option(vxba_factor* f, int option, int value);
 int vxba_get_option(const vxba_factor* f, int option, int* value);
 

@@ -364,6 +364,7 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
   }
   if (n_trace) *n_trace = nt;
   if (hess_out && last_hess) std::memcpy(hess_out, last_hess, sizeof(double) * n * n);
+  f->li_last_call_us = us(t_call0, now());
   if (timing) std::fprintf(stderr, "[vxba li] %d iterations, %.0f us in the call: joint system %.0f us (of which waiting for the sweep %.0f), solve+update %.0f us, joint residual %.0f us\n", nt, us(t_call0, now()), t_sys, f->li_wait_us - wait0, t_solve, t_res);
   return VXBA_OK;
 }
@@ -380,6 +381,7 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
   hipSetDevice(f->device);
   const int W = f->W, n = vxi::DIM * W + 3, SL = vxi::STATE_LEN;
   double u = 0.01, v = 2;
+  const auto t_call0 = std::chrono::steady_clock::now();
   bool first_sweep_queued = false;   // as in vxba_li_damping_iter: the first sweep runs under the host-side preparation
   if (max_iter > 0 && !has_collective(f)) {
     double Rp0[12 * VXBA_MAX_WIN];
@@ -485,6 +487,7 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
   if (resis_out) resis_out[1] = residual2;
   if (n_trace) *n_trace = nt;
   if (hess_out && last_hess) std::memcpy(hess_out, last_hess, sizeof(double) * n * n);
+  f->li_last_call_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call0).count();
   return VXBA_OK;
 }
 
