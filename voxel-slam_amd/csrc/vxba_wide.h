@@ -91,6 +91,7 @@ struct DenseSolver;
 DenseSolver* wide_solver_create(int n, hipStream_t s);
 void wide_solver_free(DenseSolver*& ds);
 size_t wide_solver_bytes(const DenseSolver* ds);
-int wide_solver_step(DenseSolver* ds, const double* d_packed, double u, hipStream_t s, double* dxi, double* q1, double* residual1);
+// debug_give_up (test hook): the device-wide barriers stop waiting at once -- the call must then report failure (host fallback), not hang
+int wide_solver_step(DenseSolver* ds, const double* d_packed, double u, hipStream_t s, double* dxi, double* q1, double* residual1, bool debug_give_up = false);
 
 }  // namespace vxw

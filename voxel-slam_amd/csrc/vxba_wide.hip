@@ -785,7 +785,7 @@ __device__ __forceinline__ void wide_q1(const double* __restrict__ packed, const
 // it on the stream have finished); the wait is bounded all the same -- a barrier that gives up sets `info` and every later one falls
 // straight through, the host sees info != 0 and takes the step on the CPU.
 constexpr unsigned WC_SPIN_LIMIT = 1u << 20;
-__device__ __forceinline__ void wchol_grid_barrier(unsigned* counter, unsigned& target, unsigned nwg, int* info) {
+__device__ __forceinline__ void wchol_grid_barrier(unsigned* counter, unsigned& target, unsigned nwg, int* info, unsigned spin_limit) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's written-through stores are acknowledged
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -794,7 +794,7 @@ __device__ __forceinline__ void wchol_grid_barrier(unsigned* counter, unsigned& 
     unsigned spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > WC_SPIN_LIMIT || __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) {
+      if (++spins > spin_limit || __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) {
         __hip_atomic_store(info, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -808,7 +808,7 @@ __device__ __forceinline__ void wchol_grid_barrier(unsigned* counter, unsigned& 
 // and clocked down between them: 0.9 of the 1.45 ms of a W = 99 iteration), now separated by device-wide barriers.
 __global__ __launch_bounds__(256) void wchol_persistent_kernel(const double* __restrict__ packed, int n, double u, double* __restrict__ A, double* __restrict__ Lkk_all,
                                                                double* __restrict__ dvec, double* __restrict__ xbuf, double* __restrict__ out, int* __restrict__ info,
-                                                               unsigned* __restrict__ counter) {
+                                                               unsigned* __restrict__ counter, unsigned spin_limit) {
   extern __shared__ __attribute__((aligned(16))) double wc_lds[];     // two tile buffers, the pivot column, the solution (WC_LDS_BYTES)
   double (*Li)[WC_NB + 1] = reinterpret_cast<double (*)[WC_NB + 1]>(wc_lds);
   double (*Lj)[WC_NB + 1] = reinterpret_cast<double (*)[WC_NB + 1]>(wc_lds + WC_NB * (WC_NB + 1));
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(256) void wchol_persistent_kernel(const double* __r
       wc_st(A + (size_t)i * lda + n, i < 6 ? 0.0 : -packed[t]);              // row n: the right-hand side
     }
   }
-  wchol_grid_barrier(counter, target, nwg, info);
+  wchol_grid_barrier(counter, target, nwg, info, spin_limit);
   // first diagonal block (the later ones are factored by the trailing update that completes them)
   if (wg == 0 && tid < 64) {
     const int kb0 = n < WC_NB ? n : WC_NB;
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(256) void wchol_persistent_kernel(const double* __r
     __builtin_amdgcn_wave_barrier();
     for (int e = tid; e < WC_NB * WC_NB; e += 64) { const int rr = e % WC_NB, c = e / WC_NB; wc_st(Lkk_all + e, Li[c][rr]); }
   }
-  wchol_grid_barrier(counter, target, nwg, info);
+  wchol_grid_barrier(counter, target, nwg, info, spin_limit);
   for (int k0 = 0; k0 < n; k0 += WC_NB) {
     const int kb = n - k0 < WC_NB ? n - k0 : WC_NB;
     const int below = nrows - k0 - kb;                       // rows under the diagonal block (>= 1: the right-hand side row)
@@ -854,14 +854,14 @@ __global__ __launch_bounds__(256) void wchol_persistent_kernel(const double* __r
       for (int chunk = wg; chunk < nchunks; chunk += nwg) wchol_panel_rows(A, lda, nrows, k0, kb, chunk, Li);
       __syncthreads();
     }
-    wchol_grid_barrier(counter, target, nwg, info);
+    wchol_grid_barrier(counter, target, nwg, info, spin_limit);
     const int tr = (below + WC_NB - 1) / WC_NB, tc = (n - k0 - kb + WC_NB - 1) / WC_NB;
     if (tc > 0) {
       for (int t = wg; t < tr * tc; t += nwg) {
         const int I = t / tc, J = t % tc;
         if (J <= I) wchol_trailing_tile(A, lda, nrows, n, k0, kb, I, J, Lk + WC_NB * WC_NB, info, Li, Lj, colbuf);
       }
-      wchol_grid_barrier(counter, target, nwg, info);
+      wchol_grid_barrier(counter, target, nwg, info, spin_limit);
     }
   }
   if (wg == 0) {
@@ -915,7 +915,7 @@ DenseSolver* wide_solver_create(int n, hipStream_t) {
 
 // One damped step from the packed buffer on the device.  Host outputs: dxi (n), *q1, *residual1.  Returns 0, or 1 if the
 // factorisation met a non-positive pivot / a call failed -- the caller then takes the host path for this step.
-int wide_solver_step(DenseSolver* ds, const double* d_packed, double u, hipStream_t s, double* dxi, double* q1, double* residual1) {
+int wide_solver_step(DenseSolver* ds, const double* d_packed, double u, hipStream_t s, double* dxi, double* q1, double* residual1, bool debug_give_up) {
   const int n = ds->n;
   if (ds->nwg == 0) {
     int dev = 0; hipDeviceProp_t prop;
@@ -926,7 +926,8 @@ int wide_solver_step(DenseSolver* ds, const double* d_packed, double u, hipStrea
     ds->nwg = std::max(1, std::min(std::min(prop.multiProcessorCount / 2, cap), tiles));
   }
   if (hipMemsetAsync(ds->d_counter, 0, sizeof(unsigned), s) != hipSuccess || hipMemsetAsync(ds->d_info, 0, sizeof(int), s) != hipSuccess) return 1;
-  wchol_persistent_kernel<<<dim3((unsigned)ds->nwg), dim3(256), WC_LDS_BYTES, s>>>(d_packed, n, u, ds->d_A, ds->d_Lkk, ds->d_dvec, ds->d_x, ds->d_out, ds->d_info, ds->d_counter);
+  wchol_persistent_kernel<<<dim3((unsigned)ds->nwg), dim3(256), WC_LDS_BYTES, s>>>(d_packed, n, u, ds->d_A, ds->d_Lkk, ds->d_dvec, ds->d_x, ds->d_out, ds->d_info, ds->d_counter,
+                                                                                          debug_give_up ? 0u : WC_SPIN_LIMIT);
   if (hipMemcpyAsync(ds->h_info, ds->d_info, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
   if (hipMemcpyAsync(ds->h_out, ds->d_out, sizeof(double) * (n + 2), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
   if (hipStreamSynchronize(s) != hipSuccess) return 1;
