@@ -344,7 +344,10 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
                                          once, which exercises the transparent non-fused retry of vxba_damping_iter */
 #define VXBA_OPT_LI_STRUCTURED_SOLVE 6 /* 1 (default): the host shells of LI_BA_Optimizer[Gravity] solve the damped 15W(+3) system by a band Cholesky of
                                          the velocity/bias part + Schur complement onto the poses (3x fewer flops); 0: dense pivoted LDL^T */
-#define VXBA_OPT_COUNT 7
+#define VXBA_OPT_LI_QUEUED_SWEEPS 7    /* 1 (default): the host shells of LI_BA_Optimizer[Gravity] queue an iteration's residual sweep (and the speculative Hessian sweep
+                                       * behind it) BEFORE the host has finished the damped solve; the sweep's first workgroup waits for the trial poses in mapped host
+                                       * memory while the others already hold their cluster rows.  0: every sweep is launched when its poses exist. */
+#define VXBA_OPT_COUNT 8
 #define VXBA_STAT_FUSED_FALLBACKS 100 /* read-only (vxba_get_option): times vxba_damping_iter re-ran a call with the solve as its own launch after the
                                          voxel workgroups of a fused launch had timed out waiting for it */
 #define VXBA_STAT_LI_LAST_CALL_US 101 /* read-only (vxba_get_option): wall time of the last vxba_li_damping_iter[_gravity] call, microseconds,

@@ -2,6 +2,9 @@
 // LI_BA_OptimizerGravity; host shells between the GPU sweeps, and the driver of the device-resident loop).
 #include "vxba_factor.hpp"
 
+#include <atomic>
+#include <limits>
+
 using namespace vxc;
 
 extern "C" {
@@ -233,6 +236,214 @@ static int li_damping_iter_device(vxba_factor* f, double* states, double* imus, 
   return VXBA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The LiDAR-inertial shells with their sweeps QUEUED AHEAD (VXBA_OPT_LI_QUEUED_SWEEPS, single GPU, structured solve).
+// Between "the reduced Hessian has arrived" and "the residual sweep starts" the plain shell has the host alone on the critical path:
+// hess_plus, the dense half of the solve, the state update -- and then a launch whose kernel starts ~10 us later and spends its first
+// 6-7 us loading cluster rows.  Here the residual sweep of an iteration, and the speculative Hessian sweep + reduction behind it, are
+// already in the stream when the host starts solving: the sweep's workgroups load their rows and wait; its first workgroup polls a
+// sequence number in mapped host memory, and when the host has written the trial poses there it copies them into the device-side
+// control block and releases the others (the mechanism of the in-launch solve of the LiDAR-only loop, with the host as the solver);
+// the Hessian sweep behind it reads the same control block (LMPending.pending == 2).  The host's API calls leave the critical path too.
+// Everything else -- IMU blocks of the next system under the residual sweep, band half of the solve under the Hessian sweep, the
+// reference's damping schedule, bias roll-back -- is the plain shell's.  Returns 1 if the mode does not apply (the caller then runs
+// the plain shell), else a VXBA status.
+// ------------------------------------------------------------------------------------------------------------------------------
+static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out, double* resis_out,
+                                  double* trace_out, int* n_trace, bool with_g) {
+  const int W = f->W;
+  if (!f->opt[VXBA_OPT_LI_QUEUED_SWEEPS] || !f->opt[VXBA_OPT_LI_STRUCTURED_SOLVE] || has_collective(f) || W < 2 || max_iter < 1) return 1;
+  const int n = vxi::DIM * W + (with_g ? 3 : 0), SL = vxi::STATE_LEN, m6 = 6 * W;
+  const int g0 = with_g ? 6 : vxi::DIM;          // gauge rows at the head: frame 0's pose (gravity variant) or all of frame 0
+  const int mr = n - g0;
+  const auto t_call0 = std::chrono::steady_clock::now();
+  if (!f->h_feed) {
+    VX_HIP(f, hipHostMalloc((void**)&f->h_feed, sizeof(double) * (12 * VXBA_MAX_WIN + 8), hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: the GPU must see the host's write WHILE the kernel runs
+    VX_HIP(f, hipHostGetDevicePointer((void**)&f->zc_feed, f->h_feed, 0));
+    f->h_feed[0] = 0.0;
+  }
+  if (!f->li_ev) VX_HIP(f, hipEventCreateWithFlags(&f->li_ev, hipEventDisableTiming));
+  if (!f->li_ev2) VX_HIP(f, hipEventCreateWithFlags(&f->li_ev2, hipEventDisableTiming));
+  if (!f->li_ev3) VX_HIP(f, hipEventCreateWithFlags(&f->li_ev3, hipEventDisableTiming));
+  // two events for "a joint system's sweep + reduction is done": the one the host waits on now, and the one the speculative sweep queued
+  // behind the residual sweep records (re-recording the first would make the host wait for a sweep that waits for the host)
+  hipEvent_t ev_sys[2] = {f->li_ev2, f->li_ev3};
+  int cur = 0;
+  const size_t plen = vxba_packed_len(f);
+  const FactorView fv = view(f);
+  int rc = ensure_partials3(f);
+  if (rc) return rc;
+  const int nv = vxk::k3_nv(W);
+  const int nblocks3 = vxk::k3_blocks_for((f->V - 1) / nv + 1, vxk::k3_grid_blocks(f->cus));
+  PoseArg pa0;
+  std::memset(&pa0, 0, sizeof pa0);
+  auto wait_event = [&](hipEvent_t ev) -> int {
+    hipError_t q;
+    while ((q = hipEventQuery(ev)) == hipErrorNotReady) {}
+    VX_HIP(f, q);
+    return VXBA_OK;
+  };
+  // the device-side control block the queued sweeps read their poses from: not done, no error
+  VX_HIP(f, hipMemsetAsync(f->d_lm, 0, sizeof(vxk::LMState), f->stream));
+  // first joint system: Hessian sweep at the caller's poses, as in the plain shell, marked by an event (the stream will not drain)
+  {
+    double Rp0[12 * VXBA_MAX_WIN];
+    for (int i = 0; i < W; i++) std::memcpy(Rp0 + 12 * i, states + SL * i, sizeof(double) * 12);
+    rc = sweep_hess_device(f, Rp0, nullptr, nullptr, nullptr, 0, f->V, f->zc_packed);
+    if (rc) return rc;
+    VX_HIP(f, hipEventRecord(ev_sys[cur], f->stream));
+  }
+  f->li.size(n, W - 1);
+  std::vector<double>&Hess = f->li.Hess, &A = f->li.A, &JacT = f->li.JacT, &D = f->li.D, &rhs = f->li.rhs, &dxi = f->li.dxi, &work = f->li.work;
+  std::vector<double>&HessN = f->li.HessN, &JacTN = f->li.JacTN, &cov_invs = f->li.cov_invs;
+  std::vector<int>& perm = f->li.perm;
+  std::vector<double> x_temp(states, states + (size_t)SL * W);
+  if (!vxi::li_invert_covariances(W, imus, cov_invs.data())) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
+  vxh::BandSchurWork& bs = f->li_bs;
+  const vxh::LiIndexSets sets = vxh::li_index_sets(W - 1, with_g ? 9 : 0, with_g ? 3 : 0);
+  const int ny = (int)sets.Y.size(), nx = (int)sets.X.size();
+  double* Aw = nullptr;                            // the block behind the gauge rows (set once Hess is known: the buffers swap)
+  double u = 0.01, v = 2, residual1 = 0, residual2 = 0, imu_res = 0, imu_res_next = 0;
+  bool is_calc_hess = true, imu_ready = false, sys_queued = true;   // sys_queued: a Hessian sweep for `states` is in the stream (li_ev2 marks its end)
+  int nt = 0, nparts = 0;
+  unsigned seq = 0;
+  bool armed = false;                               // a residual sweep is queued and waits for its poses
+  const double* last_hess = nullptr;
+  vxi::ImuWork wk;
+  bool ok = true;
+  // queue iteration's residual sweep (waiting for the feed) and, with_spec, the Hessian sweep + reduction at the same trial poses
+  auto queue_sweeps = [&](bool with_spec) -> int {
+    seq = ++f->lm_seq;
+    if (seq == 0) seq = ++f->lm_seq;
+    nparts = vxk::launch_k2_residual(fv, pa0, f->d_lm, 0, seq, 0, f->V, f->zc_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK], f->stream, nullptr, nullptr, f->zc_feed);
+    VX_HIP(f, hipGetLastError());
+    VX_HIP(f, hipEventRecord(f->li_ev, f->stream));
+    armed = true;
+    if (with_spec) {
+      vxk::LMPending pd;
+      std::memset(&pd, 0, sizeof pd);
+      pd.pending = 2;                               // linearise at the control block's trial poses; no decision inside the sweep
+      if (vxk::launch_k3_hessian(fv, pa0, f->d_lm, 0, pd, nullptr, 0, f->V, f->d_partial3, nblocks3, f->precision, f->stream) < 0)
+        return fail(f, VXBA_ERR_STATE, "li: cache planes are not consecutive");
+      vxk::launch_k3_finalize(f->d_partial3, nblocks3, W, nullptr, 0, 0, f->zc_packed, f->stream);
+      VX_HIP(f, hipGetLastError());
+      VX_HIP(f, hipEventRecord(ev_sys[cur ^ 1], f->stream));
+    }
+    return VXBA_OK;
+  };
+  auto feed = [&](const double* st_trial) {
+    for (int k = 0; k < nparts; k++) f->h_partial2[k] = std::numeric_limits<double>::quiet_NaN();   // a sweep that gave up leaves these
+    for (int i = 0; i < W; i++) std::memcpy(f->h_feed + 1 + 12 * i, st_trial + SL * i, sizeof(double) * 12);
+    std::atomic_thread_fence(std::memory_order_release);
+    *(volatile double*)f->h_feed = (double)seq;
+    armed = false;
+  };
+  // never leave a queued sweep waiting: whatever ends the call releases it (poses of the current states: harmless)
+  struct Release { decltype(feed)& fd; bool& armed; const double* st; ~Release() { if (armed) fd(st); } } release_guard{feed, armed, states};
+
+  for (int it = 0; it < max_iter; it++) {
+    const bool recomputed = is_calc_hess;
+    const bool with_spec = it + 1 < max_iter;
+    bool prepared = false;
+    if (is_calc_hess) {
+      if (imu_ready) { Hess.swap(HessN); JacT.swap(JacTN); imu_res = imu_res_next; imu_ready = false; }
+      else {
+        std::memset(Hess.data(), 0, sizeof(double) * n * n);
+        std::memset(JacT.data(), 0, sizeof(double) * n);
+        imu_res = vxi::li_add_imu_blocks(W, states, imus, imu_coef, true, Hess.data(), JacT.data(), wk, &ok, with_g, cov_invs.data());
+        if (!ok) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
+      }
+      Aw = &Hess[(size_t)g0 * n + g0];
+      rc = queue_sweeps(with_spec);                 // behind the system's sweep: starts when that is done, then waits for the poses
+      if (rc) return rc;
+      // band half of the solve (velocities / biases: IMU terms only) while the GPU is still sweeping
+      for (int y : sets.Y) { rhs[y] = -JacT[y + g0]; work[y] = u * Hess[(size_t)(y + g0) * n + y + g0]; }
+      prepared = vxh::band_schur_prepare(Aw, n, work.data(), rhs.data(), sets.Y.data(), ny, sets.bw, sets.X.data(), nx, sets.xlo.data(), bs);
+      if (!sys_queued) return fail(f, VXBA_ERR_STATE, "li: internal -- no Hessian sweep in flight for the accepted state");
+      {
+        const auto tw = std::chrono::steady_clock::now();
+        rc = wait_event(ev_sys[cur]);
+        f->li_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count();
+        if (rc) return rc;
+      }
+      sys_queued = false;
+      vxi::li_hess_plus(W, Hess.data(), JacT.data(), f->h_packed, f->h_packed + (size_t)m6 * m6, n);
+      residual1 = imu_res + f->h_packed[(size_t)m6 * m6 + m6];
+      last_hess = Hess.data();
+      if (it == 0 && resis_out) resis_out[0] = residual1;
+    } else {
+      rc = queue_sweeps(with_spec);                 // rejected step: same system, new damping, new trial poses
+      if (rc) return rc;
+    }
+    // gauge rows: identity with a zero right-hand side (never written into the matrix: the solve works on the block behind them)
+    for (int r = 0; r < g0; r++) { JacT[r] = 0.0; dxi[r] = 0.0; }
+    for (int r = 0; r < n; r++) D[r] = r < g0 ? 1.0 : Hess[(size_t)r * n + r];
+    for (int r = 0; r < mr; r++) { rhs[r] = -JacT[r + g0]; work[r] = u * D[r + g0]; }
+    bool solved = prepared || vxh::band_schur_prepare(Aw, n, work.data(), rhs.data(), sets.Y.data(), ny, sets.bw, sets.X.data(), nx, sets.xlo.data(), bs);
+    if (solved) vxh::band_schur_finish(Aw, n, work.data(), rhs.data(), sets.Y.data(), ny, sets.bw, sets.X.data(), nx, dxi.data() + g0, bs);
+    else {                                          // a band pivot was not positive: the reference's dense pivoted LDL^T on the whole system
+      A.resize((size_t)n * n);
+      std::memcpy(A.data(), Hess.data(), sizeof(double) * n * n);
+      for (int c = 0; c < n; c++)
+        for (int r = 0; r < g0; r++) { A[(size_t)c * n + r] = 0.0; A[(size_t)r * n + c] = 0.0; }
+      for (int r = 0; r < g0; r++) A[(size_t)r * n + r] = 1.0;
+      for (int r = 0; r < n; r++) { A[(size_t)r * n + r] += u * D[r]; rhs[r] = -JacT[r]; }
+      vxh::ldlt_solve_inplace(n, A.data(), rhs.data(), dxi.data(), perm.data(), work.data());
+    }
+    // trial state and the factors' bias deltas (voxel_map.hpp:599-609 / 813-822)
+    if (with_g) for (int k = 0; k < 3; k++) x_temp[21 + k] += dxi[n - 3 + k];     // x_stats_temp[0].g += dxi.tail(3): never reset upstream -- kept
+    for (int j = 0; j < W; j++) {
+      const double* d = &dxi[(size_t)vxi::DIM * j];
+      const double* s = states + (size_t)SL * j;
+      double* t = &x_temp[(size_t)SL * j];
+      vxh::right_multiply_exp(s, d, t);
+      for (int k = 0; k < 12; k++) t[9 + k] = s[9 + k] + d[3 + k];
+      for (int k = 0; k < 3; k++) t[21 + k] = with_g ? x_temp[21 + k] : s[21 + k];
+    }
+    feed(x_temp.data());                            // the queued residual sweep takes off
+    for (int j = 0; j < W - 1; j++) vxi::imu_update_state(imus + (size_t)vxi::IMU_LEN * j, &dxi[(size_t)vxi::DIM * j]);
+    double q1 = 0.0;
+    for (int r = 0; r < n; r++) q1 += dxi[r] * (u * D[r] * dxi[r] - JacT[r]);
+    q1 *= 0.5;
+    // under the residual sweep: the IMU half of the NEXT system at the trial state (its residual falls out of the same evaluation)
+    double r_imu;
+    if (with_spec) {
+      std::memset(HessN.data(), 0, sizeof(double) * n * n);
+      std::memset(JacTN.data(), 0, sizeof(double) * n);
+      r_imu = vxi::li_add_imu_blocks(W, x_temp.data(), imus, imu_coef, true, HessN.data(), JacTN.data(), wk, &ok, with_g, cov_invs.data());
+    } else {
+      r_imu = vxi::li_add_imu_blocks(W, x_temp.data(), imus, imu_coef, false, nullptr, nullptr, wk, &ok, false, cov_invs.data());
+    }
+    rc = wait_event(f->li_ev);
+    if (rc) return rc;
+    const double r_lidar = host_sum_partials(f->h_partial2, nparts);
+    if (!(r_lidar == r_lidar)) return fail(f, VXBA_ERR_STATE, "li: a queued residual sweep gave up waiting for its poses");
+    residual2 = r_imu + r_lidar;
+    const double q = residual1 - residual2;
+    const double u_used = u, v_used = v;
+    const bool accepted = vxh::lm_update_damping(residual1, residual2, q1, u, v);
+    if (accepted) {
+      std::memcpy(states, x_temp.data(), sizeof(double) * SL * W);
+      is_calc_hess = true;
+      if (with_spec) { imu_ready = true; imu_res_next = r_imu; sys_queued = true; cur ^= 1; }
+    } else {
+      is_calc_hess = false;
+      for (int j = 0; j < W - 1; j++) vxi::imu_rollback(imus + (size_t)vxi::IMU_LEN * j);
+    }
+    if (trace_out) {
+      double* o = trace_out + (size_t)VXBA_TRACE_COLS * nt;
+      o[0] = residual1; o[1] = residual2; o[2] = u_used; o[3] = v_used; o[4] = q; o[5] = q1; o[6] = accepted; o[7] = recomputed;
+    }
+    nt++;
+    if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
+  }
+  if (resis_out) resis_out[1] = residual2;
+  if (n_trace) *n_trace = nt;
+  if (hess_out && last_hess) std::memcpy(hess_out, last_hess, sizeof(double) * n * n);
+  f->li_last_call_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call0).count();
+  return VXBA_OK;
+}
+
 int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out, double* trace_out,
                          int* n_trace) {
   VX_LOCK(f);
@@ -244,6 +455,10 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
   double u = 0.01, v = 2;
   const auto t_call0 = std::chrono::steady_clock::now();
   const bool device_loop = f->opt[VXBA_OPT_LI_DEVICE_LOOP] != 0 && !has_collective(f);   // sharded runs keep the host shell
+  if (!device_loop) {
+    const int rq = li_damping_iter_queued(f, states, imus, imu_coef, max_iter, hess_out, nullptr, trace_out, n_trace, false);
+    if (rq != 1) return rq;
+  }
   // the first Hessian sweep goes out before any host-side preparation (covariance inverses, buffers): it needs the poses only
   bool first_sweep_queued = false;
   if (!device_loop && max_iter > 0 && !has_collective(f)) {
@@ -379,6 +594,10 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
   if (f->V == 0) return fail(f, VXBA_ERR_STATE, "li_damping_iter_gravity on an empty factor");
   VX_NARROW_ONLY(f, "li_damping_iter_gravity");
   hipSetDevice(f->device);
+  {
+    const int rq = li_damping_iter_queued(f, states, imus, imu_coef, max_iter, hess_out, resis_out, trace_out, n_trace, true);
+    if (rq != 1) return rq;
+  }
   const int W = f->W, n = vxi::DIM * W + 3, SL = vxi::STATE_LEN;
   double u = 0.01, v = 2;
   const auto t_call0 = std::chrono::steady_clock::now();

@@ -85,7 +85,7 @@ struct vxba_factor {
     }
   } li;
   vxh::BandSchurWork li_bs;
-  int opt[VXBA_OPT_COUNT] = {1, 1, 1, 0, 64, 0, 1};   // vxba_set_option; initial values may come from the environment (see vxba.h)
+  int opt[VXBA_OPT_COUNT] = {1, 1, 1, 0, 64, 0, 1, 1};   // vxba_set_option; initial values may come from the environment (see vxba.h)
   vxw::WideStore wstore;         // wide windows: the clusters, compressed rows over the observed (voxel, frame) entries (no cluster planes)
   vxw::WideIndex wide;           // wide windows: incidence structure (entries, entry pairs per Hessian block), rebuilt after a push
   bool wide_dirty = true;
@@ -96,6 +96,10 @@ struct vxba_factor {
   size_t xlen = 0;               // doubles the exchange buffers (own_packed, h_packed) hold
   int precision = 0;             // 0: fp64 throughout; 1: Hessian products in f32 on the matrix cores, f64 accumulation
   unsigned lm_seq = 0;           // sequence numbers of solves published inside residual-sweep launches (never 0)
+  hipEvent_t li_ev3 = nullptr;
+  hipEvent_t li_ev2 = nullptr;   // ... and the end of a Hessian sweep + reduction queued ahead (queued-sweeps mode: the stream never drains)
+  double* h_feed = nullptr;      // mapped host memory through which the LI shells hand the trial poses to a residual sweep that is already queued: [seq | 12 W poses]
+  double* zc_feed = nullptr;
   hipEvent_t li_ev = nullptr;    // marks the end of the residual sweep when a speculative Hessian sweep is queued behind it (LI host shells)
   bool solve_timed_out = false;  // the last damping_iter failed because voxel workgroups gave up waiting for the in-launch solve
   int fused_fallbacks = 0;       // times a call was transparently re-run with the solve as its own launch
@@ -146,6 +150,8 @@ bool is_wide(const vxba_factor* f);
 bool has_collective(const vxba_factor* f);
 vxk::FactorView view(const vxba_factor* f);
 int ensure_exchange(vxba_factor* f);
+int ensure_partials3(vxba_factor* f);
+void fill_poses(const vxba_factor* f, const double* Rp, vxk::PoseArg& pa);
 // asynchronous sweeps on f->stream, results in device (or mapped host) memory
 int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c, const vxk::LMPending* pend, int head, int end, double* d_out,
                       const double* cache_src = nullptr);

@@ -93,8 +93,10 @@ inline size_t k3_partial_len(int W) { return (size_t)k3_num_tile_pairs(W) * 256 
 int k2_voxels_per_block(int nvox, int cus);
 // fused_seq != 0 (LM mode only): workgroup 0 of the launch runs the damped solve of this iteration and publishes `fused_seq`;
 // the voxel workgroups wait for it after requesting their cluster rows.  Must be unique per launch and non-zero.
+// host_feed (with fused_seq != 0): workgroup 0 does not solve; it waits until the host has written fused_seq to host_feed[0] (mapped host
+// memory) and copies the 12W trial poses behind it into ctl[c].xt -- the LiDAR-inertial shells queue the sweep before their own solve is done.
 int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, int c, unsigned fused_seq, int head, int end, double* d_partial,
-                       int voxels_per_block, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                       int voxels_per_block, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const double* host_feed = nullptr);
 // Deterministic sum of n partials into d_out[0].
 void launch_sum_partials(const double* d_partial, int n, double* d_out, hipStream_t s);
 // Derive aux (gap scales) from eigval for voxels [head,end) (after a caller-seeded cache).

@@ -165,7 +165,7 @@ constexpr unsigned K2_SPIN_LIMIT = 1u << 22;
 #endif
 template <int W, bool DBG = false>
 __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c, unsigned seq, int head, int end,
-                                                         int VPB_arg, double* __restrict__ partial) {
+                                                         int VPB_arg, double* __restrict__ partial, const double* host_feed) {
   const int VPB = VPB_arg & 0xffff;
   __shared__ double pose_lds[12 * W];
   __shared__ double solve_lds[SOLVE_LDS + 64];
@@ -175,7 +175,22 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
   int vb = blockIdx.x;
   if (st && seq != 0) {
     if (blockIdx.x == 0) {
-      lm_solve_body<W, DBG>(st, c, solve_lds, solve_lds + SOLVE_LDS);
+      if (host_feed) {
+        // LiDAR-inertial shells: the trial poses come from the HOST (15W-dimensional solve there).  This launch was queued before
+        // they existed -- the voxel workgroups already hold their cluster rows -- and workgroup 0 waits for the host to raise the
+        // sequence number in mapped host memory, copies the poses into the control block and publishes them like a solve would.
+        const volatile double* hf = host_feed;
+        unsigned spins = 0;
+        bool fed = true;
+        while ((unsigned)hf[0] != seq) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > K2_SPIN_LIMIT) { fed = false; break; }    // the host went away: the voxel workgroups give up too, partials stay as the host left them
+        }
+        if (!fed) { if (lane == 0) st->error = 2; return; }
+        for (int k = lane; k < 12 * W; k += 64) __hip_atomic_store(&st->ctl[c].xt[k], hf[1 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        lm_solve_body<W, DBG>(st, c, solve_lds, solve_lds + SOLVE_LDS);
+      }
 #if VXBA_PUBLISH_FENCE
       __threadfence();
       if (lane == 0) __hip_atomic_store(&st->solve_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -940,7 +955,7 @@ void launch_mfma_probe(const double* dA, const double* dB, double* dD, hipStream
 // workgroup so that every CU owns the same number of voxels (49 instead of 64 at cfg2, 4 workgroups on every CU): 20.0 us instead of
 // 18.0 -- the partly filled waves cost more than the ragged last round.  VXBA_OPT_K2_VOXELS_PER_BLOCK keeps the experiment reproducible.
 int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, int c, unsigned fused_seq, int head, int end, double* d_partial,
-                       int voxels_per_block, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                       int voxels_per_block, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, const double* host_feed) {
   const int vpb0 = voxels_per_block & 0xffff;
   const int vpb = (vpb0 >= 32 && vpb0 <= 64) ? vpb0 : 64;
   const int vpb_arg = vpb | (voxels_per_block & 0x10000);   // bit 16: the voxel workgroups do not wait for the in-launch solve (test hook)
@@ -950,11 +965,11 @@ int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, 
   const int grid = nblocks + (seq != 0 ? 1 : 0);   // + the solve workgroup
   static int dbg = -1;
   if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
-  if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial)); }
+  if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed)); }
   else if (ev_start) {
     VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), dim3(grid), dim3(64), 0, s, ev_start, ev_stop, 0, fv, poses, st, c, seq, head,
-                                                end, vpb_arg, d_partial));
-  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial)); }
+                                                end, vpb_arg, d_partial, host_feed));
+  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed)); }
   return nblocks;
 }
 
