@@ -56,13 +56,18 @@ def test_joint_system_matches_oracle(vx, W, V, pts):
     assert np.isclose(r2, O.li_only_residual(fo, iw.states_init, blobs, 5, 1e-4), rtol=1e-10)
 
 
-@pytest.mark.parametrize("device_loop", [False, True])
+@pytest.mark.parametrize("mode", ["host_shell_queued_sweeps", "host_shell_plain", "host_shell_dense_solve", "device_loop"])
 @pytest.mark.parametrize("W,V,pts,iters", [(5, 800, 8000, 3), (10, 3000, 40000, 6), (2, 300, 4000, 4)])
-def test_li_damping_iter_matches_oracle(vx, W, V, pts, iters, device_loop):
-    """device_loop: the whole loop enqueued on the GPU (IMU factor kernels, Schur solve over the block-tridiagonal velocity-bias part,
-    accept / reject on the device; vxba_set_option(VXBA_OPT_LI_DEVICE_LOOP, 1)) instead of the host shell between the sweeps -- same contract."""
+def test_li_damping_iter_matches_oracle(vx, W, V, pts, iters, mode):
+    """The four ways the library runs LI_BA_Optimizer::damping_iter, same contract each: the host shell with its sweeps queued ahead of
+    the host solve (default: trial poses fed to the waiting residual sweep through mapped host memory), the host shell launching every
+    sweep when its poses exist, the same with the dense 15W LDL^T instead of the band / Schur solve, and the whole loop enqueued on the
+    GPU (IMU factor kernels, Schur solve over the block-tridiagonal velocity-bias part, accept / reject on the device)."""
     sc, iw, blobs, facs, fo, fg = build(vx, W, V, pts, seed=600 + W)
+    device_loop = mode == "device_loop"
     fg.set_option("li_device_loop", 1 if device_loop else 0)
+    fg.set_option("li_queued_sweeps", 1 if mode == "host_shell_queued_sweeps" else 0)
+    fg.set_option("li_structured_solve", 0 if mode == "host_shell_dense_solve" else 1)
     assert fg.get_option("li_device_loop") == (1 if device_loop else 0)
     ref = O.li_damping_iter(fo, iw.states_init, blobs, max_iter=iters, thd_num=5, imu_coef=1e-4)
     got = vx.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(iw.states_init, fg, facs, max_iter=iters)
@@ -92,14 +97,16 @@ def test_li_ba_improves_on_lidar_only_velocity_and_bias(vx):
     assert np.array_equal(got["states"][0], iw.states_init[0])
 
 
+@pytest.mark.parametrize("queued", [1, 0])
 @pytest.mark.parametrize("W,V,pts,iters", [(5, 800, 8000, 5), (10, 3000, 40000, 5)])
-def test_gravity_variant_matches_oracle(vx, W, V, pts, iters):
+def test_gravity_variant_matches_oracle(vx, W, V, pts, iters, queued):
     """LI_BA_OptimizerGravity (voxel_map.hpp:658-864), max_iter = 5 as at its call site (voxelslam.cpp:1644)."""
     sc, iw, blobs, facs, fo, fg = build(vx, W, V, pts, seed=700 + W)
     st = iw.states_init.copy()
     st[:, 21:24] += [0.05, -0.03, 0.08]
     ref = O.li_damping_iter_gravity(fo, st, blobs, max_iter=iters, thd_num=5, imu_coef=1e-4)
     opt = vx.LI_BA_OptimizerGravity(imu_coef=1e-4)
+    fg.set_option("li_queued_sweeps", queued)
     got = opt.damping_iter(st, fg, facs, max_iter=iters)
     assert got["hess"].shape == (15 * W + 3, 15 * W + 3)
     assert got["trace"].shape == ref["trace"].shape
