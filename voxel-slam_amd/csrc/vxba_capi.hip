@@ -97,7 +97,7 @@ int ensure_capacity(vxba_factor* f, int n_total) {
     VX_HIP(f, hipMalloc((void**)&f->d_partial2, p2 * sizeof(double)));
     if (f->h_partial2) VX_HIP(f, hipHostFree(f->h_partial2));
     f->h_partial2 = nullptr; f->zc_partial2 = nullptr;
-    VX_HIP(f, hipHostMalloc((void**)&f->h_partial2, p2 * sizeof(double), hipHostMallocMapped));
+    VX_HIP(f, hipHostMalloc((void**)&f->h_partial2, p2 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: a partial is visible to the host when its workgroup has written it
     VX_HIP(f, hipHostGetDevicePointer((void**)&f->zc_partial2, f->h_partial2, 0));
     f->partial2_len = p2;
   }

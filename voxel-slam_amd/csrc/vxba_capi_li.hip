@@ -414,8 +414,19 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
     } else {
       r_imu = vxi::li_add_imu_blocks(W, x_temp.data(), imus, imu_coef, false, nullptr, nullptr, wk, &ok, false, cov_invs.data());
     }
-    rc = wait_event(f->li_ev);
-    if (rc) return rc;
+    // The residual is complete when every block partial has replaced the NaN the host put there (fine-grained host memory: a partial
+    // arrives when its workgroup is done, a few microseconds before the kernel's end-of-launch release and the event behind it would
+    // be seen); the event is only the back-stop for a sweep that gave up.
+    for (;;) {
+      bool all = true;
+      const volatile double* hp = f->h_partial2;
+      for (int k = 0; k < nparts; k++)
+        if (!(hp[k] == hp[k])) { all = false; break; }
+      if (all) break;
+      const hipError_t q = hipEventQuery(f->li_ev);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) VX_HIP(f, q);
+    }
     const double r_lidar = host_sum_partials(f->h_partial2, nparts);
     if (!(r_lidar == r_lidar)) return fail(f, VXBA_ERR_STATE, "li: a queued residual sweep gave up waiting for its poses");
     residual2 = r_imu + r_lidar;
