@@ -29,7 +29,7 @@ int ensure_exchange(vxba_factor* f) {
   if (f->h_packed) VX_HIP(f, hipHostFree(f->h_packed));
   f->own_packed = nullptr; f->own_scalar = nullptr; f->h_packed = nullptr; f->zc_packed = nullptr; f->xlen = 0;
   VX_HIP(f, hipMalloc((void**)&f->own_packed, (plen + 1) * sizeof(double)));
-  VX_HIP(f, hipHostMalloc((void**)&f->h_packed, (plen + 1) * sizeof(double), hipHostMallocMapped));
+  VX_HIP(f, hipHostMalloc((void**)&f->h_packed, (plen + 1) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: see li_damping_iter_queued
   VX_HIP(f, hipHostGetDevicePointer((void**)&f->zc_packed, f->h_packed, 0));
   f->own_scalar = f->own_packed + plen;
   if (own_p) f->d_packed = f->own_packed;

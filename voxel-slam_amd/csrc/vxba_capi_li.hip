@@ -283,6 +283,23 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
     VX_HIP(f, q);
     return VXBA_OK;
   };
+  // "The reduced system has arrived" is read off the mapped host buffer itself: the host fills it with NaNs while no reduction can be
+  // writing it, and the system is complete when the last NaN is gone (every slot is written exactly once per reduction) -- a few
+  // microseconds before the end-of-launch release and the event behind it would be seen.  The event stays as the back-stop.
+  auto nan_fill_packed = [&]() { for (size_t k = 0; k < plen; k++) f->h_packed[k] = std::numeric_limits<double>::quiet_NaN(); };
+  auto wait_packed = [&](hipEvent_t ev) -> int {
+    const volatile double* hp = f->h_packed;
+    for (;;) {
+      bool all = true;
+      for (size_t k = 0; k < plen; k++)
+        if (!(hp[k] == hp[k])) { all = false; break; }
+      if (all) return VXBA_OK;
+      const hipError_t q = hipEventQuery(ev);
+      if (q == hipSuccess) return VXBA_OK;
+      if (q != hipErrorNotReady) VX_HIP(f, q);
+    }
+  };
+  nan_fill_packed();
   // the device-side control block the queued sweeps read their poses from: not done, no error
   VX_HIP(f, hipMemsetAsync(f->d_lm, 0, sizeof(vxk::LMState), f->stream));
   // first joint system: Hessian sweep at the caller's poses, as in the plain shell, marked by an event (the stream will not drain)
@@ -362,7 +379,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
       if (!sys_queued) return fail(f, VXBA_ERR_STATE, "li: internal -- no Hessian sweep in flight for the accepted state");
       {
         const auto tw = std::chrono::steady_clock::now();
-        rc = wait_event(ev_sys[cur]);
+        rc = wait_packed(ev_sys[cur]);
         f->li_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count();
         if (rc) return rc;
       }
@@ -428,6 +445,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
       if (q != hipErrorNotReady) VX_HIP(f, q);
     }
     const double r_lidar = host_sum_partials(f->h_partial2, nparts);
+    if (with_spec) nan_fill_packed();     // the residual sweep has run, so every earlier reduction is over, and the speculative one is a Hessian sweep away
     if (!(r_lidar == r_lidar)) return fail(f, VXBA_ERR_STATE, "li: a queued residual sweep gave up waiting for its poses");
     residual2 = r_imu + r_lidar;
     const double q = residual1 - residual2;
