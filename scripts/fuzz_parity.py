@@ -140,7 +140,12 @@ for case in range(n_cases):
         ca_scale = np.abs(ca_o).max(axis=(1, 2), keepdims=True)
         ca_err = float((np.abs(ca_g - ca_o) / ca_scale).max())
         check(ca_err < 1e-11, "planes cov_add n=%d rel %.2e" % (n_leaf, ca_err))          # per-cell scale: single entries cancel
-        check(np.all(np.abs(pl_g["plane_var"] * S[:, :, None] * S[:, None, :] - pl_o["plane_var"]) <= 1e-6 * scale_pv) and np.array_equal(pl_g["radius"], pl_o["radius"]), "planes plane_update n=%d seed=%d" % (n_leaf, s))
+        pv_dev = np.abs(pl_g["plane_var"] * S[:, :, None] * S[:, None, :] - pl_o["plane_var"]) / scale_pv
+        worst = int(np.argmax(pv_dev.max(axis=(1, 2))))
+        rad_ok = np.allclose(pl_g["radius"], pl_o["radius"], rtol=1e-12, atol=0)      # sqrt of an eigenvalue from two eigensolvers (Jacobi / QL): an ulp apart once in ~10^5 leaves
+        check(np.all(pv_dev <= 1e-6) and rad_ok,
+              "planes plane_update n=%d seed=%d: plane_var rel dev %.2e at leaf %d (eigenvalues %s, N=%d), radius within 1e-12 %s" %
+              (n_leaf, s, pv_dev.max(), worst, ev_o[worst], int(cl_o[worst, 9]), rad_ok))
         desc = "leaves=%d points=%d cov_add rel %.1e" % (n_leaf, k.size, ca_err)
     else:
         n = int(rng.integers(1, 300000)); size = float(rng.choice([0.05, 0.1, 0.25, 1.0])); scale = float(rng.choice([2.0, 30.0]))
