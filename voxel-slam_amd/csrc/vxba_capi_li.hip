@@ -283,22 +283,36 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
     VX_HIP(f, q);
     return VXBA_OK;
   };
-  // "The reduced system has arrived" is read off the mapped host buffer itself: the host fills it with NaNs while no reduction can be
-  // writing it, and the system is complete when the last NaN is gone (every slot is written exactly once per reduction) -- a few
-  // microseconds before the end-of-launch release and the event behind it would be seen.  The event stays as the back-stop.
-  auto nan_fill_packed = [&]() { for (size_t k = 0; k < plen; k++) f->h_packed[k] = std::numeric_limits<double>::quiet_NaN(); };
+  // "The reduced system has arrived" is read off the mapped host buffer itself: the host fills it with NaNs at a moment when NO
+  // reduction can be writing it, and the system is complete when the last NaN is gone (every slot is written exactly once per
+  // reduction) -- a few microseconds before the end-of-launch release and the event behind it would be seen.  Safe moments: the start
+  // of the call once the stream has drained (a previous call may have left a speculative reduction behind), and right after a system
+  // has been consumed -- the next reduction sits behind a residual sweep that is still waiting for its poses.  After a REJECTED step
+  // the wasted speculative reduction may still be running when the next poses are fed, so no fill then: `sentinel` is off and the next
+  // system is awaited through its event alone.  (A first version filled after every residual sweep, "a Hessian sweep before the next
+  // reduction": on small windows that sweep is 10 us, the fill sometimes came after the reduction, and the solve ran on NaNs.)
+  bool sentinel = false;
+  auto nan_fill_packed = [&]() { for (size_t k = 0; k < plen; k++) f->h_packed[k] = std::numeric_limits<double>::quiet_NaN(); sentinel = true; };
   auto wait_packed = [&](hipEvent_t ev) -> int {
     const volatile double* hp = f->h_packed;
     for (;;) {
-      bool all = true;
-      for (size_t k = 0; k < plen; k++)
-        if (!(hp[k] == hp[k])) { all = false; break; }
-      if (all) return VXBA_OK;
+      if (sentinel) {
+        bool all = true;
+        for (size_t k = 0; k < plen; k++)
+          if (!(hp[k] == hp[k])) { all = false; break; }
+        if (all) return VXBA_OK;
+      }
       const hipError_t q = hipEventQuery(ev);
       if (q == hipSuccess) return VXBA_OK;
       if (q != hipErrorNotReady) VX_HIP(f, q);
     }
   };
+  if (f->li_reduction_in_flight) {     // the previous call ended (converged) with its last speculative reduction unconsumed
+    hipError_t q;
+    while ((q = hipStreamQuery(f->stream)) == hipErrorNotReady) {}
+    VX_HIP(f, q);
+    f->li_reduction_in_flight = false;
+  }
   nan_fill_packed();
   // the device-side control block the queued sweeps read their poses from: not done, no error
   VX_HIP(f, hipMemsetAsync(f->d_lm, 0, sizeof(vxk::LMState), f->stream));
@@ -361,6 +375,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
   for (int it = 0; it < max_iter; it++) {
     const bool recomputed = is_calc_hess;
     const bool with_spec = it + 1 < max_iter;
+    f->li_reduction_in_flight = with_spec;          // cleared again when the next iteration consumes (or supersedes) it
     bool prepared = false;
     if (is_calc_hess) {
       if (imu_ready) { Hess.swap(HessN); JacT.swap(JacTN); imu_res = imu_res_next; imu_ready = false; }
@@ -386,11 +401,13 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
       sys_queued = false;
       vxi::li_hess_plus(W, Hess.data(), JacT.data(), f->h_packed, f->h_packed + (size_t)m6 * m6, n);
       residual1 = imu_res + f->h_packed[(size_t)m6 * m6 + m6];
+      if (with_spec) nan_fill_packed();            // consumed; the speculative reduction sits behind a residual sweep that has no poses yet
       last_hess = Hess.data();
       if (it == 0 && resis_out) resis_out[0] = residual1;
     } else {
       rc = queue_sweeps(with_spec);                 // rejected step: same system, new damping, new trial poses
       if (rc) return rc;
+      sentinel = false;                             // the rejected trial's reduction may still be writing the buffer
     }
     // gauge rows: identity with a zero right-hand side (never written into the matrix: the solve works on the block behind them)
     for (int r = 0; r < g0; r++) { JacT[r] = 0.0; dxi[r] = 0.0; }
@@ -445,8 +462,23 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
       if (q != hipErrorNotReady) VX_HIP(f, q);
     }
     const double r_lidar = host_sum_partials(f->h_partial2, nparts);
-    if (with_spec) nan_fill_packed();     // the residual sweep has run, so every earlier reduction is over, and the speculative one is a Hessian sweep away
-    if (!(r_lidar == r_lidar)) return fail(f, VXBA_ERR_STATE, "li: a queued residual sweep gave up waiting for its poses");
+    if (!(r_lidar == r_lidar)) {
+      int nan_cnt = 0, first_nan = -1;
+      for (int k = 0; k < nparts; k++) if (!(f->h_partial2[k] == f->h_partial2[k])) { nan_cnt++; if (first_nan < 0) first_nan = k; }
+      (void)hipStreamSynchronize(f->stream);
+      int nan_after = 0;
+      for (int k = 0; k < nparts; k++) if (!(f->h_partial2[k] == f->h_partial2[k])) nan_after++;
+      vxk::LMState* hl = f->h_lm;
+      (void)hipMemcpy(hl, f->d_lm, sizeof(vxk::LMState), hipMemcpyDeviceToHost);
+      int nx_nan = 0, nd_nan = 0, nh_nan = 0, nj_nan = 0;
+      for (double v2 : x_temp) if (!(v2 == v2)) nx_nan++;
+      for (int r = 0; r < n; r++) { if (!(dxi[r] == dxi[r])) nd_nan++; if (!(JacT[r] == JacT[r])) nj_nan++; }
+      for (size_t k = 0; k < (size_t)n * n; k++) if (!(Hess[k] == Hess[k])) nh_nan++;
+      char msg[480];
+      std::snprintf(msg, sizeof msg, "li: a queued residual sweep did not deliver its residual (iteration %d, seq %u: %d of %d block partials missing, first %d; %d after draining the stream; device error flag %d, published seq %u, feed word %.0f; NaNs in trial state %d, step %d, gradient %d, Hessian %d; recomputed %d, u %.3g, residual1 %.6g)",
+                    it, seq, nan_cnt, nparts, first_nan, nan_after, hl->error, hl->solve_seq, f->h_feed[0], nx_nan, nd_nan, nj_nan, nh_nan, (int)recomputed, u, residual1);
+      return fail(f, VXBA_ERR_STATE, msg);
+    }
     residual2 = r_imu + r_lidar;
     const double q = residual1 - residual2;
     const double u_used = u, v_used = v;
@@ -608,6 +640,7 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
   }
   if (n_trace) *n_trace = nt;
   if (hess_out && last_hess) std::memcpy(hess_out, last_hess, sizeof(double) * n * n);
+  f->li_reduction_in_flight = f->li_reduction_in_flight || spec_queued;   // an unconsumed speculative sweep may still be writing the host buffer
   f->li_last_call_us = us(t_call0, now());
   if (timing) std::fprintf(stderr, "[vxba li] %d iterations, %.0f us in the call: joint system %.0f us (of which waiting for the sweep %.0f), solve+update %.0f us, joint residual %.0f us\n", nt, us(t_call0, now()), t_sys, f->li_wait_us - wait0, t_solve, t_res);
   return VXBA_OK;
@@ -735,9 +768,9 @@ int vxba_li_damping_iter_gravity(vxba_factor* f, double* states, double* imus, d
   if (resis_out) resis_out[1] = residual2;
   if (n_trace) *n_trace = nt;
   if (hess_out && last_hess) std::memcpy(hess_out, last_hess, sizeof(double) * n * n);
+  f->li_reduction_in_flight = f->li_reduction_in_flight || spec_queued;
   f->li_last_call_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call0).count();
   return VXBA_OK;
 }
-
 
 }  // extern "C"

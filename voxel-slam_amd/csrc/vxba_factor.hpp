@@ -74,6 +74,7 @@ struct vxba_factor {
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
   vxw::DenseSolver* wide_solver = nullptr;   // wide windows: device Cholesky of the (6W)-dimensional LM step (vxba_wide.hip)
   bool wide_solver_tried = false;
+  bool li_reduction_in_flight = false;   // a speculative Hessian sweep + reduction of the last LI call may still be writing h_packed
   double li_last_call_us = 0;    // VXBA_STAT_LI_LAST_CALL_US
   double li_wait_us = 0;         // development (VXBA_LI_TIMING): time the LI shells spent waiting for the Hessian sweep
   struct LiScratch {             // host buffers of the LI shells, kept between calls (four (15W)^2 matrices: allocating and zeroing them
