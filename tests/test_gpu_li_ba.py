@@ -173,3 +173,43 @@ def test_queued_sweeps_back_to_back_solves_are_reproducible(vx, n_voxels):
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dbg_li_stress.py"), "2500", str(n_voxels)], capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
     assert "all identical" in r.stdout
+
+
+@pytest.mark.parametrize("queued", [1, 0])
+def test_li_edge_cases_one_iteration_and_rejected_steps(vx, queued):
+    """max_iter = 1 (no speculative sweep is ever queued), a start so far off that steps are rejected (the wasted speculative reduction,
+    the roll-back of the bias deltas, the re-solve with a larger damping), and an early convergence exit that leaves a speculative
+    reduction behind for the next call to find -- all against the oracle, in both shell modes."""
+    sc, iw, blobs, facs, fo, fg = build(vx, 6, 900, 9000, seed=811)
+    fg.set_option("li_queued_sweeps", queued)
+    ref = O.li_damping_iter(fo, iw.states_init, blobs, max_iter=1, thd_num=5, imu_coef=1e-4)
+    got = vx.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(iw.states_init, fg, facs, max_iter=1)
+    assert got["trace"].shape == ref["trace"].shape == (1, 8)
+    et, er = synth.pose_errors(got["states"][:, :12], ref["states"][:, :12])
+    assert et < 1e-7 and er < 1e-7 and np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-7)
+    # a bad start: velocities and biases far off -> rejected steps on the way
+    sc, iw, blobs, facs, fo, fg = build(vx, 5, 700, 7000, seed=812)
+    fg.set_option("li_queued_sweeps", queued)
+    st = iw.states_init.copy()
+    rng = np.random.default_rng(5)
+    st[:, 12:15] += rng.normal(0, 2.0, (5, 3)); st[:, 15:21] += rng.normal(0, 0.2, (5, 6)); st[1:, 9:12] += rng.normal(0, 0.3, (4, 3))
+    ref = O.li_damping_iter(fo, st, blobs, max_iter=8, thd_num=5, imu_coef=1e-4)
+    got = vx.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(st, fg, facs, max_iter=8)
+    assert got["trace"].shape == ref["trace"].shape
+    assert np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:])
+    assert np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-6)
+    et, er = synth.pose_errors(got["states"][:, :12], ref["states"][:, :12])
+    assert et < 1e-6 and er < 1e-6, (et, er)
+    # converge early (tiny steps from the optimum), then call again at once: the second call must not see the first one's leftovers
+    sc, iw, blobs, facs, fo, fg = build(vx, 5, 700, 7000, seed=813)
+    fg.set_option("li_queued_sweeps", queued)
+    first = vx.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(iw.states_init, fg, facs, max_iter=30)
+    assert first["trace"].shape[0] < 30                                   # stopped on the convergence test
+    blobs2 = np.stack([f.blob for f in facs])
+    fo2 = O.Oracle(5); fo2.push_voxels(sc.clusters, sc.fix, sc.coe); fo2.evaluate_only_residual(first["states"][:, :12])
+    fg.evaluate_only_residual(first["states"][:, :12])
+    ref2 = O.li_damping_iter(fo2, first["states"], blobs2, max_iter=2, thd_num=5, imu_coef=1e-4)
+    again = vx.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(first["states"], fg, facs, max_iter=2)
+    assert np.array_equal(again["trace"][:, 6:], ref2["trace"][:, 6:]) and np.allclose(again["trace"][:, :2], ref2["trace"][:, :2], rtol=1e-6)
+    et, er = synth.pose_errors(again["states"][:, :12], ref2["states"][:, :12])
+    assert et < 1e-7 and er < 1e-7
