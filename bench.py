@@ -82,8 +82,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-li-ba", action="store_true", help="skip the secondary LiDAR-inertial BA figure")
-    ap.add_argument("--precision", choices=["f64", "mixed"], default="f64",
-                    help="mixed = BASELINE configs[2]: f32 Hessian products on the matrix cores, f64 accumulation (use with --config cfg3)")
+    ap.add_argument("--precision", choices=["f64", "mixed", "mixed_f32_clusters"], default="f64",
+                    help="mixed = BASELINE configs[2]: f32 Hessian products on the matrix cores, f64 accumulation (use with --config cfg3); "
+                         "mixed_f32_clusters: mixed, and the residual sweep reads the clusters as f32 re-centred records")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = every GPU owns a full --config-sized voxel shard of an N-times larger window (BASELINE configs[3] at N = 8; "
                          "value = N*K/time in shard-iterations/s); strong = ONE --config window split over the N GPUs (value = K/time)")
@@ -261,7 +262,8 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f64" if args.precision == "f64" else "f32 products / f64 accumulation (Hessian sweep), f64 elsewhere",
+            "dtype": "f64" if args.precision == "f64" else ("f32 products / f64 accumulation (Hessian sweep), f64 elsewhere" if args.precision == "mixed" else
+                      "f32 products / f64 accumulation (Hessian sweep), f32 re-centred cluster rows (residual sweep), f64 arithmetic elsewhere"),
             "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: W={W}, {sc.points_body.shape[0] // W} pts/scan, {V} voxels per GPU, nnz={nnz}",

@@ -362,6 +362,12 @@ int vxba_get_option(const vxba_factor* f, int option, int* value);
  * fixed point is unchanged; only the step direction carries ~1e-7 relative error. */
 #define VXBA_PRECISION_F64 0
 #define VXBA_PRECISION_MIXED 1
+/* MIXED, and the residual sweep reads the clusters from an f32 copy ("clusters also emitted as f32", configs[2]): per (voxel, frame)
+ * [C sym6 | c | n] with c the cluster's mean and C its second moments ABOUT that mean -- raw body-frame moments do not survive f32, the
+ * re-centred ones do (round-off ~1e-7 m^2 against a plane thickness of ~1e-2 m^2).  Half the bytes of that sweep's dominant stream.
+ * The copy is kept beside the f64 rows (the Hessian sweep and every read-back use those) and refreshed when voxels were appended.
+ * Eigenvalues / residuals move by ~1e-6 relative, and with them the LM fixed point by micrometres. */
+#define VXBA_PRECISION_MIXED_F32_CLUSTERS 2
 int vxba_set_precision(vxba_factor* f, int mode);
 
 /* ---- odometry: point-to-plane state estimation against the voxel plane map ---------------- */
@@ -454,7 +460,7 @@ int vxba_get_kernel_times(vxba_factor* f, double ms_sum[4], int64_t calls[4], in
 int vxba_algorithmic_bytes(const vxba_factor* f, double bytes[2]);
 int vxba_nnz(vxba_factor* f, int64_t* nnz);
 /* Device memory the factor holds right now, in bytes: [0] the factor itself (cluster storage -- frame-major planes, or the compressed
- * rows of a window wider than VXBA_MAX_WIN -- per-voxel planes, batch-major copy, cache snapshot), [1] sweep work space (block
+ * rows of a window wider than VXBA_MAX_WIN -- per-voxel planes, batch-major copy, the f32 cluster copy of VXBA_PRECISION_MIXED_F32_CLUSTERS, cache snapshot), [1] sweep work space (block
  * partials, packed system; for wide windows the pair index, the row buffer and the dense solver), [2] grow-only staging / scratch
  * left behind by the push calls, [3] the sum. */
 int vxba_device_bytes(const vxba_factor* f, int64_t bytes[4]);

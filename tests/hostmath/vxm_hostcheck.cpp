@@ -47,6 +47,34 @@ void vxmh_k2(int V, int W, const double* clusters, const double* fix, const doub
   *residual = res;
 }
 
+// K2 with the f32 re-centred cluster records (VXBA_PRECISION_MIXED_F32_CLUSTERS): records out (V*W*10 floats), same outputs as vxmh_k2
+void vxmh_k2_f32(int V, int W, const double* clusters, const double* fix, const double* coe, const double* Rp, float* records, double* eig_val,
+                 double* merged, double* residual) {
+  double res = 0;
+  for (int a = 0; a < V; a++) {
+    double SP[6], Sv[3], SN;
+    for (int k = 0; k < 6; k++) SP[k] = fix[10 * a + k];
+    for (int k = 0; k < 3; k++) Sv[k] = fix[10 * a + 6 + k];
+    SN = fix[10 * a + 9];
+    for (int i = 0; i < W; i++) {
+      float* rec = records + ((size_t)a * W + i) * 10;
+      vxm::cluster_to_centred_f32(clusters + ((size_t)a * W + i) * 10, rec);
+      double R[9], p[3];
+      pose_rowmajor(Rp + 12 * i, R, p);
+      vxm::transform_accumulate_centred(rec, R, p, SP, Sv, SN);     // unobserved slots are all-zero records: no test, as in the kernel
+    }
+    double C[6], lam[3], U[9];
+    vxm::cluster_cov(SP, Sv, SN, C);
+    vxm::eig_sym3(C, lam, U);
+    for (int k = 0; k < 3; k++) eig_val[3 * a + k] = lam[k];
+    for (int k = 0; k < 6; k++) merged[10 * a + k] = SP[k];
+    for (int k = 0; k < 3; k++) merged[10 * a + 6 + k] = Sv[k];
+    merged[10 * a + 9] = SN;
+    res += coe[a] * lam[0];
+  }
+  *residual = res;
+}
+
 // K3 on the host via the rank-3 rows: Hess (6W)^2 col-major, JacT 6W, residual
 // spare != 0: the narrow-window kernel's variant -- k3_entry<false> leaves Drt / Dtt out of the accumulators and the z row of
 // every voxel carries sqrt2 sqrt(coe) u in three extra columns, whose products with the frame columns ARE Drt / Dtt

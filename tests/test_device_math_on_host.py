@@ -28,6 +28,8 @@ def hm():
     L.vxmh_k2.argtypes = [C.c_int, C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, f64p, C.POINTER(C.c_double)]
     L.vxmh_k3.argtypes = [C.c_int, C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p, C.POINTER(C.c_double)]
     L.vxmh_k3_spare.argtypes = L.vxmh_k3.argtypes
+    L.vxmh_k2_f32.argtypes = [C.c_int, C.c_int, f64p, f64p, f64p, f64p, np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS"), f64p, f64p,
+                              C.POINTER(C.c_double)]
     return L
 
 
@@ -118,3 +120,46 @@ def test_k2_and_k3_lane_math_match_oracle(hm, p_obs, fix_frac):
     assert np.allclose(H2, H_ref, rtol=1e-9, atol=1e-10 * np.abs(H_ref).max())
     assert np.allclose(H2, H2.T, rtol=0, atol=1e-12 * np.abs(H_ref).max())
     assert np.allclose(J2, J_ref, rtol=1e-9, atol=1e-11 * np.abs(J_ref).max())
+
+
+@pytest.mark.parametrize("p_obs,fix_frac", [(1.0, 0.0), (0.6, 0.3)])
+def test_f32_recentred_cluster_records(hm, p_obs, fix_frac):
+    """VXBA_PRECISION_MIXED_F32_CLUSTERS: the residual sweep's arithmetic on [C | c | n] records rounded to f32 stays within ~1e-5 of the
+    fp64 one on a window whose clusters sit tens of metres from the sensor -- and the raw moments rounded to f32 do not (why the records
+    are re-centred)."""
+    sc = synth.make_scene(win_size=6, pts_per_scan=6000, n_voxels=300, p_obs=p_obs, fix_frac=fix_frac, seed=77, rot_sigma_deg=0.2, trans_sigma=0.03)
+    V, W = sc.n_voxels, sc.win_size
+    # move the whole scene 40 m away from the sensor: body-frame second moments ~ n * 1600 m^2
+    off = np.array([40.0, -25.0, 3.0])
+    cl = sc.clusters.reshape(V, W, 10).copy()
+    n = cl[..., 9]
+    v = cl[..., 6:9].copy()
+    I, J = [0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]
+    for k in range(6):
+        cl[..., k] += v[..., I[k]] * off[J[k]] + off[I[k]] * v[..., J[k]] + n * off[I[k]] * off[J[k]]
+    cl[..., 6:9] += n[..., None] * off
+    poses = sc.poses_init.reshape(W, 12).copy()
+    for i in range(W):
+        R = poses[i, :9].reshape(3, 3).T        # column-major in the pose record
+        poses[i, 9:12] -= R @ off                # world positions unchanged
+    cl = np.ascontiguousarray(cl.reshape(V * W, 10)); poses = np.ascontiguousarray(poses.reshape(-1))
+    coe = np.linspace(0.5, 2.0, V)
+    ev = np.zeros((V, 3)); U = np.zeros((V, 9)); m = np.zeros((V, 10)); r = C.c_double(0)
+    hm.vxmh_k2(V, W, cl, sc.fix, coe, poses, ev, U, m, C.byref(r))
+    ev0 = np.zeros((V, 3)); r0 = C.c_double(0)
+    hm.vxmh_k2(V, W, np.ascontiguousarray(sc.clusters), sc.fix, coe, sc.poses_init, ev0, U, np.zeros((V, 10)), C.byref(r0))
+    assert np.isclose(r.value, r0.value, rtol=1e-9)            # the shifted scene is the same scene
+    rec = np.zeros((V * W, 10), dtype=np.float32)
+    ev32 = np.zeros((V, 3)); m32 = np.zeros((V, 10)); r32 = C.c_double(0)
+    hm.vxmh_k2_f32(V, W, cl, sc.fix, coe, poses, rec, ev32, m32, C.byref(r32))
+    assert np.array_equal(m32[:, 9], m[:, 9])                    # point counts exact
+    assert np.all(rec[cl[:, 9] == 0] == 0)                       # unobserved slots: all-zero records
+    assert abs(r32.value / r.value - 1) < 2e-5, r32.value / r.value - 1
+    assert np.allclose(ev32[:, 0], ev[:, 0], rtol=2e-4, atol=0) and np.allclose(ev32[:, 1:], ev[:, 1:], rtol=1e-5)
+    # merged mean: micrometres
+    assert np.max(np.abs(m32[:, 6:9] / m32[:, 9:10] - m[:, 6:9] / m[:, 9:10])) < 2e-5
+    # the same through naively rounded raw moments: the smallest eigenvalue (the residual) is destroyed
+    ev_n = np.zeros((V, 3)); r_n = C.c_double(0)
+    hm.vxmh_k2(V, W, cl.astype(np.float32).astype(np.float64), sc.fix, coe, poses, ev_n, U, np.zeros((V, 10)), C.byref(r_n))
+    worst_naive, worst_centred = np.max(np.abs(ev_n[:, 0] / ev[:, 0] - 1)), np.max(np.abs(ev32[:, 0] / ev[:, 0] - 1))
+    assert worst_naive > 0.05 and worst_naive > 300 * worst_centred, (worst_naive, worst_centred)

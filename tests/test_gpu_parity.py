@@ -539,6 +539,68 @@ def test_mixed_precision_lm_meets_the_pose_tolerance(vx):
     assert e1[0] < 0.2 * e0[0]
 
 
+@pytest.mark.parametrize("W", [10, 4])
+def test_f32_recentred_cluster_rows_in_the_residual_sweep(vx, W):
+    """VXBA_PRECISION_MIXED_F32_CLUSTERS (configs[2]: "clusters also emitted as f32"): the residual sweep reads [C | c | n] records in f32.
+    Against the fp64 sweep: point counts exact, eigenvalues / residual within f32 rounding of the RE-CENTRED moments; the copy follows
+    appends and clears; the Hessian sweep and the fp64 mode are untouched."""
+    sc = synth.make_scene(win_size=W, pts_per_scan=30_000, n_voxels=3000, p_obs=0.8, fix_frac=0.2, seed=950 + W)
+    V = sc.n_voxels
+    fg = vx.LidarFactor(W)
+    fg.push_voxels(sc.clusters, sc.fix, sc.coe)
+    r64 = fg.evaluate_only_residual(sc.poses_init)
+    ev64, U64, m64 = fg.read_cache()
+    b0 = fg.device_bytes()
+    fg.set_precision("mixed_f32_clusters")
+    r32 = fg.evaluate_only_residual(sc.poses_init)
+    ev32, U32, m32 = fg.read_cache()
+    extra = fg.device_bytes()["store"] - b0["store"]
+    assert extra >= 4 * 10 * W * V and extra % (4 * 10 * W) == 0            # one float per double of the cluster planes
+    assert r32 != r64 and abs(r32 / r64 - 1) < 2e-5, r32 / r64 - 1            # really the f32 rows, and within their rounding
+    assert np.array_equal(m32[:, 9], m64[:, 9])
+    assert np.allclose(ev32[:, 0], ev64[:, 0], rtol=5e-4) and np.allclose(ev32[:, 1:], ev64[:, 1:], rtol=1e-5)
+    assert np.max(np.abs(m32[:, 6:9] / m32[:, 9:10] - m64[:, 6:9] / m64[:, 9:10])) < 2e-5
+    # sub-ranges add up to the same sweep
+    ra = fg.evaluate_only_residual(sc.poses_init, 0, V // 3); rb = fg.evaluate_only_residual(sc.poses_init, V // 3, V)
+    assert np.isclose(ra + rb, r32, rtol=1e-13)
+    # appended voxels are converted before the next sweep; a clear starts over
+    cut = V // 2 + 5
+    f2 = vx.LidarFactor(W)
+    f2.set_precision("mixed_f32_clusters")
+    f2.push_voxels(sc.clusters[:cut], sc.fix[:cut], sc.coe[:cut])
+    r_head = f2.evaluate_only_residual(sc.poses_init)
+    f2.push_voxels(sc.clusters[cut:], sc.fix[cut:], sc.coe[cut:])
+    assert f2.evaluate_only_residual(sc.poses_init, 0, cut) == r_head
+    r_all = f2.evaluate_only_residual(sc.poses_init)
+    assert np.isclose(r_all, r32, rtol=1e-12)                                # same records; the block partials are cut differently
+    f2.clear()
+    f2.push_voxels(sc.clusters[cut:], sc.fix[cut:], sc.coe[cut:])
+    assert np.isclose(f2.evaluate_only_residual(sc.poses_init), r32 - r_head, rtol=1e-10)
+    # back to fp64: the fp64 rows again (merged moments bit-identical; the eigensolver is warm-started from the cached vectors, so the
+    # eigenvalues agree to round-off rather than bit for bit)
+    fg.set_precision("f64")
+    assert np.isclose(fg.evaluate_only_residual(sc.poses_init), r64, rtol=1e-12)
+    e, U, m = fg.read_cache()
+    assert np.allclose(e, ev64, rtol=1e-10, atol=1e-15) and np.array_equal(m, m64)
+
+
+def test_f32_cluster_rows_lm_meets_the_pose_tolerance(vx):
+    """The tolerance study with f32 cluster rows in the residual sweep on top of the f32 Hessian products: same accept/reject sequence
+    as the fp64 CPU oracle, poses far inside the 1e-4 m / 1e-4 rad contract (the data moved by f32 rounding of centred moments: ~um)."""
+    sc = synth.make_scene(win_size=10, pts_per_scan=60_000, n_voxels=6000, p_obs=0.9, seed=4711, rot_sigma_deg=0.1, trans_sigma=0.03)
+    fo, fg = seeded_pair(vx, sc)
+    ref = fo.damping_iter(sc.poses_init, max_iter=6, thd_num=4)
+    fg.set_precision("mixed_f32_clusters")
+    fg.evaluate_only_residual(sc.poses_init)                  # the cache the first Hessian sweep reads: from the f32 rows, like every later one
+    got = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=6)
+    assert np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:])
+    assert np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-4)
+    et, er = synth.pose_errors(got["poses"], ref["poses"])
+    assert et < 1e-5 and er < 1e-5, (et, er)
+    e0 = synth.pose_errors(sc.poses_init, sc.poses_gt); e1 = synth.pose_errors(got["poses"], sc.poses_gt)
+    assert e1[0] < 0.2 * e0[0]
+
+
 def run_two_shards(vx, sc, iters):
     """Two factors holding the two halves of the window's voxels, one host thread + one stream each, an all-reduce hook that really
     adds the two exchange buffers.  Returns (outputs, hook call counts, factors)."""

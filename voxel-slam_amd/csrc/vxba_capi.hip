@@ -50,10 +50,31 @@ FactorView view(const vxba_factor* f) {
   fv.eigvec = p;                 p += 9 * VS;
   fv.merged = p;                 p += 10 * VS;
   fv.aux = p;
+  fv.cl32 = nullptr;
   fv.VS = f->VS;
   fv.W = f->W;
   return fv;
 }
+
+int residual_view(vxba_factor* f, FactorView& fv) {
+  fv = view(f);
+  if (f->precision != VXBA_PRECISION_MIXED_F32_CLUSTERS || is_wide(f) || f->V == 0) return VXBA_OK;
+  if (!f->cl32 || f->cl32_vs != f->VS) {
+    if (f->cl32) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->cl32)); f->cl32 = nullptr; }
+    VX_HIP(f, hipMalloc((void**)&f->cl32, (size_t)10 * f->W * f->VS * sizeof(float)));
+    f->cl32_vs = f->VS;
+    f->cl32_built = 0;
+  }
+  fv.cl32 = f->cl32;
+  if (f->cl32_built < f->V) {
+    vxk::launch_build_cl32(fv, f->cl32_built, f->V - f->cl32_built, f->stream);
+    VX_HIP(f, hipGetLastError());
+    f->cl32_built = f->V;
+  }
+  return VXBA_OK;
+}
+// cluster planes of voxels >= v0 were (re)written: their f32 copies are stale
+static inline void clusters_written(vxba_factor* f, int v0) { if (v0 < f->cl32_built) f->cl32_built = v0; }
 
 vxw::WideView wview(const vxba_factor* f) { return vxw::wide_view(view(f), f->wstore); }
 
@@ -324,7 +345,8 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, in
   }
   PoseArg pa;
   if (Rp) fill_poses(f, Rp, pa); else std::memset(&pa, 0, sizeof pa);
-  const FactorView fv = view(f);
+  FactorView fv;
+  { const int rcv = residual_view(f, fv); if (rcv) return rcv; }
   int nparts;
   double* const part = (partials_to_host && !is_wide(f)) ? f->zc_partial2 : f->d_partial2;
   if (partials_to_host) d_out = nullptr;
@@ -501,7 +523,7 @@ int vxba_destroy(vxba_factor* f) {
   if (f->peer.box) hipFree(f->peer.box);
   for (auto& ep : f->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   for (auto e : f->free_events) hipEventDestroy(e);
-  hipFree(f->planes); hipFree(f->clb); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2); if (f->h_partial2) hipHostFree(f->h_partial2);
+  hipFree(f->planes); hipFree(f->clb); hipFree(f->cl32); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2); if (f->h_partial2) hipHostFree(f->h_partial2);
   if (f->h_feed) (void)hipHostFree(f->h_feed);
   if (f->li_ev2) (void)hipEventDestroy(f->li_ev2);
   if (f->li_ev3) (void)hipEventDestroy(f->li_ev3);
@@ -525,6 +547,7 @@ int vxba_clear(vxba_factor* f) {
   VX_LOCK(f);
   if (!f) return VXBA_ERR_ARG;
   f->V = 0;
+  f->cl32_built = 0;
   f->wstore.nnz = 0;
   f->wide_dirty = true;
   f->snapshot_v = 0;
@@ -539,6 +562,7 @@ int vxba_set_win_size(vxba_factor* f, int win_size) {
   if (f->V != 0) return fail(f, VXBA_ERR_STATE, "win_size can only change on an empty factor");
   hipSetDevice(f->device);
   if (f->planes) { VX_HIP(f, hipStreamSynchronize(f->stream)); VX_HIP(f, hipFree(f->planes)); if (f->clb) VX_HIP(f, hipFree(f->clb)); f->planes = nullptr; f->clb = nullptr; }
+  if (f->cl32) { VX_HIP(f, hipFree(f->cl32)); f->cl32 = nullptr; f->cl32_vs = 0; f->cl32_built = 0; }
   f->VS = 0;
   vxw::store_free(f->wstore);
   vxw::free_index(f->wide);
@@ -787,6 +811,7 @@ int vxba_push_voxels(vxba_factor* f, int n, const double* clusters, const double
   else {
     vxk::launch_scatter_clusters(f->staging, view(f), f->V, n, f->stream);
     vxk::launch_build_clb(view(f), f->V, n, f->stream);
+    clusters_written(f, f->V);
   }
   VX_HIP(f, hipStreamSynchronize(f->stream));
   rc = append_meta(f, f->V, n, fix, coe, eig_val, eig_vec, merged);
@@ -851,6 +876,7 @@ int vxba_push_voxels_csr(vxba_factor* f, int n, const int64_t* row_ptr, const in
   } else {
     vxk::launch_scatter_clusters_csr(d_ptr, d_fr, d_cl, view(f), f->V, n, d_bad, f->stream);
     vxk::launch_build_clb(view(f), f->V, n, f->stream);
+    clusters_written(f, f->V);
   }
   int bad = 0;
   VX_HIP(f, hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, f->stream));
@@ -906,6 +932,7 @@ int vxba_push_points(vxba_factor* f, int n_voxels, int64_t n_points, const doubl
       vxk::launch_k1_build(d_xyz, d_ptr, n_voxels, f->W, view(f), f->V, f->stream);
     }
     vxk::launch_build_clb(view(f), f->V, n_voxels, f->stream);
+    clusters_written(f, f->V);
   }
   e = hipStreamSynchronize(f->stream);
   if (e == hipSuccess) e = hipGetLastError();
@@ -1399,6 +1426,7 @@ static int voxelize_push_impl(vxba_factor* f, int64_t n_points, const double* xy
     } else {
       vxk::launch_scatter_clusters(d_cl, fv, v0, (int)n, f->stream);
       vxk::launch_build_clb(fv, v0, (int)n, f->stream);
+      clusters_written(f, v0);
     }
     vxk::launch_scatter_rows(d_fix, fv.fix, f->VS, v0, (int)n, 10, f->stream);
     vxk::launch_scatter_rows(d_coe, fv.coe, f->VS, v0, (int)n, 1, f->stream);
@@ -1461,6 +1489,7 @@ int vxba_internal_push_voxels_device(vxba_factor* f, int n, const double* d_clus
   else {
     vxk::launch_scatter_clusters(d_clusters, fv, v0, n, f->stream);
     vxk::launch_build_clb(fv, v0, n, f->stream);
+    clusters_written(f, v0);
   }
   vxk::launch_scatter_rows(d_fix, fv.fix, f->VS, v0, n, 10, f->stream);
   vxk::launch_scatter_rows(d_coe, fv.coe, f->VS, v0, n, 1, f->stream);
@@ -1518,7 +1547,8 @@ int vxba_get_option(const vxba_factor* f, int option, int* value) {
 
 int vxba_set_precision(vxba_factor* f, int mode) {
   VX_LOCK(f);
-  if (!f || (mode != VXBA_PRECISION_F64 && mode != VXBA_PRECISION_MIXED)) return fail(f, VXBA_ERR_ARG, "set_precision: mode must be VXBA_PRECISION_F64 or VXBA_PRECISION_MIXED");
+  if (!f || (mode != VXBA_PRECISION_F64 && mode != VXBA_PRECISION_MIXED && mode != VXBA_PRECISION_MIXED_F32_CLUSTERS))
+    return fail(f, VXBA_ERR_ARG, "set_precision: mode must be VXBA_PRECISION_F64, VXBA_PRECISION_MIXED or VXBA_PRECISION_MIXED_F32_CLUSTERS");
   if (mode != VXBA_PRECISION_F64) VX_NARROW_ONLY(f, "mixed precision");
   f->precision = mode;
   return VXBA_OK;
@@ -1574,6 +1604,7 @@ int vxba_device_bytes(const vxba_factor* f, int64_t bytes[4]) {
   size_t store = (size_t)n_planes(f) * f->VS * d + (f->snapshot ? (size_t)N_CACHE_PLANES * f->snapshot_vs * d : 0);
   if (is_wide(f)) store += vxw::store_bytes(f->wstore);
   else if (f->clb) store += vxk::k3_clb_len(f->W, f->VS) * d;
+  if (f->cl32) store += (size_t)10 * f->W * f->cl32_vs * sizeof(float);
   size_t work = f->partial2_len * d + f->partial3_len * d + f->xlen * d + sizeof(vxk::LMState);
   if (is_wide(f)) work += vxw::index_bytes(f->wide, f->W) + vxw::wide_solver_bytes(f->wide_solver) + sizeof(double) * 12 * VXBA_MAX_WIN_WIDE;
   const size_t scratch = f->staging_len * d + f->scratch_cap;
@@ -1589,7 +1620,7 @@ int vxba_algorithmic_bytes(const vxba_factor* f, double bytes[2]) {
   if (rc) return rc;
   // K3 = 80 nnz + 136 V read;  K2 = 80 nnz + 88 V read + 176 V written
   bytes[0] = 80.0 * (double)nnz + 136.0 * f->V;
-  bytes[1] = 80.0 * (double)nnz + 264.0 * f->V;
+  bytes[1] = (f->precision == VXBA_PRECISION_MIXED_F32_CLUSTERS ? 40.0 : 80.0) * (double)nnz + 264.0 * f->V;   // f32 cluster rows: 10 floats per entry
   return VXBA_OK;
 }
 

@@ -270,8 +270,10 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
   hipEvent_t ev_sys[2] = {f->li_ev2, f->li_ev3};
   int cur = 0;
   const size_t plen = vxba_packed_len(f);
-  const FactorView fv = view(f);
-  int rc = ensure_partials3(f);
+  FactorView fv;
+  int rc = residual_view(f, fv);
+  if (rc) return rc;
+  rc = ensure_partials3(f);
   if (rc) return rc;
   const int nv = vxk::k3_nv(W);
   const int nblocks3 = vxk::k3_blocks_for((f->V - 1) / nv + 1, vxk::k3_grid_blocks(f->cus));

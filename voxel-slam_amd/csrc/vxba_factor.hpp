@@ -48,6 +48,9 @@ struct vxba_factor {
   hipStream_t stream = nullptr, own_stream = nullptr;
   double* planes = nullptr;      // [(10W + N_META_PLANES)][VS]
   double* clb = nullptr;         // batch-major copy of the clusters for the Hessian sweep
+  float* cl32 = nullptr;         // VXBA_PRECISION_MIXED_F32_CLUSTERS: f32 re-centred copy of the cluster planes for the residual sweep (built on demand)
+  int cl32_vs = 0;               // voxel stride it was allocated for
+  int cl32_built = 0;            // voxels [0, cl32_built) are converted (the factor is append-only between clears)
   double* snapshot = nullptr;    // [N_CACHE_PLANES][snapshot_vs]
   int snapshot_vs = 0, snapshot_v = 0;
   double* staging = nullptr;     // device scratch for uploads / read-backs
@@ -95,7 +98,7 @@ struct vxba_factor {
   hipEvent_t pose_ev[8] = {};
   unsigned pose_slot = 0;
   size_t xlen = 0;               // doubles the exchange buffers (own_packed, h_packed) hold
-  int precision = 0;             // 0: fp64 throughout; 1: Hessian products in f32 on the matrix cores, f64 accumulation
+  int precision = 0;             // 0: fp64 throughout; 1: Hessian products in f32 on the matrix cores, f64 accumulation; 2: 1 + f32 re-centred cluster rows in the residual sweep
   unsigned lm_seq = 0;           // sequence numbers of solves published inside residual-sweep launches (never 0)
   hipEvent_t li_ev3 = nullptr;
   hipEvent_t li_ev2 = nullptr;   // ... and the end of a Hessian sweep + reduction queued ahead (queued-sweeps mode: the stream never drains)
@@ -150,6 +153,8 @@ int fail(vxba_factor* f, int code, const char* msg);
 bool is_wide(const vxba_factor* f);
 bool has_collective(const vxba_factor* f);
 vxk::FactorView view(const vxba_factor* f);
+// view for a residual sweep: under VXBA_PRECISION_MIXED_F32_CLUSTERS the f32 re-centred cluster copy is brought up to date (on f->stream) and attached
+int residual_view(vxba_factor* f, vxk::FactorView& fv);
 int ensure_exchange(vxba_factor* f);
 int ensure_partials3(vxba_factor* f);
 void fill_poses(const vxba_factor* f, const double* Rp, vxk::PoseArg& pa);

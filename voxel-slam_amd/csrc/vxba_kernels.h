@@ -32,6 +32,7 @@ struct FactorView {
   double* eigvec;
   double* merged;
   double* aux;
+  float* cl32;     // f32 re-centred copy of the cluster planes (same frame-major layout), or nullptr: residual sweep of VXBA_OPT_F32_CLUSTERS
   int VS;
   int W;
 };
@@ -148,6 +149,7 @@ void launch_k1_build_aos(const double* d_xyz, const int64_t* d_cell_ptr, int64_t
 
 // Rebuild the batch-major copy (clb) of voxels [v0, v0+n) from the frame-major planes.
 void launch_build_clb(const FactorView& fv, int v0, int n, hipStream_t s);
+void launch_build_cl32(const FactorView& fv, int v0, int n, hipStream_t s);
 
 // Layout plumbing between the C-ABI's packed AoS rows and the device planes.
 void launch_scatter_clusters(const double* d_src /*[n][W][10]*/, const FactorView& fv, int v0, int n, hipStream_t s);

@@ -163,7 +163,9 @@ constexpr unsigned K2_SPIN_LIMIT = 1u << 22;
 #ifndef VXBA_PUBLISH_FENCE
 #define VXBA_PUBLISH_FENCE 0
 #endif
-template <int W, bool DBG = false>
+// F32: the cluster rows come from the f32 re-centred copy (fv.cl32, vxm::cluster_to_centred_f32; VXBA_OPT_F32_CLUSTERS, meant for the
+// mixed-precision configuration): half the bytes of the sweep's dominant stream and half the registers of the load phase.
+template <int W, bool DBG = false, bool F32 = false>
 __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c, unsigned seq, int head, int end,
                                                          int VPB_arg, double* __restrict__ partial, const double* host_feed) {
   const int VPB = VPB_arg & 0xffff;
@@ -214,7 +216,8 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
   dbg_stamp(DBG, vb, 0);
   // issue every load of this voxel up front (10 + 10 W independent 512 B rows per wave): with < 1 wave per
   // SIMD at 50k voxels the sweep is latency-bound unless all of them are in flight together
-  double fx[10], cl[W][10], Up[9];
+  double fx[10], cl[F32 ? 1 : W][10], Up[9];
+  float cr[F32 ? W : 1][10];
   if (valid) {
 #pragma unroll
     for (int k = 0; k < 10; k++) fx[k] = fv.fix[k * VS + a];
@@ -223,10 +226,17 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
     for (int col = 0; col < 3; col++)
 #pragma unroll
       for (int row = 0; row < 3; row++) Up[3 * row + col] = fv.eigvec[(size_t)(3 * col + row) * VS + a];
+    if (F32) {
 #pragma unroll
-    for (int i = 0; i < W; i++)
+      for (int i = 0; i < W; i++)
 #pragma unroll
-      for (int k = 0; k < 10; k++) cl[i][k] = fv.cl[((size_t)i * 10 + k) * VS + a];
+        for (int k = 0; k < 10; k++) cr[F32 ? i : 0][k] = fv.cl32[((size_t)i * 10 + k) * VS + a];
+    } else {
+#pragma unroll
+      for (int i = 0; i < W; i++)
+#pragma unroll
+        for (int k = 0; k < 10; k++) cl[F32 ? 0 : i][k] = fv.cl[((size_t)i * 10 + k) * VS + a];
+    }
   }
   // poses -> LDS (wave-uniform operands of the transform).  LM mode reads the trial poses with coherent loads, after
   // the solve has published them when it runs inside this launch.
@@ -262,10 +272,6 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
     SN = fx[9];
 #pragma unroll
     for (int i = 0; i < W; i++) {
-      // N == 0 <=> frame i did not observe this voxel (voxel_map.hpp:258): contributes nothing
-      const bool obs = cl[i][9] != 0.0;
-#pragma unroll
-      for (int k = 0; k < 10; k++) cl[i][k] = obs ? cl[i][k] : 0.0;
       double R[9], p[3];
 #pragma unroll
       for (int r = 0; r < 3; r++)
@@ -273,7 +279,15 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
         for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = pose_lds[12 * i + 3 * cc + r];
 #pragma unroll
       for (int k = 0; k < 3; k++) p[k] = pose_lds[12 * i + 9 + k];
-      vxm::transform_accumulate(cl[i], cl[i] + 6, cl[i][9], R, p, SP, Sv, SN);
+      if (F32) vxm::transform_accumulate_centred(cr[F32 ? i : 0], R, p, SP, Sv, SN);
+      else {
+        // N == 0 <=> frame i did not observe this voxel (voxel_map.hpp:258): contributes nothing
+        double* ci = cl[F32 ? 0 : i];
+        const bool obs = ci[9] != 0.0;
+#pragma unroll
+        for (int k = 0; k < 10; k++) ci[k] = obs ? ci[k] : 0.0;
+        vxm::transform_accumulate(ci, ci + 6, ci[9], R, p, SP, Sv, SN);
+      }
     }
     double C[6], lam[3], U[9];
     vxm::cluster_cov(SP, Sv, SN, C);
@@ -731,6 +745,21 @@ __global__ void build_clb_kernel(FactorView fv, int nv, int V_hi, int b_lo, int 
   d[1] = x1;
 }
 
+// frame-major f64 planes -> the f32 re-centred copy the residual sweep reads under VXBA_OPT_F32_CLUSTERS, voxels [v0, v0+n)
+__global__ void build_cl32_kernel(FactorView fv, int v0, int n) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (frame, voxel)
+  if (t >= (long long)n * fv.W) return;
+  const int a = v0 + (int)(t % n), i = (int)(t / n);
+  const size_t VS = (size_t)fv.VS;
+  double c[10];
+  float r[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) c[k] = fv.cl[((size_t)i * 10 + k) * VS + a];
+  vxm::cluster_to_centred_f32(c, r);
+#pragma unroll
+  for (int k = 0; k < 10; k++) fv.cl32[((size_t)i * 10 + k) * VS + a] = r[k];
+}
+
 __global__ void scatter_clusters_kernel(const double* __restrict__ src, FactorView fv, int v0, int n) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int W = fv.W;
@@ -965,7 +994,12 @@ int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, 
   const int grid = nblocks + (seq != 0 ? 1 : 0);   // + the solve workgroup
   static int dbg = -1;
   if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
-  if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed)); }
+  if (fv.cl32) {   // f32 re-centred cluster rows (the caller built them: vxba_capi.hip, residual_view)
+    if (ev_start) {
+      VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false, true>), dim3(grid), dim3(64), 0, s, ev_start, ev_stop, 0, fv, poses, st, c, seq, head,
+                                                  end, vpb_arg, d_partial, host_feed));
+    } else { VXK_DISPATCH_W(fv.W, (k2_residual_kernel<WW, false, true><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed))); }
+  } else if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed)); }
   else if (ev_start) {
     VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), dim3(grid), dim3(64), 0, s, ev_start, ev_stop, 0, fv, poses, st, c, seq, head,
                                                 end, vpb_arg, d_partial, host_feed));
@@ -1082,6 +1116,10 @@ void launch_k1_build_aos(const double* d_xyz, const int64_t* d_cell_ptr, int64_t
 
 static inline unsigned nblk(long long n, int b) { return (unsigned)((n + b - 1) / b); }
 
+void launch_build_cl32(const FactorView& fv, int v0, int n, hipStream_t s) {
+  if (n <= 0 || !fv.cl32) return;
+  hipLaunchKernelGGL(build_cl32_kernel, dim3(nblk((long long)n * fv.W, 256)), dim3(256), 0, s, fv, v0, n);
+}
 void launch_build_clb(const FactorView& fv, int v0, int n, hipStream_t s) {
   if (n <= 0) return;
   const int nv = k3_nv(fv.W);

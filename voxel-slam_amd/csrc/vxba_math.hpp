@@ -48,6 +48,55 @@ VX_HD void transform_accumulate(const double P[6], const double v[3], double n, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The f32 cluster record of BASELINE configs[2] ("clusters also emitted as f32"), RE-CENTRED: [C sym6 | c | n] with c = v / n the
+// cluster's own mean and C = P - v v^T / n its second moments about that mean.  Raw moments cannot be rounded to f32 -- a body-frame
+// cluster 30 m from the sensor has P ~ n 900 m^2 and a plane thickness of n 4e-4 m^2 hidden in it, below f32's 6e-8 relative step --
+// whereas C is a few m^2 at most (round-off ~1e-7 m^2 against a smallest eigenvalue of ~1e-2) and c rounds like a point does (~2 um).
+//   world frame:  w = R c + p ;  P' = R C R^T + n w w^T ;  v' = n w          (tools.hpp:357-363 with P = C + n c c^T, v = n c)
+// An unobserved (voxel, frame) slot is the all-zero record and contributes exactly nothing: no test needed.
+// ---------------------------------------------------------------------------------------------
+VX_HD void cluster_to_centred_f32(const double cl[10], float rec[10]) {
+  const double n = cl[9];
+  if (n == 0.0) {
+#pragma unroll
+    for (int k = 0; k < 10; k++) rec[k] = 0.0f;
+    return;
+  }
+  const double inv = 1.0 / n;
+  const double c[3] = {cl[6] * inv, cl[7] * inv, cl[8] * inv};
+  constexpr int I[6] = {0, 0, 0, 1, 1, 2}, J[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+  for (int k = 0; k < 6; k++) rec[k] = (float)(cl[k] - cl[6 + I[k]] * c[J[k]]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) rec[6 + k] = (float)c[k];
+  rec[9] = (float)n;     // point counts are far below 2^24
+}
+VX_HD void transform_accumulate_centred(const float rec[10], const double R[9], const double p[3], double SP[6], double Sv[3], double& SN) {
+  const double n = (double)rec[9];
+  const double c[3] = {(double)rec[6], (double)rec[7], (double)rec[8]};
+  const double Cm[9] = {(double)rec[0], (double)rec[1], (double)rec[2], (double)rec[1], (double)rec[3], (double)rec[4], (double)rec[2], (double)rec[4], (double)rec[5]};
+  double RC[9], w[3], nw[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) RC[3 * i + j] = R[3 * i] * Cm[j] + R[3 * i + 1] * Cm[3 + j] + R[3 * i + 2] * Cm[6 + j];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    w[i] = (R[3 * i] * c[0] + R[3 * i + 1] * c[1] + R[3 * i + 2] * c[2]) + p[i];
+    nw[i] = n * w[i];
+  }
+  constexpr int I[6] = {0, 0, 0, 1, 1, 2}, J[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const int i = I[k], j = J[k];
+    SP[k] += (RC[3 * i] * R[3 * j] + RC[3 * i + 1] * R[3 * j + 1] + RC[3 * i + 2] * R[3 * j + 2]) + nw[i] * w[j];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) Sv[i] += nw[i];
+  SN += n;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations (fp64, relative accuracy), ascending
 // eigenvalues, unit eigenvectors in the columns of U (row-major U[3*row+col]).  Replaces Eigen's
 // SelfAdjointEigenSolver<Matrix3d> at voxel_map.hpp:267,1161,1242; eigenvalues agree to round-off, the

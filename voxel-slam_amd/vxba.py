@@ -433,8 +433,9 @@ class LidarFactor:
         return v.value
 
     def set_precision(self, mode: str):
-        """'f64' (default) or 'mixed' (f32 products on the matrix cores, f64 accumulation; BASELINE configs[2])."""
-        self._chk(self._L.vxba_set_precision(self._h, {"f64": 0, "mixed": 1}[mode]))
+        """'f64' (default), 'mixed' (f32 products on the matrix cores, f64 accumulation; BASELINE configs[2]) or 'mixed_f32_clusters'
+        (mixed, and the residual sweep reads f32 re-centred cluster records)."""
+        self._chk(self._L.vxba_set_precision(self._h, {"f64": 0, "mixed": 1, "mixed_f32_clusters": 2}[mode]))
 
     def set_profiling(self, mask: int):
         """Bit mask of kernels to time with events: 1 K3, 2 K2, 4 K3 finalize, 8 K1 (0 = off)."""
