@@ -89,6 +89,24 @@ def test_li_damping_iter_matches_oracle(vx, W, V, pts, iters, mode):
     assert np.allclose(m_g, m_o, rtol=1e-9, atol=1e-9) and np.allclose(ev_g, ev_o, rtol=1e-6, atol=1e-11)
 
 
+@pytest.mark.parametrize("queued", [1, 0])
+def test_li_shells_with_f32_cluster_rows(vx, queued):
+    """VXBA_PRECISION_MIXED_F32_CLUSTERS under the LiDAR-inertial shell (the queued residual sweep with the host-fed first workgroup is the
+    f32-row variant too): same accept / reject sequence as the fp64 oracle, states within the mixed-precision tolerance."""
+    sc, iw, blobs, facs, fo, fg = build(vx, 10, 3000, 40000, seed=610)
+    fg.set_option("li_queued_sweeps", queued)
+    fg.set_precision("mixed_f32_clusters")
+    fg.evaluate_only_residual(iw.states_init[:, :12])
+    ref = O.li_damping_iter(fo, iw.states_init, blobs, max_iter=6, thd_num=5, imu_coef=1e-4)
+    got = vx.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(iw.states_init, fg, facs, max_iter=6)
+    assert got["trace"].shape == ref["trace"].shape and np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:])
+    assert np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-4)
+    assert not np.array_equal(got["trace"][:, 1], ref["trace"][:, 1])                 # really the f32 rows
+    et, er = synth.pose_errors(got["states"][:, :12], ref["states"][:, :12])
+    assert et < 1e-5 and er < 1e-5, (et, er)
+    assert np.allclose(got["states"][:, 12:21], ref["states"][:, 12:21], atol=1e-4)
+
+
 def test_li_ba_improves_on_lidar_only_velocity_and_bias(vx):
     """The inertial terms make velocity / bias observable: after LI-BA they are closer to the truth than the initial guess."""
     sc, iw, blobs, facs, fo, fg = build(vx, 10, 3000, 40000, seed=777)
