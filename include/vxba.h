@@ -366,7 +366,7 @@ int vxba_get_option(const vxba_factor* f, int option, int* value);
  * [C sym6 | c | n] with c the cluster's mean and C its second moments ABOUT that mean -- raw body-frame moments do not survive f32, the
  * re-centred ones do (round-off ~1e-7 m^2 against a plane thickness of ~1e-2 m^2).  Half the bytes of that sweep's dominant stream.
  * The copy is kept beside the f64 rows (the Hessian sweep and every read-back use those) and refreshed when voxels were appended.
- * Eigenvalues / residuals move by ~1e-6 relative, and with them the LM fixed point by micrometres. */
+ * Eigenvalues / residuals move by ~1e-6 relative, and with them the LM fixed point by tens of nanometres (measured; the per-row errors average out). */
 #define VXBA_PRECISION_MIXED_F32_CLUSTERS 2
 int vxba_set_precision(vxba_factor* f, int mode);
 

@@ -20,7 +20,8 @@ def check(cond, msg):
 
 t0 = time.time()
 for case in range(n_cases):
-    kind = ["lm", "mixed", "wide", "li", "li_dev", "gravity", "lio", "vox", "vox_octo", "ds", "planes"][case % 11]
+    kinds = os.environ.get("FUZZ_KINDS", "lm,mixed,wide,li,li_dev,gravity,lio,vox,vox_octo,ds,planes").split(",")   # FUZZ_KINDS=mixed,li: only those
+    kind = kinds[case % len(kinds)]
     s = int(rng.integers(1, 1 << 30))
     if kind in ("lm", "mixed", "wide", "li", "li_dev", "gravity"):
         W = int(rng.integers(11, 40)) if kind == "wide" else int(rng.integers(2, 11))
@@ -33,13 +34,22 @@ for case in range(n_cases):
         iters = int(rng.integers(2, 8))
         if kind == "mixed":
             # f32 products on the matrix cores, f64 accumulation: same schedule, poses within 1e-5 of the fp64 oracle (contract 1e-4)
-            fg.set_precision("mixed")
+            # every other case also with the residual sweep on f32 re-centred cluster rows: the data moves by micrometres, tolerance 5e-5
+            f32rows = bool(rng.integers(0, 2))
+            fg.set_precision("mixed_f32_clusters" if f32rows else "mixed")
+            if f32rows: fg.evaluate_only_residual(sc.poses_init)
+            tol = 5e-5 if f32rows else 1e-5
             ref = fo.damping_iter(sc.poses_init, max_iter=iters, thd_num=3)
             got = vxba.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=iters)
             et, er = synth.pose_errors(got["poses"], ref["poses"])
-            check(got["trace"].shape == ref["trace"].shape and np.array_equal(got["trace"][:, 6], ref["trace"][:, 6]), "mixed trace W=%d V=%d seed=%d" % (W, V, s))
-            check(et < 1e-5 and er < 1e-5, "mixed poses %.2e %.2e W=%d V=%d seed=%d" % (et, er, W, V, s))
-            desc = "W=%d V=%d iters=%d acc=%s pose diff %.1e/%.1e" % (W, V, iters, got["trace"][:, 6].astype(int), et, er)
+            same = got["trace"].shape == ref["trace"].shape and np.array_equal(got["trace"][:, 6], ref["trace"][:, 6])
+            if f32rows and not same and got["trace"].shape == ref["trace"].shape:
+                # a decision may flip only where it was marginal: |residual1 - residual2| within the rows' rounding of the residual
+                k = int(np.argmax(got["trace"][:, 6] != ref["trace"][:, 6]))
+                same = abs(ref["trace"][k, 4]) < 1e-4 * abs(ref["trace"][k, 0])
+            check(same, "mixed%s trace W=%d V=%d seed=%d" % ("+f32rows" if f32rows else "", W, V, s))
+            check((et < tol and er < tol) or not np.array_equal(got["trace"][:, 6], ref["trace"][:, 6]), "mixed%s poses %.2e %.2e W=%d V=%d seed=%d" % ("+f32rows" if f32rows else "", et, er, W, V, s))
+            desc = "W=%d V=%d iters=%d %s acc=%s pose diff %.1e/%.1e" % (W, V, iters, "f32 rows" if f32rows else "f64 rows", got["trace"][:, 6].astype(int), et, er)
         elif kind in ("lm", "wide"):
             ref = fo.damping_iter(sc.poses_init, max_iter=iters, thd_num=3)
             got = vxba.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=iters)
