@@ -19,6 +19,9 @@ scw = None
 for rep in range(60):
     f = vxba.LidarFactor(10); f.push_points(sc.n_voxels, sc.points_body, sc.cell_ptr); f.evaluate_only_residual(sc.poses_init)
     vxba.Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=3)
+    if rep % 3 == 0:   # f32 re-centred cluster rows: their copy is allocated on the first residual sweep and freed with the handle
+        f.set_precision("mixed_f32_clusters"); f.evaluate_only_residual(sc.poses_init); vxba.Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=2)
+        if rep % 6 == 0: f.set_precision("f64")
     facs = []
     for gyr, acc, dts in iw.samples:
         fac = vxba.IMU_PRE(iw.states_init[0, 15:18], iw.states_init[0, 18:21])
