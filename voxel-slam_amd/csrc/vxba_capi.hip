@@ -708,6 +708,15 @@ int vxba_peer_attach(vxba_factor* f, int nranks, int rank, const void* handles) 
     f->peer.opened[p] = q;
     f->peer.boxes[p] = (double*)q;
   }
+  // The mailbox outlives detach: its per-slot flags still hold the call numbers of the previous attachment and its status word a
+  // timeout that may have ended it.  With the sequence restarting at 0 those stale flags would satisfy the first waits (stale slices
+  // summed silently, the self-test passing on the old pattern), so they are cleared here -- the caller's barrier between attach
+  // and the first collective (vxba.h) orders the clearing before any peer's first read.
+  if (hipMemsetAsync(f->peer.box + 2 * f->peer.len, 0, (2 * PEER_WGS + 1) * sizeof(double), f->stream) != hipSuccess || hipStreamSynchronize(f->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    for (int p = 0; p < nranks; p++) if (f->peer.opened[p]) { hipIpcCloseMemHandle(f->peer.opened[p]); f->peer.opened[p] = nullptr; }
+    return fail(f, VXBA_ERR_HIP, "peer_attach: cannot reset the mailbox flags");
+  }
   f->peer.nranks = nranks; f->peer.rank = rank; f->peer.seq = 0;
   return VXBA_OK;
 }
@@ -1503,6 +1512,7 @@ int vxba_internal_push_voxels_device(vxba_factor* f, int n, const double* d_clus
   f->wide_dirty = true;
   return VXBA_OK;
 }
+int vxba_internal_factor_device(const vxba_factor* f) { return f ? f->device : -1; }
 int vxba_internal_cache_view(vxba_factor* f, const double** eigval, const double** eigvec, const double** merged, int* VS, int* V) {
   VX_LOCK(f);
   if (!f || !eigval || !eigvec || !merged || !VS || !V) return VXBA_ERR_ARG;
@@ -1636,6 +1646,13 @@ static int peer_check(vxba_factor* f, int rc) {
 }
 int vxba_damping_iter(vxba_factor* f, double* Rp, int max_iter, double* hess_out, double* resis_out, double* trace_out, int* n_trace, int* is_converge) {
   int rc = damping_iter_impl(f, Rp, max_iter, hess_out, resis_out, trace_out, n_trace, is_converge);
+  if (rc == VXBA_ERR_STATE && f && f->solve_timed_out && has_collective(f)) {
+    // Sharded: a timeout is a per-GPU event, and this rank has already issued the call's all-reduces -- a rank-local retry would issue
+    // more of them which no other rank matches (RCCL hangs, the mailbox sequence numbers drift apart).  The error goes to the caller,
+    // who switches VXBA_OPT_FUSED_SOLVE off on ALL ranks and calls again.
+    f->solve_timed_out = false;
+    return fail(f, VXBA_ERR_STATE, "in-launch solve timed out on a sharded factor: set VXBA_OPT_FUSED_SOLVE = 0 on every rank and retry");
+  }
   if (rc == VXBA_ERR_STATE && f && f->solve_timed_out) {
     // The in-launch solve relies on workgroup 0 of the residual sweep making progress while the others poll (bounded): true for
     // in-order dispatch on an otherwise idle device, not guaranteed under CU masking / a serialising profiler / a co-resident

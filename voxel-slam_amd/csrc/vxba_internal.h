@@ -16,4 +16,6 @@ int vxba_internal_lio_scan_view(vxba_lio* h, const double** d_pts_soa, long long
 int vxba_internal_lio_map_update_device(vxba_lio* h, long long n, const long long* d_loc, const int* d_layer, const int* d_path, const int* d_is_plane, const double* d_center,
                                         const double* d_normal, const double* d_plane_var, const double* d_radius);
 int vxba_internal_lio_geometry(const vxba_lio* h, double* voxel_size, int* max_layer, int* device);
+// Device ordinal a factor lives on (-1 for a null handle): handles that exchange raw device pointers must share it.
+int vxba_internal_factor_device(const vxba_factor* f);
 }

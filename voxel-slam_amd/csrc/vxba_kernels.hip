@@ -34,6 +34,8 @@ __device__ __forceinline__ void dbg_stamp(bool on, int wave_id, int slot) {
   if (on && wave_id < DBG_WAVES && (threadIdx.x & 63) == 0) g_dbg[wave_id * DBG_SLOTS + slot] = __builtin_readcyclecounter();
 }
 
+#include "vxba_solve4.hpp"
+
 
 // ------------------------------------------------------------------------------------------------
 // Accept / reject + damping schedule of one LM step (voxel_map.hpp:411-439) as a pure function of the control
@@ -148,39 +150,44 @@ __device__ __forceinline__ void lm_persist(LMState* st, int c_in, const LMDecisi
 // 27-29 us against 17.5 us for this version: the extra pose loads / redundant fp64 work / barrier skew cost more
 // than the hidden dependency stalls buy, because all workgroups start together and sit in the same phase.
 // ------------------------------------------------------------------------------------------------
-template <int W, bool DBG>
-__device__ __forceinline__ void lm_solve_body(LMState* st, int c, double* colbuf, double* xs);
-
 // LM mode with seq != 0: workgroup 0 of the grid is not a voxel workgroup but the damped SOLVE of this iteration
-// (lm_solve_body, one wave).  The voxel workgroups request their cluster rows first -- those do not depend on the poses --
-// and only then wait for workgroup 0 to publish the trial poses (release store of `seq` to st->solve_seq, acquire spin
-// here), so the 6-7 us load phase of the sweep and one kernel launch disappear behind the 16 us solve.  Deadlock-free:
-// workgroups are dispatched in index order, so workgroup 0 is resident before any workgroup that could wait for it.
+// (lm_solve_body4, vxba_solve4.hpp: four waves).  The voxel workgroups request their cluster rows first -- those do not depend on
+// the poses -- and only then wait for workgroup 0 to publish the trial poses (relaxed store of `seq` to st->solve_seq, relaxed
+// polls here), so the load phase of the sweep and one kernel launch disappear behind the solve.  Deadlock-free as long as
+// workgroup 0 is resident before any workgroup that waits for it (dispatch in index order; the wait is bounded, see below).
+// Workgroups are 4 waves (the solve wants four SIMDs); a voxel wave is as independent as it was when it was a workgroup of its
+// own: wave v of the launch takes voxels [head + 64 v, ...), no barrier, its own corner of LDS for the poses.
 constexpr unsigned K2_SPIN_LIMIT = 1u << 22;
+constexpr int K2_WAVES = S4_WAVES;
+constexpr int K2_THREADS = 64 * K2_WAVES;
 #ifndef K2_HEAD_START
 #define K2_HEAD_START 100   // x 64 cycles
 #endif
 #ifndef VXBA_PUBLISH_FENCE
 #define VXBA_PUBLISH_FENCE 0
 #endif
+template <int W>
+constexpr int k2_lds_doubles() { return S4<W>::DOUBLES > K2_WAVES * 12 * W ? S4<W>::DOUBLES : K2_WAVES * 12 * W; }
 // F32: the cluster rows come from the f32 re-centred copy (fv.cl32, vxm::cluster_to_centred_f32; VXBA_OPT_F32_CLUSTERS, meant for the
 // mixed-precision configuration): half the bytes of the sweep's dominant stream and half the registers of the load phase.
 template <int W, bool DBG = false, bool F32 = false>
-__global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c, unsigned seq, int head, int end,
-                                                         int VPB_arg, double* __restrict__ partial, const double* host_feed) {
+__global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c, unsigned seq, int head, int end,
+                                                                 int VPB_arg, double* __restrict__ partial, const double* host_feed, int head_start) {
   const int VPB = VPB_arg & 0xffff;
-  __shared__ double pose_lds[12 * W];
-  __shared__ double solve_lds[SOLVE_LDS + 64];
+  __shared__ __attribute__((aligned(16))) double k2_lds[k2_lds_doubles<W>()];
   // LM mode: trial poses of ctl[c]; nothing to do once the loop is done
   if (st && st->ctl[c].done) return;
-  const int lane = threadIdx.x;
-  int vb = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  double* pose_lds = k2_lds + wave * 12 * W;
+  int vb = blockIdx.x * K2_WAVES + wave;
   if (st && seq != 0) {
     if (blockIdx.x == 0) {
       if (host_feed) {
         // LiDAR-inertial shells: the trial poses come from the HOST (15W-dimensional solve there).  This launch was queued before
-        // they existed -- the voxel workgroups already hold their cluster rows -- and workgroup 0 waits for the host to raise the
-        // sequence number in mapped host memory, copies the poses into the control block and publishes them like a solve would.
+        // they existed -- the voxel workgroups already hold their cluster rows -- and wave 0 of workgroup 0 waits for the host to raise
+        // the sequence number in mapped host memory, copies the poses into the control block and publishes them like a solve would.
+        if (wave != 0) return;
         const volatile double* hf = host_feed;
         unsigned spins = 0;
         bool fed = true;
@@ -191,7 +198,8 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
         if (!fed) { if (lane == 0) st->error = 2; return; }
         for (int k = lane; k < 12 * W; k += 64) __hip_atomic_store(&st->ctl[c].xt[k], hf[1 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        lm_solve_body<W, DBG>(st, c, solve_lds, solve_lds + SOLVE_LDS);
+        lm_solve_body4<W, DBG>(st, c, k2_lds);
+        if (wave != 0) return;
       }
 #if VXBA_PUBLISH_FENCE
       __threadfence();
@@ -205,9 +213,12 @@ __global__ __launch_bounds__(64) void k2_residual_kernel(FactorView fv, PoseArg 
 #endif
       return;
     }
-    vb = blockIdx.x - 1;
+    vb -= K2_WAVES;
+  }
+  if (vb * VPB >= end - head) return;   // the last workgroup's spare waves
+  if (st && seq != 0) {
     // let the solver's first (dependent) loads through before 780 waves put 50 MB of requests in front of them
-    __builtin_amdgcn_s_sleep(K2_HEAD_START);
+    for (int k = 0; k < head_start; k += 10) __builtin_amdgcn_s_sleep(10);
   }
   const int a = head + vb * VPB + lane;
   const bool valid = lane < VPB && a < end;
@@ -852,81 +863,12 @@ __global__ __launch_bounds__(256) void lm_init_kernel(LMState* stp, PoseArg x0, 
     stp->error = 0;   // a timed-out in-launch solve of an earlier call must not fail this one (the host retries without fusion)
   }
 }
-// Damped solve (H + u D) dxi = -JacT on ONE wave: lane i owns row i of the system in registers, the pivot column is
-// broadcast through LDS, every step is a branch-free rank-1 update -- no barriers, ~n^2/2 FMAs per lane.
-// Elimination runs in natural order without pivoting: after the gauge fix the damped system is (1+u)-diagonally
-// boosted and positive definite wherever LM accepts steps (the reference's Eigen::LDLT pivots on the largest
-// diagonal, voxel_map.hpp:403; both give the same step to round-off on such systems).  Rows/columns 0..5 are the
-// gauge (identity rows, zero right-hand side) and are skipped.
-template <int W, bool DBG>
-__device__ __forceinline__ void lm_solve_body(LMState* st, int c, double* colbuf, double* xs) {
-  dbg_stamp(DBG, 4000, 0);
-  LMCtl& ctl = st->ctl[c];
-  if (ctl.done) return;
-  dbg_stamp(DBG, 4000, 1);
-  constexpr int n = 6 * W;
-  const int lane = threadIdx.x;
-  const double u = ctl.u;
-  const bool row_ok = lane < n;
-  const int i = row_ok ? lane : 0;
-
-  // row i of the gauge-fixed system: k3_finalize_kernel left *hess, the gauge-fixed Hessian / gradient and residual1
-  // in the LM state when the Hessian sweep ran; after a rejected step the kept copy is simply reused (with a new u)
-  double A[n > 6 ? n : 7];
-#pragma unroll
-  for (int j = 0; j < n; j++) A[j] = st->Hwork[(size_t)j * n + i];
-  const double rhs = st->Jwork[i];
-  // current pose of frame `lane` (lanes < W), fetched now so its latency hides behind the elimination
-  double xcur[12];
-  {
-    const int fl = lane < W ? lane : 0;
-#pragma unroll
-    for (int k = 0; k < 12; k++) xcur[k] = ctl.x[12 * fl + k];
-  }
-  // my diagonal and gradient entry, kept for q1
-  double hii = 0.0;
-#pragma unroll
-  for (int j = 0; j < n; j++) hii = (j == i) ? A[j] : hii;
-  const double gi = rhs;
-  // A = Hess + u D, b = -JacT   (voxel_map.hpp:402-403)
-#pragma unroll
-  for (int j = 0; j < n; j++) A[j] = (j == i) ? A[j] + u * A[j] : A[j];
-  double b = -rhs;
-
-  // forward elimination (rows k = 6 .. n-1) and back substitution, fully unrolled at compile time so that the
-  // row stays in registers (static indices only)
-  if (DBG) { asm volatile("" :: "v"(A[0]), "v"(A[n - 1]), "v"(b)); dbg_stamp(true, 4000, 2); }
-  const double x = dense_solve_rows<n>(A, b, colbuf, lane);
-  if (DBG) { asm volatile("" :: "v"(x)); dbg_stamp(true, 4000, 4); }
-  // dxi, trial state (voxel_map.hpp:405-409), q1 = 0.5 dxi . (u D dxi - JacT) (:410)
-  if (row_ok) st->dxi[i] = x;
-  xs[lane] = row_ok ? x : 0.0;
-  __builtin_amdgcn_wave_barrier();
-  if (lane < W) {
-    double dl[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) dl[k] = xs[6 * lane + k];
-    double xn[9];
-    lm_right_multiply_exp(xcur, dl, xn);
-    // agent-scope stores (written through): when the solve runs inside the residual-sweep launch, the waiting workgroups read these
-    // right after the sequence number -- no device-wide fence on the publishing side
-#pragma unroll
-    for (int k = 0; k < 9; k++) __hip_atomic_store(&ctl.xt[12 * lane + k], xn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int k = 0; k < 3; k++) __hip_atomic_store(&ctl.xt[12 * lane + 9 + k], xcur[9 + k] + dl[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  double part = row_ok ? x * (u * hii * x - gi) : 0.0;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
-  if (lane == 0) ctl.q1 = 0.5 * part;
-  if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, 4000, 5); }
-}
-// stand-alone launch of the solve (VXBA_FUSED_SOLVE=0; the default runs it as workgroup 0 of the residual sweep)
+// stand-alone launch of the damped solve (VXBA_FUSED_SOLVE=0 and the retry after a timed-out in-launch solve; the default runs it
+// as workgroup 0 of the residual sweep): lm_solve_body4, vxba_solve4.hpp
 template <int W, bool DBG = false>
-__global__ __launch_bounds__(64) void lm_solve_kernel(LMState* st, int c) {
-  __shared__ double colbuf[SOLVE_LDS];   // pivot-column buffers (look-ahead)
-  __shared__ double xs[64];
-  lm_solve_body<W, DBG>(st, c, colbuf, xs);
+__global__ __launch_bounds__(S4_THREADS) void lm_solve_kernel(LMState* st, int c) {
+  __shared__ __attribute__((aligned(16))) double lds[S4<W>::DOUBLES];
+  lm_solve_body4<W, DBG>(st, c, lds);
 }
 
 // Stand-alone decision kernel that closes the loop after the last residual sweep (inside the loop the decision is
@@ -988,22 +930,24 @@ int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, 
   const int vpb0 = voxels_per_block & 0xffff;
   const int vpb = (vpb0 >= 32 && vpb0 <= 64) ? vpb0 : 64;
   const int vpb_arg = vpb | (voxels_per_block & 0x10000);   // bit 16: the voxel workgroups do not wait for the in-launch solve (test hook)
-  const int nblocks = (end - head + vpb - 1) / vpb;
+  const int nblocks = (end - head + vpb - 1) / vpb;          // voxel WAVES = partials
   if (nblocks <= 0) return 0;
   const unsigned seq = st ? fused_seq : 0u;
-  const int grid = nblocks + (seq != 0 ? 1 : 0);   // + the solve workgroup
-  static int dbg = -1;
+  const int grid = (nblocks + K2_WAVES - 1) / K2_WAVES + (seq != 0 ? 1 : 0);   // + the solve workgroup
+  static int dbg = -1, head_start = -1;
   if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
+  if (head_start < 0) { const char* ev = getenv("VXBA_K2_HEAD_START"); head_start = ev ? atoi(ev) : K2_HEAD_START; if (head_start < 0) head_start = 0; }   // development knob, x 64 cycles
+  const dim3 g(grid), b(K2_THREADS);
   if (fv.cl32) {   // f32 re-centred cluster rows (the caller built them: vxba_capi.hip, residual_view)
     if (ev_start) {
-      VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false, true>), dim3(grid), dim3(64), 0, s, ev_start, ev_stop, 0, fv, poses, st, c, seq, head,
-                                                  end, vpb_arg, d_partial, host_feed));
-    } else { VXK_DISPATCH_W(fv.W, (k2_residual_kernel<WW, false, true><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed))); }
-  } else if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed)); }
+      VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false, true>), g, b, 0, s, ev_start, ev_stop, 0, fv, poses, st, c, seq, head, end, vpb_arg,
+                                                  d_partial, host_feed, head_start));
+    } else { VXK_DISPATCH_W(fv.W, (k2_residual_kernel<WW, false, true><<<g, b, 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed, head_start))); }
+  } else if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<g, b, 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed, head_start)); }
   else if (ev_start) {
-    VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), dim3(grid), dim3(64), 0, s, ev_start, ev_stop, 0, fv, poses, st, c, seq, head,
-                                                end, vpb_arg, d_partial, host_feed));
-  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<dim3(grid), dim3(64), 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed)); }
+    VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), g, b, 0, s, ev_start, ev_stop, 0, fv, poses, st, c, seq, head, end, vpb_arg, d_partial,
+                                                host_feed, head_start));
+  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<g, b, 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed, head_start)); }
   return nblocks;
 }
 
@@ -1169,8 +1113,8 @@ void launch_lm_init(LMState* st, const PoseArg& x0, int W, int bench_mode, hipSt
 void launch_lm_solve(LMState* st, int c, int W, hipStream_t s) {
   static int dbg = -1;
   if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
-  if (dbg) { VXK_DISPATCH_W(W, lm_solve_kernel<WW, true><<<dim3(1), dim3(64), 0, s>>>(st, c)); }
-  else { VXK_DISPATCH_W(W, lm_solve_kernel<WW><<<dim3(1), dim3(64), 0, s>>>(st, c)); }
+  if (dbg) { VXK_DISPATCH_W(W, lm_solve_kernel<WW, true><<<dim3(1), dim3(S4_THREADS), 0, s>>>(st, c)); }
+  else { VXK_DISPATCH_W(W, lm_solve_kernel<WW><<<dim3(1), dim3(S4_THREADS), 0, s>>>(st, c)); }
 }
 void launch_lm_update(LMState* st, int c_in, const LMPending& pend, const PoseArg& restart_x0, int W, hipStream_t s) {
   lm_update_kernel<<<dim3(1), dim3(256), 0, s>>>(st, c_in, pend, restart_x0, W);

@@ -1100,6 +1100,7 @@ int vxba_map_cut_voxel_device(vxba_map* m, int ord, int64_t n, const double* d_p
 int vxba_map_recut(vxba_map* m, int win_count, const double* Rp, vxba_factor* factor, int64_t* n_pushed) {
   if (!m || !Rp || !factor || win_count < 1 || win_count > m->prm.win_size) return mfail(m, VXBA_ERR_ARG, "vxba_map_recut: bad argument");
   if (vxba_win_size(factor) != m->prm.win_size) return mfail(m, VXBA_ERR_ARG, "vxba_map_recut: the factor's win_size differs from the map's");
+  if (vxba_internal_factor_device(factor) != m->device) return mfail(m, VXBA_ERR_ARG, "vxba_map_recut: the factor lives on another device than the map (raw device pointers are exchanged)");
   hipSetDevice(m->device);
   if (n_pushed) *n_pushed = 0;
   if (m->n_slide < m->prm.thread_num) return VXBA_OK;                      // `if(g_size < thd_num) return;`
@@ -1157,6 +1158,7 @@ int vxba_map_recut(vxba_map* m, int win_count, const double* Rp, vxba_factor* fa
 // eig_vectors as the optimiser left them) is read on the device
 int vxba_map_margi(vxba_map* m, int win_count, const double* Rp, vxba_factor* factor) {
   if (!m || !Rp || !factor || win_count < 1 || win_count > m->prm.win_size) return mfail(m, VXBA_ERR_ARG, "vxba_map_margi: bad argument");
+  if (vxba_internal_factor_device(factor) != m->device) return mfail(m, VXBA_ERR_ARG, "vxba_map_margi: the factor lives on another device than the map (its cache planes are read in place)");
   hipSetDevice(m->device);
   if (m->n_slide < m->prm.thread_num) return VXBA_OK;
   const double *f_ev = nullptr, *f_evec = nullptr, *f_mg = nullptr;
@@ -1243,6 +1245,11 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
 // cut_voxel_multi on the scan resident in an odometry handle after vxba_lio_pvec_update: nothing crosses PCIe.
 int vxba_map_cut_voxel_lio(vxba_map* m, int ord, vxba_lio* lio) {
   if (!m || !lio) return mfail(m, VXBA_ERR_ARG, "vxba_map_cut_voxel_lio: null argument");
+  {
+    double vs_ = 0; int ml_ = 0, dev_ = -1;
+    vxba_internal_lio_geometry(lio, &vs_, &ml_, &dev_);
+    if (dev_ != m->device) return mfail(m, VXBA_ERR_ARG, "vxba_map_cut_voxel_lio: the odometry handle lives on another device than the map (its scan arrays are read in place)");
+  }
   const double *soa = nullptr, *world = nullptr;
   long long n = 0, stride = 0;
   int valid = 0;

@@ -114,15 +114,45 @@ def attach_peer(factor, group=None):
     VxbaError where IPC / peer access is not available -- fall back to attach_rccl then."""
     import torch.distributed as dist
 
+    import torch
+
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    mine = factor.peer_export()
+
+    def all_ok(flag: bool) -> bool:
+        # every rank learns whether ANY rank failed, so that all of them raise (or fall back) together instead of one raising while
+        # the others block in the next collective
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(int(t.item()))
+
+    err = None
+    try:
+        mine = factor.peer_export()
+    except Exception as e:          # no fine-grained memory / IPC disabled
+        err, mine = e, None
     handles = [None] * world
     dist.all_gather_object(handles, mine, group=group)
-    factor.peer_attach(world, rank, handles)
-    dist.barrier(group=group)        # nobody starts a collective before every rank has mapped every mailbox
-    if not factor.peer_selftest():   # one all-reduce of a known pattern: a link that does not sum exactly is not used
+    if err is None and any(h is None for h in handles):
+        err = RuntimeError("a peer could not export its mailbox")
+    if err is None:
+        try:
+            factor.peer_attach(world, rank, handles)
+        except Exception as e:
+            err = e
+    if not all_ok(err is None):       # also the barrier: nobody starts a collective before every rank has mapped every mailbox
+        if err is None:
+            factor.peer_detach()
+        raise RuntimeError("peer all-reduce: attach failed on some rank (rank %d: %s)" % (rank, err or "ok here"))
+    ok = False
+    try:
+        ok = factor.peer_selftest()   # one all-reduce of a known pattern: a link that does not sum exactly is not used
+    except Exception as e:
+        err = e
+    if not all_ok(ok):
         factor.peer_detach()
-        raise RuntimeError("peer all-reduce self-test failed on rank %d" % rank)
+        raise RuntimeError("peer all-reduce self-test failed on some rank (rank %d: %s)" % (rank, err or ("ok here" if ok else "wrong sum / peer absent")))
 
 
 def damping_iter_sharded(win_size: int, x_stats, local_hess, local_resid, max_iter: int = 3, group=None):
