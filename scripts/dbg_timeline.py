@@ -24,15 +24,25 @@ if which == "solve":
 if which == "fused":
     from voxel_slam_amd.vxba import Lidar_BA_Optimizer
     Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=1)
-    full = vxba.debug_stamps(4001).astype(np.int64)
+    full = vxba.debug_stamps(4096).astype(np.int64)
     sol = full[4000, :6]
     n = (sc.n_voxels + 63) // 64
     k2 = full[:n, :6]
+    k2 = k2[k2[:, 0] > 0]
     t0 = min(sol[0], k2[:, 0].min())
-    print("solver stamps (cycles since kernel start): start %d, done-checked %d, loaded %d, eliminated %d, back-substituted %d, end %d" % tuple(sol - t0))
+    print("solver stamps (cycles since kernel start): start %d, done-checked %d, loaded %d, factored %d, back-substituted %d, end %d" % tuple(sol - t0))
     names = ["start", "loads landed", "cov done", "eig done", "end", "flag seen"]
-    for k in (0, 1, 5, 2, 3, 4):
+    for k in (0, 5, 1, 2, 3, 4):
         print("voxel waves %-13s min %7d  median %7d  max %7d" % (names[k], k2[:, k].min() - t0, np.median(k2[:, k]) - t0, k2[:, k].max() - t0))
+    # four-wave solve (vxba_solve4.hpp): per wave, arrival at / release from the barrier of every block step; per step, the owner's chain
+    wv = full[4000:4004, 6:24]
+    if (wv > 0).any():
+        for w in range(4):
+            print("wave %d  barrier arrive/leave: " % w + "  ".join("%d/%d" % (wv[w, 2 * s_] - t0, wv[w, 2 * s_ + 1] - t0) for s_ in range(9) if wv[w, 2 * s_] > 0))
+        for s_ in range(9):
+            ch = full[4010 + s_, :5]
+            if ch[0] > 0:
+                print("step %d owner chain: start %d  applied +%d  diagonal read +%d  factored +%d  panel stored +%d" % ((s_, ch[0] - t0) + tuple(np.diff(ch))))
     sys.exit(0)
 if which == "k2":
     f.evaluate_only_residual(sc.poses_init); n = (sc.n_voxels + 63) // 64; ns = 5

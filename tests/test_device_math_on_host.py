@@ -15,13 +15,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 
 
-@pytest.fixture(scope="module")
-def hm():
+@pytest.fixture(scope="module", params=["exact", "hw_estimates"])
+def hm(request):
+    """Two builds of the lane arithmetic for the host: plain divisions / square roots, and (-DVXM_EMULATE_HW_ESTIMATES) the GPU's
+    reciprocal / reciprocal-square-root ESTIMATES emulated at their 22-bit accuracy, so that every Newton refinement on the device
+    path (eigen-solver rotations, the warm start's cheap tangents) is run and checked on the CPU."""
+    emu = request.param == "hw_estimates"
     src = os.path.join(HERE, "hostmath", "vxm_hostcheck.cpp")
-    so = os.path.join(HERE, "hostmath", "libvxm_hostcheck.so")
+    so = os.path.join(HERE, "hostmath", "libvxm_hostcheck_emu.so" if emu else "libvxm_hostcheck.so")
     hdr = os.path.join(HERE, "..", "voxel-slam_amd", "csrc", "vxba_math.hpp")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"] + (["-DVXM_EMULATE_HW_ESTIMATES"] if emu else []) + ["-o", so, src])
     L = C.CDLL(so)
     L.vxmh_eig_sym3.argtypes = [f64p, f64p, f64p]
     L.vxmh_eig_sym3_warm.argtypes = [f64p, f64p, f64p, f64p]
@@ -81,6 +85,30 @@ def test_warm_started_eigensolver(hm):
         assert np.allclose(lam, np.linalg.eigvalsh(M), rtol=0, atol=2e-15 * nrm)
         assert np.allclose(U.T @ U, np.eye(3), atol=1e-13)
         assert np.allclose(M @ U, U * lam, atol=4e-15 * nrm + 1e-13 * nrm * (trial % 3 == 0))
+
+
+def test_warm_start_fixed_sweeps_and_fallback(hm):
+    """The warm start runs three fixed branch-free sweeps and only then looks at convergence: small basis errors (the LM case) must be
+    done by then, large ones and (nearly) degenerate in-plane eigenvalues must be finished by the generic loop -- same accuracy either way."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(60)
+    for angle in (1e-7, 1e-4, 3e-3, 5e-2, 0.6, 2.0):
+        for gap in (0.3, 1e-6, 1e-12, 0.0):
+            for _ in range(20):
+                Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+                lam_true = np.sort(np.array([4e-4 * rng.uniform(0.2, 3), 0.07, 0.07 * (1 + gap)]))
+                M = Q @ np.diag(lam_true) @ Q.T; M = 0.5 * (M + M.T)
+                c6 = np.array([M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2]])
+                Up = Q @ Rotation.from_rotvec(rng.normal(size=3) * angle).as_matrix()
+                lam = np.zeros(3); U = np.zeros(9)
+                hm.vxmh_eig_sym3_warm(c6, np.ascontiguousarray(Up).reshape(9), lam, U)
+                U = U.reshape(3, 3)
+                nrm = np.abs(M).max()
+                assert np.allclose(lam, np.linalg.eigvalsh(M), rtol=0, atol=2e-15 * nrm), (angle, gap)
+                assert np.allclose(U.T @ U, np.eye(3), atol=1e-13), (angle, gap)
+                assert np.allclose(M @ U, U * lam, atol=1e-13 * nrm), (angle, gap)
+                # the plane normal (eigenvector of the isolated smallest eigenvalue) is determined: compare it up to sign
+                assert abs(abs(U[:, 0] @ Q[:, 0]) - 1.0) < 1e-12, (angle, gap)
 
 
 @pytest.mark.parametrize("p_obs,fix_frac", [(1.0, 0.0), (0.6, 0.4)])

@@ -402,7 +402,7 @@ __device__ __forceinline__ void k3_sum_linear(const double* park_d, double* out,
     for (int w = 0; w < C::WAVES; w++)
 #pragma unroll
       for (int v = 0; v < C::NV; v++) sum += park_d[(w * 64 + v * W + i) * E::DS + k];
-    out[i * DACC + E::slot(k)] = sum;
+    st_out(&out[i * DACC + E::slot(k)], sum);
   }
 }
 
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
     double sum = 0.0;
 #pragma unroll
     for (int k = 0; k < C::KSPLIT; k++) sum += park_t[((k * C::TSPLIT + ts) * C::TPW + j) * 256 + x];
-    pout[el] = sum;
+    st_out(&pout[el], sum);
   }
   dbg_stamp(DBG, gw, 6);
 }

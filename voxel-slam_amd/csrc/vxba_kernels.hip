@@ -36,6 +36,19 @@ __device__ __forceinline__ void dbg_stamp(bool on, int wave_id, int slot) {
 
 #include "vxba_solve4.hpp"
 
+// (-DVXBA_WT_STORES=0 restores plain stores; same-box A/B at cfg2: 60.0 -> 59.0 us per LM step.)  The bulk outputs of the sweeps (K2's cache planes, K3's workgroup partials) as agent-scope
+// write-through stores, so that the kernel boundary behind them has no dirty L2 lines to write back.
+#ifndef VXBA_WT_STORES
+#define VXBA_WT_STORES 1
+#endif
+__device__ __forceinline__ void st_out(double* p, double v) {
+#if VXBA_WT_STORES
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = v;
+#endif
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Accept / reject + damping schedule of one LM step (voxel_map.hpp:411-439) as a pure function of the control
@@ -306,23 +319,23 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(FactorView fv, 
     vxm::eig_sym3_warm(C, Up, lam, U);
     if (DBG) { asm volatile("" :: "v"(lam[0]), "v"(U[0]), "v"(U[8])); dbg_stamp(true, vb, 3); }
 #pragma unroll
-    for (int k = 0; k < 3; k++) fv.eigval[k * VS + a] = lam[k];
+    for (int k = 0; k < 3; k++) st_out(&fv.eigval[k * VS + a], lam[k]);
 #pragma unroll
     for (int col = 0; col < 3; col++)
 #pragma unroll
-      for (int row = 0; row < 3; row++) fv.eigvec[(3 * col + row) * VS + a] = U[3 * row + col];
+      for (int row = 0; row < 3; row++) st_out(&fv.eigvec[(3 * col + row) * VS + a], U[3 * row + col]);
 #pragma unroll
-    for (int k = 0; k < 6; k++) fv.merged[k * VS + a] = SP[k];
+    for (int k = 0; k < 6; k++) st_out(&fv.merged[k * VS + a], SP[k]);
 #pragma unroll
-    for (int k = 0; k < 3; k++) fv.merged[(6 + k) * VS + a] = Sv[k];
-    fv.merged[9 * VS + a] = SN;
+    for (int k = 0; k < 3; k++) st_out(&fv.merged[(6 + k) * VS + a], Sv[k]);
+    st_out(&fv.merged[9 * VS + a], SN);
     double s1, s2;
     vxm::gap_scales(lam, s1, s2);
     const double coe = fv.coe[a];
-    fv.aux[a] = s1;
-    fv.aux[VS + a] = s2;
-    fv.aux[2 * VS + a] = 1.0 / SN;
-    fv.aux[3 * VS + a] = sqrt(coe);
+    st_out(&fv.aux[a], s1);
+    st_out(&fv.aux[VS + a], s2);
+    st_out(&fv.aux[2 * VS + a], 1.0 / SN);
+    st_out(&fv.aux[3 * VS + a], sqrt(coe));
     res = coe * lam[0];
   }
   // fixed-tree wave reduction

@@ -104,9 +104,31 @@ VX_HD void transform_accumulate_centred(const float rec[10], const double R[9], 
 // ---------------------------------------------------------------------------------------------
 // 1/x and 1/sqrt(x) to fp64 round-off without the IEEE division / sqrt expansions (3x shorter dependent chains on
 // the GPU: hardware estimate + Newton steps); plain divisions on the host.
+// Host builds with -DVXM_EMULATE_HW_ESTIMATES (tests/test_device_math_on_host.py) replace v_rcp_f64 / v_rsq_f64 by the exact value
+// truncated to 22 mantissa bits -- the instructions' documented accuracy -- so that the Newton refinements below are exercised on the
+// CPU as they run on the GPU.
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(VXM_EMULATE_HW_ESTIMATES)
+#include <cstring>
+#define VXM_EST 1
+inline double vxm_truncate22(double v) {
+  unsigned long long b;
+  std::memcpy(&b, &v, 8);
+  b &= ~((1ull << 30) - 1ull);
+  std::memcpy(&v, &b, 8);
+  return v;
+}
+inline double vxm_est_rcp(double x) { return vxm_truncate22(1.0 / x); }
+inline double vxm_est_rsq(double x) { return vxm_truncate22(1.0 / sqrt(x)); }
+#elif defined(__HIP_DEVICE_COMPILE__)
+#define VXM_EST 1
+__device__ __forceinline__ double vxm_est_rcp(double x) { return __builtin_amdgcn_rcp(x); }
+__device__ __forceinline__ double vxm_est_rsq(double x) { return __builtin_amdgcn_rsq(x); }
+#else
+#define VXM_EST 0
+#endif
 VX_HD double fast_rcp(double x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  double r = __builtin_amdgcn_rcp(x);
+#if VXM_EST
+  double r = vxm_est_rcp(x);
   r = fma(fma(-x, r, 1.0), r, r);
   r = fma(fma(-x, r, 1.0), r, r);
   return r;
@@ -115,8 +137,8 @@ VX_HD double fast_rcp(double x) {
 #endif
 }
 VX_HD double fast_rsqrt(double x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  double r = __builtin_amdgcn_rsq(x);
+#if VXM_EST
+  double r = vxm_est_rsq(x);
   // two Newton steps: r <- r (1.5 - 0.5 x r^2)
   r = r * fma(-0.5 * x * r, r, 1.5);
   r = r * fma(-0.5 * x * r, r, 1.5);
@@ -174,6 +196,42 @@ VX_HD void jacobi_sweeps(double& a00, double& a01, double& a02, double& a11, dou
   }
 }
 
+// Branch-free Jacobi rotation for the warm-started solver below: the same rotation as jacobi_rotate (t = sgn(theta) / (|theta| +
+// sqrt(1 + theta^2)), c, s, tau), no data-dependent control flow (a wave runs every side of a divergent branch).  apq == 0 gives the
+// identity; |theta| is clamped so that theta^2 cannot overflow (beyond the clamp t apq is below 1e-150 |apq|).  The tangent needs
+// full precision too: the diagonal update app -= t apq is exact only for the exact root (a tangent from one-Newton-step reciprocals
+// was tried -- it perturbs the eigenvalues by 1e-13 |apq|, visible whenever the first rotations are large).
+VX_HD void jacobi_rotate_bf(double& app, double& aqq, double& apq, double& arp, double& arq, double* U, int p, int q) {
+  const bool nz = apq != 0.0;
+  const double h = aqq - app;
+  const double theta = 0.5 * h * fast_rcp(nz ? apq : 1.0);
+  const double at = fmin(fabs(theta), 1e150);
+  const double th2 = fma(at, at, 1.0);
+  double t = fast_rcp(at + th2 * fast_rsqrt(th2));
+  t = nz ? (theta < 0.0 ? -t : t) : 0.0;
+  const double c = fast_rsqrt(fma(t, t, 1.0));
+  const double s = t * c;
+  const double tau = s * fast_rcp(1.0 + c);
+  const double hh = t * apq;
+  app -= hh;
+  aqq += hh;
+  apq = 0.0;
+  const double g1 = arp, h1 = arq;
+  arp = g1 - s * (h1 + g1 * tau);
+  arq = h1 + s * (g1 - h1 * tau);
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const double up = U[3 * r + p], uq = U[3 * r + q];
+    U[3 * r + p] = up - s * (uq + up * tau);
+    U[3 * r + q] = uq + s * (up - uq * tau);
+  }
+}
+// off-diagonal apq negligible against both of its diagonal entries (jacobi_rotate's flush rule)
+VX_HD bool jacobi_negligible(double app, double aqq, double apq) {
+  const double g = 100.0 * fabs(apq);
+  return apq == 0.0 || ((fabs(app) + g == fabs(app)) && (fabs(aqq) + g == fabs(aqq)));
+}
+
 VX_HD void sort_eigen(double a00, double a11, double a22, double* U, double lam[3]) {
   // ascending sort (3-element network) with column swaps
   double l0 = a00, l1 = a11, l2 = a22;
@@ -222,7 +280,19 @@ VX_HD void eig_sym3_warm(const double Cin[6], const double Up[9], double lam[3],
   double a12 = Up[1] * M[2] + Up[4] * M[5] + Up[7] * M[8];
   double a22 = Up[2] * M[2] + Up[5] * M[5] + Up[8] * M[8];
   double V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  jacobi_sweeps(a00, a01, a02, a11, a12, a22, V, 1);
+  // Three fixed, branch-free sweeps: C' starts almost diagonal (off-diagonals ~ the pose update), cyclic Jacobi then converges
+  // quadratically or better -- 1e-3 -> 1e-6 -> 1e-12 -> 1e-24 relative -- so three sweeps leave nothing above round-off, at a cost that
+  // does not depend on the slowest lane of the wave (the generic loop below ran until EVERY lane's off-diagonals were exactly zero,
+  // every lane executing every branch: 8.7k cycles per wave in the residual sweep, on the critical path behind the solve).  Whoever is
+  // not converged after that (degenerate eigenvalues swapping, a cache from far away) continues in the generic loop.
+#pragma unroll 1
+  for (int sweep = 0; sweep < 3; sweep++) {
+    jacobi_rotate_bf(a00, a11, a01, a02, a12, V, 0, 1);
+    jacobi_rotate_bf(a00, a22, a02, a01, a12, V, 0, 2);
+    jacobi_rotate_bf(a11, a22, a12, a01, a02, V, 1, 2);
+  }
+  if (!(jacobi_negligible(a00, a11, a01) && jacobi_negligible(a00, a22, a02) && jacobi_negligible(a11, a22, a12)))
+    jacobi_sweeps(a00, a01, a02, a11, a12, a22, V, 0);
   double UV[9];
 #pragma unroll
   for (int i = 0; i < 3; i++)

@@ -33,8 +33,8 @@ template <int W>
 struct S4 {
   static constexpr int N = 6 * W, M = N - 6, B = W - 1;
   static constexpr int TC = 0;                                   // [B][S4_BLK]  trailing block columns, overwritten by the panels of L
-  static constexpr int G = TC + (B > 0 ? B : 1) * S4_BLK;       // [3][64][6]   g rows of the last three panels
-  static constexpr int BV = G + 3 * S4_GSLOT;                    // [64] right-hand side
+  static constexpr int G = TC + (B > 0 ? B : 1) * S4_BLK;       // [B][64][6]   g rows of every panel (a block column may lag several panels behind)
+  static constexpr int BV = G + (B > 0 ? B : 1) * S4_GSLOT;     // [64] right-hand side
   static constexpr int ZV = BV + 64;                             // [64] z = D^-1 L^-1 b
   static constexpr int XS = ZV + 64;                             // [64] dxi (all 6W entries, gauge rows 0)
   static constexpr int DOUBLES = XS + 64;
@@ -85,7 +85,7 @@ template <int W>
 __device__ __forceinline__ void s4_apply(const double* lds, int t, int b, int lane, double (&T)[6]) {
   using C = S4<W>;
   double g[6];
-  s4_load_row(lds + C::G + (t % 3) * S4_GSLOT + lane * S4_ROW, g);
+  s4_load_row(lds + C::G + t * S4_GSLOT + lane * S4_ROW, g);
   const double* lr = lds + C::TC + t * S4_BLK + (6 * b) * S4_ROW;   // rows 6b .. 6b+5 of panel t: wave-uniform (broadcast) reads
 #pragma unroll
   for (int c = 0; c < 6; c++) {
@@ -158,8 +158,10 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds) 
       const int ap = sq == 0 ? ap0 : (sq == 1 ? ap1 : ap2);
       double* trow = lds + C::TC + s * S4_BLK + lane * S4_ROW;
       double a[6];
+      dbg_stamp(DBG, 4010 + s, 0);
       s4_load_row(trow, a);
       for (int t = ap + 1; t < s; t++) s4_apply<W>(lds, t, s, lane, a);
+      if (DBG) { asm volatile("" :: "v"(a[0]), "v"(a[5])); dbg_stamp(true, 4010 + s, 1); }
       // the rows of block s to LDS, the diagonal block back into every lane (one wave: LDS operations execute in order)
       s4_store_row(trow, a);
       __builtin_amdgcn_wave_barrier();
@@ -178,7 +180,9 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds) 
         Ld[10] = r4a[0]; Ld[11] = r4a[1]; Ld[12] = r4b[0]; Ld[13] = r4b[1]; Ld[14] = r4c[0];
         Ld[15] = r5a[0]; Ld[16] = r5a[1]; Ld[17] = r5b[0]; Ld[18] = r5b[1]; Ld[19] = r5c[0]; Ld[20] = r5c[1];
       }
+      if (DBG) { asm volatile("" :: "v"(Ld[0]), "v"(Ld[20])); dbg_stamp(true, 4010 + s, 2); }
       s4_ldl6(Ld, inv);
+      if (DBG) { asm volatile("" :: "v"(inv[5])); dbg_stamp(true, 4010 + s, 3); }
       // the lane's row of the panel: g = a L^-T (= l D), l = g D^-1
       double l[6];
 #pragma unroll
@@ -190,10 +194,13 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds) 
         l[p] = acc * inv[p];
       }
       s4_store_row(trow, l);
-      s4_store_row(lds + C::G + (s % 3) * S4_GSLOT + lane * S4_ROW, g);
+      s4_store_row(lds + C::G + s * S4_GSLOT + lane * S4_ROW, g);
       if (sq == 0) ap0 = s; else if (sq == 1) ap1 = s; else ap2 = s;
+      dbg_stamp(DBG, 4010 + s, 4);
     }
+    if (s < 9) dbg_stamp(DBG, 4000 + wave, 6 + 2 * s);
     __syncthreads();
+    if (s < 9) dbg_stamp(DBG, 4000 + wave, 7 + 2 * s);
     if (wave == owner) {
       // right-hand side, one step behind the factorisation: y_s = L_ss^-1 b_s, z_s = D_s^-1 y_s, rows below lose g z
       double bb[6];
@@ -219,18 +226,27 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds) 
     }
     const bool next_owner = (s + 1 < B) && wave == ((s + 1) & (S4_WAVES - 1));
     if (!next_owner) {
-      // catch up every block column this wave owns with the panels published so far
+      // Catch up the block columns this wave owns with the panels published so far -- at most two (block, panel) updates per
+      // interval, the block that becomes urgent in the NEXT interval first and completely: that keeps every wave's work between two
+      // barriers below the owner's chain (the wave that has just factored a block otherwise arrives with two panels x two blocks of
+      // backlog and everybody waits for it), and the next owner always finds exactly one panel left to take out of its block.
+      int budget = 2;
 #pragma unroll
       for (int q = 0; q < (B + S4_WAVES - 1) / S4_WAVES; q++) {
         const int b = wave + S4_WAVES * q;
-        const int ap = q == 0 ? ap0 : (q == 1 ? ap1 : ap2);
-        if (b > s && b < B && ap < s) {
+        int ap = q == 0 ? ap0 : (q == 1 ? ap1 : ap2);
+        const bool must = b == s + 2;
+        if (b > s && b < B && ap < s && (must || budget > 0)) {
           double* trow = lds + C::TC + b * S4_BLK + lane * S4_ROW;
           double T[6];
           s4_load_row(trow, T);
-          for (int t = ap + 1; t <= s; t++) s4_apply<W>(lds, t, b, lane, T);
+          while (ap < s && (must || budget > 0)) {
+            s4_apply<W>(lds, ap + 1, b, lane, T);
+            ap++;
+            budget--;
+          }
           s4_store_row(trow, T);
-          if (q == 0) ap0 = s; else if (q == 1) ap1 = s; else ap2 = s;
+          if (q == 0) ap0 = ap; else if (q == 1) ap1 = ap; else ap2 = ap;
         }
       }
     }
