@@ -451,11 +451,16 @@ int vxba_down_sampling_voxel(int device, int64_t n, const float* xyz, double vox
 
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* Bit mask of kernels to bracket with hipEvents on the launch stream: 1 = Hessian sweep (K3), 2 = residual sweep (K2),
- * 4 = K3 cross-block reduction, 8 = cluster build (K1); 0 = off. */
+ * 4 = K3 cross-block reduction, 8 = cluster build (K1), 16 = the all-reduce of a sharded factor; 0 = off. */
 int vxba_set_profiling(vxba_factor* f, int mask);
 /* Sum of kernel durations [ms] and launch counts since the last reset: index 0 = Hessian sweep (K3),
  * 1 = residual sweep (K2), 2 = K3 cross-block reduction, 3 = cluster build (K1). */
 int vxba_get_kernel_times(vxba_factor* f, double ms_sum[4], int64_t calls[4], int reset);
+/* Voxel-sharded factors (vxba_peer_*, vxba_rccl_*, vxba_set_allreduce): with bit 16 of the profiling mask set every all-reduce of the
+ * packed [Hess | JacT | residual] buffer (the exchange step of the reference's thread fan-in, voxel_map.hpp:323-332, across GPUs) is
+ * bracketed with hipEvents on the factor's stream; sum [ms] and count since the last reset.  The interval includes the wait for the
+ * slowest peer. */
+int vxba_get_collective_time(vxba_factor* f, double* ms_sum, int64_t* calls, int reset);
 /* Algorithmic bytes of one full sweep over the current factor: 0 = K3, 1 = K2. */
 int vxba_algorithmic_bytes(const vxba_factor* f, double bytes[2]);
 int vxba_nnz(vxba_factor* f, int64_t* nnz);

@@ -151,9 +151,10 @@ def test_cfg2_size_lidar_inertial_optimizers_match_the_checkers(vx, gravity):
             ref = B.li_damping_iter_gravity(fo, iw.states_init, blobs_c, max_iter=iters, thd_num=8, imu_coef=1e-4)
         else:
             ref = B.li_damping_iter(fo, iw.states_init, blobs_c, max_iter=iters, thd_num=8, imu_coef=1e-4)
-        assert got["trace"].shape == ref["trace"].shape, cname
-        assert np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:]), cname
-        assert np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-7), cname
+        if ref["trace"].shape[0]:       # upstream prints no trace from the LiDAR-inertial optimizers (the printf at :620 is commented out): oracle only
+            assert got["trace"].shape == ref["trace"].shape, cname
+            assert np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:]), cname
+            assert np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-7), cname
         et, er = synth.pose_errors(got["states"][:, :12], ref["states"][:, :12])
         assert et < 1e-7 and er < 1e-7, (cname, et, er)
         assert np.allclose(got["states"][:, 12:24], ref["states"][:, 12:24], atol=1e-6), cname      # v, bg, ba, g

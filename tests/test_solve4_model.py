@@ -65,19 +65,26 @@ def solve4_model(H, J, u, W, order_seed=0, return_stats=False):
         for k in range(6):
             lds[off + k] = a[k]
 
-    # ---- load
+    # ---- load (no barrier behind it: a wave stores its first block column at once, the rest -- and the right-hand side -- just before the
+    # first step's barrier; wave 0's factorisation of block 0 runs in between)
+    def load_block(w, q):
+        b = w + WAVES * q
+        if b < B:
+            a = np.zeros((6, 64))
+            for cc in range(6):
+                col = 6 + 6 * b + cc
+                h = H[gi_row, col]          # Hwork[col * n + row] column-major == H[row, col]
+                a[cc] = np.where(row_ok, np.where(col == gi_row, h + u * h, h), 0.0)
+            store_row(C.TC + b * BLK + lanes * ROW, a)
+
+    def load_rest():
+        for w in range(WAVES):
+            for q in range(1, (B + WAVES - 1) // WAVES):
+                load_block(w, q)
+        lds[C.BV + lanes] = np.where(row_ok, -J[gi_row], 0.0)
+
     for w in range(WAVES):
-        for q in range((B + WAVES - 1) // WAVES):
-            b = w + WAVES * q
-            if b < B:
-                a = np.zeros((6, 64))
-                for cc in range(6):
-                    col = 6 + 6 * b + cc
-                    h = H[gi_row, col]          # Hwork[col * n + row] column-major == H[row, col]
-                    a[cc] = np.where(row_ok, np.where(col == gi_row, h + u * h, h), 0.0)
-                store_row(C.TC + b * BLK + lanes * ROW, a)
-    lds[C.BV + lanes] = np.where(row_ok, -J[gi_row], 0.0)
-    lds[C.ZV + lanes] = 0.0
+        load_block(w, 0)
 
     ap = [[-1, -1, -1] for _ in range(WAVES)]
     keep = {}
@@ -164,6 +171,7 @@ def solve4_model(H, J, u, W, order_seed=0, return_stats=False):
     # interval -1: chain(0); then for every s: barrier s, {rhs(s) + catch-up(s) of the non-next-owners} run beside chain(s + 1)
     if B > 0:
         chain(0)
+    load_rest()
     for s in range(B):
         owner = s & (WAVES - 1)
         nxt = (s + 1) & (WAVES - 1) if s + 1 < B else -1

@@ -224,6 +224,7 @@ bool has_peer(const vxba_factor* f) { return f->peer.nranks > 1; }
 // Sum `count` f64 across the voxel shards, stream-ordered: the peers' mailboxes if attached, else direct RCCL, else the caller's hook.
 bool has_collective(const vxba_factor* f) { return has_peer(f) || f->rccl_comm != nullptr || f->allreduce != nullptr; }
 int shard_allreduce(vxba_factor* f, double* d_buf, size_t count) {
+  ScopedKernelTimer timer(f, 4);   // profiling bit 16: events around the collective on the factor's stream (kernel + the wait for the peers)
   if (has_peer(f)) {
     if (count > f->peer.len) return fail(f, VXBA_ERR_STATE, "peer all-reduce: buffer larger than the mailbox");
     PeerArgs a;
@@ -1582,6 +1583,18 @@ int vxba_get_kernel_times(vxba_factor* f, double ms_sum[4], int64_t calls[4], in
     if (calls) calls[k] = f->calls[k];
     if (reset) { f->ms_sum[k] = 0; f->calls[k] = 0; }
   }
+  return VXBA_OK;
+}
+
+int vxba_get_collective_time(vxba_factor* f, double* ms_sum, int64_t* calls, int reset) {
+  VX_LOCK(f);
+  if (!f) return VXBA_ERR_ARG;
+  hipSetDevice(f->device);
+  int rc = drain_events(f);
+  if (rc) return rc;
+  if (ms_sum) *ms_sum = f->ms_sum[4];
+  if (calls) *calls = f->calls[4];
+  if (reset) { f->ms_sum[4] = 0; f->calls[4] = 0; }
   return VXBA_OK;
 }
 

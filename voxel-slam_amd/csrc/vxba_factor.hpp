@@ -123,11 +123,11 @@ struct vxba_factor {
     double* boxes[VXBA_PEER_MAX] = {};    // mailbox of rank p as seen from this process
     unsigned long long seq = 0;
   } peer;
-  int profiling = 0;             // bit mask of kernel kinds to bracket with events: 1 K3, 2 K2, 4 K3 finalize, 8 K1
+  int profiling = 0;             // bit mask of kernel kinds to bracket with events: 1 K3, 2 K2, 4 K3 finalize, 8 K1, 16 all-reduce
   std::vector<EventPair> pending;
   std::vector<hipEvent_t> free_events;
-  double ms_sum[4] = {0, 0, 0, 0};
-  int64_t calls[4] = {0, 0, 0, 0};
+  double ms_sum[5] = {0, 0, 0, 0, 0};   // [4]: the all-reduce of a sharded factor (profiling bit 16)
+  int64_t calls[5] = {0, 0, 0, 0, 0};
   std::string err;
   // The reference calls the two sweeps from several std::threads on one LidarFactor with disjoint [head,end)
   // (voxel_map.hpp:318-332); entry points serialise on this lock so such callers stay correct.

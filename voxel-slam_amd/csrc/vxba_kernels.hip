@@ -228,13 +228,15 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(FactorView fv, 
     }
     vb -= K2_WAVES;
   }
-  if (vb * VPB >= end - head) return;   // the last workgroup's spare waves
-  if (st && seq != 0) {
+  const bool fused = st && seq != 0;
+  const bool spare = vb * VPB >= end - head;   // the last workgroup's spare waves: no voxels; in a fused launch they stay for the workgroup's barrier
+  if (spare && !fused) return;
+  if (fused) {
     // let the solver's first (dependent) loads through before 780 waves put 50 MB of requests in front of them
     for (int k = 0; k < head_start; k += 10) __builtin_amdgcn_s_sleep(10);
   }
   const int a = head + vb * VPB + lane;
-  const bool valid = lane < VPB && a < end;
+  const bool valid = !spare && lane < VPB && a < end;
   const size_t VS = (size_t)fv.VS;
   double res = 0.0;
   dbg_stamp(DBG, vb, 0);
@@ -265,18 +267,32 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(FactorView fv, 
   // poses -> LDS (wave-uniform operands of the transform).  LM mode reads the trial poses with coherent loads, after
   // the solve has published them when it runs inside this launch.
   {
-    if (st) {
-      if (seq != 0) {
-        // relaxed polls and no acquire fence (either would invalidate caches chip-wide, 780 times over): the trial poses
-        // are fetched below with system-coherent (volatile) loads, issued in program order after the poll that saw `seq`
+    if (fused) {
+      // ONE wave per workgroup polls (196 pollers on one L2 line instead of 782, so they can poll four times as often) and fetches the
+      // trial poses for all four; the others sleep in the workgroup barrier.  Relaxed polls and no acquire fence (either would
+      // invalidate caches chip-wide, hundreds of times over): the poses are fetched with system-coherent (volatile) loads, issued in
+      // program order after the poll that saw `seq`.
+      __shared__ int k2_gave_up;
+      pose_lds = k2_lds;
+      if (wave == 0) {
         unsigned spins = 0;
-        const unsigned spin_limit = (VPB_arg >> 16) ? 1u : K2_SPIN_LIMIT;   // bit 16 of VPB_arg: test hook (VXBA_OPT_DEBUG_SOLVE_TIMEOUT), give up at once
+        const unsigned spin_limit = (VPB_arg >> 16) ? 1u : 4u * K2_SPIN_LIMIT;   // bit 16 of VPB_arg: test hook (VXBA_OPT_DEBUG_SOLVE_TIMEOUT), give up at once
+        bool seen = true;
         while (__hip_atomic_load(&st->solve_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
-          __builtin_amdgcn_s_sleep(16);
-          if (++spins > spin_limit) { if (lane == 0) st->error = 1; return; }   // never observed in production; a hang would cost the GPU
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > spin_limit) { seen = false; break; }   // never observed in production; a hang would cost the GPU
         }
         if (DBG) dbg_stamp(true, vb, 5);
+        if (seen) {
+          const volatile double* xt = st->ctl[c].xt;
+          if (lane < 12 * W) pose_lds[lane] = xt[lane];
+          if (lane + 64 < 12 * W) pose_lds[lane + 64] = xt[lane + 64];
+        } else if (lane == 0) st->error = 1;
+        if (lane == 0) k2_gave_up = seen ? 0 : 1;
       }
+      __syncthreads();
+      if (k2_gave_up || spare) return;
+    } else if (st) {
       const volatile double* xt = st->ctl[c].xt;
       if (lane < 12 * W) pose_lds[lane] = xt[lane];
       if (lane + 64 < 12 * W) pose_lds[lane + 64] = xt[lane + 64];

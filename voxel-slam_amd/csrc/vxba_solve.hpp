@@ -7,9 +7,26 @@ namespace vxk {
 
 __device__ __forceinline__ void lm_right_multiply_exp(const double* Rin, const double* dphi, double* Rout) {
   // R <- R Exp(dphi), column-major 3x3; Rodrigues with the reference's 1e-11 cut-off (tools.hpp:51-66)
-  const double th = sqrt(dphi[0] * dphi[0] + dphi[1] * dphi[1] + dphi[2] * dphi[2]);
+  const double th2 = dphi[0] * dphi[0] + dphi[1] * dphi[1] + dphi[2] * dphi[2];
+  const double th = sqrt(th2);
   double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  if (th >= 1e-11) {
+  if (th >= 1e-11 && th2 < 0.0625) {
+    // an LM step: |dphi| < 0.25 rad.  E = I + A K + B K^2 with K = hat(dphi) (not normalised), A = sin(th) / th, B = (1 - cos th) / th^2
+    // from their series in th^2 (eight terms: the first neglected one is below 1e-24) -- the same matrix as the branch below to
+    // round-off, without the library sincos (~150 instructions on one wave, on the critical path between solve and residual sweep).
+    double A = -1.0 / 1307674368000.0, Bc = -1.0 / 20922789888000.0;   // -1/15!, -1/16!
+    A = fma(A, th2, 1.0 / 6227020800.0);   Bc = fma(Bc, th2, 1.0 / 87178291200.0);    // +1/13!, +1/14!
+    A = fma(A, th2, -1.0 / 39916800.0);    Bc = fma(Bc, th2, -1.0 / 479001600.0);     // -1/11!, -1/12!
+    A = fma(A, th2, 1.0 / 362880.0);       Bc = fma(Bc, th2, 1.0 / 3628800.0);        // +1/9!,  +1/10!
+    A = fma(A, th2, -1.0 / 5040.0);        Bc = fma(Bc, th2, -1.0 / 40320.0);         // -1/7!,  -1/8!
+    A = fma(A, th2, 1.0 / 120.0);          Bc = fma(Bc, th2, 1.0 / 720.0);            // +1/5!,  +1/6!
+    A = fma(A, th2, -1.0 / 6.0);           Bc = fma(Bc, th2, -1.0 / 24.0);            // -1/3!,  -1/4!
+    A = fma(A, th2, 1.0);                  Bc = fma(Bc, th2, 0.5);
+    const double k0 = dphi[0], k1 = dphi[1], k2 = dphi[2];
+    E[0] = 1.0 + Bc * (k0 * k0 - th2); E[1] = -A * k2 + Bc * k0 * k1;      E[2] = A * k1 + Bc * k0 * k2;
+    E[3] = A * k2 + Bc * k0 * k1;      E[4] = 1.0 + Bc * (k1 * k1 - th2); E[5] = -A * k0 + Bc * k1 * k2;
+    E[6] = -A * k1 + Bc * k0 * k2;     E[7] = A * k0 + Bc * k1 * k2;      E[8] = 1.0 + Bc * (k2 * k2 - th2);
+  } else if (th >= 1e-11) {
     const double ith = 1.0 / th;
     const double k0 = dphi[0] * ith, k1 = dphi[1] * ith, k2 = dphi[2] * ith;
     double sn, cs;

@@ -113,8 +113,24 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds) 
   const bool row_ok = lane < M;
   const int gi_row = row_ok ? 6 + lane : 0;     // global row of this lane
 
-  // ---- load: wave w brings in the block columns it owns (damping on the diagonal, voxel_map.hpp:402), wave 1 the right-hand side
-  double hii = 0.0, gi = 0.0;
+  // ---- load: wave w brings in the block columns it owns (damping on the diagonal, voxel_map.hpp:402), wave 1 the right-hand side.
+  // No barrier behind the loads: the first step needs block column 0 only, which wave 0 loads first and stores at once -- the
+  // factorisation of block 0 starts when those six loads have landed; everything else (the other block columns, the right-hand
+  // side) is stored before the first step's barrier, which is the first point where another wave's data is read.
+  constexpr int NQ = (B + S4_WAVES - 1) / S4_WAVES;
+  double a0[NQ > 0 ? NQ : 1][6];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {          // all requests first (a block the wave does not have re-reads block `wave`)
+    const int b = wave + S4_WAVES * q;
+    const int bb = b < B ? b : 0;
+#pragma unroll
+    for (int cc = 0; cc < 6; cc++) {
+      const int col = 6 + 6 * bb + cc;
+      const double h = st->Hwork[(size_t)col * n + gi_row];
+      a0[q][cc] = row_ok ? ((col == gi_row) ? h + u * h : h) : 0.0;
+    }
+  }
+  double hii = 0.0, gi = 0.0, rhs0 = 0.0;
   double xcur[12];
   if (wave == 0) {
     hii = st->Hwork[(size_t)gi_row * n + gi_row];
@@ -123,29 +139,8 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds) 
 #pragma unroll
     for (int k = 0; k < 12; k++) xcur[k] = ctl.x[12 * fl + k];
   }
-  {
-    constexpr int NQ = (B + S4_WAVES - 1) / S4_WAVES;
-    double a[NQ > 0 ? NQ : 1][6];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {          // all requests first (a block the wave does not have re-reads block `wave`)
-      const int b = wave + S4_WAVES * q;
-      const int bb = b < B ? b : 0;
-#pragma unroll
-      for (int cc = 0; cc < 6; cc++) {
-        const int col = 6 + 6 * bb + cc;
-        const double h = st->Hwork[(size_t)col * n + gi_row];
-        a[q][cc] = row_ok ? ((col == gi_row) ? h + u * h : h) : 0.0;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-      const int b = wave + S4_WAVES * q;
-      if (b < B) s4_store_row(lds + C::TC + b * S4_BLK + lane * S4_ROW, a[q]);
-    }
-  }
-  if (wave == 1 % S4_WAVES) lds[C::BV + lane] = row_ok ? -st->Jwork[gi_row] : 0.0;
-  if (wave == 2 % S4_WAVES) lds[C::ZV + lane] = 0.0;
-  __syncthreads();
+  if (wave == 1 % S4_WAVES) rhs0 = row_ok ? -st->Jwork[gi_row] : 0.0;
+  if (wave < B) s4_store_row(lds + C::TC + wave * S4_BLK + lane * S4_ROW, a0[0]);
   dbg_stamp(DBG && wave == 0, 4000, 2);
 
   // ---- factorisation
@@ -197,6 +192,14 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds) 
       s4_store_row(lds + C::G + s * S4_GSLOT + lane * S4_ROW, g);
       if (sq == 0) ap0 = s; else if (sq == 1) ap1 = s; else ap2 = s;
       dbg_stamp(DBG, 4010 + s, 4);
+    }
+    if (s == 0) {
+#pragma unroll
+      for (int q = 1; q < NQ; q++) {
+        const int b = wave + S4_WAVES * q;
+        if (b < B) s4_store_row(lds + C::TC + b * S4_BLK + lane * S4_ROW, a0[q]);
+      }
+      if (wave == 1 % S4_WAVES) lds[C::BV + lane] = rhs0;
     }
     if (s < 9) dbg_stamp(DBG, 4000 + wave, 6 + 2 * s);
     __syncthreads();

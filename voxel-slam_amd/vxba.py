@@ -28,7 +28,7 @@ _RESID_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.
 EXPORTS = [
     "vxba_create", "vxba_destroy", "vxba_clear", "vxba_set_win_size", "vxba_win_size", "vxba_size", "vxba_set_stream",
     "vxba_reserve", "vxba_last_error", "vxba_push_voxels", "vxba_push_points", "vxba_read_clusters", "vxba_acc_evaluate2",
-    "vxba_evaluate_only_residual", "vxba_acc_evaluate2_device", "vxba_evaluate_only_residual_device", "vxba_packed_len",
+    "vxba_evaluate_only_residual", "vxba_get_collective_time", "vxba_acc_evaluate2_device", "vxba_evaluate_only_residual_device", "vxba_packed_len",
     "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_plane_fit_judge", "vxba_build_clusters", "vxba_set_allreduce",
     "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_attach_bcast", "vxba_rccl_detach", "vxba_peer_export", "vxba_peer_attach", "vxba_peer_detach", "vxba_peer_status", "vxba_peer_selftest", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_device_bytes", "vxba_debug_mfma_probe", "vxba_debug_stamps", "vxba_debug_band_schur", "vxba_push_voxels_csr",
     "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_li_evaluate",
@@ -118,6 +118,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_set_profiling.argtypes = [vp, ci]
     L.vxba_set_precision.argtypes = [vp, ci]
     L.vxba_get_kernel_times.argtypes = [vp, _f64p, _i64p, ci]
+    L.vxba_get_collective_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), ci]
     L.vxba_algorithmic_bytes.argtypes = [vp, _f64p]
     L.vxba_nnz.argtypes = [vp, C.POINTER(C.c_int64)]
     L.vxba_device_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -446,6 +447,12 @@ class LidarFactor:
         self._chk(self._L.vxba_get_kernel_times(self._h, ms, calls, int(reset)))
         names = ("k3_hessian", "k2_residual", "k3_finalize", "k1_build")
         return {k: dict(ms_sum=float(ms[i]), calls=int(calls[i])) for i, k in enumerate(names)}
+
+    def collective_time(self, reset=False):
+        """All-reduces of a voxel-sharded factor bracketed while profiling bit 16 was set: dict(ms_sum, calls)."""
+        ms = C.c_double(0); calls = C.c_int64(0)
+        self._chk(self._L.vxba_get_collective_time(self._h, C.byref(ms), C.byref(calls), int(reset)))
+        return dict(ms_sum=float(ms.value), calls=int(calls.value))
 
     def algorithmic_bytes(self):
         b = np.zeros(2)
