@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 3, session 6: Hessian sweep -- parameter round trip under the tail of phase M, 16-byte write-through stores of the workgroup partial
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_golden.py tests/test_gpu_fuzz.py -m gpu -q -x --timeout 600 -p no:cacheprovider 2>&1 | grep -v "RuntimeWarning\|ev_ref\|^$\|Docs:\|warnings.warn" | tail -5
+run() { VXBA_LIB=$PWD/$1 timeout 300 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-li-ba $2 2>&1 | grep -v amdgpu.ids | python -c "
+import sys, json
+for l in sys.stdin:
+    try: d = json.loads(l)
+    except Exception: print(l.rstrip()); continue
+    r = d['roofline']
+    print('$1 $2 it/s %.0f  us/step %.2f  k3 %.2f  k2 %.2f  fin %.2f  solve+k2 %.2f' % (d['value'], 1e3*d['ms_per_step'], r['avg_launch_ms']*1e3, r['k2_residual']['avg_launch_ms']*1e3, r['k3_finalize_avg_ms']*1e3, 1e3*r.get('solve_plus_k2_launch_avg_ms', 0)))
+"; }
+for r in 1 2; do for lib in gpurun_ab/libvxba_head.so gpurun_ab/libvxba_nohoist.so voxel-slam_amd/csrc/libvxba.so; do run $lib; done; done
+for cfg in cfg3 cfg4; do for lib in gpurun_ab/libvxba_head.so voxel-slam_amd/csrc/libvxba.so; do run $lib "--config $cfg"; done; done

@@ -519,9 +519,13 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
 
   const K3RowOfs ro = k3_row_offsets<W>(wave, vl, fi);   // lane constants: where the lane's three row pieces go inside a tile buffer
   // Phase A of the wave's batch b into tile buffer `bo`, then the requests for its next batch nb (nb < 0: none).
-  auto phase_a = [&](int b, int bo, int nb) __attribute__((always_inline)) {
+  // Measured and rejected (round 3, same box): the LDS round trip of the plane parameters issued two thirds of the way through phase M
+  // instead of at the head of phase A -- 29.8 -> 29.6 us at cfg2, but 166.9 -> 173.3 us at cfg4 (13 steps per workgroup): the wait
+  // for the parameter loads then sits inside the MFMA stream, and with more traffic in flight they have not always landed by then.
+  auto unstage = [&](int b) __attribute__((always_inline)) { k3_unstage_params<W>(stg, stage_lds, head, end, b, active, vl, lane, e); };
+  auto phase_a = [&](int b, int bo, int nb, bool staged) __attribute__((always_inline)) {
     double rows[3][6];
-    k3_unstage_params<W>(stg, stage_lds, head, end, b, active, vl, lane, e);
+    if (!staged) unstage(b);
     // voxel-level values for the spare columns, taken before phase A masks / consumes the entry
     const double spare_s = 1.4142135623730951 * e.sc;
     const double spare[3] = {spare_s * e.u[0], spare_s * e.u[1], spare_s * e.u[2]};
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
       }
       if (s < nfull) {
         const bool more = (s + 1 < nfull) || (wave < nrag);
-        phase_a(bs + s * C::WAVES + wave, (s & 1) * C::BUF, more ? bs + (s + 1) * C::WAVES + wave : -1);
+        phase_a(bs + s * C::WAVES + wave, (s & 1) * C::BUF, more ? bs + (s + 1) * C::WAVES + wave : -1, false);
         if (s >= 1 && s <= 4) dbg_stamp(DBG, gw, 14 + 3 * s);   // phase A of step s done: slots 17, 20, 23, 26
       }
       if (AF && s >= 1) phase_m();
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
     // ragged last step: nrag < 8 batches.  Only ceil(nrag R / 4) K-steps exist; they are re-split over the K ranges, and the first
     // idle wave makes the rows that round the step up to a whole K-step read as zeros.
     const int bo = (nfull & 1) * C::BUF;
-    if (wave < nrag) phase_a(bs + nfull * C::WAVES + wave, bo, -1);
+    if (wave < nrag) phase_a(bs + nfull * C::WAVES + wave, bo, -1, false);
     else if (wave == nrag) {
       if (MIXED) { float* z = reinterpret_cast<float*>(lds) + bo + C::at(nrag * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0f; }
       else { double* z = lds + bo + C::at(nrag * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0; }
@@ -633,13 +637,20 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
     for (int r = 0; r < 4; r++) park_t[(wave * C::TPW + j) * 256 + r * 64 + lane] = acc[j][r];
   __syncthreads();
   if (E::ONE_PHASE) k3_sum_linear<W>(park_d, pout + C::NTP * 256, tid);
-  for (int el = tid; el < C::NTP * 256; el += K3_BLOCK) {
+  // two consecutive elements per thread: one 16-byte store (write-through like the other bulk outputs -- an 8-byte write-through store
+  // costs 2.7x the time per byte of a 16-byte one, and this tail of 22 KB per workgroup is store-issue-bound)
+  const __amdgpu_buffer_rsrc_t rout = k3_rsrc(pout);
+  for (int el = 2 * tid; el < C::NTP * 256; el += 2 * K3_BLOCK) {
     const int t = el >> 8, x = el & 255;
     const int ts = t / C::TPW, j = t % C::TPW;
-    double sum = 0.0;
+    v2d sum = (v2d){0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < C::KSPLIT; k++) sum += park_t[((k * C::TSPLIT + ts) * C::TPW + j) * 256 + x];
-    st_out(&pout[el], sum);
+    for (int k = 0; k < C::KSPLIT; k++) sum += *reinterpret_cast<const v2d*>(park_t + ((k * C::TSPLIT + ts) * C::TPW + j) * 256 + x);
+#if VXBA_WT_STORES
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, sum), rout, el * 8, 0, 16);   // aux 16 = sc1 on gfx950
+#else
+    *reinterpret_cast<v2d*>(pout + el) = sum;
+#endif
   }
   dbg_stamp(DBG, gw, 6);
 }
