@@ -347,7 +347,11 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
 #define VXBA_OPT_LI_QUEUED_SWEEPS 7    /* 1 (default): the host shells of LI_BA_Optimizer[Gravity] queue an iteration's residual sweep (and the speculative Hessian sweep
                                        * behind it) BEFORE the host has finished the damped solve; the sweep's first workgroup waits for the trial poses in mapped host
                                        * memory while the others already hold their cluster rows.  0: every sweep is launched when its poses exist. */
-#define VXBA_OPT_COUNT 8
+#define VXBA_OPT_LI_DEVICE_POSE_SOLVE 8 /* 1 (default): LI_BA_Optimizer's host shell (queued sweeps, structured solve) eliminates velocities and biases on the host WHILE
+                                       * the Hessian sweep runs and lets the device solve the reduced 6W-dimensional pose system inside the residual-sweep launch
+                                       * (the LiDAR-only loop's four-wave solve): no kernel ever waits for the host, the LiDAR Hessian never crosses PCIe on the
+                                       * critical path.  Steps after a rejection, the gravity variant and a non-positive band pivot take the host solve.  0: host solve. */
+#define VXBA_OPT_COUNT 9
 #define VXBA_STAT_FUSED_FALLBACKS 100 /* read-only (vxba_get_option): times vxba_damping_iter re-ran a call with the solve as its own launch after the
                                          voxel workgroups of a fused launch had timed out waiting for it */
 #define VXBA_STAT_LI_LAST_CALL_US 101 /* read-only (vxba_get_option): wall time of the last vxba_li_damping_iter[_gravity] call, microseconds,

@@ -49,6 +49,9 @@ int vxba_destroy(vxba_factor* f) {
   for (auto e : f->free_events) hipEventDestroy(e);
   hipFree(f->planes); hipFree(f->clb); hipFree(f->cl32); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2); if (f->h_partial2) hipHostFree(f->h_partial2);
   if (f->h_feed) (void)hipHostFree(f->h_feed);
+  if (f->h_lirec) (void)hipHostFree(f->h_lirec);
+  if (f->h_packed2) (void)hipHostFree(f->h_packed2);
+  if (f->h_liout) (void)hipHostFree(f->h_liout);
   if (f->li_ev2) (void)hipEventDestroy(f->li_ev2);
   if (f->li_ev3) (void)hipEventDestroy(f->li_ev3);
   vxw::free_index(f->wide);
@@ -632,7 +635,7 @@ int vxba_set_option(vxba_factor* f, int option, int value) {
   VX_LOCK(f);
   switch (option) {
     case VXBA_OPT_FUSED_SOLVE: case VXBA_OPT_SPEC_COLLECTIVE: case VXBA_OPT_WIDE_DEVICE_SOLVE: case VXBA_OPT_LI_DEVICE_LOOP:
-    case VXBA_OPT_DEBUG_SOLVE_TIMEOUT: case VXBA_OPT_LI_STRUCTURED_SOLVE: case VXBA_OPT_LI_QUEUED_SWEEPS:
+    case VXBA_OPT_DEBUG_SOLVE_TIMEOUT: case VXBA_OPT_LI_STRUCTURED_SOLVE: case VXBA_OPT_LI_QUEUED_SWEEPS: case VXBA_OPT_LI_DEVICE_POSE_SOLVE:
       if (value != 0 && value != 1) return fail(f, VXBA_ERR_ARG, "vxba_set_option: this option takes 0 or 1");
       break;
     case VXBA_OPT_K2_VOXELS_PER_BLOCK:

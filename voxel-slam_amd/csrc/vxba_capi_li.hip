@@ -262,6 +262,23 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
     VX_HIP(f, hipHostGetDevicePointer((void**)&f->zc_feed, f->h_feed, 0));
     f->h_feed[0] = 0.0;
   }
+  // The reduced pose system solved INSIDE the residual-sweep launch (VXBA_OPT_LI_DEVICE_POSE_SOLVE, vxba_solve4.hpp): what eliminating the
+  // velocity / bias unknowns adds to the pose block goes up through mapped host memory before the launch, dx and the trial poses come back
+  // the same way.  Not for the gravity variant (three more dense unknowns) and not for the re-solve after a rejected step (the device's
+  // copy of the LiDAR system has been overwritten by the speculative sweep by then): those keep the host solve and the pose feed below.
+  const bool dev_solve = !with_g && f->opt[VXBA_OPT_LI_DEVICE_POSE_SOLVE] != 0 && W <= VXBA_MAX_WIN;
+  if (dev_solve && !f->h_lirec) {
+    VX_HIP(f, hipHostMalloc((void**)&f->h_lirec, sizeof(double) * vxk::li_rec_doubles(VXBA_MAX_WIN), hipHostMallocMapped | hipHostMallocCoherent));
+    VX_HIP(f, hipHostGetDevicePointer((void**)&f->zc_lirec, f->h_lirec, 0));
+    VX_HIP(f, hipHostMalloc((void**)&f->h_liout, sizeof(double) * vxk::li_out_doubles(VXBA_MAX_WIN), hipHostMallocMapped | hipHostMallocCoherent));
+    VX_HIP(f, hipHostGetDevicePointer((void**)&f->zc_liout, f->h_liout, 0));
+    std::memset(f->h_liout, 0, sizeof(double) * vxk::li_out_doubles(VXBA_MAX_WIN));
+  }
+  if (dev_solve && !f->h_packed2) {
+    const size_t plen_max = (size_t)36 * VXBA_MAX_WIN * VXBA_MAX_WIN + 6 * VXBA_MAX_WIN + 2;
+    VX_HIP(f, hipHostMalloc((void**)&f->h_packed2, plen_max * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    VX_HIP(f, hipHostGetDevicePointer((void**)&f->zc_packed2, f->h_packed2, 0));
+  }
   if (!f->li_ev) VX_HIP(f, hipEventCreateWithFlags(&f->li_ev, hipEventDisableTiming));
   if (!f->li_ev2) VX_HIP(f, hipEventCreateWithFlags(&f->li_ev2, hipEventDisableTiming));
   if (!f->li_ev3) VX_HIP(f, hipEventCreateWithFlags(&f->li_ev3, hipEventDisableTiming));
@@ -293,10 +310,18 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
   // the wasted speculative reduction may still be running when the next poses are fed, so no fill then: `sentinel` is off and the next
   // system is awaited through its event alone.  (A first version filled after every residual sweep, "a Hessian sweep before the next
   // reduction": on small windows that sweep is 10 us, the fill sometimes came after the reduction, and the solve ran on NaNs.)
-  bool sentinel = false;
-  auto nan_fill_packed = [&]() { for (size_t k = 0; k < plen; k++) f->h_packed[k] = std::numeric_limits<double>::quiet_NaN(); sentinel = true; };
+  // Device-solve mode: consecutive systems alternate between two mapped buffers (index = `cur`, like their events).  The launch whose
+  // workgroup 0 solves does not wait for the host, so the speculative reduction behind it may complete at any time: it must neither land
+  // in the buffer the host is still reading nor race the sentinel fill -- the sentinel of the NEXT buffer therefore goes in before the
+  // launches that will write it (`next_sentinel`), never after.  The host-solve modes keep one buffer (both entries alias it).
+  ensure_exchange(f);
+  double* hpk[2] = {f->h_packed, dev_solve ? f->h_packed2 : f->h_packed};
+  double* zpk[2] = {f->zc_packed, dev_solve ? f->zc_packed2 : f->zc_packed};
+  bool sentinel = false, next_sentinel = false;
+  auto nan_fill_buf = [&](double* b) { for (size_t k = 0; k < plen; k++) b[k] = std::numeric_limits<double>::quiet_NaN(); };
+  auto nan_fill_packed = [&]() { nan_fill_buf(hpk[cur]); sentinel = true; };
   auto wait_packed = [&](hipEvent_t ev) -> int {
-    const volatile double* hp = f->h_packed;
+    const volatile double* hp = hpk[cur];
     for (;;) {
       if (sentinel) {
         bool all = true;
@@ -322,8 +347,19 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
   {
     double Rp0[12 * VXBA_MAX_WIN];
     for (int i = 0; i < W; i++) std::memcpy(Rp0 + 12 * i, states + SL * i, sizeof(double) * 12);
-    rc = sweep_hess_device(f, Rp0, nullptr, nullptr, nullptr, 0, f->V, f->zc_packed);
-    if (rc) return rc;
+    if (dev_solve) {      // the reduction also leaves the gauge-fixed LiDAR system in the device's LM state, where the in-launch solve reads it
+      PoseArg pa;
+      fill_poses(f, Rp0, pa);
+      vxk::LMPending none;
+      std::memset(&none, 0, sizeof none);
+      if (vxk::launch_k3_hessian(fv, pa, nullptr, 0, none, nullptr, 0, f->V, f->d_partial3, nblocks3, f->precision, f->stream) < 0)
+        return fail(f, VXBA_ERR_STATE, "li: cache planes are not consecutive");
+      vxk::launch_k3_finalize(f->d_partial3, nblocks3, W, f->d_lm, 0, 1, zpk[cur], f->stream, 1);
+      VX_HIP(f, hipGetLastError());
+    } else {
+      rc = sweep_hess_device(f, Rp0, nullptr, nullptr, nullptr, 0, f->V, zpk[cur]);
+      if (rc) return rc;
+    }
     VX_HIP(f, hipEventRecord(ev_sys[cur], f->stream));
   }
   f->li.size(n, W - 1);
@@ -345,20 +381,30 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
   vxi::ImuWork wk;
   bool ok = true;
   // queue iteration's residual sweep (waiting for the feed) and, with_spec, the Hessian sweep + reduction at the same trial poses
-  auto queue_sweeps = [&](bool with_spec) -> int {
+  auto queue_sweeps = [&](bool with_spec, bool dev) -> int {
     seq = ++f->lm_seq;
     if (seq == 0) seq = ++f->lm_seq;
-    nparts = vxk::launch_k2_residual(fv, pa0, f->d_lm, 0, seq, 0, f->V, f->zc_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK], f->stream, nullptr, nullptr, f->zc_feed);
+    if (dev) {    // nobody will feed this launch: the sentinels of its outputs go in now (the previous launch's have been consumed)
+      for (int k = 0; k < 18 * W + 1; k++) f->h_liout[k] = std::numeric_limits<double>::quiet_NaN();
+      const int np = (f->V + (f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] & 0xffff) - 1) / (f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] & 0xffff);
+      for (int k = 0; k < np; k++) f->h_partial2[k] = std::numeric_limits<double>::quiet_NaN();
+      std::atomic_thread_fence(std::memory_order_release);
+      nparts = vxk::launch_k2_residual(fv, pa0, f->d_lm, 0, seq, 0, f->V, f->zc_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK], f->stream, nullptr, nullptr, nullptr,
+                                       f->zc_lirec, f->zc_liout);
+    } else {
+      nparts = vxk::launch_k2_residual(fv, pa0, f->d_lm, 0, seq, 0, f->V, f->zc_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK], f->stream, nullptr, nullptr, f->zc_feed);
+    }
     VX_HIP(f, hipGetLastError());
     VX_HIP(f, hipEventRecord(f->li_ev, f->stream));
-    armed = true;
+    armed = !dev;
     if (with_spec) {
       vxk::LMPending pd;
       std::memset(&pd, 0, sizeof pd);
       pd.pending = 2;                               // linearise at the control block's trial poses; no decision inside the sweep
       if (vxk::launch_k3_hessian(fv, pa0, f->d_lm, 0, pd, nullptr, 0, f->V, f->d_partial3, nblocks3, f->precision, f->stream) < 0)
         return fail(f, VXBA_ERR_STATE, "li: cache planes are not consecutive");
-      vxk::launch_k3_finalize(f->d_partial3, nblocks3, W, nullptr, 0, 0, f->zc_packed, f->stream);
+      if (dev_solve) vxk::launch_k3_finalize(f->d_partial3, nblocks3, W, f->d_lm, 0, 1, zpk[cur ^ 1], f->stream, 1);
+      else vxk::launch_k3_finalize(f->d_partial3, nblocks3, W, nullptr, 0, 0, zpk[cur ^ 1], f->stream);
       VX_HIP(f, hipGetLastError());
       VX_HIP(f, hipEventRecord(ev_sys[cur ^ 1], f->stream));
     }
@@ -379,6 +425,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
     const bool with_spec = it + 1 < max_iter;
     f->li_reduction_in_flight = with_spec;          // cleared again when the next iteration consumes (or supersedes) it
     bool prepared = false;
+    bool dev_this = false;                          // this iteration's pose system is solved inside the residual-sweep launch
     if (is_calc_hess) {
       if (imu_ready) { Hess.swap(HessN); JacT.swap(JacTN); imu_res = imu_res_next; imu_ready = false; }
       else {
@@ -388,11 +435,41 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
         if (!ok) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
       }
       Aw = &Hess[(size_t)g0 * n + g0];
-      rc = queue_sweeps(with_spec);                 // behind the system's sweep: starts when that is done, then waits for the poses
-      if (rc) return rc;
-      // band half of the solve (velocities / biases: IMU terms only) while the GPU is still sweeping
-      for (int y : sets.Y) { rhs[y] = -JacT[y + g0]; work[y] = u * Hess[(size_t)(y + g0) * n + y + g0]; }
-      prepared = vxh::band_schur_prepare(Aw, n, work.data(), rhs.data(), sets.Y.data(), ny, sets.bw, sets.X.data(), nx, sets.xlo.data(), bs);
+      if (dev_solve) {
+        // band half first (velocities / biases: IMU terms only; the GPU is still sweeping), then what it adds to the pose block goes into the
+        // record the in-launch solve reads, and only then the launches: the residual sweep's workgroup 0 solves, nobody waits for the host
+        for (int y : sets.Y) { rhs[y] = -JacT[y + g0]; work[y] = u * Hess[(size_t)(y + g0) * n + y + g0]; }
+        prepared = vxh::band_schur_prepare(Aw, n, work.data(), rhs.data(), sets.Y.data(), ny, sets.bw, sets.X.data(), nx, sets.xlo.data(), bs);
+        dev_this = prepared && nx == m6 - 6;
+        if (dev_this) {
+          double* rec = f->h_lirec;
+          rec[0] = u;
+          for (int i = 0; i < W; i++) std::memcpy(rec + 1 + 12 * i, states + SL * i, sizeof(double) * 12);
+          double* e = rec + 1 + 12 * W;
+          double* E = rec + 1 + 18 * W;
+          std::memset(e, 0, sizeof(double) * (m6 + (size_t)m6 * m6));
+          const int nc = vxh::band_schur_stride(nx);
+          for (int p = 0; p < nx; p++) {           // X[p] = pose unknown 6 + p of the device's ordering; Hess / JacT hold the IMU terms only at this point
+            const double* Arow = Aw + (size_t)sets.X[p] * n;
+            e[6 + p] = -JacT[sets.X[p] + g0] + bs.rx0[p];
+            for (int q = 0; q <= p; q++) {
+              const double v2 = Arow[sets.X[q]] + bs.S0[(size_t)p * nc + q] + (p == q ? u * Arow[sets.X[p]] : 0.0);
+              E[(size_t)(6 + q) * m6 + 6 + p] = v2;
+              E[(size_t)(6 + p) * m6 + 6 + q] = v2;
+            }
+          }
+          std::atomic_thread_fence(std::memory_order_release);
+          if (with_spec) { nan_fill_buf(hpk[cur ^ 1]); next_sentinel = true; }   // nothing can be writing that buffer: its last system was consumed an iteration ago
+        }
+        rc = queue_sweeps(with_spec, dev_this);
+        if (rc) return rc;
+      } else {
+        rc = queue_sweeps(with_spec, false);          // behind the system's sweep: starts when that is done, then waits for the poses
+        if (rc) return rc;
+        // band half of the solve (velocities / biases: IMU terms only) while the GPU is still sweeping
+        for (int y : sets.Y) { rhs[y] = -JacT[y + g0]; work[y] = u * Hess[(size_t)(y + g0) * n + y + g0]; }
+        prepared = vxh::band_schur_prepare(Aw, n, work.data(), rhs.data(), sets.Y.data(), ny, sets.bw, sets.X.data(), nx, sets.xlo.data(), bs);
+      }
       if (!sys_queued) return fail(f, VXBA_ERR_STATE, "li: internal -- no Hessian sweep in flight for the accepted state");
       {
         const auto tw = std::chrono::steady_clock::now();
@@ -401,22 +478,47 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
         if (rc) return rc;
       }
       sys_queued = false;
-      vxi::li_hess_plus(W, Hess.data(), JacT.data(), f->h_packed, f->h_packed + (size_t)m6 * m6, n);
-      residual1 = imu_res + f->h_packed[(size_t)m6 * m6 + m6];
-      if (with_spec) nan_fill_packed();            // consumed; the speculative reduction sits behind a residual sweep that has no poses yet
+      vxi::li_hess_plus(W, Hess.data(), JacT.data(), hpk[cur], hpk[cur] + (size_t)m6 * m6, n);
+      residual1 = imu_res + hpk[cur][(size_t)m6 * m6 + m6];
+      if (with_spec && !dev_this) {                // consumed; the speculative reduction sits behind a residual sweep that has no poses yet
+        nan_fill_buf(hpk[cur ^ 1]);
+        if (dev_solve) next_sentinel = true; else sentinel = true;
+      }
       last_hess = Hess.data();
       if (it == 0 && resis_out) resis_out[0] = residual1;
     } else {
-      rc = queue_sweeps(with_spec);                 // rejected step: same system, new damping, new trial poses
+      rc = queue_sweeps(with_spec, false);          // rejected step: same system, new damping, new trial poses (host solve, fed below)
       if (rc) return rc;
       sentinel = false;                             // the rejected trial's reduction may still be writing the buffer
+      next_sentinel = false;
     }
     // gauge rows: identity with a zero right-hand side (never written into the matrix: the solve works on the block behind them)
     for (int r = 0; r < g0; r++) { JacT[r] = 0.0; dxi[r] = 0.0; }
     for (int r = 0; r < n; r++) D[r] = r < g0 ? 1.0 : Hess[(size_t)r * n + r];
     for (int r = 0; r < mr; r++) { rhs[r] = -JacT[r + g0]; work[r] = u * D[r + g0]; }
     bool solved = prepared || vxh::band_schur_prepare(Aw, n, work.data(), rhs.data(), sets.Y.data(), ny, sets.bw, sets.X.data(), nx, sets.xlo.data(), bs);
-    if (solved) vxh::band_schur_finish(Aw, n, work.data(), rhs.data(), sets.Y.data(), ny, sets.bw, sets.X.data(), nx, dxi.data() + g0, bs);
+    if (dev_this) {
+      // the pose part of the step comes from the device (it has been solving while the host added the LiDAR blocks to its copy);
+      // the launch never waits, so its end is the back-stop of this poll
+      // Complete when every one of its 18W slots has replaced the NaN the host put there before the launch -- like the residual
+      // partials and the reduced system, and for the same reason: writes of a kernel to host memory are not ordered among themselves,
+      // so a "done" word written last proves nothing about the words before it (a first version polled the sequence number the
+      // solve writes behind its results: one call in ~1000 read a stale entry).
+      const volatile double* lo = f->h_liout;
+      auto complete = [&]() { for (int k = 0; k < 18 * W; k++) if (!(lo[k] == lo[k])) return false; return true; };
+      bool got = false;
+      for (;;) {
+        if (complete()) { got = true; break; }
+        const hipError_t q = hipEventQuery(f->li_ev);
+        if (q == hipSuccess) { got = complete(); break; }
+        if (q != hipErrorNotReady) VX_HIP(f, q);
+      }
+      if (!got) return fail(f, VXBA_ERR_STATE, "li: the in-launch pose solve did not deliver its step (NaN in the reduced system?)");
+      std::atomic_thread_fence(std::memory_order_acquire);
+      double xs[6 * VXBA_MAX_WIN];
+      for (int p = 0; p < nx; p++) xs[p] = lo[6 + p];
+      vxh::band_schur_finish_y(sets.Y.data(), ny, sets.bw, sets.X.data(), nx, xs, dxi.data() + g0, bs);
+    } else if (solved) vxh::band_schur_finish(Aw, n, work.data(), rhs.data(), sets.Y.data(), ny, sets.bw, sets.X.data(), nx, dxi.data() + g0, bs);
     else {                                          // a band pivot was not positive: the reference's dense pivoted LDL^T on the whole system
       A.resize((size_t)n * n);
       std::memcpy(A.data(), Hess.data(), sizeof(double) * n * n);
@@ -435,8 +537,9 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
       vxh::right_multiply_exp(s, d, t);
       for (int k = 0; k < 12; k++) t[9 + k] = s[9 + k] + d[3 + k];
       for (int k = 0; k < 3; k++) t[21 + k] = with_g ? x_temp[21 + k] : s[21 + k];
+      if (dev_this) std::memcpy(t, f->h_liout + 6 * W + 12 * j, sizeof(double) * 12);   // the poses the residual sweep is evaluating, bit for bit
     }
-    feed(x_temp.data());                            // the queued residual sweep takes off
+    if (!dev_this) feed(x_temp.data());             // the queued residual sweep takes off
     for (int j = 0; j < W - 1; j++) vxi::imu_update_state(imus + (size_t)vxi::IMU_LEN * j, &dxi[(size_t)vxi::DIM * j]);
     double q1 = 0.0;
     for (int r = 0; r < n; r++) q1 += dxi[r] * (u * D[r] * dxi[r] - JacT[r]);
@@ -488,7 +591,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
     if (accepted) {
       std::memcpy(states, x_temp.data(), sizeof(double) * SL * W);
       is_calc_hess = true;
-      if (with_spec) { imu_ready = true; imu_res_next = r_imu; sys_queued = true; cur ^= 1; }
+      if (with_spec) { imu_ready = true; imu_res_next = r_imu; sys_queued = true; cur ^= 1; if (dev_solve) { sentinel = next_sentinel; next_sentinel = false; } }
     } else {
       is_calc_hess = false;
       for (int j = 0; j < W - 1; j++) vxi::imu_rollback(imus + (size_t)vxi::IMU_LEN * j);

@@ -89,7 +89,7 @@ struct vxba_factor {
     }
   } li;
   vxh::BandSchurWork li_bs;
-  int opt[VXBA_OPT_COUNT] = {1, 1, 1, 0, 64, 0, 1, 1};   // vxba_set_option; initial values may come from the environment (see vxba.h)
+  int opt[VXBA_OPT_COUNT] = {1, 1, 1, 0, 64, 0, 1, 1, 1};   // vxba_set_option; initial values may come from the environment (see vxba.h)
   vxw::WideStore wstore;         // wide windows: the clusters, compressed rows over the observed (voxel, frame) entries (no cluster planes)
   vxw::WideIndex wide;           // wide windows: incidence structure (entries, entry pairs per Hessian block), rebuilt after a push
   bool wide_dirty = true;
@@ -104,6 +104,12 @@ struct vxba_factor {
   hipEvent_t li_ev2 = nullptr;   // ... and the end of a Hessian sweep + reduction queued ahead (queued-sweeps mode: the stream never drains)
   double* h_feed = nullptr;      // mapped host memory through which the LI shells hand the trial poses to a residual sweep that is already queued: [seq | 12 W poses]
   double* zc_feed = nullptr;
+  double* h_packed2 = nullptr;   // second mapped buffer for the reduced systems of the LI shell's device-solve mode (consecutive systems alternate: the device never waits
+  double* zc_packed2 = nullptr;  // for the host there, so the next reduction must not land in the buffer the host is still reading)
+  double* h_lirec = nullptr;     // mapped host memory: the reduced pose system of a LiDAR-inertial step for the in-launch solve [u | poses | e | E] (vxba_solve4.hpp)
+  double* zc_lirec = nullptr;
+  double* h_liout = nullptr;     // mapped host memory: that solve's answer [dx 6W | trial poses 12W | seq]
+  double* zc_liout = nullptr;
   hipEvent_t li_ev = nullptr;    // marks the end of the residual sweep when a speculative Hessian sweep is queued behind it (LI host shells)
   bool solve_timed_out = false;  // the last damping_iter failed because voxel workgroups gave up waiting for the in-launch solve
   int fused_fallbacks = 0;       // times a call was transparently re-run with the solve as its own launch

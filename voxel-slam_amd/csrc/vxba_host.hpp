@@ -287,6 +287,30 @@ __attribute__((always_inline)) inline void band_schur_finish_impl(const double* 
   }
   for (int a = 0; a < ny; a++) x[Y[a]] = ws.yb[a];
 }
+// The second half of `finish` alone: given the solution xs of the dense part (X order) -- the LiDAR-inertial shells take it from the
+// device, which solves the reduced pose system itself (vxba_solve4.hpp) -- scatter it and substitute the banded unknowns back:
+// y = L^-T (L^-1 b_Y - W x).  After a successful `prepare` on the same system.
+inline void band_schur_finish_y(const int* Y, int ny, int bw, const int* X, int nx, const double* xs, double* x, BandSchurWork& ws) {
+  const int ld = bw + 1;
+  const int nc = band_schur_stride(nx);
+  double* L = ws.L.data();
+  auto Lat = [&](int a, int c) -> double& { return L[(size_t)a * ld + (c - (a - bw))]; };
+  for (int p = 0; p < nx; p++) x[X[p]] = xs[p];
+  ws.yb.resize(ny);
+  for (int a = 0; a < ny; a++) {
+    const double* wa = ws.Wm.data() + (size_t)a * nc;
+    double sacc = ws.wb[a];
+    for (int q = 0; q < ws.qmax[a]; q++) sacc -= wa[q] * xs[q];
+    ws.yb[a] = sacc;
+  }
+  for (int a = ny - 1; a >= 0; a--) {
+    const double ya = ws.yb[a] / Lat(a, a);
+    ws.yb[a] = ya;
+    const int c0 = a - bw > 0 ? a - bw : 0;
+    for (int k = c0; k < a; k++) ws.yb[k] -= Lat(a, k) * ya;
+  }
+  for (int a = 0; a < ny; a++) x[Y[a]] = ws.yb[a];
+}
 #if defined(__x86_64__)
 __attribute__((target("avx2,fma"))) inline bool band_schur_prepare_avx2(const double* A, int lda, const double* dadd, const double* b, const int* Y, int ny, int bw,
                                                                         const int* X, int nx, const int* xlo, BandSchurWork& ws) {

@@ -97,7 +97,12 @@ int k2_voxels_per_block(int nvox, int cus);
 // host_feed (with fused_seq != 0): workgroup 0 does not solve; it waits until the host has written fused_seq to host_feed[0] (mapped host
 // memory) and copies the 12W trial poses behind it into ctl[c].xt -- the LiDAR-inertial shells queue the sweep before their own solve is done.
 int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, int c, unsigned fused_seq, int head, int end, double* d_partial,
-                       int voxels_per_block, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const double* host_feed = nullptr);
+                       int voxels_per_block, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const double* host_feed = nullptr,
+                       const double* li_rec = nullptr, double* li_out = nullptr);
+// li_rec / li_out (with fused_seq != 0, host_feed == nullptr): workgroup 0 solves the LiDAR-inertial shells' REDUCED pose system -- li_rec (mapped host memory,
+// complete before the launch) = [u | current poses 12W | e 6W | E (6W)^2 column-major], see vxba_solve4.hpp -- and writes [dx 6W | trial poses 12W | seq] to li_out.
+inline int li_rec_doubles(int W) { return 1 + 12 * W + 6 * W + 36 * W * W; }
+inline int li_out_doubles(int W) { return 6 * W + 12 * W + 1; }
 // Deterministic sum of n partials into d_out[0].
 void launch_sum_partials(const double* d_partial, int n, double* d_out, hipStream_t s);
 // Derive aux (gap scales) from eigval for voxels [head,end) (after a caller-seeded cache).

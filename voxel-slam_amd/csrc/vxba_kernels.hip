@@ -185,7 +185,8 @@ constexpr int k2_lds_doubles() { return S4<W>::DOUBLES > K2_WAVES * 12 * W ? S4<
 // mixed-precision configuration): half the bytes of the sweep's dominant stream and half the registers of the load phase.
 template <int W, bool DBG = false, bool F32 = false>
 __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c, unsigned seq, int head, int end,
-                                                                 int VPB_arg, double* __restrict__ partial, const double* host_feed, int head_start) {
+                                                                 int VPB_arg, double* __restrict__ partial, const double* host_feed, int head_start,
+                                                                 const double* li_rec, double* li_out) {
   const int VPB = VPB_arg & 0xffff;
   __shared__ __attribute__((aligned(16))) double k2_lds[k2_lds_doubles<W>()];
   // LM mode: trial poses of ctl[c]; nothing to do once the loop is done
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(FactorView fv, 
         if (!fed) { if (lane == 0) st->error = 2; return; }
         for (int k = lane; k < 12 * W; k += 64) __hip_atomic_store(&st->ctl[c].xt[k], hf[1 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        lm_solve_body4<W, DBG>(st, c, k2_lds);
+        lm_solve_body4<W, DBG>(st, c, k2_lds, li_rec, li_out, seq);    // li_rec: the LiDAR-inertial shells' reduced pose system (vxba_solve4.hpp)
         if (wave != 0) return;
       }
 #if VXBA_PUBLISH_FENCE
@@ -955,7 +956,7 @@ void launch_mfma_probe(const double* dA, const double* dB, double* dD, hipStream
 // workgroup so that every CU owns the same number of voxels (49 instead of 64 at cfg2, 4 workgroups on every CU): 20.0 us instead of
 // 18.0 -- the partly filled waves cost more than the ragged last round.  VXBA_OPT_K2_VOXELS_PER_BLOCK keeps the experiment reproducible.
 int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, int c, unsigned fused_seq, int head, int end, double* d_partial,
-                       int voxels_per_block, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, const double* host_feed) {
+                       int voxels_per_block, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, const double* host_feed, const double* li_rec, double* li_out) {
   const int vpb0 = voxels_per_block & 0xffff;
   const int vpb = (vpb0 >= 32 && vpb0 <= 64) ? vpb0 : 64;
   const int vpb_arg = vpb | (voxels_per_block & 0x10000);   // bit 16: the voxel workgroups do not wait for the in-launch solve (test hook)
@@ -970,13 +971,13 @@ int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, 
   if (fv.cl32) {   // f32 re-centred cluster rows (the caller built them: vxba_capi.hip, residual_view)
     if (ev_start) {
       VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false, true>), g, b, 0, s, ev_start, ev_stop, 0, fv, poses, st, c, seq, head, end, vpb_arg,
-                                                  d_partial, host_feed, head_start));
-    } else { VXK_DISPATCH_W(fv.W, (k2_residual_kernel<WW, false, true><<<g, b, 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed, head_start))); }
-  } else if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<g, b, 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed, head_start)); }
+                                                  d_partial, host_feed, head_start, li_rec, li_out));
+    } else { VXK_DISPATCH_W(fv.W, (k2_residual_kernel<WW, false, true><<<g, b, 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed, head_start, li_rec, li_out))); }
+  } else if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<g, b, 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed, head_start, li_rec, li_out)); }
   else if (ev_start) {
     VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), g, b, 0, s, ev_start, ev_stop, 0, fv, poses, st, c, seq, head, end, vpb_arg, d_partial,
-                                                host_feed, head_start));
-  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<g, b, 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed, head_start)); }
+                                                host_feed, head_start, li_rec, li_out));
+  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<g, b, 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed, head_start, li_rec, li_out)); }
   return nblocks;
 }
 

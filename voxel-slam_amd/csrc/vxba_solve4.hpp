@@ -99,8 +99,21 @@ __device__ __forceinline__ void s4_apply(const double* lds, int t, int b, int la
 // Called by all S4_THREADS threads of one workgroup.  lds: S4<W>::DOUBLES doubles, 16-byte aligned.  Reads the gauge-fixed system the
 // Hessian sweep's reduction left in the LM state, writes dxi, the trial poses (agent-scope stores: the residual sweep's workgroups
 // read them right after the sequence number) and q1.  Returns with the trial-pose stores of wave 0 issued but not waited for.
+//
+// LiDAR-inertial shells (li_rec != nullptr): the same solve on the REDUCED pose system of LI_BA_Optimizer's 15W-dimensional step
+// (voxel_map.hpp:597).  Velocities and biases only meet the poses through the IMU factors, so the host eliminates them while the
+// Hessian sweep is still running (band Cholesky + Schur complement, vxba_host.hpp) and leaves in mapped host memory what that
+// elimination adds to the pose block -- li_rec = [u | current poses 12W | e (6W) | E (6W x 6W, column-major)], E = IMU pose terms
+// (damped) - W^T W, e = the matching right-hand-side terms -- before this launch is issued; here
+//   (H_lidar + u diag(H_lidar) + E) dx = -J_lidar + e
+// is solved on the device, the trial poses go to the residual sweep's workgroups as in the LiDAR-only loop, and dx + the trial poses
+// + `seq` (last) go to li_out in mapped host memory, from which the host substitutes the velocity / bias unknowns back.  No kernel
+// waits for the host and the 6W-dimensional system never crosses PCIe on the critical path.
+constexpr int li_rec_len(int W) { return 1 + 12 * W + 6 * W + 36 * W * W; }
+constexpr int li_out_len(int W) { return 6 * W + 12 * W + 1; }
 template <int W, bool DBG>
-__device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds) {
+__device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds, const double* __restrict__ li_rec = nullptr, double* __restrict__ li_out = nullptr,
+                                               unsigned li_seq = 0) {
   using C = S4<W>;
   LMCtl& ctl = st->ctl[c];
   if (ctl.done) return;
@@ -109,7 +122,10 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   dbg_stamp(DBG && wave == 0, 4000, 0);
   dbg_stamp(DBG && wave == 0, 4000, 1);
-  const double u = ctl.u;
+  const double u = li_rec ? li_rec[0] : ctl.u;
+  const double* __restrict__ li_x = li_rec ? li_rec + 1 : nullptr;
+  const double* __restrict__ li_e = li_rec ? li_rec + 1 + 12 * W : nullptr;
+  const double* __restrict__ li_E = li_rec ? li_rec + 1 + 18 * W : nullptr;
   const bool row_ok = lane < M;
   const int gi_row = row_ok ? 6 + lane : 0;     // global row of this lane
 
@@ -127,7 +143,8 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds) 
     for (int cc = 0; cc < 6; cc++) {
       const int col = 6 + 6 * bb + cc;
       const double h = st->Hwork[(size_t)col * n + gi_row];
-      a0[q][cc] = row_ok ? ((col == gi_row) ? h + u * h : h) : 0.0;
+      const double add = li_E ? li_E[(size_t)col * n + gi_row] : 0.0;
+      a0[q][cc] = row_ok ? (((col == gi_row) ? h + u * h : h) + add) : 0.0;
     }
   }
   double hii = 0.0, gi = 0.0, rhs0 = 0.0;
@@ -137,9 +154,9 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds) 
     gi = st->Jwork[gi_row];
     const int fl = lane < W ? lane : 0;   // current pose of frame `lane`, fetched now so that its latency hides behind the factorisation
 #pragma unroll
-    for (int k = 0; k < 12; k++) xcur[k] = ctl.x[12 * fl + k];
+    for (int k = 0; k < 12; k++) xcur[k] = li_x ? li_x[12 * fl + k] : ctl.x[12 * fl + k];
   }
-  if (wave == 1 % S4_WAVES) rhs0 = row_ok ? -st->Jwork[gi_row] : 0.0;
+  if (wave == 1 % S4_WAVES) rhs0 = row_ok ? (li_e ? li_e[gi_row] : 0.0) - st->Jwork[gi_row] : 0.0;
   if (wave < B) s4_store_row(lds + C::TC + wave * S4_BLK + lane * S4_ROW, a0[0]);
   dbg_stamp(DBG && wave == 0, 4000, 2);
 
@@ -300,6 +317,20 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds) 
     for (int k = 0; k < 9; k++) __hip_atomic_store(&ctl.xt[12 * lane + k], xn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int k = 0; k < 3; k++) __hip_atomic_store(&ctl.xt[12 * lane + 9 + k], xcur[9 + k] + dl[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (li_out) {   // the host takes the trial poses from here, so that both sides evaluate at the same bits
+#pragma unroll
+      for (int k = 0; k < 9; k++) li_out[6 * W + 12 * lane + k] = xn[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) li_out[6 * W + 12 * lane + 9 + k] = xcur[9 + k] + dl[3 + k];
+    }
+  }
+  if (li_out) {
+    // the host's half of the step (velocities, biases, q1) needs dx; the sequence number goes out when everything before it has landed
+    if (row_ok) li_out[6 + lane] = x;
+    if (lane < 6) li_out[lane] = 0.0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) li_out[18 * W] = (double)li_seq;
   }
   double part = row_ok ? x * (u * hii * x - gi) : 0.0;
 #pragma unroll
