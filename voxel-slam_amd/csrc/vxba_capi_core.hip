@@ -421,14 +421,14 @@ int sweep_hess_host(vxba_factor* f, const double* Rp, int head, int end) {
   int rc = sweep_hess_device(f, Rp, nullptr, nullptr, nullptr, head, end, f->d_packed);
   if (rc) return rc;
   VX_HIP(f, hipMemcpyAsync(f->h_packed, f->d_packed, vxba_packed_len(f) * sizeof(double), hipMemcpyDeviceToHost, f->stream));
-  VX_HIP(f, hipStreamSynchronize(f->stream));
+  VX_HIP(f, stream_wait_spin(f->stream));
   return VXBA_OK;
 }
 int sweep_residual_host(vxba_factor* f, const double* Rp, int head, int end, double* residual) {
   int rc = sweep_residual_device(f, Rp, nullptr, 0, head, end, f->d_scalar);
   if (rc) return rc;
   VX_HIP(f, hipMemcpyAsync(f->h_scalar, f->d_scalar, sizeof(double), hipMemcpyDeviceToHost, f->stream));
-  VX_HIP(f, hipStreamSynchronize(f->stream));
+  VX_HIP(f, stream_wait_spin(f->stream));
   *residual = f->h_scalar[0];
   return VXBA_OK;
 }

@@ -3,6 +3,8 @@
 #pragma once
 #include "vxba_factor.hpp"
 
+#include <chrono>
+
 namespace vxc {
 
 using vxk::FactorView;
@@ -18,6 +20,18 @@ int ensure_capacity(vxba_factor* f, int n_total);
 int check_range(vxba_factor* f, int head, int end);
 // the f32 re-centred copy of clusters [v0, ...) is stale after a write to the f64 planes
 inline void clusters_written(vxba_factor* f, int v0) { if (v0 < f->cl32_built) f->cl32_built = v0; }
+
+// Completion of the factor's stream at the end of a device-resident LM call: a 3-iteration damping_iter is ~0.2 ms of queued kernels, and
+// waking up from hipStreamSynchronize costs ~25 us of that (measured in the map and LI shells), so the call polls -- for a bounded time:
+// a stream that is still busy after ~4 ms (a long bench loop, a wide window) is handed to the blocking wait, which does not burn a core.
+inline hipError_t stream_wait_spin(hipStream_t s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned k = 0;; k++) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q != hipErrorNotReady) return q;
+    if ((k & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(4)) return hipStreamSynchronize(s);
+  }
+}
 
 // ---- profiling: hipEvents on the factor's stream around a launch, drained by vxba_get_kernel_times / vxba_get_collective_time ----
 hipEvent_t get_event(vxba_factor* f);

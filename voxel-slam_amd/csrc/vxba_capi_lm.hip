@@ -127,7 +127,7 @@ static int damping_iter_impl(vxba_factor* f, double* Rp, int max_iter, double* h
   if (pend.pending) { vxk::launch_lm_update(f->d_lm, c, pend, x0, W, f->stream); c ^= 1; }
   VX_HIP(f, hipGetLastError());
   VX_HIP(f, hipMemcpyAsync(f->h_lm, f->d_lm, sizeof(vxk::LMState), hipMemcpyDeviceToHost, f->stream));
-  VX_HIP(f, hipStreamSynchronize(f->stream));
+  VX_HIP(f, stream_wait_spin(f->stream));
   if (f->h_lm->error) {
     f->solve_timed_out = true;
     return fail(f, VXBA_ERR_STATE, "damping_iter: a residual-sweep workgroup timed out waiting for the in-launch solve");
