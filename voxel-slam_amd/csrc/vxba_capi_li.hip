@@ -257,6 +257,12 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
   const int g0 = with_g ? 6 : vxi::DIM;          // gauge rows at the head: frame 0's pose (gravity variant) or all of frame 0
   const int mr = n - g0;
   const auto t_call0 = std::chrono::steady_clock::now();
+  // development aid (VXBA_LI_TIMING=1): where the host time of a call goes, phase by phase, summed over its iterations
+  static const bool timing = [] { const char* e = getenv("VXBA_LI_TIMING"); return e && e[0] == '1'; }();
+  enum { T_IMU, T_PREP, T_REC, T_LAUNCH, T_WAITH, T_HPLUS, T_WAITDX, T_STEP, T_IMUN, T_WAITR, T_DECIDE, T_SETUP, T_INV, T_N };
+  double tph[T_N] = {0};
+  auto tick = [&]() { return std::chrono::steady_clock::now(); };
+  auto lap = [&](int k, std::chrono::steady_clock::time_point& t) { if (timing) { const auto n2 = tick(); tph[k] += std::chrono::duration<double, std::micro>(n2 - t).count(); t = n2; } };
   if (!f->h_feed) {
     VX_HIP(f, hipHostMalloc((void**)&f->h_feed, sizeof(double) * (12 * VXBA_MAX_WIN + 8), hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: the GPU must see the host's write WHILE the kernel runs
     VX_HIP(f, hipHostGetDevicePointer((void**)&f->zc_feed, f->h_feed, 0));
@@ -367,7 +373,10 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
   std::vector<double>&HessN = f->li.HessN, &JacTN = f->li.JacTN, &cov_invs = f->li.cov_invs;
   std::vector<int>& perm = f->li.perm;
   std::vector<double> x_temp(states, states + (size_t)SL * W);
+  auto tsetup = t_call0;
+  lap(T_SETUP, tsetup);
   if (!vxi::li_invert_covariances(W, imus, cov_invs.data())) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
+  lap(T_INV, tsetup);
   vxh::BandSchurWork& bs = f->li_bs;
   const vxh::LiIndexSets sets = vxh::li_index_sets(W - 1, with_g ? 9 : 0, with_g ? 3 : 0);
   const int ny = (int)sets.Y.size(), nx = (int)sets.X.size();
@@ -389,6 +398,8 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
       const int np = (f->V + (f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] & 0xffff) - 1) / (f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] & 0xffff);
       for (int k = 0; k < np; k++) f->h_partial2[k] = std::numeric_limits<double>::quiet_NaN();
       std::atomic_thread_fence(std::memory_order_release);
+      // (measured and rejected: the record brought over by one DMA on a side stream + event instead of the solve reading it out of mapped host memory --
+      // the three extra API calls cost 10 us per iteration, the solve was no faster: the PCIe reads are not what it waits for)
       nparts = vxk::launch_k2_residual(fv, pa0, f->d_lm, 0, seq, 0, f->V, f->zc_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK], f->stream, nullptr, nullptr, nullptr,
                                        f->zc_lirec, f->zc_liout);
     } else {
@@ -426,6 +437,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
     f->li_reduction_in_flight = with_spec;          // cleared again when the next iteration consumes (or supersedes) it
     bool prepared = false;
     bool dev_this = false;                          // this iteration's pose system is solved inside the residual-sweep launch
+    auto tp = tick();
     if (is_calc_hess) {
       if (imu_ready) { Hess.swap(HessN); JacT.swap(JacTN); imu_res = imu_res_next; imu_ready = false; }
       else {
@@ -435,12 +447,14 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
         if (!ok) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
       }
       Aw = &Hess[(size_t)g0 * n + g0];
+      lap(T_IMU, tp);
       if (dev_solve) {
         // band half first (velocities / biases: IMU terms only; the GPU is still sweeping), then what it adds to the pose block goes into the
         // record the in-launch solve reads, and only then the launches: the residual sweep's workgroup 0 solves, nobody waits for the host
         for (int y : sets.Y) { rhs[y] = -JacT[y + g0]; work[y] = u * Hess[(size_t)(y + g0) * n + y + g0]; }
         prepared = vxh::band_schur_prepare(Aw, n, work.data(), rhs.data(), sets.Y.data(), ny, sets.bw, sets.X.data(), nx, sets.xlo.data(), bs);
         dev_this = prepared && nx == m6 - 6;
+        lap(T_PREP, tp);
         if (dev_this) {
           double* rec = f->h_lirec;
           rec[0] = u;
@@ -461,8 +475,10 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
           std::atomic_thread_fence(std::memory_order_release);
           if (with_spec) { nan_fill_buf(hpk[cur ^ 1]); next_sentinel = true; }   // nothing can be writing that buffer: its last system was consumed an iteration ago
         }
+        lap(T_REC, tp);
         rc = queue_sweeps(with_spec, dev_this);
         if (rc) return rc;
+        lap(T_LAUNCH, tp);
       } else {
         rc = queue_sweeps(with_spec, false);          // behind the system's sweep: starts when that is done, then waits for the poses
         if (rc) return rc;
@@ -478,6 +494,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
         if (rc) return rc;
       }
       sys_queued = false;
+      lap(T_WAITH, tp);
       vxi::li_hess_plus(W, Hess.data(), JacT.data(), hpk[cur], hpk[cur] + (size_t)m6 * m6, n);
       residual1 = imu_res + hpk[cur][(size_t)m6 * m6 + m6];
       if (with_spec && !dev_this) {                // consumed; the speculative reduction sits behind a residual sweep that has no poses yet
@@ -497,6 +514,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
     for (int r = 0; r < n; r++) D[r] = r < g0 ? 1.0 : Hess[(size_t)r * n + r];
     for (int r = 0; r < mr; r++) { rhs[r] = -JacT[r + g0]; work[r] = u * D[r + g0]; }
     bool solved = prepared || vxh::band_schur_prepare(Aw, n, work.data(), rhs.data(), sets.Y.data(), ny, sets.bw, sets.X.data(), nx, sets.xlo.data(), bs);
+    lap(T_HPLUS, tp);
     if (dev_this) {
       // the pose part of the step comes from the device (it has been solving while the host added the LiDAR blocks to its copy);
       // the launch never waits, so its end is the back-stop of this poll
@@ -515,6 +533,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
       }
       if (!got) return fail(f, VXBA_ERR_STATE, "li: the in-launch pose solve did not deliver its step (NaN in the reduced system?)");
       std::atomic_thread_fence(std::memory_order_acquire);
+      lap(T_WAITDX, tp);
       double xs[6 * VXBA_MAX_WIN];
       for (int p = 0; p < nx; p++) xs[p] = lo[6 + p];
       vxh::band_schur_finish_y(sets.Y.data(), ny, sets.bw, sets.X.data(), nx, xs, dxi.data() + g0, bs);
@@ -544,6 +563,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
     double q1 = 0.0;
     for (int r = 0; r < n; r++) q1 += dxi[r] * (u * D[r] * dxi[r] - JacT[r]);
     q1 *= 0.5;
+    lap(T_STEP, tp);
     // under the residual sweep: the IMU half of the NEXT system at the trial state (its residual falls out of the same evaluation)
     double r_imu;
     if (with_spec) {
@@ -553,6 +573,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
     } else {
       r_imu = vxi::li_add_imu_blocks(W, x_temp.data(), imus, imu_coef, false, nullptr, nullptr, wk, &ok, false, cov_invs.data());
     }
+    lap(T_IMUN, tp);
     // The residual is complete when every block partial has replaced the NaN the host put there (fine-grained host memory: a partial
     // arrives when its workgroup is done, a few microseconds before the kernel's end-of-launch release and the event behind it would
     // be seen); the event is only the back-stop for a sweep that gave up.
@@ -566,6 +587,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
       if (q == hipSuccess) break;
       if (q != hipErrorNotReady) VX_HIP(f, q);
     }
+    lap(T_WAITR, tp);
     const double r_lidar = host_sum_partials(f->h_partial2, nparts);
     if (!(r_lidar == r_lidar)) {
       int nan_cnt = 0, first_nan = -1;
@@ -601,12 +623,17 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
       o[0] = residual1; o[1] = residual2; o[2] = u_used; o[3] = v_used; o[4] = q; o[5] = q1; o[6] = accepted; o[7] = recomputed;
     }
     nt++;
+    lap(T_DECIDE, tp);
     if (std::fabs((residual1 - residual2) / residual1) < 1e-6) break;
   }
   if (resis_out) resis_out[1] = residual2;
   if (n_trace) *n_trace = nt;
   if (hess_out && last_hess) std::memcpy(hess_out, last_hess, sizeof(double) * n * n);
   f->li_last_call_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call0).count();
+  if (timing)
+    std::fprintf(stderr, "[vxba li queued] %d iterations, %.0f us: imu blocks %.0f | band half %.0f | record %.0f | launches %.0f | wait H %.0f | hess_plus+D %.0f | wait dx %.0f | "
+                 "step/trial %.0f | imu blocks(next) %.0f | wait residual %.0f | decide %.0f | setup + first launches %.0f | covariance inverses %.0f\n", nt, f->li_last_call_us, tph[T_IMU], tph[T_PREP], tph[T_REC], tph[T_LAUNCH],
+                 tph[T_WAITH], tph[T_HPLUS], tph[T_WAITDX], tph[T_STEP], tph[T_IMUN], tph[T_WAITR], tph[T_DECIDE], tph[T_SETUP], tph[T_INV]);
   return VXBA_OK;
 }
 

@@ -143,7 +143,7 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds, 
     for (int cc = 0; cc < 6; cc++) {
       const int col = 6 + 6 * bb + cc;
       const double h = st->Hwork[(size_t)col * n + gi_row];
-      const double add = li_E ? li_E[(size_t)col * n + gi_row] : 0.0;
+      const double add = (li_E && gi_row >= 6 + 6 * bb) ? li_E[(size_t)col * n + gi_row] : 0.0;   // rows above a block column are never consumed: half the PCIe reads
       a0[q][cc] = row_ok ? (((col == gi_row) ? h + u * h : h) + add) : 0.0;
     }
   }
