@@ -442,39 +442,45 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   stg.coe = 0.0;
   if (wave != 0 && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
 
-  // LDS behind the two tile buffers: both pose candidates (raw C-ABI layout: R column-major | p per frame) and what the LM
+  // LDS behind the two tile buffers: the poses to linearise at (raw C-ABI layout: R column-major | p per frame) and what the LM
   // decision needs.  Only wave 0 of a workgroup talks to the control block: with all eight waves doing it (round 1 had every
   // wave decide for itself) a CU opened the kernel with ~500 load instructions in its queue and the first phase A finished
   // 14k cycles in (profiles/r02_v2); the other seven waves now only request their first batch and clear the tiles meanwhile.
-  double* poseA = lds + 2 * C::BUF;       // current / kernel-argument / trial poses (what `xa_src` selects)
-  double* poseB = poseA + 12 * W;         // trial poses (pending decision)
-  double* lmv = poseB + 12 * W;           // [0] done, [1] calc_hess, [2] bench_mode, [3] residual1, [4] residual2
+  //
+  // The accept / reject decision of the pending step (pend.pending == 1) is SPECULATED: a rejected step means this sweep has nothing to
+  // do, an accepted one means it linearises at the trial poses -- so every workgroup starts phase A of its first step at the trial
+  // poses as soon as those are in LDS, wave 0 adds up residual2 meanwhile, and the decision is taken behind the first step's barrier
+  // (a rejected step costs one phase A instead of none; the common, accepted one no longer waits for a chain of dependent global
+  // reads with the whole chip's first batches queued around it: the first barrier came 11.3k cycles into the kernel, profiles/r03_v3).
+  double* poseA = lds + 2 * C::BUF;       // the poses `xa_src` selects
+  double* lmv = poseA + 24 * W;           // [0] done, [1] calc_hess, [2] bench_mode, [3] residual1, [4] residual2 (written after the first barrier)
   double* stage_lds = lmv + 8 + wave * K3Stage<W>::WAVE_DOUBLES;   // this wave's corner for redistributing the plane parameters
+  LMResidual2Loads r2_loads;
+  const bool decide_here = st && pend.pending == 1;
   if (wave == 0) {
-    const int fl = lane < W ? lane : 0;
+    // The poses are one contiguous run of 12 W doubles, copied as such: ceil(12 W / 64) load instructions of consecutive lanes = 15 cache
+    // lines per workgroup.  (One lane per frame and twelve strided loads each were 120 separate requests per workgroup for the same 15
+    // lines -- from all 32 workgroups of an XCD at once, into the one or two L2 channels that hold them: ~4k cycles of queueing, which is
+    // why barrier 0 of this kernel came 6k cycles in, profiles/r03_v3.)
+    const double* __restrict__ xa_src = poses.Rp;
+    double v_done = 0.0, v_calc = 0.0, v_bench = 0.0, r1 = 0.0;
     if (st) {
       const LMCtl& in = st->ctl[c_in];
-      // pending: 0 none (linearise at in.x), 1 decide here, 2 / 3 sharded speculative loop: no decision here -- linearise at the
-      // trial poses (2) or at the kernel-argument poses (3, first sweep of a solve / window), skip only when the loop is done
-      const double* __restrict__ xa_src = ((pend.pending == 1 && pend.restart) || pend.pending == 3) ? poses.Rp : (pend.pending == 2 ? in.xt : in.x);
-      double xa[12], xb[12] = {};
-#pragma unroll
-      for (int k = 0; k < 12; k++) xa[k] = xa_src[12 * fl + k];
-      if (pend.pending == 1) {
-#pragma unroll
-        for (int k = 0; k < 12; k++) xb[k] = in.xt[12 * fl + k];
-      }
-      const double v_done = in.done, v_calc = in.calc_hess, v_bench = in.bench_mode, r1 = in.residual1;
-      const double r2 = (pend.pending == 1 && !in.done) ? lm_residual2(pend) : 0.0;
-      if (lane < W) {
-#pragma unroll
-        for (int k = 0; k < 12; k++) { poseA[12 * lane + k] = xa[k]; poseB[12 * lane + k] = xb[k]; }
-      }
-      if (lane == 0) { lmv[0] = v_done; lmv[1] = v_calc; lmv[2] = v_bench; lmv[3] = r1; lmv[4] = r2; }
-    } else if (lane < W) {
-#pragma unroll
-      for (int k = 0; k < 12; k++) poseA[12 * lane + k] = poses.Rp[12 * lane + k];
+      // pending: 0 none (linearise at in.x), 1 decide here (see above: trial poses, or the kernel-argument poses when a new window
+      // starts), 2 / 3 sharded speculative loop: no decision here -- linearise at the trial poses (2) or at the kernel-argument poses
+      // (3, first sweep of a solve / window), skip only when the loop is done
+      xa_src = ((pend.pending == 1 && pend.restart) || pend.pending == 3) ? poses.Rp : (pend.pending ? in.xt : in.x);
+      v_done = in.done; v_calc = in.calc_hess; v_bench = in.bench_mode; r1 = in.residual1;
     }
+    constexpr int NPL = (12 * W + 63) / 64;
+    double xa[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; k++) xa[k] = (64 * k + lane < 12 * W) ? xa_src[64 * k + lane] : 0.0;
+    if (decide_here) lm_residual2_issue(pend, r2_loads);   // in flight across the barrier below
+#pragma unroll
+    for (int k = 0; k < NPL; k++)
+      if (64 * k + lane < 12 * W) poseA[64 * k + lane] = xa[k];
+    if (st && lane == 0) { lmv[0] = v_done; lmv[1] = v_calc; lmv[2] = v_bench; lmv[3] = r1; }
     if (cnt > 0) { k3_load_clusters(pl, bs, lane, e.c); k3_load_params<W>(pl, head, end, bs, lane, stg); }
   }
   // both tile buffers start as zeros: padding columns (6W .. NCOL) are never written
@@ -484,29 +490,37 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   }
   __syncthreads();
   dbg_stamp(DBG, gw, 1);
-  // every thread takes the same decision from the same five numbers (the last workgroup also works out the damping update and
-  // persists the control block for the kernels that follow)
-  bool use_b = false;
+  bool undecided = false;
   if (st) {
-    const bool in_done = lmv[0] != 0.0, in_calc = lmv[1] != 0.0, bench = lmv[2] != 0.0;
-    const double r1 = lmv[3], r2 = lmv[4];
+    const bool in_done = lmv[0] != 0.0, in_calc = lmv[1] != 0.0;
     if (pend.pending >= 2) {
       if (in_done) return;
     } else if (pend.pending) {
       if (in_done) { if (blockIdx.x == gridDim.x - 1) lm_carry(st, c_in, W); return; }
-      const bool accept = (r1 - r2) > 0;
-      const bool done = !bench && fabs((r1 - r2) / r1) < 1e-6;
-      if (blockIdx.x == gridDim.x - 1) {
-        const LMDecision d = lm_decide(st->ctl[c_in], r2, pend.restart);
-        lm_persist(st, c_in, d, pend.restart, poses, W);
+      undecided = true;
+      if (wave == 0) {
+        const double r2 = lm_residual2_finish(pend, r2_loads);
+        if (lane == 0) lmv[4] = r2;
       }
-      if (done || !(accept || pend.restart)) return;
-      use_b = accept && !pend.restart;
     } else {
       if (in_done || !in_calc) return;
     }
   }
-  const double* pose = (use_b ? poseB : poseA) + 12 * fi;
+  // Behind the first barrier after the one above: every thread takes the same decision from the same numbers (the last workgroup also
+  // works out the damping update and persists the control block for the kernels that follow).  True: nothing (more) to do here.
+  auto decide = [&]() __attribute__((always_inline)) -> bool {
+    undecided = false;
+    const bool bench = lmv[2] != 0.0;
+    const double r1 = lmv[3], r2 = lmv[4];
+    const bool accept = (r1 - r2) > 0;
+    const bool done = !bench && fabs((r1 - r2) / r1) < 1e-6;
+    if (blockIdx.x == gridDim.x - 1) {
+      const LMDecision d = lm_decide(st->ctl[c_in], r2, pend.restart);
+      lm_persist(st, c_in, d, pend.restart, poses, W);
+    }
+    return done || !(accept || pend.restart);
+  };
+  const double* pose = poseA + 12 * fi;
   v4d acc[C::TPW];
 #pragma unroll
   for (int t = 0; t < C::TPW; t++) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -562,7 +576,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   const int k0_full = kq * C::KPW;
   // AF (experiment, -DK3_OPPOSITE=1): the second wave of every SIMD (w >= 4) takes phase A BEFORE phase M inside an iteration -- the
   // two touch different tile buffers, so the order is free -- to put one wave's VALU work under the other's MFMAs.
-  auto full_steps = [&](auto af_tag) __attribute__((always_inline)) {
+  auto full_steps = [&](auto af_tag) __attribute__((always_inline)) -> bool {
     constexpr bool AF = decltype(af_tag)::value;
     for (int s = 0; s <= nfull; s++) {
       auto phase_m = [&]() __attribute__((always_inline)) {
@@ -583,13 +597,14 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
       if (s == nfull) break;
       __syncthreads();
       if (s < 6) dbg_stamp(DBG, gw, 8 + s);
+      if (undecided && decide()) return true;
     }
+    return false;
   };
 #if defined(K3_OPPOSITE) && K3_OPPOSITE
-  if ((wave >> 2) & 1) full_steps(std::true_type{});
-  else full_steps(std::false_type{});
+  if ((wave >> 2) & 1 ? full_steps(std::true_type{}) : full_steps(std::false_type{})) return;
 #else
-  full_steps(std::false_type{});
+  if (full_steps(std::false_type{})) return;
 #endif
   if (nrag > 0) {
     // ragged last step: nrag < 8 batches.  Only ceil(nrag R / 4) K-steps exist; they are re-split over the K ranges, and the first
@@ -602,6 +617,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
     }
     __syncthreads();
     if (nfull < 6) dbg_stamp(DBG, gw, 8 + nfull);
+    if (undecided && decide()) return;
     const int ks = (nrag * C::R + 3) >> 2;
     const int k0 = (kq * ks) / C::KSPLIT, k1 = ((kq + 1) * ks) / C::KSPLIT;
     if (MIXED) k3_mfma_phase_f32<W, false>(reinterpret_cast<const float*>(lds) + bo, set, k0, k1 - k0, lrow, lcol, af);
@@ -622,6 +638,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   double* park_d = lds;                                                   // [512 lanes][DS] linear accumulators
   double* park_t = E::ONE_PHASE ? lds + (size_t)K3_BLOCK * E::DS : lds;   // [8 waves][TPW][256] MFMA accumulators
   __syncthreads();  // every wave is done with the tiles
+  if (undecided && decide()) return;   // a workgroup without a batch: first barrier since the prologue's
   // (1) per-frame linear accumulators: every lane parks the ones in use, then one thread per (frame, slot) sums the 8*NV lanes
 #pragma unroll
   for (int k = 0; k < E::NUSED; k++) park_d[(wave * 64 + lane) * E::DS + k] = dacc[E::slot(k)];

@@ -119,6 +119,49 @@ __device__ __forceinline__ double lm_residual2(const LMPending& pend) {
   for (int m = 1; m < 64; m <<= 1) total += __shfl_xor(total, m, 64);
   return total;
 }
+// The same sum in two halves, for a caller that wants the loads in flight long before it needs the value (the Hessian sweep's prologue):
+// lm_residual2_issue requests the all-reduced scalar or the first 1024 partials, lm_residual2_finish adds them up -- and any further
+// chunks -- in exactly the order lm_residual2 uses, so both return the same bits.
+struct LMResidual2Loads { double v[16]; };
+__device__ __forceinline__ void lm_residual2_issue(const LMPending& pend, LMResidual2Loads& L) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 16; k++) L.v[k] = 0.0;
+  if (pend.d_scalar) { L.v[0] = pend.d_scalar[0]; return; }
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int i = 64 * k + lane;
+    if (i < pend.nparts) L.v[k] = pend.partial[i];
+  }
+}
+__device__ __forceinline__ double lm_residual2_finish(const LMPending& pend, LMResidual2Loads& L) {
+  if (pend.d_scalar) return L.v[0];
+  const int lane = threadIdx.x & 63;
+  const double* __restrict__ p = pend.partial;
+  const int n = pend.nparts;
+#pragma unroll
+  for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+    for (int k = 0; k < w; k++) L.v[k] += L.v[k + w];
+  double total = 0.0;
+  total += L.v[0];
+  for (int base = 1024; base < n; base += 1024) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int i = base + 64 * k + lane;
+      v[k] = i < n ? p[i] : 0.0;
+    }
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+      for (int k = 0; k < w; k++) v[k] += v[k + w];
+    total += v[0];
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) total += __shfl_xor(total, m, 64);
+  return total;
+}
 // Loop already left: the control block moves to the other slot unchanged (one workgroup).
 __device__ __forceinline__ void lm_carry(LMState* st, int c_in, int W) {
   LMCtl& out = st->ctl[c_in ^ 1];
