@@ -49,7 +49,11 @@ if which == "k2":
 else:
     # Hessian sweep (vxba_k3.hpp): 8 waves per workgroup; stamps 0 start, 1 poses decided, 8+s after the barrier of step s (s < 6),
     # 3 step loop left, 6 partial written
-    f.acc_evaluate2(sc.poses_init)
+    if which == "k3lm":   # the sweep as the LM loop runs it: second iteration, accept/reject decision of the first in its prologue
+        from voxel_slam_amd.vxba import Lidar_BA_Optimizer
+        Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=2)
+    else:
+        f.acc_evaluate2(sc.poses_init)
     full = vxba.debug_stamps(2048).astype(np.int64)
     order = [0, 1, 8, 9, 10, 11, 12, 13, 3, 6]
     names = ["start", "poses decided", "barrier 0 (phase A of step 0 done)", "barrier 1", "barrier 2", "barrier 3", "barrier 4", "barrier 5", "loop left", "end"]
@@ -61,6 +65,18 @@ else:
         col = st[:, k]; ok = col > 0
         if ok.any():
             print("%-36s min %7.2f  median %7.2f  max %7.2f us   (%d waves)" % (nm, (col[ok].min() - t0) / 100.0, (np.median(col[ok]) - t0) / 100.0, (col[ok].max() - t0) / 100.0, int(ok.sum())))
+    # prologue, per wave and relative to the wave's own start (the cycle counters of the eight XCDs have different origins, so only
+    # differences inside a workgroup mean anything): 2 first requests issued, 5 poses in LDS (wave 0), 4 tiles cleared, 1 barrier passed
+    fl = full[live]
+    wv = np.arange(fl.shape[0]) % 8
+    wg_start = fl[:, 0].reshape(-1, 8).min(axis=1).repeat(8)
+    for nm, slot in (("wave start", 0), ("first requests issued", 2), ("poses in LDS (wave 0)", 5), ("tiles cleared", 4), ("prologue barrier passed", 1), ("barrier 0 passed", 8)):
+        col = fl[:, slot] - wg_start
+        ok = fl[:, slot] > 0
+        if ok.any():
+            print("since the workgroup's first wave started: %-26s median %6.0f  p10 %6.0f  p90 %6.0f   waves 0-3 median %6.0f  waves 4-7 median %6.0f" % (
+                nm, np.median(col[ok]), np.percentile(col[ok], 10), np.percentile(col[ok], 90),
+                np.median(col[ok & (wv < 4)]) if (ok & (wv < 4)).any() else -1, np.median(col[ok & (wv >= 4)]) if (ok & (wv >= 4)).any() else -1))
     per = np.diff(st[:, 2:7], axis=1) / 100.0
     okp = (st[:, 2:7] > 0).all(axis=1)
     if okp.any():

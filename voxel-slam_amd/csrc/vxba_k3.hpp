@@ -406,9 +406,17 @@ __device__ __forceinline__ void k3_sum_linear(const double* park_d, double* out,
   }
 }
 
+// Kernel arguments: the first 14 dwords are PRELOADED into SGPRs when a wave is launched (-mllvm -amdgpu-kernarg-preload-count=14 in the
+// Makefile; gfx950 has 16 user SGPRs, two hold the kernarg pointer) -- everything a wave needs to request its first batch and the poses,
+// so that those requests do not wait for a scalar load of the argument block first (a cold miss: the block was written by the host a few
+// microseconds earlier).  Structs are not preloaded and stop the sequence, hence the flat list; what is not urgent follows as before.
+//   pend_flags = pending | restart << 8, nwg = nwg (otherwise a load from the hidden arguments)
 template <int W, bool DBG = false, bool MIXED = false>
-__global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c_in, LMPending pend, int head,
-                                                              int end, double* __restrict__ partial) {
+__global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __restrict__ clb, const double* __restrict__ cache_planes, const double* __restrict__ coe_plane,
+                                                              LMState* __restrict__ st, int VS, int head, int end, int c_in, int pend_flags, int nwg,
+                                                              PoseArg poses, LMPending pend, double* __restrict__ partial) {
+  const int pending = pend_flags & 0xff, restart = pend_flags >> 8;
+
   using C = K3Cfg<W>;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // two tile buffers; reused by the epilogue
   const int tid = threadIdx.x, lane = tid & 63;
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
 
   // this workgroup's run of batches (absolute: batch b = voxels [b NV, (b+1) NV), so the batch-major copy does not depend on `head`)
   const int b0 = head / C::NV, b1 = (end - 1) / C::NV;
-  const int nb_all = b1 - b0 + 1, G = gridDim.x;
+  const int nb_all = b1 - b0 + 1, G = nwg;
   const int q = nb_all / G, rem = nb_all % G;
   const int g = blockIdx.x;
   const int cnt = q + (g < rem ? 1 : 0);
@@ -435,33 +443,43 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
   // decision arrived 7.6k cycles into the kernel with every other wave waiting at the barrier.
   K3Entry e;
   e.ok = false;
-  const K3Planes pl = k3_planes(fv);
+  K3Planes pl;
+  pl.cache = k3_rsrc(cache_planes);
+  pl.coe = k3_rsrc(coe_plane);
+  pl.clb = clb;
+  pl.vs8 = (unsigned)VS * 8u;
   K3Stage<W> stg;
 #pragma unroll
   for (int q = 0; q < K3Stage<W>::Q; q++) stg.v[q] = 0.0;
   stg.coe = 0.0;
-  if (wave != 0 && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
-
-  // LDS behind the two tile buffers: the poses to linearise at (raw C-ABI layout: R column-major | p per frame) and what the LM
-  // decision needs.  Only wave 0 of a workgroup talks to the control block: with all eight waves doing it (round 1 had every
-  // wave decide for itself) a CU opened the kernel with ~500 load instructions in its queue and the first phase A finished
-  // 14k cycles in (profiles/r02_v2); the other seven waves now only request their first batch and clear the tiles meanwhile.
+  // The prologue, by wave:
+  //   wave 0    fetches the poses to linearise at and the four control scalars, requests the residual-sweep partials whose sum
+  //             (residual2) decides the pending step, then its first batch; the poses go to LDS once ALL of that has landed;
+  //   waves 1-3 request their first batch;
+  //   waves 4-7 request their first batch after the barrier below.
+  // First batches in two halves: a CU takes in ~10 B per clock, so eight first batches (48 KB) land together and both waves of a SIMD
+  // then run phase A back to back with nothing under it; with four, the first wave of each SIMD works while the second wave's rows are
+  // on their way.  The barrier is released by wave 0, i.e. about when the first four batches have landed -- measured on the same box
+  // (K3 at cfg2, us): this arrangement 26.8; all eight batches before the barrier 27.3; poses and partials on waves 4 / 5 (barrier 1.5k
+  // cycles earlier) 27.4; partials requested after the barrier 27.2-27.5; second half delayed by a further 512 / 1024 / 2048 cycles
+  // 27.2 / 27.4 / 28.2.
   //
-  // The accept / reject decision of the pending step (pend.pending == 1) is SPECULATED: a rejected step means this sweep has nothing to
+  // The accept / reject decision of the pending step (pending == 1) is SPECULATED: a rejected step means this sweep has nothing to
   // do, an accepted one means it linearises at the trial poses -- so every workgroup starts phase A of its first step at the trial
-  // poses as soon as those are in LDS, wave 0 adds up residual2 meanwhile, and the decision is taken behind the first step's barrier
-  // (a rejected step costs one phase A instead of none; the common, accepted one no longer waits for a chain of dependent global
-  // reads with the whole chip's first batches queued around it: the first barrier came 11.3k cycles into the kernel, profiles/r03_v3).
+  // poses as soon as those are in LDS, wave 0 adds up residual2 behind the barrier, and the decision is taken behind the first step's
+  // barrier (a rejected step costs one phase A instead of none; the common, accepted one no longer waits for the sum).
+  constexpr int K3_FIRST_WAVES = 4;
+  if (wave != 0 && wave < K3_FIRST_WAVES && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
+
+  // LDS behind the two tile buffers: the poses (raw C-ABI layout: R column-major | p per frame) and what the LM decision needs
   double* poseA = lds + 2 * C::BUF;       // the poses `xa_src` selects
-  double* lmv = poseA + 24 * W;           // [0] done, [1] calc_hess, [2] bench_mode, [3] residual1, [4] residual2 (written after the first barrier)
+  double* lmv = poseA + 24 * W;           // [0] done, [1] calc_hess, [2] bench_mode, [3] residual1, [4] residual2 (written after the barrier)
   double* stage_lds = lmv + 8 + wave * K3Stage<W>::WAVE_DOUBLES;   // this wave's corner for redistributing the plane parameters
   LMResidual2Loads r2_loads;
-  const bool decide_here = st && pend.pending == 1;
+  const bool decide_here = st && pending == 1;
   if (wave == 0) {
     // The poses are one contiguous run of 12 W doubles, copied as such: ceil(12 W / 64) load instructions of consecutive lanes = 15 cache
-    // lines per workgroup.  (One lane per frame and twelve strided loads each were 120 separate requests per workgroup for the same 15
-    // lines -- from all 32 workgroups of an XCD at once, into the one or two L2 channels that hold them: ~4k cycles of queueing, which is
-    // why barrier 0 of this kernel came 6k cycles in, profiles/r03_v3.)
+    // lines per workgroup (one lane per frame and twelve strided loads each were 120 requests per workgroup for the same 15 lines).
     const double* __restrict__ xa_src = poses.Rp;
     double v_done = 0.0, v_calc = 0.0, v_bench = 0.0, r1 = 0.0;
     if (st) {
@@ -469,42 +487,55 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
       // pending: 0 none (linearise at in.x), 1 decide here (see above: trial poses, or the kernel-argument poses when a new window
       // starts), 2 / 3 sharded speculative loop: no decision here -- linearise at the trial poses (2) or at the kernel-argument poses
       // (3, first sweep of a solve / window), skip only when the loop is done
-      xa_src = ((pend.pending == 1 && pend.restart) || pend.pending == 3) ? poses.Rp : (pend.pending ? in.xt : in.x);
+      xa_src = ((pending == 1 && restart) || pending == 3) ? poses.Rp : (pending ? in.xt : in.x);
       v_done = in.done; v_calc = in.calc_hess; v_bench = in.bench_mode; r1 = in.residual1;
     }
     constexpr int NPL = (12 * W + 63) / 64;
     double xa[NPL];
 #pragma unroll
     for (int k = 0; k < NPL; k++) xa[k] = (64 * k + lane < 12 * W) ? xa_src[64 * k + lane] : 0.0;
-    if (decide_here) lm_residual2_issue(pend, r2_loads);   // in flight across the barrier below
+    if (decide_here) lm_residual2_issue(pend, r2_loads);   // in flight across the barrier
+    if (cnt > 0) { k3_load_clusters(pl, bs, lane, e.c); k3_load_params<W>(pl, head, end, bs, lane, stg); }
 #pragma unroll
     for (int k = 0; k < NPL; k++)
       if (64 * k + lane < 12 * W) poseA[64 * k + lane] = xa[k];
     if (st && lane == 0) { lmv[0] = v_done; lmv[1] = v_calc; lmv[2] = v_bench; lmv[3] = r1; }
-    if (cnt > 0) { k3_load_clusters(pl, bs, lane, e.c); k3_load_params<W>(pl, head, end, bs, lane, stg); }
+    dbg_stamp(DBG, gw, 5);   // poses in LDS
   }
-  // both tile buffers start as zeros: padding columns (6W .. NCOL) are never written
+  dbg_stamp(DBG, gw, 2);     // first requests issued
+  // Only the padding columns 6W .. NCOL of the two tile buffers have to start as zeros: phase A writes columns 0 .. 6W of every row of
+  // a step (and the three spare columns of the z rows), the ragged step clears the rows it rounds up to, nothing else is read.
+  // (Clearing both buffers whole -- 144 KB through a 128 B / clock LDS -- kept every wave 2.5k cycles from the barrier below.)
   {
-    constexpr int NZ = MIXED ? C::BUF : 2 * C::BUF;   // doubles
-    for (int k = tid; k < NZ; k += K3_BLOCK) lds[k] = 0.0;
+    constexpr int PADC = C::NCOL - 6 * W;
+    if constexpr (PADC > 0) {
+      for (int k = tid; k < 2 * C::ROWS * PADC; k += K3_BLOCK) {
+        const int b = k / (C::ROWS * PADC), rr = (k / PADC) % C::ROWS, cc = 6 * W + k % PADC;
+        const int o = b * C::BUF + C::at(rr, cc);
+        if (MIXED) reinterpret_cast<float*>(lds)[o] = 0.0f;
+        else lds[o] = 0.0;
+      }
+    }
   }
+  dbg_stamp(DBG, gw, 4);     // tiles cleared
   __syncthreads();
   dbg_stamp(DBG, gw, 1);
   bool undecided = false;
   if (st) {
     const bool in_done = lmv[0] != 0.0, in_calc = lmv[1] != 0.0;
-    if (pend.pending >= 2) {
+    if (pending >= 2) {
       if (in_done) return;
-    } else if (pend.pending) {
-      if (in_done) { if (blockIdx.x == gridDim.x - 1) lm_carry(st, c_in, W); return; }
+    } else if (pending) {
+      if (in_done) { if (blockIdx.x == nwg - 1) lm_carry(st, c_in, W); return; }
       undecided = true;
-      if (wave == 0) {
-        const double r2 = lm_residual2_finish(pend, r2_loads);
-        if (lane == 0) lmv[4] = r2;
-      }
     } else {
       if (in_done || !in_calc) return;
     }
+  }
+  if (wave >= K3_FIRST_WAVES && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
+  if (wave == 0 && undecided) {
+    const double r2 = lm_residual2_finish(pend, r2_loads);
+    if (lane == 0) lmv[4] = r2;
   }
   // Behind the first barrier after the one above: every thread takes the same decision from the same numbers (the last workgroup also
   // works out the damping update and persists the control block for the kernels that follow).  True: nothing (more) to do here.
@@ -514,11 +545,11 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(FactorView fv, Pos
     const double r1 = lmv[3], r2 = lmv[4];
     const bool accept = (r1 - r2) > 0;
     const bool done = !bench && fabs((r1 - r2) / r1) < 1e-6;
-    if (blockIdx.x == gridDim.x - 1) {
-      const LMDecision d = lm_decide(st->ctl[c_in], r2, pend.restart);
-      lm_persist(st, c_in, d, pend.restart, poses, W);
+    if (blockIdx.x == nwg - 1) {
+      const LMDecision d = lm_decide(st->ctl[c_in], r2, restart);
+      lm_persist(st, c_in, d, restart, poses, W);
     }
-    return done || !(accept || pend.restart);
+    return done || !(accept || restart);
   };
   const double* pose = poseA + 12 * fi;
   v4d acc[C::TPW];

@@ -227,9 +227,11 @@ constexpr int k2_lds_doubles() { return S4<W>::DOUBLES > K2_WAVES * 12 * W ? S4<
 // F32: the cluster rows come from the f32 re-centred copy (fv.cl32, vxm::cluster_to_centred_f32; VXBA_OPT_F32_CLUSTERS, meant for the
 // mixed-precision configuration): half the bytes of the sweep's dominant stream and half the registers of the load phase.
 template <int W, bool DBG = false, bool F32 = false>
-__global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(FactorView fv, PoseArg poses, LMState* __restrict__ st, int c, unsigned seq, int head, int end,
-                                                                 int VPB_arg, double* __restrict__ partial, const double* host_feed, int head_start,
-                                                                 const double* li_rec, double* li_out) {
+// Argument order: the first 14 dwords are preloaded into SGPRs at wave launch (see k3_hessian_kernel) -- what the solve workgroup needs to
+// start (it is the critical path of a fused launch) and what a voxel wave needs for its done-check and its place in the sweep.
+__global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __restrict__ st, int c, unsigned seq, const double* li_rec, double* li_out,
+                                                                 const double* host_feed, int head, int end, int VPB_arg, int head_start,
+                                                                 double* __restrict__ partial, FactorView fv, PoseArg poses) {
   const int VPB = VPB_arg & 0xffff;
   __shared__ __attribute__((aligned(16))) double k2_lds[k2_lds_doubles<W>()];
   // LM mode: trial poses of ctl[c]; nothing to do once the loop is done
@@ -1013,14 +1015,12 @@ int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, 
   const dim3 g(grid), b(K2_THREADS);
   if (fv.cl32) {   // f32 re-centred cluster rows (the caller built them: vxba_capi.hip, residual_view)
     if (ev_start) {
-      VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false, true>), g, b, 0, s, ev_start, ev_stop, 0, fv, poses, st, c, seq, head, end, vpb_arg,
-                                                  d_partial, host_feed, head_start, li_rec, li_out));
-    } else { VXK_DISPATCH_W(fv.W, (k2_residual_kernel<WW, false, true><<<g, b, 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed, head_start, li_rec, li_out))); }
-  } else if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<g, b, 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed, head_start, li_rec, li_out)); }
+      VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false, true>), g, b, 0, s, ev_start, ev_stop, 0, st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses));
+    } else { VXK_DISPATCH_W(fv.W, (k2_residual_kernel<WW, false, true><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses))); }
+  } else if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses)); }
   else if (ev_start) {
-    VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), g, b, 0, s, ev_start, ev_stop, 0, fv, poses, st, c, seq, head, end, vpb_arg, d_partial,
-                                                host_feed, head_start, li_rec, li_out));
-  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<g, b, 0, s>>>(fv, poses, st, c, seq, head, end, vpb_arg, d_partial, host_feed, head_start, li_rec, li_out)); }
+    VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), g, b, 0, s, ev_start, ev_stop, 0, st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses));
+  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses)); }
   return nblocks;
 }
 
@@ -1064,6 +1064,7 @@ int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, LMState* st
   }
   static int dbg = -1;   // development knob: VXBA_DBG=1 runs the s_memtime-instrumented instantiation
   if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
+#define K3_ARGS fv.clb, fv.eigval, fv.coe, st, (int)fv.VS, head, end, c_in, (pend.pending & 0xff) | (pend.restart << 8), nblocks, poses, pend, d_partial
   VXK_DISPATCH_W(fv.W, {
     constexpr size_t lds_bytes = k3_lds_bytes<WW>();
     static_assert(lds_bytes <= 160 * 1024, "K3 tile buffers exceed the CU's LDS");
@@ -1081,18 +1082,17 @@ int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, LMState* st
     }
     if (mixed) {
       if (ev_start)
-        hipExtLaunchKernelGGL((k3_hessian_kernel<WW, false, true>), dim3(nblocks), dim3(K3_BLOCK), (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, fv, poses, st, c_in,
-                              pend, head, end, d_partial);
-      else k3_hessian_kernel<WW, false, true><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, st, c_in, pend, head, end, d_partial);
+        hipExtLaunchKernelGGL((k3_hessian_kernel<WW, false, true>), dim3(nblocks), dim3(K3_BLOCK), (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, K3_ARGS);
+      else k3_hessian_kernel<WW, false, true><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(K3_ARGS);
     } else if (dbg) {
-      k3_hessian_kernel<WW, true><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, st, c_in, pend, head, end, d_partial);
+      k3_hessian_kernel<WW, true><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(K3_ARGS);
     } else {
       if (ev_start)
-        hipExtLaunchKernelGGL((k3_hessian_kernel<WW, false>), dim3(nblocks), dim3(K3_BLOCK), (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, fv, poses, st, c_in, pend, head,
-                              end, d_partial);
-      else k3_hessian_kernel<WW, false><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(fv, poses, st, c_in, pend, head, end, d_partial);
+        hipExtLaunchKernelGGL((k3_hessian_kernel<WW, false>), dim3(nblocks), dim3(K3_BLOCK), (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, K3_ARGS);
+      else k3_hessian_kernel<WW, false><<<dim3(nblocks), dim3(K3_BLOCK), lds_bytes, s>>>(K3_ARGS);
     }
   });
+#undef K3_ARGS
   return nblocks;
 }
 
