@@ -594,7 +594,8 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
     }
     // next batch of this wave: in flight during the barrier and the whole of phase M.  Measured and rejected (round 2, same
     // box): the cluster rows requested a step earlier into a second register set (no change: the steps do not wait for loads);
-    // the two waves of a SIMD taking phase M / phase A in opposite order (13.2k instead of 11.8k cycles per step).
+    // the two waves of a SIMD taking phase M / phase A in opposite order (13.2k instead of 11.8k cycles per step).  Round 3: s_setprio
+    // for one of a SIMD's two waves during phase A (either one: K3 26.6 -> 27.2 us), for phase M (no change).
     if (nb >= 0) {
       k3_load_clusters(pl, nb, lane, e.c);
       k3_load_params<W>(pl, head, end, nb, lane, stg);
