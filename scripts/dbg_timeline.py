@@ -31,6 +31,15 @@ if which == "fused":
     k2 = k2[k2[:, 0] > 0]
     t0 = min(sol[0], k2[:, 0].min())
     print("solver stamps (cycles since kernel start): start %d, done-checked %d, loaded %d, factored %d, back-substituted %d, end %d" % tuple(sol - t0))
+    ent = full[:n, 6]; ent = ent[ent > 0]
+    if ent.size:   # kernel entry stamps (instrumented build): everything below relative to the first wave to enter
+        t0 = min(t0, ent.min(), full[4000, 30] if full[4000, 30] > 0 else t0)
+        fin = full[:n, 7]; fin = fin[fin > 0]
+        print("kernel entry: voxel waves min %d median %d; solve workgroup %d" % (ent.min() - t0, np.median(ent) - t0, full[4000, 30] - t0))
+        if fin.size:
+            print("in-launch Hessian reduction: share written + counted, waves min %d median %d max %d; solve workgroup released at %d" % (
+                fin.min() - t0, np.median(fin) - t0, fin.max() - t0, full[4000, 31] - t0))
+        print("solver stamps again, since kernel entry: start %d, loaded %d, factored %d, back-substituted %d, end %d" % tuple((sol - t0)[[0, 2, 3, 4, 5]]))
     names = ["start", "loads landed", "cov done", "eig done", "end", "flag seen"]
     for k in (0, 5, 1, 2, 3, 4):
         print("voxel waves %-13s min %7d  median %7d  max %7d" % (names[k], k2[:, k].min() - t0, np.median(k2[:, k]) - t0, k2[:, k].max() - t0))

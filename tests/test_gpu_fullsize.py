@@ -28,8 +28,10 @@ def checkers():
     return out
 
 
-def run_case(vx, sc, iters, precision="f64", tol=1e-7, need_reject=False, thd=8):
+def run_case(vx, sc, iters, precision="f64", tol=1e-7, need_reject=False, thd=8, options=None):
     fg = vx.LidarFactor(sc.win_size)
+    for name, value in (options or {}).items():
+        fg.set_option(name, value)
     fg.push_points(sc.n_voxels, sc.points_body, sc.cell_ptr, sc.fix, sc.coe)        # K1 on the device, as the bench does
     clusters = fg.read_clusters()
     fg.evaluate_only_residual(sc.poses_init)
@@ -88,6 +90,21 @@ def test_cfg2_window_with_rejected_steps_matches_the_checkers(vx):
     relative-change test stops it; checked on the oracle, nine iterations.)"""
     sc = synth.make_config("cfg2", rot_sigma_deg=0.2, trans_sigma=0.03)
     run_case(vx, sc, iters=8, need_reject=True)
+
+
+@pytest.mark.parametrize("rejects", [False, True])
+def test_cfg2_lm_with_the_hessian_reduction_inside_the_residual_sweep_launch(vx, rejects):
+    """VXBA_OPT_FINALIZE_IN_LAUNCH (off by default: measured no faster): the reduction of the Hessian sweep's workgroup
+    partials as a phase of the residual-sweep launch -- voxel workgroups reduce and write the LM state with written-through stores, the
+    solve workgroup waits for their flags instead of for a kernel boundary.  Same checkers, same tolerances; the window with rejected
+    steps exercises launches in which the phase must NOT run (Hessian not recomputed)."""
+    sc = synth.make_config("cfg2", rot_sigma_deg=0.2, trans_sigma=0.03) if rejects else synth.make_config("cfg2")
+    got = run_case(vx, sc, iters=8 if rejects else 3, need_reject=rejects, options={"finalize_in_launch": 1})
+    ref = run_case(vx, sc, iters=8 if rejects else 3, need_reject=rejects, options={"finalize_in_launch": 0})
+    assert np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:])
+    et, er = synth.pose_errors(got["poses"], ref["poses"])
+    assert et < 1e-10 and er < 1e-10, (et, er)
+    assert np.allclose(got["hess"], ref["hess"], rtol=1e-10, atol=1e-10 * np.abs(ref["hess"]).max())
 
 
 def test_cfg4_single_gpu_lm_matches_the_oracle(vx):

@@ -89,7 +89,7 @@ struct vxba_factor {
     }
   } li;
   vxh::BandSchurWork li_bs;
-  int opt[VXBA_OPT_COUNT] = {1, 1, 1, 0, 64, 0, 1, 1, 1};   // vxba_set_option; initial values may come from the environment (see vxba.h)
+  int opt[VXBA_OPT_COUNT] = {1, 1, 1, 0, 64, 0, 1, 1, 1, 0};   // vxba_set_option; initial values may come from the environment (see vxba.h)
   vxw::WideStore wstore;         // wide windows: the clusters, compressed rows over the observed (voxel, frame) entries (no cluster planes)
   vxw::WideIndex wide;           // wide windows: incidence structure (entries, entry pairs per Hessian block), rebuilt after a push
   bool wide_dirty = true;
@@ -165,8 +165,12 @@ int ensure_exchange(vxba_factor* f);
 int ensure_partials3(vxba_factor* f);
 void fill_poses(const vxba_factor* f, const double* Rp, vxk::PoseArg& pa);
 // asynchronous sweeps on f->stream, results in device (or mapped host) memory
+// defer_fin != nullptr: the reduction of the sweep's workgroup partials is NOT launched; *defer_fin describes it for the residual sweep that
+// follows (sweep_residual_device(..., fin), in-launch reduction -- vxk::FinArgs)
 int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c, const vxk::LMPending* pend, int head, int end, double* d_out,
-                      const double* cache_src = nullptr);
+                      const double* cache_src = nullptr, vxk::FinArgs* defer_fin = nullptr);
 int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int c, int head, int end, double* d_out, int* nparts_out = nullptr,
-                          unsigned fused_seq = 0, bool partials_to_host = false);
+                          unsigned fused_seq = 0, bool partials_to_host = false, const vxk::FinArgs* fin = nullptr);
+// the LM loop may fold the Hessian reduction into the residual-sweep launch (VXBA_OPT_FINALIZE_IN_LAUNCH, in-launch solve, no collective, enough voxels)
+bool finalize_in_launch(const vxba_factor* f);
 }  // namespace vxc

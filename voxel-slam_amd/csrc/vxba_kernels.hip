@@ -198,6 +198,235 @@ __device__ __forceinline__ void lm_persist(LMState* st, int c_in, const LMDecisi
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3 -- Hessian / gradient sweep: vxba_k3.hpp (work mapping, tile layout and the history of the design are described there).
+// H = -S + blockdiag(D) is assembled by k3_finalize_kernel below.
+// ------------------------------------------------------------------------------------------------
+#include "vxba_k3.hpp"
+
+// Cross-workgroup reduction + assembly.  One lane per PARTIAL element (consecutive lanes -> consecutive
+// addresses inside every workgroup partial: coalesced), 64 elements x 16 partial-slices per workgroup, fixed
+// summation order.  An MFMA tile element (I,J,row,col) becomes Hess(r,c) = -S(r,c) [+ D term when r and c belong
+// to the same frame] and is mirrored to Hess(c,r) (voxel_map.hpp:237-239); the linear elements become JacT and
+// the residual.  Output buffer: Hess (6W)^2 column-major | JacT 6W | residual.
+__device__ __forceinline__ int sym6_index(int a, int b) { return a == 0 ? b : (a == 1 ? 2 + b : 5); }  // a <= b
+
+// Where element e of a workgroup partial goes: a tile element -> Hessian entry (r, c) [+ a second stream off1: the block-diagonal D
+// element that lands on the same entry], a linear element -> output index lin (JacT / residual), or nothing.
+struct FinMap { int r, c, lin, off1; };
+template <int W>
+__device__ __forceinline__ FinMap fin_map(int e) {
+  using C = K3Cfg<W>;
+  constexpr int n = 6 * W;
+  constexpr int NTILE = C::NTP * 256;
+  constexpr int PLEN = NTILE + W * DACC;
+  FinMap m;
+  m.r = -1; m.c = -1; m.lin = -1; m.off1 = -1;
+  if (e < NTILE) {
+    const int t = e >> 8, j = (e >> 6) & 3, l = e & 63;
+    // tile t accumulates S[16 rowtile + row][16 coltile + col] (vxba_k3.hpp: K3Cfg::rowtile / coltile; tiles of the second set
+    // may be LOWER tiles); f64 MFMA C/D map: row = lane/16 + 4*reg, col = lane%16
+    const int rt = C::rowtile(t), ct = C::coltile(t);
+    int r = 16 * rt + (l >> 4) + 4 * j;
+    int c = 16 * ct + (l & 15);
+    if (rt > ct) { const int tmp = r; r = c; c = tmp; }  // lower tile: the same numbers, mirrored
+    if (r >= n || c >= n || r > c) { r = -1; c = -1; }   // padding columns; lower half of a diagonal tile is a duplicate
+    else if (r / 6 == c / 6) {
+      const int i = r / 6, a = r % 6, b = c % 6;         // a <= b
+      if (C::SPARE && b >= 3) {
+        // Drt / Dtt were accumulated by the matrix cores: S[r][6W + (b - 3)] (vxba_k3.hpp, K3Cfg::SPARE)
+        m.off1 = C::elem_offset(r, n + (b - 3));
+      } else {
+        int d;
+        if (b < 3) d = 6 + sym6_index(a, b);
+        else if (a < 3) d = 12 + 3 * a + (b - 3);
+        else d = 21 + sym6_index(a - 3, b - 3);
+        m.off1 = NTILE + i * DACC + d;
+      }
+    }
+    m.r = r; m.c = c;
+  } else if (e < PLEN) {
+    const int q = e - NTILE, i = q / DACC, d = q % DACC;
+    if (d < 6) m.lin = n * n + 6 * i + d;
+    else if (d == 27 && i == 0) m.lin = n * n + n;
+  }
+  return m;
+}
+// The reduced element (t0: its own stream, t1: the D stream) into the packed buffer [Hess (6W)^2 column-major | JacT 6W | residual] and,
+// with write_state, into the LM state the solve reads.  COH: the state goes out as written-through agent-scope stores (the solve runs in
+// the same launch, on another workgroup -- k2_residual_kernel).
+template <int W, bool COH>
+__device__ __forceinline__ void fin_emit(const FinMap& m, double t0, double t1, LMState* __restrict__ gate, int cb, int write_state, double* __restrict__ packed) {
+  constexpr int n = 6 * W;
+  auto put = [](double* p, double v) __attribute__((always_inline)) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+  };
+  if (m.lin >= 0) {
+    packed[m.lin] = t0;
+    if (gate && write_state) {   // LM state: gauge-fixed gradient (voxel_map.hpp:400), residual1 (:388)
+      if (m.lin < n * n + n) put(&gate->Jwork[m.lin - n * n], (m.lin - n * n < 6) ? 0.0 : t0);
+      else { gate->ctl[cb].residual1 = t0; if (gate->ctl[cb].iter == 0) gate->ctl[cb].resis[0] = t0; }
+    }
+  } else {
+    const int r = m.r, c = m.c;
+    const double h = t1 - t0;
+    packed[(size_t)c * n + r] = h;
+    packed[(size_t)r * n + c] = h;
+    if (gate && write_state) {   // LM state: *hess = Hess before the gauge fix (:391) and the gauge-fixed working copy (:397-400)
+      gate->hess_out[(size_t)c * n + r] = h;
+      gate->hess_out[(size_t)r * n + c] = h;
+      const double hw = (r < 6 || c < 6) ? ((r == c) ? 1.0 : 0.0) : h;
+      put(&gate->Hwork[(size_t)c * n + r], hw);
+      put(&gate->Hwork[(size_t)r * n + c], hw);
+    }
+  }
+}
+
+#ifndef FIN_EL_
+#define FIN_EL_ 16
+#endif
+constexpr int FIN_EL = FIN_EL_, FIN_SL = 64;   // FIN_EL * FIN_SL threads (<= 1024)
+template <int W>
+__global__ __launch_bounds__(FIN_EL * FIN_SL) void k3_finalize_kernel(const double* __restrict__ partial, int nblocks, LMState* __restrict__ gate, int cb,
+                                                           int write_state, double* __restrict__ packed, int force, const double* __restrict__ k2_partial,
+                                                           int k2_nparts) {
+  using C = K3Cfg<W>;
+  // LM flags: requested now (vector loads: lane-dependent zero offset), tested after the partials are in flight
+  const int zoff = threadIdx.x >> 30;
+  int f_done = gate ? (&gate->ctl[cb].done)[zoff] : 0;
+  int f_calc = gate ? (&gate->ctl[cb].calc_hess)[zoff] : 1;
+  constexpr int n = 6 * W;
+  constexpr int NTILE = C::NTP * 256;
+  constexpr int PLEN = NTILE + W * DACC;
+  // FIN_EL elements x FIN_SL slices of the workgroup partials per block: many small blocks, because one CU cannot pull
+  // more than ~10 B/clk from L2/HBM -- 64 elements per block (45 blocks) left the reduction bound by 45 CUs' load paths
+  __shared__ double red0[FIN_SL][FIN_EL];
+  __shared__ double red1[FIN_SL][FIN_EL];
+  __shared__ double mid0[8][FIN_EL];
+  __shared__ double mid1[8][FIN_EL];
+  const int el = threadIdx.x % FIN_EL, slice = threadIdx.x / FIN_EL;
+  const int e = blockIdx.x * FIN_EL + el;
+  const FinMap m = fin_map<W>(e);
+  const int off1 = m.off1;
+  const bool need0 = (m.r >= 0) || (m.lin >= 0);
+  double s0 = 0.0, s1 = 0.0;
+  bool flags_checked = false;
+  if (need0) {
+    // the loads of 4 partials are issued together (independent), added in fixed order
+    int b = slice;
+    for (; b + FIN_SL * 3 < nblocks; b += FIN_SL * 4) {
+      double v0[4], v1[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double* pb = partial + (size_t)(b + FIN_SL * q) * PLEN;
+        v0[q] = pb[e];
+        v1[q] = off1 >= 0 ? pb[off1] : 0.0;
+      }
+      if (!flags_checked) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(f_done), "+v"(f_calc));
+        flags_checked = true;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) { s0 += v0[q]; s1 += v1[q]; }
+    }
+    for (; b < nblocks; b += FIN_SL) {
+      const double* pb = partial + (size_t)b * PLEN;
+      s0 += pb[e];
+      if (off1 >= 0) s1 += pb[off1];
+    }
+  }
+  if (!flags_checked) asm volatile("" : "+v"(f_done), "+v"(f_calc));
+  if (f_done || (!f_calc && !force)) return;   // uniform over the grid
+  // sharded speculative loop: the residual of the trial state (the residual sweep's wave partials) rides in the slot behind the
+  // packed buffer, so that ONE all-reduce carries the system and the number the accept/reject test needs
+  if (k2_partial && blockIdx.x == gridDim.x - 1) {
+    double sum = 0.0;
+    for (int k = threadIdx.x; k < k2_nparts; k += FIN_EL * FIN_SL) sum += k2_partial[k];
+    double* red = &red0[0][0];
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int m = FIN_EL * FIN_SL; m > 1; m = (m + 1) >> 1) {   // any block size: the upper half folds onto the lower
+      const int half = (m + 1) >> 1;
+      if ((int)threadIdx.x < m - half) red[threadIdx.x] += red[threadIdx.x + half];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) packed[n * n + n + 1] = red[0];
+    __syncthreads();
+  }
+  red0[slice][el] = s0;
+  red1[slice][el] = s1;
+  __syncthreads();
+  if (slice < 8) {
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < FIN_SL / 8; k++) { t0 += red0[slice * (FIN_SL / 8) + k][el]; t1 += red1[slice * (FIN_SL / 8) + k][el]; }
+    mid0[slice][el] = t0;
+    mid1[slice][el] = t1;
+  }
+  __syncthreads();
+  if (slice == 0 && need0) {
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { t0 += mid0[k][el]; t1 += mid1[k][el]; }
+    fin_emit<W, false>(m, t0, t1, gate, cb, write_state, packed);
+  }
+}
+
+// The same reduction as a PHASE of the residual-sweep launch (k2_residual_kernel, fused with the damped solve): the voxel workgroups
+// -- idle until the solve publishes the trial poses -- reduce the Hessian sweep's workgroup partials first, 16 elements x 16 slices
+// per 256-thread workgroup and pass, and write the LM state the solve reads with written-through stores; the solve workgroup waits
+// for a count of finished workgroups instead of for a kernel boundary.  `wg` of `nwg` participating workgroups (all of them resident
+// at once: the caller bounds nwg).  lds: 2 * 256 doubles.
+constexpr int FINP_EL = 16, FINP_SL = 16;
+template <int W>
+__device__ __forceinline__ void fin_phase(const double* __restrict__ partial, int nblocks, LMState* __restrict__ st, int cb, int write_state, double* __restrict__ packed,
+                                          int wg, int nwg, double* lds) {
+  using C = K3Cfg<W>;
+  constexpr int PLEN = C::NTP * 256 + W * DACC;
+  const int el = threadIdx.x % FINP_EL, slice = threadIdx.x / FINP_EL;
+  double* red0 = lds;
+  double* red1 = lds + FINP_EL * FINP_SL;
+  for (int g = wg; g * FINP_EL < PLEN; g += nwg) {
+    const int e = g * FINP_EL + el;
+    const FinMap m = fin_map<W>(e);
+    const int off1 = m.off1;
+    const bool need0 = (m.r >= 0) || (m.lin >= 0);
+    double s0 = 0.0, s1 = 0.0;
+    if (need0) {
+      // every load of a pass goes out before the first one is used (up to 16 + 16 per thread: one round of memory latency per 256 partials;
+      // four at a time cost four rounds, and the phase 8 us instead of 3)
+      for (int base = 0; base < nblocks; base += FINP_SL * 16) {
+        double v0[16], v1[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const int b = base + slice + FINP_SL * q;
+          const double* pb = partial + (size_t)(b < nblocks ? b : 0) * PLEN;
+          v0[q] = pb[e];
+          v1[q] = off1 >= 0 ? pb[off1] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const bool in = base + slice + FINP_SL * q < nblocks;
+          s0 += in ? v0[q] : 0.0;
+          s1 += in ? v1[q] : 0.0;
+        }
+      }
+    }
+    red0[slice * FINP_EL + el] = s0;
+    red1[slice * FINP_EL + el] = s1;
+    __syncthreads();
+    if (slice == 0 && need0) {
+      double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < FINP_SL; k++) { t0 += red0[k * FINP_EL + el]; t1 += red1[k * FINP_EL + el]; }
+      fin_emit<W, true>(m, t0, t1, st, cb, write_state, packed);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2 -- residual sweep.  One lane per voxel, frames unrolled: every load is a 512 B contiguous row of a
 // frame-major plane, poses are wave-uniform (scalar loads), no cross-lane traffic until the final residual
 // reduction; the eigensolver is warm-started from the cached eigenvectors.
@@ -231,7 +460,7 @@ template <int W, bool DBG = false, bool F32 = false>
 // start (it is the critical path of a fused launch) and what a voxel wave needs for its done-check and its place in the sweep.
 __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __restrict__ st, int c, unsigned seq, const double* li_rec, double* li_out,
                                                                  const double* host_feed, int head, int end, int VPB_arg, int head_start,
-                                                                 double* __restrict__ partial, FactorView fv, PoseArg poses) {
+                                                                 double* __restrict__ partial, FinArgs fin, FactorView fv, PoseArg poses) {
   const int VPB = VPB_arg & 0xffff;
   __shared__ __attribute__((aligned(16))) double k2_lds[k2_lds_doubles<W>()];
   // LM mode: trial poses of ctl[c]; nothing to do once the loop is done
@@ -240,6 +469,9 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __rest
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   double* pose_lds = k2_lds + wave * 12 * W;
   int vb = blockIdx.x * K2_WAVES + wave;
+  if (DBG) { if (blockIdx.x == 0) dbg_stamp(wave == 0, 4000, 30); else dbg_stamp(true, vb - K2_WAVES, 6); }   // kernel entry
+  // same gate as k3_finalize_kernel: nothing to reduce when the Hessian sweep skipped itself (rejected step)
+  const bool fin_on = st && seq != 0 && fin.partial != nullptr && st->ctl[c].calc_hess != 0;
   if (st && seq != 0) {
     if (blockIdx.x == 0) {
       if (host_feed) {
@@ -257,6 +489,28 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __rest
         if (!fed) { if (lane == 0) st->error = 2; return; }
         for (int k = lane; k < 12 * W; k += 64) __hip_atomic_store(&st->ctl[c].xt[k], hf[1 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
+        if (fin_on) {
+          // the Hessian reduction is a phase of this launch (fin_phase): wait until every participating workgroup has written its share
+          // of the LM state, then look at memory afresh
+          if (wave == 0) {
+            unsigned spins = 0;
+            for (;;) {
+              bool ok = true;
+#pragma unroll
+              for (int k = 0; k < FIN_MAX_WG / 64; k++) {
+                const int i = 64 * k + lane;
+                const unsigned v = __hip_atomic_load(&st->fin_flag[i < fin.nwg ? i : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (v == seq);
+              }
+              if (__builtin_amdgcn_read_exec() == __ballot(ok)) break;
+              __builtin_amdgcn_s_sleep(2);
+              if (++spins > 4u * K2_SPIN_LIMIT) { if (lane == 0) st->error = 3; break; }   // never observed; the host reports it
+            }
+          }
+          __syncthreads();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          dbg_stamp(DBG && wave == 0, 4000, 31);
+        }
         lm_solve_body4<W, DBG>(st, c, k2_lds, li_rec, li_out, seq);    // li_rec: the LiDAR-inertial shells' reduced pose system (vxba_solve4.hpp)
         if (wave != 0) return;
       }
@@ -273,6 +527,13 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __rest
       return;
     }
     vb -= K2_WAVES;
+    if (fin_on && (int)blockIdx.x - 1 < fin.nwg) {
+      fin_phase<W>(fin.partial, fin.nblocks, st, c, fin.write_state, fin.packed, (int)blockIdx.x - 1, fin.nwg, k2_lds);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's written-through stores have been acknowledged
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(&st->fin_flag[blockIdx.x - 1], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dbg_stamp(DBG, vb, 7);   // this workgroup's share of the Hessian reduction is out
+    }
   }
   const bool fused = st && seq != 0;
   const bool spare = vb * VPB >= end - head;   // the last workgroup's spare waves: no voxels; in a fused launch they stay for the workgroup's barrier
@@ -431,151 +692,6 @@ __global__ void seed_aux_kernel(FactorView fv, int head, int end) {
   fv.aux[VS + a] = s2;
   fv.aux[2 * VS + a] = 1.0 / fv.merged[9 * VS + a];
   fv.aux[3 * VS + a] = sqrt(fv.coe[a]);
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3 -- Hessian / gradient sweep: vxba_k3.hpp (work mapping, tile layout and the history of the design are described there).
-// H = -S + blockdiag(D) is assembled by k3_finalize_kernel below.
-// ------------------------------------------------------------------------------------------------
-#include "vxba_k3.hpp"
-
-// Cross-workgroup reduction + assembly.  One lane per PARTIAL element (consecutive lanes -> consecutive
-// addresses inside every workgroup partial: coalesced), 64 elements x 16 partial-slices per workgroup, fixed
-// summation order.  An MFMA tile element (I,J,row,col) becomes Hess(r,c) = -S(r,c) [+ D term when r and c belong
-// to the same frame] and is mirrored to Hess(c,r) (voxel_map.hpp:237-239); the linear elements become JacT and
-// the residual.  Output buffer: Hess (6W)^2 column-major | JacT 6W | residual.
-__device__ __forceinline__ int sym6_index(int a, int b) { return a == 0 ? b : (a == 1 ? 2 + b : 5); }  // a <= b
-
-constexpr int FIN_EL = 16, FIN_SL = 64;   // FIN_EL * FIN_SL == 1024 threads
-template <int W>
-__global__ __launch_bounds__(1024) void k3_finalize_kernel(const double* __restrict__ partial, int nblocks, LMState* __restrict__ gate, int cb,
-                                                           int write_state, double* __restrict__ packed, int force, const double* __restrict__ k2_partial,
-                                                           int k2_nparts) {
-  using C = K3Cfg<W>;
-  // LM flags: requested now (vector loads: lane-dependent zero offset), tested after the partials are in flight
-  const int zoff = threadIdx.x >> 30;
-  int f_done = gate ? (&gate->ctl[cb].done)[zoff] : 0;
-  int f_calc = gate ? (&gate->ctl[cb].calc_hess)[zoff] : 1;
-  constexpr int n = 6 * W;
-  constexpr int NTILE = C::NTP * 256;
-  constexpr int PLEN = NTILE + W * DACC;
-  // FIN_EL elements x FIN_SL slices of the workgroup partials per block: many small blocks, because one CU cannot pull
-  // more than ~10 B/clk from L2/HBM -- 64 elements per block (45 blocks) left the reduction bound by 45 CUs' load paths
-  __shared__ double red0[FIN_SL][FIN_EL];
-  __shared__ double red1[FIN_SL][FIN_EL];
-  __shared__ double mid0[8][FIN_EL];
-  __shared__ double mid1[8][FIN_EL];
-  const int el = threadIdx.x % FIN_EL, slice = threadIdx.x / FIN_EL;
-  const int e = blockIdx.x * FIN_EL + el;
-  int off1 = -1;        // second stream: block-diagonal D element that lands on the same Hessian entry
-  int r = -1, c = -1;   // Hessian entry of a tile element
-  int lin = -1;         // output index of a linear element (JacT / residual)
-  if (e < NTILE) {
-    const int t = e >> 8, j = (e >> 6) & 3, l = e & 63;
-    // tile t accumulates S[16 rowtile + row][16 coltile + col] (vxba_k3.hpp: K3Cfg::rowtile / coltile; tiles of the second set
-    // may be LOWER tiles); f64 MFMA C/D map: row = lane/16 + 4*reg, col = lane%16
-    const int rt = C::rowtile(t), ct = C::coltile(t);
-    r = 16 * rt + (l >> 4) + 4 * j;
-    c = 16 * ct + (l & 15);
-    if (rt > ct) { const int tmp = r; r = c; c = tmp; }  // lower tile: the same numbers, mirrored
-    if (r >= n || c >= n || r > c) { r = -1; c = -1; }   // padding columns; lower half of a diagonal tile is a duplicate
-    else if (r / 6 == c / 6) {
-      const int i = r / 6, a = r % 6, b = c % 6;         // a <= b
-      if (C::SPARE && b >= 3) {
-        // Drt / Dtt were accumulated by the matrix cores: S[r][6W + (b - 3)] (vxba_k3.hpp, K3Cfg::SPARE)
-        off1 = C::elem_offset(r, n + (b - 3));
-      } else {
-        int d;
-        if (b < 3) d = 6 + sym6_index(a, b);
-        else if (a < 3) d = 12 + 3 * a + (b - 3);
-        else d = 21 + sym6_index(a - 3, b - 3);
-        off1 = NTILE + i * DACC + d;
-      }
-    }
-  } else if (e < PLEN) {
-    const int q = e - NTILE, i = q / DACC, d = q % DACC;
-    if (d < 6) lin = n * n + 6 * i + d;
-    else if (d == 27 && i == 0) lin = n * n + n;
-  }
-  const bool need0 = (r >= 0) || (lin >= 0);
-  double s0 = 0.0, s1 = 0.0;
-  bool flags_checked = false;
-  if (need0) {
-    // the loads of 4 partials are issued together (independent), added in fixed order
-    int b = slice;
-    for (; b + FIN_SL * 3 < nblocks; b += FIN_SL * 4) {
-      double v0[4], v1[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const double* pb = partial + (size_t)(b + FIN_SL * q) * PLEN;
-        v0[q] = pb[e];
-        v1[q] = off1 >= 0 ? pb[off1] : 0.0;
-      }
-      if (!flags_checked) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" : "+v"(f_done), "+v"(f_calc));
-        flags_checked = true;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; q++) { s0 += v0[q]; s1 += v1[q]; }
-    }
-    for (; b < nblocks; b += FIN_SL) {
-      const double* pb = partial + (size_t)b * PLEN;
-      s0 += pb[e];
-      if (off1 >= 0) s1 += pb[off1];
-    }
-  }
-  if (!flags_checked) asm volatile("" : "+v"(f_done), "+v"(f_calc));
-  if (f_done || (!f_calc && !force)) return;   // uniform over the grid
-  // sharded speculative loop: the residual of the trial state (the residual sweep's wave partials) rides in the slot behind the
-  // packed buffer, so that ONE all-reduce carries the system and the number the accept/reject test needs
-  if (k2_partial && blockIdx.x == gridDim.x - 1) {
-    double sum = 0.0;
-    for (int k = threadIdx.x; k < k2_nparts; k += FIN_EL * FIN_SL) sum += k2_partial[k];
-    double* red = &red0[0][0];
-    red[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = (FIN_EL * FIN_SL) >> 1; off > 0; off >>= 1) {
-      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) packed[n * n + n + 1] = red[0];
-    __syncthreads();
-  }
-  red0[slice][el] = s0;
-  red1[slice][el] = s1;
-  __syncthreads();
-  if (slice < 8) {
-    double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-    for (int k = 0; k < FIN_SL / 8; k++) { t0 += red0[slice * (FIN_SL / 8) + k][el]; t1 += red1[slice * (FIN_SL / 8) + k][el]; }
-    mid0[slice][el] = t0;
-    mid1[slice][el] = t1;
-  }
-  __syncthreads();
-  if (slice == 0 && need0) {
-    double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { t0 += mid0[k][el]; t1 += mid1[k][el]; }
-    if (lin >= 0) {
-      packed[lin] = t0;
-      if (gate && write_state) {   // LM state: gauge-fixed gradient (voxel_map.hpp:400), residual1 (:388)
-        if (lin < n * n + n) gate->Jwork[lin - n * n] = (lin - n * n < 6) ? 0.0 : t0;
-        else { gate->ctl[cb].residual1 = t0; if (gate->ctl[cb].iter == 0) gate->ctl[cb].resis[0] = t0; }
-      }
-    } else {
-      const double h = t1 - t0;
-      packed[(size_t)c * n + r] = h;
-      packed[(size_t)r * n + c] = h;
-      if (gate && write_state) {   // LM state: *hess = Hess before the gauge fix (:391) and the gauge-fixed working copy (:397-400)
-        gate->hess_out[(size_t)c * n + r] = h;
-        gate->hess_out[(size_t)r * n + c] = h;
-        const double hw = (r < 6 || c < 6) ? ((r == c) ? 1.0 : 0.0) : h;
-        gate->Hwork[(size_t)c * n + r] = hw;
-        gate->Hwork[(size_t)r * n + c] = hw;
-      }
-    }
-  }
 }
 
 // Voxel-sharded runs: k3_finalize only produced this rank's share of the packed buffer; after the all-reduce the LM state
@@ -936,6 +1052,7 @@ __global__ __launch_bounds__(256) void lm_init_kernel(LMState* stp, PoseArg x0, 
     st->calc_hess = 1; st->done = 0; st->iter = 0; st->converge = 1; st->rejected = 0; st->bench_mode = bench_mode;
     st->n_accept = 0; st->n_reject = 0;
     stp->error = 0;   // a timed-out in-launch solve of an earlier call must not fail this one (the host retries without fusion)
+    // fin_flag needs no reset: launch sequence numbers never repeat within a factor's lifetime
   }
 }
 // stand-alone launch of the damped solve (VXBA_FUSED_SOLVE=0 and the retry after a timed-out in-launch solve; the default runs it
@@ -1000,8 +1117,28 @@ void launch_mfma_probe(const double* dA, const double* dB, double* dD, hipStream
 // Voxels per residual-sweep workgroup.  One lane per voxel, full waves (64) by default.  Tried: ceil(V / (k * cus)) voxels per
 // workgroup so that every CU owns the same number of voxels (49 instead of 64 at cfg2, 4 workgroups on every CU): 20.0 us instead of
 // 18.0 -- the partly filled waves cost more than the ragged last round.  VXBA_OPT_K2_VOXELS_PER_BLOCK keeps the experiment reproducible.
+// Workgroups that take part in the in-launch Hessian reduction.  They must all be resident while the solve workgroup waits for them
+// (they are the first ones dispatched, one 256-thread workgroup each: 192 + the solve fit any MI355X), and there must be enough of them
+// for the reduction to take a pass or two (16 elements of the partial per workgroup and pass) -- else the stand-alone kernel is faster.
+int fin_workgroups(int W, int nvoxels, int voxels_per_block) {
+  const int vpb0 = voxels_per_block & 0xffff;
+  const int vpb = (vpb0 >= 32 && vpb0 <= 64) ? vpb0 : 64;
+  const int nwaves = (nvoxels + vpb - 1) / vpb;
+  const int nvw = (nwaves + K2_WAVES - 1) / K2_WAVES;
+  const int groups = ((int)k3_partial_len(W) + FINP_EL - 1) / FINP_EL;
+  const int nwg = nvw < FIN_MAX_WG ? nvw : FIN_MAX_WG;
+  return 2 * nwg >= groups ? nwg : 0;
+}
 int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, int c, unsigned fused_seq, int head, int end, double* d_partial,
-                       int voxels_per_block, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, const double* host_feed, const double* li_rec, double* li_out) {
+                       int voxels_per_block, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, const double* host_feed, const double* li_rec, double* li_out,
+                       const FinArgs* fin_in) {
+  FinArgs fin;
+  std::memset(&fin, 0, sizeof fin);
+  if (fin_in && st && fused_seq != 0 && !host_feed) {
+    fin = *fin_in;
+    fin.nwg = fin_workgroups(fv.W, end - head, voxels_per_block);
+    if (fin.nwg <= 0) return -1;   // the caller asked fin_workgroups() first
+  }
   const int vpb0 = voxels_per_block & 0xffff;
   const int vpb = (vpb0 >= 32 && vpb0 <= 64) ? vpb0 : 64;
   const int vpb_arg = vpb | (voxels_per_block & 0x10000);   // bit 16: the voxel workgroups do not wait for the in-launch solve (test hook)
@@ -1015,12 +1152,12 @@ int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, 
   const dim3 g(grid), b(K2_THREADS);
   if (fv.cl32) {   // f32 re-centred cluster rows (the caller built them: vxba_capi.hip, residual_view)
     if (ev_start) {
-      VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false, true>), g, b, 0, s, ev_start, ev_stop, 0, st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses));
-    } else { VXK_DISPATCH_W(fv.W, (k2_residual_kernel<WW, false, true><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses))); }
-  } else if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses)); }
+      VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false, true>), g, b, 0, s, ev_start, ev_stop, 0, st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fin, fv, poses));
+    } else { VXK_DISPATCH_W(fv.W, (k2_residual_kernel<WW, false, true><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fin, fv, poses))); }
+  } else if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fin, fv, poses)); }
   else if (ev_start) {
-    VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), g, b, 0, s, ev_start, ev_stop, 0, st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses));
-  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses)); }
+    VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), g, b, 0, s, ev_start, ev_stop, 0, st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fin, fv, poses));
+  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fin, fv, poses)); }
   return nblocks;
 }
 
