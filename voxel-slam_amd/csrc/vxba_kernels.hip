@@ -464,14 +464,16 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __rest
   const int VPB = VPB_arg & 0xffff;
   __shared__ __attribute__((aligned(16))) double k2_lds[k2_lds_doubles<W>()];
   // LM mode: trial poses of ctl[c]; nothing to do once the loop is done
-  if (st && st->ctl[c].done) return;
+  // (the solve workgroup of a fused launch tests the flag itself, behind its loads: lm_solve_body4)
+  const bool fin_en = (VPB_arg >> 17) & 1;   // FinArgs in use (a preloaded scalar: `fin` itself sits in the part of the argument block that has to be loaded)
+  if (st && (!(seq != 0 && blockIdx.x == 0 && !host_feed) || fin_en) && st->ctl[c].done) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   double* pose_lds = k2_lds + wave * 12 * W;
   int vb = blockIdx.x * K2_WAVES + wave;
   if (DBG) { if (blockIdx.x == 0) dbg_stamp(wave == 0, 4000, 30); else dbg_stamp(true, vb - K2_WAVES, 6); }   // kernel entry
   // same gate as k3_finalize_kernel: nothing to reduce when the Hessian sweep skipped itself (rejected step)
-  const bool fin_on = st && seq != 0 && fin.partial != nullptr && st->ctl[c].calc_hess != 0;
+  const bool fin_on = st && seq != 0 && fin_en && st->ctl[c].calc_hess != 0;
   if (st && seq != 0) {
     if (blockIdx.x == 0) {
       if (host_feed) {
@@ -1141,7 +1143,7 @@ int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, 
   }
   const int vpb0 = voxels_per_block & 0xffff;
   const int vpb = (vpb0 >= 32 && vpb0 <= 64) ? vpb0 : 64;
-  const int vpb_arg = vpb | (voxels_per_block & 0x10000);   // bit 16: the voxel workgroups do not wait for the in-launch solve (test hook)
+  const int vpb_arg = vpb | (voxels_per_block & 0x10000) | (fin.nwg > 0 ? 0x20000 : 0);   // bit 16: the voxel workgroups do not wait for the in-launch solve (test hook); bit 17: FinArgs in use
   const int nblocks = (end - head + vpb - 1) / vpb;          // voxel WAVES = partials
   if (nblocks <= 0) return 0;
   const unsigned seq = st ? fused_seq : 0u;

@@ -116,7 +116,9 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds, 
                                                unsigned li_seq = 0) {
   using C = S4<W>;
   LMCtl& ctl = st->ctl[c];
-  if (ctl.done) return;
+  // "loop done" is TESTED behind the loads of the system (below): one round of memory latency at the head of every step's critical path
+  // instead of two (the flag, then everything else)
+  const int loop_done = ctl.done;
   constexpr int n = C::N, M = C::M, B = C::B;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,6 +159,7 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds, 
     for (int k = 0; k < 12; k++) xcur[k] = li_x ? li_x[12 * fl + k] : ctl.x[12 * fl + k];
   }
   if (wave == 1 % S4_WAVES) rhs0 = row_ok ? (li_e ? li_e[gi_row] : 0.0) - st->Jwork[gi_row] : 0.0;
+  if (loop_done) return;
   if (wave < B) s4_store_row(lds + C::TC + wave * S4_BLK + lane * S4_ROW, a0[0]);
   dbg_stamp(DBG && wave == 0, 4000, 2);
 
