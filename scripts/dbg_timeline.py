@@ -86,6 +86,13 @@ else:
             print("since the workgroup's first wave started: %-26s median %6.0f  p10 %6.0f  p90 %6.0f   waves 0-3 median %6.0f  waves 4-7 median %6.0f" % (
                 nm, np.median(col[ok]), np.percentile(col[ok], 10), np.percentile(col[ok], 90),
                 np.median(col[ok & (wv < 4)]) if (ok & (wv < 4)).any() else -1, np.median(col[ok & (wv >= 4)]) if (ok & (wv >= 4)).any() else -1))
+    # epilogue, per wave since it left the step loop (slot 3): 27 tiles-done barrier passed, 28 accumulators parked, 29 second barrier passed,
+    # 30 linear sums written, 6 partial stores issued, 31 ... and acknowledged
+    for nm, slot in (("tiles-done barrier passed", 27), ("accumulators parked", 28), ("second barrier passed", 29), ("linear sums written", 30), ("partial stores issued", 6), ("stores acknowledged", 31)):
+        ok = (fl[:, slot] > 0) & (fl[:, 3] > 0)
+        if ok.any():
+            col = fl[ok, slot] - fl[ok, 3]
+            print("epilogue, since the wave left the step loop: %-28s median %6.0f  p10 %6.0f  p90 %6.0f" % (nm, np.median(col), np.percentile(col, 10), np.percentile(col, 90)))
     per = np.diff(st[:, 2:7], axis=1) / 100.0
     okp = (st[:, 2:7] > 0).all(axis=1)
     if okp.any():

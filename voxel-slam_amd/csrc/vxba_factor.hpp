@@ -83,6 +83,10 @@ struct vxba_factor {
   struct LiScratch {             // host buffers of the LI shells, kept between calls (four (15W)^2 matrices: allocating and zeroing them
     std::vector<double> Hess, HessN, A, JacT, JacTN, D, rhs, dxi, work, cov_invs;   // cost ~15 us of a ~300 us call)
     std::vector<int> perm;
+    // information matrices of the previous call, with the covariances they were computed from: consecutive calls of a sliding window
+    // see the same preintegrated factors again (in place, or moved down by the frames marginalised in between)
+    std::vector<double> cov_seen, cov_inv_seen;
+    int n_seen = 0;
     void size(int n, int nfac) {
       Hess.resize((size_t)n * n); HessN.resize((size_t)n * n); JacT.resize(n); JacTN.resize(n); D.resize(n); rhs.resize(n); dxi.resize(n);
       work.resize(n); perm.resize(n); cov_invs.resize((size_t)225 * nfac);

@@ -670,6 +670,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
   double* park_d = lds;                                                   // [512 lanes][DS] linear accumulators
   double* park_t = E::ONE_PHASE ? lds + (size_t)K3_BLOCK * E::DS : lds;   // [8 waves][TPW][256] MFMA accumulators
   __syncthreads();  // every wave is done with the tiles
+  dbg_stamp(DBG, gw, 27);
   if (undecided && decide()) return;   // a workgroup without a batch: first barrier since the prologue's
   // (1) per-frame linear accumulators: every lane parks the ones in use, then one thread per (frame, slot) sums the 8*NV lanes
 #pragma unroll
@@ -684,8 +685,11 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
   for (int j = 0; j < C::TPW; j++)
 #pragma unroll
     for (int r = 0; r < 4; r++) park_t[(wave * C::TPW + j) * 256 + r * 64 + lane] = acc[j][r];
+  dbg_stamp(DBG, gw, 28);
   __syncthreads();
+  dbg_stamp(DBG, gw, 29);
   if (E::ONE_PHASE) k3_sum_linear<W>(park_d, pout + C::NTP * 256, tid);
+  dbg_stamp(DBG, gw, 30);
   // two consecutive elements per thread: one 16-byte store (write-through like the other bulk outputs -- an 8-byte write-through store
   // costs 2.7x the time per byte of a 16-byte one, and this tail of 22 KB per workgroup is store-issue-bound)
   const __amdgpu_buffer_rsrc_t rout = k3_rsrc(pout);
@@ -702,4 +706,5 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
 #endif
   }
   dbg_stamp(DBG, gw, 6);
+  if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 31); }   // ... and acknowledged
 }

@@ -153,6 +153,7 @@ void launch_lm_unpack(LMState* st, int c, const double* d_packed, int W, hipStre
 // LM shell on the device: init (poses, damping, flags into ctl[0]), damped solve + trial state on ctl[c], and the
 // stand-alone decision kernel that closes the loop (ctl[c_in] -> ctl[c_in ^ 1]).
 void launch_lm_init(LMState* st, const PoseArg& x0, int W, int bench_mode, hipStream_t s);
+void launch_lm_reset(LMState* st, hipStream_t s);   // control scalars of both blocks and the error word to zero (see the kernel)
 void launch_lm_solve(LMState* st, int c, int W, hipStream_t s);
 void launch_lm_update(LMState* st, int c_in, const LMPending& pend, const PoseArg& restart_x0, int W, hipStream_t s);
 

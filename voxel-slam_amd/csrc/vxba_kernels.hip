@@ -1319,6 +1319,17 @@ void launch_count_nnz(const FactorView& fv, int V, unsigned long long* d_out, hi
   hipLaunchKernelGGL(count_nnz_kernel, dim3(nblk((long long)V * fv.W, 256)), dim3(256), 0, s, fv, V, d_out);
 }
 
+// what hipMemsetAsync(st, 0, sizeof(LMState)) does to the fields anything reads before writing them (the control scalars of both blocks, the
+// error word) -- without a 70 KB fill in front of the first sweep of a call (the LiDAR-inertial shells reset the state on every call)
+__global__ void lm_reset_kernel(LMState* st) {
+  if (threadIdx.x < 2) {
+    LMCtl& c = st->ctl[threadIdx.x];
+    c.u = 0; c.v = 0; c.residual1 = 0; c.residual2 = 0; c.q1 = 0; c.resis[0] = 0; c.resis[1] = 0;
+    c.calc_hess = 0; c.done = 0; c.iter = 0; c.converge = 0; c.rejected = 0; c.bench_mode = 0; c.n_accept = 0; c.n_reject = 0;
+  }
+  if (threadIdx.x == 2) { st->error = 0; st->solve_seq = 0; }
+}
+void launch_lm_reset(LMState* st, hipStream_t s) { lm_reset_kernel<<<dim3(1), dim3(64), 0, s>>>(st); }
 void launch_lm_init(LMState* st, const PoseArg& x0, int W, int bench_mode, hipStream_t s) {
   lm_init_kernel<<<dim3(1), dim3(256), 0, s>>>(st, x0, W, bench_mode);
 }
