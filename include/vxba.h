@@ -323,6 +323,11 @@ int vxba_map_export_planes(vxba_map* m, vxba_lio* lio, int64_t* n_exported);
 int vxba_map_slide(vxba_map* m, int mgsize);
 /* out = [roots, roots in the slide map, leaves, mp[0]] */
 int vxba_map_counts(vxba_map* m, int64_t out[4]);
+/* The pool that holds the marginalised (fix) points of all leaves: out = [cursor, capacity, compactions so far], in points (96 bytes each).
+ * The pool is a bump allocator -- a leaf that outgrows its region gets a new one, the old one is abandoned -- that is COMPACTED (live regions
+ * moved to the front of a fresh pool, inside vxba_map_recut / vxba_map_margi) whenever the cursor passes max(4M points, 3 x what was live at
+ * the last compaction), so a long mapping session holds a bounded multiple of its live points (the reference frees point_fix vectors instead). */
+int vxba_map_fix_pool(vxba_map* m, int64_t out[3]);
 /* Every leaf (octo_state == 0), unordered.  ids: [x:16 | y:16 | z:16 | octant path:9 | 0:4 | layer:3] (as vxba_voxelize_push);
  * ints n x 8 = [layer, isexist, is_plane, has window, opt_state, last_num, stored fix points, root in slide map]; dbl n x (156 + 11 W) =
  * [pcr_add 10 | pcr_fix 10 | eig_value 3 | eig_vector 9 | plane centre 3 | normal 3 | radius | plane_var 36 | cov_add 81 | window

@@ -52,6 +52,27 @@ def checker_backends():
 @pytest.mark.parametrize("backend", [n for n, _ in checker_backends()])
 @pytest.mark.parametrize("S,win,pts,seed,max_points", [(9, 4, 12000, 6, 60), (12, 5, 8000, 11, 100), (10, 3, 20000, 3, 40)])
 def test_device_map_evolves_like_the_checker(vx, backend, S, win, pts, seed, max_points):
+    evolve(vx, backend, S, win, pts, seed, max_points)
+
+
+def test_device_map_with_the_fix_point_pool_compacted_on_the_way(vx, monkeypatch):
+    """The pool of marginalised points is a bump allocator that is compacted when its cursor has run far ahead of what is live
+    (vxba_map_fix_pool, include/vxba.h).  With the threshold lowered to 2000 points the same sessions compact several times; every
+    comparison against the checker -- among them the fix-point sums of the children of leaves subdivided AFTER a compaction -- must
+    hold unchanged, and the pool must end smaller than the sum of what was ever allocated."""
+    monkeypatch.setenv("VXBA_MAP_FIX_COMPACT_AT", "2000")
+    total = 0
+    for S, win, pts, seed, max_points in [(12, 5, 8000, 11, 100), (10, 3, 20000, 3, 40)]:
+        mg = evolve(vx, "oracle", S, win, pts, seed, max_points)
+        fp = mg.fix_pool()
+        assert fp["compactions"] >= 2 and 0 < fp["cursor"] <= fp["capacity"], fp
+        total += fp["compactions"]
+    monkeypatch.delenv("VXBA_MAP_FIX_COMPACT_AT")
+    mg = evolve(vx, "oracle", 9, 4, 12000, 6, 60)
+    assert mg.fix_pool()["compactions"] == 0          # default threshold: 4M points
+
+
+def evolve(vx, backend, S, win, pts, seed, max_points):
     B = dict(checker_backends())[backend]
     xyz, fp, poses_gt, _ = synth.make_scans(win_size=S, pts_per_scan=pts, seed=synth.MASTER_SEED + 900 + seed)
     rng = np.random.default_rng(seed)
@@ -121,6 +142,7 @@ def test_device_map_evolves_like_the_checker(vx, backend, S, win, pts, seed, max
         assert ca == cb, (ca, cb)
         capped = max(capped, int((a["pcr_fix"][:, 9] >= max_points).sum()))
     assert windows == S - win + 1 and subdivided > 50 and capped > 0
+    return mg
 
 
 def test_device_map_reproduces_the_reference_octree_golden(vx):

@@ -833,6 +833,31 @@ __global__ void map_fill_u64_kernel(unsigned long long* p, long long n, unsigned
   if (i < n) p[i] = v;
 }
 
+
+// ---- fix-point pool compaction ----------------------------------------------------------------------------------------------
+// The pool is a bump allocator: a leaf that outgrows its region gets a new one at the cursor (margi), a split leaf's points move to
+// its children (subdivide), a leaf that reaches max_points drops its points -- the old regions are never handed out again.  When the
+// cursor has run far ahead of what is live, the live regions (capacity included: the slack keeps the next append in place) are moved,
+// in node order, to the front of a fresh pool.  Pure relocation: contents and order of every leaf's points are unchanged.
+__global__ void map_fix_caps_kernel(Nodes nd, int n_nodes, long long* __restrict__ caps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const bool live = nd.fix_count[i] > 0;
+  if (!live) nd.fix_cap[i] = 0;
+  caps[i] = live ? (long long)nd.fix_cap[i] : 0ll;
+}
+__global__ void map_fix_move_kernel(Nodes nd, int n_nodes, const long long* __restrict__ new_start, const double* __restrict__ old_pnt, const double* __restrict__ old_var,
+                                    double* __restrict__ new_pnt, double* __restrict__ new_var) {
+  const int i = blockIdx.x;                       // one 64-lane workgroup per node
+  if (i >= n_nodes) return;
+  const int fc = nd.fix_count[i];
+  if (fc <= 0) return;
+  const long long src = nd.fix_start[i], dst = new_start[i];
+  for (int k = threadIdx.x; k < 3 * fc; k += blockDim.x) new_pnt[3 * (size_t)dst + k] = old_pnt[3 * (size_t)src + k];
+  for (int k = threadIdx.x; k < 9 * fc; k += blockDim.x) new_var[9 * (size_t)dst + k] = old_var[9 * (size_t)src + k];
+  __syncthreads();
+  if (threadIdx.x == 0) nd.fix_start[i] = dst;
+}
 }  // namespace vxmap
 
 // =====================================================================================================================================
@@ -854,6 +879,8 @@ struct vxba_map {
   // one resident scan per window slot
   struct Scan { double* pnt = nullptr; double* var9 = nullptr; int* perm = nullptr; int* tmp = nullptr; int n = 0, cap = 0; } scan[vxmap::MAXW];
   double* fix_pnt = nullptr; double* fix_var = nullptr; long long fix_cap = 0, fix_cursor = 0;
+  long long fix_compact_min = 1ll << 22, fix_compact_at = 1ll << 22;   // compaction of the fix pool once the cursor passes fix_compact_at (points)
+  long long n_fix_compactions = 0;
   char* scratch = nullptr; size_t scratch_cap = 0;
   char* stage = nullptr; size_t stage_cap = 0;    // second grow-only buffer: outputs that live next to the scratch of the same call
   std::string err;
@@ -925,6 +952,41 @@ int ensure_fix(vxba_map* m, long long want) {
   if ((rc = grow_array(m, &m->fix_pnt, (size_t)m->fix_cap * 3, (size_t)ncap * 3))) return rc;
   if ((rc = grow_array(m, &m->fix_var, (size_t)m->fix_cap * 9, (size_t)ncap * 9))) return rc;
   m->fix_cap = ncap;
+  return VXBA_OK;
+}
+int ensure_scratch(vxba_map* m, size_t bytes);
+// Move the live regions of the fix-point pool to the front of a fresh pool when the cursor has passed m->fix_compact_at (see the kernels).
+// Called between stages (the host's view of the counters is current, nothing is in flight that allocates).
+int compact_fix(vxba_map* m) {
+  if (m->fix_cursor <= m->fix_compact_at || m->n_nodes == 0 || !m->fix_pnt) return VXBA_OK;
+  const int n = m->n_nodes;
+  size_t tb = 0;
+  rocprim::exclusive_scan(nullptr, tb, (long long*)nullptr, (long long*)nullptr, 0ll, (size_t)n, rocprim::plus<long long>(), m->stream);
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t b_l = up((size_t)n * sizeof(long long));
+  int rc = ensure_scratch(m, 2 * b_l + up(tb));
+  if (rc) return rc;
+  long long* d_caps = (long long*)m->scratch;
+  long long* d_start = (long long*)(m->scratch + b_l);
+  void* d_tmp = m->scratch + 2 * b_l;
+  map_fix_caps_kernel<<<grid_for(n), 256, 0, m->stream>>>(m->nd, n, d_caps);
+  VM_HIP(m, rocprim::exclusive_scan(d_tmp, tb, d_caps, d_start, 0ll, (size_t)n, rocprim::plus<long long>(), m->stream));
+  long long last[2] = {0, 0};
+  VM_HIP(m, hipMemcpyAsync(&last[0], d_start + (n - 1), sizeof(long long), hipMemcpyDeviceToHost, m->stream));
+  VM_HIP(m, hipMemcpyAsync(&last[1], d_caps + (n - 1), sizeof(long long), hipMemcpyDeviceToHost, m->stream));
+  VM_HIP(m, map_wait(m->stream));
+  const long long live = last[0] + last[1];
+  const long long ncap = std::max<long long>(1ll << 18, live + live / 2 + (1ll << 16));
+  double *np = nullptr, *nv = nullptr;
+  VM_HIP(m, hipMalloc((void**)&np, (size_t)ncap * 3 * sizeof(double)));
+  if (hipMalloc((void**)&nv, (size_t)ncap * 9 * sizeof(double)) != hipSuccess) { hipFree(np); return mfail(m, VXBA_ERR_HIP, "vxba_map: out of memory compacting the fix-point pool"); }
+  map_fix_move_kernel<<<dim3((unsigned)n), 64, 0, m->stream>>>(m->nd, n, d_start, m->fix_pnt, m->fix_var, np, nv);
+  VM_HIP(m, map_wait(m->stream));
+  VM_HIP(m, hipGetLastError());
+  hipFree(m->fix_pnt); hipFree(m->fix_var);
+  m->fix_pnt = np; m->fix_var = nv; m->fix_cap = ncap; m->fix_cursor = live;
+  m->fix_compact_at = std::max(m->fix_compact_min, 3 * live);
+  m->n_fix_compactions++;
   return VXBA_OK;
 }
 int ensure_scratch(vxba_map* m, size_t bytes) {
@@ -999,6 +1061,10 @@ int vxba_map_create(const vxba_map_params* p, int device, vxba_map** out) {
   for (int k = 0; k < 4; k++) { m->prm.min_point[k] = p->min_point[k]; m->prm.thre[k] = p->plane_eigen_value_thre[k]; }
   m->prm.max_points = p->max_points; m->prm.win_size = p->win_size; m->prm.thread_num = p->thread_num;
   for (int i = 0; i < vxmap::MAXW; i++) m->mp[i] = i;
+  if (const char* e = getenv("VXBA_MAP_FIX_COMPACT_AT")) {   // points; development / tests (the default compacts from 4M abandoned + live points on)
+    const long long v = atoll(e);
+    if (v > 0) m->fix_compact_min = m->fix_compact_at = v;
+  }
   bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipMalloc((void**)&m->d_cnt, sizeof(vxmap::Counters)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&m->h_cnt, sizeof(vxmap::Counters), hipHostMallocDefault) == hipSuccess;
@@ -1107,6 +1173,7 @@ int vxba_map_recut(vxba_map* m, int win_count, const double* Rp, vxba_factor* fa
   const PoseArg poses = make_poses(Rp, win_count);
   const RingArg ring = make_ring(m);
   int rc;
+  if ((rc = compact_fix(m))) return rc;
   if ((rc = cnt_push(m))) return rc;
   int bound = m->n_nodes;                      // upper bound of the node count on the device
   for (int L = 0; L <= m->prm.max_layer; L++) {
@@ -1167,6 +1234,7 @@ int vxba_map_margi(vxba_map* m, int win_count, const double* Rp, vxba_factor* fa
   if (rc != VXBA_OK) return mfail(m, rc, vxba_last_error(factor));
   const PoseArg poses = make_poses(Rp, win_count);
   const RingArg ring = make_ring(m);
+  if ((rc = compact_fix(m))) return rc;
   if ((rc = ensure_scratch(m, (size_t)m->n_nodes * sizeof(int)))) return rc;
   int* d_work = (int*)m->scratch;
   if ((rc = cnt_push(m))) return rc;
@@ -1194,6 +1262,11 @@ int vxba_map_slide(vxba_map* m, int mgsize) {
   return VXBA_OK;
 }
 
+int vxba_map_fix_pool(vxba_map* m, int64_t out[3]) {
+  if (!m || !out) return VXBA_ERR_ARG;
+  out[0] = m->fix_cursor; out[1] = m->fix_cap; out[2] = m->n_fix_compactions;
+  return VXBA_OK;
+}
 int vxba_map_counts(vxba_map* m, int64_t out[4]) {
   if (!m || !out) return VXBA_ERR_ARG;
   hipSetDevice(m->device);

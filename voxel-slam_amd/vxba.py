@@ -37,7 +37,7 @@ EXPORTS = [
     "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_lio_leaf_stats", "vxba_cov_add_build", "vxba_plane_update", "vxba_down_sampling_voxel", "vxba_voxelize_push_device",
     "vxba_set_option", "vxba_get_option", "vxba_lio_set_option",
     "vxba_map_create", "vxba_map_destroy", "vxba_map_last_error", "vxba_map_cut_voxel", "vxba_map_cut_voxel_device", "vxba_map_recut", "vxba_map_margi",
-    "vxba_map_slide", "vxba_map_counts", "vxba_map_leaves", "vxba_map_cut_voxel_lio", "vxba_map_export_planes",
+    "vxba_map_slide", "vxba_map_counts", "vxba_map_fix_pool", "vxba_map_leaves", "vxba_map_cut_voxel_lio", "vxba_map_export_planes",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -177,6 +177,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_map_margi.argtypes = [vp, ci, _f64p, vp]
     L.vxba_map_slide.argtypes = [vp, ci]
     L.vxba_map_counts.argtypes = [vp, _i64p]
+    L.vxba_map_fix_pool.argtypes = [vp, _i64p]
     L.vxba_map_leaves.argtypes = [vp, C.c_int64, vp, vp, vp, C.POINTER(C.c_int64)]
     _lib = L
     return L
@@ -969,6 +970,12 @@ class LocalMap:
         out = np.zeros(4, dtype=np.int64)
         self._chk(self._L.vxba_map_counts(self._h, out))
         return dict(roots=int(out[0]), slide=int(out[1]), leaves=int(out[2]), mp0=int(out[3]))
+
+    def fix_pool(self):
+        """Pool of the marginalised points: cursor / capacity in points, compactions so far (include/vxba.h ``vxba_map_fix_pool``)."""
+        out = np.zeros(3, dtype=np.int64)
+        self._chk(self._L.vxba_map_fix_pool(self._h, out))
+        return dict(cursor=int(out[0]), capacity=int(out[1]), compactions=int(out[2]))
 
     def leaves(self):
         """Every leaf, sorted by node id, as a dictionary of arrays (fields of include/vxba.h ``vxba_map_leaves``)."""
