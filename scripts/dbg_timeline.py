@@ -53,6 +53,19 @@ if which == "fused":
             if ch[0] > 0:
                 print("step %d owner chain: start %d  applied +%d  diagonal read +%d  factored +%d  panel stored +%d" % ((s_, ch[0] - t0) + tuple(np.diff(ch))))
     sys.exit(0)
+if which == "fin":
+    # cross-workgroup reduction of the Hessian sweep (k3_finalize_kernel): wave 0 of every workgroup, rows 3000.. of the stamp table:
+    # 0 entry, 1 loads landed and summed, 2 reduced through LDS and outputs issued, 3 outputs acknowledged
+    f.acc_evaluate2(sc.poses_init)
+    full = vxba.debug_stamps(3400).astype(np.int64)[3000:3400, :4]
+    full = full[full[:, 0] > 0]
+    d = np.diff(full, axis=1)
+    print("finalize: %d workgroups; per workgroup, cycles: entry -> loads summed  median %d p10 %d p90 %d | -> reduced, outputs issued  median %d | -> acknowledged  median %d | total median %d max %d" % (
+        full.shape[0], np.median(d[:, 0]), np.percentile(d[:, 0], 10), np.percentile(d[:, 0], 90), np.median(d[:, 1]), np.median(d[:, 2]), np.median(full[:, 3] - full[:, 0]), (full[:, 3] - full[:, 0]).max()))
+    for x in range(8):   # same-XCD workgroups share a clock: spread of the entry and of the end inside one XCD
+        g = full[x::8]
+        print("  XCD %d: %d workgroups, entry spread %d cycles, first entry -> last end %d cycles" % (x, g.shape[0], g[:, 0].max() - g[:, 0].min(), g[:, 3].max() - g[:, 0].min()))
+    sys.exit(0)
 if which == "k2":
     f.evaluate_only_residual(sc.poses_init); n = (sc.n_voxels + 63) // 64; ns = 5
 else:

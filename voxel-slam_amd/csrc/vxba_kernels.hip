@@ -286,11 +286,13 @@ __device__ __forceinline__ void fin_emit(const FinMap& m, double t0, double t1, 
 #define FIN_EL_ 16
 #endif
 constexpr int FIN_EL = FIN_EL_, FIN_SL = 64;   // FIN_EL * FIN_SL threads (<= 1024)
-template <int W>
+template <int W, bool DBG = false>
 __global__ __launch_bounds__(FIN_EL * FIN_SL) void k3_finalize_kernel(const double* __restrict__ partial, int nblocks, LMState* __restrict__ gate, int cb,
                                                            int write_state, double* __restrict__ packed, int force, const double* __restrict__ k2_partial,
                                                            int k2_nparts) {
   using C = K3Cfg<W>;
+  const int dbg_w = 3000 + (int)blockIdx.x;            // instrumented build: stamps of wave 0 of every workgroup (rows 3000.. of the stamp table)
+  dbg_stamp(DBG && threadIdx.x < 64, dbg_w, 0);
   // LM flags: requested now (vector loads: lane-dependent zero offset), tested after the partials are in flight
   const int zoff = threadIdx.x >> 30;
   int f_done = gate ? (&gate->ctl[cb].done)[zoff] : 0;
@@ -337,6 +339,7 @@ __global__ __launch_bounds__(FIN_EL * FIN_SL) void k3_finalize_kernel(const doub
     }
   }
   if (!flags_checked) asm volatile("" : "+v"(f_done), "+v"(f_calc));
+  if (DBG) { asm volatile("" :: "v"(s0), "v"(s1)); dbg_stamp(threadIdx.x < 64, dbg_w, 1); }   // loads landed, summed
   if (f_done || (!f_calc && !force)) return;   // uniform over the grid
   // sharded speculative loop: the residual of the trial state (the residual sweep's wave partials) rides in the slot behind the
   // packed buffer, so that ONE all-reduce carries the system and the number the accept/reject test needs
@@ -371,6 +374,8 @@ __global__ __launch_bounds__(FIN_EL * FIN_SL) void k3_finalize_kernel(const doub
     for (int k = 0; k < 8; k++) { t0 += mid0[k][el]; t1 += mid1[k][el]; }
     fin_emit<W, false>(m, t0, t1, gate, cb, write_state, packed);
   }
+  dbg_stamp(DBG && threadIdx.x < 64, dbg_w, 2);        // reduced through LDS, outputs issued
+  if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(threadIdx.x < 64, dbg_w, 3); }
 }
 
 // The same reduction as a PHASE of the residual-sweep launch (k2_residual_kernel, fused with the damped solve): the voxel workgroups
@@ -1238,6 +1243,13 @@ int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, LMState* st
 void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, int write_state, double* d_packed, hipStream_t s, int force,
                         const double* k2_partial, int k2_nparts) {
   const int plen = (int)k3_partial_len(W);
+  static int dbg = -1;
+  if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
+  if (dbg) {
+    VXK_DISPATCH_W(W, (k3_finalize_kernel<WW, true><<<dim3((plen + FIN_EL - 1) / FIN_EL), dim3(FIN_EL * FIN_SL), 0, s>>>(d_partial, nblocks, st, c, write_state, d_packed,
+                                                                                                                    force, k2_partial, k2_nparts)));
+    return;
+  }
   VXK_DISPATCH_W(W, k3_finalize_kernel<WW><<<dim3((plen + FIN_EL - 1) / FIN_EL), dim3(FIN_EL * FIN_SL), 0, s>>>(d_partial, nblocks, st, c, write_state, d_packed,
                                                                                                            force, k2_partial, k2_nparts));
 }
