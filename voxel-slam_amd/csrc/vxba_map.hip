@@ -70,6 +70,7 @@ struct Nodes {
 
 struct Counters {   // device block of counters, read back after each stage
   int n_nodes, n_roots, n_touched, n_slide_new, n_split, n_fac, n_removed, err;
+  int n_list, pad_;
   int n_split_l[4];
   long long fix_need_l[4];
   long long fix_cursor, fix_need;
@@ -361,6 +362,8 @@ __global__ __launch_bounds__(64) void map_subdivide_wave_kernel(Nodes nd, Params
   double a[20];
 #pragma unroll
   for (int k = 0; k < 20; k++) a[k] = 0.0;
+  // (Measured and rejected, round 3: a pre-pass that classifies the node's points first, so that it takes its children and their fix
+  // regions with one read-modify-write of each counter instead of up to sixteen: 74.4 against 72.8 us -- the folding, not the atomics.)
   auto get_child = [&]() {
     if (part == 0 && child < 0) {
       child = atomicAdd(&cnt->n_nodes, 1);
@@ -678,26 +681,44 @@ __global__ void map_margi_kernel(Nodes nd, Params prm, int n_nodes, int win_coun
   work[i] = wk;
   nd.isexist[i] = (fixc[9] >= add[9]) ? 0 : 1;       // :1292-1295
 }
-__global__ void map_margi_points_kernel(Nodes nd, Params prm, int n_nodes, PoseArg poses, RingArg ring, ScanSlots scans, const int* __restrict__ work,
-                                        double* __restrict__ fix_pnt, double* __restrict__ fix_var, Counters* cnt) {
+// Two passes.  `list`: one thread per node (coalesced reads of the work words) appends the marginalised slot's points to the node's
+// fix region when they fit (a handful of points per node) and clears the slot's running sums; nodes whose region has to MOVE first -- a
+// copy of up to max_points points -- go onto a work list (one atomic per wave).  `points`: one 64-lane workgroup per listed node, strided
+// over the list -- the points are independent of one another, so the lanes copy / transform them side by side.  (One thread per node
+// for everything took 106 us per call at 120k nodes, the movers' serial copies being the tail; one workgroup per node for everything
+// 240 us: most nodes have one or two points and 64 times the load instructions.)
+__global__ void map_margi_list_kernel(Nodes nd, Params prm, int n_nodes, PoseArg poses, RingArg ring, ScanSlots scans, const int* __restrict__ work, int* __restrict__ list,
+                                      long long* __restrict__ list_dst, double* __restrict__ fix_pnt, double* __restrict__ fix_var, Counters* cnt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_nodes || work[i] == 0) return;
   const int W = prm.win_size, m0 = ring.mp[0];
-  const int wk = work[i];
+  const int wk = i < n_nodes ? work[i] : 0;
+  const bool heavy = (wk & 3) == 3;
+  const unsigned long long mask = __ballot(heavy);
+  if (mask) {
+    // the movers of this wave: list slots and new regions from ONE atomic each (a mover per atomic -- ~20k read-modify-writes of one
+    // word -- was what the kernel behind this one spent 200 us on)
+    const int lane = threadIdx.x & 63;
+    long long mine = 0;
+    if (heavy) mine = 2ll * (nd.fix_count[i] + nd.pt_count[(size_t)i * W + m0]);
+    long long incl = mine;
+    for (int d = 1; d < 64; d <<= 1) { const long long t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    const long long total = __shfl(incl, 63, 64);
+    int base = 0;
+    unsigned long long rbase = 0;
+    if (lane == 0) { base = atomicAdd(&cnt->n_list, __popcll(mask)); rbase = atomicAdd((unsigned long long*)&cnt->fix_cursor, (unsigned long long)total); }
+    base = __shfl(base, 0, 64);
+    rbase = __shfl(rbase, 0, 64);
+    if (heavy) {
+      const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+      list[slot] = i;
+      list_dst[slot] = (long long)rbase + incl - mine;
+    }
+  }
+  if (wk == 0 || heavy) return;
   if (wk & 1) {
     const ScanSlot sc = scans.s[m0];
     const int p0 = nd.pt_start[(size_t)i * W + m0], pc = nd.pt_count[(size_t)i * W + m0];
     const int fc = nd.fix_count[i];
-    if (wk & 2) {
-      const int ncap = 2 * (fc + pc);
-      const long long dst = (long long)atomicAdd((unsigned long long*)&cnt->fix_cursor, (unsigned long long)ncap);
-      const long long src = nd.fix_start[i];
-      for (int j = 0; j < fc; j++) {
-        for (int e = 0; e < 3; e++) fix_pnt[3 * (size_t)(dst + j) + e] = fix_pnt[3 * (size_t)(src + j) + e];
-        for (int e = 0; e < 9; e++) fix_var[9 * (size_t)(dst + j) + e] = fix_var[9 * (size_t)(src + j) + e];
-      }
-      nd.fix_start[i] = dst; nd.fix_cap[i] = ncap;
-    }
     const long long dst = nd.fix_start[i] + fc;
     for (int j = 0; j < pc; j++) {                   // pv.pnt = R * pv.pnt + p; point_fix.push_back(pv)  (:1262-1266)
       const int pi = sc.perm[p0 + j];
@@ -712,6 +733,45 @@ __global__ void map_margi_points_kernel(Nodes nd, Params prm, int n_nodes, PoseA
   if (l0[9] != 0.0) {
     for (int k = 0; k < 10; k++) l0[k] = 0.0;
     nd.pt_count[(size_t)i * W + m0] = 0;
+  }
+}
+__global__ __launch_bounds__(64) void map_margi_points_kernel(Nodes nd, Params prm, PoseArg poses, RingArg ring, ScanSlots scans, const int* __restrict__ work,
+                                                              const int* __restrict__ list, const long long* __restrict__ list_dst, double* __restrict__ fix_pnt,
+                                                              double* __restrict__ fix_var, Counters* cnt) {
+  const int lane = threadIdx.x;
+  const int W = prm.win_size, m0 = ring.mp[0];
+  const ScanSlot sc = scans.s[m0];
+  const int n_list = cnt->n_list;
+  for (int q = blockIdx.x; q < n_list; q += gridDim.x) {
+    const int i = list[q];
+    const int wk = work[i];
+    const int p0 = nd.pt_start[(size_t)i * W + m0], pc = nd.pt_count[(size_t)i * W + m0];
+    const int fc = nd.fix_count[i];
+    long long base = nd.fix_start[i];
+    if (wk & 2) {
+      const long long dst = list_dst[q];
+      const long long src = base;
+      for (int k = lane; k < 3 * fc; k += 64) fix_pnt[3 * (size_t)dst + k] = fix_pnt[3 * (size_t)src + k];
+      for (int k = lane; k < 9 * fc; k += 64) fix_var[9 * (size_t)dst + k] = fix_var[9 * (size_t)src + k];
+      base = dst;
+    }
+    const long long dst = base + fc;
+    for (int j = lane; j < pc; j += 64) {          // pv.pnt = R * pv.pnt + p; point_fix.push_back(pv)  (:1262-1266)
+      const int pi = sc.perm[p0 + j];
+      double w[3];
+      to_world(poses.Rp, sc.pnt + 3 * (size_t)pi, w);
+      for (int e = 0; e < 3; e++) fix_pnt[3 * (size_t)(dst + j) + e] = w[e];
+      for (int e = 0; e < 9; e++) fix_var[9 * (size_t)(dst + j) + e] = sc.var9[9 * (size_t)pi + e];
+    }
+    double* l0 = nd.pcrs_local + ((size_t)i * W + m0) * 10;      // :1283-1288
+    const bool had = l0[9] != 0.0;                  // read by every lane before any of them writes
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      if (wk & 2) { nd.fix_start[i] = base; nd.fix_cap[i] = 2 * (fc + pc); }
+      nd.fix_count[i] = fc + pc;
+      if (had) nd.pt_count[(size_t)i * W + m0] = 0;
+    }
+    if (had && lane < 10) l0[lane] = 0.0;
   }
 }
 // internal nodes, one layer at a time from the bottom: isexist = any child (voxel_map.hpp:1297-1304)
@@ -1008,7 +1068,7 @@ int ensure_stage(vxba_map* m, size_t bytes) {
 // counters: push the host view to the device before a stage, pull it back after
 int cnt_push(vxba_map* m) {
   Counters& c = *m->h_cnt;
-  c.n_nodes = m->n_nodes; c.n_roots = m->n_roots; c.n_touched = 0; c.n_slide_new = 0; c.n_split = 0; c.n_fac = 0; c.n_removed = 0; c.err = 0; for (int k = 0; k < 4; k++) { c.n_split_l[k] = 0; c.fix_need_l[k] = 0; } c.fix_cursor = m->fix_cursor; c.fix_need = 0;
+  c.n_nodes = m->n_nodes; c.n_roots = m->n_roots; c.n_touched = 0; c.n_slide_new = 0; c.n_split = 0; c.n_fac = 0; c.n_removed = 0; c.err = 0; c.n_list = 0; c.pad_ = 0; for (int k = 0; k < 4; k++) { c.n_split_l[k] = 0; c.fix_need_l[k] = 0; } c.fix_cursor = m->fix_cursor; c.fix_need = 0;
   VM_HIP(m, hipMemcpyAsync(m->d_cnt, m->h_cnt, sizeof(Counters), hipMemcpyHostToDevice, m->stream));
   return VXBA_OK;
 }
@@ -1235,15 +1295,18 @@ int vxba_map_margi(vxba_map* m, int win_count, const double* Rp, vxba_factor* fa
   const PoseArg poses = make_poses(Rp, win_count);
   const RingArg ring = make_ring(m);
   if ((rc = compact_fix(m))) return rc;
-  if ((rc = ensure_scratch(m, (size_t)m->n_nodes * sizeof(int)))) return rc;
-  int* d_work = (int*)m->scratch;
+  if ((rc = ensure_scratch(m, (size_t)m->n_nodes * (sizeof(long long) + 2 * sizeof(int))))) return rc;
+  long long* d_list_dst = (long long*)m->scratch;
+  int* d_work = (int*)(d_list_dst + m->n_nodes);
+  int* d_list = d_work + m->n_nodes;
   if ((rc = cnt_push(m))) return rc;
   map_margi_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->prm, m->n_nodes, win_count, poses, ring, f_ev, f_evec, f_mg, VS, V, d_work, m->d_cnt);
   if ((rc = cnt_pull(m))) return rc;
   if ((rc = check_err(m, "vxba_map_margi"))) return rc;
   if ((rc = ensure_fix(m, m->fix_cursor + m->h_cnt->fix_need))) return rc;
   if ((rc = cnt_push(m))) return rc;
-  map_margi_points_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->prm, m->n_nodes, poses, ring, make_scans(m), d_work, m->fix_pnt, m->fix_var, m->d_cnt);
+  map_margi_list_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->prm, m->n_nodes, poses, ring, make_scans(m), d_work, d_list, d_list_dst, m->fix_pnt, m->fix_var, m->d_cnt);
+  map_margi_points_kernel<<<dim3((unsigned)std::min(m->n_nodes, 4096)), 64, 0, m->stream>>>(m->nd, m->prm, poses, ring, make_scans(m), d_work, d_list, d_list_dst, m->fix_pnt, m->fix_var, m->d_cnt);
   for (int L = m->prm.max_layer - 1; L >= 0; L--) map_margi_up_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, L);
   map_release_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->prm.win_size, m->n_nodes);
   map_leave_slide_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, m->d_cnt);
