@@ -234,3 +234,42 @@ def test_li_edge_cases_one_iteration_and_rejected_steps(vx, queued):
     assert np.array_equal(again["trace"][:, 6:], ref2["trace"][:, 6:]) and np.allclose(again["trace"][:, :2], ref2["trace"][:, :2], rtol=1e-6)
     et, er = synth.pose_errors(again["states"][:, :12], ref2["states"][:, :12])
     assert et < 1e-7 and er < 1e-7
+
+
+def test_information_matrices_follow_the_imu_factors_between_calls(vx):
+    """The shells keep the 15 x 15 information matrices of the previous call and re-use one when a factor's covariance is bit-identical
+    to one seen then (vxba_capi_li.hip, li_information_matrices).  Same LidarFactor, three IMU windows in turn -- A, B (other noise
+    densities: other covariances), a window that mixes factors of both (the sliding-window case: known covariances in other slots), A
+    again -- every call must equal the call of a factor that has never seen another window, bit for bit."""
+    W, V, pts = 6, 1200, 12000
+    sc = synth.make_scene(win_size=W, pts_per_scan=pts, n_voxels=V, seed=8800)
+
+    def imu_set(cov_gyr, cov_acc, seed):
+        iw = synth.make_imu(sc, seed=seed, cov_gyr=cov_gyr, cov_acc=cov_acc)
+        facs = []
+        for gyr, acc, dts in iw.samples:
+            f = vx.IMU_PRE(iw.states_init[0, 15:18], iw.states_init[0, 18:21])
+            for g, a, dt in zip(gyr, acc, dts):
+                f.add_imu(g, a, dt, iw.noise_meas, iw.noise_walk)
+            facs.append(f)
+        return iw, facs
+
+    def factor():
+        f = vx.LidarFactor(W); f.push_voxels(sc.clusters, sc.fix, sc.coe); f.evaluate_only_residual(sc.poses_init); f.snapshot_cache()
+        return f
+
+    def run(f, iw, facs):
+        blobs = [x.blob.copy() for x in facs]
+        f.restore_cache()
+        out = vx.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(iw.states_init, f, facs, max_iter=3)
+        for x, b in zip(facs, blobs): x.blob[:] = b          # the optimiser moves the factors' bias deltas: undo for the next use
+        return out
+
+    A, B = imu_set(0.01, 1.0, 8801), imu_set(0.03, 2.5, 8801)
+    assert not np.array_equal(A[1][0].blob, B[1][0].blob)
+    mixed = (A[0], [B[1][1], A[1][0], A[1][2], B[1][3], A[1][4]])       # factors of both windows, some in slots they did not have before
+    shared = factor()
+    for iw, facs in (A, B, mixed, A):
+        got = run(shared, iw, facs)
+        ref = run(factor(), iw, facs)
+        assert np.array_equal(got["states"], ref["states"]) and np.array_equal(got["trace"], ref["trace"])
