@@ -376,9 +376,13 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
     VX_HIP(f, q);
     f->li_reduction_in_flight = false;
   }
-  nan_fill_packed();
-  // the device-side control block the queued sweeps read their poses from: not done, no error
-  vxk::launch_lm_reset(f->d_lm, f->stream);
+  // Device-solve mode: the first Hessian sweep goes out before anything else (it reads neither the control block nor the host buffer);
+  // the sentinel fill and the control-block reset follow while it runs, ahead of the reduction that writes both.
+  if (!dev_solve) {
+    nan_fill_packed();
+    // the device-side control block the queued sweeps read their poses from: not done, no error
+    vxk::launch_lm_reset(f->d_lm, f->stream);
+  }
   // first joint system: Hessian sweep at the caller's poses, as in the plain shell, marked by an event (the stream will not drain)
   {
     double Rp0[12 * VXBA_MAX_WIN];
@@ -390,6 +394,8 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
       std::memset(&none, 0, sizeof none);
       if (vxk::launch_k3_hessian(fv, pa, nullptr, 0, none, nullptr, 0, f->V, f->d_partial3, nblocks3, f->precision, f->stream) < 0)
         return fail(f, VXBA_ERR_STATE, "li: cache planes are not consecutive");
+      vxk::launch_lm_reset(f->d_lm, f->stream);
+      nan_fill_packed();              // nothing that writes this buffer is in the stream yet (a previous call's reduction was drained above)
       vxk::launch_k3_finalize(f->d_partial3, nblocks3, W, f->d_lm, 0, 1, zpk[cur], f->stream, 1);
       VX_HIP(f, hipGetLastError());
     } else {
