@@ -124,6 +124,16 @@ else:
         t0w = blk[:, 9].min()
         print("workgroup %d, step 2:  wave: M done / A done / barrier 2 passed (cycles since the first wave left barrier 1)" % wg)
         print("   " + "  ".join("w%d: %5d/%5d/%5d" % (w_, blk[w_, 19] - t0w, blk[w_, 20] - t0w, blk[w_, 10] - t0w) for w_ in range(8)))
+    # inside phase A of step 2 (round 4): M done (19) -> parameters + pose back in registers (7) -> rows computed (14) -> rows stored (15) ->
+    # block-diagonal accumulators done (18) -> next batch requested = A done (20)
+    cols = full[live][:, [19, 7, 14, 15, 18, 20]]
+    okc = (cols > 0).all(axis=1)
+    if okc.any():
+        d = np.diff(cols[okc], axis=1)
+        wvo = wv[okc]
+        for nm, sel in (("all waves", wvo >= 0), ("waves 0-3", wvo < 4), ("waves 4-7", wvo >= 4)):
+            print("phase A of step 2, %-9s (cycles, median): unstage + pose %5.0f | rows computed %5.0f | rows stored %5.0f | rest of the accumulators %5.0f | requests issued %5.0f" % (
+                (nm,) + tuple(np.median(d[sel], axis=0))))
     sys.exit(0)
 full = vxba.debug_stamps(n).astype(np.int64)
 st = full[:, :ns]

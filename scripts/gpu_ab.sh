@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 for r in $(seq 1 ${ROUNDS:-3}); do
   for lib in gpurun_ab/libvxba_base.so voxel-slam_amd/csrc/libvxba.so; do
-    VXBA_LIB=$PWD/$lib timeout 600 python bench.py --steps ${STEPS:-300} --warmup 30 --no-cpu-baseline --no-li-ba 2>&1 | grep -v amdgpu.ids | python -c "
+    VXBA_LIB=$PWD/$lib timeout 600 python bench.py --steps ${STEPS:-300} --warmup 30 --no-cpu-baseline --no-li-ba --no-cold-l3 ${BENCH_ARGS:-} 2>&1 | grep -v amdgpu.ids | python -c "
 import sys, json
 for l in sys.stdin:
     try: d = json.loads(l)

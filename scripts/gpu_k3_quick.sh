@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 for lib in ${LIBS:-voxel-slam_amd/csrc/libvxba.so}; do
 echo "== $lib"
-VXBA_LIB=$PWD/$lib timeout 300 python bench.py --steps ${STEPS:-150} --warmup 15 --no-cpu-baseline --no-li-ba 2>&1 | grep -v amdgpu.ids | python -c "
+VXBA_LIB=$PWD/$lib timeout 300 python bench.py --steps ${STEPS:-150} --warmup 15 --no-cpu-baseline --no-li-ba --no-cold-l3 ${BENCH_ARGS:-} 2>&1 | grep -v amdgpu.ids | python -c "
 import sys, json
 for l in sys.stdin:
     try: d = json.loads(l)

@@ -118,17 +118,23 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // them in registers during phase M (10 registers instead of 36), and redistributes them through a wave-private corner of LDS
 // at the start of phase A: 8 vector-memory instructions per wave and batch instead of 23.
 struct K3Planes {
-  __amdgpu_buffer_rsrc_t cache, coe;   // cache = eigval(3) | eigvec(9) | merged(10) | aux(4), consecutive planes (FactorView / snapshot)
+  const double *cache_ptr, *coe_ptr;   // cache = eigval(3) | eigvec(9) | merged(10) | aux(4), consecutive planes (FactorView / snapshot)
   const double* clb;
   unsigned vs8;   // plane stride in bytes
 };
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t k3_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)0xffffffff, 0x00020000);   // raw buffer, no range limit
 }
+// The same descriptor with the range check as an on / off switch: with num_records = 0 every lane of a load is out of range, so
+// the load returns zeros WITHOUT a memory request.  A wave-uniform "is there a next batch" becomes one s_cselect on a descriptor
+// dword instead of a branch around the loads -- see the note on phi copies at phase_a in k3_hessian_kernel.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t k3_rsrc_gated(const void* p, bool on) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, __builtin_amdgcn_readfirstlane(on ? (int)0xffffffff : 0), 0x00020000);   // wave-uniform by construction; say so
+}
 __device__ __forceinline__ K3Planes k3_planes(const FactorView& fv) {
   K3Planes pl;
-  pl.cache = k3_rsrc(fv.eigval);
-  pl.coe = k3_rsrc(fv.coe);
+  pl.cache_ptr = fv.eigval;
+  pl.coe_ptr = fv.coe;
   pl.clb = fv.clb;
   pl.vs8 = (unsigned)fv.VS * 8u;
   return pl;
@@ -140,8 +146,8 @@ __device__ __forceinline__ double k3_ld64(__amdgpu_buffer_rsrc_t r, unsigned vof
 }
 
 // clusters of batch b: five contiguous 1 KB rows per wave (batch-major copy) -- 83 % of an entry's bytes
-__device__ __forceinline__ void k3_load_clusters(const K3Planes& pl, int b, int lane, double c[10]) {
-  const __amdgpu_buffer_rsrc_t rc = k3_rsrc(pl.clb + (size_t)b * 640);
+__device__ __forceinline__ void k3_load_clusters(const K3Planes& pl, int b, int lane, double c[10], bool on = true) {
+  const __amdgpu_buffer_rsrc_t rc = k3_rsrc_gated(pl.clb + (size_t)b * 640, on);
 #pragma unroll
   for (int j = 0; j < 5; j++) {
     const v2d t = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rc, lane * 16, j * 1024, 0));
@@ -168,8 +174,9 @@ struct K3Stage {
 };
 // request the plane parameters of batch b (transposed); voxels outside [head, end) read voxel `head` instead (masked later)
 template <int W>
-__device__ __forceinline__ void k3_load_params(const K3Planes& pl, int head, int end, int b, int lane, K3Stage<W>& st) {
+__device__ __forceinline__ void k3_load_params(const K3Planes& pl, int head, int end, int b, int lane, K3Stage<W>& st, bool on = true) {
   using S = K3Stage<W>;
+  const __amdgpu_buffer_rsrc_t rcache = k3_rsrc_gated(pl.cache_ptr, on), rcoe = k3_rsrc_gated(pl.coe_ptr, on);
 #pragma unroll
   for (int q = 0; q < S::Q; q++) {
     const int t = lane + 64 * q;
@@ -181,12 +188,12 @@ __device__ __forceinline__ void k3_load_params(const K3Planes& pl, int head, int
     int plane = 0;
 #pragma unroll
     for (int kk = 0; kk < 17; kk++) plane = (k == kk) ? k3_param_plane(kk) : plane;
-    st.v[q] = k3_ld64(pl.cache, (unsigned)plane * pl.vs8 + (unsigned)a * 8u, 0);
+    st.v[q] = k3_ld64(rcache, (unsigned)plane * pl.vs8 + (unsigned)a * 8u, 0);
   }
   {
     int a = b * S::NV + (lane < S::NV ? lane : 0);
     a = (a >= head && a < end) ? a : head;
-    st.coe = k3_ld64(pl.coe, (unsigned)a * 8u, 0);
+    st.coe = k3_ld64(rcoe, (unsigned)a * 8u, 0);
   }
 }
 // park the staged values in the wave's LDS corner and read back the lane's own voxel record
@@ -444,8 +451,8 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
   K3Entry e;
   e.ok = false;
   K3Planes pl;
-  pl.cache = k3_rsrc(cache_planes);
-  pl.coe = k3_rsrc(coe_plane);
+  pl.cache_ptr = cache_planes;
+  pl.coe_ptr = coe_plane;
   pl.clb = clb;
   pl.vs8 = (unsigned)VS * 8u;
   K3Stage<W> stg;
@@ -549,9 +556,21 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
       const LMDecision d = lm_decide(st->ctl[c_in], r2, restart);
       lm_persist(st, c_in, d, restart, poses, W);
     }
+    // Leave nothing in flight behind this once-per-launch path: the loop head below is a join of "came through here" and "did not", and
+    // the compiler's wait-count bookkeeping at a join is the union of what may be pending -- loads of lm_decide / lm_persist into the
+    // registers the MFMA operands are read into put an s_waitcnt vmcnt(0) at the head of EVERY phase M (the next batch's loads, issued
+    // a moment earlier, then had to land before the first MFMA instead of having the whole phase to do so).
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0); the builtin, not inline asm: the bookkeeping pass has to see it
     return done || !(accept || restart);
   };
+#if defined(K3_POSE_REGS) && K3_POSE_REGS
+  // experiment: the lane's pose (a lane constant for the whole launch) held in 24 registers instead of six ds_read_b128 per step
+  double pose[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) pose[k] = poseA[12 * fi + k];
+#else
   const double* pose = poseA + 12 * fi;
+#endif
   v4d acc[C::TPW];
 #pragma unroll
   for (int t = 0; t < C::TPW; t++) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -563,18 +582,29 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
   for (int k = 0; k < DACC; k++) dacc[k] = 0.0;
 
   const K3RowOfs ro = k3_row_offsets<W>(wave, vl, fi);   // lane constants: where the lane's three row pieces go inside a tile buffer
+  int dbg_step = -1;                                      // instrumented build: the step phase_a is running for
   // Phase A of the wave's batch b into tile buffer `bo`, then the requests for its next batch nb (nb < 0: none).
   // Measured and rejected (round 3, same box): the LDS round trip of the plane parameters issued two thirds of the way through phase M
   // instead of at the head of phase A -- 29.8 -> 29.6 us at cfg2, but 166.9 -> 173.3 us at cfg4 (13 steps per workgroup): the wait
   // for the parameter loads then sits inside the MFMA stream, and with more traffic in flight they have not always landed by then.
   auto unstage = [&](int b) __attribute__((always_inline)) { k3_unstage_params<W>(stg, stage_lds, head, end, b, active, vl, lane, e); };
-  auto phase_a = [&](int b, int bo, int nb, bool staged) __attribute__((always_inline)) {
+  // `next`: 0 = no requests behind this phase A (compile-time at the call), 1 = request batch nb if `more` (wave-uniform, run time).
+  // The run-time case issues the loads UNCONDITIONALLY through descriptors whose range check `more` switches off: with a branch around
+  // them the entry registers became a phi of (old, loaded) values, and the copies that resolve it sat behind s_waitcnt vmcnt at the END
+  // of phase A -- every wave waited out the latency of the loads it had just issued before it reached the barrier (round-4 find, from
+  // the ISA: vmcnt(7) / (6) / (5) + six v_mov_b64 in front of the barrier, vmcnt(0) at the head of phase M).
+  auto phase_a = [&](int b, int bo, int nb, bool more, auto next_tag) __attribute__((always_inline)) {
+    constexpr int next = decltype(next_tag)::value;
     double rows[3][6];
-    if (!staged) unstage(b);
+    // instrumented build, step 2 only: 7 parameters + pose back in registers, 14 rows computed, 15 rows stored, 18 = everything but the requests
+    const bool stamp_here = DBG && dbg_step == 2;
+    unstage(b);
+    if (DBG && stamp_here) { asm volatile("" :: "v"(e.u[0]), "v"(e.coe)); __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 7); __builtin_amdgcn_sched_barrier(0); }
     // voxel-level values for the spare columns, taken before phase A masks / consumes the entry
     const double spare_s = 1.4142135623730951 * e.sc;
     const double spare[3] = {spare_s * e.u[0], spare_s * e.u[1], spare_s * e.u[2]};
     k3_phase_a<!C::SPARE>(e, fi, pose, rows, dacc);
+    if (DBG && stamp_here) { asm volatile("" :: "v"(rows[0][0]), "v"(rows[1][5]), "v"(rows[2][0])); __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 14); __builtin_amdgcn_sched_barrier(0); }
     if (active) {
       const int fi_ = fi;
       if (MIXED) k3_store_rows_f32(reinterpret_cast<float*>(lds) + bo, ro, rows);
@@ -596,9 +626,16 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
     // box): the cluster rows requested a step earlier into a second register set (no change: the steps do not wait for loads);
     // the two waves of a SIMD taking phase M / phase A in opposite order (13.2k instead of 11.8k cycles per step).  Round 3: s_setprio
     // for one of a SIMD's two waves during phase A (either one: K3 26.6 -> 27.2 us), for phase M (no change).
-    if (nb >= 0) {
-      k3_load_clusters(pl, nb, lane, e.c);
-      k3_load_params<W>(pl, head, end, nb, lane, stg);
+    if (DBG && stamp_here) { __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 15); asm volatile("" :: "v"(dacc[6]), "v"(dacc[11]), "v"(dacc[0])); __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 18); }
+    if constexpr (next != 0) {
+      __builtin_amdgcn_sched_barrier(0);   // behind the last use of the entry: the loads go into the registers they free
+#if defined(K3_PARAMS_FIRST) && K3_PARAMS_FIRST
+      k3_load_params<W>(pl, head, end, nb, lane, stg, more);   // experiment: the values phase A needs first are requested first
+      k3_load_clusters(pl, nb, lane, e.c, more);
+#else
+      k3_load_clusters(pl, nb, lane, e.c, more);
+      k3_load_params<W>(pl, head, end, nb, lane, stg, more);
+#endif
     }
   };
 
@@ -622,7 +659,8 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
       }
       if (s < nfull) {
         const bool more = (s + 1 < nfull) || (wave < nrag);
-        phase_a(bs + s * C::WAVES + wave, (s & 1) * C::BUF, more ? bs + (s + 1) * C::WAVES + wave : -1, false);
+        if (DBG) dbg_step = s;
+        phase_a(bs + s * C::WAVES + wave, (s & 1) * C::BUF, bs + (s + 1) * C::WAVES + wave, more, std::integral_constant<int, 1>{});
         if (s >= 1 && s <= 4) dbg_stamp(DBG, gw, 14 + 3 * s);   // phase A of step s done: slots 17, 20, 23, 26
       }
       if (AF && s >= 1) phase_m();
@@ -642,7 +680,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
     // ragged last step: nrag < 8 batches.  Only ceil(nrag R / 4) K-steps exist; they are re-split over the K ranges, and the first
     // idle wave makes the rows that round the step up to a whole K-step read as zeros.
     const int bo = (nfull & 1) * C::BUF;
-    if (wave < nrag) phase_a(bs + nfull * C::WAVES + wave, bo, -1, false);
+    if (wave < nrag) phase_a(bs + nfull * C::WAVES + wave, bo, 0, false, std::integral_constant<int, 0>{});
     else if (wave == nrag) {
       if (MIXED) { float* z = reinterpret_cast<float*>(lds) + bo + C::at(nrag * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0f; }
       else { double* z = lds + bo + C::at(nrag * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0; }
