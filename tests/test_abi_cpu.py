@@ -59,3 +59,45 @@ def test_product_does_not_touch_the_oracle():
                 if re.search(r"oracle/|liboracle|vxo_|_oracle", txt):
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def _device_kernel_metadata():
+    """name -> dict(vgpr_count, private_segment_fixed_size, vgpr_spill_count) of every gfx950 kernel inside libvxba.so, read with the
+    ROCm llvm tools from a scratch copy (llvm-objdump --offloading writes the code objects next to its input)."""
+    import shutil
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("ROCm llvm tools not installed")
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        so = os.path.join(td, "libvxba.so")
+        shutil.copy(os.path.join(ROOT, "voxel-slam_amd", "csrc", "libvxba.so"), so)
+        subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", so], check=True, capture_output=True, cwd=td)
+        for fn in sorted(os.listdir(td)):
+            if "gfx950" not in fn:
+                continue
+            notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", os.path.join(td, fn)], check=True, capture_output=True, text=True).stdout
+            cur = {}
+            for line in notes.splitlines():
+                m = re.match(r"\s+-?\s*\.(name|vgpr_count|private_segment_fixed_size|vgpr_spill_count):\s+(\S+)", line)
+                if not m:
+                    continue
+                k, v = m.group(1), m.group(2)
+                if k == "name":
+                    cur = out.setdefault(v, {})
+                else:
+                    cur[k] = int(v)
+    return out
+
+
+def test_hessian_sweep_kernels_do_not_spill():
+    """Every instantiation of the Hessian sweep (window sizes 1..10, instrumented and mixed-precision builds) runs two waves per SIMD
+    out of registers alone: no scratch (private segment 0), no spilled VGPRs.  Round 3 shipped k3_hessian_kernel<5> with 12 bytes of
+    scratch unnoticed; this is the build-time check."""
+    meta = _device_kernel_metadata()
+    k3 = {n: m for n, m in meta.items() if "k3_hessian_kernel" in n}
+    assert len(k3) >= 30, sorted(k3)            # 10 window sizes x (plain, instrumented, mixed)
+    bad = {n: m for n, m in k3.items() if m.get("private_segment_fixed_size", -1) != 0 or m.get("vgpr_spill_count", -1) != 0 or m.get("vgpr_count", 999) > 256}
+    assert not bad, bad

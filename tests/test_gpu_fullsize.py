@@ -117,13 +117,15 @@ def test_cfg4_single_gpu_lm_matches_the_oracle(vx):
     clusters = fg.read_clusters()
     fg.evaluate_only_residual(sc.poses_init)
     got = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=2)
-    fo = O.Oracle(sc.win_size)
-    fo.push_voxels(clusters, sc.fix, sc.coe)
-    fo.evaluate_only_residual(sc.poses_init)
-    ref = fo.damping_iter(sc.poses_init, max_iter=2, thd_num=16)
-    assert np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:])
-    assert np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-9)
-    et, er = synth.pose_errors(got["poses"], ref["poses"])
-    assert et < 1e-7 and er < 1e-7, (et, er)
-    Hg = got["hess"]; Ho = ref["hess"]
-    assert np.allclose(Hg, Ho, rtol=0, atol=1e-9 * np.abs(Ho).max())
+    for name, B in checkers():      # the restatement and, when oracle/_ref/libref.so travelled, the reference's own Lidar_BA_Optimizer
+        fo = B.Oracle(sc.win_size)
+        fo.push_voxels(clusters, sc.fix, sc.coe)
+        fo.evaluate_only_residual(sc.poses_init)
+        ref = fo.damping_iter(sc.poses_init, max_iter=2, thd_num=16)
+        assert np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:]), name
+        assert np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-9), name
+        et, er = synth.pose_errors(got["poses"], ref["poses"])
+        assert et < 1e-7 and er < 1e-7, (name, et, er)
+        Hg = got["hess"]; Ho = ref["hess"]
+        assert np.allclose(Hg, Ho, rtol=0, atol=1e-9 * np.abs(Ho).max()), name
+        del fo

@@ -649,6 +649,7 @@ int vxba_set_option(vxba_factor* f, int option, int value) {
 }
 int vxba_get_option(const vxba_factor* f, int option, int* value) {
   if (f && value && option == VXBA_STAT_FUSED_FALLBACKS) { *value = f->fused_fallbacks; return VXBA_OK; }
+  if (f && value && option == VXBA_STAT_LI_DEVICE_FALLBACKS) { *value = f->li_dev_fallbacks; return VXBA_OK; }
   if (f && value && option == VXBA_STAT_LI_LAST_CALL_US) { *value = (int)(f->li_last_call_us + 0.5); return VXBA_OK; }
   if (!f || !value || option < 0 || option >= VXBA_OPT_COUNT) return VXBA_ERR_ARG;
   *value = f->opt[option];

@@ -431,7 +431,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
     if (seq == 0) seq = ++f->lm_seq;
     if (dev) {    // nobody will feed this launch: the sentinels of its outputs go in now (the previous launch's have been consumed)
       for (int k = 0; k < 18 * W + 1; k++) f->h_liout[k] = std::numeric_limits<double>::quiet_NaN();
-      const int np = (f->V + (f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] & 0xffff) - 1) / (f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] & 0xffff);
+      const int np = vxk::k2_nparts(f->V, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK]);   // the launch below returns the same number by construction
       for (int k = 0; k < np; k++) f->h_partial2[k] = std::numeric_limits<double>::quiet_NaN();
       std::atomic_thread_fence(std::memory_order_release);
       // (measured and rejected: the record brought over by one DMA on a side stream + event instead of the solve reading it out of mapped host memory --
@@ -567,7 +567,22 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
         if (q == hipSuccess) { got = complete(); break; }
         if (q != hipErrorNotReady) VX_HIP(f, q);
       }
-      if (!got) return fail(f, VXBA_ERR_STATE, "li: the in-launch pose solve did not deliver its step (NaN in the reduced system?)");
+      if (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] == 2 && it == 0) got = false;   // test hook: treat the first device step as not delivered
+      if (!got) {
+        // The launch is over and slots still hold their sentinels: the device's unpivoted elimination produced a non-finite step (an
+        // ill-conditioned or indefinite reduced system) -- which cannot be told from "not delivered".  The host-solve modes take the
+        // pivoted LDL^T for such a system; so does this one now: the launch's residual sweep (it ran at those poses) is discarded, the
+        // sweeps are queued again waiting for the host's feed -- the path of a step after a rejection -- and the host solves below.
+        f->li_dev_fallbacks++;
+        dev_this = false;
+        rc = queue_sweeps(with_spec, false);
+        if (rc) return rc;
+        sentinel = false;
+        next_sentinel = false;
+      }
+    }
+    if (dev_this) {
+      const volatile double* lo = f->h_liout;
       std::atomic_thread_fence(std::memory_order_acquire);
       lap(T_WAITDX, tp);
       double xs[6 * VXBA_MAX_WIN];

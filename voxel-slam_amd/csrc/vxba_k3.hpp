@@ -156,6 +156,14 @@ __device__ __forceinline__ void k3_load_clusters(const K3Planes& pl, int b, int 
   }
 }
 
+// one of the five cluster rows of batch b (the interleaved form of k3_load_clusters: request j behind K-step j of phase M)
+__device__ __forceinline__ void k3_load_cluster_row(const K3Planes& pl, int b, int lane, double c[10], bool on, int j) {
+  const __amdgpu_buffer_rsrc_t rc = k3_rsrc_gated(pl.clb + (size_t)b * 640, on);
+  const v2d t = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rc, lane * 16, j * 1024, 0));
+  c[2 * j] = t[0];
+  c[2 * j + 1] = t[1];
+}
+
 // Order of a voxel's 18 parameters in the staging record, and the cache plane (relative to eigval) each one comes from.
 //   0..8 eigvec 0..8 | 9, 10 s1, s2 (aux 0, 1) | 11..13 merged first moment (merged 6..8) | 14 1/N (aux 2) | 15 sqrt(coe) (aux 3) |
 //   16 lambda_0 (eigval 0) | 17 coe (its own plane)
@@ -191,6 +199,28 @@ __device__ __forceinline__ void k3_load_params(const K3Planes& pl, int head, int
     st.v[q] = k3_ld64(rcache, (unsigned)plane * pl.vs8 + (unsigned)a * 8u, 0);
   }
   {
+    int a = b * S::NV + (lane < S::NV ? lane : 0);
+    a = (a >= head && a < end) ? a : head;
+    st.coe = k3_ld64(rcoe, (unsigned)a * 8u, 0);
+  }
+}
+// request q of the transposed plane parameters (q < Q) or the coe plane (q == Q): the interleaved form of k3_load_params
+template <int W>
+__device__ __forceinline__ void k3_load_param_q(const K3Planes& pl, int head, int end, int b, int lane, K3Stage<W>& st, bool on, int q) {
+  using S = K3Stage<W>;
+  if (q < S::Q) {
+    const __amdgpu_buffer_rsrc_t rcache = k3_rsrc_gated(pl.cache_ptr, on);
+    const int t = lane + 64 * q;
+    const int tv = t < S::NITEM ? t : 0;
+    const int v = tv / 17, k = tv - 17 * v;
+    int a = b * S::NV + v;
+    a = (a >= head && a < end) ? a : head;
+    int plane = 0;
+#pragma unroll
+    for (int kk = 0; kk < 17; kk++) plane = (k == kk) ? k3_param_plane(kk) : plane;
+    st.v[q] = k3_ld64(rcache, (unsigned)plane * pl.vs8 + (unsigned)a * 8u, 0);
+  } else {
+    const __amdgpu_buffer_rsrc_t rcoe = k3_rsrc_gated(pl.coe_ptr, on);
     int a = b * S::NV + (lane < S::NV ? lane : 0);
     a = (a >= head && a < end) ? a : head;
     st.coe = k3_ld64(rcoe, (unsigned)a * 8u, 0);
@@ -303,8 +333,9 @@ __device__ __forceinline__ int k3_slot_offset(int set, int k) {
   using C = K3Cfg<W>;
   return 32 * (set == 0 ? C::slot_tile(0, k) : C::slot_tile(C::TSPLIT - 1, k));
 }
-template <int W, bool FULL>
-__device__ __forceinline__ void k3_mfma_phase(const double* buf, int set, int k0, int nk, int lrow, int lcol, v4d* acc) {
+struct K3NoHook { __device__ __forceinline__ void operator()(int) const {} };
+template <int W, bool FULL, class Hook = K3NoHook>
+__device__ __forceinline__ void k3_mfma_phase(const double* buf, int set, int k0, int nk, int lrow, int lcol, v4d* acc, Hook hook = Hook()) {
   using C = K3Cfg<W>;
   const double* bp[C::NSLOT];   // K-step kk: + kk * 4 NCOL
 #pragma unroll
@@ -322,6 +353,7 @@ __device__ __forceinline__ void k3_mfma_phase(const double* buf, int set, int k0
         __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the MFMAs (the scheduler sinks them to their first use otherwise)
       }
       k3_mfma_tiles<W, 0>(x, acc);
+      hook(kk);   // (K3_LATE_REQUESTS) one of the next batch's requests behind the MFMAs of this K-step
 #pragma unroll
       for (int k = 0; k < C::NSLOT; k++) x[k] = xn[k];
     }
@@ -418,6 +450,13 @@ __device__ __forceinline__ void k3_sum_linear(const double* park_d, double* out,
 // so that those requests do not wait for a scalar load of the argument block first (a cold miss: the block was written by the host a few
 // microseconds earlier).  Structs are not preloaded and stop the sequence, hence the flat list; what is not urgent follows as before.
 //   pend_flags = pending | restart << 8, nwg = nwg (otherwise a load from the hidden arguments)
+#ifndef K3_LATE_REQUESTS
+#define K3_LATE_REQUESTS 1   // round 4: the default (cfg4 156.6 -> 147.4 us, cfg3 44.5 -> 43.2, cfg2 unchanged; same-box A/B, gpurun_out/r4_s3.log)
+#endif
+constexpr bool K3_LATE_REQ = K3_LATE_REQUESTS != 0;
+#ifndef K3_LATE_PER
+#define K3_LATE_PER 4      // requests behind each K-step of phase M: all eight behind the first two of the nine K-steps at W = 10 (1 and 2 per K-step measured slower: later requests land later)
+#endif
 template <int W, bool DBG = false, bool MIXED = false>
 __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __restrict__ clb, const double* __restrict__ cache_planes, const double* __restrict__ coe_plane,
                                                               LMState* __restrict__ st, int VS, int head, int end, int c_in, int pend_flags, int nwg,
@@ -425,6 +464,8 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
   const int pending = pend_flags & 0xff, restart = pend_flags >> 8;
 
   using C = K3Cfg<W>;
+  // window sizes without spare tile columns (W = 5, 8) carry 15 more accumulators: no registers left for requests in flight across phase M
+  constexpr bool LATE = K3_LATE_REQ && C::SPARE;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // two tile buffers; reused by the epilogue
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // tell the compiler it is wave-uniform: scalar branches, descriptors in SGPRs
@@ -627,7 +668,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
     // the two waves of a SIMD taking phase M / phase A in opposite order (13.2k instead of 11.8k cycles per step).  Round 3: s_setprio
     // for one of a SIMD's two waves during phase A (either one: K3 26.6 -> 27.2 us), for phase M (no change).
     if (DBG && stamp_here) { __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 15); asm volatile("" :: "v"(dacc[6]), "v"(dacc[11]), "v"(dacc[0])); __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 18); }
-    if constexpr (next != 0) {
+    if constexpr (next != 0 && !LATE) {
       __builtin_amdgcn_sched_barrier(0);   // behind the last use of the entry: the loads go into the registers they free
 #if defined(K3_PARAMS_FIRST) && K3_PARAMS_FIRST
       k3_load_params<W>(pl, head, end, nb, lane, stg, more);   // experiment: the values phase A needs first are requested first
@@ -650,8 +691,34 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
     for (int s = 0; s <= nfull; s++) {
       auto phase_m = [&]() __attribute__((always_inline)) {
         const int bo = ((s - 1) & 1) * C::BUF;
-        if (MIXED) k3_mfma_phase_f32<W, true>(reinterpret_cast<const float*>(lds) + bo, set, k0_full, C::KPW, lrow, lcol, af);
-        else k3_mfma_phase<W, true>(lds + bo, set, k0_full, C::KPW, lrow, lcol, acc);
+        if (MIXED) {
+          if constexpr (LATE) {   // mixed precision: the requests in front of the f32 products (not interleaved)
+            const bool more_m = (s < nfull) || (wave < nrag);
+            const int nb_m = bs + s * C::WAVES + wave;
+            k3_load_clusters(pl, nb_m, lane, e.c, more_m);
+            k3_load_params<W>(pl, head, end, nb_m, lane, stg, more_m);
+          }
+          k3_mfma_phase_f32<W, true>(reinterpret_cast<const float*>(lds) + bo, set, k0_full, C::KPW, lrow, lcol, af);
+        } else if constexpr (LATE) {
+          // The requests for the batch of step s ride behind the K-steps of phase M of step s-1 (this iteration), one or two per K-step:
+          // a vector-memory instruction costs the wave ~60 cycles of issue when eight waves queue on the CU's one address unit
+          // (stamps: 460-540 cycles for the eight of a batch), and in front of the barrier that was on the step's critical path.
+          const bool more_m = (s < nfull) || (wave < nrag);
+          const int nb_m = bs + s * C::WAVES + wave;
+          constexpr int NQ = K3Stage<W>::Q + 1, NL = 5 + NQ;   // the parameters first: phase A starts with their LDS round trip
+          constexpr int PER = (K3_LATE_PER * C::KPW >= NL) ? K3_LATE_PER : (NL + C::KPW - 1) / C::KPW;
+          auto hook = [&](int kk) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+              const int l = kk * PER + r;
+              if (l < NQ) k3_load_param_q<W>(pl, head, end, nb_m, lane, stg, more_m, l);
+              else if (l < NL) k3_load_cluster_row(pl, nb_m, lane, e.c, more_m, l - NQ);
+            }
+          };
+          k3_mfma_phase<W, true>(lds + bo, set, k0_full, C::KPW, lrow, lcol, acc, hook);
+        } else {
+          k3_mfma_phase<W, true>(lds + bo, set, k0_full, C::KPW, lrow, lcol, acc);
+        }
       };
       if (!AF && s >= 1) {
         phase_m();

@@ -110,7 +110,10 @@ struct FinArgs {
   int write_state;
   int nwg;                 // filled by launch_k2_residual
 };
-int fin_workgroups(int W, int nvoxels, int voxels_per_block);   // 0: too few voxel workgroups for the in-launch reduction to pay
+int fin_workgroups(int W, int nvoxels, int voxels_per_block);
+// residual-sweep geometry: voxels per wave for an option value, and the number of wave partials a sweep over nvoxels writes
+int k2_voxels_per_wave(int voxels_per_block);
+int k2_nparts(int nvoxels, int voxels_per_block);   // 0: too few voxel workgroups for the in-launch reduction to pay
 int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, int c, unsigned fused_seq, int head, int end, double* d_partial,
                        int voxels_per_block, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const double* host_feed = nullptr,
                        const double* li_rec = nullptr, double* li_out = nullptr, const FinArgs* fin = nullptr);

@@ -1127,9 +1127,18 @@ void launch_mfma_probe(const double* dA, const double* dB, double* dD, hipStream
 // Workgroups that take part in the in-launch Hessian reduction.  They must all be resident while the solve workgroup waits for them
 // (they are the first ones dispatched, one 256-thread workgroup each: 192 + the solve fit any MI355X), and there must be enough of them
 // for the reduction to take a pass or two (16 elements of the partial per workgroup and pass) -- else the stand-alone kernel is faster.
-int fin_workgroups(int W, int nvoxels, int voxels_per_block) {
+// Voxels per wave of the residual sweep for an option value (32..64, else 64) and the number of wave partials a sweep over nvoxels writes:
+// the ONE place this geometry lives -- the launch, the in-launch reduction's sizing and the host shells' sentinel fills all call it.
+int k2_voxels_per_wave(int voxels_per_block) {
   const int vpb0 = voxels_per_block & 0xffff;
-  const int vpb = (vpb0 >= 32 && vpb0 <= 64) ? vpb0 : 64;
+  return (vpb0 >= 32 && vpb0 <= 64) ? vpb0 : 64;
+}
+int k2_nparts(int nvoxels, int voxels_per_block) {
+  const int vpb = k2_voxels_per_wave(voxels_per_block);
+  return nvoxels > 0 ? (nvoxels + vpb - 1) / vpb : 0;
+}
+int fin_workgroups(int W, int nvoxels, int voxels_per_block) {
+  const int vpb = k2_voxels_per_wave(voxels_per_block);
   const int nwaves = (nvoxels + vpb - 1) / vpb;
   const int nvw = (nwaves + K2_WAVES - 1) / K2_WAVES;
   const int groups = ((int)k3_partial_len(W) + FINP_EL - 1) / FINP_EL;
@@ -1146,10 +1155,9 @@ int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, 
     fin.nwg = fin_workgroups(fv.W, end - head, voxels_per_block);
     if (fin.nwg <= 0) return -1;   // the caller asked fin_workgroups() first
   }
-  const int vpb0 = voxels_per_block & 0xffff;
-  const int vpb = (vpb0 >= 32 && vpb0 <= 64) ? vpb0 : 64;
+  const int vpb = k2_voxels_per_wave(voxels_per_block);
   const int vpb_arg = vpb | (voxels_per_block & 0x10000) | (fin.nwg > 0 ? 0x20000 : 0);   // bit 16: the voxel workgroups do not wait for the in-launch solve (test hook); bit 17: FinArgs in use
-  const int nblocks = (end - head + vpb - 1) / vpb;          // voxel WAVES = partials
+  const int nblocks = k2_nparts(end - head, voxels_per_block);          // voxel WAVES = partials
   if (nblocks <= 0) return 0;
   const unsigned seq = st ? fused_seq : 0u;
   const int grid = (nblocks + K2_WAVES - 1) / K2_WAVES + (seq != 0 ? 1 : 0);   // + the solve workgroup
@@ -1333,7 +1341,13 @@ void launch_count_nnz(const FactorView& fv, int V, unsigned long long* d_out, hi
 
 // what hipMemsetAsync(st, 0, sizeof(LMState)) does to the fields anything reads before writing them (the control scalars of both blocks, the
 // error word) -- without a 70 KB fill in front of the first sweep of a call (the LiDAR-inertial shells reset the state on every call)
+// Coverage (keep in step with LMState): ctl[].{u, v, residual1, residual2, q1, resis, calc_hess, done, iter, converge, rejected, bench_mode, n_accept,
+// n_reject}, error, solve_seq, fin_flag[].  NOT reset, because every reader is preceded by a writer inside the same call: ctl[].x / xt (lm_init or the
+// shell's pose upload), trace (written per iteration, read up to `iter`), Jwork / Hwork / dxi / hess_out (k3_finalize writes them before the solve
+// reads).  The block is zeroed once at allocation (vxba_create), so a future reader-before-writer sees zeros or a previous call's values, never
+// uninitialised memory.
 __global__ void lm_reset_kernel(LMState* st) {
+  for (int k = threadIdx.x; k < FIN_MAX_WG; k += blockDim.x) st->fin_flag[k] = 0;   // as the full memset did (sequence numbers are monotonic, so a stale flag could not match anyway)
   if (threadIdx.x < 2) {
     LMCtl& c = st->ctl[threadIdx.x];
     c.u = 0; c.v = 0; c.residual1 = 0; c.residual2 = 0; c.q1 = 0; c.resis[0] = 0; c.resis[1] = 0;

@@ -944,6 +944,7 @@ struct vxba_map {
   char* scratch = nullptr; size_t scratch_cap = 0;
   char* stage = nullptr; size_t stage_cap = 0;    // second grow-only buffer: outputs that live next to the scratch of the same call
   std::string err;
+  bool broken = false;                // a failure left the device-side tree in an unknown state (see compact_fix): every stage refuses from then on
 };
 
 namespace {
@@ -1021,7 +1022,7 @@ int compact_fix(vxba_map* m) {
   if (m->fix_cursor <= m->fix_compact_at || m->n_nodes == 0 || !m->fix_pnt) return VXBA_OK;
   const int n = m->n_nodes;
   size_t tb = 0;
-  rocprim::exclusive_scan(nullptr, tb, (long long*)nullptr, (long long*)nullptr, 0ll, (size_t)n, rocprim::plus<long long>(), m->stream);
+  VM_HIP(m, rocprim::exclusive_scan(nullptr, tb, (long long*)nullptr, (long long*)nullptr, 0ll, (size_t)n, rocprim::plus<long long>(), m->stream));
   auto up = [](size_t b) { return (b + 255) / 256 * 256; };
   const size_t b_l = up((size_t)n * sizeof(long long));
   int rc = ensure_scratch(m, 2 * b_l + up(tb));
@@ -1041,8 +1042,19 @@ int compact_fix(vxba_map* m) {
   VM_HIP(m, hipMalloc((void**)&np, (size_t)ncap * 3 * sizeof(double)));
   if (hipMalloc((void**)&nv, (size_t)ncap * 9 * sizeof(double)) != hipSuccess) { hipFree(np); return mfail(m, VXBA_ERR_HIP, "vxba_map: out of memory compacting the fix-point pool"); }
   map_fix_move_kernel<<<dim3((unsigned)n), 64, 0, m->stream>>>(m->nd, n, d_start, m->fix_pnt, m->fix_var, np, nv);
-  VM_HIP(m, map_wait(m->stream));
-  VM_HIP(m, hipGetLastError());
+  {
+    // The kernel rewrites every node's fix_start as it moves the node's region: once it is launched, a failure leaves starts that may point
+    // into either pool.  Nothing is committed on the host side then -- the new pool is released and the map is marked unusable, so that
+    // no later stage reads regions through stale starts (a map_create + replay of the window is the caller's way out).
+    hipError_t e1 = map_wait(m->stream);
+    if (e1 == hipSuccess) e1 = hipGetLastError();
+    if (e1 != hipSuccess) {
+      hipFree(np); hipFree(nv);
+      m->broken = true;
+      m->err = std::string("vxba_map: compacting the fix-point pool failed (") + hipGetErrorString(e1) + "); the map is unusable from here on";
+      return VXBA_ERR_HIP;
+    }
+  }
   hipFree(m->fix_pnt); hipFree(m->fix_var);
   m->fix_pnt = np; m->fix_var = nv; m->fix_cap = ncap; m->fix_cursor = live;
   m->fix_compact_at = std::max(m->fix_compact_min, 3 * live);
@@ -1155,6 +1167,7 @@ const char* vxba_map_last_error(const vxba_map* m) { return m ? m->err.c_str() :
 // cut_voxel_multi(surf_map, pvec, ord, surf_map_slide, win_size, pwld, sws)   (voxel_map.hpp:1545-1639; voxelslam.cpp:1609)
 static int map_cut_voxel_impl(vxba_map* m, int ord, int64_t n64, const double* pnt_body, const double* var_world, const double* pwld, bool on_device) {
   if (!m || ord < 0 || ord >= m->prm.win_size || n64 < 0 || n64 > 0x3fffffff || (n64 > 0 && (!pnt_body || !var_world || !pwld))) return mfail(m, VXBA_ERR_ARG, "vxba_map_cut_voxel: bad argument");
+  if (m->broken) return VXBA_ERR_STATE;   // m->err still names the failure that broke it
   hipSetDevice(m->device);
   const int n = (int)n64;
   const int slot = m->mp[ord];
@@ -1225,6 +1238,7 @@ int vxba_map_cut_voxel_device(vxba_map* m, int ord, int64_t n, const double* d_p
 // voxhess.clear(); its win_size must be the map's)
 int vxba_map_recut(vxba_map* m, int win_count, const double* Rp, vxba_factor* factor, int64_t* n_pushed) {
   if (!m || !Rp || !factor || win_count < 1 || win_count > m->prm.win_size) return mfail(m, VXBA_ERR_ARG, "vxba_map_recut: bad argument");
+  if (m->broken) return VXBA_ERR_STATE;   // m->err still names the failure that broke it
   if (vxba_win_size(factor) != m->prm.win_size) return mfail(m, VXBA_ERR_ARG, "vxba_map_recut: the factor's win_size differs from the map's");
   if (vxba_internal_factor_device(factor) != m->device) return mfail(m, VXBA_ERR_ARG, "vxba_map_recut: the factor lives on another device than the map (raw device pointers are exchanged)");
   hipSetDevice(m->device);
@@ -1285,6 +1299,7 @@ int vxba_map_recut(vxba_map* m, int win_count, const double* Rp, vxba_factor* fa
 // eig_vectors as the optimiser left them) is read on the device
 int vxba_map_margi(vxba_map* m, int win_count, const double* Rp, vxba_factor* factor) {
   if (!m || !Rp || !factor || win_count < 1 || win_count > m->prm.win_size) return mfail(m, VXBA_ERR_ARG, "vxba_map_margi: bad argument");
+  if (m->broken) return VXBA_ERR_STATE;   // m->err still names the failure that broke it
   if (vxba_internal_factor_device(factor) != m->device) return mfail(m, VXBA_ERR_ARG, "vxba_map_margi: the factor lives on another device than the map (its cache planes are read in place)");
   hipSetDevice(m->device);
   if (m->n_slide < m->prm.thread_num) return VXBA_OK;
@@ -1381,6 +1396,7 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
 // cut_voxel_multi on the scan resident in an odometry handle after vxba_lio_pvec_update: nothing crosses PCIe.
 int vxba_map_cut_voxel_lio(vxba_map* m, int ord, vxba_lio* lio) {
   if (!m || !lio) return mfail(m, VXBA_ERR_ARG, "vxba_map_cut_voxel_lio: null argument");
+  if (m->broken) return VXBA_ERR_STATE;   // m->err still names the failure that broke it
   {
     double vs_ = 0; int ml_ = 0, dev_ = -1;
     vxba_internal_lio_geometry(lio, &vs_, &ml_, &dev_);
@@ -1404,6 +1420,7 @@ int vxba_map_cut_voxel_lio(vxba_map* m, int ord, vxba_lio* lio) {
 // the slide map since the last export.  Call after vxba_map_recut / vxba_map_margi, before the next scan is matched.
 int vxba_map_export_planes(vxba_map* m, vxba_lio* lio, int64_t* n_exported) {
   if (!m || !lio) return mfail(m, VXBA_ERR_ARG, "vxba_map_export_planes: null argument");
+  if (m->broken) return VXBA_ERR_STATE;
   double vs = 0; int ml = 0, dev = 0;
   vxba_internal_lio_geometry(lio, &vs, &ml, &dev);
   if (vs != m->prm.voxel_size || ml != m->prm.max_layer || dev != m->device) return mfail(m, VXBA_ERR_ARG, "vxba_map_export_planes: voxel_size / max_layer / device of the two handles differ");
