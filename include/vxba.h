@@ -220,6 +220,12 @@ typedef struct vxba_voxelize_params {
    * depends on the layer (min_point[layer], voxelslam.cpp:812) and a single observing frame is enough. */
   int min_points_layer[4]; /* > 0: overrides min_points for that layer */
   int min_frames;          /* a factor needs at least this many observing frames: 2 for OctreeGBA (loop_refine.hpp:371-376), 0 for OctoTree */
+  /* Voxel-sharded windows (one process per GPU; the reference shards the voxel list over threads, voxel_map.hpp:318-321, and builds per-thread
+   * factors in OctreeGBA_multi_recut, loop_refine.hpp:483-537).  shard_count > 1: every rank passes the SAME points and keeps the root voxels
+   * that hash to its shard_index -- filtered on the device right after the voxel keys are computed, so the sorts and the octree only see the
+   * shard.  Whole root voxels stay together: the union of the ranks' factor voxels is the unsharded set, each voxel bit for bit.  0 / 1: off. */
+  int shard_index;
+  int shard_count;
 } vxba_voxelize_params;
 /* xyz_local: n_points x 3 body-frame points, frame by frame in cloud order; frame_ptr: win_size + 1 offsets; Rp: win_size*12.
  * Appends the factor voxels to f (coe = 1, no fix cluster, cache seeded with (lambda, U, world cluster) as recut's push_voxel

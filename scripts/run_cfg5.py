@@ -16,37 +16,9 @@ K = a.keyframes
 t0 = time.perf_counter()
 
 
-def corridor_session(K, pts, seed):
-    """A long hall (floor, ceiling, two side walls, all slightly tilted against the voxel grid) with partial cross walls every 10 m,
-    seen by a sensor moving along it with a 30 m range: every keyframe samples only the surfaces around it."""
-    rng = np.random.Generator(np.random.PCG64([seed, 7]))
-    axis = np.array([0.2, 0.1, 1.0]); axis /= np.linalg.norm(axis)
-    Rs = np.stack([synth.rodrigues(0.004 * i * axis) for i in range(K)])
-    ps = np.stack([np.array([0.4 * i, 0.6 * np.sin(0.05 * i), 0.1 * np.sin(0.03 * i)]) for i in range(K)])
-    tilt = synth.rodrigues(np.array([0.013, -0.021, 0.017]))
-    clouds = []
-    for i in range(K):
-        x0 = ps[i, 0]
-        n_each = pts // 5
-        u = rng.uniform(x0 - 30, x0 + 30, size=(5, n_each)); v = rng.uniform(0, 1, size=(5, n_each))
-        floor = np.stack([u[0], -8 + 16 * v[0], np.full(n_each, -2.0)], 1)
-        ceil_ = np.stack([u[1], -8 + 16 * v[1], np.full(n_each, 4.0)], 1)
-        wall1 = np.stack([u[2], np.full(n_each, -8.0), -2 + 6 * v[2]], 1)
-        wall2 = np.stack([u[3], np.full(n_each, 8.0), -2 + 6 * v[3]], 1)
-        kx = np.round(u[4] / 10.0) * 10.0                                   # cross walls at x = 10 k, alternating sides, 4 m wide
-        side = np.where((kx / 10.0) % 2 == 0, 1.0, -1.0)
-        cross = np.stack([kx, side * (4 + 4 * v[4]), -2 + 6 * rng.uniform(0, 1, n_each)], 1)
-        w = np.concatenate([floor, ceil_, wall1, wall2, cross]) @ tilt.T
-        w += rng.normal(0, 0.01, size=w.shape)
-        clouds.append(((w - ps[i]) @ Rs[i]).astype(np.float32))
-    gt = synth.pack_poses(Rs, ps)
-    Ri, pi = Rs.copy(), ps.copy()
-    for i in range(1, K):
-        Ri[i] = Rs[i] @ synth.rodrigues(rng.normal(0, np.deg2rad(0.05), size=3)); pi[i] = ps[i] + rng.normal(0, 0.02, size=3)
-    return clouds, synth.pack_poses(Ri, pi), gt
 
 
-clouds, poses, gt = corridor_session(K, a.pts, synth.MASTER_SEED + 5000)
+clouds, poses, gt = synth.corridor_session(K, a.pts, synth.MASTER_SEED + 5000)
 print("synthetic session: %d keyframes x %d points (%.1f s to generate)" % (K, a.pts, time.perf_counter() - t0), flush=True)
 coarse = vxba.VoxelizeParams(voxel_size=2.0, max_layer=2, min_points=10, min_eigen_value=0.02, eigen_ratio=(1 / 9, 1 / 9, 1 / 9, 1 / 9))
 fine = vxba.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))

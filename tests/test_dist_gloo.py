@@ -191,3 +191,129 @@ def test_eight_rank_sharded_window_matches_single_process(tmp_path):
     assert np.array_equal(r[0]["trace"][:, 6:], ref["trace"][:, 6:])
     et, er = synth.pose_errors(r[0]["poses"], ref["poses"])
     assert et < 1e-10 and er < 1e-10
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: hierarchical global BA over the ranks (dist.hierarchical_ba_sharded), the oracle standing in for each rank's GPU
+# ------------------------------------------------------------------------------------------------------------------------------
+HBA_CASE = dict(K=45, wdsize=6, mgsize=3, pts=3000)
+
+
+def _hba_session():
+    from voxel_slam_amd import synth, vxba
+    c = HBA_CASE
+    xyz, fp, poses, gt = synth.make_scans(win_size=c["K"], pts_per_scan=c["pts"], extent=24.0, noise=0.005, seed=synth.MASTER_SEED + 995,
+                                          rot_sigma_deg=0.1, trans_sigma=0.02)
+    clouds = [xyz[fp[i]:fp[i + 1]].astype(np.float32) for i in range(c["K"])]
+    coarse = vxba.VoxelizeParams(voxel_size=2.0, max_layer=2, min_points=10, min_eigen_value=0.02, eigen_ratio=(1 / 9, 1 / 9, 1 / 9, 1 / 9))
+    fine = vxba.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
+    return clouds, poses, gt, coarse, fine
+
+
+class _OracleOpt:
+    def damping_iter(self, xs, f, max_iter=4):
+        return f.damping_iter(xs, max_iter=max_iter, thd_num=2)
+
+
+def _oracle_voxelize(W, shard=None):
+    """The oracle's OctreeGBA walk; with shard = (index, count) only the root voxels that hash to `index` are kept -- what
+    vxba_voxelize_push does on a rank's GPU with VoxelizeParams.sharded(index, count)."""
+    from tests import _oracle as O
+    from voxel_slam_amd import dist as vdist
+
+    def go(xyz, fp, xs, params):
+        r = O.voxelize(W, xyz, fp, xs, params.as_array())
+        ids = r["node_id"]
+        order = np.lexsort((ids, (ids & np.uint64(7)).astype(np.int64)))      # push order of the GPU path: by layer, ascending id inside a layer
+        if shard is not None:
+            keep = vdist.root_shard(ids[order] >> np.uint64(16), shard[1]) == shard[0]
+            order = order[keep]
+        n = order.size
+        f = O.Oracle(W)
+        if n:
+            f.push_voxels(r["clusters"][order], np.zeros((n, 10)), np.ones(n), r["eig_val"][order], r["eig_vec"][order], r["merged"][order])
+        return f, n
+    return go
+
+
+def _hba_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    from tests import _oracle as O
+    from voxel_slam_amd import dist as vdist, hba
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    clouds, poses, gt, coarse, fine = _hba_session()
+    c = HBA_CASE
+    n_coll = {"packed": 0}
+
+    class ShardedOpt:          # the LM shell over this rank's shard: sweeps by the oracle, sums by all-reduce (what the wide factor + RCCL do on a GPU)
+        def damping_iter(self, xs, f, max_iter=4):
+            W = xs.shape[0]
+            zero = (np.zeros((6 * W, 6 * W)), np.zeros(6 * W), 0.0)
+
+            def hess(x):
+                n_coll["packed"] += 1
+                return f.acc_evaluate2(x) if f.size() else zero
+
+            return vdist.damping_iter_sharded(W, xs, hess, lambda x: f.evaluate_only_residual(x) if f.size() else 0.0, max_iter=max_iter)
+
+    def bottom_refine(xyz, fp, xs):
+        return hba.window_refine(xyz, fp, xs, coarse, fine, max_iter=1, optimizer=_OracleOpt(), voxelize=_oracle_voxelize(c["wdsize"]))
+
+    def top_refine(xyz, fp, xs, si, sc):
+        return hba.window_refine(xyz, fp, xs, coarse, fine, max_iter=2, optimizer=ShardedOpt(), voxelize=_oracle_voxelize(xs.shape[0], (si, sc)))
+
+    out = vdist.hierarchical_ba_sharded(clouds, poses, coarse, fine, wdsize=c["wdsize"], mgsize=c["mgsize"], top_max_iter=2, bottom_refine=bottom_refine,
+                                        top_refine=top_refine, downsample=O.down_sampling_voxel)
+    np.savez(os.path.join(outdir, f"hba{rank}.npz"), submap_poses=out["submap_poses"], submap_sizes=np.asarray(out["submap_sizes"]),
+             n_edges=np.asarray([len(out["edges1"]), len(out["edges2"])]), windows=np.asarray(out["windows_of_rank"]),
+             top_voxels=np.asarray([r["n_voxels"] for r in out["top_rounds"]]), top_resis=np.asarray([r["resis"] for r in out["top_rounds"]]),
+             edge2_v6=np.asarray([e["v6"] for e in out["edges2"]]), n_packed=n_coll["packed"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_hierarchical_ba_over_ranks_matches_single_process(tmp_path, world):
+    """configs[4]'s schedule on `world` ranks: bottom-level windows round-robin (replicas), submaps all-gathered, the top-level window
+    voxel-sharded by root-voxel hash with one all-reduce of the packed system per sweep.  Every rank must end on the same submap poses
+    BIT FOR BIT; the shards must partition the single-process factor set exactly (voxel counts add up, round by round); poses and edge
+    weights must equal the single-process run (hba.hierarchical_ba on the oracle) to round-off -- the shards sum in another order."""
+    import torch.multiprocessing as mp
+    from tests import _oracle as O
+    from voxel_slam_amd import hba, synth
+
+    port = _free_port()
+    mp.spawn(_hba_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"hba{k}.npz") for k in range(world)]
+    clouds, poses, gt, coarse, fine = _hba_session()
+    c = HBA_CASE
+    ref = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=c["wdsize"], mgsize=c["mgsize"], top_max_iter=2, optimizer=_OracleOpt(),
+                              voxelize=_oracle_voxelize, downsample=O.down_sampling_voxel)
+    S = (c["K"] - c["wdsize"]) // c["mgsize"] + 1
+    assert sorted(int(w) for k in range(world) for w in r[k]["windows"]) == list(range(S))          # every window ran exactly once
+    for k in range(world):
+        assert [int(w) % world for w in r[k]["windows"]] == [k] * len(r[k]["windows"])
+        assert np.array_equal(r[k]["submap_poses"], r[0]["submap_poses"])                             # bit for bit across ranks
+        assert np.array_equal(r[k]["submap_sizes"], np.asarray(ref["submap_sizes"]))                 # the bottom level is the single-process one
+        assert np.array_equal(r[k]["n_edges"], r[0]["n_edges"]) and int(r[k]["n_packed"]) == int(r[0]["n_packed"])
+        assert np.array_equal(r[k]["top_resis"], r[0]["top_resis"])
+    # the shards partition the factor set of every top-level round
+    assert np.array_equal(sum(r[k]["top_voxels"] for k in range(world)), np.asarray([x["n_voxels"] for x in ref["top_rounds"]]))
+    assert all((r[k]["top_voxels"] > 0).all() for k in range(world)) or world == 8
+    assert [int(x) for x in r[0]["n_edges"]] == [len(ref["edges1"]), len(ref["edges2"])]
+    et, er = synth.pose_errors(r[0]["submap_poses"], ref["submap_poses"])
+    assert et < 1e-9 and er < 1e-9, (et, er)
+    assert np.allclose(r[0]["top_resis"], np.asarray([x["resis"] for x in ref["top_rounds"]]), rtol=1e-9)
+    assert np.allclose(r[0]["edge2_v6"], np.asarray([e["v6"] for e in ref["edges2"]]), rtol=1e-6)
+
+
+def test_root_shard_is_the_device_function():
+    """dist.root_shard (numpy) against the definition in csrc/vxba_voxelize.h: ((root48 * 0x9E3779B97F4A7C15) mod 2^64 >> 32) mod count."""
+    from voxel_slam_amd.dist import root_shard
+    rng = np.random.default_rng(5)
+    roots = rng.integers(0, 1 << 48, size=2000, dtype=np.uint64)
+    for count in (2, 3, 8):
+        want = np.array([(((int(x) * 0x9E3779B97F4A7C15) & ((1 << 64) - 1)) >> 32) % count for x in roots])
+        got = root_shard(roots, count)
+        assert np.array_equal(got, want)
+        assert np.bincount(got, minlength=count).min() > 2000 // count * 0.7          # spreads evenly

@@ -39,3 +39,24 @@ def test_two_process_ranks_reproduce_the_single_factor_run(spec, collective):
             assert a == b, ln
             if "lm_steps_easy" in ln:
                 assert "'rejected': 0" in a, ln
+
+
+@pytest.mark.parametrize("world,K,wd,mg", [(2, 45, 6, 3), (3, 105, 10, 5)])
+def test_hierarchical_ba_sharded_over_process_ranks(world, K, wd, mg):
+    """BASELINE configs[4]'s multi-rank driver on real GPU code paths (ranks = processes on one GPU, gloo): the top-level window is filtered to
+    the rank's root voxels ON THE DEVICE (vxba_voxelize_params.shard_*), held as a wide factor per rank and summed through the all-reduce
+    hook.  Against the single-process hba.hierarchical_ba: identical submaps, shards that partition every round's factor set, the same
+    poses on all ranks bit for bit and within round-off of the single-process ones.  (105 keyframes / 10 / 5: a 20-pose wide top level.)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HBA_K=str(K), HBA_WD=str(wd), HBA_MG=str(mg))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
+                          str(29580 + world), os.path.join(ROOT, "scripts", "dbg_two_rank_hba.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    recs = [r for r in re.split(r"(?=rank \d hba_sharded:)", out.stdout) if r.startswith("rank ")]
+    assert len(recs) == world, out.stdout[-2000:]
+    for ln in recs:
+        m = re.search(r"pose diff ([0-9.e+-]+) ([0-9.e+-]+), same bits on all ranks (\w+), top voxels per round (\[[^\]]*\]) sum (\[[^\]]*\]) vs (\[[^\]]*\]), submap sizes equal (\w+), edges (\d+) (\d+) vs (\d+) (\d+)", ln)
+        assert m, ln
+        assert float(m.group(1)) < 1e-8 and float(m.group(2)) < 1e-8, ln
+        assert m.group(3) == "True" and m.group(7) == "True", ln
+        assert m.group(5) == m.group(6), ln                      # the shards partition the factor set of every round
+        assert (m.group(8), m.group(9)) == (m.group(10), m.group(11)), ln

@@ -513,6 +513,8 @@ static int voxelize_push_impl(vxba_factor* f, int64_t n_points, const double* xy
   vp.min_eigen_value = params->min_eigen_value; vp.factor_ratio_max = params->factor_ratio_max;
   for (int k = 0; k < 4; k++) { vp.eigen_ratio[k] = params->eigen_ratio[k]; vp.min_points_layer[k] = params->min_points_layer[k]; }
   vp.min_frames = params->min_frames;
+  vp.shard_index = params->shard_index; vp.shard_count = params->shard_count;
+  if (vp.shard_count > 1 && (vp.shard_index < 0 || vp.shard_index >= vp.shard_count)) return fail(f, VXBA_ERR_ARG, "voxelize_push: shard_index outside 0 .. shard_count-1");
   vxv::VoxelizeOutput out{cap, d_cl, d_ev, d_evec, d_m, d_id};
   if (csr) { out.d_row_ptr = d_rp; out.d_eframe = d_ef; out.ecap = n_points; }
   const char* emsg = nullptr;

@@ -269,7 +269,11 @@ bool finalize_in_launch(const vxba_factor* f) {
 int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c, const vxk::LMPending* pend, int head, int end,
                       double* d_out, const double* cache_src, vxk::FinArgs* defer_fin) {
   const size_t plen = vxba_packed_len(f);
-  if (end == head) { VX_HIP(f, hipMemsetAsync(d_out, 0, plen * sizeof(double), f->stream)); return VXBA_OK; }
+  if (end == head) {
+    VX_HIP(f, hipMemsetAsync(d_out, 0, plen * sizeof(double), f->stream));
+    // a rank whose shard of a voxel-sharded wide window came out empty still takes part in the sum (the other ranks are waiting in it)
+    return (is_wide(f) && !lm && has_collective(f)) ? shard_allreduce(f, d_out, plen) : VXBA_OK;
+  }
   if (is_wide(f)) {   // sparse-incidence sweep, host-driven LM only (lm == nullptr)
     if (lm || !Rp) return fail(f, VXBA_ERR_UNSUPPORTED, "device-resident LM loop: only for win_size <= VXBA_MAX_WIN");
     int rcw = upload_poses(f, Rp);
@@ -329,7 +333,10 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c
 // with host_sum_partials once the sweep is done (d_out is ignored).
 int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int c, int head, int end, double* d_out,
                           int* nparts_out, unsigned fused_seq, bool partials_to_host, const vxk::FinArgs* fin) {
-  if (end == head) { if (d_out) VX_HIP(f, hipMemsetAsync(d_out, 0, sizeof(double), f->stream)); return VXBA_OK; }
+  if (end == head) {
+    if (d_out) VX_HIP(f, hipMemsetAsync(d_out, 0, sizeof(double), f->stream));
+    return (is_wide(f) && !lm && d_out && has_collective(f)) ? shard_allreduce(f, d_out, 1) : VXBA_OK;
+  }
   if (is_wide(f)) {
     if (lm || !Rp || !d_out) return fail(f, VXBA_ERR_UNSUPPORTED, "device-resident LM loop: only for win_size <= VXBA_MAX_WIN");
     int rcw = upload_poses(f, Rp);

@@ -14,7 +14,7 @@ static int damping_iter_impl(vxba_factor* f, double* Rp, int max_iter, double* h
                              int* is_converge) {
   VX_LOCK(f);
   if (!f || !Rp || max_iter < 0 || max_iter > vxk::LM_MAX_ITER) return fail(f, VXBA_ERR_ARG, "damping_iter: bad argument (max_iter <= 64)");
-  if (f->V == 0) return fail(f, VXBA_ERR_STATE, "damping_iter on an empty factor");
+  if (f->V == 0 && !(is_wide(f) && has_collective(f))) return fail(f, VXBA_ERR_STATE, "damping_iter on an empty factor");   // an empty SHARD of a wide window sums zeros
   hipSetDevice(f->device);
   if (is_wide(f)) {
     // wide window (voxel_map.hpp:367-442 unchanged in structure): sweeps on the GPU; the damped (6W)-dimensional step by a dense

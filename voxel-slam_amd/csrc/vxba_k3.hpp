@@ -454,6 +454,9 @@ __device__ __forceinline__ void k3_sum_linear(const double* park_d, double* out,
 #define K3_LATE_REQUESTS 1   // round 4: the default (cfg4 156.6 -> 147.4 us, cfg3 44.5 -> 43.2, cfg2 unchanged; same-box A/B, gpurun_out/r4_s3.log)
 #endif
 constexpr bool K3_LATE_REQ = K3_LATE_REQUESTS != 0;
+#ifndef K3_LATE_MIXED
+#define K3_LATE_MIXED 0
+#endif
 #ifndef K3_LATE_PER
 #define K3_LATE_PER 4      // requests behind each K-step of phase M: all eight behind the first two of the nine K-steps at W = 10 (1 and 2 per K-step measured slower: later requests land later)
 #endif
@@ -465,7 +468,8 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
 
   using C = K3Cfg<W>;
   // window sizes without spare tile columns (W = 5, 8) carry 15 more accumulators: no registers left for requests in flight across phase M
-  constexpr bool LATE = K3_LATE_REQ && C::SPARE;
+  // (mixed precision: phase M is half as long -- f32 products -- and the requests in front of it landed late: cfg3 mixed 35.6 -> 37.0 us; it keeps them in front of the barrier)
+  constexpr bool LATE = K3_LATE_REQ && C::SPARE && !(MIXED && !K3_LATE_MIXED);
   extern __shared__ __attribute__((aligned(16))) double lds[];  // two tile buffers; reused by the epilogue
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // tell the compiler it is wave-uniform: scalar branches, descriptors in SGPRs

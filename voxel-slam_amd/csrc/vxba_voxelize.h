@@ -15,6 +15,8 @@ struct VoxelizeParams {
   double factor_ratio_max;     // factor filter: lambda0 / lambda1 <= factor_ratio_max
   int min_points_layer[4];     // > 0: per-layer override of min_points (OctoTree's min_point[layer])
   int min_frames;              // observing frames a factor needs (OctreeGBA: 2, OctoTree: 0)
+  int shard_index, shard_count; // shard_count > 1: keep only the points whose ROOT voxel hashes to shard_index (vxv::root_shard) -- a rank's share of a
+                                // voxel-sharded window (whole root voxels, so every factor voxel of the unsharded run appears on exactly one shard, bit for bit)
 };
 
 // Device staging arrays for the accepted voxels (AoS, the formats of vxba_push_voxels), capacity in voxels.
@@ -36,6 +38,11 @@ struct VoxelizeOutput {
 };
 
 // Returns the number of factor voxels written (grouped by layer, ascending node key inside a layer) or -1 (*err set).
+// shard of a root voxel: [x:16 | y:16 | z:16] (coordinates offset by 32768) -> 0 .. count-1.  Fibonacci hash of the 48-bit root, so that the
+// spatially contiguous roots of a scene spread evenly.  voxel_slam_amd.dist.root_shard is the same function in numpy.
+inline __host__ __device__ int root_shard(unsigned long long root48, int count) {
+  return (int)(((root48 * 0x9E3779B97F4A7C15ull) >> 32) % (unsigned long long)count);
+}
 long long voxelize(int W, long long n_points, const double* d_xyz_local, const long long* d_frame_ptr, const double* d_poses /* W*12 */, const VoxelizeParams& p,
                    hipStream_t s, VoxelizeOutput* out, const char** err);
 

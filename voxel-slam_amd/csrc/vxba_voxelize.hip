@@ -63,6 +63,21 @@ __global__ void key_kernel(const double* __restrict__ xyz, const long long* __re
   key[q] = (root << (PATH_BITS + FRAME_BITS)) | (path << FRAME_BITS) | (unsigned long long)f;
 }
 
+// voxel-sharded windows: 1 for the points of this shard's root voxels, then their compaction to the front (order kept)
+__global__ void shard_flag_kernel(const unsigned long long* __restrict__ key, long long n, int shard_index, int shard_count, unsigned int* __restrict__ flag) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) flag[q] = root_shard(key[q] >> (PATH_BITS + FRAME_BITS), shard_count) == shard_index ? 1u : 0u;
+}
+__global__ void shard_compact_kernel(const unsigned int* __restrict__ flag, const unsigned int* __restrict__ pos, long long n, const double* __restrict__ loc,
+                                     const double* __restrict__ wld, const unsigned long long* __restrict__ key, double* __restrict__ loc_c,
+                                     double* __restrict__ wld_c, unsigned long long* __restrict__ key_c) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n || !flag[q]) return;
+  const unsigned int o = pos[q];
+  for (int k = 0; k < 3; k++) { loc_c[3 * o + k] = loc[3 * q + k]; wld_c[3 * o + k] = wld[3 * q + k]; }
+  key_c[o] = key[q];
+}
+
 // key of the (node at layer l, frame) cell: the octant bits below layer l are cleared
 __global__ void layer_key_kernel(const unsigned long long* __restrict__ key, long long n, int layer, unsigned long long* __restrict__ out,
                                  unsigned int* __restrict__ idx) {
@@ -252,7 +267,9 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
   static const char* range_msg = "voxelize: a point lies outside the +-32768-voxel range of the 16-bit voxel coordinates";
   static const char* cap_msg = "voxelize: more factor voxels than the caller's capacity";
   DevBuf B;
-  const long long n = n_points;
+  long long n = n_points;
+  const bool sharded = p.shard_count > 1;
+  if (sharded && (p.shard_index < 0 || p.shard_index >= p.shard_count)) { *err_out = "voxelize: shard_index outside 0 .. shard_count-1"; return -1; }
   // rocPRIM temporary storage: query the largest need first (size queries do not touch the pointers)
   size_t tb = 0;
   {
@@ -268,7 +285,7 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
     if (tb_scan32 > tb) tb = tb_scan32;
   }
   // worst case (every point its own cell): < 0.5 KB of scratch per point
-  VV(B.reserve((size_t)(n + 64) * 512 + tb + (size_t)(1 << 20)));
+  VV(B.reserve((size_t)(n + 64) * (sharded ? 576 : 512) + tb + (size_t)(1 << 20)));
   double *d_world, *d_loc_s, *d_wld_s;
   unsigned long long *d_key, *d_lkey, *d_lkey_s;
   unsigned int *d_idx, *d_idx_s;
@@ -298,6 +315,24 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
   VV(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, s));
   VV(hipStreamSynchronize(s));
   if (h_err) { *err_out = range_msg; return -1; }
+  if (sharded && n > 0) {
+    // this shard's points to the front, cloud order kept (the cluster sums below are in point order): everything behind works on the n_keep
+    // points of whole root voxels, so each of its factor voxels is bit for bit the one the unsharded run produces
+    double *d_loc_c, *d_wld_c;
+    unsigned long long* d_key_c;
+    VV(B.alloc(&d_loc_c, 3 * n)); VV(B.alloc(&d_wld_c, 3 * n)); VV(B.alloc(&d_key_c, n));
+    shard_flag_kernel<<<grid_for(n), 256, 0, s>>>(d_key, n, p.shard_index, p.shard_count, d_flag);
+    size_t t = tb;
+    VV(rocprim::exclusive_scan(d_temp, t, d_flag, d_pos, 0u, (size_t)n, rocprim::plus<unsigned int>(), s));
+    unsigned int last[2] = {0, 0};
+    VV(hipMemcpyAsync(&last[0], d_pos + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    VV(hipMemcpyAsync(&last[1], d_flag + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    shard_compact_kernel<<<grid_for(n), 256, 0, s>>>(d_flag, d_pos, n, d_xyz_local, d_world, d_key, d_loc_c, d_wld_c, d_key_c);
+    VV(hipStreamSynchronize(s));
+    n = (long long)last[0] + (long long)last[1];
+    d_xyz_local = d_loc_c; d_world = d_wld_c; d_key = d_key_c;
+    if (n == 0) { out->n_entries = 0; return 0; }
+  }
 
   long long total = 0, total_entries = 0;
   long long* d_epos = nullptr;

@@ -181,3 +181,134 @@ def damping_iter_sharded(win_size: int, x_stats, local_hess, local_resid, max_it
         return float(buf[0])
 
     return vxba.damping_iter_generic(win_size, x_stats, hess_fn, resid_fn, max_iter=max_iter)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: the hierarchical global BA over the GPUs of one node
+# ---------------------------------------------------------------------------------------------------------------------------------
+def root_shard(root48, count: int):
+    """Shard of a root voxel ``[x:16 | y:16 | z:16]`` (coordinates offset by 32768): the numpy twin of ``vxv::root_shard``
+    (csrc/vxba_voxelize.h) -- Fibonacci hash of the 48-bit root modulo ``count``.  Accepts node ids' upper 48 bits (``id >> 16``)."""
+    r = np.asarray(root48, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = (r * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(32)
+    return (h % np.uint64(count)).astype(np.int64)
+
+
+def _gather_arrays(arrs, group=None):
+    """all_gather of a list of variable-length float32 (n_i, 3) arrays per rank -> list over ranks of lists; any backend (tensors on the
+    GPU for RCCL, on the host for gloo)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    sizes = [None] * world
+    dist.all_gather_object(sizes, [int(a.shape[0]) for a in arrs], group=group)
+    mine = np.concatenate(arrs).astype(np.float32) if arrs else np.zeros((0, 3), np.float32)
+    cap = max(1, max(sum(s) for s in sizes))
+    buf = torch.zeros((cap, 3), dtype=torch.float32, device=dev)
+    buf[: mine.shape[0]] = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
+    outs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)
+    res = []
+    for r in range(world):
+        flat = outs[r].cpu().numpy()
+        o, parts = 0, []
+        for n in sizes[r]:
+            parts.append(flat[o:o + n].copy()); o += n
+        res.append(parts)
+    return res
+
+
+def hba_ctx_close(ctx: dict):
+    """Release what ``hierarchical_ba_sharded`` keeps in ``ctx`` (factors first, then the tensors / stream their collective hook uses)."""
+    for k in [k for k in ctx if k[0] in ("bottom", "top")]:
+        ctx.pop(k).close()
+    ctx.clear()
+
+
+def hierarchical_ba_sharded(clouds, poses, coarse, fine, wdsize: int = 10, mgsize: int = 5, top_max_iter: int = 1, device: int = 0, group=None,
+                            bottom_refine=None, top_refine=None, downsample=None, ctx: dict | None = None):
+    """``hba.hierarchical_ba`` (thd_globalmapping's bottom-up pass, voxelslam.cpp:2485-2595) over the ranks of ``group``, one process per GPU:
+
+    * **bottom level** -- the windows of ``wdsize`` keyframes (stride ``mgsize``; 99 of them at BASELINE configs[4]) are independent
+      ``HBA_add_edge`` problems: window w runs on rank ``w % world`` as a replica of the single-GPU path, no exchange inside it;
+    * the merged, voxel-filtered submaps and the windows' pose-graph edges are all-gathered (every rank needs every submap next);
+    * **top level** -- ONE window over all submap poses (W ~ 99: the wide-window path), voxel-sharded: every rank voxelises the same points
+      but keeps the root voxels that hash to it (``VoxelizeParams.sharded``; filtered on the device before the sorts), holds that shard of
+      factor voxels in its HBM, and the packed ``[Hess | JacT | residual]`` buffer ((6W)^2 + 6W + 1 doubles = 2.88 MB at W = 99) is summed
+      by ONE all-reduce per sweep -- the "multi-level Hessian reduction": wave -> workgroup -> grid -> RCCL.  At this size RCCL picks
+      reduce-scatter + all-gather over all seven xGMI links by itself; the factor calls ``ncclAllReduce`` directly (``attach_rccl``) or goes
+      through ``attach_allreduce``'s hook.  After the all-reduce every rank holds the same system and takes the same LM decisions, so the
+      refined submap poses are identical on all ranks, bit for bit.
+
+    ``bottom_refine(xyz, fp, poses) -> dict(poses, hess, rounds)`` and ``top_refine(xyz, fp, poses, shard_index, shard_count) -> the same``
+    replace the GPU path in the CPU tests (gloo): the oracle stands in for a rank's GPU.  ``ctx``: a dict that keeps the two factors (and the
+    top-level factor's communicator) alive between calls -- a mapper that runs pass after pass creates them once; release with
+    ``hba_ctx_close(ctx)``.  Returns what ``hba.hierarchical_ba`` returns, plus ``windows_of_rank``."""
+    import torch.distributed as dist
+
+    from . import hba, vxba
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    K = poses.shape[0]
+    bases = list(range(0, K - wdsize + 1, mgsize))
+    mine = [w for w in range(len(bases)) if w % world == rank]
+    bottom = None
+    own = ctx is None
+    ctx = {} if ctx is None else ctx
+    if bottom_refine is None:
+        bottom = ctx.get(("bottom", wdsize)) or vxba.LidarFactor(wdsize, device=device)
+        ctx[("bottom", wdsize)] = bottom
+
+        def bottom_refine(xyz, fp, xs):
+            return hba.window_refine(xyz, fp, xs, coarse, fine, max_iter=1, device=device, factor=bottom)
+    my_sub, my_edges = [], []
+    for w in mine:
+        ids = list(range(bases[w], bases[w] + wdsize))
+        xyz = np.ascontiguousarray(np.concatenate([np.asarray(clouds[i], dtype=np.float64) for i in ids]))
+        fp = np.concatenate([[0], np.cumsum([len(clouds[i]) for i in ids])]).astype(np.int64)
+        r = bottom_refine(xyz, fp, poses[ids])
+        my_edges.append([dict(e, i=ids[e["i"]], j=ids[e["j"]]) for e in hba.edges_from_hessian(r["poses"], r["hess"])])
+        my_sub.append(hba.merge_submap([clouds[i] for i in ids], r["poses"], fine.voxel_size, downsample=downsample, device=device))
+    # every rank needs every submap for the top level; the edges are small
+    all_sub = _gather_arrays(my_sub, group)
+    all_edges = [None] * world
+    dist.all_gather_object(all_edges, my_edges, group=group)
+    sub_clouds, edges1 = [], []
+    for w in range(len(bases)):
+        r, k = w % world, w // world
+        sub_clouds.append(all_sub[r][k])
+        edges1.extend(all_edges[r][k])
+    S = len(bases)
+    top_xyz = np.ascontiguousarray(np.concatenate(sub_clouds).astype(np.float64))
+    top_fp = np.concatenate([[0], np.cumsum([len(c) for c in sub_clouds])]).astype(np.int64)
+    sub_ids = bases
+    if top_refine is None:
+        topf = ctx.get(("top", S))
+        if topf is None:
+            topf = ctx[("top", S)] = vxba.LidarFactor(S, device=device)
+        if world > 1 and ("keep", S) not in ctx:
+            keep = None
+            try:
+                attach_rccl(topf, group) if dist.get_backend(group) == "nccl" else None
+                ok = dist.get_backend(group) == "nccl"
+            except Exception:      # noqa: BLE001 -- fall back together below
+                ok = False
+            import torch
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            if not int(t.item()):
+                if ok:
+                    topf.rccl_detach()
+                keep = attach_allreduce(topf, group)
+            ctx[("keep", S)] = keep
+
+        def top_refine(xyz, fp, xs, si, sc):
+            return hba.window_refine(xyz, fp, xs, coarse.sharded(si, sc), fine.sharded(si, sc), max_iter=top_max_iter, device=device, factor=topf)
+    top = top_refine(top_xyz, top_fp, poses[sub_ids], rank, world)
+    if own:
+        hba_ctx_close(ctx)
+    edges2 = [dict(e, i=sub_ids[e["i"]], j=sub_ids[e["j"]]) for e in hba.edges_from_hessian(top["poses"], top["hess"])]
+    return dict(edges1=edges1, edges2=edges2, submap_ids=sub_ids, submap_poses=top["poses"], submap_sizes=[len(c) for c in sub_clouds], top_rounds=top["rounds"],
+                windows_of_rank=mine)

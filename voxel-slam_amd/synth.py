@@ -432,3 +432,34 @@ def make_lio_scan(pm: PlaneMapData, n_points=20_000, noise=0.02, clutter_frac=0.
     M = rng.normal(size=(15, 15)) * 1e-3       # a propagated covariance is not diagonal
     cov = cov + 0.02 * (M @ M.T)
     return LioScan(xyz, st(R_gt, p_gt), st(R0, p0), cov)
+
+
+# BASELINE configs[4]: a long session for the hierarchical global BA (scripts/run_cfg5.py, bench.py --config cfg5)
+def corridor_session(K, pts, seed):
+    """A long hall (floor, ceiling, two side walls, all slightly tilted against the voxel grid) with partial cross walls every 10 m,
+    seen by a sensor moving along it with a 30 m range: every keyframe samples only the surfaces around it."""
+    rng = np.random.Generator(np.random.PCG64([seed, 7]))
+    axis = np.array([0.2, 0.1, 1.0]); axis /= np.linalg.norm(axis)
+    Rs = np.stack([rodrigues(0.004 * i * axis) for i in range(K)])
+    ps = np.stack([np.array([0.4 * i, 0.6 * np.sin(0.05 * i), 0.1 * np.sin(0.03 * i)]) for i in range(K)])
+    tilt = rodrigues(np.array([0.013, -0.021, 0.017]))
+    clouds = []
+    for i in range(K):
+        x0 = ps[i, 0]
+        n_each = pts // 5
+        u = rng.uniform(x0 - 30, x0 + 30, size=(5, n_each)); v = rng.uniform(0, 1, size=(5, n_each))
+        floor = np.stack([u[0], -8 + 16 * v[0], np.full(n_each, -2.0)], 1)
+        ceil_ = np.stack([u[1], -8 + 16 * v[1], np.full(n_each, 4.0)], 1)
+        wall1 = np.stack([u[2], np.full(n_each, -8.0), -2 + 6 * v[2]], 1)
+        wall2 = np.stack([u[3], np.full(n_each, 8.0), -2 + 6 * v[3]], 1)
+        kx = np.round(u[4] / 10.0) * 10.0                                   # cross walls at x = 10 k, alternating sides, 4 m wide
+        side = np.where((kx / 10.0) % 2 == 0, 1.0, -1.0)
+        cross = np.stack([kx, side * (4 + 4 * v[4]), -2 + 6 * rng.uniform(0, 1, n_each)], 1)
+        w = np.concatenate([floor, ceil_, wall1, wall2, cross]) @ tilt.T
+        w += rng.normal(0, 0.01, size=w.shape)
+        clouds.append(((w - ps[i]) @ Rs[i]).astype(np.float32))
+    gt = pack_poses(Rs, ps)
+    Ri, pi = Rs.copy(), ps.copy()
+    for i in range(1, K):
+        Ri[i] = Rs[i] @ rodrigues(rng.normal(0, np.deg2rad(0.05), size=3)); pi[i] = ps[i] + rng.normal(0, 0.02, size=3)
+    return clouds, pack_poses(Ri, pi), gt

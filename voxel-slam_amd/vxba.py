@@ -50,13 +50,20 @@ class VxbaError(RuntimeError):
 class VoxelizeParams(C.Structure):
     """vxba_voxelize_params: the knobs of OctreeGBA::recut (loop_refine.hpp:311-315, 358-378) and of the voxel grid."""
     _fields_ = [("voxel_size", C.c_double), ("max_layer", C.c_int), ("min_points", C.c_int), ("min_eigen_value", C.c_double),
-                ("eigen_ratio", C.c_double * 4), ("factor_ratio_max", C.c_double), ("min_points_layer", C.c_int * 4), ("min_frames", C.c_int)]
+                ("eigen_ratio", C.c_double * 4), ("factor_ratio_max", C.c_double), ("min_points_layer", C.c_int * 4), ("min_frames", C.c_int),
+                ("shard_index", C.c_int), ("shard_count", C.c_int)]
 
     def __init__(self, voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 16, 1 / 16),
-                 factor_ratio_max=0.12, min_points_layer=(0, 0, 0, 0), min_frames=2):
-        """Defaults: OctreeGBA.  OctoTree's batch build (motion_init): min_points_layer=min_point[layer], min_frames=0."""
+                 factor_ratio_max=0.12, min_points_layer=(0, 0, 0, 0), min_frames=2, shard_index=0, shard_count=0):
+        """Defaults: OctreeGBA.  OctoTree's batch build (motion_init): min_points_layer=min_point[layer], min_frames=0.
+        shard_count > 1: keep the root voxels that hash to shard_index (voxel-sharded windows, one rank per GPU)."""
         super().__init__(voxel_size, max_layer, min_points, min_eigen_value, (C.c_double * 4)(*eigen_ratio), factor_ratio_max,
-                         (C.c_int * 4)(*min_points_layer), min_frames)
+                         (C.c_int * 4)(*min_points_layer), min_frames, shard_index, shard_count)
+
+    def sharded(self, shard_index: int, shard_count: int) -> "VoxelizeParams":
+        """The same parameters for one shard of a voxel-sharded window."""
+        return VoxelizeParams(self.voxel_size, self.max_layer, self.min_points, self.min_eigen_value, tuple(self.eigen_ratio), self.factor_ratio_max,
+                              tuple(self.min_points_layer), self.min_frames, shard_index, shard_count)
 
     def as_array(self):
         return np.array([self.voxel_size, self.max_layer, self.min_points, self.min_eigen_value, *self.eigen_ratio, self.factor_ratio_max,
