@@ -334,6 +334,18 @@ int vxba_map_counts(vxba_map* m, int64_t out[4]);
  * moved to the front of a fresh pool, inside vxba_map_recut / vxba_map_margi) whenever the cursor passes max(4M points, 3 x what was live at
  * the last compaction), so a long mapping session holds a bounded multiple of its live points (the reference frees point_fix vectors instead). */
 int vxba_map_fix_pool(vxba_map* m, int64_t out[3]);
+/* The caller's journey odometer (`jour += spat`, voxelslam.cpp:1677).  The next vxba_map_margi stamps it on every root voxel of the slide
+ * map, as multi_margi does (`iter->second->jour = jour`, voxelslam.cpp:1349). */
+int vxba_map_set_journey(vxba_map* m, double jour);
+/* The release branch of the local-mapping loop (voxelslam.cpp:1503-1523; OctoTree::tras_ptr voxel_map.hpp:1394-1405): every root voxel with
+ * int(jour_now - root.jour) >= min_age (700 upstream) leaves the map with its whole subtree.  The node pool is compacted (survivors keep their
+ * relative order, so id-ordered steps see the order they would have seen), child / root references and the voxel table are rebuilt, the
+ * fix-point pool is compacted behind it, and the arrays are re-sized to what is left: device memory follows the map down.  Roots that are in
+ * the slide map are kept whatever their stamp (upstream would delete them under the window's feet).  lio (may be NULL): the odometry handle
+ * whose plane map mirrors this map -- the released roots are cleared there too.  Outputs may be NULL. */
+int vxba_map_release(vxba_map* m, double jour_now, int min_age, vxba_lio* lio, int64_t* n_roots_released, int64_t* n_nodes_released);
+/* Device memory held by the map, bytes: [0] node pool, [1] fix-point pool, [2] resident scans of the window, [3] voxel table + scratch, [4] total. */
+int vxba_map_device_bytes(vxba_map* m, int64_t out[5]);
 /* Every leaf (octo_state == 0), unordered.  ids: [x:16 | y:16 | z:16 | octant path:9 | 0:4 | layer:3] (as vxba_voxelize_push);
  * ints n x 8 = [layer, isexist, is_plane, has window, opt_state, last_num, stored fix points, root in slide map]; dbl n x (156 + 11 W) =
  * [pcr_add 10 | pcr_fix 10 | eig_value 3 | eig_vector 9 | plane centre 3 | normal 3 | radius | plane_var 36 | cov_add 81 | window

@@ -237,3 +237,84 @@ def test_whole_scan_cycle_on_the_device_matches_the_oracle_cycle(vx):
         n_exp = mg.export_planes(ge)
         assert n_exp > 0
     assert estimated >= 4
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# release of far-away roots (vxba_map_release; voxelslam.cpp:1503-1523) on a long drive
+# ------------------------------------------------------------------------------------------------------------------------------------------
+def _corridor_scan(k, pts, rng):
+    """Scan k of a drive along x (0.5 m per scan): floor, two walls and a cross wall every 10 m, sensor range 6 m; body frame = world - position."""
+    x0 = 0.5 * k
+    n = pts // 4
+    u = rng.uniform(x0 - 6, x0 + 6, size=(3, n)); v = rng.uniform(0, 1, size=(4, n))
+    floor = np.stack([u[0], -4 + 8 * v[0], np.full(n, -1.5)], 1)
+    wall1 = np.stack([u[1], np.full(n, -4.0), -1.5 + 4 * v[1]], 1)
+    wall2 = np.stack([u[2], np.full(n, 4.0), -1.5 + 4 * v[2]], 1)
+    kx = np.round(rng.uniform(x0 - 6, x0 + 6, size=n) / 10.0) * 10.0 + 0.3
+    cross = np.stack([kx, -4 + 3 * v[3], -1.5 + 4 * rng.uniform(0, 1, n)], 1)
+    w = np.concatenate([floor, wall1, wall2, cross]) + rng.normal(0, 0.01, size=(4 * n, 3))
+    p = np.array([x0, 0.0, 0.0])
+    pose = np.concatenate([np.eye(3).reshape(-1), p])
+    return w - p, pose
+
+
+def test_release_of_far_roots_bounds_the_map_on_a_long_drive(vx):
+    """2000 scans along a 1 km corridor, window 5, release every 100 scans of every root not marginalised for 60 journeys (metres here; 700
+    upstream).  Two maps side by side, one released and one not: (1) the released map's leaves are, field for field and BIT FOR BIT, the
+    leaves of the unreleased map under the roots it kept -- compaction is pure relocation, also of the fix-point pool; (2) its root count,
+    node count and device memory stay bounded while the other map's grow with the distance; (3) the factor it hands to the BA is the same."""
+    win, pts, S = 5, 4000, 2000
+    rng = np.random.default_rng(77)
+    kw = dict(PRM); kw["max_points"] = 60
+    ma, mb = vx.LocalMap(win_size=win, **kw), vx.LocalMap(win_size=win, **kw)      # a: released, b: grows
+    fa, fb = vx.LidarFactor(win), vx.LidarFactor(win)
+    xs = []
+    win_count = 0
+    jour = 0.0
+    hist = []
+    released_total = 0
+    for k in range(S):
+        body, pose = _corridor_scan(k, pts, rng)
+        var = point_vars(body.shape[0], k)
+        xs.append(pose)
+        win_count += 1
+        wld = to_world(pose, body)
+        na = nb = 0
+        for m, f in ((ma, fa), (mb, fb)):
+            f.clear()
+            m.cut_voxel(win_count - 1, body, var, wld)
+            n = m.recut(win_count, np.stack(xs), f)
+            if m is ma:
+                na = n
+            else:
+                nb = n
+        if win_count >= win:
+            # same root set under the window on both maps => the same factor voxels (ids are compared through the leaves below)
+            assert na == nb > 0, (k, na, nb)
+            for m, f in ((ma, fa), (mb, fb)):
+                f.evaluate_only_residual(np.stack(xs))      # the cache margi reads (no BA here: poses are exact)
+                m.set_journey(jour)
+                m.margi(win_count, np.stack(xs), f)
+                m.slide(1)
+            xs = xs[1:]; win_count -= 1
+            jour += 0.5
+        if k % 100 == 99:
+            r = ma.release(jour, 60)
+            released_total += r["roots"]
+            ca, cb = ma.counts(), mb.counts()
+            hist.append((k, ca["roots"], cb["roots"], ma.device_bytes()["total"], mb.device_bytes()["total"], r["roots"], r["nodes"]))
+            la, lb = ma.leaves(), mb.leaves()
+            keep = np.isin(lb["node_id"] >> np.uint64(16), np.unique(la["node_id"] >> np.uint64(16)))
+            assert keep.sum() == la["node_id"].size, (k, int(keep.sum()), la["node_id"].size)
+            assert released_total == 0 or keep.sum() < lb["node_id"].size
+            for key, va in la.items():
+                if isinstance(va, np.ndarray) and va.shape[:1] == la["node_id"].shape:
+                    assert np.array_equal(va, lb[key][keep]), (k, key)
+    assert released_total > 500
+    roots_a = np.array([h[1] for h in hist]); roots_b = np.array([h[2] for h in hist]); bytes_a = np.array([h[3] for h in hist]); bytes_b = np.array([h[4] for h in hist])
+    assert roots_b[-1] > 5 * roots_a[-1]                                   # the unreleased map holds the whole corridor
+    assert roots_a[5:].max() <= 1.3 * roots_a[5:].min() + 50              # steady state: what the last 60 m + the window hold
+    assert bytes_a[5:].max() <= 1.6 * bytes_a[5:].min()                    # memory follows the map: bounded ...
+    assert bytes_b[-1] > 2 * bytes_a[-1]                                   # ... while the other pool only grows
+    fp = ma.fix_pool()
+    assert fp["compactions"] >= 10 and fp["cursor"] <= fp["capacity"]

@@ -31,6 +31,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -62,6 +63,7 @@ struct Nodes {
   int *layer, *state, *child, *root, *isexist, *has_sw, *is_plane, *last_num, *opt_state, *in_slide, *stamp, *path, *dirty;
   unsigned long long* key;     // root key (x,y,z offset by LOC_OFF, 16 bits each)
   double *center, *pcr_add, *pcr_fix, *cov_add, *eigval, *eigvec, *pl_center, *pl_normal, *pl_radius, *pl_var, *pcrs_local;
+  double* jour;               // roots: the journey at the last multi_margi that saw the root in the slide map (OctoTree::jour, voxelslam.cpp:1349)
   float* ql;
   int *pt_start, *pt_count;    // [node][slot]
   long long* fix_start;
@@ -797,10 +799,63 @@ __global__ void map_release_kernel(Nodes nd, int W, int n_nodes) {
   }
   nd.has_sw[i] = 0;
 }
-__global__ void map_leave_slide_kernel(Nodes nd, int n_nodes, Counters* cnt) {
+__global__ void map_leave_slide_kernel(Nodes nd, int n_nodes, Counters* cnt, double jour) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes || nd.root[i] != i || nd.layer[i] != 0) return;
+  if (nd.in_slide[i]) nd.jour[i] = jour;       // `iter->second->jour = jour` for every root of the slide map (voxelslam.cpp:1349), leaving or not
   if (nd.in_slide[i] && !nd.isexist[i]) { nd.in_slide[i] = 0; atomicAdd(&cnt->n_removed, 1); }
+}
+
+// ---- release of far-away roots (voxelslam.cpp:1503-1523, OctoTree::tras_ptr voxel_map.hpp:1394-1405) -------------------------------------
+// keep[i] = 0 for every node under a root that has not been in a multi_margi for `min_age` journeys (int(jour_now - root.jour) >= min_age, the
+// reference's test) -- and is not in the slide map: upstream would delete such a root under the sliding window's feet; here it stays.
+__global__ void map_release_flag_kernel(Nodes nd, int n_nodes, double jour_now, int min_age, unsigned int* __restrict__ keep, Counters* cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const int r = nd.root[i];
+  const int dis = (int)(jour_now - nd.jour[r]);
+  const bool gone = !nd.in_slide[r] && dis >= min_age;
+  keep[i] = gone ? 0u : 1u;
+  if (gone && r == i) atomicAdd(&cnt->n_removed, 1);
+}
+// "nothing here any more" for the odometry's plane map: one layer-0 non-plane entry per released root clears all of its cells
+__global__ void map_release_export_kernel(Nodes nd, int n_nodes, const unsigned int* __restrict__ keep, long long* __restrict__ loc, int* __restrict__ layer, int* __restrict__ path,
+                                          int* __restrict__ is_plane, int* n_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes || keep[i] || nd.root[i] != i) return;
+  const int k = atomicAdd(n_out, 1);
+  const unsigned long long key = nd.key[i];
+  loc[3 * k] = (long long)((key >> 32) & 0xffff) - LOC_OFF; loc[3 * k + 1] = (long long)((key >> 16) & 0xffff) - LOC_OFF; loc[3 * k + 2] = (long long)(key & 0xffff) - LOC_OFF;
+  layer[k] = 0; path[k] = 0; is_plane[k] = 0;
+}
+// gather of one node array into its compacted copy: dst[new(i) * mult + k] = src[i * mult + k] for the nodes that stay
+template <class T>
+__global__ void map_compact_array_kernel(const T* __restrict__ src, T* __restrict__ dst, int n_nodes, int mult, const unsigned int* __restrict__ keep,
+                                         const unsigned int* __restrict__ pos) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (long long)n_nodes * mult) return;
+  const int i = (int)(q / mult), k = (int)(q - (long long)i * mult);
+  if (keep[i]) dst[(size_t)pos[i] * mult + k] = src[q];
+}
+// node references of the compacted pool: children (index + 1, 0 = none) and the root of every node
+__global__ void map_compact_refs_kernel(Nodes nd, int n_new, const unsigned int* __restrict__ pos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_new) return;
+  nd.root[i] = (int)pos[nd.root[i]];
+  for (int o = 0; o < 8; o++) {
+    const int c = nd.child[8 * (size_t)i + o];
+    if (c > 0) nd.child[8 * (size_t)i + o] = (int)pos[c - 1] + 1;
+  }
+}
+__global__ void map_table_insert_roots_kernel(Nodes nd, int n_nodes, unsigned long long* keys, int* vals, unsigned long long cap_mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes || nd.root[i] != i || nd.layer[i] != 0) return;
+  const unsigned long long key = nd.key[i];
+  unsigned long long h = mix64(key) & cap_mask;
+  for (;;) {
+    if (atomicCAS(&keys[h], EMPTY_KEY, key) == EMPTY_KEY) { vals[h] = i + 1; return; }
+    h = (h + 1) & cap_mask;
+  }
 }
 
 // ---- export -----------------------------------------------------------------------------------------------------------------
@@ -944,6 +999,8 @@ struct vxba_map {
   char* scratch = nullptr; size_t scratch_cap = 0;
   char* stage = nullptr; size_t stage_cap = 0;    // second grow-only buffer: outputs that live next to the scratch of the same call
   std::string err;
+  double jour = 0.0;                  // the caller's journey odometer (vxba_map_set_journey): what the next margi stamps on the slide map's roots
+  long long n_released_roots = 0, n_releases = 0;
   bool broken = false;                // a failure left the device-side tree in an unknown state (see compact_fix): every stage refuses from then on
 };
 
@@ -984,7 +1041,7 @@ int ensure_nodes(vxba_map* m, long long want) {
 #define G(field, mult) if ((rc = grow_array(m, &nd.field, o * (mult), n * (mult)))) return rc;
   G(layer, 1) G(state, 1) G(child, 8) G(root, 1) G(isexist, 1) G(has_sw, 1) G(is_plane, 1) G(last_num, 1) G(opt_state, 1) G(in_slide, 1) G(stamp, 1) G(path, 1) G(dirty, 1)
   G(key, 1) G(center, 3) G(pcr_add, 10) G(pcr_fix, 10) G(cov_add, 81) G(eigval, 3) G(eigvec, 9) G(pl_center, 3) G(pl_normal, 3) G(pl_radius, 1) G(pl_var, 36)
-  G(pcrs_local, 10 * W) G(ql, 1) G(pt_start, W) G(pt_count, W) G(fix_start, 1) G(fix_count, 1) G(fix_cap, 1)
+  G(pcrs_local, 10 * W) G(ql, 1) G(pt_start, W) G(pt_count, W) G(fix_start, 1) G(fix_count, 1) G(fix_cap, 1) G(jour, 1)
 #undef G
   nd.cap = (int)ncap;
   return VXBA_OK;
@@ -1152,7 +1209,7 @@ int vxba_map_destroy(vxba_map* m) {
   vxmap::Nodes& nd = m->nd;
   void* arrs[] = {nd.layer, nd.state, nd.child, nd.root, nd.isexist, nd.has_sw, nd.is_plane, nd.last_num, nd.opt_state, nd.in_slide, nd.stamp, nd.path, nd.dirty, nd.key, nd.center,
                   nd.pcr_add, nd.pcr_fix, nd.cov_add, nd.eigval, nd.eigvec, nd.pl_center, nd.pl_normal, nd.pl_radius, nd.pl_var, nd.pcrs_local, nd.ql, nd.pt_start,
-                  nd.pt_count, nd.fix_start, nd.fix_count, nd.fix_cap};
+                  nd.pt_count, nd.fix_start, nd.fix_count, nd.fix_cap, nd.jour};
   for (void* a : arrs) if (a) hipFree(a);
   for (auto& s : m->scan) { hipFree(s.pnt); hipFree(s.var9); hipFree(s.perm); hipFree(s.tmp); }
   hipFree(m->keys); hipFree(m->vals); hipFree(m->d_cnt); hipFree(m->fix_pnt); hipFree(m->fix_var); hipFree(m->scratch); hipFree(m->stage);
@@ -1324,9 +1381,133 @@ int vxba_map_margi(vxba_map* m, int win_count, const double* Rp, vxba_factor* fa
   map_margi_points_kernel<<<dim3((unsigned)std::min(m->n_nodes, 4096)), 64, 0, m->stream>>>(m->nd, m->prm, poses, ring, make_scans(m), d_work, d_list, d_list_dst, m->fix_pnt, m->fix_var, m->d_cnt);
   for (int L = m->prm.max_layer - 1; L >= 0; L--) map_margi_up_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, L);
   map_release_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->prm.win_size, m->n_nodes);
-  map_leave_slide_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, m->d_cnt);
+  map_leave_slide_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, m->d_cnt, m->jour);
   if ((rc = cnt_pull(m))) return rc;
   m->n_slide -= m->h_cnt->n_removed;
+  return VXBA_OK;
+}
+
+// The caller's journey odometer (`jour += spat`, voxelslam.cpp:1677): stamped on every root of the slide map by the next vxba_map_margi.
+int vxba_map_set_journey(vxba_map* m, double jour) {
+  if (!m) return VXBA_ERR_ARG;
+  m->jour = jour;
+  return VXBA_OK;
+}
+
+// The release branch of the local-mapping loop (voxelslam.cpp:1503-1523): every root voxel whose last multi_margi lies `min_age` journeys back
+// (700 upstream) leaves surf_map with its whole subtree (OctoTree::tras_ptr + delete).  Here: the node pool is COMPACTED -- surviving nodes
+// move to the front of freshly sized arrays in their old order (so every later id-ordered step sees the order it would have seen), child /
+// root references and the voxel table are rebuilt, the fix-point pool is compacted behind it -- and device memory shrinks with the map.
+// `lio` (optional): the odometry handle whose plane map mirrors this map; the released roots are cleared there as well.
+int vxba_map_release(vxba_map* m, double jour_now, int min_age, vxba_lio* lio, int64_t* n_roots_released, int64_t* n_nodes_released) {
+  if (n_roots_released) *n_roots_released = 0;
+  if (n_nodes_released) *n_nodes_released = 0;
+  if (!m || min_age < 0) return mfail(m, VXBA_ERR_ARG, "vxba_map_release: bad argument");
+  if (m->broken) return VXBA_ERR_STATE;
+  if (lio) {
+    double vs = 0; int ml = 0, dev = 0;
+    vxba_internal_lio_geometry(lio, &vs, &ml, &dev);
+    if (vs != m->prm.voxel_size || ml != m->prm.max_layer || dev != m->device) return mfail(m, VXBA_ERR_ARG, "vxba_map_release: voxel_size / max_layer / device of the two handles differ");
+  }
+  hipSetDevice(m->device);
+  const int n = m->n_nodes;
+  if (n == 0) return VXBA_OK;
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  size_t tb = 0;
+  VM_HIP(m, rocprim::exclusive_scan(nullptr, tb, (unsigned int*)nullptr, (unsigned int*)nullptr, 0u, (size_t)n, rocprim::plus<unsigned int>(), m->stream));
+  const size_t b_u = up((size_t)n * sizeof(unsigned int));
+  int rc = ensure_scratch(m, 2 * b_u + up(tb) + 256);
+  if (rc) return rc;
+  unsigned int* d_keep = (unsigned int*)m->scratch;
+  unsigned int* d_pos = (unsigned int*)(m->scratch + b_u);
+  void* d_tmp = m->scratch + 2 * b_u;
+  int* d_n = (int*)(m->scratch + 2 * b_u + up(tb));
+  if ((rc = cnt_push(m))) return rc;
+  map_release_flag_kernel<<<grid_for(n), 256, 0, m->stream>>>(m->nd, n, jour_now, min_age, d_keep, m->d_cnt);
+  VM_HIP(m, rocprim::exclusive_scan(d_tmp, tb, d_keep, d_pos, 0u, (size_t)n, rocprim::plus<unsigned int>(), m->stream));
+  unsigned int last[2] = {0, 0};
+  VM_HIP(m, hipMemcpyAsync(&last[0], d_pos + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, m->stream));
+  VM_HIP(m, hipMemcpyAsync(&last[1], d_keep + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, m->stream));
+  if ((rc = cnt_pull(m))) return rc;
+  const int n_gone_roots = m->h_cnt->n_removed;
+  const int n_new = (int)(last[0] + last[1]);
+  if (n_gone_roots == 0) return VXBA_OK;
+  if (lio) {
+    // stage (second grow-only buffer): the "no plane here" entries of the released roots; the record arrays of a non-plane entry are never read
+    const size_t c_loc = up((size_t)n_gone_roots * 3 * 8), c_i = up((size_t)n_gone_roots * 4);
+    if ((rc = ensure_stage(m, c_loc + 3 * c_i + 256))) return rc;
+    char* q = m->stage;
+    long long* d_loc = (long long*)q; q += c_loc;
+    int* d_layer = (int*)q; q += c_i;
+    int* d_path = (int*)q; q += c_i;
+    int* d_isp = (int*)q; q += c_i;
+    VM_HIP(m, hipMemsetAsync(d_n, 0, sizeof(int), m->stream));
+    map_release_export_kernel<<<grid_for(n), 256, 0, m->stream>>>(m->nd, n, d_keep, d_loc, d_layer, d_path, d_isp, d_n);
+    VM_HIP(m, map_wait(m->stream));
+    VM_HIP(m, hipGetLastError());
+    const double* dummy = (const double*)m->stage;
+    rc = vxba_internal_lio_map_update_device(lio, n_gone_roots, d_loc, d_layer, d_path, d_isp, dummy, dummy, dummy, dummy);
+    if (rc != VXBA_OK) return mfail(m, rc, vxba_lio_last_error(lio));
+  }
+  // every node array into a fresh one sized for what stays.  From the first swapped array on the pool is in a mixed state: a failure
+  // (out of memory) leaves the map unusable -- say so rather than go on.
+  Nodes& nd = m->nd;
+  const long long ncap = std::max<long long>(1 << 12, (long long)n_new + n_new / 2);   // sized for what stays: the next scan's ensure_nodes grows it as before
+  const size_t W = m->prm.win_size;
+  bool failed = false;
+  auto gather = [&](auto** arr, size_t mult) {
+    using T = std::remove_pointer_t<std::remove_pointer_t<decltype(arr)>>;
+    if (failed) return;
+    T* q = nullptr;
+    if (hipMalloc((void**)&q, (size_t)ncap * mult * sizeof(T)) != hipSuccess) { failed = true; return; }
+    hipMemsetAsync(q, 0, (size_t)ncap * mult * sizeof(T), m->stream);
+    map_compact_array_kernel<T><<<grid_for((long long)n * (long long)mult), 256, 0, m->stream>>>(*arr, q, n, (int)mult, d_keep, d_pos);
+    if (map_wait(m->stream) != hipSuccess || hipGetLastError() != hipSuccess) { hipFree(q); failed = true; return; }
+    hipFree(*arr);
+    *arr = q;
+  };
+#define G(field, mult) gather(&nd.field, (size_t)(mult));
+  G(layer, 1) G(state, 1) G(child, 8) G(root, 1) G(isexist, 1) G(has_sw, 1) G(is_plane, 1) G(last_num, 1) G(opt_state, 1) G(in_slide, 1) G(stamp, 1) G(path, 1) G(dirty, 1)
+  G(key, 1) G(center, 3) G(pcr_add, 10) G(pcr_fix, 10) G(cov_add, 81) G(eigval, 3) G(eigvec, 9) G(pl_center, 3) G(pl_normal, 3) G(pl_radius, 1) G(pl_var, 36)
+  G(pcrs_local, 10 * W) G(ql, 1) G(pt_start, W) G(pt_count, W) G(fix_start, 1) G(fix_count, 1) G(fix_cap, 1) G(jour, 1)
+#undef G
+  if (failed) { m->broken = true; return mfail(m, VXBA_ERR_HIP, "vxba_map_release: out of memory while compacting the node pool; the map is unusable from here on"); }
+  nd.cap = (int)ncap;
+  map_compact_refs_kernel<<<grid_for(n_new), 256, 0, m->stream>>>(nd, n_new, d_pos);
+  // the voxel table, from scratch (released keys must not linger: open addressing has no delete)
+  map_fill_u64_kernel<<<grid_for(m->table_cap), 256, 0, m->stream>>>(m->keys, m->table_cap, EMPTY_KEY);
+  VM_HIP(m, hipMemsetAsync(m->vals, 0, (size_t)m->table_cap * sizeof(int), m->stream));
+  map_table_insert_roots_kernel<<<grid_for(n_new), 256, 0, m->stream>>>(nd, n_new, m->keys, m->vals, (unsigned long long)m->table_cap - 1);
+  VM_HIP(m, map_wait(m->stream));
+  VM_HIP(m, hipGetLastError());
+  m->n_nodes = n_new;
+  m->n_roots -= n_gone_roots;
+  m->n_released_roots += n_gone_roots;
+  m->n_releases++;
+  // the released leaves' regions of the fix-point pool are dead weight now: compact it behind the nodes
+  const long long saved_at = m->fix_compact_at;
+  m->fix_compact_at = -1;
+  rc = compact_fix(m);
+  if (m->fix_compact_at < 0) m->fix_compact_at = saved_at;      // nothing live: compact_fix returned early
+  if (rc) return rc;
+  if (n_roots_released) *n_roots_released = n_gone_roots;
+  if (n_nodes_released) *n_nodes_released = n - n_new;
+  return VXBA_OK;
+}
+
+// Device memory held by the map, bytes: [0] node pool (capacity x ~2.3 KB), [1] fix-point pool, [2] resident scans of the window, [3] voxel table +
+// scratch + stage, [4] total.
+int vxba_map_device_bytes(vxba_map* m, int64_t out[5]) {
+  if (!m || !out) return VXBA_ERR_ARG;
+  const size_t W = m->prm.win_size;
+  const size_t per_node = 13 * sizeof(int) + sizeof(unsigned long long) + sizeof(double) * (3 + 10 + 10 + 81 + 3 + 9 + 3 + 3 + 1 + 36 + 10 * W + 1) + sizeof(float) + 2 * W * sizeof(int) + sizeof(long long) + 2 * sizeof(int);
+  out[0] = (int64_t)((size_t)m->nd.cap * per_node);
+  out[1] = (int64_t)((size_t)m->fix_cap * 12 * sizeof(double));
+  size_t sc = 0;
+  for (const auto& s : m->scan) sc += (size_t)s.cap * (12 * sizeof(double) + 2 * sizeof(int));
+  out[2] = (int64_t)sc;
+  out[3] = (int64_t)((size_t)m->table_cap * (sizeof(unsigned long long) + sizeof(int)) + m->scratch_cap + m->stage_cap);
+  out[4] = out[0] + out[1] + out[2] + out[3];
   return VXBA_OK;
 }
 

@@ -37,7 +37,7 @@ EXPORTS = [
     "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_lio_leaf_stats", "vxba_cov_add_build", "vxba_plane_update", "vxba_down_sampling_voxel", "vxba_voxelize_push_device",
     "vxba_set_option", "vxba_get_option", "vxba_lio_set_option",
     "vxba_map_create", "vxba_map_destroy", "vxba_map_last_error", "vxba_map_cut_voxel", "vxba_map_cut_voxel_device", "vxba_map_recut", "vxba_map_margi",
-    "vxba_map_slide", "vxba_map_counts", "vxba_map_fix_pool", "vxba_map_leaves", "vxba_map_cut_voxel_lio", "vxba_map_export_planes",
+    "vxba_map_slide", "vxba_map_counts", "vxba_map_fix_pool", "vxba_map_set_journey", "vxba_map_release", "vxba_map_device_bytes", "vxba_map_leaves", "vxba_map_cut_voxel_lio", "vxba_map_export_planes",
 ]
 
 _ERRNAMES = {1: "VXBA_ERR_ARG", 2: "VXBA_ERR_HIP", 3: "VXBA_ERR_NODEV", 4: "VXBA_ERR_STATE", 5: "VXBA_ERR_UNSUPPORTED"}
@@ -185,6 +185,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_map_slide.argtypes = [vp, ci]
     L.vxba_map_counts.argtypes = [vp, _i64p]
     L.vxba_map_fix_pool.argtypes = [vp, _i64p]
+    L.vxba_map_set_journey.argtypes = [vp, C.c_double]
+    L.vxba_map_release.argtypes = [vp, C.c_double, ci, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.vxba_map_device_bytes.argtypes = [vp, _i64p]
     L.vxba_map_leaves.argtypes = [vp, C.c_int64, vp, vp, vp, C.POINTER(C.c_int64)]
     _lib = L
     return L
@@ -983,6 +986,22 @@ class LocalMap:
         out = np.zeros(3, dtype=np.int64)
         self._chk(self._L.vxba_map_fix_pool(self._h, out))
         return dict(cursor=int(out[0]), capacity=int(out[1]), compactions=int(out[2]))
+
+    def set_journey(self, jour: float):
+        """The journey odometer the next margi stamps on the slide map's roots (voxelslam.cpp:1349, 1677)."""
+        self._chk(self._L.vxba_map_set_journey(self._h, float(jour)))
+
+    def release(self, jour_now: float, min_age: int = 700, est: "LioEstimator | None" = None):
+        """The release branch of the local-mapping loop (voxelslam.cpp:1503-1523): roots last seen ``min_age`` journeys ago leave the map,
+        the node pool is compacted.  Returns dict(roots, nodes) released."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(self._L.vxba_map_release(self._h, float(jour_now), int(min_age), est._h if est is not None else None, C.byref(a), C.byref(b)))
+        return dict(roots=int(a.value), nodes=int(b.value))
+
+    def device_bytes(self):
+        out = np.zeros(5, dtype=np.int64)
+        self._chk(self._L.vxba_map_device_bytes(self._h, out))
+        return dict(nodes=int(out[0]), fix_pool=int(out[1]), scans=int(out[2]), other=int(out[3]), total=int(out[4]))
 
     def leaves(self):
         """Every leaf, sorted by node id, as a dictionary of arrays (fields of include/vxba.h ``vxba_map_leaves``)."""
