@@ -364,7 +364,8 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
 #define VXBA_OPT_LI_DEVICE_LOOP 3     /* LI_BA_Optimizer loop: 0 = host shell between the GPU sweeps, 1 = whole loop device-resident */
 #define VXBA_OPT_K2_VOXELS_PER_BLOCK 4 /* 64 (default) or 32..63: voxels per residual-sweep workgroup (tuning experiment) */
 #define VXBA_OPT_DEBUG_SOLVE_TIMEOUT 5 /* test hook, 0 (default): with 1 the voxel workgroups of a fused launch give up waiting for the in-launch solve at
-                                         once, which exercises the transparent non-fused retry of vxba_damping_iter */
+                                         once, which exercises the transparent non-fused retry of vxba_damping_iter; with 2 vxba_li_damping_iter treats the
+                                         first in-launch pose step of a call as undelivered, which exercises its host-solve fallback */
 #define VXBA_OPT_LI_STRUCTURED_SOLVE 6 /* 1 (default): the host shells of LI_BA_Optimizer[Gravity] solve the damped 15W(+3) system by a band Cholesky of
                                          the velocity/bias part + Schur complement onto the poses (3x fewer flops); 0: dense pivoted LDL^T */
 #define VXBA_OPT_LI_QUEUED_SWEEPS 7    /* 1 (default): the host shells of LI_BA_Optimizer[Gravity] queue an iteration's residual sweep (and the speculative Hessian sweep

@@ -273,3 +273,32 @@ def test_information_matrices_follow_the_imu_factors_between_calls(vx):
         got = run(shared, iw, facs)
         ref = run(factor(), iw, facs)
         assert np.array_equal(got["states"], ref["states"]) and np.array_equal(got["trace"], ref["trace"])
+
+
+def test_undelivered_device_step_falls_back_to_the_host_solve(vx):
+    """The default shell lets the device solve the reduced pose system inside the residual-sweep launch and recognises its step by NaN
+    sentinels -- so a non-finite step (an ill-conditioned reduced system) looks like one that never arrived.  When the launch has ended
+    and slots still hold sentinels, the shell must discard that launch's residual sweep, queue the sweeps again and take the host's
+    (pivoted) solve, like the host-solve modes do -- not fail the call.  The test hook VXBA_OPT_DEBUG_SOLVE_TIMEOUT = 2 declares the first
+    device step of a call undelivered: the result must equal the host-solve mode's, and the fallback must be counted."""
+    sc, iw, blobs, facs, fo, fg = build(vx, 8, 3000, 24000, seed=821)
+    blobs0 = [f.blob.copy() for f in facs]
+    fg.snapshot_cache()
+    fg.set_option("li_device_pose_solve", 0)
+    host = vx.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(iw.states_init, fg, facs, max_iter=4)
+    for f, b in zip(facs, blobs0):
+        f.blob[:] = b
+    fg.restore_cache()
+    fg.set_option("li_device_pose_solve", 1)
+    n0 = fg.get_option("stat_li_device_fallbacks")
+    fg.set_option("debug_solve_timeout", 2)
+    got = vx.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(iw.states_init, fg, facs, max_iter=4)
+    fg.set_option("debug_solve_timeout", 0)
+    assert fg.get_option("stat_li_device_fallbacks") == n0 + 1
+    assert got["trace"].shape == host["trace"].shape and np.array_equal(got["trace"][:, 6:], host["trace"][:, 6:])
+    assert np.allclose(got["trace"][:, :2], host["trace"][:, :2], rtol=1e-9)
+    et, er = synth.pose_errors(got["states"][:, :12], host["states"][:, :12])
+    assert et < 1e-9 and er < 1e-9, (et, er)
+    ref = O.li_damping_iter(fo, iw.states_init, blobs, max_iter=4, thd_num=5, imu_coef=1e-4)
+    et, er = synth.pose_errors(got["states"][:, :12], ref["states"][:, :12])
+    assert et < 1e-7 and er < 1e-7, (et, er)

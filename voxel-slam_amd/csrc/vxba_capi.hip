@@ -637,9 +637,12 @@ int vxba_set_option(vxba_factor* f, int option, int value) {
   VX_LOCK(f);
   switch (option) {
     case VXBA_OPT_FUSED_SOLVE: case VXBA_OPT_SPEC_COLLECTIVE: case VXBA_OPT_WIDE_DEVICE_SOLVE: case VXBA_OPT_LI_DEVICE_LOOP:
-    case VXBA_OPT_DEBUG_SOLVE_TIMEOUT: case VXBA_OPT_LI_STRUCTURED_SOLVE: case VXBA_OPT_LI_QUEUED_SWEEPS: case VXBA_OPT_LI_DEVICE_POSE_SOLVE:
+    case VXBA_OPT_LI_STRUCTURED_SOLVE: case VXBA_OPT_LI_QUEUED_SWEEPS: case VXBA_OPT_LI_DEVICE_POSE_SOLVE:
     case VXBA_OPT_FINALIZE_IN_LAUNCH:
       if (value != 0 && value != 1) return fail(f, VXBA_ERR_ARG, "vxba_set_option: this option takes 0 or 1");
+      break;
+    case VXBA_OPT_DEBUG_SOLVE_TIMEOUT:
+      if (value < 0 || value > 2) return fail(f, VXBA_ERR_ARG, "vxba_set_option: the test hook takes 0, 1 or 2");
       break;
     case VXBA_OPT_K2_VOXELS_PER_BLOCK:
       if (value < 32 || value > 64) return fail(f, VXBA_ERR_ARG, "vxba_set_option: voxels per block must be in [32, 64]");

@@ -360,10 +360,10 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, in
   if (partials_to_host) d_out = nullptr;
   if (f->profiling & 2) {
     hipEvent_t a = get_event(f), b = get_event(f);
-    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, part, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] ? 0x10000 : 0), f->stream, a, b, nullptr, nullptr, nullptr, fin);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, part, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] == 1 ? 0x10000 : 0), f->stream, a, b, nullptr, nullptr, nullptr, fin);
     if (a && b) f->pending.push_back({a, b, 1});
   } else {
-    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, part, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] ? 0x10000 : 0), f->stream, nullptr, nullptr, nullptr, nullptr, nullptr, fin);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, part, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] == 1 ? 0x10000 : 0), f->stream, nullptr, nullptr, nullptr, nullptr, nullptr, fin);
   }
   if (nparts < 0) return fail(f, VXBA_ERR_STATE, "residual sweep: in-launch Hessian reduction asked for with too few voxel workgroups");
   if (nparts_out) *nparts_out = nparts;

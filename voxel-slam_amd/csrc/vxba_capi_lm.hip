@@ -43,7 +43,7 @@ static int damping_iter_impl(vxba_factor* f, double* Rp, int max_iter, double* h
       bool on_device = false;
       if (use_device_solver) {
         double r1 = 0;
-        on_device = vxw::wide_solver_step(f->wide_solver, f->d_packed, u, f->stream, dxi.data(), &q1, &r1, f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] != 0) == 0;
+        on_device = vxw::wide_solver_step(f->wide_solver, f->d_packed, u, f->stream, dxi.data(), &q1, &r1, f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] == 1) == 0;
         if (!on_device) f->fused_fallbacks++;     // counted like the narrow loop's fallback (VXBA_STAT_FUSED_FALLBACKS)
         if (on_device) {
           if (is_calc_hess) residual1 = r1;
