@@ -46,16 +46,25 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-def pmc_traffic_bytes(kernel_key):
+def pmc_traffic_bytes(kernel_key, config="cfg2"):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/*/pmc_hbm_counters.json):
     FETCH_SIZE x 2 (the guide's gfx950 correction for wide coalesced reads) + WRITE_SIZE, both reported in KB.
     The counters cannot be read inside this process (rocprofv3 wraps the command), so the file is tied to the binary instead:
     scripts/collect_profile.py stamps it with the hash of the kernel sources it was collected from, and a file whose stamp is not
     the hash of the sources in this tree is REFUSED (traffic = null) rather than quoted for a kernel it did not measure."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_counters.json")))
+    files = []
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_counters.json"))):
+        if "cold" in os.path.basename(os.path.dirname(fn)):
+            continue                                  # the cold-L3 rotation is another command (scripts/dbg_cold_l3.py)
+        try:
+            cfg_of = json.load(open(fn)).get("config", "cfg2")       # files from before round 4 carry no tag: they are cfg2
+        except Exception:   # noqa: BLE001
+            continue
+        if cfg_of == config:
+            files.append(fn)
     if not files:
-        return None, "no profiles/*/pmc_hbm_counters.json"
+        return None, f"no profiles/*/pmc_hbm_counters.json collected at {config}"
     d = json.load(open(files[-1]))
     rel = os.path.relpath(files[-1], ROOT)
     if d.get("kernel_source_sha256") != kernel_source_hash():
@@ -278,7 +287,7 @@ def main():
         k2s_ms = kt2["k2_residual"]["ms_sum"] / max(1, kt2["k2_residual"]["calls"])
         k3f_ms = kt2["k3_finalize"]["ms_sum"] / max(1, kt2["k3_finalize"]["calls"])
         achieved = abytes["k3"] / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic_bytes("k3_hessian_kernel")
+        traffic, traffic_src = pmc_traffic_bytes("k3_hessian_kernel", args.config)
         # fp64 work of one K3 launch: MFMA SYRK (45 MFMAs of 16x16x4x2 flops per batch of 6 voxels: 10 tile pairs x 36 K-steps per
         # 8 batches) + phase A (~232 f64 VALU instructions per entry, about 1.7 flops each)
         nbatch = (V + 5) // 6 if W == 10 else 0

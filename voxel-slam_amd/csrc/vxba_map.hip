@@ -212,12 +212,9 @@ __global__ void map_descend_kernel(Nodes nd, const int* __restrict__ vals, const
   const int s = slot_of_point[i];
   if (s < 0) { leaf[i] = 0x7fffffff; pend_parent[i] = -1; return; }
   int node = vals[s] - 1;
-  // distinct roots this scan touches (:1603-1605) and roots entering the slide map (feat_tem_map, :1566-1567, 1580).  A scan's 100k points
-  // fall into a few thousand roots: look first (a plain load), and only a lane that still sees the old value pays the atomic that decides --
-  // ~30 same-address read-modify-writes per root were most of this kernel's time.
-  if (__hip_atomic_load(&nd.stamp[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != serial && atomicExch(&nd.stamp[node], serial) != serial) atomicAdd(&cnt->n_touched, 1);
-  if (__hip_atomic_load(&nd.in_slide[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && atomicExch(&nd.in_slide[node], 1) == 0) atomicAdd(&cnt->n_slide_new, 1);
-  if (__hip_atomic_load(&nd.dirty[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) nd.dirty[node] = 1;
+  if (atomicExch(&nd.stamp[node], serial) != serial) atomicAdd(&cnt->n_touched, 1);      // distinct roots this scan touches (:1603-1605)
+  if (atomicExch(&nd.in_slide[node], 1) == 0) atomicAdd(&cnt->n_slide_new, 1);         // feat_tem_map (:1566-1567, 1580)
+  nd.dirty[node] = 1;      // (round 4, measured: a plain load in front of each exchange changes nothing -- 47.0 against 42.5 us; the bench's scans touch ~90k roots, one point each)
   const double w[3] = {pwld[3 * i], pwld[3 * i + 1], pwld[3 * i + 2]};
   pend_parent[i] = -1;
   while (nd.state[node] != 0) {
@@ -246,74 +243,10 @@ __global__ void map_iota_kernel(int* p, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
 }
-__device__ __forceinline__ void sub_accumulate(int part, const double* w, const double* x, const double* V, bool with_local, bool with_fix, double (&a)[20]);
-// OctoTree::push (voxel_map.hpp:969-993) for every run of equal leaf ids in the sorted order, EIGHT lanes per run head (round 4; one lane per
-// head with all ~110 running sums in its registers was 68 us per 100k-point scan, the third-longest kernel of the scan cycle): the sums of a
-// leaf are dealt to eight lanes exactly as in map_subdivide_wave_kernel (sub_accumulate: parts 0-5 a row of the covariance sum's 6x6 block and
-// of its borders, part 6 the 3x3 variance block + the scan's local cluster, part 7 the world cluster).  Every accumulator is still ONE
-// sequential sum over the leaf's points in scan order that starts from the stored value -- bit-identical to sequential push().
-__global__ __launch_bounds__(256) void map_push8_kernel(Nodes nd, Params prm, const int* __restrict__ leaf_sorted, const int* __restrict__ perm, int n,
-                                                        const double* __restrict__ pnt, const double* __restrict__ var9, const double* __restrict__ pwld, int mord) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int q = (int)(t >> 3), part = (int)(t & 7);
-  if (q >= n) return;
-  const int node = leaf_sorted[q];
-  if (node == 0x7fffffff || (q > 0 && leaf_sorted[q - 1] == node)) return;
-  const int W = prm.win_size;
-  double* g_cl = nd.pcrs_local + ((size_t)node * W + mord) * 10;
-  double* g_ca = nd.pcr_add + (size_t)node * 10;
-  double* g_acc = nd.cov_add + (size_t)node * 81;
-  double a[20];
-#pragma unroll
-  for (int k = 0; k < 20; k++) a[k] = 0.0;
-  if (part < 6) {
-#pragma unroll
-    for (int k = 0; k < 6; k++) a[k] = g_acc[9 * k + part];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { a[6 + k] = g_acc[9 * (6 + k) + part]; a[9 + k] = g_acc[9 * part + 6 + k]; }
-  } else if (part == 6) {
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-#pragma unroll
-      for (int r = 0; r < 3; r++) a[3 * k + r] = g_acc[9 * (6 + k) + 6 + r];
-#pragma unroll
-    for (int k = 0; k < 10; k++) a[10 + k] = g_cl[k];
-  } else {
-#pragma unroll
-    for (int k = 0; k < 10; k++) a[k] = g_ca[k];
-  }
-  int cntp = 0;
-  for (int j = q; j < n && leaf_sorted[j] == node; j++) {
-    const int i = perm[j];
-    const double x[3] = {pnt[3 * (size_t)i], pnt[3 * (size_t)i + 1], pnt[3 * (size_t)i + 2]};
-    const double w[3] = {pwld[3 * (size_t)i], pwld[3 * (size_t)i + 1], pwld[3 * (size_t)i + 2]};
-    double V[9];
-#pragma unroll
-    for (int e = 0; e < 9; e++) V[e] = var9[9 * (size_t)i + e];
-    sub_accumulate(part, w, x, V, true, false, a);
-    cntp++;
-  }
-  if (part < 6) {
-#pragma unroll
-    for (int k = 0; k < 6; k++) g_acc[9 * k + part] = a[k];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { g_acc[9 * (6 + k) + part] = a[6 + k]; g_acc[9 * part + 6 + k] = a[9 + k]; }
-  } else if (part == 6) {
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-#pragma unroll
-      for (int r = 0; r < 3; r++) g_acc[9 * (6 + k) + 6 + r] = a[3 * k + r];
-#pragma unroll
-    for (int k = 0; k < 10; k++) g_cl[k] = a[10 + k];
-  } else {
-#pragma unroll
-    for (int k = 0; k < 10; k++) g_ca[k] = a[k];
-    nd.has_sw[node] = 1;
-    nd.isexist[node] = 1;
-    if (nd.layer[node] < prm.max_layer) { nd.pt_start[(size_t)node * W + mord] = q; nd.pt_count[(size_t)node * W + mord] = cntp; }
-  }
-}
-// (the one-lane-per-head form, kept for A/B: VXBA_MAP_PUSH1=1)
+// One lane per head of a run of equal leaf ids in the sorted order: OctoTree::push (voxel_map.hpp:969-993) for the run, in scan order.
+// (Round 4, measured and rejected: eight lanes per run head with the ~110 running sums dealt out as in map_subdivide_wave_kernel -- 80.7 us
+// against 67.8.  On the bench's scans a leaf receives one or two points per scan, so the kernel is the read-modify-write of ~100k node
+// records of 808 B each = 162 MB at 2.4 TB/s, not the folding; eight lanes per record only coalesce worse.)
 __global__ __launch_bounds__(64) void map_push_kernel(Nodes nd, Params prm, const int* __restrict__ leaf_sorted, const int* __restrict__ perm, int n,
                                                       const double* __restrict__ pnt, const double* __restrict__ var9, const double* __restrict__ pwld, int mord) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1349,9 +1282,7 @@ static int map_cut_voxel_impl(vxba_map* m, int ord, int64_t n64, const double* p
   map_resolve_kernel<<<grid_for(n), 256, 0, m->stream>>>(m->nd, n, d_leaf, d_pend);
   map_iota_kernel<<<grid_for(n), 256, 0, m->stream>>>(d_iota, n);
   VM_HIP(m, rocprim::radix_sort_pairs(d_tmp, tb, d_leaf, d_leaf_s, d_iota, sc.perm, (size_t)n, 0, 32, m->stream));
-  static const bool push1 = [] { const char* e = getenv("VXBA_MAP_PUSH1"); return e && e[0] == '1'; }();
-  if (push1) map_push_kernel<<<grid_for(n, 64), 64, 0, m->stream>>>(m->nd, m->prm, d_leaf_s, sc.perm, n, sc.pnt, sc.var9, d_w, slot);
-  else map_push8_kernel<<<grid_for(8ll * n, 256), 256, 0, m->stream>>>(m->nd, m->prm, d_leaf_s, sc.perm, n, sc.pnt, sc.var9, d_w, slot);
+  map_push_kernel<<<grid_for(n, 64), 64, 0, m->stream>>>(m->nd, m->prm, d_leaf_s, sc.perm, n, sc.pnt, sc.var9, d_w, slot);
   VM_HIP(m, map_wait(m->stream));
   VM_HIP(m, hipGetLastError());
   return VXBA_OK;
