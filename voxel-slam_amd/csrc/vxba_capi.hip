@@ -50,6 +50,7 @@ int vxba_destroy(vxba_factor* f) {
   hipFree(f->planes); hipFree(f->clb); hipFree(f->cl32); hipFree(f->snapshot); hipFree(f->staging); hipFree(f->d_partial3); hipFree(f->d_partial2); if (f->h_partial2) hipHostFree(f->h_partial2);
   if (f->h_feed) (void)hipHostFree(f->h_feed);
   if (f->h_lirec) (void)hipHostFree(f->h_lirec);
+  if (f->lirec_vram) (void)hipFree(f->lirec_vram);
   if (f->h_packed2) (void)hipHostFree(f->h_packed2);
   if (f->h_liout) (void)hipHostFree(f->h_liout);
   if (f->li_ev2) (void)hipEventDestroy(f->li_ev2);

@@ -306,6 +306,16 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
   if (dev_solve && !f->h_lirec) {
     VX_HIP(f, hipHostMalloc((void**)&f->h_lirec, sizeof(double) * vxk::li_rec_doubles(VXBA_MAX_WIN), hipHostMallocMapped | hipHostMallocCoherent));
     VX_HIP(f, hipHostGetDevicePointer((void**)&f->zc_lirec, f->h_lirec, 0));
+    // Round 4: the record in fine-grained DEVICE memory, written by the host through the PCIe BAR (one sequential copy of the assembled
+    // record, posted writes: ~1 us for 30 KB) instead of read by the solve out of host memory (a round trip per load on the step's
+    // critical path: one workgroup needs ~20 us for 30 KB from host memory, ~5 from HBM -- scripts/ubench/host_write_vram.hip).  Falls
+    // back to the mapped host buffer where the allocation is refused.  VXBA_LI_REC_VRAM=0: the round-3 path (A/B).
+    const char* ev = getenv("VXBA_LI_REC_VRAM");
+    if (!(ev && ev[0] == '0')) {
+      void* p = nullptr;
+      if (hipExtMallocWithFlags(&p, sizeof(double) * vxk::li_rec_doubles(VXBA_MAX_WIN), hipDeviceMallocFinegrained) == hipSuccess) f->lirec_vram = (double*)p;
+      else (void)hipGetLastError();
+    }
     VX_HIP(f, hipHostMalloc((void**)&f->h_liout, sizeof(double) * vxk::li_out_doubles(VXBA_MAX_WIN), hipHostMallocMapped | hipHostMallocCoherent));
     VX_HIP(f, hipHostGetDevicePointer((void**)&f->zc_liout, f->h_liout, 0));
     std::memset(f->h_liout, 0, sizeof(double) * vxk::li_out_doubles(VXBA_MAX_WIN));
@@ -437,7 +447,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
       // (measured and rejected: the record brought over by one DMA on a side stream + event instead of the solve reading it out of mapped host memory --
       // the three extra API calls cost 10 us per iteration, the solve was no faster: the PCIe reads are not what it waits for)
       nparts = vxk::launch_k2_residual(fv, pa0, f->d_lm, 0, seq, 0, f->V, f->zc_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK], f->stream, nullptr, nullptr, nullptr,
-                                       f->zc_lirec, f->zc_liout);
+                                       f->lirec_vram ? f->lirec_vram : f->zc_lirec, f->zc_liout);
     } else {
       nparts = vxk::launch_k2_residual(fv, pa0, f->d_lm, 0, seq, 0, f->V, f->zc_partial2, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK], f->stream, nullptr, nullptr, f->zc_feed);
     }
@@ -508,6 +518,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
               E[(size_t)(6 + p) * m6 + 6 + q] = v2;
             }
           }
+          if (f->lirec_vram) std::memcpy(f->lirec_vram, rec, sizeof(double) * vxk::li_rec_doubles(W));   // posted writes: in front of the launch's doorbell on the same path
           std::atomic_thread_fence(std::memory_order_release);
           if (with_spec) { nan_fill_buf(hpk[cur ^ 1]); next_sentinel = true; }   // nothing can be writing that buffer: its last system was consumed an iteration ago
         }

@@ -112,6 +112,7 @@ struct vxba_factor {
   double* zc_packed2 = nullptr;  // for the host there, so the next reduction must not land in the buffer the host is still reading)
   double* h_lirec = nullptr;     // mapped host memory: the reduced pose system of a LiDAR-inertial step for the in-launch solve [u | poses | e | E] (vxba_solve4.hpp)
   double* zc_lirec = nullptr;
+  double* lirec_vram = nullptr;  // the same record in fine-grained device memory, written by the host through the BAR (round 4); null: read from zc_lirec
   double* h_liout = nullptr;     // mapped host memory: that solve's answer [dx 6W | trial poses 12W | seq]
   double* zc_liout = nullptr;
   hipEvent_t li_ev = nullptr;    // marks the end of the residual sweep when a speculative Hessian sweep is queued behind it (LI host shells)
