@@ -296,6 +296,8 @@ template <int W>
 __device__ __forceinline__ K3RowOfs k3_row_offsets(int wave, int vl, int fi) {
   using C = K3Cfg<W>;
   K3RowOfs ro;
+  // (R is even, so a block of R rows starts on a row pair: at(wave R + x, 0) = at(x, 0) + wave R NCOL -- the pair-sync variant below re-bases
+  // the same offsets by adding a multiple of R NCOL to the buffer pointer)
 #pragma unroll
   for (int r = 0; r < 3; r++) ro.rp[r] = C::at(wave * C::R + 3 * vl + r, 0);
 #pragma unroll
@@ -340,6 +342,26 @@ __device__ __forceinline__ void k3_mfma_phase(const double* buf, int set, int k0
   const double* bp[C::NSLOT];   // K-step kk: + kk * 4 NCOL
 #pragma unroll
   for (int k = 0; k < C::NSLOT; k++) bp[k] = buf + C::at(4 * k0 + lrow, lcol) + k3_slot_offset<W>(set, k);
+#if defined(K3_PREFETCH2) && K3_PREFETCH2
+  if (FULL) {
+    // experiment (the review's (b)): operands TWO K-steps ahead of the MFMAs that consume them
+    double x[C::NSLOT], xn[C::NSLOT], xnn[C::NSLOT];
+#pragma unroll
+    for (int k = 0; k < C::NSLOT; k++) { x[k] = bp[k][0]; xn[k] = C::KPW > 1 ? bp[k][4 * C::NCOL] : 0.0; }
+#pragma unroll
+    for (int kk = 0; kk < C::KPW; kk++) {
+      if (kk + 2 < C::KPW) {
+#pragma unroll
+        for (int k = 0; k < C::NSLOT; k++) xnn[k] = bp[k][(kk + 2) * 4 * C::NCOL];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      k3_mfma_tiles<W, 0>(x, acc);
+      hook(kk);
+#pragma unroll
+      for (int k = 0; k < C::NSLOT; k++) { x[k] = xn[k]; xn[k] = xnn[k]; }
+    }
+  } else
+#endif
   if (FULL) {
     // operands of K-step kk+1 are requested before the MFMAs of K-step kk are issued
     double x[C::NSLOT], xn[C::NSLOT];
@@ -450,6 +472,17 @@ __device__ __forceinline__ void k3_sum_linear(const double* park_d, double* out,
 // so that those requests do not wait for a scalar load of the argument block first (a cold miss: the block was written by the host a few
 // microseconds earlier).  Structs are not preloaded and stop the sequence, hence the flat list; what is not urgent follows as before.
 //   pend_flags = pending | restart << 8, nwg = nwg (otherwise a load from the hidden arguments)
+// K3_PAIR_SYNC (round 4, the review's experiment (a)): the two waves that share a SIMD (w and w + 4: a workgroup's waves go to the four SIMDs
+// cyclically) own ONE K range -- the 2 R rows those same two waves produce in phase A -- and the two tile sets, so a step's dependency is
+// local to the pair: a flag in LDS replaces the workgroup barrier from step 1 on (step 0 keeps it: the LM decision rides on it).
+// MEASURED, same box (gpurun_out/r4_s11.log, profiles/r04_k3_phase_a): K3 26.2 us against 25.8 (cfg2), 148.6 against 146.6 (cfg4), 43.1
+// against 42.6 (cfg3) -- no gain: the ~1k cycles a wave of the first half waits at the step barrier are spent waiting for ITS OWN partner
+// (stamps: waves 0-3 finish phase A at 8.7k cycles of a step, their partners 4-7 at 9.9k, the barrier opens at 10.2k), which a pair flag
+// waits for just the same, and the polling wave takes issue slots from the partner it waits for.  Off; kept as the record of the experiment.
+// K3_PREFETCH2 ((b): operands two K-steps ahead): 26.0 / 146.8 / 42.6 -- no change; the MFMA stream does not wait for its operands.
+#ifndef K3_PAIR_SYNC
+#define K3_PAIR_SYNC 0
+#endif
 #ifndef K3_LATE_REQUESTS
 #define K3_LATE_REQUESTS 1   // round 4: the default (cfg4 156.6 -> 147.4 us, cfg3 44.5 -> 43.2, cfg2 unchanged; same-box A/B, gpurun_out/r4_s3.log)
 #endif
@@ -477,7 +510,11 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
   const int vl = active ? lane / W : 0;
   const int fi = active ? lane % W : 0;
   const int lrow = lane >> 4, lcol = lane & 15;
-  const int set = wave % C::TSPLIT, kq = wave / C::TSPLIT;
+  constexpr bool PAIR = (K3_PAIR_SYNC != 0) && C::TSPLIT == 2 && C::WAVES == 8 && (C::R % 2 == 0);
+  const int set = PAIR ? (wave >> 2) : wave % C::TSPLIT, kq = PAIR ? (wave & 3) : wave / C::TSPLIT;
+  // full steps: where this wave's R rows go inside a tile buffer, as a shift of the plain layout (rows wave R ..): K range kq = rows
+  // [2 R kq, 2 R (kq + 1)) = the rows of wave kq (first half) and of wave kq + 4 (second half)
+  const int rowshift = PAIR ? ((2 * kq + set) - wave) * C::R * C::NCOL : 0;
   const int gw = blockIdx.x * C::WAVES + wave;
   dbg_stamp(DBG, gw, 0);
 
@@ -569,6 +606,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
       }
     }
   }
+  if (PAIR && tid < C::WAVES) reinterpret_cast<volatile int*>(lds + 2 * C::BUF + 12 * W)[tid] = 0;   // the pair flags (behind the poses)
   dbg_stamp(DBG, gw, 4);     // tiles cleared
   __syncthreads();
   dbg_stamp(DBG, gw, 1);
@@ -626,6 +664,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
 #pragma unroll
   for (int k = 0; k < DACC; k++) dacc[k] = 0.0;
 
+  volatile int* pflag = reinterpret_cast<volatile int*>(poseA + 12 * W);   // (PAIR) per wave: steps whose rows are in LDS; zeroed below, before the first barrier that follows
   const K3RowOfs ro = k3_row_offsets<W>(wave, vl, fi);   // lane constants: where the lane's three row pieces go inside a tile buffer
   int dbg_step = -1;                                      // instrumented build: the step phase_a is running for
   // Phase A of the wave's batch b into tile buffer `bo`, then the requests for its next batch nb (nb < 0: none).
@@ -638,7 +677,8 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
   // them the entry registers became a phi of (old, loaded) values, and the copies that resolve it sat behind s_waitcnt vmcnt at the END
   // of phase A -- every wave waited out the latency of the loads it had just issued before it reached the barrier (round-4 find, from
   // the ISA: vmcnt(7) / (6) / (5) + six v_mov_b64 in front of the barrier, vmcnt(0) at the head of phase M).
-  auto phase_a = [&](int b, int bo, int nb, bool more, auto next_tag) __attribute__((always_inline)) {
+  auto phase_a = [&](int b, int bo_in, int nb, bool more, auto next_tag) __attribute__((always_inline)) {
+    const int bo = bo_in + (decltype(next_tag)::value != 0 ? rowshift : 0);      // full steps (next != 0): the pair layout; the ragged step: the plain one
     constexpr int next = decltype(next_tag)::value;
     double rows[3][6];
     // instrumented build, step 2 only: 7 parameters + pose back in registers, 14 rows computed, 15 rows stored, 18 = everything but the requests
@@ -736,7 +776,17 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
       }
       if (AF && s >= 1) phase_m();
       if (s == nfull) break;
-      __syncthreads();
+      if (PAIR && s >= 1 && !undecided) {
+        // rows of step s are in LDS (the flag's store is queued behind them: one wave's LDS operations execute in order); then wait for
+        // the partner's -- nobody else's rows are read in phase M of step s
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the compiler may not sink the row stores below the flag's)
+        if (lane == 0) pflag[wave] = s + 1;
+        while (pflag[wave ^ 4] < s + 1) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      } else {
+        __syncthreads();
+        if (PAIR && lane == 0) pflag[wave] = s + 1;     // keeps the counters in step when a later step switches to the flags
+      }
       if (s < 6) dbg_stamp(DBG, gw, 8 + s);
       if (undecided && decide()) return true;
     }
@@ -807,7 +857,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
     const int ts = t / C::TPW, j = t % C::TPW;
     v2d sum = (v2d){0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < C::KSPLIT; k++) sum += *reinterpret_cast<const v2d*>(park_t + ((k * C::TSPLIT + ts) * C::TPW + j) * 256 + x);
+    for (int k = 0; k < C::KSPLIT; k++) sum += *reinterpret_cast<const v2d*>(park_t + ((PAIR ? (ts * C::KSPLIT + k) : (k * C::TSPLIT + ts)) * C::TPW + j) * 256 + x);
 #if VXBA_WT_STORES
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, sum), rout, el * 8, 0, 16);   // aux 16 = sc1 on gfx950
 #else
