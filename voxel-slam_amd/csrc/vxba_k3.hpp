@@ -256,8 +256,8 @@ __device__ __forceinline__ void k3_unstage_params(const K3Stage<W>& st, double* 
 }
 
 // Phase A of one entry: rows of B_a (3 x 6) and the per-frame linear accumulators, branch-free.
-template <bool RT>
-__device__ __forceinline__ void k3_phase_a(K3Entry& e, int fi, const double* __restrict__ pose, double rows[3][6], double dacc[DACC]) {
+template <bool RT, class Emit>
+__device__ __forceinline__ void k3_phase_a(K3Entry& e, int fi, const double* __restrict__ pose, double dacc[DACC], Emit&& emit) {
   // pose of the lane's frame from LDS (C-ABI layout: R column-major | p), transposed on the way in: 24 registers less to
   // carry through phase M
   double R[9], p[3];
@@ -283,7 +283,7 @@ __device__ __forceinline__ void k3_phase_a(K3Entry& e, int fi, const double* __r
   vc.coe = obs ? e.coe : 0.0;
   vc.sc = obs ? e.sc : 0.0;
   dacc[27] += (e.ok && fi == 0) ? e.coe * e.lam0 : 0.0;  // residual += coe * lambda_0, once per voxel (voxel_map.hpp:234)
-  vxm::k3_entry<RT>(e.c, e.c + 6, e.c[9], R, p, vc, rows, dacc);
+  vxm::k3_entry_emit<RT>(e.c, e.c + 6, e.c[9], R, p, vc, dacc, emit);
 }
 
 // Store addresses of a lane's three row pieces (element offsets inside a tile buffer): lane constants, kept as 3 row parts +
@@ -303,6 +303,14 @@ __device__ __forceinline__ K3RowOfs k3_row_offsets(int wave, int vl, int fi) {
 #pragma unroll
   for (int j = 0; j < 3; j++) ro.cp[j] = C::at(0, 6 * fi + 2 * j);
   return ro;
+}
+__device__ __forceinline__ void k3_store_row(double* buf, const K3RowOfs& ro, int r, const double row[6]) {
+#pragma unroll
+  for (int j = 0; j < 3; j++) *reinterpret_cast<v2d*>(buf + ro.rp[r] + ro.cp[j]) = (v2d){row[2 * j], row[2 * j + 1]};
+}
+__device__ __forceinline__ void k3_store_row_f32(float* buf, const K3RowOfs& ro, int r, const double row[6]) {
+#pragma unroll
+  for (int j = 0; j < 3; j++) *reinterpret_cast<v2f*>(buf + ro.rp[r] + ro.cp[j]) = (v2f){(float)row[2 * j], (float)row[2 * j + 1]};
 }
 __device__ __forceinline__ void k3_store_rows(double* buf, const K3RowOfs& ro, const double rows[3][6]) {
 #pragma unroll
@@ -665,7 +673,12 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
   for (int k = 0; k < DACC; k++) dacc[k] = 0.0;
 
   volatile int* pflag = reinterpret_cast<volatile int*>(poseA + 12 * W);   // (PAIR) per wave: steps whose rows are in LDS; zeroed below, before the first barrier that follows
-  const K3RowOfs ro = k3_row_offsets<W>(wave, vl, fi);   // lane constants: where the lane's three row pieces go inside a tile buffer
+  K3RowOfs ro = k3_row_offsets<W>(wave, vl, fi);   // lane constants: where the lane's three row pieces go inside a tile buffer
+  double* const dump = poseA + 12 * W + 8;         // 32 doubles nobody reads: where the idle lanes' (zero) rows go
+  if (!active) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ro.rp[k] = 8 * k; ro.cp[k] = 2 * k; }
+  }
   int dbg_step = -1;                                      // instrumented build: the step phase_a is running for
   // Phase A of the wave's batch b into tile buffer `bo`, then the requests for its next batch nb (nb < 0: none).
   // Measured and rejected (round 3, same box): the LDS round trip of the plane parameters issued two thirds of the way through phase M
@@ -680,7 +693,6 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
   auto phase_a = [&](int b, int bo_in, int nb, bool more, auto next_tag) __attribute__((always_inline)) {
     const int bo = bo_in + (decltype(next_tag)::value != 0 ? rowshift : 0);      // full steps (next != 0): the pair layout; the ragged step: the plain one
     constexpr int next = decltype(next_tag)::value;
-    double rows[3][6];
     // instrumented build, step 2 only: 7 parameters + pose back in registers, 14 rows computed, 15 rows stored, 18 = everything but the requests
     const bool stamp_here = DBG && dbg_step == 2;
     unstage(b);
@@ -688,25 +700,35 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
     // voxel-level values for the spare columns, taken before phase A masks / consumes the entry
     const double spare_s = 1.4142135623730951 * e.sc;
     const double spare[3] = {spare_s * e.u[0], spare_s * e.u[1], spare_s * e.u[2]};
-    k3_phase_a<!C::SPARE>(e, fi, pose, rows, dacc);
-    if (DBG && stamp_here) { asm volatile("" :: "v"(rows[0][0]), "v"(rows[1][5]), "v"(rows[2][0])); __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 14); __builtin_amdgcn_sched_barrier(0); }
-    if (active) {
-      const int fi_ = fi;
-      if (MIXED) k3_store_rows_f32(reinterpret_cast<float*>(lds) + bo, ro, rows);
-      else k3_store_rows(lds + bo, ro, rows);
-      if (C::SPARE && fi_ == W - 1) {   // one lane per voxel: columns 6W .. 6W+2 of the z row
-        const int o = ro.rp[2] + C::at(0, 6 * W);
-        if (MIXED) {
-          float* zf = reinterpret_cast<float*>(lds) + bo + o;
-          *reinterpret_cast<v2f*>(zf) = (v2f){(float)spare[0], (float)spare[1]};
-          zf[2] = (float)spare[2];
-        } else {
-          double* zd = lds + bo + o;
-          *reinterpret_cast<v2d*>(zd) = (v2d){spare[0], spare[1]};
-          zd[2] = spare[2];
-        }
+    if (active && C::SPARE && fi == W - 1) {   // one lane per voxel: columns 6W .. 6W+2 of the z row
+      const int o = ro.rp[2] + C::at(0, 6 * W);
+      if (MIXED) {
+        float* zf = reinterpret_cast<float*>(lds) + bo + o;
+        *reinterpret_cast<v2f*>(zf) = (v2f){(float)spare[0], (float)spare[1]};
+        zf[2] = (float)spare[2];
+      } else {
+        double* zd = lds + bo + o;
+        *reinterpret_cast<v2d*>(zd) = (v2d){spare[0], spare[1]};
+        zd[2] = spare[2];
       }
     }
+    // Rows go to the tile AS THEY ARE FINISHED (z row, G row 1, G row 2; round 4): stamps put ten 16-byte stores per wave, issued together
+    // at the end of phase A by all four waves of a half at once, at 1.0-1.5k cycles until the last is performed -- which the wave then
+    // waited out in front of the barrier.  With the first six under way while the second G row and the block-diagonal terms are still
+    // being computed only the last three are young at the barrier.
+    // (no branch around the stores of the 64 - NACT idle lanes: they write a dump area behind the poses instead -- a branch makes the wait-count
+    // bookkeeping at its join wait for the stores just issued)
+    double* const rowbase = active ? lds + bo : dump;
+    float* const rowbase_f = active ? reinterpret_cast<float*>(lds) + bo : reinterpret_cast<float*>(dump);
+    auto emit = [&](int r, const double row[6]) __attribute__((always_inline)) {
+      if (MIXED) k3_store_row_f32(rowbase_f, ro, r, row);
+      else k3_store_row(rowbase, ro, r, row);
+#if !defined(K3_STORES_AT_END) || !K3_STORES_AT_END
+      __builtin_amdgcn_sched_barrier(0);   // keep the stores where they are: the scheduler gathers them behind the last row otherwise
+#endif
+    };
+    k3_phase_a<!C::SPARE>(e, fi, pose, dacc, emit);
+    if (DBG && stamp_here) { __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 14); __builtin_amdgcn_sched_barrier(0); }
     // next batch of this wave: in flight during the barrier and the whole of phase M.  Measured and rejected (round 2, same
     // box): the cluster rows requested a step earlier into a second register set (no change: the steps do not wait for loads);
     // the two waves of a SIMD taking phase M / phase A in opposite order (13.2k instead of 11.8k cycles per step).  Round 3: s_setprio

@@ -382,9 +382,23 @@ VX_HD void k3_g_row(const double P[6], const double v[3], const double R[9], con
 // RT = false: the caller obtains Drt and Dtt elsewhere (K3's narrow-window kernel reads them off spare columns of its
 // MFMA tile: with sqrt2 sqrt(coe) u in three padding columns of the z row, S[6i+j][pad+k] = sum_a (2 coe/N) w_j u_k = Drt
 // and S[6i+3+j][pad+k] = sum_a (2 coe n/N) u_j u_k = Dtt) and acc[12..26] stay untouched.
+// k3_entry hands its three rows to `emit(r, row)` AS EACH IS FINISHED -- z row first (it needs w only), then the two G rows, then the
+// block-diagonal terms -- so that a caller that stores them (the narrow-window Hessian sweep: three 16-byte LDS stores per row) has the
+// first stores under way while the rest is still being computed.  Same operations in the same order per value as the array form below.
+template <bool RT = true, class Emit>
+VX_HD void k3_entry_emit(const double P[6], const double v[3], double n, const double R[9], const double p[3], const VoxelCache& vc, double acc[27], Emit&& emit);
+struct K3RowsCollector {
+  double (*rows)[6];
+  VX_HD void operator()(int r, const double row[6]) const { for (int j = 0; j < 6; j++) rows[r][j] = row[j]; }
+};
 template <bool RT = true>
 VX_HD void k3_entry(const double P[6], const double v[3], double n, const double R[9], const double p[3],
                     const VoxelCache& vc, double rows[3][6], double acc[27]) {
+  k3_entry_emit<RT>(P, v, n, R, p, vc, acc, K3RowsCollector{rows});
+}
+template <bool RT, class Emit>
+VX_HD void k3_entry_emit(const double P[6], const double v[3], double n, const double R[9], const double p[3],
+                         const VoxelCache& vc, double acc[27], Emit&& emit) {
   const double* u = vc.u0;
   const double invN = vc.invN;
   const double sc = vc.sc;
@@ -406,6 +420,30 @@ VX_HD void k3_entry(const double P[6], const double v[3], double n, const double
 #pragma unroll
   for (int i = 0; i < 3; i++) c2[i] = (R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2]) + n * t[i];
   const double c2u = dot3(c2, u);
+  // z row, then the G rows for y = u1 and y = u2
+  const double isc = invN * sc;
+  {
+    const double sz = 1.4142135623730951 * isc;
+    const double szn = sz * n;
+    double row[6];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      row[j] = sz * w[j];
+      row[3 + j] = szn * u[j];
+    }
+    emit(2, row);
+  }
+  {
+    double row[6];
+    k3_g_row(P, v, R, t, r, z, c2, c2u, u, vc.u1, vc.s1 * isc, row);
+    emit(0, row);
+  }
+  {
+    double row[6];
+    k3_g_row(P, v, R, t, r, z, c2, c2u, u, vc.u2, vc.s2 * isc, row);
+    emit(1, row);
+  }
+
   // gradient block g = A^T u = (2/N) [ z x r ; c2u u ]
   const double two_invN = 2.0 * invN;
   const double cg = vc.coe * two_invN;
@@ -415,18 +453,6 @@ VX_HD void k3_entry(const double P[6], const double v[3], double n, const double
   const double cgu = cg * c2u;
 #pragma unroll
   for (int j = 0; j < 3; j++) acc[3 + j] += cgu * u[j];
-
-  // G rows for y = u1 and y = u2, z row
-  const double isc = invN * sc;
-  k3_g_row(P, v, R, t, r, z, c2, c2u, u, vc.u1, vc.s1 * isc, rows[0]);
-  k3_g_row(P, v, R, t, r, z, c2, c2u, u, vc.u2, vc.s2 * isc, rows[1]);
-  const double sz = 1.4142135623730951 * isc;
-  const double szn = sz * n;
-#pragma unroll
-  for (int j = 0; j < 3; j++) {
-    rows[2][j] = sz * w[j];
-    rows[2][3 + j] = szn * u[j];
-  }
 
   // block-diagonal correction D_i
   const double rr = dot3(r, r), trP = (P[0] + P[3]) + P[5];
