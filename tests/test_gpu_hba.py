@@ -1,5 +1,7 @@
 """One hierarchical-BA window (HBA_add_edge's loop, voxelslam.cpp:2320-2430) end to end: GPU path vs the same schedule on
 the CPU oracle, from raw scans and perturbed keyframe poses to refined poses and pose-graph edge weights."""
+import os
+
 import numpy as np
 import pytest
 
@@ -80,3 +82,33 @@ def test_hierarchical_pass_matches_oracle(K, wdsize, mgsize):
     ids = got["submap_ids"]
     e0 = synth.pose_errors(poses[ids], gt[ids]); e1 = synth.pose_errors(got["submap_poses"], gt[ids])
     assert e1[0] < e0[0]
+
+
+@pytest.mark.skipif(os.environ.get("VXBA_RUN_SLOW") != "1", reason="BASELINE configs[4] at its stated size against the CPU oracle: minutes of oracle time; set VXBA_RUN_SLOW=1")
+def test_cfg5_size_pass_500_keyframes_matches_oracle():
+    """BASELINE configs[4] at its stated size: 500 keyframes, 99 bottom-level windows of 10 (stride 5), one top-level window over the 99 submap
+    poses (the wide-window path) with two re-voxelisation rounds -- GPU against the same orchestration on the CPU oracle: the same submaps
+    point for point, the same factor counts in every top-level round, the same edges, submap poses within 1e-6 (contract 1e-4).  The session
+    is the range-limited corridor of bench.py --config cfg5 at 5000 points per keyframe."""
+    from voxel_slam_amd import hba, vxba
+    K = 500
+    clouds, poses, gt = synth.corridor_session(K, 5000, synth.MASTER_SEED + 5000)
+    coarse = vxba.VoxelizeParams(voxel_size=2.0, max_layer=2, min_points=10, min_eigen_value=0.02, eigen_ratio=(1 / 9, 1 / 9, 1 / 9, 1 / 9))
+    fine = vxba.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
+    got = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=10, mgsize=5, top_max_iter=2)
+    ref = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=10, mgsize=5, top_max_iter=2, optimizer=_OracleOpt(), voxelize=_oracle_voxelize,
+                              downsample=O.down_sampling_voxel)
+    assert len(got["submap_ids"]) == 99 and got["submap_ids"] == ref["submap_ids"]
+    assert got["submap_sizes"] == ref["submap_sizes"]
+    assert [r["n_voxels"] for r in got["top_rounds"]] == [r["n_voxels"] for r in ref["top_rounds"]] and len(got["top_rounds"]) == 2
+    et, er = synth.pose_errors(got["submap_poses"], ref["submap_poses"])
+    assert et < 1e-6 and er < 1e-6, (et, er)
+    for key in ("edges1", "edges2"):
+        assert len(got[key]) == len(ref[key]) > 0
+        for a, b in zip(got[key], ref[key]):
+            assert (a["i"], a["j"]) == (b["i"], b["j"]) and np.allclose(a["v6"], b["v6"], rtol=1e-4) and np.allclose(a["tra"], b["tra"], atol=1e-6)
+    ids = got["submap_ids"]
+    e0 = synth.pose_errors(poses[ids], gt[ids]); e1 = synth.pose_errors(got["submap_poses"], gt[ids])
+    assert e1[0] < e0[0]
+    print("cfg5-size pass: 99 windows, top rounds %s voxels, pose diff vs oracle %.2e m %.2e rad, anchors %.4f -> %.4f m" % (
+        [r["n_voxels"] for r in got["top_rounds"]], et, er, e0[0], e1[0]))
