@@ -272,6 +272,11 @@ int vxba_li_evaluate(vxba_factor* f, const double* states, const double* imus, d
                      double* residual);
 /* LI_BA_Optimizer::only_residual (voxel_map.hpp:525-560). */
 int vxba_li_only_residual(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* residual);
+/* LI_BA_OptimizerGravity's members of the same names (voxel_map.hpp:663-773): hess_plus into a (15W+3)^2 system, divide_thread (Hess (15W+3)^2
+ * column-major, JacT 15W+3: the three gravity unknowns at the tail, IMU factors through give_evaluate_g); only_residual is vxba_li_only_residual
+ * (give_evaluate_g without Jacobian is give_evaluate without Jacobian, preintegration.hpp:214-294). */
+int vxba_hess_plus_gravity(int win_size, double* Hess15g, double* JacT15g, const double* Hess6, const double* JacT6);
+int vxba_li_evaluate_gravity(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* Hess, double* JacT, double* residual);
 /* LI_BA_Optimizer::damping_iter (voxel_map.hpp:562-653; three iterations upstream).  states and imus are in/out (the
  * factors' dbg / dba and their _buf copies move with every step and roll back on a rejected one, :608-609, 639-643).
  * hess_out (15W)^2 = `*hess`, exported before the gauge fix (:588).  trace_out max_iter*VXBA_TRACE_COLS, may be NULL. */

@@ -122,6 +122,27 @@ class LI_BA_OptimizerGravityT {
   int win_size = 0, jac_leng = 0, imu_leng = 0;
   double imu_coef = 1e-4;
 
+  // voxel_map.hpp:663-671
+  void hess_plus(MatXT& Hess, VecXT& JacT, MatXT& hs, VecXT& js) { vxba_hess_plus_gravity(win_size, Hess.data(), JacT.data(), hs.data(), js.data()); }
+  // voxel_map.hpp:673-736: the joint (15W + 3) system; Hess / JacT pre-sized by the caller as upstream
+  double divide_thread(std::vector<StateT>& x_stats, LidarFactorAdapter& voxhess, std::deque<ImuT*>& imus_factor, MatXT& Hess, VecXT& JacT) {
+    vxba_factor* h = voxhess.handle();
+    win_size = voxhess.win_size; jac_leng = 6 * win_size; imu_leng = VXBA_LI_DIM * win_size + 3;
+    LiPack<StateT, ImuT> pk(x_stats, imus_factor, win_size);
+    double residual = 0;
+    li_check(h, vxba_li_evaluate_gravity(h, pk.st.data(), pk.im.data(), imu_coef, Hess.data(), JacT.data(), &residual));
+    return residual;
+  }
+  // voxel_map.hpp:738-773
+  double only_residual(std::vector<StateT>& x_stats, LidarFactorAdapter& voxhess, std::deque<ImuT*>& imus_factor) {
+    vxba_factor* h = voxhess.handle();
+    win_size = voxhess.win_size; jac_leng = 6 * win_size; imu_leng = VXBA_LI_DIM * win_size + 3;
+    LiPack<StateT, ImuT> pk(x_stats, imus_factor, win_size);
+    double residual = 0;
+    li_check(h, vxba_li_only_residual(h, pk.st.data(), pk.im.data(), imu_coef, &residual));
+    voxhess.invalidate_cache();
+    return residual;
+  }
   // voxel_map.hpp:775-862.  Upstream never resizes *hess (the caller's matrix already has the shape); it is resized here if it has not.
   void damping_iter(std::vector<StateT>& x_stats, LidarFactorAdapter& voxhess, std::deque<ImuT*>& imus_factor, std::vector<double>& resis,
                     MatXT* hess, int max_iter = 2) {

@@ -415,6 +415,28 @@ void vxo_li_damping_iter(void* h, double* states, double* blobs, int /*thd_num*/
   if (hess_out) pack_mat(hess, hess_out);
   if (n_trace) *n_trace = 0;
 }
+// LI_BA_OptimizerGravity::divide_thread / only_residual (voxel_map.hpp:673-773), the reference's own members
+double vxo_li_divide_thread_gravity(void* h, const double* states, const double* blobs, int /*thd_num*/, double imu_coef_, double* Hess, double* JacT) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  imu_coef = imu_coef_;
+  LiCtx c(states, blobs, f.win_size);
+  LI_BA_OptimizerGravity opt;
+  opt.win_size = f.win_size; opt.jac_leng = 6 * f.win_size; opt.imu_leng = DIM * f.win_size + 3;
+  MatrixXd H(opt.imu_leng, opt.imu_leng);
+  VectorXd J(opt.imu_leng);
+  const double r = opt.divide_thread(c.xs, f, c.imus, H, J);
+  pack_mat(H, Hess);
+  pack_mat(J, JacT);
+  return r;
+}
+double vxo_li_only_residual_gravity(void* h, const double* states, const double* blobs, int /*thd_num*/, double imu_coef_) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  imu_coef = imu_coef_;
+  LiCtx c(states, blobs, f.win_size);
+  LI_BA_OptimizerGravity opt;
+  opt.win_size = f.win_size; opt.jac_leng = 6 * f.win_size; opt.imu_leng = DIM * f.win_size + 3;
+  return opt.only_residual(c.xs, f, c.imus);
+}
 // LI_BA_OptimizerGravity::damping_iter (:775-862).  `hess` is never resized upstream (:775-790): the caller's matrix must already
 // have the (15W+3)^2 shape, as voxelslam.cpp's caller provides.
 void vxo_li_damping_iter_gravity(void* h, double* states, double* blobs, int /*thd_num*/, double imu_coef_, int max_iter, double* hess_out,

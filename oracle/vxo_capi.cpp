@@ -366,6 +366,29 @@ double vxo_imu_evaluate_g(const double* blob, const double* st1, const double* s
   }
   return r;
 }
+// LI_BA_OptimizerGravity::divide_thread (voxel_map.hpp:673-736): Hess (15W+3)^2 col-major, JacT 15W+3; returns the residual
+double vxo_li_divide_thread_gravity(void* h, const double* states, const double* blobs, int thd_num, double imu_coef, double* Hess, double* JacT) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  LiCtx c(states, blobs, f.win_size);
+  LI_BA_OptimizerGravity opt;
+  opt.thd_num = thd_num; opt.imu_coef = imu_coef;
+  opt.win_size = f.win_size; opt.jac_leng = 6 * f.win_size; opt.imu_leng = DIM * f.win_size + 3;
+  MatX H(opt.imu_leng, opt.imu_leng);
+  std::vector<double> J(opt.imu_leng);
+  const double r = opt.divide_thread(c.xs, f, c.imus, H, J);
+  std::memcpy(Hess, H.a.data(), sizeof(double) * H.a.size());
+  std::memcpy(JacT, J.data(), sizeof(double) * J.size());
+  return r;
+}
+// LI_BA_OptimizerGravity::only_residual (voxel_map.hpp:738-773)
+double vxo_li_only_residual_gravity(void* h, const double* states, const double* blobs, int thd_num, double imu_coef) {
+  LidarFactor& f = ((Handle*)h)->factor;
+  LiCtx c(states, blobs, f.win_size);
+  LI_BA_OptimizerGravity opt;
+  opt.thd_num = thd_num; opt.imu_coef = imu_coef;
+  opt.win_size = f.win_size; opt.jac_leng = 6 * f.win_size; opt.imu_leng = DIM * f.win_size + 3;
+  return opt.only_residual(c.xs, f, c.imus);
+}
 // LI_BA_OptimizerGravity::damping_iter (voxel_map.hpp:775-862): hess_out (15W+3)^2, resis_out[2]
 void vxo_li_damping_iter_gravity(void* h, double* states, double* blobs, int thd_num, double imu_coef, int max_iter, double* hess_out,
                                  double* resis_out, double* trace_out, int* n_trace) {

@@ -88,6 +88,11 @@ def lib():
     L.vxo_imu_evaluate.argtypes = [f64p, f64p, f64p, f64p, f64p, C.c_int]
     L.vxo_li_divide_thread.restype = C.c_double
     L.vxo_li_divide_thread.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double, f64p, f64p]
+    if hasattr(L, "vxo_li_divide_thread_gravity"):      # (a libref.so built before round 4 lacks the two gravity members)
+        L.vxo_li_divide_thread_gravity.restype = C.c_double
+        L.vxo_li_divide_thread_gravity.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double, f64p, f64p]
+        L.vxo_li_only_residual_gravity.restype = C.c_double
+        L.vxo_li_only_residual_gravity.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double]
     L.vxo_li_only_residual.restype = C.c_double
     L.vxo_li_only_residual.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double]
     L.vxo_li_damping_iter.argtypes = [C.c_void_p, f64p, f64p, C.c_int, C.c_double, C.c_int, f64p, f64p, C.POINTER(C.c_int)]
@@ -302,6 +307,18 @@ def li_divide_thread(o, states, blobs, thd_num=5, imu_coef=1e-4):
     H = np.zeros((n, n)); J = np.zeros(n)
     r = lib().vxo_li_divide_thread(o._h, _c(states), _c(blobs), thd_num, imu_coef, H, J)
     return H.T.copy(), J, r
+
+
+def li_divide_thread_gravity(o, states, blobs, thd_num=5, imu_coef=1e-4):
+    """LI_BA_OptimizerGravity::divide_thread (voxel_map.hpp:673-736): (15W+3)^2 system, gravity unknowns at the tail."""
+    n = LI_DIM * o.win_size + 3
+    H = np.zeros((n, n)); J = np.zeros(n)
+    r = lib().vxo_li_divide_thread_gravity(o._h, _c(states), _c(blobs), thd_num, imu_coef, H, J)
+    return H.T.copy(), J, r
+
+
+def li_only_residual_gravity(o, states, blobs, thd_num=5, imu_coef=1e-4):
+    return lib().vxo_li_only_residual_gravity(o._h, _c(states), _c(blobs), thd_num, imu_coef)
 
 
 def li_only_residual(o, states, blobs, thd_num=5, imu_coef=1e-4):

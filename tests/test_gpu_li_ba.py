@@ -302,3 +302,39 @@ def test_undelivered_device_step_falls_back_to_the_host_solve(vx):
     ref = O.li_damping_iter(fo, iw.states_init, blobs, max_iter=4, thd_num=5, imu_coef=1e-4)
     et, er = synth.pose_errors(got["states"][:, :12], ref["states"][:, :12])
     assert et < 1e-7 and er < 1e-7, (et, er)
+
+
+def test_gravity_variant_joint_system_and_residual_match_the_checkers(vx):
+    """LI_BA_OptimizerGravity::divide_thread / only_residual / hess_plus under their own names (voxel_map.hpp:663-773): the (15W+3)^2 system
+    with the gravity unknowns at the tail against the oracle restatement and, where libref.so travelled, the reference's own members."""
+    from tests import _ref
+    sc, iw, blobs, facs, fo, fg = build(vx, 6, 1500, 12000, seed=831)
+    opt = vx.LI_BA_OptimizerGravity(imu_coef=1e-4)
+    H, J, r = opt.divide_thread(iw.states_init, fg, facs)
+    W = sc.win_size
+    assert H.shape == (15 * W + 3, 15 * W + 3) and J.shape == (15 * W + 3,)
+    checkers = [("oracle", O, fo)]
+    R = _ref.backend()
+    if R is not None and hasattr(R.lib(), "vxo_li_divide_thread_gravity"):
+        fr = R.Oracle(W); fr.push_voxels(sc.clusters, sc.fix, sc.coe); fr.evaluate_only_residual(sc.poses_init)
+        checkers.append(("reference", R, fr))
+    for name, B, fb in checkers:
+        Hr, Jr, rr = B.li_divide_thread_gravity(fb, iw.states_init, blobs, thd_num=5, imu_coef=1e-4)
+        scale = np.abs(Hr).max()
+        assert np.allclose(H, Hr, rtol=0, atol=1e-10 * scale), (name, np.abs(H - Hr).max() / scale)
+        assert np.allclose(J, Jr, rtol=0, atol=1e-10 * np.abs(Jr).max()), name
+        assert abs(r - rr) <= 1e-10 * abs(rr), name
+        assert np.abs(Hr[-3:, :]).max() > 0                      # the gravity rows are really there
+        r2 = opt.only_residual(iw.states_init, fg, facs)
+        assert abs(r2 - B.li_only_residual_gravity(fb, iw.states_init, blobs, thd_num=5, imu_coef=1e-4)) <= 1e-10 * abs(rr), name
+    # hess_plus into the (15W+3) system: the 6x6 blocks land at (15 i, 15 j), the tail stays untouched
+    rng = np.random.default_rng(3)
+    n, m = 15 * W + 3, 6 * W
+    H15 = np.zeros((n, n)); J15 = np.zeros(n); hs = rng.normal(size=(m, m)); js = rng.normal(size=m)
+    vx.load_library().vxba_hess_plus_gravity(W, H15, J15, np.ascontiguousarray(hs.T), js)       # column-major on the wire
+    H15 = H15.T
+    for i in range(W):
+        assert np.array_equal(J15[15 * i:15 * i + 6], js[6 * i:6 * i + 6])
+        for j in range(W):
+            assert np.array_equal(H15[15 * i:15 * i + 6, 15 * j:15 * j + 6], hs[6 * i:6 * i + 6, 6 * j:6 * j + 6])
+    assert np.count_nonzero(H15) == m * m and not H15[-3:, :].any() and not J15[-3:].any()

@@ -156,6 +156,12 @@ def test_inertial_half_matches_the_reference(W, V, pts):
     Hr, Jr, rr = R.li_divide_thread(fr, iw.states_init, br, thd_num=5, imu_coef=1e-4)
     assert rel(Ho, Hr) < 1e-8 and rel(Jo, Jr) < 1e-8 and np.isclose(ro, rr, rtol=1e-9)
     assert np.isclose(O.li_only_residual(fo, iw.states_init, br, 5, 1e-4), R.li_only_residual(fr, iw.states_init, br, 5, 1e-4), rtol=1e-9)
+    # LI_BA_OptimizerGravity::divide_thread / only_residual under their own names (voxel_map.hpp:673-773)
+    Hog, Jog, rog = O.li_divide_thread_gravity(fo, iw.states_init, br, thd_num=5, imu_coef=1e-4)
+    Hrg, Jrg, rrg = R.li_divide_thread_gravity(fr, iw.states_init, br, thd_num=5, imu_coef=1e-4)
+    assert Hog.shape == (15 * W + 3, 15 * W + 3) and rel(Hog, Hrg) < 1e-8 and rel(Jog, Jrg) < 1e-8 and np.isclose(rog, rrg, rtol=1e-9)
+    assert np.abs(Hrg[-3:, :-3]).max() > 0 and np.allclose(Hrg[:15 * W, :15 * W][:6, :6], Hr[:6, :6], rtol=1e-9)    # gravity rows present; the pose blocks are the 15W system's
+    assert np.isclose(O.li_only_residual_gravity(fo, iw.states_init, br, 5, 1e-4), R.li_only_residual_gravity(fr, iw.states_init, br, 5, 1e-4), rtol=1e-9)
     # LI_BA_Optimizer::damping_iter (3 iterations upstream)
     oo = O.li_damping_iter(fo, iw.states_init, br, max_iter=3, thd_num=5, imu_coef=1e-4)
     rr_ = R.li_damping_iter(fr, iw.states_init, br, max_iter=3, thd_num=5, imu_coef=1e-4)

@@ -169,6 +169,21 @@ int vxba_li_evaluate(vxba_factor* f, const double* states, const double* imus, d
   hipSetDevice(f->device);
   return li_joint_system(f, states, imus, imu_coef, Hess, JacT, residual);
 }
+// LI_BA_OptimizerGravity::divide_thread (voxel_map.hpp:673-736): the (15W + 3)-dimensional joint system, gravity at the tail
+int vxba_li_evaluate_gravity(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* Hess, double* JacT, double* residual) {
+  VX_LOCK(f);
+  if (!f || !states || (!imus && f->W > 1) || !Hess || !JacT || !residual) return fail(f, VXBA_ERR_ARG, "li_evaluate_gravity: null argument");
+  if (f->V == 0) return fail(f, VXBA_ERR_STATE, "li_evaluate_gravity on an empty factor");
+  VX_NARROW_ONLY(f, "li_evaluate_gravity");
+  hipSetDevice(f->device);
+  return li_joint_system(f, states, imus, imu_coef, Hess, JacT, residual, true);
+}
+// LI_BA_OptimizerGravity::hess_plus (voxel_map.hpp:663-671): the same scatter into a system with leading dimension 15W + 3
+int vxba_hess_plus_gravity(int W, double* Hess, double* JacT, const double* Hess6, const double* JacT6) {
+  if (W < 1 || !Hess || !JacT || !Hess6 || !JacT6) return VXBA_ERR_ARG;
+  vxi::li_hess_plus(W, Hess, JacT, Hess6, JacT6, vxi::DIM * W + 3);
+  return VXBA_OK;
+}
 int vxba_li_only_residual(vxba_factor* f, const double* states, const double* imus, double imu_coef, double* residual) {
   VX_LOCK(f);
   if (!f || !states || (!imus && f->W > 1) || !residual) return fail(f, VXBA_ERR_ARG, "li_only_residual: null argument");

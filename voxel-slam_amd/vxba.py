@@ -31,7 +31,7 @@ EXPORTS = [
     "vxba_evaluate_only_residual", "vxba_get_collective_time", "vxba_acc_evaluate2_device", "vxba_evaluate_only_residual_device", "vxba_packed_len",
     "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_plane_fit_judge", "vxba_build_clusters", "vxba_set_allreduce",
     "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_attach_bcast", "vxba_rccl_detach", "vxba_peer_export", "vxba_peer_attach", "vxba_peer_detach", "vxba_peer_status", "vxba_peer_selftest", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_device_bytes", "vxba_debug_mfma_probe", "vxba_debug_stamps", "vxba_debug_band_schur", "vxba_push_voxels_csr",
-    "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_li_evaluate",
+    "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_hess_plus_gravity", "vxba_li_evaluate", "vxba_li_evaluate_gravity",
     "vxba_li_only_residual", "vxba_li_damping_iter", "vxba_imu_evaluate_g", "vxba_li_damping_iter_gravity", "vxba_voxelize_push", "vxba_set_precision",
     "vxba_lio_create", "vxba_lio_destroy", "vxba_lio_last_error", "vxba_lio_map_update", "vxba_lio_map_clear", "vxba_lio_map_size", "vxba_lio_scan_raw",
     "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_lio_leaf_stats", "vxba_cov_add_build", "vxba_plane_update", "vxba_down_sampling_voxel", "vxba_voxelize_push_device",
@@ -137,6 +137,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_imu_update_state.argtypes = [_f64p, _f64p]
     L.vxba_hess_plus.argtypes = [ci, _f64p, _f64p, _f64p, _f64p]
     L.vxba_li_evaluate.argtypes = [vp, _f64p, _f64p, cd, _f64p, _f64p, C.POINTER(cd)]
+    L.vxba_hess_plus_gravity.argtypes = [ci, _f64p, _f64p, _f64p, _f64p]
+    L.vxba_li_evaluate_gravity.argtypes = [vp, _f64p, _f64p, cd, _f64p, _f64p, C.POINTER(cd)]
     L.vxba_li_only_residual.argtypes = [vp, _f64p, _f64p, cd, C.POINTER(cd)]
     L.vxba_li_damping_iter.argtypes = [vp, _f64p, _f64p, cd, ci, vp, vp, C.POINTER(ci)]
     L.vxba_voxelize_push.argtypes = [vp, C.c_int64, _f64p, _i64p, _f64p, C.POINTER(VoxelizeParams), C.POINTER(C.c_int64), vp, C.c_int64]
@@ -622,6 +624,16 @@ class LI_BA_Optimizer:
 
 class LI_BA_OptimizerGravity(LI_BA_Optimizer):
     """LI_BA_Optimizer with the gravity vector as three more unknowns (reference: voxel_map.hpp:658-864)."""
+
+    def divide_thread(self, x_stats, voxhess: LidarFactor, imus_factor):
+        """The (15W+3)-dimensional joint system (voxel_map.hpp:673-736): returns (Hess[r, c], JacT, residual)."""
+        W = voxhess.win_size
+        n = LI_DIM * W + 3
+        Hess = np.zeros((n, n)); JacT = np.zeros(n); r = C.c_double(0)
+        voxhess._chk(voxhess._L.vxba_li_evaluate_gravity(voxhess.handle, _c(x_stats), self._blobs(imus_factor), self.imu_coef, Hess, JacT, C.byref(r)))
+        return Hess.T.copy(), JacT, r.value
+
+    # only_residual: inherited -- give_evaluate_g without Jacobian is give_evaluate without Jacobian (voxel_map.hpp:738-773)
 
     def damping_iter(self, x_stats, voxhess: LidarFactor, imus_factor, max_iter: int = 2):
         W = voxhess.win_size
