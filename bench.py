@@ -560,7 +560,7 @@ def li_ba_rate(sc, f, solves=20, with_cpu=False):
     out = {"iterations_per_s": it_per_solve / med, "ms_per_iteration": 1e3 * med / it_per_solve, "solves": solves, "iterations": iters,
            "ms_per_iteration_inside_the_call": 1e3 * float(np.median(in_call)) / it_per_solve,
            "pose_rmse_vs_truth_m_rad": [et, er],
-           "where": "whole loop device-resident" if f.get_option("li_device_loop") else "sweeps on GPU; IMU factors + structured (band Cholesky + Schur complement) solve on the host, overlapped with the sweeps"}
+           "where": "sweeps and the reduced pose solve on the GPU; IMU factors + elimination of velocities / biases (band Cholesky + Schur complement) on the host, under the sweeps"}
     if with_cpu:
         # the LiDAR-inertial optimiser's own CPU baseline: LI_BA_Optimizer::damping_iter of the checker (5 std::threads, as upstream) on the
         # same window, one solve; and the pose difference of the two results (outside any timed region)

@@ -360,13 +360,14 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
 
 /* ---- execution options (per handle; none of them changes results beyond rounding) -----------------------------------------
  * Every switch that used to be an environment variable is a setter.  The environment variables of the same name
- * (VXBA_FUSED_SOLVE, VXBA_SPEC_COLLECTIVE, VXBA_WIDE_DEVICE_SOLVE, VXBA_LI_DEVICE, VXBA_K2_VPB, VXBA_LIO_DEVICE_EKF) still give the
+ * (VXBA_FUSED_SOLVE, VXBA_SPEC_COLLECTIVE, VXBA_WIDE_DEVICE_SOLVE, VXBA_K2_VPB, VXBA_LIO_DEVICE_EKF) still give the
  * INITIAL value of a new handle -- for A/B scripts -- and nothing reads them after vxba_create / vxba_lio_create. */
 #define VXBA_OPT_FUSED_SOLVE 0        /* 1 (default): the 6W damped solve runs as workgroup 0 of the residual-sweep launch; 0: own launch */
 #define VXBA_OPT_SPEC_COLLECTIVE 1    /* 1 (default): sharded LM loop with ONE all-reduce per iteration (speculative Hessian sweep at the trial poses) */
 #define VXBA_OPT_WIDE_DEVICE_SOLVE 2  /* 1 (default): the damped step of a wide window (W > 10) by the library's blocked Cholesky on the device (host pivoted
                                          LDL^T when a pivot is not positive); 0: always the host LDL^T */
-#define VXBA_OPT_LI_DEVICE_LOOP 3     /* LI_BA_Optimizer loop: 0 = host shell between the GPU sweeps, 1 = whole loop device-resident */
+#define VXBA_OPT_LI_DEVICE_LOOP 3     /* reserved: the device-resident 15W loop of rounds 1-3 (IMU factor kernels + a one-wave block-Thomas solve, ~265 us per
+                                         iteration against ~66 for the default shell) was removed in round 4; only 0 is accepted */
 #define VXBA_OPT_K2_VOXELS_PER_BLOCK 4 /* 64 (default) or 32..63: voxels per residual-sweep workgroup (tuning experiment) */
 #define VXBA_OPT_DEBUG_SOLVE_TIMEOUT 5 /* test hook, 0 (default): with 1 the voxel workgroups of a fused launch give up waiting for the in-launch solve at
                                          once, which exercises the transparent non-fused retry of vxba_damping_iter; with 2 vxba_li_damping_iter treats the

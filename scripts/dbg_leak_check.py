@@ -28,7 +28,7 @@ for rep in range(60):
         for g, a, dt in zip(gyr[:5], acc[:5], dts[:5]):
             fac.add_imu(g, a, dt, iw.noise_meas, iw.noise_walk)
         facs.append(fac)
-    f.set_option("li_device_loop", rep % 2); f.set_option("li_queued_sweeps", (rep // 2) % 2)
+    f.set_option("li_queued_sweeps", rep % 2)
     vxba.LI_BA_Optimizer().damping_iter(iw.states_init, f, facs, max_iter=2)
     f.close()
     f2 = vxba.LidarFactor(6); f2.voxelize_push(xyz, fp, poses, P, want_ids=False); f2.close()

@@ -58,22 +58,19 @@ def test_joint_system_matches_oracle(vx, W, V, pts):
     assert np.isclose(r2, O.li_only_residual(fo, iw.states_init, blobs, 5, 1e-4), rtol=1e-10)
 
 
-@pytest.mark.parametrize("mode", ["host_shell_queued_sweeps", "host_shell_queued_host_pose_solve", "host_shell_plain", "host_shell_dense_solve", "device_loop"])
+@pytest.mark.parametrize("mode", ["host_shell_queued_sweeps", "host_shell_queued_host_pose_solve", "host_shell_plain", "host_shell_dense_solve"])
 @pytest.mark.parametrize("W,V,pts,iters", [(5, 800, 8000, 3), (10, 3000, 40000, 6), (2, 300, 4000, 4)])
 def test_li_damping_iter_matches_oracle(vx, W, V, pts, iters, mode):
-    """The five ways the library runs LI_BA_Optimizer::damping_iter, same contract each: the host shell with its sweeps queued and the reduced
+    """The four ways the library runs LI_BA_Optimizer::damping_iter, same contract each: the host shell with its sweeps queued and the reduced
     pose system solved inside the residual-sweep launch (default: velocities / biases eliminated on the host under the Hessian sweep, no kernel
     waits for the host), the same with the pose system solved on the host (trial poses fed to the waiting residual sweep through mapped host
-    memory -- also what the default does after a rejected step), the host shell launching every
-    sweep when its poses exist, the same with the dense 15W LDL^T instead of the band / Schur solve, and the whole loop enqueued on the
-    GPU (IMU factor kernels, Schur solve over the block-tridiagonal velocity-bias part, accept / reject on the device)."""
+    memory -- also what the default does after a rejected step), the host shell launching every sweep when its poses exist, and the same with
+    the dense 15W LDL^T instead of the band / Schur solve.  (A fifth, the whole loop enqueued on the GPU, was removed in round 4: 4x slower.)"""
     sc, iw, blobs, facs, fo, fg = build(vx, W, V, pts, seed=600 + W)
-    device_loop = mode == "device_loop"
-    fg.set_option("li_device_loop", 1 if device_loop else 0)
     fg.set_option("li_queued_sweeps", 1 if mode.startswith("host_shell_queued") else 0)
     fg.set_option("li_device_pose_solve", 0 if mode == "host_shell_queued_host_pose_solve" else 1)   # default: the reduced pose system is solved inside the residual-sweep launch
     fg.set_option("li_structured_solve", 0 if mode == "host_shell_dense_solve" else 1)
-    assert fg.get_option("li_device_loop") == (1 if device_loop else 0)
+    assert fg._L.vxba_set_option(fg._h, 3, 1) != 0 and fg._L.vxba_set_option(fg._h, 3, 0) == 0     # VXBA_OPT_LI_DEVICE_LOOP: reserved slot, only 0 is accepted
     ref = O.li_damping_iter(fo, iw.states_init, blobs, max_iter=iters, thd_num=5, imu_coef=1e-4)
     got = vx.LI_BA_Optimizer(imu_coef=1e-4).damping_iter(iw.states_init, fg, facs, max_iter=iters)
     assert got["trace"].shape == ref["trace"].shape

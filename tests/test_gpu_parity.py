@@ -245,6 +245,16 @@ def test_lm_parity_w10_sparse_with_fix_and_rejections(vx):
     got, ref = check_lm_parity(vx, sc, max_iter=8)      # runs past convergence: exercises the reject branch / early break
 
 
+@pytest.mark.parametrize("W", [2, 3, 4, 6, 7, 8, 9])
+def test_lm_trace_and_pose_parity_every_window_size(vx, W):
+    """The device-resident LM loop against the oracle at every window size the narrow kernels are instantiated for (cfg1 is W = 5, cfg2
+    W = 10): the Hessian sweep's LDS layout -- tile buffers, poses, LM decision inputs, staging areas, dump area -- depends on W, and a
+    round-4 change that was correct at W >= 3 overwrote the decision inputs at W = 2 (found by scripts/fuzz_parity.py, not by the
+    stand-alone sweep tests: only the LM loop reads those words)."""
+    sc = synth.make_scene(win_size=W, pts_per_scan=12000, n_voxels=1200, p_obs=0.8 if W > 2 else 1.0, fix_frac=0.2, seed=900 + W, rot_sigma_deg=0.1, trans_sigma=0.03)
+    check_lm_parity(vx, sc, max_iter=5)
+
+
 def test_lm_steps_bench_driver_converges_like_damping_iter(vx):
     sc = synth.make_scene(win_size=10, pts_per_scan=20000, n_voxels=2000, seed=81)
     fo, fg = seeded_pair(vx, sc)

@@ -64,7 +64,7 @@ int vxba_destroy(vxba_factor* f) {
   if (f->li_ev) hipEventDestroy(f->li_ev);
   if (f->h_packed) hipHostFree(f->h_packed);
   if (f->h_scalar) hipHostFree(f->h_scalar);
-  hipFree(f->d_lm); hipFree(f->d_li); hipFree(f->d_li_hess); hipFree(f->d_scratch);
+  hipFree(f->d_lm); hipFree(f->d_scratch);
   if (f->h_lm) hipHostFree(f->h_lm);
   if (f->own_stream) hipStreamDestroy(f->own_stream);
   delete f;
@@ -637,7 +637,10 @@ int vxba_set_option(vxba_factor* f, int option, int value) {
   if (!f) return VXBA_ERR_ARG;
   VX_LOCK(f);
   switch (option) {
-    case VXBA_OPT_FUSED_SOLVE: case VXBA_OPT_SPEC_COLLECTIVE: case VXBA_OPT_WIDE_DEVICE_SOLVE: case VXBA_OPT_LI_DEVICE_LOOP:
+    case VXBA_OPT_LI_DEVICE_LOOP:
+      if (value != 0) return fail(f, VXBA_ERR_UNSUPPORTED, "vxba_set_option: the device-resident 15W loop was removed in round 4 (4x slower than the default shell); only 0 is accepted");
+      break;
+    case VXBA_OPT_FUSED_SOLVE: case VXBA_OPT_SPEC_COLLECTIVE: case VXBA_OPT_WIDE_DEVICE_SOLVE:
     case VXBA_OPT_LI_STRUCTURED_SOLVE: case VXBA_OPT_LI_QUEUED_SWEEPS: case VXBA_OPT_LI_DEVICE_POSE_SOLVE:
     case VXBA_OPT_FINALIZE_IN_LAUNCH:
       if (value != 0 && value != 1) return fail(f, VXBA_ERR_ARG, "vxba_set_option: this option takes 0 or 1");

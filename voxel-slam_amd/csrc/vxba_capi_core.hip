@@ -238,7 +238,7 @@ void options_from_env(vxba_factor* f) {   // initial values only; vxba_set_optio
   f->opt[VXBA_OPT_FUSED_SOLVE] = flag("VXBA_FUSED_SOLVE", 1);
   f->opt[VXBA_OPT_SPEC_COLLECTIVE] = flag("VXBA_SPEC_COLLECTIVE", 1);
   f->opt[VXBA_OPT_WIDE_DEVICE_SOLVE] = flag("VXBA_WIDE_DEVICE_SOLVE", 1);
-  f->opt[VXBA_OPT_LI_DEVICE_LOOP] = flag("VXBA_LI_DEVICE", 0);
+  f->opt[VXBA_OPT_LI_DEVICE_LOOP] = 0;   // (removed in round 4; the slot stays so that the option numbers do not move)
   f->opt[VXBA_OPT_FINALIZE_IN_LAUNCH] = flag("VXBA_FINALIZE_IN_LAUNCH", 0);
   const char* e = getenv("VXBA_K2_VPB");
   const int v = e ? atoi(e) : 64;

@@ -194,62 +194,6 @@ int vxba_li_only_residual(vxba_factor* f, const double* states, const double* im
 }
 
 // LI_BA_Optimizer::damping_iter (voxel_map.hpp:562-653): the voxel sweeps on the GPU, the 15W-dimensional shell on the host.
-// LI_BA_Optimizer::damping_iter with the whole loop on the device (vxba_li_device.hip): per iteration IMU factors -> Hessian sweep ->
-// joint system -> Schur solve + trial state -> residual sweep + IMU residuals -> accept / reject, all enqueued up front; one D2H at the end.
-// Single GPU, win_size <= VXBA_MAX_WIN.
-static int li_damping_iter_device(vxba_factor* f, double* states, double* imus, double imu_coef, int max_iter, double* hess_out, double* trace_out, int* n_trace,
-                           const double* cov_invs) {
-  const int W = f->W, n = vxi::DIM * W;
-  if (max_iter > vxk::LM_MAX_ITER) max_iter = vxk::LM_MAX_ITER;
-  if (!f->d_li) {
-    VX_HIP(f, hipMalloc((void**)&f->d_li, sizeof(vxli::LIState)));
-    VX_HIP(f, hipMalloc((void**)&f->d_li_hess, sizeof(double) * 225 * vxli::LI_MAXW * vxli::LI_MAXW));
-  }
-  int rc = ensure_exchange(f);
-  if (rc) return rc;
-  vxli::LIState* li = f->d_li;
-  hipStream_t s = f->stream;
-  VX_HIP(f, hipMemcpyAsync(li->states, states, sizeof(double) * vxi::STATE_LEN * W, hipMemcpyHostToDevice, s));
-  if (W > 1) {
-    VX_HIP(f, hipMemcpyAsync(li->imus, imus, sizeof(double) * vxi::IMU_LEN * (W - 1), hipMemcpyHostToDevice, s));
-    VX_HIP(f, hipMemcpyAsync(li->cov_inv, cov_invs, sizeof(double) * 225 * (W - 1), hipMemcpyHostToDevice, s));
-  }
-  vxli::launch_li_init(li, f->d_lm, W, imu_coef, s);
-  vxk::LMPending none;
-  std::memset(&none, 0, sizeof none);
-  for (int it = 0; it < max_iter; it++) {
-    int c = 0;
-    vxli::launch_li_imu(li, W, 0, s);
-    rc = sweep_hess_device(f, nullptr, f->d_lm, &c, &none, 0, f->V, f->d_packed);
-    if (rc) return rc;
-    vxli::launch_li_assemble(li, f->d_packed, W, hess_out ? f->d_li_hess : nullptr, s);
-    vxli::launch_li_solve(li, f->d_lm, W, s);
-    int nparts = 0;
-    rc = sweep_residual_device(f, nullptr, f->d_lm, 0, 0, f->V, nullptr, &nparts, 0);
-    if (rc) return rc;
-    vxli::launch_li_imu(li, W, 1, s);
-    vxli::launch_li_decide(li, f->d_lm, f->d_partial2, nparts, W, s);
-  }
-  VX_HIP(f, hipGetLastError());
-  // results: states, factors (their dbg / dba bookkeeping moved), trace, iteration count, *hess
-  struct Tail { double u, v, residual1, residual2, q1, imu_coef; int calc_hess, done, iter, pad; } tail;
-  std::vector<double> tr((size_t)vxk::LM_MAX_ITER * 8);
-  VX_HIP(f, hipMemcpyAsync(states, li->states, sizeof(double) * vxi::STATE_LEN * W, hipMemcpyDeviceToHost, s));
-  if (W > 1) VX_HIP(f, hipMemcpyAsync(imus, li->imus, sizeof(double) * vxi::IMU_LEN * (W - 1), hipMemcpyDeviceToHost, s));
-  VX_HIP(f, hipMemcpyAsync(&tail, &li->u, sizeof tail, hipMemcpyDeviceToHost, s));
-  VX_HIP(f, hipMemcpyAsync(tr.data(), li->trace, sizeof(double) * 8 * max_iter, hipMemcpyDeviceToHost, s));
-  if (hess_out) VX_HIP(f, hipMemcpyAsync(hess_out, f->d_li_hess, sizeof(double) * n * n, hipMemcpyDeviceToHost, s));
-  VX_HIP(f, hipStreamSynchronize(s));
-  if (trace_out) std::memcpy(trace_out, tr.data(), sizeof(double) * 8 * tail.iter);
-  if (n_trace) *n_trace = tail.iter;
-  if (getenv("VXBA_LI_DBG")) {   // development: phases of the last solve kernel, shader clocks
-    long long d[16];
-    if (hipMemcpy(d, li->dbg, sizeof d, hipMemcpyDeviceToHost) == hipSuccess)
-      std::fprintf(stderr, "[vxba li solve] stage %lld thomas-fwd %lld thomas-bwd %lld schur %lld dense %lld dy %lld q1 %lld update %lld\n", d[1] - d[0], d[2] - d[1], d[3] - d[2],
-                   d[4] - d[3], d[5] - d[4], d[6] - d[5], 0ll, d[7] - d[6]);
-  }
-  return VXBA_OK;
-}
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // The LiDAR-inertial shells with their sweeps QUEUED AHEAD (VXBA_OPT_LI_QUEUED_SWEEPS, single GPU, structured solve).
@@ -724,14 +668,13 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
   const int W = f->W, n = vxi::DIM * W, SL = vxi::STATE_LEN;
   double u = 0.01, v = 2;
   const auto t_call0 = std::chrono::steady_clock::now();
-  const bool device_loop = f->opt[VXBA_OPT_LI_DEVICE_LOOP] != 0 && !has_collective(f);   // sharded runs keep the host shell
-  if (!device_loop) {
+  {
     const int rq = li_damping_iter_queued(f, states, imus, imu_coef, max_iter, hess_out, nullptr, trace_out, n_trace, false);
     if (rq != 1) return rq;
   }
   // the first Hessian sweep goes out before any host-side preparation (covariance inverses, buffers): it needs the poses only
   bool first_sweep_queued = false;
-  if (!device_loop && max_iter > 0 && !has_collective(f)) {
+  if (max_iter > 0 && !has_collective(f)) {
     double Rp0[12 * VXBA_MAX_WIN];
     states_to_poses(W, states, Rp0);
     int rc = sweep_hess_device(f, Rp0, nullptr, nullptr, nullptr, 0, f->V, f->zc_packed);
@@ -745,7 +688,6 @@ int vxba_li_damping_iter(vxba_factor* f, double* states, double* imus, double im
   std::vector<int>& perm = f->li.perm;
   std::vector<double> x_temp(states, states + (size_t)SL * W);
   if (!li_information_matrices(f, W, imus, cov_invs.data())) return fail(f, VXBA_ERR_STATE, "li: singular IMU covariance (factor without samples?)");
-  if (device_loop) return li_damping_iter_device(f, states, imus, imu_coef, max_iter, hess_out, trace_out, n_trace, cov_invs.data());
   double residual1 = 0, residual2 = 0;
   bool is_calc_hess = true;
   int nt = 0;

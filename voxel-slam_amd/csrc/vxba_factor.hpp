@@ -20,7 +20,6 @@
 #include "vxba_imu.hpp"
 #include "vxba_voxelize.h"
 #include "vxba_wide.h"
-#include "vxba_li_device.h"
 #include "vxba_scratch.hpp"
 #include "vxba_internal.h"
 #include "vxba_kernels.h"
@@ -72,8 +71,6 @@ struct vxba_factor {
   vxk::LMState* d_lm = nullptr;  // device-resident LM shell state
   char* d_scratch = nullptr;     // grow-only device scratch of the batch factor construction (staging of points and accepted voxels)
   size_t scratch_cap = 0;
-  vxli::LIState* d_li = nullptr; // device-resident LiDAR-inertial loop state (allocated on first use)
-  double* d_li_hess = nullptr;   // (15W)^2 export of that loop's *hess
   vxk::LMState* h_lm = nullptr;  // pinned read-back copy
   vxw::DenseSolver* wide_solver = nullptr;   // wide windows: device Cholesky of the (6W)-dimensional LM step (vxba_wide.hip)
   bool wide_solver_tried = false;

@@ -15,7 +15,7 @@
 #include <cmath>
 #include <cstring>
 
-// the small fixed-size pieces are also used by the device-resident LiDAR-inertial loop (vxba_li_device.hip)
+// the small fixed-size pieces compile for the device as well (the device-resident LiDAR-inertial loop of rounds 1-3 used them)
 #if defined(__HIPCC__)
 #define VXI_FN __host__ __device__ inline
 #else

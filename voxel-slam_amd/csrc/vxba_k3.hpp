@@ -674,7 +674,8 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
 
   volatile int* pflag = reinterpret_cast<volatile int*>(poseA + 12 * W);   // (PAIR) per wave: steps whose rows are in LDS; zeroed below, before the first barrier that follows
   K3RowOfs ro = k3_row_offsets<W>(wave, vl, fi);   // lane constants: where the lane's three row pieces go inside a tile buffer
-  double* const dump = poseA + 12 * W + 8;         // 32 doubles nobody reads: where the idle lanes' (zero) rows go
+  double* const dump = lmv + 8 + C::WAVES * K3Stage<W>::WAVE_DOUBLES;   // 32 doubles behind the staging areas that nobody reads: where the idle lanes' (zero) rows go
+  // (k3_lds_bytes reserves them.  A first version put the dump behind the poses: at W <= 2 that ran into the LM decision inputs -- found by the randomised sweep)
   if (!active) {
 #pragma unroll
     for (int k = 0; k < 3; k++) { ro.rp[k] = 8 * k; ro.cp[k] = 2 * k; }

@@ -1191,7 +1191,7 @@ int k3_grid_blocks(int device_cus) { return device_cus; }  // one 8-wave workgro
 template <int W>
 constexpr size_t k3_lds_bytes() {
   using C = K3Cfg<W>;
-  constexpr size_t main_d = (size_t)2 * C::BUF + 24 * W + 8 + (size_t)C::WAVES * K3Stage<W>::WAVE_DOUBLES;   // tiles | two pose candidates | LM decision inputs | parameter staging
+  constexpr size_t main_d = (size_t)2 * C::BUF + 24 * W + 8 + (size_t)C::WAVES * K3Stage<W>::WAVE_DOUBLES + 32;   // tiles | poses (+ pair flags) | LM decision inputs | parameter staging | dump for the idle lanes' rows
   // epilogue: parked linear accumulators, then (or, when both fit, beside them) the parked MFMA accumulators
   constexpr size_t epi1 = (size_t)K3_BLOCK * K3Epi<W>::DS, epi2 = (size_t)C::WAVES * C::TPW * 256;
   constexpr size_t epi = K3Epi<W>::ONE_PHASE ? epi1 + epi2 : (epi1 > epi2 ? epi1 : epi2);

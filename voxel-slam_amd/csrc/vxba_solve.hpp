@@ -1,4 +1,4 @@
-// Device-side building blocks of the damped solves (included by vxba_kernels.hip and vxba_li_device.hip): the one-wave dense
+// Device-side building blocks of the damped solves (included by vxba_kernels.hip): the one-wave dense
 // elimination with look-ahead, lane broadcasts, the fast reciprocal, R <- R Exp(dphi).
 #pragma once
 #include <hip/hip_runtime.h>
