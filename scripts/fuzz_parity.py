@@ -20,7 +20,7 @@ def check(cond, msg):
 
 t0 = time.time()
 for case in range(n_cases):
-    kinds = os.environ.get("FUZZ_KINDS", "lm,mixed,wide,li,gravity,lio,vox,vox_octo,ds,planes").split(",")   # FUZZ_KINDS=mixed,li: only those
+    kinds = os.environ.get("FUZZ_KINDS", "lm,mixed,wide,li,gravity,lio,vox,vox_octo,vox_shard,ds,planes").split(",")   # FUZZ_KINDS=mixed,li: only those
     kind = kinds[case % len(kinds)]
     s = int(rng.integers(1, 1 << 30))
     if kind in ("lm", "mixed", "wide", "li", "gravity"):
@@ -128,6 +128,66 @@ for case in range(n_cases):
             check(np.array_equal(cl[short], ref["clusters"][short]) and np.allclose(cl, ref["clusters"], rtol=1e-12, atol=0), "%s clusters W=%d seed=%d" % (kind, W, s))
         desc = "W=%d pts=%d max_layer=%d vs=%.1f factors=%d" % (W, pts, ml, vs, ids.size)
         f.close()
+    elif kind == "vox_shard":
+        # voxel-sharded voxelisation (vxba_voxelize_params.shard_*): the shards partition the unsharded factor set, every voxel bit for bit,
+        # and every voxel sits on the shard dist.root_shard names; narrow and wide (compressed-row) factors
+        from voxel_slam_amd import dist as vdist
+        W = int(rng.integers(2, 11)) if rng.integers(0, 2) else int(rng.integers(11, 30))
+        pts = int(rng.integers(3000, 25000)); ml = int(rng.integers(0, 4)); vs = float(rng.choice([0.5, 1.0, 2.0])); N = int(rng.choice([2, 3, 5, 8]))
+        xyz, fp, poses, _ = synth.make_scans(win_size=W, pts_per_scan=pts, seed=s)
+        P = vxba.VoxelizeParams(voxel_size=vs, max_layer=ml, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
+        f = vxba.LidarFactor(W); ids = f.voxelize_push(xyz, fp, poses, P)
+        full = {int(i): k for k, i in enumerate(ids)}
+        cl_full = f.read_clusters() if W <= 10 and ids.size else None
+        ev_full = f.read_cache()[0] if ids.size else None
+        seen = 0
+        for r in range(N):
+            g = vxba.LidarFactor(W); ids_r = g.voxelize_push(xyz, fp, poses, P.sharded(r, N))
+            check(np.all(vdist.root_shard(ids_r >> np.uint64(16), N) == r), "vox_shard: a voxel on the wrong shard W=%d N=%d seed=%d" % (W, N, s))
+            check(all(int(i) in full for i in ids_r), "vox_shard: a voxel the unsharded run does not have W=%d N=%d seed=%d" % (W, N, s))
+            if ids_r.size and all(int(i) in full for i in ids_r):
+                sel = np.array([full[int(i)] for i in ids_r])
+                check(np.array_equal(g.read_cache()[0], ev_full[sel]), "vox_shard: eigenvalues differ W=%d N=%d seed=%d" % (W, N, s))
+                if cl_full is not None:
+                    check(np.array_equal(g.read_clusters(), cl_full[sel]), "vox_shard: clusters differ W=%d N=%d seed=%d" % (W, N, s))
+            seen += ids_r.size
+            g.close()
+        check(seen == ids.size, "vox_shard: shards hold %d voxels, the unsharded run %d (W=%d N=%d seed=%d)" % (seen, ids.size, W, N, s))
+        desc = "W=%d pts=%d max_layer=%d vs=%.1f shards=%d factors=%d" % (W, pts, ml, vs, N, ids.size)
+        f.close()
+    elif kind == "map_release":
+        # vxba_map_release on a random drive: a released map against an unreleased twin -- leaves under the kept roots bit for bit, after every release
+        from tests.test_gpu_map import _corridor_scan
+        from tests.test_oracle_octree import PRM, point_vars, to_world
+        win = int(rng.integers(3, 7)); ptsn = int(rng.integers(1500, 5000)); S = int(rng.integers(80, 260)); every = int(rng.integers(7, 40)); age = int(rng.integers(5, 40))
+        kw = dict(PRM); kw["max_points"] = int(rng.choice([40, 60, 100]))
+        ma, mb = vxba.LocalMap(win_size=win, **kw), vxba.LocalMap(win_size=win, **kw)
+        fa, fb = vxba.LidarFactor(win), vxba.LidarFactor(win)
+        r2 = np.random.default_rng(s)
+        xs, wc, jour, gone, ok = [], 0, 0.0, 0, True
+        for k in range(S):
+            body, pose = _corridor_scan(k, ptsn, r2)
+            var = point_vars(body.shape[0], k)
+            xs.append(pose); wc += 1
+            wld = to_world(pose, body)
+            for m, f in ((ma, fa), (mb, fb)):
+                f.clear(); m.cut_voxel(wc - 1, body, var, wld); m.recut(wc, np.stack(xs), f)
+            if wc >= win:
+                ok = ok and fa.size() == fb.size()
+                for m, f in ((ma, fa), (mb, fb)):
+                    if f.size():
+                        f.evaluate_only_residual(np.stack(xs))
+                    m.set_journey(jour); m.margi(wc, np.stack(xs), f); m.slide(1)
+                xs = xs[1:]; wc -= 1; jour += 0.5
+            if k % every == every - 1:
+                gone += ma.release(jour, age)["roots"]
+                la, lb = ma.leaves(), mb.leaves()
+                keep = np.isin(lb["node_id"] >> np.uint64(16), np.unique(la["node_id"] >> np.uint64(16)))
+                ok = ok and int(keep.sum()) == la["node_id"].size and all(np.array_equal(v, lb[key][keep]) for key, v in la.items() if isinstance(v, np.ndarray) and v.shape[:1] == la["node_id"].shape)
+        check(ok, "map_release: the released map differs from its twin under the kept roots (win=%d pts=%d S=%d every=%d age=%d seed=%d)" % (win, ptsn, S, every, age, s))
+        desc = "win=%d pts=%d scans=%d release every %d at age %d: %d roots released, %d left" % (win, ptsn, S, every, age, gone, ma.counts()["roots"])
+        for h in (ma, mb, fa, fb):
+            h.close()
     elif kind == "planes":
         # per-leaf producers of the plane map: clusters, eigen-decomposition, cov_add, plane_update
         n_leaf = int(rng.integers(50, 3000))
