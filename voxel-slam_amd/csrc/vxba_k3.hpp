@@ -502,7 +502,7 @@ constexpr bool K3_LATE_REQ = K3_LATE_REQUESTS != 0;
 #define K3_LATE_PER 4      // requests behind each K-step of phase M: all eight behind the first two of the nine K-steps at W = 10 (1 and 2 per K-step measured slower: later requests land later)
 #endif
 template <int W, bool DBG = false, bool MIXED = false>
-__global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __restrict__ clb, const double* __restrict__ cache_planes, const double* __restrict__ coe_plane,
+__global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k3_hessian_kernel(const double* __restrict__ clb, const double* __restrict__ cache_planes, const double* __restrict__ coe_plane,
                                                               LMState* __restrict__ st, int VS, int head, int end, int c_in, int pend_flags, int nwg,
                                                               PoseArg poses, LMPending pend, double* __restrict__ partial) {
   const int pending = pend_flags & 0xff, restart = pend_flags >> 8;
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hessian_kernel(const double* __re
   // do, an accepted one means it linearises at the trial poses -- so every workgroup starts phase A of its first step at the trial
   // poses as soon as those are in LDS, wave 0 adds up residual2 behind the barrier, and the decision is taken behind the first step's
   // barrier (a rejected step costs one phase A instead of none; the common, accepted one no longer waits for the sum).
-  constexpr int K3_FIRST_WAVES = 4;
+  constexpr int K3_FIRST_WAVES = C::WAVES / 2;
   if (wave != 0 && wave < K3_FIRST_WAVES && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
 
   // LDS behind the two tile buffers: the poses (raw C-ABI layout: R column-major | p per frame) and what the LM decision needs

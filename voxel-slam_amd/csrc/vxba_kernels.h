@@ -6,7 +6,10 @@
 namespace vxk {
 
 constexpr int MAXW = 10;          // VXBA_MAX_WIN: 6W <= 64 accumulator columns
-constexpr int K3_BLOCK = 512;     // 8 waves per workgroup, one workgroup per CU: two waves per SIMD
+#ifndef K3_BLOCK_V
+#define K3_BLOCK_V 512            // experiment knob (vxba_kernels.hip only): 256 = four waves per workgroup, two workgroups per CU
+#endif
+constexpr int K3_BLOCK = K3_BLOCK_V;   // 8 waves per workgroup, one workgroup per CU: two waves per SIMD
 constexpr int DACC = 28;          // per-frame linear accumulators: g(6) Drr(6) Drt(9) Dtt(6) residual(1)
 
 // Poses travel as a kernel argument (W*96 B <= 960 B): uniform scalar loads in K2, one vector load per lane in K3.

@@ -1185,7 +1185,7 @@ void launch_seed_aux(const FactorView& fv, int head, int end, hipStream_t s) {
   hipLaunchKernelGGL(seed_aux_kernel, dim3((end - head + 255) / 256), dim3(256), 0, s, fv, head, end);
 }
 
-int k3_grid_blocks(int device_cus) { return device_cus; }  // one 8-wave workgroup per CU = two waves per SIMD
+int k3_grid_blocks(int device_cus) { return device_cus * (512 / K3_BLOCK); }  // one 8-wave workgroup per CU = two waves per SIMD
 
 // dynamic LDS of the Hessian sweep: two tile buffers + the poses, or the epilogue's parking areas, whichever is larger
 template <int W>
