@@ -255,6 +255,58 @@ def test_lm_trace_and_pose_parity_every_window_size(vx, W):
     check_lm_parity(vx, sc, max_iter=5)
 
 
+def _k3_voxels_per_batch(W):
+    """K3Cfg<W>::NV (csrc/vxba_k3.hpp): voxels per wave and batch."""
+    nt = (6 * W + 15) // 16
+    cap = 12 if nt <= 2 else (8 if nt == 3 else 6)
+    return min(64 // W, cap)
+
+
+@pytest.mark.parametrize("W", [2, 3, 4, 5, 6, 7, 8, 9])
+def test_hessian_sweep_and_lm_loop_with_full_steps_every_window_size(vx, W):
+    """The Hessian sweep's STEADY-STATE loop at every window size: a workgroup only runs full steps (phase M of step s-1 with the next
+    batch's requests riding behind its K-steps, phase A of step s, one barrier) when it owns >= 8 batches, i.e. from ~16k (W = 9) to
+    ~25k (W <= 5) voxels on 256 CUs -- the windows of the other tests at W != 10 are all smaller and only ever take the ragged step.
+    Two full steps and a ragged one per workgroup here; sub-range with a partly filled first and last batch; then the LM loop."""
+    nv = _k3_voxels_per_batch(W)
+    V = nv * (8 * 256 * 2 + 701) + 5
+    sc = synth.make_scene(win_size=W, pts_per_scan=10 * V, n_voxels=V, p_obs=0.8 if W > 2 else 1.0, fix_frac=0.2, seed=1300 + W,
+                          rot_sigma_deg=0.1, trans_sigma=0.03)
+    fo, fg = seeded_pair(vx, sc)
+    H_ref, J_ref, r_ref = fo.acc_evaluate2(sc.poses_init)
+    H, J, r = fg.acc_evaluate2(sc.poses_init)
+    assert relerr(H, H_ref) < 1e-10 and relerr(J, J_ref) < 1e-10 and abs(r - r_ref) <= 1e-12 * abs(r_ref), (relerr(H, H_ref), relerr(J, J_ref))
+    assert np.array_equal(H, H.T)
+    lo, hi = 1234 + W, V - 777
+    Hs_ref, Js_ref, rs_ref = fo.acc_evaluate2(sc.poses_init, lo, hi)
+    Hs, Js, rs = fg.acc_evaluate2(sc.poses_init, lo, hi)
+    assert relerr(Hs, Hs_ref) < 1e-10 and relerr(Js, Js_ref) < 1e-10 and abs(rs - rs_ref) <= 1e-12 * abs(rs_ref)
+    ref = fo.damping_iter(sc.poses_init, max_iter=3, thd_num=4)
+    got = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=3)
+    assert got["trace"].shape == ref["trace"].shape and np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:])
+    assert np.allclose(got["trace"][:, :2], ref["trace"][:, :2], rtol=1e-9)
+    et, er = synth.pose_errors(got["poses"], ref["poses"])
+    assert et < 1e-7 and er < 1e-7, (et, er)
+    assert relerr(got["hess"], ref["hess"]) < 1e-8
+
+
+@pytest.mark.parametrize("W", [3, 5, 8, 9])
+def test_mixed_precision_lm_loop_with_full_steps(vx, W):
+    """BASELINE configs[2]'s arithmetic (f32 products on the matrix cores, f64 accumulation) through the steady-state loop of the Hessian
+    sweep at window sizes other than 10 (tile sets, K ranges and the operand permutation of the f32 instruction all depend on W)."""
+    nv = _k3_voxels_per_batch(W)
+    V = nv * (8 * 256 * 2 + 333) + 1
+    sc = synth.make_scene(win_size=W, pts_per_scan=10 * V, n_voxels=V, p_obs=0.8, fix_frac=0.2, seed=1400 + W, rot_sigma_deg=0.1, trans_sigma=0.03)
+    fo, fg = seeded_pair(vx, sc)
+    fg.set_precision("mixed")
+    ref = fo.damping_iter(sc.poses_init, max_iter=3, thd_num=4)
+    got = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=3)
+    assert got["trace"].shape == ref["trace"].shape and np.array_equal(got["trace"][:, 6], ref["trace"][:, 6])
+    et, er = synth.pose_errors(got["poses"], ref["poses"])
+    assert et < 1e-5 and er < 1e-5, (et, er)          # contract 1e-4 m / 1e-4 rad
+    assert relerr(got["hess"], ref["hess"]) < 1e-5
+
+
 def test_lm_steps_bench_driver_converges_like_damping_iter(vx):
     sc = synth.make_scene(win_size=10, pts_per_scan=20000, n_voxels=2000, seed=81)
     fo, fg = seeded_pair(vx, sc)
