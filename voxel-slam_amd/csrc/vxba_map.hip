@@ -1479,10 +1479,14 @@ int vxba_map_release(vxba_map* m, double jour_now, int min_age, vxba_lio* lio, i
   map_compact_refs_kernel<<<grid_for(n_new), 256, 0, m->stream>>>(nd, n_new, d_pos);
   // the voxel table, from scratch (released keys must not linger: open addressing has no delete)
   map_fill_u64_kernel<<<grid_for(m->table_cap), 256, 0, m->stream>>>(m->keys, m->table_cap, EMPTY_KEY);
-  VM_HIP(m, hipMemsetAsync(m->vals, 0, (size_t)m->table_cap * sizeof(int), m->stream));
+  hipError_t te = hipMemsetAsync(m->vals, 0, (size_t)m->table_cap * sizeof(int), m->stream);
   map_table_insert_roots_kernel<<<grid_for(n_new), 256, 0, m->stream>>>(nd, n_new, m->keys, m->vals, (unsigned long long)m->table_cap - 1);
-  VM_HIP(m, map_wait(m->stream));
-  VM_HIP(m, hipGetLastError());
+  if (te == hipSuccess) te = map_wait(m->stream);
+  if (te == hipSuccess) te = hipGetLastError();
+  if (te != hipSuccess) {   // the nodes have moved and the table may not point at them: as unusable as a half-compacted pool
+    m->broken = true;
+    return mfail(m, VXBA_ERR_HIP, "vxba_map_release: rebuilding the voxel table failed after the node pool was compacted; the map is unusable from here on");
+  }
   m->n_nodes = n_new;
   m->n_roots -= n_gone_roots;
   m->n_released_roots += n_gone_roots;
