@@ -30,6 +30,8 @@ CONFIGS = {
     # SURVEY 8d's secondary runs of cfg2: half the (voxel, frame) incidences missing; 30 % of the voxels with a world-frame fix cluster
     "cfg2_sparse": dict(win_size=10, pts_per_scan=100_000, n_voxels=50_000, p_obs=0.5),
     "cfg2_fix": dict(win_size=10, pts_per_scan=100_000, n_voxels=50_000, fix_frac=0.3),
+    # development: cfg2 with a voxel count that fills whole steps of the Hessian sweep on 256 CUs (256 x 4 x 48 voxels: no ragged step) -- what the ragged step costs
+    "cfg2_even": dict(win_size=10, pts_per_scan=100_000, n_voxels=49_152),
 }
 
 
