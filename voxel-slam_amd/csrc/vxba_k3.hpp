@@ -565,7 +565,10 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
   // do, an accepted one means it linearises at the trial poses -- so every workgroup starts phase A of its first step at the trial
   // poses as soon as those are in LDS, wave 0 adds up residual2 behind the barrier, and the decision is taken behind the first step's
   // barrier (a rejected step costs one phase A instead of none; the common, accepted one no longer waits for the sum).
-  constexpr int K3_FIRST_WAVES = C::WAVES / 2;
+#ifndef K3_FIRST_WAVES_V
+#define K3_FIRST_WAVES_V (C::WAVES / 2)
+#endif
+  constexpr int K3_FIRST_WAVES = K3_FIRST_WAVES_V;
   if (wave != 0 && wave < K3_FIRST_WAVES && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
 
   // LDS behind the two tile buffers: the poses (raw C-ABI layout: R column-major | p per frame) and what the LM decision needs
