@@ -1,5 +1,5 @@
 """A short run of the randomised GPU-vs-oracle sweep (scripts/fuzz_parity.py: random window sizes, voxel counts, incidences, fix
-clusters, perturbations, map depths -- LiDAR LM narrow / wide / mixed precision, LiDAR-inertial host and device loops, the gravity
+clusters, perturbations, map depths -- LiDAR LM narrow / wide / mixed precision, LiDAR-inertial shells, the gravity
 variant, odometry, both batch voxelisations, down-sampling, the per-leaf plane producers)."""
 import os
 import subprocess
