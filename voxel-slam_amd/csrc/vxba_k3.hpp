@@ -498,6 +498,13 @@ constexpr bool K3_LATE_REQ = K3_LATE_REQUESTS != 0;
 #ifndef K3_LATE_MIXED
 #define K3_LATE_MIXED 0
 #endif
+// K3_RAGGED_FIRST (round 4, experiment): the partly filled step of a workgroup (cnt mod 8 batches, one on 142 of 256 workgroups at cfg2) is
+// taken in the FILL instead of behind the last full step: waves 4 .. request those batches before the prologue barrier (they would
+// otherwise wait for the barrier with nothing in flight), run their phase A into the idle tile buffer while the first full batches are
+// still on their way, and the short phase M + a barrier of its own sit in front of step 1.
+#ifndef K3_RAGGED_FIRST
+#define K3_RAGGED_FIRST 0
+#endif
 #ifndef K3_LATE_PER
 #define K3_LATE_PER 4      // requests behind each K-step of phase M: all eight behind the first two of the nine K-steps at W = 10 (1 and 2 per K-step measured slower: later requests land later)
 #endif
@@ -533,6 +540,11 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int g = blockIdx.x;
   const int cnt = q + (g < rem ? 1 : 0);
   const int bs = b0 + g * q + (g < rem ? g : rem);
+  // (K3_RAGGED_FIRST) the ragged batches of this workgroup go first, on waves 4 .. 4 + nrag - 1
+  constexpr bool RAGF_ON = (K3_RAGGED_FIRST != 0) && C::WAVES == 8 && (C::R % 2 == 0) && !MIXED;
+  const bool ragf = RAGF_ON && (cnt / C::WAVES) >= 1 && (cnt % C::WAVES) >= 1 && (cnt % C::WAVES) <= 4;
+  const bool ragw = ragf && wave >= 4 && (wave - 4) < (cnt % C::WAVES);
+  const int b_rag = bs + (cnt / C::WAVES) * C::WAVES + (wave - 4);
 
   // The first batch is requested before anything else: it does not depend on the poses, so the LM decision below (a few
   // dependent global reads) runs in the shadow of these loads.  Wave 0 is the exception: loads return in order, so it asks for
@@ -570,6 +582,7 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
 #endif
   constexpr int K3_FIRST_WAVES = K3_FIRST_WAVES_V;
   if (wave != 0 && wave < K3_FIRST_WAVES && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
+  if (RAGF_ON && ragw) { k3_load_clusters(pl, b_rag, lane, e.c); k3_load_params<W>(pl, head, end, b_rag, lane, stg); }
 
   // LDS behind the two tile buffers: the poses (raw C-ABI layout: R column-major | p per frame) and what the LM decision needs
   double* poseA = lds + 2 * C::BUF;       // the poses `xa_src` selects
@@ -633,7 +646,7 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
       if (in_done || !in_calc) return;
     }
   }
-  if (wave >= K3_FIRST_WAVES && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
+  if (wave >= K3_FIRST_WAVES && wave < cnt && !(RAGF_ON && ragw)) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
   if (wave == 0 && undecided) {
     const double r2 = lm_residual2_finish(pend, r2_loads);
     if (lane == 0) lmv[4] = r2;
@@ -695,7 +708,7 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
   // of phase A -- every wave waited out the latency of the loads it had just issued before it reached the barrier (round-4 find, from
   // the ISA: vmcnt(7) / (6) / (5) + six v_mov_b64 in front of the barrier, vmcnt(0) at the head of phase M).
   auto phase_a = [&](int b, int bo_in, int nb, bool more, auto next_tag) __attribute__((always_inline)) {
-    const int bo = bo_in + (decltype(next_tag)::value != 0 ? rowshift : 0);      // full steps (next != 0): the pair layout; the ragged step: the plain one
+    const int bo = bo_in + (decltype(next_tag)::value == 1 ? rowshift : 0);      // full steps (next == 1): the pair layout; the ragged step: the plain one
     constexpr int next = decltype(next_tag)::value;
     // instrumented build, step 2 only: 7 parameters + pose back in registers, 14 rows computed, 15 rows stored, 18 = everything but the requests
     const bool stamp_here = DBG && dbg_step == 2;
@@ -738,7 +751,7 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
     // the two waves of a SIMD taking phase M / phase A in opposite order (13.2k instead of 11.8k cycles per step).  Round 3: s_setprio
     // for one of a SIMD's two waves during phase A (either one: K3 26.6 -> 27.2 us), for phase M (no change).
     if (DBG && stamp_here) { __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 15); asm volatile("" :: "v"(dacc[6]), "v"(dacc[11]), "v"(dacc[0])); __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 18); }
-    if constexpr (next != 0 && !LATE) {
+    if constexpr (next == 2 || (next != 0 && !LATE)) {   // next == 2: requested here whatever the mode (the ragged batch taken first: its wave's first full batch)
       __builtin_amdgcn_sched_barrier(0);   // behind the last use of the entry: the loads go into the registers they free
 #if defined(K3_PARAMS_FIRST) && K3_PARAMS_FIRST
       k3_load_params<W>(pl, head, end, nb, lane, stg, more);   // experiment: the values phase A needs first are requested first
@@ -756,14 +769,32 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int k0_full = kq * C::KPW;
   // AF (experiment, -DK3_OPPOSITE=1): the second wave of every SIMD (w >= 4) takes phase A BEFORE phase M inside an iteration -- the
   // two touch different tile buffers, so the order is free -- to put one wave's VALU work under the other's MFMAs.
+  auto ragged_m = [&](int bo) __attribute__((always_inline)) {
+    // only ceil(nrag R / 4) K-steps exist; they are re-split over the K ranges
+    const int ks = (nrag * C::R + 3) >> 2;
+    const int k0 = (kq * ks) / C::KSPLIT, k1 = ((kq + 1) * ks) / C::KSPLIT;
+    if (MIXED) k3_mfma_phase_f32<W, false>(reinterpret_cast<const float*>(lds) + bo, set, k0, k1 - k0, lrow, lcol, af);
+    else k3_mfma_phase<W, false>(lds + bo, set, k0, k1 - k0, lrow, lcol, acc);
+  };
+  if constexpr (RAGF_ON) {
+    if (ragf) {
+      // rows of ragged batch r = wave - 4 at rows [R r, R (r + 1)) of buffer 1 (a shift by four row blocks of R rows: R is even, so the pair-interleaved
+      // layout shifts linearly); behind it the wave's first full batch is requested.  Wave 0 clears the rows that round the step up to a whole K-step.
+      if (ragw) phase_a(b_rag, C::BUF - 4 * C::R * C::NCOL, bs + wave, true, std::integral_constant<int, 2>{});
+      else if (wave == 0) { double* z = lds + C::BUF + C::at(nrag * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0; }
+    }
+  }
   auto full_steps = [&](auto af_tag) __attribute__((always_inline)) -> bool {
     constexpr bool AF = decltype(af_tag)::value;
     for (int s = 0; s <= nfull; s++) {
+      if constexpr (RAGF_ON) {
+        if (ragf && s == 1) { ragged_m(C::BUF); __syncthreads(); }   // before phase A of step 1 overwrites buffer 1
+      }
       auto phase_m = [&]() __attribute__((always_inline)) {
         const int bo = ((s - 1) & 1) * C::BUF;
         if (MIXED) {
           if constexpr (LATE) {   // mixed precision: the requests in front of the f32 products (not interleaved)
-            const bool more_m = (s < nfull) || (wave < nrag);
+            const bool more_m = (s < nfull) || (wave < nrag && !ragf);
             const int nb_m = bs + s * C::WAVES + wave;
             k3_load_clusters(pl, nb_m, lane, e.c, more_m);
             k3_load_params<W>(pl, head, end, nb_m, lane, stg, more_m);
@@ -773,7 +804,7 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
           // The requests for the batch of step s ride behind the K-steps of phase M of step s-1 (this iteration), one or two per K-step:
           // a vector-memory instruction costs the wave ~60 cycles of issue when eight waves queue on the CU's one address unit
           // (stamps: 460-540 cycles for the eight of a batch), and in front of the barrier that was on the step's critical path.
-          const bool more_m = (s < nfull) || (wave < nrag);
+          const bool more_m = (s < nfull) || (wave < nrag && !ragf);
           const int nb_m = bs + s * C::WAVES + wave;
           constexpr int NQ = K3Stage<W>::Q + 1, NL = 5 + NQ;   // the parameters first: phase A starts with their LDS round trip
           constexpr int PER = (K3_LATE_PER * C::KPW >= NL) ? K3_LATE_PER : (NL + C::KPW - 1) / C::KPW;
@@ -795,7 +826,7 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (s <= 4) dbg_stamp(DBG, gw, 13 + 3 * s);   // phase M of step s-1 done: slots 16, 19, 22, 25
       }
       if (s < nfull) {
-        const bool more = (s + 1 < nfull) || (wave < nrag);
+        const bool more = (s + 1 < nfull) || (wave < nrag && !ragf);
         if (DBG) dbg_step = s;
         phase_a(bs + s * C::WAVES + wave, (s & 1) * C::BUF, bs + (s + 1) * C::WAVES + wave, more, std::integral_constant<int, 1>{});
         if (s >= 1 && s <= 4) dbg_stamp(DBG, gw, 14 + 3 * s);   // phase A of step s done: slots 17, 20, 23, 26
@@ -823,7 +854,7 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
 #else
   if (full_steps(std::false_type{})) return;
 #endif
-  if (nrag > 0) {
+  if (nrag > 0 && !ragf) {
     // ragged last step: nrag < 8 batches.  Only ceil(nrag R / 4) K-steps exist; they are re-split over the K ranges, and the first
     // idle wave makes the rows that round the step up to a whole K-step read as zeros.
     const int bo = (nfull & 1) * C::BUF;
