@@ -235,10 +235,14 @@ for case in range(n_cases):
         check(ca_err < 1e-11, "planes cov_add n=%d rel %.2e" % (n_leaf, ca_err))          # per-cell scale: single entries cancel
         pv_dev = np.abs(pl_g["plane_var"] * S[:, :, None] * S[:, None, :] - pl_o["plane_var"]) / scale_pv
         worst = int(np.argmax(pv_dev.max(axis=(1, 2))))
-        rad_ok = np.allclose(pl_g["radius"], pl_o["radius"], rtol=1e-12, atol=0)      # sqrt of an eigenvalue from two eigensolvers (Jacobi / QL): an ulp apart once in ~10^5 leaves
+        # the radius is the largest eigenvalue ROUNDED TO FLOAT (`float radius`, voxel_map.hpp:1139): two eigensolvers (Jacobi / QL) that agree to
+        # an ulp of the double may still straddle a float rounding boundary -- one float ulp (1.2e-7) apart, once in ~10^5 leaves; never more
+        rad_rel = np.abs(pl_g["radius"] / pl_o["radius"] - 1)
+        rad_dev = float(rad_rel.max())
+        rad_ok = rad_dev < 1.3e-7 and int(np.count_nonzero(rad_rel > 1e-12)) <= 2
         check(np.all(pv_dev <= 1e-6) and rad_ok,
-              "planes plane_update n=%d seed=%d: plane_var rel dev %.2e at leaf %d (eigenvalues %s, N=%d), radius within 1e-12 %s" %
-              (n_leaf, s, pv_dev.max(), worst, ev_o[worst], int(cl_o[worst, 9]), rad_ok))
+              "planes plane_update n=%d seed=%d: plane_var rel dev %.2e at leaf %d (eigenvalues %s, N=%d), radius rel dev %.2e" %
+              (n_leaf, s, pv_dev.max(), worst, ev_o[worst], int(cl_o[worst, 9]), rad_dev))
         desc = "leaves=%d points=%d cov_add rel %.1e" % (n_leaf, k.size, ca_err)
     else:
         n = int(rng.integers(1, 300000)); size = float(rng.choice([0.05, 0.1, 0.25, 1.0])); scale = float(rng.choice([2.0, 30.0]))

@@ -7,6 +7,9 @@ CONFIG=cfg2 STEPS=90 bash scripts/gpu_profile_cfg.sh | tail -3
 CONFIG=cfg3 STEPS=60 bash scripts/gpu_profile_cfg.sh | tail -3
 CONFIG=cfg4 STEPS=30 bash scripts/gpu_profile_cfg.sh | tail -3
 TAG=cold CMD="python $GRAFT_REPO_ROOT/scripts/dbg_cold_l3.py cfg2" bash scripts/gpu_profile_cfg.sh | tail -3
+# file the summaries here as well (the same command is run on the tracked tree afterwards): the bench lines below then carry roofline.traffic
+for c in cfg2 cfg3 cfg4; do python scripts/collect_profile_cfg.py r04_$c $c > /dev/null; done
+python scripts/collect_profile_cfg.py r04_cfg2_cold_l3 cfg2 cold > /dev/null
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r4_final_bench_driver_flags.json 2> gpurun_out/r4_final_bench_driver_flags.err; echo "bench(driver flags) rc=$?"
 timeout 900 python bench.py > gpurun_out/r4_final_bench.json 2> gpurun_out/r4_final_bench.err; echo "bench rc=$?"
 python - <<'PY'
