@@ -558,7 +558,13 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __rest
   // SIMD at 50k voxels the sweep is latency-bound unless all of them are in flight together
   double fx[10], cl[F32 ? 1 : W][10], Up[9];
   float cr[F32 ? W : 1][10];
+  // coe is requested HERE, with everything else: read where it is used -- behind the cache stores at the end -- the load could not be
+  // moved above those stores (may alias, for all the compiler knows), and the wave waited for its latency AND for the acknowledgement of
+  // the 22 written-through stores in front of it before its last four stores and the reduction (round 4, from the ISA: a
+  // global_load_dwordx2 + s_waitcnt vmcnt(0) between the cache stores)
+  double coe_v = 0.0;
   if (valid) {
+    coe_v = fv.coe[a];
 #pragma unroll
     for (int k = 0; k < 10; k++) fx[k] = fv.fix[k * VS + a];
     // previous eigenvectors (plane 3*col+row -> row-major): warm start of the eigensolver
@@ -616,8 +622,8 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __rest
     }
     __builtin_amdgcn_wave_barrier();
   }
+  double SP[6], Sv[3], SN = 1.0, C[6], lam[3] = {0.0, 0.0, 0.0}, U[9];
   if (valid) {
-    double SP[6], Sv[3], SN;
     if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, vb, 1); }
 #pragma unroll
     for (int k = 0; k < 6; k++) SP[k] = fx[k];
@@ -643,11 +649,18 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __rest
         vxm::transform_accumulate(ci, ci + 6, ci[9], R, p, SP, Sv, SN);
       }
     }
-    double C[6], lam[3], U[9];
     vxm::cluster_cov(SP, Sv, SN, C);
     if (DBG) { asm volatile("" :: "v"(C[0]), "v"(C[3]), "v"(C[5])); dbg_stamp(true, vb, 2); }
     vxm::eig_sym3_warm(C, Up, lam, U);
     if (DBG) { asm volatile("" :: "v"(lam[0]), "v"(U[0]), "v"(U[8])); dbg_stamp(true, vb, 3); }
+    res = coe_v * lam[0];
+  }
+  // fixed-tree wave reduction, and the workgroup's partial out BEFORE the cache stores: behind them (a join after 26 written-through stores)
+  // the partial waited for their acknowledgement
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) res += __shfl_down(res, off);
+  if (lane == 0) partial[vb] = res;   // (written through like the cache planes: measured, no change)
+  if (valid) {
 #pragma unroll
     for (int k = 0; k < 3; k++) st_out(&fv.eigval[k * VS + a], lam[k]);
 #pragma unroll
@@ -661,17 +674,11 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __rest
     st_out(&fv.merged[9 * VS + a], SN);
     double s1, s2;
     vxm::gap_scales(lam, s1, s2);
-    const double coe = fv.coe[a];
     st_out(&fv.aux[a], s1);
     st_out(&fv.aux[VS + a], s2);
     st_out(&fv.aux[2 * VS + a], 1.0 / SN);
-    st_out(&fv.aux[3 * VS + a], sqrt(coe));
-    res = coe * lam[0];
+    st_out(&fv.aux[3 * VS + a], sqrt(coe_v));
   }
-  // fixed-tree wave reduction
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) res += __shfl_down(res, off);
-  if (lane == 0) partial[vb] = res;
   if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, vb, 4); }
 }
 

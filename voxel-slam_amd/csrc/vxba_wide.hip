@@ -41,6 +41,7 @@ __global__ __launch_bounds__(64) void k2_wide_kernel(WideView wv, const double* 
   double res = 0.0;
   if (a < end) {
     double SP[6], Sv[3], SN, Up[9];
+    const double coe = fv.coe[a];   // with the other loads: read behind the cache stores below, the load cannot move above them and the wave waits it out at its very end
 #pragma unroll
     for (int k = 0; k < 6; k++) SP[k] = fv.fix[k * VS + a];
 #pragma unroll
@@ -81,7 +82,6 @@ __global__ __launch_bounds__(64) void k2_wide_kernel(WideView wv, const double* 
     fv.merged[9 * VS + a] = SN;
     double s1, s2;
     vxm::gap_scales(lam, s1, s2);
-    const double coe = fv.coe[a];
     fv.aux[a] = s1;
     fv.aux[VS + a] = s2;
     fv.aux[2 * VS + a] = 1.0 / SN;
