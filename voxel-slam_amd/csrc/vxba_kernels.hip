@@ -255,7 +255,7 @@ __device__ __forceinline__ FinMap fin_map(int e) {
 // with write_state, into the LM state the solve reads.  COH: the state goes out as written-through agent-scope stores (the solve runs in
 // the same launch, on another workgroup -- k2_residual_kernel).
 template <int W, bool COH>
-__device__ __forceinline__ void fin_emit(const FinMap& m, double t0, double t1, LMState* __restrict__ gate, int cb, int write_state, double* __restrict__ packed) {
+__device__ __forceinline__ void fin_emit(const FinMap& m, double t0, double t1, LMState* __restrict__ gate, int cb, int write_state, double* __restrict__ packed, int iter) {
   constexpr int n = 6 * W;
   auto put = [](double* p, double v) __attribute__((always_inline)) {
     if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -265,7 +265,7 @@ __device__ __forceinline__ void fin_emit(const FinMap& m, double t0, double t1, 
     packed[m.lin] = t0;
     if (gate && write_state) {   // LM state: gauge-fixed gradient (voxel_map.hpp:400), residual1 (:388)
       if (m.lin < n * n + n) put(&gate->Jwork[m.lin - n * n], (m.lin - n * n < 6) ? 0.0 : t0);
-      else { gate->ctl[cb].residual1 = t0; if (gate->ctl[cb].iter == 0) gate->ctl[cb].resis[0] = t0; }
+      else { gate->ctl[cb].residual1 = t0; if (iter == 0) gate->ctl[cb].resis[0] = t0; }   // `iter` is the caller's early load: read here, behind the stores above, it cost this thread a load + the stores' acknowledgement at the very end of the kernel
     }
   } else {
     const int r = m.r, c = m.c;
@@ -297,6 +297,7 @@ __global__ __launch_bounds__(FIN_EL * FIN_SL) void k3_finalize_kernel(const doub
   const int zoff = threadIdx.x >> 30;
   int f_done = gate ? (&gate->ctl[cb].done)[zoff] : 0;
   int f_calc = gate ? (&gate->ctl[cb].calc_hess)[zoff] : 1;
+  const int f_iter = gate ? (&gate->ctl[cb].iter)[zoff] : 1;
   constexpr int n = 6 * W;
   constexpr int NTILE = C::NTP * 256;
   constexpr int PLEN = NTILE + W * DACC;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(FIN_EL * FIN_SL) void k3_finalize_kernel(const doub
     double t0 = 0.0, t1 = 0.0;
 #pragma unroll
     for (int k = 0; k < 8; k++) { t0 += mid0[k][el]; t1 += mid1[k][el]; }
-    fin_emit<W, false>(m, t0, t1, gate, cb, write_state, packed);
+    fin_emit<W, false>(m, t0, t1, gate, cb, write_state, packed, f_iter);
   }
   dbg_stamp(DBG && threadIdx.x < 64, dbg_w, 2);        // reduced through LDS, outputs issued
   if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(threadIdx.x < 64, dbg_w, 3); }
@@ -392,6 +393,7 @@ __device__ __forceinline__ void fin_phase(const double* __restrict__ partial, in
   const int el = threadIdx.x % FINP_EL, slice = threadIdx.x / FINP_EL;
   double* red0 = lds;
   double* red1 = lds + FINP_EL * FINP_SL;
+  const int f_iter = st ? st->ctl[cb].iter : 1;
   for (int g = wg; g * FINP_EL < PLEN; g += nwg) {
     const int e = g * FINP_EL + el;
     const FinMap m = fin_map<W>(e);
@@ -425,7 +427,7 @@ __device__ __forceinline__ void fin_phase(const double* __restrict__ partial, in
       double t0 = 0.0, t1 = 0.0;
 #pragma unroll
       for (int k = 0; k < FINP_SL; k++) { t0 += red0[k * FINP_EL + el]; t1 += red1[k * FINP_EL + el]; }
-      fin_emit<W, true>(m, t0, t1, st, cb, write_state, packed);
+      fin_emit<W, true>(m, t0, t1, st, cb, write_state, packed, f_iter);
     }
     __syncthreads();
   }
