@@ -254,6 +254,7 @@ __global__ __launch_bounds__(64) void map_push_kernel(Nodes nd, Params prm, cons
   const int node = leaf_sorted[q];
   if (node == 0x7fffffff || (q > 0 && leaf_sorted[q - 1] == node)) return;
   const int W = prm.win_size;
+  const int layer_n = nd.layer[node];   // with the other loads: read behind the 101 stores below it waited for them
   double cl[10], ca[10], acc[81];
   double* g_cl = nd.pcrs_local + ((size_t)node * W + mord) * 10;
   double* g_ca = nd.pcr_add + (size_t)node * 10;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(64) void map_push_kernel(Nodes nd, Params prm, cons
   for (int k = 0; k < 81; k++) g_acc[k] = acc[k];
   nd.has_sw[node] = 1;
   nd.isexist[node] = 1;
-  if (nd.layer[node] < prm.max_layer) { nd.pt_start[(size_t)node * W + mord] = q; nd.pt_count[(size_t)node * W + mord] = cntp; }
+  if (layer_n < prm.max_layer) { nd.pt_start[(size_t)node * W + mord] = q; nd.pt_count[(size_t)node * W + mord] = cntp; }
 }
 // `iter->second->isexist = true` for roots that already existed (voxel_map.hpp:1565) -- marked through the stamp of this scan
 __global__ void map_mark_existing_roots_kernel(Nodes nd, int n_nodes_before, int serial) {
@@ -533,18 +534,32 @@ __global__ void map_factor_flag_kernel(Nodes nd, int n_bound, unsigned long long
   nodes[k] = i;
 }
 // pcrs[i] = sw->pcrs_local[mp[i]]; push_voxel(pcrs, pcr_fix, 1, eig_value, eig_vector, pcr_add)  (voxel_map.hpp:1316-1321)
-__global__ void map_factor_gather_kernel(Nodes nd, int W, RingArg ring, const int* __restrict__ nodes, int n, double* __restrict__ clusters, double* __restrict__ fix,
-                                         double* __restrict__ coe, double* __restrict__ eigval, double* __restrict__ eigvec, double* __restrict__ merged) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+// One WORKGROUP per factor voxel, one thread per copied double (10 W cluster entries + fix 10 + merged 10 + eigenvalues 3 + eigenvectors 9): every
+// thread does ONE load and ONE store.  (Round 4, from the ISA: as one thread per voxel with `out[k] = nd.x[k]` loops the 133 copies were ~25
+// dependent load -> wait -> store round trips -- the node arrays may alias the outputs for all the compiler knows -- and with ~17k
+// voxels = 270 waves on 1024 SIMDs nothing hid them: 33 us.)
+__global__ __launch_bounds__(192) void map_factor_gather_kernel(Nodes nd, int W, RingArg ring, const int* __restrict__ nodes, int n, double* __restrict__ clusters, double* __restrict__ fix,
+                                                                double* __restrict__ coe, double* __restrict__ eigval, double* __restrict__ eigvec, double* __restrict__ merged) {
+  const int a = blockIdx.x;
   if (a >= n) return;
   const int i = nodes[a];
-  nd.opt_state[i] = a;
-  for (int s = 0; s < W; s++)
-    for (int k = 0; k < 10; k++) clusters[((size_t)a * W + s) * 10 + k] = nd.pcrs_local[((size_t)i * W + ring.mp[s]) * 10 + k];
-  for (int k = 0; k < 10; k++) { fix[10 * (size_t)a + k] = nd.pcr_fix[10 * (size_t)i + k]; merged[10 * (size_t)a + k] = nd.pcr_add[10 * (size_t)i + k]; }
-  coe[a] = 1.0;
-  for (int k = 0; k < 3; k++) eigval[3 * (size_t)a + k] = nd.eigval[3 * (size_t)i + k];
-  for (int k = 0; k < 9; k++) eigvec[9 * (size_t)a + k] = nd.eigvec[9 * (size_t)i + k];
+  const int per = 10 * W + 32;
+  for (int t = threadIdx.x; t < per; t += blockDim.x) {
+    if (t < 10 * W) {
+      const int s = t / 10, k = t - 10 * s;
+      int slot = 0;     // ring.mp[s] by a select chain: a lane-dependent index into a kernel argument would go through scratch
+#pragma unroll
+      for (int q = 0; q < MAXW; q++) slot = (s == q) ? ring.mp[q] : slot;
+      clusters[((size_t)a * W + s) * 10 + k] = nd.pcrs_local[((size_t)i * W + slot) * 10 + k];
+    } else {
+      const int u = t - 10 * W;
+      if (u < 10) fix[10 * (size_t)a + u] = nd.pcr_fix[10 * (size_t)i + u];
+      else if (u < 20) merged[10 * (size_t)a + (u - 10)] = nd.pcr_add[10 * (size_t)i + (u - 10)];
+      else if (u < 23) eigval[3 * (size_t)a + (u - 20)] = nd.eigval[3 * (size_t)i + (u - 20)];
+      else eigvec[9 * (size_t)a + (u - 23)] = nd.eigvec[9 * (size_t)i + (u - 23)];
+    }
+  }
+  if (threadIdx.x == 0) { nd.opt_state[i] = a; coe[a] = 1.0; }
 }
 
 // ---- margi -------------------------------------------------------------------------------------------------------------------
@@ -572,13 +587,22 @@ __device__ __forceinline__ void cl_transform(const double* s, const double* Rp, 
   o[9] = N;
 }
 // OctoTree::plane_update (voxel_map.hpp:1118-1146) of node i
-__device__ void plane_update_node(const Nodes& nd, int i) {
-  const double* cl = nd.pcr_add + 10 * (size_t)i;
-  const double N = cl[9];
+// clv: the node's merged cluster (pcr_add), Uv / lamv: its eigenvectors (as stored: 3 * column + row) / eigenvalues -- the caller has just written them and
+// hands over the registers (read back from the node arrays they would wait for those stores)
+__device__ void plane_update_node(const Nodes& nd, int i, const double* clv, const double* Uv, const double* lamv) {
+  // Inputs into registers first, outputs out last (round 4): the node arrays are plain pointers in a struct, so a load behind a store of this function
+  // waits for that store -- the 36 entries of plane_var used to go out between the loads of cov_add, one round trip each.  Same expressions, same order.
+  const double* CA = nd.cov_add + 81 * (size_t)i;
+  double ca9[9];
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) ca9[3 * q + r] = CA[9 * (6 + q) + 6 + r];
+  const double N = clv[9];
   const double nv = 1.0 / N;
-  const double c[3] = {cl[6] / N, cl[7] / N, cl[8] / N};
-  const double* U = nd.eigvec + 9 * (size_t)i;
-  const double* lam = nd.eigval + 3 * (size_t)i;
+  const double c[3] = {clv[6] / N, clv[7] / N, clv[8] / N};
+  const double* U = Uv;
+  const double* lam = lamv;
   double u_c[3][9];
   for (int r = 0; r < 3; r++)
     for (int q = 0; q < 9; q++) u_c[r][q] = 0.0;
@@ -592,7 +616,6 @@ __device__ void plane_update_node(const Nodes& nd, int i) {
     for (int r = 0; r < 3; r++)
       for (int q = 0; q < 9; q++) u_c[r][q] += sc * uk[r] * fkl[q];
   }
-  const double* CA = nd.cov_add + 81 * (size_t)i;
   double Jc[3][9];
   for (int r = 0; r < 3; r++)
     for (int q = 0; q < 9; q++) {
@@ -600,23 +623,26 @@ __device__ void plane_update_node(const Nodes& nd, int i) {
       for (int k = 0; k < 9; k++) t += u_c[r][k] * CA[9 * q + k];
       Jc[r][q] = t;
     }
-  double* P = nd.pl_var + 36 * (size_t)i;
+  double Pv[36];
   for (int r = 0; r < 3; r++)
     for (int q = 0; q < 3; q++) {
       double t = 0.0;
       for (int k = 0; k < 9; k++) t += Jc[r][k] * u_c[q][k];
-      P[6 * q + r] = t;
+      Pv[6 * q + r] = t;
       const double jn = nv * Jc[r][6 + q];
-      P[6 * (3 + q) + r] = jn;
-      P[6 * r + 3 + q] = jn;
-      P[6 * (3 + q) + 3 + r] = nv * nv * CA[9 * (6 + q) + 6 + r];
+      Pv[6 * (3 + q) + r] = jn;
+      Pv[6 * r + 3 + q] = jn;
+      Pv[6 * (3 + q) + 3 + r] = nv * nv * ca9[3 * q + r];
     }
+  double* P = nd.pl_var + 36 * (size_t)i;
+#pragma unroll
+  for (int k = 0; k < 36; k++) P[k] = Pv[k];
   for (int k = 0; k < 3; k++) { nd.pl_center[3 * (size_t)i + k] = c[k]; nd.pl_normal[3 * (size_t)i + k] = ul[k]; }
   nd.pl_radius[i] = (double)(float)lam[2];
 }
 // OctoTree::margi's leaf branch with mgsize = 1 (voxel_map.hpp:1198-1290), one lane per leaf.  Pass 0 does the cluster work and
 // sizes the fix-pool growth; pass 1 (after the host made room) moves the oldest scan's points into the pool and clears the slot.
-__global__ void map_margi_kernel(Nodes nd, Params prm, int n_nodes, int win_count, PoseArg poses, RingArg ring, const double* __restrict__ f_eigval,
+__global__ __launch_bounds__(256) void map_margi_kernel(Nodes nd, Params prm, int n_nodes, int win_count, PoseArg poses, RingArg ring, const double* __restrict__ f_eigval,   // (without the bound: 128 registers, 129 spilled)
                                  const double* __restrict__ f_eigvec, const double* __restrict__ f_merged, int f_VS, int f_V, int* __restrict__ work, Counters* cnt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes) return;
@@ -627,20 +653,43 @@ __global__ void map_margi_kernel(Nodes nd, Params prm, int n_nodes, int win_coun
   const int m0 = ring.mp[0];
   double* add = nd.pcr_add + 10 * (size_t)i;
   double* fixc = nd.pcr_fix + 10 * (size_t)i;
+  // Round 4: the node's scalars and the two clusters this thread reads AND writes live in registers from here on (addv / fixv), every group of
+  // loads is issued before the stores that follow it -- as `add[k] = f_merged[..]` loops and re-reads of add[9] / fixc[9] / last_num behind stores
+  // the kernel was a chain of ~60 load -> wait -> store round trips per node (the arrays may alias, for all the compiler knows).  Same arithmetic.
+  const int is_plane = nd.is_plane[i];
+  const int last_num = nd.last_num[i];
+  const int pc0 = nd.pt_count[(size_t)i * W + m0];
+  const int fix_count = nd.fix_count[i], fix_cap = nd.fix_cap[i];
+  const int os = nd.opt_state[i];
+  double addv[10], fixv[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) fixv[k] = fixc[k];
   double w0[10];
   for (int k = 0; k < 10; k++) w0[k] = 0.0;
-  const int os = nd.opt_state[i];
   if (os >= f_V) { cnt->err = 2; return; }
+  double ev[3] = {0.0, 0.0, 0.0}, evec[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // the node's eigen-pairs as this thread leaves them (defined whenever plane_update_node runs)
   if (os >= 0) {                                     // adopt the optimiser's cache (:1217-1229)
-    for (int k = 0; k < 10; k++) add[k] = f_merged[(size_t)k * f_VS + os];
-    for (int k = 0; k < 3; k++) nd.eigval[3 * (size_t)i + k] = f_eigval[(size_t)k * f_VS + os];
-    for (int k = 0; k < 9; k++) nd.eigvec[9 * (size_t)i + k] = f_eigvec[(size_t)k * f_VS + os];
-    nd.opt_state[i] = -1;
+    double l0v[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) addv[k] = f_merged[(size_t)k * f_VS + os];
+#pragma unroll
+    for (int k = 0; k < 3; k++) ev[k] = f_eigval[(size_t)k * f_VS + os];
+#pragma unroll
+    for (int k = 0; k < 9; k++) evec[k] = f_eigvec[(size_t)k * f_VS + os];
     const double* l0 = nd.pcrs_local + ((size_t)i * W + m0) * 10;
-    if (l0[9] != 0.0) cl_transform(l0, poses.Rp, w0);
+#pragma unroll
+    for (int k = 0; k < 10; k++) l0v[k] = l0[k];
+#pragma unroll
+    for (int k = 0; k < 10; k++) add[k] = addv[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) nd.eigval[3 * (size_t)i + k] = ev[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) nd.eigvec[9 * (size_t)i + k] = evec[k];
+    nd.opt_state[i] = -1;
+    if (l0v[9] != 0.0) cl_transform(l0v, poses.Rp, w0);
   } else {                                           // :1230-1247
     double s[10];
-    for (int k = 0; k < 10; k++) s[k] = fixc[k];
+    for (int k = 0; k < 10; k++) s[k] = fixv[k];
     for (int j = 0; j < win_count; j++) {
       const double* lj = nd.pcrs_local + ((size_t)i * W + ring.mp[j]) * 10;
       if (lj[9] == 0.0) continue;
@@ -649,42 +698,41 @@ __global__ void map_margi_kernel(Nodes nd, Params prm, int n_nodes, int win_coun
       for (int k = 0; k < 10; k++) s[k] += wj[k];
       if (j == 0) for (int k = 0; k < 10; k++) w0[k] = wj[k];
     }
-    for (int k = 0; k < 10; k++) add[k] = s[k];
-    if (nd.is_plane[i]) {
+    for (int k = 0; k < 10; k++) { addv[k] = s[k]; add[k] = s[k]; }
+    if (is_plane) {
       double Cm[6], lam[3], U[9];
       vxm::cluster_cov(s, s + 6, s[9], Cm);
       vxm::eig_sym3(Cm, lam, U);
-      for (int k = 0; k < 3; k++) nd.eigval[3 * (size_t)i + k] = lam[k];
+      for (int k = 0; k < 3; k++) { ev[k] = lam[k]; nd.eigval[3 * (size_t)i + k] = lam[k]; }
       for (int col = 0; col < 3; col++)
-        for (int row = 0; row < 3; row++) nd.eigvec[9 * (size_t)i + 3 * col + row] = U[3 * row + col];
+        for (int row = 0; row < 3; row++) { evec[3 * col + row] = U[3 * row + col]; nd.eigvec[9 * (size_t)i + 3 * col + row] = U[3 * row + col]; }
     }
   }
-  const int Nadd = (int)add[9], Nfix = (int)fixc[9];
-  if (Nfix < prm.max_points && nd.is_plane[i])
-    if (Nadd - nd.last_num[i] >= 5 || nd.last_num[i] <= 10) {
-      plane_update_node(nd, i);
+  const int Nadd = (int)addv[9], Nfix = (int)fixv[9];
+  if (Nfix < prm.max_points && is_plane)
+    if (Nadd - last_num >= 5 || last_num <= 10) {
+      plane_update_node(nd, i, addv, evec, ev);
       nd.last_num[i] = Nadd;
     }
   int wk = 4;                                        // bit 2: the slot is cleared in pass 1
   if (Nfix < prm.max_points) {
     if (w0[9] != 0.0) {
-      for (int k = 0; k < 10; k++) fixc[k] += w0[k];
-      const int pc = nd.pt_count[(size_t)i * W + m0];
-      if (pc > 0) {
+      for (int k = 0; k < 10; k++) { fixv[k] += w0[k]; fixc[k] = fixv[k]; }
+      if (pc0 > 0) {
         wk |= 1;                                     // append the slot's points to the fix pool
-        if (nd.fix_count[i] + pc > nd.fix_cap[i]) {
-          const int ncap = 2 * (nd.fix_count[i] + pc);
+        if (fix_count + pc0 > fix_cap) {
+          const int ncap = 2 * (fix_count + pc0);
           atomicAdd((unsigned long long*)&cnt->fix_need, (unsigned long long)ncap);
           wk |= 2;                                   // needs a new region
         }
       }
     }
   } else {
-    if (w0[9] != 0.0) for (int k = 0; k < 10; k++) add[k] -= w0[k];
-    if (nd.fix_count[i] != 0) { nd.fix_count[i] = 0; nd.fix_cap[i] = 0; }
+    if (w0[9] != 0.0) for (int k = 0; k < 10; k++) { addv[k] -= w0[k]; add[k] = addv[k]; }
+    if (fix_count != 0) { nd.fix_count[i] = 0; nd.fix_cap[i] = 0; }
   }
   work[i] = wk;
-  nd.isexist[i] = (fixc[9] >= add[9]) ? 0 : 1;       // :1292-1295
+  nd.isexist[i] = (fixv[9] >= addv[9]) ? 0 : 1;       // :1292-1295
 }
 // Two passes.  `list`: one thread per node (coalesced reads of the work words) appends the marginalised slot's points to the node's
 // fix region when they fit (a handful of points per node) and clears the slot's running sums; nodes whose region has to MOVE first -- a
@@ -904,15 +952,26 @@ __global__ void map_plane_export_kernel(Nodes nd, int n_nodes, int max_layer, lo
   const int L = nd.layer[i], p = nd.path[i];
   auto lio_path = [](int p9, int lay) { int r = 0; for (int l = 0; l < lay; l++) r |= ((p9 >> (3 * (2 - l))) & 7) << (3 * l); return r; };
   if (nd.state[i] == 0) {
+    // Every load of the record BEFORE the first store (round 4, from the ISA): written as `out[e] = nd.x[e]` the 42 copies became 42 load -> wait -> store
+    // round trips, one after the other (the node arrays are plain pointers in a struct: for all the compiler knows a store may hit the next
+    // load's address), and with ~100k threads on 1024 SIMDs nothing hides a round trip: 61 us for 40 MB.
+    const int plane = (nd.is_plane[i] && nd.last_num[i] > 0) ? 1 : 0;     // a leaf that never saw plane_update holds an all-zero record: never matched
+    double c3[3], n3[3], pv[36];
+#pragma unroll
+    for (int e = 0; e < 3; e++) { c3[e] = nd.pl_center[3 * (size_t)i + e]; n3[e] = nd.pl_normal[3 * (size_t)i + e]; }
+#pragma unroll
+    for (int e = 0; e < 36; e++) pv[e] = nd.pl_var[36 * (size_t)i + e];
+    const double rad = nd.pl_radius[i];
     const int k = atomicAdd(n_out, 1);
     if (k >= capacity) return;
     loc[3 * k] = lx; loc[3 * k + 1] = ly; loc[3 * k + 2] = lz;
     layer[k] = L; path[k] = lio_path(p, L);
-    const int plane = (nd.is_plane[i] && nd.last_num[i] > 0) ? 1 : 0;     // a leaf that never saw plane_update holds an all-zero record: never matched
     is_plane[k] = plane;
-    for (int e = 0; e < 3; e++) { center[3 * k + e] = nd.pl_center[3 * (size_t)i + e]; normal[3 * k + e] = nd.pl_normal[3 * (size_t)i + e]; }
-    for (int e = 0; e < 36; e++) plane_var[36 * (size_t)k + e] = nd.pl_var[36 * (size_t)i + e];
-    radius[k] = nd.pl_radius[i];
+#pragma unroll
+    for (int e = 0; e < 3; e++) { center[3 * k + e] = c3[e]; normal[3 * k + e] = n3[e]; }
+#pragma unroll
+    for (int e = 0; e < 36; e++) plane_var[36 * (size_t)k + e] = pv[e];
+    radius[k] = rad;
   } else if (L < max_layer) {
     for (int o = 0; o < 8; o++) {
       if (nd.child[8 * (size_t)i + o] != 0) continue;
@@ -1346,7 +1405,7 @@ int vxba_map_recut(vxba_map* m, int win_count, const double* Rp, vxba_factor* fa
   double* d_stage = (double*)m->stage;
   double* d_cl = d_stage; double* d_fix = d_cl + (size_t)nf * W * 10; double* d_coe = d_fix + (size_t)nf * 10; double* d_ev = d_coe + nf;
   double* d_evec = d_ev + (size_t)nf * 3; double* d_mg = d_evec + (size_t)nf * 9;
-  map_factor_gather_kernel<<<grid_for(nf), 256, 0, m->stream>>>(m->nd, W, ring, d_nodes_s, nf, d_cl, d_fix, d_coe, d_ev, d_evec, d_mg);
+  map_factor_gather_kernel<<<dim3((unsigned)nf), 192, 0, m->stream>>>(m->nd, W, ring, d_nodes_s, nf, d_cl, d_fix, d_coe, d_ev, d_evec, d_mg);
   hipError_t e = map_wait(m->stream);
   if (e == hipSuccess) rc = vxba_internal_push_voxels_device(factor, nf, d_cl, d_fix, d_coe, d_ev, d_evec, d_mg);
   if (e != hipSuccess) return mfail(m, VXBA_ERR_HIP, "vxba_map_recut: gather failed");
