@@ -31,6 +31,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <type_traits>
 #include <vector>
 
@@ -77,6 +78,21 @@ struct Counters {   // device block of counters, read back after each stage
   long long fix_need_l[4];
   long long fix_cursor, fix_need;
 };
+
+// The counter block goes to the device as a kernel argument and comes back through host memory the device writes directly (round 4): the two
+// blit copies per stage (hipMemcpyAsync H2D / D2H: ~5.5 us of GPU time each, ~18 per scan) become two 64-thread kernels.  The host fills its pinned copy
+// with 0xffffffff words before the publish kernel is queued and polls until none is left: no counter ever holds that pattern in a 32-bit half (counts
+// and error codes are small non-negative ints, the two cursors are point counts), and a word-wise sentinel needs no ordering between the device's
+// stores into host memory (which has none, see the LiDAR-inertial shell).  The stream is in order, so a landed publish also means every kernel
+// queued before it has finished -- what the stream query of the copy told the host before.
+constexpr int CNT_WORDS = (int)(sizeof(Counters) / 4);
+static_assert(sizeof(Counters) % 4 == 0 && CNT_WORDS <= 64, "Counters: one wave publishes it word by word");
+__global__ __launch_bounds__(64) void cnt_reset_kernel(Counters* d, Counters v) {
+  if (threadIdx.x == 0) *d = v;   // (a lane-dependent index into the argument would go through scratch)
+}
+__global__ __launch_bounds__(64) void cnt_publish_kernel(const Counters* d, unsigned* h) {
+  if (threadIdx.x < CNT_WORDS) h[threadIdx.x] = reinterpret_cast<const unsigned*>(d)[threadIdx.x];
+}
 
 // ---- unfused helpers --------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double madd_u(double acc, double a, double b) {
@@ -1049,7 +1065,8 @@ struct vxba_map {
   int* vals = nullptr;
   long long table_cap = 0;
   vxmap::Counters* d_cnt = nullptr;
-  vxmap::Counters* h_cnt = nullptr;   // pinned
+  vxmap::Counters* h_cnt = nullptr;   // pinned, mapped: cnt_publish_kernel writes it
+  unsigned* h_cnt_dev = nullptr;      // the device's address of h_cnt
   int n_nodes = 0, n_roots = 0, n_slide = 0;
   int serial = 0;
   int mp[vxmap::MAXW];
@@ -1198,15 +1215,35 @@ int ensure_stage(vxba_map* m, size_t bytes) {
 }
 // counters: push the host view to the device before a stage, pull it back after
 int cnt_push(vxba_map* m) {
-  Counters& c = *m->h_cnt;
+  Counters c;
   c.n_nodes = m->n_nodes; c.n_roots = m->n_roots; c.n_touched = 0; c.n_slide_new = 0; c.n_split = 0; c.n_fac = 0; c.n_removed = 0; c.err = 0; c.n_list = 0; c.pad_ = 0; for (int k = 0; k < 4; k++) { c.n_split_l[k] = 0; c.fix_need_l[k] = 0; } c.fix_cursor = m->fix_cursor; c.fix_need = 0;
-  VM_HIP(m, hipMemcpyAsync(m->d_cnt, m->h_cnt, sizeof(Counters), hipMemcpyHostToDevice, m->stream));
+  vxmap::cnt_reset_kernel<<<1, 64, 0, m->stream>>>(m->d_cnt, c);
+  VM_HIP(m, hipGetLastError());
   return VXBA_OK;
 }
 int cnt_pull(vxba_map* m) {
-  VM_HIP(m, hipMemcpyAsync(m->h_cnt, m->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, m->stream));
-  VM_HIP(m, map_wait(m->stream));
+  volatile unsigned* hw = reinterpret_cast<volatile unsigned*>(m->h_cnt);
+  for (int k = 0; k < vxmap::CNT_WORDS; k++) hw[k] = 0xffffffffu;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  vxmap::cnt_publish_kernel<<<1, 64, 0, m->stream>>>(m->d_cnt, m->h_cnt_dev);
   VM_HIP(m, hipGetLastError());
+  // poll the words; every few thousand rounds ask the stream as well (a failed launch or a device fault would otherwise never end the wait)
+  for (unsigned spins = 1;; spins++) {
+    bool all = true;
+    for (int k = 0; k < vxmap::CNT_WORDS; k++) all = all && hw[k] != 0xffffffffu;
+    if (all) break;
+    if ((spins & 0xfff) == 0) {
+      const hipError_t q = hipStreamQuery(m->stream);
+      if (q == hipSuccess) {     // the kernel has ended: its stores are on their way, give them a moment, then give up
+        bool ok2 = false;
+        for (int t = 0; t < 100000 && !ok2; t++) { ok2 = true; for (int k = 0; k < vxmap::CNT_WORDS; k++) ok2 = ok2 && hw[k] != 0xffffffffu; }
+        if (ok2) break;
+        return mfail(m, VXBA_ERR_HIP, "vxba_map: the counter block did not arrive in host memory");
+      }
+      if (q != hipErrorNotReady) { m->err = std::string("vxba_map: ") + hipGetErrorString(q); return VXBA_ERR_HIP; }
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_seq_cst);
   m->n_nodes = m->h_cnt->n_nodes; m->n_roots = m->h_cnt->n_roots; m->fix_cursor = m->h_cnt->fix_cursor;
   return VXBA_OK;
 }
@@ -1258,7 +1295,8 @@ int vxba_map_create(const vxba_map_params* p, int device, vxba_map** out) {
   }
   bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipMalloc((void**)&m->d_cnt, sizeof(vxmap::Counters)) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&m->h_cnt, sizeof(vxmap::Counters), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&m->h_cnt, sizeof(vxmap::Counters), hipHostMallocMapped) == hipSuccess;
+  ok = ok && hipHostGetDevicePointer((void**)&m->h_cnt_dev, m->h_cnt, 0) == hipSuccess;
   if (!ok || ensure_nodes(m, 1 << 16) != VXBA_OK || ensure_table(m, 1 << 10) != VXBA_OK || ensure_fix(m, 1 << 18) != VXBA_OK) { vxba_map_destroy(m); return VXBA_ERR_HIP; }
   *out = m;
   return VXBA_OK;
@@ -1695,11 +1733,13 @@ int vxba_map_export_planes(vxba_map* m, vxba_lio* lio, int64_t* n_exported) {
     d_normal = (double*)q; q += c_3;
     d_pvar = (double*)q; q += c_36;
     d_radius = (double*)q;
-    VM_HIP(m, hipMemsetAsync(d_n, 0, sizeof(int), m->stream));
+    // the entry count rides in the counter block (n_list): a reset kernel and a publish kernel instead of a memset and a blit copy
+    if ((rc = cnt_push(m))) return rc;
+    d_n = &m->d_cnt->n_list;
     vxmap::map_plane_export_kernel<<<grid_for(m->n_nodes), 256, 0, m->stream>>>(m->nd, m->n_nodes, m->prm.max_layer, d_loc, d_layer, d_path, d_isp, d_center, d_normal, d_pvar, d_radius, d_n,
                                                                                   (int)capn);
-    VM_HIP(m, hipMemcpyAsync(&n, d_n, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    VM_HIP(m, map_wait(m->stream));
+    if ((rc = cnt_pull(m))) return rc;
+    n = m->h_cnt->n_list;
     if (n <= capn) break;
     m->export_cap = (long long)n + n / 2 + 1024;      // everything was counted, not everything written: once more with room
   }
