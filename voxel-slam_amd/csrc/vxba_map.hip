@@ -346,6 +346,8 @@ struct SubStage {
   double V[SUB_TILE][9];     // its 3x3 variance, column-major
   int pi[SUB_TILE];
   int code[SUB_TILE];
+  int out[SUB_TILE];         // a scan's point indices re-bucketed by octant (single-tile scans: straight from pi / code above)
+  long long fdst[8];         // fix points: where each octant's region of the pool starts (-1: none)
 };
 __device__ __forceinline__ void sub_accumulate(int part, const double* w, const double* x, const double* V, bool with_local, bool with_fix, double (&a)[20]) {
   if (part < 6) {
@@ -423,7 +425,28 @@ __global__ __launch_bounds__(64) void map_subdivide_wave_kernel(Nodes nd, Params
       fold(cntp, false, true, nfix);
       __syncthreads();
     }
-    if (part == 0 && nfix > 0 && keep_pts) {      // push_fix keeps the point when layer < max_layer (voxel_map.hpp:998-999)
+    if (keep_pts && fc <= SUB_TILE) {
+      // One tile: st.code / st.w / st.V still hold the node's fix points, so every lane moves one point (its place = its octant's region + the number of
+      // earlier points of that octant: the order the serial copy below produces).  Round 4: that serial copy -- lane `part 0` of an octant walking
+      // all fc points with a dependent global load each and twelve load -> store pairs per kept point -- WAS the kernel: 15-35 leaves split per
+      // scan, one wave each, ~70 us of dependent round trips.
+      long long dst = -1;
+      if (part == 0 && nfix > 0) dst = (long long)atomicAdd((unsigned long long*)&cnt->fix_cursor, (unsigned long long)nfix);
+      if (part == 0) st.fdst[oct] = dst;
+      __syncthreads();
+      for (int j = lane; j < fc; j += 64) {
+        const int o = st.code[j];
+        int rank = 0;
+        for (int q = 0; q < j; q++) rank += (st.code[q] == o) ? 1 : 0;
+        const size_t d = (size_t)(st.fdst[o] + rank);
+#pragma unroll
+        for (int e = 0; e < 3; e++) fix_pnt[3 * d + e] = st.w[j][e];
+#pragma unroll
+        for (int e = 0; e < 9; e++) fix_var[9 * d + e] = st.V[j][e];
+      }
+      if (part == 0 && nfix > 0) { nd.fix_start[child] = dst; nd.fix_count[child] = nfix; nd.fix_cap[child] = nfix; }
+      __syncthreads();
+    } else if (part == 0 && nfix > 0 && keep_pts) {      // push_fix keeps the point when layer < max_layer (voxel_map.hpp:998-999)
       const long long dst = (long long)atomicAdd((unsigned long long*)&cnt->fix_cursor, (unsigned long long)nfix);
       int k = 0;
       for (int j = 0; j < fc; j++) {
@@ -437,11 +460,16 @@ __global__ __launch_bounds__(64) void map_subdivide_wave_kernel(Nodes nd, Params
     }
   }
   // subdivide(i) for the window's scans in order (voxel_map.hpp:1096-1116)
+  // Round 4: a wave walks the window's scans one after the other and every global round trip of a scan is on its chain (~1 us each with one wave per
+  // split leaf and nothing else to run): the point ranges of all W slots are fetched once, up front, and a scan that fits one tile (the rule: a
+  // leaf holds a few points per scan) is re-bucketed out of the tile it has just folded -- no second pass over perm / pnt, no trip through tmp.
+  int my_p0 = 0, my_pc = 0;
+  if (lane < W) { my_p0 = nd.pt_start[(size_t)node * W + lane]; my_pc = nd.pt_count[(size_t)node * W + lane]; }
   for (int i = 0; i < win_count; i++) {
     const int slot = ring.mp[i];
     const ScanSlot sc = scans.s[slot];
-    const int p0 = nd.pt_start[(size_t)node * W + slot];
-    const int pc = nd.pt_count[(size_t)node * W + slot];
+    const int p0 = __shfl(my_p0, slot);
+    const int pc = __shfl(my_pc, slot);
     const double* Rp = poses.Rp + 12 * i;
     if (part == 6) {
 #pragma unroll
@@ -482,6 +510,19 @@ __global__ __launch_bounds__(64) void map_subdivide_wave_kernel(Nodes nd, Params
         if (o < oct) before += v;
       }
       int k = 0;
+      if (pc <= SUB_TILE) {
+        // st.pi / st.code still hold this scan's points (nothing has touched the tile since the fold's barrier)
+        if (part == 0 && mine > 0) {
+          for (int j = 0; j < pc; j++)
+            if (st.code[j] == oct) { st.out[before + k] = st.pi[j]; k++; }
+          nd.pt_start[(size_t)child * W + slot] = p0 + before;
+          nd.pt_count[(size_t)child * W + slot] = mine;
+        }
+        __syncthreads();
+        for (int j = lane; j < pc; j += 64) sc.perm[p0 + j] = st.out[j];
+        __syncthreads();
+        continue;
+      }
       for (int t0 = 0; t0 < pc; t0 += SUB_TILE) {
         const int cntp = pc - t0 < SUB_TILE ? pc - t0 : SUB_TILE;
         for (int j = lane; j < cntp; j += 64) {
@@ -1414,6 +1455,7 @@ int vxba_map_recut(vxba_map* m, int win_count, const double* Rp, vxba_factor* fa
     if (L >= m->prm.max_layer) break;          // leaves of the finest layer never split: nothing to read back
     if ((rc = cnt_pull(m))) return rc;         // one read-back per layer: how many leaves split
     const int n_split = m->h_cnt->n_split_l[L];
+    { static const bool dbg = getenv("VXBA_MAP_DEBUG") != nullptr; if (dbg) fprintf(stderr, "vxba_map_recut: layer %d: %d of %d nodes split, fix points needed %lld\n", L, n_split, bound, (long long)m->h_cnt->fix_need_l[L]); }
     if (n_split == 0) continue;
     if ((rc = ensure_nodes(m, (long long)m->n_nodes + 8ll * n_split))) return rc;
     if ((rc = ensure_fix(m, m->fix_cursor + m->h_cnt->fix_need_l[L]))) return rc;
