@@ -602,13 +602,13 @@ int vxba_internal_push_voxels_device(vxba_factor* f, int n, const double* d_clus
     vxk::launch_build_clb(fv, v0, n, f->stream);
     clusters_written(f, v0);
   }
-  vxk::launch_scatter_rows(d_fix, fv.fix, f->VS, v0, n, 10, f->stream);
-  vxk::launch_scatter_rows(d_coe, fv.coe, f->VS, v0, n, 1, f->stream);
-  vxk::launch_scatter_rows(d_eigval, fv.eigval, f->VS, v0, n, 3, f->stream);
-  vxk::launch_scatter_rows(d_eigvec, fv.eigvec, f->VS, v0, n, 9, f->stream);
-  vxk::launch_scatter_rows(d_merged, fv.merged, f->VS, v0, n, 10, f->stream);
+  vxk::launch_scatter_voxel_records(d_fix, d_coe, d_eigval, d_eigvec, d_merged, fv, v0, n, f->stream);   // (five launches of scatter_rows until round 4)
   vxk::launch_seed_aux(fv, v0, v0 + n, f->stream);
-  VX_HIP(f, hipStreamSynchronize(f->stream));
+  {   // completion by polling: the map's stage buffers are reused right after this call, and a blocking wait costs ~25 us to wake up from
+    hipError_t q;
+    while ((q = hipStreamQuery(f->stream)) == hipErrorNotReady) {}
+    VX_HIP(f, q);
+  }
   VX_HIP(f, hipGetLastError());
   f->V += n;
   f->wide_dirty = true;

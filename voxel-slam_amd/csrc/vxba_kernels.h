@@ -186,6 +186,8 @@ void launch_scatter_clusters_csr(const long long* d_row_ptr, const int* d_frame_
                                  hipStream_t s);
 void launch_gather_clusters(const FactorView& fv, int head, int n, double* d_dst /*[n][W][10]*/, hipStream_t s);
 void launch_scatter_rows(const double* d_src /*[n][K]*/, double* planes, int VS, int v0, int n, int K, hipStream_t s);
+void launch_scatter_voxel_records(const double* d_fix, const double* d_coe, const double* d_eigval, const double* d_eigvec, const double* d_merged, const FactorView& fv, int v0, int n,
+                                  hipStream_t s);   // fix 10 | coe 1 | eigval 3 | eigvec 9 | merged 10 of n pushed voxels, one launch
 void launch_gather_rows(const double* planes, int VS, int head, int n, int K, double* d_dst /*[n][K]*/, hipStream_t s);
 void launch_fill(double* p, size_t n, double val, hipStream_t s);
 void launch_copy_planes(const double* src, int src_vs, double* dst, int dst_vs, int nplanes, int n, hipStream_t s);

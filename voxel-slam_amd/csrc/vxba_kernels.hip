@@ -1026,6 +1026,19 @@ __global__ void scatter_rows_kernel(const double* __restrict__ src, double* __re
   const int al = (int)(t % n), k = (int)(t / n);
   planes[(size_t)k * VS + v0 + al] = src[(size_t)al * K + k];
 }
+// the five per-voxel records a pushed voxel carries besides its clusters (fix 10 | coe 1 | eigval 3 | eigvec 9 | merged 10) into their planes, one launch
+__global__ void scatter_voxel_records_kernel(const double* __restrict__ fix, const double* __restrict__ coe, const double* __restrict__ eigval, const double* __restrict__ eigvec,
+                                             const double* __restrict__ merged, FactorView fv, int v0, int n) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * 33) return;
+  const int al = (int)(t % n), k = (int)(t / n);
+  const size_t VS = (size_t)fv.VS;
+  if (k < 10) fv.fix[(size_t)k * VS + v0 + al] = fix[(size_t)al * 10 + k];
+  else if (k == 10) fv.coe[v0 + al] = coe[al];
+  else if (k < 14) fv.eigval[(size_t)(k - 11) * VS + v0 + al] = eigval[(size_t)al * 3 + (k - 11)];
+  else if (k < 23) fv.eigvec[(size_t)(k - 14) * VS + v0 + al] = eigvec[(size_t)al * 9 + (k - 14)];
+  else fv.merged[(size_t)(k - 23) * VS + v0 + al] = merged[(size_t)al * 10 + (k - 23)];
+}
 __global__ void gather_rows_kernel(const double* __restrict__ planes, int VS, int head, int n, int K, double* __restrict__ dst) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)n * K) return;
@@ -1326,6 +1339,12 @@ void launch_scatter_clusters_csr(const long long* d_row_ptr, const int* d_frame_
 void launch_gather_clusters(const FactorView& fv, int head, int n, double* d_dst, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(gather_clusters_kernel, dim3(nblk((long long)n * fv.W, 256)), dim3(256), 0, s, fv, head, n, d_dst);
+}
+void launch_scatter_voxel_records(const double* d_fix, const double* d_coe, const double* d_eigval, const double* d_eigvec, const double* d_merged, const FactorView& fv, int v0, int n,
+                                  hipStream_t s) {
+  if (n <= 0) return;
+  const long long total = (long long)n * 33;
+  hipLaunchKernelGGL(scatter_voxel_records_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_fix, d_coe, d_eigval, d_eigvec, d_merged, fv, v0, n);
 }
 void launch_scatter_rows(const double* d_src, double* planes, int VS, int v0, int n, int K, hipStream_t s) {
   if (n <= 0) return;
