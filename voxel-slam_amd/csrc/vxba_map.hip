@@ -349,6 +349,18 @@ struct SubStage {
   int out[SUB_TILE];         // a scan's point indices re-bucketed by octant (single-tile scans: straight from pi / code above)
   long long fdst[8];         // fix points: where each octant's region of the pool starts (-1: none)
 };
+// cl_push on a[OFF .. OFF + 9] of the lane's accumulator array, the offset a template constant (see sub_accumulate)
+template <int OFF>
+__device__ __forceinline__ void cl_push_at(double (&a)[20], const double* x) {
+  a[OFF + 9] += 1.0;
+  a[OFF + 0] = madd_u(a[OFF + 0], x[0], x[0]); a[OFF + 1] = madd_u(a[OFF + 1], x[0], x[1]); a[OFF + 2] = madd_u(a[OFF + 2], x[0], x[2]);
+  a[OFF + 3] = madd_u(a[OFF + 3], x[1], x[1]); a[OFF + 4] = madd_u(a[OFF + 4], x[1], x[2]); a[OFF + 5] = madd_u(a[OFF + 5], x[2], x[2]);
+  a[OFF + 6] += x[0]; a[OFF + 7] += x[1]; a[OFF + 8] += x[2];
+}
+// The pushes into a[0..9] (pcr_add: lane 7) and into a[10..19] (the per-scan local cluster: lane 6, body-frame point; pcr_fix: lane 7, world point) must not sit at the
+// ends of sibling branches: the optimiser sinks the common tail `a[OFF + 8] += x[2]` of two such branches into their successor through a POINTER phi, and the two
+// doubles it selects between then live in scratch memory -- a scratch load, a full s_waitcnt and a scratch store per folded point on the one wave that subdivides a
+// leaf (round 4, from the IR: `phi ptr addrspace(5)`).  Hence ONE push into the upper half, behind the role branches, with the source selected instead.
 __device__ __forceinline__ void sub_accumulate(int part, const double* w, const double* x, const double* V, bool with_local, bool with_fix, double (&a)[20]) {
   if (part < 6) {
     const double Bi[6][3] = {{2 * w[0], 0, 0}, {w[1], w[0], 0}, {w[2], 0, w[0]}, {0, 2 * w[1], 0}, {0, w[2], w[1]}, {0, 0, 2 * w[2]}};
@@ -367,11 +379,10 @@ __device__ __forceinline__ void sub_accumulate(int part, const double* w, const 
   } else if (part == 6) {
 #pragma unroll
     for (int k = 0; k < 9; k++) a[k] += V[k];                                  // acc[9 (6 + k/3) + 6 + k%3] += V[3 (k/3) + k%3]
-    if (with_local) cl_push(a + 10, x);
   } else {
-    cl_push(a, w);                                                             // pcr_add
-    if (with_fix) cl_push(a + 10, w);                                          // pcr_fix
+    cl_push_at<0>(a, w);                                                       // pcr_add
   }
+  if ((part == 6 && with_local) || (part == 7 && with_fix)) cl_push_at<10>(a, part == 6 ? x : w);   // lane 6: this scan's local cluster; lane 7: pcr_fix
 }
 __global__ __launch_bounds__(64) void map_subdivide_wave_kernel(Nodes nd, Params prm, const int* __restrict__ split_list, int n_split, int win_count, PoseArg poses,
                                                                 RingArg ring, ScanSlots scans, double* __restrict__ fix_pnt, double* __restrict__ fix_var, Counters* cnt) {
@@ -388,10 +399,25 @@ __global__ __launch_bounds__(64) void map_subdivide_wave_kernel(Nodes nd, Params
   for (int k = 0; k < 20; k++) a[k] = 0.0;
   // (Measured and rejected, round 3: a pre-pass that classifies the node's points first, so that it takes its children and their fix
   // regions with one read-modify-write of each counter instead of up to sixteen: 74.4 against 72.8 us -- the folding, not the atomics.)
+  // the parent's fields a child is made from, fetched ONCE (round 4): init_child read them from the node arrays between its stores -- eight load -> wait -> store
+  // round trips -- every time an octant met its first point, i.e. up to eight times per leaf, in the middle of the fold: most of this kernel's time
+  const int p_root = nd.root[node];
+  const unsigned long long p_key = nd.key[node];
+  const int p_path = nd.path[node];
+  const float p_ql = nd.ql[node];
   auto get_child = [&]() {
     if (part == 0 && child < 0) {
       child = atomicAdd(&cnt->n_nodes, 1);
-      init_child(nd, child, node, oct);
+      const int c = child;
+      nd.layer[c] = L + 1;
+      nd.root[c] = p_root;
+      nd.key[c] = p_key;
+      nd.path[c] = p_path | (oct << (3 * (2 - L)));
+      const int xyz[3] = {(oct >> 2) & 1, (oct >> 1) & 1, oct & 1};
+#pragma unroll
+      for (int k = 0; k < 3; k++) nd.center[3 * (size_t)c + k] = ctr[k] + (double)((float)(2 * xyz[k] - 1) * p_ql);
+      nd.ql[c] = p_ql / 2;
+      nd.opt_state[c] = -1;
       nd.child[8 * (size_t)node + oct] = child + 1;
     }
   };
@@ -466,7 +492,9 @@ __global__ __launch_bounds__(64) void map_subdivide_wave_kernel(Nodes nd, Params
   int my_p0 = 0, my_pc = 0;
   if (lane < W) { my_p0 = nd.pt_start[(size_t)node * W + lane]; my_pc = nd.pt_count[(size_t)node * W + lane]; }
   for (int i = 0; i < win_count; i++) {
-    const int slot = ring.mp[i];
+    int slot = 0;     // ring.mp[i] by a select chain: the run-time index into the kernel argument went through scratch memory -- a memory round trip at the head of every scan
+#pragma unroll
+    for (int q = 0; q < MAXW; q++) slot = (i == q) ? ring.mp[q] : slot;
     const ScanSlot sc = scans.s[slot];
     const int p0 = __shfl(my_p0, slot);
     const int pc = __shfl(my_pc, slot);
