@@ -536,7 +536,7 @@ __global__ __launch_bounds__(64) void lio_leaf_stats_kernel(const double* __rest
 
 // OctoTree::plane_update (voxel_map.hpp:1118-1146): centre, normal, radius and the 6x6 covariance of (normal, centre) by first-order
 // propagation of cov_add through the eigenvector derivative.  One lane per plane.
-__global__ void lio_plane_update_kernel(long long n, const double* __restrict__ clusters, const double* __restrict__ eig_val, const double* __restrict__ eig_vec,
+__global__ __launch_bounds__(64) void lio_plane_update_kernel(long long n, const double* __restrict__ clusters, const double* __restrict__ eig_val, const double* __restrict__ eig_vec,
                                         const double* __restrict__ cov_add, double* __restrict__ center, double* __restrict__ normal, double* __restrict__ plane_var,
                                         double* __restrict__ radius) {
   const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
