@@ -639,12 +639,20 @@ __global__ void lio_map_update_kernel(long long n, const long long* __restrict__
     for (int q = 0; q < span; q++) cl[q] = -1;
     return;
   }
+  // the entry's record into registers before the first store (round 4): as `pl[k] = center[..]` copies every value was its own load -> wait -> store round trip
+  // (the outputs may alias the inputs, for all the compiler knows) -- ~30 of them per thread
+  double c3[3], n3[3], Pv[36];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { c3[k] = center[3 * i + k]; n3[k] = normal[3 * i + k]; }
+  const double rad_in = radius[i];
+#pragma unroll
+  for (int k = 0; k < 36; k++) Pv[k] = plane_var[36 * i + k];
   int rec = cl[0];
   if (rec < 0 || plane_tag[rec] != tag) rec = atomicAdd(&counters[1], 1);
   plane_tag[rec] = tag;
   double* pl = planes + (size_t)rec * PLANE_LEN;
-  for (int k = 0; k < 3; k++) { pl[k] = center[3 * i + k]; pl[3 + k] = normal[3 * i + k]; }
-  pl[6] = (double)(float)radius[i];
+  for (int k = 0; k < 3; k++) { pl[k] = c3[k]; pl[3 + k] = n3[k]; }
+  pl[6] = (double)(float)rad_in;
   // the node's box: centre by the reference's own recurrence, half length = 2 * quater_length (voxel_map.hpp:1473)
   double c[3] = {(0.5 + (double)loc[3 * i]) * voxel_size, (0.5 + (double)loc[3 * i + 1]) * voxel_size, (0.5 + (double)loc[3 * i + 2]) * voxel_size};
   float ql = (float)(voxel_size / 4.0);
@@ -656,9 +664,11 @@ __global__ void lio_map_update_kernel(long long n, const long long* __restrict__
   }
   pl[7] = (double)(ql * 2);
   pl[8] = c[0]; pl[9] = c[1]; pl[10] = c[2];
-  const double* P = plane_var + 36 * i;
+  const double* P = Pv;
   int k = 11;
+#pragma unroll
   for (int r = 0; r < 6; r++)
+#pragma unroll
     for (int cc = r; cc < 6; cc++, k++) pl[k] = 0.5 * (P[6 * cc + r] + P[6 * r + cc]);
   for (int q = 0; q < span; q++) cl[q] = rec;
 }
