@@ -307,12 +307,19 @@ __global__ void map_mark_existing_roots_kernel(Nodes nd, int n_nodes_before, int
 // OctoTree::recut's leaf branch (voxel_map.hpp:1150-1172) for every leaf of layer L under a root of the slide map
 __global__ void map_judge_kernel(Nodes nd, Params prm, int n_bound, int L, int* __restrict__ split_list, Counters* cnt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_bound) return;
+  // Everything the decisions below read, requested TOGETHER (round 4): as a chain of short-circuit tests and a read of the cluster behind the store of opt_state
+  // this was ~9 dependent round trips per thread.  (i < n_bound <= the arrays' capacity: a node the device has not created yet reads as garbage and is dropped below.)
   const int n_nodes = cnt->n_nodes;          // the previous layer's subdivision may have added nodes the host has not seen yet
-  if (i >= n_bound || i >= n_nodes || nd.layer[i] != L || nd.state[i] != 0 || !nd.in_slide[nd.root[i]]) return;
+  const int lay = nd.layer[i], stt = nd.state[i], rt = nd.root[i], ex = nd.isexist[i], sw = nd.has_sw[i];
+  double c[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) c[k] = nd.pcr_add[(size_t)i * 10 + k];
+  if (i >= n_nodes || lay != L || stt != 0) return;
+  if (!nd.in_slide[rt]) return;
   nd.opt_state[i] = -1;
-  const double* c = nd.pcr_add + (size_t)i * 10;
   if (c[9] <= prm.min_point[L]) { nd.is_plane[i] = 0; return; }
-  if (!nd.isexist[i] || !nd.has_sw[i]) return;
+  if (!ex || !sw) return;
   double Cm[6], lam[3], U[9];
   vxm::cluster_cov(c, c + 6, c[9], Cm);
   vxm::eig_sym3(Cm, lam, U);
@@ -853,6 +860,8 @@ __global__ void map_margi_list_kernel(Nodes nd, Params prm, int n_nodes, PoseArg
     }
   }
   if (wk == 0 || heavy) return;
+  double* l0 = nd.pcrs_local + ((size_t)i * W + m0) * 10;      // :1283-1288
+  const double l0n = l0[9];                                     // (read here, in front of the stores below: behind them it waited for every one of them)
   if (wk & 1) {
     const ScanSlot sc = scans.s[m0];
     const int p0 = nd.pt_start[(size_t)i * W + m0], pc = nd.pt_count[(size_t)i * W + m0];
@@ -860,15 +869,20 @@ __global__ void map_margi_list_kernel(Nodes nd, Params prm, int n_nodes, PoseArg
     const long long dst = nd.fix_start[i] + fc;
     for (int j = 0; j < pc; j++) {                   // pv.pnt = R * pv.pnt + p; point_fix.push_back(pv)  (:1262-1266)
       const int pi = sc.perm[p0 + j];
-      double w[3];
-      to_world(poses.Rp, sc.pnt + 3 * (size_t)pi, w);
+      double xb[3], v9[9], w[3];                     // the point's twelve values in registers before its twelve stores (a load behind a store waits for it: may alias)
+#pragma unroll
+      for (int e = 0; e < 3; e++) xb[e] = sc.pnt[3 * (size_t)pi + e];
+#pragma unroll
+      for (int e = 0; e < 9; e++) v9[e] = sc.var9[9 * (size_t)pi + e];
+      to_world(poses.Rp, xb, w);
+#pragma unroll
       for (int e = 0; e < 3; e++) fix_pnt[3 * (size_t)(dst + j) + e] = w[e];
-      for (int e = 0; e < 9; e++) fix_var[9 * (size_t)(dst + j) + e] = sc.var9[9 * (size_t)pi + e];
+#pragma unroll
+      for (int e = 0; e < 9; e++) fix_var[9 * (size_t)(dst + j) + e] = v9[e];
     }
     nd.fix_count[i] = fc + pc;
   }
-  double* l0 = nd.pcrs_local + ((size_t)i * W + m0) * 10;      // :1283-1288
-  if (l0[9] != 0.0) {
+  if (l0n != 0.0) {
     for (int k = 0; k < 10; k++) l0[k] = 0.0;
     nd.pt_count[(size_t)i * W + m0] = 0;
   }
@@ -886,6 +900,8 @@ __global__ __launch_bounds__(64) void map_margi_points_kernel(Nodes nd, Params p
     const int p0 = nd.pt_start[(size_t)i * W + m0], pc = nd.pt_count[(size_t)i * W + m0];
     const int fc = nd.fix_count[i];
     long long base = nd.fix_start[i];
+    double* l0 = nd.pcrs_local + ((size_t)i * W + m0) * 10;      // :1283-1288
+    const bool had = l0[9] != 0.0;                  // read by every lane before any of them writes -- and before the stores below (behind them the load waits for them)
     if (wk & 2) {
       const long long dst = list_dst[q];
       const long long src = base;
@@ -896,13 +912,17 @@ __global__ __launch_bounds__(64) void map_margi_points_kernel(Nodes nd, Params p
     const long long dst = base + fc;
     for (int j = lane; j < pc; j += 64) {          // pv.pnt = R * pv.pnt + p; point_fix.push_back(pv)  (:1262-1266)
       const int pi = sc.perm[p0 + j];
-      double w[3];
-      to_world(poses.Rp, sc.pnt + 3 * (size_t)pi, w);
+      double xb[3], v9[9], w[3];                   // the point's twelve values in registers before its twelve stores
+#pragma unroll
+      for (int e = 0; e < 3; e++) xb[e] = sc.pnt[3 * (size_t)pi + e];
+#pragma unroll
+      for (int e = 0; e < 9; e++) v9[e] = sc.var9[9 * (size_t)pi + e];
+      to_world(poses.Rp, xb, w);
+#pragma unroll
       for (int e = 0; e < 3; e++) fix_pnt[3 * (size_t)(dst + j) + e] = w[e];
-      for (int e = 0; e < 9; e++) fix_var[9 * (size_t)(dst + j) + e] = sc.var9[9 * (size_t)pi + e];
+#pragma unroll
+      for (int e = 0; e < 9; e++) fix_var[9 * (size_t)(dst + j) + e] = v9[e];
     }
-    double* l0 = nd.pcrs_local + ((size_t)i * W + m0) * 10;      // :1283-1288
-    const bool had = l0[9] != 0.0;                  // read by every lane before any of them writes
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
       if (wk & 2) { nd.fix_start[i] = base; nd.fix_cap[i] = 2 * (fc + pc); }
