@@ -11,11 +11,15 @@ Every third step a new window starts: initial guess, fresh damping, cache re-see
 (inside the timed region).  Inputs are resident in HBM before the timed region starts.  One 62 KB D2H + one sync per call.
 
 Workload: BASELINE.json configs[1] ("cfg2"): 10-frame window, 100k points/scan, 50k voxels, fp64.
-N > 1: voxel-sharded weak scaling (configs[3] is exactly 8 x cfg2): every rank owns a cfg2-sized shard
-of one shared window, the packed [Hess | JacT | residual] buffer is all-reduced over RCCL each sweep;
-value = N * K / time (shard-iterations per second), the global iteration rate is in config.
+N > 1 (one process per GPU, one all-reduce of the packed [Hess | JacT | residual | trial residual] buffer per LM iteration), ONE job measures
+  * strong scaling -- the cfg2 window itself split over the N GPUs by the reference's contiguous shard rule: `value` = K / time, which is what
+    BASELINE's "BA iterations/sec (10-frame window, 100k pts/scan) at 1/2/4/8 GPU" says literally;
+  * weak scaling -- every rank owns a cfg2-sized shard of one N-times larger window (configs[3] is exactly 8 x cfg2): `weak_scaling.value` =
+    N * K / time (shard-iterations per second);
+each with both carriers -- the one-shot all-reduce through hipIpc mailboxes and ncclAllReduce (RCCL over xGMI) issued from the C++ loop --
+under `carriers`; `value` is the faster carrier of the strong leg.
 
-Launch: ``python bench.py`` (N=1) or
+Launch: ``python bench.py [--gpus N]`` (N > 1 without a launcher: the script starts its own N ranks through torch.distributed.run on 127.0.0.1) or
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N``.
 """
 import argparse
@@ -77,6 +81,133 @@ def pmc_traffic_bytes(kernel_key, config="cfg2"):
     return (2.0 * f + w) * 1024.0, rel
 
 
+CARRIER_NAMES = {"peer": "one-shot peer all-reduce (hipIpc mailboxes over xGMI)", "rccl": "RCCL all-reduce issued from the C++ loop",
+                 "hook": "torch.distributed all-reduce through the host hook"}
+
+
+def attach_collective(f, collective, W, backend, rank, strict=False):
+    """Give factor `f` its all-reduce.  collective: auto = mailboxes, else direct RCCL, else the torch.distributed hook; peer / rccl / hook = that
+    one (falling back down the same chain unless `strict`).  Every rank takes the same path: success is agreed on with a MIN all-reduce before
+    anybody commits.  Returns the carrier's name, or None when `strict` and the requested carrier is not available (on all ranks alike)."""
+    import torch
+    import torch.distributed as dist
+    from voxel_slam_amd import dist as vdist
+
+    def all_agree(ok):
+        okt = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        return int(okt.item()) == 1
+    if collective in ("auto", "peer") and W <= 10:
+        try:
+            vdist.attach_peer(f)                       # one-shot all-reduce over the peers' mailboxes (self-tested)
+            ok = 1
+        except Exception as exc:                       # noqa: BLE001 -- any failure here must not take the other ranks down
+            print(f"[bench rank {rank}] peer all-reduce not available ({exc})", file=sys.stderr)
+            ok = 0
+        if all_agree(ok):
+            return CARRIER_NAMES["peer"]
+        try:
+            f.peer_detach()
+        except Exception:                              # noqa: BLE001
+            pass
+    if strict and collective == "peer":
+        return None
+    if collective in ("auto", "rccl", "peer") and backend == "nccl":
+        try:
+            vdist.attach_rccl(f)                       # ncclAllReduce issued directly from the C++ loop
+            ok = 1
+        except Exception as exc:                       # noqa: BLE001
+            print(f"[bench rank {rank}] direct RCCL attach failed ({exc}); using the torch.distributed hook", file=sys.stderr)
+            ok = 0
+        if all_agree(ok):
+            return CARRIER_NAMES["rccl"]
+        if ok:
+            f.rccl_detach()
+    if strict and collective == "rccl":
+        return None
+    f._bench_keep = vdist.attach_allreduce(f)          # exchange buffers become torch tensors, collective via a host hook
+    return CARRIER_NAMES["hook"]
+
+
+def window_leg(args, scaling, collective, rank, world, local_rank, backend, base_seed, scene_cache):
+    """One (scaling, carrier) combination of the N > 1 job beside the primary one, by the same protocol: this rank's shard into a fresh factor,
+    the carrier attached (strictly: no fallback -- a carrier that is not available is reported as such), the untimed ramp, then `repeats` timed
+    regions of exactly --steps steps between (barrier + synchronize) pairs, max over ranks, median repeat.  Collective on all ranks."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from voxel_slam_amd import dist as vdist_mod, synth, vxba
+    if scaling not in scene_cache:
+        scene_cache[scaling] = vdist_mod.rank_scene(dict(synth.CONFIGS[args.config], seed=base_seed), scaling, rank, world)
+    sc = scene_cache[scaling]
+    W, V = sc.win_size, sc.n_voxels
+    f = vxba.LidarFactor(W, device=local_rank)
+    try:
+        f.push_points(V, sc.points_body, sc.cell_ptr)
+        used = attach_collective(f, collective, W, backend, rank, strict=True)
+        if used is None:
+            return {"available": False}
+        f.set_precision(args.precision)
+        f.evaluate_only_residual(sc.poses_init)
+        f.snapshot_cache()
+        sps = args.steps_per_solve
+
+        def sync():
+            dist.barrier()
+            torch.cuda.synchronize()
+        for _ in range(int(math.ceil(args.prewarm_seconds / 0.03))):
+            f.lm_steps(sc.poses_init, 300, sps)
+        if args.warmup > 0:
+            f.lm_steps(sc.poses_init, args.warmup, sps)
+        el = []
+        for _ in range(max(1, args.repeats)):
+            sync()
+            t0 = time.perf_counter()
+            _, resis, lmstats = f.lm_steps(sc.poses_init, args.steps, sps)
+            sync()
+            e = time.perf_counter() - t0
+            tt = torch.tensor([e], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el.append(float(tt.item()))
+        f.set_profiling(15 | 16)
+        f.collective_time(reset=True)
+        f.kernel_times(reset=True)
+        f.lm_steps(sc.poses_init, min(args.steps, 30), sps)
+        f.set_profiling(0)
+        kt = f.kernel_times(reset=True)
+        coll = f.collective_time(reset=True)
+        seen = torch.tensor([1], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(seen)
+        elapsed = float(np.median(el))
+        mult = world if scaling == "weak" else 1
+        k3 = kt["k3_hessian"]
+        return {"available": True, "collective_used": used, "scaling": scaling, "voxels_per_gpu": V, "value": mult * args.steps / elapsed,
+                "window_iterations_per_s": args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
+                "value_min": mult * args.steps / max(el), "value_max": mult * args.steps / min(el), "repeats": len(el),
+                "allreduce_us_avg": (1e3 * coll["ms_sum"] / coll["calls"]) if coll["calls"] else None,
+                "collectives_per_lm_step": coll["calls"] / max(1, min(args.steps, 30)),
+                "k3_avg_launch_ms": k3["ms_sum"] / max(1, k3["calls"]), "ranks_seen": int(seen.item()),
+                "final_residual": float(resis[1]), "lm_steps_accepted": lmstats["accepted"], "lm_steps_rejected": lmstats["rejected"]}
+    finally:
+        f.close()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N ...` without a launcher: re-run this command line as N ranks under torch.distributed.run (rendezvous on
+    127.0.0.1, a free port), stdout / stderr passed through.  Returns the job's exit code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     # The contract is ONE JSON line on stdout.  Libraries underneath (RCCL prints a version banner through C stdio, flushed at exit,
     # on every rank) also write there, so everything else is sent to stderr and the JSON line goes to the saved descriptor.
@@ -102,9 +233,11 @@ def main():
     ap.add_argument("--precision", choices=["f64", "mixed", "mixed_f32_clusters"], default="f64",
                     help="mixed = BASELINE configs[2]: f32 Hessian products on the matrix cores, f64 accumulation (use with --config cfg3); "
                          "mixed_f32_clusters: mixed, and the residual sweep reads the clusters as f32 re-centred records")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak = every GPU owns a full --config-sized voxel shard of an N-times larger window (BASELINE configs[3] at N = 8; "
-                         "value = N*K/time in shard-iterations/s); strong = ONE --config window split over the N GPUs (value = K/time)")
+    ap.add_argument("--scaling", choices=["both", "weak", "strong"], default="both",
+                    help="N > 1: strong = ONE --config window split over the N GPUs (value = K/time: BASELINE's 'BA iterations/sec (10-frame window, 100k "
+                         "pts/scan) at 1/2/4/8 GPU', literally); weak = every GPU owns a full --config-sized voxel shard of an N-times larger window "
+                         "(BASELINE configs[3] at N = 8; value = N*K/time in shard-iterations/s); both (default) = strong is the line's `value`, the weak "
+                         "leg is measured in the same job and reported beside it (`weak_scaling`), each with both carriers (`carriers`)")
     ap.add_argument("--collective", choices=["auto", "peer", "rccl", "hook"], default="auto",
                     help="N > 1: how the 29 KB exchange buffer is summed.  auto = the one-shot all-reduce through hipIpc-mapped mailboxes over xGMI "
                          "(vxba_peer_*, verified by a self-test at attach time), else ncclAllReduce issued from the C++ loop, else the torch.distributed hook")
@@ -116,8 +249,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run with N ranks")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU through torch.distributed.run on 127.0.0.1);
+            # rank 0 of the child job prints the one JSON line into OUR stdout, any rank failing makes the exit code non-zero
+            os.dup2(real_stdout, 1)
+            raise SystemExit(self_launch(args.gpus))
         args.gpus = world
 
     # torch first: it brings its own HIP runtime with the same SONAME; loading it before libvxba.so keeps ONE
@@ -152,7 +288,11 @@ def main():
     # ---- synthetic window: every rank builds its own voxel shard of one shared window ------------
     base_seed = synth.MASTER_SEED + list(synth.CONFIGS).index(args.config) + 1
     from voxel_slam_amd import dist as vdist_mod
-    sc = vdist_mod.rank_scene(dict(synth.CONFIGS[args.config], seed=base_seed), args.scaling, rank, world)
+    both_scalings = args.scaling == "both"
+    if both_scalings:
+        args.scaling = "strong"                            # the primary leg: the metric's own window over the N GPUs
+    scene_cache = {}
+    sc = scene_cache[args.scaling] = vdist_mod.rank_scene(dict(synth.CONFIGS[args.config], seed=base_seed), args.scaling, rank, world)
     W, V = sc.win_size, sc.n_voxels
     global_voxels = V * world if args.scaling == "weak" else synth.CONFIGS[args.config]["n_voxels"]
 
@@ -167,42 +307,7 @@ def main():
     k1 = f.kernel_times(reset=True)["k1_build"]
     collective_used = None
     if use_dist:
-        from voxel_slam_amd import dist as vdist
-        def all_agree(ok):                                 # every rank takes the same path
-            okt = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-            return int(okt.item()) == 1
-        collective = "hook" if args.hook_allreduce else args.collective
-        used = None
-        if collective in ("auto", "peer") and W <= 10:
-            try:
-                vdist.attach_peer(f)                       # one-shot all-reduce over the peers' mailboxes (self-tested)
-                ok = 1
-            except Exception as exc:                       # noqa: BLE001 -- any failure here must not take the other ranks down
-                print(f"[bench rank {rank}] peer all-reduce not available ({exc})", file=sys.stderr)
-                ok = 0
-            if all_agree(ok):
-                used = "one-shot peer all-reduce (hipIpc mailboxes over xGMI)"
-            else:
-                try:
-                    f.peer_detach()
-                except Exception:                          # noqa: BLE001
-                    pass
-        if used is None and collective in ("auto", "rccl", "peer") and backend == "nccl":
-            try:
-                vdist.attach_rccl(f)                       # ncclAllReduce issued directly from the C++ loop
-                ok = 1
-            except Exception as exc:                       # noqa: BLE001
-                print(f"[bench rank {rank}] direct RCCL attach failed ({exc}); using the torch.distributed hook", file=sys.stderr)
-                ok = 0
-            if all_agree(ok):
-                used = "RCCL all-reduce issued from the C++ loop"
-            elif ok:
-                f.rccl_detach()
-        if used is None:
-            _keep = vdist.attach_allreduce(f)              # exchange buffers become torch tensors, collective via a host hook
-            used = "torch.distributed all-reduce through the host hook"
-        collective_used = used
+        collective_used = attach_collective(f, "hook" if args.hook_allreduce else args.collective, W, backend, rank)
     f.set_precision(args.precision)
     f.evaluate_only_residual(sc.poses_init)                # seeds the (lambda, U, merged) cache (recut's eig)
     f.snapshot_cache()
@@ -272,6 +377,20 @@ def main():
         f.evaluate_only_residual(sc.poses_init)
     f.set_profiling(0)
     kt3 = f.kernel_times(reset=True)
+
+    # N > 1: the other carrier on this scaling, and (--scaling both) the other scaling with both carriers -- same protocol, same job.
+    legs = {}
+    if world > 1 and not args.hook_allreduce:
+        primary_key = [k for k, v in CARRIER_NAMES.items() if v == collective_used][0]
+        for scal in ([args.scaling] + ([("weak" if args.scaling == "strong" else "strong")] if both_scalings else [])):
+            legs[scal] = {}
+            for carrier in ("peer", "rccl"):
+                if scal == args.scaling and carrier == primary_key:
+                    continue                                # the primary leg itself (filled in below, on rank 0)
+                if carrier == "rccl" and backend != "nccl":
+                    legs[scal][carrier] = {"available": False, "why": f"backend {backend}: RCCL needs one GPU per rank"}
+                    continue
+                legs[scal][carrier] = window_leg(args, scal, carrier, rank, world, local_rank, backend, base_seed, scene_cache)
 
     cold = None
     if world == 1 and not args.no_cold_l3:
@@ -380,6 +499,38 @@ def main():
                 out["scan_cycle"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, f, args.cpu_seconds)
+        if world == 1:
+            out["config"]["scaling_note"] = "one GPU: the strong- and weak-scaling legs coincide (the cfg window on one GPU)"
+        if legs:
+            # every (scaling, carrier) combination measured in this job; the primary leg is one of them
+            mult = world if args.scaling == "weak" else 1
+            legs[args.scaling][primary_key] = {
+                "available": True, "collective_used": collective_used, "scaling": args.scaling, "voxels_per_gpu": V, "value": out["value"],
+                "window_iterations_per_s": out["window_iterations_per_s"], "ms_per_step": ms_per_step, "value_min": out["repeats"]["value_min"],
+                "value_max": out["repeats"]["value_max"], "repeats": n_rep, "allreduce_us_avg": out["config"]["allreduce_us_avg"],
+                "collectives_per_lm_step": out["config"]["collectives_per_lm_step"], "k3_avg_launch_ms": k3_ms, "ranks_seen": ranks_seen,
+                "final_residual": float(resis[1]), "lm_steps_accepted": lmstats["accepted"], "lm_steps_rejected": lmstats["rejected"]}
+            out["carriers"] = legs
+            # `value` is the better carrier of the primary scaling (the loop is the same, only the 29 KB exchange differs)
+            best = max((l for l in legs[args.scaling].values() if l.get("available")), key=lambda l: l["value"])
+            if best["collective_used"] != collective_used:
+                out["value"], out["window_iterations_per_s"], out["ms_per_step"] = best["value"], best["window_iterations_per_s"], best["ms_per_step"]
+                out["repeats"].update(value_min=best["value_min"], value_max=best["value_max"], ms_per_step_min=1e3 * mult * args.steps / best["value_max"] / args.steps,
+                                      ms_per_step_max=1e3 * mult * args.steps / best["value_min"] / args.steps)
+                out["config"].update(collective_used=best["collective_used"], allreduce_us_avg=best["allreduce_us_avg"],
+                                     global_iterations_per_s=best["window_iterations_per_s"],
+                                     parallelism=f"voxel-shard x{world} + {best['collective_used']} of [Hess|JacT|res]")
+                out["roofline"]["note"] = "kernel times from the leg that ran first (" + collective_used + "); the sweeps do not depend on the carrier"
+            other = "weak" if args.scaling == "strong" else "strong"
+            if other in legs:
+                ol = [l for l in legs[other].values() if l.get("available")]
+                if ol:
+                    b2 = max(ol, key=lambda l: l["value"])
+                    out[other + "_scaling"] = {"value": b2["value"], "unit": "iterations/s" if other == "strong" else "shard-iterations/s (N per LM iteration of the N-times larger window)",
+                                               "window_iterations_per_s": b2["window_iterations_per_s"], "ms_per_step": b2["ms_per_step"], "collective_used": b2["collective_used"],
+                                               "allreduce_us_avg": b2["allreduce_us_avg"], "voxels_per_gpu": b2["voxels_per_gpu"],
+                                               "what": ("every GPU owns a full cfg-sized voxel shard of one N-times larger window (BASELINE configs[3] at N = 8)" if other == "weak"
+                                                        else "ONE cfg window split over the N GPUs")}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
     f.close()

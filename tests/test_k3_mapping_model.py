@@ -1,10 +1,12 @@
 """Executable model of the Hessian sweep's work mapping (voxel-slam_amd/csrc/vxba_k3.hpp + k3_finalize_kernel), in numpy.
 
 The kernel cannot run without a GPU, but everything in it that is index arithmetic can be checked here: the run of batches a
-workgroup takes, the step / ragged-last-step logic, the pair-row tile layout `at(row, col)`, which wave multiplies which K range of
-which tile pairs, the MFMA lane maps, the epilogue's parking order, the workgroup partial's layout and k3_finalize's assembly --
-including the block-diagonal terms Drt / Dtt that the matrix cores deliver through the spare columns.  The model mirrors the
-kernel's formulas one for one (same names) and is compared with the plain definition  H = -B^T B + blockdiag(D)."""
+workgroup takes, the step / ragged-last-step logic, the row-major tile and its row stride, which wave multiplies which pairs of
+4-column groups (k3_make_pairs), the lane maps of v_mfma_f64_4x4x4_4b_f64 with its four blocks used as four K-slices of one
+output block (probed on the MI355X: scripts/ubench/k3_blockk_probe.hip -- operand lane 16 k + 4 t + i, result lane 16 i + 4 t + j),
+the fold over the four blocks, the 512-byte store pattern of the epilogue, the workgroup partial's layout and k3_finalize's
+assembly.  The model mirrors the kernel's formulas one for one (same names) and is compared with the plain definition
+H = -B^T B + blockdiag(D)."""
 import numpy as np
 import pytest
 
@@ -12,91 +14,142 @@ DACC = 28
 WAVES = 8
 
 
+def k3_groups(W):
+    return (6 * W + 3) // 4
+
+
+def k3_row_stride(W):
+    rs = 4 * k3_groups(W)
+    while rs % 8 != 4:
+        rs += 1
+    return rs
+
+
+def k3_nv(W):
+    n = min(64 // W, 12) & ~1
+    while n > 2 and 2 * 24 * n * k3_row_stride(W) * 8 > 140 * 1024:
+        n -= 2
+    return n
+
+
+def k3_make_pairs(NG):
+    """vxba_k3.hpp k3_make_pairs: per wave the (I, J) pairs, their operand slots and the column group of every slot."""
+    L = []
+
+    def intra(s0, s1):
+        for i in range(s0, s1):
+            for j in range(i, s1):
+                L.append((i, j))
+
+    def rows(r0, r1, c0, c1):
+        for i in range(r0, r1):
+            for j in range(c0, c1):
+                L.append((i, j))
+    if NG == 15:
+        intra(0, 5); intra(5, 10); intra(10, 15)
+        rows(0, 3, 5, 10)
+        rows(3, 5, 5, 10); rows(3, 4, 10, 15)
+        rows(0, 3, 10, 15)
+        rows(4, 5, 10, 15); rows(5, 7, 10, 15)
+        rows(7, 10, 10, 15)
+    else:
+        for a in range(0, NG, 5):
+            intra(a, min(a + 5, NG))
+        for a in range(0, NG, 5):
+            for b in range(a + 5, NG, 5):
+                rows(a, a + 5, b, min(b + 5, NG))
+    NP = NG * (NG + 1) // 2
+    assert len(L) == NP and len(set(L)) == NP and all(i <= j for i, j in L)
+    PPW = (NP + 7) // 8
+    tab = []
+    for w in range(8):
+        pairs = L[w * PPW:min((w + 1) * PPW, NP)]
+        slot_group, sa, sb = [], [], []
+        for (i, j) in pairs:
+            for gidx in (i, j):
+                if gidx not in slot_group:
+                    slot_group.append(gidx)
+            sa.append(slot_group.index(i)); sb.append(slot_group.index(j))
+        tab.append(dict(pairs=pairs, slot_group=slot_group, sa=sa, sb=sb))
+    return tab, PPW
+
+
 class Cfg:
     def __init__(s, W):
         s.W = W
-        s.NT = (6 * W + 15) // 16
-        s.NTP = s.NT * (s.NT + 1) // 2
-        s.NCOL = 16 * s.NT
-        cap = 12 if s.NT <= 2 else (8 if s.NT == 3 else 6)
-        s.NV = min(64 // W, cap)
+        s.NG = k3_groups(W)
+        s.NP = s.NG * (s.NG + 1) // 2
+        s.NCOLS = 4 * s.NG
+        s.RS = k3_row_stride(W)
+        s.NV = k3_nv(W)
         s.R = 3 * s.NV
         s.ROWS = WAVES * s.R
-        s.KS = s.ROWS // 4
-        s.TSPLIT = 2 if s.NTP >= 6 else 1
-        s.KSPLIT = WAVES // s.TSPLIT
-        s.TPW = s.NTP // s.TSPLIT
-        s.KPW = s.KS // s.KSPLIT
-        s.SPARE = (s.NCOL - 6 * W) >= 3
-        s.BUF = s.ROWS * s.NCOL
-        assert s.ROWS % 4 == 0 and s.NTP % s.TSPLIT == 0 and s.KS % s.KSPLIT == 0
-        assert 2 * s.BUF * 8 + 12 * W * 8 <= 160 * 1024
+        s.KC = s.ROWS // 16
+        s.BUF = s.ROWS * s.RS
+        s.tab, s.PPW = k3_make_pairs(s.NG)
+        s.PPWP = (s.PPW + 3) & ~3
+        s.NTILE = WAVES * s.PPWP * 16
+        s.PLEN = s.NTILE + W * DACC
+        assert s.NV % 2 == 0 and s.NV * W <= 64 and s.ROWS % 16 == 0 and s.RS % 8 == 4 and s.RS >= s.NCOLS
+        assert s.NG <= 15 and s.PPW <= 16 and max(len(t["slot_group"]) for t in s.tab) <= 16
+        # two tile buffers + poses + LM inputs + parameter staging + dump within the CU's LDS
+        assert (2 * s.BUF + 24 * W + 8 + WAVES * s.NV * 18 + 32) * 8 <= 160 * 1024
+        assert 512 * (DACC + 1) * 8 <= 160 * 1024
 
-    def at(s, row, col):
-        return (row >> 1) * 2 * s.NCOL + (col >> 4) * 32 + (row & 1) * 16 + (col & 15)
+    def npair(s, w):
+        return max(0, min(s.PPW, s.NP - w * s.PPW))
 
-    def _upper(s, t):
-        I = 0
-        while t >= s.NT - I:
-            t -= s.NT - I
-            I += 1
-        return I, I + t
 
-    # operand slots: tile j of a wave multiplies slot pa(j) (rows) with slot pb(j) (columns); the column tile a slot reads depends on the set
-    @property
-    def NSLOT(s):
-        return 4 if s.NT == 4 else (6 if s.NT == 3 else s.NT)
+def test_geometry_of_every_window_size():
+    for W in range(1, 11):
+        C = Cfg(W)
+        assert sum(len(t["pairs"]) for t in C.tab) == C.NP
+        for w in range(8):
+            assert len(C.tab[w]["pairs"]) == C.npair(w)
+    C = Cfg(10)
+    assert (C.NG, C.NP, C.RS, C.NV, C.ROWS, C.KC, C.PPW, C.PLEN) == (15, 120, 60, 6, 144, 9, 15, 2048 + 280)
+    # the hand-made order at W = 10: operand reads per slab and wave
+    assert [len(t["slot_group"]) for t in C.tab] == [5, 5, 5, 8, 12, 8, 8, 8]
 
-    def pa(s, j):
-        return (j if j < 3 else j - 2) if s.NT == 4 else (2 * j if s.NT == 3 else s._upper(j)[0])
 
-    def pb(s, j):
-        return (j + 1 if j < 3 else j - 2) if s.NT == 4 else (2 * j + 1 if s.NT == 3 else s._upper(j)[1])
-
-    def slot_tile(s, st, k):
-        if s.NT == 4:
-            return k if st == 0 else (2, 0, 3, 1)[k]
-        if s.NT == 3:
-            return (0, 0, 0, 1, 1, 1)[k] if st == 0 else (2, 2, 0, 2, 1, 2)[k]
-        return k
-
-    def rowtile(s, t):
-        return s.slot_tile(t // s.TPW, s.pa(t % s.TPW))
-
-    def coltile(s, t):
-        return s.slot_tile(t // s.TPW, s.pb(t % s.TPW))
-
-    def elem_offset(s, r, c):
-        I, J = r >> 4, c >> 4
-        for t in range(s.NTP):
-            if s.rowtile(t) == I and s.coltile(t) == J:
-                row, col = r - 16 * I, c - 16 * J
-            elif s.rowtile(t) == J and s.coltile(t) == I:
-                row, col = c - 16 * J, r - 16 * I
-            else:
-                continue
-            return t * 256 + (row >> 2) * 64 + ((row & 3) << 4) + col
-        return -1
+def test_operand_reads_are_bank_conflict_free():
+    """ds_read_b64 is served 32 lanes at a time over 64 banks of 4 bytes: the 32 lanes of a half-wave must touch 64 distinct banks."""
+    for W in range(1, 11):
+        C = Cfg(W)
+        for half in range(2):
+            banks = []
+            for lane in range(32 * half, 32 * half + 32):
+                byte = ((lane >> 2) * C.RS + (lane & 3)) * 8
+                banks += [(byte // 4) % 64, (byte // 4 + 1) % 64]
+            assert len(set(banks)) == 64, (W, half)
 
 
 def sym6_index(a, b):
     return b if a == 0 else (2 + b if a == 1 else 5)
 
 
+def mfma_f64_4x4x4_4b(a, b):
+    """v_mfma_f64_4x4x4_4b_f64 as probed: operand lane l = 16 k + 4 t + i holds A_t[i][k] (B: B_t[k][j] with j for i);
+    result lane 16 i + 4 t + j holds D_t[i][j] = sum_k A_t[i][k] B_t[k][j]."""
+    d = np.zeros(64)
+    for t in range(4):
+        A = np.zeros((4, 4)); B = np.zeros((4, 4))
+        for k in range(4):
+            for i in range(4):
+                A[i, k] = a[16 * k + 4 * t + i]
+                B[k, i] = b[16 * k + 4 * t + i]
+        D = A @ B
+        for i in range(4):
+            for j in range(4):
+                d[16 * i + 4 * t + j] = D[i, j]
+    return d
+
+
 def run_model(W, V, head, end, G, rng):
     C = Cfg(W)
     n = 6 * W
-    # per (voxel, frame): rows of B (3 x 6), linear accumulators; per voxel: the three spare values
     rows = rng.normal(size=(V, W, 3, 6))
     lin = rng.normal(size=(V, W, DACC))
-    if C.SPARE:
-        lin[:, :, 12:27] = 0.0     # Drt / Dtt do not exist as accumulators
-    spare = rng.normal(size=(V, 3))
-    # the z row is what Drt / Dtt are made of: give it the structure the kernel's mathematics has, z = sz [w ; n u], spare = kappa u
-    u = rng.normal(size=(V, 3)); kappa = rng.normal(size=V); sz = rng.normal(size=(V, W)); nn = rng.normal(size=(V, W)); w = rng.normal(size=(V, W, 3))
-    rows[:, :, 2, 0:3] = sz[:, :, None] * w
-    rows[:, :, 2, 3:6] = (sz * nn)[:, :, None] * u[:, None, :]
-    spare = kappa[:, None] * u
     obs = rng.random(size=(V, W)) < 0.8
     rows[~obs] = 0.0
     lin[~obs] = 0.0
@@ -119,17 +172,12 @@ def run_model(W, V, head, end, G, rng):
                 for y in range(3):
                     D[x, 3 + y] = d[12 + 3 * x + y]
                     D[3 + y, x] = d[12 + 3 * x + y]
-            if C.SPARE:   # what the spare columns deliver: Drt = sum z[0:3] spare^T, Dtt = sum z[3:6] spare^T
-                zr = rows[a, i, 2]
-                D[0:3, 3:6] += np.outer(zr[0:3], spare[a]); D[3:6, 0:3] += np.outer(zr[0:3], spare[a]).T
-                D[3:6, 3:6] += np.outer(zr[3:6], spare[a])
             H[6 * i:6 * i + 6, 6 * i:6 * i + 6] += D
             if i == 0:
                 res += d[27]
 
     # ---- the kernel, workgroup by workgroup
-    PLEN = C.NTP * 256 + W * DACC
-    partial = np.zeros((G, PLEN))
+    partial = np.full((G, C.PLEN), np.nan)          # slots nobody writes must never be read by k3_finalize
     b0, b1 = head // C.NV, (end - 1) // C.NV
     nb_all = b1 - b0 + 1
     q, rem = nb_all // G, nb_all % G
@@ -138,33 +186,24 @@ def run_model(W, V, head, end, G, rng):
         cnt = q + (1 if g < rem else 0)
         bs = b0 + g * q + min(g, rem)
         covered += list(range(bs, bs + cnt))
-        lds = np.full((2, C.BUF), 0.0)
-        acc = np.zeros((WAVES, C.TPW, 4, 64))          # [wave][tile j][register r][lane]
+        lds = np.full((2, C.BUF), np.nan)            # whatever is read must have been written
+        for b in range(2):                           # prologue: the padding columns 6W .. 4 NG
+            for rr in range(C.ROWS):
+                lds[b, rr * C.RS + 6 * W: rr * C.RS + C.NCOLS] = 0.0
+        acc = np.zeros((WAVES, C.PPW, 64))           # [wave][pair j][lane]
         dacc = np.zeros((WAVES, 64, DACC))
 
-        def phase_m(buf, nb_prev):
+        def phase_m(buf, nch):
             for wave in range(WAVES):
-                st, kq = wave % C.TSPLIT, wave // C.TSPLIT
-                if nb_prev >= WAVES:
-                    k0, nk = kq * C.KPW, C.KPW
-                else:
-                    ks = (nb_prev * C.R + 3) >> 2
-                    k0 = (kq * ks) // C.KSPLIT
-                    nk = ((kq + 1) * ks) // C.KSPLIT - k0
-                for kk in range(nk):
-                    x = np.zeros((C.NSLOT, 64))
+                T = C.tab[wave]
+                for qq in range(nch):
+                    x = np.zeros((max(1, len(T["slot_group"])), 64))
                     for lane in range(64):
-                        lrow, lcol = lane >> 4, lane & 15
-                        for k in range(C.NSLOT):
-                            x[k, lane] = buf[C.at(4 * k0 + lrow, lcol) + 32 * C.slot_tile(st, k) + kk * 4 * C.NCOL]
-                    for j in range(C.TPW):
-                        # v_mfma_f64_16x16x4: A[i][k] in lane 16k+i, B[k][jj] in lane 16k+jj, D[(l/16)+4r][l%16] in register r of lane l
-                        A = x[C.pa(j)].reshape(4, 16).T      # [i][k]
-                        Bm = x[C.pb(j)].reshape(4, 16)       # [k][jj]
-                        D = A @ Bm
-                        for lane in range(64):
-                            for r in range(4):
-                                acc[wave, j, r, lane] += D[(lane >> 4) + 4 * r, lane & 15]
+                        opnd = (lane >> 2) * C.RS + (lane & 3)
+                        for s_, grp in enumerate(T["slot_group"]):
+                            x[s_, lane] = buf[opnd + qq * 16 * C.RS + 4 * grp]
+                    for j in range(len(T["pairs"])):
+                        acc[wave, j] += mfma_f64_4x4x4_4b(x[T["sa"][j]], x[T["sb"][j]])
 
         def phase_a(buf, wave, b):
             for lane in range(C.NV * W):
@@ -175,73 +214,75 @@ def run_model(W, V, head, end, G, rng):
                 if ok:
                     dacc[wave, lane] += lin[a, fi]
                 for r in range(3):
-                    for jj in range(3):
-                        o = C.at(wave * C.R + 3 * vl + r, 0) + C.at(0, 6 * fi + 2 * jj)
-                        buf[o] = rws[r, 2 * jj]; buf[o + 1] = rws[r, 2 * jj + 1]
-                if C.SPARE and fi == W - 1:
-                    o = C.at(wave * C.R + 3 * vl + 2, 0) + C.at(0, 6 * W)
-                    sp = spare[a] if a < V else np.ones(3)    # an out-of-range slot carries some finite voxel's values
-                    buf[o], buf[o + 1], buf[o + 2] = sp
+                    o = (wave * C.R + 3 * vl + r) * C.RS + 6 * fi
+                    buf[o:o + 6] = rws[r]
 
         nfull, nrag = cnt // WAVES, cnt % WAVES
         for s in range(nfull + 1):
             if s >= 1:
-                phase_m(lds[(s - 1) & 1], WAVES)
+                phase_m(lds[(s - 1) & 1], C.KC)
             if s == nfull:
                 break
             for wave in range(WAVES):
                 phase_a(lds[s & 1], wave, bs + s * WAVES + wave)
         if nrag > 0:
             buf = lds[nfull & 1]
+            nch = (nrag * C.R + 15) >> 4
             for wave in range(WAVES):
                 if wave < nrag:
                     phase_a(buf, wave, bs + nfull * WAVES + wave)
                 elif wave == nrag:
-                    z0 = C.at(nrag * C.R, 0)
-                    buf[z0:z0 + 4 * C.NCOL] = 0.0
-            phase_m(buf, nrag)
+                    buf[nrag * C.R * C.RS: nch * 16 * C.RS] = 0.0
+            phase_m(buf, nch)
+        assert not np.isnan(acc).any()
         # epilogue
         pout = partial[g]
         for el in range(W * DACC):
             i, k = el // DACC, el % DACC
-            pout[C.NTP * 256 + el] = sum(dacc[w_, v * W + i, k] for w_ in range(WAVES) for v in range(C.NV))
-        for el in range(C.NTP * 256):
-            t, x_ = el >> 8, el & 255
-            ts, j = t // C.TPW, t % C.TPW
-            pout[el] = sum(acc[k * C.TSPLIT + ts, j, x_ >> 6, x_ & 63] for k in range(C.KSPLIT))
+            pout[C.NTILE + el] = sum(dacc[w_, v * W + i, k] for w_ in range(WAVES) for v in range(C.NV))
+        for wave in range(WAVES):
+            v = acc[wave].copy()
+            lanes = np.arange(64)
+            v = v + v[:, lanes ^ 4]
+            v = v + v[:, lanes ^ 8]
+            np_w = C.npair(wave)
+            for m in range(C.PPWP // 4):
+                for lane in range(64):
+                    t4 = (lane >> 2) & 3
+                    if 4 * m + t4 < np_w:
+                        off = (wave * C.PPWP + 4 * m + t4) * 16 + 4 * (lane >> 4) + (lane & 3)
+                        assert np.isnan(pout[off])            # every slot is stored once
+                        pout[off] = v[4 * m + t4, lane]
     assert covered == list(range(b0, b1 + 1))
 
-    # ---- k3_finalize
-    NTILE = C.NTP * 256
+    # ---- k3_finalize (fin_map)
     Hk = np.zeros((n, n)); Jk = np.zeros(n); resk = 0.0
+    seen = np.zeros((n, n), dtype=int)
     tot = partial.sum(axis=0)
-    for e in range(PLEN):
-        if e < NTILE:
-            t, j, l = e >> 8, (e >> 6) & 3, e & 63
-            rt, ct = C.rowtile(t), C.coltile(t)
-            r = 16 * rt + (l >> 4) + 4 * j
-            c = 16 * ct + (l & 15)
-            if rt > ct:
-                r, c = c, r
+    for e in range(C.PLEN):
+        if e < C.NTILE:
+            wv, pl, i, j = e // (16 * C.PPWP), (e >> 4) % C.PPWP, (e >> 2) & 3, e & 3
+            if pl >= C.npair(wv):
+                continue
+            I, Jg = C.tab[wv]["pairs"][pl]
+            r, c = 4 * I + i, 4 * Jg + j
             if r >= n or c >= n or r > c:
                 continue
             t1 = 0.0
             if r // 6 == c // 6:
-                i, a, b = r // 6, r % 6, c % 6
-                if C.SPARE and b >= 3:
-                    off1 = C.elem_offset(r, n + (b - 3))
-                    assert off1 >= 0
-                else:
-                    if b < 3: d = 6 + sym6_index(a, b)
-                    elif a < 3: d = 12 + 3 * a + (b - 3)
-                    else: d = 21 + sym6_index(a - 3, b - 3)
-                    off1 = NTILE + i * DACC + d
-                t1 = tot[off1]
+                fr, a, b = r // 6, r % 6, c % 6
+                if b < 3: d = 6 + sym6_index(a, b)
+                elif a < 3: d = 12 + 3 * a + (b - 3)
+                else: d = 21 + sym6_index(a - 3, b - 3)
+                t1 = tot[C.NTILE + fr * DACC + d]
+            assert not np.isnan(tot[e])
             Hk[r, c] = Hk[c, r] = t1 - tot[e]
+            seen[r, c] += 1
         else:
-            qq = e - NTILE; i, d = qq // DACC, qq % DACC
+            qq = e - C.NTILE; i, d = qq // DACC, qq % DACC
             if d < 6: Jk[6 * i + d] = tot[e]
             elif d == 27 and i == 0: resk = tot[e]
+    assert (seen[np.triu_indices(n)] == 1).all()      # every upper-triangular entry comes from exactly one partial element
     return (H, J, res), (Hk, Jk, resk)
 
 
@@ -249,11 +290,14 @@ def run_model(W, V, head, end, G, rng):
     (10, 333, 0, 333, 4),      # several full steps + a ragged one per workgroup
     (10, 100, 7, 95, 3),       # sub-range not aligned to batches
     (10, 5, 0, 5, 4),          # fewer batches than workgroups
-    (9, 200, 0, 200, 2),
-    (8, 150, 3, 150, 2),       # no spare columns: register accumulators
-    (5, 250, 0, 250, 2),       # no spare columns
+    (9, 200, 0, 200, 2),       # odd W: two zero padding columns
+    (8, 150, 3, 150, 2),
+    (7, 120, 0, 120, 2),
+    (5, 250, 0, 250, 2),
     (6, 170, 0, 170, 3),
+    (4, 300, 0, 300, 2),
     (3, 400, 0, 400, 2),
+    (2, 300, 0, 300, 2),
     (1, 300, 10, 290, 2),
 ])
 def test_k3_work_mapping_reproduces_the_definition(W, V, head, end, G):

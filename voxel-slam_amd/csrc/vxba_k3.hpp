@@ -2,93 +2,117 @@
 // namespace vxk, after the LM helpers (lm_decide / lm_residual2 / lm_carry / lm_persist) and dbg_stamp.
 //
 // Per voxel  H_a = -B_a^T B_a + blockdiag_i(D_{a,i})  with B_a the 3 x 6W matrix of SURVEY A.4, so the window Hessian is a
-// tall-skinny SYRK over the 3V stacked rows: v_mfma_f64_16x16x4_f64 accumulates the upper-triangular 16 x 16 tile pairs of
-// S = sum B^T B; gradient, block-diagonal terms and the residual are 28 linear accumulators per frame.
+// tall-skinny SYRK over the 3V stacked rows  S = sum B^T B;  gradient, block-diagonal terms and the residual are 28 linear
+// accumulators per frame (vxm::k3_entry_emit).
 //
-// Round-2 mapping: ONE 8-wave workgroup per CU, two waves per SIMD.  On this chip the f64 MFMA and the f64 VALU share one
-// datapath (strictly additive inside a SIMD, scripts/ubench/mfma_valu_overlap.hip), so the kernel is bound by its fp64 issue
-// count; what a second wave per SIMD buys is that everything that is NOT fp64 -- LDS operand reads and row stores, address
-// arithmetic, waits on global loads, the barrier -- runs under the other wave's fp64 work.  Two waves per SIMD means 256
-// registers per lane, which the round-1 kernel (80 accumulator registers + two entry sets) did not fit.  Here the eight
-// waves of the workgroup share the MFMA work of a STEP of eight batches instead of each wave doing all of its own:
-//   phase A  every wave turns its own batch (NV voxels x W frames, one lane per entry) into 3 NV rows of B and stores them
-//            in a workgroup-shared LDS tile of 8 x 3 NV rows (144 rows at W = 10: 36 K-steps, no K padding -- the round-1
-//            kernel padded each batch's 18 rows to 20);
-//   phase M  wave w owns tile set (w mod TSPLIT) -- half of the tile pairs at W >= 6 -- and the K range (w div TSPLIT) of the
-//            step: 45 MFMAs per wave and step at W = 10 (it was 50 per batch), 40 accumulator registers instead of 80.
-// The tile is double-buffered and the loop is skewed -- phase M of step s-1, then phase A of step s, then ONE barrier -- so a
-// wave leaves the barrier straight into MFMAs whose operands only need an LDS read.  A single entry register set suffices:
-// the loads of the next batch are issued right after phase A has consumed the current one and have the whole phase M to land.
-// Workgroups take contiguous, evenly sized runs of batches (32 or 33 at cfg2); the run's last, partly filled step only
-// covers the rows that exist (its K range is re-split over the waves), so the ragged end costs one phase A, not a step.
-// The cross-wave reduction of the epilogue and the workgroup partial (k3_finalize's input) are laid out as in round 1.
-// No float atomics: bitwise reproducible for a given launch geometry.
+// Round 5: the SYRK runs on v_mfma_f64_4x4x4_4b_f64 with the instruction's four BLOCKS used as four K-SLICES of one 4 x 4 output
+// block.  The instruction multiplies block t of A (4 x 4) with block t of B (4 x 4), t = 0..3, independently; operand lane
+// l = 16 k + 4 t + i holds A_t[i][k] (B alike, with j for i), result lane 16 i + 4 t + j holds D_t[i][j] (probed:
+// scripts/ubench/k3_blockk_probe.hip).  With the operand register of COLUMN GROUP g (columns 4g .. 4g+3 of B) loaded as
+//     X_g[lane] = T[16 q + (lane >> 2)][4 g + (lane & 3)]         (a 16-row slab q of the step's row tile T in LDS)
+// -- (k, t) -> row 4 k + t is a bijection onto the slab's 16 rows -- one  D = mfma(X_I, X_J, D)  adds, in block t, the products of
+// the four rows {t, 4 + t, 8 + t, 12 + t} to the 4 x 4 output block (I, J); the sum over the four blocks is taken ONCE, at the end
+// of the kernel.  What that buys against the 16x16x4 form of rounds 1-4 (ten 16 x 16 tile pairs on 64 padded columns):
+//   * block-exact upper triangle: 120 pairs of 4-column groups at W = 10 (1920 entries for 1830 distinct ones) instead of 2560
+//     -- 135 instructions of 17.5 cycles per wave and step instead of 45 of 64 (measured: 4717 against 5866 cycles per step);
+//   * one operand register per column group serves as A and as B of every pair it takes part in: a wave reads 5 - 13 operand
+//     registers per slab for 15 instructions (fewer LDS operand reads than before, not more);
+//   * ONE f64 accumulator (two registers) per pair: a wave OWNS 15 of the 120 pairs over ALL rows of every step -- 30 accumulator
+//     registers instead of 40, and no cross-wave reduction at the end: the epilogue of rounds 1-4 parked 80 KB of accumulators in
+//     LDS and summed four K ranges; now every wave folds its own four blocks (two lane exchanges per pair) and stores its 240 sums.
+// The block-diagonal terms Drt, Dtt can no longer ride through spare tile columns (there are none: 6W = 60 columns are 15 groups
+// exactly); they are linear accumulators again (22 fp64 operations per entry -- 176 cycles per SIMD and step against the 574 a
+// sixteenth column group would cost).
+//
+// Unchanged from round 2: ONE 8-wave workgroup per CU, two waves per SIMD (f64 MFMA and f64 VALU share one datapath: what the
+// second wave buys is that everything that is NOT fp64 runs under the other wave's fp64 work);
+//   phase A  every wave turns its own batch (NV voxels x W frames, one lane per entry) into 3 NV rows of B in a workgroup-shared,
+//            double-buffered LDS tile of 8 x 3 NV rows (144 rows at W = 10 = nine 16-row slabs);
+//   phase M  wave w multiplies ITS pairs over all slabs of the previous step's tile;
+// skewed loop -- phase M of step s-1, then phase A of step s, then ONE barrier; the next batch's loads ride behind the first two
+// slabs of phase M; workgroups take contiguous, evenly sized runs of batches; the run's last, partly filled step only covers the
+// slabs that exist.  No float atomics: bitwise reproducible for a given launch geometry.
+//
+// Mixed precision (BASELINE configs[2], "fp32 Jacobian with fp64 Hessian accumulation"): the rows of B are ROUNDED TO f32 on their
+// way into the tile, products and sums stay f64 (the f32 matrix instruction of rounds 2-4 needed 60 accumulator registers per
+// wave in this mapping; the tolerance study is what the configuration is for, and it is the same now -- tests/test_gpu_parity.py).
 #pragma once
 #include <type_traits>
 
+// ---- which (I, J) column-group pairs a wave owns -----------------------------------------------------------------------------
+// NG groups, NP = NG (NG + 1) / 2 pairs I <= J, cut into 8 runs of PPW = ceil(NP / 8) along an order that keeps a run on few groups
+// (= few operand reads per slab): groups in sets of five, intra-set pairs first, then the cross blocks row by row.  NG = 15
+// (W = 10) uses a hand-made order: three intra-set runs (5 operand reads for 15 instructions) and five runs of three rows of a
+// cross block (8 reads; one run straddles two blocks: 12).
+struct K3PairTab {
+  signed char I[8][16], J[8][16];      // pair j of wave w
+  signed char sa[8][16], sb[8][16];    // ... as operand slots of that wave
+  signed char slot_group[8][16];       // column group an operand slot reads
+  signed char npair[8], nslot[8];
+};
+__host__ __device__ constexpr K3PairTab k3_make_pairs(int NG) {
+  K3PairTab t{};
+  int LI[136] = {}, LJ[136] = {};
+  int n = 0;
+  auto intra = [&](int s0, int s1) { for (int i = s0; i < s1; i++) for (int j = i; j < s1; j++) { LI[n] = i; LJ[n] = j; n++; } };
+  auto rows = [&](int r0, int r1, int c0, int c1) { for (int i = r0; i < r1; i++) for (int j = c0; j < c1; j++) { LI[n] = i; LJ[n] = j; n++; } };
+  if (NG == 15) {
+    intra(0, 5); intra(5, 10); intra(10, 15);
+    rows(0, 3, 5, 10);
+    rows(3, 5, 5, 10); rows(3, 4, 10, 15);
+    rows(0, 3, 10, 15);
+    rows(4, 5, 10, 15); rows(5, 7, 10, 15);
+    rows(7, 10, 10, 15);
+  } else {
+    for (int a = 0; a < NG; a += 5) intra(a, a + 5 < NG ? a + 5 : NG);
+    for (int a = 0; a < NG; a += 5)
+      for (int b = a + 5; b < NG; b += 5) rows(a, a + 5, b, b + 5 < NG ? b + 5 : NG);
+  }
+  const int NP = NG * (NG + 1) / 2, PPW = (NP + 7) / 8;
+  for (int w = 0; w < 8; w++) {
+    int ns = 0, np = 0;
+    for (int p = w * PPW; p < (w + 1) * PPW && p < NP; p++, np++) {
+      t.I[w][np] = (signed char)LI[p];
+      t.J[w][np] = (signed char)LJ[p];
+      int a = -1, b = -1;
+      for (int s = 0; s < ns; s++) { if (t.slot_group[w][s] == LI[p]) a = s; if (t.slot_group[w][s] == LJ[p]) b = s; }
+      if (a < 0) { a = ns; t.slot_group[w][ns++] = (signed char)LI[p]; }
+      if (LJ[p] == LI[p]) b = a;
+      if (b < 0) { b = ns; t.slot_group[w][ns++] = (signed char)LJ[p]; }
+      t.sa[w][np] = (signed char)a;
+      t.sb[w][np] = (signed char)b;
+    }
+    t.npair[w] = (signed char)np;
+    t.nslot[w] = (signed char)ns;
+  }
+  return t;
+}
+
 template <int W>
 struct K3Cfg {
-  static constexpr int NT = (6 * W + 15) / 16;        // 16-wide column tiles
-  static constexpr int NTP = NT * (NT + 1) / 2;       // upper-triangular tile pairs
-  static constexpr int NCOL = 16 * NT;
-  static constexpr int NVCAP = (NT <= 2) ? 12 : (NT == 3 ? 8 : 6);   // keeps two tile buffers of 8 batches within 144 KB of LDS
-  static constexpr int NV = (64 / W) < NVCAP ? (64 / W) : NVCAP;     // voxels per wave-batch (== k3_nv(W))
-  static constexpr int NACT = NV * W;                 // active lanes
-  static constexpr int R = 3 * NV;                    // rows of B per batch
-  static constexpr int WAVES = K3_BLOCK / 64;         // 8
-  static constexpr int ROWS = WAVES * R;              // rows per step: 288 / 192 / 144, always a multiple of 4
-  static constexpr int KS = ROWS / 4;                 // MFMA K-steps per full step
-  static constexpr int TSPLIT = (NTP >= 6) ? 2 : 1;   // tile sets
-  static constexpr int KSPLIT = WAVES / TSPLIT;       // K ranges
-  static constexpr int TPW = NTP / TSPLIT;            // tile pairs (accumulators) per wave: 1, 3, 3, 5
-  static constexpr int KPW = KS / KSPLIT;             // K-steps per wave and full step: 9, 9, 12, 9
-  // Tile layout: rows are stored in PAIRS, column tiles interleaved -- element (row, col) sits at
-  //   (row >> 1) * 2 NCOL + (col >> 4) * 32 + (row & 1) * 16 + (col & 15)
-  // so the two rows a half-wave reads for one MFMA operand (ds_read_b64 is served 32 lanes at a time over 64 banks) are 32
-  // CONTIGUOUS doubles: conflict-free without padding (which is what lets two buffers fit), and a lane's operand address is
-  // one register plus immediates for the K-step and the column tile.
-  // Spare (padding) columns 6W .. 6W+2 of the z rows carry sqrt2 sqrt(coe) u: the MFMA then delivers the block-diagonal
-  // terms Drt, Dtt in S[.][6W + k] for free (vxm::k3_entry<false>) -- 15 accumulators (30 registers) and 22 fp64 operations
-  // per entry less.  Window sizes without three spare columns (W = 5, 8) keep the register accumulators.
-  static constexpr bool SPARE = (NCOL - 6 * W) >= 3;
-  static constexpr int BUF = ROWS * NCOL;             // doubles (f64) or floats (mixed) per tile buffer
-  __host__ __device__ static constexpr int at(int row, int col) { return (row >> 1) * 2 * NCOL + (col >> 4) * 32 + (row & 1) * 16 + (col & 15); }
-  static_assert(ROWS % 4 == 0 && NTP % TSPLIT == 0 && KS % KSPLIT == 0, "step geometry");
-
-  // Which tile pairs a wave multiplies.  Both tile sets run the SAME instruction stream: tile j of a wave multiplies operand
-  // slot pa(j) (rows) with operand slot pb(j) (columns); only the column tile an operand slot reads differs between the sets
-  // (a wave-uniform LDS offset).  With a run-time branch between two differently shaped sets the accumulators changed registers
-  // at every merge point -- ~100 v_mov_b64 per wave and step.
-  //   NT = 4: the six off-diagonal pairs of four column tiles split into two PATHS, 0-1-2-3 and 2-0-3-1 (the path graph on four
-  //           nodes is self-complementary), each set taking the diagonal tiles of its path's two inner nodes: slots a-b-c-d,
-  //           pairs (a,b) (b,c) (c,d) (b,b) (c,c).  Set 1 therefore holds (2,0) and (3,1) as LOWER tiles; k3_finalize and the
-  //           spare-column lookup go through rowtile() / coltile().
-  //   NT = 3: no symmetric split exists (three diagonal tiles); every tile gets its own two operand slots.
-  //   NT <= 2: one set, slots = column tiles.
-  static constexpr int NSLOT = (NT == 4) ? 4 : (NT == 3 ? 6 : NT);
-  __host__ __device__ static constexpr int pa(int j) { return NT == 4 ? (j < 3 ? j : j - 2) : (NT == 3 ? 2 * j : k3_tile_I_(NT, j)); }
-  __host__ __device__ static constexpr int pb(int j) { return NT == 4 ? (j < 3 ? j + 1 : j - 2) : (NT == 3 ? 2 * j + 1 : k3_tile_J_(NT, j)); }
-  __host__ __device__ static constexpr int slot_tile(int set, int k) {
-    if (NT == 4) return set == 0 ? k : (k == 0 ? 2 : (k == 1 ? 0 : (k == 2 ? 3 : 1)));
-    if (NT == 3) return set == 0 ? (k < 3 ? 0 : 1) : (k == 2 ? 0 : (k == 4 ? 1 : 2));   // set 0: (0,0) (0,1) (1,1); set 1: (2,2) (0,2) (1,2)
-    return k;
-  }
-  // tile t = set * TPW + j accumulates S[16 rowtile + i][16 coltile + jj]
-  __host__ __device__ static constexpr int rowtile(int t) { return slot_tile(t / TPW, pa(t % TPW)); }
-  __host__ __device__ static constexpr int coltile(int t) { return slot_tile(t / TPW, pb(t % TPW)); }
-  // offset inside a workgroup partial of S[r][c], r <= c (f64 MFMA accumulator layout: register (row >> 2), lane ((row & 3) << 4) | col)
-  __host__ __device__ static constexpr int elem_offset(int r, int c) {
-    const int I = r >> 4, J = c >> 4;
-    for (int t = 0; t < NTP; t++) {
-      int row = -1, col = -1;
-      if (rowtile(t) == I && coltile(t) == J) { row = r - 16 * I; col = c - 16 * J; }
-      else if (rowtile(t) == J && coltile(t) == I) { row = c - 16 * J; col = r - 16 * I; }
-      if (row >= 0) return t * 256 + (row >> 2) * 64 + ((row & 3) << 4) + col;
-    }
-    return -1;
-  }
-  __host__ __device__ static constexpr int k3_tile_I_(int nt, int t) { int I = 0; while (t >= nt - I) { t -= nt - I; I++; } return I; }
-  __host__ __device__ static constexpr int k3_tile_J_(int nt, int t) { int I = 0; while (t >= nt - I) { t -= nt - I; I++; } return I + t; }
+  static constexpr int NG = k3_groups(W);               // 4-wide column groups (6W rounded up: odd W carry two zero columns)
+  static constexpr int NP = NG * (NG + 1) / 2;          // group pairs I <= J
+  static constexpr int NCOLS = 4 * NG;
+  // Row stride of the tile in doubles, == 4 (mod 8): a half-wave of an operand read (ds_read_b64 is served 32 lanes at a time over
+  // 64 banks of 4 B) covers 8 consecutive rows x 32 B, and 8 RS mod 256 is then an odd multiple of 32 -- eight distinct 32-byte
+  // slots: conflict-free on a plain row-major tile (60 columns at W = 10: no padding at all).
+  static constexpr int RS = k3_row_stride(W);
+  static constexpr int NV = k3_nv(W);                   // voxels per wave-batch (even; sized so that two tile buffers fit the LDS)
+  static constexpr int NACT = NV * W;                   // active lanes
+  static constexpr int R = 3 * NV;                      // rows of B per batch
+  static constexpr int WAVES = K3_BLOCK / 64;           // 8
+  static constexpr int ROWS = WAVES * R;                // rows per step: 288 / 240 / 192 / 144, always a multiple of 16
+  static constexpr int KC = ROWS / 16;                  // 16-row slabs per full step
+  static constexpr int BUF = ROWS * RS;                 // doubles per tile buffer
+  static constexpr int PPW = k3_pairs_per_wave(W);      // pairs (accumulators) per wave: 15 at W = 10
+  static constexpr int PPWP = (PPW + 3) & ~3;           // ... rounded up to the store pattern (four pairs per 512-byte store)
+  static constexpr int NTILE = WAVES * PPWP * 16;       // doubles of a workgroup partial that hold S: [wave][pair][4 i + j]
+  static constexpr int PLEN = NTILE + W * DACC;
+  static_assert(WAVES == 8 && ROWS % 16 == 0 && NACT <= 64 && NG <= 15 && PPW <= 16, "step geometry");
+  static_assert(PLEN == (int)k3_partial_len(W), "partial layout");
+  __host__ __device__ static constexpr K3PairTab pairs() { return k3_make_pairs(NG); }
+  // pairs wave w owns (the last runs may be short or empty at small W)
+  __host__ __device__ static constexpr int npair(int w) { const int left = NP - w * PPW; return left < 0 ? 0 : (left < PPW ? left : PPW); }
 };
 
 // Register image of one (voxel, frame) entry plus the voxel's cached plane parameters.
@@ -286,192 +310,105 @@ __device__ __forceinline__ void k3_phase_a(K3Entry& e, int fi, const double* __r
   vxm::k3_entry_emit<RT>(e.c, e.c + 6, e.c[9], R, p, vc, dacc, emit);
 }
 
-// Store addresses of a lane's three row pieces (element offsets inside a tile buffer): lane constants, kept as 3 row parts +
-// 3 column parts (at(row, col) separates) and added at store time.
+// Where a lane's three row pieces go inside a tile buffer (element offsets, plain row-major): row 3 vl + r of the wave's R rows,
+// columns 6 fi .. 6 fi + 5 -- three 16-byte stores per row.  Idle lanes (NACT .. 63) write a dump area instead of branching.
 struct K3RowOfs {
-  int rp[3];   // row r of the lane's voxel
-  int cp[3];   // column pair j of the lane's frame
+  int rp[3];
 };
 template <int W>
 __device__ __forceinline__ K3RowOfs k3_row_offsets(int wave, int vl, int fi) {
   using C = K3Cfg<W>;
   K3RowOfs ro;
-  // (R is even, so a block of R rows starts on a row pair: at(wave R + x, 0) = at(x, 0) + wave R NCOL -- the pair-sync variant below re-bases
-  // the same offsets by adding a multiple of R NCOL to the buffer pointer)
 #pragma unroll
-  for (int r = 0; r < 3; r++) ro.rp[r] = C::at(wave * C::R + 3 * vl + r, 0);
-#pragma unroll
-  for (int j = 0; j < 3; j++) ro.cp[j] = C::at(0, 6 * fi + 2 * j);
+  for (int r = 0; r < 3; r++) ro.rp[r] = (wave * C::R + 3 * vl + r) * C::RS + 6 * fi;
   return ro;
 }
+template <bool MIXED>
 __device__ __forceinline__ void k3_store_row(double* buf, const K3RowOfs& ro, int r, const double row[6]) {
 #pragma unroll
-  for (int j = 0; j < 3; j++) *reinterpret_cast<v2d*>(buf + ro.rp[r] + ro.cp[j]) = (v2d){row[2 * j], row[2 * j + 1]};
-}
-__device__ __forceinline__ void k3_store_row_f32(float* buf, const K3RowOfs& ro, int r, const double row[6]) {
-#pragma unroll
-  for (int j = 0; j < 3; j++) *reinterpret_cast<v2f*>(buf + ro.rp[r] + ro.cp[j]) = (v2f){(float)row[2 * j], (float)row[2 * j + 1]};
-}
-__device__ __forceinline__ void k3_store_rows(double* buf, const K3RowOfs& ro, const double rows[3][6]) {
-#pragma unroll
-  for (int r = 0; r < 3; r++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) *reinterpret_cast<v2d*>(buf + ro.rp[r] + ro.cp[j]) = (v2d){rows[r][2 * j], rows[r][2 * j + 1]};
-}
-// mixed precision (BASELINE configs[2]): the rows are rounded to f32 on the way into the tile (same geometry, in floats)
-__device__ __forceinline__ void k3_store_rows_f32(float* buf, const K3RowOfs& ro, const double rows[3][6]) {
-#pragma unroll
-  for (int r = 0; r < 3; r++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) *reinterpret_cast<v2f*>(buf + ro.rp[r] + ro.cp[j]) = (v2f){(float)rows[r][2 * j], (float)rows[r][2 * j + 1]};
-}
-
-// Phase M: K-steps [k0, k0 + nk) of the tile in `buf` into the wave's accumulators.  Lane l supplies row 4k + l/16, column
-// 16c + l%16 of the column tile c its operand slot reads -- one register serves as A and as B operand.  FULL: nk == KPW at
-// compile time.  (The slot indices are template constants: as plain constexpr calls inside the loop they were evaluated at run time.)
-template <int W, int J>
-__device__ __forceinline__ void k3_mfma_tiles(const double* x, v4d* acc) {
-  using C = K3Cfg<W>;
-  if constexpr (J < C::TPW) {
-    acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[C::pa(J)], x[C::pb(J)], acc[J], 0, 0, 0);
-    k3_mfma_tiles<W, J + 1>(x, acc);
+  for (int j = 0; j < 3; j++) {
+    // mixed precision: the Jacobian row is rounded to f32 here; everything downstream (products, sums) is f64
+    const double a = MIXED ? (double)(float)row[2 * j] : row[2 * j], b = MIXED ? (double)(float)row[2 * j + 1] : row[2 * j + 1];
+    *reinterpret_cast<v2d*>(buf + ro.rp[r] + 2 * j) = (v2d){a, b};
   }
 }
-// element offset of operand slot k's column tile for tile set `set` (wave-uniform select between two constants)
-template <int W>
-__device__ __forceinline__ int k3_slot_offset(int set, int k) {
+
+// Phase M of wave WV: its pairs over `nch` 16-row slabs of the tile at `bp` (= buffer + the lane's operand offset
+// (lane >> 2) RS + (lane & 3)).  FULL: nch == KC at compile time, operands of slab q + 1 requested before the instructions of slab q
+// are issued, hook(q) behind them (the next batch's global requests ride there).  Every index below is a compile-time constant.
+template <int W, int WV, int J>
+__device__ __forceinline__ void k3_mfma_pairs(const double* x, double* acc) {
   using C = K3Cfg<W>;
-  return 32 * (set == 0 ? C::slot_tile(0, k) : C::slot_tile(C::TSPLIT - 1, k));
+  constexpr K3PairTab T = C::pairs();
+  if constexpr (J < T.npair[WV]) {
+    acc[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(x[T.sa[WV][J]], x[T.sb[WV][J]], acc[J], 0, 0, 0);
+    k3_mfma_pairs<W, WV, J + 1>(x, acc);
+  }
+}
+template <int W, int WV, int S>
+__device__ __forceinline__ void k3_read_slots(const double* bp, int slab, double* x) {
+  using C = K3Cfg<W>;
+  constexpr K3PairTab T = C::pairs();
+  if constexpr (S < T.nslot[WV]) {
+    x[S] = bp[slab * 16 * C::RS + 4 * T.slot_group[WV][S]];
+    k3_read_slots<W, WV, S + 1>(bp, slab, x);
+  }
 }
 struct K3NoHook { __device__ __forceinline__ void operator()(int) const {} };
-template <int W, bool FULL, class Hook = K3NoHook>
-__device__ __forceinline__ void k3_mfma_phase(const double* buf, int set, int k0, int nk, int lrow, int lcol, v4d* acc, Hook hook = Hook()) {
+template <int W, int WV, bool FULL, class Hook>
+__device__ __forceinline__ void k3_mfma_wave(const double* bp, int nch, double* acc, Hook& hook) {
   using C = K3Cfg<W>;
-  const double* bp[C::NSLOT];   // K-step kk: + kk * 4 NCOL
+  constexpr K3PairTab T = C::pairs();
+  constexpr int NS = T.nslot[WV] > 0 ? T.nslot[WV] : 1;
+  if constexpr (FULL) {
+    double x[NS], xn[NS];
+    k3_read_slots<W, WV, 0>(bp, 0, x);
 #pragma unroll
-  for (int k = 0; k < C::NSLOT; k++) bp[k] = buf + C::at(4 * k0 + lrow, lcol) + k3_slot_offset<W>(set, k);
-#if defined(K3_PREFETCH2) && K3_PREFETCH2
-  if (FULL) {
-    // experiment (the review's (b)): operands TWO K-steps ahead of the MFMAs that consume them
-    double x[C::NSLOT], xn[C::NSLOT], xnn[C::NSLOT];
-#pragma unroll
-    for (int k = 0; k < C::NSLOT; k++) { x[k] = bp[k][0]; xn[k] = C::KPW > 1 ? bp[k][4 * C::NCOL] : 0.0; }
-#pragma unroll
-    for (int kk = 0; kk < C::KPW; kk++) {
-      if (kk + 2 < C::KPW) {
-#pragma unroll
-        for (int k = 0; k < C::NSLOT; k++) xnn[k] = bp[k][(kk + 2) * 4 * C::NCOL];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      k3_mfma_tiles<W, 0>(x, acc);
-      hook(kk);
-#pragma unroll
-      for (int k = 0; k < C::NSLOT; k++) { x[k] = xn[k]; xn[k] = xnn[k]; }
-    }
-  } else
-#endif
-  if (FULL) {
-    // operands of K-step kk+1 are requested before the MFMAs of K-step kk are issued
-    double x[C::NSLOT], xn[C::NSLOT];
-#pragma unroll
-    for (int k = 0; k < C::NSLOT; k++) x[k] = bp[k][0];
-#pragma unroll
-    for (int kk = 0; kk < C::KPW; kk++) {
-      if (kk + 1 < C::KPW) {
-#pragma unroll
-        for (int k = 0; k < C::NSLOT; k++) xn[k] = bp[k][(kk + 1) * 4 * C::NCOL];
+    for (int q = 0; q < C::KC; q++) {
+      if (q + 1 < C::KC) {
+        k3_read_slots<W, WV, 0>(bp, q + 1, xn);
         __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the MFMAs (the scheduler sinks them to their first use otherwise)
       }
-      k3_mfma_tiles<W, 0>(x, acc);
-      hook(kk);   // (K3_LATE_REQUESTS) one of the next batch's requests behind the MFMAs of this K-step
+      k3_mfma_pairs<W, WV, 0>(x, acc);
+      hook(q);
 #pragma unroll
-      for (int k = 0; k < C::NSLOT; k++) x[k] = xn[k];
+      for (int s = 0; s < NS; s++) x[s] = xn[s];
     }
   } else {
-    for (int kk = 0; kk < nk; kk++) {
-      double x[C::NSLOT];
-#pragma unroll
-      for (int k = 0; k < C::NSLOT; k++) x[k] = bp[k][kk * 4 * C::NCOL];
-      k3_mfma_tiles<W, 0>(x, acc);
+    for (int q = 0; q < nch; q++) {
+      double x[NS];
+      k3_read_slots<W, WV, 0>(bp, q, x);
+      k3_mfma_pairs<W, WV, 0>(x, acc);
     }
   }
 }
-// Mixed precision: f32 products on v_mfma_f32_16x16x4_f32 (32 cycles per instruction instead of 64), summed in f32 over the
-// steps of ONE wave (<= 5 steps x 9 K-steps x 4 rows at cfg2/cfg3 sizes), then carried in f64 through the workgroup epilogue,
-// the cross-workgroup reduction and the all-reduce -- "fp32 Jacobian, fp64 Hessian accumulation".  The f32 instruction leaves
-// D(4 (l/16) + r, l % 16) in register r of lane l, the f64 one D((l/16) + 4 r, l % 16); feeding the A operand with the rows
-// permuted by  m -> (m >> 2) + 4 (m & 3)  makes the two maps coincide, so the epilogue and k3_finalize are shared.
-template <int W, int J>
-__device__ __forceinline__ void k3_mfma_tiles_f32(const float* xa, const float* xb, v4f* af) {
-  using C = K3Cfg<W>;
-  if constexpr (J < C::TPW) {
-    af[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[C::pa(J)], xb[C::pb(J)], af[J], 0, 0, 0);
-    k3_mfma_tiles_f32<W, J + 1>(xa, xb, af);
-  }
-}
-template <int W>
-__host__ __device__ constexpr unsigned k3_slots_as_a() { unsigned m = 0; for (int j = 0; j < K3Cfg<W>::TPW; j++) m |= 1u << K3Cfg<W>::pa(j); return m; }
-template <int W>
-__host__ __device__ constexpr unsigned k3_slots_as_b() { unsigned m = 0; for (int j = 0; j < K3Cfg<W>::TPW; j++) m |= 1u << K3Cfg<W>::pb(j); return m; }
-template <int W, bool FULL>
-__device__ __forceinline__ void k3_mfma_phase_f32(const float* buf, int set, int k0, int nk, int lrow, int lcol, v4f* af) {
-  using C = K3Cfg<W>;
-  constexpr unsigned NEEDA = k3_slots_as_a<W>(), NEEDB = k3_slots_as_b<W>();
-  const int pcol = (lcol >> 2) + 4 * (lcol & 3);
-  const float* bpa[C::NSLOT];
-  const float* bpb[C::NSLOT];
-#pragma unroll
-  for (int k = 0; k < C::NSLOT; k++) {
-    bpb[k] = buf + C::at(4 * k0 + lrow, lcol) + k3_slot_offset<W>(set, k);
-    bpa[k] = buf + C::at(4 * k0 + lrow, pcol) + k3_slot_offset<W>(set, k);
-  }
-  const int kend = FULL ? C::KPW : nk;
-  if (FULL) {
-#pragma unroll
-    for (int kk = 0; kk < C::KPW; kk++) {
-      float xa[C::NSLOT], xb[C::NSLOT];
-#pragma unroll
-      for (int k = 0; k < C::NSLOT; k++) {
-        xb[k] = ((NEEDB >> k) & 1) ? bpb[k][kk * 4 * C::NCOL] : 0.0f;
-        xa[k] = ((NEEDA >> k) & 1) ? bpa[k][kk * 4 * C::NCOL] : 0.0f;
-      }
-      k3_mfma_tiles_f32<W, 0>(xa, xb, af);
-    }
-  } else {
-    for (int kk = 0; kk < kend; kk++) {
-      float xa[C::NSLOT], xb[C::NSLOT];
-#pragma unroll
-      for (int k = 0; k < C::NSLOT; k++) {
-        xb[k] = ((NEEDB >> k) & 1) ? bpb[k][kk * 4 * C::NCOL] : 0.0f;
-        xa[k] = ((NEEDA >> k) & 1) ? bpa[k][kk * 4 * C::NCOL] : 0.0f;
-      }
-      k3_mfma_tiles_f32<W, 0>(xa, xb, af);
-    }
+template <int W, bool FULL, class Hook>
+__device__ __forceinline__ void k3_mfma_phase(const double* bp, int wave, int nch, double* acc, Hook& hook) {
+  switch (wave) {   // wave-uniform: scalar branches, eight straight-line variants
+    case 0: k3_mfma_wave<W, 0, FULL>(bp, nch, acc, hook); break;
+    case 1: k3_mfma_wave<W, 1, FULL>(bp, nch, acc, hook); break;
+    case 2: k3_mfma_wave<W, 2, FULL>(bp, nch, acc, hook); break;
+    case 3: k3_mfma_wave<W, 3, FULL>(bp, nch, acc, hook); break;
+    case 4: k3_mfma_wave<W, 4, FULL>(bp, nch, acc, hook); break;
+    case 5: k3_mfma_wave<W, 5, FULL>(bp, nch, acc, hook); break;
+    case 6: k3_mfma_wave<W, 6, FULL>(bp, nch, acc, hook); break;
+    default: k3_mfma_wave<W, 7, FULL>(bp, nch, acc, hook); break;
   }
 }
 
-// Epilogue geometry.  With the spare columns in use only 13 of the 28 linear accumulators exist (g 0..5, Drr 6..11, residual 27);
-// parked with stride 13 (odd: conflict-free column reads) they fit beside the parked MFMA accumulators, so the epilogue needs one
-// barrier instead of three.  Slots that are not in use are never written to the partial and never read by k3_finalize.
-template <int W>
-struct K3Epi {
-  using C = K3Cfg<W>;
-  static constexpr int NUSED = C::SPARE ? 13 : DACC;
-  static constexpr int DS = C::SPARE ? 13 : DACC + 1;
-  __host__ __device__ static constexpr int slot(int k) { return C::SPARE ? (k < 12 ? k : 27) : k; }
-  static constexpr bool ONE_PHASE = ((size_t)K3_BLOCK * DS + (size_t)C::WAVES * C::TPW * 256) * sizeof(double) <= 144 * 1024;
-};
+// Epilogue: the 28 linear accumulators of every lane are parked with stride 29 (odd: conflict-free column reads), then one thread per
+// (frame, slot) sums the 8 NV lanes that hold it.
+constexpr int K3_DS = DACC + 1;
 template <int W>
 __device__ __forceinline__ void k3_sum_linear(const double* park_d, double* out, int tid) {
   using C = K3Cfg<W>;
-  using E = K3Epi<W>;
-  for (int el = tid; el < W * E::NUSED; el += K3_BLOCK) {
-    const int i = el / E::NUSED, k = el % E::NUSED;
+  for (int el = tid; el < W * DACC; el += K3_BLOCK) {
+    const int i = el / DACC, k = el % DACC;
     double sum = 0.0;
     for (int w = 0; w < C::WAVES; w++)
 #pragma unroll
-      for (int v = 0; v < C::NV; v++) sum += park_d[(w * 64 + v * W + i) * E::DS + k];
-    st_out(&out[i * DACC + E::slot(k)], sum);
+      for (int v = 0; v < C::NV; v++) sum += park_d[(w * 64 + v * W + i) * K3_DS + k];
+    st_out(&out[i * DACC + k], sum);
   }
 }
 
@@ -480,33 +417,8 @@ __device__ __forceinline__ void k3_sum_linear(const double* park_d, double* out,
 // so that those requests do not wait for a scalar load of the argument block first (a cold miss: the block was written by the host a few
 // microseconds earlier).  Structs are not preloaded and stop the sequence, hence the flat list; what is not urgent follows as before.
 //   pend_flags = pending | restart << 8, nwg = nwg (otherwise a load from the hidden arguments)
-// K3_PAIR_SYNC (round 4, the review's experiment (a)): the two waves that share a SIMD (w and w + 4: a workgroup's waves go to the four SIMDs
-// cyclically) own ONE K range -- the 2 R rows those same two waves produce in phase A -- and the two tile sets, so a step's dependency is
-// local to the pair: a flag in LDS replaces the workgroup barrier from step 1 on (step 0 keeps it: the LM decision rides on it).
-// MEASURED, same box (gpurun_out/r4_s11.log, profiles/r04_k3_phase_a): K3 26.2 us against 25.8 (cfg2), 148.6 against 146.6 (cfg4), 43.1
-// against 42.6 (cfg3) -- no gain: the ~1k cycles a wave of the first half waits at the step barrier are spent waiting for ITS OWN partner
-// (stamps: waves 0-3 finish phase A at 8.7k cycles of a step, their partners 4-7 at 9.9k, the barrier opens at 10.2k), which a pair flag
-// waits for just the same, and the polling wave takes issue slots from the partner it waits for.  Off; kept as the record of the experiment.
-// K3_PREFETCH2 ((b): operands two K-steps ahead): 26.0 / 146.8 / 42.6 -- no change; the MFMA stream does not wait for its operands.
-#ifndef K3_PAIR_SYNC
-#define K3_PAIR_SYNC 0
-#endif
-#ifndef K3_LATE_REQUESTS
-#define K3_LATE_REQUESTS 1   // round 4: the default (cfg4 156.6 -> 147.4 us, cfg3 44.5 -> 43.2, cfg2 unchanged; same-box A/B, gpurun_out/r4_s3.log)
-#endif
-constexpr bool K3_LATE_REQ = K3_LATE_REQUESTS != 0;
-#ifndef K3_LATE_MIXED
-#define K3_LATE_MIXED 0
-#endif
-// K3_RAGGED_FIRST (round 4, experiment): the partly filled step of a workgroup (cnt mod 8 batches, one on 142 of 256 workgroups at cfg2) is
-// taken in the FILL instead of behind the last full step: waves 4 .. request those batches before the prologue barrier (they would
-// otherwise wait for the barrier with nothing in flight), run their phase A into the idle tile buffer while the first full batches are
-// still on their way, and the short phase M + a barrier of its own sit in front of step 1.
-#ifndef K3_RAGGED_FIRST
-#define K3_RAGGED_FIRST 0
-#endif
 #ifndef K3_LATE_PER
-#define K3_LATE_PER 4      // requests behind each K-step of phase M: all eight behind the first two of the nine K-steps at W = 10 (1 and 2 per K-step measured slower: later requests land later)
+#define K3_LATE_PER 4      // requests behind each slab of phase M: all eight behind the first two of the nine slabs at W = 10 (1 and 2 per K-step measured slower in round 4: later requests land later)
 #endif
 template <int W, bool DBG = false, bool MIXED = false>
 __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k3_hessian_kernel(const double* __restrict__ clb, const double* __restrict__ cache_planes, const double* __restrict__ coe_plane,
@@ -515,21 +427,12 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int pending = pend_flags & 0xff, restart = pend_flags >> 8;
 
   using C = K3Cfg<W>;
-  // window sizes without spare tile columns (W = 5, 8) carry 15 more accumulators: no registers left for requests in flight across phase M
-  // (mixed precision: phase M is half as long -- f32 products -- and the requests in front of it landed late: cfg3 mixed 35.6 -> 37.0 us; it keeps them in front of the barrier)
-  constexpr bool LATE = K3_LATE_REQ && C::SPARE && !(MIXED && !K3_LATE_MIXED);
   extern __shared__ __attribute__((aligned(16))) double lds[];  // two tile buffers; reused by the epilogue
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // tell the compiler it is wave-uniform: scalar branches, descriptors in SGPRs
   const bool active = lane < C::NACT;
   const int vl = active ? lane / W : 0;
   const int fi = active ? lane % W : 0;
-  const int lrow = lane >> 4, lcol = lane & 15;
-  constexpr bool PAIR = (K3_PAIR_SYNC != 0) && C::TSPLIT == 2 && C::WAVES == 8 && (C::R % 2 == 0);
-  const int set = PAIR ? (wave >> 2) : wave % C::TSPLIT, kq = PAIR ? (wave & 3) : wave / C::TSPLIT;
-  // full steps: where this wave's R rows go inside a tile buffer, as a shift of the plain layout (rows wave R ..): K range kq = rows
-  // [2 R kq, 2 R (kq + 1)) = the rows of wave kq (first half) and of wave kq + 4 (second half)
-  const int rowshift = PAIR ? ((2 * kq + set) - wave) * C::R * C::NCOL : 0;
   const int gw = blockIdx.x * C::WAVES + wave;
   dbg_stamp(DBG, gw, 0);
 
@@ -540,11 +443,6 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int g = blockIdx.x;
   const int cnt = q + (g < rem ? 1 : 0);
   const int bs = b0 + g * q + (g < rem ? g : rem);
-  // (K3_RAGGED_FIRST) the ragged batches of this workgroup go first, on waves 4 .. 4 + nrag - 1
-  constexpr bool RAGF_ON = (K3_RAGGED_FIRST != 0) && C::WAVES == 8 && (C::R % 2 == 0) && !MIXED;
-  const bool ragf = RAGF_ON && (cnt / C::WAVES) >= 1 && (cnt % C::WAVES) >= 1 && (cnt % C::WAVES) <= 4;
-  const bool ragw = ragf && wave >= 4 && (wave - 4) < (cnt % C::WAVES);
-  const int b_rag = bs + (cnt / C::WAVES) * C::WAVES + (wave - 4);
 
   // The first batch is requested before anything else: it does not depend on the poses, so the LM decision below (a few
   // dependent global reads) runs in the shadow of these loads.  Wave 0 is the exception: loads return in order, so it asks for
@@ -568,21 +466,16 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
   //   waves 4-7 request their first batch after the barrier below.
   // First batches in two halves: a CU takes in ~10 B per clock, so eight first batches (48 KB) land together and both waves of a SIMD
   // then run phase A back to back with nothing under it; with four, the first wave of each SIMD works while the second wave's rows are
-  // on their way.  The barrier is released by wave 0, i.e. about when the first four batches have landed -- measured on the same box
-  // (K3 at cfg2, us): this arrangement 26.8; all eight batches before the barrier 27.3; poses and partials on waves 4 / 5 (barrier 1.5k
-  // cycles earlier) 27.4; partials requested after the barrier 27.2-27.5; second half delayed by a further 512 / 1024 / 2048 cycles
-  // 27.2 / 27.4 / 28.2.
+  // on their way.  The barrier is released by wave 0, i.e. about when the first four batches have landed (round 3, same box, K3 at
+  // cfg2: this arrangement 26.8 us; all eight batches before the barrier 27.3; poses and partials on waves 4 / 5 27.4; partials requested
+  // after the barrier 27.2-27.5; second half delayed by a further 512 / 1024 / 2048 cycles 27.2 / 27.4 / 28.2).
   //
   // The accept / reject decision of the pending step (pending == 1) is SPECULATED: a rejected step means this sweep has nothing to
   // do, an accepted one means it linearises at the trial poses -- so every workgroup starts phase A of its first step at the trial
   // poses as soon as those are in LDS, wave 0 adds up residual2 behind the barrier, and the decision is taken behind the first step's
   // barrier (a rejected step costs one phase A instead of none; the common, accepted one no longer waits for the sum).
-#ifndef K3_FIRST_WAVES_V
-#define K3_FIRST_WAVES_V (C::WAVES / 2)
-#endif
-  constexpr int K3_FIRST_WAVES = K3_FIRST_WAVES_V;
+  constexpr int K3_FIRST_WAVES = C::WAVES / 2;
   if (wave != 0 && wave < K3_FIRST_WAVES && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
-  if (RAGF_ON && ragw) { k3_load_clusters(pl, b_rag, lane, e.c); k3_load_params<W>(pl, head, end, b_rag, lane, stg); }
 
   // LDS behind the two tile buffers: the poses (raw C-ABI layout: R column-major | p per frame) and what the LM decision needs
   double* poseA = lds + 2 * C::BUF;       // the poses `xa_src` selects
@@ -616,21 +509,17 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
     dbg_stamp(DBG, gw, 5);   // poses in LDS
   }
   dbg_stamp(DBG, gw, 2);     // first requests issued
-  // Only the padding columns 6W .. NCOL of the two tile buffers have to start as zeros: phase A writes columns 0 .. 6W of every row of
-  // a step (and the three spare columns of the z rows), the ragged step clears the rows it rounds up to, nothing else is read.
-  // (Clearing both buffers whole -- 144 KB through a 128 B / clock LDS -- kept every wave 2.5k cycles from the barrier below.)
+  // Only the padding columns 6W .. 4 NG of the two tile buffers have to start as zeros (odd W: two columns): phase A writes columns
+  // 0 .. 6W of every row of a step, the ragged step clears the rows it rounds up to, nothing else is read.
   {
-    constexpr int PADC = C::NCOL - 6 * W;
+    constexpr int PADC = C::NCOLS - 6 * W;
     if constexpr (PADC > 0) {
       for (int k = tid; k < 2 * C::ROWS * PADC; k += K3_BLOCK) {
         const int b = k / (C::ROWS * PADC), rr = (k / PADC) % C::ROWS, cc = 6 * W + k % PADC;
-        const int o = b * C::BUF + C::at(rr, cc);
-        if (MIXED) reinterpret_cast<float*>(lds)[o] = 0.0f;
-        else lds[o] = 0.0;
+        lds[b * C::BUF + rr * C::RS + cc] = 0.0;
       }
     }
   }
-  if (PAIR && tid < C::WAVES) reinterpret_cast<volatile int*>(lds + 2 * C::BUF + 12 * W)[tid] = 0;   // the pair flags (behind the poses)
   dbg_stamp(DBG, gw, 4);     // tiles cleared
   __syncthreads();
   dbg_stamp(DBG, gw, 1);
@@ -646,7 +535,7 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
       if (in_done || !in_calc) return;
     }
   }
-  if (wave >= K3_FIRST_WAVES && wave < cnt && !(RAGF_ON && ragw)) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
+  if (wave >= K3_FIRST_WAVES && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
   if (wave == 0 && undecided) {
     const double r2 = lm_residual2_finish(pend, r2_loads);
     if (lane == 0) lmv[4] = r2;
@@ -670,257 +559,142 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0); the builtin, not inline asm: the bookkeeping pass has to see it
     return done || !(accept || restart);
   };
-#if defined(K3_POSE_REGS) && K3_POSE_REGS
-  // experiment: the lane's pose (a lane constant for the whole launch) held in 24 registers instead of six ds_read_b128 per step
-  double pose[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) pose[k] = poseA[12 * fi + k];
-#else
   const double* pose = poseA + 12 * fi;
-#endif
-  v4d acc[C::TPW];
+  double acc[C::PPW];                     // the wave's pairs: block t of accumulator j holds the rows == t (mod 4) of every slab
 #pragma unroll
-  for (int t = 0; t < C::TPW; t++) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-  v4f af[MIXED ? C::TPW : 1];   // mixed precision: the wave's f32 accumulators, widened into acc after the last step
-#pragma unroll
-  for (int t = 0; t < (MIXED ? C::TPW : 1); t++) af[t] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+  for (int t = 0; t < C::PPW; t++) acc[t] = 0.0;
   double dacc[DACC];
 #pragma unroll
   for (int k = 0; k < DACC; k++) dacc[k] = 0.0;
 
-  volatile int* pflag = reinterpret_cast<volatile int*>(poseA + 12 * W);   // (PAIR) per wave: steps whose rows are in LDS; zeroed below, before the first barrier that follows
   K3RowOfs ro = k3_row_offsets<W>(wave, vl, fi);   // lane constants: where the lane's three row pieces go inside a tile buffer
   double* const dump = lmv + 8 + C::WAVES * K3Stage<W>::WAVE_DOUBLES;   // 32 doubles behind the staging areas that nobody reads: where the idle lanes' (zero) rows go
   // (k3_lds_bytes reserves them.  A first version put the dump behind the poses: at W <= 2 that ran into the LM decision inputs -- found by the randomised sweep)
   if (!active) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) { ro.rp[k] = 8 * k; ro.cp[k] = 2 * k; }
+    for (int k = 0; k < 3; k++) ro.rp[k] = 8 * k;
   }
+  const int opnd = (lane >> 2) * C::RS + (lane & 3);    // the lane's place in every operand read: row lane / 4 of a slab, column lane % 4 of a group
   int dbg_step = -1;                                      // instrumented build: the step phase_a is running for
   // Phase A of the wave's batch b into tile buffer `bo`, then the requests for its next batch nb (nb < 0: none).
   // Measured and rejected (round 3, same box): the LDS round trip of the plane parameters issued two thirds of the way through phase M
   // instead of at the head of phase A -- 29.8 -> 29.6 us at cfg2, but 166.9 -> 173.3 us at cfg4 (13 steps per workgroup): the wait
   // for the parameter loads then sits inside the MFMA stream, and with more traffic in flight they have not always landed by then.
   auto unstage = [&](int b) __attribute__((always_inline)) { k3_unstage_params<W>(stg, stage_lds, head, end, b, active, vl, lane, e); };
-  // `next`: 0 = no requests behind this phase A (compile-time at the call), 1 = request batch nb if `more` (wave-uniform, run time).
-  // The run-time case issues the loads UNCONDITIONALLY through descriptors whose range check `more` switches off: with a branch around
-  // them the entry registers became a phi of (old, loaded) values, and the copies that resolve it sat behind s_waitcnt vmcnt at the END
-  // of phase A -- every wave waited out the latency of the loads it had just issued before it reached the barrier (round-4 find, from
-  // the ISA: vmcnt(7) / (6) / (5) + six v_mov_b64 in front of the barrier, vmcnt(0) at the head of phase M).
-  auto phase_a = [&](int b, int bo_in, int nb, bool more, auto next_tag) __attribute__((always_inline)) {
-    const int bo = bo_in + (decltype(next_tag)::value == 1 ? rowshift : 0);      // full steps (next == 1): the pair layout; the ragged step: the plain one
-    constexpr int next = decltype(next_tag)::value;
-    // instrumented build, step 2 only: 7 parameters + pose back in registers, 14 rows computed, 15 rows stored, 18 = everything but the requests
+  auto phase_a = [&](int b, int bo) __attribute__((always_inline)) {
+    // instrumented build, step 2 only: 7 parameters + pose back in registers, 14 rows computed, 15 rows stored
     const bool stamp_here = DBG && dbg_step == 2;
     unstage(b);
     if (DBG && stamp_here) { asm volatile("" :: "v"(e.u[0]), "v"(e.coe)); __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 7); __builtin_amdgcn_sched_barrier(0); }
-    // voxel-level values for the spare columns, taken before phase A masks / consumes the entry
-    const double spare_s = 1.4142135623730951 * e.sc;
-    const double spare[3] = {spare_s * e.u[0], spare_s * e.u[1], spare_s * e.u[2]};
-    if (active && C::SPARE && fi == W - 1) {   // one lane per voxel: columns 6W .. 6W+2 of the z row
-      const int o = ro.rp[2] + C::at(0, 6 * W);
-      if (MIXED) {
-        float* zf = reinterpret_cast<float*>(lds) + bo + o;
-        *reinterpret_cast<v2f*>(zf) = (v2f){(float)spare[0], (float)spare[1]};
-        zf[2] = (float)spare[2];
-      } else {
-        double* zd = lds + bo + o;
-        *reinterpret_cast<v2d*>(zd) = (v2d){spare[0], spare[1]};
-        zd[2] = spare[2];
-      }
-    }
     // Rows go to the tile AS THEY ARE FINISHED (z row, G row 1, G row 2; round 4): stamps put ten 16-byte stores per wave, issued together
     // at the end of phase A by all four waves of a half at once, at 1.0-1.5k cycles until the last is performed -- which the wave then
     // waited out in front of the barrier.  With the first six under way while the second G row and the block-diagonal terms are still
     // being computed only the last three are young at the barrier.
-    // (no branch around the stores of the 64 - NACT idle lanes: they write a dump area behind the poses instead -- a branch makes the wait-count
+    // (no branch around the stores of the 64 - NACT idle lanes: they write a dump area instead -- a branch makes the wait-count
     // bookkeeping at its join wait for the stores just issued)
     double* const rowbase = active ? lds + bo : dump;
-    float* const rowbase_f = active ? reinterpret_cast<float*>(lds) + bo : reinterpret_cast<float*>(dump);
     auto emit = [&](int r, const double row[6]) __attribute__((always_inline)) {
-      if (MIXED) k3_store_row_f32(rowbase_f, ro, r, row);
-      else k3_store_row(rowbase, ro, r, row);
-#if !defined(K3_STORES_AT_END) || !K3_STORES_AT_END
+      k3_store_row<MIXED>(rowbase, ro, r, row);
       __builtin_amdgcn_sched_barrier(0);   // keep the stores where they are: the scheduler gathers them behind the last row otherwise
-#endif
     };
-    k3_phase_a<!C::SPARE>(e, fi, pose, dacc, emit);
+    k3_phase_a<true>(e, fi, pose, dacc, emit);
     if (DBG && stamp_here) { __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 14); __builtin_amdgcn_sched_barrier(0); }
-    // next batch of this wave: in flight during the barrier and the whole of phase M.  Measured and rejected (round 2, same
-    // box): the cluster rows requested a step earlier into a second register set (no change: the steps do not wait for loads);
-    // the two waves of a SIMD taking phase M / phase A in opposite order (13.2k instead of 11.8k cycles per step).  Round 3: s_setprio
-    // for one of a SIMD's two waves during phase A (either one: K3 26.6 -> 27.2 us), for phase M (no change).
-    if (DBG && stamp_here) { __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 15); asm volatile("" :: "v"(dacc[6]), "v"(dacc[11]), "v"(dacc[0])); __builtin_amdgcn_sched_barrier(0); dbg_stamp(true, gw, 18); }
-    if constexpr (next == 2 || (next != 0 && !LATE)) {   // next == 2: requested here whatever the mode (the ragged batch taken first: its wave's first full batch)
-      __builtin_amdgcn_sched_barrier(0);   // behind the last use of the entry: the loads go into the registers they free
-#if defined(K3_PARAMS_FIRST) && K3_PARAMS_FIRST
-      k3_load_params<W>(pl, head, end, nb, lane, stg, more);   // experiment: the values phase A needs first are requested first
-      k3_load_clusters(pl, nb, lane, e.c, more);
-#else
-      k3_load_clusters(pl, nb, lane, e.c, more);
-      k3_load_params<W>(pl, head, end, nb, lane, stg, more);
-#endif
-    }
   };
 
   // Full steps: step s = phase M of step s-1 (buffer (s-1)&1), phase A of step s (buffer s&1), one barrier.  The ragged last
   // step (cnt mod 8 batches) is peeled off below, so inside the loop every wave has a batch and both phases are straight-line code.
+  // The requests for the batch of step s ride behind the slabs of phase M of step s-1, K3_LATE_PER per slab, parameters first (phase A
+  // starts with their LDS round trip): a vector-memory instruction costs the wave ~60 cycles of issue when eight waves queue on the CU's
+  // one address unit (round-4 stamps: 460-540 cycles for the eight of a batch), and in front of the barrier that was on the step's
+  // critical path.  The loads are UNCONDITIONAL and gated by their descriptor (`more_m` switches the range check off: out-of-range lanes
+  // return zeros without a memory request): with a branch around them the entry registers became a phi of (old, loaded) values, and the
+  // copies that resolve it sat behind s_waitcnt vmcnt at the END of phase A.
   const int nfull = cnt / C::WAVES, nrag = cnt - nfull * C::WAVES;
-  const int k0_full = kq * C::KPW;
-  // AF (experiment, -DK3_OPPOSITE=1): the second wave of every SIMD (w >= 4) takes phase A BEFORE phase M inside an iteration -- the
-  // two touch different tile buffers, so the order is free -- to put one wave's VALU work under the other's MFMAs.
-  auto ragged_m = [&](int bo) __attribute__((always_inline)) {
-    // only ceil(nrag R / 4) K-steps exist; they are re-split over the K ranges
-    const int ks = (nrag * C::R + 3) >> 2;
-    const int k0 = (kq * ks) / C::KSPLIT, k1 = ((kq + 1) * ks) / C::KSPLIT;
-    if (MIXED) k3_mfma_phase_f32<W, false>(reinterpret_cast<const float*>(lds) + bo, set, k0, k1 - k0, lrow, lcol, af);
-    else k3_mfma_phase<W, false>(lds + bo, set, k0, k1 - k0, lrow, lcol, acc);
-  };
-  if constexpr (RAGF_ON) {
-    if (ragf) {
-      // rows of ragged batch r = wave - 4 at rows [R r, R (r + 1)) of buffer 1 (a shift by four row blocks of R rows: R is even, so the pair-interleaved
-      // layout shifts linearly); behind it the wave's first full batch is requested.  Wave 0 clears the rows that round the step up to a whole K-step.
-      if (ragw) phase_a(b_rag, C::BUF - 4 * C::R * C::NCOL, bs + wave, true, std::integral_constant<int, 2>{});
-      else if (wave == 0) { double* z = lds + C::BUF + C::at(nrag * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0; }
-    }
-  }
-  auto full_steps = [&](auto af_tag) __attribute__((always_inline)) -> bool {
-    constexpr bool AF = decltype(af_tag)::value;
-    for (int s = 0; s <= nfull; s++) {
-      if constexpr (RAGF_ON) {
-        if (ragf && s == 1) { ragged_m(C::BUF); __syncthreads(); }   // before phase A of step 1 overwrites buffer 1
-      }
-      auto phase_m = [&]() __attribute__((always_inline)) {
-        const int bo = ((s - 1) & 1) * C::BUF;
-        if (MIXED) {
-          if constexpr (LATE) {   // mixed precision: the requests in front of the f32 products (not interleaved)
-            const bool more_m = (s < nfull) || (wave < nrag && !ragf);
-            const int nb_m = bs + s * C::WAVES + wave;
-            k3_load_clusters(pl, nb_m, lane, e.c, more_m);
-            k3_load_params<W>(pl, head, end, nb_m, lane, stg, more_m);
-          }
-          k3_mfma_phase_f32<W, true>(reinterpret_cast<const float*>(lds) + bo, set, k0_full, C::KPW, lrow, lcol, af);
-        } else if constexpr (LATE) {
-          // The requests for the batch of step s ride behind the K-steps of phase M of step s-1 (this iteration), one or two per K-step:
-          // a vector-memory instruction costs the wave ~60 cycles of issue when eight waves queue on the CU's one address unit
-          // (stamps: 460-540 cycles for the eight of a batch), and in front of the barrier that was on the step's critical path.
-          const bool more_m = (s < nfull) || (wave < nrag && !ragf);
-          const int nb_m = bs + s * C::WAVES + wave;
-          constexpr int NQ = K3Stage<W>::Q + 1, NL = 5 + NQ;   // the parameters first: phase A starts with their LDS round trip
-          constexpr int PER = (K3_LATE_PER * C::KPW >= NL) ? K3_LATE_PER : (NL + C::KPW - 1) / C::KPW;
-          auto hook = [&](int kk) __attribute__((always_inline)) {
+  for (int s = 0; s <= nfull; s++) {
+    if (s >= 1) {
+      const bool more_m = (s < nfull) || (wave < nrag);
+      const int nb_m = bs + s * C::WAVES + wave;
+      constexpr int NQ = K3Stage<W>::Q + 1, NL = 5 + NQ;
+      constexpr int PER = (K3_LATE_PER * C::KC >= NL) ? K3_LATE_PER : (NL + C::KC - 1) / C::KC;
+      auto hook = [&](int kk) __attribute__((always_inline)) {
 #pragma unroll
-            for (int r = 0; r < PER; r++) {
-              const int l = kk * PER + r;
-              if (l < NQ) k3_load_param_q<W>(pl, head, end, nb_m, lane, stg, more_m, l);
-              else if (l < NL) k3_load_cluster_row(pl, nb_m, lane, e.c, more_m, l - NQ);
-            }
-          };
-          k3_mfma_phase<W, true>(lds + bo, set, k0_full, C::KPW, lrow, lcol, acc, hook);
-        } else {
-          k3_mfma_phase<W, true>(lds + bo, set, k0_full, C::KPW, lrow, lcol, acc);
+        for (int r = 0; r < PER; r++) {
+          const int l = kk * PER + r;
+          if (l < NQ) k3_load_param_q<W>(pl, head, end, nb_m, lane, stg, more_m, l);
+          else if (l < NL) k3_load_cluster_row(pl, nb_m, lane, e.c, more_m, l - NQ);
         }
       };
-      if (!AF && s >= 1) {
-        phase_m();
-        if (s <= 4) dbg_stamp(DBG, gw, 13 + 3 * s);   // phase M of step s-1 done: slots 16, 19, 22, 25
-      }
-      if (s < nfull) {
-        const bool more = (s + 1 < nfull) || (wave < nrag && !ragf);
-        if (DBG) dbg_step = s;
-        phase_a(bs + s * C::WAVES + wave, (s & 1) * C::BUF, bs + (s + 1) * C::WAVES + wave, more, std::integral_constant<int, 1>{});
-        if (s >= 1 && s <= 4) dbg_stamp(DBG, gw, 14 + 3 * s);   // phase A of step s done: slots 17, 20, 23, 26
-      }
-      if (AF && s >= 1) phase_m();
-      if (s == nfull) break;
-      if (PAIR && s >= 1 && !undecided) {
-        // rows of step s are in LDS (the flag's store is queued behind them: one wave's LDS operations execute in order); then wait for
-        // the partner's -- nobody else's rows are read in phase M of step s
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the compiler may not sink the row stores below the flag's)
-        if (lane == 0) pflag[wave] = s + 1;
-        while (pflag[wave ^ 4] < s + 1) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      } else {
-        __syncthreads();
-        if (PAIR && lane == 0) pflag[wave] = s + 1;     // keeps the counters in step when a later step switches to the flags
-      }
-      if (s < 6) dbg_stamp(DBG, gw, 8 + s);
-      if (undecided && decide()) return true;
+      k3_mfma_phase<W, true>(lds + ((s - 1) & 1) * C::BUF + opnd, wave, C::KC, acc, hook);
+      if (s <= 4) dbg_stamp(DBG, gw, 13 + 3 * s);   // phase M of step s-1 done: slots 16, 19, 22, 25
     }
-    return false;
-  };
-#if defined(K3_OPPOSITE) && K3_OPPOSITE
-  if ((wave >> 2) & 1 ? full_steps(std::true_type{}) : full_steps(std::false_type{})) return;
-#else
-  if (full_steps(std::false_type{})) return;
-#endif
-  if (nrag > 0 && !ragf) {
-    // ragged last step: nrag < 8 batches.  Only ceil(nrag R / 4) K-steps exist; they are re-split over the K ranges, and the first
-    // idle wave makes the rows that round the step up to a whole K-step read as zeros.
+    if (s == nfull) break;
+    if (DBG) dbg_step = s;
+    phase_a(bs + s * C::WAVES + wave, (s & 1) * C::BUF);
+    if (s >= 1 && s <= 4) dbg_stamp(DBG, gw, 14 + 3 * s);   // phase A of step s done: slots 17, 20, 23, 26
+    __syncthreads();
+    if (s < 6) dbg_stamp(DBG, gw, 8 + s);
+    if (undecided && decide()) return;
+  }
+  if (nrag > 0) {
+    // ragged last step: nrag < 8 batches.  Only ceil(nrag R / 16) slabs exist; the first idle wave makes the rows that round the step
+    // up to a whole slab read as zeros.
     const int bo = (nfull & 1) * C::BUF;
-    if (wave < nrag) phase_a(bs + nfull * C::WAVES + wave, bo, 0, false, std::integral_constant<int, 0>{});
+    const int nch = (nrag * C::R + 15) >> 4;
+    if (wave < nrag) phase_a(bs + nfull * C::WAVES + wave, bo);
     else if (wave == nrag) {
-      if (MIXED) { float* z = reinterpret_cast<float*>(lds) + bo + C::at(nrag * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0f; }
-      else { double* z = lds + bo + C::at(nrag * C::R, 0); for (int k = lane; k < 4 * C::NCOL; k += 64) z[k] = 0.0; }
+      double* z = lds + bo + nrag * C::R * C::RS;
+      for (int k = lane; k < (nch * 16 - nrag * C::R) * C::RS; k += 64) z[k] = 0.0;
     }
     __syncthreads();
     if (nfull < 6) dbg_stamp(DBG, gw, 8 + nfull);
     if (undecided && decide()) return;
-    const int ks = (nrag * C::R + 3) >> 2;
-    const int k0 = (kq * ks) / C::KSPLIT, k1 = ((kq + 1) * ks) / C::KSPLIT;
-    if (MIXED) k3_mfma_phase_f32<W, false>(reinterpret_cast<const float*>(lds) + bo, set, k0, k1 - k0, lrow, lcol, af);
-    else k3_mfma_phase<W, false>(lds + bo, set, k0, k1 - k0, lrow, lcol, acc);
-  }
-  if (MIXED) {
-#pragma unroll
-    for (int t = 0; t < C::TPW; t++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) acc[t][r] = (double)af[t][r];
+    K3NoHook nohook;
+    k3_mfma_phase<W, false>(lds + bo + opnd, wave, nch, acc, nohook);
   }
   dbg_stamp(DBG, gw, 3);
 
-  // Deterministic in-block reduction through LDS (fixed order), one partial per workgroup:  [NTP tiles x 256 | W x DACC]
-  using E = K3Epi<W>;
-  constexpr int PLEN = C::NTP * 256 + W * DACC;
-  double* pout = partial + (size_t)blockIdx.x * PLEN;
-  double* park_d = lds;                                                   // [512 lanes][DS] linear accumulators
-  double* park_t = E::ONE_PHASE ? lds + (size_t)K3_BLOCK * E::DS : lds;   // [8 waves][TPW][256] MFMA accumulators
+  // Epilogue.  One partial per workgroup:  [8 waves x PPWP pairs x 16 | W x DACC].
+  double* pout = partial + (size_t)blockIdx.x * C::PLEN;
+  double* park_d = lds;                                                   // [512 lanes][K3_DS] linear accumulators
   __syncthreads();  // every wave is done with the tiles
   dbg_stamp(DBG, gw, 27);
   if (undecided && decide()) return;   // a workgroup without a batch: first barrier since the prologue's
-  // (1) per-frame linear accumulators: every lane parks the ones in use, then one thread per (frame, slot) sums the 8*NV lanes
+  // (1) per-frame linear accumulators: every lane parks them, then (behind the barrier) one thread per (frame, slot) sums the 8 NV lanes
 #pragma unroll
-  for (int k = 0; k < E::NUSED; k++) park_d[(wave * 64 + lane) * E::DS + k] = dacc[E::slot(k)];
-  if (!E::ONE_PHASE) {
-    __syncthreads();
-    k3_sum_linear<W>(park_d, pout + C::NTP * 256, tid);
-    __syncthreads();
+  for (int k = 0; k < DACC; k++) park_d[(wave * 64 + lane) * K3_DS + k] = dacc[k];
+  // (2) the wave's own pairs: fold the four blocks (lanes 16 i + 4 t + j, t = 0..3: two exchanges; every lane of a quadruple ends up
+  // with the same sum bit for bit -- a + b == b + a), then lane (i, t, j) stores pair 4 m + t: one 512-byte run per instruction
+  {
+    const int t4 = (lane >> 2) & 3;
+    const int np = C::npair(wave);
+    const __amdgpu_buffer_rsrc_t rout = k3_rsrc(pout);
+#pragma unroll
+    for (int j = 0; j < C::PPW; j++) {
+      double v = acc[j];
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      acc[j] = v;
+    }
+#pragma unroll
+    for (int m = 0; m < C::PPWP / 4; m++) {
+      double v = 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+        if (4 * m + t < C::PPW) v = (t4 == t) ? acc[4 * m + t] : v;
+      const int off = (wave * C::PPWP + 4 * m + t4) * 16 + 4 * (lane >> 4) + (lane & 3);
+      if (4 * m + t4 < np) {
+#if VXBA_WT_STORES
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), rout, off * 8, 0, 16);   // aux 16 = sc1 on gfx950
+#else
+        pout[off] = v;
+#endif
+      }
+    }
   }
-  // (2) MFMA accumulator tiles: wave (kq, set) parks its TPW tiles, then tile t of set s is the sum over the K ranges
-#pragma unroll
-  for (int j = 0; j < C::TPW; j++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) park_t[(wave * C::TPW + j) * 256 + r * 64 + lane] = acc[j][r];
   dbg_stamp(DBG, gw, 28);
   __syncthreads();
   dbg_stamp(DBG, gw, 29);
-  if (E::ONE_PHASE) k3_sum_linear<W>(park_d, pout + C::NTP * 256, tid);
-  dbg_stamp(DBG, gw, 30);
-  // two consecutive elements per thread: one 16-byte store (write-through like the other bulk outputs -- an 8-byte write-through store
-  // costs 2.7x the time per byte of a 16-byte one, and this tail of 22 KB per workgroup is store-issue-bound)
-  const __amdgpu_buffer_rsrc_t rout = k3_rsrc(pout);
-  for (int el = 2 * tid; el < C::NTP * 256; el += 2 * K3_BLOCK) {
-    const int t = el >> 8, x = el & 255;
-    const int ts = t / C::TPW, j = t % C::TPW;
-    v2d sum = (v2d){0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < C::KSPLIT; k++) sum += *reinterpret_cast<const v2d*>(park_t + ((PAIR ? (ts * C::KSPLIT + k) : (k * C::TSPLIT + ts)) * C::TPW + j) * 256 + x);
-#if VXBA_WT_STORES
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, sum), rout, el * 8, 0, 16);   // aux 16 = sc1 on gfx950
-#else
-    *reinterpret_cast<v2d*>(pout + el) = sum;
-#endif
-  }
+  k3_sum_linear<W>(park_d, pout + C::NTILE, tid);
   dbg_stamp(DBG, gw, 6);
   if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 31); }   // ... and acknowledged
 }

@@ -6,10 +6,7 @@
 namespace vxk {
 
 constexpr int MAXW = 10;          // VXBA_MAX_WIN: 6W <= 64 accumulator columns
-#ifndef K3_BLOCK_V
-#define K3_BLOCK_V 512            // experiment knob (vxba_kernels.hip only): 256 = four waves per workgroup, two workgroups per CU
-#endif
-constexpr int K3_BLOCK = K3_BLOCK_V;   // 8 waves per workgroup, one workgroup per CU: two waves per SIMD
+constexpr int K3_BLOCK = 512;     // 8 waves per workgroup, one workgroup per CU: two waves per SIMD
 constexpr int DACC = 28;          // per-frame linear accumulators: g(6) Drr(6) Drt(9) Dtt(6) residual(1)
 
 // Poses travel as a kernel argument (W*96 B <= 960 B): uniform scalar loads in K2, one vector load per lane in K3.
@@ -85,13 +82,23 @@ struct LMPending {
   int nparts;
 };
 
-inline int k3_num_tiles(int W) { return (6 * W + 15) / 16; }
-// voxels per wave-batch of the Hessian sweep (must match K3Cfg<W>::NV)
-inline int k3_nv(int W) { const int nt = k3_num_tiles(W); const int cap = nt <= 2 ? 12 : (nt == 3 ? 8 : 6); return (64 / W) < cap ? (64 / W) : cap; }
-inline size_t k3_clb_len(int W, int VS) { return (size_t)((VS + k3_nv(W) - 1) / k3_nv(W)) * 640; }
-inline int k3_num_tile_pairs(int W) { int nt = k3_num_tiles(W); return nt * (nt + 1) / 2; }
-// doubles per workgroup partial: MFMA accumulator tiles (register layout) + per-frame linear accumulators
-inline size_t k3_partial_len(int W) { return (size_t)k3_num_tile_pairs(W) * 256 + (size_t)W * DACC; }
+// ---- geometry of the Hessian sweep (vxba_k3.hpp, K3Cfg<W>) shared with the host side ----------------------------------------
+// column groups of four (6W rounded up), pairs per wave (the 8 waves of a workgroup split the NG (NG + 1) / 2 group pairs)
+__host__ __device__ constexpr int k3_groups(int W) { return (6 * W + 3) / 4; }
+__host__ __device__ constexpr int k3_pairs_per_wave(int W) { return (k3_groups(W) * (k3_groups(W) + 1) / 2 + 7) / 8; }
+// row stride of the LDS tile in doubles: the smallest value >= 4 NG that is 4 (mod 8) -- conflict-free operand reads
+__host__ __device__ constexpr int k3_row_stride(int W) { int rs = 4 * k3_groups(W); while (rs % 8 != 4) rs++; return rs; }
+// voxels per wave-batch: even (a step's 24 NV rows are whole 16-row slabs), at most 64 / W lanes' worth and 12, and two tile buffers of
+// 8 batches within 140 KB of LDS (the poses, the parameter staging areas and the epilogue share the rest)
+__host__ __device__ constexpr int k3_nv(int W) {
+  int n = 64 / W < 12 ? 64 / W : 12;
+  n &= ~1;
+  while (n > 2 && (size_t)2 * 24 * n * k3_row_stride(W) * 8 > (size_t)140 * 1024) n -= 2;
+  return n;
+}
+__host__ __device__ constexpr size_t k3_clb_len(int W, int VS) { return (size_t)((VS + k3_nv(W) - 1) / k3_nv(W)) * 640; }
+// doubles per workgroup partial: [8 waves][pairs per wave rounded up to 4][16] sums of S + per-frame linear accumulators
+__host__ __device__ constexpr size_t k3_partial_len(int W) { return (size_t)8 * ((k3_pairs_per_wave(W) + 3) & ~3) * 16 + (size_t)W * DACC; }
 
 // K2: residual sweep over voxels [head,end): merge + covariance + eigen-decomposition, writes the cache,
 // block partials of sum coe*lambda_0 into d_partial[0..nblocks).  Returns the number of partials.

@@ -213,37 +213,34 @@ __device__ __forceinline__ int sym6_index(int a, int b) { return a == 0 ? b : (a
 // Where element e of a workgroup partial goes: a tile element -> Hessian entry (r, c) [+ a second stream off1: the block-diagonal D
 // element that lands on the same entry], a linear element -> output index lin (JacT / residual), or nothing.
 struct FinMap { int r, c, lin, off1; };
+// (I, J) of pair `pl` of wave `wv`: the tables of vxba_k3.hpp as device constants (fin_map indexes them at run time)
+template <int NG> __device__ const K3PairTab k3_pair_tab_d = k3_make_pairs(NG);
 template <int W>
 __device__ __forceinline__ FinMap fin_map(int e) {
   using C = K3Cfg<W>;
   constexpr int n = 6 * W;
-  constexpr int NTILE = C::NTP * 256;
-  constexpr int PLEN = NTILE + W * DACC;
+  constexpr int NTILE = C::NTILE;
+  constexpr int PLEN = C::PLEN;
   FinMap m;
   m.r = -1; m.c = -1; m.lin = -1; m.off1 = -1;
   if (e < NTILE) {
-    const int t = e >> 8, j = (e >> 6) & 3, l = e & 63;
-    // tile t accumulates S[16 rowtile + row][16 coltile + col] (vxba_k3.hpp: K3Cfg::rowtile / coltile; tiles of the second set
-    // may be LOWER tiles); f64 MFMA C/D map: row = lane/16 + 4*reg, col = lane%16
-    const int rt = C::rowtile(t), ct = C::coltile(t);
-    int r = 16 * rt + (l >> 4) + 4 * j;
-    int c = 16 * ct + (l & 15);
-    if (rt > ct) { const int tmp = r; r = c; c = tmp; }  // lower tile: the same numbers, mirrored
-    if (r >= n || c >= n || r > c) { r = -1; c = -1; }   // padding columns; lower half of a diagonal tile is a duplicate
-    else if (r / 6 == c / 6) {
-      const int i = r / 6, a = r % 6, b = c % 6;         // a <= b
-      if (C::SPARE && b >= 3) {
-        // Drt / Dtt were accumulated by the matrix cores: S[r][6W + (b - 3)] (vxba_k3.hpp, K3Cfg::SPARE)
-        m.off1 = C::elem_offset(r, n + (b - 3));
-      } else {
+    // S block (I, J) of a wave's pair pl, element (i, j): [wave][pair][4 i + j] (vxba_k3.hpp, epilogue)
+    const int wv = e / (16 * C::PPWP), pl = (e >> 4) % C::PPWP, i = (e >> 2) & 3, j = e & 3;
+    if (pl < C::npair(wv)) {
+      const K3PairTab& T = k3_pair_tab_d<C::NG>;
+      const int I = T.I[wv][pl], J = T.J[wv][pl];
+      int r = 4 * I + i, c = 4 * J + j;
+      if (r >= n || c >= n || r > c) { r = -1; c = -1; }   // padding columns (odd W); the lower half of a diagonal block is a duplicate
+      else if (r / 6 == c / 6) {
+        const int fr = r / 6, a = r % 6, bb = c % 6;       // a <= bb: the block-diagonal term that lands on the same entry
         int d;
-        if (b < 3) d = 6 + sym6_index(a, b);
-        else if (a < 3) d = 12 + 3 * a + (b - 3);
-        else d = 21 + sym6_index(a - 3, b - 3);
-        m.off1 = NTILE + i * DACC + d;
+        if (bb < 3) d = 6 + sym6_index(a, bb);
+        else if (a < 3) d = 12 + 3 * a + (bb - 3);
+        else d = 21 + sym6_index(a - 3, bb - 3);
+        m.off1 = NTILE + fr * DACC + d;
       }
+      m.r = r; m.c = c;
     }
-    m.r = r; m.c = c;
   } else if (e < PLEN) {
     const int q = e - NTILE, i = q / DACC, d = q % DACC;
     if (d < 6) m.lin = n * n + 6 * i + d;
@@ -299,8 +296,7 @@ __global__ __launch_bounds__(FIN_EL * FIN_SL) void k3_finalize_kernel(const doub
   int f_calc = gate ? (&gate->ctl[cb].calc_hess)[zoff] : 1;
   const int f_iter = gate ? (&gate->ctl[cb].iter)[zoff] : 1;
   constexpr int n = 6 * W;
-  constexpr int NTILE = C::NTP * 256;
-  constexpr int PLEN = NTILE + W * DACC;
+  constexpr int PLEN = C::PLEN;
   // FIN_EL elements x FIN_SL slices of the workgroup partials per block: many small blocks, because one CU cannot pull
   // more than ~10 B/clk from L2/HBM -- 64 elements per block (45 blocks) left the reduction bound by 45 CUs' load paths
   __shared__ double red0[FIN_SL][FIN_EL];
@@ -389,7 +385,7 @@ template <int W>
 __device__ __forceinline__ void fin_phase(const double* __restrict__ partial, int nblocks, LMState* __restrict__ st, int cb, int write_state, double* __restrict__ packed,
                                           int wg, int nwg, double* lds) {
   using C = K3Cfg<W>;
-  constexpr int PLEN = C::NTP * 256 + W * DACC;
+  constexpr int PLEN = C::PLEN;
   const int el = threadIdx.x % FINP_EL, slice = threadIdx.x / FINP_EL;
   double* red0 = lds;
   double* red1 = lds + FINP_EL * FINP_SL;
@@ -1207,16 +1203,14 @@ void launch_seed_aux(const FactorView& fv, int head, int end, hipStream_t s) {
   hipLaunchKernelGGL(seed_aux_kernel, dim3((end - head + 255) / 256), dim3(256), 0, s, fv, head, end);
 }
 
-int k3_grid_blocks(int device_cus) { return device_cus * (512 / K3_BLOCK); }  // one 8-wave workgroup per CU = two waves per SIMD
+int k3_grid_blocks(int device_cus) { return device_cus; }  // one 8-wave workgroup per CU = two waves per SIMD
 
-// dynamic LDS of the Hessian sweep: two tile buffers + the poses, or the epilogue's parking areas, whichever is larger
+// dynamic LDS of the Hessian sweep: two tile buffers + the poses, or the epilogue's parking area, whichever is larger
 template <int W>
 constexpr size_t k3_lds_bytes() {
   using C = K3Cfg<W>;
-  constexpr size_t main_d = (size_t)2 * C::BUF + 24 * W + 8 + (size_t)C::WAVES * K3Stage<W>::WAVE_DOUBLES + 32;   // tiles | poses (+ pair flags) | LM decision inputs | parameter staging | dump for the idle lanes' rows
-  // epilogue: parked linear accumulators, then (or, when both fit, beside them) the parked MFMA accumulators
-  constexpr size_t epi1 = (size_t)K3_BLOCK * K3Epi<W>::DS, epi2 = (size_t)C::WAVES * C::TPW * 256;
-  constexpr size_t epi = K3Epi<W>::ONE_PHASE ? epi1 + epi2 : (epi1 > epi2 ? epi1 : epi2);
+  constexpr size_t main_d = (size_t)2 * C::BUF + 24 * W + 8 + (size_t)C::WAVES * K3Stage<W>::WAVE_DOUBLES + 32;   // tiles | poses | LM decision inputs | parameter staging | dump for the idle lanes' rows
+  constexpr size_t epi = (size_t)K3_BLOCK * K3_DS;   // parked linear accumulators
   constexpr size_t m = main_d > epi ? main_d : epi;
   return m * sizeof(double);
 }
