@@ -60,3 +60,40 @@ def test_hierarchical_ba_sharded_over_process_ranks(world, K, wd, mg):
         assert m.group(3) == "True" and m.group(7) == "True", ln
         assert m.group(5) == m.group(6), ln                      # the shards partition the factor set of every round
         assert (m.group(8), m.group(9)) == (m.group(10), m.group(11)), ln
+
+
+def _bench_line(extra, timeout=900):
+    """`python bench.py --gpus 2 ...` exactly as the driver would type it (no launcher: the script starts its own ranks), both ranks on device 0
+    over gloo (the development switches of bench.py: RCCL refuses two ranks on one device)."""
+    import json
+    env = dict(os.environ, VXBA_BENCH_DEVICE="0", VXBA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_its_own_ranks_and_reports_both_scalings_and_carriers():
+    d = _bench_line(["--steps", "20", "--warmup", "5", "--repeats", "3", "--prewarm-seconds", "0.05"])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0
+    assert d["config"]["ranks_seen"] == 2
+    assert d["scaling"] == "strong" and abs(d["value"] - d["window_iterations_per_s"]) < 1e-9 * d["value"]
+    assert abs(d["config"]["collectives_per_lm_step"] - 1) < 0.1      # one per LM iteration (+ the one that opens a call)
+    # both scalings measured in the one job; the mailbox carrier ran on both, RCCL is reported as not available over gloo
+    for scal, vox in (("strong", 25000), ("weak", 50000)):
+        peer = d["carriers"][scal]["peer"]
+        assert peer["available"] and peer["ranks_seen"] == 2 and peer["voxels_per_gpu"] == vox and peer["allreduce_us_avg"] > 0, peer
+        assert peer["lm_steps_accepted"] == 20 and abs(peer["collectives_per_lm_step"] - 1) < 0.1
+        assert d["carriers"][scal]["rccl"]["available"] is False
+    w = d["weak_scaling"]
+    assert abs(w["value"] - 2 * w["window_iterations_per_s"]) < 1e-9 * w["value"]
+    # the two shards of the strong leg ARE the cfg2 window: same final residual as the weak leg's 2x larger window would not give
+    assert d["carriers"]["strong"]["peer"]["final_residual"] != d["carriers"]["weak"]["peer"]["final_residual"]
+
+
+def test_bench_cfg5_gpus_2_starts_its_own_ranks():
+    d = _bench_line(["--config", "cfg5", "--keyframes", "105", "--keyframe-points", "5000", "--steps", "1", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert "round-robin over ranks" in d["config"]["parallelism"]

@@ -3,6 +3,12 @@
 #include "vxba_factor.hpp"
 
 #include <atomic>
+#if defined(__x86_64__) || defined(__i386__)
+#include <immintrin.h>
+static inline void vx_store_fence() { _mm_sfence(); }
+#else
+static inline void vx_store_fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+#endif
 #include <limits>
 
 using namespace vxc;
@@ -271,9 +277,15 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
     // back to the mapped host buffer where the allocation is refused.  VXBA_LI_REC_VRAM=0: the round-3 path (A/B).
     const char* ev = getenv("VXBA_LI_REC_VRAM");
     if (!(ev && ev[0] == '0')) {
+      // Only where the CPU can actually store into device memory: without a large BAR the allocation SUCCEEDS and the first host store
+      // into it faults (round-4 advisor) -- ask the device first; any doubt keeps the mapped host buffer.
+      int dev = 0, large_bar = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) { large_bar = 0; (void)hipGetLastError(); }
       void* p = nullptr;
-      if (hipExtMallocWithFlags(&p, sizeof(double) * vxk::li_rec_doubles(VXBA_MAX_WIN), hipDeviceMallocFinegrained) == hipSuccess) f->lirec_vram = (double*)p;
-      else (void)hipGetLastError();
+      if (large_bar) {
+        if (hipExtMallocWithFlags(&p, sizeof(double) * vxk::li_rec_doubles(VXBA_MAX_WIN), hipDeviceMallocFinegrained) == hipSuccess) f->lirec_vram = (double*)p;
+        else (void)hipGetLastError();
+      }
     }
     VX_HIP(f, hipHostMalloc((void**)&f->h_liout, sizeof(double) * vxk::li_out_doubles(VXBA_MAX_WIN), hipHostMallocMapped | hipHostMallocCoherent));
     VX_HIP(f, hipHostGetDevicePointer((void**)&f->zc_liout, f->h_liout, 0));
@@ -477,7 +489,13 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
               E[(size_t)(6 + p) * m6 + 6 + q] = v2;
             }
           }
-          if (f->lirec_vram) std::memcpy(f->lirec_vram, rec, sizeof(double) * vxk::li_rec_doubles(W));   // posted writes: in front of the launch's doorbell on the same path
+          if (f->lirec_vram) {
+            // posted write-combining stores through the BAR; the store fence drains the write-combining buffers BEFORE the launch's doorbell is
+            // rung (a C++ release fence emits no instruction on x86 and does not order WC stores: the record could otherwise still sit in a
+            // buffer when the solve reads it -- round-4 advisor)
+            std::memcpy(f->lirec_vram, rec, sizeof(double) * vxk::li_rec_doubles(W));
+            vx_store_fence();
+          }
           std::atomic_thread_fence(std::memory_order_release);
           if (with_spec) { nan_fill_buf(hpk[cur ^ 1]); next_sentinel = true; }   // nothing can be writing that buffer: its last system was consumed an iteration ago
         }

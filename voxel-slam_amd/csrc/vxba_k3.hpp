@@ -474,7 +474,10 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
   // do, an accepted one means it linearises at the trial poses -- so every workgroup starts phase A of its first step at the trial
   // poses as soon as those are in LDS, wave 0 adds up residual2 behind the barrier, and the decision is taken behind the first step's
   // barrier (a rejected step costs one phase A instead of none; the common, accepted one no longer waits for the sum).
-  constexpr int K3_FIRST_WAVES = C::WAVES / 2;
+#ifndef K3_FIRST_WAVES_V
+#define K3_FIRST_WAVES_V (C::WAVES / 2)
+#endif
+  constexpr int K3_FIRST_WAVES = K3_FIRST_WAVES_V;
   if (wave != 0 && wave < K3_FIRST_WAVES && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
 
   // LDS behind the two tile buffers: the poses (raw C-ABI layout: R column-major | p per frame) and what the LM decision needs
@@ -662,31 +665,47 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
   // (1) per-frame linear accumulators: every lane parks them, then (behind the barrier) one thread per (frame, slot) sums the 8 NV lanes
 #pragma unroll
   for (int k = 0; k < DACC; k++) park_d[(wave * 64 + lane) * K3_DS + k] = dacc[k];
-  // (2) the wave's own pairs: fold the four blocks (lanes 16 i + 4 t + j, t = 0..3: two exchanges; every lane of a quadruple ends up
-  // with the same sum bit for bit -- a + b == b + a), then lane (i, t, j) stores pair 4 m + t: one 512-byte run per instruction
+  // (2) the wave's own pairs.  Fold the four blocks (lanes 16 i + 4 t + j, t = 0..3 -- inside a 16-lane row: two DPP row rotations, no LDS
+  // traffic; every lane of a quadruple ends up with the same sum bit for bit: (a + c) + (d + b) and (b + d) + (a + c) add the same two
+  // partial sums), then lane (i, t, j) hands pair 4 m + t to a wave-private staging area -- four full-wave 8-byte LDS stores -- from which
+  // the 16 PPW sums leave as 16-byte written-through stores (an 8-byte written-through store costs 2.7x the time per byte).
   {
     const int t4 = (lane >> 2) & 3;
     const int np = C::npair(wave);
-    const __amdgpu_buffer_rsrc_t rout = k3_rsrc(pout);
+    auto ror = [](double v, auto ctrl) __attribute__((always_inline)) -> double {
+      const v2i x = __builtin_bit_cast(v2i, v);
+      v2i y;
+      y[0] = __builtin_amdgcn_update_dpp(0, x[0], decltype(ctrl)::value, 0xf, 0xf, false);
+      y[1] = __builtin_amdgcn_update_dpp(0, x[1], decltype(ctrl)::value, 0xf, 0xf, false);
+      return __builtin_bit_cast(double, y);
+    };
 #pragma unroll
     for (int j = 0; j < C::PPW; j++) {
       double v = acc[j];
-      v += __shfl_xor(v, 4);
-      v += __shfl_xor(v, 8);
+      v += ror(v, std::integral_constant<int, 0x128>{});   // row_ror:8 -- blocks t and t + 2
+      v += ror(v, std::integral_constant<int, 0x124>{});   // row_ror:4 -- ... and the other two
       acc[j] = v;
     }
+    double* stage = lds + (size_t)K3_BLOCK * K3_DS + wave * (C::PPWP * 16);   // behind the parked linear accumulators
 #pragma unroll
     for (int m = 0; m < C::PPWP / 4; m++) {
       double v = 0.0;
 #pragma unroll
       for (int t = 0; t < 4; t++)
         if (4 * m + t < C::PPW) v = (t4 == t) ? acc[4 * m + t] : v;
-      const int off = (wave * C::PPWP + 4 * m + t4) * 16 + 4 * (lane >> 4) + (lane & 3);
-      if (4 * m + t4 < np) {
+      stage[(4 * m + t4) * 16 + 4 * (lane >> 4) + (lane & 3)] = v;
+    }
+    __builtin_amdgcn_wave_barrier();   // same wave, LDS operations execute in order
+    const __amdgpu_buffer_rsrc_t rout = k3_rsrc(pout + wave * (C::PPWP * 16));
+#pragma unroll
+    for (int r = 0; r < (C::PPWP * 8 + 63) / 64; r++) {
+      const int el2 = 64 * r + lane;                     // pair of doubles el2 of the wave's PPWP * 16
+      if (el2 < np * 8) {
+        const v2d v = *reinterpret_cast<const v2d*>(stage + 2 * el2);
 #if VXBA_WT_STORES
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), rout, off * 8, 0, 16);   // aux 16 = sc1 on gfx950
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), rout, el2 * 16, 0, 16);   // aux 16 = sc1 on gfx950
 #else
-        pout[off] = v;
+        *reinterpret_cast<v2d*>(pout + wave * (C::PPWP * 16) + 2 * el2) = v;
 #endif
       }
     }

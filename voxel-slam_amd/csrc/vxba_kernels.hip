@@ -610,6 +610,9 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __rest
       }
       __syncthreads();
       if (k2_gave_up || spare) return;
+      // (Round 5, measured and rejected: pulling the FIRST STEP of the Hessian sweep that follows into the XCD-local L2 from here -- one dword
+      // per 128-byte line of the 40 KB every sweep workgroup asks for first, by the workgroups of this launch that run on the same XCD.  Same
+      // box: the sweep 23.6 -> 23.7 us, this launch 21.5 -> 22.7: the sweep's fill does not wait for those lines, gpurun_out r5_s3.)
     } else if (st) {
       const volatile double* xt = st->ctl[c].xt;
       if (lane < 12 * W) pose_lds[lane] = xt[lane];
@@ -1210,7 +1213,7 @@ template <int W>
 constexpr size_t k3_lds_bytes() {
   using C = K3Cfg<W>;
   constexpr size_t main_d = (size_t)2 * C::BUF + 24 * W + 8 + (size_t)C::WAVES * K3Stage<W>::WAVE_DOUBLES + 32;   // tiles | poses | LM decision inputs | parameter staging | dump for the idle lanes' rows
-  constexpr size_t epi = (size_t)K3_BLOCK * K3_DS;   // parked linear accumulators
+  constexpr size_t epi = (size_t)K3_BLOCK * K3_DS + (size_t)C::WAVES * C::PPWP * 16;   // parked linear accumulators | the waves' folded pair sums on their way out
   constexpr size_t m = main_d > epi ? main_d : epi;
   return m * sizeof(double);
 }

@@ -258,8 +258,9 @@ def hierarchical_ba_sharded(clouds, poses, coarse, fine, wdsize: int = 10, mgsiz
     own = ctx is None
     ctx = {} if ctx is None else ctx
     if bottom_refine is None:
-        bottom = ctx.get(("bottom", wdsize)) or vxba.LidarFactor(wdsize, device=device)
-        ctx[("bottom", wdsize)] = bottom
+        bottom = ctx.get(("bottom", wdsize))     # `is None`, not truthiness: LidarFactor.__len__ is its voxel count, an empty cached factor is falsy
+        if bottom is None:
+            bottom = ctx[("bottom", wdsize)] = vxba.LidarFactor(wdsize, device=device)
 
         def bottom_refine(xyz, fp, xs):
             return hba.window_refine(xyz, fp, xs, coarse, fine, max_iter=1, device=device, factor=bottom)
@@ -284,11 +285,16 @@ def hierarchical_ba_sharded(clouds, poses, coarse, fine, wdsize: int = 10, mgsiz
     top_xyz = np.ascontiguousarray(np.concatenate(sub_clouds).astype(np.float64))
     top_fp = np.concatenate([[0], np.cumsum([len(c) for c in sub_clouds])]).astype(np.int64)
     sub_ids = bases
+    # A SHORT session's top level is a narrow window (S <= VXBA_MAX_WIN): the device-resident narrow loop refuses an empty factor and skips the
+    # collective with it, so a rank whose hashed shard came out empty would fail while the others wait in the all-reduce (round-4 advisor).
+    # There is nothing to gain from sharding ten submap poses anyway: every rank runs that top level whole -- same inputs, same arithmetic,
+    # same poses on all ranks, no collective.
+    shard_top = world > 1 and S > vxba.MAX_WIN
     if top_refine is None:
         topf = ctx.get(("top", S))
         if topf is None:
             topf = ctx[("top", S)] = vxba.LidarFactor(S, device=device)
-        if world > 1 and ("keep", S) not in ctx:
+        if shard_top and ("keep", S) not in ctx:
             keep = None
             try:
                 attach_rccl(topf, group) if dist.get_backend(group) == "nccl" else None
@@ -306,7 +312,7 @@ def hierarchical_ba_sharded(clouds, poses, coarse, fine, wdsize: int = 10, mgsiz
 
         def top_refine(xyz, fp, xs, si, sc):
             return hba.window_refine(xyz, fp, xs, coarse.sharded(si, sc), fine.sharded(si, sc), max_iter=top_max_iter, device=device, factor=topf)
-    top = top_refine(top_xyz, top_fp, poses[sub_ids], rank, world)
+    top = top_refine(top_xyz, top_fp, poses[sub_ids], rank if shard_top else 0, world if shard_top else 1)
     if own:
         hba_ctx_close(ctx)
     edges2 = [dict(e, i=sub_ids[e["i"]], j=sub_ids[e["j"]]) for e in hba.edges_from_hessian(top["poses"], top["hess"])]
