@@ -1,0 +1,25 @@
+#!/bin/bash
+# round 5, session 6: leftover voxels on the idle lanes instead of a ragged step -- parity, then same-box A/B against the build before it
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/r5_s6
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_fuzz.py tests/test_gpu_edges.py -m gpu -q --timeout 600 -p no:cacheprovider 2>&1 | tail -12
+line() { python -c "
+import sys, json
+for l in sys.stdin:
+    try: d = json.loads(l)
+    except Exception: continue
+    r = d['roofline']
+    print('$1 it/s %.0f  us/step %.2f  k3 %.2f us (%.3f)  k2 %.2f us  k3fin %.2f us  solve+k2 %.2f us acc %s' % (d['value'], 1e3*d['ms_per_step'], r['avg_launch_ms']*1e3, r['frac'], r['k2_residual']['avg_launch_ms']*1e3, r['k3_finalize_avg_ms']*1e3, 1e3*r.get('solve_plus_k2_launch_avg_ms', 0), d['config']['lm_steps_accepted']))
+"; }
+for r in 1 2; do
+  for v in base cur; do
+    VXBA_LIB=$PWD/gpurun_ab/libvxba_$v.so timeout 300 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-li-ba --no-cold-l3 2>/dev/null | line $v
+  done
+  timeout 300 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-li-ba --no-cold-l3 2>/dev/null | line extras
+done 2>&1 | tee gpurun_out/r5_s6/ab_extras.txt
+for cfg in cfg3 cfg4 cfg1; do
+  VXBA_LIB=$PWD/gpurun_ab/libvxba_cur.so timeout 300 python bench.py --config $cfg --steps 200 --warmup 20 --no-cpu-baseline --no-li-ba --no-cold-l3 2>/dev/null | line cur_$cfg
+  timeout 300 python bench.py --config $cfg --steps 200 --warmup 20 --no-cpu-baseline --no-li-ba --no-cold-l3 2>/dev/null | line extras_$cfg
+done 2>&1 | tee -a gpurun_out/r5_s6/ab_extras.txt
+timeout 300 python scripts/dbg_timeline.py k3lm > gpurun_out/r5_s6/timeline_k3lm.txt 2>&1; grep -E "barrier|epilogue|loop left|^end|step [123]|prologue" gpurun_out/r5_s6/timeline_k3lm.txt

@@ -417,9 +417,7 @@ __device__ __forceinline__ void k3_sum_linear(const double* park_d, double* out,
 // so that those requests do not wait for a scalar load of the argument block first (a cold miss: the block was written by the host a few
 // microseconds earlier).  Structs are not preloaded and stop the sequence, hence the flat list; what is not urgent follows as before.
 //   pend_flags = pending | restart << 8, nwg = nwg (otherwise a load from the hidden arguments)
-#ifndef K3_LATE_PER
-#define K3_LATE_PER 4      // requests behind each slab of phase M: all eight behind the first two of the nine slabs at W = 10 (1 and 2 per K-step measured slower in round 4: later requests land later)
-#endif
+constexpr int K3_LATE_PER = 4;   // requests behind each slab of phase M: all eight behind the first two of the nine slabs at W = 10 (1 and 2 per K-step measured slower in round 4: later requests land later)
 template <int W, bool DBG = false, bool MIXED = false>
 __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k3_hessian_kernel(const double* __restrict__ clb, const double* __restrict__ cache_planes, const double* __restrict__ coe_plane,
                                                               LMState* __restrict__ st, int VS, int head, int end, int c_in, int pend_flags, int nwg,
@@ -474,10 +472,7 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
   // do, an accepted one means it linearises at the trial poses -- so every workgroup starts phase A of its first step at the trial
   // poses as soon as those are in LDS, wave 0 adds up residual2 behind the barrier, and the decision is taken behind the first step's
   // barrier (a rejected step costs one phase A instead of none; the common, accepted one no longer waits for the sum).
-#ifndef K3_FIRST_WAVES_V
-#define K3_FIRST_WAVES_V (C::WAVES / 2)
-#endif
-  constexpr int K3_FIRST_WAVES = K3_FIRST_WAVES_V;
+  constexpr int K3_FIRST_WAVES = C::WAVES / 2;   // (round 5, rebuilt sweep, same box: 2 / 6 / 8 waves in front of the barrier are within noise of 4 -- gpurun_out/r5_s5)
   if (wave != 0 && wave < K3_FIRST_WAVES && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
 
   // LDS behind the two tile buffers: the poses (raw C-ABI layout: R column-major | p per frame) and what the LM decision needs
