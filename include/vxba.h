@@ -490,7 +490,37 @@ int vxba_plane_update(int device, int64_t n, const double* clusters, const doubl
  * (x, y, z) voxel index (upstream: unordered_map iteration order).  voxel_size < 0.001 copies the cloud through, like upstream. */
 int vxba_down_sampling_voxel(int device, int64_t n, const float* xyz, double voxel_size, float* out_xyz, int64_t* n_out);
 
+/* ---- hierarchical global BA: one bottom-up pass over a session of keyframes (BASELINE configs[4]) ----------------------------
+ * thd_globalmapping's loop (voxelslam.cpp:2485-2595): windows of `wdsize` keyframes with stride `mgsize`, each refined by one round of
+ * HBA_add_edge (:2320-2482 -- OctreeGBA::cut_voxel + OctreeGBA_multi_recut, Lidar_BA_Optimizer::damping_iter with 4 iterations, Hessian ->
+ * pose-graph edge weights :2405-2427) and merged into a voxel-filtered submap anchored at its first keyframe (:2430-2450); then ONE
+ * HBA_add_edge over all S = (K - wdsize) / mgsize + 1 submap poses (S <= VXBA_MAX_WIN_WIDE) with up to `top_max_iter` re-voxelisation
+ * rounds.  The keyframe clouds live in device memory from vxba_hba_add_keyframes on; a pass moves only poses, Hessians and counts
+ * across PCIe.  What consumes the edges (GTSAM's ISAM2 in the reference, :2231-2317) is outside this library. */
+typedef struct vxba_hba vxba_hba;
+int vxba_hba_create(int device, vxba_hba** out);
+int vxba_hba_destroy(vxba_hba* h);
+const char* vxba_hba_last_error(const vxba_hba* h);
+/* Appends n_keyframes clouds (PointType xyz as float, keyframe coordinates): cloud_ptr n_keyframes + 1 offsets in points (cloud_ptr[0] = 0). */
+int vxba_hba_add_keyframes(vxba_hba* h, int64_t n_keyframes, const int64_t* cloud_ptr, const float* xyz);
+int vxba_hba_num_keyframes(const vxba_hba* h);
+int vxba_hba_clear(vxba_hba* h); /* forget the keyframes (the device buffers are kept) */
+/* poses: K x 12 ([R column-major 9 | p 3], as everywhere).  n_threads: 1 or 2 host threads / streams for the bottom level (windows alternate).
+ * Out: submap_poses S x 12 (refined anchors), submap_sizes S (points per voxel-filtered submap; may be NULL); the edges of both levels in
+ * order -- bottom level window by window, then the top level: edge_ij 2 ints (keyframe indices i < j), edge_data 18 doubles [R_i^T R_j
+ * row-major 9 | R_i^T (p_j - p_i) 3 | v6 = 1 / |hess(6i+k, 6j+k)| 6] per edge, at most edge_capacity of them (the counts are exact even
+ * when the arrays were too small or NULL: VXBA_ERR_ARG then); top_rounds 5 doubles per top-level round [factor voxels, residual before,
+ * after, is_converge, fine parameters used] (top_max_iter x 5, may be NULL). */
+int vxba_hba_pass(vxba_hba* h, const double* poses, const vxba_voxelize_params* coarse, const vxba_voxelize_params* fine, int wdsize, int mgsize,
+                  int top_max_iter, int n_threads, double* submap_poses, int64_t* submap_sizes, int64_t edge_capacity, int32_t* edge_ij, double* edge_data,
+                  int64_t* n_edges1, int64_t* n_edges2, double* top_rounds, int* n_top_rounds);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
+/* The cluster-build kernel inside the voxeliser (vxba_voxelize_push*, vxba_hba_pass) -- the dominant kernel of a hierarchical-BA pass.
+ * enable != 0: start a fresh measurement (every launch bracketed by events bound to its dispatch, one stream synchronisation per layer:
+ * not for timed runs); enable == 0: stop and return the sums -- duration [ms], launches, algorithmic bytes (24 B per point + 8 B per
+ * cell offset read, 80 B per cluster written). */
+int vxba_voxelize_profile(int enable, double* ms_sum, long long* launches, double* algorithmic_bytes);
 /* Bit mask of kernels to bracket with hipEvents on the launch stream: 1 = Hessian sweep (K3), 2 = residual sweep (K2),
  * 4 = K3 cross-block reduction, 8 = cluster build (K1), 16 = the all-reduce of a sharded factor; 0 = off. */
 int vxba_set_profiling(vxba_factor* f, int mask);

@@ -745,4 +745,38 @@ void vxo_localmap_match(void* m, int64_t n, const double* wld, const double* var
   }
 }
 
+#ifdef VXREF_LIO_INC
 }  // extern "C"
+// ---- odometry: VOXEL_SLAM::lio_state_estimation (voxelslam.cpp:856-958), the reference's own text ----------------------------------
+// The member function is extracted at build time (oracle/Makefile: _ref/extracted/lio_state_estimation.inc) and compiled inside this harness,
+// which supplies the two members it touches: the state x_curr and the voxel map surf_map (a reference to the local map's).
+namespace {
+struct RefLioHarness {
+  IMUST x_curr;
+  unordered_map<VOXEL_LOC, OctoTree*>& surf_map;
+  explicit RefLioHarness(unordered_map<VOXEL_LOC, OctoTree*>& m) : surf_map(m) {}
+#include "lio_state_estimation.inc"
+};
+}  // namespace
+extern "C" {
+// state: [R 9 col-major | p 3 | v 3 | bg 3 | ba 3 | g 3] in / out, cov 15 x 15 column-major in / out; points and their body-frame covariances
+// (pointVar, voxel_map.hpp:14-19).  Returns the function's verdict (the degeneracy test :950-957).
+int vxo_ref_lio_state_estimation(void* m, double* state, double* cov, int64_t n, const double* pnt, const double* var9) {
+  RefLocalMap* lm = (RefLocalMap*)m;
+  lm->bind();
+  RefLioHarness h(lm->surf_map);
+  h.x_curr.R = unpack_m3(state);
+  h.x_curr.p = unpack_v3(state + 9); h.x_curr.v = unpack_v3(state + 12); h.x_curr.bg = unpack_v3(state + 15); h.x_curr.ba = unpack_v3(state + 18);
+  h.x_curr.g = unpack_v3(state + 21);
+  for (int c = 0; c < DIM; c++) for (int r = 0; r < DIM; r++) h.x_curr.cov(r, c) = cov[(size_t)c * DIM + r];
+  PVecPtr pptr(new PVec((size_t)n));
+  for (int64_t i = 0; i < n; i++) { (*pptr)[i].pnt = unpack_v3(pnt + 3 * i); (*pptr)[i].var = unpack_m3(var9 + 9 * i); }
+  const bool ok = h.lio_state_estimation(pptr);
+  pack_state(h.x_curr, state);
+  for (int c = 0; c < DIM; c++) for (int r = 0; r < DIM; r++) cov[(size_t)c * DIM + r] = h.x_curr.cov(r, c);
+  return ok ? 1 : 0;
+}
+}  // extern "C"
+#else
+}  // extern "C"
+#endif

@@ -1,4 +1,7 @@
-// TEST INFRASTRUCTURE ONLY (see vxo_linalg.hpp header).  PARITY UNPINNED.
+// TEST INFRASTRUCTURE ONLY (see vxo_linalg.hpp header).  PINNED against the reference's own code compiled here (oracle/_ref/libref.so, `make -C oracle ref`: tests/test_ref_pin.py):
+// PointCluster, LidarFactor (acc_evaluate2, evaluate_only_residual) and Lidar_BA_Optimizer::damping_iter incl. rejected steps -- through the
+// unmodified voxel_map.hpp / tools.hpp.  Eigen is absent: SelfAdjointEigenSolver / LDLT inside libref are this directory's restatements
+// (shim/Eigen), so for those three algorithms the pin is circular (vxo_linalg.hpp header).
 //
 // CPU restatement of the reference's LiDAR BA factor and LM optimizer:
 //   PointCluster                 <- VoxelSLAM/src/tools.hpp:304-365

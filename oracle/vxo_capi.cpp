@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY (see vxo_linalg.hpp header).  PARITY UNPINNED.
+// TEST INFRASTRUCTURE ONLY (see vxo_linalg.hpp header).  What is and is not pinned to the reference's own code: the headers of the vxo_*.hpp files.
 //
 // extern "C" surface of the CPU oracle so tests/ and bench.py's cpu_baseline leg
 // can drive it through ctypes.  Packed formats are the same as include/vxba.h:

@@ -1,4 +1,6 @@
-// TEST INFRASTRUCTURE ONLY (see vxo_linalg.hpp header).  PARITY UNPINNED.
+// TEST INFRASTRUCTURE ONLY (see vxo_linalg.hpp header).  PINNED against the reference's own code compiled here (oracle/_ref/libref.so, `make -C oracle ref`: tests/test_ref_pin.py):
+// IMU_PRE (add_imu, give_evaluate[_g], update_state), jr / jr_inv, LI_BA_Optimizer and its gravity variant through the unmodified
+// preintegration.hpp / voxel_map.hpp.  Matrix<15,15>::inverse() inside libref is this file's restatement (Eigen is absent): circular for that one.
 //
 // CPU restatement of the inertial half of the local BA:
 //   * IMU preintegration factor  -- class IMU_PRE, preintegration.hpp:11-310

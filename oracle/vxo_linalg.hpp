@@ -3,11 +3,13 @@
 // (voxel-slam_amd/); only tests/, __graft_entry__.smoke() and bench.py's
 // cpu_baseline leg use it, as the checker / reported baseline.
 //
-// PARITY UNPINNED: the reference (hku-mars/Voxel-SLAM) ships no tests, golden
-// vectors or fixtures for this path, and cannot be compiled here (Eigen 3.3.7,
-// PCL, ROS are absent).  This restatement is pinned through
-// mathematics instead (finite-difference derivative checks, lambda_min of raw
-// points via numpy.linalg.eigh, the rank-3 structural identity) -- tests/test_oracle_*.py.
+// Parity status.  The reference (hku-mars/Voxel-SLAM) ships no tests, golden vectors or fixtures for this path, and its build (catkin, Eigen
+// 3.3.7, PCL, ROS) does not exist here.  What does: its hot-path HEADERS compile unmodified over an API shim (oracle/shim, `make -C oracle ref`
+// -> oracle/_ref/libref.so), and tests/test_ref_pin.py pins every restatement in this directory to them -- see the header of each vxo_*.hpp.
+// NOT pinned that way, because Eigen itself is absent and the shim forwards to THIS file: SelfAdjointEigenSolver<Matrix3d> (eig_sym3 below),
+// LDLT (ldlt_solve) and Matrix<15,15>::inverse() (vxo_imu.hpp).  Those three are pinned through mathematics (tests/test_oracle_*.py: residuals
+// of the decomposition, lambda_min of raw points via numpy.linalg.eigh, finite-difference derivative checks); every on-path use of an
+// eigenvector is quadratic in it and the solved step is algorithm-independent to round-off, nine orders below the 1e-4 contract.
 //
 // Small fixed-size linear algebra with no third-party dependency.  The reference's
 // arithmetic lives in Eigen 3.3.7 (README.md:26, VoxelSLAM/CMakeLists.txt:26), which

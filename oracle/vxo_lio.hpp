@@ -1,4 +1,8 @@
-// TEST INFRASTRUCTURE ONLY (see vxo_linalg.hpp header).  PARITY UNPINNED: the reference holds no golden vectors for this path.
+// TEST INFRASTRUCTURE ONLY (see vxo_linalg.hpp header).  PINNED against the reference's own code compiled here (oracle/_ref/libref.so, `make -C oracle ref`: tests/test_ref_pin.py):
+// `match` / OctoTree::match on the reference's own tree (test_plane_match_...) and, since round 5, the EKF loop itself: the TEXT of
+// VOXEL_SLAM::lio_state_estimation (voxelslam.cpp:856-958) is extracted at build time into oracle/_ref/extracted/ and compiled inside a
+// harness in libref.so (test_lio_state_estimation_restatement_matches_the_reference_text).  calcBodyVar / var_init / pvec_update
+// (voxelslam.hpp:163-215, ROS headers) remain pinned through mathematics only.
 //
 // CPU restatement of the odometry's point-to-plane update:
 //   calcBodyVar / var_init          VoxelSLAM/src/voxelslam.hpp:163-201

@@ -1,4 +1,6 @@
-// TEST INFRASTRUCTURE ONLY (see vxo_linalg.hpp header).  PARITY UNPINNED: the reference holds no golden vectors for this path.
+// TEST INFRASTRUCTURE ONLY (see vxo_linalg.hpp header).  PINNED against the reference's own code compiled here (oracle/_ref/libref.so, `make -C oracle ref`: tests/test_ref_pin.py):
+// the reference's OctoTree / SlideWindow / cut_voxel / recut / margi / tras_opt driven scan by scan beside this restatement
+// (test_local_map_evolves_like_the_reference_octree: the trees agree leaf for leaf).
 //
 // CPU restatement of the incremental side of the local map, i.e. what the local-mapping thread does to
 // `surf_map` / `surf_map_slide` scan by scan (voxelslam.cpp:1592-1700):

@@ -1,4 +1,5 @@
-// TEST INFRASTRUCTURE ONLY (see vxo_linalg.hpp header).  PARITY UNPINNED.
+// TEST INFRASTRUCTURE ONLY (see vxo_linalg.hpp header).  PINNED against the reference's own code compiled here (oracle/_ref/libref.so, `make -C oracle ref`: tests/test_ref_pin.py):
+// OctreeGBA::cut_voxel + OctreeGBA_multi_recut from the unmodified loop_refine.hpp (test_octree_gba_voxelisation_matches_the_reference).
 //
 // CPU restatement of the batch factor construction of the hierarchical / global BA:
 //   OctreeGBA::cut_voxel   loop_refine.hpp:446-476   world point -> root voxel (float quotient, "-1 if negative", truncation)

@@ -312,6 +312,62 @@ def test_plane_match_of_the_reference_agrees_with_the_oracle_odometry():
     assert np.allclose(sw["sigma_of_point"][both], sig[both], rtol=1e-6)
 
 
+def test_lio_state_estimation_restatement_matches_the_reference_text():
+    """VOXEL_SLAM::lio_state_estimation (voxelslam.cpp:856-958) lives in a ROS translation unit; its TEXT is extracted at build time
+    (oracle/Makefile: _ref/extracted/lio_state_estimation.inc, never committed) and compiled inside a harness in libref.so that supplies
+    x_curr and surf_map.  The restatement every GPU odometry test is checked against (oracle/vxo_lio.hpp) must reproduce it: same verdict,
+    same state after the iterated update, same posterior covariance -- on the reference's own tree (its `match`, its OctoTree) for the
+    reference and on the flattened plane map of the oracle's tree for the restatement."""
+    if not hasattr(R.lib(), "vxo_ref_lio_state_estimation"):
+        pytest.skip("libref.so was built without the extraction (no voxelslam.cpp at build time)")
+    from tests.test_gpu_local_mapping_cycle import lio_leaf_args
+    S, win, pts, seed = 5, 5, 15000, 23
+    xyz, fp, poses_gt, _ = synth.make_scans(win_size=S, pts_per_scan=pts, seed=synth.MASTER_SEED + 900 + seed)
+    var = point_vars(xyz.shape[0], seed)
+    mo, mr = O.LocalMapOracle(win_size=win, **PRM), R.LocalMapOracle(win_size=win, **PRM)
+    fo, fr = O.Oracle(win), R.Oracle(win)
+    xs = []
+    for k in range(S - 1):                                   # the map holds scans 0 .. S-2; the odometry aligns scan S-1 against it
+        xs.append(poses_gt[k].copy())
+        s = slice(fp[k], fp[k + 1])
+        for m, f in ((mo, fo), (mr, fr)):
+            f.clear()
+            m.cut_voxel(k, xyz[s], var[s], to_world(xs[-1], xyz[s]))
+            m.recut(k + 1, np.stack(xs), f)
+    for m, f in ((mo, fo), (mr, fr)):
+        f.evaluate_only_residual(np.stack(xs))
+        m.margi(S - 1, np.stack(xs), f)                      # plane_update: the records `match` reads
+    args = lio_leaf_args(mo.leaves())
+    assert args[0].shape[0] > 200
+    rng = np.random.default_rng(5)
+    s = slice(fp[S - 1], fp[S])
+    n = fp[S - 1 + 1] - fp[S - 1]
+    cov = np.diag(np.concatenate([np.full(3, 1e-4), np.full(3, 1e-3), np.full(3, 1e-2), np.full(3, 1e-6), np.full(3, 1e-4)]))
+    cov[0:3, 3:6] = cov[3:6, 0:3] = 2e-5 * np.eye(3)
+    checked = 0
+    for trial, (dr, dp) in enumerate(((0.003, 0.03), (0.001, 0.01), (0.02, 0.3))):      # the last start is far off: few matches, both must say so alike
+        pose = poses_gt[S - 1].copy()
+        pose[9:12] += rng.normal(0, dp, 3)
+        Rm = pose[:9].reshape(3, 3).T @ synth.rodrigues(rng.normal(0, dr, 3))
+        pose[:9] = Rm.T.reshape(9)
+        state = np.concatenate([pose, rng.normal(0, 0.1, 3), rng.normal(0, 1e-3, 3), rng.normal(0, 1e-2, 3), [0, 0, -9.8]])
+        oe = O.LioOracle(PRM["voxel_size"], PRM["max_layer"])
+        oe.map_update(*args)
+        oe.set_points(xyz[s], var[s])
+        got = oe.lio_state_estimation(state, cov)
+        st_r = state.copy(); cv_r = np.ascontiguousarray(cov.T.copy())
+        import ctypes as C
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        pnt_c = np.ascontiguousarray(xyz[s], dtype=np.float64); var_c = np.ascontiguousarray(np.transpose(var[s], (0, 2, 1)).reshape(n, 9), dtype=np.float64)
+        ok_r = R.lib().vxo_ref_lio_state_estimation(mr._h, vp(st_r), vp(cv_r), C.c_int64(n), vp(pnt_c), vp(var_c))
+        assert bool(ok_r) == got["ok"], trial
+        assert np.allclose(got["state"], st_r, rtol=0, atol=1e-9), (trial, np.abs(got["state"] - st_r).max())
+        assert np.allclose(got["cov"], cv_r.T, rtol=1e-7, atol=1e-13), trial
+        assert not np.allclose(st_r[:12], state[:12], atol=1e-6)       # the update moved the pose
+        checked += 1
+    assert checked == 3
+
+
 # ---- OctreeGBA batch factor construction (loop_refine.hpp:273-537) and the voxel-grid filter (tools.hpp:201-238) -------------------------
 def _content_order(v):
     """Canonical order of factor voxels by content (the reference's voxels carry no id): merged cluster N, then its sums."""

@@ -16,6 +16,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "../../include/vxba.h"
+#include "vxba_downsample.h"
 
 namespace vxd {
 
@@ -67,6 +68,73 @@ __global__ void ds_widen_kernel(const unsigned int* __restrict__ cnt, long long 
 
 }  // namespace vxd
 
+namespace vxd {
+
+int downsample_device(Scratch& sc, hipStream_t s, const float* d_in, int64_t n, double voxel_size, float* d_out, int64_t* n_out) {
+  *n_out = 0;
+  if (n == 0) return VXBA_OK;
+  if (n < 0 || n >= (1ll << 32)) return VXBA_ERR_ARG;
+  if (voxel_size < 0.001) {
+    if (hipMemcpyAsync(d_out, d_in, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return VXBA_ERR_HIP;
+    *n_out = n;
+    return VXBA_OK;
+  }
+  unsigned long long *d_key = nullptr, *d_key_s = nullptr, *d_ukey = nullptr;
+  unsigned int *d_idx = nullptr, *d_idx_s = nullptr, *d_cnt = nullptr, *d_runs = nullptr;
+  long long* d_ptr = nullptr;
+  int* d_err = nullptr;
+  void* d_temp = nullptr;
+  size_t t_sort = 0, t_rle = 0, t_scan = 0;
+  unsigned int runs = 0;
+  int err = 0;
+  const unsigned grid = (unsigned)((n + 255) / 256), grid1 = (unsigned)((n + 256) / 256);
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+#define DS(call) do { if ((call) != hipSuccess) return VXBA_ERR_HIP; } while (0)
+  DS(rocprim::radix_sort_pairs(nullptr, t_sort, d_key, d_key_s, d_idx, d_idx_s, (size_t)n, 0, 63, s));
+  DS(rocprim::run_length_encode(nullptr, t_rle, d_key_s, (size_t)n, d_ukey, d_cnt, d_runs, s));
+  DS(rocprim::exclusive_scan(nullptr, t_scan, d_ptr, d_ptr, 0ll, (size_t)n + 1, rocprim::plus<long long>(), s));
+  size_t t = t_sort > t_rle ? t_sort : t_rle;
+  if (t_scan > t) t = t_scan;
+  if (!t) t = 8;
+  {
+    const size_t b_k = up((size_t)n * 8), b_i = up((size_t)n * 4), b_p = up((size_t)(n + 1) * 8), b_t = up(t);
+    const size_t need = 3 * b_k + 3 * b_i + 256 + b_p + 256 + b_t;
+    if (need > sc.cap) {
+      if (sc.base) { DS(hipStreamSynchronize(s)); hipFree(sc.base); }
+      sc.base = nullptr; sc.cap = 0;
+      DS(hipMalloc((void**)&sc.base, need + need / 4));
+      sc.cap = need + need / 4;
+    }
+    char* q = sc.base;
+    auto carve = [&](size_t bytes) { char* r = q; q += bytes; return r; };
+    d_key = (unsigned long long*)carve(b_k); d_key_s = (unsigned long long*)carve(b_k); d_ukey = (unsigned long long*)carve(b_k);
+    d_idx = (unsigned int*)carve(b_i); d_idx_s = (unsigned int*)carve(b_i); d_cnt = (unsigned int*)carve(b_i);
+    d_runs = (unsigned int*)carve(256); d_ptr = (long long*)carve(b_p); d_err = (int*)carve(256); d_temp = carve(b_t);
+  }
+  DS(hipMemsetAsync(d_err, 0, 4, s));
+  ds_key_kernel<<<grid, 256, 0, s>>>(d_in, n, voxel_size, d_key, d_idx, d_err);
+  DS(hipGetLastError());
+  size_t tt = t;
+  DS(rocprim::radix_sort_pairs(d_temp, tt, d_key, d_key_s, d_idx, d_idx_s, (size_t)n, 0, 63, s));
+  tt = t;
+  DS(rocprim::run_length_encode(d_temp, tt, d_key_s, (size_t)n, d_ukey, d_cnt, d_runs, s));
+  DS(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s));
+  DS(hipMemcpyAsync(&runs, d_runs, 4, hipMemcpyDeviceToHost, s));
+  DS(hipStreamSynchronize(s));
+  if (err) return VXBA_ERR_ARG;   // a voxel index outside [-2^20, 2^20)
+  ds_widen_kernel<<<grid1, 256, 0, s>>>(d_cnt, (long long)runs, d_ptr);
+  DS(hipGetLastError());
+  tt = t;
+  DS(rocprim::exclusive_scan(d_temp, tt, d_ptr, d_ptr, 0ll, (size_t)runs + 1, rocprim::plus<long long>(), s));
+  ds_mean_kernel<<<(unsigned)((runs + 63) / 64), 64, 0, s>>>(d_in, d_idx_s, d_ptr, (long long)runs, d_out);
+  DS(hipGetLastError());
+#undef DS
+  *n_out = (int64_t)runs;
+  return VXBA_OK;
+}
+
+}  // namespace vxd
+
 extern "C" int vxba_down_sampling_voxel(int device, int64_t n, const float* xyz, double voxel_size, float* out_xyz, int64_t* n_out) {
   if (n < 0 || !n_out || (n > 0 && (!xyz || !out_xyz)) || n >= (1ll << 32)) return VXBA_ERR_ARG;
   *n_out = 0;
@@ -79,73 +147,28 @@ extern "C" int vxba_down_sampling_voxel(int device, int64_t n, const float* xyz,
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VXBA_ERR_NODEV;
   if (hipSetDevice(device) != hipSuccess) return VXBA_ERR_HIP;
-  hipStream_t s = nullptr;
-  float *d_xyz = nullptr, *d_out = nullptr;
-  unsigned long long *d_key = nullptr, *d_key_s = nullptr, *d_ukey = nullptr;
-  unsigned int *d_idx = nullptr, *d_idx_s = nullptr, *d_cnt = nullptr, *d_runs = nullptr;
-  long long* d_ptr = nullptr;
-  int* d_err = nullptr;
-  void* d_temp = nullptr;
-  size_t t_sort = 0, t_rle = 0, t_scan = 0;
-  int rc = VXBA_OK;
-  unsigned int runs = 0;
-  int err = 0;
-  const unsigned grid = (unsigned)((n + 255) / 256), grid1 = (unsigned)((n + 256) / 256);
-  // one grow-only scratch per device for this stand-alone entry point (it runs once per scan: a dozen hipMalloc / hipFree pairs per
-  // call cost more than the sort); calls are serialised on it
+  // one grow-only scratch + in / out buffers per device for this stand-alone entry point (it runs once per scan: a dozen hipMalloc / hipFree
+  // pairs per call cost more than the sort); calls are serialised on it
   static std::mutex mtx;
-  static char* scratch[16] = {nullptr};
-  static size_t scratch_cap[16] = {0};
+  static vxd::Scratch scratch[16];
+  static float* io[16] = {nullptr};
+  static size_t io_cap[16] = {0};
   std::lock_guard<std::mutex> lock(mtx);
-  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-#define DS(call) do { if ((call) != hipSuccess) { rc = VXBA_ERR_HIP; goto done; } } while (0)
-  DS(rocprim::radix_sort_pairs(nullptr, t_sort, d_key, d_key_s, d_idx, d_idx_s, (size_t)n, 0, 63, s));
-  DS(rocprim::run_length_encode(nullptr, t_rle, d_key_s, (size_t)n, d_ukey, d_cnt, d_runs, s));
-  DS(rocprim::exclusive_scan(nullptr, t_scan, d_ptr, d_ptr, 0ll, (size_t)n + 1, rocprim::plus<long long>(), s));
-  {
-    size_t tmax = t_sort > t_rle ? t_sort : t_rle;
-    if (t_scan > tmax) tmax = t_scan;
-    const size_t b_f = up((size_t)n * 3 * sizeof(float)), b_k = up((size_t)n * 8), b_i = up((size_t)n * 4), b_p = up((size_t)(n + 1) * 8), b_t = up(tmax ? tmax : 8);
-    const size_t need = 2 * b_f + 3 * b_k + 3 * b_i + 256 + b_p + 256 + b_t;
-    const int dv = device < 16 ? device : 15;
-    if (need > scratch_cap[dv] || device >= 16) {
-      if (scratch[dv]) { hipDeviceSynchronize(); hipFree(scratch[dv]); }
-      scratch[dv] = nullptr; scratch_cap[dv] = 0;
-      DS(hipMalloc((void**)&scratch[dv], need + need / 4));
-      scratch_cap[dv] = need + need / 4;
-    }
-    char* q = scratch[dv];
-    auto carve = [&](size_t bytes) { char* r = q; q += bytes; return r; };
-    d_xyz = (float*)carve(b_f); d_out = (float*)carve(b_f);
-    d_key = (unsigned long long*)carve(b_k); d_key_s = (unsigned long long*)carve(b_k); d_ukey = (unsigned long long*)carve(b_k);
-    d_idx = (unsigned int*)carve(b_i); d_idx_s = (unsigned int*)carve(b_i); d_cnt = (unsigned int*)carve(b_i);
-    d_runs = (unsigned int*)carve(256); d_ptr = (long long*)carve(b_p); d_err = (int*)carve(256); d_temp = carve(b_t);
+  const int dv = device < 16 ? device : 15;
+  if ((size_t)n > io_cap[dv] || device >= 16) {
+    if (io[dv]) { hipDeviceSynchronize(); hipFree(io[dv]); }
+    io[dv] = nullptr; io_cap[dv] = 0;
+    const size_t want = (size_t)n + (size_t)n / 4;
+    if (hipMalloc((void**)&io[dv], 2 * want * 3 * sizeof(float)) != hipSuccess) return VXBA_ERR_HIP;
+    io_cap[dv] = want;
   }
-  DS(hipMemset(d_err, 0, 4));
-  {
-    size_t t = t_sort > t_rle ? t_sort : t_rle;
-    if (t_scan > t) t = t_scan;
-    if (!t) t = 8;
-    DS(hipMemcpy(d_xyz, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
-    vxd::ds_key_kernel<<<grid, 256, 0, s>>>(d_xyz, n, voxel_size, d_key, d_idx, d_err);
-    DS(hipGetLastError());
-    DS(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
-    if (err) { rc = VXBA_ERR_ARG; goto done; }   // a voxel index outside [-2^20, 2^20)
-    size_t tt = t;
-    DS(rocprim::radix_sort_pairs(d_temp, tt, d_key, d_key_s, d_idx, d_idx_s, (size_t)n, 0, 63, s));
-    tt = t;
-    DS(rocprim::run_length_encode(d_temp, tt, d_key_s, (size_t)n, d_ukey, d_cnt, d_runs, s));
-    DS(hipMemcpy(&runs, d_runs, 4, hipMemcpyDeviceToHost));
-    vxd::ds_widen_kernel<<<grid1, 256, 0, s>>>(d_cnt, (long long)runs, d_ptr);
-    DS(hipGetLastError());
-    tt = t;
-    DS(rocprim::exclusive_scan(d_temp, tt, d_ptr, d_ptr, 0ll, (size_t)runs + 1, rocprim::plus<long long>(), s));
-    vxd::ds_mean_kernel<<<(unsigned)((runs + 63) / 64), 64, 0, s>>>(d_xyz, d_idx_s, d_ptr, (long long)runs, d_out);
-    DS(hipGetLastError());
-    DS(hipMemcpy(out_xyz, d_out, (size_t)runs * 3 * sizeof(float), hipMemcpyDeviceToHost));
-    *n_out = (int64_t)runs;
-  }
-done:
-#undef DS
-  return rc;
+  float* d_in = io[dv];
+  float* d_out = io[dv] + 3 * io_cap[dv];
+  if (hipMemcpy(d_in, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return VXBA_ERR_HIP;
+  int64_t kept = 0;
+  const int rc = vxd::downsample_device(scratch[dv], nullptr, d_in, n, voxel_size, d_out, &kept);
+  if (rc != VXBA_OK) return rc;
+  if (hipMemcpy(out_xyz, d_out, (size_t)kept * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return VXBA_ERR_HIP;
+  *n_out = kept;
+  return VXBA_OK;
 }

@@ -179,7 +179,8 @@ struct PlaneCriteria { int min_point; double min_eigen_value, eigen_ratio_thre, 
 void launch_k4_plane_fit(const double* d_clusters, int64_t n, double* d_eigval, double* d_eigvec, const PlaneCriteria* crit, unsigned char* d_flags,
                          hipStream_t s);
 // K1 stand-alone: n_cells buckets -> packed clusters (AoS n_cells*10).
-void launch_k1_build_aos(const double* d_xyz, const int64_t* d_cell_ptr, int64_t n_cells, double* d_clusters, hipStream_t s);
+void launch_k1_build_aos(const double* d_xyz, const int64_t* d_cell_ptr, int64_t n_cells, double* d_clusters, hipStream_t s, hipEvent_t ev_start = nullptr,
+                         hipEvent_t ev_stop = nullptr);
 
 // Rebuild the batch-major copy (clb) of voxels [v0, v0+n) from the frame-major planes.
 void launch_build_clb(const FactorView& fv, int v0, int n, hipStream_t s);

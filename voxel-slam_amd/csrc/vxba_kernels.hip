@@ -1301,10 +1301,14 @@ void launch_k4_plane_fit(const double* d_clusters, int64_t n, double* d_eigval, 
   PlaneCriteria pc = crit ? *crit : PlaneCriteria{0, 0.0, 0.0, 0.0};
   k4_plane_fit_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(d_clusters, (long long)n, d_eigval, d_eigvec, pc, crit ? d_flags : nullptr);
 }
-void launch_k1_build_aos(const double* d_xyz, const int64_t* d_cell_ptr, int64_t n_cells, double* d_clusters, hipStream_t s) {
+void launch_k1_build_aos(const double* d_xyz, const int64_t* d_cell_ptr, int64_t n_cells, double* d_clusters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (n_cells <= 0) return;
   FactorView fv{};
-  k1_build_kernel<true><<<dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s>>>(d_xyz, (const long long*)d_cell_ptr, 0, 0, fv, 0, d_clusters, (long long)n_cells);
+  if (ev_start)   // events tied to the dispatch of k1_build_kernel itself (the interval rocprofv3 reports)
+    hipExtLaunchKernelGGL((k1_build_kernel<true>), dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s, ev_start, ev_stop, 0, d_xyz, (const long long*)d_cell_ptr, 0, 0, fv, 0,
+                          d_clusters, (long long)n_cells);
+  else
+    k1_build_kernel<true><<<dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s>>>(d_xyz, (const long long*)d_cell_ptr, 0, 0, fv, 0, d_clusters, (long long)n_cells);
   const long long tiles = (n_cells + 63) / 64;
   k1_long_cells_kernel<<<dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, s>>>(d_xyz, (const long long*)d_cell_ptr, (long long)n_cells, d_clusters);
 }

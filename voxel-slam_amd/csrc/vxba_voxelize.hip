@@ -11,6 +11,7 @@
 //   0.12; non-planes are subdivided while layer < max_layer), and the accepted ones are appended to the factor's planes
 //   on the device, cache seeded with (lambda, U, world cluster) like recut's push_voxel does.
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <cstdint>
 #include <cstring>
@@ -219,7 +220,10 @@ struct ArenaSlot {
   char* base = nullptr;
   size_t cap = 0;
 };
-static ArenaSlot g_arena[16];
+static ArenaSlot g_arena[16][2];
+// vxba_voxelize_profile: time of / bytes moved by the cluster-build kernel inside the voxeliser (the dominant kernel of a hierarchical-BA pass)
+struct K1Prof { std::atomic<int> on{0}; std::mutex m; double ms = 0, bytes = 0; long long launches = 0; };
+static K1Prof g_k1prof;   // two per device: two host threads (vxba_hba_pass drives two streams) voxelise concurrently
 struct DevBuf {
   char* base = nullptr;
   size_t cap = 0, used = 0;
@@ -235,8 +239,9 @@ struct DevBuf {
       own = true; cap = bytes;
       return hipMalloc((void**)&base, bytes);
     }
-    slot = &g_arena[dev];
-    slot->mtx.lock();
+    if (g_arena[dev][0].mtx.try_lock()) slot = &g_arena[dev][0];
+    else if (g_arena[dev][1].mtx.try_lock()) slot = &g_arena[dev][1];
+    else { slot = &g_arena[dev][0]; slot->mtx.lock(); }
     if (bytes > slot->cap) {
       if (slot->base) { hipDeviceSynchronize(); hipFree(slot->base); }
       slot->base = nullptr; slot->cap = 0;
@@ -369,8 +374,26 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
     // clusters: body-frame per cell, world per node -- sequential sums in upstream's push order
     gather3_kernel<<<grid_for(n), 256, 0, s>>>(d_xyz_local, d_idx_s, n, d_loc_s);
     gather3_kernel<<<grid_for(n), 256, 0, s>>>(d_world, d_idx_s, n, d_wld_s);
-    vxk::launch_k1_build_aos(d_loc_s, (const int64_t*)d_cell_ptr, n_cells, d_cell_cl, s);
-    vxk::launch_k1_build_aos(d_wld_s, (const int64_t*)d_node_ptr, n_nodes, d_node_cl, s);
+    if (g_k1prof.on.load(std::memory_order_relaxed)) {
+      // measurement mode (vxba_voxelize_profile): the two cluster builds of this layer bracketed by events bound to the dispatches themselves.
+      // Algorithmic bytes of a build: 24 B per point + 8 B per cell offset read, 80 B per cluster written.
+      hipEvent_t ev[4];
+      for (hipEvent_t& e : ev) VV(hipEventCreate(&e));
+      vxk::launch_k1_build_aos(d_loc_s, (const int64_t*)d_cell_ptr, n_cells, d_cell_cl, s, ev[0], ev[1]);
+      vxk::launch_k1_build_aos(d_wld_s, (const int64_t*)d_node_ptr, n_nodes, d_node_cl, s, ev[2], ev[3]);
+      VV(hipStreamSynchronize(s));
+      float ms0 = 0, ms1 = 0;
+      VV(hipEventElapsedTime(&ms0, ev[0], ev[1]));
+      VV(hipEventElapsedTime(&ms1, ev[2], ev[3]));
+      for (hipEvent_t& e : ev) hipEventDestroy(e);
+      std::lock_guard<std::mutex> lk(g_k1prof.m);
+      g_k1prof.ms += (double)ms0 + (double)ms1;
+      g_k1prof.launches += 2;
+      g_k1prof.bytes += 2.0 * 24.0 * (double)n + 8.0 * ((double)n_cells + (double)n_nodes + 2.0) + 80.0 * ((double)n_cells + (double)n_nodes);
+    } else {
+      vxk::launch_k1_build_aos(d_loc_s, (const int64_t*)d_cell_ptr, n_cells, d_cell_cl, s);
+      vxk::launch_k1_build_aos(d_wld_s, (const int64_t*)d_node_ptr, n_nodes, d_node_cl, s);
+    }
     // verdicts
     VV(B.alloc(&d_state[layer], n_nodes));
     judge_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_node_key[layer], d_node_cl, d_node_ncell, n_nodes, layer, p, layer ? d_node_key[layer - 1] : nullptr,
@@ -410,3 +433,15 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
 }
 
 }  // namespace vxv
+
+// Measurement (bench.py --config cfg5): enable != 0 starts a fresh measurement of the cluster-build kernel inside the voxeliser (every launch bracketed by
+// events bound to its dispatch, one stream synchronisation per layer: NOT for timed runs); enable == 0 stops it and returns the sums.
+extern "C" int vxba_voxelize_profile(int enable, double* ms_sum, long long* launches, double* algorithmic_bytes) {
+  std::lock_guard<std::mutex> lk(vxv::g_k1prof.m);
+  if (enable) { vxv::g_k1prof.ms = 0; vxv::g_k1prof.bytes = 0; vxv::g_k1prof.launches = 0; vxv::g_k1prof.on.store(1); return 0; }
+  vxv::g_k1prof.on.store(0);
+  if (ms_sum) *ms_sum = vxv::g_k1prof.ms;
+  if (launches) *launches = vxv::g_k1prof.launches;
+  if (algorithmic_bytes) *algorithmic_bytes = vxv::g_k1prof.bytes;
+  return 0;
+}

@@ -36,6 +36,7 @@ EXPORTS = [
     "vxba_lio_create", "vxba_lio_destroy", "vxba_lio_last_error", "vxba_lio_map_update", "vxba_lio_map_clear", "vxba_lio_map_size", "vxba_lio_scan_raw",
     "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_lio_leaf_stats", "vxba_cov_add_build", "vxba_plane_update", "vxba_down_sampling_voxel", "vxba_voxelize_push_device",
     "vxba_set_option", "vxba_get_option", "vxba_lio_set_option",
+    "vxba_hba_create", "vxba_hba_destroy", "vxba_hba_last_error", "vxba_hba_add_keyframes", "vxba_hba_num_keyframes", "vxba_hba_clear", "vxba_hba_pass", "vxba_voxelize_profile",
     "vxba_map_create", "vxba_map_destroy", "vxba_map_last_error", "vxba_map_cut_voxel", "vxba_map_cut_voxel_device", "vxba_map_recut", "vxba_map_margi",
     "vxba_map_slide", "vxba_map_counts", "vxba_map_fix_pool", "vxba_map_set_journey", "vxba_map_release", "vxba_map_device_bytes", "vxba_map_leaves", "vxba_map_cut_voxel_lio", "vxba_map_export_planes",
 ]
@@ -838,6 +839,76 @@ def down_sampling_voxel(xyz, voxel_size: float, device: int = 0):
     if rc != 0:
         raise VxbaError(f"vxba_down_sampling_voxel: {_ERRNAMES.get(rc, rc)}")
     return out[: n_out.value].copy()
+
+
+def voxelize_profile(enable: bool):
+    """``vxba_voxelize_profile``: start (True) or stop (False -> dict(ms_sum, launches, algorithmic_bytes)) the measurement of the
+    cluster-build kernel inside the voxeliser."""
+    L = load_library()
+    ms, n, b = C.c_double(), C.c_longlong(), C.c_double()
+    L.vxba_voxelize_profile(1 if enable else 0, C.byref(ms), C.byref(n), C.byref(b))
+    return None if enable else dict(ms_sum=ms.value, launches=int(n.value), algorithmic_bytes=b.value)
+
+
+class HbaSession:
+    """``vxba_hba_*``: a session of keyframes resident on the device and the bottom-up pass of the hierarchical global BA over it
+    (thd_globalmapping / HBA_add_edge, voxelslam.cpp:2485-2595, 2320-2482) below the C ABI -- see csrc/vxba_hba.hip.  The Python twin that
+    orchestrates the same calls window by window (and runs on the CPU oracle in the tests) is ``voxel_slam_amd.hba.hierarchical_ba``."""
+
+    def __init__(self, device: int = 0):
+        L = load_library()
+        L.vxba_hba_last_error.restype = C.c_char_p
+        self._L = L
+        self._h = C.c_void_p()
+        rc = L.vxba_hba_create(int(device), C.byref(self._h))
+        if rc != 0:
+            raise VxbaError(f"vxba_hba_create: {_ERRNAMES.get(rc, rc)}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vxba_hba_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise VxbaError(f"{what}: {_ERRNAMES.get(rc, rc)}: {self._L.vxba_hba_last_error(self._h).decode()}")
+
+    def add_keyframes(self, clouds):
+        """clouds: list of (n_i, 3) arrays in keyframe coordinates (stored as float32, like PointType)."""
+        ptr = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int64)
+        xyz = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.float32).reshape(-1, 3) for c in clouds])) if len(clouds) else np.zeros((0, 3), np.float32)
+        self._check(self._L.vxba_hba_add_keyframes(self._h, C.c_int64(len(clouds)), ptr.ctypes.data_as(C.c_void_p), xyz.ctypes.data_as(C.c_void_p)), "vxba_hba_add_keyframes")
+
+    def num_keyframes(self) -> int:
+        return int(self._L.vxba_hba_num_keyframes(self._h))
+
+    def clear(self):
+        self._check(self._L.vxba_hba_clear(self._h), "vxba_hba_clear")
+
+    def run_pass(self, poses, coarse: VoxelizeParams, fine: VoxelizeParams, wdsize: int = 10, mgsize: int = 5, top_max_iter: int = 1, n_threads: int = 2):
+        """One bottom-up pass; returns what ``hba.hierarchical_ba`` returns (edges as dicts with keyframe indices)."""
+        poses = _c(poses).reshape(-1, 12)
+        K = poses.shape[0]
+        if K != self.num_keyframes():
+            raise VxbaError(f"run_pass: {K} poses for {self.num_keyframes()} keyframes")
+        S = (K - wdsize) // mgsize + 1
+        cap = S * (wdsize * (wdsize - 1) // 2) + S * (S - 1) // 2
+        sub_poses = np.zeros((S, 12)); sizes = np.zeros(S, dtype=np.int64)
+        eij = np.zeros((cap, 2), dtype=np.int32); edata = np.zeros((cap, 18))
+        n1, n2, ntr = C.c_int64(), C.c_int64(), C.c_int()
+        rounds = np.zeros((max(1, top_max_iter), 5))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._check(self._L.vxba_hba_pass(self._h, vp(poses), C.byref(coarse), C.byref(fine), int(wdsize), int(mgsize), int(top_max_iter), int(n_threads), vp(sub_poses),
+                                          vp(sizes), C.c_int64(cap), vp(eij), vp(edata), C.byref(n1), C.byref(n2), vp(rounds), C.byref(ntr)), "vxba_hba_pass")
+
+        def edges(lo, hi):
+            return [dict(i=int(eij[k, 0]), j=int(eij[k, 1]), rot=edata[k, :9].reshape(3, 3).copy(), tra=edata[k, 9:12].copy(), v6=edata[k, 12:18].copy()) for k in range(lo, hi)]
+        return dict(edges1=edges(0, n1.value), edges2=edges(n1.value, n1.value + n2.value), submap_ids=list(range(0, K - wdsize + 1, mgsize)), submap_poses=sub_poses,
+                    submap_sizes=[int(x) for x in sizes],
+                    top_rounds=[dict(round=k, n_voxels=int(rounds[k, 0]), resis=(float(rounds[k, 1]), float(rounds[k, 2])), converged=bool(rounds[k, 3]), fine=bool(rounds[k, 4]))
+                                for k in range(ntr.value)])
 
 
 def cov_add_build(xyz_world, var, cell_ptr, device: int = 0):
