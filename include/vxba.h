@@ -381,11 +381,7 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
                                        * the Hessian sweep runs and lets the device solve the reduced 6W-dimensional pose system inside the residual-sweep launch
                                        * (the LiDAR-only loop's four-wave solve): no kernel ever waits for the host, the LiDAR Hessian never crosses PCIe on the
                                        * critical path.  Steps after a rejection, the gravity variant and a non-positive band pivot take the host solve.  0: host solve. */
-#define VXBA_OPT_FINALIZE_IN_LAUNCH 9 /* 0 (default): the reduction of the Hessian sweep's workgroup partials is a kernel of its own (k3_finalize).  1: in the
-                                         device-resident LM loop (in-launch solve, no collective, and enough voxel workgroups for the reduction to take a pass or
-                                         two: fin_workgroups(), >= ~23k voxels at W = 10) it runs as a phase of the residual-sweep launch -- on the voxel
-                                         workgroups, which idle until the solve publishes the trial poses; the solve then waits (bounded) for their flags.
-                                         Built in round 3 and measured NO faster (LM step 56.3 vs 56.1 us at cfg2), hence off; kept for the parity tests. */
+/* (option 9, the Hessian reduction as a phase of the residual-sweep launch, was measured no faster in round 4 and removed in round 5) */
 #define VXBA_OPT_COUNT 10
 #define VXBA_STAT_FUSED_FALLBACKS 100 /* read-only (vxba_get_option): times vxba_damping_iter re-ran a call with the solve as its own launch after the
                                          voxel workgroups of a fused launch had timed out waiting for it */

@@ -92,21 +92,6 @@ def test_cfg2_window_with_rejected_steps_matches_the_checkers(vx):
     run_case(vx, sc, iters=8, need_reject=True)
 
 
-@pytest.mark.parametrize("rejects", [False, True])
-def test_cfg2_lm_with_the_hessian_reduction_inside_the_residual_sweep_launch(vx, rejects):
-    """VXBA_OPT_FINALIZE_IN_LAUNCH (off by default: measured no faster): the reduction of the Hessian sweep's workgroup
-    partials as a phase of the residual-sweep launch -- voxel workgroups reduce and write the LM state with written-through stores, the
-    solve workgroup waits for their flags instead of for a kernel boundary.  Same checkers, same tolerances; the window with rejected
-    steps exercises launches in which the phase must NOT run (Hessian not recomputed)."""
-    sc = synth.make_config("cfg2", rot_sigma_deg=0.2, trans_sigma=0.03) if rejects else synth.make_config("cfg2")
-    got = run_case(vx, sc, iters=8 if rejects else 3, need_reject=rejects, options={"finalize_in_launch": 1})
-    ref = run_case(vx, sc, iters=8 if rejects else 3, need_reject=rejects, options={"finalize_in_launch": 0})
-    assert np.array_equal(got["trace"][:, 6:], ref["trace"][:, 6:])
-    et, er = synth.pose_errors(got["poses"], ref["poses"])
-    assert et < 1e-10 and er < 1e-10, (et, er)
-    assert np.allclose(got["hess"], ref["hess"], rtol=1e-10, atol=1e-10 * np.abs(ref["hess"]).max())
-
-
 def test_cfg4_single_gpu_lm_matches_the_oracle(vx):
     """BASELINE configs[3] is this 400k-voxel window sharded over eight GPUs; on one GPU it is the largest window the bench runs
     (13 workgroup steps per CU in the Hessian sweep instead of four) -- two LM iterations against the oracle restatement."""

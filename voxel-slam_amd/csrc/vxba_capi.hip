@@ -642,7 +642,6 @@ int vxba_set_option(vxba_factor* f, int option, int value) {
       break;
     case VXBA_OPT_FUSED_SOLVE: case VXBA_OPT_SPEC_COLLECTIVE: case VXBA_OPT_WIDE_DEVICE_SOLVE:
     case VXBA_OPT_LI_STRUCTURED_SOLVE: case VXBA_OPT_LI_QUEUED_SWEEPS: case VXBA_OPT_LI_DEVICE_POSE_SOLVE:
-    case VXBA_OPT_FINALIZE_IN_LAUNCH:
       if (value != 0 && value != 1) return fail(f, VXBA_ERR_ARG, "vxba_set_option: this option takes 0 or 1");
       break;
     case VXBA_OPT_DEBUG_SOLVE_TIMEOUT:

@@ -239,7 +239,6 @@ void options_from_env(vxba_factor* f) {   // initial values only; vxba_set_optio
   f->opt[VXBA_OPT_SPEC_COLLECTIVE] = flag("VXBA_SPEC_COLLECTIVE", 1);
   f->opt[VXBA_OPT_WIDE_DEVICE_SOLVE] = flag("VXBA_WIDE_DEVICE_SOLVE", 1);
   f->opt[VXBA_OPT_LI_DEVICE_LOOP] = 0;   // (removed in round 4; the slot stays so that the option numbers do not move)
-  f->opt[VXBA_OPT_FINALIZE_IN_LAUNCH] = flag("VXBA_FINALIZE_IN_LAUNCH", 0);
   const char* e = getenv("VXBA_K2_VPB");
   const int v = e ? atoi(e) : 64;
   f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] = (v >= 32 && v <= 64) ? v : 64;
@@ -262,12 +261,8 @@ int upload_poses(vxba_factor* f, const double* Rp) {
 // Stand-alone mode: poses by value (Rp, host pointer -> kernel argument), lm == nullptr.
 // LM mode (lm != nullptr): the sweep's prologue takes the pending accept/reject decision from ctl[*c] (and flips *c),
 // reads the poses from the control block and skips the work when the loop does not need it; Rp carries the restart poses.
-bool finalize_in_launch(const vxba_factor* f) {
-  return f->opt[VXBA_OPT_FINALIZE_IN_LAUNCH] && fused_solve(f) && !has_collective(f) && !is_wide(f) &&
-         vxk::fin_workgroups(f->W, f->V, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK]) > 0;
-}
 int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c, const vxk::LMPending* pend, int head, int end,
-                      double* d_out, const double* cache_src, vxk::FinArgs* defer_fin) {
+                      double* d_out, const double* cache_src) {
   const size_t plen = vxba_packed_len(f);
   if (end == head) {
     VX_HIP(f, hipMemsetAsync(d_out, 0, plen * sizeof(double), f->stream));
@@ -312,11 +307,6 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c
   } else {
     vxk::launch_k3_hessian(fv, pa, lm, c_in, pd, cache_src, head, end, f->d_partial3, nblocks, f->precision, f->stream);
   }
-  if (defer_fin && lm && !has_collective(f)) {   // reduced inside the residual-sweep launch that follows
-    defer_fin->partial = f->d_partial3; defer_fin->nblocks = nblocks; defer_fin->packed = d_out; defer_fin->write_state = 1; defer_fin->nwg = 0;
-    VX_HIP(f, hipGetLastError());
-    return VXBA_OK;
-  }
   {
     ScopedKernelTimer t(f, 2);
     // with a collective the LM state is filled after the all-reduce, from the reduced buffer
@@ -332,7 +322,7 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c
 // partials_to_host: the block partials go straight to mapped host memory (h_partial2) and no sum is launched -- the caller adds them up
 // with host_sum_partials once the sweep is done (d_out is ignored).
 int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int c, int head, int end, double* d_out,
-                          int* nparts_out, unsigned fused_seq, bool partials_to_host, const vxk::FinArgs* fin) {
+                          int* nparts_out, unsigned fused_seq, bool partials_to_host) {
   if (end == head) {
     if (d_out) VX_HIP(f, hipMemsetAsync(d_out, 0, sizeof(double), f->stream));
     return (is_wide(f) && !lm && d_out && has_collective(f)) ? shard_allreduce(f, d_out, 1) : VXBA_OK;
@@ -360,12 +350,11 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, in
   if (partials_to_host) d_out = nullptr;
   if (f->profiling & 2) {
     hipEvent_t a = get_event(f), b = get_event(f);
-    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, part, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] == 1 ? 0x10000 : 0), f->stream, a, b, nullptr, nullptr, nullptr, fin);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, part, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] == 1 ? 0x10000 : 0), f->stream, a, b);
     if (a && b) f->pending.push_back({a, b, 1});
   } else {
-    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, part, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] == 1 ? 0x10000 : 0), f->stream, nullptr, nullptr, nullptr, nullptr, nullptr, fin);
+    nparts = vxk::launch_k2_residual(fv, pa, lm, c, fused_seq, head, end, part, f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] == 1 ? 0x10000 : 0), f->stream);
   }
-  if (nparts < 0) return fail(f, VXBA_ERR_STATE, "residual sweep: in-launch Hessian reduction asked for with too few voxel workgroups");
   if (nparts_out) *nparts_out = nparts;
   if (d_out) {
     vxk::launch_sum_partials(f->d_partial2, nparts, d_out, f->stream);

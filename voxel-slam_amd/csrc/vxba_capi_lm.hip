@@ -111,16 +111,14 @@ static int damping_iter_impl(vxba_factor* f, double* Rp, int max_iter, double* h
   }
   if (spec && max_iter > 0) { int rc = spec_final_decision(f, Rp, &c, spec_nparts); if (rc) return rc; }
   for (int i = 0; !spec && i < max_iter; i++) {
-    vxk::FinArgs fin;
-    const bool fin_fold = finalize_in_launch(f);   // the Hessian reduction as a phase of the residual-sweep launch
-    int rc = sweep_hess_device(f, Rp, f->d_lm, &c, &pend, 0, f->V, f->d_packed, nullptr, fin_fold ? &fin : nullptr);
+    int rc = sweep_hess_device(f, Rp, f->d_lm, &c, &pend, 0, f->V, f->d_packed, nullptr);
     if (rc) return rc;
     // damped solve + residual sweep at the trial state: one launch (the solve is workgroup 0 of the sweep) unless
     // VXBA_FUSED_SOLVE=0; without a collective the sweep's wave partials are summed by whoever takes the decision
     const unsigned seq = fused_solve(f) ? ++f->lm_seq : 0u;
     if (!seq) vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
     int nparts = 0;
-    rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts, seq, false, fin_fold ? &fin : nullptr);
+    rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts, seq, false);
     if (rc) return rc;
     pend.pending = 1; pend.restart = 0;
     pend.d_scalar = has_collective(f) ? f->d_scalar : nullptr;
@@ -223,14 +221,12 @@ static int lm_steps_impl(vxba_factor* f, const double* Rp_init, int n_steps, int
     // the residual sweeps keep writing the live cache
     const bool first = (s % steps_per_solve) == 0;
     const bool last = ((s + 1) % steps_per_solve) == 0 && s + 1 < n_steps;
-    vxk::FinArgs fin;
-    const bool fin_fold = finalize_in_launch(f);
-    int rc = sweep_hess_device(f, Rp_init, f->d_lm, &c, &pend, 0, f->V, f->d_packed, first ? f->snapshot : nullptr, fin_fold ? &fin : nullptr);
+    int rc = sweep_hess_device(f, Rp_init, f->d_lm, &c, &pend, 0, f->V, f->d_packed, first ? f->snapshot : nullptr);
     if (rc) return rc;
     const unsigned seq = fused_solve(f) ? ++f->lm_seq : 0u;
     if (!seq) vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
     int nparts = 0;
-    rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts, seq, false, fin_fold ? &fin : nullptr);
+    rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts, seq, false);
     if (rc) return rc;
     pend.pending = 1; pend.restart = last ? 1 : 0;
     pend.d_scalar = has_collective(f) ? f->d_scalar : nullptr;

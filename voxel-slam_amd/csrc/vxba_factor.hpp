@@ -168,12 +168,8 @@ int ensure_exchange(vxba_factor* f);
 int ensure_partials3(vxba_factor* f);
 void fill_poses(const vxba_factor* f, const double* Rp, vxk::PoseArg& pa);
 // asynchronous sweeps on f->stream, results in device (or mapped host) memory
-// defer_fin != nullptr: the reduction of the sweep's workgroup partials is NOT launched; *defer_fin describes it for the residual sweep that
-// follows (sweep_residual_device(..., fin), in-launch reduction -- vxk::FinArgs)
 int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c, const vxk::LMPending* pend, int head, int end, double* d_out,
-                      const double* cache_src = nullptr, vxk::FinArgs* defer_fin = nullptr);
+                      const double* cache_src = nullptr);
 int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int c, int head, int end, double* d_out, int* nparts_out = nullptr,
-                          unsigned fused_seq = 0, bool partials_to_host = false, const vxk::FinArgs* fin = nullptr);
-// the LM loop may fold the Hessian reduction into the residual-sweep launch (VXBA_OPT_FINALIZE_IN_LAUNCH, in-launch solve, no collective, enough voxels)
-bool finalize_in_launch(const vxba_factor* f);
+                          unsigned fused_seq = 0, bool partials_to_host = false);
 }  // namespace vxc

@@ -58,7 +58,6 @@ struct LMCtl {
   int bench_mode;             // 1: never take the early break, so exactly n_steps iterations run (vxba_lm_steps)
   int n_accept, n_reject;     // running totals over all iterations of this init
 };
-constexpr int FIN_MAX_WG = 192;
 struct LMState {
   LMCtl ctl[2];
   double trace[LM_MAX_ITER * 8];
@@ -67,8 +66,6 @@ struct LMState {
   double Hwork[36 * MAXW * MAXW];         // gauge-fixed Hessian kept across rejected steps
   double hess_out[36 * MAXW * MAXW];      // *hess, exported before the gauge fix (voxel_map.hpp:391)
   unsigned solve_seq;                     // sequence number of the last solve published inside a residual-sweep launch
-  unsigned fin_flag[FIN_MAX_WG];          // per workgroup of a residual-sweep launch: sequence number of the last launch in which it finished its share of the
-                                          // Hessian reduction (FinArgs).  One word each: 192 read-modify-writes of ONE counter took longer than the reduction itself
   int error;                              // 1: a voxel workgroup gave up waiting for the solve (never observed)
 };
 // What a sweep needs to take the pending accept/reject decision in its prologue.
@@ -109,24 +106,12 @@ int k2_voxels_per_block(int nvox, int cus);
 // the voxel workgroups wait for it after requesting their cluster rows.  Must be unique per launch and non-zero.
 // host_feed (with fused_seq != 0): workgroup 0 does not solve; it waits until the host has written fused_seq to host_feed[0] (mapped host
 // memory) and copies the 12W trial poses behind it into ctl[c].xt -- the LiDAR-inertial shells queue the sweep before their own solve is done.
-// fin (with fused_seq != 0, host_feed == nullptr): the reduction of the Hessian sweep's workgroup partials (k3_finalize) runs as a PHASE of this
-// launch instead of as a kernel of its own -- the first fin_workgroups(...) voxel workgroups, which would otherwise idle until the solve
-// publishes, reduce the partials and write the LM state; the solve workgroup waits for their count (LMState::fin_count).  The caller
-// checks fin_workgroups(...) > 0 first; gated on the device like k3_finalize (loop done / Hessian not recomputed: nothing happens).
-struct FinArgs {
-  const double* partial;   // the Hessian sweep's workgroup partials
-  int nblocks;             // ... and how many
-  double* packed;          // Hess (6W)^2 | JacT 6W | residual
-  int write_state;
-  int nwg;                 // filled by launch_k2_residual
-};
-int fin_workgroups(int W, int nvoxels, int voxels_per_block);
 // residual-sweep geometry: voxels per wave for an option value, and the number of wave partials a sweep over nvoxels writes
 int k2_voxels_per_wave(int voxels_per_block);
-int k2_nparts(int nvoxels, int voxels_per_block);   // 0: too few voxel workgroups for the in-launch reduction to pay
+int k2_nparts(int nvoxels, int voxels_per_block);
 int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, int c, unsigned fused_seq, int head, int end, double* d_partial,
                        int voxels_per_block, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const double* host_feed = nullptr,
-                       const double* li_rec = nullptr, double* li_out = nullptr, const FinArgs* fin = nullptr);
+                       const double* li_rec = nullptr, double* li_out = nullptr);
 // li_rec / li_out (with fused_seq != 0, host_feed == nullptr): workgroup 0 solves the LiDAR-inertial shells' REDUCED pose system -- li_rec (mapped host memory,
 // complete before the launch) = [u | current poses 12W | e 6W | E (6W)^2 column-major], see vxba_solve4.hpp -- and writes [dx 6W | trial poses 12W | seq] to li_out.
 inline int li_rec_doubles(int W) { return 1 + 12 * W + 6 * W + 36 * W * W; }

@@ -375,60 +375,6 @@ __global__ __launch_bounds__(FIN_EL * FIN_SL) void k3_finalize_kernel(const doub
   if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(threadIdx.x < 64, dbg_w, 3); }
 }
 
-// The same reduction as a PHASE of the residual-sweep launch (k2_residual_kernel, fused with the damped solve): the voxel workgroups
-// -- idle until the solve publishes the trial poses -- reduce the Hessian sweep's workgroup partials first, 16 elements x 16 slices
-// per 256-thread workgroup and pass, and write the LM state the solve reads with written-through stores; the solve workgroup waits
-// for a count of finished workgroups instead of for a kernel boundary.  `wg` of `nwg` participating workgroups (all of them resident
-// at once: the caller bounds nwg).  lds: 2 * 256 doubles.
-constexpr int FINP_EL = 16, FINP_SL = 16;
-template <int W>
-__device__ __forceinline__ void fin_phase(const double* __restrict__ partial, int nblocks, LMState* __restrict__ st, int cb, int write_state, double* __restrict__ packed,
-                                          int wg, int nwg, double* lds) {
-  using C = K3Cfg<W>;
-  constexpr int PLEN = C::PLEN;
-  const int el = threadIdx.x % FINP_EL, slice = threadIdx.x / FINP_EL;
-  double* red0 = lds;
-  double* red1 = lds + FINP_EL * FINP_SL;
-  const int f_iter = st ? st->ctl[cb].iter : 1;
-  for (int g = wg; g * FINP_EL < PLEN; g += nwg) {
-    const int e = g * FINP_EL + el;
-    const FinMap m = fin_map<W>(e);
-    const int off1 = m.off1;
-    const bool need0 = (m.r >= 0) || (m.lin >= 0);
-    double s0 = 0.0, s1 = 0.0;
-    if (need0) {
-      // every load of a pass goes out before the first one is used (up to 16 + 16 per thread: one round of memory latency per 256 partials;
-      // four at a time cost four rounds, and the phase 8 us instead of 3)
-      for (int base = 0; base < nblocks; base += FINP_SL * 16) {
-        double v0[16], v1[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-          const int b = base + slice + FINP_SL * q;
-          const double* pb = partial + (size_t)(b < nblocks ? b : 0) * PLEN;
-          v0[q] = pb[e];
-          v1[q] = off1 >= 0 ? pb[off1] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-          const bool in = base + slice + FINP_SL * q < nblocks;
-          s0 += in ? v0[q] : 0.0;
-          s1 += in ? v1[q] : 0.0;
-        }
-      }
-    }
-    red0[slice * FINP_EL + el] = s0;
-    red1[slice * FINP_EL + el] = s1;
-    __syncthreads();
-    if (slice == 0 && need0) {
-      double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-      for (int k = 0; k < FINP_SL; k++) { t0 += red0[k * FINP_EL + el]; t1 += red1[k * FINP_EL + el]; }
-      fin_emit<W, true>(m, t0, t1, st, cb, write_state, packed, f_iter);
-    }
-    __syncthreads();
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // K2 -- residual sweep.  One lane per voxel, frames unrolled: every load is a 512 B contiguous row of a
 // frame-major plane, poses are wave-uniform (scalar loads), no cross-lane traffic until the final residual
@@ -463,20 +409,17 @@ template <int W, bool DBG = false, bool F32 = false>
 // start (it is the critical path of a fused launch) and what a voxel wave needs for its done-check and its place in the sweep.
 __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __restrict__ st, int c, unsigned seq, const double* li_rec, double* li_out,
                                                                  const double* host_feed, int head, int end, int VPB_arg, int head_start,
-                                                                 double* __restrict__ partial, FinArgs fin, FactorView fv, PoseArg poses) {
+                                                                 double* __restrict__ partial, FactorView fv, PoseArg poses) {
   const int VPB = VPB_arg & 0xffff;
   __shared__ __attribute__((aligned(16))) double k2_lds[k2_lds_doubles<W>()];
   // LM mode: trial poses of ctl[c]; nothing to do once the loop is done
   // (the solve workgroup of a fused launch tests the flag itself, behind its loads: lm_solve_body4)
-  const bool fin_en = (VPB_arg >> 17) & 1;   // FinArgs in use (a preloaded scalar: `fin` itself sits in the part of the argument block that has to be loaded)
-  if (st && (!(seq != 0 && blockIdx.x == 0 && !host_feed) || fin_en) && st->ctl[c].done) return;
+  if (st && !(seq != 0 && blockIdx.x == 0 && !host_feed) && st->ctl[c].done) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   double* pose_lds = k2_lds + wave * 12 * W;
   int vb = blockIdx.x * K2_WAVES + wave;
   if (DBG) { if (blockIdx.x == 0) dbg_stamp(wave == 0, 4000, 30); else dbg_stamp(true, vb - K2_WAVES, 6); }   // kernel entry
-  // same gate as k3_finalize_kernel: nothing to reduce when the Hessian sweep skipped itself (rejected step)
-  const bool fin_on = st && seq != 0 && fin_en && st->ctl[c].calc_hess != 0;
   if (st && seq != 0) {
     if (blockIdx.x == 0) {
       if (host_feed) {
@@ -494,28 +437,6 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __rest
         if (!fed) { if (lane == 0) st->error = 2; return; }
         for (int k = lane; k < 12 * W; k += 64) __hip_atomic_store(&st->ctl[c].xt[k], hf[1 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        if (fin_on) {
-          // the Hessian reduction is a phase of this launch (fin_phase): wait until every participating workgroup has written its share
-          // of the LM state, then look at memory afresh
-          if (wave == 0) {
-            unsigned spins = 0;
-            for (;;) {
-              bool ok = true;
-#pragma unroll
-              for (int k = 0; k < FIN_MAX_WG / 64; k++) {
-                const int i = 64 * k + lane;
-                const unsigned v = __hip_atomic_load(&st->fin_flag[i < fin.nwg ? i : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = ok && (v == seq);
-              }
-              if (__builtin_amdgcn_read_exec() == __ballot(ok)) break;
-              __builtin_amdgcn_s_sleep(2);
-              if (++spins > 4u * K2_SPIN_LIMIT) { if (lane == 0) st->error = 3; break; }   // never observed; the host reports it
-            }
-          }
-          __syncthreads();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          dbg_stamp(DBG && wave == 0, 4000, 31);
-        }
         lm_solve_body4<W, DBG>(st, c, k2_lds, li_rec, li_out, seq);    // li_rec: the LiDAR-inertial shells' reduced pose system (vxba_solve4.hpp)
         if (wave != 0) return;
       }
@@ -532,13 +453,6 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __rest
       return;
     }
     vb -= K2_WAVES;
-    if (fin_on && (int)blockIdx.x - 1 < fin.nwg) {
-      fin_phase<W>(fin.partial, fin.nblocks, st, c, fin.write_state, fin.packed, (int)blockIdx.x - 1, fin.nwg, k2_lds);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's written-through stores have been acknowledged
-      __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(&st->fin_flag[blockIdx.x - 1], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      dbg_stamp(DBG, vb, 7);   // this workgroup's share of the Hessian reduction is out
-    }
   }
   const bool fused = st && seq != 0;
   const bool spare = vb * VPB >= end - head;   // the last workgroup's spare waves: no voxels; in a fused launch they stay for the workgroup's barrier
@@ -1080,7 +994,6 @@ __global__ __launch_bounds__(256) void lm_init_kernel(LMState* stp, PoseArg x0, 
     st->calc_hess = 1; st->done = 0; st->iter = 0; st->converge = 1; st->rejected = 0; st->bench_mode = bench_mode;
     st->n_accept = 0; st->n_reject = 0;
     stp->error = 0;   // a timed-out in-launch solve of an earlier call must not fail this one (the host retries without fusion)
-    // fin_flag needs no reset: launch sequence numbers never repeat within a factor's lifetime
   }
 }
 // stand-alone launch of the damped solve (VXBA_FUSED_SOLVE=0 and the retry after a timed-out in-launch solve; the default runs it
@@ -1158,26 +1071,10 @@ int k2_nparts(int nvoxels, int voxels_per_block) {
   const int vpb = k2_voxels_per_wave(voxels_per_block);
   return nvoxels > 0 ? (nvoxels + vpb - 1) / vpb : 0;
 }
-int fin_workgroups(int W, int nvoxels, int voxels_per_block) {
-  const int vpb = k2_voxels_per_wave(voxels_per_block);
-  const int nwaves = (nvoxels + vpb - 1) / vpb;
-  const int nvw = (nwaves + K2_WAVES - 1) / K2_WAVES;
-  const int groups = ((int)k3_partial_len(W) + FINP_EL - 1) / FINP_EL;
-  const int nwg = nvw < FIN_MAX_WG ? nvw : FIN_MAX_WG;
-  return 2 * nwg >= groups ? nwg : 0;
-}
 int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, int c, unsigned fused_seq, int head, int end, double* d_partial,
-                       int voxels_per_block, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, const double* host_feed, const double* li_rec, double* li_out,
-                       const FinArgs* fin_in) {
-  FinArgs fin;
-  std::memset(&fin, 0, sizeof fin);
-  if (fin_in && st && fused_seq != 0 && !host_feed) {
-    fin = *fin_in;
-    fin.nwg = fin_workgroups(fv.W, end - head, voxels_per_block);
-    if (fin.nwg <= 0) return -1;   // the caller asked fin_workgroups() first
-  }
+                       int voxels_per_block, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, const double* host_feed, const double* li_rec, double* li_out) {
   const int vpb = k2_voxels_per_wave(voxels_per_block);
-  const int vpb_arg = vpb | (voxels_per_block & 0x10000) | (fin.nwg > 0 ? 0x20000 : 0);   // bit 16: the voxel workgroups do not wait for the in-launch solve (test hook); bit 17: FinArgs in use
+  const int vpb_arg = vpb | (voxels_per_block & 0x10000);   // bit 16: the voxel workgroups do not wait for the in-launch solve (test hook)
   const int nblocks = k2_nparts(end - head, voxels_per_block);          // voxel WAVES = partials
   if (nblocks <= 0) return 0;
   const unsigned seq = st ? fused_seq : 0u;
@@ -1188,12 +1085,12 @@ int launch_k2_residual(const FactorView& fv, const PoseArg& poses, LMState* st, 
   const dim3 g(grid), b(K2_THREADS);
   if (fv.cl32) {   // f32 re-centred cluster rows (the caller built them: vxba_capi.hip, residual_view)
     if (ev_start) {
-      VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false, true>), g, b, 0, s, ev_start, ev_stop, 0, st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fin, fv, poses));
-    } else { VXK_DISPATCH_W(fv.W, (k2_residual_kernel<WW, false, true><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fin, fv, poses))); }
-  } else if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fin, fv, poses)); }
+      VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false, true>), g, b, 0, s, ev_start, ev_stop, 0, st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses));
+    } else { VXK_DISPATCH_W(fv.W, (k2_residual_kernel<WW, false, true><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses))); }
+  } else if (dbg) { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW, true><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses)); }
   else if (ev_start) {
-    VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), g, b, 0, s, ev_start, ev_stop, 0, st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fin, fv, poses));
-  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fin, fv, poses)); }
+    VXK_DISPATCH_W(fv.W, hipExtLaunchKernelGGL((k2_residual_kernel<WW, false>), g, b, 0, s, ev_start, ev_stop, 0, st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses));
+  } else { VXK_DISPATCH_W(fv.W, k2_residual_kernel<WW><<<g, b, 0, s>>>(st, c, seq, li_rec, li_out, host_feed, head, end, vpb_arg, head_start, d_partial, fv, poses)); }
   return nblocks;
 }
 
@@ -1371,12 +1268,11 @@ void launch_count_nnz(const FactorView& fv, int V, unsigned long long* d_out, hi
 // what hipMemsetAsync(st, 0, sizeof(LMState)) does to the fields anything reads before writing them (the control scalars of both blocks, the
 // error word) -- without a 70 KB fill in front of the first sweep of a call (the LiDAR-inertial shells reset the state on every call)
 // Coverage (keep in step with LMState): ctl[].{u, v, residual1, residual2, q1, resis, calc_hess, done, iter, converge, rejected, bench_mode, n_accept,
-// n_reject}, error, solve_seq, fin_flag[].  NOT reset, because every reader is preceded by a writer inside the same call: ctl[].x / xt (lm_init or the
+// n_reject}, error, solve_seq.  NOT reset, because every reader is preceded by a writer inside the same call: ctl[].x / xt (lm_init or the
 // shell's pose upload), trace (written per iteration, read up to `iter`), Jwork / Hwork / dxi / hess_out (k3_finalize writes them before the solve
 // reads).  The block is zeroed once at allocation (vxba_create), so a future reader-before-writer sees zeros or a previous call's values, never
 // uninitialised memory.
 __global__ void lm_reset_kernel(LMState* st) {
-  for (int k = threadIdx.x; k < FIN_MAX_WG; k += blockDim.x) st->fin_flag[k] = 0;   // as the full memset did (sequence numbers are monotonic, so a stale flag could not match anyway)
   if (threadIdx.x < 2) {
     LMCtl& c = st->ctl[threadIdx.x];
     c.u = 0; c.v = 0; c.residual1 = 0; c.residual2 = 0; c.q1 = 0; c.resis[0] = 0; c.resis[1] = 0;
