@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-FP64_MFMA_MEASURED_TFLOPS = 73.0   # v_mfma_f64_16x16x4_f64 issue-bound rate, scripts/ubench/mfma_f64_sweep.hip on MI355X
+FP64_MFMA_MEASURED_TFLOPS = 73.0   # v_mfma_f64_16x16x4_f64 issue-bound rate, scripts/ubench/mfma_f64_sweep.hip on MI355X (the 4x4x4_4b form: 17.5 cycles for 512 flops, 94 % of that)
 FP64_SPEC_TFLOPS = 78.6            # vendor figure (not in the local guide)
 
 
@@ -408,12 +408,12 @@ def main():
         k3f_ms = kt2["k3_finalize"]["ms_sum"] / max(1, kt2["k3_finalize"]["calls"])
         achieved = abytes["k3"] / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic_bytes("k3_hessian_kernel", args.config)
-        # fp64 work of one K3 launch: MFMA SYRK (45 MFMAs of 16x16x4x2 flops per batch of 6 voxels: 10 tile pairs x 36 K-steps per
-        # 8 batches) + phase A (~232 f64 VALU instructions per entry, about 1.7 flops each)
+        # fp64 work of one K3 launch: MFMA SYRK (round 5: 120 pairs of 4-column groups, one v_mfma_f64_4x4x4_4b = 512 flops per pair and 16-row
+        # slab, 18 rows per batch of 6 voxels) + phase A (~294 f64 VALU instructions per entry, about 1.7 flops each)
         nbatch = (V + 5) // 6 if W == 10 else 0
-        k3_flops = nbatch * 45 * 2048.0 + nnz * 232.0 * 1.7 if W == 10 else None
+        k3_flops = nbatch * 18 * (120 * 512.0 / 16.0) + nnz * 294.0 * 1.7 if W == 10 else None
         # what one LM step touches: the two sweeps' operands (cl, clb, fix, coe, cache planes read and written) + the workgroup partials
-        working_set = abytes["k3"] + abytes["k2"] + 256 * 22.7e3
+        working_set = abytes["k3"] + abytes["k2"] + 256 * 18.6e3
         out = {
             # N > 1, weak scaling: every GPU iterates on its own cfg-sized shard of an N-times larger window, `value` counts
             # shard-iterations (N per LM iteration of the big window; the iteration rate of that window is config.global_iterations_per_s).
@@ -473,7 +473,7 @@ def main():
                 "mfma": None if not k3_flops else {
                     "bound": "mfma", "unit": "TFLOP/s", "achieved": k3_flops / (k3_ms * 1e-3) / 1e12, "peak": FP64_SPEC_TFLOPS,
                     "frac": k3_flops / (k3_ms * 1e-3) / 1e12 / FP64_SPEC_TFLOPS,
-                    "note": "issued fp64 work of one launch (MFMA tiles incl. the upper-triangle padding + phase-A VALU), DESIGN.md 5.1",
+                    "note": "issued fp64 work of one launch (120 block pairs of the upper triangle + phase-A VALU), DESIGN.md 5.1",
                     "flops_per_launch": k3_flops, "mfma_f64_measured_peak_tflops": FP64_MFMA_MEASURED_TFLOPS},
                 "avg_launch_ms": k3_ms,
                 "launches": kt["k3_hessian"]["launches_timed"],
