@@ -597,7 +597,7 @@ def bench_cfg5(args, rank, world, local_rank, use_dist, backend, real_stdout):
         if pr["launches"]:
             avg_ms = pr["ms_sum"] / pr["launches"]
             ach = pr["algorithmic_bytes"] / (pr["ms_sum"] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k1_build_kernel<true> (cluster build inside the voxeliser: vxba_voxelize_push_device)", "achieved": ach, "peak": HBM_PEAK_GBS,
+            roof = {"bound": "hbm", "kernel": "k1_build_rows_kernel (cluster build inside the voxeliser: vxba_voxelize_push_device)", "achieved": ach, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                     "traffic_source": "no --pmc pass collected for this configuration",
                     "avg_launch_ms": avg_ms, "launches": pr["launches"], "algorithmic_bytes_per_launch": pr["algorithmic_bytes"] / pr["launches"],

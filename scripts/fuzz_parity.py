@@ -39,8 +39,8 @@ for case in range(n_cases):
         W = int(rng.integers(11, 40)) if kind == "wide" else int(rng.integers(2, 11))
         V = int(rng.integers(150, 3000)); pts = int(V * rng.uniform(8, 20))   # >= 8 points per (voxel, frame): fewer make rank-deficient voxels no map would hand over
         if big:
-            nt = (6 * W + 15) // 16
-            nv = min(64 // W, 12 if nt <= 2 else (8 if nt == 3 else 6))
+            from tests.test_k3_mapping_model import k3_nv
+            nv = k3_nv(W)        # voxels per wave-batch of the Hessian sweep (round 5: the rule of csrc/vxba_kernels.h)
             V = nv * (2048 * int(rng.integers(1, 4)) + int(rng.integers(0, 2048))) + int(rng.integers(0, nv)); pts = V * 9
         p_obs = float(rng.choice([1.0, 0.8, 0.4])) if kind != "wide" else float(rng.uniform(0.1, 0.4))
         sc = synth.make_scene(win_size=W, pts_per_scan=pts, n_voxels=V, p_obs=p_obs, fix_frac=float(rng.choice([0.0, 0.3])), seed=s,
@@ -232,6 +232,29 @@ for case in range(n_cases):
         desc = "win=%d pts=%d scans=%d release every %d at age %d: %d roots released, %d left" % (win, ptsn, S, every, age, gone, ma.counts()["roots"])
         for h in (ma, mb, fa, fb):
             h.close()
+    elif kind == "hba":
+        # the bottom-up pass of the hierarchical BA below the C ABI (vxba_hba_pass: resident keyframes, two streams, submaps on the device) against the
+        # window-by-window orchestration of the same calls from Python (hba.hierarchical_ba, itself checked against the oracle in tests/test_gpu_hba.py)
+        from voxel_slam_amd import hba
+        wd = int(rng.integers(4, 9)); mg = int(rng.integers(2, wd)); S_ = int(rng.integers(3, 14)); K = wd + mg * (S_ - 1) + int(rng.integers(0, mg)); ptsn = int(rng.integers(2500, 6000))
+        xyz, fp, poses, _ = synth.make_scans(win_size=K, pts_per_scan=ptsn, extent=24.0, noise=0.005, seed=s, rot_sigma_deg=float(rng.choice([0.05, 0.15])), trans_sigma=0.02)
+        clouds = [xyz[fp[i]:fp[i + 1]].astype(np.float32) for i in range(K)]
+        coarse = vxba.VoxelizeParams(voxel_size=2.0, max_layer=2, min_points=10, min_eigen_value=0.02, eigen_ratio=(1 / 9, 1 / 9, 1 / 9, 1 / 9))
+        fine = vxba.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
+        tmi = int(rng.integers(1, 4)); nth = int(rng.integers(1, 3))
+        ref = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=wd, mgsize=mg, top_max_iter=tmi)
+        ses = vxba.HbaSession(); ses.add_keyframes(clouds)
+        got = ses.run_pass(poses, coarse, fine, wdsize=wd, mgsize=mg, top_max_iter=tmi, n_threads=nth)
+        ses.close()
+        ds_ = np.abs(np.asarray(got["submap_sizes"]) - np.asarray(ref["submap_sizes"]))
+        et, er = synth.pose_errors(got["submap_poses"], ref["submap_poses"])
+        check(got["submap_ids"] == ref["submap_ids"] and ds_.max() <= 2, "hba: submaps differ (max %d points) K=%d wd=%d mg=%d seed=%d" % (int(ds_.max()), K, wd, mg, s))
+        check(len(got["top_rounds"]) == len(ref["top_rounds"]) and all(abs(a["n_voxels"] - b["n_voxels"]) <= 2 + 0.002 * b["n_voxels"] for a, b in zip(got["top_rounds"], ref["top_rounds"])),
+              "hba: top-level rounds %s vs %s K=%d seed=%d" % ([r["n_voxels"] for r in got["top_rounds"]], [r["n_voxels"] for r in ref["top_rounds"]], K, s))
+        check(et < 1e-6 and er < 1e-6, "hba: submap poses %.2e %.2e K=%d wd=%d mg=%d seed=%d" % (et, er, K, wd, mg, s))
+        check(len(got["edges1"]) == len(ref["edges1"]) and all((a["i"], a["j"]) == (b["i"], b["j"]) and np.allclose(a["v6"], b["v6"], rtol=1e-9) for a, b in zip(got["edges1"], ref["edges1"])),
+              "hba: bottom-level edges differ K=%d seed=%d" % (K, s))
+        desc = "K=%d wd=%d mg=%d pts=%d top rounds %d threads %d: %d submaps, %d + %d edges, pose diff %.1e/%.1e" % (K, wd, mg, ptsn, tmi, nth, len(got["submap_ids"]), len(got["edges1"]), len(got["edges2"]), et, er)
     elif kind == "planes":
         # per-leaf producers of the plane map: clusters, eigen-decomposition, cov_add, plane_update
         n_leaf = int(rng.integers(50, 3000))

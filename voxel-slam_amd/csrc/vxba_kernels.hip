@@ -764,6 +764,57 @@ __global__ __launch_bounds__(256) void k1_build_kernel(const double* __restrict_
   }
 }
 
+// K1 for packed cells (the voxeliser's cell / node clusters, vxba_build_clusters), round 5: SIXTEEN LANES PER CELL.  k1_build_kernel<true> above gives
+// every lane a cell of its own -- fine for the frame-major planes of push_points (hundreds of thousands of small cells), but the voxeliser's launches
+// are 5k-40k cells of 5-400 points: 20-160 workgroups, each lane streaming its own cell from memory point by point (24-byte strided loads) -- 50 us
+// per launch, 0.04 of the HBM roofline, the dominant kernel of a hierarchical-BA pass (profiles/r05_cfg5).  Here a 16-lane row takes one cell: the
+// lanes load sixteen consecutive points (one coalesced 384-byte run), every lane then folds those sixteen points IN ORDER out of its neighbours'
+// registers (v_mov_b64_dpp row_newbcast: no LDS, no barrier) -- the sums are the sequential sums of PointCluster::push, bit for bit, sixteen times
+// over -- and lane 0 of the row stores them.  Sixteen cells per workgroup: ten to a hundred times as many workgroups in flight.
+template <int K>
+__device__ __forceinline__ double row_bcast(double v) {   // lane K of the caller's 16-lane row, to every lane of that row
+  typedef long long i64;
+  return __builtin_bit_cast(double, (i64)__builtin_amdgcn_update_dpp((i64)0, __builtin_bit_cast(i64, v), 0x150 + K, 0xf, 0xf, false));
+}
+template <int K>
+__device__ __forceinline__ void k1_fold16(double x, double y, double z, long long left, double& P0, double& P1, double& P2, double& P3, double& P4, double& P5, double& vx,
+                                          double& vy, double& vz, double& N) {
+#pragma clang fp contract(off)
+  if constexpr (K < 16) {
+    // points behind the cell's end arrive as (+0, +0, +0): adding their products and themselves changes no sum; only the count is gated
+    const double a = row_bcast<K>(x), b = row_bcast<K>(y), c = row_bcast<K>(z);
+    N += (K < left) ? 1.0 : 0.0;
+    P0 += a * a; P1 += a * b; P2 += a * c; P3 += b * b; P4 += b * c; P5 += c * c;
+    vx += a; vy += b; vz += c;
+    k1_fold16<K + 1>(x, y, z, left, P0, P1, P2, P3, P4, P5, vx, vy, vz, N);
+  }
+}
+__global__ __launch_bounds__(256) void k1_build_rows_kernel(const double* __restrict__ xyz, const long long* __restrict__ cell_ptr, long long ncells,
+                                                            double* __restrict__ aos) {
+#pragma clang fp contract(off)
+  const int gl = threadIdx.x & 15;
+  const long long c = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  long long lo = 0, hi = 0;
+  if (c < ncells) { lo = cell_ptr[c]; hi = cell_ptr[c + 1]; }
+  const bool is_long = hi - lo > K1_LONG;               // left to k1_long_cells_kernel
+  if (is_long) hi = lo;
+  double P0 = 0, P1 = 0, P2 = 0, P3 = 0, P4 = 0, P5 = 0, vx = 0, vy = 0, vz = 0, N = 0;
+  // rows of one wave run as long as the longest of their four cells (a row that is done folds zeros)
+  long long span = hi - lo;
+  span = max(span, __shfl_xor(span, 16));
+  span = max(span, __shfl_xor(span, 32));
+  for (long long q0 = 0; q0 < span; q0 += 16) {
+    const long long q = lo + q0 + gl;
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (q < hi) { x = xyz[3 * q]; y = xyz[3 * q + 1]; z = xyz[3 * q + 2]; }
+    k1_fold16<0>(x, y, z, hi - lo - q0, P0, P1, P2, P3, P4, P5, vx, vy, vz, N);
+  }
+  if (gl == 0 && c < ncells && !is_long) {                // an empty cell gets its ten zeros, as before
+    double* o = aos + 10 * c;
+    o[0] = P0; o[1] = P1; o[2] = P2; o[3] = P3; o[4] = P4; o[5] = P5; o[6] = vx; o[7] = vy; o[8] = vz; o[9] = N;
+  }
+}
+
 // Long cells (> K1_LONG points): one workgroup per cell, points staged through LDS tile by tile, thread t folds points 4t .. 4t+3 of
 // every tile, fixed-order tree over the 256 partial clusters.
 __global__ __launch_bounds__(256) void k1_long_cells_kernel(const double* __restrict__ xyz, const long long* __restrict__ cell_ptr, long long ncells,
@@ -1200,12 +1251,12 @@ void launch_k4_plane_fit(const double* d_clusters, int64_t n, double* d_eigval, 
 }
 void launch_k1_build_aos(const double* d_xyz, const int64_t* d_cell_ptr, int64_t n_cells, double* d_clusters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (n_cells <= 0) return;
-  FactorView fv{};
-  if (ev_start)   // events tied to the dispatch of k1_build_kernel itself (the interval rocprofv3 reports)
-    hipExtLaunchKernelGGL((k1_build_kernel<true>), dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s, ev_start, ev_stop, 0, d_xyz, (const long long*)d_cell_ptr, 0, 0, fv, 0,
-                          d_clusters, (long long)n_cells);
+  // sixteen lanes per cell (k1_build_rows_kernel); same-box A/B against one lane per cell on a cfg5 pass: 28.3 against 52.3 us per launch (606 launches)
+  const dim3 grid_rows((unsigned)((n_cells + 15) / 16));
+  if (ev_start)   // events tied to the dispatch itself (the interval rocprofv3 reports)
+    hipExtLaunchKernelGGL(k1_build_rows_kernel, grid_rows, dim3(256), 0, s, ev_start, ev_stop, 0, d_xyz, (const long long*)d_cell_ptr, (long long)n_cells, d_clusters);
   else
-    k1_build_kernel<true><<<dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s>>>(d_xyz, (const long long*)d_cell_ptr, 0, 0, fv, 0, d_clusters, (long long)n_cells);
+    k1_build_rows_kernel<<<grid_rows, dim3(256), 0, s>>>(d_xyz, (const long long*)d_cell_ptr, (long long)n_cells, d_clusters);
   const long long tiles = (n_cells + 63) / 64;
   k1_long_cells_kernel<<<dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, s>>>(d_xyz, (const long long*)d_cell_ptr, (long long)n_cells, d_clusters);
 }
