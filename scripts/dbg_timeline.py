@@ -21,9 +21,20 @@ if which == "solve":
     st = vxba.debug_stamps(4001).astype(np.int64)[4000, :6]
     print("solve kernel stamps (cycles since start):", st - st[0])
     sys.exit(0)
-if which == "fused":
+if which in ("fused", "fused_li"):
     from voxel_slam_amd.vxba import Lidar_BA_Optimizer
-    Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=1)
+    if which == "fused_li":   # the residual-sweep launch of the LiDAR-inertial shell (pose system solved in the launch from the host's record)
+        f.snapshot_cache()
+        iw = synth.make_imu(sc)
+        facs = []
+        for gyr, acc, dts in iw.samples:
+            fac = vxba.IMU_PRE(iw.states_init[0, 15:18], iw.states_init[0, 18:21])
+            for g, a, dt in zip(gyr, acc, dts):
+                fac.add_imu(g, a, dt, iw.noise_meas, iw.noise_walk)
+            facs.append(fac)
+        vxba.LI_BA_Optimizer().damping_iter(iw.states_init, f, facs, max_iter=1)
+    else:
+        Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=1)
     full = vxba.debug_stamps(4096).astype(np.int64)
     sol = full[4000, :6]
     n = (sc.n_voxels + 63) // 64
