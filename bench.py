@@ -221,7 +221,7 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--keyframes", type=int, default=500, help="--config cfg5: keyframes of the session")
     ap.add_argument("--keyframe-points", type=int, default=20_000, help="--config cfg5: points per keyframe")
-    ap.add_argument("--hba-threads", type=int, default=2, help="--config cfg5 on one GPU: host threads / streams of the bottom level (1 or 2)")
+    ap.add_argument("--hba-threads", type=int, default=4, help="--config cfg5 on one GPU: host threads / streams of the bottom level (1 .. 8)")
     ap.add_argument("--steps-per-solve", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=15,
                     help="the timed region (barrier + sync, exactly --steps steps, barrier + sync) is run this many times back to back; value / ms_per_step / "

@@ -241,7 +241,7 @@ for case in range(n_cases):
         clouds = [xyz[fp[i]:fp[i + 1]].astype(np.float32) for i in range(K)]
         coarse = vxba.VoxelizeParams(voxel_size=2.0, max_layer=2, min_points=10, min_eigen_value=0.02, eigen_ratio=(1 / 9, 1 / 9, 1 / 9, 1 / 9))
         fine = vxba.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
-        tmi = int(rng.integers(1, 4)); nth = int(rng.integers(1, 3))
+        tmi = int(rng.integers(1, 4)); nth = int(rng.integers(1, 9))
         ref = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=wd, mgsize=mg, top_max_iter=tmi)
         ses = vxba.HbaSession(); ses.add_keyframes(clouds)
         got = ses.run_pass(poses, coarse, fine, wdsize=wd, mgsize=mg, top_max_iter=tmi, n_threads=nth)

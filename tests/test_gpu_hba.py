@@ -84,7 +84,7 @@ def test_hierarchical_pass_matches_oracle(K, wdsize, mgsize):
     assert e1[0] < e0[0]
 
 
-@pytest.mark.parametrize("K,wdsize,mgsize,threads", [(45, 6, 3, 1), (105, 10, 5, 2)])
+@pytest.mark.parametrize("K,wdsize,mgsize,threads", [(45, 6, 3, 1), (105, 10, 5, 2), (105, 10, 5, 8)])
 def test_hba_pass_below_the_c_abi_matches_the_python_orchestration(K, wdsize, mgsize, threads):
     """vxba_hba_pass (csrc/vxba_hba.hip: keyframes resident on the device, windows over two streams, submaps merged and voxel-filtered on the
     device) against hba.hierarchical_ba, which makes the same C-ABI calls window by window from Python with the submaps going through numpy.
@@ -134,7 +134,7 @@ def test_cfg5_size_pass_500_keyframes_matches_oracle(pts):
     fine = vxba.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
     ses = vxba.HbaSession()
     ses.add_keyframes(clouds)
-    got = ses.run_pass(poses, coarse, fine, wdsize=10, mgsize=5, top_max_iter=2, n_threads=2)
+    got = ses.run_pass(poses, coarse, fine, wdsize=10, mgsize=5, top_max_iter=2, n_threads=4)
     ses.close()
     ref = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=10, mgsize=5, top_max_iter=2, optimizer=_OracleOpt(), voxelize=_oracle_voxelize,
                               downsample=O.down_sampling_voxel)

@@ -539,15 +539,15 @@ static int voxelize_push_impl(vxba_factor* f, int64_t n_points, const double* xy
       vxk::launch_build_clb(fv, v0, (int)n, f->stream);
       clusters_written(f, v0);
     }
-    vxk::launch_scatter_rows(d_fix, fv.fix, f->VS, v0, (int)n, 10, f->stream);
-    vxk::launch_scatter_rows(d_coe, fv.coe, f->VS, v0, (int)n, 1, f->stream);
-    vxk::launch_scatter_rows(d_ev, fv.eigval, f->VS, v0, (int)n, 3, f->stream);
-    vxk::launch_scatter_rows(d_evec, fv.eigvec, f->VS, v0, (int)n, 9, f->stream);
-    vxk::launch_scatter_rows(d_m, fv.merged, f->VS, v0, (int)n, 10, f->stream);
+    vxk::launch_scatter_voxel_records(d_fix, d_coe, d_ev, d_evec, d_m, fv, v0, (int)n, f->stream);
     vxk::launch_seed_aux(fv, v0, v0 + (int)n, f->stream);
     if (node_ids && ids_capacity > 0)
       VX_HIP(f, hipMemcpyAsync(node_ids, d_id, (size_t)std::min<int64_t>(n, ids_capacity) * sizeof(uint64_t), hipMemcpyDeviceToHost, f->stream));
-    VX_HIP(f, hipStreamSynchronize(f->stream));
+    {   // completion by polling (a blocking wait parks the thread: ~25 us to wake up from, and a hierarchical pass makes thousands of them)
+      hipError_t q;
+      while ((q = hipStreamQuery(f->stream)) == hipErrorNotReady) {}
+      VX_HIP(f, q);
+    }
     VX_HIP(f, hipGetLastError());
     f->V += (int)n;
     f->wide_dirty = true;

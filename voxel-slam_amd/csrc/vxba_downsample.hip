@@ -118,9 +118,16 @@ int downsample_device(Scratch& sc, hipStream_t s, const float* d_in, int64_t n, 
   DS(rocprim::radix_sort_pairs(d_temp, tt, d_key, d_key_s, d_idx, d_idx_s, (size_t)n, 0, 63, s));
   tt = t;
   DS(rocprim::run_length_encode(d_temp, tt, d_key_s, (size_t)n, d_ukey, d_cnt, d_runs, s));
-  DS(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s));
-  DS(hipMemcpyAsync(&runs, d_runs, 4, hipMemcpyDeviceToHost, s));
-  DS(hipStreamSynchronize(s));
+  if (!sc.pinned) DS(hipHostMalloc((void**)&sc.pinned, 64, hipHostMallocDefault));
+  DS(hipMemcpyAsync(sc.pinned, d_err, 4, hipMemcpyDeviceToHost, s));
+  DS(hipMemcpyAsync(sc.pinned + 1, d_runs, 4, hipMemcpyDeviceToHost, s));
+  {   // by polling: a blocking wait parks the thread (~25 us to wake up from); pinned destination: a copy into pageable memory is staged and waited for
+    hipError_t q;
+    while ((q = hipStreamQuery(s)) == hipErrorNotReady) {}
+    DS(q);
+  }
+  err = (int)((volatile unsigned int*)sc.pinned)[0];
+  runs = ((volatile unsigned int*)sc.pinned)[1];
   if (err) return VXBA_ERR_ARG;   // a voxel index outside [-2^20, 2^20)
   ds_widen_kernel<<<grid1, 256, 0, s>>>(d_cnt, (long long)runs, d_ptr);
   DS(hipGetLastError());

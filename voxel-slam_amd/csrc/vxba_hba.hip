@@ -11,8 +11,9 @@
 // (vxba_hba_add_keyframes) and everything per window happens on the device:
 //   widen (f32 -> f64 of the window's contiguous run of points)  ->  vxba_voxelize_push_device  ->  vxba_damping_iter
 //   ->  transform into the first keyframe's coordinates (float, like PointType)  ->  voxel filter (device to device)
-// with the submaps staying in HBM for the top level.  Two host threads drive two streams (two bottom-level factors): while one waits
-// for the few counters a voxelisation brings back, the other's kernels run.  Only poses, Hessians and counts cross PCIe.
+// with the submaps staying in HBM for the top level.  Up to eight host threads drive a stream and a bottom-level factor each (four by default: 0.162 / 0.113 / 0.088-0.094 / 0.092-0.095 s per
+// 500-keyframe pass with 1 / 2 / 4 / 6 threads on one box): while one waits for the few counters a voxelisation brings back -- polled out of
+// pinned host memory, not waited for in the runtime --, the others' kernels run.  Only poses, Hessians and counts cross PCIe.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -48,6 +49,7 @@ __global__ void merge_kernel(const float* __restrict__ src, long long n, FrameXf
   for (int j = 0; j < 3; j++) dst[3 * q + j] = (float)(((x * t[3 * j] + y * t[3 * j + 1]) + z * t[3 * j + 2]) + t[9 + j]);
 }
 
+constexpr int MAX_THREADS = 8;   // host threads / streams of the bottom level
 struct Worker {
   vxba_factor* f = nullptr;
   hipStream_t s = nullptr;
@@ -67,7 +69,7 @@ struct vxba_hba {
   float* d_xyz = nullptr;              // every keyframe cloud, in order
   size_t cap_pts = 0, n_pts = 0;
   std::vector<int64_t> cloud_ptr{0};   // K + 1 offsets into d_xyz (points)
-  vxhba::Worker wk[2];
+  vxhba::Worker wk[vxhba::MAX_THREADS];
   int bottom_w = 0;
   vxba_factor* top = nullptr;
   int top_w = 0;
@@ -214,7 +216,7 @@ int vxba_hba_pass(vxba_hba* h, const double* poses, const vxba_voxelize_params* 
   const int S = (K - wdsize) / mgsize + 1;
   if (S > VXBA_MAX_WIN_WIDE) return fail(h, VXBA_ERR_UNSUPPORTED, "hba_pass: more submaps than VXBA_MAX_WIN_WIDE");
   if (top_max_iter < 1) top_max_iter = 1;
-  n_threads = n_threads < 1 ? 1 : (n_threads > 2 ? 2 : n_threads);
+  n_threads = n_threads < 1 ? 1 : (n_threads > vxhba::MAX_THREADS ? vxhba::MAX_THREADS : n_threads);
   HB(hipSetDevice(h->device));
   // ---- resources -------------------------------------------------------------------------------------------------------------
   std::vector<int64_t> sub_off(S + 1, 0);
@@ -298,9 +300,10 @@ int vxba_hba_pass(vxba_hba* h, const double* poses, const vxba_voxelize_params* 
   for (int t = 0; t < n_threads; t++) { h->wk[t].rc = VXBA_OK; h->wk[t].err.clear(); }
   if (n_threads == 1) run(0);
   else {
-    std::thread th(run, 1);
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; t++) th.emplace_back(run, t);
     run(0);
-    th.join();
+    for (std::thread& x : th) x.join();
   }
   for (int t = 0; t < n_threads; t++) {
     if (h->wk[t].rc != VXBA_OK) return fail(h, h->wk[t].rc, h->wk[t].err);

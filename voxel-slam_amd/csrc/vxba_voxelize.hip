@@ -219,29 +219,36 @@ struct ArenaSlot {
   std::mutex mtx;
   char* base = nullptr;
   size_t cap = 0;
+  unsigned long long* pinned = nullptr;   // READBACK_WORDS words of pinned host memory: where the counts a call needs on the host come down
 };
-static ArenaSlot g_arena[16][2];
+constexpr int READBACK_WORDS = 16;
+constexpr int ARENA_SLOTS = 8;   // per device: vxba_hba_pass drives up to eight host threads / streams that voxelise concurrently
+static ArenaSlot g_arena[16][ARENA_SLOTS];
 // vxba_voxelize_profile: time of / bytes moved by the cluster-build kernel inside the voxeliser (the dominant kernel of a hierarchical-BA pass)
 struct K1Prof { std::atomic<int> on{0}; std::mutex m; double ms = 0, bytes = 0; long long launches = 0; };
-static K1Prof g_k1prof;   // two per device: two host threads (vxba_hba_pass drives two streams) voxelise concurrently
+static K1Prof g_k1prof;
 struct DevBuf {
   char* base = nullptr;
   size_t cap = 0, used = 0;
   ArenaSlot* slot = nullptr;
   bool own = false;
+  unsigned long long* host = nullptr;     // pinned read-back words (the slot's, or this call's own)
   ~DevBuf() {
     if (own && base) hipFree(base);
+    if (own && host) hipHostFree(host);
     if (slot) slot->mtx.unlock();
   }
   hipError_t reserve(size_t bytes) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || bytes > ((size_t)2 << 30)) {   // no cache slot / too big to keep: private to this call
       own = true; cap = bytes;
+      hipError_t e = hipHostMalloc((void**)&host, READBACK_WORDS * sizeof(unsigned long long), hipHostMallocDefault);
+      if (e != hipSuccess) return e;
       return hipMalloc((void**)&base, bytes);
     }
-    if (g_arena[dev][0].mtx.try_lock()) slot = &g_arena[dev][0];
-    else if (g_arena[dev][1].mtx.try_lock()) slot = &g_arena[dev][1];
-    else { slot = &g_arena[dev][0]; slot->mtx.lock(); }
+    for (int k = 0; k < ARENA_SLOTS && !slot; k++)
+      if (g_arena[dev][k].mtx.try_lock()) slot = &g_arena[dev][k];
+    if (!slot) { slot = &g_arena[dev][0]; slot->mtx.lock(); }
     if (bytes > slot->cap) {
       if (slot->base) { hipDeviceSynchronize(); hipFree(slot->base); }
       slot->base = nullptr; slot->cap = 0;
@@ -250,9 +257,27 @@ struct DevBuf {
       if (e != hipSuccess) return e;
       slot->cap = want;
     }
-    base = slot->base; cap = slot->cap;
+    if (!slot->pinned) {
+      hipError_t e = hipHostMalloc((void**)&slot->pinned, READBACK_WORDS * sizeof(unsigned long long), hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+    }
+    base = slot->base; cap = slot->cap; host = slot->pinned;
     return hipSuccess;
   }
+  // A count the host needs (launch sizes, capacities): copied into pinned word k behind the work queued on s -- a copy into PAGEABLE memory
+  // (a stack variable) is staged and waited for inside the runtime, and hipStreamSynchronize parks the thread; a hierarchical-BA pass makes
+  // ~2600 such round trips, from several host threads.  wait(): spin on the stream's state instead.
+  hipError_t fetch(int k, const void* d_src, size_t bytes, hipStream_t s) {
+    host[k] = 0;
+    return hipMemcpyAsync(host + k, d_src, bytes, hipMemcpyDeviceToHost, s);
+  }
+  static hipError_t wait(hipStream_t s) {
+    hipError_t q;
+    while ((q = hipStreamQuery(s)) == hipErrorNotReady) {}
+    return q;
+  }
+  unsigned int u32(int k) const { return (unsigned int)(*(volatile unsigned long long*)(host + k) & 0xffffffffull); }
+  long long i64(int k) const { return (long long)*(volatile unsigned long long*)(host + k); }
   template <class T>
   hipError_t alloc(T** p, size_t n) {
     const size_t bytes = (((n > 0 ? n : 1) * sizeof(T)) + 255) & ~(size_t)255;
@@ -316,10 +341,9 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
   char* d_temp;
   VV(B.alloc(&d_temp, tb));
 
-  int h_err = 0;
-  VV(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, s));
-  VV(hipStreamSynchronize(s));
-  if (h_err) { *err_out = range_msg; return -1; }
+  VV(B.fetch(0, d_err, sizeof(int), s));
+  VV(B.wait(s));
+  if (B.u32(0)) { *err_out = range_msg; return -1; }
   if (sharded && n > 0) {
     // this shard's points to the front, cloud order kept (the cluster sums below are in point order): everything behind works on the n_keep
     // points of whole root voxels, so each of its factor voxels is bit for bit the one the unsharded run produces
@@ -329,12 +353,11 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
     shard_flag_kernel<<<grid_for(n), 256, 0, s>>>(d_key, n, p.shard_index, p.shard_count, d_flag);
     size_t t = tb;
     VV(rocprim::exclusive_scan(d_temp, t, d_flag, d_pos, 0u, (size_t)n, rocprim::plus<unsigned int>(), s));
-    unsigned int last[2] = {0, 0};
-    VV(hipMemcpyAsync(&last[0], d_pos + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-    VV(hipMemcpyAsync(&last[1], d_flag + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    VV(B.fetch(1, d_pos + (n - 1), sizeof(unsigned int), s));
+    VV(B.fetch(2, d_flag + (n - 1), sizeof(unsigned int), s));
     shard_compact_kernel<<<grid_for(n), 256, 0, s>>>(d_flag, d_pos, n, d_xyz_local, d_world, d_key, d_loc_c, d_wld_c, d_key_c);
-    VV(hipStreamSynchronize(s));
-    n = (long long)last[0] + (long long)last[1];
+    VV(B.wait(s));
+    n = (long long)B.u32(1) + (long long)B.u32(2);
     d_xyz_local = d_loc_c; d_world = d_wld_c; d_key = d_key_c;
     if (n == 0) { out->n_entries = 0; return 0; }
   }
@@ -352,9 +375,9 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
     // (node, frame) cells
     t = tb;
     VV(rocprim::run_length_encode(d_temp, t, d_lkey_s, (size_t)n, d_cell_key, d_cell_cnt, d_runs, s));
-    unsigned int n_cells = 0;
-    VV(hipMemcpyAsync(&n_cells, d_runs, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-    VV(hipStreamSynchronize(s));
+    VV(B.fetch(3, d_runs, sizeof(unsigned int), s));
+    VV(B.wait(s));
+    const unsigned int n_cells = B.u32(3);
     widen_kernel<<<grid_for(n_cells), 256, 0, s>>>(d_cell_cnt, n_cells, d_tmp64);
     t = tb;
     VV(rocprim::exclusive_scan(d_temp, t, d_tmp64, d_cell_ptr, 0ll, (size_t)n_cells + 1, rocprim::plus<long long>(), s));
@@ -363,9 +386,9 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
     VV(B.alloc(&d_node_key[layer], n_cells));
     t = tb;
     VV(rocprim::run_length_encode(d_temp, t, d_cell_node, (size_t)n_cells, d_node_key[layer], d_node_ncell, d_runs, s));
-    unsigned int n_nodes = 0;
-    VV(hipMemcpyAsync(&n_nodes, d_runs, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-    VV(hipStreamSynchronize(s));
+    VV(B.fetch(4, d_runs, sizeof(unsigned int), s));
+    VV(B.wait(s));
+    const unsigned int n_nodes = B.u32(4);
     n_nodes_l[layer] = n_nodes;
     widen_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_node_ncell, n_nodes, d_tmp64);
     t = tb;
@@ -403,9 +426,10 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
     VV(rocprim::exclusive_scan(d_temp, t, d_flag, d_pos, 0u, (size_t)n_nodes, rocprim::plus<unsigned int>(), s));
     unsigned int last_pos = 0, last_flag = 0;
     if (n_nodes > 0) {
-      VV(hipMemcpyAsync(&last_pos, d_pos + n_nodes - 1, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-      VV(hipMemcpyAsync(&last_flag, d_flag + n_nodes - 1, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-      VV(hipStreamSynchronize(s));
+      VV(B.fetch(5, d_pos + n_nodes - 1, sizeof(unsigned int), s));
+      VV(B.fetch(6, d_flag + n_nodes - 1, sizeof(unsigned int), s));
+      VV(B.wait(s));
+      last_pos = B.u32(5); last_flag = B.u32(6);
     }
     const long long n_acc = (long long)last_pos + last_flag;
     if (total + n_acc > out->capacity) { *err_out = cap_msg; return -1; }
@@ -413,9 +437,9 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
       entry_count_kernel<<<grid_for((long long)n_nodes + 1), 256, 0, s>>>(d_state[layer], d_node_ncell, n_nodes, d_tmp64);
       t = tb;
       VV(rocprim::exclusive_scan(d_temp, t, d_tmp64, d_epos, 0ll, (size_t)n_nodes + 1, rocprim::plus<long long>(), s));
-      long long n_ent = 0;
-      VV(hipMemcpyAsync(&n_ent, d_epos + n_nodes, sizeof(long long), hipMemcpyDeviceToHost, s));
-      VV(hipStreamSynchronize(s));
+      VV(B.fetch(7, d_epos + n_nodes, sizeof(long long), s));
+      VV(B.wait(s));
+      const long long n_ent = B.i64(7);
       if (total_entries + n_ent > out->ecap) { *err_out = cap_msg; return -1; }
       emit_csr_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_state[layer], d_pos, d_epos, n_nodes, layer, d_node_key[layer], d_node_cell_ptr, d_cell_key, d_cell_cl,
                                                        d_node_cl, d_eigval, d_eigvec, total, total_entries, out->d_clusters, out->d_eframe, out->d_row_ptr,
@@ -427,7 +451,7 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
     total += n_acc;
   }
   out->n_entries = total_entries;
-  VV(hipStreamSynchronize(s));
+  VV(B.wait(s));
   VV(hipGetLastError());
   return total;
 }

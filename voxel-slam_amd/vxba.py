@@ -887,7 +887,7 @@ class HbaSession:
     def clear(self):
         self._check(self._L.vxba_hba_clear(self._h), "vxba_hba_clear")
 
-    def run_pass(self, poses, coarse: VoxelizeParams, fine: VoxelizeParams, wdsize: int = 10, mgsize: int = 5, top_max_iter: int = 1, n_threads: int = 2):
+    def run_pass(self, poses, coarse: VoxelizeParams, fine: VoxelizeParams, wdsize: int = 10, mgsize: int = 5, top_max_iter: int = 1, n_threads: int = 4):
         """One bottom-up pass; returns what ``hba.hierarchical_ba`` returns (edges as dicts with keyframe indices)."""
         poses = _c(poses).reshape(-1, 12)
         K = poses.shape[0]
