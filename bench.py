@@ -221,7 +221,7 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--keyframes", type=int, default=500, help="--config cfg5: keyframes of the session")
     ap.add_argument("--keyframe-points", type=int, default=20_000, help="--config cfg5: points per keyframe")
-    ap.add_argument("--hba-threads", type=int, default=4, help="--config cfg5 on one GPU: host threads / streams of the bottom level (1 .. 8)")
+    ap.add_argument("--hba-threads", type=int, default=0, help="--config cfg5 on one GPU: host threads / streams of the bottom level (1 .. 8; 0 = the library picks: 4, fewer under a small cgroup CPU quota)")
     ap.add_argument("--steps-per-solve", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=15,
                     help="the timed region (barrier + sync, exactly --steps steps, barrier + sync) is run this many times back to back; value / ms_per_step / "
@@ -578,11 +578,13 @@ def bench_cfg5(args, rank, world, local_rank, use_dist, backend, real_stdout):
     for _ in range(max(0, warmup)):
         out = one_pass()
     sync()
+    host0 = host_cpu_state()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = one_pass()
     sync()
     elapsed = time.perf_counter() - t0
+    host1 = host_cpu_state()
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -614,11 +616,15 @@ def bench_cfg5(args, rank, world, local_rank, use_dist, backend, real_stdout):
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": f"cfg5: {K} keyframes x {args.keyframe_points} points, {S} bottom-level windows, top level {S} submap poses / {int(np.sum(out['submap_sizes']))} points",
                            "parallelism": "bottom-level windows round-robin over ranks (replicas); top level voxel-sharded by root-voxel hash + all-reduce of [Hess|JacT|res]" if use_dist
-                                          else f"one GPU, the pass below the C ABI (vxba_hba_pass), bottom-level windows over {args.hba_threads} host thread(s) / stream(s)",
+                                          else f"one GPU, the pass below the C ABI (vxba_hba_pass), bottom-level windows over {out.get('n_threads_used', args.hba_threads)} host thread(s) / stream(s)",
                            "top_packed_bytes": 8 * (36 * S * S + 6 * S + 1), "top_rounds": [dict(n_voxels_this_rank=r["n_voxels"], resis=r["resis"]) for r in out["top_rounds"]],
                            "edges": [len(out["edges1"]), len(out["edges2"])], "anchor_error_before_m_rad": [float(x) for x in e0], "anchor_error_after_m_rad": [float(x) for x in e1],
                            "session_generation_s": t_gen},
                 "roofline": roof, "cpu_baseline": cpu,
+                "host": {"nproc": host1["nproc"], "cgroup_cpu_max": host1["cpu_max"], "quota_cores": host1["quota_cores"],
+                         "throttled_s_in_timed_region": None if host0["throttled_usec"] is None or host1["throttled_usec"] is None
+                         else (host1["throttled_usec"] - host0["throttled_usec"]) * 1e-6,
+                         "hba_threads_used": out.get("n_threads_used")},
                 "note": "secondary workload (BASELINE configs[4]); the headline metric is the default cfg2 line"}
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if ses is not None:
@@ -626,6 +632,26 @@ def bench_cfg5(args, rank, world, local_rank, use_dist, backend, real_stdout):
     vdist.hba_ctx_close(ctx)
     if use_dist:
         dist.destroy_process_group()
+
+
+def host_cpu_state():
+    """What the container may use of the host's CPUs (cgroup v2 cpu.max) and how long it has been throttled so far -- a launch-heavy leg (cfg5)
+    on several host threads is 3-5x slower where the quota is small, and a throttled timed region says so in the line instead of looking like a
+    slow GPU."""
+    st = {"nproc": os.cpu_count(), "cpu_max": None, "quota_cores": None, "throttled_usec": None}
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        st["cpu_max"] = f"{q} {per}"
+        st["quota_cores"] = None if q == "max" else float(q) / float(per)
+    except Exception:   # noqa: BLE001 -- cgroup v1 / no cgroup: nothing to report
+        pass
+    try:
+        for ln in open("/sys/fs/cgroup/cpu.stat"):
+            if ln.startswith("throttled_usec"):
+                st["throttled_usec"] = int(ln.split()[1])
+    except Exception:   # noqa: BLE001
+        pass
+    return st
 
 
 def cfg5_cpu_baseline(clouds, poses, coarse, fine, gpu_out):

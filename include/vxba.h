@@ -500,8 +500,10 @@ const char* vxba_hba_last_error(const vxba_hba* h);
 /* Appends n_keyframes clouds (PointType xyz as float, keyframe coordinates): cloud_ptr n_keyframes + 1 offsets in points (cloud_ptr[0] = 0). */
 int vxba_hba_add_keyframes(vxba_hba* h, int64_t n_keyframes, const int64_t* cloud_ptr, const float* xyz);
 int vxba_hba_num_keyframes(const vxba_hba* h);
+int vxba_hba_threads_used(const vxba_hba* h); /* host threads / streams the last vxba_hba_pass ran its bottom level on */
 int vxba_hba_clear(vxba_hba* h); /* forget the keyframes (the device buffers are kept) */
-/* poses: K x 12 ([R column-major 9 | p 3], as everywhere).  n_threads: 1 .. 8 host threads / streams for the bottom level (window w on thread w mod n_threads; 4 measured best on one MI355X).
+/* poses: K x 12 ([R column-major 9 | p 3], as everywhere).  n_threads: 1 .. 8 host threads / streams for the bottom level (window w on thread w mod n_threads); <= 0: the library picks -- 4 (measured
+ * best on one MI355X), fewer under a small cgroup CPU quota (the threads poll while their streams run).
  * Out: submap_poses S x 12 (refined anchors), submap_sizes S (points per voxel-filtered submap; may be NULL); the edges of both levels in
  * order -- bottom level window by window, then the top level: edge_ij 2 ints (keyframe indices i < j), edge_data 18 doubles [R_i^T R_j
  * row-major 9 | R_i^T (p_j - p_i) 3 | v6 = 1 / |hess(6i+k, 6j+k)| 6] per edge, at most edge_capacity of them (the counts are exact even

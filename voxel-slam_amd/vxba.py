@@ -36,7 +36,7 @@ EXPORTS = [
     "vxba_lio_create", "vxba_lio_destroy", "vxba_lio_last_error", "vxba_lio_map_update", "vxba_lio_map_clear", "vxba_lio_map_size", "vxba_lio_scan_raw",
     "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_lio_leaf_stats", "vxba_cov_add_build", "vxba_plane_update", "vxba_down_sampling_voxel", "vxba_voxelize_push_device",
     "vxba_set_option", "vxba_get_option", "vxba_lio_set_option",
-    "vxba_hba_create", "vxba_hba_destroy", "vxba_hba_last_error", "vxba_hba_add_keyframes", "vxba_hba_num_keyframes", "vxba_hba_clear", "vxba_hba_pass", "vxba_voxelize_profile",
+    "vxba_hba_create", "vxba_hba_destroy", "vxba_hba_last_error", "vxba_hba_add_keyframes", "vxba_hba_num_keyframes", "vxba_hba_threads_used", "vxba_hba_clear", "vxba_hba_pass", "vxba_voxelize_profile",
     "vxba_map_create", "vxba_map_destroy", "vxba_map_last_error", "vxba_map_cut_voxel", "vxba_map_cut_voxel_device", "vxba_map_recut", "vxba_map_margi",
     "vxba_map_slide", "vxba_map_counts", "vxba_map_fix_pool", "vxba_map_set_journey", "vxba_map_release", "vxba_map_device_bytes", "vxba_map_leaves", "vxba_map_cut_voxel_lio", "vxba_map_export_planes",
 ]
@@ -887,7 +887,7 @@ class HbaSession:
     def clear(self):
         self._check(self._L.vxba_hba_clear(self._h), "vxba_hba_clear")
 
-    def run_pass(self, poses, coarse: VoxelizeParams, fine: VoxelizeParams, wdsize: int = 10, mgsize: int = 5, top_max_iter: int = 1, n_threads: int = 4):
+    def run_pass(self, poses, coarse: VoxelizeParams, fine: VoxelizeParams, wdsize: int = 10, mgsize: int = 5, top_max_iter: int = 1, n_threads: int = 0):
         """One bottom-up pass; returns what ``hba.hierarchical_ba`` returns (edges as dicts with keyframe indices)."""
         poses = _c(poses).reshape(-1, 12)
         K = poses.shape[0]
@@ -906,7 +906,7 @@ class HbaSession:
         def edges(lo, hi):
             return [dict(i=int(eij[k, 0]), j=int(eij[k, 1]), rot=edata[k, :9].reshape(3, 3).copy(), tra=edata[k, 9:12].copy(), v6=edata[k, 12:18].copy()) for k in range(lo, hi)]
         return dict(edges1=edges(0, n1.value), edges2=edges(n1.value, n1.value + n2.value), submap_ids=list(range(0, K - wdsize + 1, mgsize)), submap_poses=sub_poses,
-                    submap_sizes=[int(x) for x in sizes],
+                    submap_sizes=[int(x) for x in sizes], n_threads_used=int(self._L.vxba_hba_threads_used(self._h)),
                     top_rounds=[dict(round=k, n_voxels=int(rounds[k, 0]), resis=(float(rounds[k, 1]), float(rounds[k, 2])), converged=bool(rounds[k, 3]), fine=bool(rounds[k, 4]))
                                 for k in range(ntr.value)])
 
