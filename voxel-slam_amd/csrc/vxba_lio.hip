@@ -874,6 +874,13 @@ int lio_sweep(vxba_lio* h, const double* state, const double* cov225, bool reset
 
 }  // namespace
 
+// completion of what is queued on s by polling: waking up from hipStreamSynchronize costs ~15-25 us, more than the per-scan kernels here
+static inline hipError_t lio_poll(hipStream_t s) {
+  hipError_t q;
+  while ((q = hipStreamQuery(s)) == hipErrorNotReady) {}
+  return q;
+}
+
 extern "C" {
 
 int vxba_lio_create(double voxel_size, int max_layer, int device, vxba_lio** out) {
@@ -1059,7 +1066,7 @@ int vxba_lio_scan_raw(vxba_lio* h, int64_t n, const float* xyz, const double* ex
     vxl::lio_var_init_kernel<<<grid_for(n), 256, 0, h->stream>>>(d, n, h->pts_stride, e12, range_inc, dir_var, h->d_pts);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = lio_poll(h->stream);
   if (e != hipSuccess) { h->err = std::string("vxba_lio_scan_raw: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
   return VXBA_OK;
 }
@@ -1104,7 +1111,7 @@ int vxba_lio_pvec_update(vxba_lio* h, const double* state, const double* cov, do
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && pwld) e = hipMemcpyAsync(pwld, d, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess && pwld && var) e = hipMemcpyAsync(var, d + 3 * n, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = lio_poll(h->stream);
   if (e != hipSuccess) { h->err = std::string("vxba_lio_pvec_update: ") + hipGetErrorString(e); return VXBA_ERR_HIP; }
   h->world_valid = true;
   return VXBA_OK;
