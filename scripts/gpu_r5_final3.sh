@@ -19,8 +19,9 @@ for fn in ("gpurun_out/r5_final3/bench_driver_flags.json", "gpurun_out/r5_final3
 PY
 timeout 900 python bench.py --config cfg5 --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench_cfg5.json; cut -c1-330 $O/bench_cfg5.json; echo
 timeout 900 python bench.py --config cfg5 --steps 3 --warmup 1 --hba-threads 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_cfg5_one_thread.json; cut -c200-330 $O/bench_cfg5_one_thread.json; echo
+python -c "import json; [print(f, json.loads(open('$O/'+f).read().strip().splitlines()[-1])['host']) for f in ('bench_cfg5.json','bench_cfg5_one_thread.json')]"
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_cfg5_r5f3 -o t -- python $GRAFT_REPO_ROOT/bench.py --config cfg5 --steps 5 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/rocprof_cfg5.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_cfg5_r5f3 -o t -- python $GRAFT_REPO_ROOT/bench.py --config cfg5 --steps 5 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/rocprof_cfg5.log 2>&1
 cd "$GRAFT_REPO_ROOT"
 find gpurun_out/prof_cfg5_r5f3 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/cfg5_kernel_stats.csv
 find gpurun_out/prof_cfg5_r5f3 -type f ! -name "*stats.csv" -delete 2>/dev/null
