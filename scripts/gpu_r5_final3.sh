@@ -27,3 +27,8 @@ find gpurun_out/prof_cfg5_r5f3 -name "*kernel_stats.csv" | head -1 | xargs -I{} 
 find gpurun_out/prof_cfg5_r5f3 -type f ! -name "*stats.csv" -delete 2>/dev/null
 head -8 $O/cfg5_kernel_stats.csv | cut -c1-60,200-300
 VXBA_BENCH_DEVICE=0 VXBA_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_2_ranks_on_one_gpu_gloo.json; cut -c1-200 $O/bench_2_ranks_on_one_gpu_gloo.json
+# the randomised sweep on what changed last (voxeliser read-backs, the pass on 1 .. 8 threads) and once over every kind
+: > $O/fuzz_r5_close.log
+FUZZ_KINDS=hba timeout 1500 python scripts/fuzz_parity.py 341 160 2>&1 | grep -v amdgpu | grep -E "MISMATCH|cases" | tail -6 >> $O/fuzz_r5_close.log
+timeout 900 python scripts/fuzz_parity.py 351 260 2>&1 | grep -v amdgpu | tail -1 >> $O/fuzz_r5_close.log
+cat $O/fuzz_r5_close.log
