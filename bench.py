@@ -202,7 +202,10 @@ def self_launch(n):
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "8")
+    # host threads of the ranks' numpy / torch pools: the container may hold a cgroup CPU quota far below the host's CPU count (16 of 256 on the
+    # 1-GPU boxes); N ranks x their pools x their polling main threads must stay inside it, or the job is throttled as a whole
+    quota = host_cpu_state()["quota_cores"]
+    env.setdefault("OMP_NUM_THREADS", str(8 if quota is None else max(1, min(8, int(quota // max(n, 1)) - 1))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
