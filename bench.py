@@ -344,6 +344,7 @@ def main():
     # line by 5 % between boxes (round-3 review) -- min / max / n go into the line beside it.
     n_rep = max(1, args.repeats)
     elapsed_all, k3_rep_ms, k3_calls = [], [], 0
+    host0 = host_cpu_state()
     for _ in range(n_rep):
         sync()
         t0 = time.perf_counter()
@@ -361,6 +362,7 @@ def main():
         k3_calls += ktr["calls"]
     f.set_profiling(0)
     elapsed = float(np.median(elapsed_all))
+    host1 = host_cpu_state()
     kt = {"k3_hessian": {"ms_sum": float(np.median(k3_rep_ms)), "calls": 1, "launches_timed": k3_calls}}
     # secondary kernels: a short untimed run with every kernel bracketed
     f.set_profiling(15 | (16 if use_dist else 0))
@@ -437,6 +439,11 @@ def main():
                         "value_max": (world if args.scaling == "weak" else 1) * args.steps / min(elapsed_all),
                         "ms_per_step_min": 1e3 * min(elapsed_all) / args.steps, "ms_per_step_max": 1e3 * max(elapsed_all) / args.steps,
                         "k3_avg_launch_ms_min": min(k3_rep_ms), "k3_avg_launch_ms_max": max(k3_rep_ms)},
+            # what the container may use of the host's CPUs (cgroup v2 cpu.max) and whether it was throttled while the repeats ran: the ranks' host
+            # threads poll, and a job that spends its quota is stopped as a whole -- which would look like a slow GPU
+            "host": {"nproc": host1["nproc"], "cgroup_cpu_max": host1["cpu_max"], "quota_cores": host1["quota_cores"],
+                     "throttled_s_in_timed_repeats": None if host0["throttled_usec"] is None or host1["throttled_usec"] is None
+                     else (host1["throttled_usec"] - host0["throttled_usec"]) * 1e-6},
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
