@@ -147,7 +147,9 @@ def test_cluster_build_with_very_long_cells(vx):
     """A coarse top-level voxelisation puts 10^5 points into one node: such cells are folded by a whole workgroup (fixed order,
     ~1e-16 from the sequential sum) instead of one lane; cells up to 2048 points keep the reference's sequential sum bit for bit."""
     rng = np.random.default_rng(77)
-    lens = np.array([5, 300_000, 17, 2048, 2049, 1, 0, 70_001, 33])
+    # around the sixteen lanes a packed cell is folded by (15 / 16 / 17 / 31 / 32 / 33 / 48), empty cells beside full ones in one wave's four rows,
+    # and both sides of the long-cell threshold
+    lens = np.array([5, 300_000, 17, 2048, 2049, 1, 0, 70_001, 33, 16, 15, 0, 32, 31, 48, 0, 0, 2047, 64, 2])
     cell_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     xyz = rng.normal(size=(int(lens.sum()), 3)) * 20 + 5
     got = vx.build_clusters(xyz, cell_ptr); ref = O.build_clusters(xyz, cell_ptr)
