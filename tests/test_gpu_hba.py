@@ -161,3 +161,34 @@ def test_cfg5_size_pass_500_keyframes_matches_oracle(pts):
     assert e1[0] < e0[0]
     print("cfg5-size pass: 99 windows, top rounds %s voxels, pose diff vs oracle %.2e m %.2e rad, anchors %.4f -> %.4f m" % (
         [r["n_voxels"] for r in got["top_rounds"]], et, er, e0[0], e1[0]))
+
+
+def test_hba_pass_with_a_window_that_has_no_planes():
+    """A stretch of keyframes whose clouds are too sparse for any plane: that window's factor is empty.  Upstream's damping_iter then runs on an
+    all-zero system (zero step, poses unchanged, zero *hess: no edges) and the pass goes on; so do the pass below the C ABI, the Python
+    orchestration and the oracle -- and they agree."""
+    from voxel_slam_amd import hba, vxba
+    K, wdsize, mgsize = 45, 10, 5
+    xyz, fp, poses, _ = synth.make_scans(win_size=K, pts_per_scan=4000, extent=24.0, noise=0.005, seed=synth.MASTER_SEED + 977, rot_sigma_deg=0.1, trans_sigma=0.02)
+    clouds = [xyz[fp[i]:fp[i + 1]].astype(np.float32) for i in range(K)]
+    rng = np.random.default_rng(5)
+    for i in range(10, 20):                                  # the window of keyframes 10 .. 19: 300 points scattered over a 400 m cube each
+        clouds[i] = rng.uniform(-200, 200, size=(300, 3)).astype(np.float32)
+    coarse = vxba.VoxelizeParams(voxel_size=2.0, max_layer=2, min_points=10, min_eigen_value=0.02, eigen_ratio=(1 / 9, 1 / 9, 1 / 9, 1 / 9))
+    fine = vxba.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
+    ref = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=wdsize, mgsize=mgsize, top_max_iter=2, optimizer=_OracleOpt(), voxelize=_oracle_voxelize,
+                              downsample=O.down_sampling_voxel)
+    py = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=wdsize, mgsize=mgsize, top_max_iter=2)
+    ses = vxba.HbaSession(); ses.add_keyframes(clouds)
+    got = ses.run_pass(poses, coarse, fine, wdsize=wdsize, mgsize=mgsize, top_max_iter=2, n_threads=3)
+    ses.close()
+    inside = lambda e: 10 <= e["i"] and e["j"] < 20                      # both keyframes in the sparse stretch: only window 2 could have made this edge
+    for out in (ref, py, got):
+        assert not any(inside(e) for e in out["edges1"])
+        assert len(out["edges1"]) > 0 and len(out["edges2"]) > 0
+    assert [(e["i"], e["j"]) for e in py["edges1"]] == [(e["i"], e["j"]) for e in ref["edges1"]] == [(e["i"], e["j"]) for e in got["edges1"]]
+    assert py["submap_sizes"] == ref["submap_sizes"]
+    assert np.max(np.abs(np.asarray(got["submap_sizes"]) - np.asarray(ref["submap_sizes"]))) <= 2
+    for out in (py, got):
+        et, er = synth.pose_errors(out["submap_poses"], ref["submap_poses"])
+        assert et < 1e-6 and er < 1e-6, (et, er)

@@ -149,7 +149,13 @@ static int window_refine(vxba_factor* f, int W, int64_t n, const double* d_xyz, 
     if (rc == VXBA_OK) rc = vxba_voxelize_push_device(f, n, d_xyz, fp, xs, use_fine ? fine : coarse, &nv, nullptr, 0);
     double resis[2] = {0, 0};
     int n_trace = 0, conv = 0;
-    if (rc == VXBA_OK) rc = vxba_damping_iter(f, xs, 4, hess.data(), resis, nullptr, &n_trace, &conv);
+    if (rc == VXBA_OK && nv == 0) {
+      // no factor voxel in this window (too few points for any plane): upstream's damping_iter then runs on an all-zero system -- Eigen's LDLT
+      // returns a zero step, the poses stay, *hess is zero (no edge passes the 1e-6 test), residuals 0 and 0 / 0 -- and the loop's schedule goes on
+      // (voxelslam.cpp:2380-2398).  The optimiser entry point refuses an empty factor, so the same outcome is written down here.
+      std::fill(hess.begin(), hess.end(), 0.0);
+      resis[0] = 0.0; resis[1] = std::nan("");
+    } else if (rc == VXBA_OK) rc = vxba_damping_iter(f, xs, 4, hess.data(), resis, nullptr, &n_trace, &conv);
     if (rc != VXBA_OK) { err = vxba_last_error(f); return rc; }
     if (log) log->push_back(RoundLog{nv, resis[0], resis[1], conv, use_fine ? 1 : 0});
     if ((std::fabs(resis[0] - resis[1]) / resis[0] < thre && conv) || (it == max_iter - 2 && converge_flag == 0)) {

@@ -36,14 +36,21 @@ def window_refine(xyz_local, frame_ptr, poses, coarse: "vxba.VoxelizeParams", fi
         else:
             f, n_vox = voxelize(xyz_local, frame_ptr, xs, params)
         opt = vxba.Lidar_BA_Optimizer() if optimizer is None else optimizer
-        out = opt.damping_iter(xs, f, max_iter=up)
+        if optimizer is None and int(n_vox) == 0:
+            # no factor voxel (too few points for any plane): upstream's damping_iter then runs on an all-zero system -- zero step, poses unchanged,
+            # *hess zero, residuals 0 and 0 / 0 -- and the schedule goes on; the GPU entry point refuses an empty factor, so that outcome is written here
+            out = dict(poses=xs, hess=np.zeros((6 * W, 6 * W)), resis=(0.0, float("nan")), is_converge=False)
+        else:
+            out = opt.damping_iter(xs, f, max_iter=up)
         xs = out["poses"]
         hess = out["hess"]
         r0, r1 = out["resis"]
         log.append(dict(round=it, n_voxels=int(n_vox), resis=(float(r0), float(r1)), converged=bool(out["is_converge"]), fine=params is fine))
         if factor is None and hasattr(f, "close"):
             f.close()
-        if (abs(r0 - r1) / r0 < converge_thre and out["is_converge"]) or (it == max_iter - 2 and converge_flag == 0):   # :2387-2398
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rel = np.float64(abs(r0 - r1)) / np.float64(r0)          # 0 / 0 for a window without factor voxels: NaN, the test below is false (as upstream)
+        if (rel < converge_thre and out["is_converge"]) or (it == max_iter - 2 and converge_flag == 0):   # :2387-2398
             converge_thre = 0.01
             if converge_flag == 0:
                 converge_flag = 1
