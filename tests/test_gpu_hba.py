@@ -192,3 +192,28 @@ def test_hba_pass_with_a_window_that_has_no_planes():
     for out in (py, got):
         et, er = synth.pose_errors(out["submap_poses"], ref["submap_poses"])
         assert et < 1e-6 and er < 1e-6, (et, er)
+
+
+@pytest.mark.parametrize("case", ["one_empty_keyframe", "window_of_empty_keyframes", "one_submap", "wdsize_2", "stride_larger_than_window", "more_threads_than_windows"])
+def test_hba_pass_degenerate_sessions_match_the_python_orchestration(case):
+    """Shapes a mapper can hand over: a keyframe without points, a whole window without points (its factor is empty), a session of exactly one
+    window (a one-pose top level), two-keyframe windows, a stride that skips keyframes, more host threads than windows."""
+    from voxel_slam_amd import hba, vxba
+    K, wd, mg, threads, empty = {"one_empty_keyframe": (25, 10, 5, 3, [7]), "window_of_empty_keyframes": (30, 10, 5, 3, list(range(10, 20))), "one_submap": (10, 10, 5, 3, []),
+                                 "wdsize_2": (12, 2, 1, 3, []), "stride_larger_than_window": (26, 4, 7, 3, []), "more_threads_than_windows": (20, 5, 5, 8, [])}[case]
+    xyz, fp, poses, _ = synth.make_scans(win_size=K, pts_per_scan=4000, extent=24.0, noise=0.005, seed=synth.MASTER_SEED + 990 + K + wd, rot_sigma_deg=0.1, trans_sigma=0.02)
+    clouds = [xyz[fp[i]:fp[i + 1]].astype(np.float32) for i in range(K)]
+    for i in empty:
+        clouds[i] = np.zeros((0, 3), np.float32)
+    coarse = vxba.VoxelizeParams(voxel_size=2.0, max_layer=2, min_points=10, min_eigen_value=0.02, eigen_ratio=(1 / 9, 1 / 9, 1 / 9, 1 / 9))
+    fine = vxba.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
+    py = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=wd, mgsize=mg, top_max_iter=2)
+    ses = vxba.HbaSession(); ses.add_keyframes(clouds)
+    got = ses.run_pass(poses, coarse, fine, wdsize=wd, mgsize=mg, top_max_iter=2, n_threads=threads)
+    ses.close()
+    assert got["submap_ids"] == py["submap_ids"] and len(got["submap_ids"]) == (K - wd) // mg + 1
+    assert np.max(np.abs(np.asarray(got["submap_sizes"]) - np.asarray(py["submap_sizes"]))) <= 2
+    for key in ("edges1", "edges2"):
+        assert [(e["i"], e["j"]) for e in got[key]] == [(e["i"], e["j"]) for e in py[key]]
+    et, er = synth.pose_errors(got["submap_poses"], py["submap_poses"])
+    assert et < 1e-7 and er < 1e-7, (et, er)
