@@ -381,7 +381,12 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
                                        * the Hessian sweep runs and lets the device solve the reduced 6W-dimensional pose system inside the residual-sweep launch
                                        * (the LiDAR-only loop's four-wave solve): no kernel ever waits for the host, the LiDAR Hessian never crosses PCIe on the
                                        * critical path.  Steps after a rejection, the gravity variant and a non-positive band pivot take the host solve.  0: host solve. */
-/* (option 9, the Hessian reduction as a phase of the residual-sweep launch, was measured no faster in round 4 and removed in round 5) */
+#define VXBA_OPT_FUSED_SWEEPS 9         /* 1 (default): inside one solve of the device-resident 6W loop (vxba_damping_iter, vxba_lm_steps; no collective attached)
+                                       * the residual sweep at the trial poses and the Hessian sweep that linearises at the same poses one iteration later are
+                                       * ONE launch behind the in-launch solve (Lidar_BA_Optimizer::damping_iter, voxel_map.hpp:386-439: only_residual, then
+                                       * divide_thread of the next iteration), and the reduction behind it takes the accept / reject decision; a rejected step
+                                       * then costs a Hessian sweep the reference does not run.  0: the three-launch iteration of rounds 1-5.  Needs
+                                       * VXBA_OPT_FUSED_SOLVE = 1.  (The number belonged to a round-4 experiment that was removed in round 5.) */
 #define VXBA_OPT_COUNT 10
 #define VXBA_STAT_FUSED_FALLBACKS 100 /* read-only (vxba_get_option): times vxba_damping_iter re-ran a call with the solve as its own launch after the
                                          voxel workgroups of a fused launch had timed out waiting for it */
@@ -520,7 +525,8 @@ int vxba_hba_pass(vxba_hba* h, const double* poses, const vxba_voxelize_params* 
  * cell offset read, 80 B per cluster written). */
 int vxba_voxelize_profile(int enable, double* ms_sum, long long* launches, double* algorithmic_bytes);
 /* Bit mask of kernels to bracket with hipEvents on the launch stream: 1 = Hessian sweep (K3), 2 = residual sweep (K2),
- * 4 = K3 cross-block reduction, 8 = cluster build (K1), 16 = the all-reduce of a sharded factor; 0 = off. */
+ * 4 = K3 cross-block reduction, 8 = cluster build (K1), 16 = the all-reduce of a sharded factor, 32 = the fused solve + residual + Hessian
+ * launch (VXBA_OPT_FUSED_SWEEPS); 0 = off. */
 int vxba_set_profiling(vxba_factor* f, int mask);
 /* Sum of kernel durations [ms] and launch counts since the last reset: index 0 = Hessian sweep (K3),
  * 1 = residual sweep (K2), 2 = K3 cross-block reduction, 3 = cluster build (K1). */
@@ -530,6 +536,9 @@ int vxba_get_kernel_times(vxba_factor* f, double ms_sum[4], int64_t calls[4], in
  * bracketed with hipEvents on the factor's stream; sum [ms] and count since the last reset.  The interval includes the wait for the
  * slowest peer. */
 int vxba_get_collective_time(vxba_factor* f, double* ms_sum, int64_t* calls, int reset);
+/* The fused launch of VXBA_OPT_FUSED_SWEEPS (in-launch solve, then evaluate_only_residual and acc_evaluate2 at the trial poses, voxel_map.hpp:132-279)
+ * bracketed while bit 32 of the profiling mask was set: sum of launch durations [ms] and count since the last reset. */
+int vxba_get_fused_time(vxba_factor* f, double* ms_sum, int64_t* calls, int reset);
 /* Algorithmic bytes of one full sweep over the current factor: 0 = K3, 1 = K2. */
 int vxba_algorithmic_bytes(const vxba_factor* f, double bytes[2]);
 int vxba_nnz(vxba_factor* f, int64_t* nnz);
@@ -550,6 +559,7 @@ int vxba_debug_band_schur(int m, const double* A, const double* b, int nframes, 
 /* Debug: per-wave s_memtime stamps written by the instrumented kernel instantiations (env VXBA_DBG=1 /
  * VXBA_K3_SGB=5); 8 slots per wave. */
 int vxba_debug_stamps(int clear, unsigned long long* out, size_t n);
+int vxba_debug_partials(vxba_factor* f, double* out, size_t n);   /* development: workgroup partials of the last Hessian sweep */
 
 #ifdef __cplusplus
 }

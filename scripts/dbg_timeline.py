@@ -3,7 +3,9 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 which = sys.argv[1]
-if which == "k2":
+if which == "k23":
+    os.environ["VXBA_DBG"] = "2"
+elif which == "k2":
     os.environ["VXBA_DBG"] = "1"
 else:
     os.environ["VXBA_DBG"] = "1"
@@ -63,6 +65,35 @@ if which in ("fused", "fused_li"):
             ch = full[4010 + s_, :5]
             if ch[0] > 0:
                 print("step %d owner chain: start %d  applied +%d  diagonal read +%d  factored +%d  panel stored +%d" % ((s_, ch[0] - t0) + tuple(np.diff(ch))))
+    sys.exit(0)
+if which == "k23":
+    # the fused launch (vxba_k23.hpp): second iteration of a 3-iteration solve.  Sweep waves: 0 entry, 30 rows requested, 5 poses in LDS + barrier,
+    # 15 transform done, 18 eigen done, 21 cache stores issued, 24 stores acknowledged, then the Hessian half's stamps (2 first requests, 1 barrier, 8+s ..)
+    from voxel_slam_amd.vxba import Lidar_BA_Optimizer
+    Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=2)
+    full = vxba.debug_stamps(4096).astype(np.int64)
+    sol = full[4000, :6]
+    live = (full[:2048, 0] > 0) & (full[:2048, 6] > 0)
+    fl = full[:2048][live]
+    wgs = fl[:, 0].reshape(-1, 8).min(axis=1).repeat(8) if fl.shape[0] % 8 == 0 else fl[:, 0]
+    print("fused launch: %d sweep waves stamped; solver (cycles since its start): loaded %d, factored %d, back-substituted %d, end %d" % ((fl.shape[0],) + tuple((sol - sol[0])[[2, 3, 4, 5]])))
+    wv = np.arange(fl.shape[0]) % 8
+    for nm, slot in (("rows requested", 30), ("poses in LDS, barrier passed", 5), ("transform done", 15), ("eigen done", 18), ("cache stores issued", 21), ("stores acknowledged", 24),
+                     ("first batch requested", 2), ("Hessian-half barrier passed", 1), ("barrier 0 (phase A of step 0)", 8), ("barrier 1", 9), ("barrier 2", 10), ("barrier 3", 11),
+                     ("barrier 4", 12), ("step loop left", 3), ("tiles-done barrier", 27), ("accumulators parked", 28), ("partial stores issued", 6), ("acknowledged", 31)):
+        ok = fl[:, slot] > 0
+        if ok.any():
+            col = (fl[:, slot] - wgs)[ok]
+            print("since the workgroup's first wave entered: %-30s median %6.0f  p10 %6.0f  p90 %6.0f  max %6.0f   (%d waves; waves 0-3 median %6.0f)" % (
+                nm, np.median(col), np.percentile(col, 10), np.percentile(col, 90), col.max(), int(ok.sum()), np.median((fl[:, slot] - wgs)[ok & (wv < 4)]) if (ok & (wv < 4)).any() else -1))
+    # relative to the moment the poses arrived (slot 5): what the launch costs BEHIND the solve
+    ok = (fl[:, 5] > 0) & (fl[:, 31] > 0)
+    if ok.any():
+        for nm, slot in (("transform done", 15), ("eigen done", 18), ("stores acknowledged", 24), ("Hessian-half barrier passed", 1), ("barrier 0", 8), ("barrier 1", 9), ("barrier 2", 10), ("barrier 3", 11), ("step loop left", 3), ("acknowledged (end)", 31)):
+            k = ok & (fl[:, slot] > 0)
+            if k.any():
+                col = fl[k, slot] - fl[k, 5]
+                print("since the poses arrived: %-30s median %6.0f  p10 %6.0f  p90 %6.0f  max %6.0f" % (nm, np.median(col), np.percentile(col, 10), np.percentile(col, 90), col.max()))
     sys.exit(0)
 if which == "fin":
     # cross-workgroup reduction of the Hessian sweep (k3_finalize_kernel): wave 0 of every workgroup, rows 3000.. of the stamp table:

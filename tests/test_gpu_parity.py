@@ -209,8 +209,10 @@ def test_k4_plane_criteria_flags_and_standalone_k1(vx):
 
 
 # ---------------------------------------------------------------------------------------------------- LM
-def check_lm_parity(vx, sc, max_iter):
+def check_lm_parity(vx, sc, max_iter, fused=None):
     fo, fg = seeded_pair(vx, sc)
+    if fused is not None:
+        fg.set_option("fused_sweeps", fused)     # 1 (default): residual + next Hessian sweep in one launch; 0: the three-launch iteration
     ref = fo.damping_iter(sc.poses_init, max_iter=max_iter, thd_num=2)
     got = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, fg, max_iter=max_iter)
     assert got["trace"].shape == ref["trace"].shape
@@ -253,6 +255,66 @@ def test_lm_trace_and_pose_parity_every_window_size(vx, W):
     stand-alone sweep tests: only the LM loop reads those words)."""
     sc = synth.make_scene(win_size=W, pts_per_scan=12000, n_voxels=1200, p_obs=0.8 if W > 2 else 1.0, fix_frac=0.2, seed=900 + W, rot_sigma_deg=0.1, trans_sigma=0.03)
     check_lm_parity(vx, sc, max_iter=5)
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+def test_lm_parity_with_and_without_the_fused_residual_hessian_launch(vx, fused):
+    """VXBA_OPT_FUSED_SWEEPS (round 6): inside a solve the residual sweep at the trial poses and the next iteration's Hessian sweep are one
+    launch behind the in-launch solve, and the solve workgroup takes the accept / reject decision while the Hessian half runs
+    (csrc/vxba_k23.hpp).  Both forms of the loop against the oracle: an all-accepted window, one that runs past convergence (rejections,
+    the early break), an odd window size (padding columns of the tile) and a window of seven voxels (most sweep workgroups without a batch)."""
+    check_lm_parity(vx, synth.make_config("cfg1"), 3, fused=fused)
+    check_lm_parity(vx, synth.make_scene(win_size=10, pts_per_scan=30000, n_voxels=3000, p_obs=0.7, fix_frac=0.3, seed=71, rot_sigma_deg=0.1, trans_sigma=0.02), 8, fused=fused)
+    check_lm_parity(vx, synth.make_scene(win_size=7, pts_per_scan=12000, n_voxels=1200, p_obs=0.8, fix_frac=0.2, seed=907, rot_sigma_deg=0.1, trans_sigma=0.03), 5, fused=fused)
+    check_lm_parity(vx, synth.make_scene(win_size=4, pts_per_scan=400, n_voxels=7, seed=5), 4, fused=fused)
+
+
+def test_fused_launch_is_the_three_launch_iteration_to_round_off(vx):
+    """The two forms of the loop against EACH OTHER, where a voxel's arithmetic is the same statement for statement (k23_finish = the body of
+    k2_residual_kernel, k3_sweep_body = k3_hessian_kernel): identical accept / reject and recompute flags, identical cache, poses and *hess to
+    round-off (bitwise on windows whose Hessian sweep takes the same workgroup split: a fused launch gives one CU to the solve, 255 sweep
+    workgroups instead of 256, which moves the partial sums' boundaries at full size); a window with REJECTED steps (the reduction behind the
+    launch must drop the speculated system and keep the old one) and the bench driver's solves back to back."""
+    cases = [(synth.make_scene(win_size=10, pts_per_scan=20000, n_voxels=2000, seed=81), 3)]
+    cases += [(synth.make_scene(win_size=W_, pts_per_scan=12000, n_voxels=1200, p_obs=0.8 if W_ > 2 else 1.0, fix_frac=0.2, seed=900 + W_,
+                                                          rot_sigma_deg=0.1, trans_sigma=0.03), 5) for W_ in (2, 5, 9)]
+    cases.append((synth.make_scene(win_size=10, pts_per_scan=30000, n_voxels=30000, seed=83, rot_sigma_deg=0.5, trans_sigma=0.03), 6))   # far start: rejected steps
+    saw_reject = False
+    for sc, iters in cases:
+        out = []
+        for fused in (0, 1):
+            f = vx.LidarFactor(sc.win_size)
+            f.push_voxels(sc.clusters, sc.fix, sc.coe)
+            f.evaluate_only_residual(sc.poses_init)
+            f.set_option("fused_sweeps", fused)
+            r = vx.Lidar_BA_Optimizer().damping_iter(sc.poses_init, f, max_iter=iters)
+            r["cache"] = f.read_cache()
+            out.append(r)
+            f.close()
+        a, b = out
+        assert a["trace"].shape == b["trace"].shape and np.array_equal(a["trace"][:, 6:], b["trace"][:, 6:]), (a["trace"][:, 6], b["trace"][:, 6])
+        saw_reject |= bool((a["trace"][:, 6] == 0).any())
+        assert np.allclose(a["trace"][:, :6], b["trace"][:, :6], rtol=1e-9, atol=0)
+        et, er = synth.pose_errors(a["poses"], b["poses"])
+        assert et < 1e-12 and er < 1e-12, (et, er)
+        assert relerr(a["hess"], b["hess"]) < 1e-11
+        for x, y in zip(a["cache"], b["cache"]):
+            assert np.allclose(x, y, rtol=1e-9, atol=1e-9)
+        assert a["is_converge"] == b["is_converge"] and np.allclose(a["resis"], b["resis"], rtol=1e-12)
+    assert saw_reject, "no window of this test rejected a step: the drop-the-speculated-system path was not exercised"
+    # bench driver: three solves of three iterations back to back, both forms
+    sc = synth.make_scene(win_size=10, pts_per_scan=20000, n_voxels=2000, seed=81)
+    res = []
+    for fused in (0, 1):
+        f = vx.LidarFactor(sc.win_size)
+        f.push_voxels(sc.clusters, sc.fix, sc.coe)
+        f.evaluate_only_residual(sc.poses_init)
+        f.set_option("fused_sweeps", fused)
+        f.snapshot_cache()
+        res.append(f.lm_steps(sc.poses_init, 9, 3))
+        f.close()
+    assert res[0][2] == res[1][2] == dict(iters=9, accepted=9, rejected=0)
+    assert np.allclose(res[0][0], res[1][0], rtol=0, atol=1e-12) and np.isclose(res[0][1][1], res[1][1][1], rtol=1e-12)
 
 
 def _k3_voxels_per_batch(W):

@@ -579,6 +579,13 @@ int vxba_debug_mfma_probe(int device, const double* A16x4, const double* B4x16, 
   return e == hipSuccess ? VXBA_OK : VXBA_ERR_HIP;
 }
 
+// development: the Hessian sweep's workgroup partials as the last sweep left them (n doubles from the start of the buffer)
+int vxba_debug_partials(vxba_factor* f, double* out, size_t n) {
+  if (!f || !out || !f->d_partial3 || n > f->partial3_len) return VXBA_ERR_ARG;
+  hipSetDevice(f->device);
+  if (hipStreamSynchronize(f->stream) != hipSuccess) return VXBA_ERR_HIP;
+  return hipMemcpy(out, f->d_partial3, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? VXBA_OK : VXBA_ERR_HIP;
+}
 int vxba_debug_stamps(int clear, unsigned long long* out, size_t n) {
   if (clear) vxk::debug_clear_stamps();
   if (out && n) { (void)hipDeviceSynchronize(); vxk::debug_read_stamps(out, n); }
@@ -641,7 +648,7 @@ int vxba_set_option(vxba_factor* f, int option, int value) {
       if (value != 0) return fail(f, VXBA_ERR_UNSUPPORTED, "vxba_set_option: the device-resident 15W loop was removed in round 4 (4x slower than the default shell); only 0 is accepted");
       break;
     case VXBA_OPT_FUSED_SOLVE: case VXBA_OPT_SPEC_COLLECTIVE: case VXBA_OPT_WIDE_DEVICE_SOLVE:
-    case VXBA_OPT_LI_STRUCTURED_SOLVE: case VXBA_OPT_LI_QUEUED_SWEEPS: case VXBA_OPT_LI_DEVICE_POSE_SOLVE:
+    case VXBA_OPT_LI_STRUCTURED_SOLVE: case VXBA_OPT_LI_QUEUED_SWEEPS: case VXBA_OPT_LI_DEVICE_POSE_SOLVE: case VXBA_OPT_FUSED_SWEEPS:
       if (value != 0 && value != 1) return fail(f, VXBA_ERR_ARG, "vxba_set_option: this option takes 0 or 1");
       break;
     case VXBA_OPT_DEBUG_SOLVE_TIMEOUT:
@@ -691,6 +698,18 @@ int vxba_get_kernel_times(vxba_factor* f, double ms_sum[4], int64_t calls[4], in
     if (calls) calls[k] = f->calls[k];
     if (reset) { f->ms_sum[k] = 0; f->calls[k] = 0; }
   }
+  return VXBA_OK;
+}
+
+int vxba_get_fused_time(vxba_factor* f, double* ms_sum, int64_t* calls, int reset) {
+  VX_LOCK(f);
+  if (!f) return VXBA_ERR_ARG;
+  hipSetDevice(f->device);
+  int rc = drain_events(f);
+  if (rc) return rc;
+  if (ms_sum) *ms_sum = f->ms_sum[5];
+  if (calls) *calls = f->calls[5];
+  if (reset) { f->ms_sum[5] = 0; f->calls[5] = 0; }
   return VXBA_OK;
 }
 

@@ -113,7 +113,7 @@ int ensure_capacity(vxba_factor* f, int n_total) {
     const char* emsg = nullptr;
     if (vxw::store_reserve(f->wstore, want, f->wstore.ES, f->V, f->stream, &emsg) != 0) return fail(f, VXBA_ERR_HIP, emsg ? emsg : "wide store: allocation failed");
   }
-  const size_t p2 = (size_t)want / 32 + 2;   // one partial per workgroup of 32..64 voxels (vxk::k2_voxels_per_block)
+  const size_t p2 = std::max((size_t)want / 32 + 2, (size_t)512);   // one partial per workgroup of 32..64 voxels (vxk::k2_voxels_per_block), or one per sweep workgroup of a fused launch
   if (p2 > f->partial2_len) {
     if (f->d_partial2) VX_HIP(f, hipFree(f->d_partial2));
     VX_HIP(f, hipMalloc((void**)&f->d_partial2, p2 * sizeof(double)));
@@ -239,6 +239,7 @@ void options_from_env(vxba_factor* f) {   // initial values only; vxba_set_optio
   f->opt[VXBA_OPT_SPEC_COLLECTIVE] = flag("VXBA_SPEC_COLLECTIVE", 1);
   f->opt[VXBA_OPT_WIDE_DEVICE_SOLVE] = flag("VXBA_WIDE_DEVICE_SOLVE", 1);
   f->opt[VXBA_OPT_LI_DEVICE_LOOP] = 0;   // (removed in round 4; the slot stays so that the option numbers do not move)
+  f->opt[VXBA_OPT_FUSED_SWEEPS] = flag("VXBA_FUSED_SWEEPS", 1);
   const char* e = getenv("VXBA_K2_VPB");
   const int v = e ? atoi(e) : 64;
   f->opt[VXBA_OPT_K2_VOXELS_PER_BLOCK] = (v >= 32 && v <= 64) ? v : 64;
@@ -310,7 +311,9 @@ int sweep_hess_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, int* c
   {
     ScopedKernelTimer t(f, 2);
     // with a collective the LM state is filled after the all-reduce, from the reduced buffer
-    vxk::launch_k3_finalize(f->d_partial3, nblocks, f->W, lm, c_now, has_collective(f) ? 0 : 1, d_out, f->stream);
+    const bool reset = lm && fused_sweeps(f);   // a fused residual + Hessian launch may follow: its residual slots start as NaN
+    vxk::launch_k3_finalize(f->d_partial3, nblocks, f->W, lm, c_now, has_collective(f) ? 0 : 1, d_out, f->stream, 0, nullptr, 0, reset ? f->d_partial2 : nullptr,
+                            reset ? vxk::K23_MAX_SWEEP_BLOCKS : 0);
   }
   VX_HIP(f, hipGetLastError());
   rc = shard_allreduce(f, d_out, plen);
@@ -361,6 +364,40 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, in
     VX_HIP(f, hipGetLastError());
     return shard_allreduce(f, d_out, 1);
   }
+  return VXBA_OK;
+}
+
+// The device-resident LM loop's fused launch (vxba_k23.hpp): damped solve of ctl[*c] | residual sweep at its trial poses | Hessian sweep at the
+// same poses, then the reduction that takes the step's accept / reject decision into ctl[*c ^ 1] and adopts the system of an accepted step.
+// Replaces [solve + residual sweep] | Hessian sweep | reduction of two consecutive iterations wherever a Hessian sweep follows a residual sweep
+// inside one solve; needs the in-launch solve, no collective, a narrow window and f64 cluster rows.
+bool fused_sweeps(const vxba_factor* f) {
+  return f->opt[VXBA_OPT_FUSED_SWEEPS] != 0 && fused_solve(f) && !has_collective(f) && !is_wide(f) && f->V > 0 && f->precision != VXBA_PRECISION_MIXED_F32_CLUSTERS &&
+         vxk::k23_supported(view(f));
+}
+int sweep_fused_device(vxba_factor* f, vxk::LMState* lm, int* c, unsigned seq) {
+  int rc = ensure_partials3(f);
+  if (rc) return rc;
+  const FactorView fv = view(f);
+  const int nv = vxk::k3_nv(f->W);
+  const int nbatches = (f->V - 1) / nv + 1;
+  const int nwg = vxk::k23_sweep_blocks(nbatches, f->cus);
+  const int flags = f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] == 1 ? 1 : 0;
+  int got;
+  if (f->profiling & 32) {   // events bound to the dispatch itself
+    hipEvent_t a = get_event(f), b = get_event(f);
+    got = vxk::launch_k23_fused(fv, lm, *c, seq, 0, f->V, f->d_partial2, f->d_partial3, nwg, f->precision == VXBA_PRECISION_MIXED ? 1 : 0, flags, f->stream, a, b);
+    if (a && b) f->pending.push_back({a, b, 5});
+  } else {
+    got = vxk::launch_k23_fused(fv, lm, *c, seq, 0, f->V, f->d_partial2, f->d_partial3, nwg, f->precision == VXBA_PRECISION_MIXED ? 1 : 0, flags, f->stream);
+  }
+  if (got != nwg) return fail(f, VXBA_ERR_STATE, "fused residual + Hessian launch refused this factor");
+  *c ^= 1;   // the launch's solve workgroup has decided the step into the other control block; the reduction is gated by it
+  {
+    ScopedKernelTimer t(f, 2);
+    vxk::launch_k3_finalize(f->d_partial3, nwg, f->W, lm, *c, 1, f->d_packed, f->stream, 0, nullptr, 0, f->d_partial2, vxk::K23_MAX_SWEEP_BLOCKS);
+  }
+  VX_HIP(f, hipGetLastError());
   return VXBA_OK;
 }
 

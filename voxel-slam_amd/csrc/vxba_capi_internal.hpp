@@ -55,6 +55,8 @@ int spec_hess_phase(vxba_factor* f, const double* Rp0, int* c, bool first_of_sol
 int spec_final_decision(vxba_factor* f, const double* Rp0, int* c, int k2_nparts);
 
 bool fused_solve(const vxba_factor* f);
+bool fused_sweeps(const vxba_factor* f);
+int sweep_fused_device(vxba_factor* f, vxk::LMState* lm, int* c, unsigned seq);
 void options_from_env(vxba_factor* f);
 int upload_poses(vxba_factor* f, const double* Rp);
 // synchronous sweeps into the pinned host buffers (single-sweep entry points, wide windows)

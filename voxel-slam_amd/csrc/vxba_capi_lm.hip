@@ -110,12 +110,27 @@ static int damping_iter_impl(vxba_factor* f, double* Rp, int max_iter, double* h
     if (rc) return rc;
   }
   if (spec && max_iter > 0) { int rc = spec_final_decision(f, Rp, &c, spec_nparts); if (rc) return rc; }
+  // VXBA_OPT_FUSED_SWEEPS: wherever another iteration follows, [solve | residual sweep | the NEXT iteration's Hessian sweep] is one launch and
+  // the reduction behind it takes this iteration's decision (have_hess: the system of the next iteration is already in the LM state)
+  const bool fuse = !spec && fused_sweeps(f);
+  bool have_hess = false;
   for (int i = 0; !spec && i < max_iter; i++) {
-    int rc = sweep_hess_device(f, Rp, f->d_lm, &c, &pend, 0, f->V, f->d_packed, nullptr);
-    if (rc) return rc;
+    int rc = VXBA_OK;
+    if (!have_hess) {
+      rc = sweep_hess_device(f, Rp, f->d_lm, &c, &pend, 0, f->V, f->d_packed, nullptr);
+      if (rc) return rc;
+      pend.pending = 0;
+    }
     // damped solve + residual sweep at the trial state: one launch (the solve is workgroup 0 of the sweep) unless
     // VXBA_FUSED_SOLVE=0; without a collective the sweep's wave partials are summed by whoever takes the decision
     const unsigned seq = fused_solve(f) ? ++f->lm_seq : 0u;
+    if (fuse && seq && i + 1 < max_iter) {
+      rc = sweep_fused_device(f, f->d_lm, &c, seq);
+      if (rc) return rc;
+      have_hess = true;
+      continue;
+    }
+    have_hess = false;
     if (!seq) vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
     int nparts = 0;
     rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts, seq, false);
@@ -215,15 +230,29 @@ static int lm_steps_impl(vxba_factor* f, const double* Rp_init, int n_steps, int
     prev_last = last;
   }
   if (spec && n_steps > 0) { int rc = spec_final_decision(f, Rp_init, &c, spec_nparts); if (rc) return rc; }
+  const bool fuse = !spec && fused_sweeps(f);
+  bool have_hess = false;
   for (int s = 0; !spec && s < n_steps; s++) {
     // a new window every steps_per_solve steps: its first Hessian sweep reads the SNAPSHOT cache directly (the re-seeded
     // cache of a new window -- no copy) and its prologue resets poses and damping (pend.restart of the previous step);
     // the residual sweeps keep writing the live cache
     const bool first = (s % steps_per_solve) == 0;
     const bool last = ((s + 1) % steps_per_solve) == 0 && s + 1 < n_steps;
-    int rc = sweep_hess_device(f, Rp_init, f->d_lm, &c, &pend, 0, f->V, f->d_packed, first ? f->snapshot : nullptr);
-    if (rc) return rc;
+    int rc = VXBA_OK;
+    if (!have_hess) {
+      rc = sweep_hess_device(f, Rp_init, f->d_lm, &c, &pend, 0, f->V, f->d_packed, first ? f->snapshot : nullptr);
+      if (rc) return rc;
+      pend.pending = 0;
+    }
     const unsigned seq = fused_solve(f) ? ++f->lm_seq : 0u;
+    // inside a solve: this step's residual sweep and the next step's Hessian sweep in one launch (as vxba_damping_iter does)
+    if (fuse && seq && ((s + 1) % steps_per_solve) != 0 && s + 1 < n_steps) {
+      rc = sweep_fused_device(f, f->d_lm, &c, seq);
+      if (rc) return rc;
+      have_hess = true;
+      continue;
+    }
+    have_hess = false;
     if (!seq) vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
     int nparts = 0;
     rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, has_collective(f) ? f->d_scalar : nullptr, &nparts, seq, false);

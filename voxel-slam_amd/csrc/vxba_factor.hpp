@@ -135,8 +135,8 @@ struct vxba_factor {
   int profiling = 0;             // bit mask of kernel kinds to bracket with events: 1 K3, 2 K2, 4 K3 finalize, 8 K1, 16 all-reduce
   std::vector<EventPair> pending;
   std::vector<hipEvent_t> free_events;
-  double ms_sum[5] = {0, 0, 0, 0, 0};   // [4]: the all-reduce of a sharded factor (profiling bit 16)
-  int64_t calls[5] = {0, 0, 0, 0, 0};
+  double ms_sum[6] = {0, 0, 0, 0, 0, 0};   // [4]: the all-reduce of a sharded factor (profiling bit 16); [5]: the fused residual + Hessian launch (bit 32)
+  int64_t calls[6] = {0, 0, 0, 0, 0, 0};
   std::string err;
   // The reference calls the two sweeps from several std::threads on one LidarFactor with disjoint [head,end)
   // (voxel_map.hpp:318-332); entry points serialise on this lock so such callers stay correct.

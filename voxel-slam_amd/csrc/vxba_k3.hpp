@@ -165,8 +165,11 @@ __device__ __forceinline__ K3Planes k3_planes(const FactorView& fv) {
 }
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
+// AUX: cache policy bits of the buffer instruction (0 = default; 16 = sc1: served by the XCD's L2, not by this CU's vector L1 -- what the
+// fused residual + Hessian launch needs for cache planes its own workgroup has just rewritten, vxba_k23.hpp)
+template <int AUX = 0>
 __device__ __forceinline__ double k3_ld64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, AUX));
 }
 
 // clusters of batch b: five contiguous 1 KB rows per wave (batch-major copy) -- 83 % of an entry's bytes
@@ -205,7 +208,7 @@ struct K3Stage {
   double coe;       // lane < NV: coe of voxel slot `lane`
 };
 // request the plane parameters of batch b (transposed); voxels outside [head, end) read voxel `head` instead (masked later)
-template <int W>
+template <int W, int AUX = 0>
 __device__ __forceinline__ void k3_load_params(const K3Planes& pl, int head, int end, int b, int lane, K3Stage<W>& st, bool on = true) {
   using S = K3Stage<W>;
   const __amdgpu_buffer_rsrc_t rcache = k3_rsrc_gated(pl.cache_ptr, on), rcoe = k3_rsrc_gated(pl.coe_ptr, on);
@@ -220,16 +223,16 @@ __device__ __forceinline__ void k3_load_params(const K3Planes& pl, int head, int
     int plane = 0;
 #pragma unroll
     for (int kk = 0; kk < 17; kk++) plane = (k == kk) ? k3_param_plane(kk) : plane;
-    st.v[q] = k3_ld64(rcache, (unsigned)plane * pl.vs8 + (unsigned)a * 8u, 0);
+    st.v[q] = k3_ld64<AUX>(rcache, (unsigned)plane * pl.vs8 + (unsigned)a * 8u, 0);
   }
   {
     int a = b * S::NV + (lane < S::NV ? lane : 0);
     a = (a >= head && a < end) ? a : head;
-    st.coe = k3_ld64(rcoe, (unsigned)a * 8u, 0);
+    st.coe = k3_ld64<AUX>(rcoe, (unsigned)a * 8u, 0);
   }
 }
 // request q of the transposed plane parameters (q < Q) or the coe plane (q == Q): the interleaved form of k3_load_params
-template <int W>
+template <int W, int AUX = 0>
 __device__ __forceinline__ void k3_load_param_q(const K3Planes& pl, int head, int end, int b, int lane, K3Stage<W>& st, bool on, int q) {
   using S = K3Stage<W>;
   if (q < S::Q) {
@@ -242,12 +245,12 @@ __device__ __forceinline__ void k3_load_param_q(const K3Planes& pl, int head, in
     int plane = 0;
 #pragma unroll
     for (int kk = 0; kk < 17; kk++) plane = (k == kk) ? k3_param_plane(kk) : plane;
-    st.v[q] = k3_ld64(rcache, (unsigned)plane * pl.vs8 + (unsigned)a * 8u, 0);
+    st.v[q] = k3_ld64<AUX>(rcache, (unsigned)plane * pl.vs8 + (unsigned)a * 8u, 0);
   } else {
     const __amdgpu_buffer_rsrc_t rcoe = k3_rsrc_gated(pl.coe_ptr, on);
     int a = b * S::NV + (lane < S::NV ? lane : 0);
     a = (a >= head && a < end) ? a : head;
-    st.coe = k3_ld64(rcoe, (unsigned)a * 8u, 0);
+    st.coe = k3_ld64<AUX>(rcoe, (unsigned)a * 8u, 0);
   }
 }
 // park the staged values in the wave's LDS corner and read back the lane's own voxel record
@@ -355,6 +358,22 @@ __device__ __forceinline__ void k3_read_slots(const double* bp, int slab, double
   }
 }
 struct K3NoHook { __device__ __forceinline__ void operator()(int) const {} };
+// A wave that owns only one to three pairs (every wave at W <= 2, waves of the last run at W = 3, 5, ..) issues DEPENDENT v_mfma_f64_4x4x4_4b
+// instructions one to three issue slots apart.  The hardware interlocks such a chain only when SrcC and vDst are the same registers; when the
+// register allocator gives the accumulator a new home (vDst != SrcC: it does, around the software-pipelined operand registers), the distance is
+// the compiler's business -- and its table for this opcode is short on gfx950 (ROCm 7.2): the consumer read the accumulator BEFORE the producer
+// had written it and a whole slab's products were lost, depending on when the operand reads happened to land (round 6: W = 2 in the fused
+// residual + Hessian launch, pair (0, 0), 1 / 18 of S missing in 213 of 256 workgroups; the stand-alone kernel had the same instruction pattern
+// and passed by timing).  Sixteen idle issue slots behind each slab of such a wave make the chain safe whatever the allocation; waves with the
+// full 5 - 15 pairs per slab have their dependent instructions that far apart anyway and pay nothing.
+template <int NPAIR>
+__device__ __forceinline__ void k3_mfma_gap() {
+  if constexpr (NPAIR >= 1 && NPAIR <= 3) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 template <int W, int WV, bool FULL, class Hook>
 __device__ __forceinline__ void k3_mfma_wave(const double* bp, int nch, double* acc, Hook& hook) {
   using C = K3Cfg<W>;
@@ -370,6 +389,7 @@ __device__ __forceinline__ void k3_mfma_wave(const double* bp, int nch, double* 
         __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the MFMAs (the scheduler sinks them to their first use otherwise)
       }
       k3_mfma_pairs<W, WV, 0>(x, acc);
+      k3_mfma_gap<T.npair[WV]>();
       hook(q);
 #pragma unroll
       for (int s = 0; s < NS; s++) x[s] = xn[s];
@@ -379,6 +399,7 @@ __device__ __forceinline__ void k3_mfma_wave(const double* bp, int nch, double* 
       double x[NS];
       k3_read_slots<W, WV, 0>(bp, q, x);
       k3_mfma_pairs<W, WV, 0>(x, acc);
+      k3_mfma_gap<T.npair[WV]>();
     }
   }
 }
@@ -418,27 +439,51 @@ __device__ __forceinline__ void k3_sum_linear(const double* park_d, double* out,
 // microseconds earlier).  Structs are not preloaded and stop the sequence, hence the flat list; what is not urgent follows as before.
 //   pend_flags = pending | restart << 8, nwg = nwg (otherwise a load from the hidden arguments)
 constexpr int K3_LATE_PER = 4;   // requests behind each slab of phase M: all eight behind the first two of the nine slabs at W = 10 (1 and 2 per K-step measured slower in round 4: later requests land later)
-template <int W, bool DBG = false, bool MIXED = false>
-__global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k3_hessian_kernel(const double* __restrict__ clb, const double* __restrict__ cache_planes, const double* __restrict__ coe_plane,
-                                                              LMState* __restrict__ st, int VS, int head, int end, int c_in, int pend_flags, int nwg,
-                                                              PoseArg poses, LMPending pend, double* __restrict__ partial) {
+// The sweep of ONE workgroup.  FUSED = false: the body of k3_hessian_kernel (g = blockIdx.x).  FUSED = true: the Hessian half of the fused
+// residual + Hessian launch (k23_fused_kernel, vxba_k23.hpp): the caller -- workgroup g of nwg sweep workgroups -- has already put the
+// poses to linearise at into LDS (poseA), run the residual half over exactly this workgroup's voxels (cache planes rewritten, stores
+// acknowledged) and passed a workgroup barrier; there is no LM decision here (the reduction kernel behind the launch takes it), and the plane
+// parameters are read past this CU's vector L1 (AUX = sc1), which may still hold lines of the OLD eigenvector planes (the residual half's warm start).
+// Only the padding columns 6W .. 4 NG of the two tile buffers have to start as zeros (odd W: two columns): phase A writes columns
+// 0 .. 6W of every row of a step, the ragged step clears the rows it rounds up to, nothing else is read.
+template <int W>
+__device__ __forceinline__ void k3_clear_pads(double* lds, int tid) {
+  using C = K3Cfg<W>;
+  constexpr int PADC = C::NCOLS - 6 * W;
+  if constexpr (PADC > 0) {
+    for (int k = tid; k < 2 * C::ROWS * PADC; k += K3_BLOCK) {
+      const int b = k / (C::ROWS * PADC), rr = (k / PADC) % C::ROWS, cc = 6 * W + k % PADC;
+      lds[b * C::BUF + rr * C::RS + cc] = 0.0;
+    }
+  }
+}
+
+// FUSED: pre_c = the wave's first batch of clusters, requested by the caller (before the residual half's barrier; nullptr never);
+// the caller has cleared the padding columns and passed a barrier, so the first phase A starts when the wave's own parameters have landed.
+template <int W, bool DBG, bool MIXED, bool FUSED>
+__device__ __forceinline__ void k3_sweep_body(double* lds, const double* __restrict__ clb, const double* __restrict__ cache_planes, const double* __restrict__ coe_plane,
+                                              LMState* __restrict__ st, int VS, int head, int end, int c_in, int pend_flags, int nwg, int g, const PoseArg& poses,
+                                              const LMPending& pend, double* __restrict__ partial, const double* pre_c = nullptr) {
   const int pending = pend_flags & 0xff, restart = pend_flags >> 8;
+#ifdef VXBA_K23_DBG_PAUX0
+  constexpr int PAUX = 0;
+#else
+  constexpr int PAUX = FUSED ? 16 : 0;   // cache policy of the plane-parameter loads
+#endif
 
   using C = K3Cfg<W>;
-  extern __shared__ __attribute__((aligned(16))) double lds[];  // two tile buffers; reused by the epilogue
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // tell the compiler it is wave-uniform: scalar branches, descriptors in SGPRs
   const bool active = lane < C::NACT;
   const int vl = active ? lane / W : 0;
   const int fi = active ? lane % W : 0;
-  const int gw = blockIdx.x * C::WAVES + wave;
-  dbg_stamp(DBG, gw, 0);
+  const int gw = g * C::WAVES + wave;
+  dbg_stamp(DBG && !FUSED, gw, 0);
 
   // this workgroup's run of batches (absolute: batch b = voxels [b NV, (b+1) NV), so the batch-major copy does not depend on `head`)
   const int b0 = head / C::NV, b1 = (end - 1) / C::NV;
   const int nb_all = b1 - b0 + 1, G = nwg;
   const int q = nb_all / G, rem = nb_all % G;
-  const int g = blockIdx.x;
   const int cnt = q + (g < rem ? 1 : 0);
   const int bs = b0 + g * q + (g < rem ? g : rem);
 
@@ -473,15 +518,32 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
   // poses as soon as those are in LDS, wave 0 adds up residual2 behind the barrier, and the decision is taken behind the first step's
   // barrier (a rejected step costs one phase A instead of none; the common, accepted one no longer waits for the sum).
   constexpr int K3_FIRST_WAVES = C::WAVES / 2;   // (round 5, rebuilt sweep, same box: 2 / 6 / 8 waves in front of the barrier are within noise of 4 -- gpurun_out/r5_s5)
-  if (wave != 0 && wave < K3_FIRST_WAVES && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
+  if constexpr (!FUSED) {
+    if (wave != 0 && wave < K3_FIRST_WAVES && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
+  } else {
+    // fused launch: the poses are in LDS and this workgroup's cache planes are final -- every wave asks for its first batch at once (the
+    // lines come out of the L2 / the Infinity Cache: the residual half has just written the planes, the clusters were read a sweep ago)
+    if (wave < cnt) {
+#ifdef VXBA_K23_DBG_NOPRE
+      k3_load_clusters(pl, bs + wave, lane, e.c);
+#else
+#pragma unroll
+      for (int k = 0; k < 10; k++) e.c[k] = pre_c[k];
+#endif
+      k3_load_params<W, PAUX>(pl, head, end, bs + wave, lane, stg);
+    }
+#ifdef VXBA_K23_DBG_BARRIER
+    __syncthreads();
+#endif
+  }
 
   // LDS behind the two tile buffers: the poses (raw C-ABI layout: R column-major | p per frame) and what the LM decision needs
   double* poseA = lds + 2 * C::BUF;       // the poses `xa_src` selects
   double* lmv = poseA + 24 * W;           // [0] done, [1] calc_hess, [2] bench_mode, [3] residual1, [4] residual2 (written after the barrier)
   double* stage_lds = lmv + 8 + wave * K3Stage<W>::WAVE_DOUBLES;   // this wave's corner for redistributing the plane parameters
   LMResidual2Loads r2_loads;
-  const bool decide_here = st && pending == 1;
-  if (wave == 0) {
+  const bool decide_here = !FUSED && st && pending == 1;
+  if (!FUSED && wave == 0) {
     // The poses are one contiguous run of 12 W doubles, copied as such: ceil(12 W / 64) load instructions of consecutive lanes = 15 cache
     // lines per workgroup (one lane per frame and twelve strided loads each were 120 requests per workgroup for the same 15 lines).
     const double* __restrict__ xa_src = poses.Rp;
@@ -507,34 +569,26 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
     dbg_stamp(DBG, gw, 5);   // poses in LDS
   }
   dbg_stamp(DBG, gw, 2);     // first requests issued
-  // Only the padding columns 6W .. 4 NG of the two tile buffers have to start as zeros (odd W: two columns): phase A writes columns
-  // 0 .. 6W of every row of a step, the ragged step clears the rows it rounds up to, nothing else is read.
-  {
-    constexpr int PADC = C::NCOLS - 6 * W;
-    if constexpr (PADC > 0) {
-      for (int k = tid; k < 2 * C::ROWS * PADC; k += K3_BLOCK) {
-        const int b = k / (C::ROWS * PADC), rr = (k / PADC) % C::ROWS, cc = 6 * W + k % PADC;
-        lds[b * C::BUF + rr * C::RS + cc] = 0.0;
-      }
-    }
+  if constexpr (!FUSED) {
+    k3_clear_pads<W>(lds, tid);
+    dbg_stamp(DBG, gw, 4);     // tiles cleared
+    __syncthreads();
   }
-  dbg_stamp(DBG, gw, 4);     // tiles cleared
-  __syncthreads();
   dbg_stamp(DBG, gw, 1);
   bool undecided = false;
-  if (st) {
+  if (!FUSED && st) {
     const bool in_done = lmv[0] != 0.0, in_calc = lmv[1] != 0.0;
     if (pending >= 2) {
       if (in_done) return;
     } else if (pending) {
-      if (in_done) { if (blockIdx.x == nwg - 1) lm_carry(st, c_in, W); return; }
+      if (in_done) { if (g == nwg - 1) lm_carry(st, c_in, W); return; }
       undecided = true;
     } else {
       if (in_done || !in_calc) return;
     }
   }
-  if (wave >= K3_FIRST_WAVES && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
-  if (wave == 0 && undecided) {
+  if (!FUSED && wave >= K3_FIRST_WAVES && wave < cnt) { k3_load_clusters(pl, bs + wave, lane, e.c); k3_load_params<W>(pl, head, end, bs + wave, lane, stg); }
+  if (!FUSED && wave == 0 && undecided) {
     const double r2 = lm_residual2_finish(pend, r2_loads);
     if (lane == 0) lmv[4] = r2;
   }
@@ -546,7 +600,7 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
     const double r1 = lmv[3], r2 = lmv[4];
     const bool accept = (r1 - r2) > 0;
     const bool done = !bench && fabs((r1 - r2) / r1) < 1e-6;
-    if (blockIdx.x == nwg - 1) {
+    if (g == nwg - 1) {
       const LMDecision d = lm_decide(st->ctl[c_in], r2, restart);
       lm_persist(st, c_in, d, restart, poses, W);
     }
@@ -618,7 +672,7 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int r = 0; r < PER; r++) {
           const int l = kk * PER + r;
-          if (l < NQ) k3_load_param_q<W>(pl, head, end, nb_m, lane, stg, more_m, l);
+          if (l < NQ) k3_load_param_q<W, PAUX>(pl, head, end, nb_m, lane, stg, more_m, l);
           else if (l < NL) k3_load_cluster_row(pl, nb_m, lane, e.c, more_m, l - NQ);
         }
       };
@@ -652,7 +706,7 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
   dbg_stamp(DBG, gw, 3);
 
   // Epilogue.  One partial per workgroup:  [8 waves x PPWP pairs x 16 | W x DACC].
-  double* pout = partial + (size_t)blockIdx.x * C::PLEN;
+  double* pout = partial + (size_t)g * C::PLEN;
   double* park_d = lds;                                                   // [512 lanes][K3_DS] linear accumulators
   __syncthreads();  // every wave is done with the tiles
   dbg_stamp(DBG, gw, 27);
@@ -711,4 +765,12 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
   k3_sum_linear<W>(park_d, pout + C::NTILE, tid);
   dbg_stamp(DBG, gw, 6);
   if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 31); }   // ... and acknowledged
+}
+
+template <int W, bool DBG = false, bool MIXED = false>
+__global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k3_hessian_kernel(const double* __restrict__ clb, const double* __restrict__ cache_planes, const double* __restrict__ coe_plane,
+                                                              LMState* __restrict__ st, int VS, int head, int end, int c_in, int pend_flags, int nwg,
+                                                              PoseArg poses, LMPending pend, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // two tile buffers; reused by the epilogue
+  k3_sweep_body<W, DBG, MIXED, false>(lds, clb, cache_planes, coe_plane, st, VS, head, end, c_in, pend_flags, nwg, (int)blockIdx.x, poses, pend, partial);
 }

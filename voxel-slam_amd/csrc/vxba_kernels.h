@@ -140,8 +140,23 @@ int launch_k3_hessian(const FactorView& fv, const PoseArg& poses, LMState* st, i
 // Cross-workgroup reduction + assembly of the packed [Hess (6W)^2 col-major | JacT 6W | residual] buffer.
 // force: run even when the state says the sweep was not needed (sharded speculative loop); k2_partial: also leave the sum of the
 // residual sweep's wave partials in d_packed[(6W)^2 + 6W + 1].
+// reset_slots (nullable): n_reset doubles set to NaN -- the residual slots the solve workgroup of the next fused launch waits on (launch_k23_fused).
 void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, int write_state, double* d_packed, hipStream_t s, int force = 0,
-                        const double* k2_partial = nullptr, int k2_nparts = 0);
+                        const double* k2_partial = nullptr, int k2_nparts = 0, double* reset_slots = nullptr, int n_reset = 0);
+// K2 + K3 in one launch behind the in-launch solve (vxba_k23.hpp): workgroup 0 solves ctl[c] and publishes `seq`; nwg sweep workgroups run the
+// residual sweep at the trial poses over their run of voxels (one residual sum per workgroup into d_partial2[0..nwg)), then the Hessian sweep
+// at the same poses over the same voxels (workgroup partials into d_partial3, k3_partial_len(W) doubles each).  Returns nwg, or -1 when the
+// factor cannot take this path (f32 cluster rows, planes beyond 32-bit offsets, foreign plane layout).  flags bit 0: test hook (give up waiting at once).
+int k23_sweep_blocks(int nbatches, int device_cus);
+bool k23_supported(const FactorView& fv);
+int launch_k23_fused(const FactorView& fv, LMState* st, int c, unsigned seq, int head, int end, double* d_partial2, double* d_partial3, int nwg, int mixed, int flags,
+                     hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const double* host_feed = nullptr, const double* li_rec = nullptr,
+                     double* li_out = nullptr);
+// The solve workgroup then waits for the nwg residual sums (d_partial2 must hold NaN in [0, nwg) when the launch starts: launch_k3_finalize's
+// reset_slots), takes the step's accept / reject decision while the Hessian sweep runs and persists the decided control block into ctl[c ^ 1]
+// (calc_hess = accepted): launch_k3_finalize on ctl[c ^ 1] behind the launch adopts the system of an accepted step and drops a rejected one's.
+// flags bit 1: no decision in the launch (the caller's own shell decides).
+constexpr int K23_MAX_SWEEP_BLOCKS = 256;
 // Sharded speculative loop: decision for the pending trial from the reduced residual slot (into ctl[c_in ^ 1]) + adoption of the reduced system.
 void launch_lm_spec_unpack(LMState* st, int c_in, const double* d_packed, int W, int has_pending, int restart, const PoseArg& x0, hipStream_t s);
 // Voxel-sharded LM loop: fill the LM state (Hwork, Jwork, hess_out, residual1) from the ALL-REDUCED packed buffer (write_state

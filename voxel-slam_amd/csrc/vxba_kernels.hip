@@ -60,7 +60,10 @@ struct LMDecision {
   double u, v, r2, q;
   int calc_hess, done, converge, rejected, iter, n_accept, n_reject;
 };
-__device__ __forceinline__ LMDecision lm_decide(const LMCtl& in, double r2, int restart) {
+// (CtlT: LMCtl itself, or the scalars of it a caller fetched ahead of time -- LMCtlScalars)
+struct LMCtlScalars { double u, v, residual1, q1; int converge, n_accept, n_reject, iter, done, bench_mode; };
+template <class CtlT>
+__device__ __forceinline__ LMDecision lm_decide(const CtlT& in, double r2, int restart) {
   LMDecision d;
   const double r1 = in.residual1, q1 = in.q1;
   d.r2 = r2;
@@ -175,6 +178,19 @@ __device__ __forceinline__ void lm_carry(LMState* st, int c_in, int W) {
     out.bench_mode = in.bench_mode; out.n_accept = in.n_accept; out.n_reject = in.n_reject;
   }
 }
+// ... by ONE wave (the solve workgroup of a fused residual + Hessian launch, when the loop was left before it)
+__device__ __forceinline__ void lm_carry_wave(LMState* st, int c_in, int W) {
+  LMCtl& out = st->ctl[c_in ^ 1];
+  const LMCtl& in = st->ctl[c_in];
+  const int lane = threadIdx.x & 63;
+  for (int k = lane; k < 12 * W; k += 64) { out.x[k] = in.x[k]; out.xt[k] = in.xt[k]; }
+  if (lane == 0) {
+    out.u = in.u; out.v = in.v; out.residual1 = in.residual1; out.residual2 = in.residual2; out.q1 = in.q1;
+    out.resis[0] = in.resis[0]; out.resis[1] = in.resis[1];
+    out.calc_hess = in.calc_hess; out.done = in.done; out.iter = in.iter; out.converge = in.converge; out.rejected = in.rejected;
+    out.bench_mode = in.bench_mode; out.n_accept = in.n_accept; out.n_reject = in.n_reject;
+  }
+}
 // Persist the decided control block (one workgroup).  Poses: restart ? x0 : accept ? xt : x.
 __device__ __forceinline__ void lm_persist(LMState* st, int c_in, const LMDecision& d, int restart, const PoseArg& x0, int W) {
   const LMCtl& in = st->ctl[c_in];
@@ -186,6 +202,27 @@ __device__ __forceinline__ void lm_persist(LMState* st, int c_in, const LMDecisi
     out.xt[tid] = restart ? x0.Rp[tid] : in.xt[tid];
   }
   if (tid == 0) {
+    const int it = in.iter;
+    double* tr = st->trace + 8 * (it < LM_MAX_ITER ? it : LM_MAX_ITER - 1);
+    tr[0] = in.residual1; tr[1] = d.r2; tr[2] = in.u; tr[3] = in.v; tr[4] = d.q; tr[5] = in.q1; tr[6] = d.accept ? 1.0 : 0.0; tr[7] = in.calc_hess;
+    out.u = d.u; out.v = d.v;
+    out.residual1 = in.residual1; out.residual2 = d.r2; out.q1 = in.q1;
+    out.resis[0] = in.resis[0]; out.resis[1] = d.r2;
+    out.calc_hess = d.calc_hess; out.done = d.done; out.iter = d.iter; out.converge = d.converge; out.rejected = d.rejected;
+    out.bench_mode = in.bench_mode; out.n_accept = d.n_accept; out.n_reject = d.n_reject;
+  }
+}
+
+// lm_persist by ONE wave, restart = 0 (the solve workgroup of a fused residual + Hessian launch takes the decision itself)
+__device__ __forceinline__ void lm_persist_wave(LMState* st, int c_in, const LMDecision& d, int W) {
+  const LMCtl& in = st->ctl[c_in];
+  LMCtl& out = st->ctl[c_in ^ 1];
+  const int lane = threadIdx.x & 63;
+  for (int k = lane; k < 12 * W; k += 64) {
+    out.x[k] = d.accept ? in.xt[k] : in.x[k];
+    out.xt[k] = in.xt[k];
+  }
+  if (lane == 0) {
     const int it = in.iter;
     double* tr = st->trace + 8 * (it < LM_MAX_ITER ? it : LM_MAX_ITER - 1);
     tr[0] = in.residual1; tr[1] = d.r2; tr[2] = in.u; tr[3] = in.v; tr[4] = d.q; tr[5] = in.q1; tr[6] = d.accept ? 1.0 : 0.0; tr[7] = in.calc_hess;
@@ -283,11 +320,17 @@ __device__ __forceinline__ void fin_emit(const FinMap& m, double t0, double t1, 
 #define FIN_EL_ 16
 #endif
 constexpr int FIN_EL = FIN_EL_, FIN_SL = 64;   // FIN_EL * FIN_SL threads (<= 1024)
+// reset_slots (nullable): n_reset doubles set to NaN by the last workgroup -- the residual slots of the NEXT fused residual + Hessian launch
+// (vxba_k23.hpp: its solve workgroup waits for every sweep workgroup's sum to replace the NaN; this kernel runs between any two such launches).
 template <int W, bool DBG = false>
 __global__ __launch_bounds__(FIN_EL * FIN_SL) void k3_finalize_kernel(const double* __restrict__ partial, int nblocks, LMState* __restrict__ gate, int cb,
                                                            int write_state, double* __restrict__ packed, int force, const double* __restrict__ k2_partial,
-                                                           int k2_nparts) {
+                                                           int k2_nparts, double* __restrict__ reset_slots, int n_reset) {
   using C = K3Cfg<W>;
+#ifndef VXBA_K23_DBG_NORESET
+  if (reset_slots && blockIdx.x == gridDim.x - 1)
+    for (int k = threadIdx.x; k < n_reset; k += FIN_EL * FIN_SL) reset_slots[k] = __builtin_nan("");
+#endif
   const int dbg_w = 3000 + (int)blockIdx.x;            // instrumented build: stamps of wave 0 of every workgroup (rows 3000.. of the stamp table)
   dbg_stamp(DBG && threadIdx.x < 64, dbg_w, 0);
   // LM flags: requested now (vector loads: lane-dependent zero offset), tested after the partials are in flight
@@ -596,6 +639,11 @@ __global__ __launch_bounds__(K2_THREADS) void k2_residual_kernel(LMState* __rest
   }
   if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, vb, 4); }
 }
+
+// ------------------------------------------------------------------------------------------------
+// K2 + K3 in one launch behind the in-launch solve: vxba_k23.hpp
+// ------------------------------------------------------------------------------------------------
+#include "vxba_k23.hpp"
 
 __global__ __launch_bounds__(1024) void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
   __shared__ double red[1024];
@@ -1216,18 +1264,77 @@ int launch_k3_hessian(const FactorView& fv_in, const PoseArg& poses, LMState* st
 }
 
 void launch_k3_finalize(const double* d_partial, int nblocks, int W, LMState* st, int c, int write_state, double* d_packed, hipStream_t s, int force,
-                        const double* k2_partial, int k2_nparts) {
+                        const double* k2_partial, int k2_nparts, double* reset_slots, int n_reset) {
   const int plen = (int)k3_partial_len(W);
   static int dbg = -1;
   if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && ev[0] == '1') ? 1 : 0; }
   if (dbg) {
     VXK_DISPATCH_W(W, (k3_finalize_kernel<WW, true><<<dim3((plen + FIN_EL - 1) / FIN_EL), dim3(FIN_EL * FIN_SL), 0, s>>>(d_partial, nblocks, st, c, write_state, d_packed,
-                                                                                                                    force, k2_partial, k2_nparts)));
+                                                                                                                    force, k2_partial, k2_nparts, reset_slots, n_reset)));
     return;
   }
   VXK_DISPATCH_W(W, k3_finalize_kernel<WW><<<dim3((plen + FIN_EL - 1) / FIN_EL), dim3(FIN_EL * FIN_SL), 0, s>>>(d_partial, nblocks, st, c, write_state, d_packed,
-                                                                                                           force, k2_partial, k2_nparts));
+                                                                                                           force, k2_partial, k2_nparts, reset_slots, n_reset));
 }
+// dynamic LDS of the fused launch: the Hessian half's tiles, or the solve's block columns (workgroup 0), whichever is larger
+template <int W>
+constexpr size_t k23_lds_bytes() {
+  constexpr size_t a = k3_lds_bytes<W>(), b = (size_t)S4<W>::DOUBLES * sizeof(double);
+  return a > b ? a : b;
+}
+int k23_sweep_blocks(int nbatches, int device_cus) {   // one CU runs the solve
+#ifdef VXBA_K23_DBG_CUS
+  device_cus = VXBA_K23_DBG_CUS + 1;
+#endif
+  const int b = k3_blocks_for(nbatches, device_cus > 1 ? device_cus - 1 : 1);
+  return b < K23_MAX_SWEEP_BLOCKS ? b : K23_MAX_SWEEP_BLOCKS;
+}
+bool k23_supported(const FactorView& fv) {
+  // one buffer descriptor spans every plane: 32-bit offsets
+  return !fv.cl32 && fv.W >= 1 && fv.W <= MAXW && (unsigned long long)(10 * fv.W + 37) * (unsigned long long)fv.VS * 8ull < (1ull << 32);
+}
+int launch_k23_fused(const FactorView& fv, LMState* st, int c, unsigned seq, int head, int end, double* d_partial2, double* d_partial3, int nwg, int mixed, int flags,
+                     hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, const double* host_feed, const double* li_rec, double* li_out) {
+  if (!st || seq == 0 || nwg < 1 || nwg > K23_MAX_SWEEP_BLOCKS || end <= head || !k23_supported(fv)) return -1;
+  {  // the planes of a factor are one allocation in the order K23Planes assumes (vxc::view): refuse anything else loudly
+    const size_t VS = (size_t)fv.VS, W = (size_t)fv.W;
+    if (fv.fix != fv.cl + 10 * W * VS || fv.coe != fv.fix + 10 * VS || fv.eigval != fv.coe + VS || fv.eigvec != fv.eigval + 3 * VS || fv.merged != fv.eigvec + 9 * VS ||
+        fv.aux != fv.merged + 10 * VS)
+      return -1;
+  }
+  static int dbg = -1, head_start = -1;
+  if (dbg < 0) { const char* ev = getenv("VXBA_DBG"); dbg = (ev && (ev[0] == '1' || ev[0] == '2')) ? 1 : 0; }   // 2: this launch only (the other kernels' stamps share the table's rows)
+  if (head_start < 0) { const char* ev = getenv("VXBA_K2_HEAD_START"); head_start = ev ? atoi(ev) : K2_HEAD_START; if (head_start < 0) head_start = 0; }
+  const int flags_hs = (flags & 0xff) | (head_start << 8);
+#define K23_ARGS st, c, seq, li_rec, li_out, host_feed, head, end, nwg, flags_hs, fv.cl, fv.clb, (int)fv.VS, d_partial2, d_partial3
+  VXK_DISPATCH_W(fv.W, {
+    constexpr size_t lds_bytes = k23_lds_bytes<WW>();
+    static_assert(lds_bytes + 64 <= 160 * 1024, "fused launch: LDS");
+    static std::atomic<unsigned long long> opted{0ull};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int variant = mixed ? 2 : (dbg ? 1 : 0);
+    const unsigned long long bit = 1ull << ((3 * dev + variant) & 63);
+    if (!(opted.load(std::memory_order_relaxed) & bit) || dev > 20) {
+      const void* fn = mixed ? (const void*)k23_fused_kernel<WW, false, true> : (dbg ? (const void*)k23_fused_kernel<WW, true> : (const void*)k23_fused_kernel<WW, false>);
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      opted.fetch_or(bit, std::memory_order_relaxed);
+    }
+    const dim3 gr(nwg + 1), bl(K3_BLOCK);
+    if (mixed) {
+      if (ev_start) hipExtLaunchKernelGGL((k23_fused_kernel<WW, false, true>), gr, bl, (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, K23_ARGS);
+      else k23_fused_kernel<WW, false, true><<<gr, bl, lds_bytes, s>>>(K23_ARGS);
+    } else if (dbg) {
+      k23_fused_kernel<WW, true><<<gr, bl, lds_bytes, s>>>(K23_ARGS);
+    } else {
+      if (ev_start) hipExtLaunchKernelGGL((k23_fused_kernel<WW, false>), gr, bl, (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, K23_ARGS);
+      else k23_fused_kernel<WW, false><<<gr, bl, lds_bytes, s>>>(K23_ARGS);
+    }
+  });
+#undef K23_ARGS
+  return nwg;
+}
+
 void launch_lm_spec_unpack(LMState* st, int c_in, const double* d_packed, int W, int has_pending, int restart, const PoseArg& x0, hipStream_t s) {
   const int n = 6 * W;
   lm_spec_unpack_kernel<<<dim3((n * n + n + 255) / 256), dim3(256), 0, s>>>(st, c_in, d_packed, W, has_pending, restart, x0);

@@ -111,8 +111,9 @@ __device__ __forceinline__ void s4_apply(const double* lds, int t, int b, int la
 // waits for the host and the 6W-dimensional system never crosses PCIe on the critical path.
 constexpr int li_rec_len(int W) { return 1 + 12 * W + 6 * W + 36 * W * W; }
 constexpr int li_out_len(int W) { return 6 * W + 12 * W + 1; }
+// Returns 1 when the loop had already been left (nothing computed, nothing written), else 0.
 template <int W, bool DBG>
-__device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds, const double* __restrict__ li_rec = nullptr, double* __restrict__ li_out = nullptr,
+__device__ __forceinline__ int lm_solve_body4(LMState* st, int c, double* lds, const double* __restrict__ li_rec = nullptr, double* __restrict__ li_out = nullptr,
                                                unsigned li_seq = 0) {
   using C = S4<W>;
   LMCtl& ctl = st->ctl[c];
@@ -159,7 +160,7 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds, 
     for (int k = 0; k < 12; k++) xcur[k] = li_x ? li_x[12 * fl + k] : ctl.x[12 * fl + k];
   }
   if (wave == 1 % S4_WAVES) rhs0 = row_ok ? (li_e ? li_e[gi_row] : 0.0) - st->Jwork[gi_row] : 0.0;
-  if (loop_done) return;
+  if (loop_done) return 1;
   if (wave < B) s4_store_row(lds + C::TC + wave * S4_BLK + lane * S4_ROW, a0[0]);
   dbg_stamp(DBG && wave == 0, 4000, 2);
 
@@ -276,7 +277,7 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds, 
   }
   __syncthreads();
   dbg_stamp(DBG && wave == 0, 4000, 3);
-  if (wave != 0) return;
+  if (wave != 0) return 0;
 
   // ---- back substitution on wave 0: x = L^-T z.  Lane j (column j) takes L(r, j) x_r out of z_j for r = M-1 .. j+1; the rows of L are
   // requested a block ahead of the dependent (readlane, fma) chain.
@@ -340,4 +341,5 @@ __device__ __forceinline__ void lm_solve_body4(LMState* st, int c, double* lds, 
   for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
   if (lane == 0) ctl.q1 = 0.5 * part;
   if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, 4000, 5); }
+  return 0;
 }

@@ -28,7 +28,7 @@ _RESID_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.
 EXPORTS = [
     "vxba_create", "vxba_destroy", "vxba_clear", "vxba_set_win_size", "vxba_win_size", "vxba_size", "vxba_set_stream",
     "vxba_reserve", "vxba_last_error", "vxba_push_voxels", "vxba_push_points", "vxba_read_clusters", "vxba_acc_evaluate2",
-    "vxba_evaluate_only_residual", "vxba_get_collective_time", "vxba_acc_evaluate2_device", "vxba_evaluate_only_residual_device", "vxba_packed_len",
+    "vxba_evaluate_only_residual", "vxba_get_collective_time", "vxba_get_fused_time", "vxba_debug_partials", "vxba_acc_evaluate2_device", "vxba_evaluate_only_residual_device", "vxba_packed_len",
     "vxba_read_cache", "vxba_snapshot_cache", "vxba_restore_cache", "vxba_plane_fit", "vxba_plane_fit_judge", "vxba_build_clusters", "vxba_set_allreduce",
     "vxba_rccl_unique_id", "vxba_rccl_attach", "vxba_rccl_attach_bcast", "vxba_rccl_detach", "vxba_peer_export", "vxba_peer_attach", "vxba_peer_detach", "vxba_peer_status", "vxba_peer_selftest", "vxba_use_external_buffers", "vxba_damping_iter", "vxba_damping_iter_generic", "vxba_lm_steps", "vxba_set_profiling", "vxba_get_kernel_times", "vxba_algorithmic_bytes", "vxba_nnz", "vxba_device_bytes", "vxba_debug_mfma_probe", "vxba_debug_stamps", "vxba_debug_band_schur", "vxba_push_voxels_csr",
     "vxba_imu_init", "vxba_imu_add", "vxba_imu_evaluate", "vxba_imu_update_state", "vxba_hess_plus", "vxba_hess_plus_gravity", "vxba_li_evaluate", "vxba_li_evaluate_gravity",
@@ -127,6 +127,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.vxba_set_precision.argtypes = [vp, ci]
     L.vxba_get_kernel_times.argtypes = [vp, _f64p, _i64p, ci]
     L.vxba_get_collective_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), ci]
+    L.vxba_get_fused_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), ci]
     L.vxba_algorithmic_bytes.argtypes = [vp, _f64p]
     L.vxba_nnz.argtypes = [vp, C.POINTER(C.c_int64)]
     L.vxba_device_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -436,7 +437,7 @@ class LidarFactor:
         return st.value
 
     OPTIONS = {"fused_solve": 0, "spec_collective": 1, "wide_device_solve": 2, "k2_voxels_per_block": 4,
-               "debug_solve_timeout": 5, "li_structured_solve": 6, "li_queued_sweeps": 7, "li_device_pose_solve": 8, "stat_fused_fallbacks": 100, "stat_li_last_call_us": 101, "stat_li_device_fallbacks": 102}
+               "debug_solve_timeout": 5, "li_structured_solve": 6, "li_queued_sweeps": 7, "li_device_pose_solve": 8, "fused_sweeps": 9, "stat_fused_fallbacks": 100, "stat_li_last_call_us": 101, "stat_li_device_fallbacks": 102}
 
     def set_option(self, name: str, value: int):
         """Execution options of include/vxba.h (VXBA_OPT_*): fused_solve, spec_collective, wide_device_solve, k2_voxels_per_block."""
@@ -453,7 +454,7 @@ class LidarFactor:
         self._chk(self._L.vxba_set_precision(self._h, {"f64": 0, "mixed": 1, "mixed_f32_clusters": 2}[mode]))
 
     def set_profiling(self, mask: int):
-        """Bit mask of kernels to time with events: 1 K3, 2 K2, 4 K3 finalize, 8 K1 (0 = off)."""
+        """Bit mask of kernels to time with events: 1 K3, 2 K2, 4 K3 finalize, 8 K1, 16 all-reduce, 32 the fused launch (0 = off)."""
         self._chk(self._L.vxba_set_profiling(self._h, int(mask)))
 
     def kernel_times(self, reset=False):
@@ -466,6 +467,12 @@ class LidarFactor:
         """All-reduces of a voxel-sharded factor bracketed while profiling bit 16 was set: dict(ms_sum, calls)."""
         ms = C.c_double(0); calls = C.c_int64(0)
         self._chk(self._L.vxba_get_collective_time(self._h, C.byref(ms), C.byref(calls), int(reset)))
+        return dict(ms_sum=float(ms.value), calls=int(calls.value))
+
+    def fused_time(self, reset=False):
+        """Fused solve + residual + Hessian launches bracketed while profiling bit 32 was set: dict(ms_sum, calls)."""
+        ms = C.c_double(0); calls = C.c_int64(0)
+        self._chk(self._L.vxba_get_fused_time(self._h, C.byref(ms), C.byref(calls), int(reset)))
         return dict(ms_sum=float(ms.value), calls=int(calls.value))
 
     def algorithmic_bytes(self):
