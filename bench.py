@@ -37,7 +37,7 @@ FP64_MFMA_MEASURED_TFLOPS = 73.0   # v_mfma_f64_16x16x4_f64 issue-bound rate, sc
 FP64_SPEC_TFLOPS = 78.6            # vendor figure (not in the local guide)
 
 
-KERNEL_SOURCES = ("vxba_kernels.hip", "vxba_kernels.h", "vxba_k3.hpp", "vxba_math.hpp", "vxba_solve.hpp", "vxba_solve4.hpp")
+KERNEL_SOURCES = ("vxba_kernels.hip", "vxba_kernels.h", "vxba_k3.hpp", "vxba_k23.hpp", "vxba_math.hpp", "vxba_solve.hpp", "vxba_solve4.hpp")
 
 
 def kernel_source_hash():
@@ -338,12 +338,12 @@ def main():
     if args.warmup > 0:
         f.lm_steps(sc.poses_init, args.warmup, sps)
     f.kernel_times(reset=True)
-    f.set_profiling(1)                                     # hipEvents around the dominant kernel (K3) on the launch stream
+    f.set_profiling(1 | 32)                                # hipEvents bound to the dispatches of the Hessian sweep (K3) and of the fused solve + residual + Hessian launch
     # The timed region, `repeats` times: each one is exactly --steps steps between (barrier + synchronize) pairs, max over ranks.  The
     # reported figure is the median repeat -- with the driver's --steps 20 one region is 1.2 ms, and a single sample of it moved the
     # line by 5 % between boxes (round-3 review) -- min / max / n go into the line beside it.
     n_rep = max(1, args.repeats)
-    elapsed_all, k3_rep_ms, k3_calls = [], [], 0
+    elapsed_all, k3_rep_ms, k3_calls, fz_rep_ms, fz_calls = [], [], 0, [], 0
     host0 = host_cpu_state()
     for _ in range(n_rep):
         sync()
@@ -360,6 +360,10 @@ def main():
         ktr = f.kernel_times(reset=True)["k3_hessian"]
         k3_rep_ms.append(ktr["ms_sum"] / max(1, ktr["calls"]))
         k3_calls += ktr["calls"]
+        fzr = f.fused_time(reset=True)
+        if fzr["calls"]:
+            fz_rep_ms.append(fzr["ms_sum"] / fzr["calls"])
+            fz_calls += fzr["calls"]
     f.set_profiling(0)
     elapsed = float(np.median(elapsed_all))
     host1 = host_cpu_state()
@@ -413,6 +417,13 @@ def main():
         k3f_ms = kt2["k3_finalize"]["ms_sum"] / max(1, kt2["k3_finalize"]["calls"])
         achieved = abytes["k3"] / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic_bytes("k3_hessian_kernel", args.config)
+        # Round 6: inside a solve the residual sweep and the next iteration's Hessian sweep are ONE launch behind the in-launch solve
+        # (VXBA_OPT_FUSED_SWEEPS, csrc/vxba_k23.hpp) -- the dominant kernel of the loop when it runs.  Its algorithmic bytes are the two sweeps'
+        # (SURVEY 8d prices each sweep: the clusters are read once per sweep, in that sweep's layout); its duration contains the solve
+        # (one workgroup, the sweep workgroups hold their first rows meanwhile).
+        fz_ms = float(np.median(fz_rep_ms)) if fz_rep_ms else 0.0
+        fz_bytes = abytes["k3"] + abytes["k2"]
+        fz_traffic, fz_traffic_src = pmc_traffic_bytes("k23_fused_kernel", args.config)
         # fp64 work of one K3 launch: MFMA SYRK (round 5: 120 pairs of 4-column groups, one v_mfma_f64_4x4x4_4b = 512 flops per pair and 16-row
         # slab, 18 rows per batch of 6 voxels) + phase A (~294 f64 VALU instructions per entry, about 1.7 flops each)
         nbatch = (V + 5) // 6 if W == 10 else 0
@@ -447,8 +458,8 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f64" if args.precision == "f64" else ("f32 products / f64 accumulation (Hessian sweep), f64 elsewhere" if args.precision == "mixed" else
-                      "f32 products / f64 accumulation (Hessian sweep), f32 re-centred cluster rows (residual sweep), f64 arithmetic elsewhere"),
+            "dtype": "f64" if args.precision == "f64" else ("Jacobian rows rounded to f32, f64 products and accumulation (Hessian sweep), f64 elsewhere" if args.precision == "mixed" else
+                      "Jacobian rows rounded to f32, f64 products and accumulation (Hessian sweep), f32 re-centred cluster rows (residual sweep), f64 arithmetic elsewhere"),
             "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: W={W}, {sc.points_body.shape[0] // W} pts/scan, {V} voxels per GPU, nnz={nnz}",
@@ -494,6 +505,21 @@ def main():
                 "solve_plus_k2_launch_avg_ms": k2s_ms,
             },
         }
+        if fz_calls:
+            # the fused launch is the dominant kernel of the timed region: it becomes the line's `roofline` kernel, the stand-alone Hessian
+            # sweep (first iteration of every solve; the figure of rounds 1-5) stays beside it
+            r = out["roofline"]
+            r["k3_hessian_standalone"] = {"kernel": r["kernel"], "avg_launch_ms": k3_ms, "launches": r["launches"], "algorithmic_bytes_per_launch": abytes["k3"],
+                                          "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "mfma": r["mfma"]}
+            fz_ach = fz_bytes / (fz_ms * 1e-3) / 1e9
+            one_read = abytes["k2"] + 136.0 * V       # the clusters counted once: 80 nnz + 88 V + 176 V (residual half) + the 136 V of plane parameters the Hessian half re-reads
+            r.update(kernel=f"k23_fused_kernel<{W}>", achieved=fz_ach, frac=fz_ach / HBM_PEAK_GBS, avg_launch_ms=fz_ms, launches=fz_calls,
+                     algorithmic_bytes_per_launch=fz_bytes, traffic=fz_traffic, traffic_source=fz_traffic_src)
+            r["launch_contains"] = "in-launch damped solve (one workgroup; the 255 sweep workgroups request their rows meanwhile) | residual sweep at the trial poses | Hessian sweep at the same poses"
+            r["algorithmic_bytes_note"] = "SURVEY 8(d) per sweep: K2 80 nnz + 88 V read + 176 V written, K3 80 nnz + 136 V (each sweep reads the clusters in its own layout)"
+            r["frac_clusters_counted_once"] = one_read / (fz_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            r["launches_per_solve"] = {"k3_hessian_standalone": 1, "k23_fused": sps - 1, "solve_plus_residual": 1, "k3_finalize": sps}
+            r["mfma"] = None
         # K1 (once per window, reported separately -- SURVEY 8d): 24 B/point read + 80 B/(voxel,frame) written
         npts = int(sc.points_body.shape[0])
         k1_ms = k1["ms_sum"] / max(1, k1["calls"])
@@ -551,9 +577,11 @@ def main():
 
 def bench_cfg5(args, rank, world, local_rank, use_dist, backend, real_stdout):
     """BASELINE configs[4]: hierarchical global BA over a session of --keyframes keyframes (500) -- bottom level = windows of 10 keyframes with
-    stride 5 (99 of them) round-robin over the ranks, top level = ONE wide window over the ~99 submap poses, voxel-sharded by root-voxel hash
-    with one all-reduce of the packed (6W)^2 + 6W + 1 doubles (2.88 MB) per sweep (voxel_slam_amd.dist.hierarchical_ba_sharded).  A step is
-    one whole bottom-up pass; strong scaling (the session is fixed, the ranks share it).  `--steps` defaults to 3 and `--warmup` to 1 here."""
+    stride 5 (99 of them + the closing 5-keyframe window of upstream's last iteration) round-robin over the ranks, top level = ONE wide window over the
+    100 submap poses, voxel-sharded by root-voxel hash with one all-reduce of the packed (6W)^2 + 6W + 1 doubles (2.9 MB) per sweep.  ONE code path
+    for any N (round 6): voxel_slam_amd.dist.hba_pass -- vxba_hba_bottom over the rank's windows, the submaps all-gathered device to device,
+    vxba_hba_top on every rank (N = 1: the same three calls without the exchange).  A step is one whole bottom-up pass; strong scaling (the session is
+    fixed, the ranks share it).  `--steps` defaults to 3 and `--warmup` to 1 here."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -567,18 +595,14 @@ def bench_cfg5(args, rank, world, local_rank, use_dist, backend, real_stdout):
     coarse = vxba.VoxelizeParams(voxel_size=2.0, max_layer=2, min_points=10, min_eigen_value=0.02, eigen_ratio=(1 / 9, 1 / 9, 1 / 9, 1 / 9))
     fine = vxba.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
 
-    ctx = {}        # the two factors and the top-level factor's communicator live across passes
-    ses = None
-    if not use_dist:
-        # one GPU: the pass below the C ABI (csrc/vxba_hba.hip) -- the keyframe clouds go up ONCE, before the timed region (a mapper uploads a
-        # keyframe when it is created); a pass moves poses, Hessians and counts
-        ses = vxba.HbaSession(device=local_rank)
-        ses.add_keyframes(clouds)
+    ctx = {}        # the exchange tensors and the top-level factor's communicator live across passes
+    # the pass below the C ABI (csrc/vxba_hba.hip) on every rank -- the keyframe clouds go up ONCE, before the timed region (a mapper uploads a
+    # keyframe when it is created); a pass moves poses, Hessians, counts and (N > 1) the merged submaps between the GPUs
+    ses = vxba.HbaSession(device=local_rank)
+    ses.add_keyframes(clouds)
 
     def one_pass():
-        if use_dist:
-            return vdist.hierarchical_ba_sharded(clouds, poses, coarse, fine, wdsize=10, mgsize=5, top_max_iter=2, device=local_rank, ctx=ctx)
-        return ses.run_pass(poses, coarse, fine, wdsize=10, mgsize=5, top_max_iter=2, n_threads=args.hba_threads)
+        return vdist.hba_pass(ses, poses, coarse, fine, wdsize=10, mgsize=5, tail=True, top_max_iter=2, n_threads=args.hba_threads, ctx=ctx)
 
     def sync():
         if use_dist:
@@ -600,23 +624,27 @@ def bench_cfg5(args, rank, world, local_rank, use_dist, backend, real_stdout):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     roof, cpu = None, None
-    if rank == 0 and not use_dist:
-        # the dominant kernel of a pass (profiles/r05_cfg5/kernel_stats.csv): the cluster build inside the voxeliser, measured live in one more,
-        # untimed pass with events bound to its dispatches
+    # the dominant kernel of a pass (profiles/r05_cfg5/kernel_stats.csv): the cluster build inside the voxeliser, measured live in one more,
+    # untimed pass with events bound to its dispatches -- every rank runs the pass (it is collective), rank 0 measures
+    if rank == 0:
         vxba.voxelize_profile(True)
-        one_pass()
+    one_pass()
+    if rank == 0:
         pr = vxba.voxelize_profile(False)
         if pr["launches"]:
             avg_ms = pr["ms_sum"] / pr["launches"]
             ach = pr["algorithmic_bytes"] / (pr["ms_sum"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k1_build_rows_kernel (cluster build inside the voxeliser: vxba_voxelize_push_device)", "achieved": ach, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "traffic_source": "no --pmc pass collected for this configuration",
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                     "avg_launch_ms": avg_ms, "launches": pr["launches"], "algorithmic_bytes_per_launch": pr["algorithmic_bytes"] / pr["launches"],
                     "note": "launch sizes differ (three octree layers x two builds per voxelisation, 10-keyframe windows and the 99-submap top level): achieved = "
                             "sum of algorithmic bytes / sum of durations over the launches of one pass; 24 B per point + 8 B per cell offset read, 80 B per cluster written"}
+            tr, tr_src = pmc_traffic_bytes("k1_build_rows_kernel", "cfg5")
+            roof["traffic"], roof["traffic_source"] = tr, tr_src
         if not args.no_cpu_baseline:
             cpu = cfg5_cpu_baseline(clouds, poses, coarse, fine, out)
+    if use_dist:
+        dist.barrier()      # the other ranks took part in rank 0's profiled pass (the pass is collective) and wait for its CPU baseline here
     if rank == 0:
         ids = np.asarray(out["submap_ids"])
         S = len(ids)
@@ -625,8 +653,9 @@ def bench_cfg5(args, rank, world, local_rank, use_dist, backend, real_stdout):
                 "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": f"cfg5: {K} keyframes x {args.keyframe_points} points, {S} bottom-level windows, top level {S} submap poses / {int(np.sum(out['submap_sizes']))} points",
-                           "parallelism": "bottom-level windows round-robin over ranks (replicas); top level voxel-sharded by root-voxel hash + all-reduce of [Hess|JacT|res]" if use_dist
-                                          else f"one GPU, the pass below the C ABI (vxba_hba_pass), bottom-level windows over {out.get('n_threads_used', args.hba_threads)} host thread(s) / stream(s)",
+                           "parallelism": (f"{world} ranks: vxba_hba_bottom over windows rank, rank + {world}, .. | submaps all-gathered ({backend}) | vxba_hba_top voxel-sharded by root-voxel hash + all-reduce of [Hess|JacT|res]"
+                                           if use_dist else "one GPU: vxba_hba_bottom over every window | vxba_hba_top") +
+                                          f"; bottom-level windows over {out.get('n_threads_used', args.hba_threads)} host thread(s) / stream(s) per rank",
                            "top_packed_bytes": 8 * (36 * S * S + 6 * S + 1), "top_rounds": [dict(n_voxels_this_rank=r["n_voxels"], resis=r["resis"]) for r in out["top_rounds"]],
                            "edges": [len(out["edges1"]), len(out["edges2"])], "anchor_error_before_m_rad": [float(x) for x in e0], "anchor_error_after_m_rad": [float(x) for x in e1],
                            "session_generation_s": t_gen},
@@ -637,9 +666,8 @@ def bench_cfg5(args, rank, world, local_rank, use_dist, backend, real_stdout):
                          "hba_threads_used": out.get("n_threads_used")},
                 "note": "secondary workload (BASELINE configs[4]); the headline metric is the default cfg2 line"}
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
-    if ses is not None:
-        ses.close()
-    vdist.hba_ctx_close(ctx)
+    ctx.clear()
+    ses.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -495,7 +495,7 @@ int vxba_down_sampling_voxel(int device, int64_t n, const float* xyz, double vox
  * thd_globalmapping's loop (voxelslam.cpp:2485-2595): windows of `wdsize` keyframes with stride `mgsize`, each refined by one round of
  * HBA_add_edge (:2320-2482 -- OctreeGBA::cut_voxel + OctreeGBA_multi_recut, Lidar_BA_Optimizer::damping_iter with 4 iterations, Hessian ->
  * pose-graph edge weights :2405-2427) and merged into a voxel-filtered submap anchored at its first keyframe (:2430-2450); then ONE
- * HBA_add_edge over all S = (K - wdsize) / mgsize + 1 submap poses (S <= VXBA_MAX_WIN_WIDE) with up to `top_max_iter` re-voxelisation
+ * HBA_add_edge over all S submap poses (S <= VXBA_MAX_WIN_WIDE; vxba_hba_num_windows) with up to `top_max_iter` re-voxelisation
  * rounds.  The keyframe clouds live in device memory from vxba_hba_add_keyframes on; a pass moves only poses, Hessians and counts
  * across PCIe.  What consumes the edges (GTSAM's ISAM2 in the reference, :2231-2317) is outside this library. */
 typedef struct vxba_hba vxba_hba;
@@ -507,16 +507,44 @@ int vxba_hba_add_keyframes(vxba_hba* h, int64_t n_keyframes, const int64_t* clou
 int vxba_hba_num_keyframes(const vxba_hba* h);
 int vxba_hba_threads_used(const vxba_hba* h); /* host threads / streams the last vxba_hba_pass ran its bottom level on */
 int vxba_hba_clear(vxba_hba* h); /* forget the keyframes (the device buffers are kept) */
-/* poses: K x 12 ([R column-major 9 | p 3], as everywhere).  n_threads: 1 .. 8 host threads / streams for the bottom level (window w on thread w mod n_threads); <= 0: the library picks -- 4 (measured
- * best on one MI355X), fewer under a small cgroup CPU quota (the threads poll while their streams run).
- * Out: submap_poses S x 12 (refined anchors), submap_sizes S (points per voxel-filtered submap; may be NULL); the edges of both levels in
- * order -- bottom level window by window, then the top level: edge_ij 2 ints (keyframe indices i < j), edge_data 18 doubles [R_i^T R_j
- * row-major 9 | R_i^T (p_j - p_i) 3 | v6 = 1 / |hess(6i+k, 6j+k)| 6] per edge, at most edge_capacity of them (the counts are exact even
- * when the arrays were too small or NULL: VXBA_ERR_ARG then); top_rounds 5 doubles per top-level round [factor voxels, residual before,
- * after, is_converge, fine parameters used] (top_max_iter x 5, may be NULL). */
-int vxba_hba_pass(vxba_hba* h, const double* poses, const vxba_voxelize_params* coarse, const vxba_voxelize_params* fine, int wdsize, int mgsize,
+/* Windows of a bottom-up pass over K keyframes (thd_globalmapping, voxelslam.cpp:2498-2575): S_full = (K - wdsize) / mgsize + 1 full windows of
+ * wdsize keyframes at stride mgsize (0 when K < wdsize) and, with tail != 0, the CLOSING window of upstream's total_ba iteration (:2519-2523: it skips
+ * the "fewer than wdsize keyframes" test) over the keyframes left behind the last pop, [S_full mgsize, K) -- wdsize - mgsize .. wdsize - 1 of them
+ * in a long session, all K of a session shorter than one window.  A closing window of one keyframe is not refined (its cloud is the submap).
+ * vxba_hba_window: first keyframe and keyframe count of window w. */
+int vxba_hba_num_windows(int n_keyframes, int wdsize, int mgsize, int tail);
+int vxba_hba_window(int n_keyframes, int wdsize, int mgsize, int tail, int w, int* first, int* count);
+/* One whole pass on one device.  poses: K x 12 ([R column-major 9 | p 3], as everywhere).  n_threads: 1 .. 8 host threads / streams for the
+ * bottom level; <= 0: the library picks -- 4 (measured best on one MI355X), fewer under a small cgroup CPU quota (the threads poll while their
+ * streams run).  tail: see above (upstream: 1).
+ * Out, S = vxba_hba_num_windows(..): submap_poses S x 12 (refined anchors), submap_sizes S (points per voxel-filtered submap; may be NULL); the edges
+ * of both levels in order -- bottom level window by window, then the top level: edge_ij 2 ints (keyframe indices i < j), edge_data 18 doubles
+ * [R_i^T R_j row-major 9 | R_i^T (p_j - p_i) 3 | v6 = 1 / |hess(6i+k, 6j+k)| 6] per edge, at most edge_capacity of them (the counts are exact even
+ * when the arrays were too small or NULL: VXBA_ERR_ARG then); top_rounds 5 doubles per top-level round [factor voxels, residual before, after,
+ * is_converge, fine parameters used] (top_max_iter x 5, may be NULL). */
+int vxba_hba_pass(vxba_hba* h, const double* poses, const vxba_voxelize_params* coarse, const vxba_voxelize_params* fine, int wdsize, int mgsize, int tail,
                   int top_max_iter, int n_threads, double* submap_poses, int64_t* submap_sizes, int64_t edge_capacity, int32_t* edge_ij, double* edge_data,
                   int64_t* n_edges1, int64_t* n_edges2, double* top_rounds, int* n_top_rounds);
+/* The same pass in its two halves, for one rank of N (one process per GPU; vxba_hba_pass is vxba_hba_bottom(0, 1) + vxba_hba_top on one device):
+ *   vxba_hba_bottom          the windows w_first, w_first + w_stride, .. (rank r of N: r, N -- independent HBA_add_edge problems, no exchange): fills
+ *                            THEIR rows of submap_poses / submap_sizes, leaves their submaps in device memory, returns their edges with the window
+ *                            each came from (edge_window, may be NULL);
+ *   vxba_hba_export_submaps  those submaps packed back to back (window order, float xyz) into the caller's DEVICE buffer -- what the rank hands to
+ *                            the all-gather (ncclAllGather / torch.distributed over RCCL, device to device);
+ *   vxba_hba_import_submaps  a peer's packed submaps (sizes: S entries, the selection's are read) into place;
+ *   vxba_hba_top_factor      the factor of the top level (session-owned): attach the rank's collective to it (vxba_rccl_attach / vxba_peer_attach /
+ *                            vxba_set_allreduce) when the top level is voxel-sharded;
+ *   vxba_hba_top             ONE HBA_add_edge over all submap poses (voxelslam.cpp:2553-2560); coarse / fine may carry the rank's voxel shard
+ *                            (shard_index / shard_count: every rank voxelises the same submaps and keeps the root voxels that hash to it; the packed
+ *                            [Hess | JacT | residual] is summed by the attached collective, one all-reduce per sweep).  Needs every submap present. */
+int vxba_hba_bottom(vxba_hba* h, const double* poses, const vxba_voxelize_params* coarse, const vxba_voxelize_params* fine, int wdsize, int mgsize, int tail,
+                    int w_first, int w_stride, int n_threads, double* submap_poses, int64_t* submap_sizes, int64_t edge_capacity, int32_t* edge_ij,
+                    double* edge_data, int32_t* edge_window, int64_t* n_edges);
+int vxba_hba_export_submaps(vxba_hba* h, int w_first, int w_stride, float* d_out, int64_t capacity_points, int64_t* n_points);
+int vxba_hba_import_submaps(vxba_hba* h, int w_first, int w_stride, const int64_t* sizes, const float* d_in);
+int vxba_hba_top_factor(vxba_hba* h, vxba_factor** out);
+int vxba_hba_top(vxba_hba* h, const double* poses, const vxba_voxelize_params* coarse, const vxba_voxelize_params* fine, int top_max_iter, double* submap_poses,
+                 int64_t edge_capacity, int32_t* edge_ij, double* edge_data, int64_t* n_edges, double* top_rounds, int* n_top_rounds);
 
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* The cluster-build kernel inside the voxeliser (vxba_voxelize_push*, vxba_hba_pass) -- the dominant kernel of a hierarchical-BA pass.

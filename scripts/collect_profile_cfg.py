@@ -36,6 +36,7 @@ nnz = V * W if c.get("p_obs", 1.0) == 1.0 else None
 roof = {"config": cfg, "voxels": V, "win_size": W, "hbm_peak_GBs": 8000.0, "infinity_cache_bytes": 256 * 2**20}
 if nnz:
     alg = {"k3_hessian_kernel": 80.0 * nnz + 136.0 * V, "k2_residual_kernel": 80.0 * nnz + 88.0 * V + 176.0 * V}
+    alg["k23_fused_kernel"] = alg["k3_hessian_kernel"] + alg["k2_residual_kernel"]     # round 6: solve | residual sweep | Hessian sweep in one launch -- both sweeps' bytes
     roof["working_set_bytes_per_step"] = alg["k3_hessian_kernel"] + alg["k2_residual_kernel"]
     roof["fits_infinity_cache"] = roof["working_set_bytes_per_step"] < roof["infinity_cache_bytes"]
     for r in csv.DictReader(open(stats)):

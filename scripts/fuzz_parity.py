@@ -244,7 +244,7 @@ for case in range(n_cases):
         tmi = int(rng.integers(1, 4)); nth = int(rng.integers(1, 9))
         ref = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=wd, mgsize=mg, top_max_iter=tmi)
         ses = vxba.HbaSession(); ses.add_keyframes(clouds)
-        got = ses.run_pass(poses, coarse, fine, wdsize=wd, mgsize=mg, top_max_iter=tmi, n_threads=nth)
+        got = ses.run_pass(poses, coarse, fine, wdsize=wd, mgsize=mg, top_max_iter=tmi, n_threads=nth)   # (both run the closing window: tail defaults to True)
         ses.close()
         ds_ = np.abs(np.asarray(got["submap_sizes"]) - np.asarray(ref["submap_sizes"]))
         et, er = synth.pose_errors(got["submap_poses"], ref["submap_poses"])

@@ -114,3 +114,37 @@ def test_no_kernel_of_the_library_uses_scratch_memory():
     assert len(ours) > 150, len(ours)
     bad = {n: m for n, m in ours.items() if m.get("private_segment_fixed_size", -1) != 0 or m.get("vgpr_spill_count", -1) != 0}
     assert not bad, bad
+
+
+def test_hba_window_schedule_is_upstreams(lib):
+    """vxba_hba_num_windows / vxba_hba_window (no GPU needed) against a literal replay of thd_globalmapping's loop (voxelslam.cpp:2498-2575): keyframes
+    arrive one by one, a window runs whenever localID holds wdsize of them and mgsize are popped, and the closing iteration (total_ba == 1) runs on
+    whatever localID still holds -- the case the round-5 pass left out (advisor).  The Python twin used by the orchestration must agree."""
+    import ctypes as C
+    from voxel_slam_amd import hba
+
+    def upstream(K, wd, mg):
+        local, wins = [], []
+        for k in range(K):
+            local.append(k)
+            if len(local) < wd:
+                continue
+            wins.append((local[0], len(local)))
+            local = local[mg:] if mg <= len(local) else []
+        if local:                                  # the closing iteration: no size test (:2519-2523)
+            wins.append((local[0], len(local)))
+        return wins
+
+    for K in range(1, 60):
+        for wd, mg in ((10, 5), (6, 3), (2, 1), (5, 5), (4, 2), (10, 9), (3, 1)):
+            want = upstream(K, wd, mg)
+            n = lib.vxba_hba_num_windows(K, wd, mg, 1)
+            got = []
+            for w in range(n):
+                f0, c = C.c_int(), C.c_int()
+                assert lib.vxba_hba_window(K, wd, mg, 1, w, C.byref(f0), C.byref(c)) == 0
+                got.append((f0.value, c.value))
+            assert got == want == hba.windows(K, wd, mg), (K, wd, mg, got, want)
+            full = [x for x in want if x[1] == wd and x[0] + wd <= K and x[0] % mg == 0][: (K - wd) // mg + 1 if K >= wd else 0]
+            assert hba.windows(K, wd, mg, tail=False) == full and lib.vxba_hba_num_windows(K, wd, mg, 0) == len(full)
+    assert lib.vxba_hba_num_windows(0, 10, 5, 1) == 0 and lib.vxba_hba_num_windows(5, 10, 5, 0) == 0

@@ -258,7 +258,7 @@ def _hba_worker(rank, world, port, outdir):
             return vdist.damping_iter_sharded(W, xs, hess, lambda x: f.evaluate_only_residual(x) if f.size() else 0.0, max_iter=max_iter)
 
     def bottom_refine(xyz, fp, xs):
-        return hba.window_refine(xyz, fp, xs, coarse, fine, max_iter=1, optimizer=_OracleOpt(), voxelize=_oracle_voxelize(c["wdsize"]))
+        return hba.window_refine(xyz, fp, xs, coarse, fine, max_iter=1, optimizer=_OracleOpt(), voxelize=_oracle_voxelize(xs.shape[0]))   # the closing window has its own size
 
     def top_refine(xyz, fp, xs, si, sc):
         return hba.window_refine(xyz, fp, xs, coarse, fine, max_iter=2, optimizer=ShardedOpt(), voxelize=_oracle_voxelize(xs.shape[0], (si, sc)))
@@ -289,7 +289,7 @@ def test_hierarchical_ba_over_ranks_matches_single_process(tmp_path, world):
     c = HBA_CASE
     ref = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=c["wdsize"], mgsize=c["mgsize"], top_max_iter=2, optimizer=_OracleOpt(),
                               voxelize=_oracle_voxelize, downsample=O.down_sampling_voxel)
-    S = (c["K"] - c["wdsize"]) // c["mgsize"] + 1
+    S = len(hba.windows(c["K"], c["wdsize"], c["mgsize"]))                                          # full windows + the closing one
     assert sorted(int(w) for k in range(world) for w in r[k]["windows"]) == list(range(S))          # every window ran exactly once
     for k in range(world):
         assert [int(w) % world for w in r[k]["windows"]] == [k] * len(r[k]["windows"])

@@ -68,8 +68,8 @@ def test_hierarchical_pass_matches_oracle(K, wdsize, mgsize):
     got = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=wdsize, mgsize=mgsize, top_max_iter=2)
     ref = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=wdsize, mgsize=mgsize, top_max_iter=2, optimizer=_OracleOpt(), voxelize=_oracle_voxelize,
                               downsample=O.down_sampling_voxel)
-    S = (K - wdsize) // mgsize + 1
-    assert got["submap_ids"] == ref["submap_ids"] and len(got["submap_ids"]) == S
+    S = len(hba.windows(K, wdsize, mgsize))          # the full windows + the closing short one (voxelslam.cpp:2519-2523)
+    assert got["submap_ids"] == ref["submap_ids"] and len(got["submap_ids"]) == S == (K - wdsize) // mgsize + 2
     assert got["submap_sizes"] == ref["submap_sizes"]
     assert [r["n_voxels"] for r in got["top_rounds"]] == [r["n_voxels"] for r in ref["top_rounds"]]
     et, er = synth.pose_errors(got["submap_poses"], ref["submap_poses"])
@@ -138,7 +138,7 @@ def test_cfg5_size_pass_500_keyframes_matches_oracle(pts):
     ses.close()
     ref = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=10, mgsize=5, top_max_iter=2, optimizer=_OracleOpt(), voxelize=_oracle_voxelize,
                               downsample=O.down_sampling_voxel)
-    assert len(got["submap_ids"]) == 99 and got["submap_ids"] == ref["submap_ids"]
+    assert len(got["submap_ids"]) == 100 and got["submap_ids"] == ref["submap_ids"]          # 99 full windows + the closing 5-keyframe one
     # At this size the two runs are no longer point for point the same: bottom-level poses that agree to 1e-8 m put a handful of the 2.5 M
     # merged points on the other side of a 0.125 m filter cell or a voxel face, so submap sizes and factor counts may differ by a few units
     # (they are identical in the 105 / 205-keyframe cases above).  What must hold: sizes within a few points, counts within 0.2 %, submap
@@ -194,13 +194,17 @@ def test_hba_pass_with_a_window_that_has_no_planes():
         assert et < 1e-6 and er < 1e-6, (et, er)
 
 
-@pytest.mark.parametrize("case", ["one_empty_keyframe", "window_of_empty_keyframes", "one_submap", "wdsize_2", "stride_larger_than_window", "more_threads_than_windows"])
+@pytest.mark.parametrize("case", ["one_empty_keyframe", "window_of_empty_keyframes", "one_submap", "wdsize_2", "stride_larger_than_window", "more_threads_than_windows",
+                                  "shorter_than_a_window", "two_keyframes"])
 def test_hba_pass_degenerate_sessions_match_the_python_orchestration(case):
     """Shapes a mapper can hand over: a keyframe without points, a whole window without points (its factor is empty), a session of exactly one
-    window (a one-pose top level), two-keyframe windows, a stride that skips keyframes, more host threads than windows."""
+    full window (plus its closing window: a two-pose top level), two-keyframe windows whose closing window is ONE keyframe (not refined: its cloud is
+    the submap), a stride that skips keyframes (no keyframe left for a closing window), more host threads than windows, a session shorter than one
+    window (upstream's closing iteration runs HBA_add_edge on whatever localID holds: one 7-keyframe window, a one-pose top level) and one of two keyframes."""
     from voxel_slam_amd import hba, vxba
     K, wd, mg, threads, empty = {"one_empty_keyframe": (25, 10, 5, 3, [7]), "window_of_empty_keyframes": (30, 10, 5, 3, list(range(10, 20))), "one_submap": (10, 10, 5, 3, []),
-                                 "wdsize_2": (12, 2, 1, 3, []), "stride_larger_than_window": (26, 4, 7, 3, []), "more_threads_than_windows": (20, 5, 5, 8, [])}[case]
+                                 "wdsize_2": (12, 2, 1, 3, []), "stride_larger_than_window": (26, 4, 7, 3, []), "more_threads_than_windows": (20, 5, 5, 8, []),
+                                 "shorter_than_a_window": (7, 10, 5, 2, []), "two_keyframes": (2, 10, 5, 1, [])}[case]
     xyz, fp, poses, _ = synth.make_scans(win_size=K, pts_per_scan=4000, extent=24.0, noise=0.005, seed=synth.MASTER_SEED + 990 + K + wd, rot_sigma_deg=0.1, trans_sigma=0.02)
     clouds = [xyz[fp[i]:fp[i + 1]].astype(np.float32) for i in range(K)]
     for i in empty:
@@ -211,9 +215,55 @@ def test_hba_pass_degenerate_sessions_match_the_python_orchestration(case):
     ses = vxba.HbaSession(); ses.add_keyframes(clouds)
     got = ses.run_pass(poses, coarse, fine, wdsize=wd, mgsize=mg, top_max_iter=2, n_threads=threads)
     ses.close()
-    assert got["submap_ids"] == py["submap_ids"] and len(got["submap_ids"]) == (K - wd) // mg + 1
+    assert got["submap_ids"] == py["submap_ids"] == [b for b, _ in hba.windows(K, wd, mg)]
     assert np.max(np.abs(np.asarray(got["submap_sizes"]) - np.asarray(py["submap_sizes"]))) <= 2
     for key in ("edges1", "edges2"):
         assert [(e["i"], e["j"]) for e in got[key]] == [(e["i"], e["j"]) for e in py[key]]
     et, er = synth.pose_errors(got["submap_poses"], py["submap_poses"])
     assert et < 1e-7 and er < 1e-7, (et, er)
+
+
+def test_hba_pass_without_the_closing_window_and_in_two_halves():
+    """tail = False is the round-5 pass (full windows only); and the pass in its two halves (vxba_hba_bottom over the windows of "rank r of 2",
+    export / import of the packed submaps through a second session standing in for the peer's GPU, vxba_hba_top on both) must give what
+    vxba_hba_pass gives: the multi-GPU driver (dist.hba_pass) is these calls plus the exchange."""
+    import torch
+    from voxel_slam_amd import hba, vxba
+    K, wd, mg = 47, 10, 5
+    xyz, fp, poses, _ = synth.make_scans(win_size=K, pts_per_scan=4000, extent=24.0, noise=0.005, seed=synth.MASTER_SEED + 977, rot_sigma_deg=0.1, trans_sigma=0.02)
+    clouds = [xyz[fp[i]:fp[i + 1]].astype(np.float32) for i in range(K)]
+    coarse = vxba.VoxelizeParams(voxel_size=2.0, max_layer=2, min_points=10, min_eigen_value=0.02, eigen_ratio=(1 / 9, 1 / 9, 1 / 9, 1 / 9))
+    fine = vxba.VoxelizeParams(voxel_size=1.0, max_layer=2, min_points=10, min_eigen_value=0.01, eigen_ratio=(1 / 16, 1 / 16, 1 / 9, 1 / 9))
+    assert hba.windows(K, wd, mg) == vxba.HbaSession.windows(K, wd, mg) == [(5 * w, 10) for w in range(8)] + [(40, 7)]
+    assert hba.windows(K, wd, mg, tail=False) == vxba.HbaSession.windows(K, wd, mg, False) == [(5 * w, 10) for w in range(8)]
+    ses = vxba.HbaSession(); ses.add_keyframes(clouds)
+    no_tail = ses.run_pass(poses, coarse, fine, wdsize=wd, mgsize=mg, top_max_iter=2, n_threads=2, tail=False)
+    py = hba.hierarchical_ba(clouds, poses, coarse, fine, wdsize=wd, mgsize=mg, top_max_iter=2, tail=False)
+    assert no_tail["submap_ids"] == py["submap_ids"] == [5 * w for w in range(8)]
+    et, er = synth.pose_errors(no_tail["submap_poses"], py["submap_poses"])
+    assert et < 1e-7 and er < 1e-7
+    whole = ses.run_pass(poses, coarse, fine, wdsize=wd, mgsize=mg, top_max_iter=2, n_threads=2)
+    assert whole["submap_ids"] == [5 * w for w in range(9)] and len(whole["submap_sizes"]) == 9
+    # two "ranks" on one GPU: sessions a and b each run their windows, swap the packed submaps, run the top level
+    a, b = ses, vxba.HbaSession()
+    b.add_keyframes(clouds)
+    ba = a.bottom(poses, coarse, fine, wd, mg, True, w_first=0, w_stride=2, n_threads=2)
+    bb = b.bottom(poses, coarse, fine, wd, mg, True, w_first=1, w_stride=2, n_threads=1)
+    assert (ba["sizes"][0::2] >= 0).all() and (ba["sizes"][1::2] == -1).all() and (bb["sizes"][1::2] >= 0).all()
+    sizes = np.maximum(ba["sizes"], bb["sizes"])
+    assert [int(x) for x in sizes] == whole["submap_sizes"]
+    cap = int(sizes.sum()) + 1
+    ta, tb = torch.zeros((cap, 3), dtype=torch.float32, device="cuda"), torch.zeros((cap, 3), dtype=torch.float32, device="cuda")
+    assert a.export_submaps(0, 2, ta.data_ptr(), cap) == int(sizes[0::2].sum()) and b.export_submaps(1, 2, tb.data_ptr(), cap) == int(sizes[1::2].sum())
+    torch.cuda.synchronize()
+    a.import_submaps(1, 2, sizes, tb.data_ptr()); b.import_submaps(0, 2, sizes, ta.data_ptr())
+    top_a, top_b = a.top(poses, coarse, fine, 2), b.top(poses, coarse, fine, 2)
+    assert np.array_equal(top_a["submap_poses"], top_b["submap_poses"]) and np.array_equal(top_a["submap_poses"], whole["submap_poses"])
+    edges = sorted(ba["edges"] + bb["edges"], key=lambda e: e["window"])
+    assert [(e["i"], e["j"]) for e in edges] == [(e["i"], e["j"]) for e in whole["edges1"]]
+    assert [(e["i"], e["j"]) for e in top_a["edges2"]] == [(e["i"], e["j"]) for e in whole["edges2"]]
+    with pytest.raises(vxba.VxbaError):
+        c = vxba.HbaSession(); c.add_keyframes(clouds)
+        c.bottom(poses, coarse, fine, wd, mg, True, w_first=0, w_stride=2)
+        c.top(poses, coarse, fine, 1)            # the other rank's submaps are missing
+    a.close(); b.close()

@@ -73,6 +73,8 @@ struct vxba_hba {
   std::vector<int64_t> cloud_ptr{0};   // K + 1 offsets into d_xyz (points)
   vxhba::Worker wk[vxhba::MAX_THREADS];
   int bottom_w = 0;
+  vxba_factor* tail_f = nullptr;       // factor of the closing short window (its own window size)
+  int tail_w = 0;
   int threads_used = 0;                // host threads of the last pass
   vxba_factor* top = nullptr;
   int top_w = 0;
@@ -80,6 +82,9 @@ struct vxba_hba {
   size_t cap_sub = 0;
   double* d_top = nullptr;
   size_t cap_top = 0;
+  // geometry of the pass in progress (vxba_hba_bottom .. vxba_hba_top)
+  int p_K = 0, p_wd = 0, p_mg = 0, p_tail = 0, p_S = 0;
+  std::vector<int64_t> sub_off, sizes;     // S + 1 upper-bound offsets into d_sub; points per voxel-filtered submap (-1: not here yet)
 };
 
 namespace vxhba {
@@ -190,6 +195,7 @@ int vxba_hba_clear(vxba_hba* h) {
   if (!h) return VXBA_ERR_ARG;
   h->n_pts = 0;
   h->cloud_ptr.assign(1, 0);
+  h->p_K = h->p_S = 0;
   return VXBA_OK;
 }
 
@@ -204,6 +210,7 @@ int vxba_hba_destroy(vxba_hba* h) {
     w.ds.release();
   }
   if (h->top) vxba_destroy(h->top);
+  if (h->tail_f) vxba_destroy(h->tail_f);
   if (h->d_xyz) hipFree(h->d_xyz);
   if (h->d_sub) hipFree(h->d_sub);
   if (h->d_top) hipFree(h->d_top);
@@ -224,7 +231,10 @@ int vxba_hba_add_keyframes(vxba_hba* h, int64_t n_keyframes, const int64_t* clou
     const size_t want = (h->n_pts + (size_t)n) * 5 / 4 + 1024;
     float* p = nullptr;
     HB(hipMalloc((void**)&p, want * 3 * sizeof(float)));
-    if (h->n_pts) HB(hipMemcpy(p, h->d_xyz, h->n_pts * 3 * sizeof(float), hipMemcpyDeviceToDevice));
+    if (h->n_pts && hipMemcpy(p, h->d_xyz, h->n_pts * 3 * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) {
+      hipFree(p);
+      return fail(h, VXBA_ERR_HIP, "hba_add_keyframes: copying the resident keyframes failed");
+    }
     if (h->d_xyz) hipFree(h->d_xyz);
     h->d_xyz = p;
     h->cap_pts = want;
@@ -235,34 +245,86 @@ int vxba_hba_add_keyframes(vxba_hba* h, int64_t n_keyframes, const int64_t* clou
   return VXBA_OK;
 }
 
-int vxba_hba_pass(vxba_hba* h, const double* poses, const vxba_voxelize_params* coarse, const vxba_voxelize_params* fine, int wdsize, int mgsize,
-                  int top_max_iter, int n_threads, double* submap_poses, int64_t* submap_sizes, int64_t edge_capacity, int32_t* edge_ij, double* edge_data,
-                  int64_t* n_edges1, int64_t* n_edges2, double* top_rounds, int* n_top_rounds) {
-  if (!h || !poses || !coarse || !fine || !submap_poses || !n_edges1 || !n_edges2) return fail(h, VXBA_ERR_ARG, "hba_pass: null argument");
+}  // extern "C"
+
+// ---- windows of a pass (thd_globalmapping, voxelslam.cpp:2498-2575) ---------------------------------------------------------------
+// Full windows of wdsize keyframes at stride mgsize: a window runs whenever localID has reached wdsize keyframes, then mgsize of them are
+// popped (:2536-2541, :2571-2574).  tail != 0: the CLOSING iteration as well (total_ba == 1, :2519-2523 -- it skips the "localID.size() <
+// wdsize" test and runs HBA_add_edge on whatever localID still holds: the keyframes left behind the last pop, [S mgsize, K), and their
+// submap joins the top level).  A session shorter than one window is that closing window alone.
+static int full_windows(int K, int wd, int mg) { return K >= wd ? (K - wd) / mg + 1 : 0; }
+static int tail_first(int K, int wd, int mg) { return full_windows(K, wd, mg) * mg; }
+
+extern "C" {
+
+int vxba_hba_num_windows(int n_keyframes, int wdsize, int mgsize, int tail) {
+  if (n_keyframes < 0 || wdsize < 1 || mgsize < 1) return 0;
+  const int S = full_windows(n_keyframes, wdsize, mgsize);
+  return S + ((tail && tail_first(n_keyframes, wdsize, mgsize) < n_keyframes) ? 1 : 0);
+}
+int vxba_hba_window(int n_keyframes, int wdsize, int mgsize, int tail, int w, int* first, int* count) {
+  const int n = vxba_hba_num_windows(n_keyframes, wdsize, mgsize, tail), S = full_windows(n_keyframes, wdsize, mgsize);
+  if (w < 0 || w >= n || !first || !count) return VXBA_ERR_ARG;
+  *first = w * mgsize;
+  *count = w < S ? wdsize : n_keyframes - S * mgsize;
+  return VXBA_OK;
+}
+
+}  // extern "C"
+
+namespace vxhba {
+
+static int pass_geometry(vxba_hba* h, int wdsize, int mgsize, int tail) {
   const int K = (int)h->cloud_ptr.size() - 1;
-  if (wdsize < 2 || wdsize > VXBA_MAX_WIN || wdsize > MAX_WD || mgsize < 1 || K < wdsize) return fail(h, VXBA_ERR_ARG, "hba_pass: need 2 <= wdsize <= VXBA_MAX_WIN, mgsize >= 1, K >= wdsize");
-  const int S = (K - wdsize) / mgsize + 1;
-  if (S > VXBA_MAX_WIN_WIDE) return fail(h, VXBA_ERR_UNSUPPORTED, "hba_pass: more submaps than VXBA_MAX_WIN_WIDE");
-  if (top_max_iter < 1) top_max_iter = 1;
-  if (n_threads <= 0) n_threads = vxhba::default_threads();
-  n_threads = n_threads > vxhba::MAX_THREADS ? vxhba::MAX_THREADS : n_threads;
-  if (n_threads > S) n_threads = S;
-  h->threads_used = n_threads;
-  HB(hipSetDevice(h->device));
-  // ---- resources -------------------------------------------------------------------------------------------------------------
-  std::vector<int64_t> sub_off(S + 1, 0);
-  size_t max_win = 0;
-  for (int w = 0; w < S; w++) {
-    const size_t n = (size_t)(h->cloud_ptr[w * mgsize + wdsize] - h->cloud_ptr[w * mgsize]);
-    max_win = std::max(max_win, n);
-    sub_off[w + 1] = sub_off[w] + (int64_t)n;       // upper bound: the filter only removes points
+  if (wdsize < 2 || wdsize > VXBA_MAX_WIN || wdsize > MAX_WD || mgsize < 1) return fail(h, VXBA_ERR_ARG, "hba pass: need 2 <= wdsize <= VXBA_MAX_WIN and mgsize >= 1");
+  const int S = vxba_hba_num_windows(K, wdsize, mgsize, tail);
+  if (S < 1) return fail(h, VXBA_ERR_ARG, "hba pass: no window (fewer keyframes than wdsize and no closing window asked for, or no keyframes)");
+  if (S > VXBA_MAX_WIN_WIDE) return fail(h, VXBA_ERR_UNSUPPORTED, "hba pass: more submaps than VXBA_MAX_WIN_WIDE");
+  if (h->p_K != K || h->p_wd != wdsize || h->p_mg != mgsize || h->p_tail != tail || h->p_S != S || (int)h->sub_off.size() != S + 1) {
+    h->p_K = K; h->p_wd = wdsize; h->p_mg = mgsize; h->p_tail = tail; h->p_S = S;
+    h->sub_off.assign(S + 1, 0);
+    for (int w = 0; w < S; w++) {
+      int f0 = 0, cnt = 0;
+      vxba_hba_window(K, wdsize, mgsize, tail, w, &f0, &cnt);
+      h->sub_off[w + 1] = h->sub_off[w] + (h->cloud_ptr[f0 + cnt] - h->cloud_ptr[f0]);     // upper bound: the filter only removes points
+    }
   }
-  if ((size_t)sub_off[S] > h->cap_sub) {
+  h->sizes.assign(S, -1);
+  HB(hipSetDevice(h->device));
+  if ((size_t)h->sub_off[S] > h->cap_sub) {
     if (h->d_sub) hipFree(h->d_sub);
     h->d_sub = nullptr; h->cap_sub = 0;
-    HB(hipMalloc((void**)&h->d_sub, (size_t)sub_off[S] * 3 * sizeof(float)));
-    h->cap_sub = (size_t)sub_off[S];
+    HB(hipMalloc((void**)&h->d_sub, std::max<size_t>(1, (size_t)h->sub_off[S]) * 3 * sizeof(float)));
+    h->cap_sub = (size_t)h->sub_off[S];
   }
+  return VXBA_OK;
+}
+
+}  // namespace vxhba
+
+extern "C" {
+
+// Bottom level: the windows w_first, w_first + w_stride, .. of the pass on this device (one rank: 0, 1; rank r of N: r, N -- the windows
+// are independent HBA_add_edge problems), window k of them on host thread k mod n_threads.  Fills the rows of submap_poses / submap_sizes
+// of THESE windows, leaves their merged, voxel-filtered submaps in device memory and returns their pose-graph edges with the window each
+// one came from (edge_window, nullable).
+int vxba_hba_bottom(vxba_hba* h, const double* poses, const vxba_voxelize_params* coarse, const vxba_voxelize_params* fine, int wdsize, int mgsize, int tail,
+                    int w_first, int w_stride, int n_threads, double* submap_poses, int64_t* submap_sizes, int64_t edge_capacity, int32_t* edge_ij,
+                    double* edge_data, int32_t* edge_window, int64_t* n_edges) {
+  if (!h || !poses || !coarse || !fine || !submap_poses || !n_edges || w_first < 0 || w_stride < 1) return fail(h, VXBA_ERR_ARG, "hba_bottom: bad argument");
+  int rc = pass_geometry(h, wdsize, mgsize, tail);
+  if (rc != VXBA_OK) return rc;
+  const int K = h->p_K, S = h->p_S;
+  std::vector<int> mine;
+  for (int w = w_first; w < S; w += w_stride) mine.push_back(w);
+  const int nm = (int)mine.size();
+  if (n_threads <= 0) n_threads = vxhba::default_threads();
+  n_threads = n_threads > vxhba::MAX_THREADS ? vxhba::MAX_THREADS : n_threads;
+  if (n_threads > nm) n_threads = nm > 0 ? nm : 1;
+  h->threads_used = n_threads;
+  // ---- resources -------------------------------------------------------------------------------------------------------------
+  size_t max_win = 0;
+  for (int w : mine) max_win = std::max(max_win, (size_t)(h->sub_off[w + 1] - h->sub_off[w]));
   if (h->bottom_w != wdsize) {
     for (Worker& w : h->wk) if (w.f) { vxba_destroy(w.f); w.f = nullptr; }
     h->bottom_w = wdsize;
@@ -271,7 +333,7 @@ int vxba_hba_pass(vxba_hba* h, const double* poses, const vxba_voxelize_params* 
     Worker& w = h->wk[t];
     if (!w.s) HB(hipStreamCreateWithFlags(&w.s, hipStreamNonBlocking));
     if (!w.f) {
-      if (vxba_create(wdsize, h->device, &w.f) != VXBA_OK) return fail(h, VXBA_ERR_HIP, "hba_pass: vxba_create failed");
+      if (vxba_create(wdsize, h->device, &w.f) != VXBA_OK) return fail(h, VXBA_ERR_HIP, "hba_bottom: vxba_create failed");
       vxba_set_stream(w.f, (void*)w.s);
     }
     if (max_win > w.cap) {
@@ -283,67 +345,187 @@ int vxba_hba_pass(vxba_hba* h, const double* poses, const vxba_voxelize_params* 
       w.cap = max_win;
     }
   }
-  // ---- bottom level: window w on thread w mod n_threads ---------------------------------------------------------------------------
+  // ---- the windows ----------------------------------------------------------------------------------------------------------------
   std::vector<std::vector<Edge>> w_edges(S);
-  std::vector<int64_t> sizes(S, 0);
   auto run = [&](int t) {
     Worker& wk = h->wk[t];
     if (hipSetDevice(h->device) != hipSuccess) { wk.rc = VXBA_ERR_HIP; wk.err = "hipSetDevice"; return; }
     std::vector<double> hess;
-    for (int w = t; w < S; w += n_threads) {
-      const int base = w * mgsize;
-      const int64_t p0 = h->cloud_ptr[base], n = h->cloud_ptr[base + wdsize] - p0;
+    for (int k = t; k < nm; k += n_threads) {
+      const int w = mine[k];
+      int base = 0, cnt = 0;
+      vxba_hba_window(K, wdsize, mgsize, tail, w, &base, &cnt);
+      const int64_t p0 = h->cloud_ptr[base], n = h->cloud_ptr[base + cnt] - p0;
       int64_t fp[MAX_WD + 1], ids[MAX_WD];
-      for (int i = 0; i <= wdsize; i++) fp[i] = h->cloud_ptr[base + i] - p0;
-      for (int i = 0; i < wdsize; i++) ids[i] = base + i;
+      for (int i = 0; i <= cnt; i++) fp[i] = h->cloud_ptr[base + i] - p0;
+      for (int i = 0; i < cnt; i++) ids[i] = base + i;
       double xs[12 * MAX_WD];
-      std::memcpy(xs, poses + 12 * (size_t)base, sizeof(double) * 12 * wdsize);
+      std::memcpy(xs, poses + 12 * (size_t)base, sizeof(double) * 12 * cnt);
       const float* src = h->d_xyz + 3 * (size_t)p0;
-      if (n > 0) widen_f32_kernel<<<(unsigned)((3 * n + 255) / 256), 256, 0, wk.s>>>(src, 3 * n, wk.d_win);
-      wk.rc = window_refine(wk.f, wdsize, n, wk.d_win, fp, xs, coarse, fine, 1, hess, nullptr, wk.err);
-      if (wk.rc != VXBA_OK) return;
-      edges_from_hessian(xs, hess.data(), wdsize, ids, w_edges[w]);
+      if (cnt >= 2) {
+        // the closing window has its own size: a factor of that size, created once and kept (the only window that uses it runs on one thread)
+        vxba_factor* f = wk.f;
+        if (cnt != wdsize) {
+          if (h->tail_f && h->tail_w != cnt) { vxba_destroy(h->tail_f); h->tail_f = nullptr; }
+          if (!h->tail_f) {
+            if (vxba_create(cnt, h->device, &h->tail_f) != VXBA_OK) { wk.rc = VXBA_ERR_HIP; wk.err = "hba_bottom: vxba_create (closing window) failed"; return; }
+            h->tail_w = cnt;
+          }
+          vxba_set_stream(h->tail_f, (void*)wk.s);
+          f = h->tail_f;
+        }
+        if (n > 0) widen_f32_kernel<<<(unsigned)((3 * n + 255) / 256), 256, 0, wk.s>>>(src, 3 * n, wk.d_win);
+        wk.rc = window_refine(f, cnt, n, wk.d_win, fp, xs, coarse, fine, 1, hess, nullptr, wk.err);
+        if (wk.rc != VXBA_OK) return;
+        edges_from_hessian(xs, hess.data(), cnt, ids, w_edges[w]);
+      }   // a closing window of ONE keyframe: nothing to refine (the gauge fixes its only pose), no pair for an edge; its cloud is the submap
       // the merged submap in the first keyframe's coordinates, voxel-filtered at voxel_size / 8 (voxelslam.cpp:2430-2450)
       FrameXf xf;
-      xf.W = wdsize;
+      xf.W = cnt;
       double R0[9];
       pose_R(xs, R0);
-      for (int i = 0; i < wdsize; i++) {
+      for (int i = 0; i < cnt; i++) {
         double Ri[9];
         pose_R(xs + 12 * i, Ri);
         for (int r = 0; r < 3; r++) {
           for (int c = 0; c < 3; c++) xf.T[i][3 * r + c] = R0[r] * Ri[c] + R0[3 + r] * Ri[3 + c] + R0[6 + r] * Ri[6 + c];   // R0^T Ri
           double s = 0;
-          for (int k = 0; k < 3; k++) s += R0[3 * k + r] * (xs[12 * i + 9 + k] - xs[9 + k]);
+          for (int q = 0; q < 3; q++) s += R0[3 * q + r] * (xs[12 * i + 9 + q] - xs[9 + q]);
           xf.T[i][9 + r] = s;
         }
         xf.fp[i] = fp[i];
       }
-      xf.fp[wdsize] = fp[wdsize];
+      xf.fp[cnt] = fp[cnt];
       if (n > 0) merge_kernel<<<(unsigned)((n + 255) / 256), 256, 0, wk.s>>>(src, n, xf, wk.d_merged);
       int64_t kept = 0;
-      const int rcd = vxd::downsample_device(wk.ds, wk.s, wk.d_merged, n, fine->voxel_size / 8, h->d_sub + 3 * (size_t)sub_off[w], &kept);
-      if (rcd != VXBA_OK) { wk.rc = rcd; wk.err = "hba_pass: voxel filter of a submap failed"; return; }
-      sizes[w] = kept;
+      const int rcd = vxd::downsample_device(wk.ds, wk.s, wk.d_merged, n, fine->voxel_size / 8, h->d_sub + 3 * (size_t)h->sub_off[w], &kept);
+      if (rcd != VXBA_OK) { wk.rc = rcd; wk.err = "hba_bottom: voxel filter of a submap failed"; return; }
+      h->sizes[w] = kept;
+      if (submap_sizes) submap_sizes[w] = kept;
       std::memcpy(submap_poses + 12 * (size_t)w, poses + 12 * (size_t)base, sizeof(double) * 12);   // the top level starts from the INPUT anchor poses
     }
   };
   for (int t = 0; t < n_threads; t++) { h->wk[t].rc = VXBA_OK; h->wk[t].err.clear(); }
-  if (n_threads == 1) run(0);
-  else {
-    std::vector<std::thread> th;
-    for (int t = 1; t < n_threads; t++) th.emplace_back(run, t);
-    run(0);
-    for (std::thread& x : th) x.join();
+  if (nm > 0) {
+    if (n_threads == 1) run(0);
+    else {
+      std::vector<std::thread> th;
+      for (int t = 1; t < n_threads; t++) th.emplace_back(run, t);
+      run(0);
+      for (std::thread& x : th) x.join();
+    }
   }
-  for (int t = 0; t < n_threads; t++) {
-    if (h->wk[t].rc != VXBA_OK) return fail(h, h->wk[t].rc, h->wk[t].err);
-    HB(hipStreamSynchronize(h->wk[t].s));
-  }
-  // ---- edges of the bottom level, in window order ----------------------------------------------------------------------------------
+  // every stream drained BEFORE any worker's status is looked at: a failed pass must not leave the others' merge / filter kernels writing the
+  // session's buffers while the caller retries, clears or destroys it (round-5 advisor)
+  for (int t = 0; t < n_threads; t++) if (h->wk[t].s) (void)hipStreamSynchronize(h->wk[t].s);
+  for (int t = 0; t < n_threads; t++) if (h->wk[t].rc != VXBA_OK) return fail(h, h->wk[t].rc, h->wk[t].err);
+  // ---- edges, in window order ----------------------------------------------------------------------------------------------------
   int64_t ne = 0;
-  auto put_edges = [&](const std::vector<Edge>& es) {
-    for (const Edge& e : es) {
+  for (int w : mine)
+    for (const Edge& e : w_edges[w]) {
+      if (ne < edge_capacity && edge_ij && edge_data) {
+        edge_ij[2 * ne] = e.i; edge_ij[2 * ne + 1] = e.j;
+        std::memcpy(edge_data + 18 * ne, e.rot, sizeof e.rot);
+        std::memcpy(edge_data + 18 * ne + 9, e.tra, sizeof e.tra);
+        std::memcpy(edge_data + 18 * ne + 12, e.v6, sizeof e.v6);
+        if (edge_window) edge_window[ne] = w;
+      }
+      ne++;
+    }
+  *n_edges = ne;
+  if (ne > edge_capacity && edge_ij) return fail(h, VXBA_ERR_ARG, "hba_bottom: more edges than edge_capacity (the count is valid: call again with room for them)");
+  return VXBA_OK;
+}
+
+// The submaps of windows w_first, w_first + w_stride, .. packed back to back (window order) into d_out (device memory, float xyz): what a rank
+// hands to the all-gather in front of the top level.  *n_points = points written.
+int vxba_hba_export_submaps(vxba_hba* h, int w_first, int w_stride, float* d_out, int64_t capacity_points, int64_t* n_points) {
+  if (!h || w_first < 0 || w_stride < 1 || !n_points || h->p_S < 1) return fail(h, VXBA_ERR_ARG, "hba_export_submaps: bad argument / no pass in progress");
+  HB(hipSetDevice(h->device));
+  int64_t o = 0;
+  for (int w = w_first; w < h->p_S; w += w_stride) {
+    if (h->sizes[w] < 0) return fail(h, VXBA_ERR_STATE, "hba_export_submaps: a window of this selection has not been run here");
+    if (o + h->sizes[w] > capacity_points || (!d_out && h->sizes[w] > 0)) return fail(h, VXBA_ERR_ARG, "hba_export_submaps: buffer too small");
+    if (h->sizes[w] > 0) HB(hipMemcpy(d_out + 3 * (size_t)o, h->d_sub + 3 * (size_t)h->sub_off[w], (size_t)h->sizes[w] * 3 * sizeof(float), hipMemcpyDeviceToDevice));
+    o += h->sizes[w];
+  }
+  *n_points = o;
+  return VXBA_OK;
+}
+// ... and the other direction: a peer's packed submaps (sizes: points per window of the pass, the entries of the selection are read) into place.
+int vxba_hba_import_submaps(vxba_hba* h, int w_first, int w_stride, const int64_t* sizes, const float* d_in) {
+  if (!h || w_first < 0 || w_stride < 1 || !sizes || h->p_S < 1) return fail(h, VXBA_ERR_ARG, "hba_import_submaps: bad argument / no pass in progress");
+  HB(hipSetDevice(h->device));
+  int64_t o = 0;
+  for (int w = w_first; w < h->p_S; w += w_stride) {
+    if (sizes[w] < 0 || sizes[w] > h->sub_off[w + 1] - h->sub_off[w]) return fail(h, VXBA_ERR_ARG, "hba_import_submaps: a submap larger than its window");
+    if (sizes[w] > 0) {
+      if (!d_in) return fail(h, VXBA_ERR_ARG, "hba_import_submaps: null points");
+      HB(hipMemcpy(h->d_sub + 3 * (size_t)h->sub_off[w], d_in + 3 * (size_t)o, (size_t)sizes[w] * 3 * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    h->sizes[w] = sizes[w];
+    o += sizes[w];
+  }
+  return VXBA_OK;
+}
+
+// The factor the top level runs on (created for the pass's window count): a rank of a multi-GPU pass attaches its collective to it
+// (vxba_rccl_attach / vxba_peer_attach / vxba_set_allreduce) before vxba_hba_top.  Owned by the session.
+int vxba_hba_top_factor(vxba_hba* h, vxba_factor** out) {
+  if (!h || !out || h->p_S < 1) return fail(h, VXBA_ERR_ARG, "hba_top_factor: no pass in progress");
+  HB(hipSetDevice(h->device));
+  const int S = h->p_S;
+  if (h->top && h->top_w != S) { vxba_destroy(h->top); h->top = nullptr; }
+  if (!h->top) {
+    if (vxba_create(S, h->device, &h->top) != VXBA_OK) return fail(h, VXBA_ERR_HIP, "hba_top_factor: vxba_create failed");
+    h->top_w = S;
+    if (!h->wk[0].s) HB(hipStreamCreateWithFlags(&h->wk[0].s, hipStreamNonBlocking));
+    vxba_set_stream(h->top, (void*)h->wk[0].s);
+  }
+  *out = h->top;
+  return VXBA_OK;
+}
+
+// Top level: ONE HBA_add_edge over all submap poses (voxelslam.cpp:2553-2560), every submap of the pass present on this device (run here or
+// imported).  coarse / fine may carry a voxel shard (shard_index / shard_count): the factor then holds that shard and needs its collective.
+int vxba_hba_top(vxba_hba* h, const double* poses, const vxba_voxelize_params* coarse, const vxba_voxelize_params* fine, int top_max_iter, double* submap_poses,
+                 int64_t edge_capacity, int32_t* edge_ij, double* edge_data, int64_t* n_edges, double* top_rounds, int* n_top_rounds) {
+  if (!h || !poses || !coarse || !fine || !submap_poses || !n_edges || h->p_S < 1) return fail(h, VXBA_ERR_ARG, "hba_top: bad argument / no pass in progress");
+  const int S = h->p_S, K = h->p_K;
+  if (top_max_iter < 1) top_max_iter = 1;
+  vxba_factor* topf = nullptr;
+  int rc = vxba_hba_top_factor(h, &topf);
+  if (rc != VXBA_OK) return rc;
+  std::vector<int64_t> tfp(S + 1, 0), sid(S);
+  for (int w = 0; w < S; w++) {
+    if (h->sizes[w] < 0) return fail(h, VXBA_ERR_STATE, "hba_top: a submap of the pass is missing on this device (vxba_hba_bottom / vxba_hba_import_submaps)");
+    int base = 0, cnt = 0;
+    vxba_hba_window(K, h->p_wd, h->p_mg, h->p_tail, w, &base, &cnt);
+    tfp[w + 1] = tfp[w] + h->sizes[w];
+    sid[w] = base;
+    std::memcpy(submap_poses + 12 * (size_t)w, poses + 12 * (size_t)base, sizeof(double) * 12);
+  }
+  const size_t ntop = (size_t)tfp[S];
+  if (ntop > h->cap_top) {
+    if (h->d_top) hipFree(h->d_top);
+    h->d_top = nullptr; h->cap_top = 0;
+    HB(hipMalloc((void**)&h->d_top, ntop * 3 * sizeof(double)));
+    h->cap_top = ntop;
+  }
+  hipStream_t s0 = h->wk[0].s;
+  for (int w = 0; w < S; w++)
+    if (h->sizes[w] > 0)
+      widen_f32_kernel<<<(unsigned)((3 * h->sizes[w] + 255) / 256), 256, 0, s0>>>(h->d_sub + 3 * (size_t)h->sub_off[w], 3 * h->sizes[w], h->d_top + 3 * (size_t)tfp[w]);
+  std::vector<double> hess;
+  std::vector<RoundLog> log;
+  std::string terr;
+  int64_t ne = 0;
+  if (S >= 2) {
+    const int rct = window_refine(topf, S, (int64_t)ntop, h->d_top, tfp.data(), submap_poses, coarse, fine, top_max_iter, hess, &log, terr);
+    if (rct != VXBA_OK) return fail(h, rct, terr);
+    std::vector<Edge> e2;
+    edges_from_hessian(submap_poses, hess.data(), S, sid.data(), e2);
+    for (const Edge& e : e2) {
       if (ne < edge_capacity && edge_ij && edge_data) {
         edge_ij[2 * ne] = e.i; edge_ij[2 * ne + 1] = e.j;
         std::memcpy(edge_data + 18 * ne, e.rot, sizeof e.rot);
@@ -352,44 +534,32 @@ int vxba_hba_pass(vxba_hba* h, const double* poses, const vxba_voxelize_params* 
       }
       ne++;
     }
-  };
-  for (int w = 0; w < S; w++) put_edges(w_edges[w]);
-  *n_edges1 = ne;
-  // ---- top level: one window over the submap poses ---------------------------------------------------------------------------------
-  std::vector<int64_t> tfp(S + 1, 0), sid(S);
-  for (int w = 0; w < S; w++) { tfp[w + 1] = tfp[w] + sizes[w]; sid[w] = (int64_t)w * mgsize; if (submap_sizes) submap_sizes[w] = sizes[w]; }
-  const size_t ntop = (size_t)tfp[S];
-  if (ntop > h->cap_top) {
-    if (h->d_top) hipFree(h->d_top);
-    h->d_top = nullptr; h->cap_top = 0;
-    HB(hipMalloc((void**)&h->d_top, ntop * 3 * sizeof(double)));
-    h->cap_top = ntop;
-  }
-  if (h->top && h->top_w != S) { vxba_destroy(h->top); h->top = nullptr; }
-  if (!h->top) {
-    if (vxba_create(S, h->device, &h->top) != VXBA_OK) return fail(h, VXBA_ERR_HIP, "hba_pass: vxba_create (top level) failed");
-    h->top_w = S;
-    vxba_set_stream(h->top, (void*)h->wk[0].s);
-  }
-  for (int w = 0; w < S; w++)
-    if (sizes[w] > 0)
-      widen_f32_kernel<<<(unsigned)((3 * sizes[w] + 255) / 256), 256, 0, h->wk[0].s>>>(h->d_sub + 3 * (size_t)sub_off[w], 3 * sizes[w], h->d_top + 3 * (size_t)tfp[w]);
-  std::vector<double> hess;
-  std::vector<RoundLog> log;
-  std::string terr;
-  const int rct = window_refine(h->top, S, (int64_t)ntop, h->d_top, tfp.data(), submap_poses, coarse, fine, top_max_iter, hess, &log, terr);
-  if (rct != VXBA_OK) return fail(h, rct, terr);
-  std::vector<Edge> e2;
-  edges_from_hessian(submap_poses, hess.data(), S, sid.data(), e2);
-  put_edges(e2);
-  *n_edges2 = ne - *n_edges1;
+  }   // one submap: nothing to refine at the top
+  *n_edges = ne;
   if (n_top_rounds) *n_top_rounds = (int)log.size();
   if (top_rounds)
     for (size_t k = 0; k < log.size() && (int)k < top_max_iter; k++) {
       top_rounds[5 * k] = (double)log[k].n_voxels; top_rounds[5 * k + 1] = log[k].r0; top_rounds[5 * k + 2] = log[k].r1;
       top_rounds[5 * k + 3] = log[k].converged; top_rounds[5 * k + 4] = log[k].fine;
     }
-  if (ne > edge_capacity && edge_ij) return fail(h, VXBA_ERR_ARG, "hba_pass: more edges than edge_capacity (the counts are valid: call again with room for them)");
+  if (ne > edge_capacity && edge_ij) return fail(h, VXBA_ERR_ARG, "hba_top: more edges than edge_capacity (the count is valid: call again with room for them)");
+  return VXBA_OK;
+}
+
+// One whole pass on one device: vxba_hba_bottom over every window, then vxba_hba_top.
+int vxba_hba_pass(vxba_hba* h, const double* poses, const vxba_voxelize_params* coarse, const vxba_voxelize_params* fine, int wdsize, int mgsize, int tail,
+                  int top_max_iter, int n_threads, double* submap_poses, int64_t* submap_sizes, int64_t edge_capacity, int32_t* edge_ij, double* edge_data,
+                  int64_t* n_edges1, int64_t* n_edges2, double* top_rounds, int* n_top_rounds) {
+  if (!h || !n_edges1 || !n_edges2) return fail(h, VXBA_ERR_ARG, "hba_pass: null argument");
+  *n_edges1 = 0; *n_edges2 = 0;
+  int rc = vxba_hba_bottom(h, poses, coarse, fine, wdsize, mgsize, tail, 0, 1, n_threads, submap_poses, submap_sizes, edge_capacity, edge_ij, edge_data, nullptr, n_edges1);
+  const bool short1 = rc == VXBA_ERR_ARG && *n_edges1 > edge_capacity && edge_ij;   // too many edges: the counts stay valid, go on for the top level's count
+  if (rc != VXBA_OK && !short1) return rc;
+  const int64_t left = edge_capacity > *n_edges1 ? edge_capacity - *n_edges1 : 0;
+  rc = vxba_hba_top(h, poses, coarse, fine, top_max_iter, submap_poses, left, (edge_ij && left > 0) ? edge_ij + 2 * *n_edges1 : nullptr,
+                    (edge_data && left > 0) ? edge_data + 18 * *n_edges1 : nullptr, n_edges2, top_rounds, n_top_rounds);
+  if (rc != VXBA_OK && !(rc == VXBA_ERR_ARG && *n_edges2 > left)) return rc;
+  if (edge_ij && *n_edges1 + *n_edges2 > edge_capacity) return fail(h, VXBA_ERR_ARG, "hba_pass: more edges than edge_capacity (the counts are valid: call again with room for them)");
   return VXBA_OK;
 }
 

@@ -228,7 +228,7 @@ def hba_ctx_close(ctx: dict):
 
 
 def hierarchical_ba_sharded(clouds, poses, coarse, fine, wdsize: int = 10, mgsize: int = 5, top_max_iter: int = 1, device: int = 0, group=None,
-                            bottom_refine=None, top_refine=None, downsample=None, ctx: dict | None = None):
+                            bottom_refine=None, top_refine=None, downsample=None, ctx: dict | None = None, tail: bool = True):
     """``hba.hierarchical_ba`` (thd_globalmapping's bottom-up pass, voxelslam.cpp:2485-2595) over the ranks of ``group``, one process per GPU:
 
     * **bottom level** -- the windows of ``wdsize`` keyframes (stride ``mgsize``; 99 of them at BASELINE configs[4]) are independent
@@ -252,26 +252,32 @@ def hierarchical_ba_sharded(clouds, poses, coarse, fine, wdsize: int = 10, mgsiz
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     K = poses.shape[0]
-    bases = list(range(0, K - wdsize + 1, mgsize))
+    wins = hba.windows(K, wdsize, mgsize, tail)
+    bases = [b for b, _ in wins]
     mine = [w for w in range(len(bases)) if w % world == rank]
     bottom = None
     own = ctx is None
     ctx = {} if ctx is None else ctx
     if bottom_refine is None:
-        bottom = ctx.get(("bottom", wdsize))     # `is None`, not truthiness: LidarFactor.__len__ is its voxel count, an empty cached factor is falsy
-        if bottom is None:
-            bottom = ctx[("bottom", wdsize)] = vxba.LidarFactor(wdsize, device=device)
-
         def bottom_refine(xyz, fp, xs):
+            cnt = xs.shape[0]
+            bottom = ctx.get(("bottom", cnt))     # `is None`, not truthiness: LidarFactor.__len__ is its voxel count, an empty cached factor is falsy
+            if bottom is None:
+                bottom = ctx[("bottom", cnt)] = vxba.LidarFactor(cnt, device=device)
             return hba.window_refine(xyz, fp, xs, coarse, fine, max_iter=1, device=device, factor=bottom)
     my_sub, my_edges = [], []
     for w in mine:
-        ids = list(range(bases[w], bases[w] + wdsize))
-        xyz = np.ascontiguousarray(np.concatenate([np.asarray(clouds[i], dtype=np.float64) for i in ids]))
-        fp = np.concatenate([[0], np.cumsum([len(clouds[i]) for i in ids])]).astype(np.int64)
-        r = bottom_refine(xyz, fp, poses[ids])
-        my_edges.append([dict(e, i=ids[e["i"]], j=ids[e["j"]]) for e in hba.edges_from_hessian(r["poses"], r["hess"])])
-        my_sub.append(hba.merge_submap([clouds[i] for i in ids], r["poses"], fine.voxel_size, downsample=downsample, device=device))
+        ids = list(range(wins[w][0], wins[w][0] + wins[w][1]))
+        if len(ids) >= 2:
+            xyz = np.ascontiguousarray(np.concatenate([np.asarray(clouds[i], dtype=np.float64) for i in ids]))
+            fp = np.concatenate([[0], np.cumsum([len(clouds[i]) for i in ids])]).astype(np.int64)
+            r = bottom_refine(xyz, fp, poses[ids])
+            my_edges.append([dict(e, i=ids[e["i"]], j=ids[e["j"]]) for e in hba.edges_from_hessian(r["poses"], r["hess"])])
+            refined = r["poses"]
+        else:                                     # a closing window of one keyframe: nothing to refine, no pair for an edge
+            my_edges.append([])
+            refined = poses[ids]
+        my_sub.append(hba.merge_submap([clouds[i] for i in ids], refined, fine.voxel_size, downsample=downsample, device=device))
     # every rank needs every submap for the top level; the edges are small
     all_sub = _gather_arrays(my_sub, group)
     all_edges = [None] * world
@@ -318,3 +324,87 @@ def hierarchical_ba_sharded(clouds, poses, coarse, fine, wdsize: int = 10, mgsiz
     edges2 = [dict(e, i=sub_ids[e["i"]], j=sub_ids[e["j"]]) for e in hba.edges_from_hessian(top["poses"], top["hess"])]
     return dict(edges1=edges1, edges2=edges2, submap_ids=sub_ids, submap_poses=top["poses"], submap_sizes=[len(c) for c in sub_clouds], top_rounds=top["rounds"],
                 windows_of_rank=mine)
+
+
+def hba_pass(ses: "vxba.HbaSession", poses, coarse, fine, wdsize: int = 10, mgsize: int = 5, tail: bool = True, top_max_iter: int = 1, group=None,
+             n_threads: int = 0, ctx: dict | None = None):
+    """ONE code path for a bottom-up pass on any number of ranks (BASELINE configs[4]; round 6): the session's keyframes are resident on every
+    rank's GPU (``HbaSession.add_keyframes``), and a pass is
+
+    * ``vxba_hba_bottom`` over the windows ``rank, rank + world, ..`` -- below the C ABI, four polled streams per rank, submaps left in HBM;
+    * the submaps exchanged DEVICE TO DEVICE: each rank packs its windows' submaps (``vxba_hba_export_submaps``) into a tensor, one
+      ``all_gather`` (RCCL over xGMI under the ``nccl`` backend; host tensors under ``gloo``), the peers' submaps unpacked into place
+      (``vxba_hba_import_submaps``); the sizes and the windows' edges travel as Python objects (a few KB);
+    * ``vxba_hba_top`` on every rank: a wide top level (S > VXBA_MAX_WIN) voxel-sharded -- every rank voxelises the same submaps and keeps the
+      root voxels that hash to it, the packed [Hess | JacT | residual] summed by the collective attached to the session's top-level factor
+      (``ncclAllReduce`` inside the factor, else the ``torch.distributed`` hook) -- a narrow one whole on every rank (same inputs, same bits).
+
+    ``world == 1`` (``group`` None and no process group initialised, or a group of one) runs the same three calls without the exchange.
+    ``ctx``: keeps the collective's attachment alive between passes.  Returns what ``HbaSession.run_pass`` returns, plus ``windows_of_rank``."""
+    import torch
+    import torch.distributed as dist
+
+    from . import vxba
+
+    have_pg = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if have_pg else (0, 1)
+    import time
+    ctx = {} if ctx is None else ctx
+    t_0 = time.perf_counter()
+    bot = ses.bottom(poses, coarse, fine, wdsize, mgsize, tail, w_first=rank, w_stride=world, n_threads=n_threads)
+    t_1 = time.perf_counter()
+    wins, sizes = bot["windows"], bot["sizes"]
+    S = len(wins)
+    edges1 = bot["edges"]
+    if world > 1:
+        on_gpu = dist.get_backend(group) == "nccl"
+        all_sizes = [None] * world
+        dist.all_gather_object(all_sizes, [int(x) for x in sizes], group=group)
+        merged = np.array([max(col) for col in zip(*all_sizes)], dtype=np.int64)            # every window was run by exactly one rank (-1 elsewhere)
+        per_rank = [int(sum(merged[r::world])) for r in range(world)]
+        cap = max(1, max(per_rank))
+        key = ("xchg", cap, world, on_gpu)
+        if key not in ctx:
+            ctx[key] = (torch.zeros((cap, 3), dtype=torch.float32, device="cuda"), [torch.zeros((cap, 3), dtype=torch.float32, device="cuda" if on_gpu else "cpu") for _ in range(world)])
+        mine_t, outs = ctx[key]
+        n = ses.export_submaps(rank, world, mine_t.data_ptr(), cap)
+        assert n == per_rank[rank], (n, per_rank)
+        torch.cuda.synchronize()
+        dist.all_gather(outs, mine_t if on_gpu else mine_t.cpu(), group=group)
+        for r in range(world):
+            if r != rank:
+                peer = outs[r] if on_gpu else outs[r].cuda()
+                ses.import_submaps(r, world, merged, peer.data_ptr())
+        torch.cuda.synchronize()
+        sizes = merged
+        all_edges = [None] * world
+        dist.all_gather_object(all_edges, edges1, group=group)
+        edges1 = sorted((e for es in all_edges for e in es), key=lambda e: e["window"])       # stable: window order, each window's edges in its own order
+    t_2 = time.perf_counter()
+    shard_top = world > 1 and S > vxba.MAX_WIN
+    if shard_top and ("topf", S) not in ctx:
+        topf = ses.top_factor()
+        ok = False
+        keep = None
+        if dist.get_backend(group) == "nccl":
+            try:
+                attach_rccl(topf, group)
+                ok = True
+            except Exception:      # noqa: BLE001 -- fall back together below
+                ok = False
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        if not int(t.item()):
+            if ok:
+                topf.rccl_detach()
+            keep = attach_allreduce(topf, group)
+        ctx[("topf", S)] = (topf, keep)
+    c, f = (coarse.sharded(rank, world), fine.sharded(rank, world)) if shard_top else (coarse, fine)
+    t_3 = time.perf_counter()
+    top = ses.top(poses, c, f, top_max_iter)
+    t_4 = time.perf_counter()
+    for e in edges1:
+        e.pop("window", None)
+    return dict(edges1=edges1, edges2=top["edges2"], submap_ids=[b for b, _ in wins], submap_poses=top["submap_poses"], submap_sizes=[int(x) for x in sizes],
+                top_rounds=top["top_rounds"], windows_of_rank=list(range(rank, S, world)), n_threads_used=bot["n_threads_used"],
+                phase_s=dict(bottom=t_1 - t_0, exchange=t_2 - t_1, attach=t_3 - t_2, top=t_4 - t_3))

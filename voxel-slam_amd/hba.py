@@ -90,34 +90,55 @@ def merge_submap(clouds, poses, voxel_size: float, downsample=None, device: int 
     return ds(pl, voxel_size / 8)
 
 
+def windows(K: int, wdsize: int, mgsize: int, tail: bool = True):
+    """[(first keyframe, keyframe count)] of one bottom-up pass: the numpy-free twin of ``vxba_hba_num_windows`` / ``vxba_hba_window`` (include/vxba.h) --
+    full windows of ``wdsize`` keyframes at stride ``mgsize`` (thd_globalmapping runs one whenever localID holds wdsize keyframes and pops mgsize,
+    voxelslam.cpp:2536-2541, 2571-2574) and, with ``tail``, the CLOSING window of upstream's last iteration (total_ba == 1, :2519-2523: no size test) over
+    the keyframes left behind the last pop, [S mgsize, K)."""
+    S = (K - wdsize) // mgsize + 1 if K >= wdsize else 0
+    out = [(w * mgsize, wdsize) for w in range(S)]
+    if tail and S * mgsize < K:
+        out.append((S * mgsize, K - S * mgsize))
+    return out
+
+
 def hierarchical_ba(clouds, poses, coarse: "vxba.VoxelizeParams", fine: "vxba.VoxelizeParams", wdsize: int = 10, mgsize: int = 5, top_max_iter: int = 1,
-                    device: int = 0, optimizer=None, voxelize=None, downsample=None):
-    """Bottom-up pass of the global mapping thread (``thd_globalmapping``, voxelslam.cpp:2485-2595) over one session: windows of
-    ``wdsize`` keyframes, stride ``mgsize``, each refined by one round of ``HBA_add_edge`` (max_iter = 1: the odometry's voxel
-    parameters straight away, :2362-2372) and merged into a submap anchored at its first keyframe; then one ``HBA_add_edge`` over all
-    submap poses (the top level, up to VXBA_MAX_WIN_WIDE of them) with ``top_max_iter`` rounds.  Returns the pose-graph edges of both
-    levels (the GTSAM optimisation that consumes them is outside this library) and the refined submap poses.
+                    device: int = 0, optimizer=None, voxelize=None, downsample=None, tail: bool = True):
+    """Bottom-up pass of the global mapping thread (``thd_globalmapping``, voxelslam.cpp:2485-2595) over one session: the windows of ``windows(K, wdsize,
+    mgsize, tail)``, each refined by one round of ``HBA_add_edge`` (max_iter = 1: the odometry's voxel parameters straight away, :2362-2372) and merged
+    into a submap anchored at its first keyframe; then one ``HBA_add_edge`` over all submap poses (the top level, up to VXBA_MAX_WIN_WIDE of them) with
+    ``top_max_iter`` rounds.  A closing window of ONE keyframe is not refined (its only pose is the gauge; its cloud is the submap).  Returns the
+    pose-graph edges of both levels (the GTSAM optimisation that consumes them is outside this library) and the refined submap poses.
     ``clouds``: list of (n_i, 3) arrays in keyframe coordinates; ``poses``: (K, 12).  The keyword hooks run the same schedule on the
     CPU oracle in the tests."""
     K = poses.shape[0]
     sub_clouds, sub_ids, edges1 = [], [], []
-    bottom = vxba.LidarFactor(wdsize, device=device) if voxelize is None else None   # one factor for all bottom-level windows
-    for base in range(0, K - wdsize + 1, mgsize):
-        ids = list(range(base, base + wdsize))
-        xyz = np.ascontiguousarray(np.concatenate([np.asarray(clouds[i], dtype=np.float64) for i in ids]))
-        fp = np.concatenate([[0], np.cumsum([len(clouds[i]) for i in ids])]).astype(np.int64)
-        r = window_refine(xyz, fp, poses[ids], coarse, fine, max_iter=1, device=device, optimizer=optimizer, voxelize=None if voxelize is None else voxelize(wdsize),
-                          factor=bottom)
-        for e in edges_from_hessian(r["poses"], r["hess"]):
-            edges1.append(dict(e, i=ids[e["i"]], j=ids[e["j"]]))
-        sub_clouds.append(merge_submap([clouds[i] for i in ids], r["poses"], fine.voxel_size, downsample=downsample, device=device))
+    factors = {}                                                  # one factor per window size (the closing window has its own)
+    for base, cnt in windows(K, wdsize, mgsize, tail):
+        ids = list(range(base, base + cnt))
+        if cnt >= 2:
+            xyz = np.ascontiguousarray(np.concatenate([np.asarray(clouds[i], dtype=np.float64) for i in ids]))
+            fp = np.concatenate([[0], np.cumsum([len(clouds[i]) for i in ids])]).astype(np.int64)
+            if voxelize is None and cnt not in factors:
+                factors[cnt] = vxba.LidarFactor(cnt, device=device)
+            r = window_refine(xyz, fp, poses[ids], coarse, fine, max_iter=1, device=device, optimizer=optimizer, voxelize=None if voxelize is None else voxelize(cnt),
+                              factor=factors.get(cnt))
+            for e in edges_from_hessian(r["poses"], r["hess"]):
+                edges1.append(dict(e, i=ids[e["i"]], j=ids[e["j"]]))
+            refined = r["poses"]
+        else:
+            refined = poses[ids]
+        sub_clouds.append(merge_submap([clouds[i] for i in ids], refined, fine.voxel_size, downsample=downsample, device=device))
         sub_ids.append(base)
-    if bottom is not None:
-        bottom.close()
+    for f in factors.values():
+        f.close()
     S = len(sub_ids)
     top_xyz = np.ascontiguousarray(np.concatenate(sub_clouds).astype(np.float64))
     top_fp = np.concatenate([[0], np.cumsum([len(c) for c in sub_clouds])]).astype(np.int64)
-    top = window_refine(top_xyz, top_fp, poses[sub_ids], coarse, fine, max_iter=top_max_iter, device=device, optimizer=optimizer,
-                        voxelize=None if voxelize is None else voxelize(S))
-    edges2 = [dict(e, i=sub_ids[e["i"]], j=sub_ids[e["j"]]) for e in edges_from_hessian(top["poses"], top["hess"])]
+    if S >= 2:
+        top = window_refine(top_xyz, top_fp, poses[sub_ids], coarse, fine, max_iter=top_max_iter, device=device, optimizer=optimizer,
+                            voxelize=None if voxelize is None else voxelize(S))
+        edges2 = [dict(e, i=sub_ids[e["i"]], j=sub_ids[e["j"]]) for e in edges_from_hessian(top["poses"], top["hess"])]
+    else:
+        top, edges2 = dict(poses=np.array(poses[sub_ids], dtype=np.float64), rounds=[]), []
     return dict(edges1=edges1, edges2=edges2, submap_ids=sub_ids, submap_poses=top["poses"], submap_sizes=[len(c) for c in sub_clouds], top_rounds=top["rounds"])

@@ -36,7 +36,7 @@ EXPORTS = [
     "vxba_lio_create", "vxba_lio_destroy", "vxba_lio_last_error", "vxba_lio_map_update", "vxba_lio_map_clear", "vxba_lio_map_size", "vxba_lio_scan_raw",
     "vxba_lio_scan_set", "vxba_lio_scan_size", "vxba_lio_scan_read", "vxba_lio_sweep", "vxba_lio_state_estimation", "vxba_lio_pvec_update", "vxba_lio_leaf_stats", "vxba_cov_add_build", "vxba_plane_update", "vxba_down_sampling_voxel", "vxba_voxelize_push_device",
     "vxba_set_option", "vxba_get_option", "vxba_lio_set_option",
-    "vxba_hba_create", "vxba_hba_destroy", "vxba_hba_last_error", "vxba_hba_add_keyframes", "vxba_hba_num_keyframes", "vxba_hba_threads_used", "vxba_hba_clear", "vxba_hba_pass", "vxba_voxelize_profile",
+    "vxba_hba_create", "vxba_hba_destroy", "vxba_hba_last_error", "vxba_hba_add_keyframes", "vxba_hba_num_keyframes", "vxba_hba_threads_used", "vxba_hba_clear", "vxba_hba_pass", "vxba_hba_num_windows", "vxba_hba_window", "vxba_hba_bottom", "vxba_hba_export_submaps", "vxba_hba_import_submaps", "vxba_hba_top_factor", "vxba_hba_top", "vxba_voxelize_profile",
     "vxba_map_create", "vxba_map_destroy", "vxba_map_last_error", "vxba_map_cut_voxel", "vxba_map_cut_voxel_device", "vxba_map_recut", "vxba_map_margi",
     "vxba_map_slide", "vxba_map_counts", "vxba_map_fix_pool", "vxba_map_set_journey", "vxba_map_release", "vxba_map_device_bytes", "vxba_map_leaves", "vxba_map_cut_voxel_lio", "vxba_map_export_planes",
 ]
@@ -221,6 +221,17 @@ class LidarFactor:
             raise VxbaError(f"vxba_create(win_size={win_size}, device={device}) failed: {_ERRNAMES.get(rc, rc)} "
                             "(needs a gfx950 GPU; there is no CPU fallback)")
         self._cb = None
+        self._owned = True
+
+    @classmethod
+    def from_handle(cls, handle):
+        """A view of a factor somebody else owns (the top-level factor of an ``HbaSession``): every method works, ``close`` leaves it alone."""
+        self = cls.__new__(cls)
+        self._L = load_library()
+        self._h = C.c_void_p(handle if isinstance(handle, int) else handle.value)
+        self._cb = None
+        self._owned = False
+        return self
 
     # -- plumbing -------------------------------------------------------------------------------
     def _chk(self, rc):
@@ -230,7 +241,8 @@ class LidarFactor:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            self._L.vxba_destroy(self._h)
+            if getattr(self, "_owned", True):
+                self._L.vxba_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -894,28 +906,109 @@ class HbaSession:
     def clear(self):
         self._check(self._L.vxba_hba_clear(self._h), "vxba_hba_clear")
 
-    def run_pass(self, poses, coarse: VoxelizeParams, fine: VoxelizeParams, wdsize: int = 10, mgsize: int = 5, top_max_iter: int = 1, n_threads: int = 0):
-        """One bottom-up pass; returns what ``hba.hierarchical_ba`` returns (edges as dicts with keyframe indices)."""
+    @staticmethod
+    def windows(K: int, wdsize: int, mgsize: int, tail: bool = True):
+        """``vxba_hba_num_windows`` / ``vxba_hba_window``: [(first keyframe, keyframe count)] of a pass over K keyframes -- the full windows at stride
+        ``mgsize`` and, with ``tail``, the closing short window of upstream's last iteration (voxelslam.cpp:2519-2523)."""
+        L = load_library()
+        n = L.vxba_hba_num_windows(int(K), int(wdsize), int(mgsize), int(bool(tail)))
+        out = []
+        for w in range(n):
+            f0, c = C.c_int(), C.c_int()
+            L.vxba_hba_window(int(K), int(wdsize), int(mgsize), int(bool(tail)), w, C.byref(f0), C.byref(c))
+            out.append((f0.value, c.value))
+        return out
+
+    @staticmethod
+    def _edges(eij, edata, lo, hi, win=None):
+        return [dict(i=int(eij[k, 0]), j=int(eij[k, 1]), rot=edata[k, :9].reshape(3, 3).copy(), tra=edata[k, 9:12].copy(), v6=edata[k, 12:18].copy(),
+                     **({} if win is None else {"window": int(win[k])})) for k in range(lo, hi)]
+
+    def _poses(self, poses):
         poses = _c(poses).reshape(-1, 12)
+        if poses.shape[0] != self.num_keyframes():
+            raise VxbaError(f"hba pass: {poses.shape[0]} poses for {self.num_keyframes()} keyframes")
+        return poses
+
+    def run_pass(self, poses, coarse: VoxelizeParams, fine: VoxelizeParams, wdsize: int = 10, mgsize: int = 5, top_max_iter: int = 1, n_threads: int = 0,
+                 tail: bool = True):
+        """One bottom-up pass on this device (``vxba_hba_pass``); returns what ``hba.hierarchical_ba`` returns (edges as dicts with keyframe indices)."""
+        poses = self._poses(poses)
         K = poses.shape[0]
-        if K != self.num_keyframes():
-            raise VxbaError(f"run_pass: {K} poses for {self.num_keyframes()} keyframes")
-        S = (K - wdsize) // mgsize + 1
-        cap = S * (wdsize * (wdsize - 1) // 2) + S * (S - 1) // 2
+        wins = self.windows(K, wdsize, mgsize, tail)
+        S = len(wins)
+        if S < 1:
+            raise VxbaError(f"hba pass: no window for {K} keyframes with wdsize {wdsize}, mgsize {mgsize}, tail {tail}")
+        cap = sum(c * (c - 1) // 2 for _, c in wins) + S * (S - 1) // 2 + 1
         sub_poses = np.zeros((S, 12)); sizes = np.zeros(S, dtype=np.int64)
         eij = np.zeros((cap, 2), dtype=np.int32); edata = np.zeros((cap, 18))
         n1, n2, ntr = C.c_int64(), C.c_int64(), C.c_int()
         rounds = np.zeros((max(1, top_max_iter), 5))
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
-        self._check(self._L.vxba_hba_pass(self._h, vp(poses), C.byref(coarse), C.byref(fine), int(wdsize), int(mgsize), int(top_max_iter), int(n_threads), vp(sub_poses),
-                                          vp(sizes), C.c_int64(cap), vp(eij), vp(edata), C.byref(n1), C.byref(n2), vp(rounds), C.byref(ntr)), "vxba_hba_pass")
+        self._check(self._L.vxba_hba_pass(self._h, vp(poses), C.byref(coarse), C.byref(fine), int(wdsize), int(mgsize), int(bool(tail)), int(top_max_iter), int(n_threads),
+                                          vp(sub_poses), vp(sizes), C.c_int64(cap), vp(eij), vp(edata), C.byref(n1), C.byref(n2), vp(rounds), C.byref(ntr)), "vxba_hba_pass")
+        return dict(edges1=self._edges(eij, edata, 0, n1.value), edges2=self._edges(eij, edata, n1.value, n1.value + n2.value), submap_ids=[f0 for f0, _ in wins],
+                    submap_poses=sub_poses, submap_sizes=[int(x) for x in sizes], n_threads_used=int(self._L.vxba_hba_threads_used(self._h)),
+                    top_rounds=self._rounds(rounds, ntr.value))
 
-        def edges(lo, hi):
-            return [dict(i=int(eij[k, 0]), j=int(eij[k, 1]), rot=edata[k, :9].reshape(3, 3).copy(), tra=edata[k, 9:12].copy(), v6=edata[k, 12:18].copy()) for k in range(lo, hi)]
-        return dict(edges1=edges(0, n1.value), edges2=edges(n1.value, n1.value + n2.value), submap_ids=list(range(0, K - wdsize + 1, mgsize)), submap_poses=sub_poses,
-                    submap_sizes=[int(x) for x in sizes], n_threads_used=int(self._L.vxba_hba_threads_used(self._h)),
-                    top_rounds=[dict(round=k, n_voxels=int(rounds[k, 0]), resis=(float(rounds[k, 1]), float(rounds[k, 2])), converged=bool(rounds[k, 3]), fine=bool(rounds[k, 4]))
-                                for k in range(ntr.value)])
+    @staticmethod
+    def _rounds(rounds, n):
+        return [dict(round=k, n_voxels=int(rounds[k, 0]), resis=(float(rounds[k, 1]), float(rounds[k, 2])), converged=bool(rounds[k, 3]), fine=bool(rounds[k, 4])) for k in range(n)]
+
+    # ---- the pass in its two halves (one rank of N: voxel_slam_amd.dist.hba_pass) ----
+    def bottom(self, poses, coarse: VoxelizeParams, fine: VoxelizeParams, wdsize: int = 10, mgsize: int = 5, tail: bool = True, w_first: int = 0, w_stride: int = 1,
+               n_threads: int = 0):
+        """``vxba_hba_bottom``: the windows w_first, w_first + w_stride, .. on this device.  Returns dict(sizes (S, -1 where not run here), edges (dicts with
+        ``window``), windows)."""
+        poses = self._poses(poses)
+        wins = self.windows(poses.shape[0], wdsize, mgsize, tail)
+        S = len(wins)
+        cap = sum(c * (c - 1) // 2 for _, c in wins[w_first::w_stride]) + 1
+        sub_poses = np.zeros((S, 12)); sizes = np.full(S, -1, dtype=np.int64)
+        eij = np.zeros((cap, 2), dtype=np.int32); edata = np.zeros((cap, 18)); ewin = np.zeros(cap, dtype=np.int32)
+        ne = C.c_int64()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._last_geom = (poses.shape[0], int(wdsize), int(mgsize), int(bool(tail)))
+        self._check(self._L.vxba_hba_bottom(self._h, vp(poses), C.byref(coarse), C.byref(fine), int(wdsize), int(mgsize), int(bool(tail)), int(w_first), int(w_stride),
+                                            int(n_threads), vp(sub_poses), vp(sizes), C.c_int64(cap), vp(eij), vp(edata), vp(ewin), C.byref(ne)), "vxba_hba_bottom")
+        return dict(sizes=sizes, edges=self._edges(eij, edata, 0, ne.value, ewin), windows=wins, n_threads_used=int(self._L.vxba_hba_threads_used(self._h)))
+
+    def export_submaps(self, w_first: int, w_stride: int, d_ptr: int, capacity_points: int) -> int:
+        """``vxba_hba_export_submaps``: this selection's submaps packed into the DEVICE buffer at ``d_ptr`` (float xyz); returns the point count."""
+        n = C.c_int64()
+        self._check(self._L.vxba_hba_export_submaps(self._h, int(w_first), int(w_stride), C.c_void_p(d_ptr), C.c_int64(capacity_points), C.byref(n)), "vxba_hba_export_submaps")
+        return int(n.value)
+
+    def import_submaps(self, w_first: int, w_stride: int, sizes, d_ptr: int):
+        """``vxba_hba_import_submaps``: a peer's packed submaps (DEVICE pointer) into place; ``sizes``: S entries."""
+        sizes = np.ascontiguousarray(sizes, dtype=np.int64)
+        self._check(self._L.vxba_hba_import_submaps(self._h, int(w_first), int(w_stride), sizes.ctypes.data_as(C.c_void_p), C.c_void_p(d_ptr)), "vxba_hba_import_submaps")
+
+    def top_factor(self) -> "LidarFactor":
+        """``vxba_hba_top_factor``: the (session-owned) factor the top level runs on, to attach a collective to."""
+        h = C.c_void_p()
+        self._check(self._L.vxba_hba_top_factor(self._h, C.byref(h)), "vxba_hba_top_factor")
+        return LidarFactor.from_handle(h)
+
+    def top(self, poses, coarse: VoxelizeParams, fine: VoxelizeParams, top_max_iter: int = 1):
+        """``vxba_hba_top``: the top level over all submaps of the pass in progress.  Returns dict(submap_poses, edges2, top_rounds)."""
+        poses = self._poses(poses)
+        S = self._L.vxba_hba_num_windows(*self._geom(poses.shape[0]))
+        cap = S * (S - 1) // 2 + 1
+        sub_poses = np.zeros((S, 12))
+        eij = np.zeros((cap, 2), dtype=np.int32); edata = np.zeros((cap, 18))
+        ne, ntr = C.c_int64(), C.c_int()
+        rounds = np.zeros((max(1, top_max_iter), 5))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._check(self._L.vxba_hba_top(self._h, vp(poses), C.byref(coarse), C.byref(fine), int(top_max_iter), vp(sub_poses), C.c_int64(cap), vp(eij), vp(edata), C.byref(ne),
+                                         vp(rounds), C.byref(ntr)), "vxba_hba_top")
+        return dict(submap_poses=sub_poses, edges2=self._edges(eij, edata, 0, ne.value), top_rounds=self._rounds(rounds, ntr.value))
+
+    def _geom(self, K):
+        g = getattr(self, "_last_geom", None)
+        if not g or g[0] != K:
+            raise VxbaError("hba top: no pass in progress (HbaSession.bottom first)")
+        return g
 
 
 def cov_add_build(xyz_world, var, cell_ptr, device: int = 0):
