@@ -47,6 +47,8 @@ for case in range(n_cases):
                               rot_sigma_deg=float(rng.choice([0.05, 0.2, 0.5])), trans_sigma=float(rng.choice([0.02, 0.08])))
         fo = O.Oracle(W); fo.push_voxels(sc.clusters, sc.fix, sc.coe); fo.evaluate_only_residual(sc.poses_init)
         fg = vxba.LidarFactor(W); fg.push_voxels(sc.clusters, sc.fix, sc.coe); fg.evaluate_only_residual(sc.poses_init)
+        fused_sw = int(rng.integers(0, 4) != 0)      # round 6: three in four cases through the fused residual + Hessian launch (the default), one through the three-launch iteration
+        if W <= vxba.MAX_WIN: fg.set_option("fused_sweeps", fused_sw)
         iters = int(rng.integers(2, 5 if big else 8))
         if kind == "mixed":
             # f32 products on the matrix cores, f64 accumulation: same schedule, poses within 1e-5 of the fp64 oracle (contract 1e-4)
@@ -101,7 +103,7 @@ for case in range(n_cases):
             rd = np.abs(got["trace"][:nt, :2] / ref["trace"][:nt, :2] - 1)
             acc_k = ref["trace"][:nt, 6] != 0
             check(marg or (rd[:, 0].max() < 1e-8 and (rd[acc_k, 1].max() if acc_k.any() else 0) < 1e-8 and rd[:, 1].max() < 1e-5), "%s residuals rel diff %s W=%d V=%d seed=%d" % (kind, rd.max(axis=0), W, V, s))
-            desc = "W=%d V=%d p_obs=%.1f iters=%d acc=%s pose diff %.1e/%.1e hess %.1e" % (W, V, p_obs, iters, got["trace"][:, 6].astype(int), et, er, hd)
+            desc = "W=%d V=%d p_obs=%.1f iters=%d fused=%d acc=%s pose diff %.1e/%.1e hess %.1e" % (W, V, p_obs, iters, fused_sw, got["trace"][:, 6].astype(int), et, er, hd)
         else:
             iw = synth.make_imu(sc, seed=s + 1)
             bg, ba = iw.states_init[0, 15:18], iw.states_init[0, 18:21]

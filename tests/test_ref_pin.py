@@ -7,6 +7,12 @@ What "equal" means here: the two differ only in the association of a few sums (t
 a different order than the reference's expression text evaluated by the shim), so cluster sums, eigen-decompositions, gradients and
 accept/reject decisions come out identical and Hessians / poses agree to a few ulps -- the assertions below say exactly how far.
 
+"Bit-identical" in this file therefore means: bit-identical to the reference's text AS THE SHIM EVALUATES IT -- every Eigen expression eagerly,
+left to right, in natural order.  Real Eigen 3.3.7 may associate some products differently (lazy expression templates, vectorised reductions);
+the image has no Eigen to run the pin against, and a real one is picked up automatically when installed (oracle/Makefile).  The three numerical
+algorithms upstream takes from Eigen (SelfAdjointEigenSolver, LDLT, inverse) are the oracle's restatements on BOTH sides of these comparisons,
+checked against LAPACK in tests/test_oracle_math.py (the round-5 review's caveat).
+
 libref.so is git-ignored but travels to the GPU box with the snapshot; where it is neither prebuilt nor buildable (no
 /root/reference and nothing under oracle/_ref/) the module is skipped, and the committed tests/golden/*.npz -- generated FROM
 libref.so by tests/golden/make_golden.py -- carry the pin instead (tests/test_golden.py).

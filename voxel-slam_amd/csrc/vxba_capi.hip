@@ -1,5 +1,6 @@
 // C-ABI implementation (include/vxba.h): device memory, streams, launch sequencing and the host part of
 // the LM shell.  No CPU fallback anywhere: without a gfx950 device every entry point fails loudly.
+#include "vxba_wait.hpp"
 #include "vxba_capi_internal.hpp"
 
 using namespace vxc;
@@ -545,7 +546,7 @@ static int voxelize_push_impl(vxba_factor* f, int64_t n_points, const double* xy
       VX_HIP(f, hipMemcpyAsync(node_ids, d_id, (size_t)std::min<int64_t>(n, ids_capacity) * sizeof(uint64_t), hipMemcpyDeviceToHost, f->stream));
     {   // completion by polling (a blocking wait parks the thread: ~25 us to wake up from, and a hierarchical pass makes thousands of them)
       hipError_t q;
-      while ((q = hipStreamQuery(f->stream)) == hipErrorNotReady) {}
+      q = vxwait::stream_wait(f->stream);
       VX_HIP(f, q);
     }
     VX_HIP(f, hipGetLastError());
@@ -613,7 +614,7 @@ int vxba_internal_push_voxels_device(vxba_factor* f, int n, const double* d_clus
   vxk::launch_seed_aux(fv, v0, v0 + n, f->stream);
   {   // completion by polling: the map's stage buffers are reused right after this call, and a blocking wait costs ~25 us to wake up from
     hipError_t q;
-    while ((q = hipStreamQuery(f->stream)) == hipErrorNotReady) {}
+    q = vxwait::stream_wait(f->stream);
     VX_HIP(f, q);
   }
   VX_HIP(f, hipGetLastError());

@@ -2,6 +2,7 @@
 // already declare.  Definitions: vxba_capi_core.hip.
 #pragma once
 #include "vxba_factor.hpp"
+#include "vxba_wait.hpp"
 
 #include <chrono>
 
@@ -24,14 +25,7 @@ inline void clusters_written(vxba_factor* f, int v0) { if (v0 < f->cl32_built) f
 // Completion of the factor's stream at the end of a device-resident LM call: a 3-iteration damping_iter is ~0.2 ms of queued kernels, and
 // waking up from hipStreamSynchronize costs ~25 us of that (measured in the map and LI shells), so the call polls -- for a bounded time:
 // a stream that is still busy after ~4 ms (a long bench loop, a wide window) is handed to the blocking wait, which does not burn a core.
-inline hipError_t stream_wait_spin(hipStream_t s) {
-  const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned k = 0;; k++) {
-    const hipError_t q = hipStreamQuery(s);
-    if (q != hipErrorNotReady) return q;
-    if ((k & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(4)) return hipStreamSynchronize(s);
-  }
-}
+inline hipError_t stream_wait_spin(hipStream_t s) { return vxwait::stream_wait(s); }   // bounded polling, then the blocking wait: vxba_wait.hpp
 
 // ---- profiling: hipEvents on the factor's stream around a launch, drained by vxba_get_kernel_times / vxba_get_collective_time ----
 hipEvent_t get_event(vxba_factor* f);

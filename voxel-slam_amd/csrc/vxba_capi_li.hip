@@ -1,5 +1,6 @@
 // C-ABI implementation, inertial half (include/vxba.h): IMU_PRE wrappers and the LiDAR-inertial LM shells (LI_BA_Optimizer,
 // LI_BA_OptimizerGravity; host shells between the GPU sweeps, and the driver of the device-resident loop).
+#include "vxba_wait.hpp"
 #include "vxba_factor.hpp"
 
 #include <atomic>
@@ -60,7 +61,7 @@ void states_to_poses(int W, const double* states, double* Rp) {
 // up from hipStreamSynchronize costs
 int wait_stream(vxba_factor* f) {
   hipError_t q;
-  while ((q = hipStreamQuery(f->stream)) == hipErrorNotReady) {}
+  q = vxwait::stream_wait(f->stream);
   VX_HIP(f, q);
   return VXBA_OK;
 }
@@ -155,7 +156,7 @@ int li_joint_residual(vxba_factor* f, const double* states, const double* imus, 
   if (imu_residual) *imu_residual = r1;
   if (spec) {
     hipError_t q;
-    while ((q = hipEventQuery(f->li_ev)) == hipErrorNotReady) {}
+    q = vxwait::event_wait(f->li_ev);
     VX_HIP(f, q);
   } else {
     rc = wait_stream(f);
@@ -315,7 +316,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
   std::memset(&pa0, 0, sizeof pa0);
   auto wait_event = [&](hipEvent_t ev) -> int {
     hipError_t q;
-    while ((q = hipEventQuery(ev)) == hipErrorNotReady) {}
+    q = vxwait::event_wait(ev);
     VX_HIP(f, q);
     return VXBA_OK;
   };
@@ -353,7 +354,7 @@ static int li_damping_iter_queued(vxba_factor* f, double* states, double* imus, 
   };
   if (f->li_reduction_in_flight) {     // the previous call ended (converged) with its last speculative reduction unconsumed
     hipError_t q;
-    while ((q = hipStreamQuery(f->stream)) == hipErrorNotReady) {}
+    q = vxwait::stream_wait(f->stream);
     VX_HIP(f, q);
     f->li_reduction_in_flight = false;
   }

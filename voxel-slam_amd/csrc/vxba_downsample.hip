@@ -5,6 +5,7 @@
 // per occupied voxel that replays the running-mean recurrence over its points in cloud order with unfused float arithmetic -- the
 // means are bit-identical to upstream's.  Output order is ascending (x, y, z) voxel index (upstream: hash-map iteration order,
 // which is implementation-defined).
+#include "vxba_wait.hpp"
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -123,7 +124,7 @@ int downsample_device(Scratch& sc, hipStream_t s, const float* d_in, int64_t n, 
   DS(hipMemcpyAsync(sc.pinned + 1, d_runs, 4, hipMemcpyDeviceToHost, s));
   {   // by polling: a blocking wait parks the thread (~25 us to wake up from); pinned destination: a copy into pageable memory is staged and waited for
     hipError_t q;
-    while ((q = hipStreamQuery(s)) == hipErrorNotReady) {}
+    q = vxwait::stream_wait(s);
     DS(q);
   }
   err = (int)((volatile unsigned int*)sc.pinned)[0];
@@ -173,7 +174,17 @@ extern "C" int vxba_down_sampling_voxel(int device, int64_t n, const float* xyz,
   float* d_out = io[dv] + 3 * io_cap[dv];
   if (hipMemcpy(d_in, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return VXBA_ERR_HIP;
   int64_t kept = 0;
-  const int rc = vxd::downsample_device(scratch[dv], nullptr, d_in, n, voxel_size, d_out, &kept);
+  int rc;
+  if (device >= 16) {
+    // devices beyond the per-device table share slot 15 for the in / out buffers (re-allocated on every call, above); the sort's scratch must
+    // not be shared: it would keep memory owned by the previous such device (round-5 advisor) -- a scratch of the call's own instead
+    vxd::Scratch own;
+    rc = vxd::downsample_device(own, nullptr, d_in, n, voxel_size, d_out, &kept);
+    (void)hipDeviceSynchronize();
+    own.release();
+  } else {
+    rc = vxd::downsample_device(scratch[dv], nullptr, d_in, n, voxel_size, d_out, &kept);
+  }
   if (rc != VXBA_OK) return rc;
   if (hipMemcpy(out_xyz, d_out, (size_t)kept * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return VXBA_ERR_HIP;
   *n_out = kept;

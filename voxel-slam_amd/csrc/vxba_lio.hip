@@ -20,6 +20,7 @@
 //
 // Bound: HBM in principle (72 B per point + the plane records, which stay in L2), launch/latency in practice -- a 100k-point
 // scan is 7 MB.  The 15x15 EKF algebra stays on the host between sweeps (4 sweeps per scan upstream).
+#include "vxba_wait.hpp"
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -854,7 +855,7 @@ int lio_sweep(vxba_lio* h, const double* state, const double* cov225, bool reset
   LIO_HIP(h, hipGetLastError());
   // the kernel is ~10 us: poll for its completion instead of sleeping on it (hipStreamSynchronize's wake-up costs more than the kernel)
   hipError_t q;
-  while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) {}
+  q = vxwait::stream_wait(h->stream);
   LIO_HIP(h, q);
   h->cache_valid = true;
   // the per-workgroup partials, added in workgroup order (fixed for a given scan size: bitwise reproducible)
@@ -877,7 +878,7 @@ int lio_sweep(vxba_lio* h, const double* state, const double* cov225, bool reset
 // completion of what is queued on s by polling: waking up from hipStreamSynchronize costs ~15-25 us, more than the per-scan kernels here
 static inline hipError_t lio_poll(hipStream_t s) {
   hipError_t q;
-  while ((q = hipStreamQuery(s)) == hipErrorNotReady) {}
+  q = vxwait::stream_wait(s);
   return q;
 }
 
@@ -1204,7 +1205,7 @@ int vxba_lio_state_estimation(vxba_lio* h, double* state, double* cov, double* i
       LIO_HIP(h, hipGetLastError());
       LIO_HIP(h, hipMemcpyAsync(&hc, h->d_ctl, sizeof hc, hipMemcpyDeviceToHost, h->stream));
       hipError_t q;
-      while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) {}
+      q = vxwait::stream_wait(h->stream);
       LIO_HIP(h, q);
       h->cache_valid = true;
       std::memcpy(state, hc.state, sizeof hc.state); std::memcpy(cov, hc.cov, sizeof hc.cov);

@@ -22,6 +22,7 @@
 //   margi is one lane per leaf on clusters; the oldest slot's points move to a per-leaf world-frame fix pool until max_points.
 // Arithmetic that decides tree structure or feeds running sums (world point, octant test, cluster push) is written unfused, as the
 // reference's x86-64 build computes it; everything else follows vxba_math.hpp.
+#include "vxba_wait.hpp"
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -1186,7 +1187,7 @@ inline int grid_for(long long n, int b = 256) { return (int)std::max<long long>(
 // what waking up from hipStreamSynchronize costs (the same observation as in the LiDAR-inertial shell: ~25 us per wait).
 inline hipError_t map_wait(hipStream_t s) {
   hipError_t q;
-  while ((q = hipStreamQuery(s)) == hipErrorNotReady) {}
+  q = vxwait::stream_wait(s);
   return q;
 }
 

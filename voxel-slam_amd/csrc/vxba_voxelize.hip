@@ -10,6 +10,7 @@
 //   PointCluster::push.  Nodes are then judged top-down (N > 10, plane_judge, >= 2 observing frames, lambda0/lambda1 <=
 //   0.12; non-planes are subdivided while layer < max_layer), and the accepted ones are appended to the factor's planes
 //   on the device, cache seeded with (lambda, U, world cluster) like recut's push_voxel does.
+#include "vxba_wait.hpp"
 #include <hip/hip_runtime.h>
 #include <atomic>
 
@@ -273,7 +274,7 @@ struct DevBuf {
   }
   static hipError_t wait(hipStream_t s) {
     hipError_t q;
-    while ((q = hipStreamQuery(s)) == hipErrorNotReady) {}
+    q = vxwait::stream_wait(s);
     return q;
   }
   unsigned int u32(int k) const { return (unsigned int)(*(volatile unsigned long long*)(host + k) & 0xffffffffull); }
