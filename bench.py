@@ -338,14 +338,20 @@ def main():
     if args.warmup > 0:
         f.lm_steps(sc.poses_init, args.warmup, sps)
     f.kernel_times(reset=True)
-    f.set_profiling(1 | 32)                                # hipEvents bound to the dispatches of the Hessian sweep (K3) and of the fused solve + residual + Hessian launch
-    # The timed region, `repeats` times: each one is exactly --steps steps between (barrier + synchronize) pairs, max over ranks.  The
-    # reported figure is the median repeat -- with the driver's --steps 20 one region is 1.2 ms, and a single sample of it moved the
-    # line by 5 % between boxes (round-3 review) -- min / max / n go into the line beside it.
+    # The timed region, `repeats` times TWICE over, interleaved: a PLAIN repeat (no instrumentation: `value`, `ms_per_step`), then an
+    # INSTRUMENTED one (hipEvents bound to the dispatches of the Hessian sweep and of the fused solve + residual + Hessian launch: the
+    # roofline's launch durations) -- each exactly --steps steps between (barrier + synchronize) pairs, max over ranks.  Round 6 measured
+    # what the event brackets cost the region they sit in: 5.3-5.6 us per LM step at cfg2 (49.3 -> 54.9 us per step at --steps 20,
+    # 47.6 -> 53.0 at 150; scripts/dbg_profiling_cost.py, gpurun_out/r6_profiling_cost.txt): a profiled dispatch is fenced on both sides.
+    # Rounds 1-5 timed the instrumented region only.  The reported figure is the median plain repeat -- with the driver's --steps 20 one
+    # region is 1 ms, and a single sample of it moved the line by 5 % between boxes (round-3 review) -- min / max / n and the instrumented
+    # repeats' median go into the line beside it.
     n_rep = max(1, args.repeats)
-    elapsed_all, k3_rep_ms, k3_calls, fz_rep_ms, fz_calls = [], [], 0, [], 0
+    elapsed_all, elapsed_inst, k3_rep_ms, k3_calls, fz_rep_ms, fz_calls = [], [], [], 0, [], 0
     host0 = host_cpu_state()
-    for _ in range(n_rep):
+    for rep in range(2 * n_rep):
+        inst = (rep % 2 == 1)
+        f.set_profiling((1 | 32) if inst else 0)
         sync()
         t0 = time.perf_counter()
         poses, resis, lmstats = f.lm_steps(sc.poses_init, args.steps, sps)
@@ -356,7 +362,10 @@ def main():
             tt = torch.tensor([e], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             e = float(tt.item())
-        elapsed_all.append(e)
+        if not inst:
+            elapsed_all.append(e)
+            continue
+        elapsed_inst.append(e)
         ktr = f.kernel_times(reset=True)["k3_hessian"]
         k3_rep_ms.append(ktr["ms_sum"] / max(1, ktr["calls"]))
         k3_calls += ktr["calls"]
@@ -445,11 +454,14 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "repeats": {"n": n_rep, "statistic": "median over back-to-back repeats of the timed region (each exactly `steps` steps)",
+            "repeats": {"n": n_rep, "statistic": "median over back-to-back PLAIN repeats of the timed region (each exactly `steps` steps, no event brackets inside)",
                         "value_min": (world if args.scaling == "weak" else 1) * args.steps / max(elapsed_all),
                         "value_max": (world if args.scaling == "weak" else 1) * args.steps / min(elapsed_all),
                         "ms_per_step_min": 1e3 * min(elapsed_all) / args.steps, "ms_per_step_max": 1e3 * max(elapsed_all) / args.steps,
-                        "k3_avg_launch_ms_min": min(k3_rep_ms), "k3_avg_launch_ms_max": max(k3_rep_ms)},
+                        "k3_avg_launch_ms_min": min(k3_rep_ms), "k3_avg_launch_ms_max": max(k3_rep_ms),
+                        "instrumented": {"n": len(elapsed_inst), "what": "the same region with hipEvents bound to the sweep dispatches (the roofline's launch durations come from these repeats), interleaved with the plain ones",
+                                         "ms_per_step": 1e3 * float(np.median(elapsed_inst)) / args.steps,
+                                         "ms_per_step_min": 1e3 * min(elapsed_inst) / args.steps, "ms_per_step_max": 1e3 * max(elapsed_inst) / args.steps}},
             # what the container may use of the host's CPUs (cgroup v2 cpu.max) and whether it was throttled while the repeats ran: the ranks' host
             # threads poll, and a job that spends its quota is stopped as a whole -- which would look like a slow GPU
             "host": {"nproc": host1["nproc"], "cgroup_cpu_max": host1["cpu_max"], "quota_cores": host1["quota_cores"],

@@ -78,7 +78,7 @@ if which == "k23":
     wgs = fl[:, 0].reshape(-1, 8).min(axis=1).repeat(8) if fl.shape[0] % 8 == 0 else fl[:, 0]
     print("fused launch: %d sweep waves stamped; solver (cycles since its start): loaded %d, factored %d, back-substituted %d, end %d" % ((fl.shape[0],) + tuple((sol - sol[0])[[2, 3, 4, 5]])))
     wv = np.arange(fl.shape[0]) % 8
-    for nm, slot in (("rows requested", 30), ("poses in LDS, barrier passed", 5), ("transform done", 15), ("eigen done", 18), ("cache stores issued", 21), ("stores acknowledged", 24),
+    for nm, slot in (("rows requested", 30), ("poses in LDS, barrier passed", 5), ("rows landed (pair mode)", 4), ("transform done", 15), ("eigen done", 18), ("cache stores issued", 21), ("residual half done", 24),
                      ("first batch requested", 2), ("Hessian-half barrier passed", 1), ("barrier 0 (phase A of step 0)", 8), ("barrier 1", 9), ("barrier 2", 10), ("barrier 3", 11),
                      ("barrier 4", 12), ("step loop left", 3), ("tiles-done barrier", 27), ("accumulators parked", 28), ("partial stores issued", 6), ("acknowledged", 31)):
         ok = fl[:, slot] > 0
@@ -89,7 +89,7 @@ if which == "k23":
     # relative to the moment the poses arrived (slot 5): what the launch costs BEHIND the solve
     ok = (fl[:, 5] > 0) & (fl[:, 31] > 0)
     if ok.any():
-        for nm, slot in (("transform done", 15), ("eigen done", 18), ("stores acknowledged", 24), ("Hessian-half barrier passed", 1), ("barrier 0", 8), ("barrier 1", 9), ("barrier 2", 10), ("barrier 3", 11), ("step loop left", 3), ("acknowledged (end)", 31)):
+        for nm, slot in (("rows landed (pair mode)", 4), ("transform done", 15), ("eigen done", 18), ("cache stores issued", 21), ("residual half done", 24), ("Hessian-half barrier passed", 1), ("barrier 0", 8), ("barrier 1", 9), ("barrier 2", 10), ("barrier 3", 11), ("step loop left", 3), ("acknowledged (end)", 31)):
             k = ok & (fl[:, slot] > 0)
             if k.any():
                 col = fl[k, slot] - fl[k, 5]

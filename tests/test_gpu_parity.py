@@ -294,7 +294,10 @@ def test_fused_launch_is_the_three_launch_iteration_to_round_off(vx):
         a, b = out
         assert a["trace"].shape == b["trace"].shape and np.array_equal(a["trace"][:, 6:], b["trace"][:, 6:]), (a["trace"][:, 6], b["trace"][:, 6])
         saw_reject |= bool((a["trace"][:, 6] == 0).any())
-        assert np.allclose(a["trace"][:, :6], b["trace"][:, :6], rtol=1e-9, atol=0)
+        # residual1 / residual2 to 1e-9; the damping trajectory and the gain ratios like the oracle comparison (check_lm_parity): q divides a
+        # DIFFERENCE of residuals, and at the metric's size the fused launch merges a voxel's clusters in two halves (lane pair, vxba_k23.hpp)
+        assert np.allclose(a["trace"][:, :2], b["trace"][:, :2], rtol=1e-9, atol=0)
+        assert np.allclose(a["trace"][:, 2:6], b["trace"][:, 2:6], rtol=1e-6, atol=0)
         et, er = synth.pose_errors(a["poses"], b["poses"])
         assert et < 1e-12 and er < 1e-12, (et, er)
         assert relerr(a["hess"], b["hess"]) < 1e-11
@@ -551,7 +554,9 @@ def test_bench_rccl_plumbing_single_rank():
                        (["--force-dist", "--collective", "peer"], "all-reduce")):
         b = run(extra)
         assert a["config"]["lm_steps_accepted"] == b["config"]["lm_steps_accepted"] == 30
-        assert abs(a["config"]["final_residual"] - b["config"]["final_residual"]) <= 1e-12 * abs(a["config"]["final_residual"])
+        # (1e-10: the plain path runs the fused residual + Hessian launch, whose lane-pair residual half adds a voxel's clusters in two halves;
+        # a factor with a collective attached keeps the three-launch iteration)
+        assert abs(a["config"]["final_residual"] - b["config"]["final_residual"]) <= 1e-10 * abs(a["config"]["final_residual"])
         assert tag in b["config"]["parallelism"] and b["value"] > 0, b["config"]["parallelism"]
 
 

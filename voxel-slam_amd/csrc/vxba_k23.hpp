@@ -23,6 +23,20 @@
 // calc_hess = "accepted" -> the reduced system is adopted, rejected -> it is dropped, like the sharded speculative loop's
 // lm_spec_unpack_kernel.  A rejected step therefore costs a whole Hessian half (the reference recomputes nothing then); the first
 // iteration of a solve (cache left by push_voxel) and the last one (no Hessian behind it) keep the stand-alone kernels.
+//
+// Two things the hand-over between the halves no longer waits for (round 6, second pass over the launch's timeline -- the residual half took
+// 19.5k cycles from the poses to its barrier against ~10k in the stand-alone kernel, and the Hessian half another 4.5k to its first barrier):
+//   * PAIR mode (a workgroup owns <= 256 voxels, i.e. up to ~65k voxels on 255 CUs: the metric's size): a voxel's frames are split over a
+//     LANE PAIR (lane 2j: fix cluster + frames [0, H1), lane 2j + 1: frames [H1, W), H1 = ceil(W / 2)).  Half the rows per lane means ALL of
+//     them -- and the warm start, coe and the Hessian half's first batch -- are in registers before the trial poses exist (140 + 20
+//     registers; the one-lane-per-voxel form could hold four frames of ten beside a second wave per SIMD and fetched the rest while it
+//     worked), the transform chain is five frames long instead of ten, and all eight waves of the workgroup work (196 voxels are 392 lanes).
+//     The halves' sums meet through one DPP quad permute per value (a + b on one lane, b + a on the other: the same bits), both lanes run
+//     the eigen-decomposition (no extra issue slots: the partner lane was idle), each stores 13 of the 26 cache planes.
+//   * The plane parameters of the workgroup's FIRST EIGHT batches go from the residual half's registers straight into the Hessian half's
+//     staging corners in LDS (the 18-double record k3_unstage_params reads): the first phase A starts behind one LDS barrier -- no wait
+//     for the cache stores' acknowledgement, no round trip through the L2.  The stores are waited for in front of the first step's
+//     barrier instead (k3_sweep_body), a phase A later, before any wave asks the L2 for the next step's parameters.
 #pragma once
 
 // Planes of a factor relative to fv.cl (ONE allocation: vxc::view): cl [10 W] | fix 10 | coe 1 | eigval 3 | eigvec 9 | merged 10 | aux 4.
@@ -70,8 +84,19 @@ __device__ __forceinline__ void k23_st64(__amdgpu_buffer_rsrc_t rs, unsigned a8,
 // Instrumented build (DBG), stamps of wave gw: 15 transform done, 18 eigen-decomposition done, 21 cache stores issued.
 // hook(): called between the eigen-decomposition and the cache stores (the Hessian half's first cluster rows are requested there).
 struct K23NoHook { __device__ __forceinline__ void operator()() const {} };
+// The record of a voxel as k3_unstage_params reads it (k3_param_plane): u planes 0..8 | s1 s2 | merged first moment | 1/N | sqrt(coe) | lambda_0 | coe
+__device__ __forceinline__ void k23_record(double v[18], const double lam[3], const double U[9], const double Sv[3], double SN, double coe) {
+#pragma unroll
+  for (int col = 0; col < 3; col++)
+#pragma unroll
+    for (int row = 0; row < 3; row++) v[3 * col + row] = U[3 * row + col];
+  vxm::gap_scales(lam, v[9], v[10]);
+  v[11] = Sv[0]; v[12] = Sv[1]; v[13] = Sv[2];
+  v[14] = 1.0 / SN; v[15] = sqrt(coe); v[16] = lam[0]; v[17] = coe;
+}
+// rec (LDS, nullable per lane): where the Hessian half's first phase A expects this voxel's record
 template <int W, bool DBG = false, class Hook = K23NoHook>
-__device__ __forceinline__ double k23_finish(__amdgpu_buffer_rsrc_t rs, unsigned vs8, unsigned a8, bool valid, const double* pose_lds, K23Regs<W>& r, int gw = 0, Hook hook = Hook()) {
+__device__ __forceinline__ double k23_finish(__amdgpu_buffer_rsrc_t rs, unsigned vs8, unsigned a8, bool valid, const double* pose_lds, K23Regs<W>& r, double* rec = nullptr, int gw = 0, Hook hook = Hook()) {
   using P = K23Planes<W>;
   constexpr int HF = K23Regs<W>::HF;
   double SP[6], Sv[3], SN, C[6], lam[3] = {0.0, 0.0, 0.0}, U[9], Up[9], coe = 0.0;
@@ -113,6 +138,12 @@ __device__ __forceinline__ double k23_finish(__amdgpu_buffer_rsrc_t rs, unsigned
   vxm::eig_sym3_warm(C, Up, lam, U);
   if (DBG) { asm volatile("" :: "v"(lam[0]), "v"(U[0]), "v"(U[8])); dbg_stamp(true, gw, 18); }
   hook();
+  if (rec) {
+    double v[18];
+    k23_record(v, lam, U, Sv, SN, coe);
+#pragma unroll
+    for (int k = 0; k < 9; k++) *reinterpret_cast<v2d*>(rec + 2 * k) = (v2d){v[2 * k], v[2 * k + 1]};
+  }
   if (valid) {
 #pragma unroll
     for (int k = 0; k < 3; k++) k23_st64(rs, a8, (unsigned)(P::EIGVAL + k) * vs8, lam[k]);
@@ -136,10 +167,110 @@ __device__ __forceinline__ double k23_finish(__amdgpu_buffer_rsrc_t rs, unsigned
   return valid ? coe * lam[0] : 0.0;
 }
 
+// ---- PAIR mode: a voxel's frames over a lane pair -------------------------------------------------------------------------------
+template <int W>
+struct K23PairRegs {
+  static constexpr int H1 = (W + 1) / 2;
+  double fx[10], fr[H1][10], Up[9], coe;
+};
+// everything the residual half reads, requested before the poses exist.  hoff = the lane's half: 0, or H1 frames of ten planes further on
+// (odd W: the upper lane's last slot then reads the fix planes -- in range, and masked in k23_pair_finish)
+template <int W>
+__device__ __forceinline__ void k23_pair_issue(__amdgpu_buffer_rsrc_t rs, unsigned vs8, unsigned a8, unsigned hoff, K23PairRegs<W>& r) {
+  using P = K23Planes<W>;
+#pragma unroll
+  for (int k = 0; k < 10; k++) r.fx[k] = k3_ld64<0>(rs, a8, (unsigned)(P::FIX + k) * vs8);
+#pragma unroll
+  for (int i = 0; i < K23PairRegs<W>::H1; i++)
+#pragma unroll
+    for (int k = 0; k < 10; k++) r.fr[i][k] = k3_ld64<0>(rs, a8 + hoff, (unsigned)(10 * i + k) * vs8);
+  r.coe = k3_ld64<0>(rs, a8, (unsigned)P::COE * vs8);
+#pragma unroll
+  for (int col = 0; col < 3; col++)
+#pragma unroll
+    for (int row = 0; row < 3; row++) r.Up[3 * row + col] = k3_ld64<0>(rs, a8, (unsigned)(P::EIGVEC + 3 * col + row) * vs8);
+}
+// the partner lane's value (lanes 2j <-> 2j + 1): DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ double k23_partner(double v) {
+  const v2i x = __builtin_bit_cast(v2i, v);
+  v2i y;
+  y[0] = __builtin_amdgcn_update_dpp(0, x[0], 0xB1, 0xf, 0xf, false);
+  y[1] = __builtin_amdgcn_update_dpp(0, x[1], 0xB1, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, y);
+}
+// The residual half of one voxel on its lane pair.  The merged cluster is (fix + frames [0, H1)) + (frames [H1, W)) -- a different
+// association from the one-lane form's running sum: round-off apart (tests/test_gpu_parity.py compares the two forms of the loop to 1e-9).
+// Returns coe * lambda_0 on the lower lane, 0 on the upper.
+// Instrumented build (DBG), stamps of wave gw: 4 rows landed, 15 transform + exchange done, 18 eigen-decomposition done, 21 record + cache stores issued.
+template <int W, bool DBG = false>
+__device__ __forceinline__ double k23_pair_finish(__amdgpu_buffer_rsrc_t rs, unsigned vs8, unsigned a8, bool valid, bool upper, const double* pose_lds, K23PairRegs<W>& r,
+                                                  double* rec, int gw = 0) {
+  using P = K23Planes<W>;
+  constexpr int H1 = K23PairRegs<W>::H1;
+  double SP[6], Sv[3], SN, C[6], lam[3] = {0.0, 0.0, 0.0}, U[9];
+#pragma unroll
+  for (int k = 0; k < 6; k++) SP[k] = upper ? 0.0 : r.fx[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) Sv[k] = upper ? 0.0 : r.fx[6 + k];
+  SN = upper ? 0.0 : r.fx[9];
+  if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(true, gw, 4); }
+#pragma unroll
+  for (int i = 0; i < H1; i++) {
+    const bool slot = H1 + i < W;                      // compile-time: false only for the upper lane's last slot at odd W
+    const double* pp = pose_lds + 12 * ((upper && slot) ? H1 + i : i);
+    double R[9], p[3];
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) R[3 * rr + cc] = pp[3 * cc + rr];
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = pp[9 + k];
+    double ci[10];
+    const bool obs = r.fr[i][9] != 0.0 && (slot || !upper);   // N == 0: frame did not observe the voxel (voxel_map.hpp:258)
+#pragma unroll
+    for (int k = 0; k < 10; k++) ci[k] = obs ? r.fr[i][k] : 0.0;
+    vxm::transform_accumulate(ci, ci + 6, ci[9], R, p, SP, Sv, SN);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) SP[k] += k23_partner(SP[k]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) Sv[k] += k23_partner(Sv[k]);
+  SN += k23_partner(SN);
+  vxm::cluster_cov(SP, Sv, SN, C);
+  if (DBG) { asm volatile("" :: "v"(C[0]), "v"(C[3]), "v"(C[5])); dbg_stamp(true, gw, 15); }
+  vxm::eig_sym3_warm(C, r.Up, lam, U);
+  if (DBG) { asm volatile("" :: "v"(lam[0]), "v"(U[0]), "v"(U[8])); dbg_stamp(true, gw, 18); }
+  const double coe = r.coe;
+  double v[18];
+  k23_record(v, lam, U, Sv, SN, coe);
+  if (rec) {   // the lower lane writes the first nine doubles of the record, the upper lane the other nine
+#pragma unroll
+    for (int k = 0; k < 9; k++) rec[(upper ? 9 : 0) + k] = upper ? v[9 + k] : v[k];
+  }
+  if (valid) {
+    // the 26 cache planes behind eigval in plane order; the lower lane stores planes 0..12, the upper lane 13..25 (its offset carries the 13 planes)
+    double c26[26];
+#pragma unroll
+    for (int k = 0; k < 3; k++) c26[k] = lam[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) c26[3 + k] = v[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) c26[12 + k] = SP[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) c26[18 + k] = Sv[k];
+    c26[21] = SN; c26[22] = v[9]; c26[23] = v[10]; c26[24] = v[14]; c26[25] = v[15];
+    const unsigned so = a8 + (upper ? 13u * vs8 : 0u);
+#pragma unroll
+    for (int j = 0; j < 13; j++) k23_st64(rs, so, (unsigned)(P::EIGVAL + j) * vs8, upper ? c26[13 + j] : c26[j]);
+  }
+  dbg_stamp(DBG, gw, 21);
+  return (valid && !upper) ? coe * lam[0] : 0.0;
+}
+
 // Argument order: the first 14 dwords are preloaded into SGPRs at wave launch (see k3_hessian_kernel) -- what the solve workgroup and a
 // sweep workgroup's first requests need.  flags: bit 0 = test hook (the sweep workgroups give up waiting for the solve at once).
 // Grid: 1 + nwg workgroups of K3_BLOCK threads (workgroup 0 = the solve on four of its waves); LDS: k23_lds_bytes<W>().
-template <int W, bool DBG = false, bool MIXED = false>
+template <int W, bool DBG = false, bool MIXED = false, bool PAIR = false>
 __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k23_fused_kernel(LMState* __restrict__ st, int c, unsigned seq, const double* li_rec, double* li_out,
                                                              const double* host_feed, int head, int end, int nwg, int flags_hs,
                                                              double* __restrict__ planes, const double* __restrict__ clb, int VS, double* __restrict__ partial2,
@@ -229,67 +360,101 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
   double* lmv = poseA + 24 * W;         // 8 doubles the Hessian half does not use in a fused launch: the waves' residual sums
   __shared__ int k23_gave_up;
 
-  // wave w of a pass takes voxels [64 w, 64 w + 64) of it; a wave without voxels (waves 4-7 at the metric's size: 196 voxels per workgroup)
-  // skips the residual half altogether -- its arithmetic would share a SIMD's fp64 issue with a wave that has voxels
-  K23Regs<W> rg;
-  int a = v0 + wave * 64 + lane;
-  bool valid = a < v1;
-  const bool wave_has = v0 + wave * 64 < v1;   // wave-uniform
-  if (wave_has) k23_issue<W>(rs, vs8, (unsigned)(valid ? a : head) * 8u, rg);
-  // The Hessian half's first batch of cluster rows does not depend on anything computed here: a wave without voxels asks for it now, the
-  // others between their eigen-decomposition and their cache stores (one pass) or behind their last pass.
+  // the Hessian half's staging corners (k3_sweep_body: lmv + 8 + wave * WAVE_DOUBLES): zeros first -- a slot of the first eight batches that
+  // no voxel of [head, end) fills must read as a finite record (its lanes are masked by coe = sqrt(coe) = 0, which only works on finite numbers)
+  double* const stage_all = lmv + 8;
+  constexpr int STAGE_W = K3Stage<W>::WAVE_DOUBLES, REC = K3Stage<W>::REC;
+  for (int k = tid; k < C::WAVES * STAGE_W; k += K3_BLOCK) stage_all[k] = 0.0;
+  // where voxel a's record goes: batch a / NV is the first batch of wave (a / NV - bs) when that is < 8
+  auto record_of = [&](int a, bool valid) __attribute__((always_inline)) -> double* {
+    const int bi = a / C::NV - bs;
+    return (valid && bi >= 0 && bi < C::WAVES) ? stage_all + bi * STAGE_W + (a - (a / C::NV) * C::NV) * REC : nullptr;
+  };
+
   K3Planes pl;
   pl.cache_ptr = nullptr; pl.coe_ptr = nullptr; pl.clb = clb; pl.vs8 = vs8;
   double c0[10];
 #pragma unroll
   for (int k = 0; k < 10; k++) c0[k] = 0.0;
-  const bool single_pass = v1 - v0 <= K3_BLOCK;
+  // The Hessian half's first batch of cluster rows does not depend on anything computed here
   auto load_first = [&]() __attribute__((always_inline)) { if (wave < cnt) k3_load_clusters(pl, bs + wave, lane, c0); };
-  if (!wave_has) load_first();
-  dbg_stamp(DBG, gw, 30);
 
   // ONE wave per workgroup polls for the trial poses and fetches them for all eight (k2_residual_kernel: relaxed polls, no acquire fence;
   // the poses are read with system-coherent loads issued after the poll that saw `seq`)
-  if (wave == 0) {
-    unsigned spins = 0;
-    const unsigned spin_limit = (flags & 1) ? 1u : 4u * K2_SPIN_LIMIT;
-    bool seen = true;
-    while (__hip_atomic_load(&st->solve_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > spin_limit) { seen = false; break; }
+  auto wait_for_poses = [&]() __attribute__((always_inline)) -> bool {
+    if (wave == 0) {
+      unsigned spins = 0;
+      const unsigned spin_limit = (flags & 1) ? 1u : 4u * K2_SPIN_LIMIT;
+      bool seen = true;
+      while (__hip_atomic_load(&st->solve_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > spin_limit) { seen = false; break; }
+      }
+      if (seen) {
+        const volatile double* xt = st->ctl[c].xt;
+        if (lane < 12 * W) poseA[lane] = xt[lane];
+        if (lane + 64 < 12 * W) poseA[lane + 64] = xt[lane + 64];
+      } else if (lane == 0) st->error = 1;
+      if (lane == 0) k23_gave_up = seen ? 0 : 1;
     }
-    if (seen) {
-      const volatile double* xt = st->ctl[c].xt;
-      if (lane < 12 * W) poseA[lane] = xt[lane];
-      if (lane + 64 < 12 * W) poseA[lane + 64] = xt[lane + 64];
-    } else if (lane == 0) st->error = 1;
-    if (lane == 0) k23_gave_up = seen ? 0 : 1;
-  }
-  __syncthreads();
-  if (k23_gave_up) return;
-  dbg_stamp(DBG, gw, 5);
+    __syncthreads();
+    return k23_gave_up == 0;
+  };
 
-  // ---- residual half: 512 voxels per pass (one pass at the metric's size: 196 voxels per workgroup); later passes request their rows
-  // when they start (nothing of a pass is carried across the loop's back edge: the ring would become 100 registers of phi copies)
   double res = 0.0;
-  if (wave_has) {
-    auto hook = [&]() __attribute__((always_inline)) { if (single_pass) load_first(); };
-    res = k23_finish<W, false>(rs, vs8, (unsigned)(valid ? a : head) * 8u, valid, poseA, rg, gw, hook);   // (stamps 15 / 18 / 21 inside it: 250 spilled registers in the instrumented build -- off)
+  if constexpr (PAIR) {
+    // ---- a voxel per lane pair, one pass (the launcher picks this instantiation when no workgroup owns more than 256 voxels); wave w takes
+    // voxels [32 w, 32 w + 32) of the workgroup's run
+    const bool upper = (lane & 1) != 0;
+    const int a = v0 + wave * 32 + (lane >> 1);
+    const bool valid = a < v1;
+    const bool wave_has = v0 + wave * 32 < v1;   // wave-uniform
+    const unsigned a8 = (unsigned)(valid ? a : head) * 8u;
+    K23PairRegs<W> rg;
+    if (wave_has) k23_pair_issue<W>(rs, vs8, a8, upper ? (unsigned)(10 * K23PairRegs<W>::H1) * vs8 : 0u, rg);
+    load_first();
+    dbg_stamp(DBG, gw, 30);
+    if (!wait_for_poses()) return;
+    dbg_stamp(DBG, gw, 5);
+    if (wave_has) res = k23_pair_finish<W, DBG>(rs, vs8, a8, valid, upper, poseA, rg, record_of(a, valid), gw);
+  } else {
+    // wave w of a pass takes voxels [64 w, 64 w + 64) of it; a wave without voxels skips the residual half altogether -- its arithmetic would
+    // share a SIMD's fp64 issue with a wave that has voxels
+    K23Regs<W> rg;
+    int a = v0 + wave * 64 + lane;
+    bool valid = a < v1;
+    const bool wave_has = v0 + wave * 64 < v1;   // wave-uniform
+    if (wave_has) k23_issue<W>(rs, vs8, (unsigned)(valid ? a : head) * 8u, rg);
+    // a wave without voxels asks for the Hessian half's first batch now, the others between their eigen-decomposition and their cache stores
+    // (one pass) or behind their last pass
+    const bool single_pass = v1 - v0 <= K3_BLOCK;
+    if (!wave_has) load_first();
+    dbg_stamp(DBG, gw, 30);
+    if (!wait_for_poses()) return;
+    dbg_stamp(DBG, gw, 5);
+
+    // ---- residual half: 512 voxels per pass; later passes request their rows when they start (nothing of a pass is carried across the
+    // loop's back edge: the ring would become 100 registers of phi copies)
+    if (wave_has) {
+      auto hook = [&]() __attribute__((always_inline)) { if (single_pass) load_first(); };
+      res = k23_finish<W, false>(rs, vs8, (unsigned)(valid ? a : head) * 8u, valid, poseA, rg, record_of(a, valid), gw, hook);   // (stamps 15 / 18 / 21 inside it: 250 spilled registers in the instrumented build -- off)
+    }
+    for (int base = v0 + K3_BLOCK; base < v1; base += K3_BLOCK) {
+      if (base + wave * 64 >= v1) break;   // wave-uniform: the later waves of the last pass have nothing
+      a = base + wave * 64 + lane;
+      valid = a < v1;
+      K23Regs<W> rn;
+      k23_issue<W>(rs, vs8, (unsigned)(valid ? a : head) * 8u, rn);
+      res += k23_finish<W>(rs, vs8, (unsigned)(valid ? a : head) * 8u, valid, poseA, rn);
+    }
+    if (wave_has && !single_pass) load_first();
   }
-  for (int base = v0 + K3_BLOCK; base < v1; base += K3_BLOCK) {
-    if (base + wave * 64 >= v1) break;   // wave-uniform: the later waves of the last pass have nothing
-    a = base + wave * 64 + lane;
-    valid = a < v1;
-    K23Regs<W> rn;
-    k23_issue<W>(rs, vs8, (unsigned)(valid ? a : head) * 8u, rn);
-    res += k23_finish<W>(rs, vs8, (unsigned)(valid ? a : head) * 8u, valid, poseA, rn);
-  }
-  if (wave_has && !single_pass) load_first();
   k3_clear_pads<W>(lds, tid);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) res += __shfl_down(res, off);
   if (lane == 0) lmv[wave] = res;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's cache stores have reached the L2
+  // (the cache stores are NOT waited for here: the first phase A of the Hessian half reads its plane parameters from the staging corners;
+  // k3_sweep_body waits in front of the first step's barrier)
   dbg_stamp(DBG, gw, 24);
   __syncthreads();
   if (tid == 0) {

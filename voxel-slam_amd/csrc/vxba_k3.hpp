@@ -254,20 +254,21 @@ __device__ __forceinline__ void k3_load_param_q(const K3Planes& pl, int head, in
   }
 }
 // park the staged values in the wave's LDS corner and read back the lane's own voxel record
+// write = false (wave-uniform): the records are in the corner already -- the residual half of a fused launch put them there (vxba_k23.hpp)
 template <int W>
 __device__ __forceinline__ void k3_unstage_params(const K3Stage<W>& st, double* stage_lds, int head, int end, int b, bool active, int vl, int lane,
-                                                  K3Entry& e) {
+                                                  K3Entry& e, bool write = true) {
   using S = K3Stage<W>;
   using C = K3Cfg<W>;
 #pragma unroll
   for (int q = 0; q < S::Q; q++) {
     const int t = lane + 64 * q;
-    if (t < S::NITEM) {
+    if (t < S::NITEM && write) {
       const int v = t / 17, k = t - 17 * v;
       stage_lds[v * S::REC + k] = st.v[q];
     }
   }
-  if (lane < S::NV) stage_lds[lane * S::REC + 17] = st.coe;
+  if (lane < S::NV && write) stage_lds[lane * S::REC + 17] = st.coe;
   __builtin_amdgcn_wave_barrier();   // same wave, LDS operations execute in order: a scheduling fence is all that is needed
   const int a = b * C::NV + vl;
   e.ok = active && a >= head && a < end;
@@ -530,7 +531,8 @@ __device__ __forceinline__ void k3_sweep_body(double* lds, const double* __restr
 #pragma unroll
       for (int k = 0; k < 10; k++) e.c[k] = pre_c[k];
 #endif
-      k3_load_params<W, PAUX>(pl, head, end, bs + wave, lane, stg);
+      // (no request for the first batch's plane parameters: the residual half left the 18-double records of the workgroup's first eight
+      // batches in the waves' staging corners -- the first phase A reads them from there, see `first_a` below)
     }
 #ifdef VXBA_K23_DBG_BARRIER
     __syncthreads();
@@ -632,7 +634,13 @@ __device__ __forceinline__ void k3_sweep_body(double* lds, const double* __restr
   // Measured and rejected (round 3, same box): the LDS round trip of the plane parameters issued two thirds of the way through phase M
   // instead of at the head of phase A -- 29.8 -> 29.6 us at cfg2, but 166.9 -> 173.3 us at cfg4 (13 steps per workgroup): the wait
   // for the parameter loads then sits inside the MFMA stream, and with more traffic in flight they have not always landed by then.
-  auto unstage = [&](int b) __attribute__((always_inline)) { k3_unstage_params<W>(stg, stage_lds, head, end, b, active, vl, lane, e); };
+  // fused launch: the first phase A of a wave finds its records in the staging corner (written by the residual half, which this workgroup ran
+  // over the same voxels a barrier ago); the cache planes in memory are for the later steps, the reduction kernel and the next launch
+  bool first_a = FUSED;
+  auto unstage = [&](int b) __attribute__((always_inline)) {
+    k3_unstage_params<W>(stg, stage_lds, head, end, b, active, vl, lane, e, !(FUSED && first_a));
+    first_a = false;
+  };
   auto phase_a = [&](int b, int bo) __attribute__((always_inline)) {
     // instrumented build, step 2 only: 7 parameters + pose back in registers, 14 rows computed, 15 rows stored
     const bool stamp_here = DBG && dbg_step == 2;
@@ -683,6 +691,9 @@ __device__ __forceinline__ void k3_sweep_body(double* lds, const double* __restr
     if (DBG) dbg_step = s;
     phase_a(bs + s * C::WAVES + wave, (s & 1) * C::BUF);
     if (s >= 1 && s <= 4) dbg_stamp(DBG, gw, 14 + 3 * s);   // phase A of step s done: slots 17, 20, 23, 26
+    // fused launch: the residual half's cache stores (issued a phase A ago) acknowledged by every wave before the barrier behind which the
+    // next step's plane parameters are requested -- from the L2, by whichever wave of the workgroup owns the batch
+    if constexpr (FUSED) { if (s == 0) __builtin_amdgcn_s_waitcnt(0x0f70); }
     __syncthreads();
     if (s < 6) dbg_stamp(DBG, gw, 8 + s);
     if (undecided && decide()) return;
@@ -697,6 +708,7 @@ __device__ __forceinline__ void k3_sweep_body(double* lds, const double* __restr
       double* z = lds + bo + nrag * C::R * C::RS;
       for (int k = lane; k < (nch * 16 - nrag * C::R) * C::RS; k += 64) z[k] = 0.0;
     }
+    if constexpr (FUSED) { if (nfull == 0) __builtin_amdgcn_s_waitcnt(0x0f70); }
     __syncthreads();
     if (nfull < 6) dbg_stamp(DBG, gw, 8 + nfull);
     if (undecided && decide()) return;

@@ -1307,30 +1307,43 @@ int launch_k23_fused(const FactorView& fv, LMState* st, int c, unsigned seq, int
   if (head_start < 0) { const char* ev = getenv("VXBA_K2_HEAD_START"); head_start = ev ? atoi(ev) : K2_HEAD_START; if (head_start < 0) head_start = 0; }
   const int flags_hs = (flags & 0xff) | (head_start << 8);
 #define K23_ARGS st, c, seq, li_rec, li_out, host_feed, head, end, nwg, flags_hs, fv.cl, fv.clb, (int)fv.VS, d_partial2, d_partial3
+#define K23_LAUNCH(...)                                                                                                      \
+  do {                                                                                                                     \
+    if (ev_start) hipExtLaunchKernelGGL((k23_fused_kernel<__VA_ARGS__>), gr, bl, (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, K23_ARGS); \
+    else k23_fused_kernel<__VA_ARGS__><<<gr, bl, lds_bytes, s>>>(K23_ARGS);                                                \
+  } while (0)
+  static int pair_env = -1;   // development knob: VXBA_K23_PAIR=0 keeps the one-lane-per-voxel residual half at every size
+  if (pair_env < 0) { const char* ev = getenv("VXBA_K23_PAIR"); pair_env = (ev && ev[0] == '0') ? 0 : 1; }
   VXK_DISPATCH_W(fv.W, {
     constexpr size_t lds_bytes = k23_lds_bytes<WW>();
     static_assert(lds_bytes + 64 <= 160 * 1024, "fused launch: LDS");
+    // PAIR (a voxel's frames over a lane pair, vxba_k23.hpp): when no sweep workgroup owns more than 256 voxels -- the kernel's own split
+    constexpr int NV = K3Cfg<WW>::NV;
+    const int nb_all = (end - 1) / NV - head / NV + 1;
+    const bool pair = pair_env && ((nb_all + nwg - 1) / nwg) * NV <= K3_BLOCK / 2;
     static std::atomic<unsigned long long> opted{0ull};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const int variant = mixed ? 2 : (dbg ? 1 : 0);
-    const unsigned long long bit = 1ull << ((3 * dev + variant) & 63);
-    if (!(opted.load(std::memory_order_relaxed) & bit) || dev > 20) {
-      const void* fn = mixed ? (const void*)k23_fused_kernel<WW, false, true> : (dbg ? (const void*)k23_fused_kernel<WW, true> : (const void*)k23_fused_kernel<WW, false>);
+    const int variant = (mixed ? 2 : (dbg ? 1 : 0)) + (pair ? 3 : 0);
+    const unsigned long long bit = 1ull << ((6 * dev + variant) & 63);
+    const void* fn = pair ? (mixed ? (const void*)k23_fused_kernel<WW, false, true, true> : (dbg ? (const void*)k23_fused_kernel<WW, true, false, true> : (const void*)k23_fused_kernel<WW, false, false, true>))
+                          : (mixed ? (const void*)k23_fused_kernel<WW, false, true> : (dbg ? (const void*)k23_fused_kernel<WW, true> : (const void*)k23_fused_kernel<WW, false>));
+    if (!(opted.load(std::memory_order_relaxed) & bit) || dev > 9) {
       (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       opted.fetch_or(bit, std::memory_order_relaxed);
     }
     const dim3 gr(nwg + 1), bl(K3_BLOCK);
-    if (mixed) {
-      if (ev_start) hipExtLaunchKernelGGL((k23_fused_kernel<WW, false, true>), gr, bl, (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, K23_ARGS);
-      else k23_fused_kernel<WW, false, true><<<gr, bl, lds_bytes, s>>>(K23_ARGS);
-    } else if (dbg) {
-      k23_fused_kernel<WW, true><<<gr, bl, lds_bytes, s>>>(K23_ARGS);
+    if (pair) {
+      if (mixed) K23_LAUNCH(WW, false, true, true);
+      else if (dbg) K23_LAUNCH(WW, true, false, true);
+      else K23_LAUNCH(WW, false, false, true);
     } else {
-      if (ev_start) hipExtLaunchKernelGGL((k23_fused_kernel<WW, false>), gr, bl, (uint32_t)lds_bytes, s, ev_start, ev_stop, 0, K23_ARGS);
-      else k23_fused_kernel<WW, false><<<gr, bl, lds_bytes, s>>>(K23_ARGS);
+      if (mixed) K23_LAUNCH(WW, false, true, false);
+      else if (dbg) K23_LAUNCH(WW, true, false, false);
+      else K23_LAUNCH(WW, false, false, false);
     }
   });
+#undef K23_LAUNCH
 #undef K23_ARGS
   return nwg;
 }
