@@ -235,7 +235,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-li-ba", action="store_true", help="skip the secondary LiDAR-inertial BA figure")
     ap.add_argument("--precision", choices=["f64", "mixed", "mixed_f32_clusters"], default="f64",
-                    help="mixed = BASELINE configs[2]: f32 Hessian products on the matrix cores, f64 accumulation (use with --config cfg3); "
+                    help="mixed = BASELINE configs[2]: the Jacobian rows of the Hessian sweep rounded to f32, f64 products and accumulation -- a TOLERANCE study since round 5, not a faster path (use with --config cfg3); "
                          "mixed_f32_clusters: mixed, and the residual sweep reads the clusters as f32 re-centred records")
     ap.add_argument("--scaling", choices=["both", "weak", "strong"], default="both",
                     help="N > 1: strong = ONE --config window split over the N GPUs (value = K/time: BASELINE's 'BA iterations/sec (10-frame window, 100k "

@@ -112,16 +112,19 @@ int downsample_device(Scratch& sc, hipStream_t s, const float* d_in, int64_t n, 
     d_idx = (unsigned int*)carve(b_i); d_idx_s = (unsigned int*)carve(b_i); d_cnt = (unsigned int*)carve(b_i);
     d_runs = (unsigned int*)carve(256); d_ptr = (long long*)carve(b_p); d_err = (int*)carve(256); d_temp = carve(b_t);
   }
-  DS(hipMemsetAsync(d_err, 0, 4, s));
+  // The two words the host needs -- the range-error flag and the number of occupied voxels -- are written by the kernels that produce them
+  // straight into mapped pinned memory (round 6: no memset, no copy-engine round trips; hipHostMalloc'd memory is mapped at the same address).
+  if (!sc.pinned) DS(hipHostMalloc((void**)&sc.pinned, 64, hipHostMallocDefault));
+  ((volatile unsigned int*)sc.pinned)[0] = 0;
+  ((volatile unsigned int*)sc.pinned)[1] = 0;
+  d_err = (int*)sc.pinned;
+  d_runs = (unsigned int*)sc.pinned + 1;
   ds_key_kernel<<<grid, 256, 0, s>>>(d_in, n, voxel_size, d_key, d_idx, d_err);
   DS(hipGetLastError());
   size_t tt = t;
   DS(rocprim::radix_sort_pairs(d_temp, tt, d_key, d_key_s, d_idx, d_idx_s, (size_t)n, 0, 63, s));
   tt = t;
   DS(rocprim::run_length_encode(d_temp, tt, d_key_s, (size_t)n, d_ukey, d_cnt, d_runs, s));
-  if (!sc.pinned) DS(hipHostMalloc((void**)&sc.pinned, 64, hipHostMallocDefault));
-  DS(hipMemcpyAsync(sc.pinned, d_err, 4, hipMemcpyDeviceToHost, s));
-  DS(hipMemcpyAsync(sc.pinned + 1, d_runs, 4, hipMemcpyDeviceToHost, s));
   {   // by polling: a blocking wait parks the thread (~25 us to wake up from); pinned destination: a copy into pageable memory is staged and waited for
     hipError_t q;
     q = vxwait::stream_wait(s);

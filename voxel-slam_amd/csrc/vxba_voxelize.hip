@@ -10,11 +10,23 @@
 //   PointCluster::push.  Nodes are then judged top-down (N > 10, plane_judge, >= 2 observing frames, lambda0/lambda1 <=
 //   0.12; non-planes are subdivided while layer < max_layer), and the accepted ones are appended to the factor's planes
 //   on the device, cache seeded with (lambda, U, world cluster) like recut's push_voxel does.
+//
+// Round 6: only layer 0 is a sort.  The cloud arrives frame by frame in cloud order, so the order a layer needs -- (node of layer l, frame,
+// cloud index) -- is the stable sort of the ORIGINAL sequence by the node key alone; and since a node of layer l is (node of layer l-1,
+// one octant), the order of layer l is the order of layer l-1 with every node's point range stably partitioned by that octant: one pass of
+// partition_kernel (a workgroup per node of layer l-1: eight ballots per 64 points) in place of a 64-bit radix sort of all n keys, which
+// at the sizes of a window (<= 1M points) rocPRIM runs as a block sort + eight merge passes, each launch-bound (a quarter of the GPU time
+// of a hierarchical-BA pass, profiles/r05_cfg5).  Same permutation, hence the same cells, nodes and cluster sums bit for bit.  The counts
+// the host needs between launches are written by the kernels that produce them straight into mapped pinned memory (rocPRIM's run-length
+// encode takes the pinned word as its count output; the others through a one-thread kernel): no copy engine round trips.
 #include "vxba_wait.hpp"
 #include <hip/hip_runtime.h>
 #include <atomic>
 
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -105,6 +117,99 @@ __global__ void node_ptr_kernel(const long long* __restrict__ cell_ptr, const lo
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j <= n_nodes) node_ptr[j] = cell_ptr[node_cell_ptr[j]];
 }
+// Layer l >= 1 from layer l-1: node j of layer l-1 owns points node_ptr[j] .. node_ptr[j+1] of the sequence idx_in, ordered (frame, cloud
+// index); its points are moved, order kept, into eight runs by the octant they fall into at layer l.  One workgroup per node; a node of up to
+// 64 points (most of them) is done by wave 0 alone with eight ballots, longer ones in two passes over chunks of PART_BLOCK points (counts,
+// then places).  Writes the new sequence and its layer keys (what layer_key_kernel + the sort produced).
+constexpr int PART_BLOCK = 256;
+__global__ __launch_bounds__(PART_BLOCK) void partition_kernel(const unsigned long long* __restrict__ key, const unsigned int* __restrict__ idx_in,
+                                                               const long long* __restrict__ node_ptr, int layer, unsigned int* __restrict__ idx_out,
+                                                               unsigned long long* __restrict__ lkey_out) {
+  const long long a = node_ptr[blockIdx.x], b = node_ptr[blockIdx.x + 1];
+  const long long m = b - a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int shift = FRAME_BITS + 3 * (3 - layer);
+  const unsigned long long keep = ~(((1ull << (3 * (3 - layer))) - 1ull) << FRAME_BITS);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  if (m <= 64) {
+    if (wave != 0) return;
+    const bool valid = lane < m;
+    unsigned int i = 0;
+    unsigned long long k = 0;
+    if (valid) { i = idx_in[a + lane]; k = key[i]; }
+    const int o = (int)((k >> shift) & 7ull);
+    unsigned int base = 0, dest = 0;
+#pragma unroll
+    for (int oo = 0; oo < 8; oo++) {
+      const unsigned long long mask = __ballot(valid && o == oo);
+      if (o == oo) dest = base + (unsigned int)__popcll(mask & lt);
+      base += (unsigned int)__popcll(mask);
+    }
+    if (valid) { idx_out[a + dest] = i; lkey_out[a + dest] = k & keep; }
+    return;
+  }
+  __shared__ unsigned int wcnt[PART_BLOCK / 64][8];
+  __shared__ long long run[8];
+  // pass 1: points per octant
+  unsigned int mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long long e = a + tid; e < b; e += PART_BLOCK) {
+    const int o = (int)((key[idx_in[e]] >> shift) & 7ull);
+#pragma unroll
+    for (int oo = 0; oo < 8; oo++) mine[oo] += (o == oo) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int oo = 0; oo < 8; oo++) {
+    unsigned int v = mine[oo];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) wcnt[wave][oo] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    long long at = a;
+    for (int oo = 0; oo < 8; oo++) {
+      run[oo] = at;
+      for (int w = 0; w < PART_BLOCK / 64; w++) at += wcnt[w][oo];
+    }
+  }
+  __syncthreads();
+  // pass 2: places, chunk by chunk in sequence order
+  for (long long c = a; c < b; c += PART_BLOCK) {
+    const long long e = c + tid;
+    const bool valid = e < b;
+    unsigned int i = 0;
+    unsigned long long k = 0;
+    if (valid) { i = idx_in[e]; k = key[i]; }
+    const int o = (int)((k >> shift) & 7ull);
+    unsigned int below = 0;
+#pragma unroll
+    for (int oo = 0; oo < 8; oo++) {
+      const unsigned long long mask = __ballot(valid && o == oo);
+      if (o == oo) below = (unsigned int)__popcll(mask & lt);
+      if (lane == 0) wcnt[wave][oo] = (unsigned int)__popcll(mask);
+    }
+    __syncthreads();
+    if (valid) {
+      long long d = run[o] + below;
+      for (int w = 0; w < wave; w++) d += wcnt[w][o];
+      idx_out[d] = i;
+      lkey_out[d] = k & keep;
+    }
+    __syncthreads();
+    if (tid < 8) {
+      long long add = 0;
+      for (int w = 0; w < PART_BLOCK / 64; w++) add += wcnt[w][tid];
+      run[tid] += add;
+    }
+    __syncthreads();
+  }
+}
+// a count the host is waiting for, written where it polls (mapped pinned memory): dst[0] = src_a[0] (+ src_b[0])
+__global__ void post_count_kernel(const unsigned int* __restrict__ src_a, const unsigned int* __restrict__ src_b, unsigned long long* __restrict__ dst) {
+  dst[0] = (unsigned long long)src_a[0] + (src_b ? (unsigned long long)src_b[0] : 0ull);
+}
+__global__ void post_count64_kernel(const long long* __restrict__ src, unsigned long long* __restrict__ dst) { dst[0] = (unsigned long long)src[0]; }
+__global__ void post_count32s_kernel(const int* __restrict__ src, unsigned long long* __restrict__ dst) { dst[0] = (unsigned long long)(unsigned int)src[0]; }
+
 __global__ void widen_kernel(const unsigned int* __restrict__ in, long long n, long long* __restrict__ out) {
   const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < n) out[q] = (long long)in[q];
@@ -228,6 +333,14 @@ static ArenaSlot g_arena[16][ARENA_SLOTS];
 // vxba_voxelize_profile: time of / bytes moved by the cluster-build kernel inside the voxeliser (the dominant kernel of a hierarchical-BA pass)
 struct K1Prof { std::atomic<int> on{0}; std::mutex m; double ms = 0, bytes = 0; long long launches = 0; };
 static K1Prof g_k1prof;
+// development: VXBA_VOXELIZE_WAITS=1 prints, at exit, how long the voxeliser's host threads spent waiting for the counts
+struct WaitProf {
+  bool on = false;
+  std::atomic<long long> us{0}, n{0}, slow{0}, max_us{0};
+  WaitProf() { const char* e = getenv("VXBA_VOXELIZE_WAITS"); on = e && e[0] == '1'; }
+  ~WaitProf() { if (on) fprintf(stderr, "[vxba voxelize] %lld waits, %.1f ms in them, %lld over 1 ms, longest %lld us\n", n.load(), us.load() / 1e3, slow.load(), max_us.load()); }
+};
+static WaitProf g_wait_prof;
 struct DevBuf {
   char* base = nullptr;
   size_t cap = 0, used = 0;
@@ -272,8 +385,37 @@ struct DevBuf {
     host[k] = 0;
     return hipMemcpyAsync(host + k, d_src, bytes, hipMemcpyDeviceToHost, s);
   }
+  // Round 6: the same counts WITHOUT the copy engine -- the kernel that produces a count (or a one-thread kernel behind it) stores it into
+  // the mapped pinned word itself; a hierarchical-BA pass made 1 870 four-byte copies of ~4 us each.  (hipHostMalloc'd memory is mapped into
+  // the device's address space at the same address; the store is visible to the host when the stream has drained, which is what wait() polls.)
+  unsigned int* word_u32(int k) { host[k] = 0; return reinterpret_cast<unsigned int*>(host + k); }
+  hipError_t post_sum_u32(int k, const unsigned int* a, const unsigned int* b, hipStream_t s) {
+    host[k] = 0;
+    post_count_kernel<<<1, 1, 0, s>>>(a, b, host + k);
+    return hipGetLastError();
+  }
+  hipError_t post_i64(int k, const long long* a, hipStream_t s) {
+    host[k] = 0;
+    post_count64_kernel<<<1, 1, 0, s>>>(a, host + k);
+    return hipGetLastError();
+  }
+  hipError_t post_i32(int k, const int* a, hipStream_t s) {
+    host[k] = 0;
+    post_count32s_kernel<<<1, 1, 0, s>>>(a, host + k);
+    return hipGetLastError();
+  }
   static hipError_t wait(hipStream_t s) {
     hipError_t q;
+    if (g_wait_prof.on) {
+      const auto t0 = std::chrono::steady_clock::now();
+      q = vxwait::stream_wait(s);
+      const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+      g_wait_prof.us.fetch_add(us); g_wait_prof.n.fetch_add(1);
+      if (us > 1000) g_wait_prof.slow.fetch_add(1);
+      long long mx = g_wait_prof.max_us.load();
+      while (us > mx && !g_wait_prof.max_us.compare_exchange_weak(mx, us)) {}
+      return q;
+    }
     q = vxwait::stream_wait(s);
     return q;
   }
@@ -342,7 +484,7 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
   char* d_temp;
   VV(B.alloc(&d_temp, tb));
 
-  VV(B.fetch(0, d_err, sizeof(int), s));
+  VV(B.post_i32(0, d_err, s));
   VV(B.wait(s));
   if (B.u32(0)) { *err_out = range_msg; return -1; }
   if (sharded && n > 0) {
@@ -354,15 +496,17 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
     shard_flag_kernel<<<grid_for(n), 256, 0, s>>>(d_key, n, p.shard_index, p.shard_count, d_flag);
     size_t t = tb;
     VV(rocprim::exclusive_scan(d_temp, t, d_flag, d_pos, 0u, (size_t)n, rocprim::plus<unsigned int>(), s));
-    VV(B.fetch(1, d_pos + (n - 1), sizeof(unsigned int), s));
-    VV(B.fetch(2, d_flag + (n - 1), sizeof(unsigned int), s));
+    VV(B.post_sum_u32(1, d_pos + (n - 1), d_flag + (n - 1), s));
     shard_compact_kernel<<<grid_for(n), 256, 0, s>>>(d_flag, d_pos, n, d_xyz_local, d_world, d_key, d_loc_c, d_wld_c, d_key_c);
     VV(B.wait(s));
-    n = (long long)B.u32(1) + (long long)B.u32(2);
+    n = B.i64(1);
     d_xyz_local = d_loc_c; d_world = d_wld_c; d_key = d_key_c;
     if (n == 0) { out->n_entries = 0; return 0; }
   }
 
+  // development knob (same-box A/B): VXBA_VOXELIZE_PARTITION=0 sorts every layer as rounds 1-5 did
+  static const bool use_partition = [] { const char* e = getenv("VXBA_VOXELIZE_PARTITION"); return !(e && e[0] == '0'); }();
+  constexpr long long PARTITION_MAX_POINTS = 1ll << 20;   // beyond this rocPRIM sorts with onesweep, and one node can be a workgroup's millisecond
   long long total = 0, total_entries = 0;
   long long* d_epos = nullptr;
   if (out->d_row_ptr) {
@@ -370,13 +514,19 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
     VV(hipMemsetAsync(out->d_row_ptr, 0, sizeof(long long), s));
   }
   for (int layer = 0; layer <= p.max_layer && n > 0; layer++) {
-    layer_key_kernel<<<grid_for(n), 256, 0, s>>>(d_key, n, layer, d_lkey, d_idx);
     size_t t = tb;
-    VV(rocprim::radix_sort_pairs(d_temp, t, d_lkey, d_lkey_s, d_idx, d_idx_s, (size_t)n, 0, 64, s));
+    if (layer > 0 && use_partition && n <= PARTITION_MAX_POINTS) {
+      // this layer's order = the previous layer's with every node's range stably partitioned by the new octant (see the header)
+      partition_kernel<<<(unsigned)n_nodes_l[layer - 1], PART_BLOCK, 0, s>>>(d_key, d_idx_s, d_node_ptr, layer, d_idx, d_lkey);
+      { unsigned int* ti = d_idx; d_idx = d_idx_s; d_idx_s = ti; }
+      { unsigned long long* tk = d_lkey; d_lkey = d_lkey_s; d_lkey_s = tk; }
+    } else {
+      layer_key_kernel<<<grid_for(n), 256, 0, s>>>(d_key, n, layer, d_lkey, d_idx);
+      VV(rocprim::radix_sort_pairs(d_temp, t, d_lkey, d_lkey_s, d_idx, d_idx_s, (size_t)n, 0, 64, s));
+    }
     // (node, frame) cells
     t = tb;
-    VV(rocprim::run_length_encode(d_temp, t, d_lkey_s, (size_t)n, d_cell_key, d_cell_cnt, d_runs, s));
-    VV(B.fetch(3, d_runs, sizeof(unsigned int), s));
+    VV(rocprim::run_length_encode(d_temp, t, d_lkey_s, (size_t)n, d_cell_key, d_cell_cnt, B.word_u32(3), s));
     VV(B.wait(s));
     const unsigned int n_cells = B.u32(3);
     widen_kernel<<<grid_for(n_cells), 256, 0, s>>>(d_cell_cnt, n_cells, d_tmp64);
@@ -386,8 +536,7 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
     shift_key_kernel<<<grid_for(n_cells), 256, 0, s>>>(d_cell_key, n_cells, d_cell_node);
     VV(B.alloc(&d_node_key[layer], n_cells));
     t = tb;
-    VV(rocprim::run_length_encode(d_temp, t, d_cell_node, (size_t)n_cells, d_node_key[layer], d_node_ncell, d_runs, s));
-    VV(B.fetch(4, d_runs, sizeof(unsigned int), s));
+    VV(rocprim::run_length_encode(d_temp, t, d_cell_node, (size_t)n_cells, d_node_key[layer], d_node_ncell, B.word_u32(4), s));
     VV(B.wait(s));
     const unsigned int n_nodes = B.u32(4);
     n_nodes_l[layer] = n_nodes;
@@ -425,20 +574,18 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
     flag_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_state[layer], n_nodes, d_flag);
     t = tb;
     VV(rocprim::exclusive_scan(d_temp, t, d_flag, d_pos, 0u, (size_t)n_nodes, rocprim::plus<unsigned int>(), s));
-    unsigned int last_pos = 0, last_flag = 0;
+    long long n_acc = 0;
     if (n_nodes > 0) {
-      VV(B.fetch(5, d_pos + n_nodes - 1, sizeof(unsigned int), s));
-      VV(B.fetch(6, d_flag + n_nodes - 1, sizeof(unsigned int), s));
+      VV(B.post_sum_u32(5, d_pos + n_nodes - 1, d_flag + n_nodes - 1, s));
       VV(B.wait(s));
-      last_pos = B.u32(5); last_flag = B.u32(6);
+      n_acc = B.i64(5);
     }
-    const long long n_acc = (long long)last_pos + last_flag;
     if (total + n_acc > out->capacity) { *err_out = cap_msg; return -1; }
     if (n_acc > 0 && out->d_row_ptr) {
       entry_count_kernel<<<grid_for((long long)n_nodes + 1), 256, 0, s>>>(d_state[layer], d_node_ncell, n_nodes, d_tmp64);
       t = tb;
       VV(rocprim::exclusive_scan(d_temp, t, d_tmp64, d_epos, 0ll, (size_t)n_nodes + 1, rocprim::plus<long long>(), s));
-      VV(B.fetch(7, d_epos + n_nodes, sizeof(long long), s));
+      VV(B.post_i64(7, d_epos + n_nodes, s));
       VV(B.wait(s));
       const long long n_ent = B.i64(7);
       if (total_entries + n_ent > out->ecap) { *err_out = cap_msg; return -1; }
