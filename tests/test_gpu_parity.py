@@ -297,7 +297,10 @@ def test_fused_launch_is_the_three_launch_iteration_to_round_off(vx):
         # residual1 / residual2 to 1e-9; the damping trajectory and the gain ratios like the oracle comparison (check_lm_parity): q divides a
         # DIFFERENCE of residuals, and at the metric's size the fused launch merges a voxel's clusters in two halves (lane pair, vxba_k23.hpp)
         assert np.allclose(a["trace"][:, :2], b["trace"][:, :2], rtol=1e-9, atol=0)
-        assert np.allclose(a["trace"][:, 2:6], b["trace"][:, 2:6], rtol=1e-6, atol=0)
+        assert np.allclose(a["trace"][:, 2:4], b["trace"][:, 2:4], rtol=1e-6, atol=0)
+        # q = residual1 - residual2 (and the model's q1): absolute against the residuals they are differences of (9.5e-9 of 2.6e-1 in the third
+        # iteration of the first window: five digits of it are the residuals' round-off)
+        assert np.allclose(a["trace"][:, 4:6], b["trace"][:, 4:6], rtol=1e-6, atol=1e-9 * float(np.abs(a["trace"][:, 0]).max()))
         et, er = synth.pose_errors(a["poses"], b["poses"])
         assert et < 1e-12 and er < 1e-12, (et, er)
         assert relerr(a["hess"], b["hess"]) < 1e-11

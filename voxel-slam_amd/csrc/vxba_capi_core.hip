@@ -395,7 +395,8 @@ int sweep_fused_device(vxba_factor* f, vxk::LMState* lm, int* c, unsigned seq) {
   *c ^= 1;   // the launch's solve workgroup has decided the step into the other control block; the reduction is gated by it
   {
     ScopedKernelTimer t(f, 2);
-    vxk::launch_k3_finalize(f->d_partial3, nwg, f->W, lm, *c, 1, f->d_packed, f->stream, 0, nullptr, 0, f->d_partial2, vxk::K23_MAX_SWEEP_BLOCKS);
+    // (no reset of the residual slots here: the launch's solve workgroup has put them back to NaN itself once it had read them all)
+    vxk::launch_k3_finalize(f->d_partial3, nwg, f->W, lm, *c, 1, f->d_packed, f->stream, 0, nullptr, 0, nullptr, 0);
   }
   VX_HIP(f, hipGetLastError());
   return VXBA_OK;

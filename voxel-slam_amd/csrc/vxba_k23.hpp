@@ -334,6 +334,13 @@ __global__ __launch_bounds__(K3_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
     LMPending pd;
     pd.pending = 1; pd.restart = 0; pd.d_scalar = nullptr; pd.partial = partial2; pd.nparts = nwg;
     const double r2 = lm_residual2_finish(pd, L);
+    // every sum has been read: the slots go back to NaN for the next fused launch (the reduction kernel behind THIS launch no longer does it:
+    // 0.7 us of its 7 at the head of its last workgroup; the one behind a stand-alone Hessian sweep -- first iteration of a solve -- still does)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = 64 * k + lane;
+      if (i < nwg) __hip_atomic_store(&partial2[i], __builtin_nan(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const LMDecision d = lm_decide(st->ctl[c], r2, 0);
     lm_persist_wave(st, c, d, W);
     return;
