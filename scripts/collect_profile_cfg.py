@@ -19,17 +19,34 @@ for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     path = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{kind}", "t_counter_collection.csv")
     if not os.path.exists(path):
         continue
-    acc = defaultdict(list)
+    acc = defaultdict(lambda: [0.0, 0])      # per kernel: sum over launches, launches (a table reduced by scripts/reduce_counters.py carries means + counts)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-    res[f"{counter}_KB_mean_per_launch"] = {k: {"n": len(v), "mean": sum(v) / len(v)} for k, v in acc.items() if "vxk" in k}
+            n = int(r["Launches"]) if r.get("Launches") else 1
+            a = acc[r["Kernel_Name"].split("(")[0]]
+            a[0] += float(r["Counter_Value"]) * n; a[1] += n
+    res[f"{counter}_KB_mean_per_launch"] = {k: {"n": v[1], "mean": v[0] / v[1]} for k, v in acc.items() if "vxk" in k}
 import bench as bench_mod
 from voxel_slam_amd import synth
 res["kernel_source_sha256"] = bench_mod.kernel_source_hash()
 res["kernel_sources"] = list(bench_mod.KERNEL_SOURCES)
 res["config"] = cfg
 json.dump(res, open(os.path.join(out, "pmc_hbm_counters.json"), "w"), indent=1)
+if cfg not in synth.CONFIGS:
+    # cfg5 (hierarchical pass): no closed-form bytes per launch (606 cluster builds of different sizes per pass; bench.py measures the algorithmic
+    # bytes live) -- file the counter traffic of the pass's own kernels beside their trace durations
+    roof = {"config": cfg, "hbm_peak_GBs": 8000.0, "kernels": []}
+    F, Wr = res.get("FETCH_SIZE_KB_mean_per_launch", {}), res.get("WRITE_SIZE_KB_mean_per_launch", {})
+    for r in csv.DictReader(open(stats)):
+        k = r["Name"].split("(")[0]
+        if k in F and k in Wr:
+            tb = (2.0 * F[k]["mean"] + Wr[k]["mean"]) * 1024.0
+            roof["kernels"].append({"kernel": k, "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "share_of_kernel_time_pct": float(r["Percentage"]),
+                                    "traffic_bytes_per_launch": tb, "traffic_GBs": tb / float(r["AverageNs"]), "traffic_frac_of_hbm_peak": tb / float(r["AverageNs"]) / 8000.0})
+    json.dump(roof, open(os.path.join(out, "roofline.json"), "w"), indent=1)
+    for e in roof["kernels"][:8]:
+        print("%-60s calls %6d avg %8.2f us  traffic %8.1f KB/launch = %6.0f GB/s" % (e["kernel"][:60], e["calls"], e["avg_us"], e["traffic_bytes_per_launch"] / 1024, e["traffic_GBs"]))
+    sys.exit(0)
 c = synth.CONFIGS[cfg]
 V, W = c["n_voxels"], c["win_size"]
 nnz = V * W if c.get("p_obs", 1.0) == 1.0 else None

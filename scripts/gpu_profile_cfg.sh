@@ -15,4 +15,5 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$G
 cd "$GRAFT_REPO_ROOT"
 # keep what the collector reads, drop the per-dispatch traces of the counter passes beyond it (gpurun_out is merged back up to 64 MiB)
 find gpurun_out/prof_${TAG}_* -type f -name "*_kernel_trace.csv" -size +8M -delete
+find gpurun_out/prof_${TAG}_* -type f -name "*_counter_collection.csv" -size +4M -exec python scripts/reduce_counters.py {} \;
 du -sh gpurun_out/prof_${TAG}_* 2>/dev/null
