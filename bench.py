@@ -613,8 +613,15 @@ def bench_cfg5(args, rank, world, local_rank, use_dist, backend, real_stdout):
     ses = vxba.HbaSession(device=local_rank)
     ses.add_keyframes(clouds)
 
+    # Several process ranks on ONE device (the plumbing runs: VXBA_BENCH_DEVICE): one stream per rank.  With four streams in each of two
+    # processes the GPU's queues are oversubscribed and the driver time-slices whole processes -- round 6 measured single count waits of
+    # 3.6 s and 22 s per pass that way, against 0.23 s with one stream per rank (gpurun_out/r6_s8_cfg5_two_rank.txt).  One rank per GPU keeps four.
+    hba_threads = args.hba_threads
+    if hba_threads <= 0 and world > 1 and os.environ.get("VXBA_BENCH_DEVICE") is not None:
+        hba_threads = 1
+
     def one_pass():
-        return vdist.hba_pass(ses, poses, coarse, fine, wdsize=10, mgsize=5, tail=True, top_max_iter=2, n_threads=args.hba_threads, ctx=ctx)
+        return vdist.hba_pass(ses, poses, coarse, fine, wdsize=10, mgsize=5, tail=True, top_max_iter=2, n_threads=hba_threads, ctx=ctx)
 
     def sync():
         if use_dist:
@@ -626,8 +633,11 @@ def bench_cfg5(args, rank, world, local_rank, use_dist, backend, real_stdout):
     sync()
     host0 = host_cpu_state()
     t0 = time.perf_counter()
+    phase_s = {}
     for _ in range(steps):
         out = one_pass()
+        for k, v in out.get("phase_s", {}).items():
+            phase_s[k] = phase_s.get(k, 0.0) + v / steps
     sync()
     elapsed = time.perf_counter() - t0
     host1 = host_cpu_state()
@@ -670,7 +680,8 @@ def bench_cfg5(args, rank, world, local_rank, use_dist, backend, real_stdout):
                                           f"; bottom-level windows over {out.get('n_threads_used', args.hba_threads)} host thread(s) / stream(s) per rank",
                            "top_packed_bytes": 8 * (36 * S * S + 6 * S + 1), "top_rounds": [dict(n_voxels_this_rank=r["n_voxels"], resis=r["resis"]) for r in out["top_rounds"]],
                            "edges": [len(out["edges1"]), len(out["edges2"])], "anchor_error_before_m_rad": [float(x) for x in e0], "anchor_error_after_m_rad": [float(x) for x in e1],
-                           "session_generation_s": t_gen},
+                           "session_generation_s": t_gen,
+                           "phase_s_rank0": {k: round(v, 5) for k, v in phase_s.items()}},
                 "roofline": roof, "cpu_baseline": cpu,
                 "host": {"nproc": host1["nproc"], "cgroup_cpu_max": host1["cpu_max"], "quota_cores": host1["quota_cores"],
                          "throttled_s_in_timed_region": None if host0["throttled_usec"] is None or host1["throttled_usec"] is None
