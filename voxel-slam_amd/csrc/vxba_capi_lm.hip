@@ -1,5 +1,6 @@
 // C-ABI implementation, LM drivers of the LiDAR-only optimiser (include/vxba.h): Lidar_BA_Optimizer::damping_iter as a device-resident
 // loop (voxel_map.hpp:367-442), the host driver over caller-supplied sweeps, and the bench loop vxba_lm_steps.
+#include <cstddef>
 #include "vxba_capi_internal.hpp"
 
 using namespace vxc;
@@ -263,7 +264,8 @@ static int lm_steps_impl(vxba_factor* f, const double* Rp_init, int n_steps, int
   }
   if (pend.pending) { vxk::launch_lm_update(f->d_lm, c, pend, x0, W, f->stream); c ^= 1; }
   VX_HIP(f, hipGetLastError());
-  VX_HIP(f, hipMemcpyAsync(f->h_lm, f->d_lm, sizeof(vxk::LMState), hipMemcpyDeviceToHost, f->stream));
+  static_assert(offsetof(vxk::LMState, trace) == vxk::LM_HEAD_BYTES, "LMState: the head vxba_lm_steps reads back");
+  VX_HIP(f, hipMemcpyAsync(f->h_lm, f->d_lm, vxk::LM_HEAD_BYTES, hipMemcpyDeviceToHost, f->stream));   // poses, residuals, counters, error flag: not the trace / Hessians (66 KB)
   VX_HIP(f, stream_wait_spin(f->stream));   // by polling, as in damping_iter: waking up from hipStreamSynchronize costs 15-25 us -- 1.5 % of a 20-step call
   if (f->h_lm->error) return fail(f, VXBA_ERR_STATE, "lm_steps: a residual-sweep workgroup timed out waiting for the in-launch solve");
   const vxk::LMCtl& st = f->h_lm->ctl[c];

@@ -60,14 +60,16 @@ struct LMCtl {
 };
 struct LMState {
   LMCtl ctl[2];
+  // (behind the control blocks, so that vxba_lm_steps reads back [ctl | solve_seq | error] -- 4 KB -- and not the 66 KB of everything: LM_HEAD_BYTES)
+  unsigned solve_seq;                     // sequence number of the last solve published inside a residual-sweep launch
+  int error;                              // 1: a voxel workgroup gave up waiting for the solve (never observed)
   double trace[LM_MAX_ITER * 8];
   double Jwork[6 * MAXW];                 // gauge-fixed gradient kept across rejected steps
   double dxi[6 * MAXW];
   double Hwork[36 * MAXW * MAXW];         // gauge-fixed Hessian kept across rejected steps
   double hess_out[36 * MAXW * MAXW];      // *hess, exported before the gauge fix (voxel_map.hpp:391)
-  unsigned solve_seq;                     // sequence number of the last solve published inside a residual-sweep launch
-  int error;                              // 1: a voxel workgroup gave up waiting for the solve (never observed)
 };
+constexpr size_t LM_HEAD_BYTES = 2 * sizeof(LMCtl) + 8;   // ctl[2] | solve_seq | error
 // What a sweep needs to take the pending accept/reject decision in its prologue.
 struct LMPending {
   int pending;                // 1: ctl[c] awaits the decision of the step whose residual sweep just ran (taken in the sweep's prologue);
