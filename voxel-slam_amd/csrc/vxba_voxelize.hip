@@ -32,7 +32,6 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_run_length_encode.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include "vxba_kernels.h"
@@ -106,16 +105,6 @@ __global__ void gather3_kernel(const double* __restrict__ src, const unsigned in
   if (q >= n) return;
   const unsigned int s = idx[q];
   dst[3 * q] = src[3 * s]; dst[3 * q + 1] = src[3 * s + 1]; dst[3 * q + 2] = src[3 * s + 2];
-}
-__global__ void shift_key_kernel(const unsigned long long* __restrict__ in, long long n, unsigned long long* __restrict__ out) {
-  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < n) out[q] = in[q] >> FRAME_BITS;
-}
-// cell_ptr[c] (exclusive scan of the cell sizes) -> node_ptr[j] = cell_ptr[node_cell_ptr[j]]
-__global__ void node_ptr_kernel(const long long* __restrict__ cell_ptr, const long long* __restrict__ node_cell_ptr, long long n_nodes,
-                                long long* __restrict__ node_ptr) {
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j <= n_nodes) node_ptr[j] = cell_ptr[node_cell_ptr[j]];
 }
 // Layer l >= 1 from layer l-1: node j of layer l-1 owns points node_ptr[j] .. node_ptr[j+1] of the sequence idx_in, ordered (frame, cloud
 // index); its points are moved, order kept, into eight runs by the octant they fall into at layer l.  One workgroup per node; a node of up to
@@ -203,6 +192,36 @@ __global__ __launch_bounds__(PART_BLOCK) void partition_kernel(const unsigned lo
     __syncthreads();
   }
 }
+// Cells and nodes of a layer from the sorted layer keys in ONE pass (round 6; rounds 1-5: run-length encode of the keys, widen, scan, shift,
+// run-length encode of the cell keys, widen, scan, gather -- fourteen launches and two host round trips per layer).  A point starts a (node,
+// frame) cell when its key differs from its predecessor's, a node when the key above the frame bits does; both flags ride one 64-bit scan
+// (low word: cells, high word: nodes -- counts stay below 2^32), and the heads then write their own entries: cell_key / cell_ptr (first point
+// of the cell), node_key / node_cell_ptr (first cell of the node) / node_ptr (first point of the node), the closing entries of the three offset
+// arrays and both counts straight into the mapped pinned words the host polls.  The arrays are the ones the encodes + scans produced.
+__global__ void heads_kernel(const unsigned long long* __restrict__ lkey_s, long long n, unsigned long long* __restrict__ flags) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const unsigned long long k = lkey_s[q];
+  const unsigned long long pk = q ? lkey_s[q - 1] : ~k;
+  flags[q] = (k != pk ? 1ull : 0ull) | ((k >> FRAME_BITS) != (pk >> FRAME_BITS) ? (1ull << 32) : 0ull);
+}
+__global__ void place_heads_kernel(const unsigned long long* __restrict__ lkey_s, const unsigned long long* __restrict__ flags, const unsigned long long* __restrict__ pos,
+                                   long long n, unsigned long long* __restrict__ cell_key, long long* __restrict__ cell_ptr, unsigned long long* __restrict__ node_key,
+                                   long long* __restrict__ node_cell_ptr, long long* __restrict__ node_ptr, unsigned long long* __restrict__ host_cells,
+                                   unsigned long long* __restrict__ host_nodes) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const unsigned long long f = flags[q], ps = pos[q], k = lkey_s[q];
+  const long long c = (long long)(ps & 0xffffffffull), j = (long long)(ps >> 32);
+  if (f & 1ull) { cell_key[c] = k; cell_ptr[c] = q; }
+  if (f >> 32) { node_key[j] = k >> FRAME_BITS; node_cell_ptr[j] = c; node_ptr[j] = q; }
+  if (q == n - 1) {
+    const long long nc = c + (long long)(f & 1ull), nn = j + (long long)(f >> 32);
+    cell_ptr[nc] = n; node_cell_ptr[nn] = nc; node_ptr[nn] = n;
+    host_cells[0] = (unsigned long long)nc; host_nodes[0] = (unsigned long long)nn;
+  }
+}
+
 // a count the host is waiting for, written where it polls (mapped pinned memory): dst[0] = src_a[0] (+ src_b[0])
 __global__ void post_count_kernel(const unsigned int* __restrict__ src_a, const unsigned int* __restrict__ src_b, unsigned long long* __restrict__ dst) {
   dst[0] = (unsigned long long)src_a[0] + (src_b ? (unsigned long long)src_b[0] : 0ull);
@@ -210,18 +229,16 @@ __global__ void post_count_kernel(const unsigned int* __restrict__ src_a, const 
 __global__ void post_count64_kernel(const long long* __restrict__ src, unsigned long long* __restrict__ dst) { dst[0] = (unsigned long long)src[0]; }
 __global__ void post_count32s_kernel(const int* __restrict__ src, unsigned long long* __restrict__ dst) { dst[0] = (unsigned long long)(unsigned int)src[0]; }
 
-__global__ void widen_kernel(const unsigned int* __restrict__ in, long long n, long long* __restrict__ out) {
-  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < n) out[q] = (long long)in[q];
-}
 
 enum NodeState : unsigned char { DEAD = 0, FACTOR = 1, SUBDIVIDE = 2 };
 
 // One thread per node of layer l: parent must have been subdivided; then loop_refine.hpp:358-405.
-__global__ void judge_kernel(const unsigned long long* __restrict__ node_key, const double* __restrict__ node_cluster, const unsigned int* __restrict__ n_frames,
+// (n_frames of node j = its number of (node, frame) cells = node_cell_ptr[j + 1] - node_cell_ptr[j]; flag[j] = 1 for an accepted node: what
+// flag_kernel wrote in its own launch before round 6)
+__global__ void judge_kernel(const unsigned long long* __restrict__ node_key, const double* __restrict__ node_cluster, const long long* __restrict__ node_cell_ptr,
                              long long n_nodes, int layer, VoxelizeParams p, const unsigned long long* __restrict__ parent_key,
                              const unsigned char* __restrict__ parent_state, long long n_parents, unsigned char* __restrict__ state,
-                             double* __restrict__ eigval, double* __restrict__ eigvec) {
+                             double* __restrict__ eigval, double* __restrict__ eigvec, unsigned int* __restrict__ flag) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_nodes) return;
   unsigned char st = DEAD;
@@ -246,7 +263,7 @@ __global__ void judge_kernel(const unsigned long long* __restrict__ node_key, co
     vxm::eig_sym3(Cm, lam, U);
     const bool is_plane = lam[0] < p.min_eigen_value && (lam[0] / lam[2]) < p.eigen_ratio[layer];
     if (is_plane) {
-      if ((int)n_frames[j] >= p.min_frames && !(lam[0] / lam[1] > p.factor_ratio_max)) st = FACTOR;
+      if ((int)(node_cell_ptr[j + 1] - node_cell_ptr[j]) >= p.min_frames && !(lam[0] / lam[1] > p.factor_ratio_max)) st = FACTOR;
     } else if (layer < p.max_layer) {
       st = SUBDIVIDE;
     }
@@ -255,22 +272,22 @@ __global__ void judge_kernel(const unsigned long long* __restrict__ node_key, co
       for (int row = 0; row < 3; row++) eigvec[9 * j + 3 * col + row] = U[3 * row + col];
   }
   state[j] = st;
+  flag[j] = st == FACTOR ? 1u : 0u;
 }
 
-__global__ void flag_kernel(const unsigned char* __restrict__ state, long long n, unsigned int* __restrict__ flag) {
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) flag[j] = state[j] == FACTOR ? 1u : 0u;
-}
 // accepted node j -> slot pos[j] of the AoS staging arrays [n][W][10], [n][3], [n][9], [n][10], ids
 __global__ void emit_kernel(const unsigned char* __restrict__ state, const unsigned int* __restrict__ pos, long long n_nodes, int W, int layer,
                             const unsigned long long* __restrict__ node_key, const long long* __restrict__ node_cell_ptr,
                             const unsigned long long* __restrict__ cell_key, const double* __restrict__ cell_cluster,
                             const double* __restrict__ node_cluster, const double* __restrict__ eigval, const double* __restrict__ eigvec,
-                            long long out_base, double* __restrict__ o_clusters, double* __restrict__ o_eigval, double* __restrict__ o_eigvec,
-                            double* __restrict__ o_merged, unsigned long long* __restrict__ o_id) {
+                            long long* d_total, long long capacity, double* __restrict__ o_clusters, double* __restrict__ o_eigval,
+                            double* __restrict__ o_eigvec, double* __restrict__ o_merged, unsigned long long* __restrict__ o_id) {
+  // d_total[0]: factor voxels emitted by the layers before this one (kept on the device since round 6: the host no longer waits for every
+  // layer's count -- advance_total_kernel adds this layer's behind this kernel); d_total[1] != 0: the caller's capacity was exceeded
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_nodes || state[j] != FACTOR) return;
-  const long long o = out_base + pos[j];
+  const long long o = d_total[0] + pos[j];
+  if (o >= capacity) { d_total[1] = 1; return; }
   double* oc = o_clusters + (size_t)o * W * 10;
   for (int k = 0; k < W * 10; k++) oc[k] = 0.0;
   for (long long cc = node_cell_ptr[j]; cc < node_cell_ptr[j + 1]; cc++) {
@@ -284,10 +301,13 @@ __global__ void emit_kernel(const unsigned char* __restrict__ state, const unsig
   o_id[o] = ((nk >> PATH_BITS) << 16) | ((nk & 511ull) << 7) | (unsigned long long)layer;
 }
 
+__global__ void advance_total_kernel(const unsigned int* __restrict__ pos, const unsigned int* __restrict__ flag, long long n_nodes, long long* __restrict__ d_total) {
+  d_total[0] += (long long)pos[n_nodes - 1] + (long long)flag[n_nodes - 1];
+}
 // compressed-row variant: entries of accepted node j at e_base + epos[j] ..
-__global__ void entry_count_kernel(const unsigned char* __restrict__ state, const unsigned int* __restrict__ ncell, long long n_nodes, long long* __restrict__ cnt) {
+__global__ void entry_count_kernel(const unsigned char* __restrict__ state, const long long* __restrict__ node_cell_ptr, long long n_nodes, long long* __restrict__ cnt) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j <= n_nodes) cnt[j] = (j < n_nodes && state[j] == FACTOR) ? (long long)ncell[j] : 0ll;
+  if (j <= n_nodes) cnt[j] = (j < n_nodes && state[j] == FACTOR) ? node_cell_ptr[j + 1] - node_cell_ptr[j] : 0ll;
 }
 __global__ void emit_csr_kernel(const unsigned char* __restrict__ state, const unsigned int* __restrict__ pos, const long long* __restrict__ epos, long long n_nodes,
                                 int layer, const unsigned long long* __restrict__ node_key, const long long* __restrict__ node_cell_ptr,
@@ -336,9 +356,17 @@ static K1Prof g_k1prof;
 // development: VXBA_VOXELIZE_WAITS=1 prints, at exit, how long the voxeliser's host threads spent waiting for the counts
 struct WaitProf {
   bool on = false;
-  std::atomic<long long> us{0}, n{0}, slow{0}, max_us{0};
+  std::atomic<long long> us{0}, n{0}, slow{0}, max_us{0}, alloc_us{0}, allocs{0}, alloc_max_us{0}, call_us{0}, calls{0};
   WaitProf() { const char* e = getenv("VXBA_VOXELIZE_WAITS"); on = e && e[0] == '1'; }
-  ~WaitProf() { if (on) fprintf(stderr, "[vxba voxelize] %lld waits, %.1f ms in them, %lld over 1 ms, longest %lld us\n", n.load(), us.load() / 1e3, slow.load(), max_us.load()); }
+  ~WaitProf() {
+    if (on) fprintf(stderr, "[vxba voxelize] %lld calls %.1f ms | %lld waits, %.1f ms in them, %lld over 1 ms, longest %lld us | %lld (re)allocations, %.1f ms in them, longest %lld us\n",
+                    calls.load(), call_us.load() / 1e3, n.load(), us.load() / 1e3, slow.load(), max_us.load(), allocs.load(), alloc_us.load() / 1e3, alloc_max_us.load());
+  }
+  void note_alloc(long long t) { alloc_us.fetch_add(t); allocs.fetch_add(1); long long mx = alloc_max_us.load(); while (t > mx && !alloc_max_us.compare_exchange_weak(mx, t)) {} }
+};
+struct ScopeUs {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  long long us() const { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); }
 };
 static WaitProf g_wait_prof;
 struct DevBuf {
@@ -348,26 +376,37 @@ struct DevBuf {
   bool own = false;
   unsigned long long* host = nullptr;     // pinned read-back words (the slot's, or this call's own)
   ~DevBuf() {
+    ScopeUs tm;
     if (own && base) hipFree(base);
     if (own && host) hipHostFree(host);
+    if (own && g_wait_prof.on) g_wait_prof.note_alloc(tm.us());
     if (slot) slot->mtx.unlock();
   }
   hipError_t reserve(size_t bytes) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || bytes > ((size_t)2 << 30)) {   // no cache slot / too big to keep: private to this call
+    // Round 6: the limit above which a call allocates privately went from 2 GiB to 64: the top level of a hierarchical pass asks for 6.2 GB
+    // four times per pass, and one hipMalloc / hipFree pair of that size in ~30 takes SECONDS on the gpurun boxes (3.55 s measured, against
+    // 0.5 ms for the others: VXBA_VOXELIZE_WAITS=1) -- most of the "slow box" passes of rounds 5-6.  A slot that has seen such a call keeps
+    // its 7.8 GB; 288 GB of HBM can afford it.
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || bytes > ((size_t)64 << 30)) {   // no cache slot / too big to keep: private to this call
       own = true; cap = bytes;
+      ScopeUs tm;
       hipError_t e = hipHostMalloc((void**)&host, READBACK_WORDS * sizeof(unsigned long long), hipHostMallocDefault);
       if (e != hipSuccess) return e;
-      return hipMalloc((void**)&base, bytes);
+      e = hipMalloc((void**)&base, bytes);
+      if (g_wait_prof.on) g_wait_prof.note_alloc(tm.us());
+      return e;
     }
     for (int k = 0; k < ARENA_SLOTS && !slot; k++)
       if (g_arena[dev][k].mtx.try_lock()) slot = &g_arena[dev][k];
     if (!slot) { slot = &g_arena[dev][0]; slot->mtx.lock(); }
     if (bytes > slot->cap) {
+      ScopeUs tm;
       if (slot->base) { hipDeviceSynchronize(); hipFree(slot->base); }
       slot->base = nullptr; slot->cap = 0;
       const size_t want = bytes + bytes / 4;
       hipError_t e = hipMalloc((void**)&slot->base, want);
+      if (g_wait_prof.on) g_wait_prof.note_alloc(tm.us());
       if (e != hipSuccess) return e;
       slot->cap = want;
     }
@@ -389,6 +428,7 @@ struct DevBuf {
   // the mapped pinned word itself; a hierarchical-BA pass made 1 870 four-byte copies of ~4 us each.  (hipHostMalloc'd memory is mapped into
   // the device's address space at the same address; the store is visible to the host when the stream has drained, which is what wait() polls.)
   unsigned int* word_u32(int k) { host[k] = 0; return reinterpret_cast<unsigned int*>(host + k); }
+  unsigned long long* word_u64(int k) { host[k] = 0; return host + k; }
   hipError_t post_sum_u32(int k, const unsigned int* a, const unsigned int* b, hipStream_t s) {
     host[k] = 0;
     post_count_kernel<<<1, 1, 0, s>>>(a, b, host + k);
@@ -440,25 +480,25 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
   static const char* range_msg = "voxelize: a point lies outside the +-32768-voxel range of the 16-bit voxel coordinates";
   static const char* cap_msg = "voxelize: more factor voxels than the caller's capacity";
   DevBuf B;
+  struct CallTimer { ScopeUs tm; ~CallTimer() { if (g_wait_prof.on) { g_wait_prof.call_us.fetch_add(tm.us()); g_wait_prof.calls.fetch_add(1); } } } call_timer;
   long long n = n_points;
   const bool sharded = p.shard_count > 1;
   if (sharded && (p.shard_index < 0 || p.shard_index >= p.shard_count)) { *err_out = "voxelize: shard_index outside 0 .. shard_count-1"; return -1; }
   // rocPRIM temporary storage: query the largest need first (size queries do not touch the pointers)
   size_t tb = 0;
   {
-    size_t tb_sort = 0, tb_rle = 0, tb_scan = 0, tb_scan32 = 0;
+    size_t tb_sort = 0, tb_scan = 0, tb_scan32 = 0;
     unsigned long long* k0 = nullptr; unsigned int* v0 = nullptr; long long* l0 = nullptr;
     VV(rocprim::radix_sort_pairs(nullptr, tb_sort, k0, k0, v0, v0, (size_t)n, 0, 64, s));
-    VV(rocprim::run_length_encode(nullptr, tb_rle, k0, (size_t)n, k0, v0, v0, s));
     VV(rocprim::exclusive_scan(nullptr, tb_scan, l0, l0, 0ll, (size_t)n + 1, rocprim::plus<long long>(), s));
     VV(rocprim::exclusive_scan(nullptr, tb_scan32, v0, v0, 0u, (size_t)n, rocprim::plus<unsigned int>(), s));
+    { size_t tb_scan64 = 0; VV(rocprim::exclusive_scan(nullptr, tb_scan64, k0, k0, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), s)); if (tb_scan64 > tb_scan) tb_scan = tb_scan64; }
     tb = tb_sort;
-    if (tb_rle > tb) tb = tb_rle;
     if (tb_scan > tb) tb = tb_scan;
     if (tb_scan32 > tb) tb = tb_scan32;
   }
-  // worst case (every point its own cell): < 0.5 KB of scratch per point
-  VV(B.reserve((size_t)(n + 64) * (sharded ? 576 : 512) + tb + (size_t)(1 << 20)));
+  // worst case (every point its own cell): ~0.5 KB of scratch per point
+  VV(B.reserve((size_t)(n + 64) * (sharded ? 608 : 544) + tb + (size_t)(1 << 20)));   // (+32 B per point in round 6: a layer's node keys are sized by the points, the node count arrives with them)
   double *d_world, *d_loc_s, *d_wld_s;
   unsigned long long *d_key, *d_lkey, *d_lkey_s;
   unsigned int *d_idx, *d_idx_s;
@@ -471,11 +511,11 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
 
   // per-layer scratch (sized for the worst case: every point its own cell)
   unsigned long long *d_cell_key, *d_cell_node, *d_node_key[4] = {nullptr, nullptr, nullptr, nullptr};
-  unsigned int *d_cell_cnt, *d_node_ncell, *d_runs, *d_flag, *d_pos;
+  unsigned int *d_flag, *d_pos;
   long long *d_cell_ptr, *d_node_cell_ptr, *d_node_ptr, *d_tmp64;
   double *d_cell_cl, *d_node_cl, *d_eigval, *d_eigvec;
   unsigned char* d_state[4] = {nullptr, nullptr, nullptr, nullptr};
-  VV(B.alloc(&d_cell_key, n)); VV(B.alloc(&d_cell_node, n)); VV(B.alloc(&d_cell_cnt, n)); VV(B.alloc(&d_node_ncell, n)); VV(B.alloc(&d_runs, 1));
+  VV(B.alloc(&d_cell_key, n)); VV(B.alloc(&d_cell_node, n));   // (d_cell_node: the scanned head flags of a layer -- cell position in the low word, node position in the high one)
   VV(B.alloc(&d_flag, n)); VV(B.alloc(&d_pos, n));
   VV(B.alloc(&d_cell_ptr, n + 1)); VV(B.alloc(&d_node_cell_ptr, n + 1)); VV(B.alloc(&d_node_ptr, n + 1)); VV(B.alloc(&d_tmp64, n + 1));
   VV(B.alloc(&d_cell_cl, 10 * n)); VV(B.alloc(&d_node_cl, 10 * n)); VV(B.alloc(&d_eigval, 3 * n)); VV(B.alloc(&d_eigvec, 9 * n));
@@ -509,6 +549,9 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
   constexpr long long PARTITION_MAX_POINTS = 1ll << 20;   // beyond this rocPRIM sorts with onesweep, and one node can be a workgroup's millisecond
   long long total = 0, total_entries = 0;
   long long* d_epos = nullptr;
+  long long* d_total = nullptr;   // [emitted so far | capacity exceeded]: the dense-row path's running total (see emit_kernel)
+  VV(B.alloc(&d_total, 2));
+  VV(hipMemsetAsync(d_total, 0, 2 * sizeof(long long), s));
   if (out->d_row_ptr) {
     VV(B.alloc(&d_epos, n + 1));
     VV(hipMemsetAsync(out->d_row_ptr, 0, sizeof(long long), s));
@@ -524,26 +567,21 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
       layer_key_kernel<<<grid_for(n), 256, 0, s>>>(d_key, n, layer, d_lkey, d_idx);
       VV(rocprim::radix_sort_pairs(d_temp, t, d_lkey, d_lkey_s, d_idx, d_idx_s, (size_t)n, 0, 64, s));
     }
-    // (node, frame) cells
+    // (node, frame) cells and nodes: head flags, one scan, the heads place themselves (see heads_kernel)
+    heads_kernel<<<grid_for(n), 256, 0, s>>>(d_lkey_s, n, (unsigned long long*)d_tmp64);
     t = tb;
-    VV(rocprim::run_length_encode(d_temp, t, d_lkey_s, (size_t)n, d_cell_key, d_cell_cnt, B.word_u32(3), s));
+    VV(rocprim::exclusive_scan(d_temp, t, (unsigned long long*)d_tmp64, d_cell_node, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), s));
+    VV(B.alloc(&d_node_key[layer], n));
+    {
+      unsigned long long* hc = B.word_u64(3);
+      unsigned long long* hn = B.word_u64(4);
+      place_heads_kernel<<<grid_for(n), 256, 0, s>>>(d_lkey_s, (const unsigned long long*)d_tmp64, d_cell_node, n, d_cell_key, d_cell_ptr, d_node_key[layer], d_node_cell_ptr,
+                                                     d_node_ptr, hc, hn);
+    }
     VV(B.wait(s));
     const unsigned int n_cells = B.u32(3);
-    widen_kernel<<<grid_for(n_cells), 256, 0, s>>>(d_cell_cnt, n_cells, d_tmp64);
-    t = tb;
-    VV(rocprim::exclusive_scan(d_temp, t, d_tmp64, d_cell_ptr, 0ll, (size_t)n_cells + 1, rocprim::plus<long long>(), s));
-    // nodes = runs of cells with the same key above the frame bits
-    shift_key_kernel<<<grid_for(n_cells), 256, 0, s>>>(d_cell_key, n_cells, d_cell_node);
-    VV(B.alloc(&d_node_key[layer], n_cells));
-    t = tb;
-    VV(rocprim::run_length_encode(d_temp, t, d_cell_node, (size_t)n_cells, d_node_key[layer], d_node_ncell, B.word_u32(4), s));
-    VV(B.wait(s));
     const unsigned int n_nodes = B.u32(4);
     n_nodes_l[layer] = n_nodes;
-    widen_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_node_ncell, n_nodes, d_tmp64);
-    t = tb;
-    VV(rocprim::exclusive_scan(d_temp, t, d_tmp64, d_node_cell_ptr, 0ll, (size_t)n_nodes + 1, rocprim::plus<long long>(), s));
-    node_ptr_kernel<<<grid_for(n_nodes + 1), 256, 0, s>>>(d_cell_ptr, d_node_cell_ptr, n_nodes, d_node_ptr);
     // clusters: body-frame per cell, world per node -- sequential sums in upstream's push order
     gather3_kernel<<<grid_for(n), 256, 0, s>>>(d_xyz_local, d_idx_s, n, d_loc_s);
     gather3_kernel<<<grid_for(n), 256, 0, s>>>(d_world, d_idx_s, n, d_wld_s);
@@ -569,11 +607,19 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
     }
     // verdicts
     VV(B.alloc(&d_state[layer], n_nodes));
-    judge_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_node_key[layer], d_node_cl, d_node_ncell, n_nodes, layer, p, layer ? d_node_key[layer - 1] : nullptr,
-                                                  layer ? d_state[layer - 1] : nullptr, layer ? n_nodes_l[layer - 1] : 0, d_state[layer], d_eigval, d_eigvec);
-    flag_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_state[layer], n_nodes, d_flag);
+    judge_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_node_key[layer], d_node_cl, d_node_cell_ptr, n_nodes, layer, p, layer ? d_node_key[layer - 1] : nullptr,
+                                                  layer ? d_state[layer - 1] : nullptr, layer ? n_nodes_l[layer - 1] : 0, d_state[layer], d_eigval, d_eigvec, d_flag);
     t = tb;
     VV(rocprim::exclusive_scan(d_temp, t, d_flag, d_pos, 0u, (size_t)n_nodes, rocprim::plus<unsigned int>(), s));
+    if (!out->d_row_ptr) {
+      // dense rows: no host round trip for this layer's count -- the running total stays on the device, the emit kernel guards the capacity
+      if (n_nodes > 0) {
+        emit_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_state[layer], d_pos, n_nodes, W, layer, d_node_key[layer], d_node_cell_ptr, d_cell_key, d_cell_cl, d_node_cl,
+                                                     d_eigval, d_eigvec, d_total, out->capacity, out->d_clusters, out->d_eigval, out->d_eigvec, out->d_merged, out->d_node_id);
+        advance_total_kernel<<<1, 1, 0, s>>>(d_pos, d_flag, n_nodes, d_total);
+      }
+      continue;
+    }
     long long n_acc = 0;
     if (n_nodes > 0) {
       VV(B.post_sum_u32(5, d_pos + n_nodes - 1, d_flag + n_nodes - 1, s));
@@ -581,8 +627,8 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
       n_acc = B.i64(5);
     }
     if (total + n_acc > out->capacity) { *err_out = cap_msg; return -1; }
-    if (n_acc > 0 && out->d_row_ptr) {
-      entry_count_kernel<<<grid_for((long long)n_nodes + 1), 256, 0, s>>>(d_state[layer], d_node_ncell, n_nodes, d_tmp64);
+    if (n_acc > 0) {
+      entry_count_kernel<<<grid_for((long long)n_nodes + 1), 256, 0, s>>>(d_state[layer], d_node_cell_ptr, n_nodes, d_tmp64);
       t = tb;
       VV(rocprim::exclusive_scan(d_temp, t, d_tmp64, d_epos, 0ll, (size_t)n_nodes + 1, rocprim::plus<long long>(), s));
       VV(B.post_i64(7, d_epos + n_nodes, s));
@@ -593,13 +639,19 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
                                                        d_node_cl, d_eigval, d_eigvec, total, total_entries, out->d_clusters, out->d_eframe, out->d_row_ptr,
                                                        out->d_eigval, out->d_eigvec, out->d_merged, out->d_node_id);
       total_entries += n_ent;
-    } else if (n_acc > 0)
-      emit_kernel<<<grid_for(n_nodes), 256, 0, s>>>(d_state[layer], d_pos, n_nodes, W, layer, d_node_key[layer], d_node_cell_ptr, d_cell_key, d_cell_cl, d_node_cl,
-                                                   d_eigval, d_eigvec, total, out->d_clusters, out->d_eigval, out->d_eigvec, out->d_merged, out->d_node_id);
+    }
     total += n_acc;
   }
   out->n_entries = total_entries;
-  VV(B.wait(s));
+  if (!out->d_row_ptr && n > 0) {
+    VV(B.post_i64(5, d_total, s));
+    VV(B.post_i64(6, d_total + 1, s));
+    VV(B.wait(s));
+    if (B.i64(6)) { *err_out = cap_msg; return -1; }
+    total = B.i64(5);
+  } else {
+    VV(B.wait(s));
+  }
   VV(hipGetLastError());
   return total;
 }
