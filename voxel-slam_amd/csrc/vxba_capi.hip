@@ -649,8 +649,12 @@ int vxba_set_option(vxba_factor* f, int option, int value) {
       if (value != 0) return fail(f, VXBA_ERR_UNSUPPORTED, "vxba_set_option: the device-resident 15W loop was removed in round 4 (4x slower than the default shell); only 0 is accepted");
       break;
     case VXBA_OPT_FUSED_SOLVE: case VXBA_OPT_SPEC_COLLECTIVE: case VXBA_OPT_WIDE_DEVICE_SOLVE:
-    case VXBA_OPT_LI_STRUCTURED_SOLVE: case VXBA_OPT_LI_QUEUED_SWEEPS: case VXBA_OPT_LI_DEVICE_POSE_SOLVE: case VXBA_OPT_FUSED_SWEEPS:
+    case VXBA_OPT_LI_STRUCTURED_SOLVE: case VXBA_OPT_LI_QUEUED_SWEEPS: case VXBA_OPT_LI_DEVICE_POSE_SOLVE:
       if (value != 0 && value != 1) return fail(f, VXBA_ERR_ARG, "vxba_set_option: this option takes 0 or 1");
+      break;
+    case VXBA_OPT_FUSED_SWEEPS:
+      if (value < 0 || value > 2) return fail(f, VXBA_ERR_ARG, "vxba_set_option: VXBA_OPT_FUSED_SWEEPS takes 0, 1 (fused unless the last call was reject-heavy) or 2 (always)");
+      f->reject_heavy = false;   // a fresh setting starts without history
       break;
     case VXBA_OPT_DEBUG_SOLVE_TIMEOUT:
       if (value < 0 || value > 2) return fail(f, VXBA_ERR_ARG, "vxba_set_option: the test hook takes 0, 1 or 2");
@@ -666,6 +670,7 @@ int vxba_set_option(vxba_factor* f, int option, int value) {
 int vxba_get_option(const vxba_factor* f, int option, int* value) {
   if (f && value && option == VXBA_STAT_FUSED_FALLBACKS) { *value = f->fused_fallbacks; return VXBA_OK; }
   if (f && value && option == VXBA_STAT_LI_DEVICE_FALLBACKS) { *value = f->li_dev_fallbacks; return VXBA_OK; }
+  if (f && value && option == VXBA_STAT_REJECT_HEAVY) { *value = f->reject_heavy ? 1 : 0; return VXBA_OK; }
   if (f && value && option == VXBA_STAT_LI_LAST_CALL_US) { *value = (int)(f->li_last_call_us + 0.5); return VXBA_OK; }
   if (!f || !value || option < 0 || option >= VXBA_OPT_COUNT) return VXBA_ERR_ARG;
   *value = f->opt[option];

@@ -372,6 +372,8 @@ int sweep_residual_device(vxba_factor* f, const double* Rp, vxk::LMState* lm, in
 // Replaces [solve + residual sweep] | Hessian sweep | reduction of two consecutive iterations wherever a Hessian sweep follows a residual sweep
 // inside one solve; needs the in-launch solve, no collective, a narrow window and f64 cluster rows.
 bool fused_sweeps(const vxba_factor* f) {
+  // 1 (default): fused unless the factor's last call was reject-heavy; 2: always; 0: never
+  if (f->opt[VXBA_OPT_FUSED_SWEEPS] == 1 && f->reject_heavy) return false;
   return f->opt[VXBA_OPT_FUSED_SWEEPS] != 0 && fused_solve(f) && !has_collective(f) && !is_wide(f) && f->V > 0 && f->precision != VXBA_PRECISION_MIXED_F32_CLUSTERS &&
          vxk::k23_supported(view(f));
 }

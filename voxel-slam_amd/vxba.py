@@ -449,7 +449,7 @@ class LidarFactor:
         return st.value
 
     OPTIONS = {"fused_solve": 0, "spec_collective": 1, "wide_device_solve": 2, "k2_voxels_per_block": 4,
-               "debug_solve_timeout": 5, "li_structured_solve": 6, "li_queued_sweeps": 7, "li_device_pose_solve": 8, "fused_sweeps": 9, "stat_fused_fallbacks": 100, "stat_li_last_call_us": 101, "stat_li_device_fallbacks": 102}
+               "debug_solve_timeout": 5, "li_structured_solve": 6, "li_queued_sweeps": 7, "li_device_pose_solve": 8, "fused_sweeps": 9, "stat_fused_fallbacks": 100, "stat_li_last_call_us": 101, "stat_li_device_fallbacks": 102, "stat_reject_heavy": 103}
 
     def set_option(self, name: str, value: int):
         """Execution options of include/vxba.h (VXBA_OPT_*): fused_solve, spec_collective, wide_device_solve, k2_voxels_per_block."""
