@@ -385,8 +385,8 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
                                        * the residual sweep at the trial poses and the Hessian sweep that linearises at the same poses one iteration later are
                                        * ONE launch behind the in-launch solve (Lidar_BA_Optimizer::damping_iter, voxel_map.hpp:386-439: only_residual, then
                                        * divide_thread of the next iteration), and the reduction behind it takes the accept / reject decision; a rejected step
-                                       * then costs a Hessian sweep the reference does not run -- so a factor whose LAST call rejected more than a quarter of its steps runs its next
-                                       * call as the three-launch iteration (the speculation pays when steps are accepted; results do not depend on the form).
+                                       * then costs a Hessian sweep the reference does not run -- so a factor whose LAST call rejected more than a third of its steps runs its next
+                                       * call as the three-launch iteration (break-even by the round-6 kernel times: 18 % rejected steps at 50k voxels, 32 % at 400k; results do not depend on the form).
                                        * 2: fused whatever the history.  0: the three-launch iteration of rounds 1-5.  Needs
                                        * VXBA_OPT_FUSED_SOLVE = 1.  (The number belonged to a round-4 experiment that was removed in round 5.) */
 #define VXBA_OPT_COUNT 10
@@ -396,7 +396,7 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
                                          * measured inside the library (what a C caller sees; the Python mirror adds its array handling) */
 #define VXBA_STAT_LI_DEVICE_FALLBACKS 102 /* read-only (vxba_get_option): times vxba_li_damping_iter found the in-launch pose step non-finite / undelivered when its
                                          * launch had ended, discarded that launch's residual sweep and took the host solve (the reference's pivoted LDL^T) instead */
-#define VXBA_STAT_REJECT_HEAVY 103     /* read-only (vxba_get_option): 1 when the factor's last device-resident LM call rejected more than a quarter of its steps
+#define VXBA_STAT_REJECT_HEAVY 103     /* read-only (vxba_get_option): 1 when the factor's last device-resident LM call rejected more than a third of its steps
                                        * (VXBA_OPT_FUSED_SWEEPS = 1 then runs the next call as the three-launch iteration) */
 int vxba_set_option(vxba_factor* f, int option, int value);
 int vxba_get_option(const vxba_factor* f, int option, int* value);

@@ -149,7 +149,7 @@ static int damping_iter_impl(vxba_factor* f, double* Rp, int max_iter, double* h
     return fail(f, VXBA_ERR_STATE, "damping_iter: a residual-sweep workgroup timed out waiting for the in-launch solve");
   }
   const vxk::LMCtl& st = f->h_lm->ctl[c];
-  f->reject_heavy = 4 * st.n_reject > st.n_accept + st.n_reject;
+  f->reject_heavy = 3 * st.n_reject > st.n_accept + st.n_reject;   // more than a third: see VXBA_OPT_FUSED_SWEEPS
   std::memcpy(Rp, st.x, sizeof(double) * 12 * W);
   if (hess_out) std::memcpy(hess_out, f->h_lm->hess_out, sizeof(double) * n * n);
   if (resis_out) { resis_out[0] = st.resis[0]; resis_out[1] = st.resis[1]; }
@@ -270,7 +270,7 @@ static int lm_steps_impl(vxba_factor* f, const double* Rp_init, int n_steps, int
   VX_HIP(f, stream_wait_spin(f->stream));   // by polling, as in damping_iter: waking up from hipStreamSynchronize costs 15-25 us -- 1.5 % of a 20-step call
   if (f->h_lm->error) return fail(f, VXBA_ERR_STATE, "lm_steps: a residual-sweep workgroup timed out waiting for the in-launch solve");
   const vxk::LMCtl& st = f->h_lm->ctl[c];
-  f->reject_heavy = 4 * st.n_reject > st.n_accept + st.n_reject;
+  f->reject_heavy = 3 * st.n_reject > st.n_accept + st.n_reject;   // more than a third: see VXBA_OPT_FUSED_SWEEPS
   if (Rp_out) std::memcpy(Rp_out, st.x, sizeof(double) * 12 * W);
   if (last_resis) { last_resis[0] = st.residual1; last_resis[1] = st.residual2; }
   if (stats_out) { stats_out[0] = st.iter; stats_out[1] = st.n_accept; stats_out[2] = st.n_reject; }

@@ -115,7 +115,7 @@ struct vxba_factor {
   hipEvent_t li_ev = nullptr;    // marks the end of the residual sweep when a speculative Hessian sweep is queued behind it (LI host shells)
   bool solve_timed_out = false;  // the last damping_iter failed because voxel workgroups gave up waiting for the in-launch solve
   int fused_fallbacks = 0;       // times a call was transparently re-run with the solve as its own launch
-  bool reject_heavy = false;     // the last device-resident LM call rejected more than a quarter of its steps: the next one runs the three-launch
+  bool reject_heavy = false;     // the last device-resident LM call rejected more than a third of its steps: the next one runs the three-launch
                                  // iteration (a fused launch speculates that its step is accepted and pays a whole Hessian half for a rejected one)
   int li_dev_fallbacks = 0;      // times the LI shell discarded a non-finite / undelivered in-launch pose step and solved on the host (VXBA_STAT_LI_DEVICE_FALLBACKS)
   vxba_allreduce_fn allreduce = nullptr;
