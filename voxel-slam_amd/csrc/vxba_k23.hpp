@@ -10,8 +10,8 @@
 // Here every sweep workgroup
 //   (1) requests the cluster rows of ITS voxels (one lane per voxel: k2_residual_kernel's mapping) while workgroup 0 runs the damped solve,
 //   (2) waits for the trial poses (one poller wave per workgroup, as before),
-//   (3) runs the residual half on those voxels -- transform, covariance, warm-started eigen-decomposition, bit for bit the arithmetic of
-//       k2_residual_kernel -- writes the (lambda, U, merged, aux) cache planes with plain stores (they stay in the XCD's L2) and adds
+//   (3) runs the residual half on those voxels -- transform, covariance, warm-started eigen-decomposition: k2_residual_kernel's arithmetic
+//       (round-off apart: the lane-pair sum, and the covariance / scales through one reciprocal, k23_cov) -- writes the (lambda, U, merged, aux) cache planes with plain stores (they stay in the XCD's L2) and adds
 //       sum coe lambda_0 into one partial per workgroup,
 //   (4) passes ONE workgroup barrier (stores acknowledged first) and runs the Hessian half over the same voxels: k3_sweep_body<FUSED>,
 //       whose first batches come out of the caches and whose plane parameters are the lines this workgroup has just written.
@@ -79,20 +79,42 @@ __device__ __forceinline__ void k23_st64(__amdgpu_buffer_rsrc_t rs, unsigned a8,
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), rs, (int)a8, (int)soff, VXBA_K23_STORE_AUX);
 }
 
-// The residual half of one voxel: k2_residual_kernel's arithmetic, statement for statement (same frame order, same unfused / fused
-// operations inside vxm::*), so that a window evaluates to the same cache bits whichever launch ran it.  Returns coe * lambda_0.
+// The residual half of one voxel, one lane per voxel: k2_residual_kernel's arithmetic, statement for statement (same frame order, same
+// unfused / fused operations inside vxm::*).  Returns coe * lambda_0.
 // Instrumented build (DBG), stamps of wave gw: 15 transform done, 18 eigen-decomposition done, 21 cache stores issued.
 // hook(): called between the eigen-decomposition and the cache stores (the Hessian half's first cluster rows are requested there).
 struct K23NoHook { __device__ __forceinline__ void operator()() const {} };
+// Covariance of the merged cluster and the derived scales with ONE reciprocal and two reciprocal square roots (estimate + Newton steps,
+// vxm::fast_rcp / fast_rsqrt: full fp64 accuracy, 1 ulp from the IEEE quotients) where vxm::cluster_cov / gap_scales spend nine IEEE divisions, two
+// more and two square roots -- ~140 of the residual half's ~1 700 fp64 instructions per wave, and the half is bound by their issue.
+// The lane-pair form only (the one-lane form has no registers to spare for it: 660 spilled registers when tried); the stand-alone sweeps
+// keep the reference's expression (voxel_map.hpp:264-267); the two forms of the loop agree to round-off, as they already do through the
+// lane-pair sum.
+__device__ __forceinline__ void k23_cov(const double P[6], const double v[3], double N, double C[6], double& invN) {
+  invN = vxm::fast_rcp(N);
+  const double vb[3] = {v[0] * invN, v[1] * invN, v[2] * invN};
+  C[0] = P[0] * invN - vb[0] * vb[0];
+  C[1] = P[1] * invN - vb[0] * vb[1];
+  C[2] = P[2] * invN - vb[0] * vb[2];
+  C[3] = P[3] * invN - vb[1] * vb[1];
+  C[4] = P[4] * invN - vb[1] * vb[2];
+  C[5] = P[5] * invN - vb[2] * vb[2];
+}
+__device__ __forceinline__ void k23_gap_scales(const double lam[3], double& s1, double& s2) {   // sqrt(2 / gap) = 1 / sqrt(gap / 2)
+  s1 = vxm::fast_rsqrt(0.5 * (lam[1] - lam[0]));
+  s2 = vxm::fast_rsqrt(0.5 * (lam[2] - lam[0]));
+}
 // The record of a voxel as k3_unstage_params reads it (k3_param_plane): u planes 0..8 | s1 s2 | merged first moment | 1/N | sqrt(coe) | lambda_0 | coe
-__device__ __forceinline__ void k23_record(double v[18], const double lam[3], const double U[9], const double Sv[3], double SN, double coe) {
+template <bool FAST>
+__device__ __forceinline__ void k23_record(double v[18], const double lam[3], const double U[9], const double Sv[3], double invN, double coe) {
 #pragma unroll
   for (int col = 0; col < 3; col++)
 #pragma unroll
     for (int row = 0; row < 3; row++) v[3 * col + row] = U[3 * row + col];
-  vxm::gap_scales(lam, v[9], v[10]);
+  if (FAST) k23_gap_scales(lam, v[9], v[10]);
+  else vxm::gap_scales(lam, v[9], v[10]);
   v[11] = Sv[0]; v[12] = Sv[1]; v[13] = Sv[2];
-  v[14] = 1.0 / SN; v[15] = sqrt(coe); v[16] = lam[0]; v[17] = coe;
+  v[14] = invN; v[15] = sqrt(coe); v[16] = lam[0]; v[17] = coe;
 }
 // rec (LDS, nullable per lane): where the Hessian half's first phase A expects this voxel's record
 template <int W, bool DBG = false, class Hook = K23NoHook>
@@ -140,7 +162,7 @@ __device__ __forceinline__ double k23_finish(__amdgpu_buffer_rsrc_t rs, unsigned
   hook();
   if (rec) {
     double v[18];
-    k23_record(v, lam, U, Sv, SN, coe);
+    k23_record<false>(v, lam, U, Sv, 1.0 / SN, coe);
 #pragma unroll
     for (int k = 0; k < 9; k++) *reinterpret_cast<v2d*>(rec + 2 * k) = (v2d){v[2 * k], v[2 * k + 1]};
   }
@@ -236,13 +258,14 @@ __device__ __forceinline__ double k23_pair_finish(__amdgpu_buffer_rsrc_t rs, uns
 #pragma unroll
   for (int k = 0; k < 3; k++) Sv[k] += k23_partner(Sv[k]);
   SN += k23_partner(SN);
-  vxm::cluster_cov(SP, Sv, SN, C);
+  double invN;
+  k23_cov(SP, Sv, SN, C, invN);
   if (DBG) { asm volatile("" :: "v"(C[0]), "v"(C[3]), "v"(C[5])); dbg_stamp(true, gw, 15); }
   vxm::eig_sym3_warm(C, r.Up, lam, U);
   if (DBG) { asm volatile("" :: "v"(lam[0]), "v"(U[0]), "v"(U[8])); dbg_stamp(true, gw, 18); }
   const double coe = r.coe;
   double v[18];
-  k23_record(v, lam, U, Sv, SN, coe);
+  k23_record<true>(v, lam, U, Sv, invN, coe);
   if (rec) {   // the lower lane writes the first nine doubles of the record, the upper lane the other nine
 #pragma unroll
     for (int k = 0; k < 9; k++) rec[(upper ? 9 : 0) + k] = upper ? v[9 + k] : v[k];
