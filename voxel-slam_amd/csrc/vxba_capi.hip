@@ -56,7 +56,7 @@ int vxba_destroy(vxba_factor* f) {
   if (f->h_liout) (void)hipHostFree(f->h_liout);
   if (f->li_ev2) (void)hipEventDestroy(f->li_ev2);
   if (f->li_ev3) (void)hipEventDestroy(f->li_ev3);
-  vxw::free_index(f->wide);
+  vxw::destroy_index(f->wide);
   vxw::store_free(f->wstore);
   vxw::wide_solver_free(f->wide_solver);
   hipFree(f->own_packed); hipFree(f->d_count); hipFree(f->d_poses);
@@ -94,7 +94,7 @@ int vxba_set_win_size(vxba_factor* f, int win_size) {
   if (f->cl32) { VX_HIP(f, hipFree(f->cl32)); f->cl32 = nullptr; f->cl32_vs = 0; f->cl32_built = 0; }
   f->VS = 0;
   vxw::store_free(f->wstore);
-  vxw::free_index(f->wide);
+  vxw::destroy_index(f->wide);
   f->W = win_size;
   return ensure_exchange(f);
 }

@@ -72,11 +72,14 @@ struct WideIndex {
   int* key_task_ptr = nullptr;           // [nkeys + 1] tasks of a key
   double* task_partial = nullptr;        // [ntasks][WIDE_TASK_OUT] work space of the sweep
   double* vrec = nullptr;                // [V][WIDE_VREC] packed per-voxel records, refreshed by every sweep
+  struct WidePool* pool = nullptr;       // the index's own device blocks, kept between builds (vxba_wide.hip: a rebuild allocates ~22 arrays and released as many;
+                                         // with hipMalloc / hipFree at 0.3-0.6 ms apiece that was half of a hierarchical pass's top level)
 };
 int build_index(const WideView& wv, int V, WideIndex& wi, hipStream_t s, const char** err);
 size_t index_bytes(const WideIndex& wi, int W);
 size_t store_bytes(const WideStore& st);   // 0, or -1 with *err set
-void free_index(WideIndex& wi);
+void free_index(WideIndex& wi);      // the arrays go back to the index's pool (a rebuild follows)
+void destroy_index(WideIndex& wi);   // ... and the pool itself is released (the factor is destroyed / changes its window size)
 
 // Hessian sweep (LidarFactor::acc_evaluate2, voxel_map.hpp:132-241) for any W <= WIDE_MAXW, pair-major: (A) one lane per observed
 // (voxel, frame) entry computes its rank-3 rows and gradient / block-diagonal terms, (B) one wave per 6x6 Hessian block sums its

@@ -312,10 +312,59 @@ int launch_k2_wide(const WideView& wv, const double* d_poses, int head, int end,
   return nblocks;
 }
 
+// The index's block pool.  Blocks are reused only by THIS index, i.e. behind each other on the factor's one stream: a block released while a
+// sweep that reads it is still queued is next written by a kernel of the following build, queued behind that sweep (hipFree's implicit
+// device-wide wait is not needed for that, and it stalled the pass's other streams).  Best fit among the free blocks that are not more than
+// four times too large; a miss allocates with a quarter of slack, so that the slightly larger index of the next re-voxelisation round fits.
+struct WidePool {
+  struct B { void* p; size_t cap; };
+  std::vector<B> free_blocks, live;
+};
+static hipError_t pool_alloc(WidePool& P, void** q, size_t bytes) {
+  if (bytes < 8) bytes = 8;
+  int best = -1;
+  for (int k = 0; k < (int)P.free_blocks.size(); k++) {
+    const size_t c = P.free_blocks[k].cap;
+    if (c >= bytes && c <= 4 * bytes + ((size_t)1 << 20) && (best < 0 || c < P.free_blocks[best].cap)) best = k;
+  }
+  if (best >= 0) {
+    *q = P.free_blocks[best].p;
+    P.live.push_back(P.free_blocks[best]);
+    P.free_blocks.erase(P.free_blocks.begin() + best);
+    return hipSuccess;
+  }
+  const size_t cap = bytes + bytes / 4;
+  hipError_t e = hipMalloc(q, cap);
+  if (e != hipSuccess) {   // under memory pressure: give the cached blocks back and try once more
+    for (auto& b : P.free_blocks) (void)hipFree(b.p);
+    P.free_blocks.clear();
+    e = hipMalloc(q, cap);
+    if (e != hipSuccess) return e;
+  }
+  P.live.push_back({*q, cap});
+  return hipSuccess;
+}
+static void pool_release(WidePool& P, void* p) {
+  if (!p) return;
+  for (size_t k = 0; k < P.live.size(); k++)
+    if (P.live[k].p == p) { P.free_blocks.push_back(P.live[k]); P.live.erase(P.live.begin() + (long)k); return; }
+  (void)hipFree(p);   // not one of the pool's (never happens: every array of the index comes from pool_alloc)
+}
 void free_index(WideIndex& wi) {
   void* ptrs[] = {wi.sei, wi.sej, wi.key_list, wi.key_ptr, wi.tasks, wi.key_task_ptr, wi.task_partial, wi.vrec};
-  for (void* q : ptrs) if (q) (void)hipFree(q);
+  WidePool* pool = wi.pool;
+  for (void* q : ptrs) if (q) { if (pool) pool_release(*pool, q); else (void)hipFree(q); }
   wi = WideIndex();
+  wi.pool = pool;
+}
+void destroy_index(WideIndex& wi) {
+  free_index(wi);
+  if (wi.pool) {
+    for (auto& b : wi.pool->free_blocks) (void)hipFree(b.p);
+    for (auto& b : wi.pool->live) (void)hipFree(b.p);
+    delete wi.pool;
+    wi.pool = nullptr;
+  }
 }
 
 size_t index_bytes(const WideIndex& wi, int W) {
@@ -330,8 +379,13 @@ int build_index(const WideView& wv, int V, WideIndex& wi, hipStream_t s, const c
   free_index(wi);
   wi.V = V;
   if (V == 0) return 0;
-  struct Tmp { std::vector<void*> p; ~Tmp() { for (void* q : p) (void)hipFree(q); } } tmp;
-  auto talloc = [&](void** q, size_t bytes) { hipError_t e = hipMalloc(q, bytes ? bytes : 8); if (e == hipSuccess) tmp.p.push_back(*q); return e; };
+  if (!wi.pool) wi.pool = new WidePool();
+  WidePool& pool = *wi.pool;
+  // temporaries of the build: back into the pool when the build returns (its last act is a stream synchronisation; on an error path the kernels
+  // queued so far may still run -- the blocks stay this index's and are only written again behind them)
+  struct Tmp { WidePool& P; std::vector<void*> p; ~Tmp() { for (void* q : p) pool_release(P, q); } } tmp{pool, {}};
+  auto talloc = [&](void** q, size_t bytes) { hipError_t e = pool_alloc(pool, q, bytes); if (e == hipSuccess) tmp.p.push_back(*q); return e; };
+  auto palloc = [&](void** q, size_t bytes) { return pool_alloc(pool, q, bytes); };
   const unsigned gV = (unsigned)((V + 256) / 256);
   const int W = wv.fv.W;
   long long *pc, *pair_ptr;
@@ -351,8 +405,8 @@ int build_index(const WideView& wv, int V, WideIndex& wi, hipStream_t s, const c
   wi.np = tot;
   if (wi.np >= 0xffffffffll || wi.nnz >= 0xffffffffll) { *err = "wide index: more than 2^32 entries or entry pairs"; return -1; }
   if (wi.nnz == 0) return 0;
-  WV(hipMalloc((void**)&wi.sei, sizeof(unsigned int) * wi.np));
-  WV(hipMalloc((void**)&wi.sej, sizeof(unsigned int) * wi.np));
+  WV(palloc((void**)&wi.sei, sizeof(unsigned int) * wi.np));
+  WV(palloc((void**)&wi.sej, sizeof(unsigned int) * wi.np));
   unsigned int *pkey, *pidx, *pkey_s, *pidx_s, *pei, *pej, *kcnt, *nruns;
   WV(talloc((void**)&pkey, sizeof(unsigned int) * wi.np)); WV(talloc((void**)&pidx, sizeof(unsigned int) * wi.np));
   WV(talloc((void**)&pkey_s, sizeof(unsigned int) * wi.np)); WV(talloc((void**)&pidx_s, sizeof(unsigned int) * wi.np));
@@ -368,7 +422,7 @@ int build_index(const WideView& wv, int V, WideIndex& wi, hipStream_t s, const c
   WV(talloc((void**)&d_temp2, tb2));
   WV(rocprim::radix_sort_pairs(d_temp2, tb2, pkey, pkey_s, pidx, pidx_s, (size_t)wi.np, 0, key_bits, s));   // stable: voxel order inside a key
   wi_gather_kernel<<<(unsigned)((wi.np + 255) / 256), 256, 0, s>>>(pidx_s, wi.np, pei, pej, wi.sei, wi.sej);
-  WV(hipMalloc((void**)&wi.key_list, sizeof(unsigned int) * maxkeys));
+  WV(palloc((void**)&wi.key_list, sizeof(unsigned int) * maxkeys));
   size_t tb3 = 0;
   WV(rocprim::run_length_encode(nullptr, tb3, pkey_s, (size_t)wi.np, wi.key_list, kcnt, nruns, s));
   char* d_temp3;
@@ -378,7 +432,7 @@ int build_index(const WideView& wv, int V, WideIndex& wi, hipStream_t s, const c
   WV(hipMemcpyAsync(&h_runs, nruns, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
   WV(hipStreamSynchronize(s));
   wi.nkeys = (int)h_runs;
-  WV(hipMalloc((void**)&wi.key_ptr, sizeof(long long) * (wi.nkeys + 1)));
+  WV(palloc((void**)&wi.key_ptr, sizeof(long long) * (wi.nkeys + 1)));
   long long* kc64;
   WV(talloc((void**)&kc64, sizeof(long long) * (wi.nkeys + 1)));
   wi_widen_kernel<<<(unsigned)((wi.nkeys + 255) / 256), 256, 0, s>>>(kcnt, wi.nkeys, kc64);
@@ -399,10 +453,10 @@ int build_index(const WideView& wv, int V, WideIndex& wi, hipStream_t s, const c
   }
   h_ktp[wi.nkeys] = (int)h_tasks.size();
   wi.ntasks = (int)h_tasks.size();
-  WV(hipMalloc((void**)&wi.tasks, sizeof(WideTask) * std::max<size_t>(1, h_tasks.size())));
-  WV(hipMalloc((void**)&wi.key_task_ptr, sizeof(int) * h_ktp.size()));
-  WV(hipMalloc((void**)&wi.task_partial, sizeof(double) * WIDE_TASK_OUT * std::max<size_t>(1, h_tasks.size())));
-  WV(hipMalloc((void**)&wi.vrec, sizeof(double) * WIDE_VREC * (size_t)V));
+  WV(palloc((void**)&wi.tasks, sizeof(WideTask) * std::max<size_t>(1, h_tasks.size())));
+  WV(palloc((void**)&wi.key_task_ptr, sizeof(int) * h_ktp.size()));
+  WV(palloc((void**)&wi.task_partial, sizeof(double) * WIDE_TASK_OUT * std::max<size_t>(1, h_tasks.size())));
+  WV(palloc((void**)&wi.vrec, sizeof(double) * WIDE_VREC * (size_t)V));
   WV(hipMemcpyAsync(wi.tasks, h_tasks.data(), sizeof(WideTask) * h_tasks.size(), hipMemcpyHostToDevice, s));
   WV(hipMemcpyAsync(wi.key_task_ptr, h_ktp.data(), sizeof(int) * h_ktp.size(), hipMemcpyHostToDevice, s));
   WV(hipStreamSynchronize(s));
