@@ -147,6 +147,8 @@ def window_leg(args, scaling, collective, rank, world, local_rank, backend, base
         used = attach_collective(f, collective, W, backend, rank, strict=True)
         if used is None:
             return {"available": False}
+        if os.environ.get("VXBA_BENCH_FUSED_SPEC") == "1" and (world == 1 or os.environ.get("VXBA_BENCH_DEVICE") is None):
+            f.set_option("fused_sweeps", 2)        # opt-in, one rank per GPU (see main)
         f.set_precision(args.precision)
         f.evaluate_only_residual(sc.poses_init)
         f.snapshot_cache()
@@ -312,6 +314,12 @@ def main():
     collective_used = None
     if use_dist:
         collective_used = attach_collective(f, "hook" if args.hook_allreduce else args.collective, W, backend, rank)
+        # The fused residual + Hessian launch inside the sharded loop is opt-in (VXBA_OPT_FUSED_SWEEPS = 2, include/vxba.h; VXBA_BENCH_FUSED_SPEC=1
+        # here, one rank per GPU only).  Measured with one rank through RCCL at cfg2 (gpurun_out/r6_s15_spec_fused_ab.txt): 50.6-51.2 us per step
+        # against 50.9-51.3 for the three-launch iteration -- nothing at a 50k-voxel shard (it is worth 7-9 % from 100k voxels per rank), so the
+        # multi-GPU legs keep the loop that the process-rank tests have run for three rounds.
+        if os.environ.get("VXBA_BENCH_FUSED_SPEC") == "1" and (world == 1 or os.environ.get("VXBA_BENCH_DEVICE") is None):
+            f.set_option("fused_sweeps", 2)
     f.set_precision(args.precision)
     f.evaluate_only_residual(sc.poses_init)                # seeds the (lambda, U, merged) cache (recut's eig)
     f.snapshot_cache()

@@ -387,7 +387,8 @@ int vxba_map_leaves(vxba_map* m, int64_t capacity, uint64_t* ids, int32_t* ints,
                                        * divide_thread of the next iteration), and the reduction behind it takes the accept / reject decision; a rejected step
                                        * then costs a Hessian sweep the reference does not run -- so a factor whose LAST call rejected more than a third of its steps runs its next
                                        * call as the three-launch iteration (break-even by the round-6 kernel times: 18 % rejected steps at 50k voxels, 32 % at 400k; results do not depend on the form).
-                                       * 2: fused whatever the history.  0: the three-launch iteration of rounds 1-5.  Needs
+                                       * 2: fused whatever the history -- and ALSO on a factor with a collective attached (one process per GPU only: the launch takes whole CUs and waits inside
+                                       * itself, which two process ranks sharing one device do not survive; worth 7-9 % of a step from ~100k voxels per rank, nothing at 50k).  0: the three-launch iteration of rounds 1-5.  Needs
                                        * VXBA_OPT_FUSED_SOLVE = 1.  (The number belonged to a round-4 experiment that was removed in round 5.) */
 #define VXBA_OPT_COUNT 10
 #define VXBA_STAT_FUSED_FALLBACKS 100 /* read-only (vxba_get_option): times vxba_damping_iter re-ran a call with the solve as its own launch after the

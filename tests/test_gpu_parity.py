@@ -792,7 +792,7 @@ def test_f32_cluster_rows_lm_meets_the_pose_tolerance(vx):
     assert e1[0] < 0.2 * e0[0]
 
 
-def run_two_shards(vx, sc, iters):
+def run_two_shards(vx, sc, iters, fused_sweeps=None):
     """Two factors holding the two halves of the window's voxels, one host thread + one stream each, an all-reduce hook that really
     adds the two exchange buffers.  Returns (outputs, hook call counts, factors)."""
     import threading
@@ -804,6 +804,8 @@ def run_two_shards(vx, sc, iters):
         f = vx.LidarFactor(sc.win_size)
         f.push_voxels(sc.clusters[lo:hi], sc.fix[lo:hi], sc.coe[lo:hi])
         f.evaluate_only_residual(sc.poses_init)
+        if fused_sweeps is not None:
+            f.set_option("fused_sweeps", fused_sweeps)
         st = torch.cuda.Stream()
         f.set_stream(st.cuda_stream)
         n = f.packed_len()
@@ -848,6 +850,34 @@ def run_two_shards(vx, sc, iters):
         t.join(timeout=300)
     assert not errs, errs
     return out, calls, facs
+
+
+def test_two_voxel_shards_with_the_fused_launch_inside_the_sharded_loop(vx):
+    """VXBA_OPT_FUSED_SWEEPS = 2 (round 6): on a factor with a collective the residual sweep and the next iteration's Hessian sweep are one launch
+    too -- the solve workgroup takes no decision there (flags bit 1), the shard's residual sums ride behind the packed system through the ONE
+    all-reduce of the iteration, lm_spec_unpack decides from the reduced numbers.  Same schedule, same number of collectives, the ranks in
+    lockstep bit for bit, the oracle's steps -- on the window with rejected steps of the test below."""
+    sc = synth.make_scene(win_size=10, pts_per_scan=40_000, n_voxels=3000, p_obs=0.8, fix_frac=0.1, seed=31337, rot_sigma_deg=0.6, trans_sigma=0.15)
+    fo = O.Oracle(sc.win_size)
+    fo.push_voxels(sc.clusters, sc.fix, sc.coe)
+    fo.evaluate_only_residual(sc.poses_init)
+    iters = 8
+    ref = fo.damping_iter(sc.poses_init, max_iter=iters, thd_num=4)
+    out, calls, facs = run_two_shards(vx, sc, iters, fused_sweeps=2)
+    a, b = out
+    assert 0 in ref["trace"][:, 6]
+    assert np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["trace"], b["trace"]) and np.array_equal(a["hess"], b["hess"])
+    assert a["trace"].shape == ref["trace"].shape and np.array_equal(a["trace"][:, 6:], ref["trace"][:, 6:])
+    assert np.allclose(a["trace"][:, :2], ref["trace"][:, :2], rtol=1e-9)
+    assert relerr(a["hess"], ref["hess"]) < 1e-9
+    et, er = synth.pose_errors(a["poses"], ref["poses"])
+    assert et < 1e-7 and er < 1e-7, (et, er)
+    assert calls[0] == calls[1] == a["trace"].shape[0] + 1
+    for f in facs:
+        assert f.get_option("stat_fused_fallbacks") == 0
+        f.set_allreduce(None)
+        f.use_external_buffers(None, None)
+        f.close()
 
 
 def test_two_voxel_shards_with_a_real_cross_shard_sum(vx):

@@ -447,6 +447,51 @@ int spec_hess_phase(vxba_factor* f, const double* Rp0, int* c, bool first_of_sol
   return VXBA_OK;
 }
 
+// The speculative loop with the fused launch (round 6): [solve of ctl[*c] | residual sweep at its trial poses | Hessian sweep at the same poses]
+// in one launch -- flags bit 1: the solve workgroup takes NO decision, the shard's residual is not the window's -- then what spec_hess_phase
+// runs behind its own Hessian sweep: the reduction with the residual sums riding behind the packed system, ONE all-reduce, the decision + adoption
+// from the reduced buffer.  Same collectives per iteration, one launch and a cold sweep start fewer.  Every rank takes the same path (the
+// predicate depends on options and on the LM history, which is identical on all ranks).
+// Opt-in (VXBA_OPT_FUSED_SWEEPS = 2) on a factor with a collective: the fused launch takes whole CUs (one 8-wave workgroup with 147 KB of LDS
+// each) and its sweep workgroups wait for workgroup 0 inside the launch -- fine with one process per GPU, but two process ranks SHARING a
+// device (the plumbing runs of tests/test_gpu_two_rank.py, bench.py with VXBA_BENCH_DEVICE) time-slice each other for longer than the wait
+// is bounded to, and a sharded factor cannot fall back rank-locally.  Measured with one rank through RCCL at cfg2: no gain at a 50k-voxel shard.
+bool fused_sweeps_spec(const vxba_factor* f) {
+  return f->opt[VXBA_OPT_FUSED_SWEEPS] == 2 && fused_solve(f) && spec_collective(f) && f->V > 0 && f->precision != VXBA_PRECISION_MIXED_F32_CLUSTERS &&
+         vxk::k23_supported(view(f));
+}
+int spec_fused_phase(vxba_factor* f, const double* Rp0, int* c, unsigned seq, int* k2_nparts) {
+  int rc = ensure_partials3(f);
+  if (rc) return rc;
+  PoseArg pa;
+  fill_poses(f, Rp0, pa);
+  const FactorView fv = view(f);
+  const int nv = vxk::k3_nv(f->W);
+  const int nbatches = (f->V - 1) / nv + 1;
+  const int nwg = vxk::k23_sweep_blocks(nbatches, f->cus);
+  const int flags = 2 | (f->opt[VXBA_OPT_DEBUG_SOLVE_TIMEOUT] == 1 ? 1 : 0);
+  int got;
+  if (f->profiling & 32) {
+    hipEvent_t a = get_event(f), b = get_event(f);
+    got = vxk::launch_k23_fused(fv, f->d_lm, *c, seq, 0, f->V, f->d_partial2, f->d_partial3, nwg, f->precision == VXBA_PRECISION_MIXED ? 1 : 0, flags, f->stream, a, b);
+    if (a && b) f->pending.push_back({a, b, 5});
+  } else {
+    got = vxk::launch_k23_fused(fv, f->d_lm, *c, seq, 0, f->V, f->d_partial2, f->d_partial3, nwg, f->precision == VXBA_PRECISION_MIXED ? 1 : 0, flags, f->stream);
+  }
+  if (got != nwg) return fail(f, VXBA_ERR_STATE, "fused residual + Hessian launch refused this factor");
+  *k2_nparts = nwg;   // one residual sum per sweep workgroup
+  {
+    ScopedKernelTimer t(f, 2);
+    vxk::launch_k3_finalize(f->d_partial3, nwg, f->W, f->d_lm, *c, 0, f->d_packed, f->stream, 1, f->d_partial2, nwg);
+  }
+  VX_HIP(f, hipGetLastError());
+  rc = shard_allreduce(f, f->d_packed, vxba_packed_len(f) + 1);
+  if (rc) return rc;
+  vxk::launch_lm_spec_unpack(f->d_lm, *c, f->d_packed, f->W, 1, 0, pa, f->stream);
+  *c ^= 1;
+  return VXBA_OK;
+}
+
 // closes a speculative loop: the last trial's residual still needs its own (scalar) all-reduce and decision
 int spec_final_decision(vxba_factor* f, const double* Rp0, int* c, int k2_nparts) {
   vxk::launch_sum_partials(f->d_partial2, k2_nparts, f->d_scalar, f->stream);

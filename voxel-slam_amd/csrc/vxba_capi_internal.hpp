@@ -51,6 +51,8 @@ int spec_final_decision(vxba_factor* f, const double* Rp0, int* c, int k2_nparts
 bool fused_solve(const vxba_factor* f);
 bool fused_sweeps(const vxba_factor* f);
 int sweep_fused_device(vxba_factor* f, vxk::LMState* lm, int* c, unsigned seq);
+bool fused_sweeps_spec(const vxba_factor* f);
+int spec_fused_phase(vxba_factor* f, const double* Rp0, int* c, unsigned seq, int* k2_nparts);
 void options_from_env(vxba_factor* f);
 int upload_poses(vxba_factor* f, const double* Rp);
 // synchronous sweeps into the pinned host buffers (single-sweep entry points, wide windows)

@@ -102,10 +102,22 @@ static int damping_iter_impl(vxba_factor* f, double* Rp, int max_iter, double* h
   std::memset(&pend, 0, sizeof pend);
   const bool spec = spec_collective(f);
   int spec_nparts = 0;
+  const bool fuse_spec = spec && fused_sweeps_spec(f);
+  bool spec_have_hess = false;   // the next iteration's Hessian sweep ran inside the previous fused launch (and its reduction + all-reduce behind it)
   for (int i = 0; spec && i < max_iter; i++) {
-    int rc = spec_hess_phase(f, Rp, &c, i == 0, i > 0, false, nullptr, spec_nparts);
-    if (rc) return rc;
+    int rc = VXBA_OK;
+    if (!spec_have_hess) {
+      rc = spec_hess_phase(f, Rp, &c, i == 0, i > 0, false, nullptr, spec_nparts);
+      if (rc) return rc;
+    }
     const unsigned seq = fused_solve(f) ? ++f->lm_seq : 0u;
+    if (fuse_spec && seq && i + 1 < max_iter) {
+      rc = spec_fused_phase(f, Rp, &c, seq, &spec_nparts);
+      if (rc) return rc;
+      spec_have_hess = true;
+      continue;
+    }
+    spec_have_hess = false;
     if (!seq) vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
     rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, nullptr, &spec_nparts, seq);
     if (rc) return rc;
@@ -220,12 +232,26 @@ static int lm_steps_impl(vxba_factor* f, const double* Rp_init, int n_steps, int
   const bool spec = spec_collective(f);
   int spec_nparts = 0;
   bool prev_last = false;
+  const bool fuse_spec = spec && fused_sweeps_spec(f);
+  bool spec_have_hess = false;
   for (int s = 0; spec && s < n_steps; s++) {
     const bool first = (s % steps_per_solve) == 0;
     const bool last = ((s + 1) % steps_per_solve) == 0 && s + 1 < n_steps;
-    int rc = spec_hess_phase(f, Rp_init, &c, first, s > 0, prev_last, first ? f->snapshot : nullptr, spec_nparts);
-    if (rc) return rc;
+    int rc = VXBA_OK;
+    if (!spec_have_hess) {
+      rc = spec_hess_phase(f, Rp_init, &c, first, s > 0, prev_last, first ? f->snapshot : nullptr, spec_nparts);
+      if (rc) return rc;
+    }
     const unsigned seq = fused_solve(f) ? ++f->lm_seq : 0u;
+    // inside a solve: this step's residual sweep and the next step's Hessian sweep in one launch, the reduction + all-reduce + decision behind it
+    if (fuse_spec && seq && ((s + 1) % steps_per_solve) != 0 && s + 1 < n_steps) {
+      rc = spec_fused_phase(f, Rp_init, &c, seq, &spec_nparts);
+      if (rc) return rc;
+      spec_have_hess = true;
+      prev_last = last;
+      continue;
+    }
+    spec_have_hess = false;
     if (!seq) vxk::launch_lm_solve(f->d_lm, c, W, f->stream);
     rc = sweep_residual_device(f, nullptr, f->d_lm, c, 0, f->V, nullptr, &spec_nparts, seq);
     if (rc) return rc;
