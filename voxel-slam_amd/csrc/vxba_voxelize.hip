@@ -42,38 +42,83 @@ namespace vxv {
 
 constexpr int FRAME_BITS = 7, PATH_BITS = 9;
 
+// bbox (round 6): per-axis minimum and maximum of the root-voxel coordinates over the cloud (block-wide in LDS, then one global atomic per
+// block and component) -- the host turns it into a compact layer-0 sort key (relkey_kernel)
+__global__ void init_err_bbox_kernel(int* __restrict__ err, int* __restrict__ bbox) {
+  if (threadIdx.x == 0) err[0] = 0;
+  if (threadIdx.x < 3) bbox[threadIdx.x] = 0x7fffffff;
+  else if (threadIdx.x < 6) bbox[threadIdx.x] = (int)0x80000000;
+}
 __global__ void key_kernel(const double* __restrict__ xyz, const long long* __restrict__ frame_ptr, int W, const double* __restrict__ poses, VoxelizeParams p,
-                           long long n, double* __restrict__ world, unsigned long long* __restrict__ key, int* __restrict__ err) {
+                           long long n, double* __restrict__ world, unsigned long long* __restrict__ key, int* __restrict__ err, int* __restrict__ bbox) {
 #pragma clang fp contract(off)
+  __shared__ int bb[6];
+  if (threadIdx.x < 3) bb[threadIdx.x] = 0x7fffffff;
+  else if (threadIdx.x < 6) bb[threadIdx.x] = (int)0x80000000;
+  __syncthreads();
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) {
+    int f = 0;
+    while (f + 1 < W && q >= frame_ptr[f + 1]) f++;
+    const double* Rp = poses + 12 * f;
+    const double x = xyz[3 * q], y = xyz[3 * q + 1], z = xyz[3 * q + 2];
+    double w[3];
+    for (int r = 0; r < 3; r++) w[r] = Rp[r] * x + Rp[3 + r] * y + Rp[6 + r] * z + Rp[9 + r];   // R * local + p, left to right
+    unsigned long long root = 0;
+    double centre[3];
+    bool ok = true;
+    for (int j = 0; j < 3; j++) {
+      float loc = (float)(w[j] / p.voxel_size);
+      if (loc < 0) loc -= 1.0f;
+      const long long pos = (long long)loc;
+      if (pos < -32768 || pos > 32767) { ok = false; break; }
+      atomicMin(&bb[j], (int)pos);
+      atomicMax(&bb[3 + j], (int)pos);
+      root = (root << 16) | (unsigned long long)(pos + 32768);
+      centre[j] = (0.5 + (double)pos) * p.voxel_size;
+    }
+    if (!ok) *err = 1;
+    else {
+      float quarter = (float)(p.voxel_size / 4.0);
+      unsigned long long path = 0;
+      for (int l = 0; l < 3; l++) {
+        int b[3];
+        for (int k = 0; k < 3; k++) b[k] = w[k] > centre[k] ? 1 : 0;
+        path = (path << 3) | (unsigned long long)(4 * b[0] + 2 * b[1] + b[2]);
+        for (int k = 0; k < 3; k++) centre[k] = centre[k] + (double)((float)(2 * b[k] - 1) * quarter);
+        quarter = quarter / 2;
+      }
+      world[3 * q] = w[0]; world[3 * q + 1] = w[1]; world[3 * q + 2] = w[2];
+      key[q] = (root << (PATH_BITS + FRAME_BITS)) | (path << FRAME_BITS) | (unsigned long long)f;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicMin(&bbox[threadIdx.x], bb[threadIdx.x]);
+  else if (threadIdx.x < 6) atomicMax(&bbox[threadIdx.x], bb[threadIdx.x]);
+}
+// Layer 0 through a COMPACT key (round 6): the root coordinates relative to the cloud's bounding box, packed x | y | z in bx + by + bz bits
+// (<= 30; a ten-keyframe window: ~20).  The cloud is in (frame, cloud index) order already, so a stable sort by the root alone is the order
+// the 64-bit (root, frame) sort produced -- and with ~20 key bits and rocPRIM's onesweep forced (its default below 1 M keys is a block sort
+// + eight merge passes whatever the key) it is a histogram + three passes.  idx = the identity; the layer keys follow by a gather.
+__global__ void relkey_kernel(const unsigned long long* __restrict__ key, long long n, int xmin, int ymin, int zmin, int by, int bz, unsigned int* __restrict__ rk,
+                              unsigned int* __restrict__ idx) {
   const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
-  int f = 0;
-  while (f + 1 < W && q >= frame_ptr[f + 1]) f++;
-  const double* Rp = poses + 12 * f;
-  const double x = xyz[3 * q], y = xyz[3 * q + 1], z = xyz[3 * q + 2];
-  double w[3];
-  for (int r = 0; r < 3; r++) w[r] = Rp[r] * x + Rp[3 + r] * y + Rp[6 + r] * z + Rp[9 + r];   // R * local + p, left to right
-  unsigned long long root = 0;
-  double centre[3];
-  for (int j = 0; j < 3; j++) {
-    float loc = (float)(w[j] / p.voxel_size);
-    if (loc < 0) loc -= 1.0f;
-    const long long pos = (long long)loc;
-    if (pos < -32768 || pos > 32767) { *err = 1; return; }
-    root = (root << 16) | (unsigned long long)(pos + 32768);
-    centre[j] = (0.5 + (double)pos) * p.voxel_size;
-  }
-  float quarter = (float)(p.voxel_size / 4.0);
-  unsigned long long path = 0;
-  for (int l = 0; l < 3; l++) {
-    int b[3];
-    for (int k = 0; k < 3; k++) b[k] = w[k] > centre[k] ? 1 : 0;
-    path = (path << 3) | (unsigned long long)(4 * b[0] + 2 * b[1] + b[2]);
-    for (int k = 0; k < 3; k++) centre[k] = centre[k] + (double)((float)(2 * b[k] - 1) * quarter);
-    quarter = quarter / 2;
-  }
-  world[3 * q] = w[0]; world[3 * q + 1] = w[1]; world[3 * q + 2] = w[2];
-  key[q] = (root << (PATH_BITS + FRAME_BITS)) | (path << FRAME_BITS) | (unsigned long long)f;
+  const unsigned long long root = key[q] >> (PATH_BITS + FRAME_BITS);
+  const unsigned int x = (unsigned int)((int)((root >> 32) & 0xffffull) - 32768 - xmin), y = (unsigned int)((int)((root >> 16) & 0xffffull) - 32768 - ymin),
+                     z = (unsigned int)((int)(root & 0xffffull) - 32768 - zmin);
+  rk[q] = (x << (by + bz)) | (y << bz) | z;
+  idx[q] = (unsigned int)q;
+}
+__global__ void lkey_gather_kernel(const unsigned long long* __restrict__ key, const unsigned int* __restrict__ idx_s, long long n, int layer, unsigned long long* __restrict__ lkey_s) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const unsigned long long keep = ~(((1ull << (3 * (3 - layer))) - 1ull) << FRAME_BITS);
+  lkey_s[q] = key[idx_s[q]] & keep;
+}
+__global__ void post_err_bbox_kernel(const int* __restrict__ err, const int* __restrict__ bbox, unsigned long long* __restrict__ host_err, unsigned long long* __restrict__ host_bbox) {
+  if (threadIdx.x == 0) host_err[0] = (unsigned long long)(unsigned int)err[0];
+  if (threadIdx.x < 6) host_bbox[threadIdx.x] = (unsigned long long)(long long)bbox[threadIdx.x];
 }
 
 // voxel-sharded windows: 1 for the points of this shard's root voxels, then their compaction to the front (order kept)
@@ -227,7 +272,6 @@ __global__ void post_count_kernel(const unsigned int* __restrict__ src_a, const 
   dst[0] = (unsigned long long)src_a[0] + (src_b ? (unsigned long long)src_b[0] : 0ull);
 }
 __global__ void post_count64_kernel(const long long* __restrict__ src, unsigned long long* __restrict__ dst) { dst[0] = (unsigned long long)src[0]; }
-__global__ void post_count32s_kernel(const int* __restrict__ src, unsigned long long* __restrict__ dst) { dst[0] = (unsigned long long)(unsigned int)src[0]; }
 
 
 enum NodeState : unsigned char { DEAD = 0, FACTOR = 1, SUBDIVIDE = 2 };
@@ -439,11 +483,6 @@ struct DevBuf {
     post_count64_kernel<<<1, 1, 0, s>>>(a, host + k);
     return hipGetLastError();
   }
-  hipError_t post_i32(int k, const int* a, hipStream_t s) {
-    host[k] = 0;
-    post_count32s_kernel<<<1, 1, 0, s>>>(a, host + k);
-    return hipGetLastError();
-  }
   static hipError_t wait(hipStream_t s) {
     hipError_t q;
     if (g_wait_prof.on) {
@@ -474,6 +513,9 @@ struct DevBuf {
 #define VV(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { *err_out = hipGetErrorString(e_); return -1; } } while (0)
 
 static inline unsigned grid_for(long long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
+// rocPRIM's radix sort with the merge-sort path switched off (MergeSortLimit = 0): below 1 M keys its default is a block sort + log2(n / block)
+// merge passes whatever the key width; the compact layer-0 key (relkey_kernel) wants a histogram + ceil(bits / 8) onesweep passes
+using OnesweepAlways = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
 
 long long voxelize(int W, long long n_points, const double* d_xyz_local, const long long* d_frame_ptr, const double* d_poses, const VoxelizeParams& p,
                    hipStream_t s, VoxelizeOutput* out, const char** err_out) {
@@ -493,6 +535,7 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
     VV(rocprim::exclusive_scan(nullptr, tb_scan, l0, l0, 0ll, (size_t)n + 1, rocprim::plus<long long>(), s));
     VV(rocprim::exclusive_scan(nullptr, tb_scan32, v0, v0, 0u, (size_t)n, rocprim::plus<unsigned int>(), s));
     { size_t tb_scan64 = 0; VV(rocprim::exclusive_scan(nullptr, tb_scan64, k0, k0, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), s)); if (tb_scan64 > tb_scan) tb_scan = tb_scan64; }
+    { size_t tb_rel = 0; VV(rocprim::radix_sort_pairs<OnesweepAlways>(nullptr, tb_rel, v0, v0, v0, v0, (size_t)n, 0, 30, s)); if (tb_rel > tb_sort) tb_sort = tb_rel; }
     tb = tb_sort;
     if (tb_scan > tb) tb = tb_scan;
     if (tb_scan32 > tb) tb = tb_scan32;
@@ -506,8 +549,10 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
   VV(B.alloc(&d_world, 3 * n)); VV(B.alloc(&d_loc_s, 3 * n)); VV(B.alloc(&d_wld_s, 3 * n));
   VV(B.alloc(&d_key, n)); VV(B.alloc(&d_lkey, n)); VV(B.alloc(&d_lkey_s, n));
   VV(B.alloc(&d_idx, n)); VV(B.alloc(&d_idx_s, n)); VV(B.alloc(&d_err, 1));
-  VV(hipMemsetAsync(d_err, 0, sizeof(int), s));
-  if (n > 0) key_kernel<<<grid_for(n), 256, 0, s>>>(d_xyz_local, d_frame_ptr, W, d_poses, p, n, d_world, d_key, d_err);
+  int* d_bbox;
+  VV(B.alloc(&d_bbox, 6));
+  init_err_bbox_kernel<<<1, 64, 0, s>>>(d_err, d_bbox);
+  if (n > 0) key_kernel<<<grid_for(n), 256, 0, s>>>(d_xyz_local, d_frame_ptr, W, d_poses, p, n, d_world, d_key, d_err, d_bbox);
 
   // per-layer scratch (sized for the worst case: every point its own cell)
   unsigned long long *d_cell_key, *d_cell_node, *d_node_key[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -524,9 +569,25 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
   char* d_temp;
   VV(B.alloc(&d_temp, tb));
 
-  VV(B.post_i32(0, d_err, s));
+  B.word_u64(0);
+  for (int k = 8; k < 14; k++) B.word_u64(k);
+  post_err_bbox_kernel<<<1, 64, 0, s>>>(d_err, d_bbox, B.host, B.host + 8);
+  VV(hipGetLastError());
   VV(B.wait(s));
   if (B.u32(0)) { *err_out = range_msg; return -1; }
+  // the compact layer-0 key: bits per axis from the cloud's bounding box (all points' box: a shard's points lie inside it)
+  int rel_min[3] = {0, 0, 0}, rel_bits[3] = {0, 0, 0}, rel_total = 64;
+  if (n > 0) {
+    rel_total = 0;
+    for (int j = 0; j < 3; j++) {
+      const long long lo = B.i64(8 + j), hi = B.i64(11 + j);
+      rel_min[j] = (int)lo;
+      int b = 1;
+      while (((long long)1 << b) < hi - lo + 1) b++;
+      rel_bits[j] = b;
+      rel_total += b;
+    }
+  }
   if (sharded && n > 0) {
     // this shard's points to the front, cloud order kept (the cluster sums below are in point order): everything behind works on the n_keep
     // points of whole root voxels, so each of its factor voxels is bit for bit the one the unsharded run produces
@@ -546,6 +607,7 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
 
   // development knob (same-box A/B): VXBA_VOXELIZE_PARTITION=0 sorts every layer as rounds 1-5 did
   static const bool use_partition = [] { const char* e = getenv("VXBA_VOXELIZE_PARTITION"); return !(e && e[0] == '0'); }();
+  static const bool use_compact = [] { const char* e = getenv("VXBA_VOXELIZE_COMPACT_KEY"); return !(e && e[0] == '0'); }();
   constexpr long long PARTITION_MAX_POINTS = 1ll << 20;   // beyond this rocPRIM sorts with onesweep, and one node can be a workgroup's millisecond
   long long total = 0, total_entries = 0;
   long long* d_epos = nullptr;
@@ -563,6 +625,11 @@ long long voxelize(int W, long long n_points, const double* d_xyz_local, const l
       partition_kernel<<<(unsigned)n_nodes_l[layer - 1], PART_BLOCK, 0, s>>>(d_key, d_idx_s, d_node_ptr, layer, d_idx, d_lkey);
       { unsigned int* ti = d_idx; d_idx = d_idx_s; d_idx_s = ti; }
       { unsigned long long* tk = d_lkey; d_lkey = d_lkey_s; d_lkey_s = tk; }
+    } else if (layer == 0 && use_compact && rel_total <= 30 && n > 4096) {
+      // layer 0 by the compact root key (relkey_kernel): d_flag / d_pos are free until the plane test and hold the keys
+      relkey_kernel<<<grid_for(n), 256, 0, s>>>(d_key, n, rel_min[0], rel_min[1], rel_min[2], rel_bits[1], rel_bits[2], d_flag, d_idx);
+      VV(rocprim::radix_sort_pairs<OnesweepAlways>(d_temp, t, d_flag, d_pos, d_idx, d_idx_s, (size_t)n, 0, (unsigned)rel_total, s));
+      lkey_gather_kernel<<<grid_for(n), 256, 0, s>>>(d_key, d_idx_s, n, layer, d_lkey_s);
     } else {
       layer_key_kernel<<<grid_for(n), 256, 0, s>>>(d_key, n, layer, d_lkey, d_idx);
       VV(rocprim::radix_sort_pairs(d_temp, t, d_lkey, d_lkey_s, d_idx, d_idx_s, (size_t)n, 0, 64, s));
